@@ -1,0 +1,173 @@
+/*
+ * spgnn_hip.h — C ABI of the MI355X (gfx950) message-passing library, libspgnn_hip.so.
+ *
+ * The reference (DIAGNijmegen/spgnn) has no FFI of its own: its graph-convolution hot path
+ * calls DGL's Python layers (reference models.py:8), which bottom out in DGL's internal
+ * _CAPI_DGLKernelSpMM / _CAPI_DGLKernelSDDMM / edge_softmax kernels.  Each entry point below
+ * names the DGL primitive sequence (and the reference call site that triggers it) it replaces.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (PyTorch); the library allocates
+ *    nothing, keeps no state besides a thread-local last-error string, never synchronises,
+ *    and enqueues all work on `stream` (a hipStream_t passed as void*).  Safe under HIP graph
+ *    capture.  Re-entrant.
+ *  - Graph arrays are int32.  CSC (dst-major): in-edges of v are slots indptr[v]..indptr[v+1]-1,
+ *    `indices[slot]` = source node.  CSR (src-major): out-edges of u are
+ *    out_indptr[u]..out_indptr[u+1]-1, `out_indices[k]` = destination node, `out_pos[k]` = the CSC
+ *    slot of the same edge.  Per-edge arrays (attn, g_e) are always indexed by CSC slot.
+ *  - Feature matrices are row-major fp32 with an explicit row stride in ELEMENTS, so callers
+ *    can point into wider buffers (fused [fc|res] GEMM output, concat buffers).
+ *  - Return value: 0 on success; SPGNN_ERR_* (< 0) on bad arguments; -(1000 + hipError_t) when
+ *    a launch fails.  spgnn_last_error() describes the last failure on the calling thread.
+ */
+#ifndef SPGNN_HIP_H_
+#define SPGNN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPGNN_ABI_VERSION 1
+
+#define SPGNN_OK            0
+#define SPGNN_ERR_NULLPTR  -1
+#define SPGNN_ERR_SHAPE    -2
+#define SPGNN_ERR_STRIDE   -3
+#define SPGNN_ERR_ENUM     -4
+
+/* activations fused into the GAT epilogue (reference models.py:303,309,440,445: F.elu, F.tanh, None) */
+#define SPGNN_ACT_NONE 0
+#define SPGNN_ACT_ELU  1
+#define SPGNN_ACT_TANH 2
+#define SPGNN_ACT_RELU 3
+
+typedef void* spgnn_stream_t;   /* hipStream_t */
+
+int         spgnn_abi_version(void);
+const char* spgnn_last_error(void);
+
+/*
+ * GATConv message passing, forward.  Replaces, per GATConv.forward call (reference
+ * models.py:324-326, 477-482, 535-538): gsddmm(u_add_v) + LeakyReLU + edge_softmax
+ * (5 DGL kernels) + attn_drop + gspmm(u_mul_e, sum) + residual add + bias add + activation.
+ *
+ *   e_uv  = leaky_relu(el[u,h] + er[v,h], slope)
+ *   a_uv  = exp(e_uv - max_{in(v)} e) / sum_{in(v)} exp(e - max)        -> attn[slot,h]
+ *   out[v,h,:] = act( sum_{in(v)} drop(a_uv) * ft[u,h,:] + res[v,h,:] + bias[h,:] )
+ *
+ * ft/res/out: (N, H*D) with row strides.  el/er: (N, H) with row stride s_stride.
+ * res, bias may be NULL.  attn: (E, H) contiguous, always written (saved for backward).
+ * p_drop in [0,1): attention dropout; the keep mask is a counter-based hash of (seed, slot, h),
+ * regenerated (not stored) by the backward entry points.
+ */
+int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
+                  const float* ft, int64_t ft_stride,
+                  const float* el, const float* er, int64_t s_stride,
+                  const float* res, int64_t res_stride,
+                  const float* bias,
+                  float* out, int64_t out_stride,
+                  float* attn,
+                  int64_t N, int64_t E, int32_t H, int32_t D,
+                  float negative_slope, int32_t activation,
+                  float p_drop, uint64_t seed,
+                  spgnn_stream_t stream);
+
+/*
+ * GATConv backward, destination-major half (replaces DGL autograd of the sequence above:
+ * gsddmm(dot) for g_a, edge_softmax backward, LeakyReLU backward, gspmm(copy_e,sum) for g_er).
+ *
+ *   g_pre[v,:]  = g_out[v,:] * act'(out[v,:])                -> g_pre   (N, H*D)
+ *   g_a_uv      = <ft[u,h,:], g_pre[v,h,:]> * keep_uv/(1-p)
+ *   g_e_uv      = (a_uv*g_a_uv - a_uv * sum_{in(v)} a*g_a) * lrelu'(el[u,h]+er[v,h])  -> g_e[slot,h]
+ *   g_er[v,h]   = sum_{in(v)} g_e_uv
+ *
+ * `out` is the forward output (post-activation); ignored when activation == NONE (may be NULL).
+ * g_pre is also the gradient of the residual branch and of the bias (column sums).
+ */
+int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
+                      const float* ft, int64_t ft_stride,
+                      const float* el, const float* er, int64_t s_stride,
+                      const float* attn,
+                      const float* g_out, int64_t g_out_stride,
+                      const float* out, int64_t out_stride,
+                      float* g_pre, int64_t g_pre_stride,
+                      float* g_e,
+                      float* g_er, int64_t g_s_stride,
+                      int64_t N, int64_t E, int32_t H, int32_t D,
+                      float negative_slope, int32_t activation,
+                      float p_drop, uint64_t seed,
+                      spgnn_stream_t stream);
+
+/*
+ * GATConv backward, source-major half (DGL: gspmm on the reverse graph for g_ft, and
+ * gspmm(copy_e,sum) on the reverse graph for g_el).  Atomics-free.
+ *
+ *   g_ft[u,h,:] = sum_{v in out(u)} drop(a_uv) * g_pre[v,h,:]
+ *   g_el[u,h]   = sum_{v in out(u)} g_e_uv
+ */
+int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                      const float* attn, const float* g_e,
+                      const float* g_pre, int64_t g_pre_stride,
+                      float* g_ft, int64_t g_ft_stride,
+                      float* g_el, int64_t g_s_stride,
+                      int64_t N, int64_t E, int32_t H, int32_t D,
+                      float p_drop, uint64_t seed,
+                      spgnn_stream_t stream);
+
+/*
+ * Weighted-sum SpMM (DGL gspmm(copy_u, sum) with the degree normalisations of GraphConv
+ * norm='both' / GINConv 'mean' folded in; reference models.py:172-182, 358-383):
+ *
+ *   out[v,:] = self_coef * x[v,:] + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u,:]
+ *
+ * w_src, w_dst: per-node scales (N) or NULL (= 1).  self_eps: device pointer to GINConv's `eps`
+ * (self_coef = 1 + *self_eps) or NULL (self_coef = 0).  The backward w.r.t. x is the same call
+ * on the transposed structure (out_indptr/out_indices) with w_src and w_dst swapped.
+ */
+int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices,
+                   const float* x, int64_t x_stride,
+                   const float* w_src, const float* w_dst, const float* self_eps,
+                   float* out, int64_t out_stride,
+                   int64_t N, int64_t E, int32_t F,
+                   spgnn_stream_t stream);
+
+/*
+ * Max SpMM (DGL gspmm(copy_u, max); SAGEConv 'pool', reference models.py:668-679):
+ *   out[v,f] = max_{u in in(v)} x[u,f]   (0 when v has no in-edge);  arg[v,f] = CSC slot of the
+ *   winning edge (first one on ties, as DGL), or -1.
+ */
+int spgnn_spmm_max_fwd(const int32_t* indptr, const int32_t* indices,
+                       const float* x, int64_t x_stride,
+                       float* out, int64_t out_stride,
+                       int32_t* arg, int64_t arg_stride,
+                       int64_t N, int64_t E, int32_t F,
+                       spgnn_stream_t stream);
+
+/*
+ *   g_x[u,f] = sum_{k in out(u)} [arg[out_indices[k], f] == out_pos[k]] * g_out[out_indices[k], f]
+ */
+int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                       const float* g_out, int64_t g_out_stride,
+                       const int32_t* arg, int64_t arg_stride,
+                       float* g_x, int64_t g_x_stride,
+                       int64_t N, int64_t E, int32_t F,
+                       spgnn_stream_t stream);
+
+/*
+ * SGD with momentum over one flat fp32 parameter bucket (torch.optim.SGD semantics, dampening 0,
+ * no nesterov; reference exp_settings/st_pgat_spgnn_3.py OPTIMIZER, job_runner.py:1919):
+ *   g = grad[i] * (*grad_scale if grad_scale else 1) + weight_decay * p[i]
+ *   buf[i] = first_step ? g : momentum * buf[i] + g ;  p[i] -= lr * buf[i]
+ * grad_scale is a DEVICE scalar (1 / global sum of class weights after the all-reduce).
+ */
+int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf,
+                            const float* grad_scale, int64_t n,
+                            float lr, float momentum, float weight_decay, int32_t first_step,
+                            spgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SPGNN_HIP_H_ */

@@ -1,0 +1,258 @@
+"""ORACLE (test infrastructure, not product code) — CPU restatement of the DGL layer
+semantics the reference's graph-convolution hot path relies on.
+
+PARITY UNPINNED: the arithmetic of this path lives in DGL (dmlc/dgl), an un-vendored,
+un-pinned dependency of the reference (``git clone`` of master at image build,
+reference docker_base/Dockerfile:130-137; README floor "0.6.x", README.md:35; API usage
+brackets it to 0.6-0.8). DGL is absent from /root/reference and not installable here, and the
+reference ships no tests or golden vectors for this path. What follows
+restates DGL's published layer definitions as used at the reference call sites
+(models.py:8,172-182,301-314,358-383,425-456,506-521,668-679); it is pinned only by
+(a) the independent dense formulation in ``oracle/dense.py`` and (b) hand-derived
+known-answer cases (tests/test_oracle.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Every function is plain PyTorch on whatever dtype/device its inputs have (fp64 for
+cross-checks, fp32 for the parity target), differentiable by autograd, and written on the
+edge list (``index_select`` / ``index_add_`` / ``scatter_reduce``), mirroring how DGL lowers
+the layers to gsddmm / edge_softmax / gspmm.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# primitives (DGL: dgl.ops.edge_softmax, gspmm copy_u/u_mul_e with sum / mean / max)
+# --------------------------------------------------------------------------------------
+def edge_softmax(dst: Tensor, e: Tensor, num_nodes: int) -> Tensor:
+    """softmax of edge scores over the edges that share a destination.
+    DGL edge_softmax: e - max_dst -> exp -> / sum_dst."""
+    shape = (num_nodes,) + tuple(e.shape[1:])
+    idx = dst.view(-1, *([1] * (e.dim() - 1))).expand_as(e)
+    emax = torch.full(shape, -float("inf"), dtype=e.dtype, device=e.device)
+    emax = emax.scatter_reduce(0, idx, e, reduce="amax", include_self=True)
+    ex = torch.exp(e - emax.index_select(0, dst))
+    esum = torch.zeros(shape, dtype=e.dtype, device=e.device).index_add_(0, dst, ex)
+    return ex / esum.index_select(0, dst)
+
+
+def spmm_sum(src: Tensor, dst: Tensor, x: Tensor, num_nodes: int, w: Optional[Tensor] = None) -> Tensor:
+    m = x.index_select(0, src)
+    if w is not None:
+        m = m * w
+    return torch.zeros((num_nodes,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device).index_add_(0, dst, m)
+
+
+def spmm_max(src: Tensor, dst: Tensor, x: Tensor, num_nodes: int) -> Tensor:
+    m = x.index_select(0, src)
+    idx = dst.view(-1, *([1] * (x.dim() - 1))).expand_as(m)
+    out = torch.full((num_nodes,) + tuple(x.shape[1:]), -float("inf"), dtype=x.dtype, device=x.device)
+    out = out.scatter_reduce(0, idx, m, reduce="amax", include_self=True)
+    return torch.where(torch.isinf(out), torch.zeros_like(out), out)   # DGL: zero for isolated nodes
+
+
+def in_degrees(dst: Tensor, num_nodes: int, dtype) -> Tensor:
+    return torch.zeros(num_nodes, dtype=dtype, device=dst.device).index_add_(
+        0, dst, torch.ones(dst.shape[0], dtype=dtype, device=dst.device))
+
+
+# --------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------
+def gat_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: Tensor, attn_l: Tensor,
+             attn_r: Tensor, res_fc_weight: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+             negative_slope: float = 0.2, activation: Optional[Callable] = None,
+             attn_keep: Optional[Tensor] = None, residual_identity: bool = False) -> Tuple[Tensor, Tensor]:
+    """dgl.nn.pytorch.GATConv.forward (Appendix A.1). Returns (rst (N,H,D), a (E,H)).
+
+    ``attn_keep`` (E,H), if given, is the already scaled dropout multiplier applied to the
+    attention (mask / (1-p)), standing in for ``attn_drop``.
+    """
+    _, H, D = attn_l.shape
+    ft = F.linear(feat, fc_weight).view(num_nodes, H, D)
+    el = (ft * attn_l).sum(-1)                                       # (N,H)
+    er = (ft * attn_r).sum(-1)
+    e = F.leaky_relu(el.index_select(0, src) + er.index_select(0, dst), negative_slope)   # u_add_v
+    a = edge_softmax(dst, e, num_nodes)                               # (E,H)
+    a_used = a if attn_keep is None else a * attn_keep
+    rst = spmm_sum(src, dst, ft, num_nodes, a_used.unsqueeze(-1))     # u_mul_e / sum
+    if res_fc_weight is not None:
+        rst = rst + F.linear(feat, res_fc_weight).view(num_nodes, H, D)
+    elif residual_identity:
+        rst = rst + feat.view(num_nodes, -1, D)
+    if bias is not None:
+        rst = rst + bias.view(1, H, D)
+    if activation is not None:
+        rst = activation(rst)
+    return rst, a
+
+
+def graph_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, weight: Tensor, bias: Optional[Tensor],
+               activation: Optional[Callable] = None) -> Tensor:
+    """dgl.nn.pytorch.GraphConv.forward with norm='both' (Appendix A.2)."""
+    out_deg = in_degrees(src, num_nodes, feat.dtype).clamp(min=1)
+    in_deg = in_degrees(dst, num_nodes, feat.dtype).clamp(min=1)
+    h = feat * out_deg.pow(-0.5).unsqueeze(-1)
+    f_in, f_out = weight.shape
+    if f_in > f_out:
+        rst = spmm_sum(src, dst, h @ weight, num_nodes)
+    else:
+        rst = spmm_sum(src, dst, h, num_nodes) @ weight
+    rst = rst * in_deg.pow(-0.5).unsqueeze(-1)
+    if bias is not None:
+        rst = rst + bias
+    if activation is not None:
+        rst = activation(rst)
+    return rst
+
+
+def gin_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, eps: Tensor, apply_func: Callable,
+             aggregator_type: str = "mean") -> Tensor:
+    """dgl.nn.pytorch.GINConv.forward (Appendix A.3)."""
+    if aggregator_type == "sum":
+        neigh = spmm_sum(src, dst, feat, num_nodes)
+    elif aggregator_type == "mean":
+        deg = in_degrees(dst, num_nodes, feat.dtype).clamp(min=1)
+        neigh = spmm_sum(src, dst, feat, num_nodes) / deg.unsqueeze(-1)
+    elif aggregator_type == "max":
+        neigh = spmm_max(src, dst, feat, num_nodes)
+    else:
+        raise KeyError(aggregator_type)
+    rst = (1 + eps) * feat + neigh
+    return apply_func(rst) if apply_func is not None else rst
+
+
+def sage_conv_pool(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_pool_w: Tensor, fc_pool_b: Tensor,
+                   fc_self_w: Tensor, fc_self_b: Optional[Tensor], fc_neigh_w: Tensor, fc_neigh_b: Optional[Tensor],
+                   bias: Optional[Tensor] = None, activation: Optional[Callable] = None) -> Tensor:
+    """dgl.nn.pytorch.SAGEConv.forward, aggregator 'pool' (Appendix A.4)."""
+    m = F.relu(F.linear(feat, fc_pool_w, fc_pool_b))
+    neigh = spmm_max(src, dst, m, num_nodes)
+    rst = F.linear(feat, fc_self_w, fc_self_b) + F.linear(neigh, fc_neigh_w, fc_neigh_b)
+    if bias is not None:
+        rst = rst + bias
+    if activation is not None:
+        rst = activation(rst)
+    return rst
+
+
+# --------------------------------------------------------------------------------------
+# model stacks (reference models.py:160-540, 650-696) driven by a state_dict
+# --------------------------------------------------------------------------------------
+def _gat_layer(sd: Dict[str, Tensor], prefix: str, src, dst, n, h, slope, act):
+    return gat_conv(src, dst, n, h, sd[prefix + "fc.weight"], sd[prefix + "attn_l"], sd[prefix + "attn_r"],
+                    sd.get(prefix + "res_fc.weight"), sd.get(prefix + "bias"), slope, act)[0]
+
+
+def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
+    idx = {int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix)}
+    return max(idx) + 1 if idx else 0
+
+
+def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, activation=F.elu, norm=False):
+    """reference models.py:321-329 (GAT.forward)."""
+    L = _count_layers(sd, prefix)
+    h = fvs
+    for l in range(L - 1):
+        h = _gat_layer(sd, f"{prefix}{l}.", src, dst, n, h, negative_slope, activation).flatten(1)
+    out = _gat_layer(sd, f"{prefix}{L - 1}.", src, dst, n, h, negative_slope, None).mean(1)
+    return F.normalize(out, p=2, dim=1) if norm else out
+
+
+def spgnn_pel_stack(sd, src, dst, n, fvs, pos_enc, negative_slope=0.2, activation=F.elu, p_activation=torch.tanh):
+    """reference models.py:472-484 (GATPSPGNN.forward)."""
+    L = _count_layers(sd, "pgnn_layers.")
+    h_s, h_p = fvs, pos_enc
+    for l in range(L):
+        h_s = torch.cat([h_s, h_p], dim=1)
+        h_s = _gat_layer(sd, f"gat_layers.{l}.", src, dst, n, h_s, negative_slope, activation).flatten(1)
+        h_p = _gat_layer(sd, f"pgnn_layers.{l}.", src, dst, n, h_p, negative_slope, p_activation).flatten(1)
+    h_s = torch.cat([h_s, h_p], dim=1)
+    h_s = _gat_layer(sd, f"gat_layers.{L}.", src, dst, n, h_s, negative_slope, activation).mean(1)
+    return h_s, h_p
+
+
+def spgnn_penl_stack(sd, src, dst, n, fvs, pos_enc, negative_slope=0.2, activation=F.elu):
+    """reference models.py:529-540 (GATPSPGNNNL.forward)."""
+    L = _count_layers(sd, "gat_layers.")
+    h_s, h_p = fvs, pos_enc
+    for l in range(L - 1):
+        h_s = torch.cat([h_s, h_p], dim=1)
+        h_s = _gat_layer(sd, f"gat_layers.{l}.", src, dst, n, h_s, negative_slope, activation).flatten(1)
+    h_s = torch.cat([h_s, h_p], dim=1)
+    h_s = _gat_layer(sd, f"gat_layers.{L - 1}.", src, dst, n, h_s, negative_slope, activation).mean(1)
+    return h_s, h_p
+
+
+def gcn_stack(sd, src, dst, n, fvs, prefix="gcn_layers.", activation=F.elu):
+    """reference models.py:188-194 (GCN.forward)."""
+    L = _count_layers(sd, prefix)
+    h = fvs
+    for l in range(L):
+        h = graph_conv(src, dst, n, h, sd[f"{prefix}{l}.weight"], sd.get(f"{prefix}{l}.bias"),
+                       activation if l < L - 1 else None)
+    return h
+
+
+def gin_stack(sd, src, dst, n, fvs, prefix="gin_layers.", norm=False):
+    """reference models.py:386-392 (GIN.forward); MLP = Linear, Dropout(0.1) [identity in eval],
+    LeakyReLU, Linear, LeakyReLU (models.py:358-383)."""
+    L = _count_layers(sd, prefix)
+    h = fvs
+    for l in range(L):
+        p = f"{prefix}{l}."
+
+        def mlp(x, p=p):
+            x = F.leaky_relu(F.linear(x, sd[p + "apply_func.0.weight"], sd[p + "apply_func.0.bias"]))
+            return F.leaky_relu(F.linear(x, sd[p + "apply_func.3.weight"], sd[p + "apply_func.3.bias"]))
+        h = gin_conv(src, dst, n, h, sd[p + "eps"], mlp, "mean")
+    return F.normalize(h, p=2, dim=1) if norm else h
+
+
+def sage_stack(sd, src, dst, n, fvs, prefix="g_layers.", activation=F.elu):
+    """reference models.py:691-696 (SAGE.forward); hidden layers use ``activation``, output none."""
+    L = _count_layers(sd, prefix)
+    h = fvs
+    for l in range(L):
+        p = f"{prefix}{l}."
+        h = sage_conv_pool(src, dst, n, h, sd[p + "fc_pool.weight"], sd[p + "fc_pool.bias"],
+                           sd[p + "fc_self.weight"], sd.get(p + "fc_self.bias"),
+                           sd[p + "fc_neigh.weight"], sd.get(p + "fc_neigh.bias"), sd.get(p + "bias"),
+                           activation if l < L - 1 else None)
+    return h
+
+
+def net_forward(kind: str, sd: Dict[str, Tensor], src, dst, n, fvs, pos_enc=None, **kw):
+    """``*Net.forward(g)`` (reference models.py:277-280, 921-925, 1167-1170): head + gnn_out Linear.
+    ``sd`` is the full-module state_dict (keys ``gat.*`` / ``gcn.*`` / ``gin.*`` / ``sage.*`` / ``gnn_out.*``)."""
+    def sub(pfx):
+        return {k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)}
+    if kind == "gat":
+        emb = (gat_stack(sub("gat."), src, dst, n, fvs, **kw),)
+    elif kind == "spgnn_pel":
+        emb = spgnn_pel_stack(sub("gat."), src, dst, n, fvs, pos_enc, **kw)
+    elif kind == "spgnn_penl":
+        emb = spgnn_penl_stack(sub("gat."), src, dst, n, fvs, pos_enc, **kw)
+    elif kind == "gcn":
+        emb = (gcn_stack(sub("gcn."), src, dst, n, fvs, **kw),)
+    elif kind == "gin":
+        emb = (gin_stack(sub("gin."), src, dst, n, fvs, **kw),)
+    elif kind == "sage":
+        emb = (sage_stack(sub("sage."), src, dst, n, fvs, **kw),)
+    else:
+        raise KeyError(kind)
+    out = F.linear(emb[0], sd["gnn_out.weight"], sd["gnn_out.bias"])
+    return (out,) + tuple(emb)
+
+
+def masked_weighted_ce(logits: Tensor, labels: Tensor, mask: Tensor, class_weight: Tensor) -> Tensor:
+    """reference job_runner.py:1900: F.cross_entropy(out[mask], y[mask], weight=w)."""
+    return F.cross_entropy(logits[mask], labels[mask], weight=class_weight)

@@ -1,0 +1,72 @@
+"""ctypes binding of libspgnn_hip.so (include/spgnn_hip.h).
+
+There is no CPU fallback: if the library is missing the import of any op fails loudly with
+build instructions.  Symbols are bound with full argtypes so a header/library mismatch shows
+up at load time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
+ABI_VERSION = 1
+
+_i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+_f32p = C.c_void_p
+_i64, _i32, _f32, _u64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p
+
+# name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
+SIGNATURES = {
+    "spgnn_abi_version": [],
+    "spgnn_last_error": [],
+    "spgnn_gat_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p,
+                      _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
+    "spgnn_gat_bwd_dst": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,
+                          _f32p, _i64, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
+    "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64,
+                          _i64, _i64, _i32, _i32, _f32, _u64, _vp],
+    "spgnn_spmm_sum": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _vp],
+    "spgnn_spmm_max_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _i32p, _i64, _i64, _i64, _i32, _vp],
+    "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
+    "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class SpgnnLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load and bind the library once.  Raises SpgnnLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpgnnLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or spgnn_amd/csrc/build.py). "
+            f"There is no CPU fallback for the message-passing ops.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int
+    ver = lib.spgnn_abi_version()
+    if ver != ABI_VERSION:
+        raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().spgnn_last_error()
+        raise RuntimeError(f"{what} failed with code {code}: {msg.decode() if msg else ''}")

@@ -1,0 +1,802 @@
+// spgnn_kernels.hip — gfx950 (MI355X / CDNA4) message-passing kernels behind include/spgnn_hip.h.
+//
+// Workload shape: batched airway trees, in-degree 2..5, E = 3N - 2B.  The
+// parallelism is in N x H x D, not in the neighbour reduction, so every kernel maps a TEAM of
+// T in {16,32,64} lanes to one node, each lane owning R float4 chunks of the node's H*D row
+// (H*D = 4*T*R), and walks the node's <=5 edges serially.  All row accesses are 16-byte vector
+// loads, contiguous across the team (up to 1 KiB per wave instruction).  Blocks are remapped so
+// that each XCD (private 4 MiB L2) sweeps a contiguous node range: a tree's rows (its neighbours
+// live within ~150 rows) are then re-read from that XCD's L2 rather than from HBM.
+//
+// No atomics anywhere: forward and the dst-major backward half reduce over in-edges (CSC), the
+// src-major backward half over out-edges (CSR + slot map), so results are run-to-run bitwise
+// reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "spgnn_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return -(1000 + (int)e);
+  }
+  return SPGNN_OK;
+}
+
+constexpr int kBlock = 256;
+
+// ---- team geometry -----------------------------------------------------------------------------
+// H*D floats per node = 4 * T * R.  T = lanes per node, R = float4 chunks per lane.
+bool pick_team(int64_t width, int& T, int& R) {
+  if (width <= 0 || (width & 3)) return false;
+  int64_t q = width >> 2;
+  const int ts[3] = {64, 32, 16};
+  for (int t : ts) {
+    if (q % t) continue;
+    int64_t r = q / t;
+    if (r == 1 || r == 2 || r == 4 || r == 8) { T = t; R = (int)r; return true; }
+  }
+  return false;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool vec_ok(const void* p, int64_t stride) { return p == nullptr || (aligned16(p) && (stride & 3) == 0); }
+
+inline unsigned grid_for(int64_t n_nodes, int nodes_per_block) {
+  int64_t nb = (n_nodes + nodes_per_block - 1) / nodes_per_block;
+  nb = (nb + 7) & ~int64_t(7);            // multiple of 8 so the XCD remap is a bijection
+  return (unsigned)nb;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch").
+// Give each XCD a contiguous run of node blocks.  Pure speed: any placement is correct.
+__device__ __forceinline__ int64_t xcd_block(void) {
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  return (int64_t)(b & 7u) * (nb >> 3) + (b >> 3);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 x) {
+  acc.x = fmaf(s, x.x, acc.x); acc.y = fmaf(s, x.y, acc.y); acc.z = fmaf(s, x.z, acc.z); acc.w = fmaf(s, x.w, acc.w);
+}
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case SPGNN_ACT_ELU:  return x > 0.f ? x : expm1f(x);
+    case SPGNN_ACT_TANH: return tanhf(x);
+    case SPGNN_ACT_RELU: return x > 0.f ? x : 0.f;
+    default:             return x;
+  }
+}
+// derivative expressed through the OUTPUT y = act(x) (what the forward saved)
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+  switch (act) {
+    case SPGNN_ACT_ELU:  return y > 0.f ? 1.f : y + 1.f;
+    case SPGNN_ACT_TANH: return 1.f - y * y;
+    case SPGNN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    default:             return 1.f;
+  }
+}
+
+// Counter-based keep mask for attention dropout: one 64-bit mix of (seed, slot*H + h).  The
+// backward kernels regenerate it instead of storing E*H bytes.
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p, float inv_keep) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0,1)
+  return u >= p ? inv_keep : 0.f;
+}
+
+template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
+#pragma unroll
+  for (int off = W >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ float team_sum(float x, int width) {
+  for (int off = width >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+// =================================================================================================
+// GAT forward
+// =================================================================================================
+struct GatFwd {
+  const int32_t* indptr; const int32_t* indices;
+  const float* ft; int64_t ft_ld;
+  const float* el; const float* er; int64_t s_ld;
+  const float* res; int64_t res_ld;
+  const float* bias;
+  float* out; int64_t out_ld;
+  float* attn;
+  int64_t N; int H; int D; int T;
+  float slope; int act; float p; float inv_keep; uint64_t seed;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
+  const int T = a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (v >= a.N) return;
+  const int lane = threadIdx.x % T;
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+
+  int c[R], h[R];
+  float m[R], s[R], erv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    c[r] = (r * T + lane) * 4;
+    h[r] = c[r] / a.D;
+  }
+  // per-(node, head) softmax statistics, recomputed by every lane of the head (deg <= ~5:
+  // cheaper than a cross-lane exchange); el/er gathers are broadcast loads.
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r > 0 && h[r] == h[r - 1]) { m[r] = m[r - 1]; s[r] = s[r - 1]; erv[r] = erv[r - 1]; continue; }
+    erv[r] = a.er[v * a.s_ld + h[r]];
+    float mx = -INFINITY;
+    for (int j = beg; j < end; ++j)
+      mx = fmaxf(mx, lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h[r]] + erv[r], a.slope));
+    float sm = 0.f;
+    for (int j = beg; j < end; ++j)
+      sm += expf(lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h[r]] + erv[r], a.slope) - mx);
+    m[r] = mx; s[r] = sm;
+  }
+
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    const float* row = a.ft + u * a.ft_ld;
+    float4 x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = ld4(row + c[r]);
+    float w_prev = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float w;
+      if (r > 0 && h[r] == h[r - 1]) {
+        w = w_prev;
+      } else {
+        const float e = lrelu(a.el[u * a.s_ld + h[r]] + erv[r], a.slope);
+        const float al = expf(e - m[r]) / s[r];
+        if (c[r] % a.D == 0) a.attn[(int64_t)j * a.H + h[r]] = al;
+        w = a.p > 0.f ? al * keep_scale(a.seed, (int64_t)j * a.H + h[r], a.p, a.inv_keep) : al;
+      }
+      w_prev = w;
+      fma4(acc[r], w, x[r]);
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float4 o = acc[r];
+    if (a.res) { const float4 q = ld4(a.res + v * a.res_ld + c[r]); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+    if (a.bias) { const float4 q = ld4(a.bias + c[r]); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+    if (a.act != SPGNN_ACT_NONE) {
+      o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act);
+    }
+    st4(a.out + v * a.out_ld + c[r], o);
+  }
+}
+
+// scalar fallback: one thread per (node, column); any H, D, stride, alignment
+__global__ void gat_fwd_scalar(GatFwd a) {
+  const int HD = a.H * a.D;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * HD) return;
+  const int64_t v = gid / HD; const int col = (int)(gid % HD); const int h = col / a.D;
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const float erv = a.er[v * a.s_ld + h];
+  float mx = -INFINITY;
+  for (int j = beg; j < end; ++j) mx = fmaxf(mx, lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv, a.slope));
+  float sm = 0.f;
+  for (int j = beg; j < end; ++j) sm += expf(lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv, a.slope) - mx);
+  float acc = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    const float al = expf(lrelu(a.el[u * a.s_ld + h] + erv, a.slope) - mx) / sm;
+    if (col % a.D == 0) a.attn[(int64_t)j * a.H + h] = al;
+    const float w = a.p > 0.f ? al * keep_scale(a.seed, (int64_t)j * a.H + h, a.p, a.inv_keep) : al;
+    acc = fmaf(w, a.ft[u * a.ft_ld + col], acc);
+  }
+  if (a.res) acc += a.res[v * a.res_ld + col];
+  if (a.bias) acc += a.bias[col];
+  a.out[v * a.out_ld + col] = act_fwd(acc, a.act);
+}
+
+// =================================================================================================
+// GAT backward, dst-major half
+// =================================================================================================
+struct GatBwdDst {
+  const int32_t* indptr; const int32_t* indices;
+  const float* ft; int64_t ft_ld;
+  const float* el; const float* er; int64_t s_ld;
+  const float* attn;
+  const float* g_out; int64_t g_out_ld;
+  const float* out; int64_t out_ld;
+  float* g_pre; int64_t g_pre_ld;
+  float* g_e;
+  float* g_er; int64_t gs_ld;
+  int64_t N; int H; int D; int T; int W;
+  float slope; int act; float p; float inv_keep; uint64_t seed;
+};
+
+// CH = float4 chunks of one lane that belong to one head (D = 4*T*CH), or 0 when a head is
+// narrower than the team (4*T % D == 0): then each chunk is its own slot and the reduction
+// width is W = D/4 lanes.
+template <int R, int CH>
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
+  constexpr int NS = (CH == 0) ? R : R / CH;
+  const int T = a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (v >= a.N) return;
+  const int lane = threadIdx.x % T;
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int width = (CH == 0) ? a.W : T;
+
+  int c[R];
+  float4 g[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    c[r] = (r * T + lane) * 4;
+    float4 q = ld4(a.g_out + v * a.g_out_ld + c[r]);
+    if (a.act != SPGNN_ACT_NONE) {
+      const float4 o = ld4(a.out + v * a.out_ld + c[r]);
+      q.x *= act_bwd_from_out(o.x, a.act); q.y *= act_bwd_from_out(o.y, a.act);
+      q.z *= act_bwd_from_out(o.z, a.act); q.w *= act_bwd_from_out(o.w, a.act);
+    }
+    g[r] = q;
+    st4(a.g_pre + v * a.g_pre_ld + c[r], q);
+  }
+  int hs[NS]; bool wr[NS];
+#pragma unroll
+  for (int sidx = 0; sidx < NS; ++sidx) {
+    const int c0 = (CH == 0) ? c[sidx] : c[sidx * CH];
+    hs[sidx] = c0 / a.D;
+    wr[sidx] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+  }
+
+  // pass 1: g_a for every in-edge (kept in g_e as scratch by the writer lane) and S = sum a*g_a
+  float S[NS];
+#pragma unroll
+  for (int sidx = 0; sidx < NS; ++sidx) S[sidx] = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    const float* row = a.ft + u * a.ft_ld;
+    float pd[NS];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) pd[sidx] = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) pd[(CH == 0) ? r : r / CH] += dot4(ld4(row + c[r]), g[r]);
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      float ga = team_sum(pd[sidx], width);
+      const int64_t eidx = (int64_t)j * a.H + hs[sidx];
+      if (a.p > 0.f) ga *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+      S[sidx] = fmaf(a.attn[eidx], ga, S[sidx]);
+      if (wr[sidx]) a.g_e[eidx] = ga;
+    }
+  }
+  // pass 2 (one lane per (node, head)): softmax backward, LeakyReLU backward, g_er
+#pragma unroll
+  for (int sidx = 0; sidx < NS; ++sidx) {
+    if (!wr[sidx]) continue;
+    const int hh = hs[sidx];
+    const float erv = a.er[v * a.s_ld + hh];
+    float ger = 0.f;
+    for (int j = beg; j < end; ++j) {
+      const int64_t eidx = (int64_t)j * a.H + hh;
+      const float al = a.attn[eidx];
+      float ge = al * a.g_e[eidx] - al * S[sidx];
+      const float epre = a.el[(int64_t)a.indices[j] * a.s_ld + hh] + erv;
+      ge = epre > 0.f ? ge : ge * a.slope;
+      a.g_e[eidx] = ge;
+      ger += ge;
+    }
+    a.g_er[v * a.gs_ld + hh] = ger;
+  }
+}
+
+// scalar fallback: one thread per (node, head)
+__global__ void gat_bwd_dst_scalar(GatBwdDst a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * a.H) return;
+  const int64_t v = gid / a.H; const int h = (int)(gid % a.H);
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int base = h * a.D;
+  for (int d = 0; d < a.D; ++d) {
+    float q = a.g_out[v * a.g_out_ld + base + d];
+    if (a.act != SPGNN_ACT_NONE) q *= act_bwd_from_out(a.out[v * a.out_ld + base + d], a.act);
+    a.g_pre[v * a.g_pre_ld + base + d] = q;
+  }
+  float S = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    float ga = 0.f;
+    for (int d = 0; d < a.D; ++d) ga = fmaf(a.ft[u * a.ft_ld + base + d], a.g_pre[v * a.g_pre_ld + base + d], ga);
+    const int64_t eidx = (int64_t)j * a.H + h;
+    if (a.p > 0.f) ga *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+    S = fmaf(a.attn[eidx], ga, S);
+    a.g_e[eidx] = ga;
+  }
+  const float erv = a.er[v * a.s_ld + h];
+  float ger = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const int64_t eidx = (int64_t)j * a.H + h;
+    const float al = a.attn[eidx];
+    float ge = al * a.g_e[eidx] - al * S;
+    const float epre = a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv;
+    ge = epre > 0.f ? ge : ge * a.slope;
+    a.g_e[eidx] = ge;
+    ger += ge;
+  }
+  a.g_er[v * a.gs_ld + h] = ger;
+}
+
+// =================================================================================================
+// GAT backward, src-major half
+// =================================================================================================
+struct GatBwdSrc {
+  const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
+  const float* attn; const float* g_e;
+  const float* g_pre; int64_t g_pre_ld;
+  float* g_ft; int64_t g_ft_ld;
+  float* g_el; int64_t gs_ld;
+  int64_t N; int H; int D; int T;
+  float p; float inv_keep; uint64_t seed;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
+  const int T = a.T;
+  const int64_t u = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (u >= a.N) return;
+  const int lane = threadIdx.x % T;
+  const int beg = a.out_indptr[u], end = a.out_indptr[u + 1];
+  int c[R], h[R];
+  float4 acc[R];
+  float gel[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    c[r] = (r * T + lane) * 4; h[r] = c[r] / a.D;
+    acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); gel[r] = 0.f;
+  }
+  for (int k = beg; k < end; ++k) {
+    const int64_t v = a.out_indices[k];
+    const int64_t pos = a.out_pos[k];
+    const float* row = a.g_pre + v * a.g_pre_ld;
+    float4 x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = ld4(row + c[r]);
+    float w_prev = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float w;
+      if (r > 0 && h[r] == h[r - 1]) {
+        w = w_prev;
+      } else {
+        const int64_t eidx = pos * a.H + h[r];
+        w = a.attn[eidx];
+        if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+        if (c[r] % a.D == 0) gel[r] += a.g_e[eidx];
+      }
+      w_prev = w;
+      fma4(acc[r], w, x[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    st4(a.g_ft + u * a.g_ft_ld + c[r], acc[r]);
+    if (c[r] % a.D == 0) a.g_el[u * a.gs_ld + h[r]] = gel[r];
+  }
+}
+
+__global__ void gat_bwd_src_scalar(GatBwdSrc a) {
+  const int HD = a.H * a.D;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * HD) return;
+  const int64_t u = gid / HD; const int col = (int)(gid % HD); const int h = col / a.D;
+  const int beg = a.out_indptr[u], end = a.out_indptr[u + 1];
+  float acc = 0.f, gel = 0.f;
+  for (int k = beg; k < end; ++k) {
+    const int64_t v = a.out_indices[k];
+    const int64_t eidx = (int64_t)a.out_pos[k] * a.H + h;
+    float w = a.attn[eidx];
+    if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+    acc = fmaf(w, a.g_pre[v * a.g_pre_ld + col], acc);
+    gel += a.g_e[eidx];
+  }
+  a.g_ft[u * a.g_ft_ld + col] = acc;
+  if (col % a.D == 0) a.g_el[u * a.gs_ld + h] = gel;
+}
+
+// =================================================================================================
+// SpMM sum / max
+// =================================================================================================
+struct SpmmSum {
+  const int32_t* indptr; const int32_t* indices;
+  const float* x; int64_t x_ld;
+  const float* w_src; const float* w_dst; const float* self_eps;
+  float* out; int64_t out_ld;
+  int64_t N; int F; int T;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
+  const int T = a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (v >= a.N) return;
+  const int lane = threadIdx.x % T;
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    const float w = a.w_src ? a.w_src[u] : 1.f;
+    const float* row = a.x + u * a.x_ld;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fma4(acc[r], w, ld4(row + (r * T + lane) * 4));
+  }
+  const float wd = a.w_dst ? a.w_dst[v] : 1.f;
+  const float sc = a.self_eps ? 1.f + a.self_eps[0] : 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (r * T + lane) * 4;
+    float4 o = make_float4(acc[r].x * wd, acc[r].y * wd, acc[r].z * wd, acc[r].w * wd);
+    if (a.self_eps) fma4(o, sc, ld4(a.x + v * a.x_ld + c));
+    st4(a.out + v * a.out_ld + c, o);
+  }
+}
+
+__global__ void spmm_sum_scalar(SpmmSum a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * a.F) return;
+  const int64_t v = gid / a.F; const int col = (int)(gid % a.F);
+  float acc = 0.f;
+  for (int j = a.indptr[v]; j < a.indptr[v + 1]; ++j) {
+    const int64_t u = a.indices[j];
+    acc = fmaf(a.w_src ? a.w_src[u] : 1.f, a.x[u * a.x_ld + col], acc);
+  }
+  acc *= a.w_dst ? a.w_dst[v] : 1.f;
+  if (a.self_eps) acc = fmaf(1.f + a.self_eps[0], a.x[v * a.x_ld + col], acc);
+  a.out[v * a.out_ld + col] = acc;
+}
+
+struct SpmmMaxFwd {
+  const int32_t* indptr; const int32_t* indices;
+  const float* x; int64_t x_ld;
+  float* out; int64_t out_ld;
+  int32_t* arg; int64_t arg_ld;
+  int64_t N; int F; int T;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec(SpmmMaxFwd a) {
+  const int T = a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (v >= a.N) return;
+  const int lane = threadIdx.x % T;
+  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  float4 best[R]; int4 arg[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { best[r] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); arg[r] = make_int4(-1, -1, -1, -1); }
+  for (int j = beg; j < end; ++j) {
+    const float* row = a.x + (int64_t)a.indices[j] * a.x_ld;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4 q = ld4(row + (r * T + lane) * 4);
+      if (q.x > best[r].x) { best[r].x = q.x; arg[r].x = j; }
+      if (q.y > best[r].y) { best[r].y = q.y; arg[r].y = j; }
+      if (q.z > best[r].z) { best[r].z = q.z; arg[r].z = j; }
+      if (q.w > best[r].w) { best[r].w = q.w; arg[r].w = j; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (r * T + lane) * 4;
+    float4 o = best[r];
+    if (arg[r].x < 0) o.x = 0.f;
+    if (arg[r].y < 0) o.y = 0.f;
+    if (arg[r].z < 0) o.z = 0.f;
+    if (arg[r].w < 0) o.w = 0.f;
+    st4(a.out + v * a.out_ld + c, o);
+    *reinterpret_cast<int4*>(a.arg + v * a.arg_ld + c) = arg[r];
+  }
+}
+
+__global__ void spmm_max_fwd_scalar(SpmmMaxFwd a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * a.F) return;
+  const int64_t v = gid / a.F; const int col = (int)(gid % a.F);
+  float best = -INFINITY; int arg = -1;
+  for (int j = a.indptr[v]; j < a.indptr[v + 1]; ++j) {
+    const float q = a.x[(int64_t)a.indices[j] * a.x_ld + col];
+    if (q > best) { best = q; arg = j; }
+  }
+  a.out[v * a.out_ld + col] = arg < 0 ? 0.f : best;
+  a.arg[v * a.arg_ld + col] = arg;
+}
+
+struct SpmmMaxBwd {
+  const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
+  const float* g_out; int64_t g_out_ld;
+  const int32_t* arg; int64_t arg_ld;
+  float* g_x; int64_t g_x_ld;
+  int64_t N; int F; int T;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
+  const int T = a.T;
+  const int64_t u = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  if (u >= a.N) return;
+  const int lane = threadIdx.x % T;
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = a.out_indptr[u]; k < a.out_indptr[u + 1]; ++k) {
+    const int64_t v = a.out_indices[k];
+    const int pos = a.out_pos[k];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int c = (r * T + lane) * 4;
+      const int4 ar = *reinterpret_cast<const int4*>(a.arg + v * a.arg_ld + c);
+      const float4 g = ld4(a.g_out + v * a.g_out_ld + c);
+      if (ar.x == pos) acc[r].x += g.x;
+      if (ar.y == pos) acc[r].y += g.y;
+      if (ar.z == pos) acc[r].z += g.z;
+      if (ar.w == pos) acc[r].w += g.w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) st4(a.g_x + u * a.g_x_ld + (r * T + lane) * 4, acc[r]);
+}
+
+__global__ void spmm_max_bwd_scalar(SpmmMaxBwd a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.N * a.F) return;
+  const int64_t u = gid / a.F; const int col = (int)(gid % a.F);
+  float acc = 0.f;
+  for (int k = a.out_indptr[u]; k < a.out_indptr[u + 1]; ++k) {
+    const int64_t v = a.out_indices[k];
+    if (a.arg[v * a.arg_ld + col] == a.out_pos[k]) acc += a.g_out[v * a.g_out_ld + col];
+  }
+  a.g_x[u * a.g_x_ld + col] = acc;
+}
+
+// =================================================================================================
+// SGD + momentum over a flat bucket
+// =================================================================================================
+__global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                    const float* __restrict__ gscale, int64_t n, float lr, float mom, float wd, int first) {
+  const float sc = gscale ? gscale[0] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float gi = fmaf(wd, w, g[i] * sc);
+    const float b = first ? gi : fmaf(mom, buf[i], gi);
+    buf[i] = b;
+    p[i] = w - lr * b;
+  }
+}
+
+#define DISPATCH_R(R_, KERNEL, ...)                                                              \
+  switch (R_) {                                                                                  \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                   \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                   \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                   \
+    default: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                  \
+  }
+
+inline unsigned scalar_grid(int64_t total) { return (unsigned)((total + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int spgnn_abi_version(void) { return SPGNN_ABI_VERSION; }
+const char* spgnn_last_error(void) { return g_err; }
+
+int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+                  const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
+                  const float* bias, float* out, int64_t out_stride, float* attn, int64_t N, int64_t E, int32_t H,
+                  int32_t D, float negative_slope, int32_t activation, float p_drop, uint64_t seed,
+                  spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: bad N/E/H/D");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !ft || !el || !er || !out || !attn || (E > 0 && !indices))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (ft_stride < HD || out_stride < HD || s_stride < H || (res && res_stride < HD))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_fwd: row stride smaller than row");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: activation");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
+  hipStream_t st = (hipStream_t)stream;
+  GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, attn,
+           N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed};
+  int T, R;
+  const bool vec = (D % 4 == 0) && pick_team(HD, T, R) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
+                   vec_ok(res, res_stride) && vec_ok(bias, 0);
+  if (vec) {
+    a.T = T;
+    DISPATCH_R(R, gat_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gat_fwd_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
+  }
+  return check_launch("spgnn_gat_fwd");
+}
+
+int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+                      const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
+                      int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre, int64_t g_pre_stride,
+                      float* g_e, float* g_er, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t D,
+                      float negative_slope, int32_t activation, float p_drop, uint64_t seed, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
+  if (N == 0) return SPGNN_OK;
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
+  if (!indptr || !ft || !el || !er || !attn || !g_out || !g_pre || !g_e || !g_er || (E > 0 && !indices) ||
+      (activation != SPGNN_ACT_NONE && !out))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_dst: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (ft_stride < HD || g_out_stride < HD || g_pre_stride < HD || s_stride < H || g_s_stride < H ||
+      (activation != SPGNN_ACT_NONE && out_stride < HD))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_dst: row stride smaller than row");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: p_drop not in [0,1)");
+  hipStream_t st = (hipStream_t)stream;
+  GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
+              g_pre, g_pre_stride, g_e, g_er, g_s_stride, N, H, D, 0, 0, negative_slope, activation, p_drop,
+              1.f / (1.f - p_drop), seed};
+  int T = 0, R = 0, CH = -1;
+  bool vec = (D % 4 == 0) && pick_team(HD, T, R) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
+             vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
+  if (vec) {
+    const int team_floats = 4 * T;
+    if (D % team_floats == 0) {
+      CH = D / team_floats;
+      if (!(CH == 1 || CH == 2 || CH == 4 || CH == 8) || R % CH) vec = false;
+    } else if (team_floats % D == 0 && ((D / 4) & (D / 4 - 1)) == 0) {
+      CH = 0; a.W = D / 4;
+    } else {
+      vec = false;
+    }
+  }
+  if (vec) {
+    a.T = T;
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+#define L(R_, CH_) hipLaunchKernelGGL((gat_bwd_dst_vec<R_, CH_>), grid, block, 0, st, a)
+    switch (R * 16 + CH) {
+      case 1 * 16 + 0: L(1, 0); break;  case 1 * 16 + 1: L(1, 1); break;
+      case 2 * 16 + 0: L(2, 0); break;  case 2 * 16 + 1: L(2, 1); break;  case 2 * 16 + 2: L(2, 2); break;
+      case 4 * 16 + 0: L(4, 0); break;  case 4 * 16 + 1: L(4, 1); break;  case 4 * 16 + 2: L(4, 2); break;
+      case 4 * 16 + 4: L(4, 4); break;
+      case 8 * 16 + 0: L(8, 0); break;  case 8 * 16 + 1: L(8, 1); break;  case 8 * 16 + 2: L(8, 2); break;
+      case 8 * 16 + 4: L(8, 4); break;  case 8 * 16 + 8: L(8, 8); break;
+      default: vec = false; break;
+    }
+#undef L
+  }
+  if (!vec) hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
+  return check_launch("spgnn_gat_bwd_dst");
+}
+
+int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                      const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
+                      float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t D, float p_drop,
+                      uint64_t seed, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src: bad N/E/H/D");
+  if (N == 0) return SPGNN_OK;
+  if (!out_indptr || !attn || !g_e || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos)))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_src: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (g_pre_stride < HD || g_ft_stride < HD || g_s_stride < H)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_src: row stride smaller than row");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
+  hipStream_t st = (hipStream_t)stream;
+  GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
+              N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed};
+  int T, R;
+  if ((D % 4 == 0) && pick_team(HD, T, R) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
+    a.T = T;
+    DISPATCH_R(R, gat_bwd_src_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
+  }
+  return check_launch("spgnn_gat_bwd_src");
+}
+
+int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
+                   const float* w_dst, const float* self_eps, float* out, int64_t out_stride, int64_t N, int64_t E,
+                   int32_t F, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_sum: bad N/E/F");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !x || !out || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_sum: null pointer");
+  if (x_stride < F || out_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_sum: row stride smaller than row");
+  hipStream_t st = (hipStream_t)stream;
+  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0};
+  int T, R;
+  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride)) {
+    a.T = T;
+    DISPATCH_R(R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(spmm_sum_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
+  }
+  return check_launch("spgnn_spmm_sum");
+}
+
+int spgnn_spmm_max_fwd(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, float* out,
+                       int64_t out_stride, int32_t* arg, int64_t arg_stride, int64_t N, int64_t E, int32_t F,
+                       spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_fwd: bad N/E/F");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !x || !out || !arg || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_fwd: null pointer");
+  if (x_stride < F || out_stride < F || arg_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_fwd: row stride smaller than row");
+  hipStream_t st = (hipStream_t)stream;
+  SpmmMaxFwd a{indptr, indices, x, x_stride, out, out_stride, arg, arg_stride, N, F, 0};
+  int T, R;
+  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && vec_ok(arg, arg_stride)) {
+    a.T = T;
+    DISPATCH_R(R, spmm_max_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(spmm_max_fwd_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
+  }
+  return check_launch("spgnn_spmm_max_fwd");
+}
+
+int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* g_out,
+                       int64_t g_out_stride, const int32_t* arg, int64_t arg_stride, float* g_x, int64_t g_x_stride,
+                       int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_bwd: bad N/E/F");
+  if (N == 0) return SPGNN_OK;
+  if (!out_indptr || !g_out || !arg || !g_x || (E > 0 && (!out_indices || !out_pos)))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_bwd: null pointer");
+  if (g_out_stride < F || arg_stride < F || g_x_stride < F)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd: row stride smaller than row");
+  hipStream_t st = (hipStream_t)stream;
+  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0};
+  int T, R;
+  if (pick_team(F, T, R) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
+    a.T = T;
+    DISPATCH_R(R, spmm_max_bwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(spmm_max_bwd_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
+  }
+  return check_launch("spgnn_spmm_max_bwd");
+}
+
+int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale, int64_t n,
+                            float lr, float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+  if (n < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sgd_momentum_step: n < 0");
+  if (n == 0) return SPGNN_OK;
+  if (!param || !grad || !momentum_buf) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step: null pointer");
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, param, grad,
+                     momentum_buf, grad_scale, n, lr, momentum, weight_decay, first_step);
+  return check_launch("spgnn_sgd_momentum_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+"""Batched airway-tree graph container (host side of the hot path).
+
+Replaces the slice of the DGL graph API the reference touches:
+``DGLGraph(nx_graph)``, ``add_edges``, ``remove_self_loop``, ``batch``/``unbatch``,
+``ndata``, ``in_degrees``, ``adjacency_matrix``, ``to_networkx``.
+
+The edge list follows the reference's construction rule bit-exactly
+(reference job_runner.py:1319-1344 and 1779-1801, batching at 1390/1882):
+
+* every directed pair (u, v), u != v, adj[u, v] != 0, sorted by (u, v);
+* then n self loops (i, i) appended last;
+* ``batch`` offsets node ids by the running node count and concatenates the
+  per-tree edge lists in order.
+
+For the HIP kernels the edge list is turned (once per loader batch, reused for the
+300 inner steps, reference job_runner.py:1892) into int32 device arrays:
+
+``indptr[N+1], indices[E], eid[E]``
+    dst-major CSC; the in-edges of v are ``indices[indptr[v]:indptr[v+1]]`` in
+    ascending edge id (stable), which is the summation order DGL's COO->CSC gives.
+``out_indptr[N+1], out_indices[E], out_pos[E]``
+    src-major CSR; ``out_pos`` is the CSC slot of the same edge, so per-edge
+    arrays kept in CSC order (attention, its gradient) are addressed from
+    either side without a second copy.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+__all__ = [
+    "edges_from_adj", "TreeGraph", "DGLGraph", "batch", "unbatch", "remove_self_loop",
+    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy",
+]
+
+
+def edges_from_adj(adj: np.ndarray, add_self_loops: bool = True):
+    """Directed edge list of one tree by the reference rule (job_runner.py:1779-1801).
+
+    ``nx.DiGraph(adj)`` enumerates non-zero entries row by row, i.e. sorted by (u, v);
+    ``dgl.remove_self_loop`` drops the diagonal keeping order; ``g.add_edges(nodes, nodes)``
+    appends (i, i) for i = 0..n-1.
+    """
+    a = np.asarray(adj)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError(f"adj must be square, got {a.shape}")
+    n = a.shape[0]
+    u, v = np.nonzero(a)                 # row-major == sorted by (u, v)
+    keep = u != v
+    u, v = u[keep], v[keep]
+    if add_self_loops:
+        loops = np.arange(n, dtype=u.dtype)
+        u = np.concatenate([u, loops])
+        v = np.concatenate([v, loops])
+    return u.astype(np.int64), v.astype(np.int64)
+
+
+def build_csc_numpy(src: np.ndarray, dst: np.ndarray, num_nodes: int):
+    """Stable COO -> CSC/CSR in numpy. Returns dict of int32 arrays."""
+    E = int(src.shape[0])
+    if E >= 2 ** 31 or num_nodes >= 2 ** 31:
+        raise ValueError("graph too large for int32 indexing")
+    order = np.argsort(dst, kind="stable")
+    indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.add.at(indptr, dst + 1, 1)
+    indptr = np.cumsum(indptr)
+    indices = src[order]
+    eid = order
+    csc_pos_of_edge = np.empty(E, dtype=np.int64)
+    csc_pos_of_edge[order] = np.arange(E)
+    oorder = np.argsort(src, kind="stable")
+    out_indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.add.at(out_indptr, src + 1, 1)
+    out_indptr = np.cumsum(out_indptr)
+    out_indices = dst[oorder]
+    out_pos = csc_pos_of_edge[oorder]
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    return dict(indptr=i32(indptr), indices=i32(indices), eid=i32(eid),
+                out_indptr=i32(out_indptr), out_indices=i32(out_indices), out_pos=i32(out_pos))
+
+
+class DeviceCSC:
+    """int32 CSC/CSR arrays of a batched graph resident on one device."""
+
+    def __init__(self, arrays: Dict[str, np.ndarray], num_nodes: int, num_edges: int, device):
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(num_edges)
+        self.device = torch.device(device)
+        for k, a in arrays.items():
+            setattr(self, k, torch.from_numpy(a).to(self.device))
+        ind = arrays["indptr"].astype(np.int64)
+        oind = arrays["out_indptr"].astype(np.int64)
+        self.max_in_degree = int((ind[1:] - ind[:-1]).max()) if num_nodes else 0
+        self.max_out_degree = int((oind[1:] - oind[:-1]).max()) if num_nodes else 0
+        self.min_in_degree = int((ind[1:] - ind[:-1]).min()) if num_nodes else 0
+        # degree-derived edge weights are computed lazily by ops (GraphConv/GIN)
+        self._cache: Dict[str, torch.Tensor] = {}
+
+    def in_degrees_f(self) -> torch.Tensor:
+        if "in_deg" not in self._cache:
+            self._cache["in_deg"] = (self.indptr[1:] - self.indptr[:-1]).to(torch.float32)
+        return self._cache["in_deg"]
+
+    def out_degrees_f(self) -> torch.Tensor:
+        if "out_deg" not in self._cache:
+            self._cache["out_deg"] = (self.out_indptr[1:] - self.out_indptr[:-1]).to(torch.float32)
+        return self._cache["out_deg"]
+
+
+class _NData(dict):
+    """``g.ndata`` — a dict of node tensors that checks the leading dimension."""
+
+    def __init__(self, graph):
+        super().__init__()
+        self._g = graph
+
+    def __setitem__(self, key, value):
+        if not torch.is_tensor(value):
+            value = torch.as_tensor(value)
+        if value.shape[0] != self._g.number_of_nodes():
+            raise ValueError(f"ndata['{key}'] has {value.shape[0]} rows, graph has "
+                             f"{self._g.number_of_nodes()} nodes")
+        if value.device != self._g.device:
+            value = value.to(self._g.device)
+        super().__setitem__(key, value)
+
+
+class TreeGraph:
+    """A (batched) directed graph in DGL edge order with node data.
+
+    Mirrors the ``DGLGraph`` calls the reference makes.
+    """
+
+    def __init__(self, data=None, num_nodes: Optional[int] = None, device="cpu"):
+        self.device = torch.device(device)
+        if data is None:
+            src = np.zeros(0, np.int64); dst = np.zeros(0, np.int64); n = num_nodes or 0
+        elif isinstance(data, tuple):
+            src = np.asarray(data[0], dtype=np.int64); dst = np.asarray(data[1], dtype=np.int64)
+            n = num_nodes if num_nodes is not None else (int(max(src.max(initial=-1), dst.max(initial=-1))) + 1)
+        else:
+            src, dst, n = _edges_from_networkx(data)
+        self._src, self._dst, self._n = src, dst, int(n)
+        self.batch_num_nodes_list: List[int] = [self._n]
+        self.batch_num_edges_list: List[int] = [int(src.shape[0])]
+        self.ndata = _NData(self)
+        self._csc: Dict[str, DeviceCSC] = {}
+
+    # ---- structure -------------------------------------------------------------------
+    def number_of_nodes(self) -> int:
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self) -> int:
+        return int(self._src.shape[0])
+
+    num_edges = number_of_edges
+
+    def nodes(self) -> torch.Tensor:
+        return torch.arange(self._n, dtype=torch.int64, device=self.device)
+
+    def edges(self):
+        return (torch.from_numpy(self._src).to(self.device), torch.from_numpy(self._dst).to(self.device))
+
+    def add_edges(self, u, v) -> None:
+        """Append edges in place (reference: ``g.add_edges(g.nodes(), g.nodes())``)."""
+        u = _as_np_i64(u); v = _as_np_i64(v)
+        if u.shape != v.shape:
+            raise ValueError("add_edges: u and v differ in length")
+        if u.size and (max(u.max(), v.max()) >= self._n or min(u.min(), v.min()) < 0):
+            raise ValueError("add_edges: node id out of range")
+        self._src = np.concatenate([self._src, u]); self._dst = np.concatenate([self._dst, v])
+        if len(self.batch_num_edges_list) == 1:
+            self.batch_num_edges_list = [int(self._src.shape[0])]
+        else:  # DGL resets batch info on mutation of a batched graph
+            self.batch_num_nodes_list = [self._n]; self.batch_num_edges_list = [int(self._src.shape[0])]
+        self._csc.clear()
+
+    @property
+    def batch_size(self) -> int:
+        return len(self.batch_num_nodes_list)
+
+    def batch_num_nodes(self) -> torch.Tensor:
+        return torch.tensor(self.batch_num_nodes_list, dtype=torch.int64)
+
+    def batch_num_edges(self) -> torch.Tensor:
+        return torch.tensor(self.batch_num_edges_list, dtype=torch.int64)
+
+    def in_degrees(self) -> torch.Tensor:
+        return torch.from_numpy(np.bincount(self._dst, minlength=self._n).astype(np.int64)).to(self.device)
+
+    def out_degrees(self) -> torch.Tensor:
+        return torch.from_numpy(np.bincount(self._src, minlength=self._n).astype(np.int64)).to(self.device)
+
+    # ---- device ----------------------------------------------------------------------
+    def to(self, device) -> "TreeGraph":
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if device == self.device:
+            return self
+        g = TreeGraph((self._src, self._dst), self._n, device)
+        g.batch_num_nodes_list = list(self.batch_num_nodes_list)
+        g.batch_num_edges_list = list(self.batch_num_edges_list)
+        for k, v in self.ndata.items():
+            g.ndata[k] = v.to(device)
+        return g
+
+    def cpu(self) -> "TreeGraph":
+        return self.to("cpu")
+
+    def csc(self, device=None) -> DeviceCSC:
+        """int32 CSC + CSR of the current edge list on ``device`` (built once, cached)."""
+        device = torch.device(device) if device is not None else self.device
+        key = str(device)
+        if key not in self._csc:
+            arrays = build_csc_numpy(self._src, self._dst, self._n)
+            self._csc[key] = DeviceCSC(arrays, self._n, self.number_of_edges(), device)
+        return self._csc[key]
+
+    # ---- conversions -----------------------------------------------------------------
+    def adjacency_matrix(self, scipy_fmt: Optional[str] = None):
+        """Row = dst, col = src ... DGL's ``adjacency_matrix()`` puts src on rows for
+        ``transpose=False`` in 0.5+; the reference only uses it on symmetric graphs
+        (job_runner.py:1742, 1814), so orientation does not matter there. Rows = src here."""
+        import scipy.sparse as sp
+        m = sp.coo_matrix((np.ones(self.number_of_edges(), np.float32), (self._src, self._dst)),
+                          shape=(self._n, self._n))
+        if scipy_fmt is not None:
+            return m.asformat(scipy_fmt)
+        idx = torch.from_numpy(np.stack([self._src, self._dst]))
+        return torch.sparse_coo_tensor(idx, torch.ones(self.number_of_edges()), (self._n, self._n))
+
+    def to_networkx(self):
+        return to_networkx(self)
+
+    def __repr__(self):
+        return (f"TreeGraph(num_nodes={self._n}, num_edges={self.number_of_edges()}, "
+                f"batch_size={self.batch_size}, ndata={list(self.ndata.keys())}, device={self.device})")
+
+
+DGLGraph = TreeGraph  # the name the reference constructs (job_runner.py:1341,1783)
+
+
+def _as_np_i64(x) -> np.ndarray:
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy().astype(np.int64)
+    return np.asarray(x, dtype=np.int64)
+
+
+def _edges_from_networkx(G):
+    """``DGLGraph(nx_graph)``: nodes must be 0..n-1; a DiGraph contributes its edges in
+    iteration order, an undirected Graph both directions (DGL converts via ``to_directed()``,
+    whose iteration is per source node in node order == sorted by (u, v) for graphs built
+    from a dense adjacency, which is all the reference does: job_runner.py:1331-1341)."""
+    import networkx as nx
+    n = G.number_of_nodes()
+    if sorted(G.nodes()) != list(range(n)):
+        raise ValueError("networkx graph nodes must be 0..n-1")
+    D = G if G.is_directed() else G.to_directed()
+    e = np.asarray(list(D.edges()), dtype=np.int64).reshape(-1, 2)
+    if not G.is_directed():   # to_directed() iterates adjacency in insertion order; sort by (u, v)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    return e[:, 0].copy(), e[:, 1].copy(), n
+
+
+def remove_self_loop(g: TreeGraph) -> TreeGraph:
+    keep = g._src != g._dst
+    out = TreeGraph((g._src[keep], g._dst[keep]), g._n, g.device)
+    for k, v in g.ndata.items():
+        out.ndata[k] = v
+    return out
+
+
+def batch(graphs: Sequence[TreeGraph]) -> TreeGraph:
+    """Block-diagonal union (``dgl.batch``): node/edge ids offset by running sums; node data
+    present in every member is concatenated."""
+    if len(graphs) == 0:
+        raise ValueError("batch of zero graphs")
+    device = graphs[0].device
+    srcs, dsts, nn, ne, off = [], [], [], [], 0
+    for g in graphs:
+        if g.device != device:
+            raise ValueError("all graphs in a batch must be on one device")
+        srcs.append(g._src + off); dsts.append(g._dst + off)
+        nn.extend(g.batch_num_nodes_list); ne.extend(g.batch_num_edges_list)
+        off += g._n
+    out = TreeGraph((np.concatenate(srcs), np.concatenate(dsts)), off, device)
+    out.batch_num_nodes_list, out.batch_num_edges_list = nn, ne
+    keys = set(graphs[0].ndata.keys())
+    for g in graphs[1:]:
+        keys &= set(g.ndata.keys())
+    for k in sorted(keys):
+        out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
+    return out
+
+
+def unbatch(g: TreeGraph) -> List[TreeGraph]:
+    outs, no, eo = [], 0, 0
+    for n, e in zip(g.batch_num_nodes_list, g.batch_num_edges_list):
+        s = g._src[eo:eo + e] - no; d = g._dst[eo:eo + e] - no
+        sub = TreeGraph((s, d), n, g.device)
+        for k, v in g.ndata.items():
+            sub.ndata[k] = v[no:no + n]
+        outs.append(sub); no += n; eo += e
+    return outs
+
+
+def to_networkx(g: TreeGraph):
+    import networkx as nx
+    G = nx.MultiDiGraph()
+    G.add_nodes_from(range(g._n))
+    G.add_edges_from(zip(g._src.tolist(), g._dst.tolist()))
+    return G
+
+
+def graph_from_adj(adj, device="cpu", add_self_loops: bool = True) -> TreeGraph:
+    """One tree's graph straight from the dense ``adj`` of the cached-embedding schema
+    (reference job_runner.py:796-803), equivalent to the nx.DiGraph -> DGLGraph ->
+    remove_self_loop -> add_edges(nodes, nodes) sequence of job_runner.py:1779-1800."""
+    a = adj.detach().cpu().numpy() if torch.is_tensor(adj) else np.asarray(adj)
+    u, v = edges_from_adj(a, add_self_loops)
+    return TreeGraph((u, v), a.shape[0], device)

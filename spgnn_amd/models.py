@@ -1,0 +1,475 @@
+"""GNN heads and ``*Net`` wrappers with the reference's class names, constructor kwargs
+(= the ``MODEL`` dict keys of exp_settings/*.py), methods and state_dict keys, built on
+:mod:`spgnn_amd.nn` instead of DGL.
+
+Reference: models.py:160-194 (GCN), 283-340 (GAT), 343-400 (GIN), 403-484 (GATPSPGNN),
+487-540 (GATPSPGNNNL), 650-696 (SAGE) and the wrappers at 196-281, 725-822, 824-933,
+936-1047, 1050-1174.
+
+The 3-D CNN trunk of the wrappers (``ds_modules``/``bg``/``fc``/``out``, built from the
+reference's ``parts.ConvBlock5d``) is outside the hot path and frozen during GNN training
+(reference models.py:1127-1130).  It is only instantiated with ``build_trunk=True`` and then
+imports ``parts`` from the caller's environment; the GNN-stage entry points
+(``forward(g)``, ``forward_emb(g)``, ``set_gcn_only``, ``init``) never touch it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .nn import GATConv, GINConv, GraphConv, SAGEConv
+
+__all__ = ["GCN", "GAT", "GIN", "SAGE", "GATPSPGNN", "GATPSPGNNNL", "GCNNet", "GATNet", "GINNet", "SAGENet",
+           "GATPositionSPGNNNet", "set_trainable"]
+
+
+def set_trainable(model: nn.Module, trainable: bool) -> None:
+    for p in model.parameters():
+        p.requires_grad = trainable
+
+
+# =================================================================================================
+# heads
+# =================================================================================================
+class GCN(nn.Module):
+    def __init__(self, num_layers, in_dim, num_hiddens, num_classes, activation):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [in_dim] + list(num_hiddens[:num_layers])
+        self.gcn_layers = nn.ModuleList(
+            [GraphConv(dims[i], dims[i + 1], activation=activation) for i in range(num_layers)]
+            + [GraphConv(dims[num_layers], num_classes)])
+
+    def reset_parameters(self):
+        for layer in self.gcn_layers:
+            layer.reset_parameters()
+
+    def forward(self, g):
+        h = g.ndata["fvs"]
+        for layer in self.gcn_layers:
+            h = layer(g, h)
+        return h
+
+
+class GAT(nn.Module):
+    def __init__(self, num_layers, in_dim, num_hiddens, out_ch, heads, activation, feat_drop, attn_drop,
+                 negative_slope, residual, norm=False):
+        super().__init__()
+        self.num_layers, self.activation, self.out_ch, self.norm = num_layers, activation, out_ch, norm
+        widths = [in_dim] + [num_hiddens[l] * heads[l] for l in range(num_layers)]
+        layers = []
+        for l in range(num_layers):          # layer 0 runs without dropout, like the reference
+            drop = (0.0, 0.0) if l == 0 else (feat_drop, attn_drop)
+            layers.append(GATConv(widths[l], num_hiddens[l], heads[l], drop[0], drop[1], negative_slope, residual,
+                                  activation))
+        layers.append(GATConv(widths[num_layers], out_ch, heads[num_layers], 0.0, 0.0, negative_slope, residual, None))
+        self.gat_layers = nn.ModuleList(layers)
+
+    def reset_parameters(self):
+        for layer in self.gat_layers:
+            layer.reset_parameters()
+
+    def _finish(self, h):
+        return F.normalize(h, p=2, dim=1) if self.norm else h
+
+    def forward(self, g):
+        h = g.ndata["fvs"]
+        for layer in self.gat_layers[:-1]:
+            h = layer(g, h).flatten(1)
+        return self._finish(self.gat_layers[-1](g, h).mean(1))
+
+    def forward_batch(self, blocks, x):
+        h = x
+        for layer, block in zip(self.gat_layers[:-1], blocks[:-1]):
+            h = layer(block, h).flatten(1)
+        return self._finish(self.gat_layers[-1](blocks[-1], h).mean(1))
+
+
+def _gin_mlp(n_in, n_out):
+    return nn.Sequential(nn.Linear(n_in, n_out), nn.Dropout(0.1), nn.LeakyReLU(), nn.Linear(n_out, n_out),
+                         nn.LeakyReLU())
+
+
+class GIN(nn.Module):
+    def __init__(self, num_layers, in_dim, num_hiddens, out_ch, norm=False):
+        super().__init__()
+        self.num_layers, self.in_dim, self.out_ch, self.norm = num_layers, in_dim, out_ch, norm
+        dims = [in_dim] + list(num_hiddens[:num_layers]) + [out_ch]
+        self.gin_layers = nn.ModuleList(
+            [GINConv(_gin_mlp(dims[i], dims[i + 1]), "mean", learn_eps=True) for i in range(num_layers + 1)])
+
+    def forward(self, g):
+        h = g.ndata["fvs"]
+        for layer in self.gin_layers:
+            h = layer(g, h)
+        return F.normalize(h, p=2, dim=1) if self.norm else h
+
+    def forward_batch(self, blocks, x):
+        h = x
+        for layer, block in zip(self.gin_layers, blocks):
+            h = layer(block, h)
+        return F.normalize(h, p=2, dim=1) if self.norm else h
+
+
+class GATPSPGNN(nn.Module):
+    """SPGNN "PEL": a structure stream on cat[h_s, h_p] and a learnable position stream
+    (1-head residual GATConv, tanh) on h_p.  Reference models.py:403-484."""
+
+    def __init__(self, num_layers, in_dim, pos_in_dim, num_hiddens, pos_hiddens, pos_heads, out_ch, heads, activation,
+                 feat_drop, attn_drop, negative_slope, residual, norm=False, p_activation=torch.tanh):
+        super().__init__()
+        self.num_layers, self.activation, self.pos_hiddens, self.out_ch, self.norm = \
+            num_layers, activation, pos_hiddens, out_ch, norm
+        s_in = [in_dim + pos_in_dim] + [num_hiddens[l] * heads[l] + pos_hiddens[l] * pos_heads[l]
+                                        for l in range(num_layers)]
+        p_in = [pos_in_dim] + [pos_hiddens[l] * pos_heads[l] for l in range(num_layers - 1)]
+        s_layers, p_layers = [], []
+        for l in range(num_layers):
+            s_drop = (0.0, 0.0) if l == 0 else (feat_drop, attn_drop)
+            # position stream: dropout only on its middle layers (not the first, not the last)
+            p_drop = (feat_drop, attn_drop) if 0 < l < num_layers - 1 else (0.0, 0.0)
+            s_layers.append(GATConv(s_in[l], num_hiddens[l], heads[l], s_drop[0], s_drop[1], negative_slope, residual,
+                                    activation))
+            p_layers.append(GATConv(p_in[l], pos_hiddens[l], pos_heads[l], p_drop[0], p_drop[1], negative_slope, True,
+                                    p_activation))
+        s_layers.append(GATConv(s_in[num_layers], out_ch, heads[num_layers], 0.0, 0.0, negative_slope, residual,
+                                activation))
+        self.gat_layers = nn.ModuleList(s_layers)
+        self.pgnn_layers = nn.ModuleList(p_layers)
+
+    def reset_parameters(self):
+        for layer in list(self.gat_layers) + list(self.pgnn_layers):
+            layer.reset_parameters()
+
+    def forward(self, g):
+        h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
+        for s_layer, p_layer in zip(self.gat_layers[:-1], self.pgnn_layers):
+            h_s = s_layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
+            h_p = p_layer(g, h_p).flatten(1)
+        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1)).mean(1)
+        return h_s, h_p
+
+
+class GATPSPGNNNL(nn.Module):
+    """"PENL" ablation: the static pos_enc is concatenated before every layer.
+    Reference models.py:487-540."""
+
+    def __init__(self, num_layers, in_dim, pos_in_dim, num_hiddens, out_ch, heads, activation, feat_drop, attn_drop,
+                 negative_slope, residual, norm=False):
+        super().__init__()
+        self.num_layers, self.activation, self.out_ch, self.norm = num_layers, activation, out_ch, norm
+        s_in = [in_dim + pos_in_dim] + [num_hiddens[l] * heads[l] + pos_in_dim for l in range(num_layers)]
+        layers = []
+        for l in range(num_layers):
+            drop = (0.0, 0.0) if l == 0 else (feat_drop, attn_drop)
+            layers.append(GATConv(s_in[l], num_hiddens[l], heads[l], drop[0], drop[1], negative_slope, residual,
+                                  activation))
+        layers.append(GATConv(s_in[num_layers], out_ch, heads[num_layers], 0.0, 0.0, negative_slope, residual,
+                              activation))
+        self.gat_layers = nn.ModuleList(layers)
+
+    def reset_parameters(self):
+        for layer in self.gat_layers:
+            layer.reset_parameters()
+
+    def forward(self, g):
+        h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
+        for layer in self.gat_layers[:-1]:
+            h_s = layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
+        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1)).mean(1)
+        return h_s, h_p
+
+
+class SAGE(nn.Module):
+    def __init__(self, num_layers, in_dim, num_hiddens, out_ch, node_ks, node_sample_rate=0.3, activation=F.elu,
+                 feat_drop=0.1, aggregator_type="pool", norm=None):
+        super().__init__()
+        self.num_layers, self.node_ks, self.node_sample_rate, self.out_ch = num_layers, node_ks, node_sample_rate, out_ch
+        dims = [in_dim] + list(num_hiddens[:num_layers])
+        layers = [SAGEConv(dims[l], dims[l + 1], aggregator_type=aggregator_type,
+                           feat_drop=0.0 if l == 0 else feat_drop, activation=activation, norm=norm)
+                  for l in range(num_layers)]
+        layers.append(SAGEConv(dims[num_layers], out_ch, aggregator_type=aggregator_type))
+        self.g_layers = nn.ModuleList(layers)
+
+    def reset_parameters(self):
+        for layer in self.g_layers:
+            layer.reset_parameters()
+
+    def forward_batch(self, blocks, x):
+        h = x
+        for layer, block in zip(self.g_layers, blocks):
+            h = layer(block, h)
+        return h
+
+    def forward(self, g):
+        h = g.ndata["fvs"]
+        for layer in self.g_layers:
+            h = layer(g, h)
+        return h
+
+
+# =================================================================================================
+# *Net wrappers: [frozen CNN trunk] + GNN head + Linear classifier
+# =================================================================================================
+class _GraphNetBase(nn.Module):
+    """Shared plumbing of the reference's ``*Net`` classes: constructor bookkeeping, optional CNN
+    trunk, ``gnn_out``, trainability switches and ``init``."""
+
+    _head_attr = "gat"
+
+    def _setup(self, *, n_layers, in_ch_list, base_ch_list, end_ch_list, checkpoint_layers, kernel_sizes, out_ch,
+               padding_list, conv_strides, dropout, spatial_size, fv_dim, num_hiddens, node_embed_dim,
+               norm_method, act_method, build_trunk):
+        assert len(end_ch_list) == len(base_ch_list) == len(in_ch_list) == len(padding_list)
+        self.fv_dim, self.dropout, self.n_layers, self.out_ch = fv_dim, dropout, n_layers, out_ch
+        self.in_ch_list, self.base_ch_list, self.end_ch_list = in_ch_list, base_ch_list, end_ch_list
+        self.checkpoint_layers, self.conv_strides = checkpoint_layers, conv_strides
+        self.spatial_size, self.kernel_sizes = spatial_size, kernel_sizes
+        self.num_hiddens, self.node_embed_dim = num_hiddens, node_embed_dim
+        self._has_trunk = bool(build_trunk)
+        if build_trunk:
+            self._build_trunk(padding_list, norm_method, act_method)
+
+    def _build_trunk(self, padding_list, norm_method, act_method):
+        try:
+            from parts import ConvBlock5d, act_wrapper      # the reference's own CNN blocks
+        except ImportError as e:
+            raise ImportError("build_trunk=True needs the reference's parts.py on sys.path "
+                              "(the 3-D CNN stage is outside this package)") from e
+        n, L = self.n_layers, self.n_layers
+        self.ds_modules = nn.ModuleList([
+            ConvBlock5d([self.in_ch_list[i], self.base_ch_list[i]], [self.base_ch_list[i], self.end_ch_list[i]],
+                        self.checkpoint_layers[i], self.kernel_sizes[i], False, padding_list[i],
+                        conv_strides=self.conv_strides[i], norm_method=norm_method, act_method=act_method,
+                        dropout=self.dropout) for i in range(n)])
+        self.bg = ConvBlock5d([self.in_ch_list[L], self.base_ch_list[L]], [self.base_ch_list[L], self.end_ch_list[L]],
+                              self.checkpoint_layers[L], self.kernel_sizes[L], False, padding_list[L],
+                              dropout=self.dropout, norm_method=norm_method, act_method=act_method)
+        self.fc = nn.Sequential(
+            nn.Conv3d(self.end_ch_list[L], self.end_ch_list[L], kernel_size=self.spatial_size, padding=0, stride=1),
+            nn.Dropout(self.dropout), act_wrapper(act_method),
+            nn.Conv3d(self.end_ch_list[L], self.fv_dim, kernel_size=1, padding=0, stride=1), act_wrapper(act_method))
+        self.out = nn.Conv3d(self.fv_dim, out_channels=self.out_ch, kernel_size=1, padding=0, bias=True)
+
+    # ---- trainability (reference models.py:1127-1139) -------------------------------------------
+    @property
+    def _head(self) -> nn.Module:
+        return getattr(self, self._head_attr)
+
+    def set_gcn_only(self):
+        set_trainable(self, False)
+        set_trainable(self._head, True)
+        set_trainable(self.gnn_out, True)
+
+    def set_cnn_only(self):
+        set_trainable(self, False)
+        if self._has_trunk:
+            for m in (self.ds_modules, self.bg, self.fc, self.out):
+                set_trainable(m, True)
+
+    def set_all(self):
+        set_trainable(self, True)
+
+    def init(self, initializer=None):
+        """reference models.py:1141-1146: generic initializer over all submodules, then the head's own
+        reset_parameters and xavier-normal on gnn_out."""
+        if initializer is not None:
+            initializer.initialize(self)
+        if hasattr(self._head, "reset_parameters"):
+            self._head.reset_parameters()
+        nn.init.xavier_normal_(self.gnn_out.weight, gain=nn.init.calculate_gain("linear"))
+        nn.init.constant_(self.gnn_out.bias, 0.0)
+
+    # ---- CNN stage (only with a trunk) ----------------------------------------------------------
+    def _need_trunk(self):
+        if not self._has_trunk:
+            raise RuntimeError("this model was built without the CNN trunk (build_trunk=False)")
+
+    def extract_feature(self, x):
+        self._need_trunk()
+        for ds in self.ds_modules:
+            x = ds(x)
+        return self.fc(self.bg(x))
+
+    def forward_without_gnn(self, x):
+        self._need_trunk()
+        from torch.utils.checkpoint import checkpoint
+        for idx, ds in enumerate(self.ds_modules):
+            x = ds(x) if idx == 0 else checkpoint(ds, x)
+        xbg = self.fc(self.bg(x))
+        return xbg, self.out(xbg)
+
+
+class GCNNet(_GraphNetBase):
+    _head_attr = "gcn"
+
+    def __init__(self, n_layers, num_gcn_layers, in_ch_list, base_ch_list, end_ch_list, checkpoint_layers,
+                 kernel_sizes, out_ch, padding_list, conv_strides, dropout, spatial_size, fv_dim, num_hiddens,
+                 node_embed_dim, norm_method="bn", act_method="relu", build_trunk=False):
+        super().__init__()
+        self._setup(n_layers=n_layers, in_ch_list=in_ch_list, base_ch_list=base_ch_list, end_ch_list=end_ch_list,
+                    checkpoint_layers=checkpoint_layers, kernel_sizes=kernel_sizes, out_ch=out_ch,
+                    padding_list=padding_list, conv_strides=conv_strides, dropout=dropout, spatial_size=spatial_size,
+                    fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
+                    act_method=act_method, build_trunk=build_trunk)
+        self.gcn = GCN(num_layers=num_gcn_layers, in_dim=fv_dim, num_hiddens=num_hiddens, num_classes=node_embed_dim,
+                       activation=F.elu)
+        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+
+    def forward(self, g):
+        n_embed = self.gcn(g)
+        return self.gnn_out(n_embed), n_embed
+
+
+class SAGENet(_GraphNetBase):
+    _head_attr = "sage"
+
+    def __init__(self, n_layers, num_layers, in_ch_list, base_ch_list, end_ch_list, checkpoint_layers,
+                 kernel_sizes, out_ch, padding_list, conv_strides, dropout, feat_drop, spatial_size, fv_dim,
+                 num_hiddens, node_embed_dim, node_ks, node_sample_rate, aggregator_type="pool",
+                 norm_method="bn", act_method="relu", build_trunk=False):
+        super().__init__()
+        self._setup(n_layers=n_layers, in_ch_list=in_ch_list, base_ch_list=base_ch_list, end_ch_list=end_ch_list,
+                    checkpoint_layers=checkpoint_layers, kernel_sizes=kernel_sizes, out_ch=out_ch,
+                    padding_list=padding_list, conv_strides=conv_strides, dropout=dropout, spatial_size=spatial_size,
+                    fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
+                    act_method=act_method, build_trunk=build_trunk)
+        self.node_sample_rate, self.node_ks = node_sample_rate, node_ks
+        self.sage = SAGE(num_layers=num_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim,
+                         activation=F.elu, feat_drop=feat_drop, node_ks=node_ks, aggregator_type=aggregator_type,
+                         node_sample_rate=node_sample_rate)
+        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+
+    def forward(self, g):
+        n_embed = self.sage(g)
+        return self.gnn_out(n_embed), n_embed
+
+    def forward_batch(self, blocks, x):
+        n_embed = self.sage.forward_batch(blocks, x)
+        return self.gnn_out(n_embed), n_embed
+
+
+class GATNet(_GraphNetBase):
+    _head_attr = "gat"
+
+    def __init__(self, n_layers, num_gat_layers, num_heads, num_out_heads, in_ch_list, base_ch_list, end_ch_list,
+                 checkpoint_layers, kernel_sizes, out_ch, padding_list, conv_strides, dropout, feat_drop, attn_drop,
+                 negative_slope, spatial_size, fv_dim, num_hiddens, node_embed_dim, res=True,
+                 norm_method="bn", act_method="relu", build_trunk=False):
+        super().__init__()
+        self._setup(n_layers=n_layers, in_ch_list=in_ch_list, base_ch_list=base_ch_list, end_ch_list=end_ch_list,
+                    checkpoint_layers=checkpoint_layers, kernel_sizes=kernel_sizes, out_ch=out_ch,
+                    padding_list=padding_list, conv_strides=conv_strides, dropout=dropout, spatial_size=spatial_size,
+                    fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
+                    act_method=act_method, build_trunk=build_trunk)
+        self.res = res
+        heads = [num_heads] * num_gat_layers + [num_out_heads]
+        self.gat = GAT(num_layers=num_gat_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim,
+                       heads=heads, activation=F.elu, feat_drop=feat_drop, attn_drop=attn_drop,
+                       negative_slope=negative_slope, residual=res)
+        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+
+    def forward(self, g):
+        n_embed = self.gat(g)
+        return self.gnn_out(n_embed), n_embed
+
+    def forward_emb(self, g):
+        n_embed = self.gat(g)
+        return n_embed, n_embed                      # sic: reference models.py:921-923 returns it twice
+
+    def forward_batch(self, blocks, x):
+        n_embed = self.gat.forward_batch(blocks, x)
+        return self.gnn_out(n_embed), n_embed
+
+
+class GINNet(_GraphNetBase):
+    _head_attr = "gin"
+
+    def __init__(self, n_layers, num_gin_layers, in_ch_list, base_ch_list, end_ch_list, checkpoint_layers,
+                 kernel_sizes, out_ch, padding_list, conv_strides, dropout, spatial_size, fv_dim, num_hiddens,
+                 node_embed_dim, norm_method="bn", act_method="relu", build_trunk=False):
+        super().__init__()
+        self._setup(n_layers=n_layers, in_ch_list=in_ch_list, base_ch_list=base_ch_list, end_ch_list=end_ch_list,
+                    checkpoint_layers=checkpoint_layers, kernel_sizes=kernel_sizes, out_ch=out_ch,
+                    padding_list=padding_list, conv_strides=conv_strides, dropout=dropout, spatial_size=spatial_size,
+                    fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
+                    act_method=act_method, build_trunk=build_trunk)
+        self.gin = GIN(num_layers=num_gin_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim)
+        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_lobe_out = nn.Linear(node_embed_dim, 6)      # auxiliary heads (reference models.py:988-989)
+        self.gnn_lung_out = nn.Linear(node_embed_dim, 3)
+
+    def set_gcn_only(self):
+        super().set_gcn_only()
+        set_trainable(self.gnn_lobe_out, True)
+        set_trainable(self.gnn_lung_out, True)
+
+    def forward(self, g):
+        n_embed = self.gin(g)
+        return self.gnn_out(n_embed), n_embed
+
+    def forward_batch(self, blocks, x):
+        n_embed = self.gin.forward_batch(blocks, x)
+        return self.gnn_out(n_embed), n_embed
+
+    def forward_all(self, g):
+        n_embed = self.gin(g)
+        return self.gnn_out(n_embed), self.gnn_lobe_out(n_embed), self.gnn_lung_out(n_embed), n_embed
+
+
+class GATPositionSPGNNNet(_GraphNetBase):
+    _head_attr = "gat"
+
+    def __init__(self, n_layers, num_gat_layers, num_heads, num_out_heads, in_ch_list, base_ch_list, end_ch_list,
+                 checkpoint_layers, kernel_sizes, out_ch, padding_list, conv_strides, dropout, feat_drop, attn_drop,
+                 negative_slope, spatial_size, fv_dim, num_hiddens, pos_hiddens, num_pos_heads, node_embed_dim,
+                 pos_enc_dim, encodng_merge="cat", norm=False, res=True, norm_method="bn", act_method="relu",
+                 p_act="tahn", mode="PEL", build_trunk=False):
+        super().__init__()
+        self._setup(n_layers=n_layers, in_ch_list=in_ch_list, base_ch_list=base_ch_list, end_ch_list=end_ch_list,
+                    checkpoint_layers=checkpoint_layers, kernel_sizes=kernel_sizes, out_ch=out_ch,
+                    padding_list=padding_list, conv_strides=conv_strides, dropout=dropout, spatial_size=spatial_size,
+                    fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
+                    act_method=act_method, build_trunk=build_trunk)
+        self.pos_enc_dim, self.num_pos_heads, self.encodng_merge = pos_enc_dim, num_pos_heads, encodng_merge
+        self.res, self.mode, self.pos_hiddens = res, mode, pos_hiddens
+        self.p_act = torch.tanh if p_act == "tahn" else F.elu          # "tahn" [sic], reference models.py:1067
+        heads = [num_heads] * num_gat_layers + [num_out_heads]
+        pos_heads = [num_pos_heads] * (num_gat_layers + 1)
+        if mode == "PEL":
+            self.gat = GATPSPGNN(num_layers=num_gat_layers, in_dim=fv_dim, pos_in_dim=pos_enc_dim,
+                                 num_hiddens=num_hiddens, pos_hiddens=pos_hiddens, pos_heads=pos_heads,
+                                 out_ch=node_embed_dim, heads=heads, activation=F.elu, feat_drop=feat_drop,
+                                 attn_drop=attn_drop, negative_slope=negative_slope, residual=res, norm=norm,
+                                 p_activation=self.p_act)
+        elif mode == "PENL":
+            self.gat = GATPSPGNNNL(num_layers=num_gat_layers, in_dim=fv_dim, pos_in_dim=pos_enc_dim,
+                                   num_hiddens=num_hiddens, out_ch=node_embed_dim, heads=heads, activation=F.elu,
+                                   feat_drop=feat_drop, attn_drop=attn_drop, negative_slope=negative_slope,
+                                   residual=res, norm=norm)
+        else:
+            raise ValueError(f"unknown mode {mode!r} (PEL or PENL)")
+        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+
+    def forward(self, g):
+        n_embed, n_p_embed = self.gat(g)
+        return self.gnn_out(n_embed), n_embed, n_p_embed
+
+    def forward_emb(self, g):
+        return self.gat(g)
+
+
+def build_model(model_cfg: dict, **extra) -> nn.Module:
+    """``cls(**settings.MODEL)`` with the dotted ``method`` popped (reference job_runner.py:217-220);
+    class names that the reference's configs misspell are mapped to the evident intent
+    (``models.GATPositionLSPENet`` -> GATPositionSPGNNNet(mode="PENL"))."""
+    cfg = dict(model_cfg)
+    name = cfg.pop("method").split(".")[-1]
+    if name == "GATPositionLSPENet":
+        name, cfg = "GATPositionSPGNNNet", {**cfg, "mode": "PENL"}
+    cls = globals()[name]
+    return cls(**cfg, **extra)

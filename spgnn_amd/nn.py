@@ -1,0 +1,282 @@
+"""Drop-in graph-convolution layers with DGL's constructor signatures, forward signatures and
+state_dict keys, running on libspgnn_hip.so.
+
+These replace ``from dgl.nn.pytorch import GATConv, GraphConv, SAGEConv, GINConv``
+(reference models.py:8).  ``graph`` is a :class:`spgnn_amd.graph.TreeGraph`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import TreeGraph
+
+__all__ = ["GATConv", "GraphConv", "GINConv", "SAGEConv", "Identity", "DGLError"]
+
+
+class DGLError(Exception):
+    """Same role as dgl.DGLError (raised for 0-in-degree nodes / bad options)."""
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def _act_code(fn) -> Optional[int]:
+    """Map an activation callable to a fused epilogue code, or None if it must run in Python."""
+    if fn is None:
+        return ops.ACT_NONE
+    if fn in (F.elu,) or (isinstance(fn, nn.ELU) and fn.alpha == 1.0):
+        return ops.ACT_ELU
+    if fn in (torch.tanh, F.tanh) or isinstance(fn, nn.Tanh):
+        return ops.ACT_TANH
+    if fn in (F.relu, torch.relu) or isinstance(fn, nn.ReLU):
+        return ops.ACT_RELU
+    return None
+
+
+def _draw_seed() -> int:
+    # host-side draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class GATConv(nn.Module):
+    """dgl.nn.pytorch.GATConv (Appendix A.1). Parameters: ``fc.weight`` (H*D, F_in), ``attn_l``,
+    ``attn_r`` (1,H,D), ``res_fc.weight`` (H*D, F_in) when residual and F_in != D, ``bias`` (H*D,).
+
+    Reference call sites: models.py:301-314, 425-456, 506-521 (positional args
+    ``in_feats, out_feats, num_heads, feat_drop, attn_drop, negative_slope, residual, activation``).
+    """
+
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0., attn_drop=0., negative_slope=0.2,
+                 residual=False, activation=None, allow_zero_in_degree=False, bias=True):
+        super().__init__()
+        if isinstance(in_feats, (tuple, list)):
+            raise DGLError("bipartite (src, dst) feature sizes are not supported")
+        self._num_heads, self._in_src_feats, self._in_dst_feats, self._out_feats = num_heads, in_feats, in_feats, out_feats
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.negative_slope = negative_slope
+        self.leaky_relu = nn.LeakyReLU(negative_slope)
+        if residual:
+            if in_feats != out_feats:
+                self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=False)
+            else:
+                self.res_fc = Identity()
+        else:
+            self.register_buffer("res_fc", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(num_heads * out_feats))
+        else:
+            self.register_buffer("bias", None)
+        self.activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False):
+        csc = graph.csc(feat.device)
+        if not self._allow_zero_in_degree and csc.min_in_degree == 0:
+            raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                           "Add self-loops (g.add_edges(g.nodes(), g.nodes())) or set allow_zero_in_degree.")
+        H, D = self._num_heads, self._out_feats
+        h = self.feat_drop(feat)
+        has_res = isinstance(self.res_fc, nn.Linear)
+        identity_res = isinstance(self.res_fc, Identity)
+        act = _act_code(self.activation)
+        fuse_epilogue = act is not None and not identity_res
+        w_fc = self.fc.weight
+        w_cat = torch.cat([w_fc, self.res_fc.weight], dim=0) if has_res else w_fc
+        # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
+        w3 = w_fc.view(H, D, -1)
+        w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),
+                          torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
+        p = float(self.attn_drop.p) if self.training else 0.0
+        seed = _draw_seed() if p > 0.0 else 0
+        out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
+                                  float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed)
+        rst = out.view(-1, H, D)
+        if not fuse_epilogue:
+            if identity_res:
+                rst = rst + h.view(h.shape[0], -1, D)
+            if self.bias is not None:
+                rst = rst + self.bias.view(1, H, D)
+            if self.activation is not None:
+                rst = self.activation(rst)
+        if get_attention:
+            a = torch.empty_like(attn)
+            a[csc.eid.long()] = attn                   # CSC slot order -> edge id order
+            return rst, a.unsqueeze(-1)
+        return rst
+
+
+class GraphConv(nn.Module):
+    """dgl.nn.pytorch.GraphConv (Appendix A.2); reference models.py:172-182."""
+
+    def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None,
+                 allow_zero_in_degree=False):
+        super().__init__()
+        if norm not in ("none", "both", "right", "left"):
+            raise DGLError(f'Invalid norm value. Must be either "none", "both", "right" or "left". But got "{norm}".')
+        self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
+        self._allow_zero_in_degree = allow_zero_in_degree
+        if weight:
+            self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        else:
+            self.register_parameter("weight", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_feats))
+        else:
+            self.register_parameter("bias", None)
+        self._activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight is not None:
+            nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, weight=None):
+        csc = graph.csc(feat.device)
+        if not self._allow_zero_in_degree and csc.min_in_degree == 0:
+            raise DGLError("There are 0-in-degree nodes in the graph.")
+        if weight is not None and self.weight is not None:
+            raise DGLError("External weight is provided while at the same time the module has defined its own weight.")
+        weight = self.weight if weight is None else weight
+        w_src = w_dst = None
+        if self._norm in ("left", "both"):
+            d = csc.out_degrees_f().clamp(min=1)
+            w_src = d.pow(-0.5) if self._norm == "both" else 1.0 / d
+        if self._norm in ("right", "both"):
+            d = csc.in_degrees_f().clamp(min=1)
+            w_dst = d.pow(-0.5) if self._norm == "both" else 1.0 / d
+        if self._in_feats > self._out_feats:       # mult W first to reduce the aggregated width
+            if weight is not None:
+                feat = torch.matmul(feat, weight)
+            rst = ops.spmm_sum(csc, feat, w_src, w_dst)
+        else:
+            rst = ops.spmm_sum(csc, feat, w_src, w_dst)
+            if weight is not None:
+                rst = torch.matmul(rst, weight)
+        if self.bias is not None:
+            rst = rst + self.bias
+        if self._activation is not None:
+            rst = self._activation(rst)
+        return rst
+
+
+class GINConv(nn.Module):
+    """dgl.nn.pytorch.GINConv (Appendix A.3); reference models.py:358-383
+    (``GINConv(apply_func, "mean", learn_eps=True)``)."""
+
+    def __init__(self, apply_func=None, aggregator_type="sum", init_eps=0, learn_eps=False, activation=None):
+        super().__init__()
+        if aggregator_type not in ("sum", "max", "mean"):
+            raise KeyError(f"Aggregator type {aggregator_type} not recognized.")
+        self.apply_func = apply_func
+        self._aggregator_type = aggregator_type
+        self.activation = activation
+        if learn_eps:
+            self.eps = nn.Parameter(torch.FloatTensor([init_eps]))
+        else:
+            self.register_buffer("eps", torch.FloatTensor([init_eps]))
+
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None):
+        if edge_weight is not None:
+            raise DGLError("edge_weight is not supported")
+        csc = graph.csc(feat.device)
+        if self._aggregator_type == "max":
+            rst = (1 + self.eps) * feat + ops.spmm_max(csc, feat)
+        else:
+            w_dst = (1.0 / csc.in_degrees_f().clamp(min=1)) if self._aggregator_type == "mean" else None
+            rst = ops.spmm_sum(csc, feat, None, w_dst, self.eps)     # (1+eps)*x fused into the SpMM
+        if self.apply_func is not None:
+            rst = self.apply_func(rst)
+        if self.activation is not None:
+            rst = self.activation(rst)
+        return rst
+
+
+class SAGEConv(nn.Module):
+    """dgl.nn.pytorch.SAGEConv (Appendix A.4); reference models.py:668-679 (aggregator 'pool').
+
+    Parameter layout follows DGL 0.6: ``fc_pool`` / ``fc_self`` / ``fc_neigh`` Linear layers, the
+    latter two carrying the bias (``bias=True``).  A DGL >= 0.7 checkpoint (bias-free fc_self/fc_neigh
+    plus a separate ``bias``) loads through ``_load_from_state_dict`` below.
+    """
+
+    def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0., bias=True, norm=None, activation=None):
+        super().__init__()
+        if aggregator_type not in ("mean", "pool", "gcn"):
+            raise DGLError(f"Invalid aggregator_type {aggregator_type!r}: this build supports 'mean', 'pool', 'gcn'.")
+        self._in_src_feats = self._in_dst_feats = in_feats
+        self._out_feats, self._aggre_type = out_feats, aggregator_type
+        self.norm, self.feat_drop, self.activation = norm, nn.Dropout(feat_drop), activation
+        if aggregator_type == "pool":
+            self.fc_pool = nn.Linear(in_feats, in_feats)
+        if aggregator_type != "gcn":
+            self.fc_self = nn.Linear(in_feats, out_feats, bias=bias)
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        if self._aggre_type == "pool":
+            nn.init.xavier_uniform_(self.fc_pool.weight, gain=gain)
+        if self._aggre_type != "gcn":
+            nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "bias"                       # DGL >= 0.7 layout: fold the shared bias into fc_neigh
+        if key in state_dict and prefix + "fc_neigh.bias" not in state_dict:
+            b = state_dict.pop(key)
+            state_dict[prefix + "fc_neigh.bias"] = b
+            if hasattr(self, "fc_self") and prefix + "fc_self.bias" not in state_dict:
+                state_dict[prefix + "fc_self.bias"] = torch.zeros_like(b)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None):
+        if edge_weight is not None:
+            raise DGLError("edge_weight is not supported")
+        csc = graph.csc(feat.device)
+        h = self.feat_drop(feat)
+        if self._aggre_type == "pool":
+            neigh = ops.spmm_max(csc, F.relu(self.fc_pool(h)))
+            rst = self.fc_self(h) + self.fc_neigh(neigh)
+        elif self._aggre_type == "mean":
+            neigh = ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1))
+            rst = self.fc_self(h) + self.fc_neigh(neigh)
+        else:  # gcn: (sum_in x_u + x_v) / (deg + 1)
+            neigh = (ops.spmm_sum(csc, h) + h) / (csc.in_degrees_f().unsqueeze(-1) + 1)
+            rst = self.fc_neigh(neigh)
+        if self.activation is not None:
+            rst = self.activation(rst)
+        if self.norm is not None:
+            rst = self.norm(rst)
+        return rst

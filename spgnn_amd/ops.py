@@ -1,0 +1,242 @@
+"""Autograd operators over the C ABI (include/spgnn_hip.h).
+
+Everything here runs on the GPU through libspgnn_hip.so; there is no CPU implementation
+(CPU restatements live under oracle/ and are test infrastructure only).
+
+``gat_layer``      X -> fused [fc | res_fc] projection GEMM + score GEMM (rocBLAS via torch.mm)
+                   -> spgnn_gat_fwd; backward = spgnn_gat_bwd_dst + spgnn_gat_bwd_src writing
+                   straight into the GEMM-gradient buffers, then two GEMMs.
+``spmm_sum``       degree-normalised neighbour sum (GraphConv / GINConv).
+``spmm_max``       neighbour max with arg slots (SAGEConv 'pool').
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from .graph import DeviceCSC
+
+ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("spgnn_amd ops run only on a ROCm device (no CPU fallback); got a CPU tensor. "
+                               "Move the graph and features to 'cuda'.")
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+# raw launches (thin, shape-checked wrappers; used by the autograd functions and by tests)
+# --------------------------------------------------------------------------------------------
+def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: float, act: int, p_drop: float = 0.0,
+                seed: int = 0, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    _require_cuda(ft, el, er, res, bias)
+    N, E = csc.num_nodes, csc.num_edges
+    assert ft.shape[0] == N and ft.shape[1] == H * D and ft.stride(1) == 1
+    assert el.shape == (N, H) and er.shape == (N, H) and el.stride(0) == er.stride(0) and el.stride(1) == 1 == er.stride(1)
+    if res is not None:
+        assert res.shape == ft.shape and res.stride(1) == 1
+    if bias is not None:
+        assert bias.numel() == H * D and bias.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H * D), dtype=torch.float32, device=ft.device)
+    attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
+    lib = _capi.load()
+    with torch.cuda.device(ft.device):
+        _capi.check(lib.spgnn_gat_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+                                      el.data_ptr(), er.data_ptr(), el.stride(0), _ptr(res),
+                                      res.stride(0) if res is not None else 0, _ptr(bias), out.data_ptr(),
+                                      out.stride(0), attn.data_ptr(), N, E, H, D, slope, act, p_drop, seed,
+                                      _stream(ft)), "spgnn_gat_fwd")
+    return out, attn
+
+
+def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, slope: float, act: int,
+                p_drop: float, seed: int, g_pre: torch.Tensor, g_ft: torch.Tensor, g_el: torch.Tensor,
+                g_er: torch.Tensor) -> torch.Tensor:
+    """Runs both backward halves. g_pre/g_ft (N,H*D), g_el/g_er (N,H) are written in place
+    (may be strided views). Returns g_e (E,H) in CSC slot order."""
+    _require_cuda(ft, g_out)
+    N, E = csc.num_nodes, csc.num_edges
+    g_e = torch.empty((E, H), dtype=torch.float32, device=ft.device)
+    assert g_el.stride(0) == g_er.stride(0)
+    lib = _capi.load()
+    with torch.cuda.device(ft.device):
+        st = _stream(ft)
+        _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+                                          el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
+                                          g_out.data_ptr(), g_out.stride(0), _ptr(out),
+                                          out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
+                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), N, E, H, D, slope, act,
+                                          p_drop, seed, st), "spgnn_gat_bwd_dst")
+        _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                          csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                          g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
+                                          g_el.stride(0), N, E, H, D, p_drop, seed, st), "spgnn_gat_bwd_src")
+    return g_e
+
+
+# --------------------------------------------------------------------------------------------
+# GAT layer
+# --------------------------------------------------------------------------------------------
+class _GATLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_cat, w_lr, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
+                p_drop: float, seed: int):
+        HD = H * D
+        x = _rowmajor(x)
+        y = torch.mm(x, w_cat.t())                     # (N, HD [+HD])  = [ft | res]
+        s = torch.mm(x, w_lr.t())                      # (N, 2H)        = [el | er]
+        ft = y[:, :HD]
+        res = y[:, HD:] if has_res else None
+        out, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed)
+        ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        x, w_cat, w_lr, y, s, attn, out = ctx.saved_tensors
+        H, D, has_res, slope, act, p_drop, seed = ctx.cfg
+        csc = ctx.csc
+        HD = H * D
+        N = x.shape[0]
+        g_out = _rowmajor(g_out)
+        g_y = torch.empty_like(y)
+        g_s = torch.empty_like(s)
+        g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
+        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:])
+        g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        g_wcat = torch.mm(g_y.t(), x) if ctx.needs_input_grad[1] else None
+        g_wlr = torch.mm(g_s.t(), x) if ctx.needs_input_grad[2] else None
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.mm(g_y, w_cat)
+            g_x.addmm_(g_s, w_lr)
+        return g_x, g_wcat, g_wlr, g_bias, None, None, None, None, None, None, None, None
+
+
+def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: bool, slope: float, act: int,
+              p_drop: float = 0.0, seed: int = 0):
+    """out (N, H*D), attn (E, H; CSC slot order, not differentiable)."""
+    _require_cuda(x, w_cat, w_lr, bias)
+    return _GATLayerFn.apply(x, w_cat, w_lr, bias, csc, H, D, has_res, slope, act, p_drop, seed)
+
+
+# --------------------------------------------------------------------------------------------
+# SpMM sum / max
+# --------------------------------------------------------------------------------------------
+def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int) -> torch.Tensor:
+    _require_cuda(x, w_src, w_dst, eps)
+    F_ = x.shape[1]
+    out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
+                                       _ptr(w_dst), _ptr(eps), out.data_ptr(), out.stride(0), N, E, F_, _stream(x)),
+                    "spgnn_spmm_sum")
+    return out
+
+
+class _SpmmSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst):
+        x = _rowmajor(x)
+        out = spmm_sum_raw(csc.indptr, csc.indices, x, w_src, w_dst, eps, csc.num_nodes, csc.num_edges)
+        ctx.csc, ctx.w = csc, (w_src, w_dst)
+        ctx.save_for_backward(x if eps is not None else None, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, eps = ctx.saved_tensors
+        csc = ctx.csc
+        w_src, w_dst = ctx.w
+        g_out = _rowmajor(g_out)
+        g_x = g_eps = None
+        if ctx.needs_input_grad[0]:   # transpose: swap the roles of the two scalings
+            g_x = spmm_sum_raw(csc.out_indptr, csc.out_indices, g_out, w_dst, w_src, eps, csc.num_nodes, csc.num_edges)
+        if eps is not None and ctx.needs_input_grad[1]:
+            g_eps = (g_out * x).sum().reshape(eps.shape)
+        return g_x, g_eps, None, None, None
+
+
+def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None) -> torch.Tensor:
+    """out[v] = (1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u]."""
+    _require_cuda(x)
+    return _SpmmSumFn.apply(x, eps, csc, w_src, w_dst)
+
+
+class _SpmmMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, csc: DeviceCSC):
+        x = _rowmajor(x)
+        N, E, F_ = csc.num_nodes, csc.num_edges, x.shape[1]
+        out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
+        arg = torch.empty((N, F_), dtype=torch.int32, device=x.device)
+        lib = _capi.load()
+        with torch.cuda.device(x.device):
+            _capi.check(lib.spgnn_spmm_max_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                               out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
+                                               _stream(x)), "spgnn_spmm_max_fwd")
+        ctx.csc = csc
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (arg,) = ctx.saved_tensors
+        csc = ctx.csc
+        g_out = _rowmajor(g_out)
+        N, E, F_ = csc.num_nodes, csc.num_edges, g_out.shape[1]
+        g_x = torch.empty((N, F_), dtype=torch.float32, device=g_out.device)
+        lib = _capi.load()
+        with torch.cuda.device(g_out.device):
+            _capi.check(lib.spgnn_spmm_max_bwd(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                               csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0),
+                                               arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,
+                                               _stream(g_out)), "spgnn_spmm_max_bwd")
+        return g_x, None
+
+
+def spmm_max(csc: DeviceCSC, x) -> torch.Tensor:
+    _require_cuda(x)
+    return _SpmmMaxFn.apply(x, csc)
+
+
+# --------------------------------------------------------------------------------------------
+# optimizer step over a flat bucket
+# --------------------------------------------------------------------------------------------
+def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float,
+                       weight_decay: float = 0.0, first_step: bool = False,
+                       grad_scale: Optional[torch.Tensor] = None) -> None:
+    _require_cuda(param, grad, buf, grad_scale)
+    assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
+    assert param.dtype == grad.dtype == buf.dtype == torch.float32 and param.numel() == grad.numel() == buf.numel()
+    lib = _capi.load()
+    with torch.cuda.device(param.device):
+        _capi.check(lib.spgnn_sgd_momentum_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), _ptr(grad_scale),
+                                                param.numel(), lr, momentum, weight_decay, int(first_step),
+                                                _stream(param)), "spgnn_sgd_momentum_step")

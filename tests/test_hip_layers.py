@@ -1,0 +1,224 @@
+"""HIP kernels vs the CPU oracle, layer level, through the C ABI (spgnn_amd.nn -> ops -> ctypes).
+Tolerance: 1e-5 normwise relative on forward outputs in fp32 (BASELINE.json north_star); gradients
+5e-5 (same arithmetic, longer reduction chains)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dgl_cpu as O
+from spgnn_amd import nn as snn
+from spgnn_amd import ops
+from spgnn_amd.graph import TreeGraph
+from tests.util import keep_scale_host, rel_err, tree_batch_edges
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 1e-5, 5e-5
+
+
+def _graph(ns, seed=0):
+    s, d, n = tree_batch_edges(ns, seed)
+    return TreeGraph((s, d), n).to("cuda"), torch.from_numpy(s), torch.from_numpy(d), n
+
+
+def _oracle_gat(layer, src, dst, n, x, act, dtype=torch.float32, attn_keep=None):
+    sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in layer.state_dict().items()}
+    xo = x.detach().cpu().to(dtype).requires_grad_(True)
+    rst, a = O.gat_conv(src, dst, n, xo, sd["fc.weight"], sd["attn_l"], sd["attn_r"], sd.get("res_fc.weight"),
+                        sd.get("bias"), layer.negative_slope, act, attn_keep)
+    return rst, a, xo, sd
+
+
+# every GATConv shape of the configs + head sweep + odd shapes (scalar fallback)
+GAT_CASES = [
+    (1063, 2, 256, True, F.elu), (39, 1, 256, True, torch.tanh), (768, 2, 128, True, F.elu),
+    (256, 1, 128, True, torch.tanh), (384, 2, 64, True, F.elu), (128, 1, 64, True, torch.tanh),
+    (192, 2, 1024, True, F.elu), (1024, 2, 256, True, F.elu), (128, 2, 1024, True, None),
+    (512, 2, 128, False, F.elu), (64, 8, 64, True, F.elu), (48, 8, 256, False, None), (40, 4, 16, True, F.relu),
+    (7, 3, 5, True, F.elu), (9, 1, 6, False, None), (20, 2, 12, True, torch.tanh), (33, 1, 1024, True, None),
+    (16, 4, 8, True, None), (16, 1, 4, False, F.elu), (24, 2, 512, True, F.elu),
+]
+
+
+@pytest.mark.parametrize("fin,H,D,res,act", GAT_CASES)
+def test_gatconv_forward_backward(fin, H, D, res, act):
+    torch.manual_seed(fin * 7 + H * 3 + D)
+    g, src, dst, n = _graph([23, 150, 1, 64], seed=fin)
+    layer = snn.GATConv(fin, D, H, 0.0, 0.0, 0.2, res, act).cuda()
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    x = torch.randn(n, fin, device="cuda").clamp_(min=-0.5).requires_grad_(True)
+    out, attn = layer(g, x, get_attention=True)
+    ref, a_ref, xo, sd = _oracle_gat(layer, src, dst, n, x, act)
+    assert out.shape == (n, H, D)
+    assert rel_err(out, ref) < FWD_TOL
+    assert rel_err(attn.squeeze(-1), a_ref) < FWD_TOL            # attention returned in edge-id order
+    cot = torch.randn(n, H, D)
+    (out * cot.cuda()).sum().backward()
+    (ref * cot).sum().backward()
+    assert rel_err(x.grad, xo.grad) < GRAD_TOL
+    for name, p in layer.named_parameters():
+        assert rel_err(p.grad, sd[name].grad) < GRAD_TOL, name
+    # the fp32 HIP path should sit as close to an fp64 evaluation as the fp32 CPU oracle does (x4 slack)
+    ref64 = _oracle_gat(layer, src, dst, n, x, act, torch.float64)[0]
+    assert rel_err(out, ref64) < max(4 * rel_err(ref, ref64), 2e-6)
+
+
+def test_gatconv_high_degree_and_no_self_loops():
+    """Star graph with 70 children (degree loops far beyond the airway 2..5) and a ring without
+    self loops (non-symmetric in/out lists)."""
+    torch.manual_seed(0)
+    n = 71
+    s = np.concatenate([np.zeros(70, np.int64), np.arange(1, 71), np.arange(71)])
+    d = np.concatenate([np.arange(1, 71), np.zeros(70, np.int64), np.arange(71)])
+    ring_s = np.arange(10, dtype=np.int64) + n
+    ring_d = (np.arange(10, dtype=np.int64) + 1) % 10 + n
+    s, d = np.concatenate([s, ring_s, ring_s]), np.concatenate([d, ring_d, (ring_d - n + 1) % 10 + n])
+    n += 10
+    g = TreeGraph((s, d), n).to("cuda")
+    for fin, H, D in [(12, 2, 64), (12, 2, 256), (5, 3, 7)]:
+        layer = snn.GATConv(fin, D, H, 0.0, 0.0, 0.2, True, F.elu).cuda()
+        x = torch.randn(n, fin, device="cuda", requires_grad=True)
+        out = layer(g, x)
+        ref, _, xo, sd = _oracle_gat(layer, torch.from_numpy(s), torch.from_numpy(d), n, x, F.elu)
+        assert rel_err(out, ref) < FWD_TOL
+        out.pow(2).sum().backward(); ref.pow(2).sum().backward()
+        assert rel_err(x.grad, xo.grad) < GRAD_TOL
+        for name, p in layer.named_parameters():
+            assert rel_err(p.grad, sd[name].grad) < GRAD_TOL, name
+
+
+def test_gatconv_edge_cases():
+    layer = snn.GATConv(8, 4, 2).cuda()
+    g0 = TreeGraph((np.array([0, 1]), np.array([1, 1])), 3).to("cuda")       # nodes 0 and 2 have no in-edge
+    with pytest.raises(snn.DGLError):
+        layer(g0, torch.zeros(3, 8, device="cuda"))
+    layer.set_allow_zero_in_degree(True)
+    out = layer(g0, torch.randn(3, 8, device="cuda"))
+    assert torch.equal(out[0], layer.bias.view(2, 4)) and torch.isfinite(out).all()   # empty sum + bias
+    g1 = TreeGraph((np.array([0]), np.array([0])), 1).to("cuda")              # single node, self loop
+    x = torch.randn(1, 8, device="cuda")
+    assert rel_err(layer(g1, x), layer.fc(x).view(1, 2, 4) + layer.bias.view(1, 2, 4)) < FWD_TOL
+    ge = TreeGraph(None, 0).to("cuda")                                        # empty graph
+    assert layer(ge, torch.zeros(0, 8, device="cuda")).shape == (0, 2, 4)
+    with pytest.raises(RuntimeError):                                         # no CPU fallback
+        layer(TreeGraph((np.array([0]), np.array([0])), 1), torch.randn(1, 8))
+    # identity residual (in_feats == out_feats): broadcast over heads, DGL 0.6-0.8 semantics
+    idl = snn.GATConv(4, 4, 3, residual=True, activation=F.elu).cuda()
+    assert isinstance(idl.res_fc, snn.Identity)
+    s, d, n = tree_batch_edges([9], 1)
+    g = TreeGraph((s, d), n).to("cuda")
+    x = torch.randn(n, 4, device="cuda")
+    sd = {k: v.cpu() for k, v in idl.state_dict().items()}
+    ref = O.gat_conv(torch.from_numpy(s), torch.from_numpy(d), n, x.cpu(), sd["fc.weight"], sd["attn_l"], sd["attn_r"],
+                     None, sd["bias"], 0.2, F.elu, residual_identity=True)[0]
+    assert rel_err(idl(g, x), ref) < FWD_TOL
+
+
+def test_attention_dropout_matches_oracle_with_same_mask(monkeypatch):
+    """attn_drop > 0: the kernel's counter-based mask is reproduced on the host and fed to the
+    oracle; forward and every gradient must then agree, and the keep rate must be ~1-p."""
+    torch.manual_seed(3)
+    g, src, dst, n = _graph([150, 140, 160], seed=9)
+    H, D, fin, p, seed = 2, 128, 96, 0.1, 123456789
+    csc = g.csc()
+    layer = snn.GATConv(fin, D, H, 0.0, p, 0.2, True, F.elu).cuda().train()
+    monkeypatch.setattr(snn, "_draw_seed", lambda: seed)
+    x = torch.randn(n, fin, device="cuda", requires_grad=True)
+    out = layer(g, x)
+    E = csc.num_edges
+    keep_slot = keep_scale_host(seed, np.arange(E * H), p).reshape(E, H)      # CSC slot order
+    keep_edge = np.empty_like(keep_slot); keep_edge[csc.eid.cpu().numpy()] = keep_slot
+    assert abs((keep_slot > 0).mean() - (1 - p)) < 0.01
+    ref, _, xo, sd = _oracle_gat(layer, src, dst, n, x, F.elu, attn_keep=torch.from_numpy(keep_edge))
+    assert rel_err(out, ref) < FWD_TOL
+    out.pow(2).sum().backward(); ref.pow(2).sum().backward()
+    assert rel_err(x.grad, xo.grad) < GRAD_TOL
+    for name, prm in layer.named_parameters():
+        assert rel_err(prm.grad, sd[name].grad) < GRAD_TOL, name
+    monkeypatch.undo()
+    # fresh seeds per call in train mode -> different masks; eval mode -> no dropout, deterministic
+    a = layer(g, x.detach()); b = layer(g, x.detach())
+    assert not torch.equal(a, b)
+    layer.eval(); c = layer(g, x.detach()); d = layer(g, x.detach())
+    assert torch.equal(c, d)
+
+
+SPMM_F = [64, 128, 256, 1024, 22, 7, 192]
+
+
+@pytest.mark.parametrize("F_", SPMM_F)
+def test_spmm_sum_and_max_vs_oracle(F_):
+    torch.manual_seed(F_)
+    g, src, dst, n = _graph([150, 33, 1, 90], seed=F_)
+    csc = g.csc()
+    x = torch.randn(n, F_, device="cuda", requires_grad=True)
+    xo = x.detach().cpu().requires_grad_(True)
+    ws, wd = csc.out_degrees_f().pow(-0.5), csc.in_degrees_f().pow(-0.5)
+    eps = torch.tensor([0.25], device="cuda", requires_grad=True)
+    epo = eps.detach().cpu().requires_grad_(True)
+    out = ops.spmm_sum(csc, x, ws, wd, eps)
+    ref = (1 + epo) * xo + O.spmm_sum(src, dst, xo * ws.cpu().unsqueeze(1), n) * wd.cpu().unsqueeze(1)
+    assert rel_err(out, ref) < FWD_TOL
+    cot = torch.randn(n, F_)
+    (out * cot.cuda()).sum().backward(); (ref * cot).sum().backward()
+    assert rel_err(x.grad, xo.grad) < GRAD_TOL and rel_err(eps.grad, epo.grad) < GRAD_TOL
+    x.grad = None; xo.grad = None
+    outm = ops.spmm_max(csc, x); refm = O.spmm_max(src, dst, xo, n)
+    assert torch.equal(outm.cpu(), refm.detach())                                # max is exact
+    (outm * cot.cuda()).sum().backward(); (refm * cot).sum().backward()
+    assert rel_err(x.grad, xo.grad) < GRAD_TOL
+
+
+def test_spmm_max_ties_go_to_one_edge():
+    g, src, dst, n = _graph([40], seed=2)
+    x = torch.ones(n, 64, device="cuda", requires_grad=True)                     # every in-edge ties
+    ops.spmm_max(g.csc(), x).sum().backward()
+    assert torch.equal(x.grad.sum(0).cpu(), torch.full((64,), float(n)))        # each dst routes its grad once
+
+
+@pytest.mark.parametrize("fi,fo", [(1024, 256), (64, 1024), (10, 10), (24, 7)])
+def test_graphconv_gin_sage_modules(fi, fo):
+    torch.manual_seed(fi + fo)
+    g, src, dst, n = _graph([60, 150, 21], seed=fi)
+    x = torch.randn(n, fi, device="cuda")
+    gc = snn.GraphConv(fi, fo, activation=F.elu).cuda()
+    with torch.no_grad():
+        gc.bias.normal_(0, 0.1)
+    sd = {k: v.cpu() for k, v in gc.state_dict().items()}
+    assert rel_err(gc(g, x), O.graph_conv(src, dst, n, x.cpu(), sd["weight"], sd["bias"], F.elu)) < FWD_TOL
+    mlp = torch.nn.Sequential(torch.nn.Linear(fi, fo), torch.nn.LeakyReLU()).cuda()
+    gin = snn.GINConv(mlp, "mean", learn_eps=True).cuda()
+    with torch.no_grad():
+        gin.eps.fill_(0.3)
+    ref = O.gin_conv(src, dst, n, x.cpu(), gin.eps.detach().cpu(), mlp.cpu(), "mean")
+    mlp.cuda()
+    assert rel_err(gin(g, x), ref) < FWD_TOL
+    sg = snn.SAGEConv(fi, fo, "pool", activation=F.elu).cuda()
+    sd = {k: v.cpu() for k, v in sg.state_dict().items()}
+    ref = O.sage_conv_pool(src, dst, n, x.cpu(), sd["fc_pool.weight"], sd["fc_pool.bias"], sd["fc_self.weight"],
+                           sd["fc_self.bias"], sd["fc_neigh.weight"], sd["fc_neigh.bias"], None, F.elu)
+    assert rel_err(sg(g, x), ref) < FWD_TOL
+
+
+def test_sgd_momentum_step_matches_torch():
+    torch.manual_seed(0)
+    p = torch.randn(100003, device="cuda"); ref = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    buf = torch.zeros_like(p)
+    scale = torch.tensor([0.5], device="cuda")
+    for step in range(4):
+        gr = torch.randn_like(p)
+        ref.grad = gr * 0.5
+        opt.step()
+        ops.sgd_momentum_step_(p, gr, buf, 0.05, 0.9, 1e-4, first_step=(step == 0), grad_scale=scale)
+        assert rel_err(p, ref) < 1e-6
+
+
+def test_c_abi_argument_errors_are_reported():
+    from spgnn_amd import _capi
+    lib = _capi.load()
+    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 2, 4, 0.2, 0, 0.0, 0, 0) == -1   # null pointers
+    assert b"null" in lib.spgnn_last_error()
+    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0) == -2  # bad shape
+    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op

@@ -1,0 +1,152 @@
+"""Pins the oracle (oracle/dgl_cpu.py): two independent formulations agree in fp64 on forward,
+attention and every gradient; hand-derivable known answers hold.  The reference has no tests or
+golden vectors for this path, so this is what pins the oracle ("parity unpinned")."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dense, dgl_cpu as O
+from spgnn_amd import synthetic
+from spgnn_amd.graph import edges_from_adj
+
+
+def _batch_edges(ns, seed=0):
+    rng = np.random.default_rng(seed)
+    srcs, dsts, off = [], [], 0
+    for n in ns:
+        u, v = edges_from_adj(synthetic.random_tree_adj(n, rng))
+        srcs.append(u + off); dsts.append(v + off); off += n
+    return torch.from_numpy(np.concatenate(srcs)), torch.from_numpy(np.concatenate(dsts)), off
+
+
+def _leaf(shape, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen, dtype=torch.float64) * scale).requires_grad_(True)
+
+
+@pytest.mark.parametrize("H,D,res", [(2, 8, True), (1, 4, True), (3, 5, False)])
+def test_gat_edge_list_vs_dense_fp64(H, D, res):
+    src, dst, n = _batch_edges([6, 9], seed=1)
+    gen = torch.Generator().manual_seed(0)
+    fin = 7
+    params = dict(x=_leaf((n, fin), gen), w=_leaf((H * D, fin), gen, 0.5), al=_leaf((1, H, D), gen),
+                  ar=_leaf((1, H, D), gen), wr=_leaf((H * D, fin), gen, 0.5) if res else None, b=_leaf((H * D,), gen))
+    mask = dense.dense_mask(src, dst, n, torch.float64)
+    for act in (None, F.elu, torch.tanh):
+        r1, a1 = O.gat_conv(src, dst, n, params["x"], params["w"], params["al"], params["ar"], params["wr"],
+                            params["b"], 0.2, act)
+        r2, a2 = dense.gat_conv_dense(mask, params["x"], params["w"], params["al"], params["ar"], params["wr"],
+                                      params["b"], 0.2, act)
+        assert torch.allclose(r1, r2, atol=1e-12, rtol=0)
+        assert torch.allclose(a1, a2[dst, src], atol=1e-13, rtol=0)     # attention per edge
+        cot = torch.randn(r1.shape, generator=gen, dtype=torch.float64)
+        leaves = [p for p in params.values() if p is not None]
+        g1 = torch.autograd.grad((r1 * cot).sum(), leaves)
+        g2 = torch.autograd.grad((r2 * cot).sum(), leaves)
+        for a, b in zip(g1, g2):
+            assert torch.allclose(a, b, atol=1e-11, rtol=0)
+
+
+def test_gcn_gin_sage_edge_list_vs_dense_fp64():
+    src, dst, n = _batch_edges([5, 8, 4], seed=2)
+    gen = torch.Generator().manual_seed(1)
+    mask = dense.dense_mask(src, dst, n, torch.float64)
+    x = _leaf((n, 6), gen)
+    for f_out in (3, 9):   # F_in > F_out (matmul first) and F_in < F_out (aggregate first)
+        w, b = _leaf((6, f_out), gen), _leaf((f_out,), gen)
+        r1 = O.graph_conv(src, dst, n, x, w, b, F.elu)
+        r2 = dense.graph_conv_dense(mask, x, w, b, F.elu)
+        assert torch.allclose(r1, r2, atol=1e-12)
+        for a, c in zip(torch.autograd.grad(r1.sum(), [x, w, b]), torch.autograd.grad(r2.sum(), [x, w, b])):
+            assert torch.allclose(a, c, atol=1e-11)
+    eps = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    r1 = O.gin_conv(src, dst, n, x, eps, None, "mean")
+    r2 = dense.gin_conv_dense(mask, x, eps)
+    assert torch.allclose(r1, r2, atol=1e-12)
+    for a, c in zip(torch.autograd.grad(r1.pow(2).sum(), [x, eps]), torch.autograd.grad(r2.pow(2).sum(), [x, eps])):
+        assert torch.allclose(a, c, atol=1e-11)
+    wp, bp = _leaf((6, 6), gen), _leaf((6,), gen)
+    ws, bs, wn, bn = _leaf((4, 6), gen), _leaf((4,), gen), _leaf((4, 6), gen), _leaf((4,), gen)
+    r1 = O.sage_conv_pool(src, dst, n, x, wp, bp, ws, bs, wn, bn, None, F.elu)
+    r2 = dense.sage_conv_pool_dense(mask, x, wp, bp, ws, bs, wn, bn, None, F.elu)
+    assert torch.allclose(r1, r2, atol=1e-12)
+    leaves = [x, wp, bp, ws, bs, wn, bn]
+    for a, c in zip(torch.autograd.grad(r1.pow(2).sum(), leaves), torch.autograd.grad(r2.pow(2).sum(), leaves)):
+        assert torch.allclose(a, c, atol=1e-11)
+
+
+# ---- hand-derivable known answers ------------------------------------------------
+def _path3():
+    adj = np.array([[1, 1, 0], [1, 1, 1], [0, 1, 1]], dtype=np.uint8)
+    u, v = edges_from_adj(adj)
+    return torch.from_numpy(u), torch.from_numpy(v), 3
+
+
+def test_known_answer_gat_constant_features():
+    """Identical node features => every ft row equal => softmax weights sum to 1 => rst == ft,
+    and attention is uniform 1/in_degree (P3 + self loops: in-degrees 2, 3, 2)."""
+    src, dst, n = _path3()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.ones(n, 5, dtype=torch.float64) * torch.randn(1, 5, generator=gen, dtype=torch.float64)
+    w = torch.randn(6, 5, generator=gen, dtype=torch.float64)
+    al, ar = torch.randn(1, 2, 3, generator=gen, dtype=torch.float64), torch.randn(1, 2, 3, generator=gen, dtype=torch.float64)
+    rst, a = O.gat_conv(src, dst, n, x, w, al, ar)
+    assert torch.allclose(rst, (x @ w.t()).view(n, 2, 3), atol=1e-13)
+    deg = torch.tensor([2.0, 3.0, 2.0], dtype=torch.float64)
+    assert torch.allclose(a, (1.0 / deg)[dst].unsqueeze(1).expand(-1, 2), atol=1e-13)
+
+
+def test_known_answer_gcn_path3():
+    """GCN, W = I, b = 0 on P3+loops: out[v] = sum_u x[u] / sqrt(d_u d_v), d = (2, 3, 2)."""
+    src, dst, n = _path3()
+    x = torch.tensor([[1.0], [10.0], [100.0]], dtype=torch.float64)
+    out = O.graph_conv(src, dst, n, x, torch.eye(1, dtype=torch.float64), None)
+    d = [2.0, 3.0, 2.0]
+    exp = [1 / 2 + 10 / np.sqrt(6), 1 / np.sqrt(6) + 10 / 3 + 100 / np.sqrt(6), 10 / np.sqrt(6) + 100 / 2]
+    assert torch.allclose(out.flatten(), torch.tensor(exp, dtype=torch.float64), atol=1e-13)
+
+
+def test_known_answer_gin_mean_constant():
+    """GIN mean, eps = 0, constant x: (1+0)*x + mean(x) = 2x."""
+    src, dst, n = _path3()
+    x = torch.full((n, 4), 1.5, dtype=torch.float64)
+    out = O.gin_conv(src, dst, n, x, torch.zeros(1, dtype=torch.float64), None, "mean")
+    assert torch.allclose(out, 2 * x, atol=1e-14)
+
+
+def test_known_answer_sage_pool_max_of_relu():
+    src, dst, n = _path3()
+    x = torch.tensor([[-1.0, 2.0], [3.0, -4.0], [0.5, 0.25]], dtype=torch.float64)
+    eye, z = torch.eye(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+    out = O.sage_conv_pool(src, dst, n, x, eye, z, torch.zeros(2, 2, dtype=torch.float64), None, eye, None)
+    exp = torch.tensor([[3.0, 2.0], [3.0, 2.0], [3.0, 0.25]], dtype=torch.float64)   # max over in-nbrs of relu(x)
+    assert torch.allclose(out, exp, atol=1e-14)
+
+
+def test_edge_permutation_invariance():
+    """Reordering the edge list leaves outputs unchanged up to fp summation order."""
+    src, dst, n = _batch_edges([12, 7], seed=4)
+    gen = torch.Generator().manual_seed(5)
+    x, w = torch.randn(n, 6, generator=gen), torch.randn(8, 6, generator=gen)
+    al, ar = torch.randn(1, 2, 4, generator=gen), torch.randn(1, 2, 4, generator=gen)
+    perm = torch.randperm(src.shape[0], generator=gen)
+    r1, _ = O.gat_conv(src, dst, n, x, w, al, ar)
+    r2, _ = O.gat_conv(src[perm], dst[perm], n, x, w, al, ar)
+    assert torch.allclose(r1, r2, atol=1e-5, rtol=1e-5)
+
+
+def test_batching_equals_concatenation():
+    """dgl.batch semantics: running B trees as one block-diagonal graph == running each alone."""
+    gen = torch.Generator().manual_seed(6)
+    w = torch.randn(8, 5, generator=gen, dtype=torch.float64)
+    al, ar = (torch.randn(1, 2, 4, generator=gen, dtype=torch.float64) for _ in range(2))
+    rng = np.random.default_rng(7)
+    outs, srcs, dsts, xs, off = [], [], [], [], 0
+    for n in (5, 9, 6):
+        u, v = edges_from_adj(synthetic.random_tree_adj(n, rng))
+        u, v = torch.from_numpy(u), torch.from_numpy(v)
+        x = torch.randn(n, 5, generator=gen, dtype=torch.float64)
+        outs.append(O.gat_conv(u, v, n, x, w, al, ar)[0])
+        srcs.append(u + off); dsts.append(v + off); xs.append(x); off += n
+    big = O.gat_conv(torch.cat(srcs), torch.cat(dsts), off, torch.cat(xs), w, al, ar)[0]
+    assert torch.allclose(big, torch.cat(outs), atol=1e-13)

@@ -1,0 +1,34 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import torch
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """Normwise relative error max|a-b| / max|b| (the 1e-5 bar of BASELINE.json.north_star)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    denom = b.abs().max().item()
+    return (a - b).abs().max().item() / (denom if denom > 0 else 1.0)
+
+
+def keep_scale_host(seed: int, idx: np.ndarray, p: float) -> np.ndarray:
+    """Bit-exact host copy of the kernels' counter-based attention-dropout mask
+    (spgnn_kernels.hip keep_scale): returns 1/(1-p) where kept, 0 where dropped."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1))) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
+
+
+def tree_batch_edges(ns, seed=0):
+    from spgnn_amd import synthetic
+    from spgnn_amd.graph import edges_from_adj
+    rng = np.random.default_rng(seed)
+    srcs, dsts, off = [], [], 0
+    for n in ns:
+        u, v = edges_from_adj(synthetic.random_tree_adj(n, rng))
+        srcs.append(u + off); dsts.append(v + off); off += n
+    return np.concatenate(srcs), np.concatenate(dsts), off
