@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — message-passing edges/sec (fwd+bwd) of the GNN training step on N MI355X.
+
+One "step" = one optimizer step on one static batched graph of synthetic random-fan-out trees
+(SURVEY.md Appendix D): Bernoulli node mask -> model forward -> class-weighted CE -> backward ->
+[RCCL all-reduce of the flat gradient bucket] -> fused SGD(momentum).  Nothing is skipped inside
+the timed region.  Default workload: st_pgat_spgnn_3 (full SPGNN + LSPE position stream), 512 trees
+per GPU, fp32, dropout on — the configuration BASELINE.json's north_star quotes its target on; with
+N GPUs every rank gets its own 512 trees (weak scaling, global batch 512*N).
+
+Single GPU:  python bench.py [--steps K --warmup W]
+Multi GPU:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                 --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+"roofline" for the dominant hand-written kernel (algorithmic bytes per launch / mean launch time
+from HIP events recorded on the launch stream during the timed region) and "cpu_baseline" (the
+DGL-CPU-equivalent restatement under oracle/, timed on this host's cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(key) -> float:
+    """Algorithmic HBM bytes of ONE launch (SURVEY.md §8d per-unit figures, fp32):
+    every operand row read once, every result row written once, index arrays once."""
+    name = key[0]
+    if name == "gat_fwd":            # read ft [+res], write out; read el, er; write a; read CSC
+        _, N, E, H, D, has_res = key
+        return 4 * (2 + has_res) * N * H * D + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
+    if name == "gat_bwd_dst":        # read g_out [,out], ft; write g_pre; read el, er, a; write g_e, g_er; CSC
+        _, N, E, H, D, act = key
+        return 4 * (3 + (1 if act else 0)) * N * H * D + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
+    if name == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
+        _, N, E, H, D = key
+        return 4 * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+    if name == "spmm_sum":
+        _, N, E, F = key
+        return 4 * 2 * N * F + 4 * (N + 1 + E)
+    if name == "spmm_max_fwd":
+        _, N, E, F = key
+        return 4 * 3 * N * F + 4 * (N + 1 + E)
+    if name == "spmm_max_bwd":
+        _, N, E, F = key
+        return 4 * 3 * N * F + 4 * (N + 1 + 2 * E)
+    raise KeyError(name)
+
+
+def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=2):
+    """DGL-CPU-equivalent (restated) fwd+bwd on the host cores: oracle/dgl_cpu.py, same weights, first
+    ``n_trees`` trees of rank 0's batch, eval-mode arithmetic (no dropout), all host threads."""
+    from oracle import dgl_cpu as O
+    from spgnn_amd import synthetic
+    from spgnn_amd.configs import class_weight_list
+    import torch.nn.functional as F
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = synthetic.batch_from_samples(samples[:n_trees], "cpu", cfg.POS_ENC_DIM)
+    src, dst = g.edges()
+    n, E = g.number_of_nodes(), g.number_of_edges()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(n) < torch.where(y != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
+    times = []
+    for i in range(warm + steps):
+        t0 = time.perf_counter()
+        out = O.net_forward(cfg.KIND, sd, src, dst, n, g.ndata["fvs"], g.ndata.get("pos_enc"))[0]
+        loss = O.masked_weighted_ce(out, y, mask, w)
+        grads = torch.autograd.grad(loss, [p for p in sd.values() if p.requires_grad], allow_unused=True)
+        del grads
+        if i >= warm:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": E * cfg.CONV_LAYERS / med, "unit": "layer-edges/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fwd+bwd, median of {steps} "
+                      f"after {warm} warm-ups, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="st_pgat_spgnn_3")
+    ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
+    ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-trees", type=int, default=32)
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the message-passing path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    from spgnn_amd import _capi, models, ops, synthetic
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    _capi.load()                                              # fail loudly if the HIP library is missing
+
+    cfg = get_config(args.config)
+    torch.manual_seed(0)                                      # identical replicas on every rank
+    model = models.build_model(cfg.MODEL).to(dev)
+    model.init(None)
+    model.set_gcn_only()
+    model.train(not args.no_dropout)
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+    samples = synthetic.synthetic_trees(args.trees, rank=rank)
+    g = synthetic.batch_from_samples(samples, dev, cfg.POS_ENC_DIM)
+    g.csc(dev)                                                # CSC/CSR built once per loader batch (static for all steps)
+    N, E = g.number_of_nodes(), g.number_of_edges()
+    step = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, cfg.OPTIMIZER["lr"],
+                     cfg.OPTIMIZER["momentum"], seed=1234 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step.step(g)
+    sync()
+    if not args.no_kernel_timers:
+        ops.KernelTimer.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step.step(g)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kt = ops.KernelTimer.stop() if not args.no_kernel_timers else {}
+    loss_val = float(loss)
+
+    tot = torch.tensor([elapsed, float(E), float(N)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, E_all, N_all = float(mx[0]), float(sm[1]), float(sm[2])
+    else:
+        E_all, N_all = float(E), float(N)
+
+    if rank == 0:
+        L = cfg.CONV_LAYERS
+        ms = elapsed / args.steps * 1e3
+        value = E_all * L * args.steps / elapsed
+        out = {
+            "metric": "message-passing edges/sec (fwd+bwd), batched trees", "value": value, "unit": "layer-edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config} training step (fwd+loss+bwd+allreduce+SGD), {args.trees} trees/GPU, "
+                                   f"random fan-out trees n~U[120,180], fp32, dropout {'off' if args.no_dropout else 'on'}",
+                       "trees_per_gpu": args.trees, "global_trees": args.trees * world, "nodes": int(N_all),
+                       "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
+                       "parallelism": f"dp{world}", "gemm": "fp32 (rocBLAS/hipBLASLt via torch.mm)"},
+            "graph_edges_per_s": E_all * args.steps / elapsed, "loss": loss_val,
+        }
+        if kt:
+            agg = {k: (sum(v) / len(v), sum(v), len(v)) for k, v in kt.items()}
+            mp_ms = sum(t for _, t, _ in agg.values()) / args.steps
+            dom = max(agg, key=lambda k: agg[k][1])
+            avg_ms = agg[dom][0]
+            bytes_alg = algorithmic_bytes(dom)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("_".join(str(x) for x in dom))
+                except Exception:
+                    traffic = None
+            ach = bytes_alg / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom[0], "shape": list(dom[1:]), "achieved": ach,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                               "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg,
+                               "avg_launch_ms": avg_ms, "launches": agg[dom][2]}
+            mp_bytes = sum(algorithmic_bytes(k) * n for k, (_, _, n) in agg.items()) / args.steps
+            out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
+                                      "algorithmic_GB_per_step": mp_bytes / 1e9,
+                                      "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9,
+                                      "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3),
+                                      "per_kernel_ms": {"_".join(str(x) for x in k): round(a, 5) for k, (a, _, _) in sorted(agg.items())}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,44 @@ from .graph import DeviceCSC
 ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the message-passing kernels (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    enabled = False
+    records: dict = {}
+
+    @classmethod
+    def start(cls):
+        cls.records, cls.enabled = {}, True
+
+    @classmethod
+    def stop(cls):
+        """-> {(kernel, shape): [ms, ...]} after synchronising."""
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in cls.records.items()}
+        cls.records = {}
+        return out
+
+
+class _timed:
+    def __init__(self, name, shape):
+        self.key = (name,) + tuple(shape)
+
+    def __enter__(self):
+        if KernelTimer.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KernelTimer.enabled:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            KernelTimer.records.setdefault(self.key, []).append((self.a, b))
+        return False
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -61,7 +99,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
         out = torch.empty((N, H * D), dtype=torch.float32, device=ft.device)
     attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
     lib = _capi.load()
-    with torch.cuda.device(ft.device):
+    with torch.cuda.device(ft.device), _timed("gat_fwd", (N, E, H, D, int(res is not None))):
         _capi.check(lib.spgnn_gat_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
                                       el.data_ptr(), er.data_ptr(), el.stride(0), _ptr(res),
                                       res.stride(0) if res is not None else 0, _ptr(bias), out.data_ptr(),
@@ -82,16 +120,20 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
     lib = _capi.load()
     with torch.cuda.device(ft.device):
         st = _stream(ft)
+        t_dst = _timed("gat_bwd_dst", (N, E, H, D, act)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
                                           el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
                                           g_out.data_ptr(), g_out.stride(0), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                           g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), N, E, H, D, slope, act,
                                           p_drop, seed, st), "spgnn_gat_bwd_dst")
+        t_dst.__exit__()
+        t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                           csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
                                           g_el.stride(0), N, E, H, D, p_drop, seed, st), "spgnn_gat_bwd_src")
+        t_src.__exit__()
     return g_e
 
 
@@ -153,7 +195,7 @@ def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int) -> torch
     F_ = x.shape[1]
     out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
     lib = _capi.load()
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed("spmm_sum", (N, E, F_)):
         _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
                                        _ptr(w_dst), _ptr(eps), out.data_ptr(), out.stride(0), N, E, F_, _stream(x)),
                     "spgnn_spmm_sum")
@@ -197,7 +239,7 @@ class _SpmmMaxFn(torch.autograd.Function):
         out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
         arg = torch.empty((N, F_), dtype=torch.int32, device=x.device)
         lib = _capi.load()
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x.device), _timed("spmm_max_fwd", (N, E, F_)):
             _capi.check(lib.spgnn_spmm_max_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
                                                out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
                                                _stream(x)), "spgnn_spmm_max_fwd")
@@ -213,7 +255,7 @@ class _SpmmMaxFn(torch.autograd.Function):
         N, E, F_ = csc.num_nodes, csc.num_edges, g_out.shape[1]
         g_x = torch.empty((N, F_), dtype=torch.float32, device=g_out.device)
         lib = _capi.load()
-        with torch.cuda.device(g_out.device):
+        with torch.cuda.device(g_out.device), _timed("spmm_max_bwd", (N, E, F_)):
             _capi.check(lib.spgnn_spmm_max_bwd(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                                csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0),
                                                arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,

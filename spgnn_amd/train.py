@@ -1,0 +1,138 @@
+"""Training-step harness around the model: per-step Bernoulli node mask,
+class-weighted cross entropy, SGD with momentum over one flat bucket, and tree-sharded data
+parallelism with a single RCCL all-reduce per step.
+
+Reference: job_runner.py:1886-1920 (SPGNN) / 1393-1416 (GCN/GAT/GIN).  Differences, all host-side:
+the mask and the loss are evaluated on device without ``nonzero`` syncs, and with W > 1 ranks the
+class-weighted mean is normalised by the GLOBAL weight sum (each rank back-propagates its local
+weighted SUM; the weight sum rides in the same all-reduce bucket), so W ranks x B trees take exactly
+the step one rank would take on W*B trees.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import ops
+
+__all__ = ["sampling_probabilities", "mask_from_draws", "weighted_nll_sums", "masked_weighted_ce", "FlatBucket",
+           "TrainStep"]
+
+
+def sampling_probabilities(labels: torch.Tensor, sampling_rate: float) -> torch.Tensor:
+    """1.0 for labelled nodes (y != 0), SAMPLING_RATE for the rest (job_runner.py:1887-1888)."""
+    p = torch.full(labels.shape, float(sampling_rate), dtype=torch.float32, device=labels.device)
+    p[labels != 0] = 1.0
+    return p
+
+
+def mask_from_draws(draws: torch.Tensor, sampling_p: torch.Tensor) -> torch.Tensor:
+    """``mask[i] = rn[i] < sampling_t[i]`` (job_runner.py:1896)."""
+    return draws < sampling_p
+
+
+def weighted_nll_sums(logits: torch.Tensor, labels: torch.Tensor, mask: torch.Tensor, class_weight: torch.Tensor):
+    """(sum_i m_i w[y_i] * nll_i, sum_i m_i w[y_i]): numerator and denominator of
+    ``F.cross_entropy(logits[mask], y[mask], weight=w)`` (job_runner.py:1900), without boolean indexing."""
+    logp = F.log_softmax(logits.float(), dim=1)
+    nll = -logp.gather(1, labels.view(-1, 1)).squeeze(1)
+    w = class_weight[labels] * mask.to(logp.dtype)
+    return (w * nll).sum(), w.sum()
+
+
+def masked_weighted_ce(logits, labels, mask, class_weight) -> torch.Tensor:
+    num, den = weighted_nll_sums(logits, labels, mask, class_weight)
+    return num / den
+
+
+class FlatBucket:
+    """All trainable parameters, their gradients and momentum buffers as three flat fp32 tensors.
+    ``p.data`` / ``p.grad`` become views, so autograd accumulates straight into the bucket and one
+    all-reduce + one fused SGD launch cover the whole model.  The last slot of the gradient bucket
+    carries the class-weight sum of the step."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        total = (self.numel + 1 + 3) // 4 * 4
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p.data)
+            p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            off += n
+        self.wsum_slot = self.flat_grad[self.numel:self.numel + 1]
+        self.steps = 0
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p in self.params:            # keep the views attached (a foreign .grad would bypass the bucket)
+            if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
+                raise RuntimeError("parameter .grad was detached from the flat bucket")
+
+
+class TrainStep:
+    """One optimizer step on a static batched graph: mask -> forward -> loss -> backward ->
+    [all-reduce] -> SGD(momentum)."""
+
+    def __init__(self, model: torch.nn.Module, class_weights: Sequence[float], sampling_rate: float, lr: float,
+                 momentum: float = 0.9, weight_decay: float = 0.0, process_group=None, seed: int = 0):
+        self.model = model
+        self.bucket = FlatBucket(list(model.parameters()))
+        dev = self.bucket.flat_param.device
+        self.class_weight = torch.tensor(list(class_weights), dtype=torch.float32, device=dev)
+        self.sampling_rate, self.lr, self.momentum, self.weight_decay = sampling_rate, lr, momentum, weight_decay
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self._sampling_cache = None
+
+    def _sampling(self, g):
+        y = g.ndata["y"]
+        if self._sampling_cache is None or self._sampling_cache[0] is not y:
+            self._sampling_cache = (y, sampling_probabilities(y, self.sampling_rate))
+        return self._sampling_cache[1]
+
+    def step(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns the (global) loss as a device scalar; never synchronises with the host."""
+        b = self.bucket
+        b.zero_grad()
+        y = g.ndata["y"]
+        p = self._sampling(g)
+        if draws is None:
+            draws = torch.rand(p.shape, device=p.device, generator=self.gen)
+        mask = mask_from_draws(draws, p)
+        logits = self.model(g)[0]
+        num, den = weighted_nll_sums(logits, y, mask, self.class_weight)
+        num.backward()
+        b.wsum_slot.copy_(den.detach().reshape(1))
+        loss_num = num.detach()
+        if self.world > 1:
+            dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            loss_num = loss_num.clone()
+            dist.all_reduce(loss_num, op=dist.ReduceOp.SUM, group=self.pg)
+        inv = torch.reciprocal(b.wsum_slot)
+        self._apply_update(inv)
+        b.steps += 1
+        return loss_num * inv[0]
+
+    def _apply_update(self, inv: torch.Tensor) -> None:
+        """Fused SGD(momentum) over the flat bucket: one HIP launch (spgnn_sgd_momentum_step)."""
+        b = self.bucket
+        ops.sgd_momentum_step_(b.flat_param, b.flat_grad, b.flat_mom, self.lr, self.momentum, self.weight_decay,
+                               first_step=(b.steps == 0), grad_scale=inv)
+
+    def set_lr(self, lr: float):
+        self.lr = lr

@@ -25,7 +25,8 @@ def _oracle_gat(layer, src, dst, n, x, act, dtype=torch.float32, attn_keep=None)
     sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in layer.state_dict().items()}
     xo = x.detach().cpu().to(dtype).requires_grad_(True)
     rst, a = O.gat_conv(src, dst, n, xo, sd["fc.weight"], sd["attn_l"], sd["attn_r"], sd.get("res_fc.weight"),
-                        sd.get("bias"), layer.negative_slope, act, attn_keep)
+                        sd.get("bias"), layer.negative_slope, act, attn_keep,
+                        residual_identity=isinstance(layer.res_fc, snn.Identity))
     return rst, a, xo, sd
 
 

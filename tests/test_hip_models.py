@@ -1,0 +1,162 @@
+"""Model-level parity (every exp_settings config) of the HIP path against the CPU oracle, at the
+configs' full layer widths on a few synthetic trees, plus size-independent properties at the
+BASELINE batch size (512 trees)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgl_cpu as O
+from spgnn_amd import models, synthetic
+from spgnn_amd.configs import CONFIGS, class_weight_list, get_config
+from spgnn_amd.train import TrainStep, masked_weighted_ce
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5     # BASELINE.json north_star: logits within 1e-5 (fp32, relative) of the DGL-CPU forward
+
+
+def _build(name, seed=0):
+    cfg = get_config(name)
+    torch.manual_seed(seed)
+    model = models.build_model(cfg.MODEL).cuda()
+    model.init(None)
+    with torch.no_grad():                       # non-trivial biases/eps so their paths are exercised
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or n.endswith("eps"):
+                p.normal_(0, 0.05)
+    model.set_gcn_only()
+    return cfg, model
+
+
+def _oracle(cfg, model, g, grad=False):
+    src, dst = g.cpu().edges()
+    sd = {k: v.detach().cpu().clone().requires_grad_(grad and v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    pe = g.ndata["pos_enc"].cpu() if "pos_enc" in g.ndata else None
+    return O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu(), pe), sd
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_config_forward_matches_oracle(name):
+    cfg, model = _build(name)
+    g = synthetic.make_batch(3, rank=7, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model.eval()
+    with torch.no_grad():
+        outs = model(g)
+    refs, _ = _oracle(cfg, model, g)
+    assert len(outs) == len(refs)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and rel_err(o, r) < TOL
+    assert outs[0].shape == (g.number_of_nodes(), 22)
+
+
+@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3", "st_gat_6_nr"])
+def test_config_loss_gradients_match_oracle(name):
+    cfg, model = _build(name, seed=1)
+    g = synthetic.make_batch(2, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model.eval()                                  # dropout off; gradients still flow
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5
+    loss = masked_weighted_ce(model(g)[0], y, mask.cuda(), w.cuda())
+    loss.backward()
+    refs, sd = _oracle(cfg, model, g, grad=True)
+    ref_loss = O.masked_weighted_ce(refs[0], y.cpu(), mask, w)
+    ref_loss.backward()
+    assert rel_err(loss, ref_loss) < TOL
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert sd[n].grad is not None, n
+            assert rel_err(p.grad, sd[n].grad) < 1e-4, n
+
+
+def test_state_dict_keys_follow_dgl_layout():
+    """Checkpoint compatibility: parameter names/shapes as DGL's layers."""
+    _, m = _build("st_pgat_spgnn_3")
+    sd = m.state_dict()
+    assert sd["gat.gat_layers.0.fc.weight"].shape == (512, 1063)
+    assert sd["gat.gat_layers.0.res_fc.weight"].shape == (512, 1063)
+    assert sd["gat.gat_layers.0.attn_l"].shape == (1, 2, 256) and sd["gat.gat_layers.0.bias"].shape == (512,)
+    assert sd["gat.pgnn_layers.1.attn_r"].shape == (1, 1, 128) and sd["gat.pgnn_layers.0.fc.weight"].shape == (256, 39)
+    assert sd["gat.gat_layers.3.fc.weight"].shape == (2048, 192) and sd["gnn_out.weight"].shape == (22, 1024)
+    assert sum(p.numel() for p in m.parameters()) == 2501078
+    for name, count in [("st_gat_3", 1931926), ("st_gat_6", 2031382), ("st_gcn_3", 392662), ("st_sage_3", 1898838)]:
+        assert sum(p.numel() for p in _build(name)[1].parameters()) == count, name
+    _, m = _build("st_gcn_3"); assert m.state_dict()["gcn.gcn_layers.0.weight"].shape == (1024, 256)
+    _, m = _build("st_gin_3")
+    assert {"gin.gin_layers.0.eps", "gin.gin_layers.0.apply_func.0.weight", "gin.gin_layers.3.apply_func.3.bias",
+            "gnn_lobe_out.weight"} <= set(m.state_dict())
+    _, m = _build("st_sage_3")
+    assert m.state_dict()["sage.g_layers.0.fc_pool.weight"].shape == (1024, 1024)
+    assert not any(k.startswith("gat.") and "res_fc" in k for k in _build("st_gat_3_nr")[1].state_dict())
+
+
+def test_train_step_matches_torch_sgd_on_oracle():
+    """Harness parity: given the same mask draws, three TrainStep steps equal three
+    torch.optim.SGD(momentum) steps on the oracle's loss."""
+    cfg, model = _build("st_gat_3", seed=2)
+    model.eval()
+    g = synthetic.make_batch(2, rank=1, device="cuda", pos_enc_dim=None)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    src, dst = g.cpu().edges()
+    ref_p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    opt = torch.optim.SGD(list(ref_p.values()), lr=0.01, momentum=0.9)
+    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 0.01, 0.9)
+    gen = torch.Generator().manual_seed(11)
+    y = g.ndata["y"].cpu()
+    for _ in range(3):
+        draws = torch.rand(y.shape[0], generator=gen)
+        loss = ts.step(g, draws.cuda())
+        opt.zero_grad()
+        mask = draws < torch.where(y != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
+        ref = O.masked_weighted_ce(O.net_forward("gat", ref_p, src, dst, y.shape[0], g.ndata["fvs"].cpu())[0], y, mask,
+                                   torch.tensor(w))
+        ref.backward(); opt.step()
+        assert rel_err(loss, ref) < TOL
+    for k, v in model.named_parameters():
+        assert rel_err(v, ref_p[k]) < 1e-5, k
+
+
+# ---- size-independent properties at the BASELINE batch size -----------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    cfg, model = _build("st_pgat_spgnn_3")
+    model.eval()
+    samples = synthetic.synthetic_trees(512, rank=0)
+    return cfg, model, samples, synthetic.batch_from_samples(samples, "cuda", 39)
+
+
+def test_full_batch_equals_per_tree_and_is_deterministic(big):
+    cfg, model, samples, g = big
+    assert g.batch_size == 512 and g.number_of_edges() == 3 * g.number_of_nodes() - 2 * 512
+    with torch.no_grad():
+        a = model(g)[0]
+        b = model(g)[0]
+        assert torch.equal(a, b)                                    # no atomics: bitwise reproducible
+        offs = np.cumsum([0] + g.batch_num_nodes_list)
+        for i in (0, 255, 511):                                     # block-diagonal: tree i alone gives the same rows
+            gi = synthetic.batch_from_samples(samples[i:i + 1], "cuda", 39)
+            assert rel_err(a[offs[i]:offs[i + 1]], model(gi)[0]) < TOL
+    refs, _ = _oracle(cfg, model, synthetic.batch_from_samples(samples[:2], "cuda", 39))
+    assert rel_err(a[:offs[2]], refs[0]) < TOL                      # and those rows match the oracle
+
+
+def test_full_batch_attention_rows_sum_to_one_and_linearity(big):
+    from spgnn_amd import ops
+    _, _, _, g = big
+    csc = g.csc()
+    N, H, D = csc.num_nodes, 2, 256
+    torch.manual_seed(0)
+    ft1, ft2 = torch.randn(N, H * D, device="cuda"), torch.randn(N, H * D, device="cuda")
+    el, er = torch.randn(N, H, device="cuda"), torch.randn(N, H, device="cuda")
+    o1, attn = ops.gat_fwd_raw(csc, ft1, el, er, None, None, H, D, 0.2, 0)
+    o2, _ = ops.gat_fwd_raw(csc, ft2, el, er, None, None, H, D, 0.2, 0)
+    o12, _ = ops.gat_fwd_raw(csc, ft1 + ft2, el, er, None, None, H, D, 0.2, 0)
+    assert rel_err(o12, o1 + o2) < 1e-5                             # linear in ft for fixed scores
+    seg = torch.repeat_interleave(torch.arange(N, device="cuda"), (csc.indptr[1:] - csc.indptr[:-1]).long())
+    sums = torch.zeros(N, H, device="cuda").index_add_(0, seg, attn)
+    assert (sums - 1).abs().max().item() < 1e-5                     # softmax over in-neighbours
+    const = torch.randn(1, H * D, device="cuda").expand(N, -1).contiguous()
+    oc, _ = ops.gat_fwd_raw(csc, const, el, er, None, None, H, D, 0.2, 0)
+    assert rel_err(oc, const) < 1e-5                                # constant rows: out == ft
