@@ -59,14 +59,27 @@ def algorithmic_bytes(key) -> float:
     raise KeyError(name)
 
 
-def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=2):
+def usable_cores(cap: int = 32) -> int:
+    """Threads the baseline may really use: scheduler affinity and cgroup quota, not os.cpu_count()
+    (the GPU box reports 256 logical CPUs but grants far fewer; oversubscribing made one iteration 50 s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=1, budget_s=25.0):
     """DGL-CPU-equivalent (restated) fwd+bwd on the host cores: oracle/dgl_cpu.py, same weights, first
     ``n_trees`` trees of rank 0's batch, eval-mode arithmetic (no dropout), all host threads."""
     from oracle import dgl_cpu as O
     from spgnn_amd import synthetic
     from spgnn_amd.configs import class_weight_list
     import torch.nn.functional as F
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     g = synthetic.batch_from_samples(samples[:n_trees], "cpu", cfg.POS_ENC_DIM)
     src, dst = g.edges()
@@ -76,7 +89,10 @@ def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=2):
     y = g.ndata["y"]
     mask = torch.rand(n) < torch.where(y != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
     times = []
+    t_start = time.perf_counter()
     for i in range(warm + steps):
+        if i > warm and time.perf_counter() - t_start > budget_s:
+            break
         t0 = time.perf_counter()
         out = O.net_forward(cfg.KIND, sd, src, dst, n, g.ndata["fvs"], g.ndata.get("pos_enc"))[0]
         loss = O.masked_weighted_ce(out, y, mask, w)
@@ -87,8 +103,8 @@ def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=2):
     times.sort()
     med = times[len(times) // 2]
     return {"value": E * cfg.CONV_LAYERS / med, "unit": "layer-edges/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fwd+bwd, median of {steps} "
-                      f"after {warm} warm-ups, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops"}
+            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fwd+bwd, median of {len(times)} "
+                      f"after {warm} warm-up(s) on {cores} threads, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops"}
 
 
 def main():
