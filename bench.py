@@ -38,12 +38,14 @@ def algorithmic_bytes(key) -> float:
     """Algorithmic HBM bytes of ONE launch (SURVEY.md §8d per-unit figures, fp32):
     every operand row read once, every result row written once, index arrays once."""
     name = key[0]
-    if name == "gat_fwd":            # read ft [+res], write out; read el, er; write a; read CSC
-        _, N, E, H, D, has_res = key
-        return 4 * (2 + has_res) * N * H * D + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
+    if name == "gat_fwd":            # read ft [+res]; write out [and/or its head mean]; read el, er; write a; CSC
+        _, N, E, H, D, has_res, mean, has_out = key
+        return (4 * (1 + has_res + has_out) * N * H * D + 4 * mean * N * D + 4 * (2 * N * H + E * H)
+                + 4 * (N + 1 + E))
     if name == "gat_bwd_dst":        # read g_out [,out], ft; write g_pre; read el, er, a; write g_e, g_er; CSC
-        _, N, E, H, D, act = key
-        return 4 * (3 + (1 if act else 0)) * N * H * D + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
+        _, N, E, H, D, act, mean = key
+        return (4 * (2 + (1 if act else 0)) * N * H * D + 4 * N * (D if mean else H * D)
+                + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E))
     if name == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
         _, N, E, H, D = key
         return 4 * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)

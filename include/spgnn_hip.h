@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 1
+#define SPGNN_ABI_VERSION 2
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -59,6 +59,10 @@ const char* spgnn_last_error(void);
  *
  * ft/res/out: (N, H*D) with row strides.  el/er: (N, H) with row stride s_stride.
  * res, bias may be NULL.  attn: (E, H) contiguous, always written (saved for backward).
+ * out_mean (nullable): (N, D) head mean of the activated output, mean_h out[v,h,:] — the
+ * `.mean(1)` the reference applies to the last layer (models.py:327, 482) fused into the epilogue.
+ * With out_mean set, `out` may be NULL iff spgnn_gat_can_fuse_mean(H, D) (the backward only needs the
+ * per-head output when an activation is fused).
  * p_drop in [0,1): attention dropout; the keep mask is a counter-based hash of (seed, slot, h),
  * regenerated (not stored) by the backward entry points.
  */
@@ -68,11 +72,15 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   const float* res, int64_t res_stride,
                   const float* bias,
                   float* out, int64_t out_stride,
+                  float* out_mean, int64_t out_mean_stride,
                   float* attn,
                   int64_t N, int64_t E, int32_t H, int32_t D,
                   float negative_slope, int32_t activation,
                   float p_drop, uint64_t seed,
                   spgnn_stream_t stream);
+
+/* 1 if the vector kernel fuses the head mean for this (H, D) (a head is at least one team wide). */
+int spgnn_gat_can_fuse_mean(int32_t H, int32_t D);
 
 /*
  * GATConv backward, destination-major half (replaces DGL autograd of the sequence above:
@@ -83,14 +91,15 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
  *   g_e_uv      = (a_uv*g_a_uv - a_uv * sum_{in(v)} a*g_a) * lrelu'(el[u,h]+er[v,h])  -> g_e[slot,h]
  *   g_er[v,h]   = sum_{in(v)} g_e_uv
  *
- * `out` is the forward output (post-activation); ignored when activation == NONE (may be NULL).
+ * `out` is the forward per-head output (post-activation); ignored when activation == NONE (may be NULL).
+ * mean_heads != 0: g_out is the gradient of the head mean, shape (N, D); each head receives g_out/H.
  * g_pre is also the gradient of the residual branch and of the bias (column sums).
  */
 int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
                       const float* ft, int64_t ft_stride,
                       const float* el, const float* er, int64_t s_stride,
                       const float* attn,
-                      const float* g_out, int64_t g_out_stride,
+                      const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                       const float* out, int64_t out_stride,
                       float* g_pre, int64_t g_pre_stride,
                       float* g_e,

@@ -11,8 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
+ABI_VERSION = 2
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -22,9 +22,10 @@ _i64, _i32, _f32, _u64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_v
 SIGNATURES = {
     "spgnn_abi_version": [],
     "spgnn_last_error": [],
-    "spgnn_gat_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p,
-                      _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
-    "spgnn_gat_bwd_dst": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,
+    "spgnn_gat_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,
+                      _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
+    "spgnn_gat_can_fuse_mean": [_i32, _i32],
+    "spgnn_gat_bwd_dst": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _f32p, _i64,
                           _f32p, _i64, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
     "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64,
                           _i64, _i64, _i32, _i32, _f32, _u64, _vp],

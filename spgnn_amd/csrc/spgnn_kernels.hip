@@ -117,86 +117,161 @@ __device__ __forceinline__ float team_sum(float x, int width) {
 }
 
 // =================================================================================================
-// GAT forward
+// GAT kernels.  Template parameters of the vector kernels:
+//   R   float4 chunks per lane (H*D = 4*T*R)
+//   CH  chunks of one lane that belong to one head when a head is at least a team wide
+//       (D = 4*T*CH, the lane then sees NS = R/CH heads, head index = chunk / CH, uniform per team);
+//       CH = 0 when a head is narrower than the team (4*T % D == 0): every chunk is its own slot,
+//       head index = column / D varies across lanes, reductions run over W = D/4 lanes.
+// kMaxFast: nodes with at most this many edges (every airway node: in-degree <= 5) take a path that
+// loads all edge indices and scores up front (independent loads) and keeps per-edge weights in
+// registers; larger degrees fall back to multi-pass loops of identical arithmetic.
 // =================================================================================================
+constexpr int kMaxFast = 8;
+// A/B switches (tools/ab_kernels.py, MI355X, 512 trees): the up-front path is 23 % faster for the forward
+// (it removes two dependent passes over the edge list), neutral for the dst-major backward and 15 % SLOWER
+// for the src-major backward (already a single pass) - so only the forward takes it by default.
+#ifndef SPGNN_FWD_FAST
+#define SPGNN_FWD_FAST 1
+#endif
+#ifndef SPGNN_DST_FAST
+#define SPGNN_DST_FAST 0
+#endif
+#ifndef SPGNN_SRC_FAST
+#define SPGNN_SRC_FAST 0
+#endif
+
+template <int R, int CH> struct Slots {
+  static constexpr int NS = (CH == 0) ? R : R / CH;
+  static __device__ __forceinline__ constexpr int of(int r) { return (CH == 0) ? r : r / CH; }
+};
+
+// -------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------
 struct GatFwd {
   const int32_t* indptr; const int32_t* indices;
   const float* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
   const float* res; int64_t res_ld;
   const float* bias;
-  float* out; int64_t out_ld;
+  float* out; int64_t out_ld;            // per-head output (N, H*D); may be null when out_mean is set
+  float* out_mean; int64_t out_mean_ld;  // optional head-mean output (N, D)
   float* attn;
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
 };
 
-template <int R>
+template <int R, int CH, bool MEAN>
 __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
+  using SL = Slots<R, CH>;
+  constexpr int NS = SL::NS;
   const int T = a.T;
   const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
   if (v >= a.N) return;
   const int lane = threadIdx.x % T;
-  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
 
-  int c[R], h[R];
-  float m[R], s[R], erv[R];
+  int hs[NS]; bool wr[NS]; float erv[NS];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    c[r] = (r * T + lane) * 4;
-    h[r] = c[r] / a.D;
+  for (int s = 0; s < NS; ++s) {
+    const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
+    hs[s] = c0 / a.D;
+    wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+    erv[s] = a.er[v * a.s_ld + hs[s]];
   }
-  // per-(node, head) softmax statistics, recomputed by every lane of the head (deg <= ~5:
-  // cheaper than a cross-lane exchange); el/er gathers are broadcast loads.
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (r > 0 && h[r] == h[r - 1]) { m[r] = m[r - 1]; s[r] = s[r - 1]; erv[r] = erv[r - 1]; continue; }
-    erv[r] = a.er[v * a.s_ld + h[r]];
-    float mx = -INFINITY;
-    for (int j = beg; j < end; ++j)
-      mx = fmaxf(mx, lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h[r]] + erv[r], a.slope));
-    float sm = 0.f;
-    for (int j = beg; j < end; ++j)
-      sm += expf(lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h[r]] + erv[r], a.slope) - mx);
-    m[r] = mx; s[r] = sm;
-  }
-
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int j = beg; j < end; ++j) {
-    const int64_t u = a.indices[j];
-    const float* row = a.ft + u * a.ft_ld;
-    float4 x[R];
+  if (SPGNN_FWD_FAST && deg <= kMaxFast) {
+    int64_t u[kMaxFast];
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = ld4(row + c[r]);
-    float w_prev = 0.f;
+    for (int k = 0; k < kMaxFast; ++k) u[k] = k < deg ? a.indices[beg + k] : 0;
+    float w[kMaxFast][NS];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float w;
-      if (r > 0 && h[r] == h[r - 1]) {
-        w = w_prev;
-      } else {
-        const float e = lrelu(a.el[u * a.s_ld + h[r]] + erv[r], a.slope);
-        const float al = expf(e - m[r]) / s[r];
-        if (c[r] % a.D == 0) a.attn[(int64_t)j * a.H + h[r]] = al;
-        w = a.p > 0.f ? al * keep_scale(a.seed, (int64_t)j * a.H + h[r], a.p, a.inv_keep) : al;
+    for (int s = 0; s < NS; ++s) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        w[k][s] = k < deg ? lrelu(a.el[u[k] * a.s_ld + hs[s]] + erv[s], a.slope) : -INFINITY;
+        mx = fmaxf(mx, w[k][s]);
       }
-      w_prev = w;
-      fma4(acc[r], w, x[r]);
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        w[k][s] = k < deg ? expf(w[k][s] - mx) : 0.f;
+        sm += w[k][s];
+      }
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        if (k < deg) {
+          const float al = w[k][s] / sm;
+          const int64_t eidx = (int64_t)(beg + k) * a.H + hs[s];
+          if (wr[s]) a.attn[eidx] = al;
+          w[k][s] = a.p > 0.f ? al * keep_scale(a.seed, eidx, a.p, a.inv_keep) : al;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) {
+      if (k < deg) {
+        const float* row = a.ft + u[k] * a.ft_ld;
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], w[k][SL::of(r)], ld4(row + (r * T + lane) * 4));
+      }
+    }
+  } else {
+    float mx[NS], sm[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float m_ = -INFINITY;
+      for (int j = beg; j < end; ++j)
+        m_ = fmaxf(m_, lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + hs[s]] + erv[s], a.slope));
+      float s_ = 0.f;
+      for (int j = beg; j < end; ++j)
+        s_ += expf(lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + hs[s]] + erv[s], a.slope) - m_);
+      mx[s] = m_; sm[s] = s_;
+    }
+    for (int j = beg; j < end; ++j) {
+      const int64_t u = a.indices[j];
+      const float* row = a.ft + u * a.ft_ld;
+      float w[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float al = expf(lrelu(a.el[u * a.s_ld + hs[s]] + erv[s], a.slope) - mx[s]) / sm[s];
+        const int64_t eidx = (int64_t)j * a.H + hs[s];
+        if (wr[s]) a.attn[eidx] = al;
+        w[s] = a.p > 0.f ? al * keep_scale(a.seed, eidx, a.p, a.inv_keep) : al;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
     }
   }
 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    const int c = (r * T + lane) * 4;
     float4 o = acc[r];
-    if (a.res) { const float4 q = ld4(a.res + v * a.res_ld + c[r]); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-    if (a.bias) { const float4 q = ld4(a.bias + c[r]); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+    if (a.res) { const float4 q = ld4(a.res + v * a.res_ld + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+    if (a.bias) { const float4 q = ld4(a.bias + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
     if (a.act != SPGNN_ACT_NONE) {
       o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act);
     }
-    st4(a.out + v * a.out_ld + c[r], o);
+    if (a.out) st4(a.out + v * a.out_ld + c, o);
+    acc[r] = o;
+  }
+  if (MEAN) {   // heads live in chunks r, r+CH, r+2CH, ... of the same lane (CH >= 1): mean is lane-local
+    constexpr int CHs = CH == 0 ? 1 : CH;
+    const float inv_h = 1.f / (float)a.H;
+#pragma unroll
+    for (int rr = 0; rr < CHs; ++rr) {
+      float4 m = acc[rr];
+#pragma unroll
+      for (int s = 1; s < NS; ++s) { const float4 q = acc[s * CHs + rr]; m.x += q.x; m.y += q.y; m.z += q.z; m.w += q.w; }
+      m.x *= inv_h; m.y *= inv_h; m.z *= inv_h; m.w *= inv_h;
+      st4(a.out_mean + v * a.out_mean_ld + (rr * T + lane) * 4, m);
+    }
   }
 }
 
@@ -225,96 +300,150 @@ __global__ void gat_fwd_scalar(GatFwd a) {
   a.out[v * a.out_ld + col] = act_fwd(acc, a.act);
 }
 
-// =================================================================================================
-// GAT backward, dst-major half
-// =================================================================================================
+// head mean for shapes the vector kernel cannot fuse: out_mean[v,d] = mean_h out[v,h,d]
+__global__ void head_mean_scalar(const float* out, int64_t out_ld, float* om, int64_t om_ld, int64_t N, int H, int D) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= N * D) return;
+  const int64_t v = gid / D; const int d = (int)(gid % D);
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s += out[v * out_ld + h * D + d];
+  om[v * om_ld + d] = s / (float)H;
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward, dst-major half
+// -------------------------------------------------------------------------------------------------
 struct GatBwdDst {
   const int32_t* indptr; const int32_t* indices;
   const float* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
   const float* attn;
-  const float* g_out; int64_t g_out_ld;
+  const float* g_out; int64_t g_out_ld;  // (N, H*D), or (N, D) when mean != 0
   const float* out; int64_t out_ld;
   float* g_pre; int64_t g_pre_ld;
   float* g_e;
   float* g_er; int64_t gs_ld;
-  int64_t N; int H; int D; int T; int W;
+  int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
 };
 
-// CH = float4 chunks of one lane that belong to one head (D = 4*T*CH), or 0 when a head is
-// narrower than the team (4*T % D == 0): then each chunk is its own slot and the reduction
-// width is W = D/4 lanes.
 template <int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
-  constexpr int NS = (CH == 0) ? R : R / CH;
+  using SL = Slots<R, CH>;
+  constexpr int NS = SL::NS;
   const int T = a.T;
   const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
   if (v >= a.N) return;
   const int lane = threadIdx.x % T;
-  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
   const int width = (CH == 0) ? a.W : T;
+  const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
 
-  int c[R];
   float4 g[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    c[r] = (r * T + lane) * 4;
-    float4 q = ld4(a.g_out + v * a.g_out_ld + c[r]);
+    const int c = (r * T + lane) * 4;
+    float4 q = ld4(a.g_out + v * a.g_out_ld + (a.mean ? c % a.D : c));
+    if (a.mean) { q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale; }
     if (a.act != SPGNN_ACT_NONE) {
-      const float4 o = ld4(a.out + v * a.out_ld + c[r]);
+      const float4 o = ld4(a.out + v * a.out_ld + c);
       q.x *= act_bwd_from_out(o.x, a.act); q.y *= act_bwd_from_out(o.y, a.act);
       q.z *= act_bwd_from_out(o.z, a.act); q.w *= act_bwd_from_out(o.w, a.act);
     }
     g[r] = q;
-    st4(a.g_pre + v * a.g_pre_ld + c[r], q);
+    st4(a.g_pre + v * a.g_pre_ld + c, q);
   }
   int hs[NS]; bool wr[NS];
 #pragma unroll
-  for (int sidx = 0; sidx < NS; ++sidx) {
-    const int c0 = (CH == 0) ? c[sidx] : c[sidx * CH];
-    hs[sidx] = c0 / a.D;
-    wr[sidx] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+  for (int s = 0; s < NS; ++s) {
+    const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
+    hs[s] = c0 / a.D;
+    wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
   }
 
-  // pass 1: g_a for every in-edge (kept in g_e as scratch by the writer lane) and S = sum a*g_a
+  if (SPGNN_DST_FAST && deg <= kMaxFast) {
+    int64_t u[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) u[k] = k < deg ? a.indices[beg + k] : 0;
+    float ga[kMaxFast][NS];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ga[k][s] = 0.f;
+      if (k < deg) {
+        const float* row = a.ft + u[k] * a.ft_ld;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ga[k][SL::of(r)] += dot4(ld4(row + (r * T + lane) * 4), g[r]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float erv = a.er[v * a.s_ld + hs[s]];
+      float al[kMaxFast];
+      float S = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        if (k < deg) {                       // deg is uniform within the team, so the shuffles stay in-team
+          float x = team_sum(ga[k][s], width);
+          const int64_t eidx = (int64_t)(beg + k) * a.H + hs[s];
+          if (a.p > 0.f) x *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+          al[k] = a.attn[eidx];
+          ga[k][s] = x;
+          S = fmaf(al[k], x, S);
+        }
+      }
+      float ger = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        if (k < deg) {
+          float ge = al[k] * ga[k][s] - al[k] * S;
+          const float epre = a.el[u[k] * a.s_ld + hs[s]] + erv;
+          ge = epre > 0.f ? ge : ge * a.slope;
+          if (wr[s]) a.g_e[(int64_t)(beg + k) * a.H + hs[s]] = ge;
+          ger += ge;
+        }
+      }
+      if (wr[s]) a.g_er[v * a.gs_ld + hs[s]] = ger;
+    }
+    return;
+  }
+
+  // general degree: pass 1 keeps g_a in g_e (written and re-read by the same writer lane), pass 2 finishes
   float S[NS];
 #pragma unroll
-  for (int sidx = 0; sidx < NS; ++sidx) S[sidx] = 0.f;
+  for (int s = 0; s < NS; ++s) S[s] = 0.f;
   for (int j = beg; j < end; ++j) {
     const int64_t u = a.indices[j];
     const float* row = a.ft + u * a.ft_ld;
     float pd[NS];
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) pd[sidx] = 0.f;
+    for (int s = 0; s < NS; ++s) pd[s] = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) pd[(CH == 0) ? r : r / CH] += dot4(ld4(row + c[r]), g[r]);
+    for (int r = 0; r < R; ++r) pd[SL::of(r)] += dot4(ld4(row + (r * T + lane) * 4), g[r]);
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-      float ga = team_sum(pd[sidx], width);
-      const int64_t eidx = (int64_t)j * a.H + hs[sidx];
-      if (a.p > 0.f) ga *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
-      S[sidx] = fmaf(a.attn[eidx], ga, S[sidx]);
-      if (wr[sidx]) a.g_e[eidx] = ga;
+    for (int s = 0; s < NS; ++s) {
+      float x = team_sum(pd[s], width);
+      const int64_t eidx = (int64_t)j * a.H + hs[s];
+      if (a.p > 0.f) x *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+      S[s] = fmaf(a.attn[eidx], x, S[s]);
+      if (wr[s]) a.g_e[eidx] = x;
     }
   }
-  // pass 2 (one lane per (node, head)): softmax backward, LeakyReLU backward, g_er
 #pragma unroll
-  for (int sidx = 0; sidx < NS; ++sidx) {
-    if (!wr[sidx]) continue;
-    const int hh = hs[sidx];
-    const float erv = a.er[v * a.s_ld + hh];
+  for (int s = 0; s < NS; ++s) {
+    if (!wr[s]) continue;
+    const float erv = a.er[v * a.s_ld + hs[s]];
     float ger = 0.f;
     for (int j = beg; j < end; ++j) {
-      const int64_t eidx = (int64_t)j * a.H + hh;
+      const int64_t eidx = (int64_t)j * a.H + hs[s];
       const float al = a.attn[eidx];
-      float ge = al * a.g_e[eidx] - al * S[sidx];
-      const float epre = a.el[(int64_t)a.indices[j] * a.s_ld + hh] + erv;
+      float ge = al * a.g_e[eidx] - al * S[s];
+      const float epre = a.el[(int64_t)a.indices[j] * a.s_ld + hs[s]] + erv;
       ge = epre > 0.f ? ge : ge * a.slope;
       a.g_e[eidx] = ge;
       ger += ge;
     }
-    a.g_er[v * a.gs_ld + hh] = ger;
+    a.g_er[v * a.gs_ld + hs[s]] = ger;
   }
 }
 
@@ -325,8 +454,9 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
   const int64_t v = gid / a.H; const int h = (int)(gid % a.H);
   const int beg = a.indptr[v], end = a.indptr[v + 1];
   const int base = h * a.D;
+  const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
   for (int d = 0; d < a.D; ++d) {
-    float q = a.g_out[v * a.g_out_ld + base + d];
+    float q = a.g_out[v * a.g_out_ld + (a.mean ? d : base + d)] * gscale;
     if (a.act != SPGNN_ACT_NONE) q *= act_bwd_from_out(a.out[v * a.out_ld + base + d], a.act);
     a.g_pre[v * a.g_pre_ld + base + d] = q;
   }
@@ -354,9 +484,9 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
   a.g_er[v * a.gs_ld + h] = ger;
 }
 
-// =================================================================================================
-// GAT backward, src-major half
-// =================================================================================================
+// -------------------------------------------------------------------------------------------------
+// backward, src-major half
+// -------------------------------------------------------------------------------------------------
 struct GatBwdSrc {
   const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
   const float* attn; const float* g_e;
@@ -367,49 +497,58 @@ struct GatBwdSrc {
   float p; float inv_keep; uint64_t seed;
 };
 
-template <int R>
+template <int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
+  using SL = Slots<R, CH>;
+  constexpr int NS = SL::NS;
   const int T = a.T;
   const int64_t u = xcd_block() * (kBlock / T) + threadIdx.x / T;
   if (u >= a.N) return;
   const int lane = threadIdx.x % T;
-  const int beg = a.out_indptr[u], end = a.out_indptr[u + 1];
-  int c[R], h[R];
+  const int beg = a.out_indptr[u], end = a.out_indptr[u + 1], deg = end - beg;
+  int hs[NS]; bool wr[NS]; float gel[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
+    hs[s] = c0 / a.D;
+    wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+    gel[s] = 0.f;
+  }
   float4 acc[R];
-  float gel[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    c[r] = (r * T + lane) * 4; h[r] = c[r] / a.D;
-    acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); gel[r] = 0.f;
-  }
-  for (int k = beg; k < end; ++k) {
-    const int64_t v = a.out_indices[k];
-    const int64_t pos = a.out_pos[k];
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto edge = [&](int64_t v, int64_t pos) {
     const float* row = a.g_pre + v * a.g_pre_ld;
-    float4 x[R];
+    float w[NS];
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = ld4(row + c[r]);
-    float w_prev = 0.f;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float w;
-      if (r > 0 && h[r] == h[r - 1]) {
-        w = w_prev;
-      } else {
-        const int64_t eidx = pos * a.H + h[r];
-        w = a.attn[eidx];
-        if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
-        if (c[r] % a.D == 0) gel[r] += a.g_e[eidx];
-      }
-      w_prev = w;
-      fma4(acc[r], w, x[r]);
+    for (int s = 0; s < NS; ++s) {
+      const int64_t eidx = pos * a.H + hs[s];
+      w[s] = a.attn[eidx];
+      if (a.p > 0.f) w[s] *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+      if (wr[s]) gel[s] += a.g_e[eidx];
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
+  };
+  if (SPGNN_SRC_FAST && deg <= kMaxFast) {
+    int64_t vv[kMaxFast], pp[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) {
+      vv[k] = k < deg ? a.out_indices[beg + k] : 0;
+      pp[k] = k < deg ? a.out_pos[beg + k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+      if (k < deg) edge(vv[k], pp[k]);
+  } else {
+    for (int k = beg; k < end; ++k) edge(a.out_indices[k], a.out_pos[k]);
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    st4(a.g_ft + u * a.g_ft_ld + c[r], acc[r]);
-    if (c[r] % a.D == 0) a.g_el[u * a.gs_ld + h[r]] = gel[r];
-  }
+  for (int r = 0; r < R; ++r) st4(a.g_ft + u * a.g_ft_ld + (r * T + lane) * 4, acc[r]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (wr[s]) a.g_el[u * a.gs_ld + hs[s]] = gel[s];
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -621,40 +760,90 @@ extern "C" {
 int spgnn_abi_version(void) { return SPGNN_ABI_VERSION; }
 const char* spgnn_last_error(void) { return g_err; }
 
+// Geometry of the vector GAT kernels for (H, D): team width T, chunks per lane R, chunks per head CH
+// (0 = heads narrower than the team, reduction width W).  false -> scalar fallback.
+static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
+  if (D % 4) return false;
+  if (!pick_team((int64_t)H * D, T, R)) return false;
+  const int team_floats = 4 * T;
+  W = T;
+  if (D % team_floats == 0) {
+    CH = D / team_floats;
+    return (CH == 1 || CH == 2 || CH == 4 || CH == 8) && R % CH == 0;
+  }
+  if (team_floats % D == 0 && ((D / 4) & (D / 4 - 1)) == 0) { CH = 0; W = D / 4; return true; }
+  return false;
+}
+
+#define SPGNN_FOR_R_CH(R_, CH_, X)                                                                  \
+  switch ((R_) * 16 + (CH_)) {                                                                      \
+    case 1 * 16 + 0: X(1, 0); break;  case 1 * 16 + 1: X(1, 1); break;                              \
+    case 2 * 16 + 0: X(2, 0); break;  case 2 * 16 + 1: X(2, 1); break;  case 2 * 16 + 2: X(2, 2); break; \
+    case 4 * 16 + 0: X(4, 0); break;  case 4 * 16 + 1: X(4, 1); break;  case 4 * 16 + 2: X(4, 2); break; \
+    case 4 * 16 + 4: X(4, 4); break;                                                                \
+    case 8 * 16 + 0: X(8, 0); break;  case 8 * 16 + 1: X(8, 1); break;  case 8 * 16 + 2: X(8, 2); break; \
+    case 8 * 16 + 4: X(8, 4); break;  case 8 * 16 + 8: X(8, 8); break;                              \
+    default: return fail(SPGNN_ERR_SHAPE, "internal: no kernel instance for this team geometry");   \
+  }
+
+int spgnn_gat_can_fuse_mean(int32_t H, int32_t D) {
+  int T, R, CH, W;
+  return (H > 0 && D > 0 && pick_gat(H, D, T, R, CH, W) && CH >= 1) ? 1 : 0;
+}
+
 int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
                   const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
-                  const float* bias, float* out, int64_t out_stride, float* attn, int64_t N, int64_t E, int32_t H,
-                  int32_t D, float negative_slope, int32_t activation, float p_drop, uint64_t seed,
-                  spgnn_stream_t stream) {
+                  const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
+                  float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
+                  float p_drop, uint64_t seed, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
-  if (!indptr || !ft || !el || !er || !out || !attn || (E > 0 && !indices))
+  if (!indptr || !ft || !el || !er || !attn || (!out && !out_mean) || (E > 0 && !indices))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: null pointer");
   const int64_t HD = (int64_t)H * D;
-  if (ft_stride < HD || out_stride < HD || s_stride < H || (res && res_stride < HD))
+  if (ft_stride < HD || (out && out_stride < HD) || s_stride < H || (res && res_stride < HD) ||
+      (out_mean && out_mean_stride < D))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_fwd: row stride smaller than row");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: activation");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, attn,
-           N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed};
-  int T, R;
-  const bool vec = (D % 4 == 0) && pick_team(HD, T, R) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
-                   vec_ok(res, res_stride) && vec_ok(bias, 0);
+  GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
+           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed};
+  int T = 0, R = 0, CH = 0, W = 0;
+  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
+                   vec_ok(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
+  const bool fuse_mean = vec && out_mean && CH >= 1;
+  if (!fuse_mean && !out)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: `out` is required when the head mean cannot be fused "
+                                   "(see spgnn_gat_can_fuse_mean)");
   if (vec) {
     a.T = T;
-    DISPATCH_R(R, gat_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+    if (fuse_mean) {
+#define X(R_, CH_) hipLaunchKernelGGL((gat_fwd_vec<R_, CH_, true>), grid, block, 0, st, a)
+      SPGNN_FOR_R_CH(R, CH, X)
+#undef X
+    } else {
+      a.out_mean = nullptr;
+#define X(R_, CH_) hipLaunchKernelGGL((gat_fwd_vec<R_, CH_, false>), grid, block, 0, st, a)
+      SPGNN_FOR_R_CH(R, CH, X)
+#undef X
+    }
   } else {
     hipLaunchKernelGGL(gat_fwd_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   }
+  if (out_mean && !fuse_mean)
+    hipLaunchKernelGGL(head_mean_scalar, dim3(scalar_grid(N * D)), dim3(kBlock), 0, st, out, out_stride, out_mean,
+                       out_mean_stride, N, H, D);
   return check_launch("spgnn_gat_fwd");
 }
 
 int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
                       const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
-                      int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre, int64_t g_pre_stride,
-                      float* g_e, float* g_er, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t D,
-                      float negative_slope, int32_t activation, float p_drop, uint64_t seed, spgnn_stream_t stream) {
+                      int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
+                      int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N, int64_t E,
+                      int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop, uint64_t seed,
+                      spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
@@ -662,44 +851,26 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
       (activation != SPGNN_ACT_NONE && !out))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_dst: null pointer");
   const int64_t HD = (int64_t)H * D;
-  if (ft_stride < HD || g_out_stride < HD || g_pre_stride < HD || s_stride < H || g_s_stride < H ||
+  if (ft_stride < HD || g_out_stride < (mean_heads ? D : HD) || g_pre_stride < HD || s_stride < H || g_s_stride < H ||
       (activation != SPGNN_ACT_NONE && out_stride < HD))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_dst: row stride smaller than row");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
-              g_pre, g_pre_stride, g_e, g_er, g_s_stride, N, H, D, 0, 0, negative_slope, activation, p_drop,
-              1.f / (1.f - p_drop), seed};
-  int T = 0, R = 0, CH = -1;
-  bool vec = (D % 4 == 0) && pick_team(HD, T, R) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
-             vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
+              g_pre, g_pre_stride, g_e, g_er, g_s_stride, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
+              activation, p_drop, 1.f / (1.f - p_drop), seed};
+  int T = 0, R = 0, CH = 0, W = 0;
+  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
+                   vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
   if (vec) {
-    const int team_floats = 4 * T;
-    if (D % team_floats == 0) {
-      CH = D / team_floats;
-      if (!(CH == 1 || CH == 2 || CH == 4 || CH == 8) || R % CH) vec = false;
-    } else if (team_floats % D == 0 && ((D / 4) & (D / 4 - 1)) == 0) {
-      CH = 0; a.W = D / 4;
-    } else {
-      vec = false;
-    }
-  }
-  if (vec) {
-    a.T = T;
+    a.T = T; a.W = W;
     const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
-#define L(R_, CH_) hipLaunchKernelGGL((gat_bwd_dst_vec<R_, CH_>), grid, block, 0, st, a)
-    switch (R * 16 + CH) {
-      case 1 * 16 + 0: L(1, 0); break;  case 1 * 16 + 1: L(1, 1); break;
-      case 2 * 16 + 0: L(2, 0); break;  case 2 * 16 + 1: L(2, 1); break;  case 2 * 16 + 2: L(2, 2); break;
-      case 4 * 16 + 0: L(4, 0); break;  case 4 * 16 + 1: L(4, 1); break;  case 4 * 16 + 2: L(4, 2); break;
-      case 4 * 16 + 4: L(4, 4); break;
-      case 8 * 16 + 0: L(8, 0); break;  case 8 * 16 + 1: L(8, 1); break;  case 8 * 16 + 2: L(8, 2); break;
-      case 8 * 16 + 4: L(8, 4); break;  case 8 * 16 + 8: L(8, 8); break;
-      default: vec = false; break;
-    }
-#undef L
+#define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_dst_vec<R_, CH_>), grid, block, 0, st, a)
+    SPGNN_FOR_R_CH(R, CH, X)
+#undef X
+  } else {
+    hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
   }
-  if (!vec) hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
   return check_launch("spgnn_gat_bwd_dst");
 }
 
@@ -718,10 +889,13 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
               N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed};
-  int T, R;
-  if ((D % 4 == 0) && pick_team(HD, T, R) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
+  int T = 0, R = 0, CH = 0, W = 0;
+  if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
     a.T = T;
-    DISPATCH_R(R, gat_bwd_src_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+#define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_src_vec<R_, CH_>), grid, block, 0, st, a)
+    SPGNN_FOR_R_CH(R, CH, X)
+#undef X
   } else {
     hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   }

@@ -79,13 +79,13 @@ class GAT(nn.Module):
         h = g.ndata["fvs"]
         for layer in self.gat_layers[:-1]:
             h = layer(g, h).flatten(1)
-        return self._finish(self.gat_layers[-1](g, h).mean(1))
+        return self._finish(self.gat_layers[-1](g, h, mean_heads=True))
 
     def forward_batch(self, blocks, x):
         h = x
         for layer, block in zip(self.gat_layers[:-1], blocks[:-1]):
             h = layer(block, h).flatten(1)
-        return self._finish(self.gat_layers[-1](blocks[-1], h).mean(1))
+        return self._finish(self.gat_layers[-1](blocks[-1], h, mean_heads=True))
 
 
 def _gin_mlp(n_in, n_out):
@@ -149,7 +149,7 @@ class GATPSPGNN(nn.Module):
         for s_layer, p_layer in zip(self.gat_layers[:-1], self.pgnn_layers):
             h_s = s_layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
             h_p = p_layer(g, h_p).flatten(1)
-        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1)).mean(1)
+        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1), mean_heads=True)
         return h_s, h_p
 
 
@@ -179,7 +179,7 @@ class GATPSPGNNNL(nn.Module):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for layer in self.gat_layers[:-1]:
             h_s = layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
-        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1)).mean(1)
+        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1), mean_heads=True)
         return h_s, h_p
 
 

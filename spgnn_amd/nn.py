@@ -95,7 +95,9 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False):
+        """DGL signature; ``mean_heads=True`` (extension) returns ``rst.mean(1)`` (N, D) with the mean fused
+        into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482)."""
         csc = graph.csc(feat.device)
         if not self._allow_zero_in_degree and csc.min_in_degree == 0:
             raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
@@ -114,9 +116,11 @@ class GATConv(nn.Module):
                           torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
+        fuse_mean = mean_heads and fuse_epilogue
         out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
-                                  float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed)
-        rst = out.view(-1, H, D)
+                                  float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed,
+                                  mean=fuse_mean)
+        rst = out if fuse_mean else out.view(-1, H, D)
         if not fuse_epilogue:
             if identity_res:
                 rst = rst + h.view(h.shape[0], -1, D)
@@ -124,6 +128,8 @@ class GATConv(nn.Module):
                 rst = rst + self.bias.view(1, H, D)
             if self.activation is not None:
                 rst = self.activation(rst)
+        if mean_heads and not fuse_mean:
+            rst = rst.mean(1)
         if get_attention:
             a = torch.empty_like(attn)
             a[csc.eid.long()] = attn                   # CSC slot order -> edge id order

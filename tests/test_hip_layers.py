@@ -65,6 +65,28 @@ def test_gatconv_forward_backward(fin, H, D, res, act):
     assert rel_err(out, ref64) < max(4 * rel_err(ref, ref64), 2e-6)
 
 
+@pytest.mark.parametrize("fin,H,D,act", [(192, 2, 1024, F.elu), (128, 2, 1024, None), (64, 2, 256, torch.tanh),
+                                          (32, 8, 256, F.elu), (24, 2, 64, F.elu), (10, 3, 5, None), (16, 1, 128, F.elu)])
+def test_gatconv_fused_head_mean(fin, H, D, act):
+    """mean_heads=True == rst.mean(1) (reference models.py:327, 482), forward and gradients; covers the fused
+    epilogue (head >= team), the unfused geometries and the scalar fallback."""
+    torch.manual_seed(H * 100 + D)
+    g, src, dst, n = _graph([40, 150, 7], seed=D)
+    layer = snn.GATConv(fin, D, H, 0.0, 0.0, 0.2, True, act).cuda()
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    x = torch.randn(n, fin, device="cuda", requires_grad=True)
+    out = layer(g, x, mean_heads=True)
+    ref, _, xo, sd = _oracle_gat(layer, src, dst, n, x, act)
+    ref = ref.mean(1)
+    assert out.shape == (n, D) and rel_err(out, ref) < FWD_TOL
+    cot = torch.randn(n, D)
+    (out * cot.cuda()).sum().backward(); (ref * cot).sum().backward()
+    assert rel_err(x.grad, xo.grad) < GRAD_TOL
+    for name, p in layer.named_parameters():
+        assert rel_err(p.grad, sd[name].grad) < GRAD_TOL, name
+
+
 def test_gatconv_high_degree_and_no_self_loops():
     """Star graph with 70 children (degree loops far beyond the airway 2..5) and a ring without
     self loops (non-symmetric in/out lists)."""
@@ -219,7 +241,7 @@ def test_sgd_momentum_step_matches_torch():
 def test_c_abi_argument_errors_are_reported():
     from spgnn_amd import _capi
     lib = _capi.load()
-    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 2, 4, 0.2, 0, 0.0, 0, 0) == -1   # null pointers
+    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 2, 4, 0.2, 0, 0.0, 0, 0) == -1   # null pointers
     assert b"null" in lib.spgnn_last_error()
-    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0) == -2  # bad shape
+    assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0) == -2  # bad shape
     assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op

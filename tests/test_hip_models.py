@@ -159,13 +159,13 @@ def test_full_batch_attention_rows_sum_to_one_and_linearity(big):
     torch.manual_seed(0)
     ft1, ft2 = torch.randn(N, H * D, device="cuda"), torch.randn(N, H * D, device="cuda")
     el, er = torch.randn(N, H, device="cuda"), torch.randn(N, H, device="cuda")
-    o1, attn = ops.gat_fwd_raw(csc, ft1, el, er, None, None, H, D, 0.2, 0)
-    o2, _ = ops.gat_fwd_raw(csc, ft2, el, er, None, None, H, D, 0.2, 0)
-    o12, _ = ops.gat_fwd_raw(csc, ft1 + ft2, el, er, None, None, H, D, 0.2, 0)
+    o1, _, attn = ops.gat_fwd_raw(csc, ft1, el, er, None, None, H, D, 0.2, 0)
+    o2 = ops.gat_fwd_raw(csc, ft2, el, er, None, None, H, D, 0.2, 0)[0]
+    o12 = ops.gat_fwd_raw(csc, ft1 + ft2, el, er, None, None, H, D, 0.2, 0)[0]
     assert rel_err(o12, o1 + o2) < 1e-5                             # linear in ft for fixed scores
     seg = torch.repeat_interleave(torch.arange(N, device="cuda"), (csc.indptr[1:] - csc.indptr[:-1]).long())
     sums = torch.zeros(N, H, device="cuda").index_add_(0, seg, attn)
     assert (sums - 1).abs().max().item() < 1e-5                     # softmax over in-neighbours
     const = torch.randn(1, H * D, device="cuda").expand(N, -1).contiguous()
-    oc, _ = ops.gat_fwd_raw(csc, const, el, er, None, None, H, D, 0.2, 0)
+    oc = ops.gat_fwd_raw(csc, const, el, er, None, None, H, D, 0.2, 0)[0]
     assert rel_err(oc, const) < 1e-5                                # constant rows: out == ft

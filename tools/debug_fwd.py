@@ -11,7 +11,7 @@ src, dst = torch.from_numpy(s), torch.from_numpy(d)
 for (H, D) in [(2,256),(8,64),(4,16),(8,256),(2,64),(4,64),(16,16)]:
     torch.manual_seed(0)
     ft = torch.randn(n, H*D, device="cuda"); el = torch.randn(n, H, device="cuda"); er = torch.randn(n, H, device="cuda")
-    out, attn = ops.gat_fwd_raw(csc, ft, el, er, None, None, H, D, 0.2, 0)
+    out, _, attn = ops.gat_fwd_raw(csc, ft, el, er, None, None, H, D, 0.2, 0)
     e = torch.nn.functional.leaky_relu(el.cpu()[src] + er.cpu()[dst], 0.2)
     a = O.edge_softmax(dst, e, n)
     ref = O.spmm_sum(src, dst, ft.cpu().view(n, H, D), n, a.unsqueeze(-1))

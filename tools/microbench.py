@@ -46,7 +46,7 @@ def main():
         y = torch.randn(N, 2 * HD, device=dev)
         s = torch.randn(N, 2 * H, device=dev)
         bias = torch.zeros(HD, device=dev)
-        out, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU)
+        out, _, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU)
         t_f = timeit(lambda: ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, out=out))
         g_out = torch.randn(N, HD, device=dev)
         g_y = torch.empty_like(y); g_s = torch.empty_like(s)
