@@ -49,6 +49,15 @@ def algorithmic_bytes(key) -> float:
     if name == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
         _, N, E, H, D = key
         return 4 * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+    if name == "scores_fwd":         # read x; write S
+        _, N, K, J = key
+        return 4 * N * K + 4 * N * J
+    if name == "scores_bwd_w":       # read x, gS; partials negligible
+        _, N, K, J = key
+        return 4 * N * K + 4 * N * J
+    if name == "scores_bwd_x":       # read + write gX; read gS
+        _, N, K, J = key
+        return 4 * 2 * N * K + 4 * N * J
     if name == "spmm_sum":
         _, N, E, F = key
         return 4 * 2 * N * F + 4 * (N + 1 + E)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 2
+#define SPGNN_ABI_VERSION 3
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -124,6 +124,27 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed,
                       spgnn_stream_t stream);
+
+/*
+ * Attention-score projections of GATConv: el = (fc(x) * attn_l).sum(-1), er likewise (reference call sites as
+ * spgnn_gat_fwd; DGL computes them with two elementwise multiplies + reductions over ft).  With the score
+ * vectors folded through fc, W[j,:] = sum_d attn[h,d] * fc.weight[h*D+d,:] (J = 2H rows: el heads, then er
+ * heads), they are one skinny projection of the layer input and its two gradients:
+ *
+ *   spgnn_scores_fwd    S[n,j]   = sum_k x[n,k] * w[j,k]
+ *   spgnn_scores_bwd_w  part[s,j,k] = sum_{n in row range s} gs[n,j] * x[n,k]   (caller sums over s)
+ *   spgnn_scores_bwd_x  gx[n,k] += sum_j gs[n,j] * w[j,k]
+ *
+ * w and part rows are zero-padded to Kp = 16*ceil(K/16) floats.  x / gx rows must be 16-byte aligned
+ * (stride % 4 == 0).  J <= 16 (fwd); J in {2,4,8,16} (bwd).
+ */
+int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
+                     float* s, int64_t s_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride,
+                       float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
+                       spgnn_stream_t stream);
+int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp,
+                       float* gx, int64_t gx_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 
 /*
  * Weighted-sum SpMM (DGL gspmm(copy_u, sum) with the degree normalisations of GraphConv

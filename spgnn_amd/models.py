@@ -21,9 +21,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .nn import GATConv, GINConv, GraphConv, SAGEConv
+from .ops import cat_padded
 
 __all__ = ["GCN", "GAT", "GIN", "SAGE", "GATPSPGNN", "GATPSPGNNNL", "GCNNet", "GATNet", "GINNet", "SAGENet",
            "GATPositionSPGNNNet", "set_trainable"]
+
+
+def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=1) (reference models.py:477, 481, 534, 537) with 16-byte-aligned rows on the GPU."""
+    return cat_padded((a, b)) if a.is_cuda else torch.cat([a, b], dim=1)
 
 
 def set_trainable(model: nn.Module, trainable: bool) -> None:
@@ -147,9 +153,9 @@ class GATPSPGNN(nn.Module):
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for s_layer, p_layer in zip(self.gat_layers[:-1], self.pgnn_layers):
-            h_s = s_layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
+            h_s = s_layer(g, _cat(h_s, h_p)).flatten(1)
             h_p = p_layer(g, h_p).flatten(1)
-        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1), mean_heads=True)
+        h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
         return h_s, h_p
 
 
@@ -178,8 +184,8 @@ class GATPSPGNNNL(nn.Module):
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for layer in self.gat_layers[:-1]:
-            h_s = layer(g, torch.cat([h_s, h_p], dim=1)).flatten(1)
-        h_s = self.gat_layers[-1](g, torch.cat([h_s, h_p], dim=1), mean_heads=True)
+            h_s = layer(g, _cat(h_s, h_p)).flatten(1)
+        h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
         return h_s, h_p
 
 

@@ -172,6 +172,93 @@ def _dw_gemm(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return part
 
 
+def _rows_aligned(t: torch.Tensor) -> bool:
+    return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def _pad16(k: int) -> int:
+    return (k + 15) // 16 * 16
+
+
+def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor) -> torch.Tensor:
+    """S = x @ w_lr^T (N, J), J = 2H: the MFMA streaming kernel when the rows of x are 16-byte aligned and
+    J <= 16, rocBLAS otherwise."""
+    N, K = x.shape
+    J = w_lr.shape[0]
+    if not (_rows_aligned(x) and J <= 16) or N == 0:
+        return torch.mm(x, w_lr.t())
+    Kp = _pad16(K)
+    w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
+    s = torch.empty((N, J), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("scores_fwd", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_fwd(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
+                                                  N, K, J, _stream(x)), "spgnn_scores_fwd")
+    return s
+
+
+def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g_w_lr = g_s^T @ x (J, K)."""
+    N, K = x.shape
+    J = g_s.shape[1]
+    if not (_rows_aligned(x) and J in (2, 4, 8, 16)) or N == 0:
+        return torch.mm(g_s.t(), x)
+    Kp = _pad16(K)
+    splits = max(1, min(4096 // ((K + 255) // 256), N // 16))      # ~4k waves in flight; partials stay < 20 MB
+    part = torch.empty((splits, J, Kp), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("scores_bwd_w", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_bwd_w(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0),
+                                                    part.data_ptr(), splits, Kp, N, K, J, _stream(x)),
+                    "spgnn_scores_bwd_w")
+    return part.sum(0)[:, :K]
+
+
+def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor) -> None:
+    """g_x += g_s @ w_lr, in place."""
+    N, K = g_x.shape
+    J = g_s.shape[1]
+    if not (_rows_aligned(g_x) and J in (2, 4, 8, 16)) or N == 0:
+        g_x.addmm_(g_s, w_lr)
+        return
+    Kp = _pad16(K)
+    w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
+    with torch.cuda.device(g_x.device), _timed("scores_bwd_x", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_bwd_x(g_s.data_ptr(), g_s.stride(0), w_p.data_ptr(), Kp, g_x.data_ptr(),
+                                                    g_x.stride(0), N, K, J, _stream(g_x)), "spgnn_scores_bwd_x")
+
+
+class _CatPad(torch.autograd.Function):
+    """cat(tensors, dim=1) into a buffer whose row stride is rounded up to 4 floats (16-byte rows for the
+    vector kernels and aligned GEMM operands, e.g. 1063 -> 1064 for the first SPGNN layer); returns the
+    (N, F) view.  Backward hands out column views of the incoming gradient (no copies)."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        widths = [t.shape[1] for t in tensors]
+        F_ = sum(widths)
+        Fp = (F_ + 3) // 4 * 4
+        buf = torch.empty((tensors[0].shape[0], Fp), dtype=torch.float32, device=tensors[0].device)
+        off = 0
+        for t in tensors:
+            buf[:, off:off + t.shape[1]].copy_(t)
+            off += t.shape[1]
+        if Fp > F_:
+            buf[:, F_:].zero_()
+        ctx.widths = widths
+        return buf[:, :F_]
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w, need in zip(ctx.widths, ctx.needs_input_grad):
+            outs.append(g[:, off:off + w] if need else None)
+            off += w
+        return tuple(outs)
+
+
+def cat_padded(tensors) -> torch.Tensor:
+    return _CatPad.apply(*tensors)
+
+
 class _GATLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_cat, w_lr, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
@@ -179,7 +266,7 @@ class _GATLayerFn(torch.autograd.Function):
         HD = H * D
         x = _rowmajor(x)
         y = torch.mm(x, w_cat.t())                     # (N, HD [+HD])  = [ft | res]
-        s = torch.mm(x, w_lr.t())                      # (N, 2H)        = [el | er]
+        s = scores_fwd(x, w_lr)                        # (N, 2H)        = [el | er]
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
         out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed,
@@ -196,7 +283,7 @@ class _GATLayerFn(torch.autograd.Function):
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
         HD = H * D
-        N = x.shape[0]
+        N, K = x.shape
         g_out = _rowmajor(g_out)
         g_y = torch.empty_like(y)
         g_s = torch.empty_like(s)
@@ -205,11 +292,13 @@ class _GATLayerFn(torch.autograd.Function):
                     g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean)
         g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
         g_wcat = _dw_gemm(g_y, x) if ctx.needs_input_grad[1] else None
-        g_wlr = torch.mm(g_s.t(), x) if ctx.needs_input_grad[2] else None
+        g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[2] else None
         g_x = None
         if ctx.needs_input_grad[0]:
-            g_x = torch.mm(g_y, w_cat)
-            g_x.addmm_(g_s, w_lr)
+            Kp = (K + 3) // 4 * 4                      # 16-byte rows for the in-place score-gradient pass
+            g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
+            torch.mm(g_y, w_cat, out=g_x)
+            scores_bwd_x_(g_x, g_s, w_lr)
         return g_x, g_wcat, g_wlr, g_bias, None, None, None, None, None, None, None, None, None
 
 

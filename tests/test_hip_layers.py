@@ -245,3 +245,26 @@ def test_c_abi_argument_errors_are_reported():
     assert b"null" in lib.spgnn_last_error()
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0) == -2  # bad shape
     assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op
+
+
+@pytest.mark.parametrize("K,J", [(1063, 4), (1064, 4), (39, 2), (768, 4), (192, 4), (256, 2), (64, 16), (100, 8), (17, 4)])
+def test_score_projection_kernels(K, J):
+    """spgnn_scores_fwd / _bwd_w / _bwd_x against plain matmuls (ragged K tails, padded row strides)."""
+    torch.manual_seed(K + J)
+    N = 2531
+    buf = torch.randn(N, (K + 3) // 4 * 4 + 4, device="cuda")
+    x = buf[:, :K]                                         # 16-byte-aligned rows, stride > K
+    w = torch.randn(J, K, device="cuda")
+    s = ops.scores_fwd(x, w)
+    assert rel_err(s, x.double() @ w.double().t()) < 2e-6
+    gs = torch.randn(N, J, device="cuda")
+    assert rel_err(ops.scores_bwd_w(gs, x), gs.double().t() @ x.double()) < 2e-6
+    gbuf = torch.randn(N, (K + 3) // 4 * 4, device="cuda")
+    gx = gbuf[:, :K]
+    ref = gx.double() + gs.double() @ w.double()
+    ops.scores_bwd_x_(gx, gs, w)
+    assert rel_err(gx, ref) < 2e-6
+    if gbuf.shape[1] > K:
+        assert torch.isfinite(gbuf).all()
+    xu = torch.randn(N, K, device="cuda")                  # unaligned rows (K odd) fall back to rocBLAS
+    assert rel_err(ops.scores_fwd(xu, w), xu.double() @ w.double().t()) < 2e-6
