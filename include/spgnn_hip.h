@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 3
+#define SPGNN_ABI_VERSION 4
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -184,6 +184,36 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
                        float* g_x, int64_t g_x_stride,
                        int64_t N, int64_t E, int32_t F,
                        spgnn_stream_t stream);
+
+/*
+ * fp32-accurate projection GEMM on the fp16 matrix cores (replaces the cuBLAS/rocBLAS SGEMMs behind
+ * nn.Linear `fc` / `res_fc` inside DGL's GATConv, reference models.py:301-314, and their input gradients):
+ *
+ *   C[M,N] = A[M,K] * B[N,K]^T            A, B, C fp32 row-major with row strides lda, ldb, ldc
+ *
+ * Every operand value is split on the fly into two fp16 terms after multiplication by a per-tensor
+ * power-of-two scale (*scale_a, *scale_b: device scalars from spgnn_pow2_scale, or NULL = 1) and the three
+ * leading products are accumulated in fp32 (v_mfma_f32_32x32x16_f16); the result carries fp32-GEMM accuracy.
+ * A and B rows must be 16-byte aligned (lda, ldb multiples of 4); K may be ragged.
+ */
+int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                  int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
+                  spgnn_stream_t stream);
+
+/*
+ * Weight-gradient form: C[M,N] = A[R,M]^T * B[R,N] with the reduction over the R rows (nodes) of both
+ * operands (A = g_Y, B = X; replaces the SGEMM-TN behind nn.Linear's weight gradient).  The row range is
+ * cut into `splits` chunks, chunk s writing its partial product to C + s*split_stride (each M x ldc);
+ * the caller sums the partials (splits == 1: C is the result).  Same split-fp16 arithmetic as spgnn_gemm_nt.
+ */
+int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                  int64_t split_stride, int32_t splits, int64_t R, int64_t M, int64_t N,
+                  const float* scale_a, const float* scale_b, spgnn_stream_t stream);
+
+/* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
+ * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */
+int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t cols, float* scale,
+                     float* workspace, int32_t workspace_floats, spgnn_stream_t stream);
 
 /*
  * SGD with momentum over one flat fp32 parameter bucket (torch.optim.SGD semantics, dampening 0,

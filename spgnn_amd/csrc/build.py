@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libspgnn_hip.so")
-SOURCES = [os.path.join(HERE, "spgnn_kernels.hip")]
+SOURCES = [os.path.join(HERE, "spgnn_kernels.hip"), os.path.join(HERE, "spgnn_gemm.hip")]
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

@@ -110,6 +110,8 @@ class GATConv(nn.Module):
         fuse_epilogue = act is not None and not identity_res
         w_fc = self.fc.weight
         w_cat = torch.cat([w_fc, self.res_fc.weight], dim=0) if has_res else w_fc
+        if w_cat.shape[1] % 4:                          # 16-byte rows for the matrix-core GEMM (e.g. 1063 -> 1064)
+            w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
         w3 = w_fc.view(H, D, -1)
         w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),

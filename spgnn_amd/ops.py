@@ -18,7 +18,13 @@ import torch
 from . import _capi
 from .graph import DeviceCSC
 
+import os
+
 ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+
+# Projection GEMMs: "f16x3" = hand-written split-fp16 MFMA kernels (spgnn_gemm.hip; fp32-GEMM accuracy, the
+# default), "fp32" = rocBLAS/hipBLASLt SGEMM through torch.mm.
+GEMM_MODE = os.environ.get("SPGNN_GEMM", "f16x3")
 
 
 class KernelTimer:
@@ -265,7 +271,13 @@ class _GATLayerFn(torch.autograd.Function):
                 p_drop: float, seed: int, mean: bool):
         HD = H * D
         x = _rowmajor(x)
-        y = torch.mm(x, w_cat.t())                     # (N, HD [+HD])  = [ft | res]
+        split = GEMM_MODE == "f16x3" and _rows_aligned(x) and _rows_aligned(w_cat) and x.shape[0] > 0
+        if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
+            sx = pow2_scale(x)
+            y = gemm_nt(x, w_cat, sx, pow2_scale(w_cat))
+        else:
+            sx = None
+            y = torch.mm(x, w_cat.t())
         s = scores_fwd(x, w_lr)                        # (N, 2H)        = [el | er]
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
@@ -273,13 +285,13 @@ class _GATLayerFn(torch.autograd.Function):
                                           mean=mean, need_out=(act != ACT_NONE))
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx)
         ctx.mark_non_differentiable(attn)
         return (out_mean if mean else out), attn
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
-        x, w_cat, w_lr, y, s, attn, out = ctx.saved_tensors
+        x, w_cat, w_lr, y, s, attn, out, sx = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
         HD = H * D
@@ -291,13 +303,21 @@ class _GATLayerFn(torch.autograd.Function):
         gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
                     g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean)
         g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        g_wcat = _dw_gemm(g_y, x) if ctx.needs_input_grad[1] else None
+        split = sx is not None
+        sg = pow2_scale(g_y) if split else None
+        g_wcat = None
+        if ctx.needs_input_grad[1]:
+            g_wcat = gemm_tn(g_y, x, sg, sx) if split else _dw_gemm(g_y, x)
         g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[2] else None
         g_x = None
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4                      # 16-byte rows for the in-place score-gradient pass
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
-            torch.mm(g_y, w_cat, out=g_x)
+            if split:
+                w_t = w_cat.t().contiguous()           # (K, C): the input gradient is an NT product with W^T
+                gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x)
+            else:
+                torch.mm(g_y, w_cat, out=g_x)
             scores_bwd_x_(g_x, g_s, w_lr)
         return g_x, g_wcat, g_wlr, g_bias, None, None, None, None, None, None, None, None, None
 
@@ -404,3 +424,56 @@ def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tenso
         _capi.check(lib.spgnn_sgd_momentum_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), _ptr(grad_scale),
                                                 param.numel(), lr, momentum, weight_decay, int(first_step),
                                                 _stream(param)), "spgnn_sgd_momentum_step")
+
+
+# --------------------------------------------------------------------------------------------
+# fp32-accurate GEMM on the fp16 matrix cores (spgnn_gemm.hip)
+# --------------------------------------------------------------------------------------------
+def pow2_scale(x: torch.Tensor) -> torch.Tensor:
+    """Device scalar 2^(14 - e), max|x| <= 2^e: centres the tensor in the fp16 range for the split GEMM."""
+    _require_cuda(x)
+    assert x.dim() == 2 and x.dtype == torch.float32
+    if not _rows_aligned(x):
+        x = x.contiguous() if x.shape[1] % 4 == 0 else torch.nn.functional.pad(x, (0, 4 - x.shape[1] % 4))
+    buf = torch.empty(1 + 2048, dtype=torch.float32, device=x.device)        # [scale | per-block partial maxima]
+    with torch.cuda.device(x.device), _timed("absmax", (x.shape[0], x.shape[1])):
+        _capi.check(_capi.load().spgnn_pow2_scale(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], buf.data_ptr(),
+                                                  buf[4:].data_ptr(), 2044, _stream(x)), "spgnn_pow2_scale")
+    return buf[:1]
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+            scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a (M,K) @ b (N,K)^T -> (M,N), fp32 in/out, fp16x3 split on the matrix cores."""
+    _require_cuda(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and _rows_aligned(a) and _rows_aligned(b)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
+        _capi.check(_capi.load().spgnn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                               out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _stream(a)),
+                    "spgnn_gemm_nt")
+    return out
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+            scale_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
+    over row chunks with a deterministic partial-sum reduction."""
+    _require_cuda(a, b)
+    R, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = max(1, min(256, 1024 // tiles, R // 128))
+    ldc = (N + 3) // 4 * 4
+    part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _timed("gemm_tn", (R, M, N)):
+        _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
+                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), _stream(a)),
+                    "spgnn_gemm_tn")
+    out = part[0] if splits == 1 else part.sum(0)
+    return out[:, :N]
