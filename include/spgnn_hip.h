@@ -200,6 +200,10 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   spgnn_stream_t stream);
 
+/* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined (default), 3 = pipelined with
+ * 128-row tiles only.  Returns the previous setting.  For A/B measurements. */
+int spgnn_gemm_set_variant(int32_t variant);
+
 /*
  * Weight-gradient form: C[M,N] = A[R,M]^T * B[R,N] with the reduction over the R rows (nodes) of both
  * operands (A = g_Y, B = X; replaces the SGEMM-TN behind nn.Linear's weight gradient).  The row range is

@@ -36,6 +36,7 @@ SIGNATURES = {
     "spgnn_spmm_max_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _i32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _vp],
+    "spgnn_gemm_set_variant": [_i32],
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
     "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],

@@ -171,6 +171,228 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_f16x3(Args a) {
 
 
 // -------------------------------------------------------------------------------------------------
+// NT kernel, second generation: (64*WM) x 128 block tile, 2*WM waves, double-buffered LDS, ONE barrier per
+// stage, and the fp32 -> fp16 hi/lo conversion of stage t+1 issued between the MFMAs of stage t (an MFMA
+// occupies the vector issue port for 8 of its 32 cycles, so ~5 VALU instructions per MFMA are free).
+// Global fp32 data is prefetched two stages ahead into two register sets.  Conversion is packed:
+//   hi = cvt_pkrtz(x),  float(hi) = x & 0xFFFFE000 (round-toward-zero keeps the top 11 significand bits),
+//   lo = cvt_pkrtz(x - float(hi))          -> 16 VALU ops per float4 instead of ~24.
+// LDS stores pair rows r and r+4 in each 16-lane group so the two 64-byte row pieces of a ds_write_b64
+// fall in different halves of the 128-byte store bank window (pitch 80 B: 4*80 = 64 mod 128).
+// -------------------------------------------------------------------------------------------------
+typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+
+#ifndef SPGNN_GEMM_ABLATE
+#define SPGNN_GEMM_ABLATE 0      // timing-only builds: 1 = no split arithmetic, 2 = no MFMA, 3 = no global loads in the loop, 4 = no LDS stores
+#endif
+__device__ __forceinline__ void split4_pk(float4 v, float s, uint2& hi, uint2& lo) {
+#if SPGNN_GEMM_ABLATE == 1
+  hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); lo = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); return;
+#endif
+  const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+  union { pk2 h; unsigned u; } h01, h23, l01, l23;
+  h01.h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  h23.h = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+  const float f0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u), f1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
+  const float f2 = __uint_as_float(__float_as_uint(x2) & 0xFFFFE000u), f3 = __uint_as_float(__float_as_uint(x3) & 0xFFFFE000u);
+  l01.h = __builtin_amdgcn_cvt_pkrtz(x0 - f0, x1 - f1);
+  l23.h = __builtin_amdgcn_cvt_pkrtz(x2 - f2, x3 - f3);
+  hi = make_uint2(h01.u, h23.u);
+  lo = make_uint2(l01.u, l23.u);
+}
+
+// natural row q (0..ROWS-1) of a tile -> stored/loaded row: inside each block of 8 rows interleave (0,4,1,5,2,6,3,7)
+__device__ __forceinline__ int pair_row(int q) { const int s_ = q & 7; return (q & ~7) | ((s_ >> 1) + 4 * (s_ & 1)); }
+
+template <int ROWS, int NT>    // ROWS x 32 fp32 tile, NT threads: NL = ROWS*8/NT float4 per thread
+struct TileIO {
+  static constexpr int NL = ROWS * 8 / NT;
+  // Interior stages (k0 + 32 <= K): unconditional 16-byte loads.  Rows past the end are clamped to the last
+  // row: they only feed output rows/columns that the epilogue never stores.  (A per-load bounds branch makes
+  // hipcc wait for every load separately - the loads of a stage must issue back to back.)
+  static __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
+                                              float4 (&r)[NL]) {
+    if (k0 + BK <= K) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int idx = threadIdx.x + NT * i;
+        int row = row0 + pair_row(idx >> 3);
+        row = row < nrows ? row : nrows - 1;
+        r[i] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + (idx & 7) * 4);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {                      // ragged last stage: branch-free, zero beyond K.  Rows are
+      const int idx = threadIdx.x + NT * i;             // 16-byte multiples (ld % 4 == 0), so a float4 that starts
+      int row = row0 + pair_row(idx >> 3);              // below K lies inside the row's stride.
+      row = row < nrows ? row : nrows - 1;
+      const int k = k0 + (idx & 7) * 4;
+      const int kc = k < K ? k : 0;
+      float4 v = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + kc);
+      v.x = k + 0 < K ? v.x : 0.f;
+      v.y = k + 1 < K ? v.y : 0.f;
+      v.z = k + 2 < K ? v.z : 0.f;
+      v.w = k + 3 < K ? v.w : 0.f;
+      r[i] = v;
+    }
+  }
+  // convert + store float4 #i (called between MFMAs)
+  static __device__ __forceinline__ void store_one(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
+    const int idx = threadIdx.x + NT * i;
+    const int off = pair_row(idx >> 3) * PITCH + (idx & 7) * 4;
+    uint2 h, l;
+    split4_pk(v, s, h, l);
+#if SPGNN_GEMM_ABLATE == 4
+    if (h.x == 0x12345678u) *reinterpret_cast<uint2*>(hi_img + off) = l;
+    return;
+#endif
+    *reinterpret_cast<uint2*>(hi_img + off) = h;
+    *reinterpret_cast<uint2*>(lo_img + off) = l;
+  }
+};
+
+template <int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
+  constexpr int TBM = 64 * WM, NT = 128 * WM;
+  constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
+  constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;                 // halves per stage: Ah | Al | Bh | Bl
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  using AIO = TileIO<TBM, NT>;
+  using BIO = TileIO<BN, NT>;
+  constexpr int NLA = AIO::NL, NLB = BIO::NL;
+
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
+  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
+  const int bm = tile / a.nbn, bn = tile % a.nbn;
+  const int row0 = bm * TBM, col0 = bn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  float4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];             // two prefetch sets (stage parity)
+
+  // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
+  AIO::load(a.A, a.lda, row0, a.M, 0, a.K, ra0);
+  BIO::load(a.B, a.ldb, col0, a.N, 0, a.K, rb0);
+  if (nk > 1) {
+    AIO::load(a.A, a.lda, row0, a.M, BK, a.K, ra1);
+    BIO::load(a.B, a.ldb, col0, a.N, BK, a.K, rb1);
+  }
+  {
+    _Float16* st = smem;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) AIO::store_one(st, st + A_IMG, ra0[i], i, sA);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) BIO::store_one(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
+  }
+  __syncthreads();
+
+  // one stage: MFMAs on buffer `cur`; convert register set (RA, RB) = stage t+1 into buffer `cur^1`;
+  // then refill that register set with stage t+3's... (stage t+2 lives in the other set)
+#define SPGNN_STAGE(T_, RA, RB)                                                                              \
+  {                                                                                                          \
+    const _Float16* cb = smem + ((T_) & 1) * STAGE;                                                          \
+    _Float16* nbuf = smem + (((T_) + 1) & 1) * STAGE;                                                        \
+    const bool has_next = (T_) + 1 < nk;                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
+      half8 ah[2], al[2], bh[2], bl[2];                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+        const int off = (wm * 64 + i * 32 + fr) * PITCH + ks * 16 + fh * 8;                                  \
+        ah[i] = *reinterpret_cast<const half8*>(cb + off);                                                   \
+        al[i] = *reinterpret_cast<const half8*>(cb + A_IMG + off);                                           \
+      }                                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+        const int off = (wn * 64 + j * 32 + fr) * PITCH + ks * 16 + fh * 8;                                  \
+        bh[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + off);                                       \
+        bl[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + B_IMG + off);                               \
+      }                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+          if (SPGNN_GEMM_ABLATE != 2) {                                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);              \
+          } else { acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1]; }    \
+          if (has_next) { /* a slice of next stage's conversion after each accumulator group */             \
+            const int slot = (ks * 4 + i * 2 + j);                                                           \
+            _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                  \
+              if (q * 8 / NLA == slot || (NLA > 8 && q % 8 == slot))                                         \
+                AIO::store_one(nbuf, nbuf + A_IMG, RA[q], q, sA);                                            \
+            _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                  \
+              if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                         \
+                BIO::store_one(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                    \
+          }                                                                                                  \
+        }                                                                                                    \
+    }                                                                                                        \
+    if ((T_) + 3 < nk && SPGNN_GEMM_ABLATE != 3) {                                                            \
+      AIO::load(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                            \
+      BIO::load(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, a.K, RB);                                            \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+  }
+
+  // register set 1 holds stage 1 (odd stages), set 0 will hold stage 2 (even stages)
+  if (nk > 2) {
+    AIO::load(a.A, a.lda, row0, a.M, 2 * BK, a.K, ra0);
+    BIO::load(a.B, a.ldb, col0, a.N, 2 * BK, a.K, rb0);
+  }
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    SPGNN_STAGE(t, ra1, rb1)          // computes stage t (even), converts stage t+1 from set 1, refills set 1 with t+3
+    SPGNN_STAGE(t + 1, ra0, rb0)      // computes stage t+1 (odd), converts stage t+2 from set 0, refills set 0 with t+4
+  }
+  if (t < nk) SPGNN_STAGE(t, ra1, rb1)
+#undef SPGNN_STAGE
+
+  // Epilogue through LDS: an accumulator register holds one element of 32 different... columns of one row
+  // (32 lanes x 4 bytes), which stores as 128-byte pieces.  Each wave parks a 32 x 64 half of its tile in its
+  // own LDS slab (pitch 68 floats) and writes it out as whole 256-byte row segments with 16-byte stores.
+  // (All waves passed the last barrier of the K loop, so the stage buffers are free; slabs are wave-private.)
+  const float alpha = 1.f / (sA * sB);
+  constexpr int EP = 68;
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * EP);
+  const bool vec_ok = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        slab[((e & 3) + 8 * (e >> 2) + 4 * fh) * EP + j * 32 + fr] = acc[i][j][e] * alpha;
+    const int r_in = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 4 + r_in;
+      const int row = row0 + wm * 64 + i * 32 + lr;
+      const int col = col0 + wn * 64 + c4;
+      const float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
+      if (row < a.M) {
+        float* dst = a.C + (int64_t)row * a.ldc + col;
+        if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
+        else {
+          if (col < a.N) dst[0] = v.x;
+          if (col + 1 < a.N) dst[1] = v.y;
+          if (col + 2 < a.N) dst[2] = v.z;
+          if (col + 3 < a.N) dst[3] = v.w;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 //   spgnn_gemm_tn : C[M,N] = A[R,M]^T * B[R,N]     (weight gradients: A = g_Y, B = X, R = node count)
 //
 // The reduction runs over the ROW index of both operands, so global tiles arrive k-major (32 rows x 128
@@ -199,17 +421,26 @@ struct ArgsTN {
 // one 32 x 128 fp32 tile = 1024 float4; thread t takes float4 #(t + 256 i): row = idx / 32, c4 = idx % 32
 __device__ __forceinline__ void load_tile_t(const float* __restrict__ base, int64_t ld, int64_t r0, int64_t rend, int c0,
                                             int ncols, float4 (&r)[4]) {
+  if (r0 + TBK <= rend && c0 + BM <= ncols) {          // interior tile: unconditional back-to-back loads
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + kThreads * i;
-    const int64_t row = r0 + (idx >> 5);
-    const int c = c0 + (idx & 31) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rend && c < ncols) {
-      const float* p = base + row * ld + c;
-      if (c + 3 < ncols) v = *reinterpret_cast<const float4*>(p);
-      else { v.x = p[0]; if (c + 1 < ncols) v.y = p[1]; if (c + 2 < ncols) v.z = p[2]; }
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + kThreads * i;
+      r[i] = *reinterpret_cast<const float4*>(base + (r0 + (idx >> 5)) * ld + c0 + (idx & 31) * 4);
     }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                         // edge tile, branch-free: rows past the range and columns
+    const int idx = threadIdx.x + kThreads * i;         // past the width contribute zeros (ld % 4 == 0: a float4
+    const int64_t row = r0 + (idx >> 5);                // that starts inside the width lies inside the stride)
+    const int c = c0 + (idx & 31) * 4;
+    const bool rv = row < rend;
+    const int cc = c < ncols ? c : 0;
+    float4 v = *reinterpret_cast<const float4*>(base + (rv ? row : rend - 1) * ld + cc);   // caller: rend > 0
+    v.x = rv && c + 0 < ncols ? v.x : 0.f;
+    v.y = rv && c + 1 < ncols ? v.y : 0.f;
+    v.z = rv && c + 2 < ncols ? v.z : 0.f;
+    v.w = rv && c + 3 < ncols ? v.w : 0.f;
     r[i] = v;
   }
 }
@@ -268,8 +499,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float4 ra[4], rb[4];
-  load_tile_t(a.A, a.lda, r_beg, r_end, m0, a.M, ra);
-  load_tile_t(a.B, a.ldb, r_beg, r_end, n0, a.N, rb);
+  if (r_beg < r_end) {                                   // an empty split (rows rounded up) only writes zeros
+    load_tile_t(a.A, a.lda, r_beg, r_end, m0, a.M, ra);
+    load_tile_t(a.B, a.ldb, r_beg, r_end, n0, a.N, rb);
+  }
   for (int64_t r0 = r_beg; r0 < r_end; r0 += TBK) {
     __syncthreads();
     store_tile_t(Ah, Al, ra, sA);
@@ -358,6 +591,9 @@ __global__ void scale_from_partials(const float* __restrict__ partial, int n, fl
 
 extern "C" {
 
+static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
+int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v == 1 || v == 2 || v == 3) g_gemm_variant = v; return old; }
+
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, spgnn_stream_t stream) {
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
@@ -366,11 +602,29 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   if (lda < K || ldb < K || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15))
     return SPGNN_ERR_STRIDE;
-  gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-               (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN)};
-  int64_t tiles = (int64_t)a.nbm * a.nbn;
-  tiles = (tiles + 7) & ~int64_t(7);
-  hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (g_gemm_variant == 1) {
+    gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN)};
+    int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
+    hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
+  } else {
+    const int WM = (g_gemm_variant == 3 || M < 4096) ? 2 : 4;        // 128- or 256-row tiles
+    const int TBM = 64 * WM;
+    gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
+                 (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN)};
+    int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
+    const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
+    if (WM == 4) {
+      static bool attr4 = false;
+      if (!attr4) { hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
+      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
+    } else {
+      static bool attr2 = false;
+      if (!attr2) { hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
+      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
+    }
+  }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

@@ -307,7 +307,9 @@ class _GATLayerFn(torch.autograd.Function):
         sg = pow2_scale(g_y) if split else None
         g_wcat = None
         if ctx.needs_input_grad[1]:
-            g_wcat = gemm_tn(g_y, x, sg, sx) if split else _dw_gemm(g_y, x)
+            # tiny outputs (position stream, 39-wide inputs) leave the 128x128-tile kernel mostly idle: rocBLAS there
+            big = g_y.shape[1] * K >= 128 * 512
+            g_wcat = gemm_tn(g_y, x, sg, sx) if (split and big) else _dw_gemm(g_y, x)
         g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[2] else None
         g_x = None
         if ctx.needs_input_grad[0]:
@@ -468,7 +470,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     N = b.shape[1]
     assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, min(256, 1024 // tiles, R // 128))
+    splits = max(1, min(64, 512 // tiles, R // 256))
     ldc = (N + 3) // 4 * 4
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device), _timed("gemm_tn", (R, M, N)):

@@ -1,0 +1,68 @@
+"""The split-fp16 MFMA GEMMs (spgnn_gemm_nt / spgnn_gemm_tn) against fp64 products: exact on small-integer
+data (catches fragment-layout errors), fp32-GEMM accuracy on random data, ragged M/N/K tails, strided
+operands, scaled tensors far outside the fp16 range."""
+import pytest
+import torch
+
+from spgnn_amd import ops
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _mat(r, c, scale=1.0, ints=False):
+    cp = (c + 3) // 4 * 4 + 4                      # row stride > width, 16-byte aligned rows
+    buf = torch.randint(-8, 9, (r, cp), device="cuda").float() if ints else torch.randn(r, cp, device="cuda") * scale
+    return buf[:, :c]
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 7), (128, 128, 32), (129, 127, 33), (300, 200, 1063), (257, 129, 39),
+                                   (1000, 22, 1024), (64, 4096, 192)])
+def test_gemm_nt_exact_on_integers_and_accurate_on_random(M, N, K):
+    a, b = _mat(M, K, ints=True), _mat(N, K, ints=True)
+    assert torch.equal(ops.gemm_nt(a, b), a @ b.t())                     # products and sums exact in fp16/fp32
+    a, b = _mat(M, K), _mat(N, K, 0.05)
+    ref = a.double() @ b.double().t()
+    c = ops.gemm_nt(a, b, ops.pow2_scale(a), ops.pow2_scale(b))
+    assert rel_err(c, ref) < max(3 * rel_err(a @ b.t(), ref), 2e-6)      # fp32-GEMM class accuracy
+
+
+@pytest.mark.parametrize("R,M,N", [(1, 1, 1), (40, 7, 5), (100, 130, 33), (1000, 256, 128), (513, 64, 300), (4097, 1024, 39),
+                                   (76410, 256, 256), (16385, 128, 128), (300, 64, 64)])   # incl. empty trailing splits
+def test_gemm_tn_exact_on_integers_and_accurate_on_random(R, M, N):
+    a, b = _mat(R, M, ints=True), _mat(R, N, ints=True)
+    assert torch.equal(ops.gemm_tn(a, b), a.t() @ b)
+    a, b = _mat(R, M, 1e-5), _mat(R, N)                                   # gradient-sized values: need the scale
+    ref = a.double().t() @ b.double()
+    c = ops.gemm_tn(a, b, ops.pow2_scale(a), ops.pow2_scale(b))
+    assert rel_err(c, ref) < max(3 * rel_err(a.t() @ b, ref), 2e-6)
+
+
+def test_gemm_scaling_keeps_extreme_magnitudes():
+    """Values far outside fp16's range (1e-9 .. 1e+7) survive through the power-of-two scales."""
+    for mag_a, mag_b in [(1e-9, 1e-3), (1e7, 1e3), (1e-12, 1e6)]:
+        a, b = _mat(200, 96, mag_a), _mat(64, 96, mag_b)
+        sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+        assert float(sa) == 2.0 ** round(torch.log2(sa).item()) and torch.isfinite(sa)
+        c = ops.gemm_nt(a, b, sa, sb)
+        assert torch.isfinite(c).all() and rel_err(c, a.double() @ b.double().t()) < 2e-6
+    z = torch.zeros(8, 8, device="cuda")
+    assert float(ops.pow2_scale(z)) == 1.0                                # all-zero tensor: neutral scale
+    assert torch.equal(ops.gemm_nt(z, z, ops.pow2_scale(z), ops.pow2_scale(z)), z)
+
+
+def test_gemm_mode_switch_gives_same_layer_output(monkeypatch):
+    import torch.nn.functional as F
+    from spgnn_amd import nn as snn
+    from spgnn_amd.graph import TreeGraph
+    from tests.util import tree_batch_edges
+    s, d, n = tree_batch_edges([150, 99], 3)
+    g = TreeGraph((s, d), n).to("cuda")
+    torch.manual_seed(0)
+    layer = snn.GATConv(1063, 256, 2, residual=True, activation=F.elu).cuda()
+    x = ops.cat_padded((torch.randn(n, 1024, device="cuda"), torch.rand(n, 39, device="cuda")))
+    outs = {}
+    for mode in ("f16x3", "fp32"):
+        monkeypatch.setattr(ops, "GEMM_MODE", mode)
+        outs[mode] = layer(g, x)
+    assert rel_err(outs["f16x3"], outs["fp32"]) < 5e-6
