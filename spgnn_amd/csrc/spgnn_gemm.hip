@@ -592,7 +592,7 @@ __global__ void scale_from_partials(const float* __restrict__ partial, int n, fl
 extern "C" {
 
 static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
-int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v == 1 || v == 2 || v == 3) g_gemm_variant = v; return old; }
+int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 3) g_gemm_variant = v; return old; }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, spgnn_stream_t stream) {
@@ -609,7 +609,8 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
-    const int WM = (g_gemm_variant == 3 || M < 4096) ? 2 : 4;        // 128- or 256-row tiles
+    // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
+    const int WM = (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN)};
@@ -617,11 +618,11 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
       static bool attr4 = false;
-      if (!attr4) { hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
+      if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
     } else {
       static bool attr2 = false;
-      if (!attr2) { hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
+      if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
     }
   }
