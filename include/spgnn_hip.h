@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 4
+#define SPGNN_ABI_VERSION 5
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -104,6 +104,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
                       float* g_pre, int64_t g_pre_stride,
                       float* g_e,
                       float* g_er, int64_t g_s_stride,
+                      float* absmax /* nullable: absmax[v] = max|g_pre[v,:]| */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float negative_slope, int32_t activation,
                       float p_drop, uint64_t seed,
@@ -121,6 +122,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       const float* g_pre, int64_t g_pre_stride,
                       float* g_ft, int64_t g_ft_stride,
                       float* g_el, int64_t g_s_stride,
+                      float* absmax /* nullable: absmax[u] = max|g_ft[u,:]| */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed,
                       spgnn_stream_t stream);
@@ -139,7 +141,8 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
  * (stride % 4 == 0).  J <= 16 (fwd); J in {2,4,8,16} (bwd).
  */
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
-                     float* s, int64_t s_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+                     float* s, int64_t s_stride, float* absmax /* nullable: ceil(N/16) per-wave maxima of |x| */,
+                     int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride,
                        float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
                        spgnn_stream_t stream);
@@ -199,6 +202,10 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   spgnn_stream_t stream);
+
+/* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by
+ * spgnn_scores_fwd / spgnn_gat_bwd_dst / spgnn_gat_bwd_src (which stream the tensors anyway) into a GEMM scale. */
+int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, spgnn_stream_t stream);
 
 /* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined (default), 3 = pipelined with
  * 128-row tiles only.  Returns the previous setting.  For A/B measurements. */

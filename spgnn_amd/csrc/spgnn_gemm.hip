@@ -576,11 +576,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 // scale[0] = 2^(14 - e) with max <= 2^e ; optional multiplicative bound factor (e.g. 1/(1-p) for dropout)
-__global__ void scale_from_partials(const float* __restrict__ partial, int n, float factor, float* __restrict__ scale) {
+__global__ __launch_bounds__(1024) void scale_from_partials(const float* __restrict__ partial, int n, float factor, float* __restrict__ scale) {
+  __shared__ float red[16];
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, partial[i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, partial[i]);
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
     m *= factor;
     float s = 1.f;
     if (m > 0.f && m < INFINITY) { int e; frexpf(m, &e); s = ldexpf(1.f, 14 - e); }
@@ -661,6 +665,16 @@ int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t col
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gemm::absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_stride, rows, (int)cols, workspace);
   hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, workspace, (int)blocks, 1.f, scale);
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+/* scale[0] = 2^(14 - e), factor * max_i partial[i] <= 2^e : the scale from per-node / per-wave partial maxima
+ * that spgnn_scores_fwd, spgnn_gat_bwd_dst and spgnn_gat_bwd_src emit while they stream the tensor anyway. */
+int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, spgnn_stream_t stream) {
+  if (n < 0 || n > INT32_MAX || !(factor > 0.f)) return SPGNN_ERR_SHAPE;
+  if (!scale || (n > 0 && !partials)) return SPGNN_ERR_NULLPTR;
+  hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(n > 4096 ? 1024 : 64), 0, (hipStream_t)stream, partials, (int)n,
+                     factor, scale);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

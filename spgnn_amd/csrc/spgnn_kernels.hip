@@ -111,6 +111,13 @@ template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
   for (int off = W >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
   return x;
 }
+__device__ __forceinline__ float team_max(float x, int width) {
+  for (int off = width >> 1; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+__device__ __forceinline__ float absmax4(float m, float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 __device__ __forceinline__ float team_sum(float x, int width) {
   for (int off = width >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
   return x;
@@ -323,6 +330,7 @@ struct GatBwdDst {
   float* g_pre; int64_t g_pre_ld;
   float* g_e;
   float* g_er; int64_t gs_ld;
+  float* absmax;                         // optional: absmax[v] = max |g_pre[v,:]| (feeds the split-GEMM scale)
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
 };
@@ -352,6 +360,13 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
     }
     g[r] = q;
     st4(a.g_pre + v * a.g_pre_ld + c, q);
+  }
+  if (a.absmax) {
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) mx = absmax4(mx, g[r]);
+    mx = team_max(mx, T);
+    if (lane == 0) a.absmax[v] = mx;
   }
   int hs[NS]; bool wr[NS];
 #pragma unroll
@@ -455,11 +470,14 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
   const int beg = a.indptr[v], end = a.indptr[v + 1];
   const int base = h * a.D;
   const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
+  float amx = 0.f;
   for (int d = 0; d < a.D; ++d) {
     float q = a.g_out[v * a.g_out_ld + (a.mean ? d : base + d)] * gscale;
     if (a.act != SPGNN_ACT_NONE) q *= act_bwd_from_out(a.out[v * a.out_ld + base + d], a.act);
     a.g_pre[v * a.g_pre_ld + base + d] = q;
+    amx = fmaxf(amx, fabsf(q));
   }
+  if (a.absmax) atomicMax(reinterpret_cast<unsigned*>(a.absmax + v), __float_as_uint(amx));   // H threads per node
   float S = 0.f;
   for (int j = beg; j < end; ++j) {
     const int64_t u = a.indices[j];
@@ -493,6 +511,7 @@ struct GatBwdSrc {
   const float* g_pre; int64_t g_pre_ld;
   float* g_ft; int64_t g_ft_ld;
   float* g_el; int64_t gs_ld;
+  float* absmax;                         // optional: absmax[u] = max |g_ft[u,:]|
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
 };
@@ -549,6 +568,13 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (wr[s]) a.g_el[u * a.gs_ld + hs[s]] = gel[s];
+  if (a.absmax) {
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) mx = absmax4(mx, acc[r]);
+    mx = team_max(mx, T);
+    if (lane == 0) a.absmax[u] = mx;
+  }
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -568,6 +594,7 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
   }
   a.g_ft[u * a.g_ft_ld + col] = acc;
   if (col % a.D == 0) a.g_el[u * a.gs_ld + h] = gel;
+  if (a.absmax) atomicMax(reinterpret_cast<unsigned*>(a.absmax + u), __float_as_uint(fabsf(acc)));   // caller zeroes it
 }
 
 // =================================================================================================
@@ -738,7 +765,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
-                                                          float* __restrict__ S, int64_t lds_, int64_t N, int K, int J) {
+                                                          float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
+                                                          float* __restrict__ absmax) {
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = wave * 16;
@@ -750,11 +778,13 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   const float* wp = W + (int64_t)(wv ? r : 0) * Kp + 4 * q;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
   int k0 = 0;
 #pragma unroll 4
   for (; k0 + 16 <= K; k0 += 16) {
     const float4 xa = rv ? ld4(xp + k0) : z4;
     const float4 wb = wv ? ld4(wp + k0) : z4;
+    amx = absmax4(amx, xa);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc, 0, 0, 0);
@@ -770,10 +800,15 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
       if (k + 3 < K) xa.w = xp[k0 + 3];
     }
     const float4 wb = wv ? ld4(wp + k0) : z4;
+    amx = absmax4(amx, xa);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc, 0, 0, 0);
+  }
+  if (absmax) {
+    for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+    if (lane == 0) absmax[wave] = amx;
   }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (r < J) {
@@ -964,9 +999,9 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
 int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
                       const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
                       int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
-                      int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N, int64_t E,
-                      int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop, uint64_t seed,
-                      spgnn_stream_t stream) {
+                      int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
+                      int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
+                      uint64_t seed, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
@@ -980,7 +1015,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
-              g_pre, g_pre_stride, g_e, g_er, g_s_stride, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
+              g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
               activation, p_drop, 1.f / (1.f - p_drop), seed};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
@@ -992,6 +1027,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
   } else {
+    if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);       // scalar path maxes with atomics
     hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
   }
   return check_launch("spgnn_gat_bwd_dst");
@@ -999,8 +1035,8 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
 
 int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
                       const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
-                      float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t D, float p_drop,
-                      uint64_t seed, spgnn_stream_t stream) {
+                      float* g_el, int64_t g_s_stride, float* absmax, int64_t N, int64_t E, int32_t H, int32_t D,
+                      float p_drop, uint64_t seed, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (!out_indptr || !attn || !g_e || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos)))
@@ -1011,7 +1047,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed};
+              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed};
   int T = 0, R = 0, CH = 0, W = 0;
   if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
     a.T = T;
@@ -1020,6 +1056,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
   } else {
+    if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);
     hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   }
   return check_launch("spgnn_gat_bwd_src");
@@ -1085,7 +1122,7 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
 }
 
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
-                     int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+                     float* absmax, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || J <= 0 || J > 16 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd: bad N/K/Kp/J");
   if (N == 0) return SPGNN_OK;
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd: null pointer");
@@ -1093,7 +1130,7 @@ int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t K
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd: x rows and w must be 16-byte aligned (stride % 4 == 0)");
   const int64_t waves = (N + 15) / 16;
   hipLaunchKernelGGL(scores_fwd_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x,
-                     x_stride, w, Kp, s, s_stride, N, K, J);
+                     x_stride, w, Kp, s, s_stride, N, K, J, absmax);
   return check_launch("spgnn_scores_fwd");
 }
 

@@ -147,6 +147,7 @@ class TreeGraph:
         self.batch_num_edges_list: List[int] = [int(src.shape[0])]
         self.ndata = _NData(self)
         self._csc: Dict[str, DeviceCSC] = {}
+        self._tensor_cache: Dict[tuple, torch.Tensor] = {}     # per-batch constants derived from node data
 
     # ---- structure -------------------------------------------------------------------
     def number_of_nodes(self) -> int:

@@ -32,6 +32,20 @@ def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return cat_padded((a, b)) if a.is_cuda else torch.cat([a, b], dim=1)
 
 
+def _data_cat(g, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """cat of two node-DATA tensors (fvs, pos_enc).  The batched graph and its node data are reused for all
+    GCN_STEPS = 300 inner steps (reference job_runner.py:1892), so the concatenation is built once per batch
+    and kept on the graph (keyed by the tensors' identity and version)."""
+    if a.requires_grad or b.requires_grad or not a.is_cuda or not hasattr(g, "_tensor_cache"):
+        return _cat(a, b)
+    key = ("cat", a.data_ptr(), b.data_ptr(), a._version, b._version, tuple(a.shape), tuple(b.shape))
+    hit = g._tensor_cache.get(key)
+    if hit is None:
+        g._tensor_cache.clear()
+        hit = g._tensor_cache[key] = _cat(a, b).detach()
+    return hit
+
+
 def set_trainable(model: nn.Module, trainable: bool) -> None:
     for p in model.parameters():
         p.requires_grad = trainable
@@ -152,8 +166,8 @@ class GATPSPGNN(nn.Module):
 
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
-        for s_layer, p_layer in zip(self.gat_layers[:-1], self.pgnn_layers):
-            h_s = s_layer(g, _cat(h_s, h_p)).flatten(1)
+        for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
+            h_s = s_layer(g, _data_cat(g, h_s, h_p) if l == 0 else _cat(h_s, h_p)).flatten(1)
             h_p = p_layer(g, h_p).flatten(1)
         h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
         return h_s, h_p
@@ -183,8 +197,8 @@ class GATPSPGNNNL(nn.Module):
 
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
-        for layer in self.gat_layers[:-1]:
-            h_s = layer(g, _cat(h_s, h_p)).flatten(1)
+        for l, layer in enumerate(self.gat_layers[:-1]):
+            h_s = layer(g, _data_cat(g, h_s, h_p) if l == 0 else _cat(h_s, h_p)).flatten(1)
         h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
         return h_s, h_p
 

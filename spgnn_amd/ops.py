@@ -126,9 +126,10 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
 
 def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, slope: float, act: int,
                 p_drop: float, seed: int, g_pre: torch.Tensor, g_ft: torch.Tensor, g_el: torch.Tensor,
-                g_er: torch.Tensor, mean: bool = False) -> torch.Tensor:
+                g_er: torch.Tensor, mean: bool = False, absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Runs both backward halves. g_pre/g_ft (N,H*D), g_el/g_er (N,H) are written in place
-    (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.
+    (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.  ``absmax`` (2N floats):
+    per-node maxima of |g_pre| then |g_ft| (for the split-GEMM scale of [g_ft | g_pre]).
     Returns g_e (E,H) in CSC slot order."""
     _require_cuda(ft, g_out)
     N, E = csc.num_nodes, csc.num_edges
@@ -143,14 +144,15 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
                                           el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
                                           g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
-                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), N, E, H, D, slope, act,
-                                          p_drop, seed, st), "spgnn_gat_bwd_dst")
+                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax), N, E, H, D, slope,
+                                          act, p_drop, seed, st), "spgnn_gat_bwd_dst")
         t_dst.__exit__()
         t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                           csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
-                                          g_el.stride(0), N, E, H, D, p_drop, seed, st), "spgnn_gat_bwd_src")
+                                          g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, N, E, H, D,
+                                          p_drop, seed, st), "spgnn_gat_bwd_src")
         t_src.__exit__()
     return g_e
 
@@ -186,20 +188,32 @@ def _pad16(k: int) -> int:
     return (k + 15) // 16 * 16
 
 
-def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor) -> torch.Tensor:
+def scale_from_partials(partials: torch.Tensor, factor: float = 1.0) -> torch.Tensor:
+    """Device scalar 2^(14 - e), factor * max(partials) <= 2^e (see pow2_scale)."""
+    scale = torch.empty(1, dtype=torch.float32, device=partials.device)
+    with torch.cuda.device(partials.device):
+        _capi.check(_capi.load().spgnn_scale_from_partials(partials.data_ptr(), partials.numel(), factor, scale.data_ptr(),
+                                                           _stream(partials)), "spgnn_scale_from_partials")
+    return scale
+
+
+def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     """S = x @ w_lr^T (N, J), J = 2H: the MFMA streaming kernel when the rows of x are 16-byte aligned and
-    J <= 16, rocBLAS otherwise."""
+    J <= 16, rocBLAS otherwise.  ``want_scale``: also return the split-GEMM scale of x — the kernel reads every
+    element of x anyway, so its absmax costs nothing extra."""
     N, K = x.shape
     J = w_lr.shape[0]
     if not (_rows_aligned(x) and J <= 16) or N == 0:
-        return torch.mm(x, w_lr.t())
+        s = torch.mm(x, w_lr.t())
+        return (s, pow2_scale(x) if N > 0 else None) if want_scale else s
     Kp = _pad16(K)
     w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
     s = torch.empty((N, J), dtype=torch.float32, device=x.device)
+    part = torch.empty(((N + 15) // 16,), dtype=torch.float32, device=x.device) if want_scale else None
     with torch.cuda.device(x.device), _timed("scores_fwd", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_fwd(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
-                                                  N, K, J, _stream(x)), "spgnn_scores_fwd")
-    return s
+                                                  _ptr(part), N, K, J, _stream(x)), "spgnn_scores_fwd")
+    return (s, scale_from_partials(part)) if want_scale else s
 
 
 def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -273,12 +287,12 @@ class _GATLayerFn(torch.autograd.Function):
         x = _rowmajor(x)
         split = GEMM_MODE == "f16x3" and _rows_aligned(x) and _rows_aligned(w_cat) and x.shape[0] > 0
         if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
-            sx = pow2_scale(x)
+            s, sx = scores_fwd(x, w_lr, want_scale=True)   # (N, 2H) = [el | er]; the scale of x comes for free
             y = gemm_nt(x, w_cat, sx, pow2_scale(w_cat))
         else:
             sx = None
             y = torch.mm(x, w_cat.t())
-        s = scores_fwd(x, w_lr)                        # (N, 2H)        = [el | er]
+            s = scores_fwd(x, w_lr)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
         out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed,
@@ -300,11 +314,13 @@ class _GATLayerFn(torch.autograd.Function):
         g_y = torch.empty_like(y)
         g_s = torch.empty_like(s)
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
-        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
-                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean)
-        g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
         split = sx is not None
-        sg = pow2_scale(g_y) if split else None
+        amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device) if split else None
+        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax)
+        g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        # [g_ft | g_pre] fills g_y when the layer has a residual; without one only g_ft does
+        sg = scale_from_partials(amax if has_res else amax[N:]) if split else None
         g_wcat = None
         if ctx.needs_input_grad[1]:
             # tiny outputs (position stream, 39-wide inputs) leave the 128x128-tile kernel mostly idle: rocBLAS there
