@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 5
+#define SPGNN_ABI_VERSION 6
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -135,10 +135,11 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
  *
  *   spgnn_scores_fwd    S[n,j]   = sum_k x[n,k] * w[j,k]
  *   spgnn_scores_bwd_w  part[s,j,k] = sum_{n in row range s} gs[n,j] * x[n,k]   (caller sums over s)
- *   spgnn_scores_bwd_x  gx[n,k] += sum_j gs[n,j] * w[j,k]
+ *   spgnn_scores_bwd_x  gx[n,k] (+)= sum_j gs[n,j] * w[j,k]        (accumulate != 0: add into gx)
  *
- * w and part rows are zero-padded to Kp = 16*ceil(K/16) floats.  x / gx rows must be 16-byte aligned
- * (stride % 4 == 0).  J <= 16 (fwd); J in {2,4,8,16} (bwd).
+ * w and part rows are zero-padded to Kp = 16*ceil(K/16) floats (part: splits x J x Kp).  x / gx rows must be
+ * 16-byte aligned (stride % 4 == 0).  J <= 32.  The same three kernels serve the model's classifier head
+ * `gnn_out = Linear(1024, 22)` (reference models.py:1125, 1169): a 22-column projection of 76k rows.
  */
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
                      float* s, int64_t s_stride, float* absmax /* nullable: ceil(N/16) per-wave maxima of |x| */,
@@ -147,7 +148,8 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
                        float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
                        spgnn_stream_t stream);
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp,
-                       float* gx, int64_t gx_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+                       float* gx, int64_t gx_stride, int32_t accumulate, int64_t N, int32_t K, int32_t J,
+                       spgnn_stream_t stream);
 
 /*
  * Weighted-sum SpMM (DGL gspmm(copy_u, sum) with the degree normalisations of GraphConv
@@ -205,7 +207,9 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 
 /* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by
  * spgnn_scores_fwd / spgnn_gat_bwd_dst / spgnn_gat_bwd_src (which stream the tensors anyway) into a GEMM scale. */
-int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, spgnn_stream_t stream);
+int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale,
+                              uint32_t* workspace /* nullable; 2 words, zeroed ONCE by the caller, self-resetting */,
+                              spgnn_stream_t stream);
 
 /* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined (default), 3 = pipelined with
  * 128-row tiles only.  Returns the previous setting.  For A/B measurements. */

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -30,9 +30,9 @@ SIGNATURES = {
     "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p,
                           _i64, _i64, _i32, _i32, _f32, _u64, _vp],
     "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
-    "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp],
+    "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
     "spgnn_scores_bwd_w": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
-    "spgnn_scores_bwd_x": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _i64, _i32, _i32, _vp],
+    "spgnn_scores_bwd_x": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _i32, _i64, _i32, _i32, _vp],
     "spgnn_spmm_sum": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _i32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],

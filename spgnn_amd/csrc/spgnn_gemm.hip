@@ -576,21 +576,46 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 // scale[0] = 2^(14 - e) with max <= 2^e ; optional multiplicative bound factor (e.g. 1/(1-p) for dropout)
-__global__ __launch_bounds__(1024) void scale_from_partials(const float* __restrict__ partial, int n, float factor, float* __restrict__ scale) {
-  __shared__ float red[16];
+__device__ __forceinline__ float pow2_scale_of(float m) {
+  float s = 1.f;
+  if (m > 0.f && m < INFINITY) { int e; frexpf(m, &e); s = ldexpf(1.f, 14 - e); }
+  return s;
+}
+// small inputs: one block
+__global__ void scale_from_partials(const float* __restrict__ partial, int n, float factor, float* __restrict__ scale) {
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, partial[i]);
+  for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, partial[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (threadIdx.x == 0) scale[0] = pow2_scale_of(m * factor);
+}
+// large inputs (per-node maxima, ~150k floats): many blocks fold into ws[0] with one atomicMax each; the block
+// that draws the last ticket (ws[1]) publishes the scale and re-zeroes both words for the next call on the
+// stream (ws is zero-initialised once by the caller).  Non-negative floats order like their bit patterns.
+__global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __restrict__ partial, int n, float factor,
+                                                              float* __restrict__ scale, unsigned* __restrict__ ws) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int n4 = n >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(partial)[i];
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, partial[n4 * 4 + threadIdx.x]);
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
-    m *= factor;
-    float s = 1.f;
-    if (m > 0.f && m < INFINITY) { int e; frexpf(m, &e); s = ldexpf(1.f, 14 - e); }
-    scale[0] = s;
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(&ws[0], __float_as_uint(m));
+    __threadfence();
+    if (atomicAdd(&ws[1], 1u) == gridDim.x - 1) {            // last block: every atomicMax above is visible
+      const float all = __uint_as_float(atomicMax(&ws[0], 0u));
+      scale[0] = pow2_scale_of(all * factor);
+      ws[0] = 0u; ws[1] = 0u;
+    }
   }
 }
+
 }  // namespace gemm
 
 extern "C" {
@@ -668,13 +693,18 @@ int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t col
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 
-/* scale[0] = 2^(14 - e), factor * max_i partial[i] <= 2^e : the scale from per-node / per-wave partial maxima
- * that spgnn_scores_fwd, spgnn_gat_bwd_dst and spgnn_gat_bwd_src emit while they stream the tensor anyway. */
-int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, spgnn_stream_t stream) {
+int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, uint32_t* workspace,
+                              spgnn_stream_t stream) {
   if (n < 0 || n > INT32_MAX || !(factor > 0.f)) return SPGNN_ERR_SHAPE;
   if (!scale || (n > 0 && !partials)) return SPGNN_ERR_NULLPTR;
-  hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(n > 4096 ? 1024 : 64), 0, (hipStream_t)stream, partials, (int)n,
-                     factor, scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 8192 && workspace && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(gemm::scale_from_partials_mb, dim3(blocks), dim3(256), 0, st, partials, (int)n, factor, scale, workspace);
+  } else {
+    hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, partials, (int)n, factor, scale);
+  }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

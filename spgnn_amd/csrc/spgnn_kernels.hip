@@ -763,6 +763,7 @@ __global__ void spmm_max_bwd_scalar(SpmmMaxBwd a) {
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int NG>      // NG 16-column groups: J <= 16 * NG
 __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
@@ -774,48 +775,56 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   const int r = lane & 15, q = lane >> 4;
   const bool rv = row0 + r < N;
   const float* xp = X + (rv ? row0 + r : 0) * ldx + 4 * q;
-  const bool wv = r < J;
-  const float* wp = W + (int64_t)(wv ? r : 0) * Kp + 4 * q;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
-  int k0 = 0;
-#pragma unroll 4
-  for (; k0 + 16 <= K; k0 += 16) {
-    const float4 xa = rv ? ld4(xp + k0) : z4;
-    const float4 wb = wv ? ld4(wp + k0) : z4;
-    amx = absmax4(amx, xa);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc, 0, 0, 0);
+  bool wv[NG]; const float* wp[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    wv[g] = r + 16 * g < J;
+    wp[g] = W + (int64_t)(wv[g] ? r + 16 * g : 0) * Kp + 4 * q;
   }
-  if (k0 < K) {                       // ragged tail: element-wise guards on X (W is zero padded)
-    const int k = k0 + 4 * q;
-    float4 xa = z4;
-    if (rv) {
-      if (k + 0 < K) xa.x = xp[k0 + 0];
-      if (k + 1 < K) xa.y = xp[k0 + 1];
-      if (k + 2 < K) xa.z = xp[k0 + 2];
-      if (k + 3 < K) xa.w = xp[k0 + 3];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
+  const int kfull = K & ~15;
+  for (int k0 = 0; k0 < kfull + 16; k0 += 16) {
+    float4 xa;
+    if (k0 < kfull) {
+      xa = rv ? ld4(xp + k0) : z4;
+    } else {                          // ragged tail: element-wise guards on X (W is zero padded)
+      if (kfull >= K) break;
+      const int k = k0 + 4 * q;
+      xa = z4;
+      if (rv) {
+        if (k + 0 < K) xa.x = xp[k0 + 0];
+        if (k + 1 < K) xa.y = xp[k0 + 1];
+        if (k + 2 < K) xa.z = xp[k0 + 2];
+        if (k + 3 < K) xa.w = xp[k0 + 3];
+      }
     }
-    const float4 wb = wv ? ld4(wp + k0) : z4;
     amx = absmax4(amx, xa);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 wb = wv[g] ? ld4(wp[g] + k0) : z4;
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
+    }
   }
   if (absmax) {
     for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
     if (lane == 0) absmax[wave] = amx;
   }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
-  if (r < J) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t orow = row0 + q * 4 + j;
-      if (orow < N) S[orow * lds_ + r] = acc[j];
+  for (int g = 0; g < NG; ++g) {
+    if (r + 16 * g < J) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t orow = row0 + q * 4 + j;
+        if (orow < N) S[orow * lds_ + r + 16 * g] = acc[g][j];
+      }
     }
   }
 }
@@ -825,7 +834,7 @@ template <int J>
 __global__ __launch_bounds__(64) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ part, int Kp, int64_t N, int K,
-                                                          int64_t rows_per_split) {
+                                                          int64_t rows_per_split, int jn) {
   const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
   if (k >= K) return;
   const bool full = k + 3 < K;
@@ -842,7 +851,9 @@ __global__ __launch_bounds__(64) void scores_bwd_w_kernel(const float* __restric
       const float* g = gS + n * ldg;   // wave-uniform addresses: scalar loads
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        fma4(acc[j], g[j], x0); fma4(acc[j], g[ldg + j], x1); fma4(acc[j], g[2 * ldg + j], x2); fma4(acc[j], g[3 * ldg + j], x3);
+        if (j < jn) {
+          fma4(acc[j], g[j], x0); fma4(acc[j], g[ldg + j], x1); fma4(acc[j], g[2 * ldg + j], x2); fma4(acc[j], g[3 * ldg + j], x3);
+        }
       }
     }
   }
@@ -853,17 +864,19 @@ __global__ __launch_bounds__(64) void scores_bwd_w_kernel(const float* __restric
     else { x = make_float4(xr[0], k + 1 < K ? xr[1] : 0.f, k + 2 < K ? xr[2] : 0.f, 0.f); }
     const float* g = gS + n * ldg;
 #pragma unroll
-    for (int j = 0; j < J; ++j) fma4(acc[j], g[j], x);
+    for (int j = 0; j < J; ++j)
+      if (j < jn) fma4(acc[j], g[j], x);
   }
 #pragma unroll
-  for (int j = 0; j < J; ++j) st4(part + ((int64_t)blockIdx.y * J + j) * Kp + k, acc[j]);
+  for (int j = 0; j < J; ++j)
+    if (j < jn) st4(part + ((int64_t)blockIdx.y * jn + j) * Kp + k, acc[j]);
 }
 
 template <int J>
 __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restrict__ gS, int64_t ldg,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ gX, int64_t ldgx, int64_t N, int K,
-                                                          int64_t rows_per_split) {
+                                                          int64_t rows_per_split, int jn, int accumulate) {
   const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
   if (k >= K) return;
   const bool full = k + 3 < K;
@@ -871,15 +884,21 @@ __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restric
   const int64_t n1 = n0 + rows_per_split < N ? n0 + rows_per_split : N;
   float4 w[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) w[j] = ld4(W + (int64_t)j * Kp + k);
+  for (int j = 0; j < J; ++j) w[j] = j < jn ? ld4(W + (int64_t)j * Kp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t n = n0; n < n1; ++n) {
     const float* g = gS + n * ldg;
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < J; ++j) fma4(d, g[j], w[j]);
+    for (int j = 0; j < J; ++j)
+      if (j < jn) fma4(d, g[j], w[j]);
     float* xr = gX + n * ldgx + k;
-    if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
-    else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
+    if (accumulate) {
+      if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
+      else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
+    } else {
+      if (full) st4(xr, d);
+      else { xr[0] = d.x; if (k + 1 < K) xr[1] = d.y; if (k + 2 < K) xr[2] = d.z; }
+    }
   }
 }
 
@@ -1123,40 +1142,42 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
 
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
                      float* absmax, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
-  if (N < 0 || K <= 0 || J <= 0 || J > 16 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd: bad N/K/Kp/J");
+  if (N < 0 || K <= 0 || J <= 0 || J > 32 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd: bad N/K/Kp/J");
   if (N == 0) return SPGNN_OK;
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd: x rows and w must be 16-byte aligned (stride % 4 == 0)");
   const int64_t waves = (N + 15) / 16;
-  hipLaunchKernelGGL(scores_fwd_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x,
-                     x_stride, w, Kp, s, s_stride, N, K, J, absmax);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+  if (J <= 16)
+    hipLaunchKernelGGL(scores_fwd_mfma<1>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
+  else
+    hipLaunchKernelGGL(scores_fwd_mfma<2>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
   return check_launch("spgnn_scores_fwd");
 }
 
+static int padded_j(int J) { return J <= 2 ? 2 : J <= 4 ? 4 : J <= 8 ? 8 : J <= 16 ? 16 : J <= 24 ? 24 : 32; }
+
 int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride, float* part,
                        int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
-  if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w: bad N/K/Kp/splits");
-  if (J != 2 && J != 4 && J != 8 && J != 16) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w: J must be 2, 4, 8 or 16");
+  if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w: bad N/K/Kp/splits/J");
   if (!gs || !x || !part) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w: null pointer");
   if (x_stride < K || gs_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(part))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w: x rows must be 16-byte aligned (stride % 4 == 0)");
   const int64_t rps = (N + splits - 1) / splits;
   const dim3 grid((unsigned)((K + 255) / 256), (unsigned)splits), block(64);
   hipStream_t st = (hipStream_t)stream;
-  switch (J) {
-    case 2: hipLaunchKernelGGL(scores_bwd_w_kernel<2>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps); break;
-    case 4: hipLaunchKernelGGL(scores_bwd_w_kernel<4>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps); break;
-    case 8: hipLaunchKernelGGL(scores_bwd_w_kernel<8>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps); break;
-    default: hipLaunchKernelGGL(scores_bwd_w_kernel<16>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps); break;
-  }
+#define X(JP) hipLaunchKernelGGL(scores_bwd_w_kernel<JP>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps, J)
+  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
+                         case 24: X(24); break; default: X(32); break; }
+#undef X
   return check_launch("spgnn_scores_bwd_w");
 }
 
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp, float* gx, int64_t gx_stride,
-                       int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
-  if (N < 0 || K <= 0 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x: bad N/K/Kp");
-  if (J != 2 && J != 4 && J != 8 && J != 16) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x: J must be 2, 4, 8 or 16");
+                       int32_t accumulate, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  if (N < 0 || K <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x: bad N/K/Kp/J");
   if (N == 0) return SPGNN_OK;
   if (!gs || !w || !gx) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_x: null pointer");
   if (gx_stride < K || gs_stride < J || (gx_stride & 3) || !aligned16(gx) || !aligned16(w))
@@ -1167,12 +1188,10 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
   const int64_t rps = (N + splits - 1) / splits;
   const dim3 grid((unsigned)((K + 255) / 256), (unsigned)((N + rps - 1) / rps)), block(64);
   hipStream_t st = (hipStream_t)stream;
-  switch (J) {
-    case 2: hipLaunchKernelGGL(scores_bwd_x_kernel<2>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps); break;
-    case 4: hipLaunchKernelGGL(scores_bwd_x_kernel<4>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps); break;
-    case 8: hipLaunchKernelGGL(scores_bwd_x_kernel<8>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps); break;
-    default: hipLaunchKernelGGL(scores_bwd_x_kernel<16>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps); break;
-  }
+#define X(JP) hipLaunchKernelGGL(scores_bwd_x_kernel<JP>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps, J, accumulate)
+  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
+                         case 24: X(24); break; default: X(32); break; }
+#undef X
   return check_launch("spgnn_scores_bwd_x");
 }
 

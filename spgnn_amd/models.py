@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn import GATConv, GINConv, GraphConv, SAGEConv
+from .nn import GATConv, GINConv, GraphConv, SAGEConv, SkinnyLinear
 from .ops import cat_padded
 
 __all__ = ["GCN", "GAT", "GIN", "SAGE", "GATPSPGNN", "GATPSPGNNNL", "GCNNet", "GATNet", "GINNet", "SAGENet",
@@ -41,8 +41,21 @@ def _data_cat(g, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     key = ("cat", a.data_ptr(), b.data_ptr(), a._version, b._version, tuple(a.shape), tuple(b.shape))
     hit = g._tensor_cache.get(key)
     if hit is None:
-        g._tensor_cache.clear()
+        if len(g._tensor_cache) > 8:
+            g._tensor_cache.clear()
         hit = g._tensor_cache[key] = _cat(a, b).detach()
+    return hit
+
+
+def _data_aligned(g, t: torch.Tensor) -> torch.Tensor:
+    """A node-data tensor with 16-byte-aligned rows (e.g. pos_enc, 39 floats wide -> row stride 40), made once
+    per batch: the aligned copy is what the MFMA kernels read."""
+    if t.requires_grad or not t.is_cuda or t.shape[1] % 4 == 0 or not hasattr(g, "_tensor_cache"):
+        return t
+    key = ("aligned", t.data_ptr(), t._version, tuple(t.shape))
+    hit = g._tensor_cache.get(key)
+    if hit is None:
+        hit = g._tensor_cache[key] = cat_padded((t,)).detach()
     return hit
 
 
@@ -168,7 +181,7 @@ class GATPSPGNN(nn.Module):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
             h_s = s_layer(g, _data_cat(g, h_s, h_p) if l == 0 else _cat(h_s, h_p)).flatten(1)
-            h_p = p_layer(g, h_p).flatten(1)
+            h_p = p_layer(g, _data_aligned(g, h_p) if l == 0 else h_p).flatten(1)
         h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
         return h_s, h_p
 
@@ -338,7 +351,7 @@ class GCNNet(_GraphNetBase):
                     act_method=act_method, build_trunk=build_trunk)
         self.gcn = GCN(num_layers=num_gcn_layers, in_dim=fv_dim, num_hiddens=num_hiddens, num_classes=node_embed_dim,
                        activation=F.elu)
-        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
         n_embed = self.gcn(g)
@@ -362,7 +375,7 @@ class SAGENet(_GraphNetBase):
         self.sage = SAGE(num_layers=num_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim,
                          activation=F.elu, feat_drop=feat_drop, node_ks=node_ks, aggregator_type=aggregator_type,
                          node_sample_rate=node_sample_rate)
-        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
         n_embed = self.sage(g)
@@ -391,7 +404,7 @@ class GATNet(_GraphNetBase):
         self.gat = GAT(num_layers=num_gat_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim,
                        heads=heads, activation=F.elu, feat_drop=feat_drop, attn_drop=attn_drop,
                        negative_slope=negative_slope, residual=res)
-        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
         n_embed = self.gat(g)
@@ -419,7 +432,7 @@ class GINNet(_GraphNetBase):
                     fv_dim=fv_dim, num_hiddens=num_hiddens, node_embed_dim=node_embed_dim, norm_method=norm_method,
                     act_method=act_method, build_trunk=build_trunk)
         self.gin = GIN(num_layers=num_gin_layers, in_dim=fv_dim, num_hiddens=num_hiddens, out_ch=node_embed_dim)
-        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
         self.gnn_lobe_out = nn.Linear(node_embed_dim, 6)      # auxiliary heads (reference models.py:988-989)
         self.gnn_lung_out = nn.Linear(node_embed_dim, 3)
 
@@ -473,7 +486,7 @@ class GATPositionSPGNNNet(_GraphNetBase):
                                    residual=res, norm=norm)
         else:
             raise ValueError(f"unknown mode {mode!r} (PEL or PENL)")
-        self.gnn_out = nn.Linear(node_embed_dim, out_ch)
+        self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
         n_embed, n_p_embed = self.gat(g)

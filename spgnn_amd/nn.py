@@ -16,11 +16,21 @@ import torch.nn.functional as F
 from . import ops
 from .graph import TreeGraph
 
-__all__ = ["GATConv", "GraphConv", "GINConv", "SAGEConv", "Identity", "DGLError"]
+__all__ = ["GATConv", "GraphConv", "GINConv", "SAGEConv", "Identity", "DGLError", "SkinnyLinear"]
 
 
 class DGLError(Exception):
     """Same role as dgl.DGLError (raised for 0-in-degree nodes / bad options)."""
+
+
+class SkinnyLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict) for a classifier head with few outputs on ~1e5 rows, e.g. the
+    reference's ``gnn_out = nn.Linear(node_embed_dim, out_ch)`` (models.py:1125): streaming HIP kernels on the GPU."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 2 and self.out_features <= 32 and x.dtype == torch.float32:
+            return ops.skinny_linear(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 class Identity(nn.Module):

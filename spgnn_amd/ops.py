@@ -188,12 +188,19 @@ def _pad16(k: int) -> int:
     return (k + 15) // 16 * 16
 
 
+_SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-block reduction resets after each use
+
+
 def scale_from_partials(partials: torch.Tensor, factor: float = 1.0) -> torch.Tensor:
     """Device scalar 2^(14 - e), factor * max(partials) <= 2^e (see pow2_scale)."""
     scale = torch.empty(1, dtype=torch.float32, device=partials.device)
+    key = (partials.device, _stream(partials))
+    ws = _SCALE_WS.get(key)
+    if ws is None:
+        ws = _SCALE_WS[key] = torch.zeros(4, dtype=torch.int32, device=partials.device)
     with torch.cuda.device(partials.device):
         _capi.check(_capi.load().spgnn_scale_from_partials(partials.data_ptr(), partials.numel(), factor, scale.data_ptr(),
-                                                           _stream(partials)), "spgnn_scale_from_partials")
+                                                           ws.data_ptr(), _stream(partials)), "spgnn_scale_from_partials")
     return scale
 
 
@@ -203,7 +210,7 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     element of x anyway, so its absmax costs nothing extra."""
     N, K = x.shape
     J = w_lr.shape[0]
-    if not (_rows_aligned(x) and J <= 16) or N == 0:
+    if not (_rows_aligned(x) and J <= 32) or N == 0:
         s = torch.mm(x, w_lr.t())
         return (s, pow2_scale(x) if N > 0 else None) if want_scale else s
     Kp = _pad16(K)
@@ -220,7 +227,7 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """g_w_lr = g_s^T @ x (J, K)."""
     N, K = x.shape
     J = g_s.shape[1]
-    if not (_rows_aligned(x) and J in (2, 4, 8, 16)) or N == 0:
+    if not (_rows_aligned(x) and J <= 32) or N == 0:
         return torch.mm(g_s.t(), x)
     Kp = _pad16(K)
     splits = max(1, min(4096 // ((K + 255) // 256), N // 16))      # ~4k waves in flight; partials stay < 20 MB
@@ -232,18 +239,55 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return part.sum(0)[:, :K]
 
 
-def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor) -> None:
-    """g_x += g_s @ w_lr, in place."""
+def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor, accumulate: bool = True) -> None:
+    """g_x (+)= g_s @ w_lr, in place."""
     N, K = g_x.shape
     J = g_s.shape[1]
-    if not (_rows_aligned(g_x) and J in (2, 4, 8, 16)) or N == 0:
-        g_x.addmm_(g_s, w_lr)
+    if not (_rows_aligned(g_x) and J <= 32) or N == 0:
+        if accumulate:
+            g_x.addmm_(g_s, w_lr)
+        else:
+            torch.mm(g_s, w_lr, out=g_x)
         return
     Kp = _pad16(K)
     w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
     with torch.cuda.device(g_x.device), _timed("scores_bwd_x", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_bwd_x(g_s.data_ptr(), g_s.stride(0), w_p.data_ptr(), Kp, g_x.data_ptr(),
-                                                    g_x.stride(0), N, K, J, _stream(g_x)), "spgnn_scores_bwd_x")
+                                                    g_x.stride(0), int(accumulate), N, K, J, _stream(g_x)),
+                    "spgnn_scores_bwd_x")
+
+
+class _SkinnyLinearFn(torch.autograd.Function):
+    """y = x @ W^T + b for a tall x (N ~ 1e5 rows) and <= 32 output features: the three streaming kernels of the
+    score projections instead of rocBLAS (which leaves most of the chip idle on a 22-column output)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _rowmajor(x)
+        y = scores_fwd(x, weight)
+        if bias is not None:
+            y = y + bias
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, weight = ctx.saved_tensors
+        g_y = g_y.contiguous()
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x) if _rows_aligned(x) and x.is_contiguous() else torch.empty(x.shape, device=x.device)
+            scores_bwd_x_(g_x, g_y, weight, accumulate=False)
+        if ctx.needs_input_grad[1]:
+            g_w = scores_bwd_w(g_y, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = g_y.sum(0)
+        return g_x, g_w, g_b
+
+
+def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _SkinnyLinearFn.apply(x, weight, bias)
 
 
 class _CatPad(torch.autograd.Function):

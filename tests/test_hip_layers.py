@@ -268,3 +268,19 @@ def test_score_projection_kernels(K, J):
         assert torch.isfinite(gbuf).all()
     xu = torch.randn(N, K, device="cuda")                  # unaligned rows (K odd) fall back to rocBLAS
     assert rel_err(ops.scores_fwd(xu, w), xu.double() @ w.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("K,J", [(1024, 22), (100, 17), (64, 32), (1024, 6)])
+def test_skinny_linear_matches_nn_linear(K, J):
+    """The classifier head gnn_out = Linear(1024, 22) on the streaming kernels: same parameters, same results."""
+    torch.manual_seed(J)
+    lin = snn.SkinnyLinear(K, J).cuda()
+    ref = torch.nn.Linear(K, J).cuda(); ref.load_state_dict(lin.state_dict())
+    x = torch.randn(3001, K, device="cuda", requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    y, yr = lin(x), ref(xr)
+    assert rel_err(y, yr) < 2e-6
+    cot = torch.randn_like(y)
+    (y * cot).sum().backward(); (yr * cot).sum().backward()
+    assert rel_err(x.grad, xr.grad) < 2e-6 and rel_err(lin.weight.grad, ref.weight.grad) < 5e-6
+    assert rel_err(lin.bias.grad, ref.bias.grad) < 2e-6
