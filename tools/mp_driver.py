@@ -14,10 +14,14 @@ for (H, D) in [(2, 1024), (2, 256), (2, 128), (2, 64), (1, 256), (1, 128), (1, 6
     HD = H * D
     y = torch.randn(N, 2 * HD, device=dev); s = torch.randn(N, 2 * H, device=dev); bias = torch.zeros(HD, device=dev)
     g_out = torch.randn(N, HD, device=dev); g_y = torch.empty_like(y); g_s = torch.empty_like(s)
+    mean = D == 1024                      # the output layer runs with the fused head mean (as in the model)
+    if mean:
+        g_out = torch.randn(N, D, device=dev)
+    amax = torch.empty(2 * N, device=dev)
     for _ in range(reps):
-        out, _, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU)
+        out, _, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, mean=mean)
         ops.gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, 0.2, ops.ACT_ELU, 0.0, 0,
-                        g_y[:, HD:], g_y[:, :HD], g_s[:, :H], g_s[:, H:])
+                        g_y[:, HD:], g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax)
     torch.cuda.synchronize()
     del y, s, g_out, g_y, g_s, out, attn
 print("done", N, E)
