@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 6
+#define SPGNN_ABI_VERSION 7
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -229,6 +229,18 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */
 int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t cols, float* scale,
                      float* workspace, int32_t workspace_floats, spgnn_stream_t stream);
+
+/*
+ * Distance positional encoding of a batch of trees (reference job_runner.py:1759-1777: networkx all-pairs
+ * shortest paths + diameter per tree, on the host):
+ *   pos_enc[t, a] = (float)((double)hops(t, anchors[tree(t), a]) / (double)diameter(tree(t)))
+ * out_indptr/out_indices: CSR of the batched graph (self loops allowed, ignored by the BFS); tree_ptr[B+1]:
+ * node offsets of the trees (int64); anchors: (B, num_anchors) GLOBAL node ids; diameters (nullable): (B).
+ * Trees must be connected and hold at most 2048 nodes (pass the batch maximum as max_tree_nodes).
+ */
+int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_indices, const int64_t* tree_ptr,
+                                 const int32_t* anchors, int32_t num_anchors, float* pos_enc, int64_t pos_enc_stride,
+                                 int32_t* diameters, int64_t num_trees, int64_t max_tree_nodes, spgnn_stream_t stream);
 
 /*
  * SGD with momentum over one flat fp32 parameter bucket (torch.optim.SGD semantics, dampening 0,

@@ -902,6 +902,71 @@ __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restric
   }
 }
 
+
+// =================================================================================================
+// Distance positional encoding on the device (reference job_runner.py:1759-1777):
+//   pos_enc[t, a] = hop_distance(t, anchor_a) / diameter(tree of t)
+// The reference runs networkx all-pairs shortest paths per tree on the host.  Here one workgroup takes one
+// tree: its 4 waves run independent level-synchronous BFS passes (one anchor per wave at a time) over the
+// tree's CSR rows with the distance array of each pass in LDS; the diameter comes from a double sweep
+// (exact on trees).  The division is done in double and rounded once to float, like the reference's
+// `dist / float(diameter)` stored into a float32 array, so results are bit-identical.
+// =================================================================================================
+constexpr int kPeMaxNodes = 2048;           // nodes per tree held in LDS (airway trees: 100-300)
+
+__device__ __forceinline__ int wave_bfs(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                        int64_t base, int n, int src_local, volatile int* dist, int lane) {
+  for (int i = lane; i < n; i += 64) dist[i] = -1;
+  if (lane == 0) dist[src_local] = 0;
+  int level = 0, far = src_local;
+  for (;;) {                                             // every wave iteration is one BFS level
+    bool grew = false;
+    for (int i = lane; i < n; i += 64) {
+      if (dist[i] == level) {
+        for (int k = indptr[base + i]; k < indptr[base + i + 1]; ++k) {
+          const int j = (int)(indices[k] - base);
+          if (dist[j] < 0) { dist[j] = level + 1; grew = true; far = j; }
+        }
+      }
+    }
+    if (!__any(grew)) break;
+    ++level;
+  }
+  // a node of the last level (for the double sweep): take the largest lane's candidate at that level
+  int cand = -1;
+  for (int i = lane; i < n; i += 64) if (dist[i] == level) cand = i;
+  for (int off = 32; off > 0; off >>= 1) cand = max(cand, __shfl_xor(cand, off, 64));
+  (void)far;
+  return (level << 16) | (cand & 0xFFFF);                // [eccentricity | one farthest node]
+}
+
+__global__ __launch_bounds__(256) void tree_distance_encoding(const int32_t* __restrict__ indptr,
+                                                              const int32_t* __restrict__ indices,
+                                                              const int64_t* __restrict__ tree_ptr,
+                                                              const int32_t* __restrict__ anchors, int A,
+                                                              float* __restrict__ pe, int64_t pe_ld,
+                                                              int32_t* __restrict__ diam_out) {
+  __shared__ int dist_s[4][kPeMaxNodes];
+  __shared__ int diam_s;
+  const int t = blockIdx.x;
+  const int64_t base = tree_ptr[t];
+  const int n = (int)(tree_ptr[t + 1] - base);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    const int r0 = wave_bfs(indptr, indices, base, n, 0, dist_s[0], lane);
+    const int r1 = wave_bfs(indptr, indices, base, n, r0 & 0xFFFF, dist_s[0], lane);
+    if (lane == 0) { diam_s = r1 >> 16; if (diam_out) diam_out[t] = r1 >> 16; }
+  }
+  __syncthreads();
+  const double diam = (double)diam_s;
+  for (int a = wave; a < A; a += 4) {
+    const int src = (int)(anchors[(int64_t)t * A + a] - base);
+    wave_bfs(indptr, indices, base, n, src, dist_s[wave], lane);
+    for (int i = lane; i < n; i += 64)
+      pe[(base + i) * pe_ld + a] = (float)((double)dist_s[wave][i] / diam);
+  }
+}
+
 // =================================================================================================
 // SGD + momentum over a flat bucket
 // =================================================================================================
@@ -1193,6 +1258,21 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
                          case 24: X(24); break; default: X(32); break; }
 #undef X
   return check_launch("spgnn_scores_bwd_x");
+}
+
+int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_indices, const int64_t* tree_ptr,
+                                 const int32_t* anchors, int32_t num_anchors, float* pos_enc, int64_t pos_enc_stride,
+                                 int32_t* diameters, int64_t num_trees, int64_t max_tree_nodes, spgnn_stream_t stream) {
+  if (num_trees < 0 || num_anchors <= 0 || max_tree_nodes < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_tree_distance_encoding: bad sizes");
+  if (num_trees == 0) return SPGNN_OK;
+  if (max_tree_nodes > kPeMaxNodes || max_tree_nodes > 65535)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_tree_distance_encoding: a tree exceeds 2048 nodes (LDS-resident distances)");
+  if (!out_indptr || !out_indices || !tree_ptr || !anchors || !pos_enc)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_tree_distance_encoding: null pointer");
+  if (pos_enc_stride < num_anchors) return fail(SPGNN_ERR_STRIDE, "spgnn_tree_distance_encoding: row stride smaller than row");
+  hipLaunchKernelGGL(tree_distance_encoding, dim3((unsigned)num_trees), dim3(256), 0, (hipStream_t)stream, out_indptr,
+                     out_indices, tree_ptr, anchors, num_anchors, pos_enc, pos_enc_stride, diameters);
+  return check_launch("spgnn_tree_distance_encoding");
 }
 
 int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale, int64_t n,

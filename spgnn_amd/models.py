@@ -50,7 +50,8 @@ def _data_cat(g, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def _data_aligned(g, t: torch.Tensor) -> torch.Tensor:
     """A node-data tensor with 16-byte-aligned rows (e.g. pos_enc, 39 floats wide -> row stride 40), made once
     per batch: the aligned copy is what the MFMA kernels read."""
-    if t.requires_grad or not t.is_cuda or t.shape[1] % 4 == 0 or not hasattr(g, "_tensor_cache"):
+    already = t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    if t.requires_grad or not t.is_cuda or already or not hasattr(g, "_tensor_cache"):
         return t
     key = ("aligned", t.data_ptr(), t._version, tuple(t.shape))
     hit = g._tensor_cache.get(key)

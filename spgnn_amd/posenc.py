@@ -12,7 +12,8 @@ from typing import List, Tuple
 
 import numpy as np
 
-__all__ = ["anchors_from_cnn_prediction", "add_distal_leafs", "distance_pos_enc", "bfs_distances"]
+__all__ = ["anchors_from_cnn_prediction", "add_distal_leafs", "distance_pos_enc", "bfs_distances",
+           "distance_pos_enc_device"]
 
 
 def _softmax(x: np.ndarray) -> np.ndarray:
@@ -113,3 +114,32 @@ def distance_pos_enc(adj: np.ndarray, anchors) -> Tuple[np.ndarray, int]:
     diameter = _tree_diameter(adj)
     d = bfs_distances(adj, list(anchors)).T.astype(np.float64)
     return (d / float(diameter)).astype(np.float32), diameter
+
+
+def distance_pos_enc_device(g, anchors_per_tree):
+    """Device version of :func:`distance_pos_enc` for a whole batched graph.
+
+    ``g``: batched TreeGraph on a ROCm device; ``anchors_per_tree``: list (one per tree) of LOCAL anchor ids.
+    Returns ``(pos_enc (N, A) float32 on the device, diameters (B,) int32)``; bit-identical to the host/networkx
+    path.  One HIP workgroup per tree, BFS distance arrays in LDS (spgnn_tree_distance_encoding)."""
+    import torch
+    from . import _capi
+    csc = g.csc()
+    dev = csc.indptr.device
+    if dev.type != "cuda":
+        raise RuntimeError("distance_pos_enc_device needs the graph on a ROCm device (use distance_pos_enc on the host)")
+    nn = np.asarray(g.batch_num_nodes_list, dtype=np.int64)
+    B, A = len(nn), len(anchors_per_tree[0])
+    tree_ptr = np.concatenate([[0], np.cumsum(nn)])
+    anc = np.asarray(anchors_per_tree, dtype=np.int64).reshape(B, A) + tree_ptr[:-1, None]
+    tree_ptr_d = torch.from_numpy(tree_ptr).to(dev)
+    anc_d = torch.from_numpy(anc.astype(np.int32)).to(dev)
+    # rows padded to 16 bytes (39 -> stride 40) so the encoding feeds the vector/MFMA kernels without a copy
+    pe = torch.zeros((int(tree_ptr[-1]), (A + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :A]
+    diam = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().spgnn_tree_distance_encoding(
+            csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), tree_ptr_d.data_ptr(), anc_d.data_ptr(), A,
+            pe.data_ptr(), pe.stride(0), diam.data_ptr(), B, int(nn.max()) if B else 0,
+            torch.cuda.current_stream(dev).cuda_stream), "spgnn_tree_distance_encoding")
+    return pe, diam

@@ -67,22 +67,34 @@ def synthetic_trees(num_trees: int, rank: int = 0, n_lo: int = 120, n_hi: int = 
 
 
 def batch_from_samples(samples: List[Dict[str, np.ndarray]], device="cpu", pos_enc_dim: Optional[int] = 39,
-                       dtype=torch.float32) -> G.TreeGraph:
+                       dtype=torch.float32, device_posenc: Optional[bool] = None) -> G.TreeGraph:
     """List of schema dicts -> one batched graph with ndata fvs / fvs_out / y [/ pos_enc / p],
-    the host sequence of reference job_runner.py:1872-1885."""
-    graphs = []
+    the host sequence of reference job_runner.py:1872-1885.  On a ROCm device the distance encoding is
+    computed by the HIP kernel (one workgroup per tree) instead of per-tree host BFS (``device_posenc``)."""
+    dev = torch.device(device)
+    if device_posenc is None:
+        device_posenc = dev.type == "cuda"
+    graphs, anchors = [], []
     for s in samples:
         g = G.graph_from_adj(s["adj"], device="cpu", add_self_loops=True)
         g.ndata["fvs"] = torch.from_numpy(np.ascontiguousarray(s["fvs"])).to(dtype)
         g.ndata["fvs_out"] = torch.from_numpy(np.ascontiguousarray(s["fvs_out"])).to(dtype)
         g.ndata["y"] = torch.from_numpy(s["labels"].astype(np.int64))
         if pos_enc_dim:
-            anchors = anchors_from_cnn_prediction(s["fvs_out"], s["adj"], pos_enc_dim)
-            pe, _ = distance_pos_enc(s["adj"], anchors)
-            g.ndata["pos_enc"] = torch.from_numpy(pe).to(dtype)
-            g.ndata["p"] = torch.from_numpy(pe).to(dtype)
+            anc = anchors_from_cnn_prediction(s["fvs_out"], s["adj"], pos_enc_dim)
+            anchors.append(anc)
+            if not device_posenc:
+                pe, _ = distance_pos_enc(s["adj"], anc)
+                g.ndata["pos_enc"] = torch.from_numpy(pe).to(dtype)
+                g.ndata["p"] = torch.from_numpy(pe).to(dtype)
         graphs.append(g)
-    return G.batch(graphs).to(device)
+    bg = G.batch(graphs).to(device)
+    if pos_enc_dim and device_posenc:
+        from .posenc import distance_pos_enc_device
+        pe, _ = distance_pos_enc_device(bg, anchors)
+        bg.ndata["pos_enc"] = pe if dtype == torch.float32 else pe.to(dtype)
+        bg.ndata["p"] = bg.ndata["pos_enc"]
+    return bg
 
 
 def make_batch(num_trees: int, rank: int = 0, device="cpu", pos_enc_dim: Optional[int] = 39, **kw) -> G.TreeGraph:

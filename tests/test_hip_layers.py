@@ -284,3 +284,28 @@ def test_skinny_linear_matches_nn_linear(K, J):
     (y * cot).sum().backward(); (yr * cot).sum().backward()
     assert rel_err(x.grad, xr.grad) < 2e-6 and rel_err(lin.weight.grad, ref.weight.grad) < 5e-6
     assert rel_err(lin.bias.grad, ref.bias.grad) < 2e-6
+
+
+def test_device_positional_encoding_is_bit_exact():
+    """spgnn_tree_distance_encoding == host restatement == networkx (reference job_runner.py:1759-1777)."""
+    from oracle import graph_rule_nx as R
+    from spgnn_amd import posenc, synthetic
+    samples = synthetic.synthetic_trees(24, rank=5, n_lo=21, n_hi=300)
+    g = synthetic.batch_from_samples(samples, "cuda", 39, device_posenc=False)
+    anchors = [posenc.anchors_from_cnn_prediction(s["fvs_out"], s["adj"], 39) for s in samples]
+    pe, diam = posenc.distance_pos_enc_device(g, anchors)
+    assert torch.equal(pe.cpu(), g.ndata["pos_enc"].cpu())                       # vs the host path (bitwise)
+    for i in (0, 7, 23):
+        ref, d = R.distance_pos_enc(samples[i]["adj"], anchors[i])              # vs networkx
+        off = sum(s["adj"].shape[0] for s in samples[:i])
+        assert np.array_equal(pe[off:off + ref.shape[0]].cpu().numpy(), ref) and int(diam[i]) == d
+    # a path graph (diameter n-1) and a star, single anchor
+    from spgnn_amd.graph import graph_from_adj, batch
+    n = 50
+    path = np.eye(n, dtype=np.uint8); idx = np.arange(n - 1); path[idx, idx + 1] = 1; path[idx + 1, idx] = 1
+    star = np.eye(n, dtype=np.uint8); star[0, 1:] = 1; star[1:, 0] = 1
+    gb = batch([graph_from_adj(path), graph_from_adj(star)]).to("cuda")
+    pe2, d2 = posenc.distance_pos_enc_device(gb, [[0, n - 1], [0, 5]])
+    assert d2.tolist() == [n - 1, 2]
+    assert torch.equal(pe2[:n, 0].cpu(), torch.tensor([(i / (n - 1)) for i in range(n)], dtype=torch.float64).float())
+    assert pe2[n:, 1].cpu().tolist() == [0.5] + [1.0] * 4 + [0.0] + [1.0] * (n - 6)
