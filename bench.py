@@ -174,17 +174,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Warm-up.  Its last two steps are fully instrumented (HIP events around every hand-written kernel launch):
+    # they give the per-kernel breakdown and identify the dominant kernel.  Recording ~140 events per step
+    # perturbs the step by ~20 % (measured), so inside the timed region only the dominant kernel is bracketed
+    # (two events per step).
+    probe = 0 if args.no_kernel_timers else min(2, args.warmup)
+    for _ in range(args.warmup - probe):
         loss = step.step(g)
-    sync()
-    if not args.no_kernel_timers:
+    kt_all = {}
+    if probe:
+        sync()
         ops.KernelTimer.start()
+        for _ in range(probe):
+            loss = step.step(g)
+        kt_all = ops.KernelTimer.stop()
+    hip_keys = [k for k in kt_all if k[0] not in ("gemm_nt", "gemm_tn", "absmax")]
+    dom = max(hip_keys, key=lambda k: sum(kt_all[k])) if hip_keys else None
+    sync()
+    if dom is not None:
+        ops.KernelTimer.start(only=dom)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step.step(g)
     sync()
     elapsed = time.perf_counter() - t0
-    kt = ops.KernelTimer.stop() if not args.no_kernel_timers else {}
+    kt_dom = ops.KernelTimer.stop() if dom is not None else {}
+    kt = dict(kt_all)
     loss_val = float(loss)
 
     tot = torch.tensor([elapsed, float(E), float(N)], dtype=torch.float64, device=dev)
@@ -213,20 +228,22 @@ def main():
             "graph_edges_per_s": E_all * args.steps / elapsed, "loss": loss_val,
         }
         if kt:
+            nprobe = max(probe, 1)
             gemm_keys = [k for k in kt if k[0] in ("gemm_nt", "gemm_tn", "absmax")]
             gemm_kt = {k: kt.pop(k) for k in gemm_keys}
             if gemm_kt:
-                fl = sum(2.0 * k[1] * k[2] * k[3] * len(v) for k, v in gemm_kt.items() if k[0] != "absmax") / args.steps
-                g_ms = sum(sum(v) for k, v in gemm_kt.items() if k[0] != "absmax") / args.steps
+                fl = sum(2.0 * k[1] * k[2] * k[3] * len(v) for k, v in gemm_kt.items() if k[0] != "absmax") / nprobe
+                g_ms = sum(sum(v) for k, v in gemm_kt.items() if k[0] != "absmax") / nprobe
                 out["gemm"] = {"kernel": "spgnn_gemm_nt/tn (split-fp16, 3 MFMA products, fp32 accumulate)",
                                "ms_per_step": g_ms, "fp32_equiv_TFLOPs": fl / (g_ms * 1e-3) / 1e12,
                                "mfma_f16_TFLOPs": 3 * fl / (g_ms * 1e-3) / 1e12, "mfma_f16_peak_TFLOPs": 2500.0,
                                "frac_of_f16_peak": 3 * fl / (g_ms * 1e-3) / 1e12 / 2500.0,
-                               "absmax_ms_per_step": sum(sum(v) for k, v in gemm_kt.items() if k[0] == "absmax") / args.steps}
+                               "absmax_ms_per_step": sum(sum(v) for k, v in gemm_kt.items() if k[0] == "absmax") / nprobe,
+                               "measured_in": f"{nprobe} instrumented warm-up step(s)"}
             agg = {k: (sum(v) / len(v), sum(v), len(v)) for k, v in kt.items()}
-            mp_ms = sum(t for _, t, _ in agg.values()) / args.steps
-            dom = max(agg, key=lambda k: agg[k][1])
-            avg_ms = agg[dom][0]
+            mp_ms = sum(t for _, t, _ in agg.values()) / nprobe
+            dom_times = kt_dom.get(dom, kt[dom])          # timed-region launches of the dominant kernel
+            avg_ms = sum(dom_times) / len(dom_times)
             bytes_alg = algorithmic_bytes(dom)
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -239,13 +256,15 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom[0], "shape": list(dom[1:]), "achieved": ach,
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_alg,
-                               "avg_launch_ms": avg_ms, "launches": agg[dom][2]}
-            mp_bytes = sum(algorithmic_bytes(k) * n for k, (_, _, n) in agg.items()) / args.steps
+                               "avg_launch_ms": avg_ms, "launches": len(dom_times),
+                               "measured_in": "timed region (HIP events on the launch stream around every launch of this kernel)"}
+            mp_bytes = sum(algorithmic_bytes(k) * n for k, (_, _, n) in agg.items()) / nprobe
             out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
                                       "algorithmic_GB_per_step": mp_bytes / 1e9,
                                       "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9,
                                       "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                       "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3),
+                                      "measured_in": f"{nprobe} instrumented warm-up step(s)",
                                       "per_kernel_ms": {"_".join(str(x) for x in k): round(a, 5) for k, (a, _, _) in sorted(agg.items())}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees))

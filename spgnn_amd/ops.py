@@ -32,10 +32,11 @@ class KernelTimer:
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
     enabled = False
     records: dict = {}
+    only = None          # when set: record this one (kernel, shape) key only (two events per step: no perturbation)
 
     @classmethod
-    def start(cls):
-        cls.records, cls.enabled = {}, True
+    def start(cls, only=None):
+        cls.records, cls.enabled, cls.only = {}, True, only
 
     @classmethod
     def stop(cls):
@@ -52,13 +53,14 @@ class _timed:
         self.key = (name,) + tuple(shape)
 
     def __enter__(self):
-        if KernelTimer.enabled:
+        self.on = KernelTimer.enabled and (KernelTimer.only is None or KernelTimer.only == self.key)
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
         return self
 
     def __exit__(self, *exc):
-        if KernelTimer.enabled:
+        if self.on:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             KernelTimer.records.setdefault(self.key, []).append((self.a, b))
