@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 7
+#define SPGNN_ABI_VERSION 8
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -200,9 +200,13 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
  * power-of-two scale (*scale_a, *scale_b: device scalars from spgnn_pow2_scale, or NULL = 1) and the three
  * leading products are accumulated in fp32 (v_mfma_f32_32x32x16_f16); the result carries fp32-GEMM accuracy.
  * A and B rows must be 16-byte aligned (lda, ldb multiples of 4); K may be ragged.
+ * Optional exact fp32 rank-J update fused into the epilogue: C += U[M,J] * V[J,N] (upd_j <= 32; V rows
+ * 16-byte aligned and zero padded to a multiple of 4 columns; upd_j = 0 disables it).  The layer uses it for
+ * the score term of the input gradient, g_X = g_Y * W + g_S * W_lr, instead of a second pass over g_X.
  */
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
+                  const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                   spgnn_stream_t stream);
 
 /* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by
@@ -220,10 +224,12 @@ int spgnn_gemm_set_variant(int32_t variant);
  * operands (A = g_Y, B = X; replaces the SGEMM-TN behind nn.Linear's weight gradient).  The row range is
  * cut into `splits` chunks, chunk s writing its partial product to C + s*split_stride (each M x ldc);
  * the caller sums the partials (splits == 1: C is the result).  Same split-fp16 arithmetic as spgnn_gemm_nt.
+ * colsum_a (nullable): (splits, M) per-split column sums of A in plain fp32, taken from the operand stream the
+ * kernel reads anyway — with A = [g_ft | g_pre] its right half summed over splits is the bias gradient.
  */
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t split_stride, int32_t splits, int64_t R, int64_t M, int64_t N,
-                  const float* scale_a, const float* scale_b, spgnn_stream_t stream);
+                  const float* scale_a, const float* scale_b, float* colsum_a, spgnn_stream_t stream);
 
 /* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */

@@ -41,6 +41,9 @@ struct Args {
   int M, N, K;
   const float* sA; const float* sB;             // device scalars (power-of-two scales) or null (= 1)
   int nbm, nbn;
+  // optional exact fp32 rank-J update applied in the epilogue: C += U[M,J] * V[J,N]  (J <= 16; the score
+  // gradient term g_S * W_lr of the input gradient, which otherwise costs a read-modify-write pass over C)
+  const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
 };
 
 __device__ __forceinline__ void split4(float4 v, float s, half4& hi, half4& lo) {
@@ -377,8 +380,16 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
       const int lr = it * 4 + r_in;
       const int row = row0 + wm * 64 + i * 32 + lr;
       const int col = col0 + wn * 64 + c4;
-      const float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
+      float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
       if (row < a.M) {
+        if (a.J > 0 && col + 3 < a.ldv) {                 // exact fp32 rank-J term (V rows are zero padded)
+          const float* urow = a.U + (int64_t)row * a.ldu;
+          for (int jj = 0; jj < a.J; ++jj) {
+            const float u = urow[jj];
+            const float4 w = *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col);
+            v.x = fmaf(u, w.x, v.x); v.y = fmaf(u, w.y, v.y); v.z = fmaf(u, w.z, v.z); v.w = fmaf(u, w.w, v.w);
+          }
+        }
         float* dst = a.C + (int64_t)row * a.ldc + col;
         if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
         else {
@@ -416,6 +427,7 @@ struct ArgsTN {
   int64_t rows_per_split;
   const float* sA; const float* sB;
   int nbm, nbn;
+  float* colsum;                                  // optional (splits, M): per-split column sums of A (bias gradient)
 };
 
 // one 32 x 128 fp32 tile = 1024 float4; thread t takes float4 #(t + 256 i): row = idx / 32, c4 = idx % 32
@@ -503,8 +515,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
     load_tile_t(a.A, a.lda, r_beg, r_end, m0, a.M, ra);
     load_tile_t(a.B, a.ldb, r_beg, r_end, n0, a.N, rb);
   }
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // column sums of this thread's A columns (raw fp32, pre-split)
+  const bool do_colsum = a.colsum != nullptr && bn == 0;
   for (int64_t r0 = r_beg; r0 < r_end; r0 += TBK) {
     __syncthreads();
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+    }
     store_tile_t(Ah, Al, ra, sA);
     store_tile_t(Bh, Bl, rb, sB);
     __syncthreads();
@@ -536,6 +554,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
     }
   }
 
+  if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4) = csum;
+    __syncthreads();
+    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < a.M) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
+      a.colsum[(int64_t)blockIdx.y * a.M + m0 + threadIdx.x] = t_;
+    }
+  }
   const float alpha = 1.f / (sA * sB);
   float* Cp = a.C + (int64_t)blockIdx.y * a.split_stride;
 #pragma unroll
@@ -624,8 +654,16 @@ static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference
 int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 3) g_gemm_variant = v; return old; }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                  int64_t N, int64_t K, const float* scale_a, const float* scale_b, spgnn_stream_t stream) {
+                  int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
+                  int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, spgnn_stream_t stream) {
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
+  if (upd_j > 0) {
+    if (!upd_u || !upd_v) return SPGNN_ERR_NULLPTR;
+    if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
+        (reinterpret_cast<uintptr_t>(upd_v) & 15) || g_gemm_variant == 1)
+      return SPGNN_ERR_STRIDE;        // V rows: 16-byte aligned, zero padded to a multiple of 4 columns
+  }
   if (M == 0 || N == 0) return SPGNN_OK;
   if (!A || !B || !C) return SPGNN_ERR_NULLPTR;
   if (lda < K || ldb < K || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
@@ -634,7 +672,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_variant == 1) {
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN)};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
@@ -642,7 +680,8 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const int WM = (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN)};
+                 (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
+                 (int)upd_j};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
@@ -660,7 +699,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                   int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
-                  spgnn_stream_t stream) {
+                  float* colsum_a, spgnn_stream_t stream) {
   if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return SPGNN_ERR_SHAPE;
   if (!A || !B || !C) return SPGNN_ERR_NULLPTR;
   if (lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
@@ -670,7 +709,7 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
   gemm::ArgsTN a{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN)};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a};
   int64_t tiles = (int64_t)a.nbm * a.nbn;
   tiles = (tiles + 7) & ~int64_t(7);
   hipLaunchKernelGGL(gemm::gemm_tn_f16x3, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), 0,

@@ -364,25 +364,41 @@ class _GATLayerFn(torch.autograd.Function):
         amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device) if split else None
         gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
                     g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax)
-        g_bias = g_pre.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
         # [g_ft | g_pre] fills g_y when the layer has a residual; without one only g_ft does
         sg = scale_from_partials(amax if has_res else amax[N:]) if split else None
+        need_bias = ctx.has_bias and ctx.needs_input_grad[3]
+        g_bias = None
         g_wcat = None
         if ctx.needs_input_grad[1]:
             # tiny outputs (position stream, 39-wide inputs) leave the 128x128-tile kernel mostly idle: rocBLAS there
             big = g_y.shape[1] * K >= 128 * 512
-            g_wcat = gemm_tn(g_y, x, sg, sx) if (split and big) else _dw_gemm(g_y, x)
+            if split and big:
+                if need_bias and has_res:        # column sums of g_pre ride along with the operand stream
+                    g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True)
+                    g_bias = cs[HD:]
+                else:
+                    g_wcat = gemm_tn(g_y, x, sg, sx)
+            else:
+                g_wcat = _dw_gemm(g_y, x)
+        if need_bias and g_bias is None:
+            g_bias = g_pre.sum(0)
         g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[2] else None
         g_x = None
         if ctx.needs_input_grad[0]:
-            Kp = (K + 3) // 4 * 4                      # 16-byte rows for the in-place score-gradient pass
+            Kp = (K + 3) // 4 * 4                      # 16-byte rows for the vector kernels downstream
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
             if split:
                 w_t = w_cat.t().contiguous()           # (K, C): the input gradient is an NT product with W^T
-                gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x)
+                J = g_s.shape[1]
+                if J <= 32:                            # + g_S @ W_lr as an exact fp32 rank-2H update in the epilogue
+                    w_lr_p = torch.nn.functional.pad(w_lr, (0, _pad16(K) - K)).contiguous()
+                    gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x, upd_u=g_s, upd_v=w_lr_p)
+                else:
+                    gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x)
+                    scores_bwd_x_(g_x, g_s, w_lr)
             else:
                 torch.mm(g_y, w_cat, out=g_x)
-            scores_bwd_x_(g_x, g_s, w_lr)
+                scores_bwd_x_(g_x, g_s, w_lr)
         return g_x, g_wcat, g_wlr, g_bias, None, None, None, None, None, None, None, None, None
 
 
@@ -507,8 +523,10 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
-            scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """a (M,K) @ b (N,K)^T -> (M,N), fp32 in/out, fp16x3 split on the matrix cores."""
+            scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
+    in/out, fp16x3 split on the matrix cores."""
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -516,17 +534,24 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1
+    J = 0
+    if upd_u is not None:
+        J = upd_u.shape[1]
+        assert upd_u.shape[0] == M and upd_u.stride(1) == 1 and upd_v.shape[0] == J and upd_v.shape[1] >= N
+        assert _rows_aligned(upd_v) and upd_v.stride(0) >= (N + 3) // 4 * 4 and J <= 32
     with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
         _capi.check(_capi.load().spgnn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                               out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _stream(a)),
-                    "spgnn_gemm_nt")
+                                               out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(upd_u),
+                                               upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
+                                               _stream(a)), "spgnn_gemm_nt")
     return out
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
-            scale_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+            scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
-    over row chunks with a deterministic partial-sum reduction."""
+    over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
+    accumulated from the operand stream the kernel reads anyway."""
     _require_cuda(a, b)
     R, M = a.shape
     N = b.shape[1]
@@ -535,9 +560,12 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     splits = max(1, min(64, 512 // tiles, R // 256))
     ldc = (N + 3) // 4 * 4
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
+    cs = torch.empty((splits, M), dtype=torch.float32, device=a.device) if want_colsum else None
     with torch.cuda.device(a.device), _timed("gemm_tn", (R, M, N)):
         _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
-                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), _stream(a)),
-                    "spgnn_gemm_tn")
+                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), _ptr(cs),
+                                               _stream(a)), "spgnn_gemm_tn")
     out = part[0] if splits == 1 else part.sum(0)
+    if want_colsum:
+        return out[:, :N], (cs[0] if splits == 1 else cs.sum(0))
     return out[:, :N]

@@ -66,3 +66,24 @@ def test_gemm_mode_switch_gives_same_layer_output(monkeypatch):
         monkeypatch.setattr(ops, "GEMM_MODE", mode)
         outs[mode] = layer(g, x)
     assert rel_err(outs["f16x3"], outs["fp32"]) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K,J", [(300, 200, 64, 4), (5000, 768, 512, 4), (4097, 39, 256, 2), (129, 1063, 33, 16)])
+def test_gemm_nt_fused_rank_update(M, N, K, J):
+    """C = A B^T + U V (the score-gradient term of the input gradient) applied in the epilogue, exact fp32."""
+    a, b = _mat(M, K), _mat(N, K, 0.05)
+    u = torch.randn(M, J, device="cuda")
+    npad = (N + 15) // 16 * 16
+    v = torch.zeros(J, npad, device="cuda"); v[:, :N] = torch.randn(J, N, device="cuda")
+    out = torch.empty(M, (N + 3) // 4 * 4, device="cuda")[:, :N]
+    ops.gemm_nt(a, b, ops.pow2_scale(a), ops.pow2_scale(b), out=out, upd_u=u, upd_v=v)
+    ref = a.double() @ b.double().t() + u.double() @ v[:, :N].double()
+    assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("R,M,N", [(1000, 256, 128), (4097, 1024, 39), (76410, 512, 384), (513, 130, 300)])
+def test_gemm_tn_column_sums(R, M, N):
+    a, b = _mat(R, M, 1e-4), _mat(R, N)
+    c, cs = ops.gemm_tn(a, b, ops.pow2_scale(a), ops.pow2_scale(b), want_colsum=True)
+    assert rel_err(c, a.double().t() @ b.double()) < 2e-6
+    assert rel_err(cs, a.double().sum(0)) < 2e-6 and cs.shape == (M,)
