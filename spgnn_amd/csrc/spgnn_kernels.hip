@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include "spgnn_hip.h"
@@ -167,6 +168,7 @@ struct GatFwd {
   float* attn;
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
+  int npt;                               // consecutive nodes per team (1 = one node per team)
 };
 
 template <int R, int CH, bool MEAN>
@@ -174,9 +176,10 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
-  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  if (v >= a.N) return;
   const int lane = threadIdx.x % T;
+  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  const int64_t v_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
+  for (int64_t v = team * a.npt; v < v_end; ++v) {
   const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
 
   int hs[NS]; bool wr[NS]; float erv[NS];
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
     int64_t u[kMaxFast];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) u[k] = k < deg ? a.indices[beg + k] : 0;
+    // (Fetching the neighbour rows before the softmax arithmetic, to overlap them with the score loads, was
+    // measured 10-20 % SLOWER on MI355X for the narrow layers: more live registers, no shorter critical path.)
     float w[kMaxFast][NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
       st4(a.out_mean + v * a.out_mean_ld + (rr * T + lane) * 4, m);
     }
   }
+  }   // node loop
 }
 
 // scalar fallback: one thread per (node, column); any H, D, stride, alignment
@@ -333,6 +339,7 @@ struct GatBwdDst {
   float* absmax;                         // optional: absmax[v] = max |g_pre[v,:]| (feeds the split-GEMM scale)
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
+  int npt;
 };
 
 template <int R, int CH>
@@ -340,9 +347,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
-  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  if (v >= a.N) return;
   const int lane = threadIdx.x % T;
+  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  const int64_t v_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
+  for (int64_t v = team * a.npt; v < v_end; ++v) {
   const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
   const int width = (CH == 0) ? a.W : T;
   const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
       }
       if (wr[s]) a.g_er[v * a.gs_ld + hs[s]] = ger;
     }
-    return;
+    continue;
   }
 
   // general degree: pass 1 keeps g_a in g_e (written and re-read by the same writer lane), pass 2 finishes
@@ -460,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
     }
     a.g_er[v * a.gs_ld + hs[s]] = ger;
   }
+  }   // node loop
 }
 
 // scalar fallback: one thread per (node, head)
@@ -514,6 +523,7 @@ struct GatBwdSrc {
   float* absmax;                         // optional: absmax[u] = max |g_ft[u,:]|
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
+  int npt;
 };
 
 template <int R, int CH>
@@ -521,9 +531,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
-  const int64_t u = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  if (u >= a.N) return;
   const int lane = threadIdx.x % T;
+  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  const int64_t u_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
+  for (int64_t u = team * a.npt; u < u_end; ++u) {
   const int beg = a.out_indptr[u], end = a.out_indptr[u + 1], deg = end - beg;
   int hs[NS]; bool wr[NS]; float gel[NS];
 #pragma unroll
@@ -575,6 +586,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
     mx = team_max(mx, T);
     if (lane == 0) a.absmax[u] = mx;
   }
+  }   // node loop
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -1004,6 +1016,14 @@ const char* spgnn_last_error(void) { return g_err; }
 
 // Geometry of the vector GAT kernels for (H, D): team width T, chunks per lane R, chunks per head CH
 // (0 = heads narrower than the team, reduction width W).  false -> scalar fallback.
+// Consecutive nodes per team.  Measured (tools/npt_sweep.py, MI355X): 1 is best - 2/4/8/16 nodes per team are
+// 2/8/24/50 % slower; many short-lived workgroups hide the dependent index -> score -> row latency chain better
+// than a loop inside fewer workgroups does.  SPGNN_NPT overrides (A/B runs only).
+static int nodes_per_team(int64_t, int) {
+  static const int forced = []() { const char* e = getenv("SPGNN_NPT"); return e ? atoi(e) : 0; }();
+  return forced > 0 ? forced : 1;
+}
+
 static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
   if (D % 4) return false;
   if (!pick_team((int64_t)H * D, T, R)) return false;
@@ -1050,7 +1070,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed};
+           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, 1};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
                    vec_ok(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
@@ -1060,7 +1080,8 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
                                    "(see spgnn_gat_can_fuse_mean)");
   if (vec) {
     a.T = T;
-    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+    a.npt = nodes_per_team(N, T);
+    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
     if (fuse_mean) {
 #define X(R_, CH_) hipLaunchKernelGGL((gat_fwd_vec<R_, CH_, true>), grid, block, 0, st, a)
       SPGNN_FOR_R_CH(R, CH, X)
@@ -1100,13 +1121,14 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
   hipStream_t st = (hipStream_t)stream;
   GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
               g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
-              activation, p_drop, 1.f / (1.f - p_drop), seed};
+              activation, p_drop, 1.f / (1.f - p_drop), seed, 1};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
                    vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
   if (vec) {
     a.T = T; a.W = W;
-    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+    a.npt = nodes_per_team(N, T);
+    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
 #define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_dst_vec<R_, CH_>), grid, block, 0, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
@@ -1131,11 +1153,12 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed};
+              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, 1};
   int T = 0, R = 0, CH = 0, W = 0;
   if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
     a.T = T;
-    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+    a.npt = nodes_per_team(N, T);
+    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
 #define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_src_vec<R_, CH_>), grid, block, 0, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X

@@ -35,11 +35,11 @@ for (H, D, mean) in shapes:
         _capi.check(_capi._lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), y.data_ptr(), y.stride(0),
             s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(), g_out.data_ptr(), g_out.stride(0), int(mean),
             out.data_ptr(), out.stride(0), g_y[:, HD:].data_ptr(), g_y.stride(0), g_e.data_ptr(), g_s[:, H:].data_ptr(),
-            g_s.stride(0), N, E, H, D, 0.2, ops.ACT_ELU, 0.0, 0, st), "dst")
+            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, 0.0, 0, st), "dst")
     def src():
         _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(),
             attn.data_ptr(), g_e.data_ptr(), g_y[:, HD:].data_ptr(), g_y.stride(0), g_y.data_ptr(), g_y.stride(0),
-            g_s.data_ptr(), g_s.stride(0), N, E, H, D, 0.0, 0, st), "src")
+            g_s.data_ptr(), g_s.stride(0), 0, N, E, H, D, 0.0, 0, st), "src")
     for name, fn in (("fwd", fwd), ("dst", dst), ("src", src)):
         for lib in libs.values():
             _capi._lib = lib; fn()
