@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-trees", type=int, default=32)
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (single GPU); per-kernel figures then come from the "
+                         "eager instrumented warm-up steps only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,14 +194,20 @@ def main():
     hip_keys = [k for k in kt_all if k[0] not in ("gemm_nt", "gemm_tn", "absmax")]
     dom = max(hip_keys, key=lambda k: sum(kt_all[k])) if hip_keys else None
     sync()
-    if dom is not None:
-        ops.KernelTimer.start(only=dom)
+    if args.graph:
+        step.capture(g)
+        run_step = step.replay
+        sync()
+    else:
+        run_step = lambda: step.step(g)
+        if dom is not None:
+            ops.KernelTimer.start(only=dom)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step.step(g)
+        loss = run_step()
     sync()
     elapsed = time.perf_counter() - t0
-    kt_dom = ops.KernelTimer.stop() if dom is not None else {}
+    kt_dom = ops.KernelTimer.stop() if (dom is not None and not args.graph) else {}
     kt = dict(kt_all)
     loss_val = float(loss)
 
@@ -222,7 +231,7 @@ def main():
                                    f"random fan-out trees n~U[120,180], fp32, dropout {'off' if args.no_dropout else 'on'}",
                        "trees_per_gpu": args.trees, "global_trees": args.trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}", "launch": "hip-graph replay" if args.graph else "eager",
                        "gemm": ("split-fp16 x3 MFMA, fp32 accumulate (fp32-GEMM accuracy)" if ops.GEMM_MODE == "f16x3"
                                 else "fp32 (rocBLAS/hipBLASLt via torch.mm)")},
             "graph_edges_per_s": E_all * args.steps / elapsed, "loss": loss_val,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 8
+#define SPGNN_ABI_VERSION 9
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -64,7 +64,8 @@ const char* spgnn_last_error(void);
  * With out_mean set, `out` may be NULL iff spgnn_gat_can_fuse_mean(H, D) (the backward only needs the
  * per-head output when an activation is fused).
  * p_drop in [0,1): attention dropout; the keep mask is a counter-based hash of (seed, slot, h),
- * regenerated (not stored) by the backward entry points.
+ * regenerated (not stored) by the backward entry points.  seed_offset (nullable): a device word added to
+ * `seed` at run time, so a captured HIP graph draws a fresh mask on every replay.
  */
 int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   const float* ft, int64_t ft_stride,
@@ -76,7 +77,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   float* attn,
                   int64_t N, int64_t E, int32_t H, int32_t D,
                   float negative_slope, int32_t activation,
-                  float p_drop, uint64_t seed,
+                  float p_drop, uint64_t seed, const uint64_t* seed_offset /* nullable device word added to seed */,
                   spgnn_stream_t stream);
 
 /* 1 if the vector kernel fuses the head mean for this (H, D) (a head is at least one team wide). */
@@ -107,7 +108,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
                       float* absmax /* nullable: absmax[v] = max|g_pre[v,:]| */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float negative_slope, int32_t activation,
-                      float p_drop, uint64_t seed,
+                      float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       spgnn_stream_t stream);
 
 /*
@@ -124,7 +125,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       float* g_el, int64_t g_s_stride,
                       float* absmax /* nullable: absmax[u] = max|g_ft[u,:]| */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
-                      float p_drop, uint64_t seed,
+                      float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       spgnn_stream_t stream);
 
 /*
@@ -256,8 +257,8 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
  * grad_scale is a DEVICE scalar (1 / global sum of class weights after the all-reduce).
  */
 int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf,
-                            const float* grad_scale, int64_t n,
-                            float lr, float momentum, float weight_decay, int32_t first_step,
+                            const float* grad_scale, const float* lr_dev /* nullable: overrides lr (graph replay) */,
+                            int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
                             spgnn_stream_t stream);
 
 #ifdef __cplusplus

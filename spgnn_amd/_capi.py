@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -23,12 +23,12 @@ SIGNATURES = {
     "spgnn_abi_version": [],
     "spgnn_last_error": [],
     "spgnn_gat_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,
-                      _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
+                      _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_gat_can_fuse_mean": [_i32, _i32],
     "spgnn_gat_bwd_dst": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _f32p, _i64,
-                          _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp],
+                          _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p,
-                          _i64, _i64, _i32, _i32, _f32, _u64, _vp],
+                          _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
     "spgnn_scores_bwd_w": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
@@ -41,7 +41,7 @@ SIGNATURES = {
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
     "spgnn_tree_distance_encoding": [_i32p, _i32p, _vp, _i32p, _i32, _f32p, _i64, _i32p, _i64, _i64, _vp],
-    "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
+    "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -169,10 +169,12 @@ struct GatFwd {
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   int npt;                               // consecutive nodes per team (1 = one node per team)
+  const uint64_t* seed_off;              // optional device word added to `seed` (fresh masks under graph replay)
 };
 
 template <int R, int CH, bool MEAN>
 __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
 
 // scalar fallback: one thread per (node, column); any H, D, stride, alignment
 __global__ void gat_fwd_scalar(GatFwd a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   const int HD = a.H * a.D;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= a.N * HD) return;
@@ -340,10 +343,12 @@ struct GatBwdDst {
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   int npt;
+  const uint64_t* seed_off;
 };
 
 template <int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
 
 // scalar fallback: one thread per (node, head)
 __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= a.N * a.H) return;
   const int64_t v = gid / a.H; const int h = (int)(gid % a.H);
@@ -524,10 +530,12 @@ struct GatBwdSrc {
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
   int npt;
+  const uint64_t* seed_off;
 };
 
 template <int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   const int T = a.T;
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
   const int HD = a.H * a.D;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= a.N * HD) return;
@@ -983,8 +992,10 @@ __global__ __launch_bounds__(256) void tree_distance_encoding(const int32_t* __r
 // SGD + momentum over a flat bucket
 // =================================================================================================
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    const float* __restrict__ gscale, int64_t n, float lr, float mom, float wd, int first) {
+                                    const float* __restrict__ gscale, const float* __restrict__ lr_dev, int64_t n, float lr,
+                                    float mom, float wd, int first) {
   const float sc = gscale ? gscale[0] : 1.f;
+  if (lr_dev) lr = lr_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float w = p[i];
     const float gi = fmaf(wd, w, g[i] * sc);
@@ -1057,7 +1068,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
                   const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
                   const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                   float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
-                  float p_drop, uint64_t seed, spgnn_stream_t stream) {
+                  float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !ft || !el || !er || !attn || (!out && !out_mean) || (E > 0 && !indices))
@@ -1070,7 +1081,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, 1};
+           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
                    vec_ok(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
@@ -1106,7 +1117,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
                       int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
                       int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
                       int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
-                      uint64_t seed, spgnn_stream_t stream) {
+                      uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
@@ -1121,7 +1132,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
   hipStream_t st = (hipStream_t)stream;
   GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
               g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
-              activation, p_drop, 1.f / (1.f - p_drop), seed, 1};
+              activation, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
                    vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
@@ -1142,7 +1153,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
 int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
                       const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
                       float* g_el, int64_t g_s_stride, float* absmax, int64_t N, int64_t E, int32_t H, int32_t D,
-                      float p_drop, uint64_t seed, spgnn_stream_t stream) {
+                      float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (!out_indptr || !attn || !g_e || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos)))
@@ -1153,7 +1164,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, 1};
+              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
     a.T = T;
@@ -1298,15 +1309,16 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
   return check_launch("spgnn_tree_distance_encoding");
 }
 
-int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale, int64_t n,
-                            float lr, float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale,
+                            const float* lr_dev, int64_t n, float lr, float momentum, float weight_decay,
+                            int32_t first_step, spgnn_stream_t stream) {
   if (n < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sgd_momentum_step: n < 0");
   if (n == 0) return SPGNN_OK;
   if (!param || !grad || !momentum_buf) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step: null pointer");
   int64_t blocks = (n + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, grad_scale, n, lr, momentum, weight_decay, first_step);
+                     momentum_buf, grad_scale, lr_dev, n, lr, momentum, weight_decay, first_step);
   return check_launch("spgnn_sgd_momentum_step");
 }
 

@@ -26,6 +26,16 @@ ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 # default), "fp32" = rocBLAS/hipBLASLt SGEMM through torch.mm.
 GEMM_MODE = os.environ.get("SPGNN_GEMM", "f16x3")
 
+# Optional device word (int64 tensor, one element) added to every attention-dropout seed at run time.  A step
+# captured into a HIP graph bakes its host-drawn seeds in; incrementing this word inside the captured step
+# (train.TrainStep does) gives every replay fresh masks.
+DROPOUT_SEED_OFFSET: Optional["torch.Tensor"] = None
+
+
+def _seed_off_ptr(device) -> int:
+    t = DROPOUT_SEED_OFFSET
+    return t.data_ptr() if t is not None and t.device == device else 0
+
 
 class KernelTimer:
     """Optional per-launch HIP-event timing of the message-passing kernels (bench.py's roofline leg).
@@ -122,7 +132,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
                                       res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
                                       out.stride(0) if out is not None else 0, _ptr(out_mean),
                                       out_mean.stride(0) if mean else 0, attn.data_ptr(), N, E, H, D, slope, act,
-                                      p_drop, seed, _stream(ft)), "spgnn_gat_fwd")
+                                      p_drop, seed, _seed_off_ptr(ft.device), _stream(ft)), "spgnn_gat_fwd")
     return out, out_mean, attn
 
 
@@ -147,14 +157,14 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
                                           g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                           g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax), N, E, H, D, slope,
-                                          act, p_drop, seed, st), "spgnn_gat_bwd_dst")
+                                          act, p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_dst")
         t_dst.__exit__()
         t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                           csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
                                           g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, N, E, H, D,
-                                          p_drop, seed, st), "spgnn_gat_bwd_src")
+                                          p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src")
         t_src.__exit__()
     return g_e
 
@@ -495,15 +505,16 @@ def spmm_max(csc: DeviceCSC, x) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float,
                        weight_decay: float = 0.0, first_step: bool = False,
-                       grad_scale: Optional[torch.Tensor] = None) -> None:
-    _require_cuda(param, grad, buf, grad_scale)
+                       grad_scale: Optional[torch.Tensor] = None, lr_dev: Optional[torch.Tensor] = None) -> None:
+    """``lr_dev`` (device scalar) overrides ``lr`` at run time (learning-rate schedules under graph replay)."""
+    _require_cuda(param, grad, buf, grad_scale, lr_dev)
     assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
     assert param.dtype == grad.dtype == buf.dtype == torch.float32 and param.numel() == grad.numel() == buf.numel()
     lib = _capi.load()
     with torch.cuda.device(param.device):
         _capi.check(lib.spgnn_sgd_momentum_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), _ptr(grad_scale),
-                                                param.numel(), lr, momentum, weight_decay, int(first_step),
-                                                _stream(param)), "spgnn_sgd_momentum_step")
+                                                _ptr(lr_dev), param.numel(), lr, momentum, weight_decay,
+                                                int(first_step), _stream(param)), "spgnn_sgd_momentum_step")
 
 
 # --------------------------------------------------------------------------------------------

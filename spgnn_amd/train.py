@@ -98,6 +98,8 @@ class TrainStep:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._sampling_cache = None
+        self._graph = None
+        self._lr_dev = None
 
     def _sampling(self, g):
         y = g.ndata["y"]
@@ -112,7 +114,12 @@ class TrainStep:
         y = g.ndata["y"]
         p = self._sampling(g)
         if draws is None:
-            draws = torch.rand(p.shape, device=p.device, generator=self.gen)
+            if getattr(self, "_use_default_rng", False):       # graph capture: torch's default generator is graph-safe
+                draws = torch.rand(p.shape, device=p.device)
+            else:
+                draws = torch.rand(p.shape, device=p.device, generator=self.gen)
+        if getattr(self, "_seed_ctr", None) is not None:
+            self._seed_ctr.add_(1)
         mask = mask_from_draws(draws, p)
         logits = self.model(g)[0]
         num, den = weighted_nll_sums(logits, y, mask, self.class_weight)
@@ -132,7 +139,40 @@ class TrainStep:
         """Fused SGD(momentum) over the flat bucket: one HIP launch (spgnn_sgd_momentum_step)."""
         b = self.bucket
         ops.sgd_momentum_step_(b.flat_param, b.flat_grad, b.flat_mom, self.lr, self.momentum, self.weight_decay,
-                               first_step=(b.steps == 0), grad_scale=inv)
+                               first_step=(b.steps == 0), grad_scale=inv, lr_dev=self._lr_dev)
 
     def set_lr(self, lr: float):
         self.lr = lr
+        if self._lr_dev is not None:
+            self._lr_dev.fill_(lr)
+
+    # ---- HIP-graph replay of the static-graph step ---------------------------------------------------------
+    def capture(self, g, warmup: int = 3):
+        """Capture one optimizer step on the static batched graph ``g`` into a HIP graph (the reference takes 300
+        steps on each batched graph, job_runner.py:1892).  At the reference's own batch of 64 trees the step is
+        ~360 launches of a few microseconds each and is launch-bound when issued eagerly; a replay is one launch.
+        Randomness stays fresh per replay: the node-mask draws and feature dropout use torch's graph-safe Philox
+        offsets, attention dropout adds a device counter (ops.DROPOUT_SEED_OFFSET) that the captured step increments;
+        the learning rate is read from a device scalar (``set_lr`` keeps working)."""
+        if self.world > 1:
+            raise NotImplementedError("graph capture is wired for the single-process step")
+        dev = self.bucket.flat_param.device
+        self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
+        self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.DROPOUT_SEED_OFFSET = self._seed_ctr
+        self._use_default_rng = True
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):        # warm-up on the capture stream: lazy inits, allocator pools, steps > 0
+                self._static_loss = self.step(g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self.step(g)
+        return self
+
+    def replay(self) -> torch.Tensor:
+        self._graph.replay()
+        return self._static_loss

@@ -179,3 +179,33 @@ def test_full_batch_attention_rows_sum_to_one_and_linearity(big):
     const = torch.randn(1, H * D, device="cuda").expand(N, -1).contiguous()
     oc = ops.gat_fwd_raw(csc, const, el, er, None, None, H, D, 0.2, 0)[0]
     assert rel_err(oc, const) < 1e-5                                # constant rows: out == ft
+
+
+def test_graph_replay_matches_eager_and_refreshes_dropout():
+    """TrainStep.capture: replays of the captured step train like eager steps; with dropout on, successive
+    replays draw different attention-dropout masks (device seed counter) and losses stay finite."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build("st_gat_3", seed=3)
+    g = synthetic.make_batch(4, rank=2, device="cuda", pos_enc_dim=None)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    model.eval()                                           # deterministic arithmetic: replay == eager
+    eager = copy.deepcopy(model)
+    ts_g = TrainStep(model, w, 1.0, 1e-3, 0.9)             # sampling rate 1: the mask does not depend on the RNG
+    ts_e = TrainStep(eager, w, 1.0, 1e-3, 0.9)
+    ts_g.capture(g, warmup=2)                              # two eager warm-up steps; the capture itself executes nothing
+    for _ in range(3):
+        lg = ts_g.replay()
+    for _ in range(5):
+        le = ts_e.step(g)
+    assert torch.isfinite(lg) and rel_err(lg, le) < 1e-5
+    n = ts_g.bucket.numel
+    assert rel_err(ts_g.bucket.flat_param[:n], ts_e.bucket.flat_param[:n]) < 1e-6     # 2 + 3 steps == 5 steps
+    _ops.DROPOUT_SEED_OFFSET = None
+    # fresh attention-dropout masks per replay
+    cfg, model = _build("st_gat_3", seed=4)
+    model.train()
+    ts = TrainStep(model, w, 1.0, 0.0, 0.0)                # lr 0: parameters frozen, only the masks change
+    ts.capture(g, warmup=1)
+    l1 = float(ts.replay()); l2 = float(ts.replay()); l3 = float(ts.replay())
+    assert len({l1, l2, l3}) == 3 and all(np.isfinite([l1, l2, l3]))
+    _ops.DROPOUT_SEED_OFFSET = None
