@@ -86,6 +86,16 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     default:             return x;
   }
 }
+// whole register rows at once: one wave-uniform switch, then straight-line element code
+template <int R> __device__ __forceinline__ void act_fwd_rows(float4 (&o)[R], int act) {
+#define SPGNN_ROWS(EXPR) _Pragma("unroll") for (int r = 0; r < R; ++r) { \
+    { float x = o[r].x; o[r].x = (EXPR); } { float x = o[r].y; o[r].y = (EXPR); } \
+    { float x = o[r].z; o[r].z = (EXPR); } { float x = o[r].w; o[r].w = (EXPR); } }
+  if (act == SPGNN_ACT_ELU) { SPGNN_ROWS(x > 0.f ? x : expm1f(x)) }
+  else if (act == SPGNN_ACT_TANH) { SPGNN_ROWS(tanhf(x)) }
+  else if (act == SPGNN_ACT_RELU) { SPGNN_ROWS(x > 0.f ? x : 0.f) }
+#undef SPGNN_ROWS
+}
 // derivative expressed through the OUTPUT y = act(x) (what the forward saved)
 __device__ __forceinline__ float act_bwd_from_out(float y, int act) {
   switch (act) {
@@ -94,6 +104,16 @@ __device__ __forceinline__ float act_bwd_from_out(float y, int act) {
     case SPGNN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
     default:             return 1.f;
   }
+}
+
+template <int R> __device__ __forceinline__ void act_bwd_rows(float4 (&g)[R], const float4 (&o)[R], int act) {
+#define SPGNN_ROWS(EXPR) _Pragma("unroll") for (int r = 0; r < R; ++r) { \
+    { float y = o[r].x; g[r].x *= (EXPR); } { float y = o[r].y; g[r].y *= (EXPR); } \
+    { float y = o[r].z; g[r].z *= (EXPR); } { float y = o[r].w; g[r].w *= (EXPR); } }
+  if (act == SPGNN_ACT_ELU) { SPGNN_ROWS(y > 0.f ? 1.f : y + 1.f) }
+  else if (act == SPGNN_ACT_TANH) { SPGNN_ROWS(1.f - y * y) }
+  else if (act == SPGNN_ACT_RELU) { SPGNN_ROWS(y > 0.f ? 1.f : 0.f) }
+#undef SPGNN_ROWS
 }
 
 // Counter-based keep mask for attention dropout: one 64-bit mix of (seed, slot*H + h).  The
@@ -107,6 +127,11 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p,
   return u >= p ? inv_keep : 0.f;
 }
 
+// wave-uniform value -> SGPR (no-op when the template flag is off)
+template <bool ON> __device__ __forceinline__ int uni(int x) { return ON ? __builtin_amdgcn_readfirstlane(x) : x; }
+template <bool ON> __device__ __forceinline__ float uni(float x) {
+  return ON ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : x;
+}
 template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
 #pragma unroll
   for (int off = W >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -136,17 +161,21 @@ __device__ __forceinline__ float team_sum(float x, int width) {
 // registers; larger degrees fall back to multi-pass loops of identical arithmetic.
 // =================================================================================================
 constexpr int kMaxFast = 8;
-// A/B switches (tools/ab_kernels.py, MI355X, 512 trees): the up-front path is 23 % faster for the forward
-// (it removes two dependent passes over the edge list), neutral for the dst-major backward and 15 % SLOWER
-// for the src-major backward (already a single pass) - so only the forward takes it by default.
+// A/B switches (tools/ab_kernels.py, MI355X, 512 trees).  With exec-masked per-edge branches (one s_waitcnt per
+// load) the up-front path only paid off for the forward; written as unconditional clamped loads + wave-uniform
+// scalars it wins everywhere: fwd 1213 -> 692 us, bwd_dst 1162 -> 779 us, bwd_src 540 -> 451 us summed over the
+// seven st_pgat_spgnn_3 layer shapes (2x1024 forward alone 770 -> 385 us = 5.7 TB/s algorithmic).
 #ifndef SPGNN_FWD_FAST
 #define SPGNN_FWD_FAST 1
 #endif
+#ifndef SPGNN_GATHER8
+#define SPGNN_GATHER8 1
+#endif
 #ifndef SPGNN_DST_FAST
-#define SPGNN_DST_FAST 0
+#define SPGNN_DST_FAST 1
 #endif
 #ifndef SPGNN_SRC_FAST
-#define SPGNN_SRC_FAST 0
+#define SPGNN_SRC_FAST 1
 #endif
 
 template <int R, int CH> struct Slots {
@@ -168,47 +197,81 @@ struct GatFwd {
   float* attn;
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
-  int npt;                               // consecutive nodes per team (1 = one node per team)
   const uint64_t* seed_off;              // optional device word added to `seed` (fresh masks under graph replay)
 };
 
-template <int R, int CH, bool MEAN>
+// TT = 64: the team is the whole wave (one node per wave).  Node id, degree, edge endpoints and - when a head is
+// at least a wave wide (CH >= 1) - the attention weights are then wave-uniform: they are moved to SGPRs
+// (v_readfirstlane), row bases become scalar, the degree tests become scalar branches, and about 30 VGPRs per
+// lane are freed (2x1024 forward: 159 -> ~90 VGPRs).  TT = 0: team width a.T < 64 at run time (several nodes
+// per wave; only R = 1 geometries get there), everything stays per lane.
+template <int TT, int R, int CH, bool MEAN>
 __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
-  const int T = a.T;
+  constexpr bool WAVE = TT == 64;
+  constexpr bool UW = WAVE && CH >= 1;          // per-edge weights are wave-uniform too
+  const int T = WAVE ? 64 : a.T;
   const int lane = threadIdx.x % T;
-  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  const int64_t v_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
-  for (int64_t v = team * a.npt; v < v_end; ++v) {
-  const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
+  if (v >= a.N) return;
+#ifdef SPGNN_DIAG
+  const int beg = uni<WAVE>(a.indptr[v]), end = (SPGNN_DIAG & 4) ? beg + 1 : uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
+#else
+  const int beg = uni<WAVE>(a.indptr[v]), end = uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
+#endif
 
   int hs[NS]; bool wr[NS]; float erv[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
-    hs[s] = c0 / a.D;
+    hs[s] = (CH == 0) ? c0 / a.D : s;
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+#ifdef SPGNN_DIAG
+    if (SPGNN_DIAG & 8) wr[s] = false;
+#endif
     erv[s] = a.er[v * a.s_ld + hs[s]];
   }
+  // The accumulator starts from the residual row (+ bias): those loads depend on nothing, so they are in flight
+  // while the index -> score -> neighbour-row chain resolves (as an epilogue they cost a serial HBM round trip).
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  if (SPGNN_FWD_FAST && deg <= kMaxFast) {
-    int64_t u[kMaxFast];
+#ifdef SPGNN_DIAG
+  if (a.res && !(SPGNN_DIAG & 2)) {
+#else
+  if (a.res) {
+#endif
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = k < deg ? a.indices[beg + k] : 0;
-    // (Fetching the neighbour rows before the softmax arithmetic, to overlap them with the score loads, was
-    // measured 10-20 % SLOWER on MI355X for the narrow layers: more live registers, no shorter critical path.)
+    for (int r = 0; r < R; ++r) acc[r] = ld4(a.res + v * a.res_ld + (r * T + lane) * 4);
+  }
+  if (a.bias) {
+    float4 q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] = ld4(a.bias + (r * T + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r].x += q[r].x; acc[r].y += q[r].y; acc[r].z += q[r].z; acc[r].w += q[r].w; }
+  }
+
+  if (SPGNN_FWD_FAST && deg > 0 && deg <= kMaxFast) {
+    // Straight-line loads: every index / score load is unconditional (slot k >= deg re-reads the last edge and
+    // gets weight 0), so they issue back to back instead of one exec-masked branch and one s_waitcnt per edge;
+    // neighbour rows then arrive in batches of kGather edges behind a wave-uniform test.
+    int u[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
     float w[kMaxFast][NS];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) w[k][s] = a.el[(int64_t)u[k] * a.s_ld + hs[s]];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       float mx = -INFINITY;
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) {
-        w[k][s] = k < deg ? lrelu(a.el[u[k] * a.s_ld + hs[s]] + erv[s], a.slope) : -INFINITY;
+        w[k][s] = k < deg ? lrelu(w[k][s] + erv[s], a.slope) : -INFINITY;
         mx = fmaxf(mx, w[k][s]);
       }
       float sm = 0.f;
@@ -219,21 +282,35 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
       }
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) {
-        if (k < deg) {
-          const float al = w[k][s] / sm;
-          const int64_t eidx = (int64_t)(beg + k) * a.H + hs[s];
-          if (wr[s]) a.attn[eidx] = al;
-          w[k][s] = a.p > 0.f ? al * keep_scale(a.seed, eidx, a.p, a.inv_keep) : al;
-        }
+        const float al = w[k][s] / sm;
+        if (wr[s] && k < deg) a.attn[(int64_t)(beg + k) * a.H + hs[s]] = al;
+        w[k][s] = al;
       }
     }
+    if (a.p > 0.f) {
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) {
-      if (k < deg) {
-        const float* row = a.ft + u[k] * a.ft_ld;
+      for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
-        for (int r = 0; r < R; ++r) fma4(acc[r], w[k][SL::of(r)], ld4(row + (r * T + lane) * 4));
-      }
+        for (int s = 0; s < NS; ++s)
+          w[k][s] *= keep_scale(a.seed, (int64_t)(beg + (k < deg ? k : deg - 1)) * a.H + hs[s], a.p, a.inv_keep);
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) w[k][s] = uni<UW>(w[k][s]);
+    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);   // edges per batch (8 float4 in flight for R >= 2)
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      float4 x[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], w[k0 + q][SL::of(r)], x[q][r]);
     }
   } else {
     float mx[NS], sm[NS];
@@ -263,17 +340,14 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
     }
   }
 
+  act_fwd_rows<R>(acc, a.act);
+#ifdef SPGNN_DIAG
+  if (a.out && !(SPGNN_DIAG & 1)) {
+#else
+  if (a.out) {
+#endif
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int c = (r * T + lane) * 4;
-    float4 o = acc[r];
-    if (a.res) { const float4 q = ld4(a.res + v * a.res_ld + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-    if (a.bias) { const float4 q = ld4(a.bias + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-    if (a.act != SPGNN_ACT_NONE) {
-      o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act);
-    }
-    if (a.out) st4(a.out + v * a.out_ld + c, o);
-    acc[r] = o;
+    for (int r = 0; r < R; ++r) st4(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]);
   }
   if (MEAN) {   // heads live in chunks r, r+CH, r+2CH, ... of the same lane (CH >= 1): mean is lane-local
     constexpr int CHs = CH == 0 ? 1 : CH;
@@ -287,7 +361,11 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
       st4(a.out_mean + v * a.out_mean_ld + (rr * T + lane) * 4, m);
     }
   }
-  }   // node loop
+}
+
+// teams narrower than a wave exist only for R = 1 (pick_team tries 64 lanes first): keep the other instances out
+template <int R, int CH, bool MEAN> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatFwd& a) {
+  if constexpr (R == 1) hipLaunchKernelGGL((gat_fwd_vec<0, R, CH, MEAN>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, column); any H, D, stride, alignment
@@ -342,38 +420,46 @@ struct GatBwdDst {
   float* absmax;                         // optional: absmax[v] = max |g_pre[v,:]| (feeds the split-GEMM scale)
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
-  int npt;
   const uint64_t* seed_off;
 };
 
-template <int R, int CH>
+template <int TT, int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
-  const int T = a.T;
+  constexpr bool WAVE = TT == 64;               // see gat_fwd_vec
+  constexpr bool UW = WAVE && CH >= 1;
+  const int T = WAVE ? 64 : a.T;
   const int lane = threadIdx.x % T;
-  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  const int64_t v_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
-  for (int64_t v = team * a.npt; v < v_end; ++v) {
-  const int beg = a.indptr[v], end = a.indptr[v + 1], deg = end - beg;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
+  if (v >= a.N) return;
+  const int beg = uni<WAVE>(a.indptr[v]), end = uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
   const int width = (CH == 0) ? a.W : T;
   const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
 
+  // g = dL/d(pre-activation row): all row loads first, then the activation derivative with one uniform switch
   float4 g[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int c = (r * T + lane) * 4;
-    float4 q = ld4(a.g_out + v * a.g_out_ld + (a.mean ? c % a.D : c));
-    if (a.mean) { q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale; }
-    if (a.act != SPGNN_ACT_NONE) {
-      const float4 o = ld4(a.out + v * a.out_ld + c);
-      q.x *= act_bwd_from_out(o.x, a.act); q.y *= act_bwd_from_out(o.y, a.act);
-      q.z *= act_bwd_from_out(o.z, a.act); q.w *= act_bwd_from_out(o.w, a.act);
-    }
-    g[r] = q;
-    st4(a.g_pre + v * a.g_pre_ld + c, q);
+    g[r] = ld4(a.g_out + v * a.g_out_ld + (a.mean ? (CH >= 1 ? ((r % (CH ? CH : 1)) * T + lane) * 4 : c % a.D) : c));
   }
+  if (a.act != SPGNN_ACT_NONE) {
+    float4 o[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) o[r] = ld4(a.out + v * a.out_ld + (r * T + lane) * 4);
+    if (a.mean) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { g[r].x *= gscale; g[r].y *= gscale; g[r].z *= gscale; g[r].w *= gscale; }
+    }
+    act_bwd_rows<R>(g, o, a.act);
+  } else if (a.mean) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { g[r].x *= gscale; g[r].y *= gscale; g[r].z *= gscale; g[r].w *= gscale; }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) st4(a.g_pre + v * a.g_pre_ld + (r * T + lane) * 4, g[r]);
   if (a.absmax) {
     float mx = 0.f;
 #pragma unroll
@@ -385,55 +471,67 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
-    hs[s] = c0 / a.D;
+    hs[s] = (CH == 0) ? c0 / a.D : s;
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
   }
 
-  if (SPGNN_DST_FAST && deg <= kMaxFast) {
-    int64_t u[kMaxFast];
+  if (SPGNN_DST_FAST && deg > 0 && deg <= kMaxFast) {
+    // unconditional, batched loads (slot k >= deg repeats the last edge with attention 0): see gat_fwd_vec
+    int u[kMaxFast];
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = k < deg ? a.indices[beg + k] : 0;
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    float al[kMaxFast][NS], ep[kMaxFast][NS], erv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) erv[s] = a.er[v * a.s_ld + hs[s]];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        al[k][s] = a.attn[(int64_t)(beg + (k < deg ? k : deg - 1)) * a.H + hs[s]];
+        ep[k][s] = a.el[(int64_t)u[k] * a.s_ld + hs[s]];
+      }
     float ga[kMaxFast][NS];
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) {
+    for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
       for (int s = 0; s < NS; ++s) ga[k][s] = 0.f;
-      if (k < deg) {
-        const float* row = a.ft + u[k] * a.ft_ld;
+    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
 #pragma unroll
-        for (int r = 0; r < R; ++r) ga[k][SL::of(r)] += dot4(ld4(row + (r * T + lane) * 4), g[r]);
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      float4 x[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ga[k0 + q][SL::of(r)] += dot4(x[q][r], g[r]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ga[k0 + q][s] = uni<UW>(team_sum(ga[k0 + q][s], width));
       }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float erv = a.er[v * a.s_ld + hs[s]];
-      float al[kMaxFast];
       float S = 0.f;
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) {
-        if (k < deg) {                       // deg is uniform within the team, so the shuffles stay in-team
-          float x = team_sum(ga[k][s], width);
-          const int64_t eidx = (int64_t)(beg + k) * a.H + hs[s];
-          if (a.p > 0.f) x *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
-          al[k] = a.attn[eidx];
-          ga[k][s] = x;
-          S = fmaf(al[k], x, S);
-        }
+        al[k][s] = k < deg ? al[k][s] : 0.f;
+        if (a.p > 0.f) ga[k][s] *= keep_scale(a.seed, (int64_t)(beg + (k < deg ? k : deg - 1)) * a.H + hs[s], a.p, a.inv_keep);
+        S = k < deg ? fmaf(al[k][s], ga[k][s], S) : S;
       }
       float ger = 0.f;
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) {
-        if (k < deg) {
-          float ge = al[k] * ga[k][s] - al[k] * S;
-          const float epre = a.el[u[k] * a.s_ld + hs[s]] + erv;
-          ge = epre > 0.f ? ge : ge * a.slope;
-          if (wr[s]) a.g_e[(int64_t)(beg + k) * a.H + hs[s]] = ge;
-          ger += ge;
-        }
+        float ge = al[k][s] * ga[k][s] - al[k][s] * S;
+        ge = ep[k][s] + erv[s] > 0.f ? ge : ge * a.slope;
+        if (wr[s] && k < deg) a.g_e[(int64_t)(beg + k) * a.H + hs[s]] = ge;
+        ger += k < deg ? ge : 0.f;
       }
       if (wr[s]) a.g_er[v * a.gs_ld + hs[s]] = ger;
     }
-    continue;
+    return;
   }
 
   // general degree: pass 1 keeps g_a in g_e (written and re-read by the same writer lane), pass 2 finishes
@@ -473,7 +571,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
     }
     a.g_er[v * a.gs_ld + hs[s]] = ger;
   }
-  }   // node loop
+}
+
+template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdDst& a) {
+  if constexpr (R == 1) hipLaunchKernelGGL((gat_bwd_dst_vec<0, R, CH>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, head)
@@ -529,26 +630,26 @@ struct GatBwdSrc {
   float* absmax;                         // optional: absmax[u] = max |g_ft[u,:]|
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
-  int npt;
   const uint64_t* seed_off;
 };
 
-template <int R, int CH>
+template <int TT, int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
-  const int T = a.T;
+  constexpr bool WAVE = TT == 64;               // see gat_fwd_vec
+  constexpr bool UW = WAVE && CH >= 1;
+  const int T = WAVE ? 64 : a.T;
   const int lane = threadIdx.x % T;
-  const int64_t team = xcd_block() * (kBlock / T) + threadIdx.x / T;
-  const int64_t u_end = (team + 1) * a.npt < a.N ? (team + 1) * a.npt : a.N;
-  for (int64_t u = team * a.npt; u < u_end; ++u) {
-  const int beg = a.out_indptr[u], end = a.out_indptr[u + 1], deg = end - beg;
+  const int64_t u = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
+  if (u >= a.N) return;
+  const int beg = uni<WAVE>(a.out_indptr[u]), end = uni<WAVE>(a.out_indptr[u + 1]), deg = end - beg;
   int hs[NS]; bool wr[NS]; float gel[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
-    hs[s] = c0 / a.D;
+    hs[s] = (CH == 0) ? c0 / a.D : s;
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
     gel[s] = 0.f;
   }
@@ -556,31 +657,59 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto edge = [&](int64_t v, int64_t pos) {
-    const float* row = a.g_pre + v * a.g_pre_ld;
-    float w[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int64_t eidx = pos * a.H + hs[s];
-      w[s] = a.attn[eidx];
-      if (a.p > 0.f) w[s] *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
-      if (wr[s]) gel[s] += a.g_e[eidx];
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
-  };
-  if (SPGNN_SRC_FAST && deg <= kMaxFast) {
-    int64_t vv[kMaxFast], pp[kMaxFast];
+  if (SPGNN_SRC_FAST && deg > 0 && deg <= kMaxFast) {
+    // unconditional, batched loads (slot k >= deg repeats the last edge with weight 0): see gat_fwd_vec
+    int vv[kMaxFast], pp[kMaxFast];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) {
-      vv[k] = k < deg ? a.out_indices[beg + k] : 0;
-      pp[k] = k < deg ? a.out_pos[beg + k] : 0;
+      vv[k] = uni<WAVE>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
+      pp[k] = uni<WAVE>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
     }
+    float w[kMaxFast][NS], ge[kMaxFast][NS];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
-      if (k < deg) edge(vv[k], pp[k]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        w[k][s] = a.attn[(int64_t)pp[k] * a.H + hs[s]];
+        ge[k][s] = a.g_e[(int64_t)pp[k] * a.H + hs[s]];
+      }
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (a.p > 0.f) w[k][s] *= keep_scale(a.seed, (int64_t)pp[k] * a.H + hs[s], a.p, a.inv_keep);
+        w[k][s] = uni<UW>(k < deg ? w[k][s] : 0.f);
+        gel[s] += k < deg ? ge[k][s] : 0.f;
+      }
+    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      float4 x[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.g_pre + (int64_t)vv[k0 + q] * a.g_pre_ld + (r * T + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], w[k0 + q][SL::of(r)], x[q][r]);
+    }
   } else {
-    for (int k = beg; k < end; ++k) edge(a.out_indices[k], a.out_pos[k]);
+    for (int k = beg; k < end; ++k) {
+      const int64_t v = a.out_indices[k], pos = a.out_pos[k];
+      const float* row = a.g_pre + v * a.g_pre_ld;
+      float w[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int64_t eidx = pos * a.H + hs[s];
+        w[s] = a.attn[eidx];
+        if (a.p > 0.f) w[s] *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+        if (wr[s]) gel[s] += a.g_e[eidx];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) st4(a.g_ft + u * a.g_ft_ld + (r * T + lane) * 4, acc[r]);
@@ -594,7 +723,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
     mx = team_max(mx, T);
     if (lane == 0) a.absmax[u] = mx;
   }
-  }   // node loop
+}
+
+template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdSrc& a) {
+  if constexpr (R == 1) hipLaunchKernelGGL((gat_bwd_src_vec<0, R, CH>), grid, block, 0, st, a);
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -1027,14 +1159,8 @@ const char* spgnn_last_error(void) { return g_err; }
 
 // Geometry of the vector GAT kernels for (H, D): team width T, chunks per lane R, chunks per head CH
 // (0 = heads narrower than the team, reduction width W).  false -> scalar fallback.
-// Consecutive nodes per team.  Measured (tools/npt_sweep.py, MI355X): 1 is best - 2/4/8/16 nodes per team are
-// 2/8/24/50 % slower; many short-lived workgroups hide the dependent index -> score -> row latency chain better
-// than a loop inside fewer workgroups does.  SPGNN_NPT overrides (A/B runs only).
-static int nodes_per_team(int64_t, int) {
-  static const int forced = []() { const char* e = getenv("SPGNN_NPT"); return e ? atoi(e) : 0; }();
-  return forced > 0 ? forced : 1;
-}
-
+// One node per team.  Measured (tools/npt_sweep.py, MI355X): looping a team over 2/4/8/16 consecutive nodes was
+// 2/8/24/50 % slower - many short-lived workgroups hide the dependent index -> score -> row chain better.
 static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
   if (D % 4) return false;
   if (!pick_team((int64_t)H * D, T, R)) return false;
@@ -1081,7 +1207,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
+           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
                    vec_ok(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
@@ -1091,15 +1217,16 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
                                    "(see spgnn_gat_can_fuse_mean)");
   if (vec) {
     a.T = T;
-    a.npt = nodes_per_team(N, T);
-    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
     if (fuse_mean) {
-#define X(R_, CH_) hipLaunchKernelGGL((gat_fwd_vec<R_, CH_, true>), grid, block, 0, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<64, R_, CH_, true>), grid, block, 0, st, a); \
+                   else launch_small_team<R_, CH_, true>(grid, block, st, a)
       SPGNN_FOR_R_CH(R, CH, X)
 #undef X
     } else {
       a.out_mean = nullptr;
-#define X(R_, CH_) hipLaunchKernelGGL((gat_fwd_vec<R_, CH_, false>), grid, block, 0, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<64, R_, CH_, false>), grid, block, 0, st, a); \
+                   else launch_small_team<R_, CH_, false>(grid, block, st, a)
       SPGNN_FOR_R_CH(R, CH, X)
 #undef X
     }
@@ -1132,15 +1259,15 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
   hipStream_t st = (hipStream_t)stream;
   GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
               g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
-              activation, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
+              activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
                    vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
   if (vec) {
     a.T = T; a.W = W;
-    a.npt = nodes_per_team(N, T);
-    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
-#define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_dst_vec<R_, CH_>), grid, block, 0, st, a)
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_dst_vec<64, R_, CH_>), grid, block, 0, st, a); \
+                   else launch_small_team<R_, CH_>(grid, block, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
   } else {
@@ -1164,13 +1291,13 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, 1, seed_offset};
+              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
     a.T = T;
-    a.npt = nodes_per_team(N, T);
-    const dim3 grid(grid_for((N + a.npt - 1) / a.npt, kBlock / T)), block(kBlock);
-#define X(R_, CH_) hipLaunchKernelGGL((gat_bwd_src_vec<R_, CH_>), grid, block, 0, st, a)
+    const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_src_vec<64, R_, CH_>), grid, block, 0, st, a); \
+                   else launch_small_team<R_, CH_>(grid, block, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
   } else {

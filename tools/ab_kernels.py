@@ -20,7 +20,11 @@ def t_once(fn, iters=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
 
+only = os.environ.get("AB_SHAPES")        # e.g. "2x1024" to restrict the sweep
 shapes = [(2, 1024, True), (2, 256, False), (2, 128, False), (2, 64, False), (1, 256, False), (1, 128, False), (1, 64, False)]
+if only:
+    shapes = [s_ for s_ in shapes if f"{s_[0]}x{s_[1]}" in only.split(",")]
+kinds = os.environ.get("AB_KINDS", "fwd,dst,src").split(",")
 res = {}
 for (H, D, mean) in shapes:
     HD = H * D
@@ -35,12 +39,14 @@ for (H, D, mean) in shapes:
         _capi.check(_capi._lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), y.data_ptr(), y.stride(0),
             s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(), g_out.data_ptr(), g_out.stride(0), int(mean),
             out.data_ptr(), out.stride(0), g_y[:, HD:].data_ptr(), g_y.stride(0), g_e.data_ptr(), g_s[:, H:].data_ptr(),
-            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, 0.0, 0, st), "dst")
+            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, 0.0, 0, 0, st), "dst")
     def src():
         _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(),
             attn.data_ptr(), g_e.data_ptr(), g_y[:, HD:].data_ptr(), g_y.stride(0), g_y.data_ptr(), g_y.stride(0),
-            g_s.data_ptr(), g_s.stride(0), 0, N, E, H, D, 0.0, 0, st), "src")
+            g_s.data_ptr(), g_s.stride(0), 0, N, E, H, D, 0.0, 0, 0, st), "src")
     for name, fn in (("fwd", fwd), ("dst", dst), ("src", src)):
+        if name not in kinds:
+            continue
         for lib in libs.values():
             _capi._lib = lib; fn()
         torch.cuda.synchronize()
@@ -52,6 +58,6 @@ for (H, D, mean) in shapes:
         res[(H, D, name)] = {k: sorted(v)[len(v) // 2] for k, v in rounds.items()}
         print(H, D, name, " ".join(f"{k}={v*1e3:.1f}us" for k, v in res[(H, D, name)].items()), flush=True)
     del y, s, g_out, g_y, g_s, out, attn, g_e
-tot = {k: {n: sum(v[k] for kk, v in res.items() if kk[2] == n) for n in ("fwd", "dst", "src")} for k in libs}
+tot = {k: {n: sum(v[k] for kk, v in res.items() if kk[2] == n) for n in kinds} for k in libs}
 for k, v in tot.items():
     print(k, {n: round(x * 1e3, 1) for n, x in v.items()}, "total us", round(sum(v.values()) * 1e3, 1))
