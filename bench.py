@@ -58,6 +58,21 @@ def algorithmic_bytes(key) -> float:
     if name == "scores_bwd_x":       # read + write gX; read gS
         _, N, K, J = key
         return 4 * 2 * N * K + 4 * N * J
+    if name == "gat_agg_fwd":        # read x; write the z blocks [with a copy of x per head]; el, er, a; CSC
+        _, N, E, H, F_, xcopy = key
+        return 4 * N * F_ + 4 * N * H * F_ * (2 if xcopy else 1) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
+    if name == "gat_agg_bwd_dst":    # read the z part of g_z and x; el, er, a; write g_e, g_er; CSC
+        _, N, E, H, F_ = key
+        return 4 * N * (H + 1) * F_ + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
+    if name == "gat_agg_bwd_src":    # read g_z (both parts); write g_x; a, g_e, g_er, g_el; CSR + slot map
+        _, N, E, H, F_ = key
+        return 4 * N * (2 * H + 1) * F_ + 4 * (2 * N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+    if name == "head_mean":
+        _, N, H, D = key
+        return 4 * N * (H + 1) * D
+    if name == "act_bwd":            # read g_out [and out]; write g_pre
+        _, N, H, D, act, mean = key
+        return 4 * N * (D if mean else H * D) + 4 * N * H * D * (2 if act else 1)
     if name in ("gemm_nt", "gemm_tn", "absmax"):
         return 0.0                    # compute-bound / helper kernels: reported in "gemm", not in the HBM accounting
     if name == "spmm_sum":

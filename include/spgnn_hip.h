@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 9
+#define SPGNN_ABI_VERSION 10
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -129,6 +129,69 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       spgnn_stream_t stream);
 
 /*
+ * Aggregate-first form of the same GATConv (reference call site models.py:456-482, the 192 -> 2 x 1024 output layer
+ * of st_pgat_spgnn_3; DGL semantics as spgnn_gat_fwd).  When the layer input (F columns) is narrower than one head's
+ * output, sum_u a_uv (W_h x_u) = W_h (sum_u a_uv x_u): the attention-weighted sums run over the INPUT rows, once per
+ * head, and the projection follows as a GEMM on [z_h | x] (fc and res_fc in one product, bias + activation in its
+ * epilogue: spgnn_gemm_nt).  The H*D-wide projected rows are never gathered.
+ *
+ *   a_uv        = edge softmax of LeakyReLU(el[u,h] + er[v,h])                      -> attn[slot,h]
+ *   z[v, h*head_stride + f]                 = sum_{u in in(v)} drop(a_uv) * x[u,f]     f in [0,F)
+ *   z[v, h*head_stride + x_copy_offset + f] = x[v,f]        (x_copy_offset >= F; < 0: no residual operand copy)
+ *   absmax[v] (nullable) = max |z[v,:]| over the columns written (split-GEMM scale of the operand)
+ *
+ * H in {1,2,4}, F % 4 == 0, F <= 1024 (spgnn_gat_agg_supported); rows 16-byte aligned; head_stride % 4 == 0.
+ */
+int spgnn_gat_agg_supported(int32_t H, int32_t F);
+int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices,
+                      const float* x, int64_t x_stride,
+                      const float* el, const float* er, int64_t s_stride,
+                      float* attn,
+                      float* z, int64_t z_stride, int32_t head_stride, int32_t x_copy_offset,
+                      float* absmax,
+                      int64_t N, int64_t E, int32_t H, int32_t F,
+                      float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      spgnn_stream_t stream);
+
+/*
+ * Its backward halves (replace DGL autograd as spgnn_gat_bwd_dst / spgnn_gat_bwd_src do).  g_z has the layout of z.
+ *   dst-major:  g_a_uv = <x[u,:], g_z[v, h-block]> * keep_uv/(1-p);  g_e, g_er as in spgnn_gat_bwd_dst
+ *   src-major:  g_x[u,:] = sum_h g_z[u, h-block copy of x]  +  sum_{v in out(u)} sum_h drop(a_uv) * g_z[v, h-block]
+ *                          + g_el[u,:] @ w_lr[:H] + g_er[u,:] @ w_lr[H:]      (score projection backward, w_lr nullable)
+ *               g_el[u,h] = sum_{v in out(u)} g_e_uv
+ */
+int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices,
+                          const float* x, int64_t x_stride,
+                          const float* el, const float* er, int64_t s_stride,
+                          const float* attn,
+                          const float* g_z, int64_t g_z_stride, int32_t head_stride,
+                          float* g_e, float* g_er, int64_t g_s_stride,
+                          int64_t N, int64_t E, int32_t H, int32_t F,
+                          float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                          spgnn_stream_t stream);
+int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                          const float* attn, const float* g_e,
+                          const float* g_z, int64_t g_z_stride, int32_t head_stride, int32_t x_copy_offset,
+                          const float* g_er, const float* w_lr, int64_t w_lr_stride,
+                          float* g_x, int64_t g_x_stride,
+                          float* g_el, int64_t g_s_stride,
+                          int64_t N, int64_t E, int32_t H, int32_t F,
+                          float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                          spgnn_stream_t stream);
+
+/* out_mean[v,d] = mean_h out[v, h*D + d]: `rst.mean(1)` of the reference's output layer (models.py:327, 482) when
+ * the per-head rows come out of a GEMM epilogue instead of spgnn_gat_fwd. */
+int spgnn_head_mean(const float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
+                    int64_t N, int32_t H, int32_t D, spgnn_stream_t stream);
+
+/* g_pre[v,c] = g_out[v, mean_heads ? c % D : c] * (mean_heads ? 1/H : 1) * act'(out[v,c]) (the first phase of
+ * spgnn_gat_bwd_dst as an entry point of its own); absmax[v] (nullable) = max_c |g_pre[v,c]|.  D % 4 == 0. */
+int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
+                  const float* out, int64_t out_stride,
+                  float* g_pre, int64_t g_pre_stride, float* absmax,
+                  int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+
+/*
  * Attention-score projections of GATConv: el = (fc(x) * attn_l).sum(-1), er likewise (reference call sites as
  * spgnn_gat_fwd; DGL computes them with two elementwise multiplies + reductions over ft).  With the score
  * vectors folded through fc, W[j,:] = sum_d attn[h,d] * fc.weight[h*D+d,:] (J = 2H rows: el heads, then er
@@ -204,10 +267,13 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
  * Optional exact fp32 rank-J update fused into the epilogue: C += U[M,J] * V[J,N] (upd_j <= 32; V rows
  * 16-byte aligned and zero padded to a multiple of 4 columns; upd_j = 0 disables it).  The layer uses it for
  * the score term of the input gradient, g_X = g_Y * W + g_S * W_lr, instead of a second pass over g_X.
+ * Optional epilogue C = act(C + bias[col]) (bias nullable, N floats; activation = SPGNN_ACT_*): GATConv's bias and
+ * activation when the projection FOLLOWS the aggregation (spgnn_gat_agg_fwd).
  */
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
+                  const float* bias, int32_t activation,
                   spgnn_stream_t stream);
 
 /* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by

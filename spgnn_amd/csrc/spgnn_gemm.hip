@@ -44,6 +44,7 @@ struct Args {
   // optional exact fp32 rank-J update applied in the epilogue: C += U[M,J] * V[J,N]  (J <= 16; the score
   // gradient term g_S * W_lr of the input gradient, which otherwise costs a read-modify-write pass over C)
   const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
+  const float* bias; int act;                   // optional epilogue C = act(C + bias[col]) (pipelined kernel only)
 };
 
 __device__ __forceinline__ void split4(float4 v, float s, half4& hi, half4& lo) {
@@ -390,6 +391,18 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
             v.x = fmaf(u, w.x, v.x); v.y = fmaf(u, w.y, v.y); v.z = fmaf(u, w.z, v.z); v.w = fmaf(u, w.w, v.w);
           }
         }
+        if (a.bias) {
+          v.x += col + 0 < a.N ? a.bias[col + 0] : 0.f; v.y += col + 1 < a.N ? a.bias[col + 1] : 0.f;
+          v.z += col + 2 < a.N ? a.bias[col + 2] : 0.f; v.w += col + 3 < a.N ? a.bias[col + 3] : 0.f;
+        }
+        if (a.act == SPGNN_ACT_ELU) {
+          v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+          v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
+        } else if (a.act == SPGNN_ACT_TANH) {
+          v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        } else if (a.act == SPGNN_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
         float* dst = a.C + (int64_t)row * a.ldc + col;
         if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
         else {
@@ -655,8 +668,11 @@ int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >=
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
-                  int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, spgnn_stream_t stream) {
+                  int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
+                  int32_t activation, spgnn_stream_t stream) {
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return SPGNN_ERR_ENUM;
+  if ((bias || activation != SPGNN_ACT_NONE) && g_gemm_variant == 1) return SPGNN_ERR_ENUM;   // pipelined kernel only
   if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
   if (upd_j > 0) {
     if (!upd_u || !upd_v) return SPGNN_ERR_NULLPTR;
@@ -672,7 +688,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_variant == 1) {
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
@@ -681,7 +697,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                 (int)upd_j};
+                 (int)upd_j, bias, (int)activation};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {

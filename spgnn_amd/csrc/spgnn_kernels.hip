@@ -751,6 +751,423 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
 }
 
 // =================================================================================================
+// Aggregate-first GAT (layers whose input is narrower than one head's output, e.g. the 192 -> 2 x 1024 output
+// layer of st_pgat_spgnn_3).  sum_u alpha_h(u,v) (W_h x_u) = W_h (sum_u alpha_h(u,v) x_u): the attention-weighted
+// sums run over the F-wide INPUT rows, once per head, and the projection follows as a GEMM on [z_h | x] (the
+// residual projection rides in the same product).  The H*D-wide projected rows are then never gathered.
+// One wave per node; lane l owns float4 chunks l, l+64, ... of the F-wide row (R chunks, F <= 256*R); lanes
+// past the row end re-read chunk 0 and are masked at the stores and in the reductions.
+//   z      (N, H*zs): head h's block starts at column h*zs; [0,F) = z_h, [xoff, xoff+F) = copy of x (xoff < 0: none)
+// =================================================================================================
+struct GatAggFwd {
+  const int32_t* indptr; const int32_t* indices;
+  const float* x; int64_t x_ld;
+  const float* el; const float* er; int64_t s_ld;
+  float* attn;
+  float* z; int64_t z_ld; int zs; int xoff;
+  float* absmax;                         // optional: absmax[v] = max |z row v| (split-GEMM scale of the operand)
+  int64_t N; int F;
+  float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
+};
+
+template <int H, int R>
+__global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t v = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  if (v >= a.N) return;
+  const int beg = uni<true>(a.indptr[v]), end = uni<true>(a.indptr[v + 1]), deg = end - beg;
+  int col[R]; bool ok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  float erv[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) erv[h] = a.er[v * a.s_ld + h];
+  float4 xs[R];                                     // the node's own row (residual operand)
+#pragma unroll
+  for (int r = 0; r < R; ++r) xs[r] = ld4(a.x + v * a.x_ld + col[r]);
+  float4 acc[H][R];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (deg > 0 && deg <= kMaxFast) {
+    int u[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<true>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    float w[kMaxFast][H];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int h = 0; h < H; ++h) w[k][h] = a.el[(int64_t)u[k] * a.s_ld + h];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        w[k][h] = k < deg ? lrelu(w[k][h] + erv[h], a.slope) : -INFINITY;
+        mx = fmaxf(mx, w[k][h]);
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        w[k][h] = k < deg ? expf(w[k][h] - mx) : 0.f;
+        sm += w[k][h];
+      }
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        const float al = w[k][h] / sm;
+        if (lane == 0 && k < deg) a.attn[(int64_t)(beg + k) * H + h] = al;
+        w[k][h] = al;
+      }
+    }
+    if (a.p > 0.f) {
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+          w[k][h] *= keep_scale(a.seed, (int64_t)(beg + (k < deg ? k : deg - 1)) * H + h, a.p, a.inv_keep);
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int h = 0; h < H; ++h) w[k][h] = uni<true>(w[k][h]);
+    constexpr int G = R >= 4 ? 2 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += G) {
+      if (!(k0 < deg)) break;
+      float4 xr[G][R];
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) xr[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int r = 0; r < R; ++r) fma4(acc[h][r], w[k0 + q][h], xr[q][r]);
+    }
+  } else {
+    float mx[H], sm[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float m_ = -INFINITY;
+      for (int j = beg; j < end; ++j) m_ = fmaxf(m_, lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv[h], a.slope));
+      float s_ = 0.f;
+      for (int j = beg; j < end; ++j) s_ += expf(lrelu(a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv[h], a.slope) - m_);
+      mx[h] = m_; sm[h] = s_;
+    }
+    for (int j = beg; j < end; ++j) {
+      const int64_t u = a.indices[j];
+      float w[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float al = expf(lrelu(a.el[u * a.s_ld + h] + erv[h], a.slope) - mx[h]) / sm[h];
+        const int64_t eidx = (int64_t)j * H + h;
+        if (lane == 0) a.attn[eidx] = al;
+        w[h] = a.p > 0.f ? al * keep_scale(a.seed, eidx, a.p, a.inv_keep) : al;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float4 xr = ld4(a.x + u * a.x_ld + col[r]);
+#pragma unroll
+        for (int h = 0; h < H; ++h) fma4(acc[h][r], w[h], xr);
+      }
+    }
+  }
+  float mxv = 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!ok[r]) continue;
+      float* dst = a.z + v * a.z_ld + (int64_t)h * a.zs + col[r];
+      st4(dst, acc[h][r]);
+      mxv = absmax4(mxv, acc[h][r]);
+      if (a.xoff >= 0) { st4(dst + a.xoff, xs[r]); mxv = absmax4(mxv, xs[r]); }
+    }
+  if (a.absmax) {
+    mxv = team_max(mxv, 64);
+    if (lane == 0) a.absmax[v] = mxv;
+  }
+}
+
+struct GatAggBwdDst {
+  const int32_t* indptr; const int32_t* indices;
+  const float* x; int64_t x_ld;
+  const float* el; const float* er; int64_t s_ld;
+  const float* attn;
+  const float* gz; int64_t gz_ld; int zs;          // gradient of the z blocks (same layout as z)
+  float* g_e; float* g_er; int64_t gs_ld;
+  int64_t N; int F;
+  float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
+};
+
+template <int H, int R>
+__global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t v = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  if (v >= a.N) return;
+  const int beg = uni<true>(a.indptr[v]), end = uni<true>(a.indptr[v + 1]), deg = end - beg;
+  int col[R]; bool ok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  float4 g[H][R];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4 q = ld4(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]);
+      g[h][r] = ok[r] ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  float erv[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) erv[h] = a.er[v * a.s_ld + h];
+
+  if (deg > 0 && deg <= kMaxFast) {
+    int u[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<true>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    float al[kMaxFast][H], ep[kMaxFast][H], ga[kMaxFast][H];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        al[k][h] = a.attn[(int64_t)(beg + (k < deg ? k : deg - 1)) * H + h];
+        ep[k][h] = a.el[(int64_t)u[k] * a.s_ld + h];
+        ga[k][h] = 0.f;
+      }
+    constexpr int G = R >= 4 ? 2 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += G) {
+      if (!(k0 < deg)) break;
+      float4 xr[G][R];
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) xr[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float pd = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) pd += dot4(xr[q][r], g[h][r]);
+          ga[k0 + q][h] = uni<true>(team_sum(pd, 64));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float S = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        al[k][h] = k < deg ? al[k][h] : 0.f;
+        if (a.p > 0.f) ga[k][h] *= keep_scale(a.seed, (int64_t)(beg + (k < deg ? k : deg - 1)) * H + h, a.p, a.inv_keep);
+        S = k < deg ? fmaf(al[k][h], ga[k][h], S) : S;
+      }
+      float ger = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        float ge = al[k][h] * ga[k][h] - al[k][h] * S;
+        ge = ep[k][h] + erv[h] > 0.f ? ge : ge * a.slope;
+        if (lane == 0 && k < deg) a.g_e[(int64_t)(beg + k) * H + h] = ge;
+        ger += k < deg ? ge : 0.f;
+      }
+      if (lane == 0) a.g_er[v * a.gs_ld + h] = ger;
+    }
+    return;
+  }
+  // general degree: pass 1 parks g_alpha in g_e (written and re-read by lane 0), pass 2 finishes
+  float S[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) S[h] = 0.f;
+  for (int j = beg; j < end; ++j) {
+    const int64_t u = a.indices[j];
+    float4 xr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xr[r] = ld4(a.x + u * a.x_ld + col[r]);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float pd = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) pd += dot4(xr[r], g[h][r]);
+      float xg = team_sum(pd, 64);
+      const int64_t eidx = (int64_t)j * H + h;
+      if (a.p > 0.f) xg *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+      S[h] = fmaf(a.attn[eidx], xg, S[h]);
+      if (lane == 0) a.g_e[eidx] = xg;
+    }
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float ger = 0.f;
+    for (int j = beg; j < end; ++j) {
+      const int64_t eidx = (int64_t)j * H + h;
+      const float al = a.attn[eidx];
+      float ge = al * a.g_e[eidx] - al * S[h];
+      ge = a.el[(int64_t)a.indices[j] * a.s_ld + h] + erv[h] > 0.f ? ge : ge * a.slope;
+      a.g_e[eidx] = ge;
+      ger += ge;
+    }
+    a.g_er[v * a.gs_ld + h] = ger;
+  }
+}
+
+struct GatAggBwdSrc {
+  const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
+  const float* attn; const float* g_e;
+  const float* gz; int64_t gz_ld; int zs; int xoff;
+  const float* g_er;                               // (N, H) at stride gs_ld, written by the dst-major half
+  const float* w_lr; int64_t wlr_ld;               // (2H, F): g_x += [g_el | g_er] @ w_lr fused here
+  float* g_x; int64_t gx_ld;
+  float* g_el; int64_t gs_ld;
+  int64_t N; int F;
+  float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
+};
+
+template <int H, int R>
+__global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
+  if (a.seed_off) a.seed += a.seed_off[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t u = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  if (u >= a.N) return;
+  const int beg = uni<true>(a.out_indptr[u]), end = uni<true>(a.out_indptr[u + 1]), deg = end - beg;
+  int col[R]; bool ok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.xoff >= 0) {                                // gradient of the residual operand copies
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float4 q = ld4(a.gz + u * a.gz_ld + (int64_t)h * a.zs + a.xoff + col[r]);
+        acc[r].x += q.x; acc[r].y += q.y; acc[r].z += q.z; acc[r].w += q.w;
+      }
+  }
+  float gel[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) gel[h] = 0.f;
+  if (deg > 0 && deg <= kMaxFast) {
+    int vv[kMaxFast], pp[kMaxFast];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) {
+      vv[k] = uni<true>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
+      pp[k] = uni<true>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
+    }
+    float w[kMaxFast][H];
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        w[k][h] = a.attn[(int64_t)pp[k] * H + h];
+        const float ge = a.g_e[(int64_t)pp[k] * H + h];
+        if (a.p > 0.f) w[k][h] *= keep_scale(a.seed, (int64_t)pp[k] * H + h, a.p, a.inv_keep);
+        w[k][h] = uni<true>(k < deg ? w[k][h] : 0.f);
+        gel[h] += k < deg ? ge : 0.f;
+      }
+    constexpr int G = H * R >= 8 ? 1 : H * R >= 4 ? 2 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += G) {
+      if (!(k0 < deg)) break;
+      float4 gr[G][H][R];
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int r = 0; r < R; ++r) gr[q][h][r] = ld4(a.gz + (int64_t)vv[k0 + q] * a.gz_ld + (int64_t)h * a.zs + col[r]);
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int r = 0; r < R; ++r) fma4(acc[r], w[k0 + q][h], gr[q][h][r]);
+    }
+  } else {
+    for (int k = beg; k < end; ++k) {
+      const int64_t v = a.out_indices[k], pos = a.out_pos[k];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int64_t eidx = pos * H + h;
+        float w = a.attn[eidx];
+        if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
+        gel[h] += a.g_e[eidx];
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], w, ld4(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]));
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) a.g_el[u * a.gs_ld + h] = gel[h];
+  }
+  if (a.w_lr) {                                     // score-projection backward: g_x += g_el @ w_lr[:H] + g_er @ w_lr[H:]
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float ger = a.g_er[u * a.gs_ld + h];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        fma4(acc[r], gel[h], ld4(a.w_lr + (int64_t)h * a.wlr_ld + col[r]));
+        fma4(acc[r], ger, ld4(a.w_lr + (int64_t)(H + h) * a.wlr_ld + col[r]));
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (ok[r]) st4(a.g_x + u * a.gx_ld + col[r], acc[r]);
+}
+
+// out_mean[v, d] = mean_h out[v, h*D + d]  (vector form of head_mean_scalar; D % 4 == 0, 16-byte rows)
+__global__ __launch_bounds__(kBlock) void head_mean_vec(const float* __restrict__ out, int64_t out_ld, float* __restrict__ om,
+                                                        int64_t om_ld, int64_t N, int H, int D) {
+  const int d4 = D >> 2;
+  const float inv_h = 1.f / (float)H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * d4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / d4; const int c = (int)(i % d4) * 4;
+    float4 m = ld4(out + v * out_ld + c);
+    for (int h = 1; h < H; ++h) { const float4 q = ld4(out + v * out_ld + (int64_t)h * D + c); m.x += q.x; m.y += q.y; m.z += q.z; m.w += q.w; }
+    m.x *= inv_h; m.y *= inv_h; m.z *= inv_h; m.w *= inv_h;
+    st4(om + v * om_ld + c, m);
+  }
+}
+
+// g_pre[v, c] = g[v, mean ? c % D : c] * (mean ? 1/H : 1) * act'(out[v, c]);  absmax[v] = max_c |g_pre[v, c]|
+// (the dst-major backward's first phase as a kernel of its own, for layers whose projection follows the aggregation)
+__global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict__ g, int64_t g_ld, int mean,
+                                                         const float* __restrict__ out, int64_t out_ld,
+                                                         float* __restrict__ g_pre, int64_t gp_ld, float* __restrict__ absmax,
+                                                         int64_t N, int H, int D, int act) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (v >= N) return;
+  const int HD = H * D;
+  const float gscale = mean ? 1.f / (float)H : 1.f;
+  float mx = 0.f;
+  for (int c = lane * 4; c < HD; c += 256) {
+    float4 q = ld4(g + v * g_ld + (mean ? c % D : c));
+    q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
+    if (act != SPGNN_ACT_NONE) {
+      const float4 o = ld4(out + v * out_ld + c);
+      q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
+      q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+    }
+    st4(g_pre + v * gp_ld + c, q);
+    mx = absmax4(mx, q);
+  }
+  if (absmax) {
+    mx = team_max(mx, 64);
+    if (lane == 0) absmax[v] = mx;
+  }
+}
+
+// =================================================================================================
 // SpMM sum / max
 // =================================================================================================
 struct SpmmSum {
@@ -1305,6 +1722,130 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
     hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   }
   return check_launch("spgnn_gat_bwd_src");
+}
+
+int spgnn_gat_agg_supported(int32_t H, int32_t F) {
+  return ((H == 1 || H == 2 || H == 4) && F > 0 && F % 4 == 0 && F <= 1024) ? 1 : 0;
+}
+
+#define SPGNN_FOR_H_R(H_, R_, X)                                                                    \
+  switch ((H_) * 16 + (R_)) {                                                                       \
+    case 1 * 16 + 1: X(1, 1); break;  case 1 * 16 + 2: X(1, 2); break;  case 1 * 16 + 4: X(1, 4); break; \
+    case 2 * 16 + 1: X(2, 1); break;  case 2 * 16 + 2: X(2, 2); break;  case 2 * 16 + 4: X(2, 4); break; \
+    case 4 * 16 + 1: X(4, 1); break;  case 4 * 16 + 2: X(4, 2); break;  case 4 * 16 + 4: X(4, 4); break; \
+    default: return fail(SPGNN_ERR_SHAPE, "aggregate-first GAT: H must be 1, 2 or 4 and F <= 1024");  \
+  }
+static int agg_chunks(int F) { return F <= 256 ? 1 : F <= 512 ? 2 : 4; }
+
+int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* el,
+                      const float* er, int64_t s_stride, float* attn, float* z, int64_t z_stride, int32_t head_stride,
+                      int32_t x_copy_offset, float* absmax, int64_t N, int64_t E, int32_t H, int32_t F,
+                      float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_fwd: bad N/E/H/F");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !x || !el || !er || !attn || !z || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_fwd: null pointer");
+  const int64_t need = x_copy_offset >= 0 ? (int64_t)x_copy_offset + F : F;
+  if (x_stride < F || s_stride < H || head_stride < need || z_stride < (int64_t)H * head_stride || x_copy_offset >= 0 && x_copy_offset < F)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: row stride / block layout too small");
+  if (!vec_ok(x, x_stride) || !vec_ok(z, z_stride) || (head_stride & 3) || (x_copy_offset > 0 && (x_copy_offset & 3)))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: rows must be 16-byte aligned");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_fwd: p_drop not in [0,1)");
+  GatAggFwd a{indptr, indices, x, x_stride, el, er, s_stride, attn, z, z_stride, head_stride, x_copy_offset, absmax, N, F,
+              negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_>), grid, block, 0, st, a)
+  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  return check_launch("spgnn_gat_agg_fwd");
+}
+
+int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride,
+                          const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_z,
+                          int64_t g_z_stride, int32_t head_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
+                          int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop, uint64_t seed,
+                          const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_bwd_dst: bad N/E/H/F");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !x || !el || !er || !attn || !g_z || !g_e || !g_er || (E > 0 && !indices))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_bwd_dst: null pointer");
+  if (x_stride < F || s_stride < H || g_s_stride < H || head_stride < F || g_z_stride < (int64_t)(H - 1) * head_stride + F)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_dst: row stride / block layout too small");
+  if (!vec_ok(x, x_stride) || !vec_ok(g_z, g_z_stride) || (head_stride & 3))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_dst: rows must be 16-byte aligned");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_dst: p_drop not in [0,1)");
+  GatAggBwdDst a{indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride, head_stride, g_e, g_er, g_s_stride,
+                 N, F, negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_>), grid, block, 0, st, a)
+  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  return check_launch("spgnn_gat_agg_bwd_dst");
+}
+
+int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                          const float* g_e, const float* g_z, int64_t g_z_stride, int32_t head_stride,
+                          int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, float* g_x,
+                          int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F,
+                          float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_bwd_src: bad N/E/H/F");
+  if (N == 0) return SPGNN_OK;
+  if (!out_indptr || !attn || !g_e || !g_z || !g_x || !g_el || (w_lr && !g_er) || (E > 0 && (!out_indices || !out_pos)))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_bwd_src: null pointer");
+  const int64_t need = x_copy_offset >= 0 ? (int64_t)x_copy_offset + F : F;
+  if (g_x_stride < F || g_s_stride < H || head_stride < need || g_z_stride < (int64_t)(H - 1) * head_stride + need ||
+      (w_lr && w_lr_stride < F))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_src: row stride / block layout too small");
+  if (!vec_ok(g_x, g_x_stride) || !vec_ok(g_z, g_z_stride) || !vec_ok(w_lr, w_lr_stride) || (head_stride & 3) ||
+      (x_copy_offset > 0 && (x_copy_offset & 3)))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_src: rows must be 16-byte aligned");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_src: p_drop not in [0,1)");
+  GatAggBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
+                 w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, F, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_>), grid, block, 0, st, a)
+  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  return check_launch("spgnn_gat_agg_bwd_src");
+}
+
+int spgnn_head_mean(const float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride, int64_t N, int32_t H,
+                    int32_t D, spgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_head_mean: bad N/H/D");
+  if (N == 0) return SPGNN_OK;
+  if (!out || !out_mean) return fail(SPGNN_ERR_NULLPTR, "spgnn_head_mean: null pointer");
+  if (out_stride < (int64_t)H * D || out_mean_stride < D) return fail(SPGNN_ERR_STRIDE, "spgnn_head_mean: row stride smaller than row");
+  hipStream_t st = (hipStream_t)stream;
+  if (D % 4 == 0 && vec_ok(out, out_stride) && vec_ok(out_mean, out_mean_stride)) {
+    int64_t blocks = (N * (D / 4) + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_mean_vec, dim3((unsigned)blocks), dim3(kBlock), 0, st, out, out_stride, out_mean, out_mean_stride, N, H, D);
+  } else {
+    hipLaunchKernelGGL(head_mean_scalar, dim3(scalar_grid(N * D)), dim3(kBlock), 0, st, out, out_stride, out_mean,
+                       out_mean_stride, N, H, D);
+  }
+  return check_launch("spgnn_head_mean");
+}
+
+int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride,
+                  float* g_pre, int64_t g_pre_stride, float* absmax, int64_t N, int32_t H, int32_t D, int32_t activation,
+                  spgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || D <= 0 || D % 4) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd: bad N/H/D (D must be a multiple of 4)");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd: activation");
+  if (N == 0) return SPGNN_OK;
+  if (!g_out || !g_pre || (activation != SPGNN_ACT_NONE && !out)) return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (g_out_stride < (mean_heads ? D : HD) || g_pre_stride < HD || (activation != SPGNN_ACT_NONE && out_stride < HD))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd: row stride smaller than row");
+  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd: rows must be 16-byte aligned");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((N + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                     (hipStream_t)stream, g_out, g_out_stride, mean_heads ? 1 : 0, out, out_stride, g_pre, g_pre_stride, absmax,
+                     N, H, D, activation);
+  return check_launch("spgnn_act_bwd");
 }
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,

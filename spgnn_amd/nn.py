@@ -9,6 +9,8 @@ from __future__ import annotations
 import math
 from typing import Callable, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -54,6 +56,9 @@ def _act_code(fn) -> Optional[int]:
 def _draw_seed() -> int:
     # host-side draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+AGGREGATE_FIRST = os.environ.get("SPGNN_AGG_FIRST", "1") != "0"    # A/B switch for the aggregate-first layer form
 
 
 class GATConv(nn.Module):
@@ -129,9 +134,15 @@ class GATConv(nn.Module):
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
         fuse_mean = mean_heads and fuse_epilogue
-        out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
-                                  float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed,
-                                  mean=fuse_mean)
+        if (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
+                and ops.agg_first_supported(H, h.shape[1])):
+            # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)
+            out, attn = ops.gat_layer_agg_first(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D,
+                                                float(self.negative_slope), act, p, seed, mean=fuse_mean)
+        else:
+            out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
+                                      float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed,
+                                      mean=fuse_mean)
         rst = out if fuse_mean else out.view(-1, H, D)
         if not fuse_epilogue:
             if identity_res:

@@ -420,6 +420,142 @@ def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: boo
 
 
 # --------------------------------------------------------------------------------------------
+# aggregate-first GAT layer (input narrower than one head's output)
+# --------------------------------------------------------------------------------------------
+def agg_first_supported(H: int, F_in: int) -> bool:
+    return bool(_capi.load().spgnn_gat_agg_supported(H, F_in))
+
+
+def gat_agg_fwd_raw(csc: DeviceCSC, x, el, er, H: int, slope: float, p_drop: float, seed: int, with_x_copy: bool):
+    """-> (z (N, H*zs), attn (E,H), absmax (N,)); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F)."""
+    N, E = csc.num_nodes, csc.num_edges
+    F_ = x.shape[1]
+    zs = 2 * F_ if with_x_copy else F_
+    z = torch.empty((N, H * zs), dtype=torch.float32, device=x.device)
+    attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
+    amax = torch.empty((N,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("gat_agg_fwd", (N, E, H, F_, int(with_x_copy))):
+        _capi.check(_capi.load().spgnn_gat_agg_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                   el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(), z.data_ptr(),
+                                                   z.stride(0), zs, F_ if with_x_copy else -1, amax.data_ptr(), N, E, H, F_,
+                                                   slope, p_drop, seed, _seed_off_ptr(x.device), _stream(x)),
+                    "spgnn_gat_agg_fwd")
+    return z, attn, amax
+
+
+def head_mean(out: torch.Tensor, H: int, D: int) -> torch.Tensor:
+    N = out.shape[0]
+    om = torch.empty((N, D), dtype=torch.float32, device=out.device)
+    with torch.cuda.device(out.device), _timed("head_mean", (N, H, D)):
+        _capi.check(_capi.load().spgnn_head_mean(out.data_ptr(), out.stride(0), om.data_ptr(), om.stride(0), N, H, D,
+                                                 _stream(out)), "spgnn_head_mean")
+    return om
+
+
+def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int, mean: bool):
+    """-> (g_pre (N, H*D), absmax (N,))."""
+    N = g_out.shape[0]
+    g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_out.device)
+    amax = torch.empty((N,), dtype=torch.float32, device=g_out.device)
+    with torch.cuda.device(g_out.device), _timed("act_bwd", (N, H, D, act, int(mean))):
+        _capi.check(_capi.load().spgnn_act_bwd(g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
+                                               out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
+                                               amax.data_ptr(), N, H, D, act, _stream(g_out)), "spgnn_act_bwd")
+    return g_pre, amax
+
+
+class _GATAggFirstFn(torch.autograd.Function):
+    """GATConv with the projection AFTER the aggregation: out_h = act([z_h | x] @ [W_fc,h | W_res,h]^T + b_h),
+    z_h[v] = sum_u a_h(u,v) x[u].  Same function as _GATLayerFn; chosen when the input is narrower than one head's
+    output, so that the (N, 2*H*D) projected rows are neither written nor gathered."""
+
+    @staticmethod
+    def forward(ctx, x, w_fc, w_res, w_lr, bias, csc: DeviceCSC, H: int, D: int, slope: float, act: int, p_drop: float,
+                seed: int, mean: bool):
+        x = _rowmajor(x)
+        N, F_ = x.shape
+        has_res = w_res is not None
+        s = scores_fwd(x, w_lr)
+        z, attn, amax = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, has_res)
+        zs = z.shape[1] // H
+        sz = scale_from_partials(amax)
+        w3 = w_fc.view(H, D, F_)
+        wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
+        sw = pow2_scale(wc.view(H * D, zs))
+        out = torch.empty((N, H * D), dtype=torch.float32, device=x.device)
+        for h in range(H):
+            gemm_nt(z[:, h * zs:(h + 1) * zs], wc[h], sz, sw, out=out[:, h * D:(h + 1) * D],
+                    bias=bias[h * D:(h + 1) * D] if bias is not None else None, act=act)
+        ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw)
+        ctx.mark_non_differentiable(attn)
+        return (head_mean(out, H, D) if mean else out), attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        x, wc, w_lr, s, attn, z, out, sz, sw = ctx.saved_tensors
+        H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
+        csc = ctx.csc
+        N, F_ = x.shape
+        E = csc.num_edges
+        zs = z.shape[1] // H
+        g_pre, amax = act_bwd(_rowmajor(g_out), out, H, D, act, mean)
+        sg = scale_from_partials(amax)
+        need_w = ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2])
+        need_bias = ctx.has_bias and ctx.needs_input_grad[4]
+        g_z = torch.empty_like(z)
+        g_wc = torch.empty_like(wc) if need_w else None
+        g_bias = torch.empty((H * D,), dtype=torch.float32, device=x.device) if need_bias else None
+        for h in range(H):
+            gp_h = g_pre[:, h * D:(h + 1) * D]
+            gemm_nt(gp_h, wc[h].t().contiguous(), sg, sw, out=g_z[:, h * zs:(h + 1) * zs])
+            if need_w:
+                if need_bias:
+                    g_wc[h], g_bias[h * D:(h + 1) * D] = gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=True)
+                else:
+                    g_wc[h] = gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz)
+        if need_bias and not need_w:
+            g_bias = g_pre.sum(0)
+        g_s = torch.empty_like(s)
+        g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
+        lib = _capi.load()
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            with _timed("gat_agg_bwd_dst", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                      s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                      g_z.data_ptr(), g_z.stride(0), zs, g_e.data_ptr(), g_s[:, H:].data_ptr(),
+                                                      g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
+                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst")
+            need_x = ctx.needs_input_grad[0]
+            Fp = (F_ + 3) // 4 * 4
+            g_x = torch.empty((N, Fp), dtype=torch.float32, device=x.device)[:, :F_]
+            w_lr_c = w_lr.contiguous()
+            with _timed("gat_agg_bwd_src", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                      csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_z.data_ptr(),
+                                                      g_z.stride(0), zs, F_ if has_res else -1, g_s[:, H:].data_ptr(),
+                                                      w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
+                                                      g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
+                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
+        g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[3] else None
+        g_wfc = g_wres = None
+        if need_w:
+            g_wfc = g_wc[:, :, :F_].reshape(H * D, F_)
+            if has_res:
+                g_wres = g_wc[:, :, F_:].reshape(H * D, F_)
+        return (g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, None, None, None, None, None, None, None, None
+
+
+def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, act: int,
+                        p_drop: float = 0.0, seed: int = 0, mean: bool = False):
+    """Same contract as gat_layer; ``w_fc`` / ``w_res`` (H*D, F) separately (w_res may be None)."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias)
+    return _GATAggFirstFn.apply(x, w_fc, w_res, w_lr, bias, csc, H, D, slope, act, p_drop, seed, mean)
+
+
+# --------------------------------------------------------------------------------------------
 # SpMM sum / max
 # --------------------------------------------------------------------------------------------
 def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int) -> torch.Tensor:
@@ -535,9 +671,10 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-            upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None) -> torch.Tensor:
+            upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
-    in/out, fp16x3 split on the matrix cores."""
+    in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias)."""
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -545,6 +682,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1
+    assert bias is None or (bias.numel() == N and bias.is_contiguous())
     J = 0
     if upd_u is not None:
         J = upd_u.shape[1]
@@ -554,7 +692,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
         _capi.check(_capi.load().spgnn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                                                out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(upd_u),
                                                upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
-                                               _stream(a)), "spgnn_gemm_nt")
+                                               _ptr(bias), act, _stream(a)), "spgnn_gemm_nt")
     return out
 
 

@@ -167,6 +167,75 @@ def test_attention_dropout_matches_oracle_with_same_mask(monkeypatch):
     assert torch.equal(c, d)
 
 
+@pytest.mark.parametrize("fin,H,D,res,act,mean", [(192, 2, 1024, True, F.elu, True), (600, 4, 640, True, F.elu, False),
+                                                  (300, 1, 512, False, torch.tanh, False), (36, 2, 64, False, None, True),
+                                                  (256, 4, 260, True, F.elu, True), (1024, 1, 2048, True, F.elu, False)])
+def test_aggregate_first_form_matches_project_first_and_oracle(monkeypatch, fin, H, D, res, act, mean):
+    """Input narrower than a head: the layer aggregates input rows first and projects afterwards (ops._GATAggFirstFn).
+    Same function as the project-first form (A/B through nn.AGGREGATE_FIRST) and as the oracle, with attention
+    dropout on (same counter-based mask in both forms).  (Smooth activations only: with ReLU a pre-activation of
+    -1.8e-7 came out +2.7e-7 in one form, and that single flipped derivative moves the gradients by 1 %; the ReLU
+    epilogue and derivative kernels are checked on their own below.)"""
+    torch.manual_seed(fin + H + D)
+    g, src, dst, n = _graph([33, 150, 2, 64], seed=fin)
+    p, seed = 0.1, 987654321
+    layer = snn.GATConv(fin, D, H, 0.0, p, 0.2, res, act).cuda().train()
+    monkeypatch.setattr(snn, "_draw_seed", lambda: seed)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    x = torch.randn(n, fin, device="cuda")
+    cot = torch.randn(n, D, device="cuda") if mean else torch.randn(n, H, D, device="cuda")
+    results = {}
+    for form in (True, False):
+        monkeypatch.setattr(snn, "AGGREGATE_FIRST", form)
+        ops.KernelTimer.start()
+        xg = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        out = layer(g, xg, mean_heads=mean)
+        (out * cot).sum().backward()
+        used = {k[0] for k in ops.KernelTimer.stop()}
+        assert ("gat_agg_fwd" in used) == form and ("gat_fwd" in used) != form
+        results[form] = [out.detach(), xg.grad] + [q.grad.clone() for q in layer.parameters()]
+    csc = g.csc()
+    E = csc.num_edges
+    keep_slot = keep_scale_host(seed, np.arange(E * H), p).reshape(E, H)
+    keep_edge = np.empty_like(keep_slot); keep_edge[csc.eid.cpu().numpy()] = keep_slot
+    ref, _, xo, sd = _oracle_gat(layer, src, dst, n, x, act, attn_keep=torch.from_numpy(keep_edge))
+    ref = ref.mean(1) if mean else ref
+    (ref * cot.cpu()).sum().backward()
+    names = ["out", "x"] + [k for k, _ in layer.named_parameters()]
+    want = [ref, xo.grad] + [sd[k].grad for k in names[2:]]
+    for form in (True, False):
+        for name, got, w in zip(names, results[form], want):
+            assert rel_err(got, w) < (FWD_TOL if name == "out" else GRAD_TOL), (form, name)
+    for name, a, b in zip(names, results[True], results[False]):
+        assert rel_err(a, b) < GRAD_TOL, name
+
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_ELU, ops.ACT_TANH, ops.ACT_RELU])
+def test_epilogue_and_derivative_kernels_of_the_aggregate_first_form(act):
+    """spgnn_gemm_nt's bias + activation epilogue (on column-slice outputs), spgnn_head_mean and spgnn_act_bwd."""
+    torch.manual_seed(act)
+    M, K, Nn, H = 249, 512, 260, 4
+    a = torch.randn(M, K, device="cuda"); b = torch.randn(Nn, K, device="cuda") / 16; bias = torch.randn(Nn, device="cuda")
+    big = torch.full((M, H * Nn), float("nan"), device="cuda")
+    for h in range(H):
+        ops.gemm_nt(a, b, ops.pow2_scale(a), ops.pow2_scale(b), out=big[:, h * Nn:(h + 1) * Nn], bias=bias, act=act)
+    pre = a.double() @ b.double().t() + bias.double()
+    f = {ops.ACT_NONE: lambda t: t, ops.ACT_ELU: F.elu, ops.ACT_TANH: torch.tanh, ops.ACT_RELU: torch.relu}[act]
+    ref = f(pre).float()
+    for h in range(H):
+        assert rel_err(big[:, h * Nn:(h + 1) * Nn], ref) < 4e-6      # tanhf: 2.1e-6 against fp64
+    out = f(torch.randn(M, H * Nn, device="cuda"))
+    assert rel_err(ops.head_mean(out, H, Nn), out.view(M, H, Nn).mean(1)) < 1e-6
+    for mean in (False, True):
+        g = torch.randn(M, Nn if mean else H * Nn, device="cuda")
+        gp, amax = ops.act_bwd(g, out if act != ops.ACT_NONE else None, H, Nn, act, mean)
+        d = {ops.ACT_NONE: torch.ones_like(out), ops.ACT_ELU: torch.where(out > 0, torch.ones_like(out), out + 1),
+             ops.ACT_TANH: 1 - out * out, ops.ACT_RELU: (out > 0).float()}[act]
+        want = (g / H).repeat(1, H) * d if mean else g * d
+        assert rel_err(gp, want) < 1e-6 and rel_err(amax, want.abs().amax(1)) < 1e-6
+
+
 SPMM_F = [64, 128, 256, 1024, 22, 7, 192]
 
 
