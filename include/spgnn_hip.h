@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 10
+#define SPGNN_ABI_VERSION 11
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -190,6 +190,21 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                   const float* out, int64_t out_stride,
                   float* g_pre, int64_t g_pre_stride, float* absmax,
                   int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+
+/*
+ * Folding of GATConv's score vectors through fc (what makes el/er a projection of the layer INPUT; reference
+ * models.py:301-314 via DGL GATConv: el = (fc(x).view(N,H,D) * attn_l).sum(-1)):
+ *   w_lr[h,:]   = sum_d attn_l[h,d] * W[h*D+d,:]      w_lr[H+h,:] = sum_d attn_r[h,d] * W[h*D+d,:]
+ * w_lr: (2H, w_lr_stride) with columns [K, w_lr_stride) zeroed (the padded form spgnn_scores_* take).
+ * Backward: g_attn_l[h,d] = <g_w_lr[h,:], W[h*D+d,:]> (g_attn_r likewise) and the fc-weight term
+ *   g_W[h*D+d,:] = attn_l[h,d] * g_w_lr[h,:] + attn_r[h,d] * g_w_lr[H+h,:]   (written, not accumulated).
+ */
+int spgnn_fold_scores_fwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r,
+                          float* w_lr, int32_t w_lr_stride, int32_t H, int32_t D, int32_t K, spgnn_stream_t stream);
+int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r,
+                          const float* g_w_lr, int32_t w_lr_stride,
+                          float* g_W, int64_t g_w_stride, float* g_attn_l, float* g_attn_r,
+                          int32_t H, int32_t D, int32_t K, spgnn_stream_t stream);
 
 /*
  * Attention-score projections of GATConv: el = (fc(x) * attn_l).sum(-1), er likewise (reference call sites as

@@ -1168,6 +1168,63 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
 }
 
 // =================================================================================================
+// Score-vector folding: w_lr[h,:] = sum_d attn_l[h,d] * W[h*D+d,:], w_lr[H+h,:] likewise with attn_r - the (2H, K)
+// weights of the skinny score projection (and their gradients), as two small kernels instead of a dozen
+// batched-GEMM / cat / add launches per layer and step.
+// =================================================================================================
+__global__ __launch_bounds__(1024) void fold_scores_fwd(const float* __restrict__ W, int64_t ldw, const float* __restrict__ al,
+                                                        const float* __restrict__ ar, float* __restrict__ out, int Kp, int H,
+                                                        int D, int K) {
+  // fp64 accumulation: these few MFLOP cost nothing, and the scores' gradients downstream are near-total
+  // cancellations (softmax is shift-invariant in er up to the LeakyReLU kink), so every ulp here shows there.
+  __shared__ double red[2][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
+  const int k = blockIdx.x * 64 + lane;
+  double sl = 0.0, sr = 0.0;
+  if (k < K) {
+    for (int d0 = wave; d0 < D; d0 += 16 * 8) {
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int d = d0 + 16 * i; w[i] = d < D ? W[(int64_t)(h * D + d) * ldw + k] : 0.f; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = d0 + 16 * i;
+        if (d < D) { sl = fma((double)al[h * D + d], (double)w[i], sl); sr = fma((double)ar[h * D + d], (double)w[i], sr); }
+      }
+    }
+  }
+  red[0][wave][lane] = sl; red[1][wave][lane] = sr;
+  __syncthreads();
+  if (wave < 2 && k < Kp) {                       // fixed summation order: reproducible
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[wave][i][lane];
+    out[(int64_t)(wave * H + h) * Kp + k] = k < K ? (float)s : 0.f;
+  }
+}
+
+// one wave per weight row (h,d): g_al[h,d] = <g_wlr[h,:], W[row,:]>, g_ar likewise; g_W[row,:] = al*g_wlr[h,:] + ar*g_wlr[H+h,:]
+__global__ __launch_bounds__(kBlock) void fold_scores_bwd(const float* __restrict__ W, int64_t ldw, const float* __restrict__ al,
+                                                          const float* __restrict__ ar, const float* __restrict__ g_wlr, int Kp,
+                                                          float* __restrict__ g_W, int64_t ldg, float* __restrict__ g_al,
+                                                          float* __restrict__ g_ar, int H, int D, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= H * D) return;
+  const int h = row / D;
+  const float a_l = al[row], a_r = ar[row];
+  double dl = 0.0, dr = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(int64_t)row * ldw + k];
+    const float gl = g_wlr[(int64_t)h * Kp + k], gr = g_wlr[(int64_t)(H + h) * Kp + k];
+    dl = fma((double)gl, (double)w, dl); dr = fma((double)gr, (double)w, dr);
+    g_W[(int64_t)row * ldg + k] = a_l * gl + a_r * gr;
+  }
+  for (int off = 32; off > 0; off >>= 1) { dl += __shfl_xor(dl, off, 64); dr += __shfl_xor(dr, off, 64); }
+  if (lane == 0) { g_al[row] = (float)dl; g_ar[row] = (float)dr; }
+}
+
+// =================================================================================================
 // SpMM sum / max
 // =================================================================================================
 struct SpmmSum {
@@ -1846,6 +1903,30 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
                      (hipStream_t)stream, g_out, g_out_stride, mean_heads ? 1 : 0, out, out_stride, g_pre, g_pre_stride, absmax,
                      N, H, D, activation);
   return check_launch("spgnn_act_bwd");
+}
+
+int spgnn_fold_scores_fwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r, float* w_lr,
+                          int32_t w_lr_stride, int32_t H, int32_t D, int32_t K, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || K <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_fold_scores_fwd: bad H/D/K");
+  if (!W || !attn_l || !attn_r || !w_lr) return fail(SPGNN_ERR_NULLPTR, "spgnn_fold_scores_fwd: null pointer");
+  if (w_stride < K || w_lr_stride < K) return fail(SPGNN_ERR_STRIDE, "spgnn_fold_scores_fwd: row stride smaller than row");
+  hipLaunchKernelGGL(fold_scores_fwd, dim3((unsigned)((w_lr_stride + 63) / 64), (unsigned)H), dim3(1024), 0, (hipStream_t)stream,
+                     W, w_stride, attn_l, attn_r, w_lr, w_lr_stride, H, D, K);
+  return check_launch("spgnn_fold_scores_fwd");
+}
+
+int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r, const float* g_w_lr,
+                          int32_t w_lr_stride, float* g_W, int64_t g_w_stride, float* g_attn_l, float* g_attn_r, int32_t H,
+                          int32_t D, int32_t K, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || K <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_fold_scores_bwd: bad H/D/K");
+  if (!W || !attn_l || !attn_r || !g_w_lr || !g_W || !g_attn_l || !g_attn_r)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_fold_scores_bwd: null pointer");
+  if (w_stride < K || w_lr_stride < K || g_w_stride < K) return fail(SPGNN_ERR_STRIDE, "spgnn_fold_scores_bwd: row stride smaller than row");
+  const int rows = H * D;
+  hipLaunchKernelGGL(fold_scores_bwd, dim3((unsigned)((rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                     (hipStream_t)stream, W, w_stride, attn_l, attn_r, g_w_lr, w_lr_stride, g_W, g_w_stride, g_attn_l, g_attn_r,
+                     H, D, K);
+  return check_launch("spgnn_fold_scores_bwd");
 }
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,

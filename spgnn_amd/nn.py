@@ -58,6 +58,7 @@ def _draw_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+FOLD_KERNEL = os.environ.get("SPGNN_FOLD", "1") != "0"             # A/B switch: score folding by spgnn_fold_scores_* vs einsum
 AGGREGATE_FIRST = os.environ.get("SPGNN_AGG_FIRST", "1") != "0"    # A/B switch for the aggregate-first layer form
 
 
@@ -128,9 +129,12 @@ class GATConv(nn.Module):
         if w_cat.shape[1] % 4:                          # 16-byte rows for the matrix-core GEMM (e.g. 1063 -> 1064)
             w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
-        w3 = w_fc.view(H, D, -1)
-        w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),
-                          torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
+        if FOLD_KERNEL:
+            w_lr = ops.fold_scores(w_fc, self.attn_l[0], self.attn_r[0])
+        else:
+            w3 = w_fc.view(H, D, -1)
+            w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),
+                              torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
         fuse_mean = mean_heads and fuse_epilogue

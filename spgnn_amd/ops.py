@@ -216,6 +216,55 @@ def scale_from_partials(partials: torch.Tensor, factor: float = 1.0) -> torch.Te
     return scale
 
 
+class _FoldScoresFn(torch.autograd.Function):
+    """(fc.weight (H*D, K), attn_l (H, D), attn_r (H, D)) -> w_lr (2H, K): a view of a (2H, pad16(K)) zero-padded
+    buffer, the form the score kernels take.  Two kernels (forward, backward) per layer and step."""
+
+    @staticmethod
+    def forward(ctx, w, attn_l, attn_r):
+        H, D = attn_l.shape
+        K = w.shape[1]
+        Kp = _pad16(K)
+        al, ar = attn_l.contiguous(), attn_r.contiguous()
+        buf = torch.empty((2 * H, Kp), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _capi.check(_capi.load().spgnn_fold_scores_fwd(w.data_ptr(), w.stride(0), al.data_ptr(), ar.data_ptr(),
+                                                           buf.data_ptr(), Kp, H, D, K, _stream(w)), "spgnn_fold_scores_fwd")
+        ctx.save_for_backward(w, al, ar)
+        return buf[:, :K]
+
+    @staticmethod
+    def backward(ctx, g):
+        w, al, ar = ctx.saved_tensors
+        H, D = al.shape
+        K = w.shape[1]
+        if not (g.stride(1) == 1 and g.stride(0) >= K):
+            g = g.contiguous()
+        g_w = torch.empty_like(w)
+        g_al, g_ar = torch.empty_like(al), torch.empty_like(ar)
+        with torch.cuda.device(w.device):
+            _capi.check(_capi.load().spgnn_fold_scores_bwd(w.data_ptr(), w.stride(0), al.data_ptr(), ar.data_ptr(), g.data_ptr(),
+                                                           g.stride(0), g_w.data_ptr(), g_w.stride(0), g_al.data_ptr(),
+                                                           g_ar.data_ptr(), H, D, K, _stream(w)), "spgnn_fold_scores_bwd")
+        return g_w, g_al, g_ar
+
+
+def fold_scores(w_fc: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor) -> torch.Tensor:
+    _require_cuda(w_fc, attn_l, attn_r)
+    assert w_fc.stride(1) == 1
+    return _FoldScoresFn.apply(w_fc, attn_l, attn_r)
+
+
+def _padded_rows(w: torch.Tensor, Kp: int) -> torch.Tensor:
+    """(J, Kp) zero-padded contiguous copy of w (J, K) - or w's own buffer when it already is one (fold_scores)."""
+    if w.shape[1] == Kp and w.is_contiguous():
+        return w
+    if w.stride(1) == 1 and w.stride(0) == Kp and w.storage_offset() == 0 and getattr(w, "_base", None) is not None \
+            and w._base.shape == (w.shape[0], Kp):
+        return w._base
+    return torch.nn.functional.pad(w, (0, Kp - w.shape[1])).contiguous()
+
+
 def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     """S = x @ w_lr^T (N, J), J = 2H: the MFMA streaming kernel when the rows of x are 16-byte aligned and
     J <= 16, rocBLAS otherwise.  ``want_scale``: also return the split-GEMM scale of x — the kernel reads every
@@ -226,7 +275,7 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
         s = torch.mm(x, w_lr.t())
         return (s, pow2_scale(x) if N > 0 else None) if want_scale else s
     Kp = _pad16(K)
-    w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
+    w_p = _padded_rows(w_lr, Kp)
     s = torch.empty((N, J), dtype=torch.float32, device=x.device)
     part = torch.empty(((N + 15) // 16,), dtype=torch.float32, device=x.device) if want_scale else None
     with torch.cuda.device(x.device), _timed("scores_fwd", (N, K, J)):
@@ -262,7 +311,7 @@ def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor, accu
             torch.mm(g_s, w_lr, out=g_x)
         return
     Kp = _pad16(K)
-    w_p = torch.nn.functional.pad(w_lr, (0, Kp - K)).contiguous()
+    w_p = _padded_rows(w_lr, Kp)
     with torch.cuda.device(g_x.device), _timed("scores_bwd_x", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_bwd_x(g_s.data_ptr(), g_s.stride(0), w_p.data_ptr(), Kp, g_x.data_ptr(),
                                                     g_x.stride(0), int(accumulate), N, K, J, _stream(g_x)),
@@ -401,7 +450,7 @@ class _GATLayerFn(torch.autograd.Function):
                 w_t = w_cat.t().contiguous()           # (K, C): the input gradient is an NT product with W^T
                 J = g_s.shape[1]
                 if J <= 32:                            # + g_S @ W_lr as an exact fp32 rank-2H update in the epilogue
-                    w_lr_p = torch.nn.functional.pad(w_lr, (0, _pad16(K) - K)).contiguous()
+                    w_lr_p = _padded_rows(w_lr, _pad16(K))
                     gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x, upd_u=g_s, upd_v=w_lr_p)
                 else:
                     gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x)

@@ -73,6 +73,7 @@ def test_config_loss_gradients_match_oracle(name):
     pe = g.ndata["pos_enc"].cpu().double() if "pos_enc" in g.ndata else None
     out64 = O.net_forward(cfg.KIND, sd64, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu().double(), pe)[0]
     O.masked_weighted_ce(out64, y.cpu(), mask, w.double()).backward()
+    gmax = max(float(v.grad.abs().max()) for v in sd64.values() if v.grad is not None)
     for n, p in model.named_parameters():
         if p.requires_grad and not (p.grad is None and sd[n].grad is None):     # (GINNet's auxiliary heads are unused)
             assert sd[n].grad is not None and p.grad is not None, n
@@ -87,7 +88,11 @@ def test_config_loss_gradients_match_oracle(name):
                 d = (p.grad.cpu().double() - sd[n].grad.double())
                 assert d.norm() / sd[n].grad.double().norm() < 5e-3, (n, e32)
                 continue
-            assert e32 < 1e-4 or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6, (n, e32)
+            # ... or the tensor sits below the fp32 resolution of the computation it comes from: the score vectors'
+            # gradients in the position stream are ~1e-6 (softmax is shift-invariant in er up to the LeakyReLU kink, so
+            # they are near-total cancellations of ~1e-2 terms) and move by 1e-4 relative when el/er change by one ulp.
+            tiny = (p.grad.cpu().double() - sd64[n].grad).abs().max() < 1e-7 * gmax
+            assert e32 < 1e-4 or tiny or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6, (n, e32)
 
 
 def test_state_dict_keys_follow_dgl_layout():
