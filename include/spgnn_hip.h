@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 11
+#define SPGNN_ABI_VERSION 12
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -290,6 +290,24 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                   const float* bias, int32_t activation,
                   spgnn_stream_t stream);
+
+/*
+ * Split-form ("planes") operands for the projection GEMMs.  spgnn_split_rows writes, once per tensor,
+ *   hi = fp16(s x), lo = fp16(s x - hi),   s = *scale * extra_factor  (scale nullable = 1)
+ * as two row-major fp16 matrices (Mp x Kp, zero padded; Kp % 32 == 0, plane_stride % 8 == 0, 16-byte aligned bases)
+ * with the same round-toward-zero split the fp32-operand kernels apply on the fly, so both GEMM forms agree
+ * bit for bit.  spgnn_gemm_nt_planes is spgnn_gemm_nt on such operands (same epilogue options; scale_a / scale_b
+ * are the scales the planes were written with): tiles go global -> LDS by DMA, no per-tile conversion.
+ * Replaces the same reference Linear projections as spgnn_gemm_nt (models.py:301-314).
+ */
+int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
+                     uint16_t* hi, uint16_t* lo, int64_t plane_stride, int64_t Mp, int64_t Kp, spgnn_stream_t stream);
+int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
+                         const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
+                         float* C, int64_t ldc, int64_t M, int64_t N, int64_t Kp,
+                         const float* scale_a, const float* scale_b,
+                         const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
+                         const float* bias, int32_t activation, spgnn_stream_t stream);
 
 /* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by
  * spgnn_scores_fwd / spgnn_gat_bwd_dst / spgnn_gat_bwd_src (which stream the tensors anyway) into a GEMM scale. */

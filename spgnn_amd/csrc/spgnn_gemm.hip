@@ -186,6 +186,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_f16x3(Args a) {
 // -------------------------------------------------------------------------------------------------
 typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
 
+// same ELU as spgnn_kernels.hip (expm1 for x <= 0: degree-9 Taylor on [-0.5, 0], exp(x) - 1 below; 2 ulp of expm1f)
+__device__ __forceinline__ float elu_fwd(float x) {
+  const float p = x * (1.f + x * (0.5f + x * (1.f / 6 + x * (1.f / 24 + x * (1.f / 120 + x * (1.f / 720 + x * (1.f / 5040 +
+                  x * (1.f / 40320 + x * (1.f / 362880)))))))));
+  const float e = __expf(x) - 1.f;
+  return x > 0.f ? x : (x > -0.5f ? p : e);
+}
+
 #ifndef SPGNN_GEMM_ABLATE
 #define SPGNN_GEMM_ABLATE 0      // timing-only builds: 1 = no split arithmetic, 2 = no MFMA, 3 = no global loads in the loop, 4 = no LDS stores
 #endif
@@ -255,6 +263,95 @@ struct TileIO {
     *reinterpret_cast<uint2*>(lo_img + off) = l;
   }
 };
+
+// Epilogue through LDS: an accumulator register holds one element of 32 different... columns of one row
+// (32 lanes x 4 bytes), which stores as 128-byte pieces.  Each wave parks a 32 x 64 half of its tile in its
+// own LDS slab (pitch 68 floats) and writes it out as whole 256-byte row segments with 16-byte stores.
+// (All waves passed the last barrier of the K loop, so the stage buffers are free; slabs are wave-private.)
+// Optional terms, in this order: exact fp32 rank-J update, bias, activation.
+template <class ARGS>
+__device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&acc)[2][2], _Float16* smem, int row0, int col0,
+                                                       int wave, int lane, int wm, int wn, float alpha) {
+  const int fr = lane & 31, fh = lane >> 5;
+  constexpr int EP = 68;
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * EP);
+  const bool vec_ok = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+  // Everything that depends only on the lane's column group is fetched once, and the rank-J row factors of a
+  // 32-row half are fetched together: as loads inside the store loop they cost one dependent round trip per
+  // iteration (bias alone: 55 us of a 330 us product).
+  const int r_in = lane >> 4, c4 = (lane & 15) * 4;
+  const int col = col0 + wn * 64 + c4;
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) {
+    bq.x = col + 0 < a.N ? a.bias[col + 0] : 0.f; bq.y = col + 1 < a.N ? a.bias[col + 1] : 0.f;
+    bq.z = col + 2 < a.N ? a.bias[col + 2] : 0.f; bq.w = col + 3 < a.N ? a.bias[col + 3] : 0.f;
+  }
+  const bool use_j = a.J > 0 && col + 3 < a.ldv;          // exact fp32 rank-J term (V rows are zero padded)
+  const bool small_j = a.J <= 4;
+  float4 wv[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+    wv[jj] = (use_j && small_j && jj < a.J) ? *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        slab[((e & 3) + 8 * (e >> 2) + 4 * fh) * EP + j * 32 + fr] = acc[i][j][e] * alpha;
+    float uu[8][4];
+    if (use_j && small_j) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int row = row0 + wm * 64 + i * 32 + it * 4 + r_in;
+        row = row < a.M ? row : a.M - 1;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) uu[it][jj] = a.U[(int64_t)row * a.ldu + (jj < a.J ? jj : 0)];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 4 + r_in;
+      const int row = row0 + wm * 64 + i * 32 + lr;
+      float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
+      if (row < a.M) {
+        if (use_j) {
+          if (small_j) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float u = uu[it][jj];
+              v.x = fmaf(u, wv[jj].x, v.x); v.y = fmaf(u, wv[jj].y, v.y); v.z = fmaf(u, wv[jj].z, v.z); v.w = fmaf(u, wv[jj].w, v.w);
+            }
+          } else {
+            const float* urow = a.U + (int64_t)row * a.ldu;
+            for (int jj = 0; jj < a.J; ++jj) {
+              const float u = urow[jj];
+              const float4 w = *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col);
+              v.x = fmaf(u, w.x, v.x); v.y = fmaf(u, w.y, v.y); v.z = fmaf(u, w.z, v.z); v.w = fmaf(u, w.w, v.w);
+            }
+          }
+        }
+        v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+        if (a.act == SPGNN_ACT_ELU) {
+          v.x = elu_fwd(v.x); v.y = elu_fwd(v.y); v.z = elu_fwd(v.z); v.w = elu_fwd(v.w);
+        } else if (a.act == SPGNN_ACT_TANH) {
+          v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        } else if (a.act == SPGNN_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        float* dst = a.C + (int64_t)row * a.ldc + col;
+        if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
+        else {
+          if (col < a.N) dst[0] = v.x;
+          if (col + 1 < a.N) dst[1] = v.y;
+          if (col + 2 < a.N) dst[2] = v.z;
+          if (col + 3 < a.N) dst[3] = v.w;
+        }
+      }
+    }
+  }
+}
 
 template <int WM>
 __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
@@ -360,59 +457,181 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
   if (t < nk) SPGNN_STAGE(t, ra1, rb1)
 #undef SPGNN_STAGE
 
-  // Epilogue through LDS: an accumulator register holds one element of 32 different... columns of one row
-  // (32 lanes x 4 bytes), which stores as 128-byte pieces.  Each wave parks a 32 x 64 half of its tile in its
-  // own LDS slab (pitch 68 floats) and writes it out as whole 256-byte row segments with 16-byte stores.
-  // (All waves passed the last barrier of the K loop, so the stage buffers are free; slabs are wave-private.)
-  const float alpha = 1.f / (sA * sB);
-  constexpr int EP = 68;
-  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * EP);
-  const bool vec_ok = (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
+}
+
+// -------------------------------------------------------------------------------------------------
+//   Operands already in split form ("planes"): hi = fp16(s x), lo = fp16(s x - hi) as two row-major fp16
+//   matrices (Mp x Kp, zero padded: Kp % 32 == 0, Mp % 32 == 0), written once by spgnn_split_rows instead of
+//   being re-derived by every workgroup that touches a tile (the fp32-operand kernels above convert an A tile
+//   N/128 times and a B tile M/256 times).  Tiles then go global -> LDS directly (global_load_lds_dwordx4: no
+//   staging registers, no conversion VALU work, no ds_write), double buffered, with the next stage in flight
+//   across a raw s_barrier under a counted s_waitcnt.
+//
+//   LDS image of a ROWS x 32-half tile: 64-byte rows, lane-linear as the DMA writes them (piece q = 16 bytes:
+//   row q >> 2, position q & 3).  ds_read_b128 fragment reads of 16 consecutive... rows at one k-chunk would hit
+//   4 bank-row slots 4-way, so position = chunk XOR ((row >> 2) & 3), applied on the global SOURCE address when
+//   staging and again on the read (cdna_hip_programming.md rule 21).
+// -------------------------------------------------------------------------------------------------
+struct ArgsP {
+  const _Float16* Ah; const _Float16* Al; int64_t lda;    // (M, Kp) planes, row stride in halves (% 8 == 0)
+  const _Float16* Bh; const _Float16* Bl; int64_t ldb;    // (N, Kp)
+  float* C; int64_t ldc;
+  int M, N, Kp;
+  const float* sA; const float* sB;
+  int nbm, nbn;
+  const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
+  const float* bias; int act;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_image(const _Float16* __restrict__ g, int64_t ld, int row0, int nrows, int k0,
+                                            _Float16* img) {
+  constexpr int NP = ROWS * 4 / NT;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NP; ++i) {
+    const int q = threadIdx.x + NT * i;
+    const int row = q >> 2;
+    const int c = (q & 3) ^ ((row >> 2) & 3);
+    int grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;
+    const _Float16* src = g + (int64_t)grow * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(img + q * 8), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ half8 frag_swz(const _Float16* img, int row, int chunk) {
+  return *reinterpret_cast<const half8*>(img + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
+}
+
+template <int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_nt_planes(ArgsP a) {
+  constexpr int TBM = 64 * WM, NT = 128 * WM;
+  constexpr int A_IMG = TBM * 32, B_IMG = BN * 32;            // halves
+  constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;                 // Ah | Al | Bh | Bl
+  constexpr int LOADS = 2 * (TBM * 4 / NT) + 2 * (BN * 4 / NT);   // DMA instructions per thread and stage
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
+  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
+  const int bm = tile / a.nbn, bn = tile % a.nbn;
+  const int row0 = bm * TBM, col0 = bn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        slab[((e & 3) + 8 * (e >> 2) + 4 * fh) * EP + j * 32 + fr] = acc[i][j][e] * alpha;
-    const int r_in = lane >> 4, c4 = (lane & 15) * 4;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = a.Kp / BK;
+#define SPGNN_STAGE_IN(T_)                                                                     \
+  {                                                                                            \
+    _Float16* sb_ = smem + ((T_) & 1) * STAGE;                                                 \
+    stage_image<TBM, NT>(a.Ah, a.lda, row0, a.M, (T_) * BK, sb_);                              \
+    stage_image<TBM, NT>(a.Al, a.lda, row0, a.M, (T_) * BK, sb_ + A_IMG);                      \
+    stage_image<BN, NT>(a.Bh, a.ldb, col0, a.N, (T_) * BK, sb_ + 2 * A_IMG);                   \
+    stage_image<BN, NT>(a.Bl, a.ldb, col0, a.N, (T_) * BK, sb_ + 2 * A_IMG + B_IMG);           \
+  }
+#ifndef SPGNN_PLANES_ABLATE
+#define SPGNN_PLANES_ABLATE 0     // timing-only builds: 1 = no MFMA, 2 = no DMA inside the loop, 3 = fragments read once
+#endif
+  SPGNN_STAGE_IN(0)
+#if SPGNN_PLANES_ABLATE == 2
+  SPGNN_STAGE_IN(1)
+#endif
+  for (int t = 0; t < nk; ++t) {
+    if (SPGNN_PLANES_ABLATE == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (t + 1 < nk) {
+      SPGNN_STAGE_IN(t + 1)                               // next stage in flight while this one is consumed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                         // every wave's pieces of stage t have landed
+    const _Float16* cb = smem + ((SPGNN_PLANES_ABLATE == 3 ? 0 : t) & 1) * STAGE;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int lr = it * 4 + r_in;
-      const int row = row0 + wm * 64 + i * 32 + lr;
-      const int col = col0 + wn * 64 + c4;
-      float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
-      if (row < a.M) {
-        if (a.J > 0 && col + 3 < a.ldv) {                 // exact fp32 rank-J term (V rows are zero padded)
-          const float* urow = a.U + (int64_t)row * a.ldu;
-          for (int jj = 0; jj < a.J; ++jj) {
-            const float u = urow[jj];
-            const float4 w = *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col);
-            v.x = fmaf(u, w.x, v.x); v.y = fmaf(u, w.y, v.y); v.z = fmaf(u, w.z, v.z); v.w = fmaf(u, w.w, v.w);
-          }
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + fr;
+        ah[i] = frag_swz(cb, row, ks * 2 + fh);
+        al[i] = frag_swz(cb + A_IMG, row, ks * 2 + fh);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + fr;
+        bh[j] = frag_swz(cb + 2 * A_IMG, row, ks * 2 + fh);
+        bl[j] = frag_swz(cb + 2 * A_IMG + B_IMG, row, ks * 2 + fh);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#if SPGNN_PLANES_ABLATE == 1
+          acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1];
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
         }
-        if (a.bias) {
-          v.x += col + 0 < a.N ? a.bias[col + 0] : 0.f; v.y += col + 1 < a.N ? a.bias[col + 1] : 0.f;
-          v.z += col + 2 < a.N ? a.bias[col + 2] : 0.f; v.w += col + 3 < a.N ? a.bias[col + 3] : 0.f;
-        }
-        if (a.act == SPGNN_ACT_ELU) {
-          v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
-          v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
-        } else if (a.act == SPGNN_ACT_TANH) {
-          v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
-        } else if (a.act == SPGNN_ACT_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        float* dst = a.C + (int64_t)row * a.ldc + col;
-        if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
-        else {
-          if (col < a.N) dst[0] = v.x;
-          if (col + 1 < a.N) dst[1] = v.y;
-          if (col + 2 < a.N) dst[2] = v.z;
-          if (col + 3 < a.N) dst[3] = v.w;
-        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // buffer t&1 is free for stage t+2
+  }
+#undef SPGNN_STAGE_IN
+  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
+}
+
+// x (M, K) fp32 -> hi, lo (Mp, Kp) fp16 planes of scale * x [* dropout keep/(1-p)], zero padded rows and columns.
+// One thread per 8 columns (two 16-byte loads, one 16-byte store per plane).  Same packed RTZ split as the
+// on-the-fly kernels, so a planes GEMM and an fp32-operand GEMM of the same data agree bit for bit.
+__device__ __forceinline__ float keep_hash(uint64_t seed, int64_t idx, float p, float inv_keep) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int M, int K,
+                                                         const float* __restrict__ scale, float extra,
+                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t ldp,
+                                                         int Mp, int Kp) {
+  const int k8 = Kp >> 3;
+  const float s = (scale ? scale[0] : 1.f) * extra;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Mp * k8;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / k8), c = (int)(idx % k8) * 8;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < M) {
+      const float* src = x + (int64_t)row * ldx;
+      if (c + 8 <= K) { v0 = *reinterpret_cast<const float4*>(src + c); v1 = *reinterpret_cast<const float4*>(src + c + 4); }
+      else {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = c + j < K ? src[c + j] : 0.f;
+        v0 = make_float4(t[0], t[1], t[2], t[3]); v1 = make_float4(t[4], t[5], t[6], t[7]);
       }
     }
+    uint2 h0, l0, h1, l1;
+    split4_pk(v0, s, h0, l0);
+    split4_pk(v1, s, h1, l1);
+    *reinterpret_cast<uint4*>(hi + (int64_t)row * ldp + c) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4*>(lo + (int64_t)row * ldp + c) = make_uint4(l0.x, l0.y, l1.x, l1.y);
   }
 }
 
@@ -664,7 +883,7 @@ __global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __res
 extern "C" {
 
 static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
-int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 3) g_gemm_variant = v; return old; }
+int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 4) g_gemm_variant = v; return old; }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
@@ -693,7 +912,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
     // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
-    const int WM = (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
+    const int WM = g_gemm_variant == 4 ? 4 : (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
@@ -709,6 +928,63 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
       if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
     }
+  }
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
+                     uint16_t* hi, uint16_t* lo, int64_t plane_stride, int64_t Mp, int64_t Kp, spgnn_stream_t stream) {
+  if (M < 0 || K <= 0 || Mp < M || Kp < K || (Kp & 31) || Mp > INT32_MAX || Kp > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (Mp == 0) return SPGNN_OK;
+  if (!hi || !lo || (M > 0 && !x)) return SPGNN_ERR_NULLPTR;
+  if (x_stride < K || plane_stride < Kp || (plane_stride & 7) || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(lo) & 15))
+    return SPGNN_ERR_STRIDE;
+  int64_t blocks = (Mp * (Kp / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(gemm::split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, (int)M,
+                     (int)K, scale, extra_factor, reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), plane_stride,
+                     (int)Mp, (int)Kp);
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi, const uint16_t* B_lo,
+                         int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t Kp, const float* scale_a,
+                         const float* scale_b, const float* upd_u, int64_t upd_u_stride, const float* upd_v,
+                         int64_t upd_v_stride, int32_t upd_j, const float* bias, int32_t activation, spgnn_stream_t stream) {
+  if (M < 0 || N < 0 || Kp <= 0 || (Kp & 31) || M > INT32_MAX || N > INT32_MAX || Kp > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return SPGNN_ERR_ENUM;
+  if (upd_j > 0) {
+    if (!upd_u || !upd_v) return SPGNN_ERR_NULLPTR;
+    if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
+        (reinterpret_cast<uintptr_t>(upd_v) & 15))
+      return SPGNN_ERR_STRIDE;
+  }
+  if (M == 0 || N == 0) return SPGNN_OK;
+  if (!A_hi || !A_lo || !B_hi || !B_lo || !C) return SPGNN_ERR_NULLPTR;
+  if (lda < Kp || ldb < Kp || ldc < N || (lda & 7) || (ldb & 7) || (reinterpret_cast<uintptr_t>(A_hi) & 15) ||
+      (reinterpret_cast<uintptr_t>(A_lo) & 15) || (reinterpret_cast<uintptr_t>(B_hi) & 15) || (reinterpret_cast<uintptr_t>(B_lo) & 15))
+    return SPGNN_ERR_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  const int WM = (g_gemm_variant == 3 || M < 4096 || Kp < 512 || N < 512) ? 2 : 4;
+  const int TBM = 64 * WM;
+  gemm::ArgsP a{reinterpret_cast<const _Float16*>(A_hi), reinterpret_cast<const _Float16*>(A_lo), lda,
+                reinterpret_cast<const _Float16*>(B_hi), reinterpret_cast<const _Float16*>(B_lo), ldb, C, ldc, (int)M, (int)N,
+                (int)Kp, scale_a, scale_b, (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride,
+                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation};
+  int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
+  size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * 32 * sizeof(_Float16);
+  const size_t epi = (size_t)(2 * WM) * 32 * 68 * sizeof(float);               // epilogue slabs share the buffer
+  if (lds_bytes < epi) lds_bytes = epi;
+  if (WM == 4) {
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_planes<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
+    hipLaunchKernelGGL(gemm::gemm_nt_planes<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
+  } else {
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_planes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
+    hipLaunchKernelGGL(gemm::gemm_nt_planes<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
   }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }

@@ -745,6 +745,50 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     return out
 
 
+class Planes:
+    """A tensor in split form for the matrix-core GEMMs: fp16 planes hi, lo of scale * x, (Mp, Kp) zero padded."""
+    __slots__ = ("hi", "lo", "scale", "M", "K")
+
+    def __init__(self, hi, lo, scale, M, K):
+        self.hi, self.lo, self.scale, self.M, self.K = hi, lo, scale, M, K
+
+
+def split_rows(x: torch.Tensor, scale: Optional[torch.Tensor], extra: float = 1.0) -> Planes:
+    _require_cuda(x)
+    M, K = x.shape
+    assert _rows_aligned(x)
+    Mp, Kp = (M + 31) // 32 * 32, (K + 31) // 32 * 32
+    hi = torch.empty((Mp, Kp), dtype=torch.float16, device=x.device)
+    lo = torch.empty((Mp, Kp), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device), _timed("split_rows", (M, K)):
+        _capi.check(_capi.load().spgnn_split_rows(x.data_ptr(), x.stride(0), M, K, _ptr(scale), extra, hi.data_ptr(),
+                                                  lo.data_ptr(), Kp, Mp, Kp, _stream(x)), "spgnn_split_rows")
+    return Planes(hi, lo, scale, M, K)
+
+
+def gemm_nt_planes(a: Planes, b: Planes, out: Optional[torch.Tensor] = None, upd_u: Optional[torch.Tensor] = None,
+                   upd_v: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
+    """gemm_nt on operands already in split form."""
+    M, N = a.M, b.M
+    Kp = a.hi.shape[1]
+    assert b.hi.shape[1] == Kp and a.K == b.K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.hi.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    J = 0
+    if upd_u is not None:
+        J = upd_u.shape[1]
+        assert upd_u.shape[0] == M and upd_u.stride(1) == 1 and upd_v.shape[0] == J and upd_v.shape[1] >= N
+        assert _rows_aligned(upd_v) and upd_v.stride(0) >= (N + 3) // 4 * 4 and J <= 32
+    with torch.cuda.device(out.device), _timed("gemm_nt", (M, N, a.K)):
+        _capi.check(_capi.load().spgnn_gemm_nt_planes(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), b.hi.data_ptr(),
+                                                      b.lo.data_ptr(), b.hi.stride(0), out.data_ptr(), out.stride(0), M, N, Kp,
+                                                      _ptr(a.scale), _ptr(b.scale), _ptr(upd_u),
+                                                      upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
+                                                      _ptr(bias), act, _stream(out)), "spgnn_gemm_nt_planes")
+    return out
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K

@@ -87,3 +87,24 @@ def test_gemm_tn_column_sums(R, M, N):
     c, cs = ops.gemm_tn(a, b, ops.pow2_scale(a), ops.pow2_scale(b), want_colsum=True)
     assert rel_err(c, a.double().t() @ b.double()) < 2e-6
     assert rel_err(cs, a.double().sum(0)) < 2e-6 and cs.shape == (M,)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 1063), (1000, 130, 96), (257, 512, 384), (64, 64, 32)])
+def test_planes_gemm_is_bit_identical_to_the_fp32_operand_gemm(M, N, K):
+    """spgnn_split_rows + spgnn_gemm_nt_planes (operands split once, tiles by LDS DMA) against spgnn_gemm_nt (split on
+    the fly): same round-toward-zero split, same product order -> the same bits; plus the epilogue options."""
+    torch.manual_seed(M + N + K)
+    Kp4 = (K + 3) // 4 * 4
+    a = torch.randn(M, Kp4, device="cuda")[:, :K]; b = (torch.randn(N, Kp4, device="cuda") * 0.1)[:, :K]
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    pa, pb = ops.split_rows(a, sa), ops.split_rows(b, sb)
+    assert pa.hi.shape == ((M + 31) // 32 * 32, (K + 31) // 32 * 32) and pa.hi.dtype == torch.float16
+    rec = (pa.hi[:M, :K].double() + pa.lo[:M, :K].double()) / float(sa)
+    assert (rec - a.double()).abs().max() <= 2.0 ** -21 * a.abs().max()          # 22 significant bits
+    assert not pa.hi[M:].any() and not pa.hi[:, K:].any() and not pa.lo[M:].any() and not pa.lo[:, K:].any()
+    assert torch.equal(ops.gemm_nt_planes(pa, pb), ops.gemm_nt(a, b, sa, sb))
+    bias = torch.randn(N, device="cuda")
+    u = torch.randn(M, 4, device="cuda"); v = torch.randn(4, (N + 15) // 16 * 16, device="cuda")
+    v[:, N:] = 0
+    assert torch.equal(ops.gemm_nt_planes(pa, pb, upd_u=u, upd_v=v, bias=bias, act=ops.ACT_ELU),
+                       ops.gemm_nt(a, b, sa, sb, upd_u=u, upd_v=v, bias=bias, act=ops.ACT_ELU))
