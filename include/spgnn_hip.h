@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 12
+#define SPGNN_ABI_VERSION 13
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -190,6 +190,18 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                   const float* out, int64_t out_stride,
                   float* g_pre, int64_t g_pre_stride, float* absmax,
                   int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+
+/*
+ * Layer-input assembly of the hidden SPGNN layers, dropout(cat[h_s, h_p]) (reference models.py:477-481 + GATConv's
+ * feat_drop), one source per call:  dst[:, col_offset : col_offset + width] = src * keep/(1-p)   (backward == 0)
+ * and its gradient                    dst = src[:, col_offset : col_offset + width] * keep/(1-p)   (backward != 0, src =
+ * gradient of the concatenation).  keep: one 64-bit counter hash (the attention dropout's mixer) per group of four
+ * columns starting at a multiple of 4 inside the source, counter = row * total_width + col_offset + c; 16 bits per
+ * element, kept iff bits >= p * 65536.
+ */
+int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t N, int32_t width,
+                      int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      int32_t backward, spgnn_stream_t stream);
 
 /*
  * Folding of GATConv's score vectors through fc (what makes el/er a projection of the layer INPUT; reference

@@ -1158,19 +1158,22 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (v >= N) return;
-  const int HD = H * D;
   const float gscale = mean ? 1.f / (float)H : 1.f;
   float mx = 0.f;
-  for (int c = lane * 4; c < HD; c += 256) {
-    float4 q = ld4(g + v * g_ld + (mean ? c % D : c));
-    q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
-    if (act != SPGNN_ACT_NONE) {
-      const float4 o = ld4(out + v * out_ld + c);
-      q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
-      q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+  for (int c = lane * 4; c < D; c += 256) {             // the mean's gradient row is read once and shared by the heads
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mean) { gm = ld4(g + v * g_ld + c); gm.x *= gscale; gm.y *= gscale; gm.z *= gscale; gm.w *= gscale; }
+    for (int h = 0; h < H; ++h) {
+      const int idx = h * D + c;
+      float4 q = mean ? gm : ld4(g + v * g_ld + idx);
+      if (act != SPGNN_ACT_NONE) {
+        const float4 o = ld4(out + v * out_ld + idx);
+        q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
+        q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+      }
+      st4(g_pre + v * gp_ld + idx, q);
+      mx = absmax4(mx, q);
     }
-    st4(g_pre + v * gp_ld + c, q);
-    mx = absmax4(mx, q);
   }
   if (absmax) {
     mx = team_max(mx, 64);
@@ -1233,6 +1236,55 @@ __global__ __launch_bounds__(kBlock) void fold_scores_bwd(const float* __restric
   }
   for (int off = 32; off > 0; off >>= 1) { dl += __shfl_xor(dl, off, 64); dr += __shfl_xor(dr, off, 64); }
   if (lane == 0) { g_al[row] = (float)dl; g_ar[row] = (float)dr; }
+}
+
+// =================================================================================================
+// cat + feature dropout in one pass (the layer input of every hidden SPGNN layer is dropout(cat[h_s, h_p]),
+// reference models.py:477-481 with GATConv's feat_drop): out[:, off:off+w] = src * keep/(1-p), keep from the same
+// counter hash as the attention dropout, regenerated (not stored) by the backward pass
+//   g_src = g_out[:, off:off+w] * keep/(1-p).
+// One launch per source; element (row, off + c) uses counter row * width_total + off + c.
+// =================================================================================================
+// One 64-bit hash serves four neighbouring elements (16 bits each: keep iff bits >= p * 65536), counter = index of the
+// group's first element.
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __restrict__ src, int64_t src_ld, float* __restrict__ dst,
+                                                             int64_t dst_ld, int64_t N, int w, int off, int total, float p,
+                                                             float inv_keep, uint64_t seed, const uint64_t* __restrict__ seed_off,
+                                                             int backward) {
+  if (seed_off) seed += seed_off[0];
+  const int w4 = (w + 3) >> 2;
+  const unsigned thr = (unsigned)(p * 65536.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * w4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / w4; const int c = (int)(i % w4) * 4;
+    // forward: src is a source tensor (its own column 0 = output column off); backward: src is the gradient of the
+    // concatenation (read at off + c) and dst the gradient of the source
+    const float* sp = src + row * src_ld + (backward ? off : 0) + c;
+    float* dp = dst + row * dst_ld + (backward ? 0 : off) + c;
+    float v[4];
+    if (VEC) { const float4 q = ld4(sp); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = c + j < w ? sp[j] : 0.f;
+    }
+    if (p > 0.f) {
+      const uint64_t z = mix64(seed, row * total + off + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= ((unsigned)(z >> (16 * j)) & 0xFFFFu) >= thr ? inv_keep : 0.f;
+    }
+    if (VEC) st4(dp, make_float4(v[0], v[1], v[2], v[3]));
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (c + j < w) dp[j] = v[j];
+    }
+  }
 }
 
 // =================================================================================================
@@ -1938,6 +1990,27 @@ int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l,
                      (hipStream_t)stream, W, w_stride, attn_l, attn_r, g_w_lr, w_lr_stride, g_W, g_w_stride, g_attn_l, g_attn_r,
                      H, D, K);
   return check_launch("spgnn_fold_scores_bwd");
+}
+
+int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t N, int32_t width,
+                      int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      int32_t backward, spgnn_stream_t stream) {
+  if (N < 0 || width <= 0 || col_offset < 0 || total_width < col_offset + width) return fail(SPGNN_ERR_SHAPE, "spgnn_cat_dropout: bad N/width/offset");
+  if (N == 0) return SPGNN_OK;
+  if (!src || !dst) return fail(SPGNN_ERR_NULLPTR, "spgnn_cat_dropout: null pointer");
+  if (src_stride < (backward ? total_width : width) || dst_stride < (backward ? width : total_width))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_cat_dropout: row stride smaller than row");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_cat_dropout: p_drop not in [0,1)");
+  int64_t blocks = (N * ((width + 3) / 4) + kBlock - 1) / kBlock;
+  if (blocks > 32768) blocks = 32768;
+  const bool vec = (width & 3) == 0 && (col_offset & 3) == 0 && vec_ok(src, src_stride) && vec_ok(dst, dst_stride);
+  if (vec)
+    hipLaunchKernelGGL(cat_dropout_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
+                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0);
+  else
+    hipLaunchKernelGGL(cat_dropout_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
+                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0);
+  return check_launch("spgnn_cat_dropout");
 }
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,

@@ -20,11 +20,29 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn import GATConv, GINConv, GraphConv, SAGEConv, SkinnyLinear
+from . import ops
+from .nn import GATConv, GINConv, GraphConv, SAGEConv, SkinnyLinear, _draw_seed
 from .ops import cat_padded
 
 __all__ = ["GCN", "GAT", "GIN", "SAGE", "GATPSPGNN", "GATPSPGNNNL", "GCNNet", "GATNet", "GINNet", "SAGENet",
            "GATPositionSPGNNNet", "set_trainable"]
+
+
+def _cat_for(layer, a: torch.Tensor, b: torch.Tensor):
+    """(cat[a, b] with ``layer``'s feature dropout applied, True) when the fused kernel can be used (GPU), else
+    (plain cat, False): the layer then applies its own nn.Dropout."""
+    if not a.is_cuda:
+        return torch.cat([a, b], dim=1), False
+    p = float(layer.feat_drop.p) if layer.training else 0.0
+    return ops.cat_dropout((a, b), p, _draw_seed() if p > 0.0 else 0), True
+
+
+def _drop_for(layer, x: torch.Tensor):
+    """(x with ``layer``'s feature dropout applied by the hash-mask kernel, True) on the GPU in training mode."""
+    p = float(layer.feat_drop.p) if layer.training else 0.0
+    if not x.is_cuda or p == 0.0:
+        return x, False
+    return ops.cat_dropout((x,), p, _draw_seed()), True
 
 
 def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -181,9 +199,15 @@ class GATPSPGNN(nn.Module):
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
-            h_s = s_layer(g, _data_cat(g, h_s, h_p) if l == 0 else _cat(h_s, h_p)).flatten(1)
-            h_p = p_layer(g, _data_aligned(g, h_p) if l == 0 else h_p).flatten(1)
-        h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
+            if l == 0:
+                x, dropped = _data_cat(g, h_s, h_p), False
+            else:
+                x, dropped = _cat_for(s_layer, h_s, h_p)
+            h_s = s_layer(g, x, feat_dropped=dropped).flatten(1)
+            xp, dropped = (_data_aligned(g, h_p), False) if l == 0 else _drop_for(p_layer, h_p)
+            h_p = p_layer(g, xp, feat_dropped=dropped).flatten(1)
+        x, dropped = _cat_for(self.gat_layers[-1], h_s, h_p)
+        h_s = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped)
         return h_s, h_p
 
 
@@ -212,8 +236,13 @@ class GATPSPGNNNL(nn.Module):
     def forward(self, g):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for l, layer in enumerate(self.gat_layers[:-1]):
-            h_s = layer(g, _data_cat(g, h_s, h_p) if l == 0 else _cat(h_s, h_p)).flatten(1)
-        h_s = self.gat_layers[-1](g, _cat(h_s, h_p), mean_heads=True)
+            if l == 0:
+                x, dropped = _data_cat(g, h_s, h_p), False
+            else:
+                x, dropped = _cat_for(layer, h_s, h_p)
+            h_s = layer(g, x, feat_dropped=dropped).flatten(1)
+        x, dropped = _cat_for(self.gat_layers[-1], h_s, h_p)
+        h_s = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped)
         return h_s, h_p
 
 

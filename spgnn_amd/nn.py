@@ -111,15 +111,18 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False,
+                feat_dropped: bool = False):
         """DGL signature; ``mean_heads=True`` (extension) returns ``rst.mean(1)`` (N, D) with the mean fused
-        into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482)."""
+        into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482).
+        ``feat_dropped=True`` (extension): the caller already applied this layer's feature dropout while assembling
+        ``feat`` (ops.cat_dropout fuses it into the concatenation)."""
         csc = graph.csc(feat.device)
         if not self._allow_zero_in_degree and csc.min_in_degree == 0:
             raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
                            "Add self-loops (g.add_edges(g.nodes(), g.nodes())) or set allow_zero_in_degree.")
         H, D = self._num_heads, self._out_feats
-        h = self.feat_drop(feat)
+        h = feat if feat_dropped else self.feat_drop(feat)
         has_res = isinstance(self.res_fc, nn.Linear)
         identity_res = isinstance(self.res_fc, Identity)
         act = _act_code(self.activation)

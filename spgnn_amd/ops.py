@@ -380,6 +380,57 @@ class _CatPad(torch.autograd.Function):
         return tuple(outs)
 
 
+class _CatDropout(torch.autograd.Function):
+    """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
+    counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""
+
+    @staticmethod
+    def forward(ctx, p, seed, *tensors):
+        widths = [t.shape[1] for t in tensors]
+        F_ = sum(widths)
+        Fp = (F_ + 3) // 4 * 4
+        N = tensors[0].shape[0]
+        buf = torch.empty((N, Fp), dtype=torch.float32, device=tensors[0].device)
+        if Fp > F_:
+            buf[:, F_:].zero_()
+        lib = _capi.load()
+        off = 0
+        with torch.cuda.device(buf.device):
+            for t in tensors:
+                t = t if t.stride(1) == 1 else t.contiguous()
+                _capi.check(lib.spgnn_cat_dropout(t.data_ptr(), t.stride(0), buf.data_ptr(), buf.stride(0), N, t.shape[1], off, F_,
+                                                  p, seed, _seed_off_ptr(buf.device), 0, _stream(buf)), "spgnn_cat_dropout")
+                off += t.shape[1]
+        ctx.widths, ctx.p, ctx.seed = widths, p, seed
+        return buf[:, :F_]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        N, F_ = g.shape
+        lib = _capi.load()
+        outs, off = [], 0
+        with torch.cuda.device(g.device):
+            for w, need in zip(ctx.widths, ctx.needs_input_grad[2:]):
+                if need:
+                    wp = (w + 3) // 4 * 4
+                    go = torch.empty((N, wp), dtype=torch.float32, device=g.device)[:, :w]
+                    _capi.check(lib.spgnn_cat_dropout(g.data_ptr(), g.stride(0), go.data_ptr(), go.stride(0), N, w, off, F_,
+                                                      ctx.p, ctx.seed, _seed_off_ptr(g.device), 1, _stream(g)), "spgnn_cat_dropout")
+                    outs.append(go)
+                else:
+                    outs.append(None)
+                off += w
+        return (None, None) + tuple(outs)
+
+
+def cat_dropout(tensors, p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """dropout(cat(tensors, 1), p) with 16-byte-aligned rows; p = 0: a plain concatenation."""
+    _require_cuda(*tensors)
+    return _CatDropout.apply(float(p), int(seed), *tensors)
+
+
 def cat_padded(tensors) -> torch.Tensor:
     return _CatPad.apply(*tensors)
 

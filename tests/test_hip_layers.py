@@ -10,7 +10,7 @@ from oracle import dgl_cpu as O
 from spgnn_amd import nn as snn
 from spgnn_amd import ops
 from spgnn_amd.graph import TreeGraph
-from tests.util import keep_scale_host, rel_err, tree_batch_edges
+from tests.util import keep4_scale_host, keep_scale_host, rel_err, tree_batch_edges
 
 pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 1e-5, 5e-5
@@ -234,6 +234,25 @@ def test_epilogue_and_derivative_kernels_of_the_aggregate_first_form(act):
              ops.ACT_TANH: 1 - out * out, ops.ACT_RELU: (out > 0).float()}[act]
         want = (g / H).repeat(1, H) * d if mean else g * d
         assert rel_err(gp, want) < 1e-6 and rel_err(amax, want.abs().amax(1)) < 1e-6
+
+
+def test_cat_dropout_is_cat_then_dropout_with_a_regenerated_mask():
+    torch.manual_seed(0)
+    N, p, seed = 777, 0.25, 4242
+    a = torch.randn(N, 130, device="cuda", requires_grad=True); b = torch.randn(N, 39, device="cuda", requires_grad=True)
+    y0 = ops.cat_dropout((a, b), 0.0)
+    assert y0.stride(0) % 4 == 0 and torch.equal(y0, torch.cat([a, b], 1))
+    y = ops.cat_dropout((a, b), p, seed)
+    keep = torch.from_numpy(keep4_scale_host(seed, N, (130, 39), p)).cuda()
+    assert abs(float((keep > 0).float().mean()) - (1 - p)) < 0.01
+    assert torch.equal(y, torch.cat([a, b], 1) * keep)
+    cot = torch.randn(N, 169, device="cuda")
+    (y * cot).sum().backward()
+    assert torch.equal(a.grad, (cot * keep)[:, :130]) and torch.equal(b.grad, (cot * keep)[:, 130:])
+    assert torch.equal(ops.cat_dropout((a, b), p, seed), y) and not torch.equal(ops.cat_dropout((a, b), p, seed + 1), y)
+    c = torch.randn(N, 512, device="cuda"); d = torch.randn(N, 256, device="cuda")      # the 16-byte vector path
+    keep2 = torch.from_numpy(keep4_scale_host(seed, N, (512, 256), p)).cuda()
+    assert torch.equal(ops.cat_dropout((c, d), p, seed), torch.cat([c, d], 1) * keep2)
 
 
 SPMM_F = [64, 128, 256, 1024, 22, 7, 192]

@@ -23,6 +23,32 @@ def keep_scale_host(seed: int, idx: np.ndarray, p: float) -> np.ndarray:
     return np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
 
 
+def keep4_scale_host(seed: int, N: int, widths, p: float) -> np.ndarray:
+    """Host copy of spgnn_cat_dropout's mask for sources of the given widths: one 64-bit hash per group of four
+    columns of a source, 16 bits per element."""
+    total = int(sum(widths))
+    out = np.zeros((N, total), dtype=np.float32)
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    rows = np.arange(N, dtype=np.int64)[:, None]
+    off = 0
+    for w in widths:
+        c = np.arange(0, w, 4, dtype=np.int64)[None, :]
+        idx = (rows * total + off + c).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))) & M
+            z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+            z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+            z = z ^ (z >> np.uint64(31))
+        for j in range(4):
+            cols = off + c[0] + j
+            ok = cols < off + w
+            bits = (z >> np.uint64(16 * j)) & np.uint64(0xFFFF)
+            out[:, cols[ok]] = np.where(bits[:, ok] >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0))
+        off += w
+    return out
+
+
 def tree_batch_edges(ns, seed=0):
     from spgnn_amd import synthetic
     from spgnn_amd.graph import edges_from_adj

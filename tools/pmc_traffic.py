@@ -13,7 +13,7 @@ def counter_rows(d, counter):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     df = pd.read_csv(f)
     df = df[df["Counter_Name"] == counter]
-    df = df[df["Kernel_Name"].str.contains("gat_fwd|gat_bwd_dst|gat_bwd_src")]
+    df = df[df["Kernel_Name"].str.contains("gat_fwd|gat_bwd_dst|gat_bwd_src|gat_agg_|head_mean|act_bwd")]
     df = df.groupby(["Dispatch_Id", "Kernel_Name", "Grid_Size"], as_index=False)["Counter_Value"].sum().sort_values("Dispatch_Id")
     return df.reset_index(drop=True)
 
