@@ -444,9 +444,10 @@ class _GATLayerFn(torch.autograd.Function):
         split = GEMM_MODE == "f16x3" and _rows_aligned(x) and _rows_aligned(w_cat) and x.shape[0] > 0
         if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
             s, sx = scores_fwd(x, w_lr, want_scale=True)   # (N, 2H) = [el | er]; the scale of x comes for free
-            y = gemm_nt(x, w_cat, sx, pow2_scale(w_cat))
+            sw = pow2_scale(w_cat)
+            y = gemm_nt(x, w_cat, sx, sw)
         else:
-            sx = None
+            sx = sw = None
             y = torch.mm(x, w_cat.t())
             s = scores_fwd(x, w_lr)
         ft = y[:, :HD]
@@ -455,13 +456,13 @@ class _GATLayerFn(torch.autograd.Function):
                                           mean=mean, need_out=(act != ACT_NONE))
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx)
+        ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx, sw)
         ctx.mark_non_differentiable(attn)
         return (out_mean if mean else out), attn
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
-        x, w_cat, w_lr, y, s, attn, out, sx = ctx.saved_tensors
+        x, w_cat, w_lr, y, s, attn, out, sx, sw = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
         HD = H * D
@@ -502,9 +503,9 @@ class _GATLayerFn(torch.autograd.Function):
                 J = g_s.shape[1]
                 if J <= 32:                            # + g_S @ W_lr as an exact fp32 rank-2H update in the epilogue
                     w_lr_p = _padded_rows(w_lr, _pad16(K))
-                    gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x, upd_u=g_s, upd_v=w_lr_p)
+                    gemm_nt(g_y, w_t, sg, sw, out=g_x, upd_u=g_s, upd_v=w_lr_p)   # W^T shares W's scale
                 else:
-                    gemm_nt(g_y, w_t, sg, pow2_scale(w_t), out=g_x)
+                    gemm_nt(g_y, w_t, sg, sw, out=g_x)
                     scores_bwd_x_(g_x, g_s, w_lr)
             else:
                 torch.mm(g_y, w_cat, out=g_x)

@@ -75,11 +75,34 @@ class FlatBucket:
         self.wsum_slot = self.flat_grad[self.numel:self.numel + 1]
         self.steps = 0
 
+        self._views = [p.grad for p in self.params]
+        self._zeros = {}
+
     def zero_grad(self):
         self.flat_grad.zero_()
         for p in self.params:            # keep the views attached (a foreign .grad would bypass the bucket)
             if p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr():
                 raise RuntimeError("parameter .grad was detached from the flat bucket")
+
+    def detach_grads(self):
+        """Before backward: with ``.grad`` unset autograd hands each parameter its gradient tensor as is - no zero
+        fill of the bucket and no accumulate launch per parameter (44 adds of a few microseconds each per step)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """After backward: one batched copy of all gradients into the flat bucket; ``.grad`` becomes the bucket view again."""
+        parts = []
+        for p in self.params:
+            g = p.grad
+            if g is None:                # parameter not reached by this loss (e.g. unused auxiliary heads)
+                g = self._zeros.get(p.numel())
+                if g is None:
+                    g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat_grad.device)
+            parts.append(g.reshape(-1))
+        torch.cat(parts, out=self.flat_grad[:self.numel])
+        for p, v in zip(self.params, self._views):
+            p.grad = v
 
 
 class TrainStep:
@@ -110,7 +133,7 @@ class TrainStep:
     def step(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns the (global) loss as a device scalar; never synchronises with the host."""
         b = self.bucket
-        b.zero_grad()
+        b.detach_grads()
         y = g.ndata["y"]
         p = self._sampling(g)
         if draws is None:
@@ -124,6 +147,7 @@ class TrainStep:
         logits = self.model(g)[0]
         num, den = weighted_nll_sums(logits, y, mask, self.class_weight)
         num.backward()
+        b.gather_grads()
         b.wsum_slot.copy_(den.detach().reshape(1))
         loss_num = num.detach()
         if self.world > 1:
