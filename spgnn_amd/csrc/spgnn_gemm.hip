@@ -660,6 +660,7 @@ struct ArgsTN {
   const float* sA; const float* sB;
   int nbm, nbn;
   float* colsum;                                  // optional (splits, M): per-split column sums of A (bias gradient)
+  int by_xcd;                                     // pipelined kernel: 1-D grid, one split per XCD (splits % 8 == 0)
 };
 
 // one 32 x 128 fp32 tile = 1024 float4; thread t takes float4 #(t + 256 i): row = idx / 32, c4 = idx % 32
@@ -800,6 +801,153 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
   }
   const float alpha = 1.f / (sA * sB);
   float* Cp = a.C + (int64_t)blockIdx.y * a.split_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + fr;
+      if (col >= a.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (row < a.M) Cp[(int64_t)row * a.ldc + col] = acc[i][j][e] * alpha;
+      }
+    }
+}
+
+// Pipelined form of gemm_tn_f16x3 (same tiles, fragments and arithmetic): fp32 tiles are prefetched two stages
+// ahead into two register sets, the conversion + LDS store of stage t+1 is interleaved between the MFMAs of
+// stage t (double-buffered LDS, one barrier per stage) - the schedule of gemm_nt_f16x3_v2.  The first-generation
+// kernel above loads, converts and multiplies in sequence and is kept as the A/B reference (variant 1).
+__device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
+  const int idx = threadIdx.x + kThreads * i;
+  const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
+  uint2 h, l;
+  split4_pk(v, s, h, l);
+  *reinterpret_cast<uint2*>(hi_img + off) = h;
+  *reinterpret_cast<uint2*>(lo_img + off) = l;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];          // 2 stages x (Ah | Al | Bh | Bl)
+  constexpr int STAGE = 4 * TTILE;
+
+  // Placement.  Every tile of one split streams the same row range of both operands, so a split is given to ONE
+  // XCD (workgroups go to XCDs round-robin by linear id): the range is fetched into that XCD's L2 once and the
+  // tiles' re-reads (8-9x per operand at 128x128 tiles) are L2 hits instead of fabric traffic.  Needs
+  // splits % 8 == 0 (a.by_xcd); otherwise tiles are spread as in the NT kernel.
+  unsigned tile, split;
+  if (a.by_xcd) {
+    const unsigned L = blockIdx.x, tiles = (unsigned)(a.nbm * a.nbn);
+    const unsigned xcd = L & 7u, q = L >> 3;
+    split = xcd + 8u * (q / tiles);
+    tile = q % tiles;
+  } else {
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    tile = (b & 7u) * (nb >> 3) + (b >> 3);
+    split = blockIdx.y;
+    if (tile >= (unsigned)(a.nbm * a.nbn)) return;
+  }
+  const int bm = tile / a.nbn, bn = tile % a.nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int64_t r_beg = (int64_t)split * a.rows_per_split;
+  const int64_t r_end = r_beg + a.rows_per_split < a.R ? r_beg + a.rows_per_split : a.R;
+  const int nk = r_beg < r_end ? (int)((r_end - r_beg + TBK - 1) / TBK) : 0;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_colsum = a.colsum != nullptr && bn == 0;
+#define SPGNN_TN_LOAD(T_, RA, RB)                                                    \
+  {                                                                                  \
+    load_tile_t(a.A, a.lda, r_beg + (int64_t)(T_) * TBK, r_end, m0, a.M, RA);        \
+    load_tile_t(a.B, a.ldb, r_beg + (int64_t)(T_) * TBK, r_end, n0, a.N, RB);        \
+  }
+#define SPGNN_TN_CSUM(RA)                                                            \
+  if (do_colsum) {                                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
+  }
+  if (nk > 0) {
+    SPGNN_TN_LOAD(0, ra0, rb0)
+    if (nk > 1) SPGNN_TN_LOAD(1, ra1, rb1)
+    SPGNN_TN_CSUM(ra0)
+    _Float16* st = smem_t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_one_t(st, st + TTILE, ra0[q], q, sA);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_one_t(st + 2 * TTILE, st + 3 * TTILE, rb0[q], q, sB);
+  }
+  __syncthreads();
+  if (nk > 2) SPGNN_TN_LOAD(2, ra0, rb0)
+
+  // stage T_: MFMAs on buffer T_&1; register set (RA, RB) = stage T_+1 is converted into the other buffer,
+  // one float4 pair per accumulator group; then the set is refilled with stage T_+3
+#define SPGNN_TN_STAGE(T_, RA, RB)                                                                           \
+  {                                                                                                          \
+    const _Float16* cb = smem_t + ((T_) & 1) * STAGE;                                                        \
+    _Float16* nbuf = smem_t + (((T_) + 1) & 1) * STAGE;                                                      \
+    const bool has_next = (T_) + 1 < nk;                                                                     \
+    if (has_next) SPGNN_TN_CSUM(RA)                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < TBK / 16; ++ks) {                                                \
+      half8 ah[2], al[2], bh[2], bl[2];                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+        ah[i] = tr_frag(cb, wm * 64 + i * 32, ks * 16, lane);                                                \
+        al[i] = tr_frag(cb + TTILE, wm * 64 + i * 32, ks * 16, lane);                                        \
+      }                                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+        bh[j] = tr_frag(cb + 2 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
+        bl[j] = tr_frag(cb + 3 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
+      }                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);              \
+          if (has_next) {                                                                                    \
+            const int slot = ks * 4 + i * 2 + j;                        /* 8 slots, 8 float4 to convert */   \
+            if (slot < 4) store_one_t(nbuf, nbuf + TTILE, RA[slot], slot, sA);                               \
+            else store_one_t(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4, sB);                \
+          }                                                                                                  \
+        }                                                                                                    \
+    }                                                                                                        \
+    if ((T_) + 3 < nk) SPGNN_TN_LOAD((T_) + 3, RA, RB)                                                       \
+    __syncthreads();                                                                                         \
+  }
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    SPGNN_TN_STAGE(t, ra1, rb1)
+    SPGNN_TN_STAGE(t + 1, ra0, rb0)
+  }
+  if (t < nk) SPGNN_TN_STAGE(t, ra1, rb1)
+#undef SPGNN_TN_STAGE
+#undef SPGNN_TN_LOAD
+#undef SPGNN_TN_CSUM
+
+  if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
+    float* red = reinterpret_cast<float*>(smem_t);
+    *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4) = csum;
+    __syncthreads();
+    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < a.M) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
+      a.colsum[(int64_t)split * a.M + m0 + threadIdx.x] = t_;
+    }
+  }
+  const float alpha = 1.f / (sA * sB);
+  float* Cp = a.C + (int64_t)split * a.split_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1001,11 +1149,31 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
   gemm::ArgsTN a{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, 0};
   int64_t tiles = (int64_t)a.nbm * a.nbn;
   tiles = (tiles + 7) & ~int64_t(7);
-  hipLaunchKernelGGL(gemm::gemm_tn_f16x3, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), 0,
-                     (hipStream_t)stream, a);
+#ifndef SPGNN_TN_OLD
+#define SPGNN_TN_OLD 0
+#endif
+  if (g_gemm_variant == 1 || SPGNN_TN_OLD) {
+    hipLaunchKernelGGL(gemm::gemm_tn_f16x3, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), 0,
+                       (hipStream_t)stream, a);
+  } else {
+    const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm::gemm_tn_f16x3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr = true; }
+#ifndef SPGNN_TN_BY_XCD
+#define SPGNN_TN_BY_XCD 1
+#endif
+    if (SPGNN_TN_BY_XCD && splits % 8 == 0) {
+      a.by_xcd = 1;
+      hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)((int64_t)a.nbm * a.nbn * splits)), dim3(gemm::kThreads), lds_bytes,
+                         (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), lds_bytes,
+                         (hipStream_t)stream, a);
+    }
+  }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

@@ -27,4 +27,4 @@ for (M, N) in [(1024, 1064), (512, 768), (1024, 384), (256, 384), (512, 256)]:
     ks = list(libs)
     fl = 2.0 * R * M * N
     print(f"M={M} N={N}: " + " | ".join(f"{k[2:-3]} {sorted(v)[2]*1e3:.0f}us ({fl/sorted(v)[2]/1e9:.0f} TF)" for k, v in res.items()),
-          "equal", all(torch.equal(outs[ks[0]], outs[k]) for k in ks), flush=True)
+          "maxrel", max(float((outs[ks[0]] - outs[k]).abs().max() / outs[ks[0]].abs().max()) for k in ks), flush=True)
