@@ -194,6 +194,9 @@ __device__ __forceinline__ float elu_fwd(float x) {
   return x > 0.f ? x : (x > -0.5f ? p : e);
 }
 
+#ifndef SPGNN_MFMA_ORDER
+#define SPGNN_MFMA_ORDER 1
+#endif
 #ifndef SPGNN_GEMM_ABLATE
 #define SPGNN_GEMM_ABLATE 0      // timing-only builds: 1 = no split arithmetic, 2 = no MFMA, 3 = no global loads in the loop, 4 = no LDS stores
 #endif
@@ -419,23 +422,24 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
         bh[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + off);                                       \
         bl[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + B_IMG + off);                               \
       }                                                                                                      \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
-          if (SPGNN_GEMM_ABLATE != 2) {                                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);              \
-          } else { acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1]; }    \
-          if (has_next) { /* a slice of next stage's conversion after each accumulator group */             \
-            const int slot = (ks * 4 + i * 2 + j);                                                           \
-            _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                  \
-              if (q * 8 / NLA == slot || (NLA > 8 && q % 8 == slot))                                         \
-                AIO::store_one(nbuf, nbuf + A_IMG, RA[q], q, sA);                                            \
-            _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                  \
-              if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                         \
-                BIO::store_one(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                    \
-          }                                                                                                  \
+      /* product-major order: the four accumulators take turns, so no MFMA waits on the one issued just */  \
+      /* before it (SPGNN_MFMA_ORDER 0 = accumulator-major, three dependent MFMAs in a row: A/B only)      */  \
+      _Pragma("unroll") for (int c = 0; c < 12; ++c) {                                                       \
+        const int pr = SPGNN_MFMA_ORDER ? c >> 2 : c % 3, ij = SPGNN_MFMA_ORDER ? c & 3 : c / 3;             \
+        const int i = ij >> 1, j = ij & 1;                                                                   \
+        if (SPGNN_GEMM_ABLATE != 2) {                                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
+        } else if (pr == 0) { acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1]; } \
+        if (has_next && c % 3 == 2) { /* a slice of next stage's conversion after every third MFMA */        \
+          const int slot = ks * 4 + c / 3;                                                                   \
+          _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                    \
+            if (q * 8 / NLA == slot || (NLA > 8 && q % 8 == slot))                                           \
+              AIO::store_one(nbuf, nbuf + A_IMG, RA[q], q, sA);                                              \
+          _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                    \
+            if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                           \
+              BIO::store_one(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                      \
         }                                                                                                    \
+      }                                                                                                      \
     }                                                                                                        \
     if ((T_) + 3 < nk && SPGNN_GEMM_ABLATE != 3) {                                                            \
       AIO::load(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                            \
@@ -910,17 +914,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
         bh[j] = tr_frag(cb + 2 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
         bl[j] = tr_frag(cb + 3 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
       }                                                                                                      \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);              \
-          if (has_next) {                                                                                    \
-            const int slot = ks * 4 + i * 2 + j;                        /* 8 slots, 8 float4 to convert */   \
-            if (slot < 4) store_one_t(nbuf, nbuf + TTILE, RA[slot], slot, sA);                               \
-            else store_one_t(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4, sB);                \
-          }                                                                                                  \
+      _Pragma("unroll") for (int c = 0; c < 12; ++c) {                   /* product-major, as the NT kernel */ \
+        const int pr = SPGNN_MFMA_ORDER ? c >> 2 : c % 3, ij = SPGNN_MFMA_ORDER ? c & 3 : c / 3;             \
+        const int i = ij >> 1, j = ij & 1;                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
+        if (has_next && c % 3 == 2) {                                                                        \
+          const int slot = ks * 4 + c / 3;                              /* 8 slots, 8 float4 to convert */   \
+          if (slot < 4) store_one_t(nbuf, nbuf + TTILE, RA[slot], slot, sA);                                 \
+          else store_one_t(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4, sB);                  \
         }                                                                                                    \
+      }                                                                                                      \
     }                                                                                                        \
     if ((T_) + 3 < nk) SPGNN_TN_LOAD((T_) + 3, RA, RB)                                                       \
     __syncthreads();                                                                                         \
