@@ -1477,20 +1477,28 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
   const int kfull = K & ~15;
-  for (int k0 = 0; k0 < kfull + 16; k0 += 16) {
-    float4 xa;
-    if (k0 < kfull) {
-      xa = rv ? ld4(xp + k0) : z4;
-    } else {                          // ragged tail: element-wise guards on X (W is zero padded)
-      if (kfull >= K) break;
-      const int k = k0 + 4 * q;
-      xa = z4;
-      if (rv) {
-        if (k + 0 < K) xa.x = xp[k0 + 0];
-        if (k + 1 < K) xa.y = xp[k0 + 1];
-        if (k + 2 < K) xa.z = xp[k0 + 2];
-        if (k + 3 < K) xa.w = xp[k0 + 3];
-      }
+  // main loop: straight-line body (one X load, NG W loads, 4 NG MFMAs), unrolled so that several row loads are in flight
+#pragma unroll 4
+  for (int k0 = 0; k0 < kfull; k0 += 16) {
+    const float4 xa = rv ? ld4(xp + k0) : z4;
+    amx = absmax4(amx, xa);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 wb = wv[g] ? ld4(wp[g] + k0) : z4;
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
+    }
+  }
+  if (kfull < K) {                      // ragged tail: element-wise guards on X (W is zero padded)
+    const int k0 = kfull, k = k0 + 4 * q;
+    float4 xa = z4;
+    if (rv) {
+      if (k + 0 < K) xa.x = xp[k0 + 0];
+      if (k + 1 < K) xa.y = xp[k0 + 1];
+      if (k + 2 < K) xa.z = xp[k0 + 2];
+      if (k + 3 < K) xa.w = xp[k0 + 3];
     }
     amx = absmax4(amx, xa);
 #pragma unroll
@@ -1519,13 +1527,14 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   }
 }
 
-// one wave per 256 columns x one row range; partial sums per range, reduced by the caller
+// one wave per 256 columns x one row range (four waves of a block side by side: a row is then read as one 4 KB
+// run instead of 1 KB pieces at different times - DRAM-friendlier); partial sums per range, reduced by the caller
 template <int J>
-__global__ __launch_bounds__(64) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
+__global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ part, int Kp, int64_t N, int K,
                                                           int64_t rows_per_split, int jn) {
-  const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // a block's waves sit side by side on one row: 4 KB contiguous per row
   if (k >= K) return;
   const bool full = k + 3 < K;
   const int64_t n0 = (int64_t)blockIdx.y * rows_per_split;
@@ -1534,15 +1543,20 @@ __global__ __launch_bounds__(64) void scores_bwd_w_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t n = n0;
-  if (full) {                          // 4 rows per trip: four independent 16-byte loads in flight per lane
+  if (full && n + 4 <= n1) {           // 4 rows per trip, the next trip's rows already in flight while this one is summed
+    const float* xr = X + n * ldx + k;
+    float4 x0 = ld4(xr), x1 = ld4(xr + ldx), x2 = ld4(xr + 2 * ldx), x3 = ld4(xr + 3 * ldx);
     for (; n + 4 <= n1; n += 4) {
-      const float* xr = X + n * ldx + k;
-      const float4 x0 = ld4(xr), x1 = ld4(xr + ldx), x2 = ld4(xr + 2 * ldx), x3 = ld4(xr + 3 * ldx);
+      const float4 c0 = x0, c1 = x1, c2 = x2, c3 = x3;
+      if (n + 8 <= n1) {
+        const float* xn = X + (n + 4) * ldx + k;
+        x0 = ld4(xn); x1 = ld4(xn + ldx); x2 = ld4(xn + 2 * ldx); x3 = ld4(xn + 3 * ldx);
+      }
       const float* g = gS + n * ldg;   // wave-uniform addresses: scalar loads
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         if (j < jn) {
-          fma4(acc[j], g[j], x0); fma4(acc[j], g[ldg + j], x1); fma4(acc[j], g[2 * ldg + j], x2); fma4(acc[j], g[3 * ldg + j], x3);
+          fma4(acc[j], g[j], c0); fma4(acc[j], g[ldg + j], c1); fma4(acc[j], g[2 * ldg + j], c2); fma4(acc[j], g[3 * ldg + j], c3);
         }
       }
     }
@@ -1567,7 +1581,7 @@ __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restric
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ gX, int64_t ldgx, int64_t N, int K,
                                                           int64_t rows_per_split, int jn, int accumulate) {
-  const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // a block's waves sit side by side on one row: 4 KB contiguous per row
   if (k >= K) return;
   const bool full = k + 3 < K;
   const int64_t n0 = (int64_t)blockIdx.y * rows_per_split;
@@ -2098,7 +2112,7 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
   if (x_stride < K || gs_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(part))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w: x rows must be 16-byte aligned (stride % 4 == 0)");
   const int64_t rps = (N + splits - 1) / splits;
-  const dim3 grid((unsigned)((K + 255) / 256), (unsigned)splits), block(64);
+  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define X(JP) hipLaunchKernelGGL(scores_bwd_w_kernel<JP>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps, J)
   switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
@@ -2107,6 +2121,9 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
   return check_launch("spgnn_scores_bwd_w");
 }
 
+#ifndef SPGNN_BWDX_WAVES
+#define SPGNN_BWDX_WAVES 8192
+#endif
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp, float* gx, int64_t gx_stride,
                        int32_t accumulate, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x: bad N/K/Kp/J");
@@ -2114,7 +2131,9 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
   if (!gs || !w || !gx) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_x: null pointer");
   if (gx_stride < K || gs_stride < J || (gx_stride & 3) || !aligned16(gx) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_x: gx rows must be 16-byte aligned (stride % 4 == 0)");
-  int64_t splits = 2048 / ((K + 255) / 256);
+  // every row waits for its own scalar score loads, so the latency is hidden by waves, not by unrolling (measured):
+  // ~8 waves per SIMD
+  int64_t splits = SPGNN_BWDX_WAVES / ((K + 255) / 256);
   if (splits < 1) splits = 1;
   if (splits > N) splits = N;
   const int64_t rps = (N + splits - 1) / splits;
