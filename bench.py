@@ -73,7 +73,10 @@ def algorithmic_bytes(key) -> float:
     if name == "act_bwd":            # read g_out [and out]; write g_pre
         _, N, H, D, act, mean = key
         return 4 * N * (D if mean else H * D) + 4 * N * H * D * (2 if act else 1)
-    if name in ("gemm_nt", "gemm_tn", "absmax"):
+    if name == "masked_ce":
+        _, N, C = key
+        return 4 * 2 * N * C + 4 * 4 * N
+    if name in ("gemm_nt", "gemm_tn", "absmax", "split_rows"):
         return 0.0                    # compute-bound / helper kernels: reported in "gemm", not in the HBM accounting
     if name == "spmm_sum":
         _, N, E, F = key

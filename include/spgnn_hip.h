@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 13
+#define SPGNN_ABI_VERSION 14
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -359,6 +359,17 @@ int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t col
 int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_indices, const int64_t* tree_ptr,
                                  const int32_t* anchors, int32_t num_anchors, float* pos_enc, int64_t pos_enc_stride,
                                  int32_t* diameters, int64_t num_trees, int64_t max_tree_nodes, spgnn_stream_t stream);
+
+/*
+ * Masked, class-weighted cross entropy of the training step in one pass (reference job_runner.py:1896-1900:
+ * `mask = rn < sampling_t`, `F.cross_entropy(pre[mask], y[mask], weight=w)`):
+ *   partials[2b], partials[2b+1] = per-256-node-block sums of  m_i w[y_i] nll_i  and  m_i w[y_i]   (b < ceil(N/256))
+ *   g_logits[i,c] (nullable)     = m_i w[y_i] (softmax(logits[i,:])_c - [c == y_i])   (gradient of the numerator)
+ * with m_i = draws[i] < sampling_p[i].  labels: int64.  The loss is sum(partials[0::2]) / sum(partials[1::2]).
+ */
+int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,
+                    const float* sampling_p, const float* class_weight, float* partials,
+                    float* g_logits, int64_t g_stride, int64_t N, int32_t C, spgnn_stream_t stream);
 
 /*
  * SGD with momentum over one flat fp32 parameter bucket (torch.optim.SGD semantics, dampening 0,

@@ -1672,6 +1672,50 @@ __global__ __launch_bounds__(256) void tree_distance_encoding(const int32_t* __r
 }
 
 // =================================================================================================
+// Masked, class-weighted cross entropy in one pass (reference job_runner.py:1896-1900:
+// mask = rn < sampling_t; loss = F.cross_entropy(pre[mask], y[mask], weight=w)).  One thread per node:
+//   m_i = draws[i] < sampling_p[i];  nll_i = logsumexp(logits[i,:]) - logits[i, y_i]
+//   partial[block] = (sum m_i w[y_i] nll_i, sum m_i w[y_i])          (numerator, denominator of the weighted mean)
+//   g_logits[i,c]  = m_i w[y_i] (softmax(logits[i,:])_c - [c == y_i])  (gradient of the NUMERATOR)
+// No boolean indexing (no host sync), no separate log-softmax / gather / multiply / reduce launches.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ draws, const float* __restrict__ sampling_p,
+                                                           const float* __restrict__ class_w, float* __restrict__ partial,
+                                                           float* __restrict__ g_logits, int64_t g_ld, int64_t N, int C) {
+  __shared__ float red[2][kBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  float num = 0.f, den = 0.f;
+  if (i < N) {
+    const float* row = logits + i * ld;
+    const int y = (int)labels[i];
+    const float m = draws[i] < sampling_p[i] ? 1.f : 0.f;
+    const float w = m * class_w[y];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+    const float lse = mx + logf(se);
+    num = w * (lse - row[y]);
+    den = w;
+    if (g_logits) {
+      float* g = g_logits + i * g_ld;
+      const float inv = 1.f / se;
+      for (int c = 0; c < C; ++c) g[c] = w * (expf(row[c] - mx) * inv - (c == y ? 1.f : 0.f));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { num += __shfl_xor(num, off, 64); den += __shfl_xor(den, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) { a += red[0][q]; b += red[1][q]; }
+    partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// =================================================================================================
 // SGD + momentum over a flat bucket
 // =================================================================================================
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
@@ -2159,6 +2203,18 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
   hipLaunchKernelGGL(tree_distance_encoding, dim3((unsigned)num_trees), dim3(256), 0, (hipStream_t)stream, out_indptr,
                      out_indices, tree_ptr, anchors, num_anchors, pos_enc, pos_enc_stride, diameters);
   return check_launch("spgnn_tree_distance_encoding");
+}
+
+int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,
+                    const float* sampling_p, const float* class_weight, float* partials, float* g_logits, int64_t g_stride,
+                    int64_t N, int32_t C, spgnn_stream_t stream) {
+  if (N < 0 || C <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_masked_ce: bad N/C");
+  if (N == 0) return SPGNN_OK;
+  if (!logits || !labels || !draws || !sampling_p || !class_weight || !partials) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
+  if (logits_stride < C || (g_logits && g_stride < C)) return fail(SPGNN_ERR_STRIDE, "spgnn_masked_ce: row stride smaller than row");
+  hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits,
+                     logits_stride, labels, draws, sampling_p, class_weight, partials, g_logits, g_stride, N, C);
+  return check_launch("spgnn_masked_ce");
 }
 
 int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale,

@@ -380,6 +380,41 @@ class _CatPad(torch.autograd.Function):
         return tuple(outs)
 
 
+class _MaskedCE(torch.autograd.Function):
+    """(logits, labels, draws, sampling_p, class_weight) -> [numerator, denominator] of the masked class-weighted
+    cross entropy (train.weighted_nll_sums) in one kernel that also leaves the numerator's gradient behind."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, draws, sampling_p, class_weight):
+        N, C = logits.shape
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        nb = (N + 255) // 256
+        part = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=logits.device)
+        g = torch.empty((N, C), dtype=torch.float32, device=logits.device) if ctx.needs_input_grad[0] else None
+        if N == 0:
+            part.zero_()
+        with torch.cuda.device(logits.device), _timed("masked_ce", (N, C)):
+            _capi.check(_capi.load().spgnn_masked_ce(logits.data_ptr(), logits.stride(0), labels.data_ptr(), draws.data_ptr(),
+                                                     sampling_p.data_ptr(), class_weight.data_ptr(), part.data_ptr(), _ptr(g),
+                                                     C, N, C, _stream(logits)), "spgnn_masked_ce")
+        ctx.save_for_backward(g)
+        return part.sum(0)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (g,) = ctx.saved_tensors
+        return (g * g_out[0] if g is not None else None), None, None, None, None
+
+
+def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: torch.Tensor, sampling_p: torch.Tensor,
+                   class_weight: torch.Tensor) -> torch.Tensor:
+    """-> tensor [sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]], m = draws < sampling_p (reference job_runner.py:1896-1900)."""
+    _require_cuda(logits, labels, draws, sampling_p, class_weight)
+    assert labels.dtype == torch.int64 and logits.dtype == torch.float32
+    return _MaskedCE.apply(logits, labels.contiguous(), draws.contiguous(), sampling_p.contiguous(), class_weight.contiguous())
+
+
 class _CatDropout(torch.autograd.Function):
     """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
     counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""

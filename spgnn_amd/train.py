@@ -143,9 +143,12 @@ class TrainStep:
                 draws = torch.rand(p.shape, device=p.device, generator=self.gen)
         if getattr(self, "_seed_ctr", None) is not None:
             self._seed_ctr.add_(1)
-        mask = mask_from_draws(draws, p)
         logits = self.model(g)[0]
-        num, den = weighted_nll_sums(logits, y, mask, self.class_weight)
+        if logits.is_cuda:               # one kernel: mask, log-softmax, weighted NLL sums and the gradient
+            nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight)
+            num, den = nd[0], nd[1]
+        else:
+            num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
         num.backward()
         b.gather_grads()
         b.wsum_slot.copy_(den.detach().reshape(1))
