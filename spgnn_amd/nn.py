@@ -213,17 +213,29 @@ class GraphConv(nn.Module):
             w_dst = d.pow(-0.5) if self._norm == "both" else 1.0 / d
         if self._in_feats > self._out_feats:       # mult W first to reduce the aggregated width
             if weight is not None:
-                feat = torch.matmul(feat, weight)
+                feat = ops.linear(feat, weight.t())
             rst = ops.spmm_sum(csc, feat, w_src, w_dst)
         else:
             rst = ops.spmm_sum(csc, feat, w_src, w_dst)
             if weight is not None:
-                rst = torch.matmul(rst, weight)
+                rst = ops.linear(rst, weight.t())
         if self.bias is not None:
             rst = rst + self.bias
         if self._activation is not None:
             rst = self._activation(rst)
         return rst
+
+
+def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``module(x)`` with every plain ``nn.Linear`` (also inside an ``nn.Sequential``, e.g. the reference's GIN MLP,
+    models.py:236-246) evaluated by ops.linear on the matrix-core GEMMs; any other module runs as it is."""
+    if type(module) is nn.Linear:
+        return ops.linear(x, module.weight, module.bias)
+    if type(module) is nn.Sequential:
+        for m in module:
+            x = _apply_fast_linear(m, x)
+        return x
+    return module(x)
 
 
 class GINConv(nn.Module):
@@ -252,7 +264,7 @@ class GINConv(nn.Module):
             w_dst = (1.0 / csc.in_degrees_f().clamp(min=1)) if self._aggregator_type == "mean" else None
             rst = ops.spmm_sum(csc, feat, None, w_dst, self.eps)     # (1+eps)*x fused into the SpMM
         if self.apply_func is not None:
-            rst = self.apply_func(rst)
+            rst = _apply_fast_linear(self.apply_func, rst)
         if self.activation is not None:
             rst = self.activation(rst)
         return rst
@@ -303,14 +315,14 @@ class SAGEConv(nn.Module):
         csc = graph.csc(feat.device)
         h = self.feat_drop(feat)
         if self._aggre_type == "pool":
-            neigh = ops.spmm_max(csc, F.relu(self.fc_pool(h)))
-            rst = self.fc_self(h) + self.fc_neigh(neigh)
+            neigh = ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU))
+            rst = ops.linear(h, self.fc_self.weight, self.fc_self.bias) + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
         elif self._aggre_type == "mean":
             neigh = ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1))
-            rst = self.fc_self(h) + self.fc_neigh(neigh)
+            rst = ops.linear(h, self.fc_self.weight, self.fc_self.bias) + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
         else:  # gcn: (sum_in x_u + x_v) / (deg + 1)
             neigh = (ops.spmm_sum(csc, h) + h) / (csc.in_degrees_f().unsqueeze(-1) + 1)
-            rst = self.fc_neigh(neigh)
+            rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
         if self.activation is not None:
             rst = self.activation(rst)
         if self.norm is not None:

@@ -415,6 +415,72 @@ def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: torch.Tens
     return _MaskedCE.apply(logits, labels.contiguous(), draws.contiguous(), sampling_p.contiguous(), class_weight.contiguous())
 
 
+class _LinearFn(torch.autograd.Function):
+    """act(x @ W^T + b) for tall x on the fp32-accurate matrix-core GEMMs (the nn.Linear / weight products inside
+    GraphConv, GINConv and SAGEConv; reference models.py:172-182, 236-246, 668-679): forward and input gradient on
+    spgnn_gemm_nt (bias + activation in its epilogue), weight gradient on spgnn_gemm_tn with the bias gradient as a
+    by-product of the operand stream."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _rowmajor(x)
+        if not _rows_aligned(x):
+            x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
+        w = weight if weight.stride(1) == 1 else weight.contiguous()      # e.g. GraphConv's (in, out) weight seen as W^T
+        if not _rows_aligned(w):
+            w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
+        sx, sw = pow2_scale(x), pow2_scale(w)
+        y = gemm_nt(x, w, sx, sw, bias=bias, act=act)
+        ctx.act, ctx.has_bias = act, bias is not None
+        ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, sx, sw, y = ctx.saved_tensors
+        N, K = x.shape
+        C = w.shape[0]
+        g = _rowmajor(g)
+        if ctx.act != ACT_NONE and C % 4 == 0:
+            g, amax = act_bwd(g, y, 1, C, ctx.act, False)
+            sg = scale_from_partials(amax)
+        else:
+            if ctx.act != ACT_NONE:
+                g = g * {ACT_ELU: torch.where(y > 0, torch.ones_like(y), y + 1), ACT_TANH: 1 - y * y,
+                         ACT_RELU: (y > 0).to(y.dtype)}[ctx.act]
+            if not _rows_aligned(g):
+                g = cat_padded((g,))
+            sg = pow2_scale(g)
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :K]
+            w_t = w.t().contiguous() if C % 4 == 0 else torch.nn.functional.pad(w.t(), (0, -C % 4)).contiguous()[:, :C]
+            gemm_nt(g, w_t, sg, sw, out=g_x)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.has_bias:
+                g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
+            else:
+                g_w = gemm_tn(g, x, sg, sx)
+        return g_x, g_w, g_b, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
+    """act(F.linear(x, weight, bias)).  Tall operands (>= 512 rows, both widths >= 32) on a ROCm device take the
+    matrix-core GEMM path; anything else goes to torch (tiny products are launch-bound either way)."""
+    N = x.shape[0] if x.dim() == 2 else 0
+    if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32 and weight.shape[1] >= 32
+            and x.dtype == torch.float32 and weight.dtype == torch.float32):
+        return _LinearFn.apply(x, weight, bias, act)
+    y = torch.nn.functional.linear(x, weight, bias)
+    if act == ACT_ELU:
+        y = torch.nn.functional.elu(y)
+    elif act == ACT_TANH:
+        y = torch.tanh(y)
+    elif act == ACT_RELU:
+        y = torch.relu(y)
+    return y
+
+
 class _CatDropout(torch.autograd.Function):
     """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
     counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""

@@ -108,3 +108,34 @@ def test_planes_gemm_is_bit_identical_to_the_fp32_operand_gemm(M, N, K):
     v[:, N:] = 0
     assert torch.equal(ops.gemm_nt_planes(pa, pb, upd_u=u, upd_v=v, bias=bias, act=ops.ACT_ELU),
                        ops.gemm_nt(a, b, sa, sb, upd_u=u, upd_v=v, bias=bias, act=ops.ACT_ELU))
+
+
+@pytest.mark.parametrize("N,K,C,act", [(5000, 1024, 256, ops.ACT_NONE), (1000, 100, 36, ops.ACT_RELU), (700, 64, 1024, ops.ACT_ELU),
+                                        (2048, 33, 50, ops.ACT_TANH), (600, 40, 34, ops.ACT_NONE)])
+def test_linear_on_matrix_cores_matches_torch(N, K, C, act):
+    """ops.linear (nn.Linear / weight products of GraphConv, GINConv, SAGEConv on the split-fp16 GEMMs) against
+    torch in fp64: output and all three gradients, with odd widths (row padding paths) and fused activations."""
+    import torch.nn.functional as F
+    torch.manual_seed(N + K + C)
+    x = torch.randn(N, K, device="cuda", requires_grad=True)
+    w = (torch.randn(C, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    b = torch.randn(C, device="cuda", requires_grad=True)
+    ops.KernelTimer.start()
+    y = ops.linear(x, w, b, act)
+    cot = torch.randn(N, C, device="cuda")
+    (y * cot).sum().backward()
+    used = {k[0] for k in ops.KernelTimer.stop()}
+    assert "gemm_nt" in used and "gemm_tn" in used
+    f = {ops.ACT_NONE: lambda t: t, ops.ACT_ELU: F.elu, ops.ACT_TANH: torch.tanh, ops.ACT_RELU: torch.relu}[act]
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = f(F.linear(xd, wd, bd))
+    (yd * cot.double()).sum().backward()
+    y32 = f(F.linear(x.detach(), w.detach(), b.detach()))
+    tol = max(3 * rel_err(y32, yd), 2e-6)
+    assert rel_err(y, yd) < tol
+    for got, want in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        assert rel_err(got, want) < 5e-6
+    wt = torch.randn(K, C, device="cuda", requires_grad=True)                       # GraphConv's (in, out) weight
+    y2 = ops.linear(x.detach(), wt.t())
+    y2.sum().backward()
+    assert rel_err(y2, x.detach().double() @ wt.detach().double()) < 2e-6 and wt.grad.shape == (K, C)

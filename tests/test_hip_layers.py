@@ -289,9 +289,10 @@ def test_spmm_max_ties_go_to_one_edge():
 
 
 @pytest.mark.parametrize("fi,fo", [(1024, 256), (64, 1024), (10, 10), (24, 7)])
-def test_graphconv_gin_sage_modules(fi, fo):
+@pytest.mark.parametrize("sizes", [[60, 150, 21], [150, 170, 130, 160, 140]])      # 231 nodes: torch products; 750: matrix-core ops.linear
+def test_graphconv_gin_sage_modules(fi, fo, sizes):
     torch.manual_seed(fi + fo)
-    g, src, dst, n = _graph([60, 150, 21], seed=fi)
+    g, src, dst, n = _graph(sizes, seed=fi)
     x = torch.randn(n, fi, device="cuda")
     gc = snn.GraphConv(fi, fo, activation=F.elu).cuda()
     with torch.no_grad():
@@ -305,6 +306,11 @@ def test_graphconv_gin_sage_modules(fi, fo):
     ref = O.gin_conv(src, dst, n, x.cpu(), gin.eps.detach().cpu(), mlp.cpu(), "mean")
     mlp.cuda()
     assert rel_err(gin(g, x), ref) < FWD_TOL
+    lin = torch.nn.Linear(fi, fo).cuda()                                    # bare nn.Linear: routed through ops.linear
+    gin2 = snn.GINConv(lin, "mean", learn_eps=True).cuda()
+    ref2 = O.gin_conv(src, dst, n, x.cpu(), gin2.eps.detach().cpu(), lin.cpu(), "mean")
+    lin.cuda()
+    assert rel_err(gin2(g, x), ref2) < FWD_TOL
     sg = snn.SAGEConv(fi, fo, "pool", activation=F.elu).cuda()
     sd = {k: v.cpu() for k, v in sg.state_dict().items()}
     ref = O.sage_conv_pool(src, dst, n, x.cpu(), sd["fc_pool.weight"], sd["fc_pool.bias"], sd["fc_self.weight"],
