@@ -141,8 +141,8 @@ def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=1, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--config", default="st_pgat_spgnn_3")
     ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
