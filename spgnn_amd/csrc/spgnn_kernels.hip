@@ -227,11 +227,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
   const int lane = threadIdx.x % T;
   const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
   if (v >= a.N) return;
-#ifdef SPGNN_DIAG
-  const int beg = uni<WAVE>(a.indptr[v]), end = (SPGNN_DIAG & 4) ? beg + 1 : uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
-#else
   const int beg = uni<WAVE>(a.indptr[v]), end = uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
-#endif
 
   int hs[NS]; bool wr[NS]; float erv[NS];
 #pragma unroll
@@ -239,21 +235,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
     const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
     hs[s] = (CH == 0) ? c0 / a.D : s;
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
-#ifdef SPGNN_DIAG
-    if (SPGNN_DIAG & 8) wr[s] = false;
-#endif
-    erv[s] = a.er[v * a.s_ld + hs[s]];
-  }
-  // The accumulator starts from the residual row (+ bias): those loads depend on nothing, so they are in flight
-  // while the index -> score -> neighbour-row chain resolves (as an epilogue they cost a serial HBM round trip).
-  float4 acc[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef SPGNN_DIAG
-  if (a.res && !(SPGNN_DIAG & 2)) {
-#else
   if (a.res) {
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = ld4(a.res + v * a.res_ld + (r * T + lane) * 4);
   }
@@ -352,11 +334,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
   }
 
   act_fwd_rows<R>(acc, a.act);
-#ifdef SPGNN_DIAG
-  if (a.out && !(SPGNN_DIAG & 1)) {
-#else
   if (a.out) {
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) st4(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]);
   }
