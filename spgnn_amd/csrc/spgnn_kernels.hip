@@ -235,6 +235,13 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
     const int c0 = ((CH == 0 ? s : s * CH) * T + lane) * 4;
     hs[s] = (CH == 0) ? c0 / a.D : s;
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
+    erv[s] = a.er[v * a.s_ld + hs[s]];
+  }
+  // The accumulator starts from the residual row (+ bias): those loads depend on nothing, so they are in flight
+  // while the index -> score -> neighbour-row chain resolves (as an epilogue they cost a serial HBM round trip).
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.res) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = ld4(a.res + v * a.res_ld + (r * T + lane) * 4);
