@@ -1283,22 +1283,51 @@ struct SpmmSum {
   int64_t N; int F; int T;
 };
 
-template <int R>
+// TT = 64: one node per wave with wave-uniform index / weight values in SGPRs; TT = 0: run-time team width
+// (see gat_fwd_vec).  Nodes with 1..8 in-edges load all indices and source weights unconditionally and fetch
+// the neighbour rows in batches; larger degrees loop.
+template <int TT, int R>
 __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
-  const int T = a.T;
-  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  constexpr bool WAVE = TT == 64;
+  const int T = WAVE ? 64 : a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
   if (v >= a.N) return;
   const int lane = threadIdx.x % T;
-  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int beg = uni<WAVE>(a.indptr[v]), end = uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = beg; j < end; ++j) {
-    const int64_t u = a.indices[j];
-    const float w = a.w_src ? a.w_src[u] : 1.f;
-    const float* row = a.x + u * a.x_ld;
+  if (deg > 0 && deg <= kMaxFast) {
+    int u[kMaxFast]; float w[kMaxFast];
 #pragma unroll
-    for (int r = 0; r < R; ++r) fma4(acc[r], w, ld4(row + (r * T + lane) * 4));
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) {
+      const float ws = a.w_src ? a.w_src[u[k]] : 1.f;
+      w[k] = uni<WAVE>(k < deg ? ws : 0.f);
+    }
+    constexpr int kGather = R >= 8 ? 1 : R == 4 ? 2 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      float4 x[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + (r * T + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], w[k0 + q], x[q][r]);
+    }
+  } else {
+    for (int j = beg; j < end; ++j) {
+      const int64_t u = a.indices[j];
+      const float w = a.w_src ? a.w_src[u] : 1.f;
+      const float* row = a.x + u * a.x_ld;
+#pragma unroll
+      for (int r = 0; r < R; ++r) fma4(acc[r], w, ld4(row + (r * T + lane) * 4));
+    }
   }
   const float wd = a.w_dst ? a.w_dst[v] : 1.f;
   const float sc = a.self_eps ? 1.f + a.self_eps[0] : 0.f;
@@ -1333,25 +1362,55 @@ struct SpmmMaxFwd {
   int64_t N; int F; int T;
 };
 
-template <int R>
+template <int TT, int R>
 __global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec(SpmmMaxFwd a) {
-  const int T = a.T;
-  const int64_t v = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  constexpr bool WAVE = TT == 64;
+  const int T = WAVE ? 64 : a.T;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
   if (v >= a.N) return;
   const int lane = threadIdx.x % T;
-  const int beg = a.indptr[v], end = a.indptr[v + 1];
+  const int beg = uni<WAVE>(a.indptr[v]), end = uni<WAVE>(a.indptr[v + 1]), deg = end - beg;
   float4 best[R]; int4 arg[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { best[r] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); arg[r] = make_int4(-1, -1, -1, -1); }
-  for (int j = beg; j < end; ++j) {
-    const float* row = a.x + (int64_t)a.indices[j] * a.x_ld;
+  if (deg > 0 && deg <= kMaxFast) {
+    int u[kMaxFast];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float4 q = ld4(row + (r * T + lane) * 4);
-      if (q.x > best[r].x) { best[r].x = q.x; arg[r].x = j; }
-      if (q.y > best[r].y) { best[r].y = q.y; arg[r].y = j; }
-      if (q.z > best[r].z) { best[r].z = q.z; arg[r].z = j; }
-      if (q.w > best[r].w) { best[r].w = q.w; arg[r].w = j; }
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    constexpr int kGather = R >= 8 ? 1 : R == 4 ? 2 : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      float4 x[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + (r * T + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < kGather; ++q) {
+        const bool live = k0 + q < deg;               // clamped slots repeat the last edge: they must not win a tie
+        const int j = beg + k0 + q;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float4 t = x[q][r];
+          if (live && t.x > best[r].x) { best[r].x = t.x; arg[r].x = j; }
+          if (live && t.y > best[r].y) { best[r].y = t.y; arg[r].y = j; }
+          if (live && t.z > best[r].z) { best[r].z = t.z; arg[r].z = j; }
+          if (live && t.w > best[r].w) { best[r].w = t.w; arg[r].w = j; }
+        }
+      }
+    }
+  } else {
+    for (int j = beg; j < end; ++j) {
+      const float* row = a.x + (int64_t)a.indices[j] * a.x_ld;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float4 q = ld4(row + (r * T + lane) * 4);
+        if (q.x > best[r].x) { best[r].x = q.x; arg[r].x = j; }
+        if (q.y > best[r].y) { best[r].y = q.y; arg[r].y = j; }
+        if (q.z > best[r].z) { best[r].z = q.z; arg[r].z = j; }
+        if (q.w > best[r].w) { best[r].w = q.w; arg[r].w = j; }
+      }
     }
   }
 #pragma unroll
@@ -1388,27 +1447,62 @@ struct SpmmMaxBwd {
   int64_t N; int F; int T;
 };
 
-template <int R>
+template <int TT, int R>
 __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
-  const int T = a.T;
-  const int64_t u = xcd_block() * (kBlock / T) + threadIdx.x / T;
+  constexpr bool WAVE = TT == 64;
+  const int T = WAVE ? 64 : a.T;
+  const int64_t u = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
   if (u >= a.N) return;
   const int lane = threadIdx.x % T;
+  const int beg = uni<WAVE>(a.out_indptr[u]), end = uni<WAVE>(a.out_indptr[u + 1]), deg = end - beg;
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = a.out_indptr[u]; k < a.out_indptr[u + 1]; ++k) {
-    const int64_t v = a.out_indices[k];
-    const int pos = a.out_pos[k];
+  if (deg > 0 && deg <= kMaxFast) {
+    int vv[kMaxFast], pp[kMaxFast];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int c = (r * T + lane) * 4;
-      const int4 ar = *reinterpret_cast<const int4*>(a.arg + v * a.arg_ld + c);
-      const float4 g = ld4(a.g_out + v * a.g_out_ld + c);
-      if (ar.x == pos) acc[r].x += g.x;
-      if (ar.y == pos) acc[r].y += g.y;
-      if (ar.z == pos) acc[r].z += g.z;
-      if (ar.w == pos) acc[r].w += g.w;
+    for (int k = 0; k < kMaxFast; ++k) {
+      vv[k] = uni<WAVE>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
+      pp[k] = uni<WAVE>(k < deg ? a.out_pos[beg + (k < deg ? k : deg - 1)] : -2);      // -2 never equals an arg
+    }
+    constexpr int kGather = R >= 4 ? 1 : 2;          // two row streams (arg, g_out) per edge
+#pragma unroll
+    for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
+      if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+      int4 ar[kGather][R]; float4 g[kGather][R];
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int c = (r * T + lane) * 4;
+          ar[q][r] = *reinterpret_cast<const int4*>(a.arg + (int64_t)vv[k0 + q] * a.arg_ld + c);
+          g[q][r] = ld4(a.g_out + (int64_t)vv[k0 + q] * a.g_out_ld + c);
+        }
+#pragma unroll
+      for (int q = 0; q < kGather; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int pos = pp[k0 + q];
+          if (ar[q][r].x == pos) acc[r].x += g[q][r].x;
+          if (ar[q][r].y == pos) acc[r].y += g[q][r].y;
+          if (ar[q][r].z == pos) acc[r].z += g[q][r].z;
+          if (ar[q][r].w == pos) acc[r].w += g[q][r].w;
+        }
+    }
+  } else {
+    for (int k = beg; k < end; ++k) {
+      const int64_t v = a.out_indices[k];
+      const int pos = a.out_pos[k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int c = (r * T + lane) * 4;
+        const int4 ar = *reinterpret_cast<const int4*>(a.arg + v * a.arg_ld + c);
+        const float4 g = ld4(a.g_out + v * a.g_out_ld + c);
+        if (ar.x == pos) acc[r].x += g.x;
+        if (ar.y == pos) acc[r].y += g.y;
+        if (ar.z == pos) acc[r].z += g.z;
+        if (ar.w == pos) acc[r].w += g.w;
+      }
     }
   }
 #pragma unroll
@@ -1717,12 +1811,14 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
-#define DISPATCH_R(R_, KERNEL, ...)                                                              \
-  switch (R_) {                                                                                  \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                   \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                   \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                   \
-    default: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                  \
+// T < 64 only occurs with R = 1 (pick_team tries 64 lanes first)
+#define DISPATCH_R(T_, R_, KERNEL, ...)                                                          \
+  if ((T_) != 64) { hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); }                           \
+  else switch (R_) {                                                                             \
+    case 1: hipLaunchKernelGGL((KERNEL<64, 1>), __VA_ARGS__); break;                             \
+    case 2: hipLaunchKernelGGL((KERNEL<64, 2>), __VA_ARGS__); break;                             \
+    case 4: hipLaunchKernelGGL((KERNEL<64, 4>), __VA_ARGS__); break;                             \
+    default: hipLaunchKernelGGL((KERNEL<64, 8>), __VA_ARGS__); break;                            \
   }
 
 inline unsigned scalar_grid(int64_t total) { return (unsigned)((total + kBlock - 1) / kBlock); }
@@ -2068,7 +2164,7 @@ int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x
   int T, R;
   if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride)) {
     a.T = T;
-    DISPATCH_R(R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+    DISPATCH_R(T, R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {
     hipLaunchKernelGGL(spmm_sum_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
   }
@@ -2087,7 +2183,7 @@ int spgnn_spmm_max_fwd(const int32_t* indptr, const int32_t* indices, const floa
   int T, R;
   if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && vec_ok(arg, arg_stride)) {
     a.T = T;
-    DISPATCH_R(R, spmm_max_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+    DISPATCH_R(T, R, spmm_max_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {
     hipLaunchKernelGGL(spmm_max_fwd_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
   }
@@ -2108,7 +2204,7 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   int T, R;
   if (pick_team(F, T, R) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
     a.T = T;
-    DISPATCH_R(R, spmm_max_bwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+    DISPATCH_R(T, R, spmm_max_bwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {
     hipLaunchKernelGGL(spmm_max_bwd_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
   }
