@@ -41,9 +41,17 @@ constexpr int kBlock = 256;
 
 // ---- team geometry -----------------------------------------------------------------------------
 // H*D floats per node = 4 * T * R.  T = lanes per node, R = float4 chunks per lane.
-bool pick_team(int64_t width, int& T, int& R) {
+// `narrow`: rows of <= 64 float4 go to 16-lane teams (four nodes per wave, R = q/16 chunks per lane).  Such rows make
+// the kernels latency-bound - a wave walks one dependent index -> score -> row chain per node - and four chains per
+// wave hide more of it than the SGPR savings of a whole-wave team are worth: measured for single-head layers
+// (1x256: fwd 51 -> 42, bwd 68 -> 59 / 35 -> 27 us; 1x128: 33 -> 25, 39 -> 30, 20 -> 17 us), not for two-head ones.
+bool pick_team(int64_t width, int& T, int& R, bool narrow = false) {
   if (width <= 0 || (width & 3)) return false;
   int64_t q = width >> 2;
+  if (narrow && q <= 64 && q % 16 == 0) {
+    const int64_t r = q / 16;
+    if (r == 1 || r == 2 || r == 4) { T = 16; R = (int)r; return true; }
+  }
   const int ts[3] = {64, 32, 16};
   for (int t : ts) {
     if (q % t) continue;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
 
 // teams narrower than a wave exist only for R = 1 (pick_team tries 64 lanes first): keep the other instances out
 template <int R, int CH, bool MEAN> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatFwd& a) {
-  if constexpr (R == 1) hipLaunchKernelGGL((gat_fwd_vec<0, R, CH, MEAN>), grid, block, 0, st, a);
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_fwd_vec<0, R, CH, MEAN>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, column); any H, D, stride, alignment
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
 }
 
 template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdDst& a) {
-  if constexpr (R == 1) hipLaunchKernelGGL((gat_bwd_dst_vec<0, R, CH>), grid, block, 0, st, a);
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_dst_vec<0, R, CH>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, head)
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
 }
 
 template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdSrc& a) {
-  if constexpr (R == 1) hipLaunchKernelGGL((gat_bwd_src_vec<0, R, CH>), grid, block, 0, st, a);
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_src_vec<0, R, CH>), grid, block, 0, st, a);
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -1837,9 +1845,12 @@ const char* spgnn_last_error(void) { return g_err; }
 // (0 = heads narrower than the team, reduction width W).  false -> scalar fallback.
 // One node per team.  Measured (tools/npt_sweep.py, MI355X): looping a team over 2/4/8/16 consecutive nodes was
 // 2/8/24/50 % slower - many short-lived workgroups hide the dependent index -> score -> row chain better.
+#ifndef SPGNN_NARROW_TEAMS
+#define SPGNN_NARROW_TEAMS 1
+#endif
 static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
   if (D % 4) return false;
-  if (!pick_team((int64_t)H * D, T, R)) return false;
+  if (!pick_team((int64_t)H * D, T, R, SPGNN_NARROW_TEAMS && H == 1)) return false;
   const int team_floats = 4 * T;
   W = T;
   if (D % team_floats == 0) {
