@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 14
+#define SPGNN_ABI_VERSION 15
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -336,12 +336,15 @@ int spgnn_gemm_set_variant(int32_t variant);
  * operands (A = g_Y, B = X; replaces the SGEMM-TN behind nn.Linear's weight gradient).  The row range is
  * cut into `splits` chunks, chunk s writing its partial product to C + s*split_stride (each M x ldc);
  * the caller sums the partials (splits == 1: C is the result).  Same split-fp16 arithmetic as spgnn_gemm_nt.
- * colsum_a (nullable): (splits, M) per-split column sums of A in plain fp32, taken from the operand stream the
- * kernel reads anyway — with A = [g_ft | g_pre] its right half summed over splits is the bias gradient.
+ * colsum_a (nullable): per-split column sums of A in plain fp32, taken from the operand stream the kernel reads
+ * anyway — with A = [g_ft | g_pre] its right half summed over splits is the bias gradient.  Element (split, m) goes
+ * to colsum_a[split * colsum_split_stride + m * colsum_stride], so the sums can live in a spare column of the
+ * partial-product buffer and fall out of the same reduction over splits.
  */
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t split_stride, int32_t splits, int64_t R, int64_t M, int64_t N,
-                  const float* scale_a, const float* scale_b, float* colsum_a, spgnn_stream_t stream);
+                  const float* scale_a, const float* scale_b,
+                  float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream);
 
 /* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */

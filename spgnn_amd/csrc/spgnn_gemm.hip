@@ -663,7 +663,8 @@ struct ArgsTN {
   int64_t rows_per_split;
   const float* sA; const float* sB;
   int nbm, nbn;
-  float* colsum;                                  // optional (splits, M): per-split column sums of A (bias gradient)
+  float* colsum;                                  // optional per-split column sums of A (bias gradient):
+  int64_t cs_stride, cs_split_stride;             //   element (split, m) at colsum[split * cs_split_stride + m * cs_stride]
   int by_xcd;                                     // pipelined kernel: 1-D grid, one split per XCD (splits % 8 == 0)
 };
 
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
       float t_ = 0.f;
 #pragma unroll
       for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
-      a.colsum[(int64_t)blockIdx.y * a.M + m0 + threadIdx.x] = t_;
+      a.colsum[(int64_t)blockIdx.y * a.cs_split_stride + (int64_t)(m0 + threadIdx.x) * a.cs_stride] = t_;
     }
   }
   const float alpha = 1.f / (sA * sB);
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
       float t_ = 0.f;
 #pragma unroll
       for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
-      a.colsum[(int64_t)split * a.M + m0 + threadIdx.x] = t_;
+      a.colsum[(int64_t)split * a.cs_split_stride + (int64_t)(m0 + threadIdx.x) * a.cs_stride] = t_;
     }
   }
   const float alpha = 1.f / (sA * sB);
@@ -1142,8 +1143,9 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                   int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
-                  float* colsum_a, spgnn_stream_t stream) {
+                  float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
   if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return SPGNN_ERR_STRIDE;
   if (!A || !B || !C) return SPGNN_ERR_NULLPTR;
   if (lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15) || (splits > 1 && split_stride < M * ldc))
@@ -1152,7 +1154,7 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
   gemm::ArgsTN a{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, 0};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, 0};
   int64_t tiles = (int64_t)a.nbm * a.nbn;
   tiles = (tiles + 7) & ~int64_t(7);
 #ifndef SPGNN_TN_OLD

@@ -953,14 +953,15 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(64, 512 // tiles, R // 256))
-    ldc = (N + 3) // 4 * 4
+    ldn = (N + 3) // 4 * 4
+    ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
-    cs = torch.empty((splits, M), dtype=torch.float32, device=a.device) if want_colsum else None
+    cs_ptr = part[0, 0, ldn:].data_ptr() if want_colsum else 0
     with torch.cuda.device(a.device), _timed("gemm_tn", (R, M, N)):
         _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
-                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), _ptr(cs),
+                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), cs_ptr, ldc, M * ldc,
                                                _stream(a)), "spgnn_gemm_tn")
     out = part[0] if splits == 1 else part.sum(0)
     if want_colsum:
-        return out[:, :N], (cs[0] if splits == 1 else cs.sum(0))
+        return out[:, :N], out[:, ldn]
     return out[:, :N]
