@@ -73,6 +73,9 @@ def algorithmic_bytes(key) -> float:
     if name == "act_bwd":            # read g_out [and out]; write g_pre
         _, N, H, D, act, mean = key
         return 4 * N * (D if mean else H * D) + 4 * N * H * D * (2 if act else 1)
+    if name == "scores_from_parts":      # read the (N, H*D/64, 2) partials, write (N, 2H)
+        _, N, H, D = key
+        return 4 * 2 * N * H * (D // 64) + 4 * 2 * N * H
     if name == "masked_ce":
         _, N, C = key
         return 4 * 2 * N * C + 4 * 4 * N

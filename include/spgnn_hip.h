@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 15
+#define SPGNN_ABI_VERSION 16
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -117,6 +117,9 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
  *
  *   g_ft[u,h,:] = sum_{v in out(u)} drop(a_uv) * g_pre[v,h,:]
  *   g_el[u,h]   = sum_{v in out(u)} g_e_uv
+ * With score_l / score_r set (el = (ft * attn_l).sum(-1) taken from ft itself, DGL's own formulation, see
+ * spgnn_gemm_nt's score partials) the scores' gradient returns to ft here:
+ *   g_ft[u,h,:] += g_el[u,h] * attn_l[h,:] + g_er[u,h] * attn_r[h,:]
  */
 int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
                       const float* attn, const float* g_e,
@@ -124,6 +127,8 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       float* g_ft, int64_t g_ft_stride,
                       float* g_el, int64_t g_s_stride,
                       float* absmax /* nullable: absmax[u] = max|g_ft[u,:]| */,
+                      const float* score_l, const float* score_r /* nullable: attn_l, attn_r flat (H*D) */,
+                      const float* g_er /* with score_l: (N, H) at stride g_s_stride, from spgnn_gat_bwd_dst */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       spgnn_stream_t stream);
@@ -201,7 +206,15 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
  */
 int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t N, int32_t width,
                       int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
-                      int32_t backward, spgnn_stream_t stream);
+                      int32_t backward,
+                      float* absmax_partials /* nullable: spgnn_cat_dropout_blocks(N, width) maxima of |dst| (GEMM operand scale) */,
+                      spgnn_stream_t stream);
+int64_t spgnn_cat_dropout_blocks(int64_t N, int32_t width);
+
+/* el / er from spgnn_gemm_nt's score partials: s[v,h] = sum_b parts[v, h*D/64 + b, 0], s[v,H+h] = sum_b parts[v, h*D/64 + b, 1]
+ * (parts: (N, H*D/64, 2); D % 64 == 0).  Replaces DGL GATConv's (ft * attn).sum(-1) pair. */
+int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int64_t N, int32_t H, int32_t D,
+                            spgnn_stream_t stream);
 
 /*
  * Folding of GATConv's score vectors through fc (what makes el/er a projection of the layer INPUT; reference
@@ -296,11 +309,18 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
  * the score term of the input gradient, g_X = g_Y * W + g_S * W_lr, instead of a second pass over g_X.
  * Optional epilogue C = act(C + bias[col]) (bias nullable, N floats; activation = SPGNN_ACT_*): GATConv's bias and
  * activation when the projection FOLLOWS the aggregation (spgnn_gat_agg_fwd).
+ * Optional score partials (score_out nullable): GATConv's el = (ft * attn_l).sum(-1), er likewise, taken from the
+ * product while it is still in registers.  For each row and each 64-column block b of the first score_cols output
+ * columns (= H*D, a multiple of 64; D % 64 == 0 so that no block straddles two heads)
+ *   score_out[(row * (score_cols/64) + b) * 2 + 0] = <C[row, 64b:64b+64], score_l[64b:64b+64]>     (score_l = attn_l flat)
+ *   score_out[(row * (score_cols/64) + b) * 2 + 1] = <C[row, 64b:64b+64], score_r[64b:64b+64]>
+ * computed on the raw product (before rank-J / bias / activation); spgnn_scores_from_parts sums a head's blocks.
  */
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                   const float* bias, int32_t activation,
+                  const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                   spgnn_stream_t stream);
 
 /*

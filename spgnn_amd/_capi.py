@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -27,7 +27,7 @@ SIGNATURES = {
     "spgnn_gat_can_fuse_mean": [_i32, _i32],
     "spgnn_gat_bwd_dst": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _f32p, _i64,
                           _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
-    "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p,
+    "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _f32p, _f32p,
                           _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
@@ -37,7 +37,7 @@ SIGNATURES = {
     "spgnn_spmm_max_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _i32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
-                      _f32p, _i32, _vp],
+                      _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
     "spgnn_gat_agg_supported": [_i32, _i32],
     "spgnn_gat_agg_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _f32p, _i64, _i64,
                           _i32, _i32, _f32, _f32, _u64, _vp, _vp],
@@ -50,7 +50,9 @@ SIGNATURES = {
     "spgnn_split_rows": [_f32p, _i64, _i64, _i64, _f32p, _f32, _vp, _vp, _i64, _i64, _i64, _vp],
     "spgnn_gemm_nt_planes": [_vp, _vp, _i64, _vp, _vp, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p,
                              _i64, _i32, _f32p, _i32, _vp],
-    "spgnn_cat_dropout": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _vp],
+    "spgnn_cat_dropout": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _f32p, _vp],
+    "spgnn_cat_dropout_blocks": [_i64, _i32],
+    "spgnn_scores_from_parts": [_f32p, _f32p, _i64, _i64, _i32, _i32, _vp],
     "spgnn_masked_ce": [_f32p, _i64, _vp, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i32, _vp],
     "spgnn_head_mean": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _vp],
     "spgnn_act_bwd": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
@@ -85,7 +87,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name == "spgnn_cat_dropout_blocks" else C.c_int
     ver = lib.spgnn_abi_version()
     if ver != ABI_VERSION:
         raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")

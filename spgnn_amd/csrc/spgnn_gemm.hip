@@ -45,6 +45,10 @@ struct Args {
   // gradient term g_S * W_lr of the input gradient, which otherwise costs a read-modify-write pass over C)
   const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
   const float* bias; int act;                   // optional epilogue C = act(C + bias[col]) (pipelined kernel only)
+  // optional score partials (GATConv's el / er straight from the projection): for every row and every 64-column
+  // block b of the first sc_cols output columns, sc_out[(row * (sc_cols/64) + b) * 2 + {0,1}] =
+  // <C[row, 64b : 64b+64], sc_l / sc_r[64b : 64b+64]>  (raw product, before rank-J / bias / activation)
+  const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
 };
 
 __device__ __forceinline__ void split4(float4 v, float s, half4& hi, half4& lo) {
@@ -272,6 +276,24 @@ struct TileIO {
 // own LDS slab (pitch 68 floats) and writes it out as whole 256-byte row segments with 16-byte stores.
 // (All waves passed the last barrier of the K loop, so the stage buffers are free; slabs are wave-private.)
 // Optional terms, in this order: exact fp32 rank-J update, bias, activation.
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), then the two mirrors.
+// The empty asm statements keep hipcc from pairing two such chains into v_pk_add_f32 / v_pk_fma_f32: a DPP (or
+// ds_bpermute) read of a register written by a PACKED fp32 op got only the two wait states of a single-pass op and
+// lanes 48-63 - written in the op's last pass - were read early: a few wrong sums per million, different every run
+// (ROCm 7.2, gfx950; seen with the 256-thread kernel).
+__device__ __forceinline__ float row16_sum(float x) {
+  asm volatile("" : "+v"(x));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  asm volatile("" : "+v"(x));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  asm volatile("" : "+v"(x));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  asm volatile("" : "+v"(x));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 template <class ARGS>
 __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&acc)[2][2], _Float16* smem, int row0, int col0,
                                                        int wave, int lane, int wm, int wn, float alpha) {
@@ -289,6 +311,9 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
     bq.x = col + 0 < a.N ? a.bias[col + 0] : 0.f; bq.y = col + 1 < a.N ? a.bias[col + 1] : 0.f;
     bq.z = col + 2 < a.N ? a.bias[col + 2] : 0.f; bq.w = col + 3 < a.N ? a.bias[col + 3] : 0.f;
   }
+  const bool use_sc = a.sc_out != nullptr && col < a.sc_cols;          // wave-uniform: a wave's 64 columns are one block
+  float4 sl = make_float4(0.f, 0.f, 0.f, 0.f), sr = sl;
+  if (use_sc) { sl = *reinterpret_cast<const float4*>(a.sc_l + col); sr = *reinterpret_cast<const float4*>(a.sc_r + col); }
   const bool use_j = a.J > 0 && col + 3 < a.ldv;          // exact fp32 rank-J term (V rows are zero padded)
   const bool small_j = a.J <= 4;
   float4 wv[4];
@@ -303,6 +328,9 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         slab[((e & 3) + 8 * (e >> 2) + 4 * fh) * EP + j * 32 + fr] = acc[i][j][e] * alpha;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slab is exchanged between the lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float uu[8][4];
     if (use_j && small_j) {
 #pragma unroll
@@ -353,6 +381,22 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
         }
       }
     }
+    if (use_sc) {                                     // 16 lanes hold one row's 64 columns: reduce across them
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 4 + r_in;
+        const int row = row0 + wm * 64 + i * 32 + lr;
+        const float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
+        float pl = v.x * sl.x + v.y * sl.y + v.z * sl.z + v.w * sl.w;
+        float pr = v.x * sr.x + v.y * sr.y + v.z * sr.z + v.w * sr.w;
+        pl = row16_sum(pl); pr = row16_sum(pr);
+        if ((lane & 15) == 0 && row < a.M)
+          *reinterpret_cast<float2*>(a.sc_out + ((int64_t)row * (a.sc_cols >> 6) + (col >> 6)) * 2) = make_float2(pl, pr);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // all reads of this half done before it is overwritten
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -486,6 +530,7 @@ struct ArgsP {
   int nbm, nbn;
   const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
   const float* bias; int act;
+  const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -1040,8 +1085,16 @@ int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >=
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
                   int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
-                  int32_t activation, spgnn_stream_t stream) {
+                  int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                  spgnn_stream_t stream) {
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (score_out) {
+    if (!score_l || !score_r) return SPGNN_ERR_NULLPTR;
+    if (score_cols <= 0 || (score_cols & 63) || score_cols > N || g_gemm_variant == 1 ||
+        (reinterpret_cast<uintptr_t>(score_l) & 15) || (reinterpret_cast<uintptr_t>(score_r) & 15) ||
+        (reinterpret_cast<uintptr_t>(score_out) & 7))
+      return SPGNN_ERR_SHAPE;
+  }
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return SPGNN_ERR_ENUM;
   if ((bias || activation != SPGNN_ACT_NONE) && g_gemm_variant == 1) return SPGNN_ERR_ENUM;   // pipelined kernel only
   if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
@@ -1059,7 +1112,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_variant == 1) {
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
@@ -1068,7 +1121,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                 (int)upd_j, bias, (int)activation};
+                 (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
@@ -1124,7 +1177,7 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
   gemm::ArgsP a{reinterpret_cast<const _Float16*>(A_hi), reinterpret_cast<const _Float16*>(A_lo), lda,
                 reinterpret_cast<const _Float16*>(B_hi), reinterpret_cast<const _Float16*>(B_lo), ldb, C, ldc, (int)M, (int)N,
                 (int)Kp, scale_a, scale_b, (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride,
-                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation};
+                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation, nullptr, nullptr, nullptr, 0};
   int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
   size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * 32 * sizeof(_Float16);
   const size_t epi = (size_t)(2 * WM) * 32 * 68 * sizeof(float);               // epilogue slabs share the buffer

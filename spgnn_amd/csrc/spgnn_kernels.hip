@@ -151,20 +151,32 @@ template <bool ON> __device__ __forceinline__ int uni(int x) { return ON ? __bui
 template <bool ON> __device__ __forceinline__ float uni(float x) {
   return ON ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : x;
 }
+// Cross-lane reductions.  `single_pass` re-writes the value with a plain v_mov first: hipcc pairs neighbouring fp32
+// chains into packed ops (v_pk_fma_f32 / v_pk_add_f32, two passes), and a ds_bpermute / DPP read of a register such an
+// op has just written was observed to see lanes 48-63 - written in the last pass - too early (a few wrong sums per
+// million, different every run; ROCm 7.2, gfx950; found in the GEMM's score-partial epilogue).  A VALU -> VALU
+// dependency is fully interlocked, so the one extra move makes the cross-lane read safe.
+__device__ __forceinline__ float single_pass(float x) {
+  asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+  return x;
+}
 template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
+  x = single_pass(x);
 #pragma unroll
-  for (int off = W >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  for (int off = W >> 1; off > 0; off >>= 1) x = single_pass(x + __shfl_xor(x, off, 64));
   return x;
 }
 __device__ __forceinline__ float team_max(float x, int width) {
-  for (int off = width >> 1; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  x = single_pass(x);
+  for (int off = width >> 1; off > 0; off >>= 1) x = single_pass(fmaxf(x, __shfl_xor(x, off, 64)));
   return x;
 }
 __device__ __forceinline__ float absmax4(float m, float4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 __device__ __forceinline__ float team_sum(float x, int width) {
-  for (int off = width >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  x = single_pass(x);
+  for (int off = width >> 1; off > 0; off >>= 1) x = single_pass(x + __shfl_xor(x, off, 64));
   return x;
 }
 
@@ -635,6 +647,8 @@ struct GatBwdSrc {
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;
+  // optional score term (el / er computed FROM ft, DGL's own form): g_ft[u,h,:] += g_el[u,h] * sc_l[h,:] + g_er[u,h] * sc_r[h,:]
+  const float* sc_l; const float* sc_r; const float* g_er;
 };
 
 template <int TT, int R, int CH>
@@ -709,10 +723,21 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
         const int64_t eidx = pos * a.H + hs[s];
         w[s] = a.attn[eidx];
         if (a.p > 0.f) w[s] *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
-        if (wr[s]) gel[s] += a.g_e[eidx];
+        gel[s] += a.g_e[eidx];
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
+    }
+  }
+  if (a.sc_l) {
+    float ger[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ger[s] = a.g_er[u * a.gs_ld + hs[s]];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int c = (r * T + lane) * 4;
+      fma4(acc[r], gel[SL::of(r)], ld4(a.sc_l + c));
+      fma4(acc[r], ger[SL::of(r)], ld4(a.sc_r + c));
     }
   }
 #pragma unroll
@@ -749,6 +774,7 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
     acc = fmaf(w, a.g_pre[v * a.g_pre_ld + col], acc);
     gel += a.g_e[eidx];
   }
+  if (a.sc_l) acc = fmaf(gel, a.sc_l[col], fmaf(a.g_er[u * a.gs_ld + h], a.sc_r[col], acc));
   a.g_ft[u * a.g_ft_ld + col] = acc;
   if (col % a.D == 0) a.g_el[u * a.gs_ld + h] = gel;
   if (a.absmax) atomicMax(reinterpret_cast<unsigned*>(a.absmax + u), __float_as_uint(fabsf(acc)));   // caller zeroes it
@@ -1227,7 +1253,10 @@ __global__ __launch_bounds__(kBlock) void fold_scores_bwd(const float* __restric
     dl = fma((double)gl, (double)w, dl); dr = fma((double)gr, (double)w, dr);
     g_W[(int64_t)row * ldg + k] = a_l * gl + a_r * gr;
   }
-  for (int off = 32; off > 0; off >>= 1) { dl += __shfl_xor(dl, off, 64); dr += __shfl_xor(dr, off, 64); }
+  for (int off = 32; off > 0; off >>= 1) {
+    asm volatile("s_nop 7" ::: "memory");         // multi-pass fp64 results settle before the cross-lane read (see single_pass)
+    dl += __shfl_xor(dl, off, 64); dr += __shfl_xor(dr, off, 64);
+  }
   if (lane == 0) { g_al[row] = (float)dl; g_ar[row] = (float)dr; }
 }
 
@@ -1251,10 +1280,11 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __restrict__ src, int64_t src_ld, float* __restrict__ dst,
                                                              int64_t dst_ld, int64_t N, int w, int off, int total, float p,
                                                              float inv_keep, uint64_t seed, const uint64_t* __restrict__ seed_off,
-                                                             int backward) {
+                                                             int backward, float* __restrict__ absmax) {
   if (seed_off) seed += seed_off[0];
   const int w4 = (w + 3) >> 2;
   const unsigned thr = (unsigned)(p * 65536.f);
+  float amx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * w4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / w4; const int c = (int)(i % w4) * 4;
     // forward: src is a source tensor (its own column 0 = output column off); backward: src is the gradient of the
@@ -1277,7 +1307,33 @@ __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (c + j < w) dp[j] = v[j];
     }
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));   // padded lanes hold 0
   }
+  if (absmax) {                                     // one partial maximum per block (the consumer GEMM's operand scale)
+    __shared__ float red[kBlock / 64];
+    amx = team_max(amx, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = red[0];
+#pragma unroll
+      for (int q = 1; q < kBlock / 64; ++q) m = fmaxf(m, red[q]);
+      absmax[blockIdx.x] = m;
+    }
+  }
+}
+
+// el / er from the projection GEMM's score partials: s[v, h] = sum of head h's 64-column blocks of parts[v, :, 0],
+// s[v, H + h] likewise of parts[v, :, 1]  (parts: (N, H*D/64, 2))
+__global__ __launch_bounds__(kBlock) void scores_from_parts_kernel(const float* __restrict__ parts, float* __restrict__ s, int64_t s_ld,
+                                                                   int64_t N, int H, int bph) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t v = i / H; const int h = (int)(i % H);
+  const float2* p = reinterpret_cast<const float2*>(parts) + (v * H + h) * bph;
+  float l = 0.f, r = 0.f;
+  for (int b = 0; b < bph; ++b) { const float2 q = p[b]; l += q.x; r += q.y; }
+  s[v * s_ld + h] = l; s[v * s_ld + H + h] = r;
 }
 
 // =================================================================================================
@@ -1791,7 +1847,7 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
       for (int c = 0; c < C; ++c) g[c] = w * (expf(row[c] - mx) * inv - (c == y ? 1.f : 0.f));
     }
   }
-  for (int off = 32; off > 0; off >>= 1) { num += __shfl_xor(num, off, 64); den += __shfl_xor(den, off, 64); }
+  num = team_sum(num, 64); den = team_sum(den, 64);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1966,8 +2022,10 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
 
 int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
                       const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
-                      float* g_el, int64_t g_s_stride, float* absmax, int64_t N, int64_t E, int32_t H, int32_t D,
+                      float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
+                      const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (score_l && (!score_r || !g_er)) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_src: score_l needs score_r and g_er");
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (!out_indptr || !attn || !g_e || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos)))
@@ -1978,9 +2036,10 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, score_l, score_r, g_er};
   int T = 0, R = 0, CH = 0, W = 0;
-  if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride)) {
+  if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride) && vec_ok(score_l, 0) &&
+      vec_ok(score_r, 0)) {
     a.T = T;
     const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
 #define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_src_vec<64, R_, CH_>), grid, block, 0, st, a); \
@@ -2142,9 +2201,14 @@ int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l,
   return check_launch("spgnn_fold_scores_bwd");
 }
 
+int64_t spgnn_cat_dropout_blocks(int64_t N, int32_t width) {
+  int64_t blocks = (N * ((width + 3) / 4) + kBlock - 1) / kBlock;
+  return blocks > 32768 ? 32768 : (blocks < 1 ? 1 : blocks);
+}
+
 int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t N, int32_t width,
                       int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
-                      int32_t backward, spgnn_stream_t stream) {
+                      int32_t backward, float* absmax_partials, spgnn_stream_t stream) {
   if (N < 0 || width <= 0 || col_offset < 0 || total_width < col_offset + width) return fail(SPGNN_ERR_SHAPE, "spgnn_cat_dropout: bad N/width/offset");
   if (N == 0) return SPGNN_OK;
   if (!src || !dst) return fail(SPGNN_ERR_NULLPTR, "spgnn_cat_dropout: null pointer");
@@ -2156,11 +2220,22 @@ int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t 
   const bool vec = (width & 3) == 0 && (col_offset & 3) == 0 && vec_ok(src, src_stride) && vec_ok(dst, dst_stride);
   if (vec)
     hipLaunchKernelGGL(cat_dropout_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
-                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0);
+                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0, absmax_partials);
   else
     hipLaunchKernelGGL(cat_dropout_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
-                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0);
+                       dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0, absmax_partials);
   return check_launch("spgnn_cat_dropout");
+}
+
+int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int64_t N, int32_t H, int32_t D,
+                            spgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || D <= 0 || (D & 63)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_from_parts: D must be a multiple of 64");
+  if (N == 0) return SPGNN_OK;
+  if (!parts || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_from_parts: null pointer");
+  if (s_stride < 2 * H) return fail(SPGNN_ERR_STRIDE, "spgnn_scores_from_parts: row stride smaller than row");
+  hipLaunchKernelGGL(scores_from_parts_kernel, dim3((unsigned)((N * H + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, parts, s, s_stride, N, H, D / 64);
+  return check_launch("spgnn_scores_from_parts");
 }
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,

@@ -58,6 +58,7 @@ def _draw_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+SCORES_FROM_FT = os.environ.get("SPGNN_SCORES_FROM_FT", "1") != "0"  # A/B switch: el/er from ft in the GEMM epilogue vs folded weights
 FOLD_KERNEL = os.environ.get("SPGNN_FOLD", "1") != "0"             # A/B switch: score folding by spgnn_fold_scores_* vs einsum
 AGGREGATE_FIRST = os.environ.get("SPGNN_AGG_FIRST", "1") != "0"    # A/B switch for the aggregate-first layer form
 
@@ -132,17 +133,25 @@ class GATConv(nn.Module):
         if w_cat.shape[1] % 4:                          # 16-byte rows for the matrix-core GEMM (e.g. 1063 -> 1064)
             w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
+        p = float(self.attn_drop.p) if self.training else 0.0
+        seed = _draw_seed() if p > 0.0 else 0
+        fuse_mean = mean_heads and fuse_epilogue
+        agg_first = (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
+                     and ops.agg_first_supported(H, h.shape[1]))
+        if SCORES_FROM_FT and not agg_first and ops.scores_from_ft_supported(h, w_cat, D):
+            # el / er from ft in the projection GEMM's epilogue (DGL's own formulation): ops._GATLayerScoresFromFtFn
+            out, attn = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l[0], self.attn_r[0],
+                                                     self.bias if fuse_epilogue else None, H, D, has_res,
+                                                     float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p,
+                                                     seed, mean=fuse_mean)
+            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
         if FOLD_KERNEL:
             w_lr = ops.fold_scores(w_fc, self.attn_l[0], self.attn_r[0])
         else:
             w3 = w_fc.view(H, D, -1)
             w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),
                               torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
-        p = float(self.attn_drop.p) if self.training else 0.0
-        seed = _draw_seed() if p > 0.0 else 0
-        fuse_mean = mean_heads and fuse_epilogue
-        if (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
-                and ops.agg_first_supported(H, h.shape[1])):
+        if agg_first:
             # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)
             out, attn = ops.gat_layer_agg_first(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D,
                                                 float(self.negative_slope), act, p, seed, mean=fuse_mean)
@@ -150,6 +159,9 @@ class GATConv(nn.Module):
             out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
                                       float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed,
                                       mean=fuse_mean)
+        return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
+
+    def _finish(self, out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention):
         rst = out if fuse_mean else out.view(-1, H, D)
         if not fuse_epilogue:
             if identity_res:

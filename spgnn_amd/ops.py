@@ -138,7 +138,8 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
 
 def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, slope: float, act: int,
                 p_drop: float, seed: int, g_pre: torch.Tensor, g_ft: torch.Tensor, g_el: torch.Tensor,
-                g_er: torch.Tensor, mean: bool = False, absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
+                g_er: torch.Tensor, mean: bool = False, absmax: Optional[torch.Tensor] = None,
+                score_l: Optional[torch.Tensor] = None, score_r: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Runs both backward halves. g_pre/g_ft (N,H*D), g_el/g_er (N,H) are written in place
     (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.  ``absmax`` (2N floats):
     per-node maxima of |g_pre| then |g_ft| (for the split-GEMM scale of [g_ft | g_pre]).
@@ -163,7 +164,8 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                           csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
-                                          g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, N, E, H, D,
+                                          g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, _ptr(score_l),
+                                          _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, E, H, D,
                                           p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src")
         t_src.__exit__()
     return g_e
@@ -495,18 +497,24 @@ class _CatDropout(torch.autograd.Function):
         if Fp > F_:
             buf[:, F_:].zero_()
         lib = _capi.load()
-        off = 0
+        nblk = [int(lib.spgnn_cat_dropout_blocks(N, w)) for w in widths]
+        part = torch.empty((sum(nblk),), dtype=torch.float32, device=buf.device)     # per-block maxima of |output|
+        off = boff = 0
         with torch.cuda.device(buf.device):
-            for t in tensors:
+            for t, nb in zip(tensors, nblk):
                 t = t if t.stride(1) == 1 else t.contiguous()
                 _capi.check(lib.spgnn_cat_dropout(t.data_ptr(), t.stride(0), buf.data_ptr(), buf.stride(0), N, t.shape[1], off, F_,
-                                                  p, seed, _seed_off_ptr(buf.device), 0, _stream(buf)), "spgnn_cat_dropout")
+                                                  p, seed, _seed_off_ptr(buf.device), 0, part[boff:].data_ptr(), _stream(buf)),
+                            "spgnn_cat_dropout")
                 off += t.shape[1]
+                boff += nb
         ctx.widths, ctx.p, ctx.seed = widths, p, seed
-        return buf[:, :F_]
+        scale = scale_from_partials(part) if N > 0 else torch.ones(1, dtype=torch.float32, device=buf.device)
+        ctx.mark_non_differentiable(scale)
+        return buf[:, :F_], scale
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_scale):
         if g.stride(1) != 1:
             g = g.contiguous()
         N, F_ = g.shape
@@ -518,7 +526,7 @@ class _CatDropout(torch.autograd.Function):
                     wp = (w + 3) // 4 * 4
                     go = torch.empty((N, wp), dtype=torch.float32, device=g.device)[:, :w]
                     _capi.check(lib.spgnn_cat_dropout(g.data_ptr(), g.stride(0), go.data_ptr(), go.stride(0), N, w, off, F_,
-                                                      ctx.p, ctx.seed, _seed_off_ptr(g.device), 1, _stream(g)), "spgnn_cat_dropout")
+                                                      ctx.p, ctx.seed, _seed_off_ptr(g.device), 1, 0, _stream(g)), "spgnn_cat_dropout")
                     outs.append(go)
                 else:
                     outs.append(None)
@@ -527,9 +535,24 @@ class _CatDropout(torch.autograd.Function):
 
 
 def cat_dropout(tensors, p: float = 0.0, seed: int = 0) -> torch.Tensor:
-    """dropout(cat(tensors, 1), p) with 16-byte-aligned rows; p = 0: a plain concatenation."""
+    """dropout(cat(tensors, 1), p) with 16-byte-aligned rows; p = 0: a plain concatenation.  The result carries
+    its split-GEMM operand scale (``_spgnn_scale``, from maxima the kernel collects while writing)."""
     _require_cuda(*tensors)
-    return _CatDropout.apply(float(p), int(seed), *tensors)
+    y, scale = _CatDropout.apply(float(p), int(seed), *tensors)
+    y._spgnn_scale = (y._version, scale)
+    return y
+
+
+def operand_scale(x: torch.Tensor) -> torch.Tensor:
+    """Power-of-two GEMM scale of x: the one its producer attached (cat_dropout), else one absmax pass - remembered on
+    the tensor when it is constant data (the batch's cached layer-0 input), so that pass runs once per batch."""
+    tag = getattr(x, "_spgnn_scale", None)
+    if tag is not None and tag[0] == x._version:
+        return tag[1]
+    sc = pow2_scale(x)
+    if not x.requires_grad:
+        x._spgnn_scale = (x._version, sc)
+    return sc
 
 
 def cat_padded(tensors) -> torch.Tensor:
@@ -612,6 +635,103 @@ class _GATLayerFn(torch.autograd.Function):
                 torch.mm(g_y, w_cat, out=g_x)
                 scores_bwd_x_(g_x, g_s, w_lr)
         return g_x, g_wcat, g_wlr, g_bias, None, None, None, None, None, None, None, None, None
+
+
+def scores_from_parts(parts: torch.Tensor, H: int, D: int) -> torch.Tensor:
+    N = parts.shape[0]
+    s = torch.empty((N, 2 * H), dtype=torch.float32, device=parts.device)
+    with torch.cuda.device(parts.device), _timed("scores_from_parts", (N, H, D)):
+        _capi.check(_capi.load().spgnn_scores_from_parts(parts.data_ptr(), s.data_ptr(), s.stride(0), N, H, D, _stream(parts)),
+                    "spgnn_scores_from_parts")
+    return s
+
+
+class _GATLayerScoresFromFtFn(torch.autograd.Function):
+    """Project-first GATConv with el / er taken from ft = fc(x) as DGL does, (ft * attn_l).sum(-1), instead of from x
+    through folded score weights: the products fall out of the projection GEMM's epilogue while the tile is in
+    registers (64-column partials, summed per head by a tiny kernel), and in the backward pass the scores' gradient
+    returns to g_ft inside spgnn_gat_bwd_src.  Every projected layer of the configs has K > H*D, so this reads less
+    than the folded form (no pass over x for the scores, none for their weight gradient, no folding kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, w_cat, attn_l, attn_r, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
+                p_drop: float, seed: int, mean: bool, sx):
+        HD = H * D
+        x = _rowmajor(x)
+        N = x.shape[0]
+        if sx is None:
+            sx = pow2_scale(x)
+        sw = pow2_scale(w_cat)
+        al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
+        parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
+        y = gemm_nt(x, w_cat, sx, sw, score_l=al, score_r=ar, score_out=parts)
+        s = scores_from_parts(parts, H, D)
+        ft = y[:, :HD]
+        res = y[:, HD:] if has_res else None
+        out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed,
+                                          mean=mean, need_out=(act != ACT_NONE))
+        ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_cat, al, ar, y, s, attn, out if act != ACT_NONE else None, sx, sw)
+        ctx.mark_non_differentiable(attn)
+        return (out_mean if mean else out), attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        x, w_cat, al, ar, y, s, attn, out, sx, sw = ctx.saved_tensors
+        H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
+        csc = ctx.csc
+        HD = H * D
+        N, K = x.shape
+        g_out = _rowmajor(g_out)
+        g_y = torch.empty_like(y)
+        g_s = torch.empty_like(s)
+        g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
+        amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device)
+        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax, score_l=al, score_r=ar)
+        sg = scale_from_partials(amax if has_res else amax[N:])
+        need_bias = ctx.has_bias and ctx.needs_input_grad[4]
+        g_bias = g_wcat = None
+        if ctx.needs_input_grad[1]:
+            big = g_y.shape[1] * K >= 128 * 512
+            if big:
+                if need_bias and has_res:
+                    g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True)
+                    g_bias = cs[HD:]
+                else:
+                    g_wcat = gemm_tn(g_y, x, sg, sx)
+            else:
+                g_wcat = _dw_gemm(g_y, x)
+        if need_bias and g_bias is None:
+            g_bias = g_pre.sum(0)
+        g_al = g_ar = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            m = scores_bwd_w(g_s, y[:, :HD])                     # (2H, HD): row h x head-h block = g_attn_l[h], row H+h = g_attn_r[h]
+            g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)])
+            g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)])
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            Kp = (K + 3) // 4 * 4
+            g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
+            gemm_nt(g_y, w_cat.t().contiguous(), sg, sw, out=g_x)
+        return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None
+
+
+def scores_from_ft_supported(x: torch.Tensor, w_cat: torch.Tensor, D: int) -> bool:
+    return (GEMM_MODE == "f16x3" and D % 64 == 0 and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32
+            and _rows_aligned(w_cat))
+
+
+def gat_layer_scores_from_ft(csc: DeviceCSC, x, w_cat, attn_l, attn_r, bias, H: int, D: int, has_res: bool, slope: float,
+                             act: int, p_drop: float = 0.0, seed: int = 0, mean: bool = False):
+    """Same contract as gat_layer, with the score vectors attn_l / attn_r (H, D) instead of folded score weights."""
+    _require_cuda(x, w_cat, attn_l, attn_r, bias)
+    xr = _rowmajor(x)
+    sx = operand_scale(x) if xr is x and _rows_aligned(x) else None
+    if not _rows_aligned(xr):
+        xr = cat_padded((xr,))
+    return _GATLayerScoresFromFtFn.apply(xr, w_cat, attn_l, attn_r, bias, csc, H, D, has_res, slope, act, p_drop, seed, mean, sx)
 
 
 def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: bool, slope: float, act: int,
@@ -874,9 +994,11 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
-            bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
+            bias: Optional[torch.Tensor] = None, act: int = 0, score_l: Optional[torch.Tensor] = None,
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
-    in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias)."""
+    in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias).  ``score_out``
+    (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns."""
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -894,7 +1016,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
         _capi.check(_capi.load().spgnn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                                                out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(upd_u),
                                                upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
-                                               _ptr(bias), act, _stream(a)), "spgnn_gemm_nt")
+                                               _ptr(bias), act, _ptr(score_l), _ptr(score_r), _ptr(score_out),
+                                               score_l.numel() if score_out is not None else 0, _stream(a)), "spgnn_gemm_nt")
     return out
 
 

@@ -43,7 +43,7 @@ for (H, D, mean) in shapes:
     def src():
         _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(),
             attn.data_ptr(), g_e.data_ptr(), g_y[:, HD:].data_ptr(), g_y.stride(0), g_y.data_ptr(), g_y.stride(0),
-            g_s.data_ptr(), g_s.stride(0), 0, N, E, H, D, 0.0, 0, 0, st), "src")
+            g_s.data_ptr(), g_s.stride(0), 0, 0, 0, 0, N, E, H, D, 0.0, 0, 0, st), "src")
     for name, fn in (("fwd", fwd), ("dst", dst), ("src", src)):
         if name not in kinds:
             continue
