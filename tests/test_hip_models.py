@@ -166,6 +166,24 @@ def test_full_batch_equals_per_tree_and_is_deterministic(big):
     assert rel_err(a[:offs[2]], refs[0]) < TOL                      # and those rows match the oracle
 
 
+def test_full_batch_backward_is_bitwise_reproducible(big):
+    """No atomics and no order-dependent reductions: at the BASELINE batch size every gradient must repeat bit for bit
+    (the check that exposed the packed-op / cross-lane read hazard, DESIGN.md §4.1: a few wrong 16-lane sums per
+    million elements, different on every run)."""
+    cfg, model, samples, g = big
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS), device="cuda")
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(1)).cuda() < 0.5
+    runs = []
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        masked_weighted_ce(model(g)[0], y, mask, w).backward()
+        runs.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.zero_grad(set_to_none=True)
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[1][n], runs[2][n]), n
+
+
 def test_full_batch_attention_rows_sum_to_one_and_linearity(big):
     from spgnn_amd import ops
     _, _, _, g = big
