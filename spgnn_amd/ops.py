@@ -489,6 +489,7 @@ class _CatDropout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, seed, *tensors):
+        ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of the scale output
         widths = [t.shape[1] for t in tensors]
         F_ = sum(widths)
         Fp = (F_ + 3) // 4 * 4
@@ -515,6 +516,8 @@ class _CatDropout(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_scale):
+        if g is None:
+            return (None, None) + (None,) * len(ctx.widths)
         if g.stride(1) != 1:
             g = g.contiguous()
         N, F_ = g.shape
@@ -563,6 +566,7 @@ class _GATLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_cat, w_lr, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
                 p_drop: float, seed: int, mean: bool):
+        ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
         HD = H * D
         x = _rowmajor(x)
         split = GEMM_MODE == "f16x3" and _rows_aligned(x) and _rows_aligned(w_cat) and x.shape[0] > 0
@@ -586,6 +590,8 @@ class _GATLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
+        if g_out is None:                      # only the (non-differentiable) attention output was used
+            return (None,) * 13
         x, w_cat, w_lr, y, s, attn, out, sx, sw = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
@@ -656,6 +662,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_cat, attn_l, attn_r, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
                 p_drop: float, seed: int, mean: bool, sx):
+        ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
         HD = H * D
         x = _rowmajor(x)
         N = x.shape[0]
@@ -678,6 +685,8 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
+        if g_out is None:                      # only the (non-differentiable) attention output was used
+            return (None,) * 15
         x, w_cat, al, ar, y, s, attn, out, sx, sw = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
@@ -794,6 +803,7 @@ class _GATAggFirstFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_fc, w_res, w_lr, bias, csc: DeviceCSC, H: int, D: int, slope: float, act: int, p_drop: float,
                 seed: int, mean: bool):
+        ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
         x = _rowmajor(x)
         N, F_ = x.shape
         has_res = w_res is not None
@@ -816,6 +826,8 @@ class _GATAggFirstFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
+        if g_out is None:                      # only the (non-differentiable) attention output was used
+            return (None,) * 13
         x, wc, w_lr, s, attn, z, out, sz, sw = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
