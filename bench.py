@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--config", default="st_pgat_spgnn_3")
     ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
+    ap.add_argument("--no-graph-replay", action="store_true", help="skip the extra HIP-graph replay measurement (1 GPU)")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-trees", type=int, default=32)
@@ -296,6 +297,22 @@ def main():
                                       "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3),
                                       "measured_in": f"{nprobe} instrumented warm-up step(s)",
                                       "per_kernel_ms": {"_".join(str(x) for x in k): round(a, 5) for k, (a, _, _) in sorted(agg.items())}}
+        if world == 1 and not args.graph and not args.no_graph_replay:
+            # extra, after the timed region: the same K steps as HIP-graph replays of the static-graph step (the
+            # reference takes 300 steps per batched graph, job_runner.py:1892).  `value` above stays the eager number,
+            # whose dominant kernel is bracketed by HIP events; a replay cannot be instrumented that way.
+            try:
+                step.capture(g)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step.replay()
+                sync()
+                r_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                out["hip_graph_replay"] = {"ms_per_step": r_ms, "value": float(E) * L / (r_ms * 1e-3), "unit": "layer-edges/s",
+                                           "steps": args.steps}
+            except Exception as e:                     # never let the extra measurement lose the main line
+                out["hip_graph_replay"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees))
         print(json.dumps(out), flush=True)
