@@ -230,6 +230,109 @@ def sage_stack(sd, src, dst, n, fvs, prefix="g_layers.", activation=F.elu):
     return h
 
 
+# --------------------------------------------------------------------------------------
+# the same layers on a message-flow graph ("block") of neighbour-sampled training
+# (reference forward_batch: models.py:331-340, 394-400, 685-689; job_runner.py:1499-1503)
+#
+# DGL: on a block ``expand_as_pair(feat, g)`` gives feat_src = feat (num_src rows) and
+# feat_dst = feat[:g.number_of_dst_nodes()] — the dst nodes are the first src nodes — messages
+# flow src -> dst and every reduction yields num_dst rows.  Written bipartite here, directly:
+# edge endpoints ``src`` in [0,num_src), ``dst`` in [0,num_dst).
+# --------------------------------------------------------------------------------------
+def gat_conv_block(src, dst, num_src: int, num_dst: int, feat, fc_weight, attn_l, attn_r, res_fc_weight=None, bias=None,
+                   negative_slope: float = 0.2, activation=None, residual_identity: bool = False):
+    """GATConv.forward on a block: fc on src and dst rows, el from src, er from dst, residual from feat_dst."""
+    _, H, D = attn_l.shape
+    ft_src = F.linear(feat, fc_weight).view(num_src, H, D)
+    ft_dst = ft_src[:num_dst]
+    el = (ft_src * attn_l).sum(-1)
+    er = (ft_dst * attn_r).sum(-1)
+    e = F.leaky_relu(el.index_select(0, src) + er.index_select(0, dst), negative_slope)
+    a = edge_softmax(dst, e, num_dst)
+    rst = spmm_sum(src, dst, ft_src, num_dst, a.unsqueeze(-1))
+    h_dst = feat[:num_dst]
+    if res_fc_weight is not None:
+        rst = rst + F.linear(h_dst, res_fc_weight).view(num_dst, H, D)
+    elif residual_identity:
+        rst = rst + h_dst.view(num_dst, -1, D)
+    if bias is not None:
+        rst = rst + bias.view(1, H, D)
+    if activation is not None:
+        rst = activation(rst)
+    return rst, a
+
+
+def gin_conv_block(src, dst, num_src: int, num_dst: int, feat, eps, apply_func, aggregator_type: str = "mean"):
+    if aggregator_type == "sum":
+        neigh = spmm_sum(src, dst, feat, num_dst)
+    elif aggregator_type == "mean":
+        neigh = spmm_sum(src, dst, feat, num_dst) / in_degrees(dst, num_dst, feat.dtype).clamp(min=1).unsqueeze(-1)
+    elif aggregator_type == "max":
+        neigh = spmm_max(src, dst, feat, num_dst)
+    else:
+        raise KeyError(aggregator_type)
+    rst = (1 + eps) * feat[:num_dst] + neigh
+    return apply_func(rst) if apply_func is not None else rst
+
+
+def graph_conv_block(src, dst, num_src: int, num_dst: int, feat, weight, bias, activation=None):
+    out_deg = in_degrees(src, num_src, feat.dtype).clamp(min=1)
+    in_deg = in_degrees(dst, num_dst, feat.dtype).clamp(min=1)
+    h = feat * out_deg.pow(-0.5).unsqueeze(-1)
+    f_in, f_out = weight.shape
+    rst = spmm_sum(src, dst, h @ weight, num_dst) if f_in > f_out else spmm_sum(src, dst, h, num_dst) @ weight
+    rst = rst * in_deg.pow(-0.5).unsqueeze(-1)
+    if bias is not None:
+        rst = rst + bias
+    return activation(rst) if activation is not None else rst
+
+
+def sage_conv_pool_block(src, dst, num_src: int, num_dst: int, feat, fc_pool_w, fc_pool_b, fc_self_w, fc_self_b,
+                         fc_neigh_w, fc_neigh_b, bias=None, activation=None):
+    """SAGEConv 'pool' on a block: max over the sampled in-neighbours of relu(fc_pool(feat_src)); h_self = feat_dst."""
+    neigh = spmm_max(src, dst, F.relu(F.linear(feat, fc_pool_w, fc_pool_b)), num_dst)
+    rst = F.linear(feat[:num_dst], fc_self_w, fc_self_b) + F.linear(neigh, fc_neigh_w, fc_neigh_b)
+    if bias is not None:
+        rst = rst + bias
+    return activation(rst) if activation is not None else rst
+
+
+def stack_blocks(kind: str, sd: Dict[str, Tensor], blocks, x, negative_slope=0.2, activation=F.elu, norm=False):
+    """``forward_batch(blocks, x)`` of SAGE / GAT / GIN (reference models.py:685-689, 331-340, 394-400): layer ``l``
+    runs on ``blocks[l]`` = (src, dst, num_src, num_dst), each block's src rows being the previous block's dst rows."""
+    prefix = {"sage": "g_layers.", "gat": "gat_layers.", "gin": "gin_layers."}[kind]
+    L = _count_layers(sd, prefix)
+    if len(blocks) != L:
+        raise ValueError(f"{L} layers but {len(blocks)} blocks")
+    h = x
+    for l, (src, dst, ns, nd) in enumerate(blocks):
+        p = f"{prefix}{l}."
+        if kind == "sage":
+            h = sage_conv_pool_block(src, dst, ns, nd, h, sd[p + "fc_pool.weight"], sd[p + "fc_pool.bias"],
+                                     sd[p + "fc_self.weight"], sd.get(p + "fc_self.bias"), sd[p + "fc_neigh.weight"],
+                                     sd.get(p + "fc_neigh.bias"), sd.get(p + "bias"), activation if l < L - 1 else None)
+        elif kind == "gat":
+            r = gat_conv_block(src, dst, ns, nd, h, sd[p + "fc.weight"], sd[p + "attn_l"], sd[p + "attn_r"],
+                               sd.get(p + "res_fc.weight"), sd.get(p + "bias"), negative_slope,
+                               activation if l < L - 1 else None)[0]
+            h = r.flatten(1) if l < L - 1 else r.mean(1)
+        else:
+            def mlp(t, p=p):
+                t = F.leaky_relu(F.linear(t, sd[p + "apply_func.0.weight"], sd[p + "apply_func.0.bias"]))
+                return F.leaky_relu(F.linear(t, sd[p + "apply_func.3.weight"], sd[p + "apply_func.3.bias"]))
+            h = gin_conv_block(src, dst, ns, nd, h, sd[p + "eps"], mlp, "mean")
+    if norm and kind in ("gat", "gin"):
+        h = F.normalize(h, p=2, dim=1)
+    return h
+
+
+def net_forward_batch(kind: str, sd: Dict[str, Tensor], blocks, x, **kw):
+    """``*Net.forward_batch(blocks, x)`` (reference models.py:814-817, 930-933): (gnn_out(embed), embed)."""
+    pfx = kind + "."
+    emb = stack_blocks(kind, {k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)}, blocks, x, **kw)
+    return F.linear(emb, sd["gnn_out.weight"], sd["gnn_out.bias"]), emb
+
+
 def net_forward(kind: str, sd: Dict[str, Tensor], src, dst, n, fvs, pos_enc=None, **kw):
     """``*Net.forward(g)`` (reference models.py:277-280, 921-925, 1167-1170): head + gnn_out Linear.
     ``sd`` is the full-module state_dict (keys ``gat.*`` / ``gcn.*`` / ``gin.*`` / ``sage.*`` / ``gnn_out.*``)."""

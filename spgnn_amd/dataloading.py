@@ -1,0 +1,245 @@
+"""Neighbour-sampled mini-batches over one batched tree graph.
+
+Replaces the slice of ``dgl.dataloading`` / ``dgl.sampling`` the reference's sampled GraphSAGE training touches
+(job_runner.py:1484-1506):
+
+    sampler = dgl.dataloading.MultiLayerNeighborSampler(self.model.node_ks)
+    dataloader = dgl.dataloading.NodeDataLoader(batch_g, nids, sampler, device=..., batch_size=NODE_BATCH_SIZE,
+                                                shuffle=True, drop_last=False, num_workers=NUM_WORKERS)
+    for input_nodes, seeds, blocks in dataloader:
+        batch_inputs = blocks[0].srcdata['fvs'];  batch_labels = blocks[-1].dstdata['y']
+        batch_outputs, _ = self.model.forward_batch(blocks, batch_inputs)
+
+Sampling is index work on the host, as it is in DGL (its samplers run in the DataLoader's CPU workers); the blocks
+it produces are the :class:`spgnn_amd.graph.Block` layout the HIP layers run on unchanged.  The algorithm follows
+DGL 0.6's ``BlockSampler.sample_blocks``: walking the layers from the output side, sample at most ``fanout`` in-edges
+of every seed uniformly without replacement (all of them when the in-degree is not larger, or when the fanout is
+``None`` / -1), compact the frontier with ``to_block``, and let the block's source nodes seed the next layer down.
+DGL's own random stream is not reproduced (it is a C++ generator seeded by ``dgl.seed``); the parity contract is on
+the block a sample defines — layer outputs on a block equal the oracle's on the same edge list — and on the
+sampler's distributional properties (tests/test_sampling.py).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .graph import Block, TreeGraph, build_csc_numpy, to_block, _as_np_i64
+
+__all__ = ["seed", "sample_neighbors", "in_subgraph", "BlockSampler", "MultiLayerNeighborSampler",
+           "MultiLayerFullNeighborSampler", "NodeCollator", "NodeDataLoader"]
+
+_rng: Optional[np.random.Generator] = None
+
+
+def seed(val: int) -> None:
+    """``dgl.seed`` / ``dgl.random.seed``: reseed the sampler's generator."""
+    global _rng
+    _rng = np.random.default_rng(int(val))
+
+
+def _generator() -> np.random.Generator:
+    global _rng
+    if _rng is None:                                  # follow torch.manual_seed unless seeded explicitly
+        _rng = np.random.default_rng(torch.initial_seed() % (2 ** 63))
+    return _rng
+
+
+def _host_in_csc(g: TreeGraph):
+    """(indptr, indices, eid) int64 host arrays of the in-edges of ``g``, cached on the graph."""
+    cached = getattr(g, "_host_in_csc", None)
+    if cached is not None and cached[0] == g.number_of_edges():
+        return cached[1]
+    a = build_csc_numpy(g._src, g._dst, g.number_of_nodes())
+    arrays = (a["indptr"].astype(np.int64), a["indices"].astype(np.int64), a["eid"].astype(np.int64))
+    g._host_in_csc = (g.number_of_edges(), arrays)
+    return arrays
+
+
+def _frontier(g: TreeGraph, src, dst, eid) -> TreeGraph:
+    f = TreeGraph((src, dst), g.number_of_nodes(), "cpu")
+    f.edata = {"_ID": torch.from_numpy(eid)}
+    return f
+
+
+def sample_neighbors(g: TreeGraph, nodes, fanout, edge_dir: str = "in", prob=None, replace: bool = False,
+                     generator: Optional[np.random.Generator] = None) -> TreeGraph:
+    """``dgl.sampling.sample_neighbors``: a graph over the nodes of ``g`` holding, for every node in ``nodes``, at most
+    ``fanout`` of its in-edges chosen uniformly without replacement (all of them if it has no more than that, or if
+    ``fanout`` is None / -1).  Edges come out grouped by seed in the order of ``nodes``, in ascending parent edge id
+    within a seed; ``edata['_ID']`` holds the parent edge ids."""
+    if edge_dir != "in":
+        raise ValueError("sample_neighbors: only edge_dir='in' is supported")
+    if prob is not None or replace:
+        raise ValueError("sample_neighbors: only uniform sampling without replacement is supported")
+    nodes = _as_np_i64(nodes)
+    n = g.number_of_nodes()
+    if nodes.size and (nodes.min() < 0 or nodes.max() >= n):
+        raise ValueError("sample_neighbors: seed node id out of range")
+    indptr, indices, eid = _host_in_csc(g)
+    start = indptr[nodes]
+    deg = indptr[nodes + 1] - start
+    total = int(deg.sum())
+    seg = np.repeat(np.arange(nodes.size, dtype=np.int64), deg)
+    first = np.cumsum(deg) - deg                                      # offset of each seed's segment
+    pos = np.repeat(start - first, deg) + np.arange(total, dtype=np.int64)   # CSC slot of every candidate edge
+    take_all = fanout is None or int(fanout) < 0
+    if not take_all and int(fanout) == 0:
+        pos = pos[:0]; seg = seg[:0]
+    elif not take_all and total and int(deg.max()) > int(fanout):
+        rng = generator if generator is not None else _generator()
+        keys = rng.random(total)
+        order = np.lexsort((keys, seg))                               # by seed, random within a seed
+        rank = np.arange(total, dtype=np.int64) - np.repeat(first, deg)
+        chosen = np.sort(order[rank < int(fanout)])                   # back to ascending slot order
+        pos, seg = pos[chosen], seg[chosen]
+    return _frontier(g, indices[pos], nodes[seg], eid[pos])
+
+
+def in_subgraph(g: TreeGraph, nodes) -> TreeGraph:
+    """``dgl.in_subgraph``: all in-edges of ``nodes``."""
+    return sample_neighbors(g, nodes, None)
+
+
+class BlockSampler:
+    """``dgl.dataloading.BlockSampler``: ``sample_blocks`` builds the list of blocks from ``sample_frontier``."""
+
+    def __init__(self, num_layers: int, return_eids: bool = False):
+        self.num_layers = int(num_layers)
+        self.return_eids = return_eids
+
+    def sample_frontier(self, block_id: int, g: TreeGraph, seed_nodes) -> TreeGraph:
+        raise NotImplementedError
+
+    def sample_blocks(self, g: TreeGraph, seed_nodes) -> List[Block]:
+        blocks: List[Block] = []
+        seed_nodes = _as_np_i64(seed_nodes)
+        for block_id in reversed(range(self.num_layers)):
+            frontier = self.sample_frontier(block_id, g, seed_nodes)
+            block = to_block(frontier, seed_nodes)
+            seed_nodes = block.srcdata["_ID"].numpy()
+            blocks.insert(0, block)
+        return blocks
+
+
+class MultiLayerNeighborSampler(BlockSampler):
+    """``dgl.dataloading.MultiLayerNeighborSampler(fanouts)`` — ``fanouts[i]`` in-edges per node for layer ``i``
+    (the reference passes ``model.node_ks``, models.py:665)."""
+
+    def __init__(self, fanouts: Sequence[Optional[int]], replace: bool = False, return_eids: bool = False):
+        super().__init__(len(fanouts), return_eids)
+        if replace:
+            raise ValueError("MultiLayerNeighborSampler: sampling with replacement is not supported")
+        self.fanouts = list(fanouts)
+
+    def sample_frontier(self, block_id, g, seed_nodes):
+        return sample_neighbors(g, seed_nodes, self.fanouts[block_id])
+
+
+class MultiLayerFullNeighborSampler(MultiLayerNeighborSampler):
+    """``dgl.dataloading.MultiLayerFullNeighborSampler(n_layers)``: every in-edge at every layer."""
+
+    def __init__(self, n_layers: int, return_eids: bool = False):
+        super().__init__([None] * int(n_layers), return_eids=return_eids)
+
+
+class NodeCollator:
+    """``dgl.dataloading.NodeCollator``: ``collate(seeds)`` -> (input_nodes, output_nodes, blocks) with the parent's
+    node data gathered into ``blocks[0].srcdata`` and ``blocks[-1].dstdata``."""
+
+    def __init__(self, g: TreeGraph, nids, block_sampler: BlockSampler):
+        self.g, self.nids, self.block_sampler = g, _as_np_i64(nids), block_sampler
+
+    @property
+    def dataset(self):
+        return self.nids
+
+    def sample(self, seeds) -> List[Block]:
+        return self.block_sampler.sample_blocks(self.g, seeds)
+
+    def attach(self, blocks: List[Block], device=None):
+        """Move the blocks to ``device`` and gather the parent's node data for the outermost src / dst nodes."""
+        g = self.g
+        device = torch.device(device) if device is not None else g.device
+        input_nodes = blocks[0].srcdata["_ID"]
+        output_nodes = blocks[-1].dstdata["_ID"]
+        blocks = [b.to(device) for b in blocks]
+        in_idx, out_idx = input_nodes.to(g.device), output_nodes.to(g.device)
+        for k, v in g.ndata.items():
+            blocks[0].srcdata[k] = v.index_select(0, in_idx).to(device)
+            blocks[-1].dstdata[k] = v.index_select(0, out_idx).to(device)
+        return blocks[0].srcdata["_ID"], blocks[-1].dstdata["_ID"], blocks
+
+    def collate(self, seeds, device=None):
+        return self.attach(self.sample(seeds), device)
+
+
+class NodeDataLoader:
+    """``dgl.dataloading.NodeDataLoader(g, nids, block_sampler, device=, batch_size=, shuffle=, drop_last=,
+    num_workers=)``: iterating yields ``(input_nodes, output_nodes, blocks)`` per mini-batch of seed nodes.
+
+    ``num_workers > 0`` samples ahead on a host thread (numpy index work) while the device runs the previous
+    mini-batch; graph transfer and feature gathers stay on the iterating thread's stream."""
+
+    def __init__(self, g: TreeGraph, nids, block_sampler: BlockSampler, device="cpu", batch_size: int = 1,
+                 shuffle: bool = False, drop_last: bool = False, num_workers: int = 0, **kwargs):
+        if kwargs:
+            raise TypeError(f"NodeDataLoader: unsupported arguments {sorted(kwargs)}")
+        if int(batch_size) <= 0:
+            raise ValueError("batch_size should be a positive integer value")
+        self.collator = NodeCollator(g, nids, block_sampler)
+        self.device = device
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
+        self.num_workers = int(num_workers)
+
+    def __len__(self) -> int:
+        n = self.collator.nids.size
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def _seed_batches(self):
+        nids = self.collator.nids
+        if self.shuffle:
+            nids = nids[torch.randperm(nids.size).numpy()]          # torch's generator, like torch's DataLoader
+        for i in range(len(self)):
+            yield nids[i * self.batch_size: (i + 1) * self.batch_size]
+
+    def __iter__(self):
+        if self.num_workers <= 0:
+            for seeds in self._seed_batches():
+                yield self.collator.collate(seeds, self.device)
+            return
+        q: "queue.Queue" = queue.Queue(maxsize=2 * self.num_workers)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for seeds in self._seed_batches():
+                    if stop.is_set():
+                        return
+                    q.put(("ok", self.collator.sample(seeds)))
+                q.put(("end", None))
+            except BaseException as e:                               # surfaced on the consumer side
+                q.put(("err", e))
+
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        try:
+            while True:
+                kind, item = q.get()
+                if kind == "end":
+                    break
+                if kind == "err":
+                    raise item
+                yield self.collator.attach(item, self.device)
+        finally:
+            stop.set()
+            while t.is_alive():                                      # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.01)

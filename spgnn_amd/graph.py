@@ -32,7 +32,7 @@ import torch
 
 __all__ = [
     "edges_from_adj", "TreeGraph", "DGLGraph", "batch", "unbatch", "remove_self_loop",
-    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy",
+    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy", "Block", "to_block",
 ]
 
 
@@ -149,11 +149,15 @@ class TreeGraph:
         self._csc: Dict[str, DeviceCSC] = {}
         self._tensor_cache: Dict[tuple, torch.Tensor] = {}     # per-batch constants derived from node data
 
+    is_block = False      # Block (below) is the bipartite message-flow graph of neighbour-sampled training
+
     # ---- structure -------------------------------------------------------------------
     def number_of_nodes(self) -> int:
         return self._n
 
     num_nodes = number_of_nodes
+    number_of_src_nodes = num_src_nodes = number_of_nodes
+    number_of_dst_nodes = num_dst_nodes = number_of_nodes
 
     def number_of_edges(self) -> int:
         return int(self._src.shape[0])
@@ -244,6 +248,128 @@ class TreeGraph:
 
 
 DGLGraph = TreeGraph  # the name the reference constructs (job_runner.py:1341,1783)
+
+
+class _Rows:
+    """The (row count, device) pair ``_NData`` checks against, for a block's dst-side data."""
+
+    def __init__(self, n, device):
+        self._n, self.device = int(n), device
+
+    def number_of_nodes(self):
+        return self._n
+
+
+class Block(TreeGraph):
+    """One message-flow graph of neighbour-sampled training (``dgl.to_block``; the ``blocks`` the reference hands to
+    ``forward_batch``, job_runner.py:1499-1503, models.py:331-340, 394-400, 685-689).
+
+    Layout: the block is held as a *square* graph over its ``num_src`` source nodes whose first ``num_dst`` nodes
+    are the destination nodes (DGL puts the dst nodes first among the src nodes, ``include_dst_in_src=True``) and are
+    the only ones with in-edges.  Every aggregation kernel then runs on it unchanged with N = num_src, and a layer
+    keeps rows ``[:num_dst]`` of the result, which is what DGL's ``expand_as_pair(feat, block)`` formulation computes.
+    ``srcdata`` (num_src rows) is ``ndata``; ``dstdata`` has num_dst rows.
+    """
+
+    is_block = True
+
+    def __init__(self, data, num_src: int, num_dst: int, device="cpu"):
+        super().__init__(data, num_src, device)
+        self._num_dst = int(num_dst)
+        if not 0 <= self._num_dst <= self._n:
+            raise ValueError(f"block with {num_dst} dst nodes but {num_src} src nodes (dst nodes come first among src)")
+        if self._dst.size and int(self._dst.max()) >= self._num_dst:
+            raise ValueError("block edge points at a node outside the dst range")
+        self.srcdata = self.ndata
+        self.dstdata = _NData(_Rows(self._num_dst, self.device))
+
+    def number_of_dst_nodes(self) -> int:
+        return self._num_dst
+
+    num_dst_nodes = number_of_dst_nodes
+
+    def number_of_src_nodes(self) -> int:
+        return self._n
+
+    num_src_nodes = number_of_src_nodes
+
+    def dstnodes(self) -> torch.Tensor:
+        return torch.arange(self._num_dst, dtype=torch.int64, device=self.device)
+
+    srcnodes = TreeGraph.nodes
+
+    def in_degrees(self) -> torch.Tensor:           # of the dst nodes, as DGL reports for a block
+        return super().in_degrees()[: self._num_dst]
+
+    def add_edges(self, u, v) -> None:
+        raise ValueError("a Block is immutable")
+
+    def int(self) -> "Block":
+        return self
+
+    long = int
+
+    def to(self, device) -> "Block":
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if device == self.device:
+            return self
+        b = Block((self._src, self._dst), self._n, self._num_dst, device)
+        for k, v in self.srcdata.items():
+            b.srcdata[k] = v.to(device)
+        for k, v in self.dstdata.items():
+            b.dstdata[k] = v.to(device)
+        return b
+
+    def csc(self, device=None) -> DeviceCSC:
+        device = torch.device(device) if device is not None else self.device
+        key = str(device)
+        if key not in self._csc:
+            c = super().csc(device)
+            # the zero-in-degree check of GATConv / GraphConv is about the dst nodes only
+            ind = np.bincount(self._dst, minlength=self._n)[: self._num_dst]
+            c.min_in_degree = int(ind.min()) if self._num_dst else 0
+            c.num_dst = self._num_dst
+        return self._csc[key]
+
+    def __repr__(self):
+        return (f"Block(num_src_nodes={self._n}, num_dst_nodes={self._num_dst}, num_edges={self.number_of_edges()}, "
+                f"device={self.device})")
+
+
+def to_block(frontier: "TreeGraph", dst_nodes, include_dst_in_src: bool = True) -> Block:
+    """``dgl.to_block(frontier, dst_nodes)``: compact the edges of ``frontier`` (a graph over the parent's node ids)
+    into a Block.  The dst nodes are ``dst_nodes`` in the given order; the src nodes are the dst nodes followed by
+    every other edge source in order of first appearance.  ``srcdata['_ID']`` / ``dstdata['_ID']`` hold the parent
+    node ids (``dgl.NID``), ``edata['_ID']`` the parent edge ids when the frontier carries them."""
+    if not include_dst_in_src:
+        raise ValueError("to_block: only include_dst_in_src=True is supported (the layers slice feat[:num_dst])")
+    dst_nodes = _as_np_i64(dst_nodes)
+    n = frontier.number_of_nodes()
+    local = np.full(n, -1, dtype=np.int64)
+    if dst_nodes.size:
+        if dst_nodes.min() < 0 or dst_nodes.max() >= n:
+            raise ValueError("to_block: dst node id out of range")
+        local[dst_nodes] = np.arange(dst_nodes.size)
+        if np.count_nonzero(local >= 0) != dst_nodes.size:
+            raise ValueError("to_block: dst_nodes must be unique")
+    src, dst = frontier._src, frontier._dst
+    if dst.size and (local[dst] < 0).any():
+        raise ValueError("to_block: an edge of the frontier ends outside dst_nodes")
+    extra = src[local[src] < 0]
+    if extra.size:
+        uniq, first = np.unique(extra, return_index=True)
+        extra = uniq[np.argsort(first, kind="stable")]          # order of first appearance
+        local[extra] = dst_nodes.size + np.arange(extra.size)
+    src_nodes = np.concatenate([dst_nodes, extra]) if extra.size else dst_nodes.copy()
+    b = Block((local[src], local[dst]), int(src_nodes.size), int(dst_nodes.size), frontier.device)
+    b.srcdata["_ID"] = torch.from_numpy(src_nodes)
+    b.dstdata["_ID"] = torch.from_numpy(dst_nodes.copy())
+    b.edata = {}
+    if getattr(frontier, "edata", None) and "_ID" in frontier.edata:
+        b.edata["_ID"] = frontier.edata["_ID"]
+    return b
 
 
 def _as_np_i64(x) -> np.ndarray:

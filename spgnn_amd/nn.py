@@ -172,6 +172,9 @@ class GATConv(nn.Module):
                 rst = self.activation(rst)
         if mean_heads and not fuse_mean:
             rst = rst.mean(1)
+        nd = getattr(csc, "num_dst", None)             # a Block: the dst nodes are the first rows (graph.Block)
+        if nd is not None:
+            rst = rst[:nd]
         if get_attention:
             a = torch.empty_like(attn)
             a[csc.eid.long()] = attn                   # CSC slot order -> edge id order
@@ -226,9 +229,9 @@ class GraphConv(nn.Module):
         if self._in_feats > self._out_feats:       # mult W first to reduce the aggregated width
             if weight is not None:
                 feat = ops.linear(feat, weight.t())
-            rst = ops.spmm_sum(csc, feat, w_src, w_dst)
+            rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
         else:
-            rst = ops.spmm_sum(csc, feat, w_src, w_dst)
+            rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
             if weight is not None:
                 rst = ops.linear(rst, weight.t())
         if self.bias is not None:
@@ -236,6 +239,13 @@ class GraphConv(nn.Module):
         if self._activation is not None:
             rst = self._activation(rst)
         return rst
+
+
+def _dst_rows(csc, x: torch.Tensor) -> torch.Tensor:
+    """Rows of the destination nodes: all of them on a graph, the leading ``num_dst`` on a Block (graph.Block holds
+    a block as a square graph over its src nodes, dst nodes first — DGL's ``expand_as_pair`` slice feat[:num_dst])."""
+    nd = getattr(csc, "num_dst", None)
+    return x if nd is None else x[:nd]
 
 
 def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -271,10 +281,10 @@ class GINConv(nn.Module):
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
         if self._aggregator_type == "max":
-            rst = (1 + self.eps) * feat + ops.spmm_max(csc, feat)
+            rst = _dst_rows(csc, (1 + self.eps) * feat + ops.spmm_max(csc, feat))
         else:
             w_dst = (1.0 / csc.in_degrees_f().clamp(min=1)) if self._aggregator_type == "mean" else None
-            rst = ops.spmm_sum(csc, feat, None, w_dst, self.eps)     # (1+eps)*x fused into the SpMM
+            rst = _dst_rows(csc, ops.spmm_sum(csc, feat, None, w_dst, self.eps))     # (1+eps)*x fused into the SpMM
         if self.apply_func is not None:
             rst = _apply_fast_linear(self.apply_func, rst)
         if self.activation is not None:
@@ -327,13 +337,15 @@ class SAGEConv(nn.Module):
         csc = graph.csc(feat.device)
         h = self.feat_drop(feat)
         if self._aggre_type == "pool":
-            neigh = ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU))
-            rst = ops.linear(h, self.fc_self.weight, self.fc_self.bias) + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
+            neigh = _dst_rows(csc, ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)))
+            rst = (ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias)
+                   + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias))
         elif self._aggre_type == "mean":
-            neigh = ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1))
-            rst = ops.linear(h, self.fc_self.weight, self.fc_self.bias) + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
+            neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1)))
+            rst = (ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias)
+                   + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias))
         else:  # gcn: (sum_in x_u + x_v) / (deg + 1)
-            neigh = (ops.spmm_sum(csc, h) + h) / (csc.in_degrees_f().unsqueeze(-1) + 1)
+            neigh = _dst_rows(csc, (ops.spmm_sum(csc, h) + h) / (csc.in_degrees_f().unsqueeze(-1) + 1))
             rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias)
         if self.activation is not None:
             rst = self.activation(rst)
