@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 16
+#define SPGNN_ABI_VERSION 17
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -393,6 +393,31 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
 int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,
                     const float* sampling_p, const float* class_weight, float* partials,
                     float* g_logits, int64_t g_stride, int64_t N, int32_t C, spgnn_stream_t stream);
+
+/*
+ * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's
+ * sampled GraphSAGE loop (job_runner.py:1484-1499, dgl.dataloading.MultiLayerNeighborSampler(node_ks) behind
+ * NodeDataLoader).  Two calls per block with one host read of (num_edges, num_extra) between them.
+ *
+ * spgnn_sample_neighbors: seed s = parent node seeds[s] keeps k_s = min(indegree, fanout) in-edges (all when
+ * fanout < 0), uniformly without replacement, in CSC order.  The caller passes out_indptr[S+1] = exclusive prefix sum
+ * of k_s, `local` = int32[num_nodes] filled with -1 and `flag` = int32[num_nodes] zeros.  On return
+ *   out_src[out_indptr[s] .. out_indptr[s+1]) = parent ids of the kept sources (out_eid likewise the parent edge ids,
+ *     or CSC slots when eid is null; out_eid nullable),
+ *   local[seeds[s]] = s, flag[u] = 1 for every kept source u that is not a seed.
+ * Seeds must be distinct (a duplicate leaves local[seeds[s]] != s for some s; the host side checks that).
+ * The draws are a pure function of (seed, CSC slot): mix64 as in spgnn_cat_dropout, top 32 bits, multiply-shift.
+ *
+ * spgnn_block_relabel: rank = inclusive prefix sum of flag.  Numbers the flagged nodes num_seeds + rank - 1 (the
+ * block's extra sources, ascending parent id), writes them to extra_nodes[num_extra] (int64 parent ids) and rewrites
+ * the edge sources: src_local[e] = local[out_src[e]].
+ */
+int spgnn_sample_neighbors(const int32_t* indptr, const int32_t* indices, const int32_t* eid, int64_t num_nodes,
+                           const int64_t* seeds, int64_t num_seeds, int32_t fanout, const int32_t* out_indptr, uint64_t seed,
+                           int32_t* local, int32_t* out_src, int32_t* out_eid, int32_t* flag, spgnn_stream_t stream);
+int spgnn_block_relabel(const int32_t* flag, const int32_t* rank, int32_t* local, int64_t num_nodes, int64_t num_seeds,
+                        const int32_t* out_src, int64_t num_edges, int64_t* extra_nodes, int32_t* src_local,
+                        spgnn_stream_t stream);
 
 /*
  * SGD with momentum over one flat fp32 parameter bucket (torch.optim.SGD semantics, dampening 0,

@@ -1885,6 +1885,75 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     default: hipLaunchKernelGGL((KERNEL<64, 8>), __VA_ARGS__); break;                            \
   }
 
+// =================================================================================================
+// Neighbour sampling on the device-resident CSC (dgl.sampling.sample_neighbors + dgl.to_block as the reference's
+// sampled GraphSAGE loop uses them, job_runner.py:1484-1499).  Index work, one thread per seed / node / edge.
+//
+// sample: seed s (parent node v) keeps k = min(deg(v), fanout) of its in-edges, chosen uniformly without replacement
+// by selection sampling (Knuth 3.4.2 S): walking the in-edges in CSC order, edge i of d is taken with probability
+// (k - taken) / (d - i).  The draw for CSC slot j is the top 32 bits of mix64(seed, j) mapped to [0, d - i) by
+// multiply-shift, so a sample is a pure function of (seed, graph, seeds) and the kept edges stay in CSC (= ascending
+// parent edge id) order.  Sources that are not seeds themselves are flagged for the block's relabelling.
+// =================================================================================================
+__global__ __launch_bounds__(kBlock) void block_mark_seeds(const int64_t* __restrict__ seeds, int64_t S, int64_t N,
+                                                           int32_t* __restrict__ local) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= S) return;
+  const int64_t v = seeds[s];
+  if (v >= 0 && v < N) local[v] = (int32_t)s;       // an id outside the graph is never dereferenced
+}
+
+__global__ __launch_bounds__(kBlock) void sample_neighbors_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                                  const int32_t* __restrict__ eid, const int64_t* __restrict__ seeds,
+                                                                  int64_t S, int64_t N, int32_t fanout,
+                                                                  const int32_t* __restrict__ out_indptr, uint64_t seed,
+                                                                  const int32_t* __restrict__ local,
+                                                                  int32_t* __restrict__ out_src, int32_t* __restrict__ out_eid,
+                                                                  int32_t* __restrict__ flag) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= S) return;
+  const int64_t v = seeds[s];
+  if (v < 0 || v >= N) return;
+  const int32_t b = indptr[v], d = indptr[v + 1] - b;
+  const int32_t k = (fanout < 0 || fanout > d) ? d : fanout;
+  const int32_t o = out_indptr[s];
+  int32_t m = 0;
+  for (int32_t i = 0; i < d && m < k; ++i) {
+    const uint32_t left = (uint32_t)(d - i), need = (uint32_t)(k - m);
+    bool take = need >= left;
+    if (!take) {
+      const uint64_t r = mix64(seed, (int64_t)b + i) >> 32;
+      take = (uint32_t)((r * (uint64_t)left) >> 32) < need;
+    }
+    if (take) {
+      const int32_t u = indices[b + i];
+      out_src[o + m] = u;
+      if (out_eid) out_eid[o + m] = eid ? eid[b + i] : b + i;
+      if (local[u] < 0) flag[u] = 1;                 // racing writers all store 1
+      ++m;
+    }
+  }
+}
+
+// relabel: a flagged parent node v becomes block source S + rank[v] - 1 (rank = inclusive prefix sum of flag, i.e.
+// the extra sources follow the seeds in ascending parent id); then every sampled edge's source is rewritten.
+__global__ __launch_bounds__(kBlock) void block_number_sources(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank,
+                                                               int32_t* __restrict__ local, int64_t* __restrict__ extra_nodes,
+                                                               int64_t N, int64_t S) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v < N && flag[v]) {
+    const int32_t r = rank[v] - 1;
+    local[v] = (int32_t)S + r;
+    extra_nodes[r] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void block_relabel_edges(const int32_t* __restrict__ local, const int32_t* __restrict__ out_src,
+                                                              int32_t* __restrict__ src_local, int64_t E) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e < E) src_local[e] = local[out_src[e]];
+}
+
 inline unsigned scalar_grid(int64_t total) { return (unsigned)((total + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -2382,6 +2451,36 @@ int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* l
   hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits,
                      logits_stride, labels, draws, sampling_p, class_weight, partials, g_logits, g_stride, N, C);
   return check_launch("spgnn_masked_ce");
+}
+
+int spgnn_sample_neighbors(const int32_t* indptr, const int32_t* indices, const int32_t* eid, int64_t num_nodes,
+                           const int64_t* seeds, int64_t num_seeds, int32_t fanout, const int32_t* out_indptr, uint64_t seed,
+                           int32_t* local, int32_t* out_src, int32_t* out_eid, int32_t* flag, spgnn_stream_t stream) {
+  if (num_nodes < 0 || num_seeds < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sample_neighbors: negative size");
+  if (num_seeds == 0) return SPGNN_OK;
+  if (num_nodes == 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sample_neighbors: seeds given for an empty graph");
+  if (!indptr || !indices || !seeds || !out_indptr || !local || !out_src || !flag)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_sample_neighbors: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(block_mark_seeds, dim3(scalar_grid(num_seeds)), dim3(kBlock), 0, st, seeds, num_seeds, num_nodes, local);
+  hipLaunchKernelGGL(sample_neighbors_kernel, dim3(scalar_grid(num_seeds)), dim3(kBlock), 0, st, indptr, indices, eid, seeds,
+                     num_seeds, num_nodes, fanout, out_indptr, seed, local, out_src, out_eid, flag);
+  return check_launch("spgnn_sample_neighbors");
+}
+
+int spgnn_block_relabel(const int32_t* flag, const int32_t* rank, int32_t* local, int64_t num_nodes, int64_t num_seeds,
+                        const int32_t* out_src, int64_t num_edges, int64_t* extra_nodes, int32_t* src_local,
+                        spgnn_stream_t stream) {
+  if (num_nodes < 0 || num_seeds < 0 || num_edges < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_block_relabel: negative size");
+  if (num_nodes == 0) return SPGNN_OK;
+  if (!flag || !rank || !local || !extra_nodes || (num_edges && (!out_src || !src_local)))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_block_relabel: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(block_number_sources, dim3(scalar_grid(num_nodes)), dim3(kBlock), 0, st, flag, rank, local, extra_nodes,
+                     num_nodes, num_seeds);
+  if (num_edges)
+    hipLaunchKernelGGL(block_relabel_edges, dim3(scalar_grid(num_edges)), dim3(kBlock), 0, st, local, out_src, src_local, num_edges);
+  return check_launch("spgnn_block_relabel");
 }
 
 int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale,

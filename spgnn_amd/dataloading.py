@@ -28,7 +28,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from .graph import Block, TreeGraph, build_csc_numpy, to_block, _as_np_i64
+from . import _capi
+from .graph import Block, DeviceBlock, DeviceCSC, TreeGraph, build_csc_numpy, to_block, _as_np_i64
 
 __all__ = ["seed", "sample_neighbors", "in_subgraph", "BlockSampler", "MultiLayerNeighborSampler",
            "MultiLayerFullNeighborSampler", "NodeCollator", "NodeDataLoader"]
@@ -100,6 +101,70 @@ def sample_neighbors(g: TreeGraph, nodes, fanout, edge_dir: str = "in", prob=Non
     return _frontier(g, indices[pos], nodes[seg], eid[pos])
 
 
+def sample_block_device(g: TreeGraph, seeds: torch.Tensor, fanout, rng_seed: Optional[int] = None) -> DeviceBlock:
+    """``to_block(sample_neighbors(g, seeds, fanout), seeds)`` entirely on the device holding ``g`` (a CUDA graph):
+    the HIP sampler (include/spgnn_hip.h spgnn_sample_neighbors / spgnn_block_relabel) reads the graph's resident
+    CSC, and the block's own CSC / CSR are assembled from its output with device scans and one sort; the host reads
+    back two integers (edge and source counts) per block.  The block's dst nodes are ``seeds`` in order; its other
+    source nodes follow in ascending parent id (DGL's order among them is an artefact of its hash map; no layer
+    depends on it).  Sampled edges keep CSC (ascending parent edge id) order within a seed, like the host sampler."""
+    if g.device.type != "cuda":
+        raise ValueError("sample_block_device: the graph must live on a GPU (use sample_neighbors + to_block on the host)")
+    dev = g.device
+    lib = _capi.load()
+    csc = g.csc(dev)
+    N = csc.num_nodes
+    seeds = torch.as_tensor(seeds, dtype=torch.int64, device=dev).contiguous()
+    S = int(seeds.shape[0])
+    fan = -1 if fanout is None or int(fanout) < 0 else int(fanout)
+    if rng_seed is None:
+        rng_seed = int(_generator().integers(0, 2 ** 62))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    i32 = dict(dtype=torch.int32, device=dev)
+    if S and N == 0:
+        raise ValueError("sample_block_device: seeds given for an empty graph")
+    safe = seeds.clamp(0, max(N - 1, 0))                            # out-of-range ids are reported below, never dereferenced
+    deg = csc.indptr[safe + 1] - csc.indptr[safe]
+    cnt = deg if fan < 0 else deg.clamp(max=fan)
+    out_indptr = torch.zeros(S + 1, **i32)
+    torch.cumsum(cnt, 0, dtype=torch.int32, out=out_indptr[1:])
+    # room for every edge the kernel can emit: fanout per seed, or (all in-edges) the exact count, read back first
+    bound = S * fan if fan >= 0 else int(out_indptr[-1])
+    out_src = torch.empty(max(bound, 1), **i32)                     # (never a null pointer across the C ABI)
+    out_eid = torch.empty(max(bound, 1), **i32)
+    local = torch.full((N,), -1, **i32)
+    flag = torch.zeros(N, **i32)
+    _capi.check(lib.spgnn_sample_neighbors(csc.indptr.data_ptr(), csc.indices.data_ptr(), csc.eid.data_ptr(), N, safe.data_ptr(),
+                                           S, fan, out_indptr.data_ptr(), rng_seed, local.data_ptr(), out_src.data_ptr(),
+                                           out_eid.data_ptr(), flag.data_ptr(), stream), "spgnn_sample_neighbors")
+    rank = torch.cumsum(flag, 0, dtype=torch.int32)
+    ar = torch.arange(S, **i32)
+    bad = (local[safe] != ar).any() if S else torch.zeros((), dtype=torch.bool, device=dev)
+    oob = (safe != seeds).any() if S else bad
+    E, n_extra, bad, min_in = torch.stack([out_indptr[-1], rank[-1] if N else out_indptr[-1], (bad | oob).to(torch.int32),
+                                           cnt.min() if S else out_indptr[-1]]).tolist()       # the one host read
+    if bad:
+        raise ValueError("sample_block_device: seed nodes must be distinct ids of the graph")
+    extra_buf = torch.empty(max(n_extra, 1), dtype=torch.int64, device=dev)
+    extra = extra_buf[:n_extra]
+    src_local = torch.empty(E, **i32)
+    _capi.check(lib.spgnn_block_relabel(flag.data_ptr(), rank.data_ptr(), local.data_ptr(), N, S, out_src.data_ptr(), E,
+                                        extra_buf.data_ptr(), src_local.data_ptr(), stream), "spgnn_block_relabel")
+    num_src = S + n_extra
+    dst_local = torch.repeat_interleave(ar, cnt.long(), output_size=E)
+    order = torch.sort(src_local, stable=True)                      # src-major view for the backward kernels
+    tensors = dict(
+        indptr=torch.cat([out_indptr, out_indptr[-1:].expand(n_extra)]).contiguous(),
+        indices=src_local,
+        eid=torch.arange(E, **i32),
+        out_indptr=torch.searchsorted(order.values, torch.arange(num_src + 1, **i32), out_int32=True),
+        out_indices=dst_local[order.indices],
+        out_pos=order.indices.to(torch.int32),
+    )
+    dcsc = DeviceCSC.from_tensors(tensors, num_src, E, min_in_degree=min_in if S else 0)
+    return DeviceBlock(dcsc, S, torch.cat([seeds, extra]), seeds, out_eid[:E].long())
+
+
 def in_subgraph(g: TreeGraph, nodes) -> TreeGraph:
     """``dgl.in_subgraph``: all in-edges of ``nodes``."""
     return sample_neighbors(g, nodes, None)
@@ -117,6 +182,13 @@ class BlockSampler:
 
     def sample_blocks(self, g: TreeGraph, seed_nodes) -> List[Block]:
         blocks: List[Block] = []
+        if g.device.type == "cuda" and type(self).sample_frontier is MultiLayerNeighborSampler.sample_frontier:
+            # graph resident on a GPU: sample there (sample_block_device); the seeds never leave the device
+            for block_id in reversed(range(self.num_layers)):
+                block = sample_block_device(g, seed_nodes, self.fanouts[block_id])
+                seed_nodes = block.srcdata["_ID"]
+                blocks.insert(0, block)
+            return blocks
         seed_nodes = _as_np_i64(seed_nodes)
         for block_id in reversed(range(self.num_layers)):
             frontier = self.sample_frontier(block_id, g, seed_nodes)
@@ -207,7 +279,46 @@ class NodeDataLoader:
         for i in range(len(self)):
             yield nids[i * self.batch_size: (i + 1) * self.batch_size]
 
+    def _iter_device(self):
+        """Graph resident on a GPU: the blocks of mini-batch i+1 are sampled on a side stream while the caller's
+        stream still runs mini-batch i, so the sampler's per-block host read (two integers) waits for the sampling
+        kernels only, never for the training step queued ahead of it."""
+        g = self.collator.g
+        main = torch.cuda.current_stream(g.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(g.device)
+        side = self._side
+        side.wait_stream(main)                                       # the graph's CSC may have just been uploaded
+
+        def launch(seeds):
+            with torch.cuda.stream(side):
+                blocks = self.collator.sample(seeds)
+                done = torch.cuda.Event()
+                done.record(side)
+            return blocks, done
+
+        batches = self._seed_batches()
+        pending = None
+        for seeds in batches:
+            ahead = launch(seeds)
+            if pending is not None:
+                yield self._hand_over(pending, main)
+            pending = ahead
+        if pending is not None:
+            yield self._hand_over(pending, main)
+
+    def _hand_over(self, pending, main):
+        blocks, done = pending
+        main.wait_event(done)
+        for b in blocks:
+            if hasattr(b, "record_stream"):
+                b.record_stream(main)
+        return self.collator.attach(blocks, self.device)
+
     def __iter__(self):
+        if self.collator.g.device.type == "cuda" and isinstance(self.collator.block_sampler, MultiLayerNeighborSampler):
+            yield from self._iter_device()
+            return
         if self.num_workers <= 0:
             for seeds in self._seed_batches():
                 yield self.collator.collate(seeds, self.device)

@@ -32,7 +32,7 @@ import torch
 
 __all__ = [
     "edges_from_adj", "TreeGraph", "DGLGraph", "batch", "unbatch", "remove_self_loop",
-    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy", "Block", "to_block",
+    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy", "Block", "DeviceBlock", "to_block",
 ]
 
 
@@ -97,6 +97,28 @@ class DeviceCSC:
         self.min_in_degree = int((ind[1:] - ind[:-1]).min()) if num_nodes else 0
         # degree-derived edge weights are computed lazily by ops (GraphConv/GIN)
         self._cache: Dict[str, torch.Tensor] = {}
+
+    @classmethod
+    def from_tensors(cls, tensors: Dict[str, torch.Tensor], num_nodes: int, num_edges: int, min_in_degree: int = 1,
+                     max_in_degree: int = 0, max_out_degree: int = 0) -> "DeviceCSC":
+        """Wrap int32 index arrays that were built on the device (dataloading's device sampler); the degree bounds
+        are whatever the builder knows without a host read."""
+        self = cls.__new__(cls)
+        self.num_nodes, self.num_edges = int(num_nodes), int(num_edges)
+        for k in ("indptr", "indices", "eid", "out_indptr", "out_indices", "out_pos"):
+            t = tensors[k]
+            if t.dtype != torch.int32 or not t.is_contiguous():
+                raise ValueError(f"DeviceCSC.from_tensors: {k} must be contiguous int32")
+            setattr(self, k, t)
+        if self.indptr.shape[0] != self.num_nodes + 1 or self.out_indptr.shape[0] != self.num_nodes + 1:
+            raise ValueError("DeviceCSC.from_tensors: indptr length != num_nodes + 1")
+        for k in ("indices", "eid", "out_indices", "out_pos"):
+            if getattr(self, k).shape[0] != self.num_edges:
+                raise ValueError(f"DeviceCSC.from_tensors: {k} length != num_edges")
+        self.device = self.indptr.device
+        self.min_in_degree, self.max_in_degree, self.max_out_degree = int(min_in_degree), int(max_in_degree), int(max_out_degree)
+        self._cache = {}
+        return self
 
     def in_degrees_f(self) -> torch.Tensor:
         if "in_deg" not in self._cache:
@@ -336,6 +358,85 @@ class Block(TreeGraph):
     def __repr__(self):
         return (f"Block(num_src_nodes={self._n}, num_dst_nodes={self._num_dst}, num_edges={self.number_of_edges()}, "
                 f"device={self.device})")
+
+
+class DeviceBlock(Block):
+    """A Block whose index arrays were built on the device (dataloading's device sampler): it is born with its
+    DeviceCSC; the host edge list is only materialised if somebody asks for it (``edges()``, the oracle in tests)."""
+
+    def __init__(self, csc: DeviceCSC, num_dst: int, src_nodes: torch.Tensor, dst_nodes: torch.Tensor,
+                 edge_ids: Optional[torch.Tensor] = None):
+        self._host_edges = None
+        self._device_csc = csc
+        TreeGraph.__init__(self, None, csc.num_nodes, csc.device)
+        self.batch_num_edges_list = [csc.num_edges]
+        self._num_dst = int(num_dst)
+        self.srcdata = self.ndata
+        self.dstdata = _NData(_Rows(self._num_dst, self.device))
+        self.srcdata["_ID"] = src_nodes
+        self.dstdata["_ID"] = dst_nodes
+        self.edata = {} if edge_ids is None else {"_ID": edge_ids}
+        csc.num_dst = self._num_dst
+        self._csc[str(self.device)] = csc
+
+    def record_stream(self, stream) -> None:
+        """The block was built on another stream than the one that will use it: tell the caching allocator."""
+        c = self._device_csc
+        for t in (c.indptr, c.indices, c.eid, c.out_indptr, c.out_indices, c.out_pos, *self.srcdata.values(),
+                  *self.dstdata.values(), *self.edata.values()):
+            if t.is_cuda:
+                t.record_stream(stream)
+
+    def _edges_host(self):
+        if self._host_edges is None:
+            c = self._device_csc
+            indptr = c.indptr.cpu().numpy().astype(np.int64)
+            dst = np.repeat(np.arange(c.num_nodes, dtype=np.int64), np.diff(indptr))
+            src = c.indices.cpu().numpy().astype(np.int64)
+            order = np.argsort(c.eid.cpu().numpy(), kind="stable")       # CSC slot order -> edge id order
+            self._host_edges = (src[order], dst[order])
+        return self._host_edges
+
+    # TreeGraph keeps the edge list in _src/_dst; here they are views of the device arrays, fetched on demand
+    @property
+    def _src(self):
+        return self._edges_host()[0]
+
+    @_src.setter
+    def _src(self, value):
+        pass
+
+    @property
+    def _dst(self):
+        return self._edges_host()[1]
+
+    @_dst.setter
+    def _dst(self, value):
+        pass
+
+    def number_of_edges(self) -> int:
+        return self._device_csc.num_edges
+
+    num_edges = number_of_edges
+
+    def to(self, device) -> "Block":
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if device == self.device:
+            return self
+        b = Block((self._src, self._dst), self._n, self._num_dst, device)
+        for k, v in self.srcdata.items():
+            b.srcdata[k] = v.to(device)
+        for k, v in self.dstdata.items():
+            b.dstdata[k] = v.to(device)
+        return b
+
+    def csc(self, device=None) -> DeviceCSC:
+        device = torch.device(device) if device is not None else self.device
+        if device == self.device:
+            return self._device_csc
+        return self.to(device).csc(device)
 
 
 def to_block(frontier: "TreeGraph", dst_nodes, include_dst_in_src: bool = True) -> Block:

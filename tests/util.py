@@ -58,3 +58,33 @@ def tree_batch_edges(ns, seed=0):
         u, v = edges_from_adj(synthetic.random_tree_adj(n, rng))
         srcs.append(u + off); dsts.append(v + off); off += n
     return np.concatenate(srcs), np.concatenate(dsts), off
+
+
+def mix64_host(seed: int, idx: np.ndarray) -> np.ndarray:
+    """Host copy of the kernels' counter hash (spgnn_kernels.hip mix64)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1))) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        return z ^ (z >> np.uint64(31))
+
+
+def sample_neighbors_host(indptr, indices, eid, seeds, fanout, seed):
+    """Bit-exact host copy of spgnn_sample_neighbors (selection sampling over the CSC slots of every seed):
+    returns (src parent ids, parent edge ids, per-seed counts), edges grouped by seed."""
+    src, eids, cnt = [], [], []
+    for v in seeds:
+        b, d = int(indptr[v]), int(indptr[v + 1] - indptr[v])
+        k = d if fanout is None or fanout < 0 or fanout > d else fanout
+        r = (mix64_host(seed, np.arange(b, b + d, dtype=np.int64)) >> np.uint64(32)).astype(np.uint64)
+        m = 0
+        for i in range(d):
+            if m >= k:
+                break
+            left, need = d - i, k - m
+            take = need >= left or int((int(r[i]) * left) >> 32) < need
+            if take:
+                src.append(int(indices[b + i])); eids.append(int(eid[b + i])); m += 1
+        cnt.append(m)
+    return np.array(src, np.int64), np.array(eids, np.int64), np.array(cnt, np.int64)

@@ -1,8 +1,10 @@
 """Timing of the neighbour-sampled GraphSAGE step (reference job_runner.py:1484-1506) on one GPU:
-host sampling, block upload (+ CSC build) and the device fwd+bwd+SGD, per mini-batch.
+block sampling (on the device when the graph lives there, SPGNN_SAMPLE_ON=cpu forces the host sampler), feature
+gather and the device fwd+bwd+SGD, per mini-batch.
 
     python tools/sampled_bench.py [trees] [node_batch] [workers] [iters]
 """
+import os
 import sys
 import time
 
@@ -26,6 +28,8 @@ def main():
     model.init(None); model.set_gcn_only(); model.train()
     opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
     g = synthetic.make_batch(trees, rank=0, device="cuda")
+    if os.environ.get("SPGNN_SAMPLE_ON", "cuda") == "cpu":
+        g = g.cpu()
     n = g.number_of_nodes()
     rng = np.random.default_rng(0)
     nids = rng.choice(n, int(n * model.node_sample_rate), replace=False)
@@ -68,7 +72,7 @@ def main():
             step(bl); nb += 1; ne += sum(b.number_of_edges() for b in bl)
     torch.cuda.synchronize(); t_loop = (time.perf_counter() - t0) / nb
     print(f"trees={trees} nodes={n} seeds/batch={node_batch} workers={workers} blocks(src,dst,E)={sizes}")
-    print(f"  host sample {t_sample*1e3:.3f} ms | upload+csc {t_attach*1e3:.3f} ms | device fwd+bwd+sgd {t_step*1e3:.3f} ms "
+    print(f"  sample 4 blocks {t_sample*1e3:.3f} ms | attach features {t_attach*1e3:.3f} ms | device fwd+bwd+sgd {t_step*1e3:.3f} ms "
           f"({edges / t_step / 1e6:.2f} M layer-edges/s)")
     print(f"  dataloader loop: {t_loop*1e3:.3f} ms per mini-batch over {nb} batches ({ne / nb / t_loop / 1e6:.2f} M layer-edges/s)")
 
