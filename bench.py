@@ -270,6 +270,10 @@ def main():
                                "mfma_f16_TFLOPs": 3 * fl / (g_ms * 1e-3) / 1e12, "mfma_f16_peak_TFLOPs": 2500.0,
                                "frac_of_f16_peak": 3 * fl / (g_ms * 1e-3) / 1e12 / 2500.0,
                                "absmax_ms_per_step": sum(sum(v) for k, v in gemm_kt.items() if k[0] == "absmax") / nprobe,
+                               # per shape (M, N, K): launches per step, mean ms, fp32-equivalent TFLOP/s
+                               "per_shape": {"_".join(str(x) for x in k): [len(v) // nprobe, round(sum(v) / len(v), 4),
+                                                                           round(2.0 * k[1] * k[2] * k[3] / (sum(v) / len(v) * 1e-3) / 1e12, 1)]
+                                             for k, v in sorted(gemm_kt.items(), key=lambda kv: -sum(kv[1])) if k[0] != "absmax"},
                                "measured_in": f"{nprobe} instrumented warm-up step(s)"}
             agg = {k: (sum(v) / len(v), sum(v), len(v)) for k, v in kt.items()}
             mp_ms = sum(t for _, t, _ in agg.values()) / nprobe

@@ -11,7 +11,7 @@ tot = df.TotalDurationNs.sum()
 with open(f"profiles/{tag}_kernel_stats_st_pgat_spgnn_3_b512.md", "w") as fp:
     fp.write(f"# rocprofv3 --kernel-trace --stats, round 1, state at the end of the round\n\n"
              f"Command (MI355X, 1 GPU): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -- python3 bench.py --no-cpu-baseline`\n\n"
-             f"{steps} optimizer steps (20 timed + 5 warm-up, 2 of them instrumented) of st_pgat_spgnn_3, 512 trees (N=76410, E=228206), fp32 parity path "
+             f"{steps} optimizer steps ({b['steps']} timed + {b['warmup']} warm-up, 2 of them instrumented) of st_pgat_spgnn_3, 512 trees (N=76410, E=228206), fp32 parity path "
              f"(split-fp16 MFMA GEMMs), dropout on.  bench.py under the profiler: {b['ms_per_step']:.2f} ms/step "
              f"({b['value']/1e6:.1f} M layer-edges/s); kernel time summed: {tot/1e6/steps:.2f} ms/step, {df.Calls.sum()/steps:.0f} launches/step.\n"
              f"Dominant hand-written HBM-bound kernel in bench.py's `roofline`: `{b['roofline']['kernel']}` "
