@@ -1088,6 +1088,12 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(64, 512 // tiles, R // 256))
+    if tiles >= 48 and R >= 32 * 512:
+        # More tiles than one XCD can hold at once (2 x 32 workgroups): with few splits every XCD ends up streaming a
+        # whole operand (PMC: 2.7-5.3x the algorithmic bytes, profiles/r01_pmc_gemm_l2_lds.md).  32 splits = 4 per
+        # XCD, each split's rows fetched into one L2 only (by_xcd placement needs splits % 8 == 0); measured
+        # (tools/tn_splits.py, 1024 x 1063, incl. the partial-sum reduction): 7 splits 847 us, 16: 743, 32: 701, 64: 732.
+        splits = 32
     ldn = (N + 3) // 4 * 4
     ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
