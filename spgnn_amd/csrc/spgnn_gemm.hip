@@ -226,34 +226,44 @@ __device__ __forceinline__ int pair_row(int q) { const int s_ = q & 7; return (q
 template <int ROWS, int NT>    // ROWS x 32 fp32 tile, NT threads: NL = ROWS*8/NT float4 per thread
 struct TileIO {
   static constexpr int NL = ROWS * 8 / NT;
-  // Interior stages (k0 + 32 <= K): unconditional 16-byte loads.  Rows past the end are clamped to the last
-  // row: they only feed output rows/columns that the epilogue never stores.  (A per-load bounds branch makes
-  // hipcc wait for every load separately - the loads of a stage must issue back to back.)
-  static __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
-                                              float4 (&r)[NL]) {
-    if (k0 + BK <= K) {
+  // The loads of the K loop are UNCONDITIONAL straight-line code.  A branch around a load (bounds test, "is there a
+  // next stage") makes hipcc's s_waitcnt insertion merge two histories of the VM queue at the join and wait for the
+  // worse one: the old loop waited vmcnt(3..0) at the top of every stage, i.e. it drained the refill issued one
+  // barrier earlier and the two-stage prefetch hid nothing (timing-only build without the loop's loads: -31 %).
+  //   load_full : a stage that lies wholly below K (k0 + 32 <= K).  Rows past the end are clamped to the last row:
+  //               they only feed output rows/columns that the epilogue never stores.
+  //   load_any  : any stage, existing or not: a float4 that starts at or beyond K is fetched from column 0 instead
+  //               (valid memory; rows are 16-byte multiples, ld % 4 == 0, so a float4 that starts below K lies
+  //               inside the row's stride) and mask() zeroes what lies beyond K before the set is converted.
+  static __device__ __forceinline__ void load_full(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0,
+                                                   float4 (&r)[NL]) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int idx = threadIdx.x + NT * i;
-        int row = row0 + pair_row(idx >> 3);
-        row = row < nrows ? row : nrows - 1;
-        r[i] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + (idx & 7) * 4);
-      }
-      return;
+    for (int i = 0; i < NL; ++i) {
+      const int idx = threadIdx.x + NT * i;
+      int row = row0 + pair_row(idx >> 3);
+      row = row < nrows ? row : nrows - 1;
+      r[i] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + (idx & 7) * 4);
     }
+  }
+  static __device__ __forceinline__ void load_any(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
+                                                  float4 (&r)[NL]) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {                      // ragged last stage: branch-free, zero beyond K.  Rows are
-      const int idx = threadIdx.x + NT * i;             // 16-byte multiples (ld % 4 == 0), so a float4 that starts
-      int row = row0 + pair_row(idx >> 3);              // below K lies inside the row's stride.
+    for (int i = 0; i < NL; ++i) {
+      const int idx = threadIdx.x + NT * i;
+      int row = row0 + pair_row(idx >> 3);
       row = row < nrows ? row : nrows - 1;
       const int k = k0 + (idx & 7) * 4;
-      const int kc = k < K ? k : 0;
-      float4 v = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + kc);
-      v.x = k + 0 < K ? v.x : 0.f;
-      v.y = k + 1 < K ? v.y : 0.f;
-      v.z = k + 2 < K ? v.z : 0.f;
-      v.w = k + 3 < K ? v.w : 0.f;
-      r[i] = v;
+      r[i] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + (k < K ? k : 0));
+    }
+  }
+  static __device__ __forceinline__ void mask(float4 (&r)[NL], int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int k = k0 + ((threadIdx.x + NT * i) & 7) * 4;
+      r[i].x = k + 0 < K ? r[i].x : 0.f;
+      r[i].y = k + 1 < K ? r[i].y : 0.f;
+      r[i].z = k + 2 < K ? r[i].z : 0.f;
+      r[i].w = k + 3 < K ? r[i].w : 0.f;
     }
   }
   // convert + store float4 #i (called between MFMAs)
@@ -431,15 +441,15 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
   const int nk = (a.K + BK - 1) / BK;
   float4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];             // two prefetch sets (stage parity)
 
-  // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
-  AIO::load(a.A, a.lda, row0, a.M, 0, a.K, ra0);
-  BIO::load(a.B, a.ldb, col0, a.N, 0, a.K, rb0);
-  if (nk > 1) {
-    AIO::load(a.A, a.lda, row0, a.M, BK, a.K, ra1);
-    BIO::load(a.B, a.ldb, col0, a.N, BK, a.K, rb1);
-  }
+  // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1 (unconditional loads, see TileIO)
+  AIO::load_any(a.A, a.lda, row0, a.M, 0, a.K, ra0);
+  BIO::load_any(a.B, a.ldb, col0, a.N, 0, a.K, rb0);
+  AIO::load_any(a.A, a.lda, row0, a.M, BK, a.K, ra1);
+  BIO::load_any(a.B, a.ldb, col0, a.N, BK, a.K, rb1);
   {
     _Float16* st = smem;
+    AIO::mask(ra0, 0, a.K);
+    BIO::mask(rb0, 0, a.K);
 #pragma unroll
     for (int i = 0; i < NLA; ++i) AIO::store_one(st, st + A_IMG, ra0[i], i, sA);
 #pragma unroll
@@ -447,13 +457,19 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
   }
   __syncthreads();
 
-  // one stage: MFMAs on buffer `cur`; convert register set (RA, RB) = stage t+1 into buffer `cur^1`;
-  // then refill that register set with stage t+3's... (stage t+2 lives in the other set)
-#define SPGNN_STAGE(T_, RA, RB)                                                                              \
+  // one stage: MFMAs on buffer PAR_ (= T_ & 1); convert register set (RA, RB) = stage T_+1 into the other buffer;
+  // then refill that set with stage T_+3 (stage T_+2 lives in the other set).
+  // STEADY_ = 1: stages T_+1 and T_+3 exist and lie wholly below K: no tests, no masks.
+  // STEADY_ = 0: the last stages: the set is masked beyond K first, the refill is a harmless load_any.
+#define SPGNN_STAGE(T_, PAR_, RA, RB, STEADY_)                                                               \
   {                                                                                                          \
-    const _Float16* cb = smem + ((T_) & 1) * STAGE;                                                          \
-    _Float16* nbuf = smem + (((T_) + 1) & 1) * STAGE;                                                        \
-    const bool has_next = (T_) + 1 < nk;                                                                     \
+    const _Float16* cb = smem + (PAR_) * STAGE;                                                              \
+    _Float16* nbuf = smem + (1 - (PAR_)) * STAGE;                                                            \
+    const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
+    if (!(STEADY_) && has_next) {                                                                            \
+      AIO::mask(RA, ((T_) + 1) * BK, a.K);                                                                   \
+      BIO::mask(RB, ((T_) + 1) * BK, a.K);                                                                   \
+    }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
       half8 ah[2], al[2], bh[2], bl[2];                                                                      \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
@@ -485,24 +501,33 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    if ((T_) + 3 < nk && SPGNN_GEMM_ABLATE != 3) {                                                            \
-      AIO::load(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                            \
-      BIO::load(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, a.K, RB);                                            \
+    if (SPGNN_GEMM_ABLATE != 3) {                                                                            \
+      if (STEADY_) {                                                                                         \
+        AIO::load_full(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, RA);                                          \
+        BIO::load_full(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, RB);                                          \
+      } else {                                                                                               \
+        AIO::load_any(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                      \
+        BIO::load_any(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, a.K, RB);                                      \
+      }                                                                                                      \
     }                                                                                                        \
     __syncthreads();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);   /* keep the next stage's conversion arithmetic (and its vmcnt) behind the barrier */ \
   }
 
   // register set 1 holds stage 1 (odd stages), set 0 will hold stage 2 (even stages)
-  if (nk > 2) {
-    AIO::load(a.A, a.lda, row0, a.M, 2 * BK, a.K, ra0);
-    BIO::load(a.B, a.ldb, col0, a.N, 2 * BK, a.K, rb0);
-  }
+  AIO::load_any(a.A, a.lda, row0, a.M, 2 * BK, a.K, ra0);
+  BIO::load_any(a.B, a.ldb, col0, a.N, 2 * BK, a.K, rb0);
+  const int nfull = a.K / BK;                                   // stages that lie wholly below K
   int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    SPGNN_STAGE(t, ra1, rb1)          // computes stage t (even), converts stage t+1 from set 1, refills set 1 with t+3
-    SPGNN_STAGE(t + 1, ra0, rb0)      // computes stage t+1 (odd), converts stage t+2 from set 0, refills set 0 with t+4
+  for (; t + 4 < nfull; t += 2) {                               // refill targets t+3, t+4 are full stages
+    SPGNN_STAGE(t, 0, ra1, rb1, 1)     // computes stage t (even), converts stage t+1 from set 1, refills set 1 with t+3
+    SPGNN_STAGE(t + 1, 1, ra0, rb0, 1) // computes stage t+1 (odd), converts stage t+2 from set 0, refills set 0 with t+4
   }
-  if (t < nk) SPGNN_STAGE(t, ra1, rb1)
+  for (; t + 1 < nk; t += 2) {
+    SPGNN_STAGE(t, 0, ra1, rb1, 0)
+    SPGNN_STAGE(t + 1, 1, ra0, rb0, 0)
+  }
+  if (t < nk) SPGNN_STAGE(t, 0, ra1, rb1, 0)
 #undef SPGNN_STAGE
 
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
@@ -920,36 +945,75 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
   float4 ra0[4], rb0[4], ra1[4], rb1[4];
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool do_colsum = a.colsum != nullptr && bn == 0;
-#define SPGNN_TN_LOAD(T_, RA, RB)                                                    \
-  {                                                                                  \
-    load_tile_t(a.A, a.lda, r_beg + (int64_t)(T_) * TBK, r_end, m0, a.M, RA);        \
-    load_tile_t(a.B, a.ldb, r_beg + (int64_t)(T_) * TBK, r_end, n0, a.N, RB);        \
+
+  // Loads are unconditional straight-line code (see TileIO in the NT kernel: a branch around a load makes hipcc drain
+  // the VM queue at every stage).  A thread's four float4 of a tile share one column (idx & 31 = tid & 31) and sit in
+  // rows (tid >> 5) + 8 i.  A float4 that starts at or beyond the width is fetched from column 0 instead, rows past the
+  // split's range from its last row; SPGNN_TN_MASK zeroes both before the set is summed / converted.  In the steady
+  // loop all rows exist, so only tiles that hang over the width (edge_a / edge_b, block-uniform) are masked there.
+  const int tcol = (threadIdx.x & 31) * 4, trow = threadIdx.x >> 5;
+  const int ca = m0 + tcol, cbn = n0 + tcol;
+  const float* pA = a.A + (ca < a.M ? ca : 0);
+  const float* pB = a.B + (cbn < a.N ? cbn : 0);
+  const bool edge_a = m0 + BM > a.M, edge_b = n0 + BN > a.N;
+  const int64_t r_last = r_end - 1;
+#define SPGNN_TN_LOAD_FULL(T_, RA, RB)                                                                       \
+  {                                                                                                          \
+    const int64_t rr = r_beg + (int64_t)(T_) * TBK + trow;                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) RA[q] = *reinterpret_cast<const float4*>(pA + (rr + 8 * q) * a.lda); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) RB[q] = *reinterpret_cast<const float4*>(pB + (rr + 8 * q) * a.ldb); \
+  }
+#define SPGNN_TN_LOAD_ANY(T_, RA, RB)                                                                        \
+  {                                                                                                          \
+    const int64_t rr = r_beg + (int64_t)(T_) * TBK + trow;                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
+      const int64_t r_ = rr + 8 * q < r_end ? rr + 8 * q : r_last;                                           \
+      RA[q] = *reinterpret_cast<const float4*>(pA + r_ * a.lda);                                             \
+      RB[q] = *reinterpret_cast<const float4*>(pB + r_ * a.ldb);                                             \
+    }                                                                                                        \
+  }
+#define SPGNN_TN_MASK1(R_, C_, W_, ROWS_TOO, T_)                                                             \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + trow + 8 * q < r_end;                       \
+    R_[q].x = rv && (C_) + 0 < (W_) ? R_[q].x : 0.f;                                                         \
+    R_[q].y = rv && (C_) + 1 < (W_) ? R_[q].y : 0.f;                                                         \
+    R_[q].z = rv && (C_) + 2 < (W_) ? R_[q].z : 0.f;                                                         \
+    R_[q].w = rv && (C_) + 3 < (W_) ? R_[q].w : 0.f;                                                         \
+  }
+#define SPGNN_TN_MASK(T_, RA, RB, ROWS_TOO)                                                                  \
+  {                                                                                                          \
+    if ((ROWS_TOO) || edge_a) SPGNN_TN_MASK1(RA, ca, a.M, ROWS_TOO, T_)                                      \
+    if ((ROWS_TOO) || edge_b) SPGNN_TN_MASK1(RB, cbn, a.N, ROWS_TOO, T_)                                     \
   }
 #define SPGNN_TN_CSUM(RA)                                                            \
   if (do_colsum) {                                                                   \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
   }
-  if (nk > 0) {
-    SPGNN_TN_LOAD(0, ra0, rb0)
-    if (nk > 1) SPGNN_TN_LOAD(1, ra1, rb1)
+  if (nk > 0) {                                          // block-uniform; an empty split only writes zeros
+    SPGNN_TN_LOAD_ANY(0, ra0, rb0)
+    SPGNN_TN_LOAD_ANY(1, ra1, rb1)
+    SPGNN_TN_MASK(0, ra0, rb0, true)
     SPGNN_TN_CSUM(ra0)
     _Float16* st = smem_t;
 #pragma unroll
     for (int q = 0; q < 4; ++q) store_one_t(st, st + TTILE, ra0[q], q, sA);
 #pragma unroll
     for (int q = 0; q < 4; ++q) store_one_t(st + 2 * TTILE, st + 3 * TTILE, rb0[q], q, sB);
-  }
-  __syncthreads();
-  if (nk > 2) SPGNN_TN_LOAD(2, ra0, rb0)
+    __syncthreads();
+    SPGNN_TN_LOAD_ANY(2, ra0, rb0)
 
-  // stage T_: MFMAs on buffer T_&1; register set (RA, RB) = stage T_+1 is converted into the other buffer,
-  // one float4 pair per accumulator group; then the set is refilled with stage T_+3
-#define SPGNN_TN_STAGE(T_, RA, RB)                                                                           \
+  // stage T_: MFMAs on buffer PAR_ (= T_ & 1); register set (RA, RB) = stage T_+1 is converted into the other buffer,
+  // one float4 pair per accumulator group; then the set is refilled with stage T_+3.  STEADY_ = 1: stages T_+1 and
+  // T_+3 exist with all their rows (no tests); STEADY_ = 0: the last stages (set masked first, harmless refill).
+#define SPGNN_TN_STAGE(T_, PAR_, RA, RB, STEADY_)                                                            \
   {                                                                                                          \
-    const _Float16* cb = smem_t + ((T_) & 1) * STAGE;                                                        \
-    _Float16* nbuf = smem_t + (((T_) + 1) & 1) * STAGE;                                                      \
-    const bool has_next = (T_) + 1 < nk;                                                                     \
-    if (has_next) SPGNN_TN_CSUM(RA)                                                                          \
+    const _Float16* cb = smem_t + (PAR_) * STAGE;                                                            \
+    _Float16* nbuf = smem_t + (1 - (PAR_)) * STAGE;                                                          \
+    const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
+    if (has_next) {                                                                                          \
+      SPGNN_TN_MASK((T_) + 1, RA, RB, !(STEADY_))                                                            \
+      SPGNN_TN_CSUM(RA)                                                                                      \
+    }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < TBK / 16; ++ks) {                                                \
       half8 ah[2], al[2], bh[2], bl[2];                                                                      \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
@@ -971,17 +1035,27 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    if ((T_) + 3 < nk) SPGNN_TN_LOAD((T_) + 3, RA, RB)                                                       \
+    if (STEADY_) SPGNN_TN_LOAD_FULL((T_) + 3, RA, RB) else SPGNN_TN_LOAD_ANY((T_) + 3, RA, RB)               \
     __syncthreads();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    SPGNN_TN_STAGE(t, ra1, rb1)
-    SPGNN_TN_STAGE(t + 1, ra0, rb0)
+    const int nfull = (int)((r_end - r_beg) / TBK);            // stages with all 32 rows
+    int t = 0;
+    for (; t + 4 < nfull; t += 2) {
+      SPGNN_TN_STAGE(t, 0, ra1, rb1, 1)
+      SPGNN_TN_STAGE(t + 1, 1, ra0, rb0, 1)
+    }
+    for (; t + 1 < nk; t += 2) {
+      SPGNN_TN_STAGE(t, 0, ra1, rb1, 0)
+      SPGNN_TN_STAGE(t + 1, 1, ra0, rb0, 0)
+    }
+    if (t < nk) SPGNN_TN_STAGE(t, 0, ra1, rb1, 0)
   }
-  if (t < nk) SPGNN_TN_STAGE(t, ra1, rb1)
 #undef SPGNN_TN_STAGE
-#undef SPGNN_TN_LOAD
+#undef SPGNN_TN_LOAD_FULL
+#undef SPGNN_TN_LOAD_ANY
+#undef SPGNN_TN_MASK
+#undef SPGNN_TN_MASK1
 #undef SPGNN_TN_CSUM
 
   if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
