@@ -42,11 +42,13 @@ class KernelTimer:
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
     enabled = False
     records: dict = {}
-    only = None          # when set: record this one (kernel, shape) key only (two events per step: no perturbation)
+    only = None          # when set: record these (kernel, shape) keys only (a few events per step: no perturbation)
 
     @classmethod
     def start(cls, only=None):
-        cls.records, cls.enabled, cls.only = {}, True, only
+        if only is not None and only and not isinstance(next(iter(only)), tuple):
+            only = (tuple(only),)                      # a single key
+        cls.records, cls.enabled, cls.only = {}, True, (None if only is None else frozenset(only))
 
     @classmethod
     def stop(cls):
@@ -63,7 +65,7 @@ class _timed:
         self.key = (name,) + tuple(shape)
 
     def __enter__(self):
-        self.on = KernelTimer.enabled and (KernelTimer.only is None or KernelTimer.only == self.key)
+        self.on = KernelTimer.enabled and (KernelTimer.only is None or self.key in KernelTimer.only)
         if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()

@@ -132,6 +132,11 @@ class TrainStep:
 
     def step(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns the (global) loss as a device scalar; never synchronises with the host."""
+        return self._back(self._reduce(self._front(g, draws)))
+
+    def _front(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Mask draw, forward, loss sums, backward; leaves the local gradient sums in the flat bucket (its last slot
+        carries the local class-weight sum) and returns the local loss numerator."""
         b = self.bucket
         b.detach_grads()
         y = g.ndata["y"]
@@ -152,11 +157,19 @@ class TrainStep:
         num.backward()
         b.gather_grads()
         b.wsum_slot.copy_(den.detach().reshape(1))
-        loss_num = num.detach()
+        return num.detach()
+
+    def _reduce(self, loss_num: torch.Tensor) -> torch.Tensor:
+        """The step's only exchange: one sum all-reduce of the flat gradient bucket (RCCL), one of the loss numerator."""
         if self.world > 1:
-            dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            loss_num = loss_num.clone()
+            dist.all_reduce(self.bucket.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if loss_num.data_ptr() != getattr(self, "_loss_buf_ptr", 0):
+                loss_num = loss_num.clone()
             dist.all_reduce(loss_num, op=dist.ReduceOp.SUM, group=self.pg)
+        return loss_num
+
+    def _back(self, loss_num: torch.Tensor) -> torch.Tensor:
+        b = self.bucket
         inv = torch.reciprocal(b.wsum_slot)
         self._apply_update(inv)
         b.steps += 1
@@ -175,19 +188,22 @@ class TrainStep:
 
     # ---- HIP-graph replay of the static-graph step ---------------------------------------------------------
     def capture(self, g, warmup: int = 3):
-        """Capture one optimizer step on the static batched graph ``g`` into a HIP graph (the reference takes 300
-        steps on each batched graph, job_runner.py:1892).  At the reference's own batch of 64 trees the step is
-        ~360 launches of a few microseconds each and is launch-bound when issued eagerly; a replay is one launch.
+        """Capture one optimizer step on the static batched graph ``g`` into HIP graphs (the reference takes 300
+        steps on each batched graph, job_runner.py:1892).  Eagerly the step is ~230 launches of a few microseconds
+        each plus autograd's host work, and the host, not the GPU, sets the pace once the kernels are fast enough; a
+        replay is two graph launches.  Two graphs, split where the ranks exchange: ``front`` = mask draw, forward, loss,
+        backward, gradient gather; [eager: the RCCL all-reduces of ``_reduce``]; ``back`` = SGD update and the loss
+        scalar.  One process runs the same two graphs with nothing in between.
         Randomness stays fresh per replay: the node-mask draws and feature dropout use torch's graph-safe Philox
         offsets, attention dropout adds a device counter (ops.DROPOUT_SEED_OFFSET) that the captured step increments;
         the learning rate is read from a device scalar (``set_lr`` keeps working)."""
-        if self.world > 1:
-            raise NotImplementedError("graph capture is wired for the single-process step")
         dev = self.bucket.flat_param.device
         self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
         self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)
         ops.DROPOUT_SEED_OFFSET = self._seed_ctr
         self._use_default_rng = True
+        self._loss_buf = torch.zeros((), dtype=torch.float32, device=dev)      # local loss numerator, all-reduced in place
+        self._loss_buf_ptr = self._loss_buf.data_ptr()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -195,11 +211,17 @@ class TrainStep:
                 self._static_loss = self.step(g)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # thread-local capture mode: other threads (the process group's watchdog) may touch the runtime meanwhile
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_loss = self.step(g)
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+            self._loss_buf.copy_(self._front(g))
+        self._graph_back = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
+            self._static_loss = self._back(self._loss_buf)
         return self
 
     def replay(self) -> torch.Tensor:
         self._graph.replay()
+        self._reduce(self._loss_buf)
+        self._graph_back.replay()
         return self._static_loss
