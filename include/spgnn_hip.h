@@ -347,8 +347,10 @@ int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, fl
                               uint32_t* workspace /* nullable; 2 words, zeroed ONCE by the caller, self-resetting */,
                               spgnn_stream_t stream);
 
-/* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined (default), 3 = pipelined with
- * 128-row tiles only.  Returns the previous setting.  For A/B measurements. */
+/* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined kernels, tile shape chosen per product
+ * (default: 128 x 128, 256 x 128 or 256 x 256 tiles), 3 = 128 x 128 tiles only, 4 = 256 x 128 tiles only,
+ * 5 = 256 x 256 tiles only (needs operand extents below 2^31 bytes, otherwise as 2).  All give bit-identical results
+ * except 1.  Returns the previous setting.  For A/B measurements and tests. */
 int spgnn_gemm_set_variant(int32_t variant);
 
 /*

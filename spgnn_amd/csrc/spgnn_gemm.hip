@@ -256,6 +256,19 @@ struct TileIO {
       r[i] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + (k < K ? k : 0));
     }
   }
+  static __device__ __forceinline__ float4 load_full1(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int i) {
+    const int idx = threadIdx.x + NT * i;
+    int row = row0 + pair_row(idx >> 3);
+    row = row < nrows ? row : nrows - 1;
+    return *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k0 + (idx & 7) * 4);
+  }
+  static __device__ __forceinline__ float4 load_any1(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K, int i) {
+    const int idx = threadIdx.x + NT * i;
+    int row = row0 + pair_row(idx >> 3);
+    row = row < nrows ? row : nrows - 1;
+    const int k = k0 + (idx & 7) * 4;
+    return *reinterpret_cast<const float4*>(base + (int64_t)row * ld + (k < K ? k : 0));
+  }
   static __device__ __forceinline__ void mask(float4 (&r)[NL], int k0, int K) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -304,8 +317,8 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
-template <class ARGS>
-__device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&acc)[2][2], _Float16* smem, int row0, int col0,
+template <class ARGS, int MI>
+__device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&acc)[MI][2], _Float16* smem, int row0, int col0,
                                                        int wave, int lane, int wm, int wn, float alpha) {
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int EP = 68;
@@ -332,7 +345,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
     wv[jj] = (use_j && small_j && jj < a.J) ? *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -345,7 +358,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
     if (use_j && small_j) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        int row = row0 + wm * 64 + i * 32 + it * 4 + r_in;
+        int row = row0 + wm * (32 * MI) + i * 32 + it * 4 + r_in;
         row = row < a.M ? row : a.M - 1;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) uu[it][jj] = a.U[(int64_t)row * a.ldu + (jj < a.J ? jj : 0)];
@@ -354,7 +367,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int lr = it * 4 + r_in;
-      const int row = row0 + wm * 64 + i * 32 + lr;
+      const int row = row0 + wm * (32 * MI) + i * 32 + lr;
       float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
       if (row < a.M) {
         if (use_j) {
@@ -395,7 +408,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 4 + r_in;
-        const int row = row0 + wm * 64 + i * 32 + lr;
+        const int row = row0 + wm * (32 * MI) + i * 32 + lr;
         const float4 v = *reinterpret_cast<const float4*>(slab + lr * EP + c4);
         float pl = v.x * sl.x + v.y * sl.y + v.z * sl.z + v.w * sl.w;
         float pr = v.x * sr.x + v.y * sr.y + v.z * sr.z + v.w * sr.w;
@@ -532,6 +545,164 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_f16x3_v2(Args a) {
 
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
+
+// -------------------------------------------------------------------------------------------------
+// NT kernel, third generation: 256 x 256 block tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA
+// tiles (128 accumulator registers), one workgroup per CU.  Per MFMA it moves 2/3 of the operand bytes, converts
+// 2/3 of the values, reads 3/4 of the LDS fragments and meets half the barriers of the 256 x 128 kernel above.
+// ONE register set: a staging register is refilled (stage t+2) right after it has been converted (stage t+1) between
+// the MFMAs of stage t, so every load has a whole stage to land; fragments are read per k16 step in two halves
+// (B once, A for two of the four row tiles at a time) to stay inside 256 registers.  LDS: 2 stages x 4 images of
+// 256 rows x 80 bytes = 160 KB.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
+  constexpr int TB = 256;
+  constexpr int IMG = TB * PITCH;                               // halves per image
+  constexpr int STAGE = 4 * IMG;                                // Ah | Al | Bh | Bl
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
+  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
+  const int bm = tile / a.nbn, bn = tile % a.nbn;
+  const int row0 = bm * TB, col0 = bn * TB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+
+  // Operand tiles come through buffer descriptors: one 32-bit per-thread offset per operand, everything else (tile
+  // row, staging register, stage) in the scalar offset; rows past the end read as zero (no clamps, no 64-bit address
+  // arithmetic: 14 fewer registers than eight flat pointers).  The host guarantees the byte extents fit 31 bits.
+  // Thread t's float4 #i of a 256 x 32 tile: row pair_row(t >> 3) + 64 i, columns 4 (t & 7) .. + 3.
+  const int kq = (threadIdx.x & 7) * 4, rq = pair_row(threadIdx.x >> 3);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, (short)0, (int)((((int64_t)a.M - 1) * a.lda + ((a.K + 3) & ~3)) * 4), 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, (short)0, (int)((((int64_t)a.N - 1) * a.ldb + ((a.K + 3) & ~3)) * 4), 0x00020000);
+  const int vA = (rq * (int)a.lda + kq) * 4, vB = (rq * (int)a.ldb + kq) * 4;
+  const int sA0 = row0 * (int)a.lda * 4, sB0 = col0 * (int)a.ldb * 4;
+  const int stepA = 64 * (int)a.lda * 4, stepB = 64 * (int)a.ldb * 4;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define SPGNN_LDA(I_, K0_) __builtin_amdgcn_raw_buffer_load_b128(rsA, vA, sA0 + (I_) * stepA + (K0_) * 4, 0)
+#define SPGNN_LDB(I_, K0_) __builtin_amdgcn_raw_buffer_load_b128(rsB, vB, sB0 + (I_) * stepB + (K0_) * 4, 0)
+  const int woff = rq * PITCH + kq;                            // LDS store offset (halves) of staging register 0
+#define SPGNN_CVT(IMG0_, R_, I_, S_)                                                                         \
+  {                                                                                                          \
+    uint2 h_, l_;                                                                                            \
+    split4_pk(make_float4(__uint_as_float(R_[0]), __uint_as_float(R_[1]), __uint_as_float(R_[2]), __uint_as_float(R_[3])), S_, h_, l_); \
+    *reinterpret_cast<uint2*>((IMG0_) + woff + (I_) * 64 * PITCH) = h_;                                      \
+    *reinterpret_cast<uint2*>((IMG0_) + IMG + woff + (I_) * 64 * PITCH) = l_;                                \
+  }
+#define SPGNN_MASK(R_, K0_)                                                                                  \
+  {                                                                                                          \
+    const int k_ = (K0_) + kq;                                                                               \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+      R_[q_][0] = k_ + 0 < a.K ? R_[q_][0] : 0u; R_[q_][1] = k_ + 1 < a.K ? R_[q_][1] : 0u;                  \
+      R_[q_][2] = k_ + 2 < a.K ? R_[q_][2] : 0u; R_[q_][3] = k_ + 3 < a.K ? R_[q_][3] : 0u;                  \
+    }                                                                                                        \
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  u32x4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ra[i] = SPGNN_LDA(i, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rb[i] = SPGNN_LDB(i, 0);
+  SPGNN_MASK(ra, 0)
+  SPGNN_MASK(rb, 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) SPGNN_CVT(smem, ra[i], i, sA)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) SPGNN_CVT(smem + 2 * IMG, rb[i], i, sB)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ra[i] = SPGNN_LDA(i, BK);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rb[i] = SPGNN_LDB(i, BK);
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // stage T_: MFMAs on buffer PAR_; the register set (stage T_+1) is converted into the other buffer, one float4 per
+  // six MFMAs, and each register is refilled with stage T_+2 as soon as it is free (loads past K or past the last
+  // row return in-bounds garbage or zeros; the tail stages mask beyond K).  STEADY_ as in the kernel above.
+#define SPGNN_STAGE3(T_, PAR_, STEADY_)                                                                      \
+  {                                                                                                          \
+    const _Float16* cb = smem + (PAR_) * STAGE;                                                              \
+    _Float16* nbuf = smem + (1 - (PAR_)) * STAGE;                                                            \
+    const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
+    if (!(STEADY_) && has_next) {                                                                            \
+      SPGNN_MASK(ra, ((T_) + 1) * BK)                                                                        \
+      SPGNN_MASK(rb, ((T_) + 1) * BK)                                                                        \
+    }                                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
+      half8 bh[2], bl[2];                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+        const int off = (wn * 64 + j * 32 + fr) * PITCH + ks * 16 + fh * 8;                                  \
+        bh[j] = *reinterpret_cast<const half8*>(cb + 2 * IMG + off);                                         \
+        bl[j] = *reinterpret_cast<const half8*>(cb + 3 * IMG + off);                                         \
+      }                                                                                                      \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                        \
+        half8 ah[2], al[2];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+          const int off = (wm * 128 + (2 * h + i) * 32 + fr) * PITCH + ks * 16 + fh * 8;                     \
+          ah[i] = *reinterpret_cast<const half8*>(cb + off);                                                 \
+          al[i] = *reinterpret_cast<const half8*>(cb + IMG + off);                                           \
+        }                                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 12; ++c) {                   /* product-major over four tiles */ \
+          const int pr = c >> 2, i = (c >> 1) & 1, j = c & 1;                                                \
+          acc[2 * h + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], \
+                                                                     acc[2 * h + i][j], 0, 0, 0);            \
+          if (has_next && c % 6 == 5) {                                                                      \
+            /* pin the slot: hipcc otherwise hoists the first multiply of every staging register to the top of */ \
+            /* the stage and waits vmcnt(0) there - for loads that were issued moments ago                      */ \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            const int slot = ks * 4 + h * 2 + c / 6;                       /* 8 slots = 4 A + 4 B registers */ \
+            const int k2 = ((T_) + 2) * BK;                                                                  \
+            if (slot < 4) {                                                                                  \
+              SPGNN_CVT(nbuf, ra[slot], slot, sA)                                                            \
+              ra[slot] = SPGNN_LDA(slot, k2);                                                                \
+            } else {                                                                                         \
+              SPGNN_CVT(nbuf + 2 * IMG, rb[slot - 4], slot - 4, sB)                                          \
+              rb[slot - 4] = SPGNN_LDB(slot - 4, k2);                                                        \
+            }                                                                                                \
+          }                                                                                                  \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+  const int nfull = a.K / BK;
+  int t = 0;
+  for (; t + 3 < nfull; t += 2) {                                 // stages t+1 .. t+3 lie wholly below K
+    SPGNN_STAGE3(t, 0, 1)
+    SPGNN_STAGE3(t + 1, 1, 1)
+  }
+  for (; t + 1 < nk; t += 2) {
+    SPGNN_STAGE3(t, 0, 0)
+    SPGNN_STAGE3(t + 1, 1, 0)
+  }
+  if (t < nk) SPGNN_STAGE3(t, 0, 0)
+#undef SPGNN_STAGE3
+#undef SPGNN_LDA
+#undef SPGNN_LDB
+#undef SPGNN_CVT
+#undef SPGNN_MASK
+
+  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
+}
+
+// A phase-skewed form of this kernel (the two waves of every SIMD one phase apart - R: fragment reads + wait, M: twelve
+// MFMAs with the conversions between them - so that one of them is always in its MFMA cluster; eight barriers per stage,
+// s_setprio / sched_barrier fences to keep hipcc from moving MFMAs across them) was written, verified bit-identical and
+// measured in one process against this one: 578 vs 572 us on the 1063 -> 1024 product, equal everywhere else.  The
+// barrier drain is not what holds the kernel at ~45 % MFMA-busy; removed again.
 
 // -------------------------------------------------------------------------------------------------
 //   Operands already in split form ("planes"): hi = fp16(s x), lo = fp16(s x - hi) as two row-major fp16
@@ -1153,8 +1324,11 @@ __global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __res
 
 extern "C" {
 
+#ifndef SPGNN_NT_V3
+#define SPGNN_NT_V3 1      // 0: never pick the 256 x 256 kernel by itself (A/B builds)
+#endif
 static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
-int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 4) g_gemm_variant = v; return old; }
+int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 5) g_gemm_variant = v; return old; }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
@@ -1191,6 +1365,24 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
     // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
+    // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones when the tiles fill whole rounds
+    // over the 256 CUs, and lose to the larger quantisation otherwise (measured at M = 76 410: N = 1024 / 1063, 4.67 /
+    // 5.84 rounds, win 12 % / 3 %; N = 768 / 512, 3.50 / 2.34 rounds, lose 7 % / 10 %): take it when at most 8 % of the
+    // last round is idle.  Offsets inside that kernel are 32-bit.
+    const bool fits31 = M * lda * 4 < (int64_t(1) << 31) && N * ldb * 4 < (int64_t(1) << 31);
+    const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
+    const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3;
+    if (fits31 && (g_gemm_variant == 5 || (g_gemm_variant == 2 && SPGNN_NT_V3 && v3_wins))) {
+      gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
+                   (int)((M + 255) / 256), (int)((N + 255) / 256), upd_u, upd_u_stride, upd_v, upd_v_stride,
+                   (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0};
+      int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
+      const size_t lds_bytes = 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16);       // 160 KB
+      static bool attr3 = false;
+      if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr3 = true; }
+      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v3, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
+      return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+    }
     const int WM = g_gemm_variant == 4 ? 4 : (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,

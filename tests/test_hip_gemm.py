@@ -38,6 +38,36 @@ def test_gemm_tn_exact_on_integers_and_accurate_on_random(R, M, N):
     assert rel_err(c, ref) < max(3 * rel_err(a.t() @ b, ref), 2e-6)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (300, 200, 1063), (513, 257, 39), (700, 512, 64), (256, 256, 96), (257, 1030, 100)])
+def test_gemm_nt_256x256_kernel(M, N, K):
+    """gemm_nt_f16x3_v3 (256 x 256 tiles, buffer-descriptor loads, one staging set) forced on every shape: bit-identical
+    to the 256 x 128 kernel - same split, same products, same summation order per output element - with every epilogue
+    option (rank-J update, bias, activation, score partials)."""
+    from spgnn_amd import _capi
+    lib = _capi.load()
+    a, b = _mat(M, K), _mat(N, K, 0.05)
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    u, v = torch.randn(M, 4, device="cuda"), torch.randn(4, (N + 3) // 4 * 4, device="cuda")
+    v[:, N:] = 0
+    bias = torch.randn(N, device="cuda")
+    kw = dict(upd_u=u, upd_v=v, bias=bias, act=ops.ACT_ELU)
+    C = N // 64 * 64
+    sc = [torch.zeros(M, max(C // 64, 1), 2, device="cuda") for _ in range(2)]
+    if C:
+        kw.update(score_l=torch.randn(C, device="cuda"), score_r=torch.randn(C, device="cuda"))
+    old = lib.spgnn_gemm_set_variant(4)                       # 256 x 128 tiles
+    try:
+        ref, ref2 = ops.gemm_nt(a, b, sa, sb), ops.gemm_nt(a, b, sa, sb, **kw, **({"score_out": sc[0]} if C else {}))
+        lib.spgnn_gemm_set_variant(5)                         # 256 x 256 tiles
+        out, out2 = ops.gemm_nt(a, b, sa, sb), ops.gemm_nt(a, b, sa, sb, **kw, **({"score_out": sc[1]} if C else {}))
+        ai, bi = _mat(M, K, ints=True), _mat(N, K, ints=True)
+        exact = ops.gemm_nt(ai, bi)
+    finally:
+        lib.spgnn_gemm_set_variant(old)
+    assert torch.equal(out, ref) and torch.equal(out2, ref2) and torch.equal(sc[0], sc[1])
+    assert torch.equal(exact, ai @ bi.t())
+
+
 def test_gemm_scaling_keeps_extreme_magnitudes():
     """Values far outside fp16's range (1e-9 .. 1e+7) survive through the power-of-two scales."""
     for mag_a, mag_b in [(1e-9, 1e-3), (1e7, 1e3), (1e-12, 1e6)]:

@@ -13,7 +13,7 @@ def t_once(fn, iters=6):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
-for (K, N) in [(1063, 1024), (768, 512), (384, 1024), (384, 256), (512, 768), (1024, 384), (256, 384)]:
+for (K, N) in [(1063, 1024), (1024, 1063), (768, 512), (384, 1024), (384, 256), (512, 768), (1024, 384), (256, 384)]:
     Kp4 = (K + 3) // 4 * 4
     x = torch.randn(M, Kp4, device=dev)[:, :K]; w = (torch.randn(N, Kp4, device=dev) * 0.05)[:, :K]
     sx, sw = ops.pow2_scale(x), ops.pow2_scale(w)
