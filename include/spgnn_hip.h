@@ -341,6 +341,18 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
                          const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                          const float* bias, int32_t activation, spgnn_stream_t stream);
 
+/* Weight preparation of a projection layer in one pass.  The reference multiplies by fc.weight and res_fc.weight
+ * separately (DGL GATConv: self.fc(h), self.res_fc(h); models.py:301-314 call sites); here both share one GEMM, whose B
+ * operand is dst = [a ; b] (rows_a + rows_b rows of K columns, row stride dst_stride >= K with the pad columns zeroed,
+ * 16-byte rows).  dst_t (nullable) receives the transpose (K rows, row stride dst_t_stride >= rows_a + rows_b, pad
+ * columns zeroed): the B operand of the input-gradient product.  absmax_partials gets
+ * spgnn_weight_cat_partials(rows_a + rows_b, K, dst_stride, dst_t ? dst_t_stride : 0) block maxima of |w| for
+ * spgnn_scale_from_partials.  rows_b may be 0 (b ignored). */
+int spgnn_weight_cat(const float* a, int64_t a_stride, int32_t rows_a, const float* b, int64_t b_stride, int32_t rows_b, int32_t K,
+                     float* dst, int64_t dst_stride, float* dst_t, int64_t dst_t_stride, float* absmax_partials,
+                     spgnn_stream_t stream);
+int64_t spgnn_weight_cat_partials(int32_t rows, int32_t K, int64_t dst_stride, int64_t dst_t_stride);
+
 /* scale[0] = 2^(14 - e) with factor * max_i partials[i] <= 2^e: turns the partial maxima emitted by
  * spgnn_scores_fwd / spgnn_gat_bwd_dst / spgnn_gat_bwd_src (which stream the tensors anyway) into a GEMM scale. */
 int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale,

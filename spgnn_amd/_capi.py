@@ -61,6 +61,8 @@ SIGNATURES = {
     "spgnn_gemm_set_variant": [_i32],
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
+    "spgnn_weight_cat": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _f32p, _i64, _f32p, _i64, _f32p, _vp],
+    "spgnn_weight_cat_partials": [_i32, _i32, _i64, _i64],
     "spgnn_tree_distance_encoding": [_i32p, _i32p, _vp, _i32p, _i32, _f32p, _i64, _i32p, _i64, _i64, _vp],
     "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
 }
@@ -89,7 +91,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name == "spgnn_cat_dropout_blocks" else C.c_int
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials") else C.c_int
     ver = lib.spgnn_abi_version()
     if ver != ABI_VERSION:
         raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")

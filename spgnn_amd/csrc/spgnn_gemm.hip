@@ -1256,6 +1256,44 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
     }
 }
 
+// Weight preparation for a projection layer in ONE pass: the rows of A (ra x K) then B (rb x K) -> dst (ra + rb rows,
+// row stride ldd >= K, pad columns zeroed: 16-byte rows for the GEMMs), optionally the transpose dst_t (K rows, row
+// stride ldt >= ra + rb, pad columns zeroed: the B operand of the input-gradient product), and one |max| partial per
+// block for the tensor's GEMM scale.  32 x 32 tiles through LDS so both images are written in whole row segments.
+// (Replaces torch.cat + F.pad + slice + absmax per layer and step, and the transposing copy in the backward pass.)
+__global__ __launch_bounds__(256) void weight_cat_kernel(const float* __restrict__ A, int64_t lda, int ra,
+                                                         const float* __restrict__ B, int64_t ldb, int rb, int K,
+                                                         float* __restrict__ dst, int64_t ldd, float* __restrict__ dst_t,
+                                                         int64_t ldt, float* __restrict__ partial) {
+  __shared__ float tile[32][33];
+  __shared__ float red[4];
+  const int R = ra + rb;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < K) v = r < ra ? A[(int64_t)r * lda + c] : B[(int64_t)(r - ra) * ldb + c];
+    tile[ty + 8 * i][tx] = v;
+    if (r < R && c < ldd) dst[(int64_t)r * ldd + c] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  __syncthreads();
+  if (dst_t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;                   // dst_t[c][r] = tile[r - r0][c - c0]
+      if (c < K && r < ldt) dst_t[(int64_t)c * ldt + r] = tile[tx][ty + 8 * i];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // absmax -> power-of-two scale that puts the largest magnitude at 2^14 (fp16 max is 2^16): scale[0] = 2^(14 - ceil(log2 max))
 // one partial maximum per block (no atomics: deterministic, no contention); rows must be 16-byte aligned
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int cols,
@@ -1499,6 +1537,27 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     }
   }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_weight_cat(const float* a, int64_t a_stride, int32_t rows_a, const float* b, int64_t b_stride, int32_t rows_b, int32_t K,
+                     float* dst, int64_t dst_stride, float* dst_t, int64_t dst_t_stride, float* absmax_partials,
+                     spgnn_stream_t stream) {
+  const int64_t R = (int64_t)rows_a + rows_b;
+  if (rows_a <= 0 || rows_b < 0 || K <= 0) return SPGNN_ERR_SHAPE;
+  if (!a || !dst || !absmax_partials || (rows_b > 0 && !b)) return SPGNN_ERR_NULLPTR;
+  if (a_stride < K || (rows_b > 0 && b_stride < K) || dst_stride < K || (dst_t && dst_t_stride < R)) return SPGNN_ERR_STRIDE;
+  const int64_t wide = dst_stride > K ? dst_stride : K;             // tiles cover dst's pad columns and dst_t's pad columns
+  const int64_t tall = dst_t && dst_t_stride > R ? dst_t_stride : R;
+  const dim3 grid((unsigned)((wide + 31) / 32), (unsigned)((tall + 31) / 32));
+  hipLaunchKernelGGL(gemm::weight_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, a_stride, (int)rows_a, b, b_stride,
+                     (int)rows_b, (int)K, dst, dst_stride, dst_t, dst_t_stride, absmax_partials);
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int64_t spgnn_weight_cat_partials(int32_t rows, int32_t K, int64_t dst_stride, int64_t dst_t_stride) {
+  const int64_t wide = dst_stride > K ? dst_stride : K;
+  const int64_t tall = dst_t_stride > rows ? dst_t_stride : rows;
+  return ((wide + 31) / 32) * ((tall + 31) / 32);
 }
 
 int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t cols, float* scale, float* workspace,

@@ -129,18 +129,25 @@ class GATConv(nn.Module):
         act = _act_code(self.activation)
         fuse_epilogue = act is not None and not identity_res
         w_fc = self.fc.weight
-        w_cat = torch.cat([w_fc, self.res_fc.weight], dim=0) if has_res else w_fc
-        if w_cat.shape[1] % 4:                          # 16-byte rows for the matrix-core GEMM (e.g. 1063 -> 1064)
-            w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
         fuse_mean = mean_heads and fuse_epilogue
         agg_first = (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
                      and ops.agg_first_supported(H, h.shape[1]))
+        w_cat = None
+        if not agg_first:                               # [W_fc ; W_res]: one projection GEMM reads the input once for both
+            if h.is_cuda and ops.GEMM_MODE == "f16x3":
+                # one kernel: both row blocks into 16-byte rows (e.g. 1063 -> 1064), the transpose for the input
+                # gradient (not for a data input) and the split-GEMM scale
+                w_cat = ops.weight_cat(w_fc, self.res_fc.weight if has_res else None, want_t=h.requires_grad)
+            else:
+                w_cat = torch.cat([w_fc, self.res_fc.weight], dim=0) if has_res else w_fc
+                if w_cat.shape[1] % 4:
+                    w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         if SCORES_FROM_FT and not agg_first and ops.scores_from_ft_supported(h, w_cat, D):
             # el / er from ft in the projection GEMM's epilogue (DGL's own formulation): ops._GATLayerScoresFromFtFn
-            out, attn = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l[0], self.attn_r[0],
+            out, attn = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l, self.attn_r,
                                                      self.bias if fuse_epilogue else None, H, D, has_res,
                                                      float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p,
                                                      seed, mean=fuse_mean)

@@ -560,6 +560,54 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+class _WeightCat(torch.autograd.Function):
+    """[w_a ; w_b] (rows of fc.weight, then of res_fc.weight) as ONE GEMM operand with 16-byte rows, its transpose (the
+    operand of the input-gradient product) and its split-GEMM scale: one kernel + the scale kernel per layer and step
+    (spgnn_weight_cat) instead of cat, pad, slice, absmax and a transposing copy.  Backward: the two row ranges of the
+    incoming gradient as views - no kernels."""
+
+    @staticmethod
+    def forward(ctx, w_a, w_b, want_t: bool):
+        R1, K = w_a.shape
+        R2 = 0 if w_b is None else w_b.shape[0]
+        R, Kp, Rp = R1 + R2, (K + 3) // 4 * 4, (R1 + R2 + 3) // 4 * 4
+        wa = w_a if w_a.stride(1) == 1 else w_a.contiguous()
+        wb = None if w_b is None else (w_b if w_b.stride(1) == 1 else w_b.contiguous())
+        buf = torch.empty((R, Kp), dtype=torch.float32, device=w_a.device)
+        buf_t = torch.empty((K, Rp), dtype=torch.float32, device=w_a.device) if want_t else None
+        lib = _capi.load()
+        nb = lib.spgnn_weight_cat_partials(R, K, Kp, Rp if want_t else 0)
+        part = torch.empty((nb,), dtype=torch.float32, device=w_a.device)
+        with torch.cuda.device(w_a.device):
+            _capi.check(lib.spgnn_weight_cat(wa.data_ptr(), wa.stride(0), R1, _ptr(wb), 0 if wb is None else wb.stride(0), R2, K,
+                                             buf.data_ptr(), Kp, _ptr(buf_t), Rp if want_t else 0, part.data_ptr(),
+                                             _stream(w_a)), "spgnn_weight_cat")
+        scale = scale_from_partials(part)
+        ctx.rows = (R1, R2)
+        out = buf[:, :K]
+        outs = (out, scale) + ((buf_t[:, :R],) if want_t else ())
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        R1, R2 = ctx.rows
+        if g is None:
+            return None, None, None
+        return g[:R1], (g[R1:] if R2 else None), None
+
+
+def weight_cat(w_a: torch.Tensor, w_b: Optional[torch.Tensor] = None, want_t: bool = True) -> torch.Tensor:
+    """-> w_cat (R, K) view of a 16-byte-row buffer; carries ``_spgnn_scale`` (its GEMM scale) and, with ``want_t``,
+    ``_spgnn_t`` = w_cat^T (K, R) with 16-byte rows."""
+    _require_cuda(w_a, w_b)
+    outs = _WeightCat.apply(w_a, w_b, want_t)
+    w = outs[0]
+    w._spgnn_scale = (w._version, outs[1])
+    w._spgnn_t = outs[2] if want_t else None
+    return w
+
+
 def cat_padded(tensors) -> torch.Tensor:
     return _CatPad.apply(*tensors)
 
@@ -574,7 +622,7 @@ class _GATLayerFn(torch.autograd.Function):
         split = GEMM_MODE == "f16x3" and _rows_aligned(x) and _rows_aligned(w_cat) and x.shape[0] > 0
         if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
             s, sx = scores_fwd(x, w_lr, want_scale=True)   # (N, 2H) = [el | er]; the scale of x comes for free
-            sw = pow2_scale(w_cat)
+            sw = operand_scale(w_cat)                      # attached by weight_cat, else one absmax pass
             y = gemm_nt(x, w_cat, sx, sw)
         else:
             sx = sw = None
@@ -586,6 +634,7 @@ class _GATLayerFn(torch.autograd.Function):
                                           mean=mean, need_out=(act != ACT_NONE))
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
+        ctx.w_t = getattr(w_cat, "_spgnn_t", None)     # W^T with 16-byte rows, written by weight_cat alongside W
         ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx, sw)
         ctx.mark_non_differentiable(attn)
         return (out_mean if mean else out), attn
@@ -631,7 +680,7 @@ class _GATLayerFn(torch.autograd.Function):
             Kp = (K + 3) // 4 * 4                      # 16-byte rows for the vector kernels downstream
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
             if split:
-                w_t = w_cat.t().contiguous()           # (K, C): the input gradient is an NT product with W^T
+                w_t = ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous()   # (K, C): an NT product with W^T
                 J = g_s.shape[1]
                 if J <= 32:                            # + g_S @ W_lr as an exact fp32 rank-2H update in the epilogue
                     w_lr_p = _padded_rows(w_lr, _pad16(K))
@@ -670,7 +719,9 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         N = x.shape[0]
         if sx is None:
             sx = pow2_scale(x)
-        sw = pow2_scale(w_cat)
+        sw = operand_scale(w_cat)                  # attached by weight_cat, else one absmax pass
+        ctx.w_t = getattr(w_cat, "_spgnn_t", None)
+        ctx.attn_shape = attn_l.shape              # (H, D) or the parameter's own (1, H, D): no select / stack autograd nodes
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
         y = gemm_nt(x, w_cat, sx, sw, score_l=al, score_r=ar, score_out=parts)
@@ -719,13 +770,13 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         g_al = g_ar = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             m = scores_bwd_w(g_s, y[:, :HD])                     # (2H, HD): row h x head-h block = g_attn_l[h], row H+h = g_attn_r[h]
-            g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)])
-            g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)])
+            g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
+            g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
         g_x = None
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
-            gemm_nt(g_y, w_cat.t().contiguous(), sg, sw, out=g_x)
+            gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=g_x)
         return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None
 
 
