@@ -2,6 +2,7 @@
 configs' full layer widths on a few synthetic trees, plus size-independent properties at the
 BASELINE batch size (512 trees)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -259,3 +260,47 @@ def test_fused_masked_ce_matches_cross_entropy(N, C):
     ref_t = torch.nn.functional.cross_entropy(lt[mask], y[mask], weight=w)
     ref_t.backward()
     assert rel_err(loss, ref_t) < 1e-6 and rel_err(logits.grad, lt.grad) < 1e-5
+
+
+# ---- the N > 1 step as HIP-graph replays: two processes on the one GPU, gloo carrying the CUDA tensors ----------------
+def _dp_graph_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from spgnn_amd import models, synthetic
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_config("st_pgat_spgnn_3")
+    out = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = models.build_model(cfg.MODEL).cuda()
+        model.init(None); model.set_gcn_only(); model.eval()          # deterministic arithmetic: replay == eager
+        g = synthetic.make_batch(3, rank=rank, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+        ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), 1.0, 0.05, 0.9, seed=5)   # sampling rate 1: no draws
+        if mode == "eager":
+            losses = [float(ts.step(g)) for _ in range(5)]
+        else:
+            ts.capture(g, warmup=2)                                   # two eager steps, then three replays
+            losses = [float(ts.replay()) for _ in range(3)]
+        out[mode] = (losses, ts.bucket.flat_param[:ts.bucket.numel].detach().cpu().clone())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_two_rank_graph_replay_equals_two_rank_eager():
+    """TrainStep.capture with world_size 2: the front graph, the eager all-reduces, the back graph.  Both ranks end
+    with the same parameters, equal to those of five eagerly issued 2-rank steps (RCCL is replaced by gloo here: two
+    ranks cannot share one GPU under RCCL; the graphs and their hand-over are what is tested)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_graph_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        le, pe = ret[r]["eager"]
+        lg, pg = ret[r]["graph"]
+        assert all(np.isfinite(le)) and all(np.isfinite(lg))
+        assert np.allclose(le[2:], lg, rtol=1e-5), (le, lg)
+        assert torch.allclose(pe, pg, rtol=1e-5, atol=1e-7)
+    assert torch.equal(ret[0]["graph"][1], ret[1]["graph"][1])      # replicas stay identical
