@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 17
+#define SPGNN_ABI_VERSION 18
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -340,6 +340,10 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
                          const float* scale_a, const float* scale_b,
                          const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                          const float* bias, int32_t activation, spgnn_stream_t stream);
+
+/* out[i] = sum over s < splits of partials[s * split_stride + i], i < n (n % 4 == 0, 16-byte aligned): the deterministic
+ * reduction of the split-K partial tiles of spgnn_gemm_tn and spgnn_scores_bwd_w (fixed summation order). */
+int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream);
 
 /* Weight preparation of a projection layer in one pass.  The reference multiplies by fc.weight and res_fc.weight
  * separately (DGL GATConv: self.fc(h), self.res_fc(h); models.py:301-314 call sites); here both share one GEMM, whose B

@@ -1256,6 +1256,43 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
     }
 }
 
+// out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
+// score-weight gradients).  One float4 per thread; SL threads share a float4 and take every SL-th split (fixed order,
+// folded through LDS), so a reduction over thousands of small partials still fills the chip.
+template <int SL>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int64_t stride4, int S, int64_t n4,
+                                                           float* __restrict__ out) {
+  constexpr int QB = 256 / SL;
+  __shared__ float4 red[256];
+  const int q = threadIdx.x % QB, l = threadIdx.x / QB;
+  const int64_t i = (int64_t)blockIdx.x * QB + q;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = reinterpret_cast<const float4*>(part) + i;
+    int s = l;
+    for (; s + 3 * SL < S; s += 4 * SL) {
+      const float4 a = p[(int64_t)s * stride4], b = p[(int64_t)(s + SL) * stride4], c = p[(int64_t)(s + 2 * SL) * stride4],
+                   d = p[(int64_t)(s + 3 * SL) * stride4];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    for (; s < S; s += SL) { const float4 a = p[(int64_t)s * stride4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+  }
+  if (SL > 1) {
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (l == 0 && i < n4) {
+#pragma unroll
+      for (int k = 1; k < SL; ++k) { const float4 a = red[k * QB + q]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+      reinterpret_cast<float4*>(out)[i] = acc;
+    }
+  } else if (i < n4) {
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
 // Weight preparation for a projection layer in ONE pass: the rows of A (ra x K) then B (rb x K) -> dst (ra + rb rows,
 // row stride ldd >= K, pad columns zeroed: 16-byte rows for the GEMMs), optionally the transpose dst_t (K rows, row
 // stride ldt >= ra + rb, pad columns zeroed: the B operand of the input-gradient product), and one |max| partial per
@@ -1536,6 +1573,22 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                          (hipStream_t)stream, a);
     }
   }
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream) {
+  if (splits <= 0 || n < 0 || (n & 3) || (split_stride & 3) || split_stride < n) return SPGNN_ERR_SHAPE;
+  if (n == 0) return SPGNN_OK;
+  if (!partials || !out) return SPGNN_ERR_NULLPTR;
+  if ((reinterpret_cast<uintptr_t>(partials) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return SPGNN_ERR_STRIDE;
+  const int64_t n4 = n / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (splits <= 8)
+    hipLaunchKernelGGL(gemm::sum_partials_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
+  else if (splits <= 128)
+    hipLaunchKernelGGL(gemm::sum_partials_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
+  else
+    hipLaunchKernelGGL(gemm::sum_partials_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

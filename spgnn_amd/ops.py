@@ -207,6 +207,24 @@ def _pad16(k: int) -> int:
 _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-block reduction resets after each use
 
 
+_NO_SUM_PARTIALS = os.environ.get("SPGNN_NO_SUM_PARTIALS", "0") == "1"      # A/B switch: torch's reduction instead
+
+
+def sum_partials(part: torch.Tensor) -> torch.Tensor:
+    """part (S, ...) contiguous -> part.sum(0) in a fixed order, one launch that fills the chip for any S
+    (torch's reduction took 16-47 us on the thousands of small score-gradient partials)."""
+    S = part.shape[0]
+    n = part[0].numel()
+    if S == 1:
+        return part[0]
+    if n % 4 or not part.is_contiguous() or part.data_ptr() % 16 or _NO_SUM_PARTIALS:
+        return part.sum(0)
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        _capi.check(_capi.load().spgnn_sum_partials(part.data_ptr(), n, S, n, out.data_ptr(), _stream(part)), "spgnn_sum_partials")
+    return out
+
+
 def scale_from_partials(partials: torch.Tensor, factor: float = 1.0) -> torch.Tensor:
     """Device scalar 2^(14 - e), factor * max(partials) <= 2^e (see pow2_scale)."""
     scale = torch.empty(1, dtype=torch.float32, device=partials.device)
@@ -301,7 +319,7 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         _capi.check(_capi.load().spgnn_scores_bwd_w(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0),
                                                     part.data_ptr(), splits, Kp, N, K, J, _stream(x)),
                     "spgnn_scores_bwd_w")
-    return part.sum(0)[:, :K]
+    return sum_partials(part)[:, :K]
 
 
 def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor, accumulate: bool = True) -> None:
@@ -1155,7 +1173,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
         _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
                                                M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), cs_ptr, ldc, M * ldc,
                                                _stream(a)), "spgnn_gemm_tn")
-    out = part[0] if splits == 1 else part.sum(0)
+    out = sum_partials(part)
     if want_colsum:
         return out[:, :N], out[:, ldn]
     return out[:, :N]

@@ -169,3 +169,13 @@ def test_linear_on_matrix_cores_matches_torch(N, K, C, act):
     y2 = ops.linear(x.detach(), wt.t())
     y2.sum().backward()
     assert rel_err(y2, x.detach().double() @ wt.detach().double()) < 2e-6 and wt.grad.shape == (K, C)
+
+
+@pytest.mark.parametrize("S,shape", [(2, (8, 12)), (7, (130, 36)), (32, (64, 68)), (128, (22, 1024)), (1000, (4, 512)), (3, (5, 7))])
+def test_sum_partials(S, shape):
+    """spgnn_sum_partials (the split-K partial-tile reduction) against an fp64 sum; run-to-run bitwise reproducible."""
+    part = torch.randn((S,) + shape, device="cuda")
+    out = ops.sum_partials(part)
+    ref = part.double().sum(0)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1e-6
+    assert torch.equal(out, ops.sum_partials(part))
