@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
