@@ -1159,12 +1159,14 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(64, 512 // tiles, R // 256))
-    if tiles >= 48 and R >= 32 * 512:
-        # More tiles than one XCD can hold at once (2 x 32 workgroups): with few splits every XCD ends up streaming a
-        # whole operand (PMC: 2.7-5.3x the algorithmic bytes, profiles/r01_pmc_gemm_l2_lds.md).  32 splits = 4 per
-        # XCD, each split's rows fetched into one L2 only (by_xcd placement needs splits % 8 == 0); measured
-        # (tools/tn_splits.py, 1024 x 1063, incl. the partial-sum reduction): 7 splits 847 us, 16: 743, 32: 701, 64: 732.
-        splits = 32
+    if splits >= 8 or tiles >= 16:
+        # A split count that is a multiple of 8 gives every split to ONE XCD (by_xcd placement in the kernel): its rows
+        # are fetched into one L2 only.  With few splits and more tiles than an XCD holds at once (2 x 32 workgroups)
+        # every XCD ends up streaming a whole operand (PMC: 2.7-5.3x the algorithmic bytes, profiles/r01_pmc_gemm_l2_lds.md).
+        # Measured incl. the partial-sum reduction (tools/tn_splits.py, R = 76 410): 1024 x 1063 (72 tiles) 7 splits
+        # 748 us, 16: 630, 32: 599, 64: 656; 1024 x 384 and 512 x 768 (24 tiles) 21: 235 / 224, 32: 216 / 209;
+        # 256 x 256 (4 tiles) 32: 81, 64: 54.
+        splits = 32 if tiles >= 16 and R >= 32 * 512 else (splits // 8 * 8 if splits >= 8 else splits)
     ldn = (N + 3) // 4 * 4
     ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
