@@ -16,7 +16,7 @@ fe, wr = rows(O + "/fetch", "FETCH_SIZE"), rows(O + "/write", "WRITE_SIZE")
 assert len(fe) == len(wr)
 # gemm_driver.py launch order per shape (K, C): nt(x, w) then tn(g, x), twice each; shapes (1063,1024), (768,512), (192,4096)
 keys = []
-for (K, C) in [(1063, 1024), (768, 512), (192, 4096)]:
+for (K, C) in [(1063, 1024), (768, 512), (192, 4096), (384, 1024)]:
     keys += [f"gemm_nt_76410_{C}_{K}", f"gemm_tn_76410_{C}_{K}"] * 2
 out = {}
 with open(O + "/summary.md", "w") as fp:
