@@ -179,3 +179,23 @@ def test_sum_partials(S, shape):
     ref = part.double().sum(0)
     assert out.shape == ref.shape and rel_err(out, ref) < 1e-6
     assert torch.equal(out, ops.sum_partials(part))
+
+
+@pytest.mark.parametrize("R1,R2,K", [(512, 512, 1063), (256, 0, 39), (64, 64, 128), (5, 3, 7), (1024, 1024, 192)])
+def test_weight_cat(R1, R2, K):
+    """spgnn_weight_cat: [w_a; w_b] with 16-byte rows, its transpose, its GEMM scale - against cat / t() / pow2_scale -
+    and the row-range views its autograd backward hands to the two parameters."""
+    wa = torch.randn(R1, K, device="cuda", requires_grad=True)
+    wb = torch.randn(R2, K, device="cuda", requires_grad=True) if R2 else None
+    w = ops.weight_cat(wa, wb, want_t=True)
+    ref = torch.cat([wa, wb], 0) if R2 else wa
+    assert torch.equal(w, ref.detach()) and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
+    buf = w._base if w._base is not None else w
+    assert float(buf[:, K:].abs().sum()) == 0.0                                  # pad columns are zero
+    wt = w._spgnn_t
+    assert torch.equal(wt, ref.detach().t()) and wt.stride(0) % 4 == 0
+    assert float(ops.operand_scale(w)) == float(ops.pow2_scale(ref.detach().contiguous() if K % 4 == 0 else
+                                                               torch.nn.functional.pad(ref.detach(), (0, -K % 4))))
+    g = torch.randn(R1 + R2, K, device="cuda")
+    w.backward(g)
+    assert torch.equal(wa.grad, g[:R1]) and (wb is None or torch.equal(wb.grad, g[R1:]))
