@@ -1621,13 +1621,38 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
   const int kfull = K & ~15;
   // main loop: straight-line body (one X load, NG W loads, 4 NG MFMAs), unrolled so that several row loads are in flight
-#pragma unroll 4
-  for (int k0 = 0; k0 < kfull; k0 += 16) {
-    const float4 xa = rv ? ld4(xp + k0) : z4;
-    amx = absmax4(amx, xa);
+  // Loads are unconditional: rows past N and columns past J read row 0 / column 0 (valid memory) and only feed
+  // outputs that are never stored.  A per-lane test around a load (or around the absmax update) is a branch to hipcc:
+  // the loop was not unrolled and every trip waited vmcnt(0) for its own three loads - one load in flight per wave.
+  // Now four k16 steps per trip, all twelve loads issued before the first MFMA.
+  const float rvf = rv ? 1.f : 0.f;
+  int k0 = 0;
+  for (; k0 + 64 <= kfull; k0 += 64) {
+    float4 xa[4], wb[NG][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xa[u] = ld4(xp + k0 + 16 * u);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wb[g][u] = ld4(wp[g] + k0 + 16 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      amx = fmaxf(amx, rvf * fmaxf(fmaxf(fabsf(xa[u].x), fabsf(xa[u].y)), fmaxf(fabsf(xa[u].z), fabsf(xa[u].w))));
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].x, wb[g][u].x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].y, wb[g][u].y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].z, wb[g][u].z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].w, wb[g][u].w, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  for (; k0 < kfull; k0 += 16) {
+    const float4 xa = ld4(xp + k0);
+    amx = fmaxf(amx, rvf * fmaxf(fmaxf(fabsf(xa.x), fabsf(xa.y)), fmaxf(fabsf(xa.z), fabsf(xa.w))));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const float4 wb = wv[g] ? ld4(wp[g] + k0) : z4;
+      const float4 wb = ld4(wp[g] + k0);
       acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
       acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
       acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
@@ -1689,20 +1714,24 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
   if (full && n + 4 <= n1) {           // 4 rows per trip, the next trip's rows already in flight while this one is summed
     const float* xr = X + n * ldx + k;
     float4 x0 = ld4(xr), x1 = ld4(xr + ldx), x2 = ld4(xr + 2 * ldx), x3 = ld4(xr + 3 * ldx);
-    for (; n + 4 <= n1; n += 4) {
-      const float4 c0 = x0, c1 = x1, c2 = x2, c3 = x3;
-      if (n + 8 <= n1) {
-        const float* xn = X + (n + 4) * ldx + k;
-        x0 = ld4(xn); x1 = ld4(xn + ldx); x2 = ld4(xn + 2 * ldx); x3 = ld4(xn + 3 * ldx);
-      }
-      const float* g = gS + n * ldg;   // wave-uniform addresses: scalar loads
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        if (j < jn) {
-          fma4(acc[j], g[j], c0); fma4(acc[j], g[ldg + j], c1); fma4(acc[j], g[2 * ldg + j], c2); fma4(acc[j], g[3 * ldg + j], c3);
-        }
-      }
+#define SPGNN_SBW_FMA(C0, C1, C2, C3)                                                                          \
+    {                                                                                                          \
+      const float* g = gS + n * ldg;   /* wave-uniform addresses: scalar loads */                              \
+      _Pragma("unroll") for (int j = 0; j < J; ++j) {                                                          \
+        if (j < jn) {                                                                                          \
+          fma4(acc[j], g[j], C0); fma4(acc[j], g[ldg + j], C1); fma4(acc[j], g[2 * ldg + j], C2); fma4(acc[j], g[3 * ldg + j], C3); \
+        }                                                                                                      \
+      }                                                                                                        \
     }
+    for (; n + 8 <= n1; n += 4) {      // steady state: the prefetch is unconditional (a test around it made hipcc drain the queue)
+      const float4 c0 = x0, c1 = x1, c2 = x2, c3 = x3;
+      const float* xn = X + (n + 4) * ldx + k;
+      x0 = ld4(xn); x1 = ld4(xn + ldx); x2 = ld4(xn + 2 * ldx); x3 = ld4(xn + 3 * ldx);
+      SPGNN_SBW_FMA(c0, c1, c2, c3)
+    }
+    SPGNN_SBW_FMA(x0, x1, x2, x3)      // last full trip
+    n += 4;
+#undef SPGNN_SBW_FMA
   }
   for (; n < n1; ++n) {
     const float* xr = X + n * ldx + k;
