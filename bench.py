@@ -73,6 +73,11 @@ def algorithmic_bytes(key) -> float:
     if name == "act_bwd":            # read g_out [and out]; write g_pre
         _, N, H, D, act, mean = key
         return 4 * N * (D if mean else H * D) + 4 * N * H * D * (2 if act else 1)
+    if name == "act_bwd_proj":       # read g_logits and out; write g_pre (the classifier's input gradient stays in registers)
+        _, N, H, D, act, J = key
+        return 4 * N * H * D * (2 if act else 1) + 4 * N * J + 4 * J * D
+    if name == "sum_partials":
+        return 0.0
     if name == "scores_from_parts":      # read the (N, H*D/64, 2) partials, write (N, 2H)
         _, N, H, D = key
         return 4 * 2 * N * H * (D // 64) + 4 * 2 * N * H

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 18
+#define SPGNN_ABI_VERSION 19
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -195,6 +195,17 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                   const float* out, int64_t out_stride,
                   float* g_pre, int64_t g_pre_stride, float* absmax,
                   int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+
+/* spgnn_act_bwd for a mean-over-heads output layer that feeds a skinny Linear (the reference's classifier
+ * `gnn_out = nn.Linear(node_embed_dim, out_ch)`, models.py:1125, on the head mean of models.py:482), with that
+ * Linear's input gradient formed on the fly instead of written by spgnn_scores_bwd_x and re-read:
+ *   g_pre[v, h*D + c] = (1/H) * (sum_j g_s[v, j] * w[j, c]) * act'(out[v, h*D + c]),  j < J <= 32, H <= 4, D <= 1024.
+ * absmax_partials receives spgnn_act_bwd_proj_blocks(N) block maxima of |g_pre| (for spgnn_scale_from_partials).
+ * `out` may be NULL when activation == SPGNN_ACT_NONE. */
+int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                       int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
+                       int32_t D, int32_t activation, spgnn_stream_t stream);
+int32_t spgnn_act_bwd_proj_blocks(int64_t N);
 
 /*
  * Layer-input assembly of the hidden SPGNN layers, dropout(cat[h_s, h_p]) (reference models.py:477-481 + GATConv's

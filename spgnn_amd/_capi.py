@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -57,6 +57,8 @@ SIGNATURES = {
     "spgnn_sample_neighbors": [_i32p, _i32p, _i32p, _i64, _vp, _i64, _i32, _i32p, _u64, _i32p, _i32p, _i32p, _i32p, _vp],
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],
     "spgnn_head_mean": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _vp],
+    "spgnn_act_bwd_proj": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
+    "spgnn_act_bwd_proj_blocks": [_i64],
     "spgnn_act_bwd": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
     "spgnn_gemm_set_variant": [_i32],
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _vp],

@@ -1200,6 +1200,86 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
   }
 }
 
+// act_bwd with the classifier's input gradient formed on the fly (mean-over-heads output layer followed by a skinny
+// Linear, reference models.py:1125 `gnn_out`):
+//   g_pre[v, h*D + c] = (1/H) * (sum_j gS[v, j] * W[j, c]) * act'(out[v, h*D + c])
+// i.e. spgnn_scores_bwd_x (g_mean = g_logits W, written) + spgnn_act_bwd (g_mean re-read) in one pass: g_mean never
+// exists in memory.  A thread owns four columns and keeps their W entries in registers (J float4); a block walks a row
+// range, two rows per trip with all loads issued first; gS rows are wave-uniform (scalar loads); one |max| per block.
+template <int JP>
+__global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restrict__ gS, int64_t ldg, int J,
+                                                           const float* __restrict__ W, int64_t ldw,
+                                                           const float* __restrict__ out, int64_t out_ld,
+                                                           float* __restrict__ g_pre, int64_t gp_ld, float* __restrict__ absmax,
+                                                           int64_t N, int64_t rows_per_block, int H, int D, int act) {
+  __shared__ float red[4];
+  const int c = threadIdx.x * 4;
+  const bool cv = c < D;
+  const int cc = cv ? c : 0;
+  float4 w[JP];
+#pragma unroll
+  for (int j = 0; j < JP; ++j) {
+    const float4 q = ld4(W + (int64_t)(j < J ? j : 0) * ldw + cc);
+    w[j] = j < J ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float inv_h = 1.f / (float)H;
+  const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
+  float mx = 0.f;
+  constexpr int HMAX = 4;
+  // the row of gS is fetched by ONE vector load (lane j holds gS[row, j]) issued with the row's other loads and
+  // broadcast by v_readlane: scalar loads would each expose their latency (and spilled 88 SGPRs with two rows in flight)
+  const int jl = (threadIdx.x & 63) < J ? (threadIdx.x & 63) : 0;
+#define SPGNN_ABP_GM(GM, GV)                                                                                 \
+  {                                                                                                          \
+    GM = make_float4(0.f, 0.f, 0.f, 0.f);                                                                    \
+    _Pragma("unroll") for (int j = 0; j < JP; ++j)                                                           \
+      if (j < J) fma4(GM, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GV), j)), w[j]);           \
+    GM.x *= inv_h; GM.y *= inv_h; GM.z *= inv_h; GM.w *= inv_h;                                              \
+  }
+#define SPGNN_ABP_OUT(GM, O, ROW, HH)                                                                        \
+  {                                                                                                          \
+    float4 q = GM;                                                                                           \
+    if (act != SPGNN_ACT_NONE) {                                                                             \
+      q.x *= act_bwd_from_out(O.x, act); q.y *= act_bwd_from_out(O.y, act);                                  \
+      q.z *= act_bwd_from_out(O.z, act); q.w *= act_bwd_from_out(O.w, act);                                  \
+    }                                                                                                        \
+    if (cv) { st4(g_pre + (ROW) * gp_ld + (int64_t)(HH) * D + c, q); mx = absmax4(mx, q); }                  \
+  }
+  int64_t n = n0;
+  for (; n + 2 <= n1; n += 2) {
+    float4 o0[HMAX], o1[HMAX];
+    if (act != SPGNN_ACT_NONE) {
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if (h < H) { o0[h] = ld4(out + n * out_ld + (int64_t)h * D + cc); o1[h] = ld4(out + (n + 1) * out_ld + (int64_t)h * D + cc); }
+    }
+    const float gv0 = gS[n * ldg + jl], gv1 = gS[(n + 1) * ldg + jl];
+    float4 gm0, gm1;
+    SPGNN_ABP_GM(gm0, gv0)
+    SPGNN_ABP_GM(gm1, gv1)
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) { SPGNN_ABP_OUT(gm0, o0[h], n, h) SPGNN_ABP_OUT(gm1, o1[h], n + 1, h) }
+  }
+  for (; n < n1; ++n) {
+    const float gv = gS[n * ldg + jl];
+    float4 gm;
+    SPGNN_ABP_GM(gm, gv)
+    for (int h = 0; h < H; ++h) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act != SPGNN_ACT_NONE) o = ld4(out + n * out_ld + (int64_t)h * D + cc);
+      SPGNN_ABP_OUT(gm, o, n, h)
+    }
+  }
+#undef SPGNN_ABP_GM
+#undef SPGNN_ABP_OUT
+  mx = team_max(mx, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) absmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // =================================================================================================
 // Score-vector folding: w_lr[h,:] = sum_d attn_l[h,d] * W[h*D+d,:], w_lr[H+h,:] likewise with attn_r - the (2H, K)
 // weights of the skinny score projection (and their gradients), as two small kernels instead of a dozen
@@ -2273,6 +2353,36 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
                      (hipStream_t)stream, g_out, g_out_stride, mean_heads ? 1 : 0, out, out_stride, g_pre, g_pre_stride, absmax,
                      N, H, D, activation);
   return check_launch("spgnn_act_bwd");
+}
+
+int32_t spgnn_act_bwd_proj_blocks(int64_t N) {
+  int64_t b = (N + 31) / 32;                         // >= 32 rows per block: the block's W slice (J x 4 KB) is read once per block
+  if (b > 1536) b = 1536;
+  return (int32_t)(b < 1 ? 1 : b);
+}
+
+int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                       int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
+                       int32_t D, int32_t activation, spgnn_stream_t stream) {
+  if (N < 0 || H <= 0 || H > 4 || D <= 0 || D % 4 || D > 1024 || J <= 0 || J > 32)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_proj: bad N/H/D/J (H <= 4, D % 4 == 0, D <= 1024, J <= 32)");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_proj: activation");
+  if (N == 0) return SPGNN_OK;
+  if (!g_s || !w || !g_pre || !absmax_partials || (activation != SPGNN_ACT_NONE && !out))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_proj: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (g_s_stride < J || w_stride < D || g_pre_stride < HD || (activation != SPGNN_ACT_NONE && out_stride < HD))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_proj: row stride smaller than row");
+  if (!vec_ok(w, w_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_proj: rows must be 16-byte aligned");
+  const int32_t blocks = spgnn_act_bwd_proj_blocks(N);
+  const int64_t rpb = (N + blocks - 1) / blocks;
+  hipStream_t st = (hipStream_t)stream;
+#define X(JP) hipLaunchKernelGGL(act_bwd_proj_kernel<JP>, dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, (int)J, w, w_stride, \
+                                 out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation)
+  if (J <= 8) X(8); else if (J <= 16) X(16); else if (J <= 24) X(24); else X(32);
+#undef X
+  return check_launch("spgnn_act_bwd_proj");
 }
 
 int spgnn_fold_scores_fwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r, float* w_lr,

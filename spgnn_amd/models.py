@@ -127,11 +127,16 @@ class GAT(nn.Module):
     def _finish(self, h):
         return F.normalize(h, p=2, dim=1) if self.norm else h
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))`` with the classifier
+        joined to the output layer's autograd node (not with ``norm``: the normalisation sits in between)."""
         h = g.ndata["fvs"]
         for layer in self.gat_layers[:-1]:
             h = layer(g, h).flatten(1)
-        return self._finish(self.gat_layers[-1](g, h, mean_heads=True))
+        if classifier is not None and not self.norm:
+            return self.gat_layers[-1](g, h, mean_heads=True, classifier=classifier)
+        h = self._finish(self.gat_layers[-1](g, h, mean_heads=True))
+        return h if classifier is None else (h, classifier(h))
 
     def forward_batch(self, blocks, x):
         h = x
@@ -196,7 +201,9 @@ class GATPSPGNN(nn.Module):
         for layer in list(self.gat_layers) + list(self.pgnn_layers):
             layer.reset_parameters()
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h_s, h_p, classifier(h_s))`` with the
+        classifier joined to the output layer's autograd node."""
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
             if l == 0:
@@ -207,6 +214,9 @@ class GATPSPGNN(nn.Module):
             xp, dropped = (_data_aligned(g, h_p), False) if l == 0 else _drop_for(p_layer, h_p)
             h_p = p_layer(g, xp, feat_dropped=dropped).flatten(1)
         x, dropped = _cat_for(self.gat_layers[-1], h_s, h_p)
+        if classifier is not None:
+            h_s, logits = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
+            return h_s, h_p, logits
         h_s = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped)
         return h_s, h_p
 
@@ -233,7 +243,7 @@ class GATPSPGNNNL(nn.Module):
         for layer in self.gat_layers:
             layer.reset_parameters()
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         for l, layer in enumerate(self.gat_layers[:-1]):
             if l == 0:
@@ -242,6 +252,9 @@ class GATPSPGNNNL(nn.Module):
                 x, dropped = _cat_for(layer, h_s, h_p)
             h_s = layer(g, x, feat_dropped=dropped).flatten(1)
         x, dropped = _cat_for(self.gat_layers[-1], h_s, h_p)
+        if classifier is not None:
+            h_s, logits = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
+            return h_s, h_p, logits
         h_s = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped)
         return h_s, h_p
 
@@ -437,8 +450,8 @@ class GATNet(_GraphNetBase):
         self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
-        n_embed = self.gat(g)
-        return self.gnn_out(n_embed), n_embed
+        n_embed, n_out = self.gat(g, classifier=self.gnn_out)
+        return n_out, n_embed
 
     def forward_emb(self, g):
         n_embed = self.gat(g)
@@ -519,8 +532,8 @@ class GATPositionSPGNNNet(_GraphNetBase):
         self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
-        n_embed, n_p_embed = self.gat(g)
-        return self.gnn_out(n_embed), n_embed, n_p_embed
+        n_embed, n_p_embed, n_out = self.gat(g, classifier=self.gnn_out)
+        return n_out, n_embed, n_p_embed
 
     def forward_emb(self, g):
         return self.gat(g)

@@ -61,6 +61,7 @@ def _draw_seed() -> int:
 SCORES_FROM_FT = os.environ.get("SPGNN_SCORES_FROM_FT", "1") != "0"  # A/B switch: el/er from ft in the GEMM epilogue vs folded weights
 FOLD_KERNEL = os.environ.get("SPGNN_FOLD", "1") != "0"             # A/B switch: score folding by spgnn_fold_scores_* vs einsum
 AGGREGATE_FIRST = os.environ.get("SPGNN_AGG_FIRST", "1") != "0"    # A/B switch for the aggregate-first layer form
+FUSE_CLASSIFIER = os.environ.get("SPGNN_FUSE_CLS", "1") != "0"     # A/B switch: classifier joined to the output layer's node
 
 
 class GATConv(nn.Module):
@@ -113,11 +114,27 @@ class GATConv(nn.Module):
         self._allow_zero_in_degree = set_value
 
     def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False,
-                feat_dropped: bool = False):
+                feat_dropped: bool = False, classifier: Optional[nn.Linear] = None):
         """DGL signature; ``mean_heads=True`` (extension) returns ``rst.mean(1)`` (N, D) with the mean fused
         into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482).
         ``feat_dropped=True`` (extension): the caller already applied this layer's feature dropout while assembling
-        ``feat`` (ops.cat_dropout fuses it into the concatenation)."""
+        ``feat`` (ops.cat_dropout fuses it into the concatenation).
+        ``classifier`` (extension, with ``mean_heads``): an ``nn.Linear`` applied to the head mean (the reference's
+        ``gnn_out(n_embed)``, models.py:1127-1130); the layer then returns ``(rst, classifier(rst))`` and, in the
+        aggregate-first form, back-propagates through both in one node (ops._GATAggFirstFn)."""
+        if classifier is not None:
+            if not mean_heads or get_attention:
+                raise ValueError("classifier= needs mean_heads=True and get_attention=False")
+            return self._forward_with_classifier(graph, feat, feat_dropped, classifier)
+        return self._forward(graph, feat, get_attention, mean_heads, feat_dropped, None)
+
+    def _forward_with_classifier(self, graph, feat, feat_dropped, classifier):
+        res = self._forward(graph, feat, False, True, feat_dropped, classifier)
+        if isinstance(res, tuple):
+            return res
+        return res, classifier(res)
+
+    def _forward(self, graph, feat, get_attention, mean_heads, feat_dropped, classifier):
         csc = graph.csc(feat.device)
         if not self._allow_zero_in_degree and csc.min_in_degree == 0:
             raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
@@ -160,6 +177,13 @@ class GATConv(nn.Module):
                               torch.einsum("hd,hdk->hk", self.attn_r[0], w3)], dim=0)
         if agg_first:
             # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)
+            fuse_cls = (FUSE_CLASSIFIER and classifier is not None and fuse_mean and classifier.out_features <= 32
+                        and classifier.in_features == D and getattr(csc, "num_dst", None) is None)
+            if fuse_cls:
+                out, attn, logits = ops.gat_layer_agg_first(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr,
+                                                            self.bias, H, D, float(self.negative_slope), act, p, seed,
+                                                            mean=True, w_cls=classifier.weight, b_cls=classifier.bias)
+                return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, False), logits
             out, attn = ops.gat_layer_agg_first(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D,
                                                 float(self.negative_slope), act, p, seed, mean=fuse_mean)
         else:

@@ -869,15 +869,36 @@ def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, ac
     return g_pre, amax
 
 
+def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int):
+    """act_bwd of a mean-over-heads layer whose mean feeds a skinny Linear (weight ``w`` (J, D)), with that Linear's
+    input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), block maxima of |g_pre|)."""
+    N, J = g_s.shape
+    lib = _capi.load()
+    g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_s.device)
+    part = torch.empty((lib.spgnn_act_bwd_proj_blocks(N),), dtype=torch.float32, device=g_s.device)
+    with torch.cuda.device(g_s.device), _timed("act_bwd_proj", (N, H, D, act, J)):
+        _capi.check(lib.spgnn_act_bwd_proj(g_s.data_ptr(), g_s.stride(0), J, w.data_ptr(), w.stride(0), _ptr(out),
+                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
+                                           part.data_ptr(), N, H, D, act, _stream(g_s)), "spgnn_act_bwd_proj")
+    return g_pre, part
+
+
+def act_bwd_proj_supported(H: int, D: int, J: int, w: torch.Tensor) -> bool:
+    return H <= 4 and D % 4 == 0 and D <= 1024 and J <= 32 and w.stride(1) == 1 and _rows_aligned(w)
+
+
 class _GATAggFirstFn(torch.autograd.Function):
     """GATConv with the projection AFTER the aggregation: out_h = act([z_h | x] @ [W_fc,h | W_res,h]^T + b_h),
     z_h[v] = sum_u a_h(u,v) x[u].  Same function as _GATLayerFn; chosen when the input is narrower than one head's
     output, so that the (N, 2*H*D) projected rows are neither written nor gathered."""
 
     @staticmethod
-    def forward(ctx, x, w_fc, w_res, w_lr, bias, csc: DeviceCSC, H: int, D: int, slope: float, act: int, p_drop: float,
-                seed: int, mean: bool):
-        ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
+    def forward(ctx, x, w_fc, w_res, w_lr, bias, w_cls, b_cls, csc: DeviceCSC, H: int, D: int, slope: float, act: int,
+                p_drop: float, seed: int, mean: bool):
+        """``w_cls`` (J, D) / ``b_cls`` (J,), optional, with ``mean``: the classifier on the head mean (reference
+        ``gnn_out``) joins this node, third output = logits; its input gradient then never exists as a tensor
+        (backward: spgnn_act_bwd_proj)."""
+        ctx.set_materialize_grads(False)       # no zero tensors for the unused gradients of `attn` / mean / logits
         x = _rowmajor(x)
         N, F_ = x.shape
         has_res = w_res is not None
@@ -894,21 +915,49 @@ class _GATAggFirstFn(torch.autograd.Function):
                     bias=bias[h * D:(h + 1) * D] if bias is not None else None, act=act)
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw)
+        rst = head_mean(out, H, D) if mean else out
+        has_cls = w_cls is not None and mean
+        logits = None
+        if has_cls:
+            logits = scores_fwd(rst, w_cls)
+            if b_cls is not None:
+                logits = logits + b_cls
+        ctx.has_cls, ctx.has_cls_bias = has_cls, has_cls and b_cls is not None
+        ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw,
+                              rst if has_cls else None, w_cls if has_cls else None)
         ctx.mark_non_differentiable(attn)
-        return (head_mean(out, H, D) if mean else out), attn
+        if has_cls:
+            return rst, attn, logits
+        empty = x.new_empty(0)
+        ctx.mark_non_differentiable(empty)
+        return rst, attn, empty
 
     @staticmethod
-    def backward(ctx, g_out, _g_attn):
-        if g_out is None:                      # only the (non-differentiable) attention output was used
-            return (None,) * 13
-        x, wc, w_lr, s, attn, z, out, sz, sw = ctx.saved_tensors
+    def backward(ctx, g_out, _g_attn, g_logits):
+        if g_out is None and (g_logits is None or not ctx.has_cls):   # only the (non-differentiable) attention output was used
+            return (None,) * 15
+        x, wc, w_lr, s, attn, z, out, sz, sw, rst, w_cls = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
         N, F_ = x.shape
         E = csc.num_edges
         zs = z.shape[1] // H
-        g_pre, amax = act_bwd(_rowmajor(g_out), out, H, D, act, mean)
+        g_wcls = g_bcls = None
+        if ctx.has_cls and g_logits is not None:
+            g_logits = g_logits.contiguous()
+            if ctx.needs_input_grad[5]:
+                g_wcls = scores_bwd_w(g_logits, rst)
+            if ctx.has_cls_bias and ctx.needs_input_grad[6]:
+                g_bcls = g_logits.sum(0)
+            if g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls):
+                # the usual training case (only the logits reach the loss): g_mean = g_logits W is formed inside act_bwd
+                g_pre, amax = act_bwd_proj(g_logits, w_cls, out, H, D, act)
+            else:
+                g_mean = torch.empty_like(rst) if g_out is None else _rowmajor(g_out).clone()
+                scores_bwd_x_(g_mean, g_logits, w_cls, accumulate=g_out is not None)
+                g_pre, amax = act_bwd(g_mean, out, H, D, act, mean)
+        else:
+            g_pre, amax = act_bwd(_rowmajor(g_out), out, H, D, act, mean)
         sg = scale_from_partials(amax)
         need_w = ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2])
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
@@ -953,14 +1002,19 @@ class _GATAggFirstFn(torch.autograd.Function):
             g_wfc = g_wc[:, :, :F_].reshape(H * D, F_)
             if has_res:
                 g_wres = g_wc[:, :, F_:].reshape(H * D, F_)
-        return (g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, None, None, None, None, None, None, None, None
+        return ((g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, g_wcls, g_bcls, None, None, None, None, None, None,
+                None, None)
 
 
 def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, act: int,
-                        p_drop: float = 0.0, seed: int = 0, mean: bool = False):
-    """Same contract as gat_layer; ``w_fc`` / ``w_res`` (H*D, F) separately (w_res may be None)."""
-    _require_cuda(x, w_fc, w_res, w_lr, bias)
-    return _GATAggFirstFn.apply(x, w_fc, w_res, w_lr, bias, csc, H, D, slope, act, p_drop, seed, mean)
+                        p_drop: float = 0.0, seed: int = 0, mean: bool = False, w_cls=None, b_cls=None):
+    """Same contract as gat_layer; ``w_fc`` / ``w_res`` (H*D, F) separately (w_res may be None).  With ``mean`` and a
+    classifier (``w_cls`` (J, D), ``b_cls``): returns (mean, attn, logits), the classifier fused into the node."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias, w_cls, b_cls)
+    rst, attn, logits = _GATAggFirstFn.apply(x, w_fc, w_res, w_lr, bias, w_cls, b_cls, csc, H, D, slope, act, p_drop, seed, mean)
+    if w_cls is not None and mean:
+        return rst, attn, logits
+    return rst, attn
 
 
 # --------------------------------------------------------------------------------------------

@@ -403,3 +403,22 @@ def test_device_positional_encoding_is_bit_exact():
     assert d2.tolist() == [n - 1, 2]
     assert torch.equal(pe2[:n, 0].cpu(), torch.tensor([(i / (n - 1)) for i in range(n)], dtype=torch.float64).float())
     assert pe2[n:, 1].cpu().tolist() == [0.5] + [1.0] * 4 + [0.0] + [1.0] * (n - 6)
+
+
+@pytest.mark.parametrize("N,H,D,J,act", [(1000, 2, 1024, 22, "elu"), (257, 2, 1024, 22, "none"), (300, 1, 64, 3, "tanh"),
+                                         (129, 4, 256, 32, "relu"), (5, 2, 1000, 9, "elu")])
+def test_act_bwd_with_the_classifier_gradient_formed_on_the_fly(N, H, D, J, act):
+    """spgnn_act_bwd_proj = spgnn_scores_bwd_x (g_mean = g_logits W) followed by spgnn_act_bwd, without g_mean in memory."""
+    from spgnn_amd import ops
+    code = {"none": ops.ACT_NONE, "elu": ops.ACT_ELU, "tanh": ops.ACT_TANH, "relu": ops.ACT_RELU}[act]
+    g_s = torch.randn(N, J, device="cuda")
+    w = torch.randn(J, D, device="cuda") * 0.1
+    pre = torch.randn(N, H * D, device="cuda")
+    out = {"none": pre, "elu": torch.nn.functional.elu(pre), "tanh": torch.tanh(pre), "relu": torch.relu(pre)}[act]
+    g_pre, part = ops.act_bwd_proj(g_s, w, out if code != ops.ACT_NONE else None, H, D, code)
+    g_mean = (g_s.double() @ w.double()) / H
+    dact = {"none": torch.ones_like(pre), "elu": torch.where(pre > 0, torch.ones_like(pre), torch.exp(pre)),
+            "tanh": 1 - torch.tanh(pre) ** 2, "relu": (pre > 0).float()}[act].double()
+    ref = g_mean.repeat(1, H) * dact
+    assert rel_err(g_pre, ref) < 2e-6
+    assert abs(float(part.max()) - float(g_pre.abs().max())) <= 1e-6 * float(g_pre.abs().max())
