@@ -925,11 +925,11 @@ class _GATAggFirstFn(torch.autograd.Function):
         ctx.has_cls, ctx.has_cls_bias = has_cls, has_cls and b_cls is not None
         ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw,
                               rst if has_cls else None, w_cls if has_cls else None)
-        ctx.mark_non_differentiable(attn)
         if has_cls:
+            ctx.mark_non_differentiable(attn)
             return rst, attn, logits
         empty = x.new_empty(0)
-        ctx.mark_non_differentiable(empty)
+        ctx.mark_non_differentiable(attn, empty)       # one call: a second one would replace the first
         return rst, attn, empty
 
     @staticmethod
