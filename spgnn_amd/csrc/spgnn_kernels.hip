@@ -86,13 +86,19 @@ __device__ __forceinline__ void fma4(float4& acc, float s, float4 x) {
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 
+// exp(x) for x <= -0.5 as ONE v_exp_f32 (2^(x log2 e)): __expf expands to a guarded sequence that hipcc wraps in
+// exec-mask branches per element (the same ELU in the GEMM epilogue: ~17 000 instructions of them).  Used for ELU
+// only (result exp(x) - 1 in (-1, -0.39]: the exponent's rounding stays below one ulp of it).  The softmax keeps expf:
+// the one-instruction form there was neutral for the step (6.78 ms either way) and cost 3e-7 of logits parity.
+__device__ __forceinline__ float exp_nb(float x) { return __builtin_amdgcn_exp2f(fmaxf(x * 1.44269504088896341f, -127.f)); }
+
 // expm1 for x <= 0, branch-free and ~4x cheaper than libm's expm1f (the ELU epilogues are VALU-heavy: 120 us of a
 // 400 us GEMM went into it): Taylor polynomial of degree 9 on [-0.5, 0] (truncation 5e-9), exp(x) - 1 below
 // (result in (-1, -0.39]: 2e-7 relative).  Within 2 ulp of expm1f on x <= 0.
 __device__ __forceinline__ float expm1_neg(float x) {
   const float p = x * (1.f + x * (0.5f + x * (1.f / 6 + x * (1.f / 24 + x * (1.f / 120 + x * (1.f / 720 + x * (1.f / 5040 +
                   x * (1.f / 40320 + x * (1.f / 362880)))))))));
-  const float e = __expf(x) - 1.f;
+  const float e = exp_nb(x) - 1.f;
   return x > -0.5f ? p : e;
 }
 __device__ __forceinline__ float elu_fwd(float x) { return x > 0.f ? x : expm1_neg(x); }
