@@ -32,6 +32,7 @@ H, D, F_ = 2, 1024, 192
 x = torch.randn(N, F_, device=dev); s = torch.randn(N, 2 * H, device=dev)
 out = torch.randn(N, H * D, device=dev); g_mean = torch.randn(N, D, device=dev)
 w_lr = torch.randn(2 * H, F_, device=dev)
+g_logits = torch.randn(N, 22, device=dev); w_cls = torch.randn(22, D, device=dev) * 0.03
 from spgnn_amd import _capi
 lib = _capi.load()
 st = torch.cuda.current_stream().cuda_stream
@@ -40,6 +41,7 @@ for _ in range(reps):
     z, attn, amax = ops.gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, 0.2, 0.0, 0, True)
     om = ops.head_mean(out, H, D)
     g_pre, amax_g = ops.act_bwd(g_mean, out, H, D, ops.ACT_ELU, True)
+    g_pre2, amax_g2 = ops.act_bwd_proj(g_logits, w_cls, out, H, D, ops.ACT_ELU)
     g_z = torch.randn_like(z); g_e = torch.empty(E, H, device=dev); g_s = torch.empty_like(s); g_x = torch.empty_like(x)
     with ops._timed("gat_agg_bwd_dst", (N, E, H, F_)):
         _capi.check(lib.spgnn_gat_agg_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0), s.data_ptr(),
@@ -51,6 +53,7 @@ for _ in range(reps):
             w_lr.stride(0), g_x.data_ptr(), g_x.stride(0), g_s.data_ptr(), g_s.stride(0), N, E, H, F_, 0.0, 0, 0, st), "src")
 keys = {k[0]: "_".join(str(v) for v in k) for k in ops.KernelTimer.stop()}
 manifest += [["gat_agg_fwd", keys["gat_agg_fwd"]], ["head_mean", keys["head_mean"]], ["act_bwd", keys["act_bwd"]],
+             ["act_bwd_proj", keys["act_bwd_proj"]],
              ["gat_agg_bwd_dst", keys["gat_agg_bwd_dst"]], ["gat_agg_bwd_src", keys["gat_agg_bwd_src"]]] * reps
 import json
 os.makedirs("gpurun_out", exist_ok=True)

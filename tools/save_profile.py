@@ -15,6 +15,11 @@ if not rf.get("traffic"):                      # the PMC table may be newer than
         rf["traffic"] = json.load(open("profiles/traffic_latest.json")).get("_".join(str(x) for x in [rf["kernel"].replace("spgnn_", "")] + rf["shape"]))
     except Exception:
         pass
+if rh and not rh.get("traffic"):
+    try:
+        rh["traffic"] = json.load(open("profiles/traffic_latest.json")).get("_".join(str(x) for x in [rh["kernel"]] + rh["shape"]))
+    except Exception:
+        pass
 with open(f"profiles/{tag}_kernel_stats_st_pgat_spgnn_3_b512.md", "w") as fp:
     fp.write(f"# rocprofv3 --kernel-trace --stats of bench.py ({tag})\n\n"
              f"Command (MI355X, 1 GPU): `{cmd}`\n\n"
