@@ -20,7 +20,7 @@ O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_gemm'
 rows=[]
 for f in sorted(glob.glob(O+'/p*/**/*counter_collection.csv', recursive=True)):
     df=pd.read_csv(f)
-    df=df[df.Kernel_Name.str.contains('gemm_nt_f16x3_v2|gemm_tn_f16x3_v2')]
+    df=df[df.Kernel_Name.str.contains('gemm_nt_f16x3|gemm_tn_f16x3')]
     g=df.groupby(['Kernel_Name','Grid_Size','Counter_Name'],as_index=False)['Counter_Value'].mean()
     rows.append(g)
 if rows:
