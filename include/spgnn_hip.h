@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 19
+#define SPGNN_ABI_VERSION 20
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -333,6 +333,17 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   const float* bias, int32_t activation,
                   const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                   spgnn_stream_t stream);
+
+/* spgnn_gemm_nt for the SECOND head of a two-head layer whose heads are averaged (the reference's output GATConv,
+ * `.mean(1)` at models.py:327 / 482): besides C = act(A B^T + bias) it writes
+ *   mean_out[row, col] = 0.5 * (C[row, col] + other_head[row, col])
+ * from the tile in registers (other_head = the first head's C, computed by an earlier launch on the same stream), which
+ * replaces spgnn_head_mean's pass over both heads.  Strides % 4 == 0, 16-byte aligned bases. */
+int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
+                           const float* bias, int32_t activation,
+                           const float* other_head, int64_t other_head_stride, float* mean_out, int64_t mean_out_stride,
+                           spgnn_stream_t stream);
 
 /*
  * Split-form ("planes") operands for the projection GEMMs.  spgnn_split_rows writes, once per tensor,

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -38,6 +38,8 @@ SIGNATURES = {
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
                       _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
+    "spgnn_gemm_nt_headmean": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64,
+                               _f32p, _i64, _vp],
     "spgnn_gat_agg_supported": [_i32, _i32],
     "spgnn_gat_agg_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _f32p, _i64, _i64,
                           _i32, _i32, _f32, _f32, _u64, _vp, _vp],

@@ -49,6 +49,9 @@ struct Args {
   // block b of the first sc_cols output columns, sc_out[(row * (sc_cols/64) + b) * 2 + {0,1}] =
   // <C[row, 64b : 64b+64], sc_l / sc_r[64b : 64b+64]>  (raw product, before rank-J / bias / activation)
   const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
+  // optional head mean of a two-head layer (pipelined kernels): mean_out[row, col] = 0.5 * (this tile's final value +
+  // mean_other[row, col]) - the second head's product also writes the mean over heads (replaces a pass over both heads)
+  const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
 };
 
 __device__ __forceinline__ void split4(float4 v, float s, half4& hi, half4& lo) {
@@ -419,6 +422,18 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
           vv[it].x = fmaxf(vv[it].x, 0.f); vv[it].y = fmaxf(vv[it].y, 0.f); vv[it].z = fmaxf(vv[it].z, 0.f); vv[it].w = fmaxf(vv[it].w, 0.f);
         }
       }
+      if (a.mean_out) {
+        const int64_t r0_ = row0 + wm * (32 * MI) + i * 32 + r_in;
+        float4 oo[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) oo[it] = *reinterpret_cast<const float4*>(a.mean_other + (r0_ + it * 4) * a.ld_mo + col);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const float4 m = make_float4(0.5f * (vv[it].x + oo[it].x), 0.5f * (vv[it].y + oo[it].y), 0.5f * (vv[it].z + oo[it].z),
+                                       0.5f * (vv[it].w + oo[it].w));
+          *reinterpret_cast<float4*>(a.mean_out + (r0_ + it * 4) * a.ld_mn + col) = m;
+        }
+      }
       float* dst0 = a.C + (int64_t)(row0 + wm * (32 * MI) + i * 32 + r_in) * a.ldc + col;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
@@ -468,6 +483,13 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
           v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
         } else if (a.act == SPGNN_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (a.mean_out) {
+          const float vq[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q_ = 0; q_ < 4; ++q_)
+            if (col + q_ < a.N)
+              a.mean_out[(int64_t)row * a.ld_mn + col + q_] = 0.5f * (vq[q_] + a.mean_other[(int64_t)row * a.ld_mo + col + q_]);
         }
         float* dst = a.C + (int64_t)row * a.ldc + col;
 #ifdef SPGNN_EPI_NOSTORE                      /* timing-only build: the epilogue without its global stores */
@@ -811,6 +833,7 @@ struct ArgsP {
   const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
   const float* bias; int act;
   const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
+  const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -1500,11 +1523,18 @@ extern "C" {
 static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
 int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 5) g_gemm_variant = v; return old; }
 
-int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                  int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
-                  int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
-                  int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
-                  spgnn_stream_t stream) {
+static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                        int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
+                        int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
+                        int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                        const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
+                        spgnn_stream_t stream) {
+  if (mean_out) {
+    if (!mean_other) return SPGNN_ERR_NULLPTR;
+    if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
+        (reinterpret_cast<uintptr_t>(mean_other) & 15) || (reinterpret_cast<uintptr_t>(mean_out) & 15) || g_gemm_variant == 1)
+      return SPGNN_ERR_STRIDE;
+  }
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
   if (score_out) {
     if (!score_l || !score_r) return SPGNN_ERR_NULLPTR;
@@ -1530,7 +1560,7 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_variant == 1) {
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0};
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
   } else {
@@ -1545,7 +1575,8 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     if (fits31 && (g_gemm_variant == 5 || (g_gemm_variant == 2 && SPGNN_NT_V3 && v3_wins))) {
       gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                    (int)((M + 255) / 256), (int)((N + 255) / 256), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                   (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0};
+                   (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
+                   mean_other, mean_other_stride, mean_out, mean_out_stride};
       int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
       const size_t lds_bytes = 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16);       // 160 KB
       static bool attr3 = false;
@@ -1557,7 +1588,8 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                 (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0};
+                 (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
+                   mean_other, mean_other_stride, mean_out, mean_out_stride};
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
@@ -1571,6 +1603,24 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     }
   }
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                  int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
+                  int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
+                  int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                  spgnn_stream_t stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
+                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, stream);
+}
+
+int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                           int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* bias,
+                           int32_t activation, const float* other_head, int64_t other_head_stride, float* mean_out,
+                           int64_t mean_out_stride, spgnn_stream_t stream) {
+  if (!other_head || !mean_out) return SPGNN_ERR_NULLPTR;
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
+                      nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, stream);
 }
 
 int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
@@ -1613,7 +1663,7 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
   gemm::ArgsP a{reinterpret_cast<const _Float16*>(A_hi), reinterpret_cast<const _Float16*>(A_lo), lda,
                 reinterpret_cast<const _Float16*>(B_hi), reinterpret_cast<const _Float16*>(B_lo), ldb, C, ldc, (int)M, (int)N,
                 (int)Kp, scale_a, scale_b, (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride,
-                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation, nullptr, nullptr, nullptr, 0};
+                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
   size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * 32 * sizeof(_Float16);
   const size_t epi = (size_t)(2 * WM) * 32 * 68 * sizeof(float);               // epilogue slabs share the buffer

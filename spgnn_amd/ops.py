@@ -910,12 +910,19 @@ class _GATAggFirstFn(torch.autograd.Function):
         wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
         sw = pow2_scale(wc.view(H * D, zs))
         out = torch.empty((N, H * D), dtype=torch.float32, device=x.device)
+        fuse_mean = mean and headmean_fusable(out, H, D)
+        rst = None
         for h in range(H):
-            gemm_nt(z[:, h * zs:(h + 1) * zs], wc[h], sz, sw, out=out[:, h * D:(h + 1) * D],
-                    bias=bias[h * D:(h + 1) * D] if bias is not None else None, act=act)
+            bh_ = bias[h * D:(h + 1) * D] if bias is not None else None
+            if fuse_mean and h == 1:                   # the second head's tiles also write 0.5 * (head 0 + head 1)
+                rst = torch.empty((N, D), dtype=torch.float32, device=x.device)
+                gemm_nt_headmean(z[:, zs:2 * zs], wc[1], sz, sw, out[:, D:2 * D], out[:, :D], rst, bias=bh_, act=act)
+            else:
+                gemm_nt(z[:, h * zs:(h + 1) * zs], wc[h], sz, sw, out=out[:, h * D:(h + 1) * D], bias=bh_, act=act)
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
-        rst = head_mean(out, H, D) if mean else out
+        if rst is None:
+            rst = head_mean(out, H, D) if mean else out
         has_cls = w_cls is not None and mean
         logits = None
         if has_cls:
@@ -1203,6 +1210,29 @@ def gemm_nt_planes(a: Planes, b: Planes, out: Optional[torch.Tensor] = None, upd
                                                       upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
                                                       _ptr(bias), act, _stream(out)), "spgnn_gemm_nt_planes")
     return out
+
+
+def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: torch.Tensor, other: torch.Tensor,
+                     mean_out: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0) -> None:
+    """out = act(a @ b^T + bias) and mean_out = 0.5 * (out + other): the second head's projection of a two-head layer also
+    writes the mean over heads from its tiles (spgnn_gemm_nt_headmean)."""
+    _require_cuda(a, b, out, other, mean_out)
+    M, K = a.shape
+    N = b.shape[0]
+    assert _rows_aligned(a) and _rows_aligned(b) and out.shape == (M, N) and other.shape == (M, N) and mean_out.shape == (M, N)
+    with torch.cuda.device(out.device), _timed("gemm_nt", (M, N, K)):
+        _capi.check(_capi.load().spgnn_gemm_nt_headmean(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                                        out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act,
+                                                        other.data_ptr(), other.stride(0), mean_out.data_ptr(),
+                                                        mean_out.stride(0), _stream(out)), "spgnn_gemm_nt_headmean")
+
+
+def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
+    return (_FUSE_HEADMEAN and H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+            and GEMM_MODE == "f16x3")
+
+
+_FUSE_HEADMEAN = os.environ.get("SPGNN_FUSE_HEADMEAN", "1") != "0"      # A/B switch
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,

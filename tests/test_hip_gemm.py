@@ -199,3 +199,18 @@ def test_weight_cat(R1, R2, K):
     g = torch.randn(R1 + R2, K, device="cuda")
     w.backward(g)
     assert torch.equal(wa.grad, g[:R1]) and (wb is None or torch.equal(wb.grad, g[R1:]))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 384), (257, 128, 96), (4100, 512, 64)])
+def test_gemm_nt_headmean(M, N, K):
+    """spgnn_gemm_nt_headmean: the second head's product also writes 0.5 * (head 0 + head 1); C and the mean are
+    bit-identical to spgnn_gemm_nt followed by the mean, on interior and edge tiles, with bias + ELU."""
+    a, b = _mat(M, K), _mat(N, K, 0.05)
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    bias = torch.randn(N, device="cuda")
+    other = torch.randn(M, N, device="cuda")
+    ref = ops.gemm_nt(a, b, sa, sb, bias=bias, act=ops.ACT_ELU)
+    out, mean = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm_nt_headmean(a, b, sa, sb, out, other, mean, bias=bias, act=ops.ACT_ELU)
+    assert torch.equal(out, ref)
+    assert torch.equal(mean, 0.5 * (ref + other))
