@@ -170,7 +170,7 @@ class GATConv(nn.Module):
                                                      seed, mean=fuse_mean)
             return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
         if FOLD_KERNEL:
-            w_lr = ops.fold_scores(w_fc, self.attn_l[0], self.attn_r[0])
+            w_lr = ops.fold_scores(w_fc, self.attn_l, self.attn_r)
         else:
             w3 = w_fc.view(H, D, -1)
             w_lr = torch.cat([torch.einsum("hd,hdk->hk", self.attn_l[0], w3),

@@ -244,10 +244,11 @@ class _FoldScoresFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, attn_l, attn_r):
-        H, D = attn_l.shape
+        ctx.attn_shape = attn_l.shape           # (H, D) or the parameter's own (1, H, D): no select / zeros / copy autograd nodes
+        H, D = attn_l.shape[-2:]
         K = w.shape[1]
         Kp = _pad16(K)
-        al, ar = attn_l.contiguous(), attn_r.contiguous()
+        al, ar = attn_l.reshape(H, D).contiguous(), attn_r.reshape(H, D).contiguous()
         buf = torch.empty((2 * H, Kp), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _capi.check(_capi.load().spgnn_fold_scores_fwd(w.data_ptr(), w.stride(0), al.data_ptr(), ar.data_ptr(),
@@ -268,7 +269,7 @@ class _FoldScoresFn(torch.autograd.Function):
             _capi.check(_capi.load().spgnn_fold_scores_bwd(w.data_ptr(), w.stride(0), al.data_ptr(), ar.data_ptr(), g.data_ptr(),
                                                            g.stride(0), g_w.data_ptr(), g_w.stride(0), g_al.data_ptr(),
                                                            g_ar.data_ptr(), H, D, K, _stream(w)), "spgnn_fold_scores_bwd")
-        return g_w, g_al, g_ar
+        return g_w, g_al.view(ctx.attn_shape), g_ar.view(ctx.attn_shape)
 
 
 def fold_scores(w_fc: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor) -> torch.Tensor:
