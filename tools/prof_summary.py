@@ -2,7 +2,8 @@
 import glob, re, sys
 import pandas as pd
 d, steps = sys.argv[1], int(sys.argv[2])
-f = glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 df = pd.read_csv(f)
 def cat(n):
     if n.startswith("Cijk"): return "rocblas_gemm"

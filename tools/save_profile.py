@@ -3,7 +3,8 @@ import glob, json, re, shutil, sys
 import pandas as pd
 d, steps, tag, bj = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 cmd = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --no-cpu-baseline"
-f = glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 shutil.copy(f, f"profiles/{tag}_kernel_stats_st_pgat_spgnn_3_b512.csv")
 shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof.json")
 b = json.load(open(bj))
