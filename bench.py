@@ -251,17 +251,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kt_dom = ops.KernelTimer.stop() if (bracket and launch == "eager") else {}
     eager_leg = None
-    if launch != "eager" and bracket and not args.no_eager_leg:
+    if (launch != "eager" or not kt_all) and not args.no_eager_leg and not args.no_kernel_timers:
         # a replay cannot carry HIP events per launch: the dominant kernels' launches are bracketed in eagerly
         # issued steps right after the timed region (same kernels, same operands, same stream)
         n_leg = min(args.steps, 20)
-        ops.KernelTimer.start(only=bracket)
+        ops.KernelTimer.start(only=bracket or None)      # no instrumented warm-up steps (--warmup 0): time every kernel here
         t1 = time.perf_counter()
         for _ in range(n_leg):
             step.step(g)
         sync()
         eager_leg = {"ms_per_step": (time.perf_counter() - t1) / n_leg * 1e3, "steps": n_leg}
         kt_dom = ops.KernelTimer.stop()
+        if not kt_all:
+            kt_all, probe = dict(kt_dom), n_leg
+            hip_keys = [k for k in kt_all if k[0] not in ("gemm_nt", "gemm_tn", "absmax")]
+            dom = max(hip_keys, key=lambda k: sum(kt_all[k])) if hip_keys else None
+            dom_all = max(kt_all, key=lambda k: sum(kt_all[k])) if kt_all else None
     kt = dict(kt_all)
     loss_val = float(loss)
 
@@ -309,8 +314,8 @@ def main():
                                "measured_in": f"{nprobe} instrumented warm-up step(s)"}
             agg = {k: (sum(v) / len(v), sum(v), len(v)) for k, v in kt.items()}
             mp_ms = sum(t for _, t, _ in agg.values()) / nprobe
-            where = ("timed region" if launch == "eager" else
-                     "eagerly issued launches right after the timed region of graph replays") + \
+            where = ("timed region" if (launch == "eager" and eager_leg is None) else
+                     "eagerly issued launches right after the timed region") + \
                     " (HIP events on the launch stream around every launch of this kernel)"
             traffic_tab = {}
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
