@@ -210,6 +210,9 @@ _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-bloc
 _NO_SUM_PARTIALS = os.environ.get("SPGNN_NO_SUM_PARTIALS", "0") == "1"      # A/B switch: torch's reduction instead
 
 
+_TN_MIN_ELEMS = int(os.environ.get("SPGNN_TN_MIN_ELEMS", "16384"))   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
+
+
 def sum_partials(part: torch.Tensor) -> torch.Tensor:
     """part (S, ...) contiguous -> part.sum(0) in a fixed order, one launch that fills the chip for any S
     (torch's reduction took 16-47 us on the thousands of small score-gradient partials)."""
@@ -685,7 +688,7 @@ class _GATLayerFn(torch.autograd.Function):
         g_wcat = None
         if ctx.needs_input_grad[1]:
             # tiny outputs (position stream, 39-wide inputs) leave the 128x128-tile kernel mostly idle: rocBLAS there
-            big = g_y.shape[1] * K >= 128 * 512
+            big = g_y.shape[1] * K >= _TN_MIN_ELEMS
             if split and big:
                 if need_bias and has_res:        # column sums of g_pre ride along with the operand stream
                     g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True)
@@ -778,7 +781,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_bias = g_wcat = None
         if ctx.needs_input_grad[1]:
-            big = g_y.shape[1] * K >= 128 * 512
+            big = g_y.shape[1] * K >= _TN_MIN_ELEMS
             if big:
                 if need_bias and has_res:
                     g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True)
