@@ -173,11 +173,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the message-passing path has no CPU fallback)")
+    # Rehearsal of the N > 1 flow on a one-GPU box: SPGNN_BENCH_REHEARSAL=1 puts every rank on device 0 and moves the
+    # tensors with gloo (RCCL refuses two ranks per device).  Never set by the driver; numbers from it mean nothing.
+    rehearsal = os.environ.get("SPGNN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from spgnn_amd import _capi, models, ops, synthetic
     from spgnn_amd.configs import class_weight_list, get_config
