@@ -795,8 +795,11 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         g_al = g_ar = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             m = scores_bwd_w(g_s, y[:, :HD])                     # (2H, HD): row h x head-h block = g_attn_l[h], row H+h = g_attn_r[h]
-            g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
-            g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
+            if H == 1:                                           # rows 0 and 1 of m are the two gradients: views, no copies
+                g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
+            else:
+                g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
+                g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
         g_x = None
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4
