@@ -593,6 +593,7 @@ class _WeightCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w_a, w_b, want_t: bool):
+        ctx.set_materialize_grads(False)       # no zero tensors for the gradients of the scale / transpose outputs
         R1, K = w_a.shape
         R2 = 0 if w_b is None else w_b.shape[0]
         R, Kp, Rp = R1 + R2, (K + 3) // 4 * 4, (R1 + R2 + 3) // 4 * 4
