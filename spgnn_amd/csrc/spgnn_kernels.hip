@@ -2362,8 +2362,8 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
 }
 
 int32_t spgnn_act_bwd_proj_blocks(int64_t N) {
-  int64_t b = (N + 31) / 32;                         // >= 32 rows per block: the block's W slice (J x 4 KB) is read once per block
-  if (b > 1536) b = 1536;
+  int64_t b = (N + 7) / 8;                           // >= 8 rows per block (the block's W slice, J x 4 KB, is read once per
+  if (b > 1536) b = 1536;                            // block); 6 blocks per CU at large N, enough blocks at N ~ 1e4 too
   return (int32_t)(b < 1 ? 1 : b);
 }
 
