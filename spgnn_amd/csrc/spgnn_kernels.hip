@@ -1296,29 +1296,35 @@ __global__ __launch_bounds__(1024) void fold_scores_fwd(const float* __restrict_
                                                         int D, int K) {
   // fp64 accumulation: these few MFLOP cost nothing, and the scores' gradients downstream are near-total
   // cancellations (softmax is shift-invariant in er up to the LeakyReLU kink), so every ulp here shows there.
-  __shared__ double red[2][16][64];
+  // 16 columns x 64 row groups per block (was 64 columns x 16: 6 blocks for the 192-column output layer, 45 us at any
+  // batch size - a quarter of the launches' time at 64 trees); the weights are L2-resident, 64-byte row pieces do no harm.
+  __shared__ double red[2][64][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y;
-  const int k = blockIdx.x * 64 + lane;
+  const int c = lane & 15, rg = wave * 4 + (lane >> 4);
+  const int k = blockIdx.x * 16 + c;
   double sl = 0.0, sr = 0.0;
   if (k < K) {
-    for (int d0 = wave; d0 < D; d0 += 16 * 8) {
+    for (int d0 = rg; d0 < D; d0 += 64 * 8) {
       float w[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int d = d0 + 16 * i; w[i] = d < D ? W[(int64_t)(h * D + d) * ldw + k] : 0.f; }
+      for (int i = 0; i < 8; ++i) { const int d = d0 + 64 * i; w[i] = d < D ? W[(int64_t)(h * D + d) * ldw + k] : 0.f; }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int d = d0 + 16 * i;
+        const int d = d0 + 64 * i;
         if (d < D) { sl = fma((double)al[h * D + d], (double)w[i], sl); sr = fma((double)ar[h * D + d], (double)w[i], sr); }
       }
     }
   }
-  red[0][wave][lane] = sl; red[1][wave][lane] = sr;
+  red[0][rg][c] = sl; red[1][rg][c] = sr;
   __syncthreads();
-  if (wave < 2 && k < Kp) {                       // fixed summation order: reproducible
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += red[wave][i][lane];
-    out[(int64_t)(wave * H + h) * Kp + k] = k < K ? (float)s : 0.f;
+  if (threadIdx.x < 32) {                         // fixed summation order: reproducible
+    const int which = threadIdx.x >> 4, c2 = threadIdx.x & 15, k2 = blockIdx.x * 16 + c2;
+    if (k2 < Kp) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) s += red[which][i][c2];
+      out[(int64_t)(which * H + h) * Kp + k2] = k2 < K ? (float)s : 0.f;
+    }
   }
 }
 
@@ -2396,7 +2402,7 @@ int spgnn_fold_scores_fwd(const float* W, int64_t w_stride, const float* attn_l,
   if (H <= 0 || D <= 0 || K <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_fold_scores_fwd: bad H/D/K");
   if (!W || !attn_l || !attn_r || !w_lr) return fail(SPGNN_ERR_NULLPTR, "spgnn_fold_scores_fwd: null pointer");
   if (w_stride < K || w_lr_stride < K) return fail(SPGNN_ERR_STRIDE, "spgnn_fold_scores_fwd: row stride smaller than row");
-  hipLaunchKernelGGL(fold_scores_fwd, dim3((unsigned)((w_lr_stride + 63) / 64), (unsigned)H), dim3(1024), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(fold_scores_fwd, dim3((unsigned)((w_lr_stride + 15) / 16), (unsigned)H), dim3(1024), 0, (hipStream_t)stream,
                      W, w_stride, attn_l, attn_r, w_lr, w_lr_stride, H, D, K);
   return check_launch("spgnn_fold_scores_fwd");
 }
