@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 20
+#define SPGNN_ABI_VERSION 21
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -366,6 +366,12 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
 /* out[i] = sum over s < splits of partials[s * split_stride + i], i < n (n % 4 == 0, 16-byte aligned): the deterministic
  * reduction of the split-K partial tiles of spgnn_gemm_tn and spgnn_scores_bwd_w (fixed summation order). */
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream);
+
+/* The same reduction for partial TILES with padded rows (spgnn_gemm_tn: M rows of ld_in >= N floats per split), written
+ * compact: out (M, N) contiguous; extra (nullable, M floats) = the same sum over column extra_col of the partial rows
+ * (the bias column sums that spgnn_gemm_tn lets ride in a spare column). */
+int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int32_t splits, int32_t M, int32_t N, int64_t ld_in,
+                               float* out, float* extra, int32_t extra_col, spgnn_stream_t stream);
 
 /* Weight preparation of a projection layer in one pass.  The reference multiplies by fc.weight and res_fc.weight
  * separately (DGL GATConv: self.fc(h), self.res_fc(h); models.py:301-314 call sites); here both share one GEMM, whose B

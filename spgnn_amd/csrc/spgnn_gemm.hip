@@ -1411,6 +1411,29 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
 }
 
+// The same reduction for the weight-gradient tiles, written COMPACT: out (M, N) contiguous, plus one extra column of the
+// partial rows (the bias column sums that ride in a spare column) as its own vector.  Contiguous gradients are taken
+// over by autograd's accumulation as they are; row-strided views (N + 4 floats per row) were cloned once per parameter.
+__global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride, int S, int M,
+                                                                   int N, int64_t ldi, float* __restrict__ out,
+                                                                   float* __restrict__ extra, int extra_col) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, mn = (int64_t)M * N;
+  int64_t src;
+  float* dst;
+  if (i < mn) { const int64_t r = i / N; src = r * ldi + (i - r * N); dst = out + i; }
+  else if (extra && i < mn + M) { src = (i - mn) * ldi + extra_col; dst = extra + (i - mn); }
+  else return;
+  float acc = 0.f;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    const float a = part[s * stride + src], b = part[(s + 1) * stride + src], c = part[(s + 2) * stride + src],
+                d = part[(s + 3) * stride + src];
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; s < S; ++s) acc += part[s * stride + src];
+  *dst = acc;
+}
+
 // Weight preparation for a projection layer in ONE pass: the rows of A (ra x K) then B (rb x K) -> dst (ra + rb rows,
 // row stride ldd >= K, pad columns zeroed: 16-byte rows for the GEMMs), optionally the transpose dst_t (K rows, row
 // stride ldt >= ra + rb, pad columns zeroed: the B operand of the input-gradient product), and one |max| partial per
@@ -1734,6 +1757,17 @@ int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t spli
     hipLaunchKernelGGL(gemm::sum_partials_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
   else
     hipLaunchKernelGGL(gemm::sum_partials_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int32_t splits, int32_t M, int32_t N, int64_t ld_in,
+                               float* out, float* extra, int32_t extra_col, spgnn_stream_t stream) {
+  if (splits <= 0 || M <= 0 || N <= 0 || ld_in < N || split_stride < (int64_t)M * ld_in || (extra && (extra_col < 0 || extra_col >= ld_in)))
+    return SPGNN_ERR_SHAPE;
+  if (!partials || !out) return SPGNN_ERR_NULLPTR;
+  const int64_t total = (int64_t)M * N + (extra ? M : 0);
+  hipLaunchKernelGGL(gemm::sum_partials_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     partials, split_stride, (int)splits, (int)M, (int)N, ld_in, out, extra, (int)extra_col);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

@@ -1270,7 +1270,13 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
         _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
                                                M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), cs_ptr, ldc, M * ldc,
                                                _stream(a)), "spgnn_gemm_tn")
-    out = sum_partials(part)
+    # compact outputs: (M, N) contiguous and the column sums as their own vector - autograd takes contiguous gradients
+    # over as they are, the row-strided views of the padded tile were cloned once per parameter (18 copies per step)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    cs = torch.empty((M,), dtype=torch.float32, device=a.device) if want_colsum else None
+    with torch.cuda.device(a.device):
+        _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), _ptr(cs),
+                                                            ldn if want_colsum else 0, _stream(a)), "spgnn_sum_partials_compact")
     if want_colsum:
-        return out[:, :N], out[:, ldn]
-    return out[:, :N]
+        return out, cs
+    return out
