@@ -368,10 +368,13 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream);
 
 /* The same reduction for partial TILES with padded rows (spgnn_gemm_tn: M rows of ld_in >= N floats per split), written
- * compact: out (M, N) contiguous; extra (nullable, M floats) = the same sum over column extra_col of the partial rows
- * (the bias column sums that spgnn_gemm_tn lets ride in a spare column). */
+ * where the gradients live: columns [0, N) to out (row stride out_stride), or - with out2 - columns [0, split_col) to
+ * out and [split_col, N) to out2 (the aggregate-first layer's [W_fc,h | W_res,h] gradient goes to the two parameters'
+ * row blocks directly); extra (nullable, M floats) = the same sum over column extra_col of the partial rows (the bias
+ * column sums that spgnn_gemm_tn lets ride in a spare column). */
 int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int32_t splits, int32_t M, int32_t N, int64_t ld_in,
-                               float* out, float* extra, int32_t extra_col, spgnn_stream_t stream);
+                               float* out, int64_t out_stride, float* out2, int64_t out2_stride, int32_t split_col, float* extra,
+                               int32_t extra_col, spgnn_stream_t stream);
 
 /* Weight preparation of a projection layer in one pass.  The reference multiplies by fc.weight and res_fc.weight
  * separately (DGL GATConv: self.fc(h), self.res_fc(h); models.py:301-314 call sites); here both share one GEMM, whose B

@@ -66,7 +66,7 @@ SIGNATURES = {
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
     "spgnn_sum_partials": [_f32p, _i64, _i32, _i64, _f32p, _vp],
-    "spgnn_sum_partials_compact": [_f32p, _i64, _i32, _i32, _i32, _i64, _f32p, _f32p, _i32, _vp],
+    "spgnn_sum_partials_compact": [_f32p, _i64, _i32, _i32, _i32, _i64, _f32p, _i64, _f32p, _i64, _i32, _f32p, _i32, _vp],
     "spgnn_weight_cat": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _f32p, _i64, _f32p, _i64, _f32p, _vp],
     "spgnn_weight_cat_partials": [_i32, _i32, _i64, _i64],
     "spgnn_tree_distance_encoding": [_i32p, _i32p, _vp, _i32p, _i32, _f32p, _i64, _i32p, _i64, _i64, _vp],

@@ -1415,13 +1415,17 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // partial rows (the bias column sums that ride in a spare column) as its own vector.  Contiguous gradients are taken
 // over by autograd's accumulation as they are; row-strided views (N + 4 floats per row) were cloned once per parameter.
 __global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride, int S, int M,
-                                                                   int N, int64_t ldi, float* __restrict__ out,
+                                                                   int N, int64_t ldi, float* __restrict__ out, int64_t ldo,
+                                                                   float* __restrict__ out2, int64_t ldo2, int split_col,
                                                                    float* __restrict__ extra, int extra_col) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, mn = (int64_t)M * N;
   int64_t src;
   float* dst;
-  if (i < mn) { const int64_t r = i / N; src = r * ldi + (i - r * N); dst = out + i; }
-  else if (extra && i < mn + M) { src = (i - mn) * ldi + extra_col; dst = extra + (i - mn); }
+  if (i < mn) {
+    const int64_t r = i / N; const int c = (int)(i - r * N);
+    src = r * ldi + c;
+    dst = (out2 && c >= split_col) ? out2 + r * ldo2 + (c - split_col) : out + r * ldo + c;
+  } else if (extra && i < mn + M) { src = (i - mn) * ldi + extra_col; dst = extra + (i - mn); }
   else return;
   float acc = 0.f;
   int s = 0;
@@ -1761,13 +1765,17 @@ int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t spli
 }
 
 int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int32_t splits, int32_t M, int32_t N, int64_t ld_in,
-                               float* out, float* extra, int32_t extra_col, spgnn_stream_t stream) {
+                               float* out, int64_t out_stride, float* out2, int64_t out2_stride, int32_t split_col, float* extra,
+                               int32_t extra_col, spgnn_stream_t stream) {
   if (splits <= 0 || M <= 0 || N <= 0 || ld_in < N || split_stride < (int64_t)M * ld_in || (extra && (extra_col < 0 || extra_col >= ld_in)))
     return SPGNN_ERR_SHAPE;
   if (!partials || !out) return SPGNN_ERR_NULLPTR;
+  if (out2 ? (split_col <= 0 || split_col >= N || out_stride < split_col || out2_stride < N - split_col) : out_stride < N)
+    return SPGNN_ERR_STRIDE;
   const int64_t total = (int64_t)M * N + (extra ? M : 0);
   hipLaunchKernelGGL(gemm::sum_partials_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     partials, split_stride, (int)splits, (int)M, (int)N, ld_in, out, extra, (int)extra_col);
+                     partials, split_stride, (int)splits, (int)M, (int)N, ld_in, out, out_stride, out2, out2_stride, (int)split_col,
+                     extra, (int)extra_col);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

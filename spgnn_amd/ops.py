@@ -428,17 +428,21 @@ class _MaskedCE(torch.autograd.Function):
                                                      sampling_p.data_ptr(), class_weight.data_ptr(), part.data_ptr(), _ptr(g),
                                                      C, N, C, _stream(logits)), "spgnn_masked_ce")
         ctx.save_for_backward(g)
-        return part.sum(0)
+        ctx.set_materialize_grads(False)
+        s = part.sum(0)
+        num, den = s[0], s[1]                   # two outputs: indexing ONE output outside would add a select node whose
+        ctx.mark_non_differentiable(den)        # backward is a zero fill + a copy
+        return num, den
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_num, _g_den):
         (g,) = ctx.saved_tensors
-        return (g * g_out[0] if g is not None else None), None, None, None, None
+        return (g * g_num if (g is not None and g_num is not None) else None), None, None, None, None
 
 
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: torch.Tensor, sampling_p: torch.Tensor,
-                   class_weight: torch.Tensor) -> torch.Tensor:
-    """-> tensor [sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]], m = draws < sampling_p (reference job_runner.py:1896-1900)."""
+                   class_weight: torch.Tensor):
+    """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900)."""
     _require_cuda(logits, labels, draws, sampling_p, class_weight)
     assert labels.dtype == torch.int64 and logits.dtype == torch.float32
     return _MaskedCE.apply(logits, labels.contiguous(), draws.contiguous(), sampling_p.contiguous(), class_weight.contiguous())
@@ -977,16 +981,16 @@ class _GATAggFirstFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2])
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_z = torch.empty_like(z)
-        g_wc = torch.empty_like(wc) if need_w else None
+        g_wfc = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if need_w else None
+        g_wres = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if (need_w and has_res) else None
         g_bias = torch.empty((H * D,), dtype=torch.float32, device=x.device) if need_bias else None
         for h in range(H):
             gp_h = g_pre[:, h * D:(h + 1) * D]
             gemm_nt(gp_h, wc[h].t().contiguous(), sg, sw, out=g_z[:, h * zs:(h + 1) * zs])
-            if need_w:
-                if need_bias:
-                    g_wc[h], g_bias[h * D:(h + 1) * D] = gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=True)
-                else:
-                    g_wc[h] = gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz)
+            if need_w:                                 # [g_W_fc,h | g_W_res,h] (D, 2F) straight into the two parameters' row blocks
+                gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=need_bias, out=g_wfc[h * D:(h + 1) * D],
+                        out2=g_wres[h * D:(h + 1) * D] if has_res else None,
+                        colsum_out=g_bias[h * D:(h + 1) * D] if need_bias else None)
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
         g_s = torch.empty_like(s)
@@ -1012,11 +1016,6 @@ class _GATAggFirstFn(torch.autograd.Function):
                                                       g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
                                                       _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
         g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[3] else None
-        g_wfc = g_wres = None
-        if need_w:
-            g_wfc = g_wc[:, :, :F_].reshape(H * D, F_)
-            if has_res:
-                g_wres = g_wc[:, :, F_:].reshape(H * D, F_)
         return ((g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, g_wcls, g_bcls, None, None, None, None, None, None,
                 None, None)
 
@@ -1244,10 +1243,13 @@ _FUSE_HEADMEAN = os.environ.get("SPGNN_FUSE_HEADMEAN", "1") != "0"      # A/B sw
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
-            scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False):
+            scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
+            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
     over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
-    accumulated from the operand stream the kernel reads anyway."""
+    accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
+    stride): write the result there - with ``out2`` columns [0, out.shape[1]) to ``out`` and the rest to ``out2``;
+    ``colsum_out`` (M,) contiguous likewise for the column sums."""
     _require_cuda(a, b)
     R, M = a.shape
     N = b.shape[1]
@@ -1272,11 +1274,17 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
                                                _stream(a)), "spgnn_gemm_tn")
     # compact outputs: (M, N) contiguous and the column sums as their own vector - autograd takes contiguous gradients
     # over as they are, the row-strided views of the padded tile were cloned once per parameter (18 copies per step)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    cs = torch.empty((M,), dtype=torch.float32, device=a.device) if want_colsum else None
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    split_col = out.shape[1] if out2 is not None else 0
+    assert out.stride(1) == 1 and out.shape[0] == M and (out2 is None or (out2.stride(1) == 1 and out2.shape == (M, N - split_col)))
+    cs = (colsum_out if colsum_out is not None else torch.empty((M,), dtype=torch.float32, device=a.device)) if want_colsum else None
+    assert cs is None or cs.is_contiguous()
     with torch.cuda.device(a.device):
-        _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), _ptr(cs),
-                                                            ldn if want_colsum else 0, _stream(a)), "spgnn_sum_partials_compact")
+        _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
+                                                            _ptr(out2), out2.stride(0) if out2 is not None else 0, split_col,
+                                                            _ptr(cs), ldn if want_colsum else 0, _stream(a)),
+                    "spgnn_sum_partials_compact")
     if want_colsum:
         return out, cs
     return out
