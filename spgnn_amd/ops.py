@@ -313,6 +313,9 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
 _SCORES_SPLIT_WAVES = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES", "2048"))   # row ranges x column groups of scores_bwd_w: 2048 measured best (7.38 vs 7.46 ms/step at 4096: half the partials; 1024: 7.43, 512: 7.65)
 
 
+_SCORES_SPLIT_WAVES_SMALL = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES_SMALL", "1024"))   # the same for J <= 8 (attention-vector gradients)
+
+
 def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """g_w_lr = g_s^T @ x (J, K)."""
     N, K = x.shape
@@ -320,7 +323,8 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     if not (_rows_aligned(x) and J <= 32) or N == 0:
         return torch.mm(g_s.t(), x)
     Kp = _pad16(K)
-    splits = max(1, min(_SCORES_SPLIT_WAVES // ((K + 255) // 256), N // 16))
+    waves = _SCORES_SPLIT_WAVES if J > 8 else _SCORES_SPLIT_WAVES_SMALL
+    splits = max(1, min(waves // ((K + 255) // 256), N // 16))
     part = torch.empty((splits, J, Kp), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("scores_bwd_w", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_bwd_w(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0),
