@@ -1414,28 +1414,48 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 // The same reduction for the weight-gradient tiles, written COMPACT: out (M, N) contiguous, plus one extra column of the
 // partial rows (the bias column sums that ride in a spare column) as its own vector.  Contiguous gradients are taken
 // over by autograd's accumulation as they are; row-strided views (N + 4 floats per row) were cloned once per parameter.
-__global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride, int S, int M,
-                                                                   int N, int64_t ldi, float* __restrict__ out, int64_t ldo,
+__global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride4, int S, int M,
+                                                                   int N, int ldi4, float* __restrict__ out, int64_t ldo,
                                                                    float* __restrict__ out2, int64_t ldo2, int split_col,
                                                                    float* __restrict__ extra, int extra_col) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, mn = (int64_t)M * N;
-  int64_t src;
-  float* dst;
-  if (i < mn) {
-    const int64_t r = i / N; const int c = (int)(i - r * N);
-    src = r * ldi + c;
-    dst = (out2 && c >= split_col) ? out2 + r * ldo2 + (c - split_col) : out + r * ldo + c;
-  } else if (extra && i < mn + M) { src = (i - mn) * ldi + extra_col; dst = extra + (i - mn); }
-  else return;
-  float acc = 0.f;
-  int s = 0;
-  for (; s + 4 <= S; s += 4) {
-    const float a = part[s * stride + src], b = part[(s + 1) * stride + src], c = part[(s + 2) * stride + src],
-                d = part[(s + 3) * stride + src];
-    acc += a; acc += b; acc += c; acc += d;
+  // one float4 of a partial row per four threads (each takes every fourth split, folded through LDS in a fixed order),
+  // as sum_partials_kernel<4>; the destination of each of its four columns is looked up afterwards
+  constexpr int SL = 4, QB = 256 / SL;
+  __shared__ float4 red[256];
+  const int q = threadIdx.x % QB, l = threadIdx.x / QB;
+  const int64_t i = (int64_t)blockIdx.x * QB + q, n4 = (int64_t)M * ldi4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = reinterpret_cast<const float4*>(part) + i;
+    int s = l;
+    for (; s + 3 * SL < S; s += 4 * SL) {
+      const float4 a = p[(int64_t)s * stride4], b = p[(int64_t)(s + SL) * stride4], c = p[(int64_t)(s + 2 * SL) * stride4],
+                   d = p[(int64_t)(s + 3 * SL) * stride4];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    for (; s < S; s += SL) { const float4 a = p[(int64_t)s * stride4]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
   }
-  for (; s < S; ++s) acc += part[s * stride + src];
-  *dst = acc;
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (l != 0 || i >= n4) return;
+#pragma unroll
+  for (int k = 1; k < SL; ++k) { const float4 a = red[k * QB + q]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+  const int64_t r = i / ldi4; const int c = (int)(i - r * ldi4) * 4;
+  const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  float* dst = (out2 && c >= split_col) ? out2 + r * ldo2 + (c - split_col) : out + r * ldo + c;
+  const bool whole = c + 3 < N && (!out2 || c + 3 < split_col || c >= split_col) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  if (whole) { *reinterpret_cast<float4*>(dst) = acc; return; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cc = c + j;
+    if (cc < N) {
+      if (out2 && cc >= split_col) out2[r * ldo2 + (cc - split_col)] = v[j];
+      else out[r * ldo + cc] = v[j];
+    } else if (extra && cc == extra_col) extra[r] = v[j];
+  }
 }
 
 // Weight preparation for a projection layer in ONE pass: the rows of A (ra x K) then B (rb x K) -> dst (ra + rb rows,
@@ -1772,10 +1792,11 @@ int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int3
   if (!partials || !out) return SPGNN_ERR_NULLPTR;
   if (out2 ? (split_col <= 0 || split_col >= N || out_stride < split_col || out2_stride < N - split_col) : out_stride < N)
     return SPGNN_ERR_STRIDE;
-  const int64_t total = (int64_t)M * N + (extra ? M : 0);
-  hipLaunchKernelGGL(gemm::sum_partials_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     partials, split_stride, (int)splits, (int)M, (int)N, ld_in, out, out_stride, out2, out2_stride, (int)split_col,
-                     extra, (int)extra_col);
+  if ((ld_in & 3) || (split_stride & 3) || (reinterpret_cast<uintptr_t>(partials) & 15)) return SPGNN_ERR_STRIDE;   // float4 reads
+  const int64_t n4 = (int64_t)M * (ld_in / 4);
+  hipLaunchKernelGGL(gemm::sum_partials_compact_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     partials, split_stride / 4, (int)splits, (int)M, (int)N, (int)(ld_in / 4), out, out_stride, out2, out2_stride,
+                     (int)split_col, extra, (int)extra_col);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 
