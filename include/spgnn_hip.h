@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 21
+#define SPGNN_ABI_VERSION 22
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -366,6 +366,12 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
 /* out[i] = sum over s < splits of partials[s * split_stride + i], i < n (n % 4 == 0, 16-byte aligned): the deterministic
  * reduction of the split-K partial tiles of spgnn_gemm_tn and spgnn_scores_bwd_w (fixed summation order). */
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream);
+
+/* The block diagonal of the summed partials of spgnn_scores_bwd_w(g_s (N, 2H), ft (N, H*D)) as (2, H, D):
+ * out[(w*H + h)*D + d] = sum_s partials[s][w*H + h][h*D + d] = the gradients of DGL GATConv's attn_l (w = 0) and
+ * attn_r (w = 1), `(ft * attn).sum(-1)`; ld = row stride of a partial (>= H*D). */
+int spgnn_sum_partials_blockdiag(const float* partials, int64_t split_stride, int32_t splits, int32_t H, int32_t D, int32_t ld,
+                                 float* out, spgnn_stream_t stream);
 
 /* The same reduction for partial TILES with padded rows (spgnn_gemm_tn: M rows of ld_in >= N floats per split), written
  * where the gradients live: columns [0, N) to out (row stride out_stride), or - with out2 - columns [0, split_col) to

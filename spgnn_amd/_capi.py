@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -66,6 +66,7 @@ SIGNATURES = {
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
     "spgnn_sum_partials": [_f32p, _i64, _i32, _i64, _f32p, _vp],
+    "spgnn_sum_partials_blockdiag": [_f32p, _i64, _i32, _i32, _i32, _i32, _f32p, _vp],
     "spgnn_sum_partials_compact": [_f32p, _i64, _i32, _i32, _i32, _i64, _f32p, _i64, _f32p, _i64, _i32, _f32p, _i32, _vp],
     "spgnn_weight_cat": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _f32p, _i64, _f32p, _i64, _f32p, _vp],
     "spgnn_weight_cat_partials": [_i32, _i32, _i64, _i64],

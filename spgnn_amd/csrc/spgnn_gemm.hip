@@ -1411,6 +1411,30 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
 }
 
+// Block diagonal of the summed (2H, H*D) score-weight gradient, as (2, H, D): out[(w*H + h)*D + d] = sum_s part[s][w*H + h][h*D + d]
+// - the attention vectors' gradients g_attn_l (w = 0) and g_attn_r (w = 1) of a GATConv whose scores come from ft; the
+// off-diagonal blocks (other heads' columns) are never needed, so they are neither summed nor copied.
+__global__ __launch_bounds__(256) void sum_partials_blockdiag_kernel(const float* __restrict__ part, int64_t stride, int S, int H,
+                                                                     int D, int ld, float* __restrict__ out) {
+  constexpr int SL = 16, QB = 256 / SL;
+  __shared__ float red[256];
+  const int q = threadIdx.x % QB, l = threadIdx.x / QB;
+  const int i = blockIdx.x * QB + q, n = 2 * H * D;
+  float acc = 0.f;
+  if (i < n) {
+    const int row = i / D, d = i - row * D, h = row % H;
+    const float* p = part + (int64_t)row * ld + h * D + d;
+    for (int s = l; s < S; s += SL) acc += p[(int64_t)s * stride];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (l == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < SL; ++k) acc += red[k * QB + q];
+    out[i] = acc;
+  }
+}
+
 // The same reduction for the weight-gradient tiles, written COMPACT: out (M, N) contiguous, plus one extra column of the
 // partial rows (the bias column sums that ride in a spare column) as its own vector.  Contiguous gradients are taken
 // over by autograd's accumulation as they are; row-strided views (N + 4 floats per row) were cloned once per parameter.
@@ -1781,6 +1805,16 @@ int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t spli
     hipLaunchKernelGGL(gemm::sum_partials_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
   else
     hipLaunchKernelGGL(gemm::sum_partials_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
+  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+}
+
+int spgnn_sum_partials_blockdiag(const float* partials, int64_t split_stride, int32_t splits, int32_t H, int32_t D, int32_t ld,
+                                 float* out, spgnn_stream_t stream) {
+  if (splits <= 0 || H <= 0 || D <= 0 || ld < H * D || split_stride < (int64_t)2 * H * ld) return SPGNN_ERR_SHAPE;
+  if (!partials || !out) return SPGNN_ERR_NULLPTR;
+  const int n = 2 * H * D;
+  hipLaunchKernelGGL(gemm::sum_partials_blockdiag_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                     partials, split_stride, (int)splits, (int)H, (int)D, (int)ld, out);
   return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
 }
 

@@ -316,12 +316,17 @@ _SCORES_SPLIT_WAVES = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES", "2048"))   
 _SCORES_SPLIT_WAVES_SMALL = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES_SMALL", "1024"))   # the same for J <= 8 (attention-vector gradients)
 
 
-def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """g_w_lr = g_s^T @ x (J, K)."""
+def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0) -> torch.Tensor:
+    """g_w_lr = g_s^T @ x (J, K).  ``blockdiag_heads`` = H (J = 2H, K = H*D): only the (2, H, D) block diagonal
+    [w, h, :] = (g_s[:, w*H + h]^T @ x)[h*D:(h+1)*D] - the attention vectors' gradients."""
     N, K = x.shape
     J = g_s.shape[1]
     if not (_rows_aligned(x) and J <= 32) or N == 0:
-        return torch.mm(g_s.t(), x)
+        m = torch.mm(g_s.t(), x)
+        if blockdiag_heads:
+            H = blockdiag_heads; D = K // H
+            return torch.stack([torch.stack([m[w * H + h, h * D:(h + 1) * D] for h in range(H)]) for w in range(2)])
+        return m
     Kp = _pad16(K)
     waves = _SCORES_SPLIT_WAVES if J > 8 else _SCORES_SPLIT_WAVES_SMALL
     splits = max(1, min(waves // ((K + 255) // 256), N // 16))
@@ -330,6 +335,13 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         _capi.check(_capi.load().spgnn_scores_bwd_w(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0),
                                                     part.data_ptr(), splits, Kp, N, K, J, _stream(x)),
                     "spgnn_scores_bwd_w")
+    if blockdiag_heads:
+        H = blockdiag_heads; D = K // H
+        out = torch.empty((2, H, D), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.load().spgnn_sum_partials_blockdiag(part.data_ptr(), J * Kp, splits, H, D, Kp, out.data_ptr(),
+                                                                  _stream(x)), "spgnn_sum_partials_blockdiag")
+        return out
     return sum_partials(part)[:, :K]
 
 
@@ -803,12 +815,8 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             g_bias = g_pre.sum(0)
         g_al = g_ar = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            m = scores_bwd_w(g_s, y[:, :HD])                     # (2H, HD): row h x head-h block = g_attn_l[h], row H+h = g_attn_r[h]
-            if H == 1:                                           # rows 0 and 1 of m are the two gradients: views, no copies
-                g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
-            else:
-                g_al = torch.stack([m[h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
-                g_ar = torch.stack([m[H + h, h * D:(h + 1) * D] for h in range(H)]).view(ctx.attn_shape)
+            m = scores_bwd_w(g_s, y[:, :HD], blockdiag_heads=H)  # (2, H, D): [0] = g_attn_l, [1] = g_attn_r (contiguous views)
+            g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
         g_x = None
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4
