@@ -795,6 +795,9 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
 // past the row end re-read chunk 0 and are masked at the stores and in the reductions.
 //   z      (N, H*zs): head h's block starts at column h*zs; [0,F) = z_h, [xoff, xoff+F) = copy of x (xoff < 0: none)
 // =================================================================================================
+// The three aggregate-first kernels take a team of T lanes per node: T = 64 (one node per wave, wave-uniform scalars) for
+// wide inputs, T = 16 (four nodes per wave, R <= 3 float4 per lane) for F <= 192: these kernels are latency-bound per node
+// (index -> score -> row chains), so four nodes in flight per wave is what fills the memory pipe.
 struct GatAggFwd {
   const int32_t* indptr; const int32_t* indices;
   const float* x; int64_t x_ld;
@@ -806,16 +809,16 @@ struct GatAggFwd {
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R>
+template <int H, int R, int T>
 __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
   if (a.seed_off) a.seed += a.seed_off[0];
-  const int lane = threadIdx.x & 63;
-  const int64_t v = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x % T;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
   if (v >= a.N) return;
-  const int beg = uni<true>(a.indptr[v]), end = uni<true>(a.indptr[v + 1]), deg = end - beg;
+  const int beg = uni<T == 64>(a.indptr[v]), end = uni<T == 64>(a.indptr[v + 1]), deg = end - beg;
   int col[R]; bool ok[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  for (int r = 0; r < R; ++r) { const int c = (r * T + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
   float erv[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) erv[h] = a.er[v * a.s_ld + h];
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
   if (deg > 0 && deg <= kMaxFast) {
     int u[kMaxFast];
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<true>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<T == 64>(a.indices[beg + (k < deg ? k : deg - 1)]);
     float w[kMaxFast][H];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
-      for (int h = 0; h < H; ++h) w[k][h] = uni<true>(w[k][h]);
+      for (int h = 0; h < H; ++h) w[k][h] = uni<T == 64>(w[k][h]);
     constexpr int G = R >= 4 ? 2 : 4;
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += G) {
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
       if (a.xoff >= 0) { st4(dst + a.xoff, xs[r]); mxv = absmax4(mxv, xs[r]); }
     }
   if (a.absmax) {
-    mxv = team_max(mxv, 64);
+    mxv = team_max(mxv, T);
     if (lane == 0) a.absmax[v] = mxv;
   }
 }
@@ -941,16 +944,16 @@ struct GatAggBwdDst {
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R>
+template <int H, int R, int T>
 __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
   if (a.seed_off) a.seed += a.seed_off[0];
-  const int lane = threadIdx.x & 63;
-  const int64_t v = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x % T;
+  const int64_t v = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
   if (v >= a.N) return;
-  const int beg = uni<true>(a.indptr[v]), end = uni<true>(a.indptr[v + 1]), deg = end - beg;
+  const int beg = uni<T == 64>(a.indptr[v]), end = uni<T == 64>(a.indptr[v + 1]), deg = end - beg;
   int col[R]; bool ok[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  for (int r = 0; r < R; ++r) { const int c = (r * T + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
   float4 g[H][R];
 #pragma unroll
   for (int h = 0; h < H; ++h)
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
   if (deg > 0 && deg <= kMaxFast) {
     int u[kMaxFast];
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<true>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<T == 64>(a.indices[beg + (k < deg ? k : deg - 1)]);
     float al[kMaxFast][H], ep[kMaxFast][H], ga[kMaxFast][H];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
           float pd = 0.f;
 #pragma unroll
           for (int r = 0; r < R; ++r) pd += dot4(xr[q][r], g[h][r]);
-          ga[k0 + q][h] = uni<true>(team_sum(pd, 64));
+          ga[k0 + q][h] = uni<T == 64>(team_sum(pd, T));
         }
     }
 #pragma unroll
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
       float pd = 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) pd += dot4(xr[r], g[h][r]);
-      float xg = team_sum(pd, 64);
+      float xg = team_sum(pd, T);
       const int64_t eidx = (int64_t)j * H + h;
       if (a.p > 0.f) xg *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
       S[h] = fmaf(a.attn[eidx], xg, S[h]);
@@ -1065,16 +1068,16 @@ struct GatAggBwdSrc {
   float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R>
+template <int H, int R, int T>
 __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
   if (a.seed_off) a.seed += a.seed_off[0];
-  const int lane = threadIdx.x & 63;
-  const int64_t u = xcd_block() * (kBlock / 64) + uni<true>((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x % T;
+  const int64_t u = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
   if (u >= a.N) return;
-  const int beg = uni<true>(a.out_indptr[u]), end = uni<true>(a.out_indptr[u + 1]), deg = end - beg;
+  const int beg = uni<T == 64>(a.out_indptr[u]), end = uni<T == 64>(a.out_indptr[u + 1]), deg = end - beg;
   int col[R]; bool ok[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) { const int c = (r * 64 + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
+  for (int r = 0; r < R; ++r) { const int c = (r * T + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1094,8 +1097,8 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
     int vv[kMaxFast], pp[kMaxFast];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) {
-      vv[k] = uni<true>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
-      pp[k] = uni<true>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
+      vv[k] = uni<T == 64>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
+      pp[k] = uni<T == 64>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
     }
     float w[kMaxFast][H];
 #pragma unroll
@@ -1105,7 +1108,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
         w[k][h] = a.attn[(int64_t)pp[k] * H + h];
         const float ge = a.g_e[(int64_t)pp[k] * H + h];
         if (a.p > 0.f) w[k][h] *= keep_scale(a.seed, (int64_t)pp[k] * H + h, a.p, a.inv_keep);
-        w[k][h] = uni<true>(k < deg ? w[k][h] : 0.f);
+        w[k][h] = uni<T == 64>(k < deg ? w[k][h] : 0.f);
         gel[h] += k < deg ? ge : 0.f;
       }
     constexpr int G = H * R >= 8 ? 1 : H * R >= 4 ? 2 : 4;
@@ -2255,6 +2258,17 @@ int spgnn_gat_agg_supported(int32_t H, int32_t F) {
     default: return fail(SPGNN_ERR_SHAPE, "aggregate-first GAT: H must be 1, 2 or 4 and F <= 1024");  \
   }
 static int agg_chunks(int F) { return F <= 256 ? 1 : F <= 512 ? 2 : 4; }
+#ifndef SPGNN_AGG_TEAM16
+#define SPGNN_AGG_TEAM16 1        // 0: one node per wave for every width (A/B)
+#endif
+static bool agg_team16(int F) { return SPGNN_AGG_TEAM16 && F <= 192; }
+#define SPGNN_FOR_H_R16(H_, R_, X)                                                                  \
+  switch ((H_) * 16 + (R_)) {                                                                       \
+    case 1 * 16 + 1: X(1, 1); break;  case 1 * 16 + 2: X(1, 2); break;  case 1 * 16 + 3: X(1, 3); break; \
+    case 2 * 16 + 1: X(2, 1); break;  case 2 * 16 + 2: X(2, 2); break;  case 2 * 16 + 3: X(2, 3); break; \
+    case 4 * 16 + 1: X(4, 1); break;  case 4 * 16 + 2: X(4, 2); break;  case 4 * 16 + 3: X(4, 3); break; \
+    default: return fail(SPGNN_ERR_SHAPE, "aggregate-first GAT: H must be 1, 2 or 4 and F <= 1024");  \
+  }
 
 int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* el,
                       const float* er, int64_t s_stride, float* attn, float* z, int64_t z_stride, int32_t head_stride,
@@ -2272,11 +2286,19 @@ int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_fwd: p_drop not in [0,1)");
   GatAggFwd a{indptr, indices, x, x_stride, el, er, s_stride, attn, z, z_stride, head_stride, x_copy_offset, absmax, N, F,
               negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
-  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_>), grid, block, 0, st, a)
-  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+  const dim3 block(kBlock);
+  if (agg_team16(F)) {
+    const dim3 grid(grid_for(N, kBlock / 16));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_, 16>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
+  } else {
+    const dim3 grid(grid_for(N, kBlock / 64));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_, 64>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  }
   return check_launch("spgnn_gat_agg_fwd");
 }
 
@@ -2296,11 +2318,19 @@ int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const f
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_dst: p_drop not in [0,1)");
   GatAggBwdDst a{indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride, head_stride, g_e, g_er, g_s_stride,
                  N, F, negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
-  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_>), grid, block, 0, st, a)
-  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+  const dim3 block(kBlock);
+  if (agg_team16(F)) {
+    const dim3 grid(grid_for(N, kBlock / 16));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_, 16>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
+  } else {
+    const dim3 grid(grid_for(N, kBlock / 64));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_, 64>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  }
   return check_launch("spgnn_gat_agg_bwd_dst");
 }
 
@@ -2323,11 +2353,19 @@ int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices,
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_src: p_drop not in [0,1)");
   GatAggBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
                  w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, F, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
-  const dim3 grid(grid_for(N, kBlock / 64)), block(kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_>), grid, block, 0, st, a)
-  SPGNN_FOR_H_R(H, agg_chunks(F), X)
+  const dim3 block(kBlock);
+  if (agg_team16(F)) {
+    const dim3 grid(grid_for(N, kBlock / 16));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_, 16>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
+  } else {
+    const dim3 grid(grid_for(N, kBlock / 64));
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_, 64>), grid, block, 0, st, a)
+    SPGNN_FOR_H_R(H, agg_chunks(F), X)
+#undef X
+  }
   return check_launch("spgnn_gat_agg_bwd_src");
 }
 
