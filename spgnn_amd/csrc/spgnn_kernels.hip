@@ -45,6 +45,9 @@ constexpr int kBlock = 256;
 // the kernels latency-bound - a wave walks one dependent index -> score -> row chain per node - and four chains per
 // wave hide more of it than the SGPR savings of a whole-wave team are worth: measured for single-head layers
 // (1x256: fwd 51 -> 42, bwd 68 -> 59 / 35 -> 27 us; 1x128: 33 -> 25, 39 -> 30, 20 -> 17 us), not for two-head ones.
+#ifndef SPGNN_NARROW_TEAMS
+#define SPGNN_NARROW_TEAMS 2      // 1: 16-lane teams for one-head layers up to 256 columns; 2: two-head layers too; 3: and 32 lanes at 512
+#endif
 bool pick_team(int64_t width, int& T, int& R, bool narrow = false) {
   if (width <= 0 || (width & 3)) return false;
   int64_t q = width >> 2;
@@ -52,6 +55,7 @@ bool pick_team(int64_t width, int& T, int& R, bool narrow = false) {
     const int64_t r = q / 16;
     if (r == 1 || r == 2 || r == 4) { T = 16; R = (int)r; return true; }
   }
+  if (narrow && SPGNN_NARROW_TEAMS >= 3 && q == 128) { T = 32; R = 4; return true; }
   const int ts[3] = {64, 32, 16};
   for (int t : ts) {
     if (q % t) continue;
@@ -2094,12 +2098,9 @@ const char* spgnn_last_error(void) { return g_err; }
 // (0 = heads narrower than the team, reduction width W).  false -> scalar fallback.
 // One node per team.  Measured (tools/npt_sweep.py, MI355X): looping a team over 2/4/8/16 consecutive nodes was
 // 2/8/24/50 % slower - many short-lived workgroups hide the dependent index -> score -> row chain better.
-#ifndef SPGNN_NARROW_TEAMS
-#define SPGNN_NARROW_TEAMS 1
-#endif
 static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
   if (D % 4) return false;
-  if (!pick_team((int64_t)H * D, T, R, SPGNN_NARROW_TEAMS && H == 1)) return false;
+  if (!pick_team((int64_t)H * D, T, R, SPGNN_NARROW_TEAMS && (H == 1 || (SPGNN_NARROW_TEAMS >= 2 && H == 2)))) return false;
   const int team_floats = 4 * T;
   W = T;
   if (D % team_floats == 0) {
