@@ -341,7 +341,7 @@ def test_c_abi_argument_errors_are_reported():
     assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op
 
 
-@pytest.mark.parametrize("K,J", [(1063, 4), (1064, 4), (39, 2), (768, 4), (192, 4), (256, 2), (64, 16), (100, 8), (17, 4)])
+@pytest.mark.parametrize("K,J", [(1063, 4), (1064, 4), (39, 2), (768, 4), (192, 4), (256, 2), (64, 16), (100, 8), (17, 4), (600, 22), (520, 4), (1024, 22)])
 def test_score_projection_kernels(K, J):
     """spgnn_scores_fwd / _bwd_w / _bwd_x against plain matmuls (ragged K tails, padded row strides)."""
     torch.manual_seed(K + J)
@@ -351,6 +351,8 @@ def test_score_projection_kernels(K, J):
     w = torch.randn(J, K, device="cuda")
     s = ops.scores_fwd(x, w)
     assert rel_err(s, x.double() @ w.double().t()) < 2e-6
+    s2, scale = ops.scores_fwd(x, w, want_scale=True)      # the absmax the kernel collects on the way (K >= 512: four waves per row group)
+    assert torch.equal(s2, s) and torch.equal(scale, ops.pow2_scale(x))
     gs = torch.randn(N, J, device="cuda")
     assert rel_err(ops.scores_bwd_w(gs, x), gs.double().t() @ x.double()) < 2e-6
     gbuf = torch.randn(N, (K + 3) // 4 * 4, device="cuda")
