@@ -530,6 +530,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+_CAT_GRAD_VIEWS = os.environ.get("SPGNN_CAT_GRAD_VIEWS", "1") != "0"
+
+
 class _CatDropout(torch.autograd.Function):
     """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
     counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""
@@ -572,7 +575,9 @@ class _CatDropout(torch.autograd.Function):
         outs, off = [], 0
         with torch.cuda.device(g.device):
             for w, need in zip(ctx.widths, ctx.needs_input_grad[2:]):
-                if need:
+                if need and ctx.p == 0.0 and _CAT_GRAD_VIEWS and off % 4 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0:
+                    outs.append(g[:, off:off + w])      # a plain concatenation: its gradient's column blocks, no copy
+                elif need:
                     wp = (w + 3) // 4 * 4
                     go = torch.empty((N, wp), dtype=torch.float32, device=g.device)[:, :w]
                     _capi.check(lib.spgnn_cat_dropout(g.data_ptr(), g.stride(0), go.data_ptr(), go.stride(0), N, w, off, F_,

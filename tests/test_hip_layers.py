@@ -253,6 +253,12 @@ def test_cat_dropout_is_cat_then_dropout_with_a_regenerated_mask():
     c = torch.randn(N, 512, device="cuda"); d = torch.randn(N, 256, device="cuda")      # the 16-byte vector path
     keep2 = torch.from_numpy(keep4_scale_host(seed, N, (512, 256), p)).cuda()
     assert torch.equal(ops.cat_dropout((c, d), p, seed), torch.cat([c, d], 1) * keep2)
+    # p = 0: the gradients are column blocks of the incoming one (views when 16-byte aligned, copies otherwise)
+    for wa, wb in ((512, 64), (130, 39)):
+        e = torch.randn(N, wa, device="cuda", requires_grad=True); f = torch.randn(N, wb, device="cuda", requires_grad=True)
+        cot = torch.randn(N, wa + wb, device="cuda")
+        (ops.cat_dropout((e, f), 0.0) * cot).sum().backward()
+        assert torch.equal(e.grad, cot[:, :wa]) and torch.equal(f.grad, cot[:, wa:])
 
 
 SPMM_F = [64, 128, 256, 1024, 22, 7, 192]
