@@ -1801,50 +1801,66 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ part, int Kp, int64_t N, int K,
                                                           int64_t rows_per_split, int jn) {
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // a block's waves sit side by side on one row: 4 KB contiguous per row
-  if (k >= K) return;
-  const bool full = k + 3 < K;
+  // a block's waves sit side by side on one row: 4 KB contiguous per row.  Every lane of a wave stays in the loop (the gS
+  // rows travel through lanes, see below): lanes past the width read column 0 and store nothing; a float4 that hangs over
+  // the width reads the row's padding (rows are 16-byte aligned with a stride that is a multiple of 4) and the columns
+  // that do not exist are cleared before the store.
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if ((k & ~255) >= K) return;         // a wave with no column at all (wave-uniform)
+  const bool live = k < K;
+  const int kk = live ? k : 0;
   const int64_t n0 = (int64_t)blockIdx.y * rows_per_split;
   const int64_t n1 = n0 + rows_per_split < N ? n0 + rows_per_split : N;
   float4 acc[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t n = n0;
-  if (full && n + 4 <= n1) {           // 4 rows per trip, the next trip's rows already in flight while this one is summed
-    const float* xr = X + n * ldx + k;
+  if (n + 4 <= n1) {                   // 4 rows per trip, the next trip's rows already in flight while this one is summed
+    const float* xr = X + n * ldx + kk;
     float4 x0 = ld4(xr), x1 = ld4(xr + ldx), x2 = ld4(xr + 2 * ldx), x3 = ld4(xr + 3 * ldx);
-#define SPGNN_SBW_FMA(C0, C1, C2, C3)                                                                          \
+    // the four gS rows of a trip arrive as two vector loads issued with the x rows (lanes 0-31: one row, lanes 32-63: the
+    // next; J <= 32) and are broadcast by v_readlane: as scalar loads at the point of use they were waited for in every trip
+    const int gl = threadIdx.x & 63;
+    const float* gp = gS + (int64_t)(gl >> 5) * ldg + ((gl & 31) < jn ? (gl & 31) : 0);
+    float ga = gp[n * ldg], gb = gp[(n + 2) * ldg];
+#define SPGNN_SBW_FMA(C0, C1, C2, C3, GA, GB)                                                                  \
     {                                                                                                          \
-      const float* g = gS + n * ldg;   /* wave-uniform addresses: scalar loads */                              \
       _Pragma("unroll") for (int j = 0; j < J; ++j) {                                                          \
         if (j < jn) {                                                                                          \
-          fma4(acc[j], g[j], C0); fma4(acc[j], g[ldg + j], C1); fma4(acc[j], g[2 * ldg + j], C2); fma4(acc[j], g[3 * ldg + j], C3); \
+          fma4(acc[j], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GA), j)), C0);                  \
+          fma4(acc[j], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GA), 32 + j)), C1);             \
+          fma4(acc[j], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GB), j)), C2);                  \
+          fma4(acc[j], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GB), 32 + j)), C3);             \
         }                                                                                                      \
       }                                                                                                        \
     }
     for (; n + 8 <= n1; n += 4) {      // steady state: the prefetch is unconditional (a test around it made hipcc drain the queue)
       const float4 c0 = x0, c1 = x1, c2 = x2, c3 = x3;
-      const float* xn = X + (n + 4) * ldx + k;
+      const float ca = ga, cb = gb;
+      const float* xn = X + (n + 4) * ldx + kk;
       x0 = ld4(xn); x1 = ld4(xn + ldx); x2 = ld4(xn + 2 * ldx); x3 = ld4(xn + 3 * ldx);
-      SPGNN_SBW_FMA(c0, c1, c2, c3)
+      ga = gp[(n + 4) * ldg]; gb = gp[(n + 6) * ldg];
+      SPGNN_SBW_FMA(c0, c1, c2, c3, ca, cb)
     }
-    SPGNN_SBW_FMA(x0, x1, x2, x3)      // last full trip
+    SPGNN_SBW_FMA(x0, x1, x2, x3, ga, gb)      // last full trip
     n += 4;
 #undef SPGNN_SBW_FMA
   }
   for (; n < n1; ++n) {
-    const float* xr = X + n * ldx + k;
-    float4 x;
-    if (full) x = ld4(xr);
-    else { x = make_float4(xr[0], k + 1 < K ? xr[1] : 0.f, k + 2 < K ? xr[2] : 0.f, 0.f); }
+    const float4 x = ld4(X + n * ldx + kk);
     const float* g = gS + n * ldg;
 #pragma unroll
     for (int j = 0; j < J; ++j)
       if (j < jn) fma4(acc[j], g[j], x);
   }
+  if (!live) return;
 #pragma unroll
   for (int j = 0; j < J; ++j)
-    if (j < jn) st4(part + ((int64_t)blockIdx.y * jn + j) * Kp + k, acc[j]);
+    if (j < jn) {
+      float4 q = acc[j];
+      q.y = k + 1 < K ? q.y : 0.f; q.z = k + 2 < K ? q.z : 0.f; q.w = k + 3 < K ? q.w : 0.f;
+      st4(part + ((int64_t)blockIdx.y * jn + j) * Kp + k, q);
+    }
 }
 
 template <int J>
