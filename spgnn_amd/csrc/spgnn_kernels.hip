@@ -45,6 +45,9 @@ constexpr int kBlock = 256;
 // the kernels latency-bound - a wave walks one dependent index -> score -> row chain per node - and four chains per
 // wave hide more of it than the SGPR savings of a whole-wave team are worth: measured for single-head layers
 // (1x256: fwd 51 -> 42, bwd 68 -> 59 / 35 -> 27 us; 1x128: 33 -> 25, 39 -> 30, 20 -> 17 us), not for two-head ones.
+#ifndef SPGNN_ABP_ROWS
+#define SPGNN_ABP_ROWS 4          // rows per trip of act_bwd_proj (2 measured slower: see DESIGN.md)
+#endif
 #ifndef SPGNN_NARROW_TEAMS
 #define SPGNN_NARROW_TEAMS 2      // 1: 16-lane teams for one-head layers up to 256 columns; 2: two-head layers too; 3: and 32 lanes at 512
 #endif
@@ -1219,13 +1222,15 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
 // i.e. spgnn_scores_bwd_x (g_mean = g_logits W, written) + spgnn_act_bwd (g_mean re-read) in one pass: g_mean never
 // exists in memory.  A thread owns four columns and keeps their W entries in registers (J float4); a block walks a row
 // range, two rows per trip with all loads issued first; gS rows are wave-uniform (scalar loads); one |max| per block.
-template <int JP>
+template <int JP, int HT, int RB>       // HT: heads at compile time (0: run-time H <= 4); RB rows per trip
 __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restrict__ gS, int64_t ldg, int J,
                                                            const float* __restrict__ W, int64_t ldw,
                                                            const float* __restrict__ out, int64_t out_ld,
                                                            float* __restrict__ g_pre, int64_t gp_ld, float* __restrict__ absmax,
-                                                           int64_t N, int64_t rows_per_block, int H, int D, int act) {
+                                                           int64_t N, int64_t rows_per_block, int Hrt, int D, int act) {
   __shared__ float red[4];
+  constexpr int HMAX = HT ? HT : 4;
+  const int H = HT ? HT : Hrt;
   const int c = threadIdx.x * 4;
   const bool cv = c < D;
   const int cc = cv ? c : 0;
@@ -1239,7 +1244,6 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
   const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
   float mx = 0.f;
-  constexpr int HMAX = 4;
   // the row of gS is fetched by ONE vector load (lane j holds gS[row, j]) issued with the row's other loads and
   // broadcast by v_readlane: scalar loads would each expose their latency (and spilled 88 SGPRs with two rows in flight)
   const int jl = (threadIdx.x & 63) < J ? (threadIdx.x & 63) : 0;
@@ -1260,20 +1264,26 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
     if (cv) { st4(g_pre + (ROW) * gp_ld + (int64_t)(HH) * D + c, q); mx = absmax4(mx, q); }                  \
   }
   int64_t n = n0;
-  for (; n + 2 <= n1; n += 2) {
-    float4 o0[HMAX], o1[HMAX];
+  for (; n + RB <= n1; n += RB) {      // RB rows per trip, every load of the trip issued before the first use
+    float4 o[RB][HMAX];
+    float gv[RB];
     if (act != SPGNN_ACT_NONE) {
 #pragma unroll
-      for (int h = 0; h < HMAX; ++h)
-        if (h < H) { o0[h] = ld4(out + n * out_ld + (int64_t)h * D + cc); o1[h] = ld4(out + (n + 1) * out_ld + (int64_t)h * D + cc); }
-    }
-    const float gv0 = gS[n * ldg + jl], gv1 = gS[(n + 1) * ldg + jl];
-    float4 gm0, gm1;
-    SPGNN_ABP_GM(gm0, gv0)
-    SPGNN_ABP_GM(gm1, gv1)
+      for (int r = 0; r < RB; ++r)
 #pragma unroll
-    for (int h = 0; h < HMAX; ++h)
-      if (h < H) { SPGNN_ABP_OUT(gm0, o0[h], n, h) SPGNN_ABP_OUT(gm1, o1[h], n + 1, h) }
+        for (int h = 0; h < HMAX; ++h)
+          if (HT || h < H) o[r][h] = ld4(out + (n + r) * out_ld + (int64_t)h * D + cc);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) gv[r] = gS[(n + r) * ldg + jl];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      float4 gm;
+      SPGNN_ABP_GM(gm, gv[r])
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if (HT || h < H) SPGNN_ABP_OUT(gm, o[r][h], n + r, h)
+    }
   }
   for (; n < n1; ++n) {
     const float gv = gS[n * ldg + jl];
@@ -2445,10 +2455,12 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
   const int32_t blocks = spgnn_act_bwd_proj_blocks(N);
   const int64_t rpb = (N + blocks - 1) / blocks;
   hipStream_t st = (hipStream_t)stream;
-#define X(JP) hipLaunchKernelGGL(act_bwd_proj_kernel<JP>, dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, (int)J, w, w_stride, \
-                                 out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation)
-  if (J <= 8) X(8); else if (J <= 16) X(16); else if (J <= 24) X(24); else X(32);
+#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, SPGNN_ABP_ROWS>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
+                                      (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation)
+#define X(JP) { if (H == 2) XH(JP, 2); else if (H == 1) XH(JP, 1); else XH(JP, 0); }
+  if (J <= 8) X(8) else if (J <= 16) X(16) else if (J <= 24) X(24) else X(32)
 #undef X
+#undef XH
   return check_launch("spgnn_act_bwd_proj");
 }
 
