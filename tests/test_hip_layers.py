@@ -169,7 +169,8 @@ def test_attention_dropout_matches_oracle_with_same_mask(monkeypatch):
 
 @pytest.mark.parametrize("fin,H,D,res,act,mean", [(192, 2, 1024, True, F.elu, True), (600, 4, 640, True, F.elu, False),
                                                   (300, 1, 512, False, torch.tanh, False), (36, 2, 64, False, None, True),
-                                                  (256, 4, 260, True, F.elu, True), (1024, 1, 2048, True, F.elu, False)])
+                                                  (256, 4, 260, True, F.elu, True), (1024, 1, 2048, True, F.elu, False),
+                                                  (100, 2, 128, True, F.elu, False), (128, 4, 256, False, F.elu, True)])   # 16-lane teams, two chunks per lane
 def test_aggregate_first_form_matches_project_first_and_oracle(monkeypatch, fin, H, D, res, act, mean):
     """Input narrower than a head: the layer aggregates input rows first and projects afterwards (ops._GATAggFirstFn).
     Same function as the project-first form (A/B through nn.AGGREGATE_FIRST) and as the oracle, with attention
