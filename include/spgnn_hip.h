@@ -253,7 +253,8 @@ int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l,
  *   spgnn_scores_bwd_x  gx[n,k] (+)= sum_j gs[n,j] * w[j,k]        (accumulate != 0: add into gx)
  *
  * w and part rows are zero-padded to Kp = 16*ceil(K/16) floats (part: splits x J x Kp).  x / gx rows must be
- * 16-byte aligned (stride % 4 == 0).  J <= 32.  The same three kernels serve the model's classifier head
+ * 16-byte aligned (stride % 4 == 0); spgnn_scores_bwd_w reads (and discards) the up to three floats of row padding that
+ * complete a row's last 16-byte group.  J <= 32.  The same three kernels serve the model's classifier head
  * `gnn_out = Linear(1024, 22)` (reference models.py:1125, 1169): a 22-column projection of 76k rows.
  */
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
