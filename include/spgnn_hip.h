@@ -17,6 +17,10 @@
  *    slot of the same edge.  Per-edge arrays (attn, g_e) are always indexed by CSC slot.
  *  - Feature matrices are row-major fp32 with an explicit row stride in ELEMENTS, so callers
  *    can point into wider buffers (fused [fc|res] GEMM output, concat buffers).
+ *  - Entry points ending in _bf16 are the bf16-STORAGE path (BASELINE config "st_gat_6 ... bf16"): node-feature
+ *    rows, projected rows and their gradients are bfloat16 in HBM (uint16_t* here), every sum is accumulated in
+ *    fp32, and parameters, scores (el/er), attention weights and weight gradients stay fp32.  Same semantics and
+ *    argument meaning as the fp32 entry point of the same name unless stated.
  *  - Return value: 0 on success; SPGNN_ERR_* (< 0) on bad arguments; -(1000 + hipError_t) when
  *    a launch fails.  spgnn_last_error() describes the last failure on the calling thread.
  */
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 22
+#define SPGNN_ABI_VERSION 23
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -486,6 +490,98 @@ int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf
                             const float* grad_scale, const float* lr_dev /* nullable: overrides lr (graph replay) */,
                             int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
                             spgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16-storage path (BASELINE.json config 4: st_gat_6, 512 trees, bf16; reference precision hook
+ * job_runner.py:263-280, model exp_settings/st_gat_6.py:81-106).  Rows are bfloat16 with 8-byte aligned rows
+ * (stride % 4 == 0); only vector geometries (H*D = 4*T*R) are supported - there is no scalar fallback.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* spgnn_gat_fwd with ft / res / out as bf16 rows; out_mean (the head mean, `.mean(1)` of the output layer) stays fp32. */
+int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices,
+                       const uint16_t* ft, int64_t ft_stride,
+                       const float* el, const float* er, int64_t s_stride,
+                       const uint16_t* res, int64_t res_stride,
+                       const float* bias,
+                       uint16_t* out, int64_t out_stride,
+                       float* out_mean, int64_t out_mean_stride,
+                       float* attn,
+                       int64_t N, int64_t E, int32_t H, int32_t D,
+                       float negative_slope, int32_t activation,
+                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                       spgnn_stream_t stream);
+
+/* spgnn_gat_bwd_dst with ft / out / g_pre as bf16 rows.  g_out: bf16 (N, H*D), or - mean_heads != 0 - the fp32
+ * gradient of the head mean (N, D).  The per-edge dots use the ROUNDED g_pre (what the other kernels read back). */
+int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices,
+                           const uint16_t* ft, int64_t ft_stride,
+                           const float* el, const float* er, int64_t s_stride,
+                           const float* attn,
+                           const void* g_out, int64_t g_out_stride, int32_t mean_heads,
+                           const uint16_t* out, int64_t out_stride,
+                           uint16_t* g_pre, int64_t g_pre_stride,
+                           float* g_e,
+                           float* g_er, int64_t g_s_stride,
+                           int64_t N, int64_t E, int32_t H, int32_t D,
+                           float negative_slope, int32_t activation,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           spgnn_stream_t stream);
+
+/* spgnn_gat_bwd_src with g_pre / g_ft as bf16 rows (score vectors and score gradients fp32). */
+int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                           const float* attn, const float* g_e,
+                           const uint16_t* g_pre, int64_t g_pre_stride,
+                           uint16_t* g_ft, int64_t g_ft_stride,
+                           float* g_el, int64_t g_s_stride,
+                           const float* score_l, const float* score_r, const float* g_er,
+                           int64_t N, int64_t E, int32_t H, int32_t D,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           spgnn_stream_t stream);
+
+/* spgnn_scores_bwd_w with x as bf16 rows (the attention vectors' gradients g_s^T ft); J <= 8. */
+int spgnn_scores_bwd_w_bf16(const float* g_s, int64_t g_s_stride, const uint16_t* x, int64_t x_stride, float* partials,
+                            int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+
+/* spgnn_cat_dropout on bf16 rows (widths, offsets and strides multiples of 4; no absmax by-product). */
+int spgnn_cat_dropout_bf16(const uint16_t* src, int64_t src_stride, uint16_t* dst, int64_t dst_stride, int64_t N,
+                           int32_t width, int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed,
+                           const uint64_t* seed_offset, int32_t backward, spgnn_stream_t stream);
+
+/*
+ * C[M,N] = act(A[M,K] * B[N,K]^T + bias) on v_mfma_f32_32x32x16_bf16, fp32 accumulate: GATConv's `fc` / `res_fc`
+ * projections as ONE product Y = X [W_fc ; W_res]^T (reference models.py:301-314 -> DGL GATConv.fc / res_fc), and the
+ * input gradient g_X = g_Y W with B = W^T.  A, B: bf16 rows, 16-byte aligned, stride % 8 == 0 and >= K rounded up to 8
+ * with columns [K, K8) zero.  C: bf16 (c_is_f32 == 0) or fp32; N % 4 == 0.  bias (N, fp32) / activation optional.
+ * score_out (nullable): per row and per 64-column block b of the first score_cols columns,
+ *   score_out[(row * score_cols/64 + b) * 2 + {0,1}] = <C[row, 64b:64b+64], score_l / score_r[64b:64b+64]>
+ * taken from the values AS STORED (bf16-rounded): DGL's el / er = (ft * attn_l / attn_r).sum(-1) without a pass over ft
+ * (spgnn_scores_from_parts adds a head's blocks).  Not combined with bias / activation.
+ */
+int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                       int32_t c_is_f32, int64_t M, int64_t N, int64_t K, const float* bias, int32_t activation,
+                       const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                       spgnn_stream_t stream);
+
+/*
+ * Weight gradients: partial[s] (M, N; row stride ldc; fp32) = A[rows of split s, :M]^T * B[rows of split s, :N] for
+ * `splits` row ranges of the R rows (A = g_Y, B = X, both bf16 rows, 16-byte aligned, stride % 8 == 0, pad columns up
+ * to a multiple of 8 zero); the caller sums the partials (spgnn_sum_partials_compact).  colsum (nullable): per split
+ * the column sums of A (the bias gradient), element (s, m) at colsum[s * colsum_split_stride + m * colsum_stride].
+ */
+int spgnn_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* partials, int64_t ldc,
+                       int64_t split_stride, int32_t splits, int64_t R, int64_t M, int64_t N, float* colsum,
+                       int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream);
+
+/* [w_a ; w_b] (fp32 parameter row blocks, w_b nullable) -> bf16 GEMM operand w (rows_a + rows_b, w_stride) and, w_t
+ * non-null, its transpose (K, w_t_stride); pad columns are written as zeros. */
+int spgnn_weight_cat_bf16(const float* w_a, int64_t a_stride, int32_t rows_a, const float* w_b, int64_t b_stride,
+                          int32_t rows_b, int32_t K, uint16_t* w, int64_t w_stride, uint16_t* w_t, int64_t w_t_stride,
+                          spgnn_stream_t stream);
+
+/* x (N, K) fp32 -> y (N, y_stride) bf16 (round to nearest even), columns [K, y_stride) zero: node data (fvs, pos_enc)
+ * converted once per loader batch. */
+int spgnn_cast_rows_bf16(const float* x, int64_t x_stride, int64_t N, int32_t K, uint16_t* y, int64_t y_stride,
+                         spgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

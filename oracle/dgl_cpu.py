@@ -65,19 +65,125 @@ def in_degrees(dst: Tensor, num_nodes: int, dtype) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# reduced-precision STORAGE emulation (the build's bf16-storage extension, BASELINE config 4; the reference is fp32
+# only).  The product keeps node-feature rows, projected rows and their gradients as bfloat16 in HBM and accumulates in
+# fp32; here that is modelled by rounding a tensor to bf16 where the product stores it:
+#   store(x)      value rounded in the forward pass AND its gradient rounded in the backward pass (a stored activation
+#                 and its stored gradient);
+#   store_fwd(x)  value rounded, gradient passed through (fp32 parameters fed to a bf16 GEMM: their gradient stays fp32);
+#   round_grad(x) identity whose gradient is rounded (the pre-activation gradient g_pre, which the product stores before
+#                 any other kernel reads it).
+# Arithmetic between those points runs in the tensors' own dtype (fp32 or fp64).
+# --------------------------------------------------------------------------------------
+def _rb(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _Store(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class _StoreFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+def _act_kind(fn) -> str:
+    if fn is None:
+        return "none"
+    if fn is F.elu:
+        return "elu"
+    if fn in (torch.tanh, F.tanh):
+        return "tanh"
+    if fn in (F.relu, torch.relu):
+        return "relu"
+    raise ValueError("storage emulation knows elu / tanh / relu / None activations")
+
+
+class _ActStore(torch.autograd.Function):
+    """y = act(x) with the product's storage behaviour: the activated rows are stored rounded (``store_out``; the output
+    layer's rows feed an fp32 head mean unrounded, but the copy kept for the backward pass is rounded all the same), the
+    derivative is formed from that STORED output (ELU: y > 0 ? 1 : y + 1; tanh: 1 - y^2 - all the backward kernel has),
+    the incoming gradient of a stored tensor is itself stored, and the pre-activation gradient is stored before anything
+    else reads it."""
+
+    @staticmethod
+    def forward(ctx, x, kind, store_out):
+        y = {"none": lambda t: t, "elu": F.elu, "tanh": torch.tanh, "relu": F.relu}[kind](x)
+        yr = _rb(y)
+        ctx.save_for_backward(yr)
+        ctx.kind, ctx.store_out = kind, store_out
+        return yr if store_out else y
+
+    @staticmethod
+    def backward(ctx, g):
+        (yr,) = ctx.saved_tensors
+        if ctx.store_out:
+            g = _rb(g)
+        if ctx.kind == "elu":
+            g = g * torch.where(yr > 0, torch.ones_like(yr), yr + 1)
+        elif ctx.kind == "tanh":
+            g = g * (1 - yr * yr)
+        elif ctx.kind == "relu":
+            g = g * (yr > 0).to(g.dtype)
+        return _rb(g), None, None
+
+
+class Bf16Storage:
+    """Hooks for ``gat_conv(..., storage=Bf16Storage)``."""
+    store = staticmethod(_Store.apply)
+    store_fwd = staticmethod(_StoreFwd.apply)
+    round_grad = staticmethod(_RoundGrad.apply)
+
+    @staticmethod
+    def activate(x, fn, store_out: bool):
+        return _ActStore.apply(x, _act_kind(fn), store_out)
+
+
+# --------------------------------------------------------------------------------------
 # layers (SURVEY.md Appendix A)
 # --------------------------------------------------------------------------------------
 def gat_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: Tensor, attn_l: Tensor,
              attn_r: Tensor, res_fc_weight: Optional[Tensor] = None, bias: Optional[Tensor] = None,
              negative_slope: float = 0.2, activation: Optional[Callable] = None,
-             attn_keep: Optional[Tensor] = None, residual_identity: bool = False) -> Tuple[Tensor, Tensor]:
+             attn_keep: Optional[Tensor] = None, residual_identity: bool = False, storage=None,
+             store_out: bool = True) -> Tuple[Tensor, Tensor]:
     """dgl.nn.pytorch.GATConv.forward (Appendix A.1). Returns (rst (N,H,D), a (E,H)).
 
     ``attn_keep`` (E,H), if given, is the already scaled dropout multiplier applied to the
     attention (mask / (1-p)), standing in for ``attn_drop``.
+    ``storage`` (e.g. ``Bf16Storage``): emulate reduced-precision storage of ft / res / out and of their gradients;
+    ``store_out=False`` leaves the layer output unrounded (the output layer, whose head mean is kept in fp32).
     """
     _, H, D = attn_l.shape
-    ft = F.linear(feat, fc_weight).view(num_nodes, H, D)
+    if storage is not None:
+        fc_weight = storage.store_fwd(fc_weight)
+        res_fc_weight = storage.store_fwd(res_fc_weight) if res_fc_weight is not None else None
+    ft = F.linear(feat, fc_weight)
+    if storage is not None:
+        ft = storage.store(ft)
+    ft = ft.view(num_nodes, H, D)
     el = (ft * attn_l).sum(-1)                                       # (N,H)
     er = (ft * attn_r).sum(-1)
     e = F.leaky_relu(el.index_select(0, src) + er.index_select(0, dst), negative_slope)   # u_add_v
@@ -85,12 +191,17 @@ def gat_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: 
     a_used = a if attn_keep is None else a * attn_keep
     rst = spmm_sum(src, dst, ft, num_nodes, a_used.unsqueeze(-1))     # u_mul_e / sum
     if res_fc_weight is not None:
-        rst = rst + F.linear(feat, res_fc_weight).view(num_nodes, H, D)
+        res = F.linear(feat, res_fc_weight)
+        if storage is not None:
+            res = storage.store(res)
+        rst = rst + res.view(num_nodes, H, D)
     elif residual_identity:
         rst = rst + feat.view(num_nodes, -1, D)
     if bias is not None:
         rst = rst + bias.view(1, H, D)
-    if activation is not None:
+    if storage is not None:
+        rst = storage.activate(rst, activation, store_out)
+    elif activation is not None:
         rst = activation(rst)
     return rst, a
 
@@ -147,9 +258,14 @@ def sage_conv_pool(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_po
 # --------------------------------------------------------------------------------------
 # model stacks (reference models.py:160-540, 650-696) driven by a state_dict
 # --------------------------------------------------------------------------------------
-def _gat_layer(sd: Dict[str, Tensor], prefix: str, src, dst, n, h, slope, act):
+def _gat_layer(sd: Dict[str, Tensor], prefix: str, src, dst, n, h, slope, act, storage=None, store_out=True,
+               residual_identity=False):
+    """``residual_identity``: the layer is residual with in_feats == out_feats (DGL then uses an Identity ``res_fc``, which
+    has no state_dict entry, so it cannot be inferred from ``sd``)."""
+    w_res = sd.get(prefix + "res_fc.weight")
     return gat_conv(src, dst, n, h, sd[prefix + "fc.weight"], sd[prefix + "attn_l"], sd[prefix + "attn_r"],
-                    sd.get(prefix + "res_fc.weight"), sd.get(prefix + "bias"), slope, act)[0]
+                    w_res, sd.get(prefix + "bias"), slope, act, storage=storage, store_out=store_out,
+                    residual_identity=residual_identity and w_res is None)[0]
 
 
 def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
@@ -157,13 +273,27 @@ def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
     return max(idx) + 1 if idx else 0
 
 
-def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, activation=F.elu, norm=False):
-    """reference models.py:321-329 (GAT.forward)."""
+def _is_identity_res(sd, prefix: str, residual: bool) -> bool:
+    """A residual GATConv whose in_feats equals its per-head out_feats has DGL's Identity ``res_fc`` (no weight)."""
+    if not residual or (prefix + "res_fc.weight") in sd:
+        return False
+    H_D, f_in = sd[prefix + "fc.weight"].shape
+    return f_in == sd[prefix + "attn_l"].shape[-1]
+
+
+def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, activation=F.elu, norm=False, storage=None,
+              residual=True):
+    """reference models.py:321-329 (GAT.forward).  ``residual``: the stack was built with ``residual=True`` (every
+    shipped GAT config): layers without a ``res_fc.weight`` whose widths match then carry DGL's identity residual."""
     L = _count_layers(sd, prefix)
-    h = fvs
+    h = fvs if storage is None else storage.store_fwd(fvs)
     for l in range(L - 1):
-        h = _gat_layer(sd, f"{prefix}{l}.", src, dst, n, h, negative_slope, activation).flatten(1)
-    out = _gat_layer(sd, f"{prefix}{L - 1}.", src, dst, n, h, negative_slope, None).mean(1)
+        p = f"{prefix}{l}."
+        h = _gat_layer(sd, p, src, dst, n, h, negative_slope, activation, storage,
+                       residual_identity=_is_identity_res(sd, p, residual)).flatten(1)
+    p = f"{prefix}{L - 1}."
+    out = _gat_layer(sd, p, src, dst, n, h, negative_slope, None, storage, store_out=False,
+                     residual_identity=_is_identity_res(sd, p, residual)).mean(1)
     return F.normalize(out, p=2, dim=1) if norm else out
 
 

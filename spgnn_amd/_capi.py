@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -72,6 +72,19 @@ SIGNATURES = {
     "spgnn_weight_cat_partials": [_i32, _i32, _i64, _i64],
     "spgnn_tree_distance_encoding": [_i32p, _i32p, _vp, _i32p, _i32, _f32p, _i64, _i32p, _i64, _i64, _vp],
     "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
+    # bf16-storage path
+    "spgnn_gat_fwd_bf16": [_i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _vp, _i64, _f32p, _vp, _i64, _f32p, _i64,
+                           _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+    "spgnn_gat_bwd_dst_bf16": [_i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _f32p, _vp, _i64, _i32, _vp, _i64,
+                               _vp, _i64, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+    "spgnn_gat_bwd_src_bf16": [_i32p, _i32p, _i32p, _f32p, _f32p, _vp, _i64, _vp, _i64, _f32p, _i64, _f32p, _f32p, _f32p,
+                               _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
+    "spgnn_scores_bwd_w_bf16": [_f32p, _i64, _vp, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
+    "spgnn_cat_dropout_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _vp],
+    "spgnn_gemm_nt_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
+    "spgnn_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _i64, _i64, _vp],
+    "spgnn_weight_cat_bf16": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp],
+    "spgnn_cast_rows_bf16": [_f32p, _i64, _i64, _i32, _vp, _i64, _vp],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,24 +1,49 @@
-"""Build libspgnn_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Build libspgnn_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+Each .hip source is compiled to its own object (in parallel: the three files take 30-80 s each) and only the
+sources that changed since the last build are recompiled; then one link step."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libspgnn_hip.so")
-SOURCES = [os.path.join(HERE, "spgnn_kernels.hip"), os.path.join(HERE, "spgnn_gemm.hip")]
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
+HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+
+
+def _stale(target: str, deps) -> bool:
+    return not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    deps = SOURCES + [os.path.join(ROOT, "include", "spgnn_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-I", os.path.join(ROOT, "include"), "-o", OUT] + SOURCES
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo = [s for s in SOURCES if force or _stale(_obj(s), [s] + HEADERS)]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=len(todo)) as ex:
+            list(ex.map(compile_one, todo))
+    objs = [_obj(s) for s in SOURCES]
+    if todo or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return OUT
 
 

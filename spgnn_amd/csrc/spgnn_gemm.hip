@@ -22,6 +22,7 @@
 #include <stdio.h>
 
 #include "spgnn_hip.h"
+#include "spgnn_internal.h"
 
 namespace gemm {
 
@@ -1610,33 +1611,33 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
                         spgnn_stream_t stream) {
   if (mean_out) {
-    if (!mean_other) return SPGNN_ERR_NULLPTR;
+    if (!mean_other) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
         (reinterpret_cast<uintptr_t>(mean_other) & 15) || (reinterpret_cast<uintptr_t>(mean_out) & 15) || g_gemm_variant == 1)
-      return SPGNN_ERR_STRIDE;
+      return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   }
-  if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (score_out) {
-    if (!score_l || !score_r) return SPGNN_ERR_NULLPTR;
+    if (!score_l || !score_r) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (score_cols <= 0 || (score_cols & 63) || score_cols > N || g_gemm_variant == 1 ||
         (reinterpret_cast<uintptr_t>(score_l) & 15) || (reinterpret_cast<uintptr_t>(score_r) & 15) ||
         (reinterpret_cast<uintptr_t>(score_out) & 7))
-      return SPGNN_ERR_SHAPE;
+      return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   }
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return SPGNN_ERR_ENUM;
-  if ((bias || activation != SPGNN_ACT_NONE) && g_gemm_variant == 1) return SPGNN_ERR_ENUM;   // pipelined kernel only
-  if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if ((bias || activation != SPGNN_ACT_NONE) && g_gemm_variant == 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);   // pipelined kernel only
+  if (upd_j < 0 || upd_j > 32) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (upd_j > 0) {
-    if (!upd_u || !upd_v) return SPGNN_ERR_NULLPTR;
+    if (!upd_u || !upd_v) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
         (reinterpret_cast<uintptr_t>(upd_v) & 15) || g_gemm_variant == 1)
-      return SPGNN_ERR_STRIDE;        // V rows: 16-byte aligned, zero padded to a multiple of 4 columns
+      return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);        // V rows: 16-byte aligned, zero padded to a multiple of 4 columns
   }
   if (M == 0 || N == 0) return SPGNN_OK;
-  if (!A || !B || !C) return SPGNN_ERR_NULLPTR;
+  if (!A || !B || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (lda < K || ldb < K || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15))
-    return SPGNN_ERR_STRIDE;
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_variant == 1) {
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
@@ -1659,10 +1660,9 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                    mean_other, mean_other_stride, mean_out, mean_out_stride};
       int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
       const size_t lds_bytes = 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16);       // 160 KB
-      static bool attr3 = false;
-      if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr3 = true; }
+      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v3, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v3, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
-      return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+      return spgnn_detail::check_launch("spgnn_gemm");
     }
     const int WM = g_gemm_variant == 4 ? 4 : (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
@@ -1673,16 +1673,14 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
-      static bool attr4 = false;
-      if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
+      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v2<4>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
     } else {
-      static bool attr2 = false;
-      if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_f16x3_v2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
+      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v2<2>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
     }
   }
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1698,45 +1696,45 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
                            int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* bias,
                            int32_t activation, const float* other_head, int64_t other_head_stride, float* mean_out,
                            int64_t mean_out_stride, spgnn_stream_t stream) {
-  if (!other_head || !mean_out) return SPGNN_ERR_NULLPTR;
+  if (!other_head || !mean_out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
                       nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, stream);
 }
 
 int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
                      uint16_t* hi, uint16_t* lo, int64_t plane_stride, int64_t Mp, int64_t Kp, spgnn_stream_t stream) {
-  if (M < 0 || K <= 0 || Mp < M || Kp < K || (Kp & 31) || Mp > INT32_MAX || Kp > INT32_MAX) return SPGNN_ERR_SHAPE;
+  if (M < 0 || K <= 0 || Mp < M || Kp < K || (Kp & 31) || Mp > INT32_MAX || Kp > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (Mp == 0) return SPGNN_OK;
-  if (!hi || !lo || (M > 0 && !x)) return SPGNN_ERR_NULLPTR;
+  if (!hi || !lo || (M > 0 && !x)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (x_stride < K || plane_stride < Kp || (plane_stride & 7) || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
       (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(lo) & 15))
-    return SPGNN_ERR_STRIDE;
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   int64_t blocks = (Mp * (Kp / 8) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(gemm::split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, (int)M,
                      (int)K, scale, extra_factor, reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), plane_stride,
                      (int)Mp, (int)Kp);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi, const uint16_t* B_lo,
                          int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t Kp, const float* scale_a,
                          const float* scale_b, const float* upd_u, int64_t upd_u_stride, const float* upd_v,
                          int64_t upd_v_stride, int32_t upd_j, const float* bias, int32_t activation, spgnn_stream_t stream) {
-  if (M < 0 || N < 0 || Kp <= 0 || (Kp & 31) || M > INT32_MAX || N > INT32_MAX || Kp > INT32_MAX) return SPGNN_ERR_SHAPE;
-  if (upd_j < 0 || upd_j > 32) return SPGNN_ERR_SHAPE;
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return SPGNN_ERR_ENUM;
+  if (M < 0 || N < 0 || Kp <= 0 || (Kp & 31) || M > INT32_MAX || N > INT32_MAX || Kp > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (upd_j < 0 || upd_j > 32) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (upd_j > 0) {
-    if (!upd_u || !upd_v) return SPGNN_ERR_NULLPTR;
+    if (!upd_u || !upd_v) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
         (reinterpret_cast<uintptr_t>(upd_v) & 15))
-      return SPGNN_ERR_STRIDE;
+      return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   }
   if (M == 0 || N == 0) return SPGNN_OK;
-  if (!A_hi || !A_lo || !B_hi || !B_lo || !C) return SPGNN_ERR_NULLPTR;
+  if (!A_hi || !A_lo || !B_hi || !B_lo || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (lda < Kp || ldb < Kp || ldc < N || (lda & 7) || (ldb & 7) || (reinterpret_cast<uintptr_t>(A_hi) & 15) ||
       (reinterpret_cast<uintptr_t>(A_lo) & 15) || (reinterpret_cast<uintptr_t>(B_hi) & 15) || (reinterpret_cast<uintptr_t>(B_lo) & 15))
-    return SPGNN_ERR_STRIDE;
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
   const int WM = (g_gemm_variant == 3 || M < 4096 || Kp < 512 || N < 512) ? 2 : 4;
   const int TBM = 64 * WM;
@@ -1749,26 +1747,24 @@ int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda
   const size_t epi = (size_t)(2 * WM) * 32 * 68 * sizeof(float);               // epilogue slabs share the buffer
   if (lds_bytes < epi) lds_bytes = epi;
   if (WM == 4) {
-    static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_planes<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr4 = true; }
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_planes<4>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
     hipLaunchKernelGGL(gemm::gemm_nt_planes<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
   } else {
-    static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm::gemm_nt_planes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr2 = true; }
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_planes<2>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
     hipLaunchKernelGGL(gemm::gemm_nt_planes<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
   }
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                   int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
                   float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
-  if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return SPGNN_ERR_SHAPE;
-  if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return SPGNN_ERR_STRIDE;
-  if (!A || !B || !C) return SPGNN_ERR_NULLPTR;
+  if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+  if (!A || !B || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (lda < M || ldb < N || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15) || (splits > 1 && split_stride < M * ldc))
-    return SPGNN_ERR_STRIDE;
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   int64_t rps = (R + splits - 1) / splits;
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
@@ -1784,8 +1780,7 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                        (hipStream_t)stream, a);
   } else {
     const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm::gemm_tn_f16x3_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr = true; }
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
 #ifndef SPGNN_TN_BY_XCD
 #define SPGNN_TN_BY_XCD 1
 #endif
@@ -1798,14 +1793,14 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                          (hipStream_t)stream, a);
     }
   }
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream) {
-  if (splits <= 0 || n < 0 || (n & 3) || (split_stride & 3) || split_stride < n) return SPGNN_ERR_SHAPE;
+  if (splits <= 0 || n < 0 || (n & 3) || (split_stride & 3) || split_stride < n) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (n == 0) return SPGNN_OK;
-  if (!partials || !out) return SPGNN_ERR_NULLPTR;
-  if ((reinterpret_cast<uintptr_t>(partials) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return SPGNN_ERR_STRIDE;
+  if (!partials || !out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if ((reinterpret_cast<uintptr_t>(partials) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   const int64_t n4 = n / 4;
   hipStream_t st = (hipStream_t)stream;
   if (splits <= 8)
@@ -1814,48 +1809,48 @@ int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t spli
     hipLaunchKernelGGL(gemm::sum_partials_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
   else
     hipLaunchKernelGGL(gemm::sum_partials_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, partials, split_stride / 4, (int)splits, n4, out);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_sum_partials_blockdiag(const float* partials, int64_t split_stride, int32_t splits, int32_t H, int32_t D, int32_t ld,
                                  float* out, spgnn_stream_t stream) {
-  if (splits <= 0 || H <= 0 || D <= 0 || ld < H * D || split_stride < (int64_t)2 * H * ld) return SPGNN_ERR_SHAPE;
-  if (!partials || !out) return SPGNN_ERR_NULLPTR;
+  if (splits <= 0 || H <= 0 || D <= 0 || ld < H * D || split_stride < (int64_t)2 * H * ld) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!partials || !out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   const int n = 2 * H * D;
   hipLaunchKernelGGL(gemm::sum_partials_blockdiag_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
                      partials, split_stride, (int)splits, (int)H, (int)D, (int)ld, out);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_sum_partials_compact(const float* partials, int64_t split_stride, int32_t splits, int32_t M, int32_t N, int64_t ld_in,
                                float* out, int64_t out_stride, float* out2, int64_t out2_stride, int32_t split_col, float* extra,
                                int32_t extra_col, spgnn_stream_t stream) {
   if (splits <= 0 || M <= 0 || N <= 0 || ld_in < N || split_stride < (int64_t)M * ld_in || (extra && (extra_col < 0 || extra_col >= ld_in)))
-    return SPGNN_ERR_SHAPE;
-  if (!partials || !out) return SPGNN_ERR_NULLPTR;
+    return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!partials || !out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (out2 ? (split_col <= 0 || split_col >= N || out_stride < split_col || out2_stride < N - split_col) : out_stride < N)
-    return SPGNN_ERR_STRIDE;
-  if ((ld_in & 3) || (split_stride & 3) || (reinterpret_cast<uintptr_t>(partials) & 15)) return SPGNN_ERR_STRIDE;   // float4 reads
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+  if ((ld_in & 3) || (split_stride & 3) || (reinterpret_cast<uintptr_t>(partials) & 15)) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);   // float4 reads
   const int64_t n4 = (int64_t)M * (ld_in / 4);
   hipLaunchKernelGGL(gemm::sum_partials_compact_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                      partials, split_stride / 4, (int)splits, (int)M, (int)N, (int)(ld_in / 4), out, out_stride, out2, out2_stride,
                      (int)split_col, extra, (int)extra_col);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_weight_cat(const float* a, int64_t a_stride, int32_t rows_a, const float* b, int64_t b_stride, int32_t rows_b, int32_t K,
                      float* dst, int64_t dst_stride, float* dst_t, int64_t dst_t_stride, float* absmax_partials,
                      spgnn_stream_t stream) {
   const int64_t R = (int64_t)rows_a + rows_b;
-  if (rows_a <= 0 || rows_b < 0 || K <= 0) return SPGNN_ERR_SHAPE;
-  if (!a || !dst || !absmax_partials || (rows_b > 0 && !b)) return SPGNN_ERR_NULLPTR;
-  if (a_stride < K || (rows_b > 0 && b_stride < K) || dst_stride < K || (dst_t && dst_t_stride < R)) return SPGNN_ERR_STRIDE;
+  if (rows_a <= 0 || rows_b < 0 || K <= 0) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!a || !dst || !absmax_partials || (rows_b > 0 && !b)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (a_stride < K || (rows_b > 0 && b_stride < K) || dst_stride < K || (dst_t && dst_t_stride < R)) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   const int64_t wide = dst_stride > K ? dst_stride : K;             // tiles cover dst's pad columns and dst_t's pad columns
   const int64_t tall = dst_t && dst_t_stride > R ? dst_t_stride : R;
   const dim3 grid((unsigned)((wide + 31) / 32), (unsigned)((tall + 31) / 32));
   hipLaunchKernelGGL(gemm::weight_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, a_stride, (int)rows_a, b, b_stride,
                      (int)rows_b, (int)K, dst, dst_stride, dst_t, dst_t_stride, absmax_partials);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int64_t spgnn_weight_cat_partials(int32_t rows, int32_t K, int64_t dst_stride, int64_t dst_t_stride) {
@@ -1866,9 +1861,9 @@ int64_t spgnn_weight_cat_partials(int32_t rows, int32_t K, int64_t dst_stride, i
 
 int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t cols, float* scale, float* workspace,
                      int32_t workspace_floats, spgnn_stream_t stream) {
-  if (rows < 0 || cols <= 0 || cols > INT32_MAX || workspace_floats < 1) return SPGNN_ERR_SHAPE;
-  if (!scale || !workspace || (rows > 0 && !x)) return SPGNN_ERR_NULLPTR;
-  if (rows > 0 && ((x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return SPGNN_ERR_STRIDE;
+  if (rows < 0 || cols <= 0 || cols > INT32_MAX || workspace_floats < 1) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!scale || !workspace || (rows > 0 && !x)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (rows > 0 && ((x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (rows * ((cols + 3) / 4) + 255) / 256;
   if (blocks > workspace_floats) blocks = workspace_floats;
@@ -1876,13 +1871,13 @@ int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t col
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gemm::absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_stride, rows, (int)cols, workspace);
   hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, workspace, (int)blocks, 1.f, scale);
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale, uint32_t* workspace,
                               spgnn_stream_t stream) {
-  if (n < 0 || n > INT32_MAX || !(factor > 0.f)) return SPGNN_ERR_SHAPE;
-  if (!scale || (n > 0 && !partials)) return SPGNN_ERR_NULLPTR;
+  if (n < 0 || n > INT32_MAX || !(factor > 0.f)) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!scale || (n > 0 && !partials)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
   if (n > 1024 && workspace && (reinterpret_cast<uintptr_t>(partials) & 15) == 0) {   // one 64-thread block: 13 us at n = 4776
     int blocks = (int)((n / 4 + 255) / 256);
@@ -1891,7 +1886,7 @@ int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, fl
   } else {
     hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, partials, (int)n, factor, scale);
   }
-  return hipGetLastError() == hipSuccess ? SPGNN_OK : -1000;
+  return spgnn_detail::check_launch("spgnn_gemm");
 }
 
 }  // extern "C"

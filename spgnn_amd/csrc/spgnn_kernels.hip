@@ -17,9 +17,12 @@
 #include <stdlib.h>
 #include <math.h>
 
-#include "spgnn_hip.h"
+#include <mutex>
 
-namespace {
+#include "spgnn_hip.h"
+#include "spgnn_internal.h"
+
+namespace spgnn_detail {
 
 thread_local char g_err[512] = "";
 
@@ -36,6 +39,46 @@ int check_launch(const char* what) {
   }
   return SPGNN_OK;
 }
+
+int fail_at(int code, const char* func, int line) {
+  const char* kind = code == SPGNN_ERR_NULLPTR ? "null pointer" : code == SPGNN_ERR_SHAPE ? "bad shape / size argument"
+                   : code == SPGNN_ERR_STRIDE ? "bad row stride or alignment" : code == SPGNN_ERR_ENUM ? "bad enum / option value"
+                   : "argument error";
+  snprintf(g_err, sizeof(g_err), "%s: %s (line %d)", func, kind, line);
+  return code;
+}
+
+int ensure_dynamic_lds(const void* func, int bytes) {
+  constexpr int kMaxDev = 64, kMaxFn = 64;
+  static const void* fns[kMaxFn];
+  static int sizes[kMaxFn][kMaxDev];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  int slot = -1;
+  for (int i = 0; i < kMaxFn; ++i) {
+    if (fns[i] == func) { slot = i; break; }
+    if (fns[i] == nullptr) { fns[i] = func; slot = i; break; }
+  }
+  if (slot >= 0 && sizes[slot][dev] >= bytes) return SPGNN_OK;
+  hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return -(1000 + (int)e);
+  }
+  if (slot >= 0) sizes[slot][dev] = bytes;
+  return SPGNN_OK;
+}
+
+}  // namespace spgnn_detail
+
+namespace {
+
+using spgnn_detail::check_launch;
+using spgnn_detail::fail;
+using spgnn_detail::g_err;
 
 constexpr int kBlock = 256;
 
@@ -86,6 +129,27 @@ __device__ __forceinline__ int64_t xcd_block(void) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Row storage types.  Every row kernel computes in fp32; `ST` is what the node-feature rows are STORED as in HBM:
+// float, or bf16s = bfloat16 (BASELINE config "st_gat_6 ... bf16": bf16 storage, fp32 accumulate).  A lane's chunk is four
+// consecutive elements either way (16-byte or 8-byte vector access), so the team geometry is the same for both.
+struct bf16s { uint16_t bits; };
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldv(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldv(const bf16s* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void stv(float* p, float4 v) { st4(p, v); }
+__device__ __forceinline__ void stv(bf16s* p, float4 v) {       // round to nearest even (v_cvt_pk_bf16_f32)
+  const f32x4_t f = {v.x, v.y, v.z, v.w};
+  union { bf16x4_t h; uint2 u; } q;
+  q.h = __builtin_convertvector(f, bf16x4_t);
+  *reinterpret_cast<uint2*>(p) = q.u;
+}
+template <typename ST> struct is_f32 { static constexpr bool value = false; };
+template <> struct is_f32<float> { static constexpr bool value = true; };
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ void fma4(float4& acc, float s, float4 x) {
   acc.x = fmaf(s, x.x, acc.x); acc.y = fmaf(s, x.y, acc.y); acc.z = fmaf(s, x.z, acc.z); acc.w = fmaf(s, x.w, acc.w);
@@ -230,27 +294,28 @@ template <int R, int CH> struct Slots {
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
-struct GatFwd {
+template <typename ST> struct GatFwdT {
   const int32_t* indptr; const int32_t* indices;
-  const float* ft; int64_t ft_ld;
+  const ST* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
-  const float* res; int64_t res_ld;
+  const ST* res; int64_t res_ld;
   const float* bias;
-  float* out; int64_t out_ld;            // per-head output (N, H*D); may be null when out_mean is set
+  ST* out; int64_t out_ld;               // per-head output (N, H*D); may be null when out_mean is set
   float* out_mean; int64_t out_mean_ld;  // optional head-mean output (N, D)
   float* attn;
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;              // optional device word added to `seed` (fresh masks under graph replay)
 };
+using GatFwd = GatFwdT<float>;
 
 // TT = 64: the team is the whole wave (one node per wave).  Node id, degree, edge endpoints and - when a head is
 // at least a wave wide (CH >= 1) - the attention weights are then wave-uniform: they are moved to SGPRs
 // (v_readfirstlane), row bases become scalar, the degree tests become scalar branches, and about 30 VGPRs per
 // lane are freed (2x1024 forward: 159 -> ~90 VGPRs).  TT = 0: team width a.T < 64 at run time (several nodes
 // per wave; only R = 1 geometries get there), everything stays per lane.
-template <int TT, int R, int CH, bool MEAN>
-__global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
+template <typename ST, int TT, int R, int CH, bool MEAN>
+__global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
@@ -277,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.res) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = ld4(a.res + v * a.res_ld + (r * T + lane) * 4);
+    for (int r = 0; r < R; ++r) acc[r] = ldv(a.res + v * a.res_ld + (r * T + lane) * 4);
   }
   if (a.bias) {
     float4 q[R];
@@ -339,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
 #pragma unroll
       for (int q = 0; q < kGather; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
+        for (int r = 0; r < R; ++r) x[q][r] = ldv(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
 #pragma unroll
       for (int q = 0; q < kGather; ++q)
 #pragma unroll
@@ -359,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
     }
     for (int j = beg; j < end; ++j) {
       const int64_t u = a.indices[j];
-      const float* row = a.ft + u * a.ft_ld;
+      const ST* row = a.ft + u * a.ft_ld;
       float w[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -369,14 +434,14 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
         w[s] = a.p > 0.f ? al * keep_scale(a.seed, eidx, a.p, a.inv_keep) : al;
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
+      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ldv(row + (r * T + lane) * 4));
     }
   }
 
   act_fwd_rows<R>(acc, a.act);
   if (a.out) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) st4(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]);
+    for (int r = 0; r < R; ++r) stv(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]);
   }
   if (MEAN) {   // heads live in chunks r, r+CH, r+2CH, ... of the same lane (CH >= 1): mean is lane-local
     constexpr int CHs = CH == 0 ? 1 : CH;
@@ -393,8 +458,8 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwd a) {
 }
 
 // teams narrower than a wave exist only for R = 1 (pick_team tries 64 lanes first): keep the other instances out
-template <int R, int CH, bool MEAN> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatFwd& a) {
-  if constexpr (R <= 4) hipLaunchKernelGGL((gat_fwd_vec<0, R, CH, MEAN>), grid, block, 0, st, a);
+template <typename ST, int R, int CH, bool MEAN> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatFwdT<ST>& a) {
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_fwd_vec<ST, 0, R, CH, MEAN>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, column); any H, D, stride, alignment
@@ -436,14 +501,14 @@ __global__ void head_mean_scalar(const float* out, int64_t out_ld, float* om, in
 // -------------------------------------------------------------------------------------------------
 // backward, dst-major half
 // -------------------------------------------------------------------------------------------------
-struct GatBwdDst {
+template <typename ST> struct GatBwdDstT {
   const int32_t* indptr; const int32_t* indices;
-  const float* ft; int64_t ft_ld;
+  const ST* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
   const float* attn;
-  const float* g_out; int64_t g_out_ld;  // (N, H*D), or (N, D) when mean != 0
-  const float* out; int64_t out_ld;
-  float* g_pre; int64_t g_pre_ld;
+  const void* g_out; int64_t g_out_ld;   // (N, H*D) of ST, or the head mean's gradient (N, D), always fp32, when mean != 0
+  const ST* out; int64_t out_ld;
+  ST* g_pre; int64_t g_pre_ld;
   float* g_e;
   float* g_er; int64_t gs_ld;
   float* absmax;                         // optional: absmax[v] = max |g_pre[v,:]| (feeds the split-GEMM scale)
@@ -451,9 +516,10 @@ struct GatBwdDst {
   float slope; int act; float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;
 };
+using GatBwdDst = GatBwdDstT<float>;
 
-template <int TT, int R, int CH>
-__global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
+template <typename ST, int TT, int R, int CH>
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
@@ -472,12 +538,16 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int c = (r * T + lane) * 4;
-    g[r] = ld4(a.g_out + v * a.g_out_ld + (a.mean ? (CH >= 1 ? ((r % (CH ? CH : 1)) * T + lane) * 4 : c % a.D) : c));
+    if (is_f32<ST>::value || a.mean)
+      g[r] = ld4(reinterpret_cast<const float*>(a.g_out) + v * a.g_out_ld +
+                 (a.mean ? (CH >= 1 ? ((r % (CH ? CH : 1)) * T + lane) * 4 : c % a.D) : c));
+    else
+      g[r] = ldv(reinterpret_cast<const ST*>(a.g_out) + v * a.g_out_ld + c);
   }
   if (a.act != SPGNN_ACT_NONE) {
     float4 o[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) o[r] = ld4(a.out + v * a.out_ld + (r * T + lane) * 4);
+    for (int r = 0; r < R; ++r) o[r] = ldv(a.out + v * a.out_ld + (r * T + lane) * 4);
     if (a.mean) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { g[r].x *= gscale; g[r].y *= gscale; g[r].z *= gscale; g[r].w *= gscale; }
@@ -488,7 +558,16 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
     for (int r = 0; r < R; ++r) { g[r].x *= gscale; g[r].y *= gscale; g[r].z *= gscale; g[r].w *= gscale; }
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) st4(a.g_pre + v * a.g_pre_ld + (r * T + lane) * 4, g[r]);
+  for (int r = 0; r < R; ++r) stv(a.g_pre + v * a.g_pre_ld + (r * T + lane) * 4, g[r]);
+  if (!is_f32<ST>::value) {      // the dots below must see what the src-major half and the GEMMs will read: the ROUNDED g_pre
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const f32x4_t f = {g[r].x, g[r].y, g[r].z, g[r].w};
+      const bf16x4_t h = __builtin_convertvector(f, bf16x4_t);
+      const f32x4_t b = __builtin_convertvector(h, f32x4_t);
+      g[r] = make_float4(b[0], b[1], b[2], b[3]);
+    }
+  }
   if (a.absmax) {
     float mx = 0.f;
 #pragma unroll
@@ -532,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
 #pragma unroll
       for (int q = 0; q < kGather; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
+        for (int r = 0; r < R; ++r) x[q][r] = ldv(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
 #pragma unroll
       for (int q = 0; q < kGather; ++q) {
 #pragma unroll
@@ -569,12 +648,12 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
   for (int s = 0; s < NS; ++s) S[s] = 0.f;
   for (int j = beg; j < end; ++j) {
     const int64_t u = a.indices[j];
-    const float* row = a.ft + u * a.ft_ld;
+    const ST* row = a.ft + u * a.ft_ld;
     float pd[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) pd[s] = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) pd[SL::of(r)] += dot4(ld4(row + (r * T + lane) * 4), g[r]);
+    for (int r = 0; r < R; ++r) pd[SL::of(r)] += dot4(ldv(row + (r * T + lane) * 4), g[r]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       float x = team_sum(pd[s], width);
@@ -602,8 +681,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDst a) {
   }
 }
 
-template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdDst& a) {
-  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_dst_vec<0, R, CH>), grid, block, 0, st, a);
+template <typename ST, int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdDstT<ST>& a) {
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_dst_vec<ST, 0, R, CH>), grid, block, 0, st, a);
 }
 
 // scalar fallback: one thread per (node, head)
@@ -617,7 +696,7 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
   const float gscale = a.mean ? 1.f / (float)a.H : 1.f;
   float amx = 0.f;
   for (int d = 0; d < a.D; ++d) {
-    float q = a.g_out[v * a.g_out_ld + (a.mean ? d : base + d)] * gscale;
+    float q = reinterpret_cast<const float*>(a.g_out)[v * a.g_out_ld + (a.mean ? d : base + d)] * gscale;
     if (a.act != SPGNN_ACT_NONE) q *= act_bwd_from_out(a.out[v * a.out_ld + base + d], a.act);
     a.g_pre[v * a.g_pre_ld + base + d] = q;
     amx = fmaxf(amx, fabsf(q));
@@ -650,11 +729,11 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
 // -------------------------------------------------------------------------------------------------
 // backward, src-major half
 // -------------------------------------------------------------------------------------------------
-struct GatBwdSrc {
+template <typename ST> struct GatBwdSrcT {
   const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
   const float* attn; const float* g_e;
-  const float* g_pre; int64_t g_pre_ld;
-  float* g_ft; int64_t g_ft_ld;
+  const ST* g_pre; int64_t g_pre_ld;
+  ST* g_ft; int64_t g_ft_ld;
   float* g_el; int64_t gs_ld;
   float* absmax;                         // optional: absmax[u] = max |g_ft[u,:]|
   int64_t N; int H; int D; int T;
@@ -663,9 +742,10 @@ struct GatBwdSrc {
   // optional score term (el / er computed FROM ft, DGL's own form): g_ft[u,h,:] += g_el[u,h] * sc_l[h,:] + g_er[u,h] * sc_r[h,:]
   const float* sc_l; const float* sc_r; const float* g_er;
 };
+using GatBwdSrc = GatBwdSrcT<float>;
 
-template <int TT, int R, int CH>
-__global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
+template <typename ST, int TT, int R, int CH>
+__global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
@@ -720,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
 #pragma unroll
       for (int q = 0; q < kGather; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) x[q][r] = ld4(a.g_pre + (int64_t)vv[k0 + q] * a.g_pre_ld + (r * T + lane) * 4);
+        for (int r = 0; r < R; ++r) x[q][r] = ldv(a.g_pre + (int64_t)vv[k0 + q] * a.g_pre_ld + (r * T + lane) * 4);
 #pragma unroll
       for (int q = 0; q < kGather; ++q)
 #pragma unroll
@@ -729,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
   } else {
     for (int k = beg; k < end; ++k) {
       const int64_t v = a.out_indices[k], pos = a.out_pos[k];
-      const float* row = a.g_pre + v * a.g_pre_ld;
+      const ST* row = a.g_pre + v * a.g_pre_ld;
       float w[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -739,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
         gel[s] += a.g_e[eidx];
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ld4(row + (r * T + lane) * 4));
+      for (int r = 0; r < R; ++r) fma4(acc[r], w[SL::of(r)], ldv(row + (r * T + lane) * 4));
     }
   }
   if (a.sc_l) {
@@ -754,7 +834,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
     }
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) st4(a.g_ft + u * a.g_ft_ld + (r * T + lane) * 4, acc[r]);
+  for (int r = 0; r < R; ++r) stv(a.g_ft + u * a.g_ft_ld + (r * T + lane) * 4, acc[r]);
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (wr[s]) a.g_el[u * a.gs_ld + hs[s]] = gel[s];
@@ -767,8 +847,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrc a) {
   }
 }
 
-template <int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdSrc& a) {
-  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_src_vec<0, R, CH>), grid, block, 0, st, a);
+template <typename ST, int R, int CH> static void launch_small_team(dim3 grid, dim3 block, hipStream_t st, const GatBwdSrcT<ST>& a) {
+  if constexpr (R <= 4) hipLaunchKernelGGL((gat_bwd_src_vec<ST, 0, R, CH>), grid, block, 0, st, a);
 }
 
 __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
@@ -1385,8 +1465,8 @@ __device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
   return z ^ (z >> 31);
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __restrict__ src, int64_t src_ld, float* __restrict__ dst,
+template <typename ST, bool VEC>
+__global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const ST* __restrict__ src, int64_t src_ld, ST* __restrict__ dst,
                                                              int64_t dst_ld, int64_t N, int w, int off, int total, float p,
                                                              float inv_keep, uint64_t seed, const uint64_t* __restrict__ seed_off,
                                                              int backward, float* __restrict__ absmax) {
@@ -1398,11 +1478,11 @@ __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __rest
     const int64_t row = i / w4; const int c = (int)(i % w4) * 4;
     // forward: src is a source tensor (its own column 0 = output column off); backward: src is the gradient of the
     // concatenation (read at off + c) and dst the gradient of the source
-    const float* sp = src + row * src_ld + (backward ? off : 0) + c;
-    float* dp = dst + row * dst_ld + (backward ? 0 : off) + c;
+    const ST* sp = src + row * src_ld + (backward ? off : 0) + c;
+    ST* dp = dst + row * dst_ld + (backward ? 0 : off) + c;
     float v[4];
-    if (VEC) { const float4 q = ld4(sp); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-    else {
+    if (VEC) { const float4 q = ldv(sp); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else if constexpr (is_f32<ST>::value) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = c + j < w ? sp[j] : 0.f;
     }
@@ -1411,8 +1491,8 @@ __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] *= ((unsigned)(z >> (16 * j)) & 0xFFFFu) >= thr ? inv_keep : 0.f;
     }
-    if (VEC) st4(dp, make_float4(v[0], v[1], v[2], v[3]));
-    else {
+    if (VEC) stv(dp, make_float4(v[0], v[1], v[2], v[3]));
+    else if constexpr (is_f32<ST>::value) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (c + j < w) dp[j] = v[j];
     }
@@ -1806,9 +1886,9 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
 
 // one wave per 256 columns x one row range (four waves of a block side by side: a row is then read as one 4 KB
 // run instead of 1 KB pieces at different times - DRAM-friendlier); partial sums per range, reduced by the caller
-template <int J>
+template <typename ST, int J>
 __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
-                                                          const float* __restrict__ X, int64_t ldx,
+                                                          const ST* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ part, int Kp, int64_t N, int K,
                                                           int64_t rows_per_split, int jn) {
   // a block's waves sit side by side on one row: 4 KB contiguous per row.  Every lane of a wave stays in the loop (the gS
@@ -1826,8 +1906,8 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
   for (int j = 0; j < J; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t n = n0;
   if (n + 4 <= n1) {                   // 4 rows per trip, the next trip's rows already in flight while this one is summed
-    const float* xr = X + n * ldx + kk;
-    float4 x0 = ld4(xr), x1 = ld4(xr + ldx), x2 = ld4(xr + 2 * ldx), x3 = ld4(xr + 3 * ldx);
+    const ST* xr = X + n * ldx + kk;
+    float4 x0 = ldv(xr), x1 = ldv(xr + ldx), x2 = ldv(xr + 2 * ldx), x3 = ldv(xr + 3 * ldx);
     // the four gS rows of a trip arrive as two vector loads issued with the x rows (lanes 0-31: one row, lanes 32-63: the
     // next; J <= 32) and are broadcast by v_readlane: as scalar loads at the point of use they were waited for in every trip
     const int gl = threadIdx.x & 63;
@@ -1847,8 +1927,8 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
     for (; n + 8 <= n1; n += 4) {      // steady state: the prefetch is unconditional (a test around it made hipcc drain the queue)
       const float4 c0 = x0, c1 = x1, c2 = x2, c3 = x3;
       const float ca = ga, cb = gb;
-      const float* xn = X + (n + 4) * ldx + kk;
-      x0 = ld4(xn); x1 = ld4(xn + ldx); x2 = ld4(xn + 2 * ldx); x3 = ld4(xn + 3 * ldx);
+      const ST* xn = X + (n + 4) * ldx + kk;
+      x0 = ldv(xn); x1 = ldv(xn + ldx); x2 = ldv(xn + 2 * ldx); x3 = ldv(xn + 3 * ldx);
       ga = gp[(n + 4) * ldg]; gb = gp[(n + 6) * ldg];
       SPGNN_SBW_FMA(c0, c1, c2, c3, ca, cb)
     }
@@ -1857,7 +1937,7 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
 #undef SPGNN_SBW_FMA
   }
   for (; n < n1; ++n) {
-    const float4 x = ld4(X + n * ldx + kk);
+    const float4 x = ldv(X + n * ldx + kk);
     const float* g = gS + n * ldg;
 #pragma unroll
     for (int j = 0; j < J; ++j)
@@ -2153,14 +2233,22 @@ int spgnn_gat_can_fuse_mean(int32_t H, int32_t D) {
   return (H > 0 && D > 0 && pick_gat(H, D, T, R, CH, W) && CH >= 1) ? 1 : 0;
 }
 
-int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
-                  const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
-                  const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
-                  float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
-                  float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+}  // extern "C"
+
+// rows stored as ST: 16-byte (fp32) or 8-byte (bf16) vector access
+template <typename ST> static bool vec_ok_t(const ST* p, int64_t stride) {
+  return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & (4 * sizeof(ST) - 1)) == 0 && (stride & 3) == 0);
+}
+
+template <typename ST>
+static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const ST* ft, int64_t ft_stride,
+                        const float* el, const float* er, int64_t s_stride, const ST* res, int64_t res_stride,
+                        const float* bias, ST* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
+                        float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
+                        float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
-  if (!indptr || !ft || !el || !er || !attn || (!out && !out_mean) || (E > 0 && !indices))
+  if (!indptr || !ft || !el || !er || (E > 0 && !attn) || (!out && !out_mean) || (E > 0 && !indices))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: null pointer");
   const int64_t HD = (int64_t)H * D;
   if (ft_stride < HD || (out && out_stride < HD) || s_stride < H || (res && res_stride < HD) ||
@@ -2169,11 +2257,11 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: activation");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatFwd a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-           out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+  GatFwdT<ST> a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
+                out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
-  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(out, out_stride) &&
-                   vec_ok(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
+  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok_t(ft, ft_stride) && vec_ok_t(out, out_stride) &&
+                   vec_ok_t(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
   const bool fuse_mean = vec && out_mean && CH >= 1;
   if (!fuse_mean && !out)
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: `out` is required when the head mean cannot be fused "
@@ -2182,36 +2270,67 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft
     a.T = T;
     const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
     if (fuse_mean) {
-#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<64, R_, CH_, true>), grid, block, 0, st, a); \
-                   else launch_small_team<R_, CH_, true>(grid, block, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<ST, 64, R_, CH_, true>), grid, block, 0, st, a); \
+                   else launch_small_team<ST, R_, CH_, true>(grid, block, st, a)
       SPGNN_FOR_R_CH(R, CH, X)
 #undef X
     } else {
       a.out_mean = nullptr;
-#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<64, R_, CH_, false>), grid, block, 0, st, a); \
-                   else launch_small_team<R_, CH_, false>(grid, block, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_fwd_vec<ST, 64, R_, CH_, false>), grid, block, 0, st, a); \
+                   else launch_small_team<ST, R_, CH_, false>(grid, block, st, a)
       SPGNN_FOR_R_CH(R, CH, X)
 #undef X
     }
-  } else {
+  } else if constexpr (is_f32<ST>::value) {
     hipLaunchKernelGGL(gat_fwd_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
+  } else {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd_bf16: needs a vector geometry (H*D = 4*T*R) and 8-byte aligned rows");
   }
-  if (out_mean && !fuse_mean)
-    hipLaunchKernelGGL(head_mean_scalar, dim3(scalar_grid(N * D)), dim3(kBlock), 0, st, out, out_stride, out_mean,
-                       out_mean_stride, N, H, D);
+  if constexpr (is_f32<ST>::value) {
+    if (out_mean && !fuse_mean)
+      hipLaunchKernelGGL(head_mean_scalar, dim3(scalar_grid(N * D)), dim3(kBlock), 0, st, out, out_stride, out_mean,
+                         out_mean_stride, N, H, D);
+  } else if (out_mean && !fuse_mean) {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd_bf16: the head mean must be fusable (see spgnn_gat_can_fuse_mean)");
+  }
   return check_launch("spgnn_gat_fwd");
 }
 
-int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
-                      const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
-                      int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
-                      int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
-                      int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
-                      uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+extern "C" {
+
+int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+                  const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
+                  const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
+                  float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
+                  float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_fwd_impl<float>(indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
+                             out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* ft, int64_t ft_stride,
+                       const float* el, const float* er, int64_t s_stride, const uint16_t* res, int64_t res_stride,
+                       const float* bias, uint16_t* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
+                       float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
+                       float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_fwd_impl<bf16s>(indptr, indices, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride,
+                             reinterpret_cast<const bf16s*>(res), res_stride, bias, reinterpret_cast<bf16s*>(out), out_stride,
+                             out_mean, out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset,
+                             stream);
+}
+
+}  // extern "C"
+
+template <typename ST>
+static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const ST* ft, int64_t ft_stride,
+                            const float* el, const float* er, int64_t s_stride, const float* attn, const void* g_out,
+                            int64_t g_out_stride, int32_t mean_heads, const ST* out, int64_t out_stride, ST* g_pre,
+                            int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
+                            int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
+                            uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
-  if (!indptr || !ft || !el || !er || !attn || !g_out || !g_pre || !g_e || !g_er || (E > 0 && !indices) ||
+  if (!indptr || !ft || !el || !er || !g_out || !g_pre || !g_er || (E > 0 && (!indices || !attn || !g_e)) ||
       (activation != SPGNN_ACT_NONE && !out))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_dst: null pointer");
   const int64_t HD = (int64_t)H * D;
@@ -2220,57 +2339,111 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_dst: row stride smaller than row");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatBwdDst a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
-              g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
-              activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+  GatBwdDstT<ST> a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
+                   g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
+                   activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
-  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok(ft, ft_stride) && vec_ok(g_out, g_out_stride) &&
-                   vec_ok(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok(out, out_stride));
+  const bool g_ok = mean_heads ? vec_ok(g_out, g_out_stride) : vec_ok_t(reinterpret_cast<const ST*>(g_out), g_out_stride);
+  const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok_t(ft, ft_stride) && g_ok &&
+                   vec_ok_t(g_pre, g_pre_stride) && (activation == SPGNN_ACT_NONE || vec_ok_t(out, out_stride));
   if (vec) {
     a.T = T; a.W = W;
     const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
-#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_dst_vec<64, R_, CH_>), grid, block, 0, st, a); \
-                   else launch_small_team<R_, CH_>(grid, block, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_dst_vec<ST, 64, R_, CH_>), grid, block, 0, st, a); \
+                   else launch_small_team<ST, R_, CH_>(grid, block, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
-  } else {
+  } else if constexpr (is_f32<ST>::value) {
     if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);       // scalar path maxes with atomics
     hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
+  } else {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst_bf16: needs a vector geometry (H*D = 4*T*R) and 8-byte aligned rows");
   }
   return check_launch("spgnn_gat_bwd_dst");
 }
 
-int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
-                      const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
-                      float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
-                      const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
-                      float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+extern "C" {
+
+int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+                      const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
+                      int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
+                      int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
+                      int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
+                      uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_bwd_dst_impl<float>(indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, mean_heads, out,
+                                 out_stride, g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, E, H, D, negative_slope,
+                                 activation, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* ft, int64_t ft_stride,
+                           const float* el, const float* er, int64_t s_stride, const float* attn, const void* g_out,
+                           int64_t g_out_stride, int32_t mean_heads, const uint16_t* out, int64_t out_stride, uint16_t* g_pre,
+                           int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
+                           int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
+                           uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_bwd_dst_impl<bf16s>(indptr, indices, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride, attn, g_out,
+                                 g_out_stride, mean_heads, reinterpret_cast<const bf16s*>(out), out_stride,
+                                 reinterpret_cast<bf16s*>(g_pre), g_pre_stride, g_e, g_er, g_s_stride, nullptr, N, E, H, D,
+                                 negative_slope, activation, p_drop, seed, seed_offset, stream);
+}
+
+}  // extern "C"
+
+template <typename ST>
+static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                            const float* g_e, const ST* g_pre, int64_t g_pre_stride, ST* g_ft, int64_t g_ft_stride,
+                            float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
+                            const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
+                            float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (score_l && (!score_r || !g_er)) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_src: score_l needs score_r and g_er");
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src: bad N/E/H/D");
   if (N == 0) return SPGNN_OK;
-  if (!out_indptr || !attn || !g_e || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos)))
+  if (!out_indptr || !g_pre || !g_ft || !g_el || (E > 0 && (!out_indices || !out_pos || !attn || !g_e)))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_src: null pointer");
   const int64_t HD = (int64_t)H * D;
   if (g_pre_stride < HD || g_ft_stride < HD || g_s_stride < H)
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_src: row stride smaller than row");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
-              absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, score_l, score_r, g_er};
+  GatBwdSrcT<ST> a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
+                   absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, score_l, score_r, g_er};
   int T = 0, R = 0, CH = 0, W = 0;
-  if (pick_gat(H, D, T, R, CH, W) && vec_ok(g_pre, g_pre_stride) && vec_ok(g_ft, g_ft_stride) && vec_ok(score_l, 0) &&
+  if (pick_gat(H, D, T, R, CH, W) && vec_ok_t(g_pre, g_pre_stride) && vec_ok_t(g_ft, g_ft_stride) && vec_ok(score_l, 0) &&
       vec_ok(score_r, 0)) {
     a.T = T;
     const dim3 grid(grid_for(N, kBlock / T)), block(kBlock);
-#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_src_vec<64, R_, CH_>), grid, block, 0, st, a); \
-                   else launch_small_team<R_, CH_>(grid, block, st, a)
+#define X(R_, CH_) if (T == 64) hipLaunchKernelGGL((gat_bwd_src_vec<ST, 64, R_, CH_>), grid, block, 0, st, a); \
+                   else launch_small_team<ST, R_, CH_>(grid, block, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
-  } else {
+  } else if constexpr (is_f32<ST>::value) {
     if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);
     hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
+  } else {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src_bf16: needs a vector geometry (H*D = 4*T*R) and 8-byte aligned rows");
   }
   return check_launch("spgnn_gat_bwd_src");
+}
+
+extern "C" {
+
+int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                      const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
+                      float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
+                      const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
+                      float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_bwd_src_impl<float>(out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el,
+                                 g_s_stride, absmax, score_l, score_r, g_er, N, E, H, D, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                           const float* g_e, const uint16_t* g_pre, int64_t g_pre_stride, uint16_t* g_ft, int64_t g_ft_stride,
+                           float* g_el, int64_t g_s_stride, const float* score_l, const float* score_r,
+                           const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_bwd_src_impl<bf16s>(out_indptr, out_indices, out_pos, attn, g_e, reinterpret_cast<const bf16s*>(g_pre), g_pre_stride,
+                                 reinterpret_cast<bf16s*>(g_ft), g_ft_stride, g_el, g_s_stride, nullptr, score_l, score_r, g_er,
+                                 N, E, H, D, p_drop, seed, seed_offset, stream);
 }
 
 int spgnn_gat_agg_supported(int32_t H, int32_t F) {
@@ -2506,12 +2679,33 @@ int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t 
   if (blocks > 32768) blocks = 32768;
   const bool vec = (width & 3) == 0 && (col_offset & 3) == 0 && vec_ok(src, src_stride) && vec_ok(dst, dst_stride);
   if (vec)
-    hipLaunchKernelGGL(cat_dropout_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
+    hipLaunchKernelGGL((cat_dropout_kernel<float, true>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
                        dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0, absmax_partials);
   else
-    hipLaunchKernelGGL(cat_dropout_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
+    hipLaunchKernelGGL((cat_dropout_kernel<float, false>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, dst,
                        dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0, absmax_partials);
   return check_launch("spgnn_cat_dropout");
+}
+
+int spgnn_cat_dropout_bf16(const uint16_t* src, int64_t src_stride, uint16_t* dst, int64_t dst_stride, int64_t N, int32_t width,
+                           int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           int32_t backward, spgnn_stream_t stream) {
+  if (N < 0 || width <= 0 || col_offset < 0 || total_width < col_offset + width) return fail(SPGNN_ERR_SHAPE, "spgnn_cat_dropout_bf16: bad N/width/offset");
+  if (N == 0) return SPGNN_OK;
+  if (!src || !dst) return fail(SPGNN_ERR_NULLPTR, "spgnn_cat_dropout_bf16: null pointer");
+  if (src_stride < (backward ? total_width : width) || dst_stride < (backward ? width : total_width))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_cat_dropout_bf16: row stride smaller than row");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_cat_dropout_bf16: p_drop not in [0,1)");
+  const bf16s* s_ = reinterpret_cast<const bf16s*>(src);
+  bf16s* d_ = reinterpret_cast<bf16s*>(dst);
+  if ((width & 3) || (col_offset & 3) || !vec_ok_t(s_, src_stride) || !vec_ok_t(d_, dst_stride))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_cat_dropout_bf16: widths, offsets and strides must be multiples of 4, rows 8-byte aligned");
+  int64_t blocks = (N * (width / 4) + kBlock - 1) / kBlock;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL((cat_dropout_kernel<bf16s, true>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, s_, src_stride, d_,
+                     dst_stride, N, width, col_offset, total_width, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, backward ? 1 : 0,
+                     (float*)nullptr);
+  return check_launch("spgnn_cat_dropout_bf16");
 }
 
 int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int64_t N, int32_t H, int32_t D,
@@ -2612,11 +2806,28 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
   const int64_t rps = (N + splits - 1) / splits;
   const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define X(JP) hipLaunchKernelGGL(scores_bwd_w_kernel<JP>, grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps, J)
+#define X(JP) hipLaunchKernelGGL((scores_bwd_w_kernel<float, JP>), grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps, J)
   switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
                          case 24: X(24); break; default: X(32); break; }
 #undef X
   return check_launch("spgnn_scores_bwd_w");
+}
+
+int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* x, int64_t x_stride, float* part,
+                            int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 8)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w_bf16: bad N/K/Kp/splits/J (J <= 8)");
+  if (!gs || !x || !part) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w_bf16: null pointer");
+  const bf16s* x_ = reinterpret_cast<const bf16s*>(x);
+  if (x_stride < K || gs_stride < J || !vec_ok_t(x_, x_stride) || !aligned16(part))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w_bf16: x rows must be 8-byte aligned (stride % 4 == 0)");
+  const int64_t rps = (N + splits - 1) / splits;
+  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define X(JP) hipLaunchKernelGGL((scores_bwd_w_kernel<bf16s, JP>), grid, block, 0, st, gs, gs_stride, x_, x_stride, part, Kp, N, K, rps, J)
+  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; default: X(8); break; }
+#undef X
+  return check_launch("spgnn_scores_bwd_w_bf16");
 }
 
 #ifndef SPGNN_BWDX_WAVES

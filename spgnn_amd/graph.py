@@ -147,6 +147,27 @@ class _NData(dict):
         if value.device != self._g.device:
             value = value.to(self._g.device)
         super().__setitem__(key, value)
+        self._invalidate()
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        self._invalidate()
+
+    def pop(self, key, *default):
+        self._invalidate()
+        return super().pop(key, *default)
+
+    def update(self, *args, **kwargs):
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    def _invalidate(self):
+        # per-batch constants derived from node data (models._data_cat / _data_aligned / _data_in) are keyed by the
+        # source tensors' address and version: a replaced tensor may be handed the freed block's address again, so
+        # every (re)assignment drops them
+        cache = getattr(self._g, "_tensor_cache", None)
+        if cache:
+            cache.clear()
 
 
 class TreeGraph:

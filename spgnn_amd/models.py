@@ -20,12 +20,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, ops_bf16
 from .nn import GATConv, GINConv, GraphConv, SAGEConv, SkinnyLinear, _draw_seed
 from .ops import cat_padded
 
 __all__ = ["GCN", "GAT", "GIN", "SAGE", "GATPSPGNN", "GATPSPGNNNL", "GCNNet", "GATNet", "GINNet", "SAGENet",
-           "GATPositionSPGNNNet", "set_trainable"]
+           "GATPositionSPGNNNet", "set_trainable", "set_storage_dtype"]
 
 
 def _cat_for(layer, a: torch.Tensor, b: torch.Tensor):
@@ -34,6 +34,8 @@ def _cat_for(layer, a: torch.Tensor, b: torch.Tensor):
     if not a.is_cuda:
         return torch.cat([a, b], dim=1), False
     p = float(layer.feat_drop.p) if layer.training else 0.0
+    if a.dtype == torch.bfloat16:
+        return ops_bf16.cat_dropout((a, b), p, _draw_seed() if p > 0.0 else 0), True
     return ops.cat_dropout((a, b), p, _draw_seed() if p > 0.0 else 0), True
 
 
@@ -42,6 +44,8 @@ def _drop_for(layer, x: torch.Tensor):
     p = float(layer.feat_drop.p) if layer.training else 0.0
     if not x.is_cuda or p == 0.0:
         return x, False
+    if x.dtype == torch.bfloat16:
+        return ops_bf16.cat_dropout((x,), p, _draw_seed()), True
     return ops.cat_dropout((x,), p, _draw_seed()), True
 
 
@@ -76,6 +80,33 @@ def _data_aligned(g, t: torch.Tensor) -> torch.Tensor:
     if hit is None:
         hit = g._tensor_cache[key] = cat_padded((t,)).detach()
     return hit
+
+
+def _data_in(g, t: torch.Tensor, dtype) -> torch.Tensor:
+    """A node-DATA tensor in the head's storage dtype: fp32 data -> bf16 rows (16-byte rows, zero padded) once per batch
+    (the batched graph and its node data are reused for all GCN_STEPS inner steps, reference job_runner.py:1892)."""
+    if dtype is None or t.dtype == dtype:
+        return t
+    if dtype != torch.bfloat16 or t.dtype != torch.float32:
+        raise ValueError(f"storage dtype {dtype} from node data of dtype {t.dtype} is not supported")
+    if t.requires_grad or not hasattr(g, "_tensor_cache"):
+        return ops_bf16.cast_rows(t)
+    key = ("bf16", t.data_ptr(), t._version, tuple(t.shape))
+    hit = g._tensor_cache.get(key)
+    if hit is None:
+        hit = g._tensor_cache[key] = ops_bf16.cast_rows(t).detach()
+    return hit
+
+
+def set_storage_dtype(model: nn.Module, dtype) -> nn.Module:
+    """Storage dtype of node-feature rows inside the GNN head: None / torch.float32 (the reference's arithmetic, parity
+    path) or torch.bfloat16 (rows and their gradients in bf16, fp32 accumulate, fp32 parameters; BASELINE config 4)."""
+    if dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError(f"unsupported storage dtype {dtype}")
+    for m in model.modules():
+        if hasattr(m, "storage_dtype"):
+            m.storage_dtype = None if dtype == torch.float32 else dtype
+    return model
 
 
 def set_trainable(model: nn.Module, trainable: bool) -> None:
@@ -119,6 +150,7 @@ class GAT(nn.Module):
                                   activation))
         layers.append(GATConv(widths[num_layers], out_ch, heads[num_layers], 0.0, 0.0, negative_slope, residual, None))
         self.gat_layers = nn.ModuleList(layers)
+        self.storage_dtype = None            # see set_storage_dtype
 
     def reset_parameters(self):
         for layer in self.gat_layers:
@@ -130,12 +162,14 @@ class GAT(nn.Module):
     def forward(self, g, classifier=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))`` with the classifier
         joined to the output layer's autograd node (not with ``norm``: the normalisation sits in between)."""
-        h = g.ndata["fvs"]
+        h = _data_in(g, g.ndata["fvs"], self.storage_dtype)
         for layer in self.gat_layers[:-1]:
-            h = layer(g, h).flatten(1)
+            x, dropped = _drop_for(layer, h)
+            h = layer(g, x, feat_dropped=dropped).flatten(1)
+        x, dropped = _drop_for(self.gat_layers[-1], h)
         if classifier is not None and not self.norm:
-            return self.gat_layers[-1](g, h, mean_heads=True, classifier=classifier)
-        h = self._finish(self.gat_layers[-1](g, h, mean_heads=True))
+            return self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
+        h = self._finish(self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped))
         return h if classifier is None else (h, classifier(h))
 
     def forward_batch(self, blocks, x):

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, ops_bf16
 from .graph import TreeGraph
 
 __all__ = ["GATConv", "GraphConv", "GINConv", "SAGEConv", "Identity", "DGLError", "SkinnyLinear"]
@@ -150,6 +150,15 @@ class GATConv(nn.Module):
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
         fuse_mean = mean_heads and fuse_epilogue
+        if h.dtype == torch.bfloat16:
+            # bf16-storage path (BASELINE config 4): project-first on the bf16 matrix cores, fp32 parameters and scores
+            if not ops_bf16.gat_layer_supported(h, H, D):
+                raise DGLError(f"bf16 GATConv needs a ROCm device, out_feats % 64 == 0 and in_feats % 4 == 0 (got {tuple(h.shape)} -> {H}x{D})")
+            fuse_mean = fuse_mean and ops.can_fuse_mean(H, D)
+            out, attn = ops_bf16.gat_layer(csc, h, w_fc, self.res_fc.weight if has_res else None, self.attn_l, self.attn_r,
+                                           self.bias if fuse_epilogue else None, H, D, float(self.negative_slope),
+                                           act if fuse_epilogue else ops.ACT_NONE, p, seed, mean=fuse_mean)
+            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
         agg_first = (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
                      and ops.agg_first_supported(H, h.shape[1]))
         w_cat = None

@@ -1,0 +1,335 @@
+"""bf16-STORAGE operators over the C ABI (include/spgnn_hip.h, entry points ending in ``_bf16``).
+
+BASELINE.json config 4 ("st_gat_6 deep GAT, batch=512 trees, bf16"): node-feature rows, projected rows and their
+gradients are ``torch.bfloat16`` tensors in HBM; every kernel accumulates in fp32; parameters (and therefore weight
+gradients, the optimizer and the all-reduce), attention scores el/er and attention weights stay fp32.  The reference
+itself is fp32 only (its AMP hook, job_runner.py:263-280, is unused by every config), so this path is a build-side
+extension and the fp32 path in ops.py stays the parity path.
+
+Layout rules (what the kernels require and every producer here guarantees):
+  * rows are 16-byte aligned: row stride a multiple of 8 elements, base pointer 16-byte aligned;
+  * columns between the logical width and the width rounded up to 8 hold zeros (the GEMMs read whole 8-element chunks).
+There is no CPU implementation; CPU tensors raise like everywhere else in this package.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from .graph import DeviceCSC
+from .ops import (ACT_NONE, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts)
+
+BF16 = torch.bfloat16
+
+
+def _pad8(k: int) -> int:
+    return (k + 7) // 8 * 8
+
+
+def rows_ok(t: torch.Tensor) -> bool:
+    """bf16 rows a GEMM can read: unit column stride, row stride % 8 == 0 and >= width rounded up to 8, 16-byte aligned."""
+    return (t.dtype == BF16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= _pad8(t.shape[1])
+            and t.data_ptr() % 16 == 0)
+
+
+def empty_rows(n: int, width: int, device) -> torch.Tensor:
+    """(n, width) bf16 view of a buffer whose rows are padded to a multiple of 8 elements; the pad columns are zeroed."""
+    wp = _pad8(width)
+    buf = torch.empty((n, wp), dtype=BF16, device=device)
+    if wp > width:
+        buf[:, width:].zero_()
+    return buf[:, :width]
+
+
+def as_rows(x: torch.Tensor) -> torch.Tensor:
+    """x as GEMM-readable bf16 rows (a padded copy when its layout does not qualify: never on the hot path)."""
+    if rows_ok(x):
+        return x
+    out = empty_rows(x.shape[0], x.shape[1], x.device)
+    out.copy_(x)
+    return out
+
+
+def cast_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32 node data (N, K) -> bf16 rows (round to nearest even), 16-byte rows, zero padded: once per loader batch."""
+    _require_cuda(x)
+    assert x.dim() == 2 and x.dtype == torch.float32
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    N, K = x.shape
+    out = torch.empty((N, _pad8(K)), dtype=BF16, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().spgnn_cast_rows_bf16(x.data_ptr(), x.stride(0), N, K, out.data_ptr(), out.stride(0), _stream(x)),
+                    "spgnn_cast_rows_bf16")
+    return out[:, :K]
+
+
+def weight_operands(w_a: torch.Tensor, w_b: Optional[torch.Tensor], want_t: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """[w_a ; w_b] (fp32 parameters) -> (W (R, K) bf16 rows, W^T (K, R) bf16 rows or None): one kernel per layer and step."""
+    R1, K = w_a.shape
+    R2 = 0 if w_b is None else w_b.shape[0]
+    R = R1 + R2
+    wa = w_a if w_a.stride(1) == 1 else w_a.contiguous()
+    wb = None if w_b is None else (w_b if w_b.stride(1) == 1 else w_b.contiguous())
+    w = torch.empty((R, _pad8(K)), dtype=BF16, device=w_a.device)
+    w_t = torch.empty((K, _pad8(R)), dtype=BF16, device=w_a.device) if want_t else None
+    with torch.cuda.device(w_a.device):
+        _capi.check(_capi.load().spgnn_weight_cat_bf16(wa.data_ptr(), wa.stride(0), R1, _ptr(wb), 0 if wb is None else wb.stride(0),
+                                                       R2, K, w.data_ptr(), w.stride(0), _ptr(w_t),
+                                                       w_t.stride(0) if want_t else 0, _stream(w_a)), "spgnn_weight_cat_bf16")
+    return w[:, :K], (w_t[:, :R] if want_t else None)
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, out_f32: bool = False,
+            bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, score_l: Optional[torch.Tensor] = None,
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a (M,K) @ b (N,K)^T -> (M,N) bf16 rows (or fp32 with ``out_f32``); bf16 MFMA, fp32 accumulate.  ``bias`` (N,) fp32 /
+    ``act``: epilogue act(C + bias).  ``score_out`` (M, C/64, 2) fp32 with ``score_l`` / ``score_r`` (C,) fp32: per
+    64-column block dot products of the first C output columns, taken from the values as stored."""
+    _require_cuda(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and rows_ok(a) and rows_ok(b), "bf16 GEMM operands must be 16-byte-row bf16 tensors"
+    assert N % 4 == 0, "bf16 GEMM output width must be a multiple of 4"
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device) if out_f32 else empty_rows(M, N, a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == (torch.float32 if out_f32 else BF16)
+    with torch.cuda.device(a.device), _timed("gemm_nt_bf16", (M, N, K)):
+        _capi.check(_capi.load().spgnn_gemm_nt_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                                    out.stride(0), int(out_f32), M, N, K, _ptr(bias), act, _ptr(score_l),
+                                                    _ptr(score_r), _ptr(score_out),
+                                                    score_l.numel() if score_out is not None else 0, _stream(a)),
+                    "spgnn_gemm_nt_bf16")
+    return out
+
+
+def _tn_splits(R: int, M: int, N: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = max(1, min(64, 512 // tiles, R // 256))
+    if splits >= 8 or tiles >= 16:          # one split per XCD (see ops.gemm_tn)
+        splits = 32 if tiles >= 16 and R >= 32 * 512 else (splits // 8 * 8 if splits >= 8 else splits)
+    return splits
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False):
+    """a (R,M)^T @ b (R,N) -> (M,N) fp32 (weight gradients): bf16 MFMA, fp32 accumulate, split over row ranges with a
+    deterministic partial-sum reduction.  ``want_colsum``: also a.sum(0) (M,) fp32 from the operand stream."""
+    _require_cuda(a, b)
+    R, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == R and rows_ok(a) and rows_ok(b)
+    lib = _capi.load()
+    splits = _tn_splits(R, M, N)
+    ldn = (N + 3) // 4 * 4
+    ldc = ldn + 4 if want_colsum else ldn
+    part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
+    cs_ptr = part[0, 0, ldn:].data_ptr() if want_colsum else 0
+    with torch.cuda.device(a.device), _timed("gemm_tn_bf16", (R, M, N)):
+        _capi.check(lib.spgnn_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc,
+                                           splits, R, M, N, cs_ptr, ldc, M * ldc, _stream(a)), "spgnn_gemm_tn_bf16")
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    cs = torch.empty((M,), dtype=torch.float32, device=a.device) if want_colsum else None
+    with torch.cuda.device(a.device):
+        _capi.check(lib.spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
+                                                   0, 0, 0, _ptr(cs), ldn if want_colsum else 0, _stream(a)),
+                    "spgnn_sum_partials_compact")
+    return (out, cs) if want_colsum else out
+
+
+def attn_vector_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int) -> torch.Tensor:
+    """(2, H, D): [w, h, :] = g_s[:, w*H + h]^T @ ft[:, h*D:(h+1)*D] - the gradients of attn_l / attn_r (fp32), ft bf16."""
+    N, K = ft.shape
+    J = g_s.shape[1]
+    D = K // H
+    Kp = (K + 15) // 16 * 16
+    splits = max(1, min(1024 // ((K + 255) // 256), N // 16))
+    part = torch.empty((splits, J, Kp), dtype=torch.float32, device=ft.device)
+    lib = _capi.load()
+    out = torch.empty((2, H, D), dtype=torch.float32, device=ft.device)
+    with torch.cuda.device(ft.device), _timed("scores_bwd_w_bf16", (N, K, J)):
+        _capi.check(lib.spgnn_scores_bwd_w_bf16(g_s.data_ptr(), g_s.stride(0), ft.data_ptr(), ft.stride(0), part.data_ptr(), splits,
+                                                Kp, N, K, J, _stream(ft)), "spgnn_scores_bwd_w_bf16")
+        _capi.check(lib.spgnn_sum_partials_blockdiag(part.data_ptr(), J * Kp, splits, H, D, Kp, out.data_ptr(), _stream(ft)),
+                    "spgnn_sum_partials_blockdiag")
+    return out
+
+
+def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: float, act: int, p_drop: float, seed: int,
+                mean: bool, need_out: bool):
+    """-> (out (N, H*D) bf16 or None, out_mean (N, D) fp32 or None, attn (E, H) fp32)."""
+    N, E = csc.num_nodes, csc.num_edges
+    lib = _capi.load()
+    fuse = mean and bool(lib.spgnn_gat_can_fuse_mean(H, D))
+    skip_out = fuse and not need_out
+    out = None if skip_out else torch.empty((N, H * D), dtype=BF16, device=ft.device)
+    out_mean = torch.empty((N, D), dtype=torch.float32, device=ft.device) if fuse else None
+    attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
+    with torch.cuda.device(ft.device), _timed("gat_fwd_bf16", (N, E, H, D, int(res is not None), int(fuse), int(out is not None))):
+        _capi.check(lib.spgnn_gat_fwd_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+                                           el.data_ptr(), er.data_ptr(), el.stride(0), _ptr(res),
+                                           res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
+                                           out.stride(0) if out is not None else 0, _ptr(out_mean),
+                                           out_mean.stride(0) if fuse else 0, attn.data_ptr(), N, E, H, D, slope, act, p_drop,
+                                           seed, _seed_off_ptr(ft.device), _stream(ft)), "spgnn_gat_fwd_bf16")
+    return out, out_mean, attn
+
+
+class _GATLayerBf16Fn(torch.autograd.Function):
+    """Project-first GATConv on bf16 rows: Y = X [W_fc ; W_res]^T on the bf16 matrix cores with el / er from the stored ft
+    in the GEMM epilogue (DGL's (ft * attn).sum(-1)), spgnn_gat_fwd_bf16, and in the backward pass spgnn_gat_bwd_dst/src_bf16
+    writing [g_ft | g_pre] straight into the GEMM-gradient buffer, one weight-gradient product (fp32 result, bias gradient
+    from its operand stream) and one input-gradient product.  The fp32 parameters enter here directly: their gradients must
+    stay fp32 (autograd would cast the gradient of a bf16 weight tensor to bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, w_fc, w_res, attn_l, attn_r, bias, csc: DeviceCSC, H: int, D: int, slope: float, act: int,
+                p_drop: float, seed: int, mean: bool):
+        ctx.set_materialize_grads(False)
+        HD = H * D
+        N = x.shape[0]
+        has_res = w_res is not None
+        need_gx = ctx.needs_input_grad[0]
+        w, w_t = weight_operands(w_fc, w_res, want_t=need_gx)
+        ctx.attn_shape = attn_l.shape
+        al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
+        parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
+        y = gemm_nt(x, w, score_l=al, score_r=ar, score_out=parts)
+        s = scores_from_parts(parts, H, D)
+        ft = y[:, :HD]
+        res = y[:, HD:] if has_res else None
+        out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed, mean,
+                                          need_out=(act != ACT_NONE))
+        fused_mean = out_mean is not None
+        ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, fused_mean)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_t, al, ar, y, s, attn, out if act != ACT_NONE else None)
+        ctx.mark_non_differentiable(attn)
+        return (out_mean if fused_mean else out), attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        if g_out is None:
+            return (None,) * 14
+        x, w_t, al, ar, y, s, attn, out = ctx.saved_tensors
+        H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
+        csc = ctx.csc
+        HD = H * D
+        N, K = x.shape
+        E = csc.num_edges
+        if mean:
+            g_out = g_out.float() if g_out.dtype != torch.float32 else g_out
+        elif g_out.dtype != BF16:
+            g_out = g_out.to(BF16)
+        if g_out.stride(1) != 1 or g_out.stride(0) % 4 or g_out.data_ptr() % 16:
+            g_out = g_out.contiguous()
+        g_y = torch.empty_like(y)
+        g_s = torch.empty_like(s)
+        g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=BF16, device=x.device)
+        g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
+        lib = _capi.load()
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            with _timed("gat_bwd_dst_bf16", (N, E, H, D, act, int(mean))):
+                _capi.check(lib.spgnn_gat_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), y.data_ptr(), y.stride(0),
+                                                       s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                       g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
+                                                       out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
+                                                       g_e.data_ptr(), g_s[:, H:].data_ptr(), g_s.stride(0), N, E, H, D, slope, act,
+                                                       p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_dst_bf16")
+            with _timed("gat_bwd_src_bf16", (N, E, H, D)):
+                _capi.check(lib.spgnn_gat_bwd_src_bf16(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                       csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                                       g_pre.stride(0), g_y.data_ptr(), g_y.stride(0), g_s.data_ptr(),
+                                                       g_s.stride(0), al.data_ptr(), ar.data_ptr(), g_s[:, H:].data_ptr(), N, E, H, D,
+                                                       p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_src_bf16")
+        need_bias = ctx.has_bias and ctx.needs_input_grad[5]
+        g_wfc = g_wres = g_bias = None
+        if ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2]):
+            if need_bias and has_res:                   # column sums of g_pre ride along with the operand stream
+                g_w, cs = gemm_tn(g_y, x, want_colsum=True)
+                g_bias = cs[HD:]
+            else:
+                g_w = gemm_tn(g_y, x)
+            g_wfc = g_w[:HD]
+            g_wres = g_w[HD:] if has_res else None
+        if need_bias and g_bias is None:
+            g_bias = g_pre.float().sum(0)
+        g_al = g_ar = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            m = attn_vector_grads(g_s, y[:, :HD], H)
+            g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = gemm_nt(g_y, w_t)
+        return g_x, g_wfc, g_wres, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None
+
+
+def gat_layer_supported(x: torch.Tensor, H: int, D: int) -> bool:
+    """The bf16 project-first layer needs 64-column score blocks (D % 64 == 0) and an input gradient width the GEMM can
+    write (K % 4 == 0 when the input needs a gradient)."""
+    return (x.is_cuda and x.dtype == BF16 and x.dim() == 2 and x.shape[0] > 0 and D % 64 == 0
+            and (not x.requires_grad or x.shape[1] % 4 == 0))
+
+
+def gat_layer(csc: DeviceCSC, x, w_fc, w_res, attn_l, attn_r, bias, H: int, D: int, slope: float, act: int,
+              p_drop: float = 0.0, seed: int = 0, mean: bool = False):
+    """-> (out (N, H*D) bf16, or the fp32 head mean (N, D) when ``mean`` and the geometry fuses it; attn (E, H) fp32)."""
+    _require_cuda(x, w_fc, w_res, attn_l, attn_r, bias)
+    return _GATLayerBf16Fn.apply(as_rows(x), w_fc, w_res, attn_l, attn_r, bias, csc, H, D, slope, act, p_drop, seed, mean)
+
+
+class _CatDropoutBf16(torch.autograd.Function):
+    """dropout(cat(tensors, dim=1), p) on bf16 rows in one pass per source; the keep mask is the counter hash of
+    spgnn_cat_dropout, regenerated by the backward pass."""
+
+    @staticmethod
+    def forward(ctx, p, seed, *tensors):
+        widths = [t.shape[1] for t in tensors]
+        F_ = sum(widths)
+        N = tensors[0].shape[0]
+        buf = empty_rows(N, F_, tensors[0].device)
+        lib = _capi.load()
+        off = 0
+        with torch.cuda.device(buf.device):
+            for t in tensors:
+                if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 8:
+                    t = t.contiguous()
+                _capi.check(lib.spgnn_cat_dropout_bf16(t.data_ptr(), t.stride(0), buf.data_ptr(), buf.stride(0), N, t.shape[1], off,
+                                                       F_, p, seed, _seed_off_ptr(buf.device), 0, _stream(buf)),
+                            "spgnn_cat_dropout_bf16")
+                off += t.shape[1]
+        ctx.widths, ctx.p, ctx.seed = widths, p, seed
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None, None) + (None,) * len(ctx.widths)
+        if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 8:
+            g = g.contiguous()
+        N, F_ = g.shape
+        lib = _capi.load()
+        outs, off = [], 0
+        with torch.cuda.device(g.device):
+            for w, need in zip(ctx.widths, ctx.needs_input_grad[2:]):
+                if need and ctx.p == 0.0 and off % 8 == 0 and g.stride(0) % 8 == 0 and g.data_ptr() % 16 == 0:
+                    outs.append(g[:, off:off + w])      # a plain concatenation: column blocks of its gradient, no copy
+                elif need:
+                    go = empty_rows(N, w, g.device)
+                    _capi.check(lib.spgnn_cat_dropout_bf16(g.data_ptr(), g.stride(0), go.data_ptr(), go.stride(0), N, w, off, F_,
+                                                           ctx.p, ctx.seed, _seed_off_ptr(g.device), 1, _stream(g)),
+                                "spgnn_cat_dropout_bf16")
+                    outs.append(go)
+                else:
+                    outs.append(None)
+                off += w
+        return (None, None) + tuple(outs)
+
+
+def cat_dropout(tensors, p: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """dropout(cat(tensors, 1), p) as GEMM-readable bf16 rows; every width must be a multiple of 4."""
+    _require_cuda(*tensors)
+    assert all(t.dtype == BF16 and t.shape[1] % 4 == 0 for t in tensors)
+    return _CatDropoutBf16.apply(float(p), int(seed), *tensors)

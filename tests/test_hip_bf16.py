@@ -1,0 +1,275 @@
+"""bf16-STORAGE path (BASELINE.json config 4: "st_gat_6 deep GAT, batch=512 trees, bf16").
+
+The reference is fp32 only, so there is no reference result in bf16; what is checked is
+  (1) the kernels against an exact model of what they are meant to do: the oracle with bf16 rounding applied at the
+      product's storage points (``oracle.dgl_cpu.Bf16Storage``: inputs, weights fed to the GEMMs, ft / res / out and the
+      gradients g_pre / g_ft / g_x), arithmetic in between in fp64.  The HIP path differs from that model only by fp32
+      accumulation order, which can move a value across a bf16 rounding boundary (one ulp = 2^-8 relative of THAT
+      element); tolerance below: normwise 2^-7 per tensor, and a small fraction of elements off by more than fp32 noise;
+  (2) the distance to the true fp64 oracle, bounded by what bf16 storage costs: <= 4x the distance of the storage model
+      itself to fp64 (+ a floor), stated per test.
+The fp32 path stays the parity path (tests/test_hip_models.py, 1e-5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dgl_cpu as O
+from spgnn_amd import models, nn as snn, ops, ops_bf16, synthetic
+from spgnn_amd.configs import class_weight_list, get_config
+from spgnn_amd.graph import TreeGraph
+from spgnn_amd.train import TrainStep, masked_weighted_ce
+from tests.util import rel_err, tree_batch_edges
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+ULP = 2.0 ** -8            # bf16: 8 significant bits, round to nearest: relative rounding error <= 2^-9, one ulp = 2^-8
+
+
+def _rows(x):
+    return ops_bf16.cast_rows(x.float().cuda())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GEMMs
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 4, 8), (77, 64, 32), (300, 128, 64), (513, 256, 128), (1000, 512, 1063),
+                                   (2049, 132, 40), (4100, 1024, 200), (131, 4096, 128)])
+def test_gemm_nt_bf16_exact_on_integers(M, N, K):
+    """fp32 output, small-integer operands: every product and partial sum is exact, so any tile / fragment / ragged-K
+    (K % 64 != 0, chunks redirected to the zero line) / edge-row mistake shows as an integer error."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float()
+    out = ops_bf16.gemm_nt(_rows(a), _rows(b), out_f32=True)
+    assert torch.equal(out.cpu(), a @ b.t())
+    out16 = ops_bf16.gemm_nt(_rows(a), _rows(b))
+    assert out16.dtype == BF and torch.equal(out16.float().cpu(), (a @ b.t()).to(BF).float())
+
+
+def test_gemm_nt_bf16_asymmetric_identity():
+    """A = I with an asymmetric B: catches a transposed output / fragment map (cdna_hip_programming.md §3)."""
+    n = 256
+    a = torch.eye(n)
+    b = (torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] % 7).float() % 64      # asymmetric, exact in bf16
+    out = ops_bf16.gemm_nt(_rows(a), _rows(b), out_f32=True)
+    assert torch.equal(out.cpu(), b.t())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(700, 256, 192, ops.ACT_NONE), (700, 128, 256, ops.ACT_ELU), (90, 64, 64, ops.ACT_RELU)])
+def test_gemm_nt_bf16_random_bias_act(M, N, K, act):
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, K, generator=g).to(BF).float()
+    b = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).float()
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = a.double() @ b.double().t() + bias.double()
+    ref = {ops.ACT_NONE: ref, ops.ACT_ELU: F.elu(ref), ops.ACT_RELU: F.relu(ref)}[act]
+    out32 = ops_bf16.gemm_nt(_rows(a), _rows(b), out_f32=True, bias=bias.cuda(), act=act)
+    assert rel_err(out32, ref) < 2e-6                                   # fp32 accumulation of exact bf16 products
+    out16 = ops_bf16.gemm_nt(_rows(a), _rows(b), bias=bias.cuda(), act=act)
+    d = (out16.float().cpu().double() - ref).abs()
+    assert (d <= ULP * ref.abs() + 1e-6).all()                          # the stored value is the rounding of an fp32-accurate sum
+
+
+def test_gemm_nt_bf16_score_partials():
+    """el / er partials from the values AS STORED (bf16-rounded ft), per 64-column block."""
+    M, K, HD, R = 333, 128, 256, 512
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(BF).float()
+    b = (torch.randn(R, K, generator=g) / K ** 0.5).to(BF).float()
+    sl, sr = torch.randn(HD, generator=g), torch.randn(HD, generator=g)
+    parts = torch.empty((M, HD // 64, 2), device="cuda")
+    y = ops_bf16.gemm_nt(_rows(a), _rows(b), score_l=sl.cuda(), score_r=sr.cuda(), score_out=parts)
+    ft = y[:, :HD].float().cpu().double()
+    ref_l = (ft * sl.double()).view(M, HD // 64, 64).sum(-1)
+    ref_r = (ft * sr.double()).view(M, HD // 64, 64).sum(-1)
+    assert rel_err(parts[..., 0], ref_l) < 2e-6 and rel_err(parts[..., 1], ref_r) < 2e-6
+
+
+@pytest.mark.parametrize("R,M,N", [(1, 8, 8), (500, 128, 64), (4097, 256, 128), (9000, 512, 1063), (20000, 1024, 40),
+                                   (777, 200, 136)])
+def test_gemm_tn_bf16_exact_on_integers(R, M, N):
+    g = torch.Generator().manual_seed(R + M + N)
+    a = torch.randint(-2, 3, (R, M), generator=g).float()
+    b = torch.randint(-2, 3, (R, N), generator=g).float()
+    out, cs = ops_bf16.gemm_tn(_rows(a), _rows(b), want_colsum=True)
+    assert torch.equal(out.cpu(), a.t() @ b)
+    assert torch.equal(cs.cpu(), a.sum(0))
+    assert torch.equal(ops_bf16.gemm_tn(_rows(a), _rows(b)).cpu(), a.t() @ b)
+
+
+def test_weight_operands_and_cast():
+    g = torch.Generator().manual_seed(1)
+    wa, wb = torch.randn(96, 1063, generator=g), torch.randn(32, 1063, generator=g)
+    w, wt = ops_bf16.weight_operands(wa.cuda(), wb.cuda(), want_t=True)
+    ref = torch.cat([wa, wb]).to(BF)
+    assert ops_bf16.rows_ok(w) and ops_bf16.rows_ok(wt)
+    assert torch.equal(w.cpu(), ref) and torch.equal(wt.cpu(), ref.t())
+    # pad columns are zero (the GEMMs read whole 8-element chunks)
+    assert w.stride(0) == 1064 and float(w._base[:, 1063:].abs().max()) == 0.0
+    x = torch.randn(50, 39, generator=g)
+    xb = ops_bf16.cast_rows(x.cuda())
+    assert torch.equal(xb.cpu(), x.to(BF)) and xb.stride(0) == 40 and float(xb._base[:, 39:].abs().max()) == 0.0
+
+
+def test_cat_dropout_bf16_matches_fp32_mask():
+    """Same counter hash as the fp32 kernel: equal keep masks; backward multiplies by the same mask."""
+    N, w1, w2, p, seed = 257, 64, 128, 0.3, 1234
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.randn(N, w1, generator=g), torch.randn(N, w2, generator=g)
+    y32 = ops.cat_dropout((a.cuda(), b.cuda()), p, seed)
+    ab, bb = _rows(a).requires_grad_(), _rows(b).requires_grad_()
+    y16 = ops_bf16.cat_dropout((ab, bb), p, seed)
+    assert ops_bf16.rows_ok(y16)
+    keep = (y32 != 0).cpu()
+    ref = torch.cat([a.to(BF).float(), b.to(BF).float()], 1) * keep / (1 - p)
+    assert torch.equal(y16.float().cpu(), ref.to(BF).float())
+    go = torch.randn(N, w1 + w2, generator=g).to(BF)
+    y16.backward(go.cuda())
+    gref = (go.float() * keep / (1 - p)).to(BF).float()
+    assert torch.equal(ab.grad.float().cpu(), gref[:, :w1]) and torch.equal(bb.grad.float().cpu(), gref[:, w1:])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GATConv layer: HIP bf16 path vs the storage model (fp64 arithmetic, bf16 rounding at the storage points)
+# ----------------------------------------------------------------------------------------------------------------
+def _close_to_model(x, ref, what, frac=0.02):
+    """x (HIP) against the storage model: normwise within one bf16 ulp, and all but a small fraction of the elements
+    within fp32-accumulation noise of the model (the rest crossed a bf16 rounding boundary somewhere upstream)."""
+    x, ref = x.detach().float().cpu().double(), ref.detach().double().cpu()
+    scale = ref.abs().max().item() or 1.0
+    d = (x - ref).abs()
+    assert d.max().item() <= 2 * ULP * scale, (what, d.max().item() / scale)
+    off = (d > 1e-4 * scale).double().mean().item()
+    assert off <= frac, (what, off)
+
+
+@pytest.mark.parametrize("F_in,H,D,res,act,mean", [(128, 2, 64, True, "elu", False), (256, 2, 128, True, "elu", False),
+                                                   (64, 1, 64, False, None, False), (128, 2, 1024, True, None, True),
+                                                   (1024, 2, 256, True, "elu", False), (96, 4, 64, True, "tanh", True)])
+def test_gat_layer_bf16_matches_storage_model(F_in, H, D, res, act, mean):
+    src, dst, n = tree_batch_edges([37, 61, 150, 9], seed=4)
+    g = TreeGraph((src, dst), n, device="cuda")
+    actf = {"elu": F.elu, "tanh": torch.tanh, None: None}[act]
+    torch.manual_seed(F_in + H + D)
+    layer = snn.GATConv(F_in, D, H, 0.0, 0.0, 0.2, res, actf).cuda()
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.05)
+    x = torch.randn(n, F_in).to(BF).float()
+    xb = _rows(x).requires_grad_()
+    out = layer(g, xb, mean_heads=mean)
+    out = out if mean else out.flatten(1)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
+    go = go if out.dtype == torch.float32 else go.to(BF).float()
+    out.backward(go.cuda().to(out.dtype))
+    # storage model in fp64
+    fused = mean and ops.can_fuse_mean(H, D)        # a head narrower than a team: per-head rows are stored, torch takes the mean
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in layer.state_dict().items()}
+    x64 = x.double().requires_grad_()
+    r = O.gat_conv(torch.as_tensor(src), torch.as_tensor(dst), n, x64, sd["fc.weight"], sd["attn_l"], sd["attn_r"],
+                   sd.get("res_fc.weight"), sd["bias"], 0.2, actf, storage=O.Bf16Storage, store_out=not fused)[0]
+    r = r.mean(1) if mean else r.flatten(1)
+    if mean and not fused:
+        r = O.Bf16Storage.store(r)
+    r.backward(go.double())
+    assert out.dtype == (torch.float32 if fused else BF)
+    _close_to_model(out, r, "out")
+    _close_to_model(xb.grad, O._rb(x64.grad), "g_x")
+    for k, p in layer.named_parameters():
+        # attn_l / attn_r gradients are sums over all nodes of g_el * ft: cancellation-heavy (the softmax is shift invariant
+        # in er up to the LeakyReLU kink), so single rounding-boundary flips upstream move many of their elements by more
+        # than fp32 noise; they keep the normwise 2-ulp bound only
+        _close_to_model(p.grad, sd[k].grad, k, frac=1.0 if k.startswith("attn") else 0.05)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# model level: st_gat_6 (BASELINE config 4) and st_gat_3
+# ----------------------------------------------------------------------------------------------------------------
+def _build(name, seed=0):
+    cfg = get_config(name)
+    torch.manual_seed(seed)
+    model = models.build_model(cfg.MODEL).cuda()
+    model.init(None)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+    model.set_gcn_only()
+    models.set_storage_dtype(model, BF)
+    return cfg, model
+
+
+def _oracle_logits(cfg, model, g, dtype, storage, grad=False):
+    src, dst = g.cpu().edges()
+    sd = {k: v.detach().cpu().to(dtype).requires_grad_(grad and v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    return O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu().to(dtype), None, storage=storage), sd
+
+
+@pytest.mark.parametrize("name", ["st_gat_6", "st_gat_3"])
+def test_bf16_model_forward_and_gradients(name):
+    cfg, model = _build(name)
+    g = synthetic.make_batch(3, rank=5, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model.eval()
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5
+    logits, emb = model(g)
+    loss = masked_weighted_ce(logits, y, mask.cuda(), w.cuda())
+    loss.backward()
+    assert logits.dtype == torch.float32 and emb.dtype == torch.float32
+    (m_logits, m_emb), sd_m = _oracle_logits(cfg, model, g, torch.float64, O.Bf16Storage, grad=True)
+    O.masked_weighted_ce(m_logits, y.cpu(), mask, w.double()).backward()
+    (t_logits, t_emb), sd_t = _oracle_logits(cfg, model, g, torch.float64, None, grad=True)
+    O.masked_weighted_ce(t_logits, y.cpu(), mask, w.double()).backward()
+    # (1) against the storage model.  Rounding-boundary flips upstream perturb downstream layers, so at model level the
+    # bound is a small multiple of one ulp rather than fp32 noise: normwise 4 ulp on embeddings and logits.
+    assert rel_err(emb, m_emb) < 4 * ULP and rel_err(logits, m_logits) < 4 * ULP
+    # (2) against the true fp64 oracle: no worse than 4x what bf16 storage itself costs (model vs truth), floor 2 ulp
+    cost = rel_err(m_logits, t_logits)
+    assert rel_err(logits, t_logits) < 4 * cost + 2 * ULP, (rel_err(logits, t_logits), cost)
+    assert rel_err(logits, t_logits) < 0.05            # absolute sanity bound: 7 layers of 2^-9 relative rounding noise
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gm, gt = sd_m[n].grad, sd_t[n].grad
+        e_model = rel_err(p.grad, gm)
+        e_true, cost_g = rel_err(p.grad, gt), rel_err(gm, gt)
+        assert e_model < 0.05 or e_true < 4 * cost_g + 0.02, (n, e_model, e_true, cost_g)
+
+
+def test_bf16_train_step_tracks_fp32_and_replays():
+    """The full training step (dropout on) on bf16 storage follows the fp32-storage step taken from the same weights with
+    the same mask / dropout draws (identical counter hashes in both paths) within bf16 noise, keeps fp32 master weights,
+    and runs as HIP-graph replays."""
+    losses = {}
+    for dt in (torch.float32, BF):
+        cfg, model = _build("st_gat_6", seed=11)
+        models.set_storage_dtype(model, dt)
+        g = synthetic.make_batch(6, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+        model.train()
+        torch.manual_seed(77)                       # the host-side seed draws of the dropout hashes
+        step = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, 1e-3, 0.9, seed=3)
+        losses[dt] = [float(step.step(g)) for _ in range(6)]
+        assert all(p.dtype == torch.float32 for p in model.parameters())
+    a, b = np.array(losses[torch.float32]), np.array(losses[BF])
+    assert np.isfinite(b).all() and np.abs(a - b).max() < 0.03 * np.abs(a).max(), (a, b)
+    step.capture(g)                                  # the bf16 step, captured
+    l2 = [float(step.replay()) for _ in range(4)]
+    assert np.isfinite(l2).all() and max(l2) < 2 * a.max()
+
+
+def test_bf16_512_trees_properties():
+    """BASELINE config 4 at its full size (512 trees): batching B trees == concatenating single-tree results (block
+    diagonal graph: no cross-tree traffic) and bitwise run-to-run reproducibility."""
+    cfg, model = _build("st_gat_6")
+    model.eval()
+    samples = synthetic.synthetic_trees(512, rank=0)
+    g = synthetic.batch_from_samples(samples, "cuda", cfg.POS_ENC_DIM)
+    with torch.no_grad():
+        a = model(g)[0]
+        b = model(g)[0]
+        assert torch.equal(a, b)
+        sub = synthetic.batch_from_samples(samples[100:103], "cuda", cfg.POS_ENC_DIM)
+        n0 = sum(s["fvs"].shape[0] for s in samples[:100])
+        c = model(sub)[0]
+        assert torch.equal(a[n0:n0 + c.shape[0]], c)
