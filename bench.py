@@ -7,15 +7,22 @@ One "step" = one optimizer step on one static batched graph of synthetic random-
 the timed region.  Default workload: st_pgat_spgnn_3 (full SPGNN + LSPE position stream), 512 trees
 per GPU, fp32, dropout on — the configuration BASELINE.json's north_star quotes its target on; with
 N GPUs every rank gets its own 512 trees (weak scaling, global batch 512*N).
+`--config st_gat_6 --dtype bf16` is BASELINE config 4 (bf16 storage, fp32 accumulate).
 
 Single GPU:  python bench.py [--steps K --warmup W]
 Multi GPU:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                  --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-"roofline" for the dominant hand-written kernel (algorithmic bytes per launch / mean launch time
-from HIP events recorded on the launch stream during the timed region) and "cpu_baseline" (the
-DGL-CPU-equivalent restatement under oracle/, timed on this host's cores on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement).  Protocol: W warm-up steps, then
+exactly K timed steps between barrier + synchronize on both sides (`value`, `ms_per_step`: max over ranks); every
+timed step is also bracketed by HIP events on the compute stream (`step_ms`: median / p10 / p90).  Extra objects:
+  roofline        the step's dominant kernel, FIXED per dtype (f32: spgnn_gemm_nt, all its launches of a step, MFMA bound;
+                  bf16: the GAT message-passing kernels spgnn_gat_{fwd,bwd_dst,bwd_src}_bf16, HBM bound): algorithmic
+                  flops or bytes per step / its measured time per step (HIP events on the launch stream) / peak
+  roofline_k123   SURVEY.md §8d's K1-K3 (GAT kernels): vs the survey's per-model byte count and vs their own bytes
+  composite       SURVEY.md §8d / BASELINE.md §2: t_graph + max(t_gemm_bytes, t_gemm_flops) against the measured step
+  copy_bandwidth  achievable HBM bandwidth of a plain device copy on this box, measured in the same run
+  cpu_baseline    the DGL-CPU-equivalent restatement (oracle/, "port") timed on this host's cores on a bounded sample
 """
 from __future__ import annotations
 
@@ -31,71 +38,98 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+MFMA_F16_PEAK = 2500.0      # dense fp16 / bf16 TFLOP/s
+FP32_MATRIX_PEAK = 157.3    # native fp32 MFMA TFLOP/s (the pipe an fp32 GEMM would otherwise use)
+GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16")
+HELPER_NAMES = ("absmax", "split_rows")
+GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg")
 
 
 def algorithmic_bytes(key) -> float:
-    """Algorithmic HBM bytes of ONE launch (SURVEY.md §8d per-unit figures, fp32):
-    every operand row read once, every result row written once, index arrays once."""
+    """Algorithmic HBM bytes of ONE launch (SURVEY.md §8d per-unit figures): every operand row
+    read once, every result row written once, index arrays once.  s = bytes per stored row element (4, or 2 for the
+    *_bf16 kernels; scores, attention and indices are always 4 bytes)."""
     name = key[0]
-    if name == "gat_fwd":            # read ft [+res]; write out [and/or its head mean]; read el, er; write a; CSC
+    s = 2 if name.endswith("_bf16") else 4
+    base = name[:-5] if name.endswith("_bf16") else name
+    if base == "gat_fwd":            # read ft [+res]; write out [and/or its fp32 head mean]; read el, er; write a; CSC
         _, N, E, H, D, has_res, mean, has_out = key
-        return (4 * (1 + has_res + has_out) * N * H * D + 4 * mean * N * D + 4 * (2 * N * H + E * H)
+        return (s * (1 + has_res + has_out) * N * H * D + 4 * mean * N * D + 4 * (2 * N * H + E * H)
                 + 4 * (N + 1 + E))
-    if name == "gat_bwd_dst":        # read g_out [,out], ft; write g_pre; read el, er, a; write g_e, g_er; CSC
+    if base == "gat_bwd_dst":        # read g_out [,out], ft; write g_pre; read el, er, a; write g_e, g_er; CSC
         _, N, E, H, D, act, mean = key
-        return (4 * (2 + (1 if act else 0)) * N * H * D + 4 * N * (D if mean else H * D)
+        return (s * (2 + (1 if act else 0)) * N * H * D + (4 * N * D if mean else s * N * H * D)
                 + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E))
-    if name == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
+    if base == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
         _, N, E, H, D = key
-        return 4 * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
-    if name == "scores_fwd":         # read x; write S
+        return s * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+    if base == "scores_fwd":         # read x; write S
         _, N, K, J = key
         return 4 * N * K + 4 * N * J
-    if name == "scores_bwd_w":       # read x, gS; partials negligible
+    if base == "scores_bwd_w":       # read x, gS; partials negligible
         _, N, K, J = key
-        return 4 * N * K + 4 * N * J
-    if name == "scores_bwd_x":       # read + write gX; read gS
+        return s * N * K + 4 * N * J
+    if base == "scores_bwd_x":       # read + write gX; read gS
         _, N, K, J = key
         return 4 * 2 * N * K + 4 * N * J
-    if name == "gat_agg_fwd":        # read x; write the z blocks [with a copy of x per head]; el, er, a; CSC
+    if base == "gat_agg_fwd":        # read x; write the z blocks [with a copy of x per head]; el, er, a; CSC
         _, N, E, H, F_, xcopy = key
         return 4 * N * F_ + 4 * N * H * F_ * (2 if xcopy else 1) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
-    if name == "gat_agg_bwd_dst":    # read the z part of g_z and x; el, er, a; write g_e, g_er; CSC
+    if base == "gat_agg_bwd_dst":    # read the z part of g_z and x; el, er, a; write g_e, g_er; CSC
         _, N, E, H, F_ = key
         return 4 * N * (H + 1) * F_ + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
-    if name == "gat_agg_bwd_src":    # read g_z (both parts); write g_x; a, g_e, g_er, g_el; CSR + slot map
+    if base == "gat_agg_bwd_src":    # read g_z (both parts); write g_x; a, g_e, g_er, g_el; CSR + slot map
         _, N, E, H, F_ = key
         return 4 * N * (2 * H + 1) * F_ + 4 * (2 * N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
-    if name == "head_mean":
+    if base == "head_mean":
         _, N, H, D = key
         return 4 * N * (H + 1) * D
-    if name == "act_bwd":            # read g_out [and out]; write g_pre
+    if base == "act_bwd":            # read g_out [and out]; write g_pre
         _, N, H, D, act, mean = key
         return 4 * N * (D if mean else H * D) + 4 * N * H * D * (2 if act else 1)
-    if name == "act_bwd_proj":       # read g_logits and out; write g_pre (the classifier's input gradient stays in registers)
+    if base == "act_bwd_proj":       # read g_logits and out; write g_pre (the classifier's input gradient stays in registers)
         _, N, H, D, act, J = key
         return 4 * N * H * D * (2 if act else 1) + 4 * N * J + 4 * J * D
-    if name == "sum_partials":
+    if base == "sum_partials":
         return 0.0
-    if name == "scores_from_parts":      # read the (N, H*D/64, 2) partials, write (N, 2H)
+    if base == "scores_from_parts":      # read the (N, H*D/64, 2) partials, write (N, 2H)
         _, N, H, D = key
         return 4 * 2 * N * H * (D // 64) + 4 * 2 * N * H
-    if name == "masked_ce":
+    if base == "masked_ce":
         _, N, C = key
         return 4 * 2 * N * C + 4 * 4 * N
-    if name in ("gemm_nt", "gemm_tn", "absmax", "split_rows"):
-        return 0.0                    # compute-bound / helper kernels: reported in "gemm", not in the HBM accounting
-    if name == "spmm_sum":
+    if base in ("gemm_nt", "gemm_tn") or base in HELPER_NAMES:
+        return 0.0                    # compute-side kernels: accounted in "gemm" / "composite", not in the message-passing bytes
+    if base == "spmm_sum":
         _, N, E, F = key
         return 4 * 2 * N * F + 4 * (N + 1 + E)
-    if name == "spmm_max_fwd":
+    if base == "spmm_max_fwd":
         _, N, E, F = key
         return 4 * 3 * N * F + 4 * (N + 1 + E)
-    if name == "spmm_max_bwd":
+    if base == "spmm_max_bwd":
         _, N, E, F = key
         return 4 * 3 * N * F + 4 * (N + 1 + 2 * E)
     raise KeyError(name)
+
+
+def gemm_bytes(key) -> float:
+    """Algorithmic HBM bytes of one projection product: both operands once + the result once."""
+    name, a, b, c = key
+    s = 2 if name.endswith("_bf16") else 4
+    if name.startswith("gemm_nt"):           # (M, N, K): A (M,K), B (N,K) -> C (M,N) in the storage dtype
+        return s * (a * c + b * c + a * b)
+    return s * (a * b + a * c) + 4 * b * c   # gemm_tn (R, M, N): A (R,M), B (R,N) -> fp32 C (M,N)
+
+
+def survey_k123_bytes(gat_keys, dtype_bytes) -> float:
+    """SURVEY.md §8d's per-GATConv figure B_fwd + B_bwd (= 5.29 GB for st_pgat_spgnn_3 at 512 trees in fp32) from the
+    layer shapes that ran: B_fwd = s 2 N HD + 4 (2 N H + E H) + 4 (N + 1 + E); B_bwd = s 3 N HD + 4 (2 N H + 3 E H) +
+    8 (N + 1 + E).  ``gat_keys``: [((name, N, E, H, D), launches per step)], one entry per GATConv layer."""
+    tot, s = 0.0, dtype_bytes
+    for (_, N, E, H, D), n in gat_keys:
+        tot += n * (s * 5 * N * H * D + 4 * (4 * N * H + 4 * E * H) + 12 * (N + 1 + E))
+    return tot
 
 
 def usable_cores(cap: int = 32) -> int:
@@ -111,13 +145,13 @@ def usable_cores(cap: int = 32) -> int:
     return max(1, min(n, cap))
 
 
-def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=1, budget_s=25.0):
-    """DGL-CPU-equivalent (restated) fwd+bwd on the host cores: oracle/dgl_cpu.py, same weights, first
-    ``n_trees`` trees of rank 0's batch, eval-mode arithmetic (no dropout), all host threads."""
+def cpu_baseline(cfg, model, samples, n_trees, iters=10, warm=3, budget_s=40.0):
+    """DGL-CPU-equivalent (restated) fwd+bwd on the host cores: oracle/dgl_cpu.py, same weights, first ``n_trees`` trees of
+    rank 0's batch, eval-mode arithmetic (no dropout), fp32, all usable host threads; median of >= 10 iterations after 3
+    warm-ups, stopping early only past ``budget_s``."""
     from oracle import dgl_cpu as O
     from spgnn_amd import synthetic
     from spgnn_amd.configs import class_weight_list
-    import torch.nn.functional as F
     cores = usable_cores()
     torch.set_num_threads(cores)
     g = synthetic.batch_from_samples(samples[:n_trees], "cpu", cfg.POS_ENC_DIM)
@@ -129,8 +163,8 @@ def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=1, budget_s=25.0):
     mask = torch.rand(n) < torch.where(y != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
     times = []
     t_start = time.perf_counter()
-    for i in range(warm + steps):
-        if i > warm and time.perf_counter() - t_start > budget_s:
+    for i in range(warm + iters):
+        if len(times) >= 3 and time.perf_counter() - t_start > budget_s:
             break
         t0 = time.perf_counter()
         out = O.net_forward(cfg.KIND, sd, src, dst, n, g.ndata["fvs"], g.ndata.get("pos_enc"))[0]
@@ -142,24 +176,50 @@ def cpu_baseline(cfg, model, samples, n_trees, steps=5, warm=1, budget_s=25.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": E * cfg.CONV_LAYERS / med, "unit": "layer-edges/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fwd+bwd, median of {len(times)} "
-                      f"after {warm} warm-up(s) on {cores} threads, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops"}
+            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fp32 fwd+bwd, median of {len(times)} "
+                      f"after {warm} warm-ups on {cores} threads, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops"}
+
+
+def copy_bandwidth(dev, mib=1024, iters=10):
+    """Achievable HBM bandwidth of a plain device-to-device copy (read + write), median of ``iters``."""
+    n = mib * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    med = ts[len(ts) // 2]
+    del a, b
+    return {"GBps": 2.0 * n * 4 / (med * 1e-3) / 1e9, "frac_of_hbm_peak": 2.0 * n * 4 / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "what": f"torch device copy of {mib} MiB fp32 (read + write), median of {iters}"}
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="st_pgat_spgnn_3")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage dtype of node-feature rows inside the GNN head")
     ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
     ap.add_argument("--eager", action="store_true",
                     help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
     ap.add_argument("--no-eager-leg", action="store_true", help="graph mode: skip the eager steps after the timed region "
-                    "(they carry the HIP events around the dominant kernel for the roofline object)")
+                    "(they carry the HIP events around the roofline kernels)")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trees", type=int, default=32)
+    ap.add_argument("--cpu-trees", type=int, default=64)
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
@@ -198,6 +258,9 @@ def main():
     model.init(None)
     model.set_gcn_only()
     model.train(not args.no_dropout)
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        models.set_storage_dtype(model, torch.bfloat16)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
 
     samples = synthetic.synthetic_trees(args.trees, rank=rank)
@@ -213,10 +276,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up.  Its last two steps are fully instrumented (HIP events around every hand-written kernel launch):
-    # they give the per-kernel breakdown and identify the dominant kernel.  Recording ~140 events per step
-    # perturbs the step by ~20 % (measured), so inside the timed region only the dominant kernel is bracketed
-    # (two events per step).
+    # Warm-up.  Its last two steps are fully instrumented (HIP events around every hand-written kernel launch): they give
+    # the per-kernel breakdown.  Recording ~140 event pairs per step perturbs the step, so they are never inside the
+    # timed region; the roofline kernels are re-timed on their own (few events per step) after it.
     probe = 0 if args.no_kernel_timers else min(2, args.warmup)
     for _ in range(args.warmup - probe):
         loss = step.step(g)
@@ -227,15 +289,14 @@ def main():
         for _ in range(probe):
             loss = step.step(g)
         kt_all = ops.KernelTimer.stop()
-    hip_keys = [k for k in kt_all if k[0] not in ("gemm_nt", "gemm_tn", "absmax")]
-    dom = max(hip_keys, key=lambda k: sum(kt_all[k])) if hip_keys else None           # dominant HBM-bound kernel
-    dom_all = max(kt_all, key=lambda k: sum(kt_all[k])) if kt_all else None            # dominant kernel of the step
-    bracket = [k for k in (dom, dom_all) if k is not None]
+    # The roofline kernel is FIXED per dtype (not "whichever shape won this run"): all launches of it in a step.
+    roof_names = ("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16") if bf16 else ("gemm_nt",)
+    gat_names = tuple(k for k in {k[0] for k in kt_all} if k.startswith(GAT_PREFIXES))
+    bracket = [k for k in kt_all if k[0] in roof_names or k[0] in gat_names or k[0] in GEMM_NAMES]
     sync()
     # Timed region.  Default: every step is a replay of the captured step (two HIP graphs around the gradient
-    # all-reduce, TrainStep.capture) - eagerly the ~230 launches and autograd's host work per step take the host as
-    # long as the GPU needs for the kernels (7.5 ms), so a slow host core would be what is measured.  --eager times
-    # eagerly issued steps.  The work per step is identical.
+    # all-reduce, TrainStep.capture) - eagerly the launches and autograd's host work per step take the host as long as
+    # the GPU needs for the kernels, so a slow host core would be what is measured.  --eager times eagerly issued steps.
     launch, capture_error = "eager", None
     if not args.eager:
         try:
@@ -249,21 +310,24 @@ def main():
         if float(ok) == 0.0:
             launch = "eager"
     run_step = step.replay if launch != "eager" else (lambda: step.step(g))
-    sync()
-    if launch == "eager" and bracket:
-        ops.KernelTimer.start(only=bracket)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(3):                              # replays of the fresh graphs before the clock starts
         loss = run_step()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        loss = run_step()
+        marks[i + 1].record()
+    sync()
     elapsed = time.perf_counter() - t0
-    kt_dom = ops.KernelTimer.stop() if (bracket and launch == "eager") else {}
-    eager_leg = None
-    if (launch != "eager" or not kt_all) and not args.no_eager_leg and not args.no_kernel_timers:
-        # a replay cannot carry HIP events per launch: the dominant kernels' launches are bracketed in eagerly
-        # issued steps right after the timed region (same kernels, same operands, same stream)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    kt_dom, eager_leg = {}, None
+    if not args.no_eager_leg and not args.no_kernel_timers:
+        # a replay cannot carry HIP events per launch: the roofline kernels' launches are bracketed in eagerly issued
+        # steps right after the timed region (same kernels, same operands, same stream; only these kernels carry events)
         n_leg = min(args.steps, 20)
-        ops.KernelTimer.start(only=bracket or None)      # no instrumented warm-up steps (--warmup 0): time every kernel here
+        ops.KernelTimer.start(only=bracket or None)
         t1 = time.perf_counter()
         for _ in range(n_leg):
             step.step(g)
@@ -272,11 +336,8 @@ def main():
         kt_dom = ops.KernelTimer.stop()
         if not kt_all:
             kt_all, probe = dict(kt_dom), n_leg
-            hip_keys = [k for k in kt_all if k[0] not in ("gemm_nt", "gemm_tn", "absmax")]
-            dom = max(hip_keys, key=lambda k: sum(kt_all[k])) if hip_keys else None
-            dom_all = max(kt_all, key=lambda k: sum(kt_all[k])) if kt_all else None
-    kt = dict(kt_all)
     loss_val = float(loss)
+    copy_bw = copy_bandwidth(dev) if rank == 0 else None
 
     tot = torch.tensor([elapsed, float(E), float(N)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -290,41 +351,37 @@ def main():
         L = cfg.CONV_LAYERS
         ms = elapsed / args.steps * 1e3
         value = E_all * L * args.steps / elapsed
+        s_row = 2 if bf16 else 4
+        gemm_desc = ("bf16 MFMA, single product, fp32 accumulate (bf16 storage)" if bf16 else
+                     "split-fp16 x3 MFMA, fp32 accumulate (fp32-GEMM accuracy)" if ops.GEMM_MODE == "f16x3"
+                     else "fp32 (rocBLAS/hipBLASLt via torch.mm)")
         out = {
             "metric": "message-passing edges/sec (fwd+bwd), batched trees", "value": value, "unit": "layer-edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} training step (fwd+loss+bwd+allreduce+SGD), {args.trees} trees/GPU, "
-                                   f"random fan-out trees n~U[120,180], fp32, dropout {'off' if args.no_dropout else 'on'}",
+                                   f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
+                                   f"dropout {'off' if args.no_dropout else 'on'}",
                        "trees_per_gpu": args.trees, "global_trees": args.trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
-                       "parallelism": f"dp{world}", "launch": launch,
-                       "gemm": ("split-fp16 x3 MFMA, fp32 accumulate (fp32-GEMM accuracy)" if ops.GEMM_MODE == "f16x3"
-                                else "fp32 (rocBLAS/hipBLASLt via torch.mm)")},
+                       "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc},
             "graph_edges_per_s": E_all * args.steps / elapsed, "loss": loss_val,
+            "step_ms": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
+                        "n": len(step_ms), "how": "HIP events on the compute stream around every timed step (rank 0)"},
+            "copy_bandwidth": copy_bw,
         }
-        if kt:
+        if kt_all:
             nprobe = max(probe, 1)
-            gemm_keys = [k for k in kt if k[0] in ("gemm_nt", "gemm_tn", "absmax")]
-            gemm_kt = {k: kt.pop(k) for k in gemm_keys}
-            if gemm_kt:
-                fl = sum(2.0 * k[1] * k[2] * k[3] * len(v) for k, v in gemm_kt.items() if k[0] != "absmax") / nprobe
-                g_ms = sum(sum(v) for k, v in gemm_kt.items() if k[0] != "absmax") / nprobe
-                out["gemm"] = {"kernel": "spgnn_gemm_nt/tn (split-fp16, 3 MFMA products, fp32 accumulate)",
-                               "ms_per_step": g_ms, "fp32_equiv_TFLOPs": fl / (g_ms * 1e-3) / 1e12,
-                               "mfma_f16_TFLOPs": 3 * fl / (g_ms * 1e-3) / 1e12, "mfma_f16_peak_TFLOPs": 2500.0,
-                               "frac_of_f16_peak": 3 * fl / (g_ms * 1e-3) / 1e12 / 2500.0,
-                               "absmax_ms_per_step": sum(sum(v) for k, v in gemm_kt.items() if k[0] == "absmax") / nprobe,
-                               # per shape (M, N, K): launches per step, mean ms, fp32-equivalent TFLOP/s
-                               "per_shape": {"_".join(str(x) for x in k): [len(v) // nprobe, round(sum(v) / len(v), 4),
-                                                                           round(2.0 * k[1] * k[2] * k[3] / (sum(v) / len(v) * 1e-3) / 1e12, 1)]
-                                             for k, v in sorted(gemm_kt.items(), key=lambda kv: -sum(kv[1])) if k[0] != "absmax"},
-                               "measured_in": f"{nprobe} instrumented warm-up step(s)"}
-            agg = {k: (sum(v) / len(v), sum(v), len(v)) for k, v in kt.items()}
-            mp_ms = sum(t for _, t, _ in agg.values()) / nprobe
-            where = ("timed region" if (launch == "eager" and eager_leg is None) else
-                     "eagerly issued launches right after the timed region") + \
-                    " (HIP events on the launch stream around every launch of this kernel)"
+            n_leg = eager_leg["steps"] if eager_leg else nprobe
+
+            def per_step(key):
+                """(ms per step, launches per step) of one (kernel, shape): from the dedicated leg when it was bracketed there."""
+                if key in kt_dom:
+                    return sum(kt_dom[key]) / n_leg, len(kt_dom[key]) / n_leg
+                return sum(kt_all[key]) / nprobe, len(kt_all[key]) / nprobe
+
+            where = ("eagerly issued steps right after the timed region, HIP events on the launch stream around the launches "
+                     "of the roofline / GAT / GEMM kernels only") if kt_dom else f"{nprobe} fully instrumented warm-up step(s)"
             traffic_tab = {}
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tpath):
@@ -333,57 +390,128 @@ def main():
                 except Exception:
                     traffic_tab = {}
 
-            def hbm_roofline(key):
-                times = kt_dom.get(key) or kt_all[key]
-                avg_ms = sum(times) / len(times)
-                bytes_alg = algorithmic_bytes(key)
-                ach = bytes_alg / (avg_ms * 1e-3) / 1e9
-                return {"bound": "hbm", "kernel": key[0], "shape": list(key[1:]), "achieved": ach, "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic_tab.get("_".join(str(x) for x in key)),
-                        "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": avg_ms, "launches": len(times),
+            def traffic_of(keys):
+                """PMC HBM bytes per step of these (kernel, shape) keys, from the committed rocprofv3 --pmc pass, or None."""
+                tot_, seen = 0.0, False
+                for k in keys:
+                    t = traffic_tab.get("_".join(str(x) for x in k))
+                    if t is None:
+                        return None
+                    tot_ += t * per_step(k)[1]
+                    seen = True
+                return tot_ if seen else None
+
+            # ---- projection GEMMs ---------------------------------------------------------------------------------
+            gemm_keys = [k for k in kt_all if k[0] in GEMM_NAMES]
+            products = 1 if bf16 else 3
+            g_ms = g_fl = g_by = 0.0
+            per_name = {}
+            for k in gemm_keys:
+                t, n = per_step(k)
+                fl = 2.0 * k[1] * k[2] * k[3] * n
+                g_ms += t; g_fl += fl; g_by += gemm_bytes(k) * n
+                d = per_name.setdefault(k[0], [0.0, 0.0, 0.0, 0])
+                d[0] += t; d[1] += fl; d[2] += gemm_bytes(k) * n; d[3] += n
+            if gemm_keys:
+                out["gemm"] = {
+                    "kernels": {nm: {"ms_per_step": d[0], "launches_per_step": d[3], "algorithmic_TFLOPs": d[1] / (d[0] * 1e-3) / 1e12,
+                                     "executed_mfma_TFLOPs": products * d[1] / (d[0] * 1e-3) / 1e12,
+                                     "algorithmic_GBps": d[2] / (d[0] * 1e-3) / 1e9}
+                                for nm, d in per_name.items()},
+                    "ms_per_step": g_ms, "algorithmic_TFLOP_per_step": g_fl / 1e12, "algorithmic_GB_per_step": g_by / 1e9,
+                    "algorithmic_TFLOPs": g_fl / (g_ms * 1e-3) / 1e12, "executed_mfma_TFLOPs": products * g_fl / (g_ms * 1e-3) / 1e12,
+                    "mfma_products_per_fp32_product": products,
+                    # per shape: launches per step, mean ms per launch, algorithmic TFLOP/s
+                    "per_shape": {"_".join(str(x) for x in k): [round(per_step(k)[1], 2), round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 4),
+                                                                round(2.0 * k[1] * k[2] * k[3] * per_step(k)[1] / (per_step(k)[0] * 1e-3) / 1e12, 1)]
+                                  for k in sorted(gemm_keys, key=lambda kk: -per_step(kk)[0])},
+                    "measured_in": where}
+
+            # ---- message passing (every hand-written non-GEMM kernel) ---------------------------------------------
+            mp_keys = [k for k in kt_all if k[0] not in GEMM_NAMES and k[0] not in HELPER_NAMES]
+            mp_ms = sum(per_step(k)[0] for k in mp_keys)
+            mp_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in mp_keys)
+            gat_keys = [k for k in mp_keys if k[0].startswith(GAT_PREFIXES)]
+            k123 = None
+            if gat_keys:
+                k_ms = sum(per_step(k)[0] for k in gat_keys)
+                k_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in gat_keys)
+                # the survey's figure needs (H, D) per layer: the aggregate-first output layer (F -> H x D) is entered with
+                # its projected width, as the survey counts it
+                fwd_layers = []
+                for k in gat_keys:
+                    base = k[0][:-5] if k[0].endswith("_bf16") else k[0]
+                    if base == "gat_fwd":
+                        fwd_layers.append(((k[0],) + tuple(k[1:5]), per_step(k)[1]))
+                    elif base == "gat_agg_fwd":
+                        fwd_layers.append((("gat_fwd", k[1], k[2], k[3], cfg.MODEL.get("node_embed_dim", 1024)), per_step(k)[1]))
+                sv_bytes = survey_k123_bytes(fwd_layers, s_row)
+                k123 = {"kernels": sorted({k[0] for k in gat_keys}), "ms_per_step": k_ms,
+                        "layer_edges_per_s": E * L / (k_ms * 1e-3),
+                        "own_algorithmic_GB_per_step": k_bytes / 1e9, "own_achieved_GBps": k_bytes / (k_ms * 1e-3) / 1e9,
+                        "own_frac_of_hbm_peak": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "survey_algorithmic_GB_per_step": sv_bytes / 1e9,
+                        "survey_roofline_layer_edges_per_s": E * L / (sv_bytes / (HBM_PEAK_GBPS * 1e9)) if sv_bytes else None,
+                        "frac_of_survey_roofline": (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (k_ms * 1e-3) if sv_bytes else None,
+                        "traffic_GB_per_step": (lambda t: t / 1e9 if t is not None else None)(traffic_of(gat_keys)),
                         "measured_in": where}
-
-            def mfma_roofline(key):
-                # algorithmic flops of one launch: 2 M N K (an fp32 product); the kernel executes them as three fp16
-                # MFMA products (hi*hi + hi*lo + lo*hi), so the matrix pipe does 3x that: `achieved` counts the
-                # EXECUTED fp16 MFMA flops against the dense fp16 peak; `algorithmic_TFLOPs` is the fp32 product rate.
-                times = kt_dom.get(key) or kt_all[key]
-                avg_ms = sum(times) / len(times)
-                fl = 2.0 * key[1] * key[2] * key[3]
-                ach = 3.0 * fl / (avg_ms * 1e-3) / 1e12
-                return {"bound": "mfma", "kernel": "spgnn_" + key[0], "shape": list(key[1:]), "achieved": ach, "peak": 2500.0,
-                        "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic_tab.get("_".join(str(x) for x in key)),
-                        "algorithmic_flops_per_launch": fl, "executed_mfma_flops_per_launch": 3.0 * fl,
-                        "algorithmic_TFLOPs": fl / (avg_ms * 1e-3) / 1e12, "fp32_matrix_peak_TFLOPs": 157.3,
-                        "avg_launch_ms": avg_ms, "launches": len(times), "measured_in": where,
-                        "note": "fp32 operands split on the fly into fp16 hi+lo, three MFMA products, fp32 accumulate"}
-
-            if dom_all is not None and dom_all[0] in ("gemm_nt", "gemm_tn"):
-                out["roofline"] = mfma_roofline(dom_all)          # the step's dominant kernel
-                if dom is not None:
-                    out["roofline_hbm"] = hbm_roofline(dom)        # and its dominant HBM-bound kernel
-            elif dom is not None:
-                out["roofline"] = hbm_roofline(dom)
-            mp_bytes = sum(algorithmic_bytes(k) * n for k, (_, _, n) in agg.items()) / nprobe
-            # SURVEY.md 8d's K1-K3 (scores + softmax + aggregation and their backward passes) on their own: the kernels
-            # the >= 50 % HBM-roofline target is stated over (its 2.43 G layer-edges/s roofline for st_pgat_spgnn_3 at 8 TB/s)
-            gk = {k: v for k, v in agg.items() if k[0].startswith(("gat_fwd", "gat_bwd", "gat_agg"))}
-            gat_part = None
-            if gk:
-                g_ms = sum(t for _, t, _ in gk.values()) / nprobe
-                g_bytes = sum(algorithmic_bytes(k) * n for k, (_, _, n) in gk.items()) / nprobe
-                gat_part = {"ms_per_step": g_ms, "algorithmic_GB_per_step": g_bytes / 1e9,
-                            "achieved_GBps": g_bytes / (g_ms * 1e-3) / 1e9,
-                            "frac_of_hbm_peak": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                            "layer_edges_per_s": E * L / (g_ms * 1e-3)}
+                out["roofline_k123"] = k123
             out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
                                       "algorithmic_GB_per_step": mp_bytes / 1e9,
-                                      "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9,
-                                      "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                      "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3),
-                                      "gat_kernels": gat_part,
-                                      "measured_in": f"{nprobe} instrumented warm-up step(s)",
-                                      "per_kernel_ms": {"_".join(str(x) for x in k): round(a, 5) for k, (a, _, _) in sorted(agg.items())}}
+                                      "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms else None,
+                                      "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if mp_ms else None,
+                                      "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3) if mp_ms else None,
+                                      "measured_in": f"{nprobe} fully instrumented warm-up step(s); GAT kernels: " + where,
+                                      "per_kernel_ms": {"_".join(str(x) for x in k): round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 5)
+                                                        for k in sorted(mp_keys)}}
+
+            # ---- the roofline object: fixed kernel per dtype ------------------------------------------------------
+            rkeys = [k for k in kt_all if k[0] in roof_names]
+            if rkeys:
+                r_ms = sum(per_step(k)[0] for k in rkeys)
+                r_n = sum(per_step(k)[1] for k in rkeys)
+                if bf16:
+                    r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
+                    ach = r_bytes / (r_ms * 1e-3) / 1e9
+                    tr = traffic_of(rkeys)
+                    out["roofline"] = {"bound": "hbm", "kernel": "spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 "
+                                       "(all launches of a step)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBPS, "traffic": tr,
+                                       "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
+                                       "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,
+                                       "avg_launch_ms": r_ms / r_n, "measured_in": where}
+                else:
+                    r_fl = sum(2.0 * k[1] * k[2] * k[3] * per_step(k)[1] for k in rkeys)
+                    ach = r_fl / (r_ms * 1e-3) / 1e12
+                    out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt (all launches of a step: forward projections and "
+                                       "input gradients)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
+                                       "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
+                                       "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys),
+                                       "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,
+                                       "avg_launch_ms": r_ms / r_n, "measured_in": where,
+                                       "note": "achieved = ALGORITHMIC flops (2MNK of the fp32 product) / time; the kernel executes "
+                                               "three fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi): "
+                                               "executed_mfma_frac = 3 x frac; against the native fp32 matrix pipe (157.3 TFLOP/s) "
+                                               "the same rate is frac_of_fp32_matrix_peak"}
+
+            # ---- composite roofline (SURVEY.md 8d / BASELINE.md 2): t_graph + max(t_gemm_bytes, t_gemm_flops) -----
+            t_graph = mp_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
+            t_gb = g_by / (HBM_PEAK_GBPS * 1e9) * 1e3
+            t_gf32 = g_fl / (FP32_MATRIX_PEAK * 1e12) * 1e3
+            t_gf16 = g_fl / (MFMA_F16_PEAK * 1e12) * 1e3
+            comp_hbm = t_graph + t_gb
+            comp_f32 = t_graph + max(t_gb, t_gf32)
+            comp_16 = t_graph + max(t_gb, t_gf16 * products)
+            out["composite"] = {"t_graph_ms": t_graph, "t_gemm_bytes_ms": t_gb, "t_gemm_flops_fp32_matrix_ms": t_gf32,
+                                "t_gemm_flops_16bit_mfma_ms": t_gf16 * products,
+                                "hbm_only_ms": comp_hbm, "fp32_matrix_ms": comp_f32, "as_executed_ms": comp_16,
+                                "step_vs_hbm_only": comp_hbm / ms, "step_vs_fp32_matrix": comp_f32 / ms, "step_vs_as_executed": comp_16 / ms,
+                                "layer_edges_per_s_at_hbm_only": E * L / (comp_hbm * 1e-3),
+                                "layer_edges_per_s_at_fp32_matrix": E * L / (comp_f32 * 1e-3),
+                                "note": "roofline step time = message-passing algorithmic bytes at 8 TB/s + max(GEMM algorithmic bytes at "
+                                        "8 TB/s, GEMM flops at the named matrix peak); 'as_executed' prices the flops at the 2.5 PFLOP/s "
+                                        f"16-bit MFMA peak times the {products} product(s) this precision executes per algorithmic product; "
+                                        "step_vs_* = that time / the measured ms_per_step"}
         if capture_error:
             out["config"]["capture_error"] = capture_error
         if eager_leg:

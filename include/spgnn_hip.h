@@ -444,6 +444,21 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
                                  int32_t* diameters, int64_t num_trees, int64_t max_tree_nodes, spgnn_stream_t stream);
 
 /*
+ * Anchor selection of the distance positional encoding, one batch per call (reference job_runner.py:1727-1757
+ * get_anchors_from_cnn_prediction, 1712-1725 add_distal_leafs).  prob: (num_nodes, >= num_labels + 1)
+ * softmax of the CNN logits.  Per tree, anchors[t, l-1] = argmax_i prob[i, l] over the nodes not yet taken (first
+ * maximum), l = 1 .. num_labels; then anchors[t, num_labels + k] = the farthest descendant leaf of anchor k in the
+ * downstream DAG (edges u -> v, v > u), k < num_distal, ties resolved as the reference's Python does (last leaf in
+ * the iteration order of the set nx.descendants returns: CPython's small-int set is replayed).  anchors:
+ * (num_trees, num_labels + num_distal) int32 GLOBAL node ids - the input of spgnn_tree_distance_encoding.
+ * Every tree needs at least num_labels nodes (caller checks).  workspace: spgnn_tree_anchors_workspace() bytes.
+ */
+int64_t spgnn_tree_anchors_workspace(int64_t num_trees, int32_t num_distal, int64_t max_tree_nodes);
+int spgnn_tree_anchors(const float* prob, int64_t prob_stride, const int32_t* out_indptr, const int32_t* out_indices,
+                       const int64_t* tree_ptr, int64_t num_trees, int64_t num_nodes, int64_t max_tree_nodes,
+                       int32_t num_labels, int32_t num_distal, int32_t* anchors, void* workspace, spgnn_stream_t stream);
+
+/*
  * Masked, class-weighted cross entropy of the training step in one pass (reference job_runner.py:1896-1900:
  * `mask = rn < sampling_t`, `F.cross_entropy(pre[mask], y[mask], weight=w)`):
  *   partials[2b], partials[2b+1] = per-256-node-block sums of  m_i w[y_i] nll_i  and  m_i w[y_i]   (b < ceil(N/256))

@@ -84,6 +84,13 @@ def anchors_from_cnn_prediction(fvs_out, adj_np, pos_enc_dim=39):
     x = np.asarray(fvs_out, dtype=np.float32)
     z = x - x.max(axis=1, keepdims=True)
     p = np.exp(z); p = p / p.sum(axis=1, keepdims=True)
+    return anchors_from_probabilities(p, adj_np, pos_enc_dim)
+
+
+def anchors_from_probabilities(p, adj_np, pos_enc_dim=39):
+    """reference job_runner.py:1727-1757 from the softmax onwards (the reference forms ``F.softmax(fvs_out)`` with torch
+    on its device and continues on the host with exactly these lines)."""
+    p = np.asarray(p)
     mask = np.ones(p.shape[0]) * 1.0
     anchors = []
     for label in range(1, 22):

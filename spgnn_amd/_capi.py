@@ -72,6 +72,8 @@ SIGNATURES = {
     "spgnn_weight_cat_partials": [_i32, _i32, _i64, _i64],
     "spgnn_tree_distance_encoding": [_i32p, _i32p, _vp, _i32p, _i32, _f32p, _i64, _i32p, _i64, _i64, _vp],
     "spgnn_sgd_momentum_step": [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
+    "spgnn_tree_anchors_workspace": [_i64, _i32, _i64],
+    "spgnn_tree_anchors": [_f32p, _i64, _i32p, _i32p, _vp, _i64, _i64, _i64, _i32, _i32, _i32p, _vp, _vp],
     # bf16-storage path
     "spgnn_gat_fwd_bf16": [_i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _vp, _i64, _f32p, _vp, _i64, _f32p, _i64,
                            _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
@@ -111,7 +113,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials") else C.c_int
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials", "spgnn_tree_anchors_workspace") else C.c_int
     ver = lib.spgnn_abi_version()
     if ver != ABI_VERSION:
         raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")

@@ -1,0 +1,74 @@
+"""Checkpoint save / filtered reload with the reference's file layout and reload rule.
+
+Reference: ``JobRunner.save_model`` / ``update_model_state`` (job_runner.py:333-350) write one ``torch.save`` dict
+``{iteration, epoch_n, model_dict, optimizer_dict, scheduler_dict, metric[, amp]}``; ``load_pretrained_model``
+(job_runner.py:85-123) reloads the objects named in ``RELOAD_DICT_LIST`` and, for everything but "metric", keeps only
+entries whose KEY exists in the live object's state_dict and whose tensor SIZE matches it (silently skipping the rest),
+then ``load_state_dict``s the merged dict.  The layers in :mod:`spgnn_amd.nn` carry DGL's state_dict keys, so a GNN
+checkpoint written by the reference (DGL 0.6: GATConv without ``bias``; DGL >= 0.7: with it) loads through this rule.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+__all__ = ["filter_state", "reload_state", "load_pretrained_model", "make_states", "save_states"]
+
+log = logging.getLogger(__name__)
+
+
+def filter_state(current: Dict[str, torch.Tensor], saved: Dict[str, torch.Tensor], ignored_keys: Iterable[str] = ()) -> Dict:
+    """Entries of ``saved`` that may overwrite ``current``: known key, not ignored, same tensor size."""
+    ignored = set(ignored_keys)
+    kept = {}
+    for k, v in saved.items():
+        if k not in current:
+            continue
+        if k in ignored:
+            log.info("ignore key: %s", k)
+            continue
+        cv = current[k]
+        if isinstance(cv, torch.Tensor) and torch.is_tensor(v) and v.size() != cv.size():
+            log.info("in %s, saved tensor size %s does not match current tensor size %s", k, tuple(v.size()), tuple(cv.size()))
+            continue
+        kept[k] = v
+    return kept
+
+
+def reload_state(obj, saved: Dict, overwrite: bool = False, ignored_keys: Iterable[str] = ()) -> List[str]:
+    """Merge ``saved`` into ``obj.state_dict()`` (filtered unless ``overwrite``) and load it; returns the keys taken."""
+    current = obj.state_dict()
+    matched = dict(saved) if overwrite else filter_state(current, saved, ignored_keys)
+    current.update(matched)
+    obj.load_state_dict(current)
+    return sorted(matched)
+
+
+def load_pretrained_model(cpk_path, reload_objects: Sequence, state_keys: Sequence[str], ignored_keys: Iterable[str] = (),
+                          device: str = "cuda") -> Dict:
+    """Same contract as the reference function of this name: ``reload_objects[n]`` is restored from
+    ``saved_states[state_keys[n]]`` when that key exists ("metric" is taken as it is, everything else filtered)."""
+    saved_states = torch.load(cpk_path, map_location="cpu" if device == "cpu" else None, weights_only=False)
+    for obj, key in zip(reload_objects, state_keys):
+        if key in saved_states:
+            reload_state(obj, saved_states[key], overwrite=(key == "metric"), ignored_keys=ignored_keys)
+    return saved_states
+
+
+def make_states(model, optimizer=None, scheduler=None, metric=None, iteration: int = 0, epoch_n: int = 0, **extra) -> Dict:
+    """The dict ``update_model_state`` builds (job_runner.py:333-343)."""
+    states = {"iteration": iteration, "epoch_n": epoch_n, "model_dict": model.state_dict()}
+    if optimizer is not None:
+        states["optimizer_dict"] = optimizer.state_dict()
+    if scheduler is not None:
+        states["scheduler_dict"] = scheduler.state_dict()
+    if metric is not None:
+        states["metric"] = metric.state_dict()
+    states.update(extra)
+    return states
+
+
+def save_states(path, states: Dict) -> None:
+    torch.save(states, path)

@@ -2049,6 +2049,113 @@ __global__ __launch_bounds__(256) void tree_distance_encoding(const int32_t* __r
 }
 
 // =================================================================================================
+// Anchor selection of the distance positional encoding on the device (reference
+// job_runner.py:1727-1757 get_anchors_from_cnn_prediction and 1712-1725 add_distal_leafs), one batch per call.
+//
+// (1) greedy_anchors: per tree, for label = 1 .. num_labels: index = argmax_i prob[i, label] * mask[i] (first
+//     occurrence of the maximum, as numpy.argmax), then mask[index] = 0.  One wave per tree; `prob` is the softmax
+//     of the CNN logits (the reference forms it with torch on the device too, job_runner.py:1730).
+// (2) distal_leafs: for each of the first num_distal anchors, its farthest descendant leaf in the "downstream" DAG
+//     (edges u -> v with v > u: numpy.triu of the adjacency), the anchor itself when it has no child.  The reference
+//     picks `sorted(leafs.items(), key=distance)[-1]` where `leafs` is a dict filled while iterating the Python SET
+//     nx.descendants() returns: among leaves at the maximal distance the winner is the LAST one in that set's
+//     iteration order, i.e. in hash-table slot order.  To return the same node, the kernel replays CPython's set of
+//     small ints exactly (Objects/setobject.c: hash(i) = i, 8 initial slots, linear probes of 9 then
+//     i = 5 i + 1 + perturb, growth to the next power of two above 4 * used when fill * 5 >= mask * 3, re-insertion in
+//     slot order) with the descendants inserted in BFS discovery order (children ascending), as networkx builds it.
+//     One thread per (tree, anchor); the table, the BFS queue and the distances live in a caller-provided workspace.
+// =================================================================================================
+__global__ __launch_bounds__(64) void greedy_anchors_kernel(const float* __restrict__ prob, int64_t ld, const int64_t* __restrict__ tree_ptr,
+                                                            int32_t* __restrict__ anchors, int A, int num_labels,
+                                                            uint8_t* __restrict__ taken) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int64_t base = tree_ptr[t];
+  const int n = (int)(tree_ptr[t + 1] - base);
+  for (int i = lane; i < n; i += 64) taken[base + i] = 0;
+  __syncthreads();
+  for (int label = 1; label <= num_labels; ++label) {
+    double best = -1.0; int arg = 0x7FFFFFFF;
+    for (int i = lane; i < n; i += 64) {
+      const double v = taken[base + i] ? 0.0 : (double)prob[(base + i) * ld + label];
+      if (v > best) { best = v; arg = i; }                     // ascending i within a lane: first occurrence kept
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64); const int oa = __shfl_xor(arg, off, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) { anchors[(int64_t)t * A + (label - 1)] = (int32_t)(base + arg); taken[base + arg] = 1; }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void pyset_insert_clean(uint16_t* table, unsigned mask, unsigned key) {
+  unsigned perturb = key, i = key & mask;
+  while (true) {
+    if (table[i] == 0xFFFFu) { table[i] = (uint16_t)key; return; }
+    if (i + 9 <= mask) {
+      for (unsigned j = 1; j <= 9; ++j)
+        if (table[i + j] == 0xFFFFu) { table[i + j] = (uint16_t)key; return; }
+    }
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & mask;
+  }
+}
+
+__global__ __launch_bounds__(64) void distal_leafs_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          const int64_t* __restrict__ tree_ptr, int32_t* __restrict__ anchors,
+                                                          int A, int first_extra, int num_distal, int64_t num_trees,
+                                                          uint16_t* __restrict__ ws, int64_t ws_per_thread, int n_cap) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= num_trees * num_distal) return;
+  const int64_t t = tid / num_distal; const int k = (int)(tid % num_distal);
+  const int64_t base = tree_ptr[t];
+  const int n = (int)(tree_ptr[t + 1] - base);
+  uint16_t* dist = ws + tid * ws_per_thread;          // [n_cap] hop distance from the anchor (0xFFFF: not reached)
+  uint16_t* queue = dist + n_cap;                     // [n_cap] BFS queue = discovery order
+  uint16_t* tab_a = queue + n_cap;                    // [8 n_cap] the emulated set's table ...
+  uint16_t* tab_b = tab_a + 8 * n_cap;                // [8 n_cap] ... and the one it is rebuilt into on growth
+  const int a = (int)(anchors[t * A + k] - base);
+  for (int i = 0; i < n; ++i) dist[i] = 0xFFFFu;
+  unsigned mask = 7, fill = 0;
+  uint16_t* table = tab_a;
+  for (unsigned i = 0; i <= mask; ++i) table[i] = 0xFFFFu;
+  int head = 0, tail = 0;
+  dist[a] = 0; queue[tail++] = (uint16_t)a;
+  while (head < tail) {
+    const int p = queue[head++];
+    const int64_t gp = base + p;
+    for (int j = indptr[gp]; j < indptr[gp + 1]; ++j) {        // out-neighbours ascending; children = those with a larger id
+      const int c = (int)(indices[j] - base);
+      if (c <= p || dist[c] != 0xFFFFu) continue;
+      dist[c] = (uint16_t)(dist[p] + 1);
+      queue[tail++] = (uint16_t)c;
+      pyset_insert_clean(table, mask, (unsigned)c);            // a new key: set_add_entry takes the same probe sequence
+      ++fill;
+      if (fill * 5 >= mask * 3) {                              // set_table_resize(used * 4): next power of two above it
+        unsigned newsize = 8;
+        while (newsize <= fill * 4) newsize <<= 1;
+        uint16_t* nt = table == tab_a ? tab_b : tab_a;
+        for (unsigned i = 0; i < newsize; ++i) nt[i] = 0xFFFFu;
+        for (unsigned i = 0; i <= mask; ++i)
+          if (table[i] != 0xFFFFu) pyset_insert_clean(nt, newsize - 1, table[i]);
+        table = nt; mask = newsize - 1;
+      }
+    }
+  }
+  int best = a, best_d = -1;
+  for (unsigned i = 0; i <= mask; ++i) {                       // set iteration = slot order; stable sort by distance, last wins
+    const unsigned c = table[i];
+    if (c == 0xFFFFu) continue;
+    const int64_t gc = base + c;
+    bool leaf = true;
+    for (int j = indptr[gc]; j < indptr[gc + 1]; ++j)
+      if (indices[j] - base > (int64_t)c) { leaf = false; break; }
+    if (leaf && (int)dist[c] >= best_d) { best_d = dist[c]; best = (int)c; }
+  }
+  anchors[t * A + first_extra + k] = (int32_t)(base + best);
+}
+
+// =================================================================================================
 // Masked, class-weighted cross entropy in one pass (reference job_runner.py:1896-1900:
 // mask = rn < sampling_t; loss = F.cross_entropy(pre[mask], y[mask], weight=w)).  One thread per node:
 //   m_i = draws[i] < sampling_p[i];  nll_i = logsumexp(logits[i,:]) - logits[i, y_i]
@@ -2065,9 +2172,11 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
   float num = 0.f, den = 0.f;
   if (i < N) {
     const float* row = logits + i * ld;
-    const int y = (int)labels[i];
+    const int64_t yl = labels[i];
+    const bool y_ok = yl >= 0 && yl < C;                     // F.cross_entropy raises for such a label; here the node gets a
+    const int y = y_ok ? (int)yl : 0;                        // NaN weight, so the loss is NaN instead of an out-of-bounds read
     const float m = draws[i] < sampling_p[i] ? 1.f : 0.f;
-    const float w = m * class_w[y];
+    const float w = y_ok ? m * class_w[y] : NAN;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
     float se = 0.f;
@@ -2868,6 +2977,35 @@ int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_i
   hipLaunchKernelGGL(tree_distance_encoding, dim3((unsigned)num_trees), dim3(256), 0, (hipStream_t)stream, out_indptr,
                      out_indices, tree_ptr, anchors, num_anchors, pos_enc, pos_enc_stride, diameters);
   return check_launch("spgnn_tree_distance_encoding");
+}
+
+int64_t spgnn_tree_anchors_workspace(int64_t num_trees, int32_t num_distal, int64_t max_tree_nodes) {
+  return num_trees * (int64_t)num_distal * 18 * max_tree_nodes * (int64_t)sizeof(uint16_t) + num_trees * max_tree_nodes;
+}
+
+int spgnn_tree_anchors(const float* prob, int64_t prob_stride, const int32_t* out_indptr, const int32_t* out_indices,
+                       const int64_t* tree_ptr, int64_t num_trees, int64_t num_nodes, int64_t max_tree_nodes, int32_t num_labels,
+                       int32_t num_distal, int32_t* anchors, void* workspace, spgnn_stream_t stream) {
+  if (num_trees < 0 || num_nodes < 0 || num_labels <= 0 || num_distal < 0 || num_distal > num_labels || max_tree_nodes < 0 ||
+      max_tree_nodes >= 65535)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_tree_anchors: bad sizes (trees of at most 65534 nodes, num_distal <= num_labels)");
+  if (num_trees == 0) return SPGNN_OK;
+  if (!prob || !out_indptr || !out_indices || !tree_ptr || !anchors || !workspace)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_tree_anchors: null pointer");
+  if (prob_stride <= num_labels) return fail(SPGNN_ERR_STRIDE, "spgnn_tree_anchors: prob needs num_labels + 1 columns");
+  hipStream_t st = (hipStream_t)stream;
+  const int A = num_labels + num_distal;
+  uint16_t* ws = reinterpret_cast<uint16_t*>(workspace);
+  const int64_t per_thread = 18 * max_tree_nodes;
+  uint8_t* taken = reinterpret_cast<uint8_t*>(ws + num_trees * (int64_t)num_distal * per_thread);
+  hipLaunchKernelGGL(greedy_anchors_kernel, dim3((unsigned)num_trees), dim3(64), 0, st, prob, prob_stride, tree_ptr, anchors, A,
+                     num_labels, taken);
+  if (num_distal > 0) {
+    const int64_t threads = num_trees * num_distal;
+    hipLaunchKernelGGL(distal_leafs_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, out_indptr, out_indices, tree_ptr,
+                       anchors, A, num_labels, num_distal, num_trees, ws, per_thread, (int)max_tree_nodes);
+  }
+  return check_launch("spgnn_tree_anchors");
 }
 
 int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import graph as G
-from .posenc import anchors_from_cnn_prediction, distance_pos_enc, distance_pos_enc_device
+from .posenc import anchors_device, anchors_from_cnn_prediction, distance_pos_enc, distance_pos_enc_device
 
 __all__ = ["ConvEmbeddingDataset", "collate_native", "assemble_batch", "write_embedding"]
 
@@ -93,7 +93,7 @@ def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: O
     fv_dim = int(np.asarray(samples[0]["fvs"]).shape[1]); n_cls = int(np.asarray(samples[0]["fvs_out"]).shape[1])
     fvs_h, out_h, y_h = _pinned((N, fv_dim), torch.float32, pin), _pinned((N, n_cls), torch.float32, pin), _pinned((N,), torch.int64, pin)
     fvs_np, out_np, y_np = fvs_h.numpy(), out_h.numpy(), y_h.numpy()
-    srcs, dsts, anchors, pes, off = [], [], [], [], 0
+    srcs, dsts, pes, off = [], [], [], 0
     for s, n in zip(samples, ns):
         adj = np.asarray(s["adj"])
         fvs_np[off:off + n] = s["fvs"]                       # float64 -> float32 while filling the pinned buffer
@@ -101,11 +101,9 @@ def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: O
         y_np[off:off + n] = s["labels"]
         u, v = G.edges_from_adj(adj, add_self_loops=True)
         srcs.append(u + off); dsts.append(v + off)
-        if pos_enc_dim:
+        if pos_enc_dim and not on_gpu:                       # host path (CPU graphs): per-tree anchors + BFS in Python
             anc = anchors_from_cnn_prediction(np.asarray(s["fvs_out"], dtype=np.float32), adj, pos_enc_dim)
-            anchors.append(anc)
-            if not on_gpu:
-                pes.append(distance_pos_enc(adj, anc)[0])
+            pes.append(distance_pos_enc(adj, anc)[0])
         off += n
     g = G.TreeGraph((np.concatenate(srcs), np.concatenate(dsts)), N, dev)
     g.batch_num_nodes_list = ns
@@ -115,8 +113,8 @@ def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: O
     g.ndata["y"] = y_h.to(dev, non_blocking=True)
     g.csc(dev)
     if pos_enc_dim:
-        if on_gpu:
-            pe, _ = distance_pos_enc_device(g, anchors)
+        if on_gpu:                                           # anchors and distances for the whole batch on the device:
+            pe, _ = distance_pos_enc_device(g, anchors_device(g, g.ndata["fvs_out"], pos_enc_dim))   # two HIP calls, no per-tree BFS
         else:
             pe = torch.from_numpy(np.concatenate(pes))
         g.ndata["pos_enc"] = pe

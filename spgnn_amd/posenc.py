@@ -13,7 +13,7 @@ from typing import List, Tuple
 import numpy as np
 
 __all__ = ["anchors_from_cnn_prediction", "add_distal_leafs", "distance_pos_enc", "bfs_distances",
-           "distance_pos_enc_device"]
+           "distance_pos_enc_device", "anchors_device"]
 
 
 def _softmax(x: np.ndarray) -> np.ndarray:
@@ -116,10 +116,43 @@ def distance_pos_enc(adj: np.ndarray, anchors) -> Tuple[np.ndarray, int]:
     return (d / float(diameter)).astype(np.float32), diameter
 
 
+def anchors_device(g, fvs_out, pos_enc_dim: int = 39):
+    """Device version of :func:`anchors_from_cnn_prediction` for a whole batched graph (reference job_runner.py:1727-1757,
+    1712-1725): softmax of the CNN logits (torch, on the device, as the reference forms it), then one HIP call for the
+    greedy per-label argmax and the distal leaves of every tree (spgnn_tree_anchors).  Returns (B, A) int32 GLOBAL node
+    ids on the device - what :func:`distance_pos_enc_device` takes.  No per-tree host work."""
+    import torch
+    from . import _capi
+    if pos_enc_dim not in (39, 21):
+        raise NotImplementedError(f"pos enc dim : {pos_enc_dim}!")
+    csc = g.csc()
+    dev = csc.indptr.device
+    if dev.type != "cuda":
+        raise RuntimeError("anchors_device needs the graph on a ROCm device (use anchors_from_cnn_prediction on the host)")
+    nn = np.asarray(g.batch_num_nodes_list, dtype=np.int64)
+    if len(nn) and nn.min() < 21:
+        raise ValueError("anchor rule needs at least 21 nodes per tree")
+    B = len(nn)
+    num_labels, num_distal = 21, (18 if pos_enc_dim == 39 else 0)
+    tree_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(nn)])).to(dev)
+    prob = torch.softmax(fvs_out.to(device=dev, dtype=torch.float32), dim=1).contiguous()
+    anchors = torch.empty((B, num_labels + num_distal), dtype=torch.int32, device=dev)
+    lib = _capi.load()
+    nmax = int(nn.max()) if B else 0
+    ws = torch.empty((int(lib.spgnn_tree_anchors_workspace(B, num_distal, nmax)),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(lib.spgnn_tree_anchors(prob.data_ptr(), prob.stride(0), csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                           tree_ptr.data_ptr(), B, int(nn.sum()), nmax, num_labels, num_distal,
+                                           anchors.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                    "spgnn_tree_anchors")
+    return anchors
+
+
 def distance_pos_enc_device(g, anchors_per_tree):
     """Device version of :func:`distance_pos_enc` for a whole batched graph.
 
-    ``g``: batched TreeGraph on a ROCm device; ``anchors_per_tree``: list (one per tree) of LOCAL anchor ids.
+    ``g``: batched TreeGraph on a ROCm device; ``anchors_per_tree``: list (one per tree) of LOCAL anchor ids, or the
+    (B, A) int32 device tensor of GLOBAL ids :func:`anchors_device` returns.
     Returns ``(pos_enc (N, A) float32 on the device, diameters (B,) int32)``; bit-identical to the host/networkx
     path.  One HIP workgroup per tree, BFS distance arrays in LDS (spgnn_tree_distance_encoding)."""
     import torch
@@ -129,11 +162,16 @@ def distance_pos_enc_device(g, anchors_per_tree):
     if dev.type != "cuda":
         raise RuntimeError("distance_pos_enc_device needs the graph on a ROCm device (use distance_pos_enc on the host)")
     nn = np.asarray(g.batch_num_nodes_list, dtype=np.int64)
-    B, A = len(nn), len(anchors_per_tree[0])
     tree_ptr = np.concatenate([[0], np.cumsum(nn)])
-    anc = np.asarray(anchors_per_tree, dtype=np.int64).reshape(B, A) + tree_ptr[:-1, None]
     tree_ptr_d = torch.from_numpy(tree_ptr).to(dev)
-    anc_d = torch.from_numpy(anc.astype(np.int32)).to(dev)
+    if torch.is_tensor(anchors_per_tree):
+        anc_d = anchors_per_tree.to(device=dev, dtype=torch.int32).contiguous()
+        B, A = anc_d.shape
+        assert B == len(nn)
+    else:
+        B, A = len(nn), len(anchors_per_tree[0])
+        anc = np.asarray(anchors_per_tree, dtype=np.int64).reshape(B, A) + tree_ptr[:-1, None]
+        anc_d = torch.from_numpy(anc.astype(np.int32)).to(dev)
     # rows padded to 16 bytes (39 -> stride 40) so the encoding feeds the vector/MFMA kernels without a copy
     pe = torch.zeros((int(tree_ptr[-1]), (A + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :A]
     diam = torch.empty((B,), dtype=torch.int32, device=dev)

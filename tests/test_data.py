@@ -41,15 +41,101 @@ def test_assemble_batch_on_cpu_matches_generator(tmp_path):
         assert torch.equal(g.ndata[k], ref.ndata[k]), k
 
 
+def _write_reference_state(tmp_path, samples, uids):
+    """Pickles with the reference's exact ``save_state`` dict (job_runner.py:796-805): float64 fvs / fvs_out, uint8 adj /
+    labels, plus the keys the GNN stage never reads (ref, all_airway, branch_info, meta)."""
+    import pickle
+    d = tmp_path / "derived" / "conv_embedding"
+    d.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(0)
+    for uid, s in zip(uids, samples):
+        n = s["adj"].shape[0]
+        state = {"fvs": s["fvs"].astype(np.float64), "adj": s["adj"].astype(np.uint8), "labels": s["labels"].astype(np.uint8),
+                 "fvs_out": s["fvs_out"].astype(np.float64), "ref": rng.integers(0, 2, (4, 4, 4)).astype(np.uint8),
+                 "all_airway": rng.integers(0, n, (4, 4, 4)).astype(np.int16),
+                 "branch_info": {i: {"len": float(i)} for i in range(n)}, "meta": {"uid": [uid], "spacing": [np.ones(3)]}}
+        with open(d / f"{uid}.pkl", "wb") as fp:
+            pickle.dump(state, fp)
+
+
 @pytest.mark.gpu
-def test_assemble_batch_on_gpu_matches_host_path(tmp_path):
-    samples, uids = _write(tmp_path, n=12)
+def test_assemble_batch_on_gpu_matches_networkx_oracle(tmp_path):
+    """SURVEY.md §8f-2 end to end on the device, checked against the ORACLE (real networkx driven as the reference drives
+    it: oracle/graph_rule_nx.py), not against this package's own host path: edge list and batching, CSC, node data,
+    anchors (device kernel) and the distance encoding (device kernel), all bit-exact."""
+    from oracle import graph_rule_nx as R
+    n_trees = 24
+    samples = synthetic.synthetic_trees(n_trees, rank=3, n_lo=21, n_hi=200)
+    uids = [f"1.2.840.{i}" for i in range(n_trees)]
+    _write_reference_state(tmp_path, samples, uids)
     ds = data.ConvEmbeddingDataset(str(tmp_path), uids)
-    g = data.assemble_batch([ds[i] for i in range(12)], device="cuda")
-    ref = synthetic.batch_from_samples(samples, "cpu", 39)
-    for k in ("fvs", "fvs_out", "y", "pos_enc"):
-        assert torch.equal(g.ndata[k].cpu(), ref.ndata[k]), k
-    csc, rcsc = g.csc(), ref.csc("cpu")
-    for name in ("indptr", "indices", "eid", "out_indptr", "out_indices", "out_pos"):
-        assert torch.equal(getattr(csc, name).cpu(), getattr(rcsc, name)), name
+    loader = torch.utils.data.DataLoader(ds, batch_size=n_trees, collate_fn=data.collate_native, num_workers=0)
+    g = data.assemble_batch(next(iter(loader)), device="cuda")
+    # graph rule + dgl.batch
+    edges = [R.edges_spgnn(s["adj"]) for s in samples]
+    ns = [s["adj"].shape[0] for s in samples]
+    src, dst = R.batch_edges(edges, ns)
+    assert np.array_equal(g._src, src) and np.array_equal(g._dst, dst)
+    indptr, indices, eid = R.csc_stable(src, dst, sum(ns))
+    csc = g.csc()
+    assert np.array_equal(csc.indptr.cpu().numpy(), indptr) and np.array_equal(csc.indices.cpu().numpy(), indices)
+    assert np.array_equal(csc.eid.cpu().numpy(), eid)
+    # node data: float64 -> float32 casts of the pickled arrays
+    assert torch.equal(g.ndata["fvs"].cpu(), torch.from_numpy(np.concatenate([s["fvs"] for s in samples]).astype(np.float32)))
+    assert torch.equal(g.ndata["fvs_out"].cpu(), torch.from_numpy(np.concatenate([s["fvs_out"] for s in samples]).astype(np.float32)))
+    assert torch.equal(g.ndata["y"].cpu(), torch.from_numpy(np.concatenate([s["labels"] for s in samples]).astype(np.int64)))
+    # anchors + distance encoding: the reference takes softmax(fvs_out) with torch on its device and continues on the host
+    prob = torch.softmax(g.ndata["fvs_out"], dim=1).cpu().numpy()
+    off, pes = 0, []
+    for s, n in zip(samples, ns):
+        anc = R.anchors_from_probabilities(prob[off:off + n], s["adj"], 39)
+        pes.append(R.distance_pos_enc(s["adj"], anc)[0])
+        off += n
+    assert torch.equal(g.ndata["pos_enc"].cpu(), torch.from_numpy(np.concatenate(pes)))
     assert g.ndata["pos_enc"].stride(0) % 4 == 0           # rows ready for the vector / MFMA kernels
+
+
+def _tree_from_parents(parent):
+    n = len(parent)
+    adj = np.eye(n, dtype=np.uint8)
+    c = np.arange(1, n)
+    adj[parent[1:], c] = 1; adj[c, parent[1:]] = 1
+    return adj
+
+
+@pytest.mark.gpu
+def test_device_anchor_selection_matches_networkx_oracle_including_ties():
+    """spgnn_tree_anchors vs the reference's own host code on real networkx + real Python sets, on trees built to tie:
+    complete binary / ternary trees (all leaves at one depth), brooms, paths, random trees up to 700 nodes (ids beyond
+    the emulated set's table mask, several table growths), with exactly tied probabilities for the greedy argmax too."""
+    from oracle import graph_rule_nx as R
+    from spgnn_amd import graph as G
+    from spgnn_amd.posenc import anchors_device
+    rng = np.random.default_rng(5)
+    adjs = []
+    for k in (2, 3):                                       # complete k-ary trees, breadth-first numbering
+        for n in (40, 121, 364, 700):
+            adjs.append(_tree_from_parents(np.array([-1] + [(i - 1) // k for i in range(1, n)])))
+    adjs.append(_tree_from_parents(np.array([-1] + list(range(0, 59)))))                       # a path
+    adjs.append(_tree_from_parents(np.array([-1] + list(range(0, 30)) + [30] * 40)))           # a broom: 40 tied leaves
+    for n in (21, 33, 150, 299, 511, 640):
+        adjs.append(synthetic.random_tree_adj(n, rng))
+    graphs, probs = [], []
+    for adj in adjs:
+        n = adj.shape[0]
+        lg = rng.standard_normal((n, 22)).astype(np.float32)
+        lg[rng.integers(0, n, 8)] = lg[rng.integers(0, n)]                                      # identical rows: exact argmax ties
+        g = G.graph_from_adj(adj, device="cpu", add_self_loops=True)
+        g.ndata["fvs_out"] = torch.from_numpy(lg)
+        graphs.append(g)
+    bg = G.batch(graphs).to("cuda")
+    anc = anchors_device(bg, bg.ndata["fvs_out"], 39).cpu().numpy()
+    prob = torch.softmax(bg.ndata["fvs_out"], dim=1).cpu().numpy()
+    off = 0
+    for t, adj in enumerate(adjs):
+        n = adj.shape[0]
+        ref = R.anchors_from_probabilities(prob[off:off + n], adj, 39)
+        assert (anc[t] - off).tolist() == [int(x) for x in ref], (t, n)
+        off += n
+    anc21 = anchors_device(bg, bg.ndata["fvs_out"], 21).cpu().numpy()
+    assert anc21.shape[1] == 21 and np.array_equal(anc21, anc[:, :21])

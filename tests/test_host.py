@@ -144,3 +144,46 @@ def test_data_parallel_step_equals_single_rank_step():
         assert np.allclose(ret[r][0], losses, rtol=1e-5)            # global class-weighted mean, not a mean of means
         assert torch.allclose(ret[r][1], flat, rtol=1e-5, atol=1e-7)
     assert torch.equal(ret[0][1], ret[1][1])                        # replicas stay identical
+
+
+def test_balanced_tree_partition_balances_node_counts():
+    """shard trees over ranks by node count.  4096 trees of U[120,180] nodes over 8 ranks (BASELINE config 5):
+    per-rank node sums within 1 % of each other; every tree exactly once; deterministic."""
+    from spgnn_amd.train import balanced_tree_partition
+    rng = np.random.default_rng(0)
+    for trees, world in ((4096, 8), (512, 4), (64, 2), (7, 3)):
+        n = rng.integers(120, 181, size=trees)
+        parts = balanced_tree_partition(n.tolist(), world)
+        assert sorted(i for p in parts for i in p) == list(range(trees))
+        assert all(p == sorted(p) for p in parts)
+        sums = np.array([n[p].sum() for p in parts])
+        if trees >= 64:
+            assert (sums.max() - sums.min()) / sums.mean() < 0.01, sums
+        assert parts == balanced_tree_partition(n.tolist(), world)
+    assert balanced_tree_partition([5, 5, 5], 5)[3:] == [[], []]
+    with pytest.raises(ValueError):
+        balanced_tree_partition([1], 0)
+
+
+def test_checkpoint_filter_follows_reference_rule(tmp_path):
+    """reference job_runner.py:85-123: keep a saved entry iff its key exists in the live state_dict, it is not ignored and
+    its tensor size matches; "metric" objects are overwritten as they are."""
+    from spgnn_amd import checkpoint
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    saved = {"0.weight": torch.ones(3, 4), "0.bias": torch.ones(5), "1.weight": torch.full((2, 3), 2.0), "9.weight": torch.ones(1)}
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    taken = checkpoint.reload_state(net, saved, ignored_keys=["1.weight"])
+    assert taken == ["0.weight"]
+    after = net.state_dict()
+    assert torch.equal(after["0.weight"], torch.ones(3, 4)) and torch.equal(after["0.bias"], before["0.bias"])
+    assert torch.equal(after["1.weight"], before["1.weight"])
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+    path = os.path.join(tmp_path, "3.pth")
+    checkpoint.save_states(path, checkpoint.make_states(net, opt, sched, iteration=3, epoch_n=1))
+    net2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    opt2 = torch.optim.SGD(net2.parameters(), lr=0.5, momentum=0.9)
+    sched2 = torch.optim.lr_scheduler.ExponentialLR(opt2, gamma=0.9)
+    states = checkpoint.load_pretrained_model(path, [net2, opt2, sched2], ["model_dict", "optimizer_dict", "scheduler_dict"], device="cpu")
+    assert states["iteration"] == 3 and states["epoch_n"] == 1
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
