@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 23
+#define SPGNN_ABI_VERSION 24
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -350,23 +350,15 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
                            const float* other_head, int64_t other_head_stride, float* mean_out, int64_t mean_out_stride,
                            spgnn_stream_t stream);
 
-/*
- * Split-form ("planes") operands for the projection GEMMs.  spgnn_split_rows writes, once per tensor,
- *   hi = fp16(s x), lo = fp16(s x - hi),   s = *scale * extra_factor  (scale nullable = 1)
- * as two row-major fp16 matrices (Mp x Kp, zero padded; Kp % 32 == 0, plane_stride % 8 == 0, 16-byte aligned bases)
- * with the same round-toward-zero split the fp32-operand kernels apply on the fly, so both GEMM forms agree
- * bit for bit.  spgnn_gemm_nt_planes is spgnn_gemm_nt on such operands (same epilogue options; scale_a / scale_b
- * are the scales the planes were written with): tiles go global -> LDS by DMA, no per-tile conversion.
- * Replaces the same reference Linear projections as spgnn_gemm_nt (models.py:301-314).
- */
-int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
-                     uint16_t* hi, uint16_t* lo, int64_t plane_stride, int64_t Mp, int64_t Kp, spgnn_stream_t stream);
-int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
-                         const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
-                         float* C, int64_t ldc, int64_t M, int64_t N, int64_t Kp,
-                         const float* scale_a, const float* scale_b,
-                         const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
-                         const float* bias, int32_t activation, spgnn_stream_t stream);
+/* spgnn_gemm_nt with the block tile pinned: tile = 0 chosen from the shape (= spgnn_gemm_nt), 2 = 128 x 128,
+ * 4 = 256 x 128, 5 = 256 x 256 (operand extents below 2^31 bytes).  Every tile shape performs the same arithmetic in the
+ * same order per output element, so the results are bit-identical; a caller that knows its shapes can skip the heuristic. */
+int spgnn_gemm_nt_tile(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                       int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
+                       const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
+                       const float* bias, int32_t activation,
+                       const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                       int32_t tile, spgnn_stream_t stream);
 
 /* out[i] = sum over s < splits of partials[s * split_stride + i], i < n (n % 4 == 0, 16-byte aligned): the deterministic
  * reduction of the split-K partial tiles of spgnn_gemm_tn and spgnn_scores_bwd_w (fixed summation order). */
@@ -404,12 +396,6 @@ int64_t spgnn_weight_cat_partials(int32_t rows, int32_t K, int64_t dst_stride, i
 int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, float* scale,
                               uint32_t* workspace /* nullable; 2 words, zeroed ONCE by the caller, self-resetting */,
                               spgnn_stream_t stream);
-
-/* Kernel generation used by spgnn_gemm_nt: 1 = reference kernel, 2 = pipelined kernels, tile shape chosen per product
- * (default: 128 x 128, 256 x 128 or 256 x 256 tiles), 3 = 128 x 128 tiles only, 4 = 256 x 128 tiles only,
- * 5 = 256 x 256 tiles only (needs operand extents below 2^31 bytes, otherwise as 2).  All give bit-identical results
- * except 1.  Returns the previous setting.  For A/B measurements and tests. */
-int spgnn_gemm_set_variant(int32_t variant);
 
 /*
  * Weight-gradient form: C[M,N] = A[R,M]^T * B[R,N] with the reduction over the R rows (nodes) of both

@@ -11,8 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SPGNN_AMD_LIB") or os.path.join(_HERE, "libspgnn_hip.so")   # env override: kernel A/B builds
-ABI_VERSION = 23
+LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
+ABI_VERSION = 24
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -38,6 +38,8 @@ SIGNATURES = {
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
                       _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
+    "spgnn_gemm_nt_tile": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
+                           _f32p, _i32, _f32p, _f32p, _f32p, _i32, _i32, _vp],
     "spgnn_gemm_nt_headmean": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64,
                                _f32p, _i64, _vp],
     "spgnn_gat_agg_supported": [_i32, _i32],
@@ -49,9 +51,6 @@ SIGNATURES = {
                               _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_fold_scores_fwd": [_f32p, _i64, _f32p, _f32p, _f32p, _i32, _i32, _i32, _i32, _vp],
     "spgnn_fold_scores_bwd": [_f32p, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _f32p, _f32p, _i32, _i32, _i32, _vp],
-    "spgnn_split_rows": [_f32p, _i64, _i64, _i64, _f32p, _f32, _vp, _vp, _i64, _i64, _i64, _vp],
-    "spgnn_gemm_nt_planes": [_vp, _vp, _i64, _vp, _vp, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p,
-                             _i64, _i32, _f32p, _i32, _vp],
     "spgnn_cat_dropout": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _f32p, _vp],
     "spgnn_cat_dropout_blocks": [_i64, _i32],
     "spgnn_scores_from_parts": [_f32p, _f32p, _i64, _i64, _i32, _i32, _vp],
@@ -62,7 +61,6 @@ SIGNATURES = {
     "spgnn_act_bwd_proj": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
     "spgnn_act_bwd_proj_blocks": [_i64],
     "spgnn_act_bwd": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
-    "spgnn_gemm_set_variant": [_i32],
     "spgnn_gemm_tn": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _vp],
     "spgnn_pow2_scale": [_f32p, _i64, _i64, _i64, _f32p, _f32p, _i32, _vp],
     "spgnn_sum_partials": [_f32p, _i64, _i32, _i64, _f32p, _vp],

@@ -55,133 +55,6 @@ struct Args {
   const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
 };
 
-__device__ __forceinline__ void split4(float4 v, float s, half4& hi, half4& lo) {
-  const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-  hi = half4{(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
-  lo = half4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]),
-             (_Float16)(x3 - (float)hi[3])};
-}
-
-// one 128 x 32 fp32 tile = 1024 float4; thread t loads float4 #(t + 256 i), i = 0..3: row = idx / 8, k4 = idx % 8
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K,
-                                          float4 (&r)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + kThreads * i;
-    const int row = row0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-      const float* p = base + (int64_t)row * ld + k;
-      if (k + 3 < K) v = *reinterpret_cast<const float4*>(p);
-      else {
-        if (k < K) v.x = p[0];
-        if (k + 1 < K) v.y = p[1];
-        if (k + 2 < K) v.z = p[2];
-      }
-    }
-    r[i] = v;
-  }
-}
-
-__device__ __forceinline__ void store_tile(_Float16* hi_img, _Float16* lo_img, const float4 (&r)[4], float s) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + kThreads * i;
-    const int off = (idx >> 3) * PITCH + (idx & 7) * 4;
-    half4 h, l;
-    split4(r[i], s, h, l);
-    *reinterpret_cast<half4*>(hi_img + off) = h;
-    *reinterpret_cast<half4*>(lo_img + off) = l;
-  }
-}
-
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_f16x3(Args a) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[4 * TILE_HALVES];   // Ah | Al | Bh | Bl  (40 KB)
-  _Float16* Ah = lds;
-  _Float16* Al = lds + TILE_HALVES;
-  _Float16* Bh = lds + 2 * TILE_HALVES;
-  _Float16* Bl = lds + 3 * TILE_HALVES;
-
-  // XCD-aware tile order: blocks that share an XCD (b % 8) walk consecutive tiles; tiles are numbered with
-  // the n-block fastest, so the A row panel of a tile row stays in that XCD's L2 for all its column tiles.
-  const unsigned nb = gridDim.x, b = blockIdx.x;
-  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
-  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
-  const int bm = tile / a.nbn, bn = tile % a.nbn;
-  const int row0 = bm * BM, col0 = bn * BN;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, 64 x 64 each
-  const int fr = lane & 31, fh = lane >> 5;                // fragment row / k-half
-
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  float4 ra[4], rb[4];
-  load_tile(a.A, a.lda, row0, a.M, 0, a.K, ra);
-  load_tile(a.B, a.ldb, col0, a.N, 0, a.K, rb);
-  // row index inside load_tile is absolute; make store offsets tile-relative by construction (row0 folded below)
-
-  const int nk = (a.K + BK - 1) / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();                                       // previous stage's fragment reads are done
-    store_tile(Ah, Al, ra, sA);
-    store_tile(Bh, Bl, rb, sB);
-    __syncthreads();
-    if (kt + 1 < nk) {                                     // next stage in flight while this one computes
-      load_tile(a.A, a.lda, row0, a.M, (kt + 1) * BK, a.K, ra);
-      load_tile(a.B, a.ldb, col0, a.N, (kt + 1) * BK, a.K, rb);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int off = (wm * 64 + i * 32 + fr) * PITCH + ks * 16 + fh * 8;
-        ah[i] = *reinterpret_cast<const half8*>(Ah + off);
-        al[i] = *reinterpret_cast<const half8*>(Al + off);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int off = (wn * 64 + j * 32 + fr) * PITCH + ks * 16 + fh * 8;
-        bh[j] = *reinterpret_cast<const half8*>(Bh + off);
-        bl[j] = *reinterpret_cast<const half8*>(Bl + off);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  }
-
-  // epilogue: C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float alpha = 1.f / (sA * sB);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = col0 + wn * 64 + j * 32 + fr;
-      if (col >= a.N) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[i][j][e] * alpha;
-      }
-    }
-}
-
-
 // -------------------------------------------------------------------------------------------------
 // NT kernel, second generation: (64*WM) x 128 block tile, 2*WM waves, double-buffered LDS, ONE barrier per
 // stage, and the fp32 -> fp16 hi/lo conversion of stage t+1 issued between the MFMAs of stage t (an MFMA
@@ -194,14 +67,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_f16x3(Args a) {
 // -------------------------------------------------------------------------------------------------
 typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
 
-// same ELU as spgnn_kernels.hip (expm1 for x <= 0: degree-9 Taylor on [-0.5, 0], exp(x) - 1 below; 2 ulp of expm1f)
-__device__ __forceinline__ float elu_fwd(float x) {
-  const float p = x * (1.f + x * (0.5f + x * (1.f / 6 + x * (1.f / 24 + x * (1.f / 120 + x * (1.f / 720 + x * (1.f / 5040 +
-                  x * (1.f / 40320 + x * (1.f / 362880)))))))));
-  const float e = __expf(x) - 1.f;
-  return x > 0.f ? x : (x > -0.5f ? p : e);
-}
-
 // the same function without data-dependent branches: __expf expands to a guarded sequence that hipcc wraps in
 // exec-mask branches per element; v_exp_f32 (2^x) directly is one instruction and both sides become selects.
 // exp(x) - 1 is only taken for x <= -0.5, where exp(x) < 0.61: no denormal input, no cancellation issue.
@@ -213,16 +78,7 @@ __device__ __forceinline__ float elu_fwd_nb(float x) {
   return x > 0.f ? x : n;
 }
 
-#ifndef SPGNN_MFMA_ORDER
-#define SPGNN_MFMA_ORDER 1
-#endif
-#ifndef SPGNN_GEMM_ABLATE
-#define SPGNN_GEMM_ABLATE 0      // timing-only builds: 1 = no split arithmetic, 2 = no MFMA, 3 = no global loads in the loop, 4 = no LDS stores
-#endif
 __device__ __forceinline__ void split4_pk(float4 v, float s, uint2& hi, uint2& lo) {
-#if SPGNN_GEMM_ABLATE == 1
-  hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); lo = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); return;
-#endif
   const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
   union { pk2 h; unsigned u; } h01, h23, l01, l23;
   h01.h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
@@ -300,10 +156,6 @@ struct TileIO {
     const int off = pair_row(idx >> 3) * PITCH + (idx & 7) * 4;
     uint2 h, l;
     split4_pk(v, s, h, l);
-#if SPGNN_GEMM_ABLATE == 4
-    if (h.x == 0x12345678u) *reinterpret_cast<uint2*>(hi_img + off) = l;
-    return;
-#endif
     *reinterpret_cast<uint2*>(hi_img + off) = h;
     *reinterpret_cast<uint2*>(lo_img + off) = l;
   }
@@ -438,11 +290,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
       float* dst0 = a.C + (int64_t)(row0 + wm * (32 * MI) + i * 32 + r_in) * a.ldc + col;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-#ifndef SPGNN_EPI_NOSTORE
         *reinterpret_cast<float4*>(dst0 + (int64_t)(it * 4) * a.ldc) = vv[it];
-#else
-        if (vv[it].x == 123456.f) dst0[it] = vv[it].y;
-#endif
       }
     } else {
     float uu[8][4];
@@ -493,10 +341,6 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
               a.mean_out[(int64_t)row * a.ld_mn + col + q_] = 0.5f * (vq[q_] + a.mean_other[(int64_t)row * a.ld_mo + col + q_]);
         }
         float* dst = a.C + (int64_t)row * a.ldc + col;
-#ifdef SPGNN_EPI_NOSTORE                      /* timing-only build: the epilogue without its global stores */
-        if (v.x == 123456.f) dst[0] = v.y;
-        continue;
-#endif
         if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
         else {
           if (col < a.N) dst[0] = v.x;
@@ -602,14 +446,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
         bh[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + off);                                       \
         bl[j] = *reinterpret_cast<const half8*>(cb + 2 * A_IMG + B_IMG + off);                               \
       }                                                                                                      \
-      /* product-major order: the four accumulators take turns, so no MFMA waits on the one issued just */  \
-      /* before it (SPGNN_MFMA_ORDER 0 = accumulator-major, three dependent MFMAs in a row: A/B only)      */  \
+      /* product-major order: the four accumulators take turns, so no MFMA waits on the one issued just before it */ \
       _Pragma("unroll") for (int c = 0; c < 12; ++c) {                                                       \
-        const int pr = SPGNN_MFMA_ORDER ? c >> 2 : c % 3, ij = SPGNN_MFMA_ORDER ? c & 3 : c / 3;             \
+        const int pr = c >> 2, ij = c & 3;                                                                   \
         const int i = ij >> 1, j = ij & 1;                                                                   \
-        if (SPGNN_GEMM_ABLATE != 2) {                                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
-        } else if (pr == 0) { acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1]; } \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
         if (has_next && c % 3 == 2) { /* a slice of next stage's conversion after every third MFMA */        \
           const int slot = ks * 4 + c / 3;                                                                   \
           _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                    \
@@ -621,14 +462,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    if (SPGNN_GEMM_ABLATE != 3) {                                                                            \
-      if (STEADY_) {                                                                                         \
-        AIO::load_full(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, RA);                                          \
-        BIO::load_full(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, RB);                                          \
-      } else {                                                                                               \
-        AIO::load_any(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                      \
-        BIO::load_any(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, a.K, RB);                                      \
-      }                                                                                                      \
+    if (STEADY_) {                                                                                           \
+      AIO::load_full(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, RA);                                            \
+      BIO::load_full(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, RB);                                            \
+    } else {                                                                                                 \
+      AIO::load_any(a.A, a.lda, row0, a.M, ((T_) + 3) * BK, a.K, RA);                                        \
+      BIO::load_any(a.B, a.ldb, col0, a.N, ((T_) + 3) * BK, a.K, RB);                                        \
     }                                                                                                        \
     __syncthreads();                                                                                         \
     __builtin_amdgcn_sched_barrier(0);   /* keep the next stage's conversion arithmetic (and its vmcnt) behind the barrier */ \
@@ -812,183 +651,6 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
 // barrier drain is not what holds the kernel at ~45 % MFMA-busy; removed again.
 
 // -------------------------------------------------------------------------------------------------
-//   Operands already in split form ("planes"): hi = fp16(s x), lo = fp16(s x - hi) as two row-major fp16
-//   matrices (Mp x Kp, zero padded: Kp % 32 == 0, Mp % 32 == 0), written once by spgnn_split_rows instead of
-//   being re-derived by every workgroup that touches a tile (the fp32-operand kernels above convert an A tile
-//   N/128 times and a B tile M/256 times).  Tiles then go global -> LDS directly (global_load_lds_dwordx4: no
-//   staging registers, no conversion VALU work, no ds_write), double buffered, with the next stage in flight
-//   across a raw s_barrier under a counted s_waitcnt.
-//
-//   LDS image of a ROWS x 32-half tile: 64-byte rows, lane-linear as the DMA writes them (piece q = 16 bytes:
-//   row q >> 2, position q & 3).  ds_read_b128 fragment reads of 16 consecutive... rows at one k-chunk would hit
-//   4 bank-row slots 4-way, so position = chunk XOR ((row >> 2) & 3), applied on the global SOURCE address when
-//   staging and again on the read (cdna_hip_programming.md rule 21).
-// -------------------------------------------------------------------------------------------------
-struct ArgsP {
-  const _Float16* Ah; const _Float16* Al; int64_t lda;    // (M, Kp) planes, row stride in halves (% 8 == 0)
-  const _Float16* Bh; const _Float16* Bl; int64_t ldb;    // (N, Kp)
-  float* C; int64_t ldc;
-  int M, N, Kp;
-  const float* sA; const float* sB;
-  int nbm, nbn;
-  const float* U; int64_t ldu; const float* V; int64_t ldv; int J;
-  const float* bias; int act;
-  const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
-  const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
-
-template <int ROWS, int NT>
-__device__ __forceinline__ void stage_image(const _Float16* __restrict__ g, int64_t ld, int row0, int nrows, int k0,
-                                            _Float16* img) {
-  constexpr int NP = ROWS * 4 / NT;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int q = threadIdx.x + NT * i;
-    const int row = q >> 2;
-    const int c = (q & 3) ^ ((row >> 2) & 3);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;
-    const _Float16* src = g + (int64_t)grow * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(img + q * 8), 16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ half8 frag_swz(const _Float16* img, int row, int chunk) {
-  return *reinterpret_cast<const half8*>(img + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
-}
-
-template <int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_planes(ArgsP a) {
-  constexpr int TBM = 64 * WM, NT = 128 * WM;
-  constexpr int A_IMG = TBM * 32, B_IMG = BN * 32;            // halves
-  constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;                 // Ah | Al | Bh | Bl
-  constexpr int LOADS = 2 * (TBM * 4 / NT) + 2 * (BN * 4 / NT);   // DMA instructions per thread and stage
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-
-  const unsigned nb = gridDim.x, b = blockIdx.x;
-  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
-  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
-  const int bm = tile / a.nbn, bn = tile % a.nbn;
-  const int row0 = bm * TBM, col0 = bn * BN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fh = lane >> 5;
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = a.Kp / BK;
-#define SPGNN_STAGE_IN(T_)                                                                     \
-  {                                                                                            \
-    _Float16* sb_ = smem + ((T_) & 1) * STAGE;                                                 \
-    stage_image<TBM, NT>(a.Ah, a.lda, row0, a.M, (T_) * BK, sb_);                              \
-    stage_image<TBM, NT>(a.Al, a.lda, row0, a.M, (T_) * BK, sb_ + A_IMG);                      \
-    stage_image<BN, NT>(a.Bh, a.ldb, col0, a.N, (T_) * BK, sb_ + 2 * A_IMG);                   \
-    stage_image<BN, NT>(a.Bl, a.ldb, col0, a.N, (T_) * BK, sb_ + 2 * A_IMG + B_IMG);           \
-  }
-#ifndef SPGNN_PLANES_ABLATE
-#define SPGNN_PLANES_ABLATE 0     // timing-only builds: 1 = no MFMA, 2 = no DMA inside the loop, 3 = fragments read once
-#endif
-  SPGNN_STAGE_IN(0)
-#if SPGNN_PLANES_ABLATE == 2
-  SPGNN_STAGE_IN(1)
-#endif
-  for (int t = 0; t < nk; ++t) {
-    if (SPGNN_PLANES_ABLATE == 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (t + 1 < nk) {
-      SPGNN_STAGE_IN(t + 1)                               // next stage in flight while this one is consumed
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                         // every wave's pieces of stage t have landed
-    const _Float16* cb = smem + ((SPGNN_PLANES_ABLATE == 3 ? 0 : t) & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + fr;
-        ah[i] = frag_swz(cb, row, ks * 2 + fh);
-        al[i] = frag_swz(cb + A_IMG, row, ks * 2 + fh);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + fr;
-        bh[j] = frag_swz(cb + 2 * A_IMG, row, ks * 2 + fh);
-        bl[j] = frag_swz(cb + 2 * A_IMG + B_IMG, row, ks * 2 + fh);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#if SPGNN_PLANES_ABLATE == 1
-          acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1];
-#else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#endif
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // buffer t&1 is free for stage t+2
-  }
-#undef SPGNN_STAGE_IN
-  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
-}
-
-// x (M, K) fp32 -> hi, lo (Mp, Kp) fp16 planes of scale * x [* dropout keep/(1-p)], zero padded rows and columns.
-// One thread per 8 columns (two 16-byte loads, one 16-byte store per plane).  Same packed RTZ split as the
-// on-the-fly kernels, so a planes GEMM and an fp32-operand GEMM of the same data agree bit for bit.
-__device__ __forceinline__ float keep_hash(uint64_t seed, int64_t idx, float p, float inv_keep) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
-  return u >= p ? inv_keep : 0.f;
-}
-
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int M, int K,
-                                                         const float* __restrict__ scale, float extra,
-                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t ldp,
-                                                         int Mp, int Kp) {
-  const int k8 = Kp >> 3;
-  const float s = (scale ? scale[0] : 1.f) * extra;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Mp * k8;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int row = (int)(idx / k8), c = (int)(idx % k8) * 8;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (row < M) {
-      const float* src = x + (int64_t)row * ldx;
-      if (c + 8 <= K) { v0 = *reinterpret_cast<const float4*>(src + c); v1 = *reinterpret_cast<const float4*>(src + c + 4); }
-      else {
-        float t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = c + j < K ? src[c + j] : 0.f;
-        v0 = make_float4(t[0], t[1], t[2], t[3]); v1 = make_float4(t[4], t[5], t[6], t[7]);
-      }
-    }
-    uint2 h0, l0, h1, l1;
-    split4_pk(v0, s, h0, l0);
-    split4_pk(v1, s, h1, l1);
-    *reinterpret_cast<uint4*>(hi + (int64_t)row * ldp + c) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    *reinterpret_cast<uint4*>(lo + (int64_t)row * ldp + c) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
 //   spgnn_gemm_tn : C[M,N] = A[R,M]^T * B[R,N]     (weight gradients: A = g_Y, B = X, R = node count)
 //
 // The reduction runs over the ROW index of both operands, so global tiles arrive k-major (32 rows x 128
@@ -1017,45 +679,6 @@ struct ArgsTN {
   int by_xcd;                                     // pipelined kernel: 1-D grid, one split per XCD (splits % 8 == 0)
 };
 
-// one 32 x 128 fp32 tile = 1024 float4; thread t takes float4 #(t + 256 i): row = idx / 32, c4 = idx % 32
-__device__ __forceinline__ void load_tile_t(const float* __restrict__ base, int64_t ld, int64_t r0, int64_t rend, int c0,
-                                            int ncols, float4 (&r)[4]) {
-  if (r0 + TBK <= rend && c0 + BM <= ncols) {          // interior tile: unconditional back-to-back loads
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = threadIdx.x + kThreads * i;
-      r[i] = *reinterpret_cast<const float4*>(base + (r0 + (idx >> 5)) * ld + c0 + (idx & 31) * 4);
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {                         // edge tile, branch-free: rows past the range and columns
-    const int idx = threadIdx.x + kThreads * i;         // past the width contribute zeros (ld % 4 == 0: a float4
-    const int64_t row = r0 + (idx >> 5);                // that starts inside the width lies inside the stride)
-    const int c = c0 + (idx & 31) * 4;
-    const bool rv = row < rend;
-    const int cc = c < ncols ? c : 0;
-    float4 v = *reinterpret_cast<const float4*>(base + (rv ? row : rend - 1) * ld + cc);   // caller: rend > 0
-    v.x = rv && c + 0 < ncols ? v.x : 0.f;
-    v.y = rv && c + 1 < ncols ? v.y : 0.f;
-    v.z = rv && c + 2 < ncols ? v.z : 0.f;
-    v.w = rv && c + 3 < ncols ? v.w : 0.f;
-    r[i] = v;
-  }
-}
-
-__device__ __forceinline__ void store_tile_t(_Float16* hi_img, _Float16* lo_img, const float4 (&r)[4], float s) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + kThreads * i;
-    const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
-    half4 h, l;
-    split4(r[i], s, h, l);
-    *reinterpret_cast<half4*>(hi_img + off) = h;
-    *reinterpret_cast<half4*>(lo_img + off) = l;
-  }
-}
-
 // fragment of the 32 (m) x 16 (k) operand block whose first column is m0 and first k-row is k0
 __device__ __forceinline__ half8 tr_frag(const _Float16* img, int m0, int k0, int lane) {
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
@@ -1069,110 +692,9 @@ __device__ __forceinline__ half8 tr_frag(const _Float16* img, int m0, int k0, in
   return u.h;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3(ArgsTN a) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[4 * TTILE];        // Ah | Al | Bh | Bl  (40 KB)
-  _Float16* Ah = lds;
-  _Float16* Al = lds + TTILE;
-  _Float16* Bh = lds + 2 * TTILE;
-  _Float16* Bl = lds + 3 * TTILE;
-
-  const unsigned nb = gridDim.x, b = blockIdx.x;
-  const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
-  if (tile >= (unsigned)(a.nbm * a.nbn)) return;
-  const int bm = tile / a.nbn, bn = tile % a.nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int64_t r_beg = (int64_t)blockIdx.y * a.rows_per_split;
-  const int64_t r_end = r_beg + a.rows_per_split < a.R ? r_beg + a.rows_per_split : a.R;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fh = lane >> 5;
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  float4 ra[4], rb[4];
-  if (r_beg < r_end) {                                   // an empty split (rows rounded up) only writes zeros
-    load_tile_t(a.A, a.lda, r_beg, r_end, m0, a.M, ra);
-    load_tile_t(a.B, a.ldb, r_beg, r_end, n0, a.N, rb);
-  }
-  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // column sums of this thread's A columns (raw fp32, pre-split)
-  const bool do_colsum = a.colsum != nullptr && bn == 0;
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += TBK) {
-    __syncthreads();
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
-    }
-    store_tile_t(Ah, Al, ra, sA);
-    store_tile_t(Bh, Bl, rb, sB);
-    __syncthreads();
-    if (r0 + TBK < r_end) {
-      load_tile_t(a.A, a.lda, r0 + TBK, r_end, m0, a.M, ra);
-      load_tile_t(a.B, a.ldb, r0 + TBK, r_end, n0, a.N, rb);
-    }
-#pragma unroll
-    for (int ks = 0; ks < TBK / 16; ++ks) {
-      half8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = tr_frag(Ah, wm * 64 + i * 32, ks * 16, lane);
-        al[i] = tr_frag(Al, wm * 64 + i * 32, ks * 16, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[j] = tr_frag(Bh, wn * 64 + j * 32, ks * 16, lane);
-        bl[j] = tr_frag(Bl, wn * 64 + j * 32, ks * 16, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  }
-
-  if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4) = csum;
-    __syncthreads();
-    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < a.M) {
-      float t_ = 0.f;
-#pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
-      a.colsum[(int64_t)blockIdx.y * a.cs_split_stride + (int64_t)(m0 + threadIdx.x) * a.cs_stride] = t_;
-    }
-  }
-  const float alpha = 1.f / (sA * sB);
-  float* Cp = a.C + (int64_t)blockIdx.y * a.split_stride;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + fr;
-      if (col >= a.N) continue;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (row < a.M) Cp[(int64_t)row * a.ldc + col] = acc[i][j][e] * alpha;
-      }
-    }
-}
-
-// Pipelined form of gemm_tn_f16x3 (same tiles, fragments and arithmetic): fp32 tiles are prefetched two stages
-// ahead into two register sets, the conversion + LDS store of stage t+1 is interleaved between the MFMAs of
-// stage t (double-buffered LDS, one barrier per stage) - the schedule of gemm_nt_f16x3_v2.  The first-generation
-// kernel above loads, converts and multiplies in sequence and is kept as the A/B reference (variant 1).
+// fp32 tiles are prefetched two stages ahead into two register sets, the conversion + LDS store of stage t+1 is
+// interleaved between the MFMAs of stage t (double-buffered LDS, one barrier per stage) - the schedule of
+// gemm_nt_f16x3_v2.
 __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
   const int idx = threadIdx.x + kThreads * i;
   const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
@@ -1304,7 +826,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
         bl[j] = tr_frag(cb + 3 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
       }                                                                                                      \
       _Pragma("unroll") for (int c = 0; c < 12; ++c) {                   /* product-major, as the NT kernel */ \
-        const int pr = SPGNN_MFMA_ORDER ? c >> 2 : c % 3, ij = SPGNN_MFMA_ORDER ? c & 3 : c / 3;             \
+        const int pr = c >> 2, ij = c & 3;                                                                   \
         const int i = ij >> 1, j = ij & 1;                                                                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
         if (has_next && c % 3 == 2) {                                                                        \
@@ -1598,39 +1120,35 @@ __global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __res
 
 extern "C" {
 
-#ifndef SPGNN_NT_V3
-#define SPGNN_NT_V3 1      // 0: never pick the 256 x 256 kernel by itself (A/B builds)
-#endif
-static int g_gemm_variant = 2;     // 1 = first-generation kernel (A/B reference), 2 = pipelined kernel
-int spgnn_gemm_set_variant(int32_t v) { const int old = g_gemm_variant; if (v >= 1 && v <= 5) g_gemm_variant = v; return old; }
-
+// `tile`: 0 = chosen from the shape (below); 2 = 128 x 128, 4 = 256 x 128, 5 = 256 x 256 block tiles.  Every tile shape
+// performs the same arithmetic in the same order per output element: results are bit-identical (tests/test_hip_gemm.py).
 static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                         int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
                         int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                         int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
-                        spgnn_stream_t stream) {
+                        int32_t tile, spgnn_stream_t stream) {
+  if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (mean_out) {
     if (!mean_other) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
-        (reinterpret_cast<uintptr_t>(mean_other) & 15) || (reinterpret_cast<uintptr_t>(mean_out) & 15) || g_gemm_variant == 1)
+        (reinterpret_cast<uintptr_t>(mean_other) & 15) || (reinterpret_cast<uintptr_t>(mean_out) & 15))
       return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   }
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (score_out) {
     if (!score_l || !score_r) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-    if (score_cols <= 0 || (score_cols & 63) || score_cols > N || g_gemm_variant == 1 ||
+    if (score_cols <= 0 || (score_cols & 63) || score_cols > N ||
         (reinterpret_cast<uintptr_t>(score_l) & 15) || (reinterpret_cast<uintptr_t>(score_r) & 15) ||
         (reinterpret_cast<uintptr_t>(score_out) & 7))
       return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   }
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
-  if ((bias || activation != SPGNN_ACT_NONE) && g_gemm_variant == 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);   // pipelined kernel only
   if (upd_j < 0 || upd_j > 32) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (upd_j > 0) {
     if (!upd_u || !upd_v) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
-        (reinterpret_cast<uintptr_t>(upd_v) & 15) || g_gemm_variant == 1)
+        (reinterpret_cast<uintptr_t>(upd_v) & 15))
       return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);        // V rows: 16-byte aligned, zero padded to a multiple of 4 columns
   }
   if (M == 0 || N == 0) return SPGNN_OK;
@@ -1639,12 +1157,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
       (reinterpret_cast<uintptr_t>(B) & 15))
     return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
-  if (g_gemm_variant == 1) {
-    gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
-    int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
-    hipLaunchKernelGGL(gemm::gemm_nt_f16x3, dim3((unsigned)tiles), dim3(gemm::kThreads), 0, st, a);
-  } else {
+  {
     // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
     // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones when the tiles fill whole rounds
     // over the 256 CUs, and lose to the larger quantisation otherwise (measured at M = 76 410: N = 1024 / 1063, 4.67 /
@@ -1653,7 +1166,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
     const bool fits31 = M * lda * 4 < (int64_t(1) << 31) && N * ldb * 4 < (int64_t(1) << 31);
     const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
     const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3;
-    if (fits31 && (g_gemm_variant == 5 || (g_gemm_variant == 2 && SPGNN_NT_V3 && v3_wins))) {
+    if (fits31 && (tile == 5 || (tile == 0 && v3_wins))) {
       gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                    (int)((M + 255) / 256), (int)((N + 255) / 256), upd_u, upd_u_stride, upd_v, upd_v_stride,
                    (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
@@ -1664,7 +1177,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
       hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v3, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
       return spgnn_detail::check_launch("spgnn_gemm");
     }
-    const int WM = g_gemm_variant == 4 ? 4 : (g_gemm_variant == 3 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
+    const int WM = tile == 4 ? 4 : (tile == 2 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
     const int TBM = 64 * WM;
     gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                  (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
@@ -1689,7 +1202,16 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                   spgnn_stream_t stream) {
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
-                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, stream);
+                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+int spgnn_gemm_nt_tile(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                       int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
+                       int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
+                       int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                       int32_t tile, spgnn_stream_t stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
+                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, tile, stream);
 }
 
 int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1698,62 +1220,7 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
                            int64_t mean_out_stride, spgnn_stream_t stream) {
   if (!other_head || !mean_out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
-                      nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, stream);
-}
-
-int spgnn_split_rows(const float* x, int64_t x_stride, int64_t M, int64_t K, const float* scale, float extra_factor,
-                     uint16_t* hi, uint16_t* lo, int64_t plane_stride, int64_t Mp, int64_t Kp, spgnn_stream_t stream) {
-  if (M < 0 || K <= 0 || Mp < M || Kp < K || (Kp & 31) || Mp > INT32_MAX || Kp > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
-  if (Mp == 0) return SPGNN_OK;
-  if (!hi || !lo || (M > 0 && !x)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  if (x_stride < K || plane_stride < Kp || (plane_stride & 7) || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
-      (reinterpret_cast<uintptr_t>(hi) & 15) || (reinterpret_cast<uintptr_t>(lo) & 15))
-    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
-  int64_t blocks = (Mp * (Kp / 8) + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(gemm::split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_stride, (int)M,
-                     (int)K, scale, extra_factor, reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo), plane_stride,
-                     (int)Mp, (int)Kp);
-  return spgnn_detail::check_launch("spgnn_gemm");
-}
-
-int spgnn_gemm_nt_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi, const uint16_t* B_lo,
-                         int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t Kp, const float* scale_a,
-                         const float* scale_b, const float* upd_u, int64_t upd_u_stride, const float* upd_v,
-                         int64_t upd_v_stride, int32_t upd_j, const float* bias, int32_t activation, spgnn_stream_t stream) {
-  if (M < 0 || N < 0 || Kp <= 0 || (Kp & 31) || M > INT32_MAX || N > INT32_MAX || Kp > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
-  if (upd_j < 0 || upd_j > 32) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
-  if (upd_j > 0) {
-    if (!upd_u || !upd_v) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-    if (upd_u_stride < upd_j || upd_v_stride < ((N + 3) & ~int64_t(3)) || (upd_v_stride & 3) ||
-        (reinterpret_cast<uintptr_t>(upd_v) & 15))
-      return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
-  }
-  if (M == 0 || N == 0) return SPGNN_OK;
-  if (!A_hi || !A_lo || !B_hi || !B_lo || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  if (lda < Kp || ldb < Kp || ldc < N || (lda & 7) || (ldb & 7) || (reinterpret_cast<uintptr_t>(A_hi) & 15) ||
-      (reinterpret_cast<uintptr_t>(A_lo) & 15) || (reinterpret_cast<uintptr_t>(B_hi) & 15) || (reinterpret_cast<uintptr_t>(B_lo) & 15))
-    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
-  hipStream_t st = (hipStream_t)stream;
-  const int WM = (g_gemm_variant == 3 || M < 4096 || Kp < 512 || N < 512) ? 2 : 4;
-  const int TBM = 64 * WM;
-  gemm::ArgsP a{reinterpret_cast<const _Float16*>(A_hi), reinterpret_cast<const _Float16*>(A_lo), lda,
-                reinterpret_cast<const _Float16*>(B_hi), reinterpret_cast<const _Float16*>(B_lo), ldb, C, ldc, (int)M, (int)N,
-                (int)Kp, scale_a, scale_b, (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride,
-                upd_v, upd_v_stride, (int)upd_j, bias, (int)activation, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
-  int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
-  size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * 32 * sizeof(_Float16);
-  const size_t epi = (size_t)(2 * WM) * 32 * 68 * sizeof(float);               // epilogue slabs share the buffer
-  if (lds_bytes < epi) lds_bytes = epi;
-  if (WM == 4) {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_planes<4>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_nt_planes<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
-  } else {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_planes<2>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_nt_planes<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
-  }
-  return spgnn_detail::check_launch("spgnn_gemm");
+                      nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, 0, stream);
 }
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
@@ -1772,26 +1239,15 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                  (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, 0};
   int64_t tiles = (int64_t)a.nbm * a.nbn;
   tiles = (tiles + 7) & ~int64_t(7);
-#ifndef SPGNN_TN_OLD
-#define SPGNN_TN_OLD 0
-#endif
-  if (g_gemm_variant == 1 || SPGNN_TN_OLD) {
-    hipLaunchKernelGGL(gemm::gemm_tn_f16x3, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), 0,
+  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
+  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+  if (splits % 8 == 0) {              // one split per XCD: its row range is fetched into that XCD's L2 once
+    a.by_xcd = 1;
+    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)((int64_t)a.nbm * a.nbn * splits)), dim3(gemm::kThreads), lds_bytes,
                        (hipStream_t)stream, a);
   } else {
-    const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-#ifndef SPGNN_TN_BY_XCD
-#define SPGNN_TN_BY_XCD 1
-#endif
-    if (SPGNN_TN_BY_XCD && splits % 8 == 0) {
-      a.by_xcd = 1;
-      hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)((int64_t)a.nbm * a.nbn * splits)), dim3(gemm::kThreads), lds_bytes,
-                         (hipStream_t)stream, a);
-    } else {
-      hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), lds_bytes,
-                         (hipStream_t)stream, a);
-    }
+    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), lds_bytes,
+                       (hipStream_t)stream, a);
   }
   return spgnn_detail::check_launch("spgnn_gemm");
 }

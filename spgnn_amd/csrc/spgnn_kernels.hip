@@ -81,6 +81,7 @@ using spgnn_detail::fail;
 using spgnn_detail::g_err;
 
 constexpr int kBlock = 256;
+static_assert(kBlock % 64 == 0 && kBlock >= 64 && kBlock <= 1024, "whole waves per block; every grid below is derived from kBlock");
 
 // ---- team geometry -----------------------------------------------------------------------------
 // H*D floats per node = 4 * T * R.  T = lanes per node, R = float4 chunks per lane.
@@ -2894,8 +2895,8 @@ int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t K
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd: x rows and w must be 16-byte aligned (stride % 4 == 0)");
-  const int64_t waves = (N + 15) / 16;
-  const dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+  const int64_t waves = (N + 15) / 16;          // one wave per 16 rows (the kernel derives its rows from kBlock too)
+  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
   if (J <= 16)
     hipLaunchKernelGGL(scores_fwd_mfma<1>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
   else

@@ -18,13 +18,11 @@ import torch
 from . import _capi
 from .graph import DeviceCSC
 
-import os
-
 ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
-# Projection GEMMs: "f16x3" = hand-written split-fp16 MFMA kernels (spgnn_gemm.hip; fp32-GEMM accuracy, the
-# default), "fp32" = rocBLAS/hipBLASLt SGEMM through torch.mm.
-GEMM_MODE = os.environ.get("SPGNN_GEMM", "f16x3")
+# Projection GEMMs: "f16x3" = hand-written split-fp16 MFMA kernels (spgnn_gemm.hip; fp32-GEMM accuracy), "fp32" =
+# rocBLAS/hipBLASLt SGEMM through torch.mm (kept as the arithmetic cross-check of tests/test_hip_gemm.py).
+GEMM_MODE = "f16x3"
 
 # Optional device word (int64 tensor, one element) added to every attention-dropout seed at run time.  A step
 # captured into a HIP graph bakes its host-drawn seeds in; incrementing this word inside the captured step
@@ -207,10 +205,7 @@ def _pad16(k: int) -> int:
 _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-block reduction resets after each use
 
 
-_NO_SUM_PARTIALS = os.environ.get("SPGNN_NO_SUM_PARTIALS", "0") == "1"      # A/B switch: torch's reduction instead
-
-
-_TN_MIN_ELEMS = int(os.environ.get("SPGNN_TN_MIN_ELEMS", "16384"))   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
+_TN_MIN_ELEMS = 16384   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
 
 
 def sum_partials(part: torch.Tensor) -> torch.Tensor:
@@ -220,7 +215,7 @@ def sum_partials(part: torch.Tensor) -> torch.Tensor:
     n = part[0].numel()
     if S == 1:
         return part[0]
-    if n % 4 or not part.is_contiguous() or part.data_ptr() % 16 or _NO_SUM_PARTIALS:
+    if n % 4 or not part.is_contiguous() or part.data_ptr() % 16:
         return part.sum(0)
     out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
     with torch.cuda.device(part.device):
@@ -310,10 +305,10 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     return (s, scale_from_partials(part)) if want_scale else s
 
 
-_SCORES_SPLIT_WAVES = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES", "2048"))   # row ranges x column groups of scores_bwd_w: 2048 measured best (7.38 vs 7.46 ms/step at 4096: half the partials; 1024: 7.43, 512: 7.65)
+_SCORES_SPLIT_WAVES = 2048   # row ranges x column groups of scores_bwd_w: 2048 measured best (7.38 vs 7.46 ms/step at 4096: half the partials; 1024: 7.43, 512: 7.65)
 
 
-_SCORES_SPLIT_WAVES_SMALL = int(os.environ.get("SPGNN_SCORES_SPLIT_WAVES_SMALL", "1024"))   # the same for J <= 8 (attention-vector gradients)
+_SCORES_SPLIT_WAVES_SMALL = 1024   # the same for J <= 8 (attention-vector gradients)
 
 
 def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0) -> torch.Tensor:
@@ -530,9 +525,6 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
-_CAT_GRAD_VIEWS = os.environ.get("SPGNN_CAT_GRAD_VIEWS", "1") != "0"
-
-
 class _CatDropout(torch.autograd.Function):
     """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
     counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""
@@ -575,7 +567,7 @@ class _CatDropout(torch.autograd.Function):
         outs, off = [], 0
         with torch.cuda.device(g.device):
             for w, need in zip(ctx.widths, ctx.needs_input_grad[2:]):
-                if need and ctx.p == 0.0 and _CAT_GRAD_VIEWS and off % 4 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0:
+                if need and ctx.p == 0.0 and off % 4 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0:
                     outs.append(g[:, off:off + w])      # a plain concatenation: its gradient's column blocks, no copy
                 elif need:
                     wp = (w + 3) // 4 * 4
@@ -1166,7 +1158,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
             scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, act: int = 0, score_l: Optional[torch.Tensor] = None,
-            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
     in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias).  ``score_out``
     (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns."""
@@ -1183,56 +1175,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
         J = upd_u.shape[1]
         assert upd_u.shape[0] == M and upd_u.stride(1) == 1 and upd_v.shape[0] == J and upd_v.shape[1] >= N
         assert _rows_aligned(upd_v) and upd_v.stride(0) >= (N + 3) // 4 * 4 and J <= 32
+    args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K, _ptr(scale_a),
+            _ptr(scale_b), _ptr(upd_u), upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J, _ptr(bias), act,
+            _ptr(score_l), _ptr(score_r), _ptr(score_out), score_l.numel() if score_out is not None else 0)
     with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
-        _capi.check(_capi.load().spgnn_gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                               out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(upd_u),
-                                               upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
-                                               _ptr(bias), act, _ptr(score_l), _ptr(score_r), _ptr(score_out),
-                                               score_l.numel() if score_out is not None else 0, _stream(a)), "spgnn_gemm_nt")
-    return out
-
-
-class Planes:
-    """A tensor in split form for the matrix-core GEMMs: fp16 planes hi, lo of scale * x, (Mp, Kp) zero padded."""
-    __slots__ = ("hi", "lo", "scale", "M", "K")
-
-    def __init__(self, hi, lo, scale, M, K):
-        self.hi, self.lo, self.scale, self.M, self.K = hi, lo, scale, M, K
-
-
-def split_rows(x: torch.Tensor, scale: Optional[torch.Tensor], extra: float = 1.0) -> Planes:
-    _require_cuda(x)
-    M, K = x.shape
-    assert _rows_aligned(x)
-    Mp, Kp = (M + 31) // 32 * 32, (K + 31) // 32 * 32
-    hi = torch.empty((Mp, Kp), dtype=torch.float16, device=x.device)
-    lo = torch.empty((Mp, Kp), dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device), _timed("split_rows", (M, K)):
-        _capi.check(_capi.load().spgnn_split_rows(x.data_ptr(), x.stride(0), M, K, _ptr(scale), extra, hi.data_ptr(),
-                                                  lo.data_ptr(), Kp, Mp, Kp, _stream(x)), "spgnn_split_rows")
-    return Planes(hi, lo, scale, M, K)
-
-
-def gemm_nt_planes(a: Planes, b: Planes, out: Optional[torch.Tensor] = None, upd_u: Optional[torch.Tensor] = None,
-                   upd_v: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
-    """gemm_nt on operands already in split form."""
-    M, N = a.M, b.M
-    Kp = a.hi.shape[1]
-    assert b.hi.shape[1] == Kp and a.K == b.K
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.hi.device)
-    assert out.shape == (M, N) and out.stride(1) == 1
-    J = 0
-    if upd_u is not None:
-        J = upd_u.shape[1]
-        assert upd_u.shape[0] == M and upd_u.stride(1) == 1 and upd_v.shape[0] == J and upd_v.shape[1] >= N
-        assert _rows_aligned(upd_v) and upd_v.stride(0) >= (N + 3) // 4 * 4 and J <= 32
-    with torch.cuda.device(out.device), _timed("gemm_nt", (M, N, a.K)):
-        _capi.check(_capi.load().spgnn_gemm_nt_planes(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), b.hi.data_ptr(),
-                                                      b.lo.data_ptr(), b.hi.stride(0), out.data_ptr(), out.stride(0), M, N, Kp,
-                                                      _ptr(a.scale), _ptr(b.scale), _ptr(upd_u),
-                                                      upd_u.stride(0) if J else 0, _ptr(upd_v), upd_v.stride(0) if J else 0, J,
-                                                      _ptr(bias), act, _stream(out)), "spgnn_gemm_nt_planes")
+        if tile:                                       # block tile pinned by the caller (2 / 4 / 5): bit-identical results
+            _capi.check(_capi.load().spgnn_gemm_nt_tile(*args, tile, _stream(a)), "spgnn_gemm_nt_tile")
+        else:
+            _capi.check(_capi.load().spgnn_gemm_nt(*args, _stream(a)), "spgnn_gemm_nt")
     return out
 
 
@@ -1252,11 +1202,7 @@ def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: to
 
 
 def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
-    return (_FUSE_HEADMEAN and H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
-            and GEMM_MODE == "f16x3")
-
-
-_FUSE_HEADMEAN = os.environ.get("SPGNN_FUSE_HEADMEAN", "1") != "0"      # A/B switch
+    return H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and GEMM_MODE == "f16x3"
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,

@@ -96,6 +96,36 @@ def test_config_loss_gradients_match_oracle(name):
             assert e32 < 1e-4 or tiny or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6, (n, e32)
 
 
+def test_st_gat_3_with_eight_heads_matches_oracle():
+    """BASELINE.json words config 2 as "st_gat_3 (3-layer 8-head GAT)"; the reference's st_gat_3 has 2 heads
+    (exp_settings/st_gat_3.py:101-102).  H is a run-time parameter here: the same model with num_heads = 8 (hidden layers
+    8 x 256 / 8 x 128 / 8 x 64, output 2 x 1024), forward and loss gradients against the oracle at model level."""
+    cfg = get_config("st_gat_3")
+    torch.manual_seed(0)
+    model = models.build_model({**cfg.MODEL, "num_heads": 8}).cuda()
+    model.init(None)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+    model.set_gcn_only(); model.eval()
+    assert model.state_dict()["gat.gat_layers.0.fc.weight"].shape == (2048, 1024)
+    g = synthetic.make_batch(2, rank=6, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5
+    outs = model(g)
+    masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda()).backward()
+    refs, sd = _oracle(cfg, model, g, grad=True)
+    O.masked_weighted_ce(refs[0], y.cpu(), mask, w).backward()
+    assert rel_err(outs[0], refs[0]) < TOL and rel_err(outs[1], refs[1]) < TOL
+    gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            tiny = float((p.grad.cpu() - sd[n].grad).abs().max()) < 1e-7 * gmax
+            assert rel_err(p.grad, sd[n].grad) < 1e-4 or tiny, n
+
+
 def test_state_dict_keys_follow_dgl_layout():
     """Checkpoint compatibility: parameter names/shapes as DGL's layers."""
     _, m = _build("st_pgat_spgnn_3")
