@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 24
+#define SPGNN_ABI_VERSION 25
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -70,8 +70,15 @@ const char* spgnn_last_error(void);
  * p_drop in [0,1): attention dropout; the keep mask is a counter-based hash of (seed, slot, h),
  * regenerated (not stored) by the backward entry points.  seed_offset (nullable): a device word added to
  * `seed` at run time, so a captured HIP graph draws a fresh mask on every replay.
+ * nbr8 (nullable): the in-neighbour lists once more as padded rows, (N, 8) int32 with
+ *   nbr8[v, k] = indices[indptr[v] + min(k, deg(v) - 1)]   (any valid node id for deg(v) == 0 or k beyond a degree > 8)
+ * - "ELL" rows built once per loader batch next to the CSC.  A node's neighbour ids then depend on v alone and are
+ * fetched together with indptr[v]: two dependent memory round trips per node (ids + degree; scores + rows) instead of
+ * three.  Pure speed: nodes of degree > 8 and calls without nbr8 walk the CSC.  spgnn_gat_bwd_dst takes the same rows,
+ * spgnn_gat_bwd_src their out-edge counterparts out_nbr8 / out_pos8 (rows of out_indices / out_pos; both or neither).
  */
 int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
+                  const int32_t* nbr8 /* nullable, see below */,
                   const float* ft, int64_t ft_stride,
                   const float* el, const float* er, int64_t s_stride,
                   const float* res, int64_t res_stride,
@@ -101,6 +108,7 @@ int spgnn_gat_can_fuse_mean(int32_t H, int32_t D);
  * g_pre is also the gradient of the residual branch and of the bias (column sums).
  */
 int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
+                      const int32_t* nbr8 /* nullable */,
                       const float* ft, int64_t ft_stride,
                       const float* el, const float* er, int64_t s_stride,
                       const float* attn,
@@ -126,6 +134,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
  *   g_ft[u,h,:] += g_el[u,h] * attn_l[h,:] + g_er[u,h] * attn_r[h,:]
  */
 int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                      const int32_t* out_nbr8 /* nullable */, const int32_t* out_pos8 /* nullable */,
                       const float* attn, const float* g_e,
                       const float* g_pre, int64_t g_pre_stride,
                       float* g_ft, int64_t g_ft_stride,
@@ -499,7 +508,7 @@ int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf
  * ------------------------------------------------------------------------------------------------ */
 
 /* spgnn_gat_fwd with ft / res / out as bf16 rows; out_mean (the head mean, `.mean(1)` of the output layer) stays fp32. */
-int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices,
+int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8,
                        const uint16_t* ft, int64_t ft_stride,
                        const float* el, const float* er, int64_t s_stride,
                        const uint16_t* res, int64_t res_stride,
@@ -514,7 +523,7 @@ int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices,
 
 /* spgnn_gat_bwd_dst with ft / out / g_pre as bf16 rows.  g_out: bf16 (N, H*D), or - mean_heads != 0 - the fp32
  * gradient of the head mean (N, D).  The per-edge dots use the ROUNDED g_pre (what the other kernels read back). */
-int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices,
+int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8,
                            const uint16_t* ft, int64_t ft_stride,
                            const float* el, const float* er, int64_t s_stride,
                            const float* attn,
@@ -530,6 +539,7 @@ int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices,
 
 /* spgnn_gat_bwd_src with g_pre / g_ft as bf16 rows (score vectors and score gradients fp32). */
 int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                           const int32_t* out_nbr8, const int32_t* out_pos8,
                            const float* attn, const float* g_e,
                            const uint16_t* g_pre, int64_t g_pre_stride,
                            uint16_t* g_ft, int64_t g_ft_stride,

@@ -286,6 +286,9 @@ constexpr int kMaxFast = 8;
 #ifndef SPGNN_SRC_FAST
 #define SPGNN_SRC_FAST 1
 #endif
+#ifndef SPGNN_DIST_SOFTMAX
+#define SPGNN_DIST_SOFTMAX 1      // one (slot, head) attention entry per lane + broadcast instead of the whole table per lane
+#endif
 
 template <int R, int CH> struct Slots {
   static constexpr int NS = (CH == 0) ? R : R / CH;
@@ -297,6 +300,7 @@ template <int R, int CH> struct Slots {
 // -------------------------------------------------------------------------------------------------
 template <typename ST> struct GatFwdT {
   const int32_t* indptr; const int32_t* indices;
+  const int32_t* nbr8;                   // optional (N, 8): in-neighbours of v, slots >= deg repeat the last one (see spgnn_gat_fwd)
   const ST* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
   const ST* res; int64_t res_ld;
@@ -353,14 +357,73 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
     for (int r = 0; r < R; ++r) { acc[r].x += q[r].x; acc[r].y += q[r].y; acc[r].z += q[r].z; acc[r].w += q[r].w; }
   }
 
+  // Neighbour ids.  With the padded (N, 8) neighbour rows they depend on v only, so they are fetched together with
+  // indptr[v] (one round trip) instead of after it: the per-node dependent chain is two memory round trips
+  // (ids + degree, then scores + rows) instead of three.
+  int u[kMaxFast];
+  const bool ell = a.nbr8 != nullptr;
+  if (ell) {
+#pragma unroll
+    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.nbr8[v * 8 + k]);
+  }
   if (SPGNN_FWD_FAST && deg > 0 && deg <= kMaxFast) {
     // Straight-line loads: every index / score load is unconditional (slot k >= deg re-reads the last edge and
     // gets weight 0), so they issue back to back instead of one exec-masked branch and one s_waitcnt per edge;
     // neighbour rows then arrive in batches of kGather edges behind a wave-uniform test.
-    int u[kMaxFast];
+    if (!ell) {
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+      for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    }
     float w[kMaxFast][NS];
+    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1) {
+      // One (edge slot, head) ENTRY per lane instead of the whole 8 x NS table in every lane.  With a head at least a
+      // team wide (CH >= 1) every lane of the team needs the same NS x 8 attention weights; computing the table
+      // redundantly per lane made the narrow layers (<= 128 columns, 16-lane teams) VALU-bound: 16 expf, 16 divisions
+      // and - with attention dropout - 16 64-bit hashes per lane against 64 FMAs of payload.  Entry e = s * 8 + k lives
+      // in lane e % T (register e / T): leaky-relu, the segment max / sum over the 8 lanes of a head (xor shuffles),
+      // exp, the division, the attention store and the dropout hash are done once per entry, then the NS x 8 weights
+      // are broadcast to the lanes (v_readlane into SGPRs when the team is the wave).
+      constexpr int NENT = NS * 8;
+      constexpr int NREG = WAVE ? 1 : (NENT + 15) / 16;       // registers per lane (narrowest team: 16 lanes; a wave holds all 64)
+      const int wl = threadIdx.x & 63, tbase = wl & ~(T - 1);
+      float al[NREG];
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) {
+        const int e = lane + i * T;                           // this lane's entry (teams wider than NENT: idle lanes)
+        const int k = e & 7, s_ = e >> 3;
+        const bool own = e < NENT, valid = own && k < deg;
+        const int kk = k < deg ? k : deg - 1;
+        const int hh = own ? s_ : 0;
+        const int ue = ell ? a.nbr8[v * 8 + k] : a.indices[beg + kk];
+        float x = a.el[(int64_t)ue * a.s_ld + hh] + a.er[v * a.s_ld + hh];
+        x = valid ? lrelu(x, a.slope) : -INFINITY;
+        float mx = single_pass(x);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) mx = single_pass(fmaxf(mx, __shfl_xor(mx, off, 64)));
+        const float ex = valid ? expf(x - mx) : 0.f;
+        float sm = single_pass(ex);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) sm = single_pass(sm + __shfl_xor(sm, off, 64));
+        float a_ = ex / sm;
+        if (valid) a.attn[(int64_t)(beg + k) * a.H + hh] = a_;
+        if (a.p > 0.f) a_ *= keep_scale(a.seed, (int64_t)(beg + kk) * a.H + hh, a.p, a.inv_keep);
+        al[i] = valid ? a_ : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < kMaxFast; ++k) {
+          // entry e = s * 8 + k sits in lane e % T, register e / T (T = 64: always register 0)
+          if constexpr (WAVE) {
+            w[k][s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(al[0]), s * 8 + k));
+          } else {
+            const int e = s * 8 + k;
+            float v0 = __shfl(al[0], tbase + (e & (T - 1)), 64);
+            if constexpr (NREG > 1) { const float v1 = __shfl(al[NREG - 1], tbase + (e & (T - 1)), 64); v0 = (e / T) ? v1 : v0; }
+            w[k][s] = v0;
+          }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
@@ -397,6 +460,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
     for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
       for (int s = 0; s < NS; ++s) w[k][s] = uni<UW>(w[k][s]);
+    }
     constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);   // edges per batch (8 float4 in flight for R >= 2)
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
@@ -504,6 +568,7 @@ __global__ void head_mean_scalar(const float* out, int64_t out_ld, float* om, in
 // -------------------------------------------------------------------------------------------------
 template <typename ST> struct GatBwdDstT {
   const int32_t* indptr; const int32_t* indices;
+  const int32_t* nbr8;
   const ST* ft; int64_t ft_ld;
   const float* el; const float* er; int64_t s_ld;
   const float* attn;
@@ -587,8 +652,71 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
   if (SPGNN_DST_FAST && deg > 0 && deg <= kMaxFast) {
     // unconditional, batched loads (slot k >= deg repeats the last edge with attention 0): see gat_fwd_vec
     int u[kMaxFast];
+    if (a.nbr8) {                        // ids from the padded neighbour rows: they depend on v only (fetched with indptr[v])
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+      for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.nbr8[v * 8 + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
+    }
+    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1 && (NS & (NS - 1)) == 0 && (WAVE || NS * 8 <= 16)) {   // the table must fit the team
+      // One (edge slot, head) entry per lane (see gat_fwd_vec).  The NS x 8 per-edge dots <ft[u], g_pre[v]> are summed
+      // over the team by a reduce-scatter - each round halves the values a lane carries, 8 NS - 1 shuffles in all instead
+      // of log2(T) per value - which leaves entry e = s * 8 + k complete in lane e; the softmax / LeakyReLU backward, the
+      // dropout hash and the stores then run once per entry.
+      constexpr int NENT = NS * 8;
+      float pd[NENT];
+#pragma unroll
+      for (int e = 0; e < NENT; ++e) pd[e] = 0.f;
+      constexpr int kGatherD = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
+#pragma unroll
+      for (int k0 = 0; k0 < kMaxFast; k0 += kGatherD) {
+        if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
+        float4 x[kGatherD][R];
+#pragma unroll
+        for (int q = 0; q < kGatherD; ++q)
+#pragma unroll
+          for (int r = 0; r < R; ++r) x[q][r] = ldv(a.ft + (int64_t)u[k0 + q] * a.ft_ld + (r * T + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < kGatherD; ++q)
+#pragma unroll
+          for (int r = 0; r < R; ++r) pd[SL::of(r) * 8 + k0 + q] += dot4(x[q][r], g[r]);
+      }
+#pragma unroll
+      for (int half = NENT / 2; half >= 1; half >>= 1) {        // entry bit `half` pairs with lane bit `half`
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+          const float keep = up ? pd[i + half] : pd[i];
+          const float send = single_pass(up ? pd[i] : pd[i + half]);
+          pd[i] = keep + __shfl_xor(send, half, 64);
+        }
+      }
+      float ga = single_pass(pd[0]);
+      for (int off = NENT; off < T; off <<= 1) ga = single_pass(ga + __shfl_xor(ga, off, 64));   // teams wider than the table
+      const int e = lane & (NENT - 1), k = e & 7, hh = e >> 3;
+      const bool valid = k < deg;
+      const int kk = valid ? k : deg - 1;
+      const int64_t slot = (int64_t)(beg + kk) * a.H + hh;
+      float al = a.attn[slot];
+      const int ue = a.nbr8 ? a.nbr8[v * 8 + k] : a.indices[beg + kk];
+      const float epre = a.el[(int64_t)ue * a.s_ld + hh] + a.er[v * a.s_ld + hh];
+      al = valid ? al : 0.f;
+      if (a.p > 0.f) ga *= keep_scale(a.seed, slot, a.p, a.inv_keep);
+      float S = single_pass(valid ? al * ga : 0.f);
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) S = single_pass(S + __shfl_xor(S, off, 64));
+      float ge = al * ga - al * S;
+      ge = epre > 0.f ? ge : ge * a.slope;
+      ge = valid ? ge : 0.f;
+      const bool writer = lane < NENT;                         // wider teams hold identical copies of the table
+      if (writer && valid) a.g_e[slot] = ge;
+      float ger = single_pass(ge);
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) ger = single_pass(ger + __shfl_xor(ger, off, 64));
+      if (writer && k == 0) a.g_er[v * a.gs_ld + hh] = ger;
+      return;
+    }
     float al[kMaxFast][NS], ep[kMaxFast][NS], erv[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) erv[s] = a.er[v * a.s_ld + hs[s]];
@@ -732,6 +860,7 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
 // -------------------------------------------------------------------------------------------------
 template <typename ST> struct GatBwdSrcT {
   const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
+  const int32_t* out_nbr8; const int32_t* out_pos8;   // optional (N, 8) rows of out_indices / out_pos, padded like nbr8
   const float* attn; const float* g_e;
   const ST* g_pre; int64_t g_pre_ld;
   ST* g_ft; int64_t g_ft_ld;
@@ -772,12 +901,69 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
   if (SPGNN_SRC_FAST && deg > 0 && deg <= kMaxFast) {
     // unconditional, batched loads (slot k >= deg repeats the last edge with weight 0): see gat_fwd_vec
     int vv[kMaxFast], pp[kMaxFast];
+    if (a.out_nbr8) {                    // padded out-neighbour rows: ids and slots depend on u only
 #pragma unroll
-    for (int k = 0; k < kMaxFast; ++k) {
-      vv[k] = uni<WAVE>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
-      pp[k] = uni<WAVE>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
+      for (int k = 0; k < kMaxFast; ++k) {
+        vv[k] = uni<WAVE>(a.out_nbr8[u * 8 + k]);
+        pp[k] = uni<WAVE>(a.out_pos8[u * 8 + k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        vv[k] = uni<WAVE>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
+        pp[k] = uni<WAVE>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
+      }
     }
-    float w[kMaxFast][NS], ge[kMaxFast][NS];
+    float w[kMaxFast][NS];
+    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1) {
+      // one (edge slot, head) entry per lane (see gat_fwd_vec): attention weight, dropout hash and score gradient are read /
+      // formed once per entry, g_el is an 8-lane sum, the NS x 8 weights are broadcast for the row phase
+      constexpr int NENT = NS * 8;
+      constexpr int NREG = WAVE ? 1 : (NENT + 15) / 16;
+      const int wl = threadIdx.x & 63, tbase = wl & ~(T - 1);
+      float wv[NREG], gsum[NREG];
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) {
+        const int e = lane + i * T;
+        const int k = e & 7, s_ = e >> 3;
+        const bool own = e < NENT, valid = own && k < deg;
+        const int hh = own ? s_ : 0;
+        const int kk = k < deg ? k : deg - 1;
+        const int pe = a.out_nbr8 ? a.out_pos8[u * 8 + k] : a.out_pos[beg + kk];
+        const int64_t slot = (int64_t)pe * a.H + hh;
+        float x = a.attn[slot];
+        const float gq = a.g_e[slot];
+        if (a.p > 0.f) x *= keep_scale(a.seed, slot, a.p, a.inv_keep);
+        wv[i] = valid ? x : 0.f;
+        float gs = single_pass(valid ? gq : 0.f);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) gs = single_pass(gs + __shfl_xor(gs, off, 64));
+        gsum[i] = gs;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int e0 = s * 8;                                   // entry (k = 0, head s): its lane holds the head's g_el sum
+        if constexpr (WAVE) {
+          gel[s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gsum[0]), e0));
+        } else {
+          float v0 = __shfl(gsum[0], tbase + (e0 & (T - 1)), 64);
+          if constexpr (NREG > 1) { const float v1 = __shfl(gsum[NREG - 1], tbase + (e0 & (T - 1)), 64); v0 = (e0 / T) ? v1 : v0; }
+          gel[s] = v0;
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxFast; ++k) {
+          const int e = s * 8 + k;
+          if constexpr (WAVE) {
+            w[k][s] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[0]), e));
+          } else {
+            float v0 = __shfl(wv[0], tbase + (e & (T - 1)), 64);
+            if constexpr (NREG > 1) { const float v1 = __shfl(wv[NREG - 1], tbase + (e & (T - 1)), 64); v0 = (e / T) ? v1 : v0; }
+            w[k][s] = v0;
+          }
+        }
+      }
+    } else {
+    float ge[kMaxFast][NS];
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
@@ -793,6 +979,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
         w[k][s] = uni<UW>(k < deg ? w[k][s] : 0.f);
         gel[s] += k < deg ? ge[k][s] : 0.f;
       }
+    }
     constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
@@ -2351,7 +2538,7 @@ template <typename ST> static bool vec_ok_t(const ST* p, int64_t stride) {
 }
 
 template <typename ST>
-static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const ST* ft, int64_t ft_stride,
+static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const ST* ft, int64_t ft_stride,
                         const float* el, const float* er, int64_t s_stride, const ST* res, int64_t res_stride,
                         const float* bias, ST* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                         float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
@@ -2367,7 +2554,7 @@ static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const ST*
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: activation");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatFwdT<ST> a{indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
+  GatFwdT<ST> a{indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
                 out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok_t(ft, ft_stride) && vec_ok_t(out, out_stride) &&
@@ -2408,21 +2595,21 @@ static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const ST*
 
 extern "C" {
 
-int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const float* ft, int64_t ft_stride,
                   const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
                   const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                   float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
                   float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_fwd_impl<float>(indptr, indices, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
+  return gat_fwd_impl<float>(indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
                              out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset, stream);
 }
 
-int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* ft, int64_t ft_stride,
+int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const uint16_t* ft, int64_t ft_stride,
                        const float* el, const float* er, int64_t s_stride, const uint16_t* res, int64_t res_stride,
                        const float* bias, uint16_t* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                        float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
                        float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_fwd_impl<bf16s>(indptr, indices, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride,
+  return gat_fwd_impl<bf16s>(indptr, indices, nbr8, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride,
                              reinterpret_cast<const bf16s*>(res), res_stride, bias, reinterpret_cast<bf16s*>(out), out_stride,
                              out_mean, out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset,
                              stream);
@@ -2431,7 +2618,7 @@ int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const uint
 }  // extern "C"
 
 template <typename ST>
-static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const ST* ft, int64_t ft_stride,
+static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const ST* ft, int64_t ft_stride,
                             const float* el, const float* er, int64_t s_stride, const float* attn, const void* g_out,
                             int64_t g_out_stride, int32_t mean_heads, const ST* out, int64_t out_stride, ST* g_pre,
                             int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
@@ -2449,7 +2636,7 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_dst: row stride smaller than row");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatBwdDstT<ST> a{indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
+  GatBwdDstT<ST> a{indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
                    g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
                    activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   int T = 0, R = 0, CH = 0, W = 0;
@@ -2474,24 +2661,24 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
 
 extern "C" {
 
-int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* ft, int64_t ft_stride,
+int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const float* ft, int64_t ft_stride,
                       const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_out,
                       int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
                       int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
                       int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
                       uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_bwd_dst_impl<float>(indptr, indices, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, mean_heads, out,
+  return gat_bwd_dst_impl<float>(indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, mean_heads, out,
                                  out_stride, g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, E, H, D, negative_slope,
                                  activation, p_drop, seed, seed_offset, stream);
 }
 
-int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* ft, int64_t ft_stride,
+int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const uint16_t* ft, int64_t ft_stride,
                            const float* el, const float* er, int64_t s_stride, const float* attn, const void* g_out,
                            int64_t g_out_stride, int32_t mean_heads, const uint16_t* out, int64_t out_stride, uint16_t* g_pre,
                            int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
                            int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
                            uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_bwd_dst_impl<bf16s>(indptr, indices, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride, attn, g_out,
+  return gat_bwd_dst_impl<bf16s>(indptr, indices, nbr8, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride, attn, g_out,
                                  g_out_stride, mean_heads, reinterpret_cast<const bf16s*>(out), out_stride,
                                  reinterpret_cast<bf16s*>(g_pre), g_pre_stride, g_e, g_er, g_s_stride, nullptr, N, E, H, D,
                                  negative_slope, activation, p_drop, seed, seed_offset, stream);
@@ -2500,7 +2687,8 @@ int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const 
 }  // extern "C"
 
 template <typename ST>
-static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                            const int32_t* out_nbr8, const int32_t* out_pos8, const float* attn,
                             const float* g_e, const ST* g_pre, int64_t g_pre_stride, ST* g_ft, int64_t g_ft_stride,
                             float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
                             const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
@@ -2515,7 +2703,8 @@ static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indice
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_bwd_src: row stride smaller than row");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_src: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
-  GatBwdSrcT<ST> a{out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
+  if ((out_nbr8 == nullptr) != (out_pos8 == nullptr)) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_bwd_src: out_nbr8 and out_pos8 come together");
+  GatBwdSrcT<ST> a{out_indptr, out_indices, out_pos, out_nbr8, out_pos8, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el, g_s_stride,
                    absmax, N, H, D, 0, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, score_l, score_r, g_er};
   int T = 0, R = 0, CH = 0, W = 0;
   if (pick_gat(H, D, T, R, CH, W) && vec_ok_t(g_pre, g_pre_stride) && vec_ok_t(g_ft, g_ft_stride) && vec_ok(score_l, 0) &&
@@ -2537,21 +2726,23 @@ static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indice
 
 extern "C" {
 
-int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                      const int32_t* out_nbr8, const int32_t* out_pos8, const float* attn,
                       const float* g_e, const float* g_pre, int64_t g_pre_stride, float* g_ft, int64_t g_ft_stride,
                       float* g_el, int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r,
                       const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_bwd_src_impl<float>(out_indptr, out_indices, out_pos, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el,
+  return gat_bwd_src_impl<float>(out_indptr, out_indices, out_pos, out_nbr8, out_pos8, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el,
                                  g_s_stride, absmax, score_l, score_r, g_er, N, E, H, D, p_drop, seed, seed_offset, stream);
 }
 
-int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                           const int32_t* out_nbr8, const int32_t* out_pos8, const float* attn,
                            const float* g_e, const uint16_t* g_pre, int64_t g_pre_stride, uint16_t* g_ft, int64_t g_ft_stride,
                            float* g_el, int64_t g_s_stride, const float* score_l, const float* score_r,
                            const float* g_er, int64_t N, int64_t E, int32_t H, int32_t D,
                            float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
-  return gat_bwd_src_impl<bf16s>(out_indptr, out_indices, out_pos, attn, g_e, reinterpret_cast<const bf16s*>(g_pre), g_pre_stride,
+  return gat_bwd_src_impl<bf16s>(out_indptr, out_indices, out_pos, out_nbr8, out_pos8, attn, g_e, reinterpret_cast<const bf16s*>(g_pre), g_pre_stride,
                                  reinterpret_cast<bf16s*>(g_ft), g_ft_stride, g_el, g_s_stride, nullptr, score_l, score_r, g_er,
                                  N, E, H, D, p_drop, seed, seed_offset, stream);
 }

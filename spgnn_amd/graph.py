@@ -120,6 +120,25 @@ class DeviceCSC:
         self._cache = {}
         return self
 
+    def ell(self):
+        """(nbr8, out_nbr8, out_pos8): the in- / out-neighbour lists once more as padded (N, 8) int32 rows,
+        ``nbr8[v, k] = indices[indptr[v] + min(k, deg(v) - 1)]`` (and the same over out_indices / out_pos), built on the
+        device once per batch.  The GAT kernels fetch them with indptr[v] instead of after it (include/spgnn_hip.h,
+        spgnn_gat_fwd); rows of nodes with more than 8 edges are never used."""
+        if "ell" not in self._cache:
+            def rows(ptr, *arrays):
+                if self.num_nodes == 0 or self.num_edges == 0:
+                    return tuple(torch.zeros((self.num_nodes, 8), dtype=torch.int32, device=ptr.device) for _ in arrays)
+                deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
+                k = torch.arange(8, device=ptr.device, dtype=torch.int64)
+                pos = ptr[:-1].to(torch.int64)[:, None] + torch.minimum(k[None, :], (deg - 1).clamp(min=0)[:, None])
+                pos.clamp_(max=self.num_edges - 1)
+                return tuple(a[pos].contiguous() for a in arrays)
+            (nbr8,) = rows(self.indptr, self.indices)
+            out_nbr8, out_pos8 = rows(self.out_indptr, self.out_indices, self.out_pos)
+            self._cache["ell"] = (nbr8, out_nbr8, out_pos8)
+        return self._cache["ell"]
+
     def in_degrees_f(self) -> torch.Tensor:
         if "in_deg" not in self._cache:
             self._cache["in_deg"] = (self.indptr[1:] - self.indptr[:-1]).to(torch.float32)

@@ -100,6 +100,17 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+USE_ELL = True     # hand the GAT kernels the padded (N, 8) neighbour rows (graph.DeviceCSC.ell); False: CSC walk only (A/B, tests)
+
+
+def _ell(csc):
+    """(nbr8, out_nbr8, out_pos8) device pointers, zeros when the rows are not used."""
+    if not USE_ELL or csc.num_nodes == 0:
+        return 0, 0, 0
+    a, b, c = csc.ell()
+    return a.data_ptr(), b.data_ptr(), c.data_ptr()
+
+
 # --------------------------------------------------------------------------------------------
 # raw launches (thin, shape-checked wrappers; used by the autograd functions and by tests)
 # --------------------------------------------------------------------------------------------
@@ -127,7 +138,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
     attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
     lib = _capi.load()
     with torch.cuda.device(ft.device), _timed("gat_fwd", (N, E, H, D, int(res is not None), int(mean), int(out is not None))):
-        _capi.check(lib.spgnn_gat_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+        _capi.check(lib.spgnn_gat_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], ft.data_ptr(), ft.stride(0),
                                       el.data_ptr(), er.data_ptr(), el.stride(0), _ptr(res),
                                       res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
                                       out.stride(0) if out is not None else 0, _ptr(out_mean),
@@ -153,7 +164,7 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
     with torch.cuda.device(ft.device):
         st = _stream(ft)
         t_dst = _timed("gat_bwd_dst", (N, E, H, D, act, int(mean))).__enter__()
-        _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+        _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], ft.data_ptr(), ft.stride(0),
                                           el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
                                           g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
@@ -162,7 +173,7 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
         t_dst.__exit__()
         t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                          csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                          csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
                                           g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, _ptr(score_l),
                                           _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, E, H, D,

@@ -19,7 +19,7 @@ import torch
 
 from . import _capi
 from .graph import DeviceCSC
-from .ops import (ACT_NONE, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts)
+from .ops import (ACT_NONE, _ell, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts)
 
 BF16 = torch.bfloat16
 
@@ -167,7 +167,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
     out_mean = torch.empty((N, D), dtype=torch.float32, device=ft.device) if fuse else None
     attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
     with torch.cuda.device(ft.device), _timed("gat_fwd_bf16", (N, E, H, D, int(res is not None), int(fuse), int(out is not None))):
-        _capi.check(lib.spgnn_gat_fwd_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), ft.data_ptr(), ft.stride(0),
+        _capi.check(lib.spgnn_gat_fwd_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], ft.data_ptr(), ft.stride(0),
                                            el.data_ptr(), er.data_ptr(), el.stride(0), _ptr(res),
                                            res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
                                            out.stride(0) if out is not None else 0, _ptr(out_mean),
@@ -232,7 +232,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             st = _stream(x)
             with _timed("gat_bwd_dst_bf16", (N, E, H, D, act, int(mean))):
-                _capi.check(lib.spgnn_gat_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), y.data_ptr(), y.stride(0),
+                _capi.check(lib.spgnn_gat_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], y.data_ptr(), y.stride(0),
                                                        s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
                                                        g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                                        out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
@@ -240,7 +240,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
                                                        p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_dst_bf16")
             with _timed("gat_bwd_src_bf16", (N, E, H, D)):
                 _capi.check(lib.spgnn_gat_bwd_src_bf16(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                                       csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                                       csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                                        g_pre.stride(0), g_y.data_ptr(), g_y.stride(0), g_s.data_ptr(),
                                                        g_s.stride(0), al.data_ptr(), ar.data_ptr(), g_s[:, H:].data_ptr(), N, E, H, D,
                                                        p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_src_bf16")

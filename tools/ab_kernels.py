@@ -25,25 +25,26 @@ shapes = [(2, 1024, True), (2, 256, False), (2, 128, False), (2, 64, False), (1,
 if only:
     shapes = [s_ for s_ in shapes if f"{s_[0]}x{s_[1]}" in only.split(",")]
 kinds = os.environ.get("AB_KINDS", "fwd,dst,src").split(",")
+P = float(os.environ.get("AB_P", "0"))     # attention dropout (0.1 in the training configs)
 res = {}
 for (H, D, mean) in shapes:
     HD = H * D
     y = torch.randn(N, 2 * HD, device=dev); s = torch.randn(N, 2 * H, device=dev); bias = torch.zeros(HD, device=dev)
     g_out = torch.randn(N, D if mean else HD, device=dev); g_y = torch.empty_like(y); g_s = torch.empty_like(s)
     _capi._lib = libs[list(libs)[0]]
-    out, om, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, mean=mean)
-    fwd = lambda: ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, out=out, mean=mean)
+    out, om, attn = ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, P, 7, mean=mean)
+    fwd = lambda: ops.gat_fwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], y[:, HD:], bias, H, D, 0.2, ops.ACT_ELU, P, 7, out=out, mean=mean)
     st = torch.cuda.current_stream().cuda_stream
     g_e = torch.empty(E, H, device=dev)
     def dst():
-        _capi.check(_capi._lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), y.data_ptr(), y.stride(0),
+        _capi.check(_capi._lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ops._ell(csc)[0], y.data_ptr(), y.stride(0),
             s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(), g_out.data_ptr(), g_out.stride(0), int(mean),
             out.data_ptr(), out.stride(0), g_y[:, HD:].data_ptr(), g_y.stride(0), g_e.data_ptr(), g_s[:, H:].data_ptr(),
-            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, 0.0, 0, 0, st), "dst")
+            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, P, 7, 0, st), "dst")
     def src():
-        _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(),
+        _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(), ops._ell(csc)[1], ops._ell(csc)[2],
             attn.data_ptr(), g_e.data_ptr(), g_y[:, HD:].data_ptr(), g_y.stride(0), g_y.data_ptr(), g_y.stride(0),
-            g_s.data_ptr(), g_s.stride(0), 0, 0, 0, 0, N, E, H, D, 0.0, 0, 0, st), "src")
+            g_s.data_ptr(), g_s.stride(0), 0, 0, 0, 0, N, E, H, D, P, 7, 0, st), "src")
     for name, fn in (("fwd", fwd), ("dst", dst), ("src", src)):
         if name not in kinds:
             continue
