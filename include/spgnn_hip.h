@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 25
+#define SPGNN_ABI_VERSION 26
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -76,6 +76,14 @@ const char* spgnn_last_error(void);
  * fetched together with indptr[v]: two dependent memory round trips per node (ids + degree; scores + rows) instead of
  * three.  Pure speed: nodes of degree > 8 and calls without nbr8 walk the CSC.  spgnn_gat_bwd_dst takes the same rows,
  * spgnn_gat_bwd_src their out-edge counterparts out_nbr8 / out_pos8 (rows of out_indices / out_pos; both or neither).
+ * out_drop_p in [0,1) (0 = off): the CONSUMER's feature dropout applied to the stored per-head output.  The reference feeds
+ * a hidden layer's output through the next GATConv's feat_drop, after torch.cat with the position stream
+ * (models.py:477-481: h_s = cat[h_s, h_p]; GATConv.feat_drop); with `out` pointing at column out_drop_offset of that
+ * next layer's input buffer (row stride out_stride, out_drop_total columns) the rows are written there once, already
+ * dropped - element (v, c) scaled by spgnn_cat_dropout's keep factor for (out_drop_seed, out_drop_total,
+ * out_drop_offset + c) - instead of being stored plain and copied + masked by a second kernel.  The plain rows are
+ * not needed again: spgnn_gat_bwd_dst takes the same four values, applies the mask to g_out and recovers the kept
+ * elements of `out` for the activation derivative (where an element was dropped its gradient is zero).  Not with out_mean.
  */
 int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   const int32_t* nbr8 /* nullable, see below */,
@@ -89,6 +97,8 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   int64_t N, int64_t E, int32_t H, int32_t D,
                   float negative_slope, int32_t activation,
                   float p_drop, uint64_t seed, const uint64_t* seed_offset /* nullable device word added to seed */,
+                  float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
+                  float* out_absmax /* nullable: out_absmax[v] = max |out[v,:]| as stored (split-GEMM scale of the consumer) */,
                   spgnn_stream_t stream);
 
 /* 1 if the vector kernel fuses the head mean for this (H, D) (a head is at least one team wide). */
@@ -121,6 +131,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float negative_slope, int32_t activation,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
                       spgnn_stream_t stream);
 
 /*
@@ -519,6 +530,7 @@ int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const int3
                        int64_t N, int64_t E, int32_t H, int32_t D,
                        float negative_slope, int32_t activation,
                        float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                       float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
                        spgnn_stream_t stream);
 
 /* spgnn_gat_bwd_dst with ft / out / g_pre as bf16 rows.  g_out: bf16 (N, H*D), or - mean_heads != 0 - the fp32
@@ -535,6 +547,7 @@ int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const 
                            int64_t N, int64_t E, int32_t H, int32_t D,
                            float negative_slope, int32_t activation,
                            float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
                            spgnn_stream_t stream);
 
 /* spgnn_gat_bwd_src with g_pre / g_ft as bf16 rows (score vectors and score gradients fp32). */

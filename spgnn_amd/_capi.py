@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -23,10 +23,10 @@ SIGNATURES = {
     "spgnn_abi_version": [],
     "spgnn_last_error": [],
     "spgnn_gat_fwd": [_i32p, _i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,
-                      _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+                      _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _f32p, _vp],
     "spgnn_gat_can_fuse_mean": [_i32, _i32],
     "spgnn_gat_bwd_dst": [_i32p, _i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _f32p, _i64,
-                          _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+                          _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp],
     "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _f32p, _f32p,
                           _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
@@ -74,9 +74,9 @@ SIGNATURES = {
     "spgnn_tree_anchors": [_f32p, _i64, _i32p, _i32p, _vp, _i64, _i64, _i64, _i32, _i32, _i32p, _vp, _vp],
     # bf16-storage path
     "spgnn_gat_fwd_bf16": [_i32p, _i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _vp, _i64, _f32p, _vp, _i64, _f32p, _i64,
-                           _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+                           _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp],
     "spgnn_gat_bwd_dst_bf16": [_i32p, _i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _f32p, _vp, _i64, _i32, _vp, _i64,
-                               _vp, _i64, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _vp],
+                               _vp, _i64, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp],
     "spgnn_gat_bwd_src_bf16": [_i32p, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _vp, _i64, _vp, _i64, _f32p, _i64, _f32p, _f32p, _f32p,
                                _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_scores_bwd_w_bf16": [_f32p, _i64, _vp, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],

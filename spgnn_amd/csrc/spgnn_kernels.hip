@@ -224,6 +224,21 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p,
   return u >= p ? inv_keep : 0.f;
 }
 
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// Feature-dropout keep factors of four neighbouring elements (spgnn_cat_dropout's mask: one 64-bit hash per group of four
+// columns, 16 bits per element, counter = row * total_width + column of the group's first element).
+__device__ __forceinline__ float4 feat_keep4(uint64_t seed, int64_t counter, float p, float inv_keep) {
+  const uint64_t z = mix64(seed, counter);
+  const unsigned thr = (unsigned)(p * 65536.f);
+  return make_float4(((unsigned)(z) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 16) & 0xFFFFu) >= thr ? inv_keep : 0.f,
+                     ((unsigned)(z >> 32) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 48) & 0xFFFFu) >= thr ? inv_keep : 0.f);
+}
+
 // wave-uniform value -> SGPR (no-op when the template flag is off)
 template <bool ON> __device__ __forceinline__ int uni(int x) { return ON ? __builtin_amdgcn_readfirstlane(x) : x; }
 template <bool ON> __device__ __forceinline__ float uni(float x) {
@@ -289,10 +304,27 @@ constexpr int kMaxFast = 8;
 #ifndef SPGNN_DIST_SOFTMAX
 #define SPGNN_DIST_SOFTMAX 1      // one (slot, head) attention entry per lane + broadcast instead of the whole table per lane
 #endif
+#ifndef SPGNN_DIST_FWD
+#define SPGNN_DIST_FWD SPGNN_DIST_SOFTMAX
+#endif
+#ifndef SPGNN_DIST_DST
+// The dst-major backward half keeps the table-per-lane form.  Its entry-per-lane form (reduce-scatter of the per-edge dots,
+// below) measured 9 % faster and is bitwise repeatable kernel by kernel, alone and under contention
+// (tools/stress_determinism.py), but with it the 2-rank training step (two processes on one GPU) stopped being bitwise
+// repeatable run to run (tools/dbg_replay2.py: 3 of 5 trials, ~1e-5 on the parameters; never with it compiled out, never
+// with only the forward / src-major halves in that form).  Unresolved, so it stays off.
+#define SPGNN_DIST_DST 0
+#endif
+#ifndef SPGNN_DST_SEL
+#define SPGNN_DST_SEL(NS_, WAVE_) true
+#endif
+#ifndef SPGNN_DIST_SRC
+#define SPGNN_DIST_SRC SPGNN_DIST_SOFTMAX
+#endif
 
 template <int R, int CH> struct Slots {
-  static constexpr int NS = (CH == 0) ? R : R / CH;
-  static __device__ __forceinline__ constexpr int of(int r) { return (CH == 0) ? r : r / CH; }
+  static constexpr int NS = (CH == 0) ? R : R / (CH == 0 ? 1 : CH);
+  static __device__ __forceinline__ constexpr int of(int r) { return (CH == 0) ? r : r / (CH == 0 ? 1 : CH); }
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -311,6 +343,10 @@ template <typename ST> struct GatFwdT {
   int64_t N; int H; int D; int T;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;              // optional device word added to `seed` (fresh masks under graph replay)
+  // optional feature dropout of the CONSUMER applied to the stored per-head output (spgnn_gat_fwd: out_drop_*): the
+  // rows land in the next layer's input buffer already dropped, mask = spgnn_cat_dropout's for (fseed, ftotal, foff)
+  float fp; float finv; uint64_t fseed; int ftotal; int foff;
+  float* absmax;                         // optional: absmax[v] = max |stored out[v, :]| (the consumer GEMM's operand scale)
 };
 using GatFwd = GatFwdT<float>;
 
@@ -321,7 +357,7 @@ using GatFwd = GatFwdT<float>;
 // per wave; only R = 1 geometries get there), everything stays per lane.
 template <typename ST, int TT, int R, int CH, bool MEAN>
 __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
-  if (a.seed_off) a.seed += a.seed_off[0];
+  if (a.seed_off) { a.seed += a.seed_off[0]; a.fseed += a.seed_off[0]; }
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   constexpr bool WAVE = TT == 64;
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
       for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
     }
     float w[kMaxFast][NS];
-    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1) {
+    if constexpr (SPGNN_DIST_FWD && CH >= 1) {
       // One (edge slot, head) ENTRY per lane instead of the whole 8 x NS table in every lane.  With a head at least a
       // team wide (CH >= 1) every lane of the team needs the same NS x 8 attention weights; computing the table
       // redundantly per lane made the narrow layers (<= 128 columns, 16-lane teams) VALU-bound: 16 expf, 16 divisions
@@ -505,8 +541,24 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
 
   act_fwd_rows<R>(acc, a.act);
   if (a.out) {
+    float amx = 0.f;
+    if (a.fp > 0.f) {                     // store dropout(out) for the consumer: the un-dropped rows are never needed again
+#pragma unroll                            // (where an element is dropped its gradient is zero whatever act' was)
+      for (int r = 0; r < R; ++r) {
+        const int c = (r * T + lane) * 4;
+        const float4 kf = feat_keep4(a.fseed, v * a.ftotal + a.foff + c, a.fp, a.finv);
+        const float4 d = make_float4(acc[r].x * kf.x, acc[r].y * kf.y, acc[r].z * kf.z, acc[r].w * kf.w);
+        stv(a.out + v * a.out_ld + c, d);
+        amx = absmax4(amx, d);
+      }
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) stv(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]);
+      for (int r = 0; r < R; ++r) { stv(a.out + v * a.out_ld + (r * T + lane) * 4, acc[r]); amx = absmax4(amx, acc[r]); }
+    }
+    if (a.absmax) {
+      amx = team_max(amx, T);
+      if (lane == 0) a.absmax[v] = amx;
+    }
   }
   if (MEAN) {   // heads live in chunks r, r+CH, r+2CH, ... of the same lane (CH >= 1): mean is lane-local
     constexpr int CHs = CH == 0 ? 1 : CH;
@@ -581,12 +633,13 @@ template <typename ST> struct GatBwdDstT {
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;
+  float fp; float finv; uint64_t fseed; int ftotal; int foff;     // `out` was stored dropped (see GatFwdT): g_out gets the same mask
 };
 using GatBwdDst = GatBwdDstT<float>;
 
 template <typename ST, int TT, int R, int CH>
 __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
-  if (a.seed_off) a.seed += a.seed_off[0];
+  if (a.seed_off) { a.seed += a.seed_off[0]; a.fseed += a.seed_off[0]; }
   using SL = Slots<R, CH>;
   constexpr int NS = SL::NS;
   constexpr bool WAVE = TT == 64;               // see gat_fwd_vec
@@ -610,10 +663,22 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
     else
       g[r] = ldv(reinterpret_cast<const ST*>(a.g_out) + v * a.g_out_ld + c);
   }
+  if (a.fp > 0.f) {                       // the forward pass stored dropout(out): the same mask on the incoming gradient
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4 kf = feat_keep4(a.fseed, v * a.ftotal + a.foff + (r * T + lane) * 4, a.fp, a.finv);
+      g[r].x *= kf.x; g[r].y *= kf.y; g[r].z *= kf.z; g[r].w *= kf.w;
+    }
+  }
   if (a.act != SPGNN_ACT_NONE) {
     float4 o[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) o[r] = ldv(a.out + v * a.out_ld + (r * T + lane) * 4);
+    if (a.fp > 0.f) {                     // kept elements: out = stored / inv_keep; dropped ones are irrelevant (g is 0 there)
+      const float un = 1.f - a.fp;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { o[r].x *= un; o[r].y *= un; o[r].z *= un; o[r].w *= un; }
+    }
     if (a.mean) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { g[r].x *= gscale; g[r].y *= gscale; g[r].z *= gscale; g[r].w *= gscale; }
@@ -659,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
     }
-    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1 && (NS & (NS - 1)) == 0 && (WAVE || NS * 8 <= 16)) {   // the table must fit the team
+    if constexpr (SPGNN_DIST_DST && CH >= 1 && (NS & (NS - 1)) == 0 && (WAVE || NS * 8 <= 16) && SPGNN_DST_SEL(NS, WAVE)) {   // the table must fit the team
       // One (edge slot, head) entry per lane (see gat_fwd_vec).  The NS x 8 per-edge dots <ft[u], g_pre[v]> are summed
       // over the team by a reduce-scatter - each round halves the values a lane carries, 8 NS - 1 shuffles in all instead
       // of log2(T) per value - which leaves entry e = s * 8 + k complete in lane e; the softmax / LeakyReLU backward, the
@@ -915,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
       }
     }
     float w[kMaxFast][NS];
-    if constexpr (SPGNN_DIST_SOFTMAX && CH >= 1) {
+    if constexpr (SPGNN_DIST_SRC && CH >= 1) {
       // one (edge slot, head) entry per lane (see gat_fwd_vec): attention weight, dropout hash and score gradient are read /
       // formed once per entry, g_el is an 8-lane sum, the NS x 8 weights are broadcast for the row phase
       constexpr int NENT = NS * 8;
@@ -1646,12 +1711,6 @@ __global__ __launch_bounds__(kBlock) void fold_scores_bwd(const float* __restric
 // =================================================================================================
 // One 64-bit hash serves four neighbouring elements (16 bits each: keep iff bits >= p * 65536), counter = index of the
 // group's first element.
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 
 template <typename ST, bool VEC>
 __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const ST* __restrict__ src, int64_t src_ld, ST* __restrict__ dst,
@@ -2542,8 +2601,12 @@ static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const int
                         const float* el, const float* er, int64_t s_stride, const ST* res, int64_t res_stride,
                         const float* bias, ST* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                         float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
-                        float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                        float p_drop, uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                        int32_t out_drop_total, int32_t out_drop_offset, float* out_absmax, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: bad N/E/H/D");
+  if (!(out_drop_p >= 0.f && out_drop_p < 1.f) || (out_drop_p > 0.f && (out_drop_offset < 0 || (out_drop_offset & 3) ||
+      (int64_t)out_drop_total < (int64_t)out_drop_offset + (int64_t)H * D || !out)))
+    return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: out_drop_p in [0,1), out_drop_offset % 4 == 0, offset + H*D <= total, `out` set");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !ft || !el || !er || (E > 0 && !attn) || (!out && !out_mean) || (E > 0 && !indices))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_fwd: null pointer");
@@ -2555,7 +2618,8 @@ static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const int
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_fwd: p_drop not in [0,1)");
   hipStream_t st = (hipStream_t)stream;
   GatFwdT<ST> a{indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-                out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+                out_mean_stride, attn, N, H, D, 0, negative_slope, activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset,
+                out_drop_p, 1.f / (1.f - out_drop_p), out_drop_seed, out_drop_total, out_drop_offset, out_absmax};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok_t(ft, ft_stride) && vec_ok_t(out, out_stride) &&
                    vec_ok_t(res, res_stride) && vec_ok(bias, 0) && vec_ok(out_mean, out_mean_stride);
@@ -2578,6 +2642,8 @@ static int gat_fwd_impl(const int32_t* indptr, const int32_t* indices, const int
       SPGNN_FOR_R_CH(R, CH, X)
 #undef X
     }
+  } else if (out_drop_p > 0.f || out_absmax) {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_fwd: out_drop_p / out_absmax need a vector geometry (H*D = 4*T*R, aligned rows)");
   } else if constexpr (is_f32<ST>::value) {
     hipLaunchKernelGGL(gat_fwd_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   } else {
@@ -2599,20 +2665,23 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices, const int32_t* 
                   const float* el, const float* er, int64_t s_stride, const float* res, int64_t res_stride,
                   const float* bias, float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                   float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
-                  float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                  float p_drop, uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                  int32_t out_drop_total, int32_t out_drop_offset, float* out_absmax, spgnn_stream_t stream) {
   return gat_fwd_impl<float>(indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, out_mean,
-                             out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset, stream);
+                             out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset, out_drop_p,
+                             out_drop_seed, out_drop_total, out_drop_offset, out_absmax, stream);
 }
 
 int spgnn_gat_fwd_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const uint16_t* ft, int64_t ft_stride,
                        const float* el, const float* er, int64_t s_stride, const uint16_t* res, int64_t res_stride,
                        const float* bias, uint16_t* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride,
                        float* attn, int64_t N, int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation,
-                       float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                       float p_drop, uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                       int32_t out_drop_total, int32_t out_drop_offset, spgnn_stream_t stream) {
   return gat_fwd_impl<bf16s>(indptr, indices, nbr8, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride,
                              reinterpret_cast<const bf16s*>(res), res_stride, bias, reinterpret_cast<bf16s*>(out), out_stride,
                              out_mean, out_mean_stride, attn, N, E, H, D, negative_slope, activation, p_drop, seed, seed_offset,
-                             stream);
+                             out_drop_p, out_drop_seed, out_drop_total, out_drop_offset, nullptr, stream);
 }
 
 }  // extern "C"
@@ -2623,8 +2692,12 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
                             int64_t g_out_stride, int32_t mean_heads, const ST* out, int64_t out_stride, ST* g_pre,
                             int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
                             int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
-                            uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                            uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                            int32_t out_drop_total, int32_t out_drop_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || H <= 0 || D <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: bad N/E/H/D");
+  if (!(out_drop_p >= 0.f && out_drop_p < 1.f) || (out_drop_p > 0.f && (out_drop_offset < 0 || (out_drop_offset & 3) || mean_heads ||
+      (int64_t)out_drop_total < (int64_t)out_drop_offset + (int64_t)H * D)))
+    return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: out_drop_p in [0,1), offset % 4 == 0, offset + H*D <= total, not with mean_heads");
   if (N == 0) return SPGNN_OK;
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_gat_bwd_dst: activation");
   if (!indptr || !ft || !el || !er || !g_out || !g_pre || !g_er || (E > 0 && (!indices || !attn || !g_e)) ||
@@ -2638,7 +2711,8 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
   hipStream_t st = (hipStream_t)stream;
   GatBwdDstT<ST> a{indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride,
                    g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, H, D, 0, 0, mean_heads ? 1 : 0, negative_slope,
-                   activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+                   activation, p_drop, 1.f / (1.f - p_drop), seed, seed_offset,
+                   out_drop_p, 1.f / (1.f - out_drop_p), out_drop_seed, out_drop_total, out_drop_offset};
   int T = 0, R = 0, CH = 0, W = 0;
   const bool g_ok = mean_heads ? vec_ok(g_out, g_out_stride) : vec_ok_t(reinterpret_cast<const ST*>(g_out), g_out_stride);
   const bool vec = pick_gat(H, D, T, R, CH, W) && vec_ok_t(ft, ft_stride) && g_ok &&
@@ -2650,6 +2724,8 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
                    else launch_small_team<ST, R_, CH_>(grid, block, st, a)
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
+  } else if (out_drop_p > 0.f) {
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: out_drop_p needs a vector geometry (H*D = 4*T*R, aligned rows)");
   } else if constexpr (is_f32<ST>::value) {
     if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);       // scalar path maxes with atomics
     hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
@@ -2666,10 +2742,12 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices, const int32
                       int64_t g_out_stride, int32_t mean_heads, const float* out, int64_t out_stride, float* g_pre,
                       int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N,
                       int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
-                      uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                      uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                      int32_t out_drop_total, int32_t out_drop_offset, spgnn_stream_t stream) {
   return gat_bwd_dst_impl<float>(indptr, indices, nbr8, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, mean_heads, out,
                                  out_stride, g_pre, g_pre_stride, g_e, g_er, g_s_stride, absmax, N, E, H, D, negative_slope,
-                                 activation, p_drop, seed, seed_offset, stream);
+                                 activation, p_drop, seed, seed_offset, out_drop_p, out_drop_seed, out_drop_total, out_drop_offset,
+                                 stream);
 }
 
 int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const int32_t* nbr8, const uint16_t* ft, int64_t ft_stride,
@@ -2677,11 +2755,13 @@ int spgnn_gat_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const 
                            int64_t g_out_stride, int32_t mean_heads, const uint16_t* out, int64_t out_stride, uint16_t* g_pre,
                            int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
                            int64_t E, int32_t H, int32_t D, float negative_slope, int32_t activation, float p_drop,
-                           uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                           uint64_t seed, const uint64_t* seed_offset, float out_drop_p, uint64_t out_drop_seed,
+                           int32_t out_drop_total, int32_t out_drop_offset, spgnn_stream_t stream) {
   return gat_bwd_dst_impl<bf16s>(indptr, indices, nbr8, reinterpret_cast<const bf16s*>(ft), ft_stride, el, er, s_stride, attn, g_out,
                                  g_out_stride, mean_heads, reinterpret_cast<const bf16s*>(out), out_stride,
                                  reinterpret_cast<bf16s*>(g_pre), g_pre_stride, g_e, g_er, g_s_stride, nullptr, N, E, H, D,
-                                 negative_slope, activation, p_drop, seed, seed_offset, stream);
+                                 negative_slope, activation, p_drop, seed, seed_offset, out_drop_p, out_drop_seed, out_drop_total,
+                                 out_drop_offset, stream);
 }
 
 }  // extern "C"

@@ -49,6 +49,22 @@ def _drop_for(layer, x: torch.Tensor):
     return ops.cat_dropout((x,), p, _draw_seed()), True
 
 
+FUSE_OUTPUT_DROPOUT = True     # hidden GATConvs write their rows straight into the next layer's input buffer, already under that
+                               # layer's feature dropout (nn.GATConv fuse_out); False: separate concat + dropout pass (tests flip it)
+
+
+def _fuse_plan(layer, nxt, x: torch.Tensor, extra_width: int):
+    """(total, p, seed, extra) for ``layer(g, x, fuse_out=...)`` feeding ``nxt`` together with ``extra_width`` more columns,
+    or None when the fused form is not available."""
+    if not (FUSE_OUTPUT_DROPOUT and layer.can_fuse_out(x)):
+        return None
+    total = layer._num_heads * layer._out_feats + extra_width
+    if total % 4 or (extra_width and ((layer._num_heads * layer._out_feats) % 4 or x.dtype != torch.float32)):
+        return None
+    p = float(nxt.feat_drop.p) if nxt.training else 0.0
+    return total, p, (_draw_seed() if p > 0.0 else 0), ops.fused_extra_partials(x.shape[0], extra_width)
+
+
 def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=1) (reference models.py:477, 481, 534, 537) with 16-byte-aligned rows on the GPU."""
     return cat_padded((a, b)) if a.is_cuda else torch.cat([a, b], dim=1)
@@ -163,10 +179,15 @@ class GAT(nn.Module):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))`` with the classifier
         joined to the output layer's autograd node (not with ``norm``: the normalisation sits in between)."""
         h = _data_in(g, g.ndata["fvs"], self.storage_dtype)
-        for layer in self.gat_layers[:-1]:
-            x, dropped = _drop_for(layer, h)
-            h = layer(g, x, feat_dropped=dropped).flatten(1)
-        x, dropped = _drop_for(self.gat_layers[-1], h)
+        x, dropped = h, False                        # layer 0 runs without dropout
+        for l, layer in enumerate(self.gat_layers[:-1]):
+            plan = _fuse_plan(layer, self.gat_layers[l + 1], x, 0)
+            if plan is not None:                     # the rows arrive at the next layer already under ITS feature dropout
+                x, _ = layer(g, x, feat_dropped=dropped, fuse_out=plan)
+                dropped = True
+            else:
+                h = layer(g, x, feat_dropped=dropped).flatten(1)
+                x, dropped = _drop_for(self.gat_layers[l + 1], h)
         if classifier is not None and not self.norm:
             return self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
         h = self._finish(self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped))
@@ -239,15 +260,22 @@ class GATPSPGNN(nn.Module):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h_s, h_p, classifier(h_s))`` with the
         classifier joined to the output layer's autograd node."""
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
+        x, dropped = _data_cat(g, h_s, h_p), False
         for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
-            if l == 0:
-                x, dropped = _data_cat(g, h_s, h_p), False
+            nxt = self.gat_layers[l + 1]
+            w_p = p_layer._num_heads * p_layer._out_feats
+            plan = _fuse_plan(s_layer, nxt, x, w_p)
+            if plan is not None:       # the structure rows go straight into the next layer's input, under its feature dropout
+                buf, amax = s_layer(g, x, feat_dropped=dropped, fuse_out=plan)
             else:
-                x, dropped = _cat_for(s_layer, h_s, h_p)
-            h_s = s_layer(g, x, feat_dropped=dropped).flatten(1)
-            xp, dropped = (_data_aligned(g, h_p), False) if l == 0 else _drop_for(p_layer, h_p)
-            h_p = p_layer(g, xp, feat_dropped=dropped).flatten(1)
-        x, dropped = _cat_for(self.gat_layers[-1], h_s, h_p)
+                h_s = s_layer(g, x, feat_dropped=dropped).flatten(1)
+            xp, dropped_p = (_data_aligned(g, h_p), False) if l == 0 else _drop_for(p_layer, h_p)
+            h_p = p_layer(g, xp, feat_dropped=dropped_p).flatten(1)
+            if plan is not None:       # ... and the position rows complete it (same seed: one mask over the concatenation)
+                total, p, seed, _ = plan
+                x, dropped = ops.fill_cols_dropout(buf, h_p, total - w_p, total, p, seed, amax), True
+            else:
+                x, dropped = _cat_for(nxt, h_s, h_p)
         if classifier is not None:
             h_s, logits = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
             return h_s, h_p, logits

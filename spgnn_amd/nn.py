@@ -111,15 +111,36 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
+    def can_fuse_out(self, feat: torch.Tensor) -> bool:
+        """True when ``forward(..., fuse_out=...)`` is available for this layer and input: the project-first form with
+        el / er from the GEMM epilogue (out_feats % 64 == 0, input at least as wide as one head's output), a fusable
+        activation and a Linear (or no) residual, fp32 rows on a ROCm device."""
+        H, D = self._num_heads, self._out_feats
+        if feat.dtype == torch.bfloat16:          # bf16 rows: the project-first layer, single source (total == H*D)
+            return (ops_bf16.gat_layer_supported(feat, H, D) and _act_code(self.activation) is not None
+                    and not isinstance(self.res_fc, Identity))
+        return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2 and feat.shape[0] > 0 and SCORES_FROM_FT
+                and D % 64 == 0 and _act_code(self.activation) is not None and not isinstance(self.res_fc, Identity)
+                and not (AGGREGATE_FIRST and feat.shape[1] < D and ops.agg_first_supported(H, feat.shape[1]))
+                and ops.GEMM_MODE == "f16x3" and (H * D) % 4 == 0)
+
     def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False,
-                feat_dropped: bool = False, classifier: Optional[nn.Linear] = None):
+                feat_dropped: bool = False, classifier: Optional[nn.Linear] = None, fuse_out=None):
         """DGL signature; ``mean_heads=True`` (extension) returns ``rst.mean(1)`` (N, D) with the mean fused
         into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482).
         ``feat_dropped=True`` (extension): the caller already applied this layer's feature dropout while assembling
         ``feat`` (ops.cat_dropout fuses it into the concatenation).
         ``classifier`` (extension, with ``mean_heads``): an ``nn.Linear`` applied to the head mean (the reference's
         ``gnn_out(n_embed)``, models.py:1127-1130); the layer then returns ``(rst, classifier(rst))`` and, in the
-        aggregate-first form, back-propagates through both in one node (ops._GATAggFirstFn)."""
+        aggregate-first form, back-propagates through both in one node (ops._GATAggFirstFn).
+        ``fuse_out`` = (total, p, seed, extra) (extension; see ``can_fuse_out``): the flattened output is written, already
+        under the NEXT layer's feature dropout (p, seed), into columns [0, H*D) of a fresh (N, total) buffer - that
+        layer's input, completed by ``ops.fill_cols_dropout`` when total > H*D - and ``(buffer, maxima)`` is returned
+        (reference models.py:477-481: ``h_s = cat[h_s, h_p]`` then ``GATConv.feat_drop``, without the separate pass)."""
+        if fuse_out is not None:
+            if classifier is not None or mean_heads or get_attention or not self.can_fuse_out(feat):
+                raise ValueError("fuse_out= needs can_fuse_out(feat) and none of classifier / mean_heads / get_attention")
+            return self._forward(graph, feat, False, False, feat_dropped, None, fuse_out)
         if classifier is not None:
             if not mean_heads or get_attention:
                 raise ValueError("classifier= needs mean_heads=True and get_attention=False")
@@ -132,7 +153,7 @@ class GATConv(nn.Module):
             return res
         return res, classifier(res)
 
-    def _forward(self, graph, feat, get_attention, mean_heads, feat_dropped, classifier):
+    def _forward(self, graph, feat, get_attention, mean_heads, feat_dropped, classifier, fuse_out=None):
         csc = graph.csc(feat.device)
         if not self._allow_zero_in_degree and csc.min_in_degree == 0:
             raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
@@ -153,6 +174,13 @@ class GATConv(nn.Module):
             if not ops_bf16.gat_layer_supported(h, H, D):
                 raise DGLError(f"bf16 GATConv needs a ROCm device, out_feats % 64 == 0 and in_feats % 4 == 0 (got {tuple(h.shape)} -> {H}x{D})")
             fuse_mean = fuse_mean and ops.can_fuse_mean(H, D)
+            if fuse_out is not None:
+                total, fp, fseed, extra = fuse_out
+                if total != H * D or extra:
+                    raise ValueError("bf16 fuse_out: single source only (total == num_heads * out_feats)")
+                out, attn = ops_bf16.gat_layer(csc, h, w_fc, self.res_fc.weight if has_res else None, self.attn_l, self.attn_r,
+                                               self.bias, H, D, float(self.negative_slope), act, p, seed, out_drop=(fp, fseed))
+                return out, None
             out, attn = ops_bf16.gat_layer(csc, h, w_fc, self.res_fc.weight if has_res else None, self.attn_l, self.attn_r,
                                            self.bias if fuse_epilogue else None, H, D, float(self.negative_slope),
                                            act if fuse_epilogue else ops.ACT_NONE, p, seed, mean=fuse_mean)
@@ -171,6 +199,15 @@ class GATConv(nn.Module):
                     w_cat = F.pad(w_cat, (0, -w_cat.shape[1] % 4))[:, :w_cat.shape[1]]
         if SCORES_FROM_FT and not agg_first and ops.scores_from_ft_supported(h, w_cat, D):
             # el / er from ft in the projection GEMM's epilogue (DGL's own formulation): ops._GATLayerScoresFromFtFn
+            if fuse_out is not None:
+                total, fp, fseed, extra = fuse_out
+                if total % 4 or getattr(csc, "num_dst", None) is not None:
+                    raise ValueError("fuse_out: the buffer width must be a multiple of 4 and the graph not a block")
+                buf, attn, amax = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l, self.attn_r, self.bias, H, D, has_res,
+                                                               float(self.negative_slope), act, p, seed, fuse=fuse_out)
+                if extra == 0:                         # nothing to add: the buffer is complete, its GEMM scale known
+                    buf._spgnn_scale = (buf._version, ops.scale_from_partials(amax))
+                return buf, amax
             out, attn = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l, self.attn_r,
                                                      self.bias if fuse_epilogue else None, H, D, has_res,
                                                      float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p,

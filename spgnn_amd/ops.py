@@ -119,10 +119,14 @@ def can_fuse_mean(H: int, D: int) -> bool:
 
 
 def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: float, act: int, p_drop: float = 0.0,
-                seed: int = 0, out: Optional[torch.Tensor] = None, mean: bool = False, need_out: bool = True):
+                seed: int = 0, out: Optional[torch.Tensor] = None, mean: bool = False, need_out: bool = True,
+                out_drop=None, out_absmax: Optional[torch.Tensor] = None):
     """-> (out (N,H*D) or None, out_mean (N,D) or None, attn (E,H)).  ``mean``: also produce the head mean
     (fused into the epilogue when the geometry allows); ``need_out=False`` lets the per-head output be
-    skipped when only the mean is consumed and nothing in the backward needs it."""
+    skipped when only the mean is consumed and nothing in the backward needs it.
+    ``out_drop`` = (p, seed, total, offset): store the consumer's feature dropout of the output (``out`` = the column
+    block [offset, offset + H*D) of the consumer's (N, total) input buffer); ``out_absmax`` (N,): per-node maxima of the
+    stored rows."""
     _require_cuda(ft, el, er, res, bias)
     N, E = csc.num_nodes, csc.num_edges
     assert ft.shape[0] == N and ft.shape[1] == H * D and ft.stride(1) == 1
@@ -143,14 +147,15 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
                                       res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
                                       out.stride(0) if out is not None else 0, _ptr(out_mean),
                                       out_mean.stride(0) if mean else 0, attn.data_ptr(), N, E, H, D, slope, act,
-                                      p_drop, seed, _seed_off_ptr(ft.device), _stream(ft)), "spgnn_gat_fwd")
+                                      p_drop, seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), _ptr(out_absmax),
+                                      _stream(ft)), "spgnn_gat_fwd")
     return out, out_mean, attn
 
 
 def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, slope: float, act: int,
                 p_drop: float, seed: int, g_pre: torch.Tensor, g_ft: torch.Tensor, g_el: torch.Tensor,
                 g_er: torch.Tensor, mean: bool = False, absmax: Optional[torch.Tensor] = None,
-                score_l: Optional[torch.Tensor] = None, score_r: Optional[torch.Tensor] = None) -> torch.Tensor:
+                score_l: Optional[torch.Tensor] = None, score_r: Optional[torch.Tensor] = None, out_drop=None) -> torch.Tensor:
     """Runs both backward halves. g_pre/g_ft (N,H*D), g_el/g_er (N,H) are written in place
     (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.  ``absmax`` (2N floats):
     per-node maxima of |g_pre| then |g_ft| (for the split-GEMM scale of [g_ft | g_pre]).
@@ -169,7 +174,8 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
                                           g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                           g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax), N, E, H, D, slope,
-                                          act, p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_dst")
+                                          act, p_drop, seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), st),
+                    "spgnn_gat_bwd_dst")
         t_dst.__exit__()
         t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
@@ -766,7 +772,12 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_cat, attn_l, attn_r, bias, csc: DeviceCSC, H: int, D: int, has_res: bool, slope: float, act: int,
-                p_drop: float, seed: int, mean: bool, sx):
+                p_drop: float, seed: int, mean: bool, sx, fuse):
+        """``fuse`` = None, or (total, p, seed, extra): the output is written, already under the CONSUMER's feature
+        dropout (p, seed), into columns [0, H*D) of a fresh (N, total) buffer - the next layer's input, whose remaining
+        columns ``fill_cols_dropout`` adds in place - and that buffer is returned instead of the (N, H*D) rows, together
+        with a third output: per-node maxima of the stored rows followed by ``extra`` free slots for the filler's maxima
+        (the buffer's split-GEMM scale needs no extra pass)."""
         ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
         HD = H * D
         x = _rowmajor(x)
@@ -782,6 +793,25 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
+        ctx.fused = None
+        if fuse is not None:
+            total, fp, fseed, extra = fuse
+            assert not mean and total >= HD
+            assert total % 4 == 0                  # (the buffer itself is returned, never a view of it: it is completed in place)
+            buf = torch.empty((N, total), dtype=torch.float32, device=x.device)
+            amax = torch.empty((N + extra,), dtype=torch.float32, device=x.device)
+            od = (float(fp), int(fseed), int(total), 0)
+            out, _, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed, out=buf[:, :HD],
+                                       out_drop=od, out_absmax=amax)
+            # the stored rows are stashed, not saved: the buffer is completed IN PLACE afterwards (fill_cols_dropout writes
+            # the other columns) and autograd's version check would reject a saved tensor over it; this function only ever
+            # reads its own columns
+            ctx.fused = (out.detach() if act != ACT_NONE else None, od)
+            ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, False)
+            ctx.has_bias = bias is not None
+            ctx.save_for_backward(x, w_cat, al, ar, y, s, attn, None, sx, sw)
+            ctx.mark_non_differentiable(attn, amax)
+            return buf, attn, amax
         out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed,
                                           mean=mean, need_out=(act != ACT_NONE))
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
@@ -791,10 +821,14 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         return (out_mean if mean else out), attn
 
     @staticmethod
-    def backward(ctx, g_out, _g_attn):
+    def backward(ctx, g_out, _g_attn, _g_amax=None):
         if g_out is None:                      # only the (non-differentiable) attention output was used
-            return (None,) * 15
+            return (None,) * 16
         x, w_cat, al, ar, y, s, attn, out, sx, sw = ctx.saved_tensors
+        out_drop = None
+        if ctx.fused is not None:              # g_out is the gradient of the whole (N, total) buffer: this layer's columns come first
+            out, out_drop = ctx.fused
+            g_out = g_out[:, :ctx.cfg[0] * ctx.cfg[1]]
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
         HD = H * D
@@ -805,7 +839,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
         amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device)
         gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
-                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax, score_l=al, score_r=ar)
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax, score_l=al, score_r=ar, out_drop=out_drop)
         sg = scale_from_partials(amax if has_res else amax[N:])
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_bias = g_wcat = None
@@ -830,7 +864,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             Kp = (K + 3) // 4 * 4
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
             gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=g_x)
-        return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None
+        return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None
 
 
 def scores_from_ft_supported(x: torch.Tensor, w_cat: torch.Tensor, D: int) -> bool:
@@ -839,14 +873,81 @@ def scores_from_ft_supported(x: torch.Tensor, w_cat: torch.Tensor, D: int) -> bo
 
 
 def gat_layer_scores_from_ft(csc: DeviceCSC, x, w_cat, attn_l, attn_r, bias, H: int, D: int, has_res: bool, slope: float,
-                             act: int, p_drop: float = 0.0, seed: int = 0, mean: bool = False):
-    """Same contract as gat_layer, with the score vectors attn_l / attn_r (H, D) instead of folded score weights."""
+                             act: int, p_drop: float = 0.0, seed: int = 0, mean: bool = False, fuse=None):
+    """Same contract as gat_layer, with the score vectors attn_l / attn_r (H, D) instead of folded score weights.
+    ``fuse`` (see _GATLayerScoresFromFtFn.forward): -> (next layer's input buffer (N, total), attn, maxima)."""
     _require_cuda(x, w_cat, attn_l, attn_r, bias)
     xr = _rowmajor(x)
     sx = operand_scale(x) if xr is x and _rows_aligned(x) else None
     if not _rows_aligned(xr):
         xr = cat_padded((xr,))
-    return _GATLayerScoresFromFtFn.apply(xr, w_cat, attn_l, attn_r, bias, csc, H, D, has_res, slope, act, p_drop, seed, mean, sx)
+    return _GATLayerScoresFromFtFn.apply(xr, w_cat, attn_l, attn_r, bias, csc, H, D, has_res, slope, act, p_drop, seed, mean, sx,
+                                         fuse)
+
+
+class _FillColsDropout(torch.autograd.Function):
+    """buf[:, off:off+w] = dropout(src, p) IN PLACE, with the mask spgnn_cat_dropout gives column block ``off`` of a
+    ``total``-wide concatenation under ``seed`` (the same seed as the block a fused GATConv already wrote into ``buf``): the
+    second half of ``dropout(cat[h_s, h_p])`` (reference models.py:477-481) when the first half came straight from the
+    producing layer.  Backward: the incoming gradient goes on to the producer unchanged (it reads its own columns only)
+    and this block's gradient is the masked column block."""
+
+    @staticmethod
+    def forward(ctx, buf, src, off, total, p, seed, part):
+        N, w = src.shape
+        s_ = src if src.stride(1) == 1 else src.contiguous()
+        base = buf._base if buf._base is not None else buf
+        with torch.cuda.device(buf.device):
+            _capi.check(_capi.load().spgnn_cat_dropout(s_.data_ptr(), s_.stride(0), buf.data_ptr(), buf.stride(0), N, w, off, total,
+                                                       p, seed, _seed_off_ptr(buf.device), 0, _ptr(part), _stream(buf)),
+                        "spgnn_cat_dropout")
+        ctx.cfg = (off, w, total, p, seed)
+        ctx.mark_dirty(buf)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        off, w, total, p, seed = ctx.cfg
+        if g is None:
+            return (None,) * 7
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        g_src = None
+        if ctx.needs_input_grad[1]:
+            if p == 0.0 and off % 4 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0:
+                g_src = g[:, off:off + w]
+            else:
+                N = g.shape[0]
+                g_src = torch.empty((N, (w + 3) // 4 * 4), dtype=torch.float32, device=g.device)[:, :w]
+                with torch.cuda.device(g.device):
+                    _capi.check(_capi.load().spgnn_cat_dropout(g.data_ptr(), g.stride(0), g_src.data_ptr(), g_src.stride(0), N, w, off,
+                                                               total, p, seed, _seed_off_ptr(g.device), 1, 0, _stream(g)),
+                                "spgnn_cat_dropout")
+        return g, g_src, None, None, None, None, None
+
+
+def fill_cols_dropout(buf: torch.Tensor, src: torch.Tensor, off: int, total: int, p: float, seed: int,
+                      amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Complete a fused GATConv's output buffer (see _GATLayerScoresFromFtFn.forward): columns [off, off + w) = dropout(src).
+    ``amax``: the maxima tensor the layer returned; its tail takes this block's maxima and the buffer's split-GEMM scale
+    is attached to the result."""
+    _require_cuda(buf, src)
+    N, w = src.shape
+    lib = _capi.load()
+    part = None
+    if amax is not None:
+        nb = int(lib.spgnn_cat_dropout_blocks(N, w))
+        assert amax.numel() >= N + nb
+        part = amax[N:N + nb]
+    y = _FillColsDropout.apply(buf, src, int(off), int(total), float(p), int(seed), part)
+    if amax is not None and N > 0:
+        y._spgnn_scale = (y._version, scale_from_partials(amax[:N + nb]))
+    return y
+
+
+def fused_extra_partials(N: int, width: int) -> int:
+    """Slots the maxima tensor of a fused layer must reserve for a later fill_cols_dropout of ``width`` columns."""
+    return int(_capi.load().spgnn_cat_dropout_blocks(N, width)) if width > 0 else 0
 
 
 def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: bool, slope: float, act: int,

@@ -157,8 +157,9 @@ def attn_vector_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int) -> torch.Tens
 
 
 def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: float, act: int, p_drop: float, seed: int,
-                mean: bool, need_out: bool):
-    """-> (out (N, H*D) bf16 or None, out_mean (N, D) fp32 or None, attn (E, H) fp32)."""
+                mean: bool, need_out: bool, out_drop=None):
+    """-> (out (N, H*D) bf16 or None, out_mean (N, D) fp32 or None, attn (E, H) fp32).  ``out_drop`` = (p, seed, total,
+    offset): the stored rows carry the consumer's feature dropout (ops.gat_fwd_raw)."""
     N, E = csc.num_nodes, csc.num_edges
     lib = _capi.load()
     fuse = mean and bool(lib.spgnn_gat_can_fuse_mean(H, D))
@@ -172,7 +173,8 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
                                            res.stride(0) if res is not None else 0, _ptr(bias), _ptr(out),
                                            out.stride(0) if out is not None else 0, _ptr(out_mean),
                                            out_mean.stride(0) if fuse else 0, attn.data_ptr(), N, E, H, D, slope, act, p_drop,
-                                           seed, _seed_off_ptr(ft.device), _stream(ft)), "spgnn_gat_fwd_bf16")
+                                           seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), _stream(ft)),
+                    "spgnn_gat_fwd_bf16")
     return out, out_mean, attn
 
 
@@ -185,7 +187,9 @@ class _GATLayerBf16Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_fc, w_res, attn_l, attn_r, bias, csc: DeviceCSC, H: int, D: int, slope: float, act: int,
-                p_drop: float, seed: int, mean: bool):
+                p_drop: float, seed: int, mean: bool, out_drop):
+        """``out_drop`` = None or (p, seed): the rows are stored under the NEXT layer's feature dropout (nn.GATConv
+        fuse_out with total == H*D): no separate dropout pass over them."""
         ctx.set_materialize_grads(False)
         HD = H * D
         N = x.shape[0]
@@ -199,9 +203,11 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
+        od = None if out_drop is None else (float(out_drop[0]), int(out_drop[1]), HD, 0)
         out, out_mean, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed, mean,
-                                          need_out=(act != ACT_NONE))
+                                          need_out=(act != ACT_NONE) or od is not None, out_drop=od)
         fused_mean = out_mean is not None
+        ctx.out_drop = od
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, fused_mean)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w_t, al, ar, y, s, attn, out if act != ACT_NONE else None)
@@ -211,7 +217,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_attn):
         if g_out is None:
-            return (None,) * 14
+            return (None,) * 15
         x, w_t, al, ar, y, s, attn, out = ctx.saved_tensors
         H, D, has_res, slope, act, p_drop, seed, mean = ctx.cfg
         csc = ctx.csc
@@ -237,7 +243,8 @@ class _GATLayerBf16Fn(torch.autograd.Function):
                                                        g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                                        out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                                        g_e.data_ptr(), g_s[:, H:].data_ptr(), g_s.stride(0), N, E, H, D, slope, act,
-                                                       p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_dst_bf16")
+                                                       p_drop, seed, _seed_off_ptr(x.device), *(ctx.out_drop or (0.0, 0, 0, 0)), st),
+                            "spgnn_gat_bwd_dst_bf16")
             with _timed("gat_bwd_src_bf16", (N, E, H, D)):
                 _capi.check(lib.spgnn_gat_bwd_src_bf16(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                                        csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
@@ -263,7 +270,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = gemm_nt(g_y, w_t)
-        return g_x, g_wfc, g_wres, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None
+        return g_x, g_wfc, g_wres, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None
 
 
 def gat_layer_supported(x: torch.Tensor, H: int, D: int) -> bool:
@@ -274,10 +281,12 @@ def gat_layer_supported(x: torch.Tensor, H: int, D: int) -> bool:
 
 
 def gat_layer(csc: DeviceCSC, x, w_fc, w_res, attn_l, attn_r, bias, H: int, D: int, slope: float, act: int,
-              p_drop: float = 0.0, seed: int = 0, mean: bool = False):
-    """-> (out (N, H*D) bf16, or the fp32 head mean (N, D) when ``mean`` and the geometry fuses it; attn (E, H) fp32)."""
+              p_drop: float = 0.0, seed: int = 0, mean: bool = False, out_drop=None):
+    """-> (out (N, H*D) bf16, or the fp32 head mean (N, D) when ``mean`` and the geometry fuses it; attn (E, H) fp32).
+    ``out_drop`` = (p, seed): the rows are stored under the next layer's feature dropout."""
     _require_cuda(x, w_fc, w_res, attn_l, attn_r, bias)
-    return _GATLayerBf16Fn.apply(as_rows(x), w_fc, w_res, attn_l, attn_r, bias, csc, H, D, slope, act, p_drop, seed, mean)
+    return _GATLayerBf16Fn.apply(as_rows(x), w_fc, w_res, attn_l, attn_r, bias, csc, H, D, slope, act, p_drop, seed, mean,
+                                 out_drop)
 
 
 class _CatDropoutBf16(torch.autograd.Function):

@@ -126,6 +126,38 @@ def test_st_gat_3_with_eight_heads_matches_oracle():
             assert rel_err(p.grad, sd[n].grad) < 1e-4 or tiny, n
 
 
+@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_gat_3", "st_gat_6_nr"])
+def test_fused_output_dropout_equals_separate_pass(name, monkeypatch):
+    """Training mode (feature + attention dropout on): hidden layers writing their rows straight into the next layer's
+    input buffer under that layer's feature dropout (nn.GATConv fuse_out + ops.fill_cols_dropout) against the separate
+    concat + dropout pass (reference models.py:477-481 order of operations).  Every seed draw returns one constant, so both
+    forms see identical masks whatever the order of the draws: the forward pass must agree to rounding (the stored rows are
+    the same products), the gradients to fp32 noise (the activation derivative is recovered from stored * (1 - p))."""
+    from spgnn_amd import nn as snn
+    monkeypatch.setattr(snn, "_draw_seed", lambda: 424242)
+    monkeypatch.setattr(models, "_draw_seed", lambda: 424242)
+    cfg, model = _build(name, seed=2)
+    model.train()
+    g = synthetic.make_batch(3, rank=8, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS)).cuda()
+    y = g.ndata["y"]
+    mask = (torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5).cuda()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(models, "FUSE_OUTPUT_DROPOUT", fused)
+        model.zero_grad(set_to_none=True)
+        logits = model(g)[0]
+        masked_weighted_ce(logits, y, mask, w).backward()
+        res[fused] = (logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert rel_err(res[True][0], res[False][0]) < 1e-6
+    gmax = max(float(v.abs().max()) for v in res[False][1].values())
+    for n, gref in res[False][1].items():
+        tiny = float((res[True][1][n] - gref).abs().max()) < 1e-7 * gmax
+        assert rel_err(res[True][1][n], gref) < 2e-5 or tiny, n
+    # the keep rate of what the next layer reads: fraction of zeros in a fused buffer ~ p (plus ELU's exact zeros: none)
+    monkeypatch.setattr(models, "FUSE_OUTPUT_DROPOUT", True)
+
+
 def test_state_dict_keys_follow_dgl_layout():
     """Checkpoint compatibility: parameter names/shapes as DGL's layers."""
     _, m = _build("st_pgat_spgnn_3")

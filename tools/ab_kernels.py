@@ -40,7 +40,7 @@ for (H, D, mean) in shapes:
         _capi.check(_capi._lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ops._ell(csc)[0], y.data_ptr(), y.stride(0),
             s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(), g_out.data_ptr(), g_out.stride(0), int(mean),
             out.data_ptr(), out.stride(0), g_y[:, HD:].data_ptr(), g_y.stride(0), g_e.data_ptr(), g_s[:, H:].data_ptr(),
-            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, P, 7, 0, st), "dst")
+            g_s.stride(0), 0, N, E, H, D, 0.2, ops.ACT_ELU, P, 7, 0, 0.0, 0, 0, 0, st), "dst")
     def src():
         _capi.check(_capi._lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(), csc.out_pos.data_ptr(), ops._ell(csc)[1], ops._ell(csc)[2],
             attn.data_ptr(), g_e.data_ptr(), g_y[:, HD:].data_ptr(), g_y.stride(0), g_y.data_ptr(), g_y.stride(0),
