@@ -59,6 +59,7 @@ def _draw_seed() -> int:
 # Layer forms (fixed choices; the parity tests flip AGGREGATE_FIRST / SCORES_FROM_FT to check the forms against each other)
 SCORES_FROM_FT = True      # el / er from ft in the projection GEMM's epilogue (DGL's own formulation) vs folded score weights
 AGGREGATE_FIRST = True     # inputs narrower than one head's output: aggregate the input rows, then project
+LINEAR_MEAN = True         # an output layer without activation whose heads are averaged: ONE product on [z_0 .. z_H-1 | x]
 FUSE_CLASSIFIER = True     # the *Net's gnn_out joined to the output layer's autograd node
 
 
@@ -214,6 +215,13 @@ class GATConv(nn.Module):
                                                      seed, mean=fuse_mean)
             return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
         w_lr = ops.fold_scores(w_fc, self.attn_l, self.attn_r)
+        if (agg_first and LINEAR_MEAN and fuse_mean and act == ops.ACT_NONE and (H + 1) * h.shape[1] <= H * D
+                and getattr(csc, "num_dst", None) is None):
+            # no activation between the projection and the head mean: the layer is linear in [z_0 .. z_{H-1} | x]
+            # (ops._GATAggregateFn): one product, no per-head (N, H*D) tensors in either direction
+            out, attn = ops.gat_layer_linear_mean(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D,
+                                                  float(self.negative_slope), p, seed)
+            return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
         if agg_first:
             # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)
             fuse_cls = (FUSE_CLASSIFIER and classifier is not None and fuse_mean and classifier.out_features <= 32

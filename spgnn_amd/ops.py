@@ -964,12 +964,14 @@ def agg_first_supported(H: int, F_in: int) -> bool:
     return bool(_capi.load().spgnn_gat_agg_supported(H, F_in))
 
 
-def gat_agg_fwd_raw(csc: DeviceCSC, x, el, er, H: int, slope: float, p_drop: float, seed: int, with_x_copy: bool):
-    """-> (z (N, H*zs), attn (E,H), absmax (N,)); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F)."""
+def gat_agg_fwd_raw(csc: DeviceCSC, x, el, er, H: int, slope: float, p_drop: float, seed: int, with_x_copy: bool,
+                    out: Optional[torch.Tensor] = None):
+    """-> (z (N, H*zs), attn (E,H), absmax (N,)); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F).  ``out``: a
+    buffer at least (N, H*zs) wide to write the blocks into (its row stride is used)."""
     N, E = csc.num_nodes, csc.num_edges
     F_ = x.shape[1]
     zs = 2 * F_ if with_x_copy else F_
-    z = torch.empty((N, H * zs), dtype=torch.float32, device=x.device)
+    z = out if out is not None else torch.empty((N, H * zs), dtype=torch.float32, device=x.device)
     attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
     amax = torch.empty((N,), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("gat_agg_fwd", (N, E, H, F_, int(with_x_copy))):
@@ -1139,6 +1141,80 @@ class _GATAggFirstFn(torch.autograd.Function):
         g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[3] else None
         return ((g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, g_wcls, g_bcls, None, None, None, None, None, None,
                 None, None)
+
+
+class _GATAggregateFn(torch.autograd.Function):
+    """x (N, F) -> Zx = [z_0 | ... | z_{H-1} | x] (N, (H+1) F), z_h[v] = sum_u a_h(u, v) x[u]: the attention-weighted sums
+    of the INPUT rows for every head, next to the rows themselves.  What an output GATConv WITHOUT activation needs when
+    its heads are averaged (reference models.py:320-327: ``self.gat_layers[-1](g, h).mean(1)``): the layer is then linear
+    in Zx,  mean_h(W_h z_h + Wres_h x + b_h) = Zx [W_0 | ... | W_{H-1} | sum_h Wres_h]^T / H + mean_h b_h,
+    ONE product with (H+1) F reduction columns instead of H products of 2 F, and no (N, H*D) tensor exists at all -
+    neither the per-head outputs nor their gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w_lr, csc: DeviceCSC, H: int, slope: float, p_drop: float, seed: int):
+        ctx.set_materialize_grads(False)
+        x = _rowmajor(x)
+        N, F_ = x.shape
+        s = scores_fwd(x, w_lr)
+        zx = torch.empty((N, (H + 1) * F_), dtype=torch.float32, device=x.device)
+        _, attn, _amax = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, False, out=zx)
+        zx[:, H * F_:].copy_(x)
+        ctx.csc, ctx.cfg = csc, (H, slope, p_drop, seed)
+        ctx.save_for_backward(x, w_lr, s, attn)
+        ctx.mark_non_differentiable(attn)
+        return zx, attn
+
+    @staticmethod
+    def backward(ctx, g_zx, _g_attn):
+        if g_zx is None:
+            return (None,) * 7
+        x, w_lr, s, attn = ctx.saved_tensors
+        H, slope, p_drop, seed = ctx.cfg
+        csc = ctx.csc
+        N, F_ = x.shape
+        E = csc.num_edges
+        g_zx = _rowmajor(g_zx)
+        if not _rows_aligned(g_zx):
+            g_zx = g_zx.contiguous()
+        g_s = torch.empty_like(s)
+        g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
+        lib = _capi.load()
+        g_x = torch.empty((N, (F_ + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :F_]
+        w_lr_c = w_lr.contiguous()
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            with _timed("gat_agg_bwd_dst", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                      s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                      g_zx.data_ptr(), g_zx.stride(0), F_, g_e.data_ptr(), g_s[:, H:].data_ptr(),
+                                                      g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
+                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst")
+            with _timed("gat_agg_bwd_src", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                      csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_zx.data_ptr(),
+                                                      g_zx.stride(0), F_, -1, g_s[:, H:].data_ptr(),
+                                                      w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
+                                                      g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
+                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
+        g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0]:
+            g_x = g_x + g_zx[:, H * F_:]                 # the copy of x inside Zx
+        return (g_x if ctx.needs_input_grad[0] else None), g_wlr, None, None, None, None, None
+
+
+def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
+                          seed: int = 0):
+    """mean over heads of a GATConv WITHOUT activation (see _GATAggregateFn) -> (mean (N, D), attn (E, H)).  The weight
+    assembly below is a few tiny torch ops, so autograd hands the gradients back to ``w_fc`` / ``w_res`` / ``bias``."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias)
+    F_ = x.shape[1]
+    zx, attn = _GATAggregateFn.apply(x, w_lr, csc, H, slope, p_drop, seed)
+    parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
+    parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
+    w_comb = torch.cat(parts, dim=1) * (1.0 / H)
+    b_mean = bias.view(H, D).mean(0) if bias is not None else None
+    return linear(zx, w_comb, b_mean), attn
 
 
 def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, act: int,

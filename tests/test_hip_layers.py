@@ -212,6 +212,45 @@ def test_aggregate_first_form_matches_project_first_and_oracle(monkeypatch, fin,
     for name, a, b in zip(names, results[True], results[False]):
         assert rel_err(a, b) < GRAD_TOL, name
 
+@pytest.mark.parametrize("fin,H,D,res,p", [(128, 2, 1024, True, 0.0), (36, 2, 64, False, 0.1), (192, 4, 256, True, 0.1), (64, 1, 512, True, 0.0)])
+def test_linear_mean_output_layer_matches_per_head_form_and_oracle(monkeypatch, fin, H, D, res, p):
+    """An output GATConv without activation whose heads are averaged (reference models.py:320-327, GAT's last layer) is
+    linear in [z_0 .. z_{H-1} | x]: ops.gat_layer_linear_mean evaluates it as ONE product (nn.LINEAR_MEAN).  Same
+    function as the per-head aggregate-first form and as the oracle, forward and every gradient, attention dropout on."""
+    torch.manual_seed(fin + H + D)
+    g, src, dst, n = _graph([150, 33, 2, 64], seed=fin)
+    seed = 192837465
+    layer = snn.GATConv(fin, D, H, 0.0, p, 0.2, res, None).cuda().train()
+    monkeypatch.setattr(snn, "_draw_seed", lambda: seed)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    x = torch.randn(n, fin, device="cuda")
+    cot = torch.randn(n, D, device="cuda")
+    results = {}
+    for form in (True, False):
+        monkeypatch.setattr(snn, "LINEAR_MEAN", form)
+        xg = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        out = layer(g, xg, mean_heads=True)
+        (out * cot).sum().backward()
+        results[form] = [out.detach(), xg.grad] + [q.grad.clone() for q in layer.parameters()]
+    csc = g.csc()
+    E = csc.num_edges
+    keep_edge = None
+    if p > 0:
+        keep_slot = keep_scale_host(seed, np.arange(E * H), p).reshape(E, H)
+        keep_edge = np.empty_like(keep_slot); keep_edge[csc.eid.cpu().numpy()] = keep_slot
+        keep_edge = torch.from_numpy(keep_edge)
+    ref, _, xo, sd = _oracle_gat(layer, src, dst, n, x, None, attn_keep=keep_edge)
+    ref = ref.mean(1)
+    (ref * cot.cpu()).sum().backward()
+    names = ["out", "x"] + [k for k, _ in layer.named_parameters()]
+    want = [ref, xo.grad] + [sd[k].grad for k in names[2:]]
+    for form in (True, False):
+        for name, got, w in zip(names, results[form], want):
+            assert rel_err(got, w) < (FWD_TOL if name == "out" else GRAD_TOL), (form, name)
+
+
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_ELU, ops.ACT_TANH, ops.ACT_RELU])
 def test_epilogue_and_derivative_kernels_of_the_aggregate_first_form(act):
     """spgnn_gemm_nt's bias + activation epilogue (on column-slice outputs), spgnn_head_mean and spgnn_act_bwd."""
