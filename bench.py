@@ -66,7 +66,7 @@ def algorithmic_bytes(key) -> float:
         return s * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
     if base == "scores_fwd":         # read x; write S
         _, N, K, J = key
-        return 4 * N * K + 4 * N * J
+        return s * N * K + 4 * N * J
     if base == "scores_bwd_w":       # read x, gS; partials negligible
         _, N, K, J = key
         return s * N * K + 4 * N * J
@@ -75,13 +75,13 @@ def algorithmic_bytes(key) -> float:
         return 4 * 2 * N * K + 4 * N * J
     if base == "gat_agg_fwd":        # read x; write the z blocks [with a copy of x per head]; el, er, a; CSC
         _, N, E, H, F_, xcopy = key
-        return 4 * N * F_ + 4 * N * H * F_ * (2 if xcopy else 1) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
+        return s * N * F_ + s * N * H * F_ * (2 if xcopy else 1) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
     if base == "gat_agg_bwd_dst":    # read the z part of g_z and x; el, er, a; write g_e, g_er; CSC
         _, N, E, H, F_ = key
-        return 4 * N * (H + 1) * F_ + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
+        return s * N * (H + 1) * F_ + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)
     if base == "gat_agg_bwd_src":    # read g_z (both parts); write g_x; a, g_e, g_er, g_el; CSR + slot map
         _, N, E, H, F_ = key
-        return 4 * N * (2 * H + 1) * F_ + 4 * (2 * N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+        return s * N * (2 * H + 1) * F_ + 4 * (2 * N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
     if base == "head_mean":
         _, N, H, D = key
         return 4 * N * (H + 1) * D
@@ -290,7 +290,8 @@ def main():
             loss = step.step(g)
         kt_all = ops.KernelTimer.stop()
     # The roofline kernel is FIXED per dtype (not "whichever shape won this run"): all launches of it in a step.
-    roof_names = ("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16") if bf16 else ("gemm_nt",)
+    roof_names = (("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16", "gat_agg_fwd_bf16", "gat_agg_bwd_dst_bf16",
+                   "gat_agg_bwd_src_bf16") if bf16 else ("gemm_nt",))
     gat_names = tuple(k for k in {k[0] for k in kt_all} if k.startswith(GAT_PREFIXES))
     bracket = [k for k in kt_all if k[0] in roof_names or k[0] in gat_names or k[0] in GEMM_NAMES]
     sync()
@@ -474,8 +475,8 @@ def main():
                     r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
                     ach = r_bytes / (r_ms * 1e-3) / 1e9
                     tr = traffic_of(rkeys)
-                    out["roofline"] = {"bound": "hbm", "kernel": "spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 "
-                                       "(all launches of a step)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    out["roofline"] = {"bound": "hbm", "kernel": "spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the "
+                                       "output layer's spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBPS, "traffic": tr,
                                        "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
                                        "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 26
+#define SPGNN_ABI_VERSION 27
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -561,6 +561,35 @@ int spgnn_gat_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices
                            int64_t N, int64_t E, int32_t H, int32_t D,
                            float p_drop, uint64_t seed, const uint64_t* seed_offset,
                            spgnn_stream_t stream);
+
+/* The aggregate-first kernels (spgnn_gat_agg_fwd / _bwd_dst / _bwd_src above) and spgnn_scores_fwd on bf16 rows: x, the z
+ * blocks, their gradient g_z and g_x are bf16 (8-byte aligned rows, stride % 4 == 0); el / er / attn / g_e / g_el / g_er
+ * and w / w_lr stay fp32.  Same arguments otherwise (no absmax by-product: the bf16 GEMMs need no operand scale).  Used
+ * for the GAT OUTPUT layer without activation whose head mean is one product on [z_0 | .. | z_{H-1} | x]
+ * (reference models.py:320-327). */
+int spgnn_gat_agg_fwd_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* x, int64_t x_stride,
+                           const float* el, const float* er, int64_t s_stride, float* attn,
+                           uint16_t* z, int64_t z_stride, int32_t head_stride, int32_t x_copy_offset,
+                           int64_t N, int64_t E, int32_t H, int32_t F,
+                           float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           spgnn_stream_t stream);
+int spgnn_gat_agg_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* x, int64_t x_stride,
+                               const float* el, const float* er, int64_t s_stride, const float* attn,
+                               const uint16_t* g_z, int64_t g_z_stride, int32_t head_stride,
+                               float* g_e, float* g_er, int64_t g_s_stride,
+                               int64_t N, int64_t E, int32_t H, int32_t F,
+                               float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                               spgnn_stream_t stream);
+int spgnn_gat_agg_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                               const float* attn, const float* g_e,
+                               const uint16_t* g_z, int64_t g_z_stride, int32_t head_stride, int32_t x_copy_offset,
+                               const float* g_er, const float* w_lr, int64_t w_lr_stride,
+                               uint16_t* g_x, int64_t g_x_stride, float* g_el, int64_t g_s_stride,
+                               int64_t N, int64_t E, int32_t H, int32_t F,
+                               float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                               spgnn_stream_t stream);
+int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp,
+                          float* s, int64_t s_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 
 /* spgnn_scores_bwd_w with x as bf16 rows (the attention vectors' gradients g_s^T ft); J <= 8. */
 int spgnn_scores_bwd_w_bf16(const float* g_s, int64_t g_s_stride, const uint16_t* x, int64_t x_stride, float* partials,

@@ -206,6 +206,52 @@ def gat_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: 
     return rst, a
 
 
+def linear_mean_form(H: int, D: int, f_in: int, has_res_weight: bool) -> bool:
+    """Where the build's bf16 path evaluates an output GATConv (no activation, heads averaged) in the linear-mean form
+    below instead of projecting first: input narrower than a head, [z | x] no wider than the per-head rows, vector-aligned
+    widths, a learned (or no) residual.  Only the STORAGE POINTS differ between the two forms; in exact arithmetic they
+    are the same function (tests/test_oracle.py checks that)."""
+    return H in (1, 2, 4) and f_in < D and (H + 1) * f_in <= H * D and f_in % 8 == 0 and f_in <= 1024
+
+
+def gat_conv_linear_mean(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: Tensor, attn_l: Tensor,
+                         attn_r: Tensor, res_fc_weight: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+                         negative_slope: float = 0.2, attn_keep: Optional[Tensor] = None, storage=None) -> Tuple[Tensor, Tensor]:
+    """``gat_conv(..., activation=None)[0].mean(1)`` restated as ONE product (reference models.py:320-327,
+    ``self.gat_layers[-1](g, h).mean(1)`` with DGL's GATConv, Appendix A.1):
+        el = x (W_h^T attn_l_h),  z_h[v] = sum_u a_h(u, v) x[u],
+        mean_h(W_h z_h + Wres_h x + b_h) = [z_0 | .. | z_{H-1} | x] [W_0 | .. | W_{H-1} | sum_h Wres_h]^T / H + mean_h b_h.
+    Returns (mean (N, D), a (E, H)).  ``storage``: z and the combined weight are what the bf16 path stores rounded (the
+    scores come from the fp32 parameters, the product is kept in fp32); the gradients it stores are those of the
+    product, of [z | x] and of x."""
+    _, H, D = attn_l.shape
+    n, f_in = feat.shape
+    W = fc_weight.view(H, D, f_in)
+    w_l = (W * attn_l.view(H, D, 1)).sum(1)                          # (H, F)
+    w_r = (W * attn_r.view(H, D, 1)).sum(1)
+    xa = feat if storage is None else storage.round_grad(feat)       # the aggregate kernels store their g_x
+    el, er = xa @ w_l.t(), xa @ w_r.t()
+    e = F.leaky_relu(el.index_select(0, src) + er.index_select(0, dst), negative_slope)
+    a = edge_softmax(dst, e, num_nodes)
+    a_used = a if attn_keep is None else a * attn_keep
+    z = spmm_sum(src, dst, xa.unsqueeze(1).expand(n, H, f_in), num_nodes, a_used.unsqueeze(-1))   # (N, H, F)
+    if storage is not None:
+        z = storage.store_fwd(z)
+    zx = torch.cat([z.flatten(1), feat], dim=1)
+    if storage is not None:
+        zx = storage.round_grad(zx)
+    w_res = res_fc_weight.view(H, D, f_in).sum(0) if res_fc_weight is not None else fc_weight.new_zeros((D, f_in))
+    w_comb = torch.cat([W.permute(1, 0, 2).reshape(D, H * f_in), w_res], dim=1) / H
+    if storage is not None:
+        w_comb = storage.store_fwd(w_comb)
+    out = zx @ w_comb.t()
+    if bias is not None:
+        out = out + bias.view(H, D).mean(0)
+    if storage is not None:
+        out = storage.round_grad(out)                                # the incoming gradient is a bf16 GEMM operand
+    return out, a
+
+
 def graph_conv(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, weight: Tensor, bias: Optional[Tensor],
                activation: Optional[Callable] = None) -> Tensor:
     """dgl.nn.pytorch.GraphConv.forward with norm='both' (Appendix A.2)."""
@@ -292,8 +338,13 @@ def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, ac
         h = _gat_layer(sd, p, src, dst, n, h, negative_slope, activation, storage,
                        residual_identity=_is_identity_res(sd, p, residual)).flatten(1)
     p = f"{prefix}{L - 1}."
-    out = _gat_layer(sd, p, src, dst, n, h, negative_slope, None, storage, store_out=False,
-                     residual_identity=_is_identity_res(sd, p, residual)).mean(1)
+    _, H, D = sd[p + "attn_l"].shape
+    ident = _is_identity_res(sd, p, residual)
+    if storage is not None and not ident and linear_mean_form(H, D, h.shape[1], (p + "res_fc.weight") in sd):
+        out = gat_conv_linear_mean(src, dst, n, h, sd[p + "fc.weight"], sd[p + "attn_l"], sd[p + "attn_r"],
+                                   sd.get(p + "res_fc.weight"), sd.get(p + "bias"), negative_slope, storage=storage)[0]
+    else:
+        out = _gat_layer(sd, p, src, dst, n, h, negative_slope, None, storage, store_out=False, residual_identity=ident).mean(1)
     return F.normalize(out, p=2, dim=1) if norm else out
 
 

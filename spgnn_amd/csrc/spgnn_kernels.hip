@@ -1138,19 +1138,19 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
 // The three aggregate-first kernels take a team of T lanes per node: T = 64 (one node per wave, wave-uniform scalars) for
 // wide inputs, T = 16 (four nodes per wave, R <= 3 float4 per lane) for F <= 192: these kernels are latency-bound per node
 // (index -> score -> row chains), so four nodes in flight per wave is what fills the memory pipe.
-struct GatAggFwd {
+template <typename ST> struct GatAggFwdT {
   const int32_t* indptr; const int32_t* indices;
-  const float* x; int64_t x_ld;
+  const ST* x; int64_t x_ld;
   const float* el; const float* er; int64_t s_ld;
   float* attn;
-  float* z; int64_t z_ld; int zs; int xoff;
+  ST* z; int64_t z_ld; int zs; int xoff;
   float* absmax;                         // optional: absmax[v] = max |z row v| (split-GEMM scale of the operand)
   int64_t N; int F;
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R, int T>
-__global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
+template <typename ST, int H, int R, int T>
+__global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwdT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   const int lane = threadIdx.x % T;
   const int64_t v = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
   for (int h = 0; h < H; ++h) erv[h] = a.er[v * a.s_ld + h];
   float4 xs[R];                                     // the node's own row (residual operand)
 #pragma unroll
-  for (int r = 0; r < R; ++r) xs[r] = ld4(a.x + v * a.x_ld + col[r]);
+  for (int r = 0; r < R; ++r) xs[r] = ldv(a.x + v * a.x_ld + col[r]);
   float4 acc[H][R];
 #pragma unroll
   for (int h = 0; h < H; ++h)
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) xr[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
+        for (int r = 0; r < R; ++r) xr[q][r] = ldv(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float4 xr = ld4(a.x + u * a.x_ld + col[r]);
+        const float4 xr = ldv(a.x + u * a.x_ld + col[r]);
 #pragma unroll
         for (int h = 0; h < H; ++h) fma4(acc[h][r], w[h], xr);
       }
@@ -1262,10 +1262,10 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (!ok[r]) continue;
-      float* dst = a.z + v * a.z_ld + (int64_t)h * a.zs + col[r];
-      st4(dst, acc[h][r]);
+      ST* dst = a.z + v * a.z_ld + (int64_t)h * a.zs + col[r];
+      stv(dst, acc[h][r]);
       mxv = absmax4(mxv, acc[h][r]);
-      if (a.xoff >= 0) { st4(dst + a.xoff, xs[r]); mxv = absmax4(mxv, xs[r]); }
+      if (a.xoff >= 0) { stv(dst + a.xoff, xs[r]); mxv = absmax4(mxv, xs[r]); }
     }
   if (a.absmax) {
     mxv = team_max(mxv, T);
@@ -1273,19 +1273,19 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwd a) {
   }
 }
 
-struct GatAggBwdDst {
+template <typename ST> struct GatAggBwdDstT {
   const int32_t* indptr; const int32_t* indices;
-  const float* x; int64_t x_ld;
+  const ST* x; int64_t x_ld;
   const float* el; const float* er; int64_t s_ld;
   const float* attn;
-  const float* gz; int64_t gz_ld; int zs;          // gradient of the z blocks (same layout as z)
+  const ST* gz; int64_t gz_ld; int zs;             // gradient of the z blocks (same layout as z)
   float* g_e; float* g_er; int64_t gs_ld;
   int64_t N; int F;
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R, int T>
-__global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
+template <typename ST, int H, int R, int T>
+__global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDstT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   const int lane = threadIdx.x % T;
   const int64_t v = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float4 q = ld4(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]);
+      const float4 q = ldv(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]);
       g[h][r] = ok[r] ? q : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   float erv[H];
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) xr[q][r] = ld4(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
+        for (int r = 0; r < R; ++r) xr[q][r] = ldv(a.x + (int64_t)u[k0 + q] * a.x_ld + col[r]);
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
     const int64_t u = a.indices[j];
     float4 xr[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) xr[r] = ld4(a.x + u * a.x_ld + col[r]);
+    for (int r = 0; r < R; ++r) xr[r] = ldv(a.x + u * a.x_ld + col[r]);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float pd = 0.f;
@@ -1396,20 +1396,20 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDst a) {
   }
 }
 
-struct GatAggBwdSrc {
+template <typename ST> struct GatAggBwdSrcT {
   const int32_t* out_indptr; const int32_t* out_indices; const int32_t* out_pos;
   const float* attn; const float* g_e;
-  const float* gz; int64_t gz_ld; int zs; int xoff;
+  const ST* gz; int64_t gz_ld; int zs; int xoff;
   const float* g_er;                               // (N, H) at stride gs_ld, written by the dst-major half
   const float* w_lr; int64_t wlr_ld;               // (2H, F): g_x += [g_el | g_er] @ w_lr fused here
-  float* g_x; int64_t gx_ld;
+  ST* g_x; int64_t gx_ld;
   float* g_el; int64_t gs_ld;
   int64_t N; int F;
   float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
 
-template <int H, int R, int T>
-__global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
+template <typename ST, int H, int R, int T>
+__global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrcT<ST> a) {
   if (a.seed_off) a.seed += a.seed_off[0];
   const int lane = threadIdx.x % T;
   const int64_t u = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
     for (int h = 0; h < H; ++h)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float4 q = ld4(a.gz + u * a.gz_ld + (int64_t)h * a.zs + a.xoff + col[r]);
+        const float4 q = ldv(a.gz + u * a.gz_ld + (int64_t)h * a.zs + a.xoff + col[r]);
         acc[r].x += q.x; acc[r].y += q.y; acc[r].z += q.z; acc[r].w += q.w;
       }
   }
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int r = 0; r < R; ++r) gr[q][h][r] = ld4(a.gz + (int64_t)vv[k0 + q] * a.gz_ld + (int64_t)h * a.zs + col[r]);
+          for (int r = 0; r < R; ++r) gr[q][h][r] = ldv(a.gz + (int64_t)vv[k0 + q] * a.gz_ld + (int64_t)h * a.zs + col[r]);
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
         if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
         gel[h] += a.g_e[eidx];
 #pragma unroll
-        for (int r = 0; r < R; ++r) fma4(acc[r], w, ld4(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]));
+        for (int r = 0; r < R; ++r) fma4(acc[r], w, ldv(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]));
       }
     }
   }
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrc a) {
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (ok[r]) st4(a.g_x + u * a.gx_ld + col[r], acc[r]);
+    if (ok[r]) stv(a.g_x + u * a.gx_ld + col[r], acc[r]);
 }
 
 // out_mean[v, d] = mean_h out[v, h*D + d]  (vector form of head_mean_scalar; D % 4 == 0, 16-byte rows)
@@ -2032,8 +2032,8 @@ __global__ void spmm_max_bwd_scalar(SpmmMaxBwd a) {
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NG>      // NG 16-column groups: J <= 16 * NG
-__global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restrict__ X, int64_t ldx,
+template <typename ST, int NG>      // NG 16-column groups: J <= 16 * NG; ST: storage type of the rows of X (W, S fp32)
+__global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
                                                           float* __restrict__ absmax) {
@@ -2043,7 +2043,7 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   if (row0 >= N) return;
   const int r = lane & 15, q = lane >> 4;
   const bool rv = row0 + r < N;
-  const float* xp = X + (rv ? row0 + r : 0) * ldx + 4 * q;
+  const ST* xp = X + (rv ? row0 + r : 0) * ldx + 4 * q;
   bool wv[NG]; const float* wp[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -2066,7 +2066,7 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   for (; k0 + 64 <= kfull; k0 += 64) {
     float4 xa[4], wb[NG][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xa[u] = ld4(xp + k0 + 16 * u);
+    for (int u = 0; u < 4; ++u) xa[u] = ldv(xp + k0 + 16 * u);
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -2084,7 +2084,7 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
     }
   }
   for (; k0 < kfull; k0 += 16) {
-    const float4 xa = ld4(xp + k0);
+    const float4 xa = ldv(xp + k0);
     amx = fmaxf(amx, rvf * fmaxf(fmaxf(fabsf(xa.x), fabsf(xa.y)), fmaxf(fabsf(xa.z), fabsf(xa.w))));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -2098,11 +2098,12 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const float* __restric
   if (kfull < K) {                      // ragged tail: element-wise guards on X (W is zero padded)
     const int k0 = kfull, k = k0 + 4 * q;
     float4 xa = z4;
-    if (rv) {
-      if (k + 0 < K) xa.x = xp[k0 + 0];
-      if (k + 1 < K) xa.y = xp[k0 + 1];
-      if (k + 2 < K) xa.z = xp[k0 + 2];
-      if (k + 3 < K) xa.w = xp[k0 + 3];
+    if (rv && k < K) {                  // the row stride is a multiple of 4 >= K: the whole chunk at k < K is inside the row
+      const float4 t_ = ldv(xp + k0);
+      if (k + 0 < K) xa.x = t_.x;
+      if (k + 1 < K) xa.y = t_.y;
+      if (k + 2 < K) xa.z = t_.z;
+      if (k + 3 < K) xa.w = t_.w;
     }
     amx = absmax4(amx, xa);
 #pragma unroll
@@ -2851,8 +2852,11 @@ static bool agg_team16(int F) { return SPGNN_AGG_TEAM16 && F <= 192; }
     default: return fail(SPGNN_ERR_SHAPE, "aggregate-first GAT: H must be 1, 2 or 4 and F <= 1024");  \
   }
 
-int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* el,
-                      const float* er, int64_t s_stride, float* attn, float* z, int64_t z_stride, int32_t head_stride,
+}  // extern "C"
+
+template <typename ST>
+static int gat_agg_fwd_impl(const char* name, const int32_t* indptr, const int32_t* indices, const ST* x, int64_t x_stride, const float* el,
+                      const float* er, int64_t s_stride, float* attn, ST* z, int64_t z_stride, int32_t head_stride,
                       int32_t x_copy_offset, float* absmax, int64_t N, int64_t E, int32_t H, int32_t F,
                       float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       spgnn_stream_t stream) {
@@ -2862,29 +2866,30 @@ int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float
   const int64_t need = x_copy_offset >= 0 ? (int64_t)x_copy_offset + F : F;
   if (x_stride < F || s_stride < H || head_stride < need || z_stride < (int64_t)H * head_stride || x_copy_offset >= 0 && x_copy_offset < F)
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: row stride / block layout too small");
-  if (!vec_ok(x, x_stride) || !vec_ok(z, z_stride) || (head_stride & 3) || (x_copy_offset > 0 && (x_copy_offset & 3)))
+  if (!vec_ok_t(x, x_stride) || !vec_ok_t(z, z_stride) || (head_stride & 3) || (x_copy_offset > 0 && (x_copy_offset & 3)))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: rows must be 16-byte aligned");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_fwd: p_drop not in [0,1)");
-  GatAggFwd a{indptr, indices, x, x_stride, el, er, s_stride, attn, z, z_stride, head_stride, x_copy_offset, absmax, N, F,
+  GatAggFwdT<ST> a{indptr, indices, x, x_stride, el, er, s_stride, attn, z, z_stride, head_stride, x_copy_offset, absmax, N, F,
               negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(kBlock);
   if (agg_team16(F)) {
     const dim3 grid(grid_for(N, kBlock / 16));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_, 16>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<ST, H_, R_, 16>), grid, block, 0, st, a)
     SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
   } else {
     const dim3 grid(grid_for(N, kBlock / 64));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<H_, R_, 64>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_fwd<ST, H_, R_, 64>), grid, block, 0, st, a)
     SPGNN_FOR_H_R(H, agg_chunks(F), X)
 #undef X
   }
-  return check_launch("spgnn_gat_agg_fwd");
+  return check_launch(name);
 }
 
-int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride,
-                          const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_z,
+template <typename ST>
+static int gat_agg_bwd_dst_impl(const char* name, const int32_t* indptr, const int32_t* indices, const ST* x, int64_t x_stride,
+                          const float* el, const float* er, int64_t s_stride, const float* attn, const ST* g_z,
                           int64_t g_z_stride, int32_t head_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
                           int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop, uint64_t seed,
                           const uint64_t* seed_offset, spgnn_stream_t stream) {
@@ -2894,30 +2899,31 @@ int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const f
     return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_bwd_dst: null pointer");
   if (x_stride < F || s_stride < H || g_s_stride < H || head_stride < F || g_z_stride < (int64_t)(H - 1) * head_stride + F)
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_dst: row stride / block layout too small");
-  if (!vec_ok(x, x_stride) || !vec_ok(g_z, g_z_stride) || (head_stride & 3))
+  if (!vec_ok_t(x, x_stride) || !vec_ok_t(g_z, g_z_stride) || (head_stride & 3))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_dst: rows must be 16-byte aligned");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_dst: p_drop not in [0,1)");
-  GatAggBwdDst a{indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride, head_stride, g_e, g_er, g_s_stride,
+  GatAggBwdDstT<ST> a{indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride, head_stride, g_e, g_er, g_s_stride,
                  N, F, negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(kBlock);
   if (agg_team16(F)) {
     const dim3 grid(grid_for(N, kBlock / 16));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_, 16>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<ST, H_, R_, 16>), grid, block, 0, st, a)
     SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
   } else {
     const dim3 grid(grid_for(N, kBlock / 64));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<H_, R_, 64>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_dst<ST, H_, R_, 64>), grid, block, 0, st, a)
     SPGNN_FOR_H_R(H, agg_chunks(F), X)
 #undef X
   }
-  return check_launch("spgnn_gat_agg_bwd_dst");
+  return check_launch(name);
 }
 
-int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
-                          const float* g_e, const float* g_z, int64_t g_z_stride, int32_t head_stride,
-                          int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, float* g_x,
+template <typename ST>
+static int gat_agg_bwd_src_impl(const char* name, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                          const float* g_e, const ST* g_z, int64_t g_z_stride, int32_t head_stride,
+                          int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, ST* g_x,
                           int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F,
                           float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_bwd_src: bad N/E/H/F");
@@ -2928,26 +2934,87 @@ int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices,
   if (g_x_stride < F || g_s_stride < H || head_stride < need || g_z_stride < (int64_t)(H - 1) * head_stride + need ||
       (w_lr && w_lr_stride < F))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_src: row stride / block layout too small");
-  if (!vec_ok(g_x, g_x_stride) || !vec_ok(g_z, g_z_stride) || !vec_ok(w_lr, w_lr_stride) || (head_stride & 3) ||
+  if (!vec_ok_t(g_x, g_x_stride) || !vec_ok_t(g_z, g_z_stride) || !vec_ok(w_lr, w_lr_stride) || (head_stride & 3) ||
       (x_copy_offset > 0 && (x_copy_offset & 3)))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_src: rows must be 16-byte aligned");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_src: p_drop not in [0,1)");
-  GatAggBwdSrc a{out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
+  GatAggBwdSrcT<ST> a{out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
                  w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, F, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(kBlock);
   if (agg_team16(F)) {
     const dim3 grid(grid_for(N, kBlock / 16));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_, 16>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<ST, H_, R_, 16>), grid, block, 0, st, a)
     SPGNN_FOR_H_R16(H, (F + 63) / 64, X)
 #undef X
   } else {
     const dim3 grid(grid_for(N, kBlock / 64));
-#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<H_, R_, 64>), grid, block, 0, st, a)
+#define X(H_, R_) hipLaunchKernelGGL((gat_agg_bwd_src<ST, H_, R_, 64>), grid, block, 0, st, a)
     SPGNN_FOR_H_R(H, agg_chunks(F), X)
 #undef X
   }
-  return check_launch("spgnn_gat_agg_bwd_src");
+  return check_launch(name);
+}
+
+extern "C" {
+
+int spgnn_gat_agg_fwd(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* el,
+                      const float* er, int64_t s_stride, float* attn, float* z, int64_t z_stride, int32_t head_stride,
+                      int32_t x_copy_offset, float* absmax, int64_t N, int64_t E, int32_t H, int32_t F,
+                      float negative_slope, float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                      spgnn_stream_t stream) {
+  return gat_agg_fwd_impl<float>("spgnn_gat_agg_fwd", indptr, indices, x, x_stride, el, er, s_stride, attn, z, z_stride, head_stride,
+                                 x_copy_offset, absmax, N, E, H, F, negative_slope, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_agg_fwd_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* x, int64_t x_stride, const float* el,
+                           const float* er, int64_t s_stride, float* attn, uint16_t* z, int64_t z_stride, int32_t head_stride,
+                           int32_t x_copy_offset, int64_t N, int64_t E, int32_t H, int32_t F, float negative_slope,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_agg_fwd_impl<bf16s>("spgnn_gat_agg_fwd_bf16", indptr, indices, reinterpret_cast<const bf16s*>(x), x_stride, el, er,
+                                 s_stride, attn, reinterpret_cast<bf16s*>(z), z_stride, head_stride, x_copy_offset, nullptr, N, E,
+                                 H, F, negative_slope, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride,
+                          const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_z,
+                          int64_t g_z_stride, int32_t head_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
+                          int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop, uint64_t seed,
+                          const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_agg_bwd_dst_impl<float>("spgnn_gat_agg_bwd_dst", indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride,
+                                     head_stride, g_e, g_er, g_s_stride, N, E, H, F, negative_slope, p_drop, seed, seed_offset,
+                                     stream);
+}
+
+int spgnn_gat_agg_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* x, int64_t x_stride,
+                               const float* el, const float* er, int64_t s_stride, const float* attn, const uint16_t* g_z,
+                               int64_t g_z_stride, int32_t head_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
+                               int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop, uint64_t seed,
+                               const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_agg_bwd_dst_impl<bf16s>("spgnn_gat_agg_bwd_dst_bf16", indptr, indices, reinterpret_cast<const bf16s*>(x), x_stride, el,
+                                     er, s_stride, attn, reinterpret_cast<const bf16s*>(g_z), g_z_stride, head_stride, g_e, g_er,
+                                     g_s_stride, N, E, H, F, negative_slope, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_agg_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                          const float* g_e, const float* g_z, int64_t g_z_stride, int32_t head_stride,
+                          int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, float* g_x,
+                          int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F,
+                          float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_agg_bwd_src_impl<float>("spgnn_gat_agg_bwd_src", out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride,
+                                     head_stride, x_copy_offset, g_er, w_lr, w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, E,
+                                     H, F, p_drop, seed, seed_offset, stream);
+}
+
+int spgnn_gat_agg_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                               const float* g_e, const uint16_t* g_z, int64_t g_z_stride, int32_t head_stride,
+                               int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, uint16_t* g_x,
+                               int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F,
+                               float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return gat_agg_bwd_src_impl<bf16s>("spgnn_gat_agg_bwd_src_bf16", out_indptr, out_indices, out_pos, attn, g_e,
+                                     reinterpret_cast<const bf16s*>(g_z), g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
+                                     w_lr_stride, reinterpret_cast<bf16s*>(g_x), g_x_stride, g_el, g_s_stride, N, E, H, F, p_drop,
+                                     seed, seed_offset, stream);
 }
 
 int spgnn_head_mean(const float* out, int64_t out_stride, float* out_mean, int64_t out_mean_stride, int64_t N, int32_t H,
@@ -3169,10 +3236,27 @@ int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t K
   const int64_t waves = (N + 15) / 16;          // one wave per 16 rows (the kernel derives its rows from kBlock too)
   const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
   if (J <= 16)
-    hipLaunchKernelGGL(scores_fwd_mfma<1>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
+    hipLaunchKernelGGL((scores_fwd_mfma<float, 1>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
   else
-    hipLaunchKernelGGL(scores_fwd_mfma<2>, grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
+    hipLaunchKernelGGL((scores_fwd_mfma<float, 2>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
   return check_launch("spgnn_scores_fwd");
+}
+
+int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
+                          int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  if (N < 0 || K <= 0 || J <= 0 || J > 32 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd_bf16: bad N/K/Kp/J");
+  if (N == 0) return SPGNN_OK;
+  if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd_bf16: null pointer");
+  if (x_stride < K || s_stride < J || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 7) || !aligned16(w))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd_bf16: x rows must be 8-byte aligned (stride % 4 == 0), w 16-byte aligned");
+  const int64_t waves = (N + 15) / 16;
+  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
+  const bf16s* xb = reinterpret_cast<const bf16s*>(x);
+  if (J <= 16)
+    hipLaunchKernelGGL((scores_fwd_mfma<bf16s, 1>), grid, block, 0, (hipStream_t)stream, xb, x_stride, w, Kp, s, s_stride, N, K, J, nullptr);
+  else
+    hipLaunchKernelGGL((scores_fwd_mfma<bf16s, 2>), grid, block, 0, (hipStream_t)stream, xb, x_stride, w, Kp, s, s_stride, N, K, J, nullptr);
+  return check_launch("spgnn_scores_fwd_bf16");
 }
 
 static int padded_j(int J) { return J <= 2 ? 2 : J <= 4 ? 4 : J <= 8 ? 8 : J <= 16 ? 16 : J <= 24 ? 24 : 32; }

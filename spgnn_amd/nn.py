@@ -174,6 +174,14 @@ class GATConv(nn.Module):
             # bf16-storage path (BASELINE config 4): project-first on the bf16 matrix cores, fp32 parameters and scores
             if not ops_bf16.gat_layer_supported(h, H, D):
                 raise DGLError(f"bf16 GATConv needs a ROCm device, out_feats % 64 == 0 and in_feats % 4 == 0 (got {tuple(h.shape)} -> {H}x{D})")
+            F_in = h.shape[1]
+            if (LINEAR_MEAN and fuse_mean and fuse_out is None and act == ops.ACT_NONE and F_in < D and (H + 1) * F_in <= H * D
+                    and getattr(csc, "num_dst", None) is None and ops_bf16.linear_mean_supported(h, H, F_in)):
+                # output layer without activation, heads averaged: one product on [z_0 .. z_{H-1} | x] (ops._GATAggregateFn)
+                w_lr = ops.fold_scores(w_fc, self.attn_l, self.attn_r)
+                out, attn = ops_bf16.gat_layer_linear_mean(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias,
+                                                           H, D, float(self.negative_slope), p, seed)
+                return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
             fuse_mean = fuse_mean and ops.can_fuse_mean(H, D)
             if fuse_out is not None:
                 total, fp, fseed, extra = fuse_out

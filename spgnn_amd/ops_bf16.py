@@ -19,7 +19,8 @@ import torch
 
 from . import _capi
 from .graph import DeviceCSC
-from .ops import (ACT_NONE, _ell, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts)
+from .ops import (ACT_NONE, _ell, _pad16, _padded_rows, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts,
+                  sum_partials)
 
 BF16 = torch.bfloat16
 
@@ -287,6 +288,143 @@ def gat_layer(csc: DeviceCSC, x, w_fc, w_res, attn_l, attn_r, bias, H: int, D: i
     _require_cuda(x, w_fc, w_res, attn_l, attn_r, bias)
     return _GATLayerBf16Fn.apply(as_rows(x), w_fc, w_res, attn_l, attn_r, bias, csc, H, D, slope, act, p_drop, seed, mean,
                                  out_drop)
+
+
+# --------------------------------------------------------------------------------------------
+# GAT output layer without activation, heads averaged: one product on [z_0 | .. | z_{H-1} | x]  (ops._GATAggregateFn)
+# --------------------------------------------------------------------------------------------
+def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor) -> torch.Tensor:
+    """S = x @ w_lr^T (N, J) fp32, x bf16 rows, w_lr (J, K) fp32 (the attention vectors folded through W_fc)."""
+    N, K = x.shape
+    J = w_lr.shape[0]
+    Kp = _pad16(K)
+    w_p = _padded_rows(w_lr, Kp)
+    s = torch.empty((N, J), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("scores_fwd_bf16", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_fwd_bf16(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
+                                                       N, K, J, _stream(x)), "spgnn_scores_fwd_bf16")
+    return s
+
+
+def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g_w_lr = g_s^T @ x (J, K) fp32, x bf16 rows; J <= 8."""
+    N, K = x.shape
+    J = g_s.shape[1]
+    Kp = _pad16(K)
+    splits = max(1, min(1024 // ((K + 255) // 256), N // 16))
+    part = torch.empty((splits, J, Kp), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("scores_bwd_w_bf16", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_bwd_w_bf16(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(),
+                                                         splits, Kp, N, K, J, _stream(x)), "spgnn_scores_bwd_w_bf16")
+    return sum_partials(part)[:, :K]
+
+
+def linear_mean_supported(x: torch.Tensor, H: int, F_in: int) -> bool:
+    """bf16 rows the aggregate kernels and the GEMM can read: F % 8 == 0 keeps every block of Zx 16-byte aligned."""
+    return (x.is_cuda and x.dtype == BF16 and x.dim() == 2 and x.shape[0] > 0 and F_in % 8 == 0 and 2 * H <= 8
+            and bool(_capi.load().spgnn_gat_agg_supported(H, F_in)))
+
+
+class _GATAggregateBf16Fn(torch.autograd.Function):
+    """ops._GATAggregateFn on bf16 rows: x (N, F) -> Zx = [z_0 | .. | z_{H-1} | x] (N, (H+1) F) bf16, scores and attention
+    fp32.  ``w_lr`` (2H, F) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w_lr, csc: DeviceCSC, H: int, slope: float, p_drop: float, seed: int):
+        ctx.set_materialize_grads(False)
+        N, F_ = x.shape
+        E = csc.num_edges
+        s = scores_fwd(x, w_lr)
+        zx = empty_rows(N, (H + 1) * F_, x.device)
+        attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _timed("gat_agg_fwd_bf16", (N, E, H, F_, 0)):
+            _capi.check(_capi.load().spgnn_gat_agg_fwd_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                            s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                            zx.data_ptr(), zx.stride(0), F_, -1, N, E, H, F_, slope, p_drop, seed,
+                                                            _seed_off_ptr(x.device), _stream(x)), "spgnn_gat_agg_fwd_bf16")
+        zx[:, H * F_:].copy_(x)
+        ctx.csc, ctx.cfg = csc, (H, slope, p_drop, seed)
+        ctx.save_for_backward(x, w_lr, s, attn)
+        ctx.mark_non_differentiable(attn)
+        return zx, attn
+
+    @staticmethod
+    def backward(ctx, g_zx, _g_attn):
+        if g_zx is None:
+            return (None,) * 7
+        x, w_lr, s, attn = ctx.saved_tensors
+        H, slope, p_drop, seed = ctx.cfg
+        csc = ctx.csc
+        N, F_ = x.shape
+        E = csc.num_edges
+        if g_zx.dtype != BF16 or g_zx.stride(1) != 1 or g_zx.stride(0) % 4 or g_zx.data_ptr() % 8:
+            g_zx = g_zx.to(BF16).contiguous()
+        g_s = torch.empty_like(s)
+        g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
+        g_x = empty_rows(N, F_, x.device)
+        w_lr_c = w_lr.contiguous()
+        lib = _capi.load()
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            with _timed("gat_agg_bwd_dst_bf16", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                           s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                           g_zx.data_ptr(), g_zx.stride(0), F_, g_e.data_ptr(),
+                                                           g_s[:, H:].data_ptr(), g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
+                                                           _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst_bf16")
+            with _timed("gat_agg_bwd_src_bf16", (N, E, H, F_)):
+                _capi.check(lib.spgnn_gat_agg_bwd_src_bf16(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                           csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(),
+                                                           g_zx.data_ptr(), g_zx.stride(0), F_, -1, g_s[:, H:].data_ptr(),
+                                                           w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
+                                                           g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
+                                                           _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src_bf16")
+        g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0]:
+            g_x += g_zx[:, H * F_:]                      # the copy of x inside Zx (fp32 add, one rounding)
+        return (g_x if ctx.needs_input_grad[0] else None), g_wlr, None, None, None, None, None
+
+
+class _LinearBf16Fn(torch.autograd.Function):
+    """x (N, K) bf16 rows, fp32 ``weight`` (C, K) / ``bias`` (C,) -> x W^T + b as an fp32 (N, C) tensor: bf16 MFMA, fp32
+    accumulate.  Backward: the incoming fp32 gradient is rounded to bf16 rows once (it is a GEMM operand twice), input
+    gradient as bf16 rows, weight / bias gradients fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w, w_t = weight_operands(weight, None, want_t=ctx.needs_input_grad[0])
+        y = gemm_nt(x, w, out_f32=True, bias=bias)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_t = ctx.saved_tensors
+        gb = cast_rows(g if g.dtype == torch.float32 else g.float())
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = gemm_nt(gb, w_t)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.has_bias:
+                g_w, g_b = gemm_tn(gb, x, want_colsum=True)
+            else:
+                g_w = gemm_tn(gb, x)
+        return g_x, g_w, g_b
+
+
+def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
+                          seed: int = 0):
+    """ops.gat_layer_linear_mean on bf16 rows -> (mean (N, D) fp32, attn (E, H) fp32).  The combined weight is assembled
+    from the fp32 parameters by a few tiny torch ops (autograd hands its fp32 gradient back to w_fc / w_res / bias)."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias)
+    F_ = x.shape[1]
+    zx, attn = _GATAggregateBf16Fn.apply(as_rows(x), w_lr, csc, H, slope, p_drop, seed)
+    parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
+    parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
+    w_comb = torch.cat(parts, dim=1) * (1.0 / H)
+    b_mean = bias.view(H, D).mean(0) if bias is not None else None
+    return _LinearBf16Fn.apply(zx, w_comb, b_mean), attn
 
 
 class _CatDropoutBf16(torch.autograd.Function):

@@ -47,6 +47,25 @@ def test_gat_edge_list_vs_dense_fp64(H, D, res):
             assert torch.allclose(a, b, atol=1e-11, rtol=0)
 
 
+@pytest.mark.parametrize("H,D,res", [(2, 24, True), (4, 16, False), (1, 16, True)])
+def test_gat_linear_mean_form_is_the_same_function(H, D, res):
+    """The output layer's linear-mean restatement (one product on [z_0 .. z_{H-1} | x]) equals
+    ``gat_conv(..., activation=None).mean(1)`` (reference models.py:320-327) in fp64: value, attention, every gradient."""
+    src, dst, n = _batch_edges([7, 12], seed=3)
+    gen = torch.Generator().manual_seed(1)
+    fin = 8
+    leaves = dict(x=_leaf((n, fin), gen), w=_leaf((H * D, fin), gen, 0.5), al=_leaf((1, H, D), gen), ar=_leaf((1, H, D), gen),
+                  wr=_leaf((H * D, fin), gen, 0.5) if res else None, b=_leaf((H * D,), gen))
+    r1, a1 = O.gat_conv(src, dst, n, leaves["x"], leaves["w"], leaves["al"], leaves["ar"], leaves["wr"], leaves["b"], 0.2, None)
+    r2, a2 = O.gat_conv_linear_mean(src, dst, n, leaves["x"], leaves["w"], leaves["al"], leaves["ar"], leaves["wr"], leaves["b"], 0.2)
+    r1 = r1.mean(1)
+    assert torch.allclose(r1, r2, atol=1e-12, rtol=0) and torch.allclose(a1, a2, atol=1e-13, rtol=0)
+    cot = torch.randn(r1.shape, generator=gen, dtype=torch.float64)
+    ls = [p for p in leaves.values() if p is not None]
+    for a, b in zip(torch.autograd.grad((r1 * cot).sum(), ls), torch.autograd.grad((r2 * cot).sum(), ls)):
+        assert torch.allclose(a, b, atol=1e-11, rtol=0)
+
+
 def test_gcn_gin_sage_edge_list_vs_dense_fp64():
     src, dst, n = _batch_edges([5, 8, 4], seed=2)
     gen = torch.Generator().manual_seed(1)
