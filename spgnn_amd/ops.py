@@ -41,12 +41,14 @@ class KernelTimer:
     enabled = False
     records: dict = {}
     only = None          # when set: record these (kernel, shape) keys only (a few events per step: no perturbation)
+    sequence: list = []  # the recorded keys in launch order (tools/pmc_step.py matches profiler rows to keys with it)
 
     @classmethod
     def start(cls, only=None):
         if only is not None and only and not isinstance(next(iter(only)), tuple):
             only = (tuple(only),)                      # a single key
         cls.records, cls.enabled, cls.only = {}, True, (None if only is None else frozenset(only))
+        cls.sequence = []
 
     @classmethod
     def stop(cls):
@@ -74,6 +76,7 @@ class _timed:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             KernelTimer.records.setdefault(self.key, []).append((self.a, b))
+            KernelTimer.sequence.append(self.key)
         return False
 
 
