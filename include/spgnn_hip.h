@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 27
+#define SPGNN_ABI_VERSION 28
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -591,7 +591,11 @@ int spgnn_gat_agg_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_ind
 int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp,
                           float* s, int64_t s_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 
-/* spgnn_scores_bwd_w with x as bf16 rows (the attention vectors' gradients g_s^T ft); J <= 8. */
+/* spgnn_scores_bwd_x writing (or accumulating into) bf16 rows g_x; the row padding up to a multiple of 4 is written as zeros. */
+int spgnn_scores_bwd_x_bf16(const float* g_s, int64_t g_s_stride, const float* w, int32_t Kp, uint16_t* g_x, int64_t g_x_stride,
+                            int32_t accumulate, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+
+/* spgnn_scores_bwd_w with x as bf16 rows (the attention vectors' gradients g_s^T ft; the folded classifier's g_logits^T Zx). */
 int spgnn_scores_bwd_w_bf16(const float* g_s, int64_t g_s_stride, const uint16_t* x, int64_t x_stride, float* partials,
                             int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 

@@ -216,14 +216,17 @@ def linear_mean_form(H: int, D: int, f_in: int, has_res_weight: bool) -> bool:
 
 def gat_conv_linear_mean(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_weight: Tensor, attn_l: Tensor,
                          attn_r: Tensor, res_fc_weight: Optional[Tensor] = None, bias: Optional[Tensor] = None,
-                         negative_slope: float = 0.2, attn_keep: Optional[Tensor] = None, storage=None) -> Tuple[Tensor, Tensor]:
+                         negative_slope: float = 0.2, attn_keep: Optional[Tensor] = None, storage=None,
+                         round_out_grad: bool = True) -> Tuple[Tensor, Tensor]:
     """``gat_conv(..., activation=None)[0].mean(1)`` restated as ONE product (reference models.py:320-327,
     ``self.gat_layers[-1](g, h).mean(1)`` with DGL's GATConv, Appendix A.1):
         el = x (W_h^T attn_l_h),  z_h[v] = sum_u a_h(u, v) x[u],
         mean_h(W_h z_h + Wres_h x + b_h) = [z_0 | .. | z_{H-1} | x] [W_0 | .. | W_{H-1} | sum_h Wres_h]^T / H + mean_h b_h.
     Returns (mean (N, D), a (E, H)).  ``storage``: z and the combined weight are what the bf16 path stores rounded (the
     scores come from the fp32 parameters, the product is kept in fp32); the gradients it stores are those of the
-    product, of [z | x] and of x."""
+    product, of [z | x] and of x.  ``round_out_grad=False``: the product's gradient is never stored - the build joins the
+    *Net's classifier to this node and, when only the logits carry a gradient, goes from the fp32 logit gradient to the
+    gradient of [z | x] directly (ops_bf16._LinearClassifierBf16Fn)."""
     _, H, D = attn_l.shape
     n, f_in = feat.shape
     W = fc_weight.view(H, D, f_in)
@@ -247,7 +250,7 @@ def gat_conv_linear_mean(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor,
     out = zx @ w_comb.t()
     if bias is not None:
         out = out + bias.view(H, D).mean(0)
-    if storage is not None:
+    if storage is not None and round_out_grad:
         out = storage.round_grad(out)                                # the incoming gradient is a bf16 GEMM operand
     return out, a
 
@@ -328,7 +331,7 @@ def _is_identity_res(sd, prefix: str, residual: bool) -> bool:
 
 
 def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, activation=F.elu, norm=False, storage=None,
-              residual=True):
+              residual=True, classifier_joined=False):
     """reference models.py:321-329 (GAT.forward).  ``residual``: the stack was built with ``residual=True`` (every
     shipped GAT config): layers without a ``res_fc.weight`` whose widths match then carry DGL's identity residual."""
     L = _count_layers(sd, prefix)
@@ -342,7 +345,8 @@ def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, ac
     ident = _is_identity_res(sd, p, residual)
     if storage is not None and not ident and linear_mean_form(H, D, h.shape[1], (p + "res_fc.weight") in sd):
         out = gat_conv_linear_mean(src, dst, n, h, sd[p + "fc.weight"], sd[p + "attn_l"], sd[p + "attn_r"],
-                                   sd.get(p + "res_fc.weight"), sd.get(p + "bias"), negative_slope, storage=storage)[0]
+                                   sd.get(p + "res_fc.weight"), sd.get(p + "bias"), negative_slope, storage=storage,
+                                   round_out_grad=not classifier_joined)[0]
     else:
         out = _gat_layer(sd, p, src, dst, n, h, negative_slope, None, storage, store_out=False, residual_identity=ident).mean(1)
     return F.normalize(out, p=2, dim=1) if norm else out
@@ -520,7 +524,8 @@ def net_forward(kind: str, sd: Dict[str, Tensor], src, dst, n, fvs, pos_enc=None
     def sub(pfx):
         return {k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)}
     if kind == "gat":
-        emb = (gat_stack(sub("gat."), src, dst, n, fvs, **kw),)
+        # under a storage model: the *Net's classifier is joined to the output layer's node and the loss reads the logits only
+        emb = (gat_stack(sub("gat."), src, dst, n, fvs, classifier_joined=kw.get("storage") is not None, **kw),)
     elif kind == "spgnn_pel":
         emb = spgnn_pel_stack(sub("gat."), src, dst, n, fvs, pos_enc, **kw)
     elif kind == "spgnn_penl":

@@ -2201,10 +2201,10 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
     }
 }
 
-template <int J>
+template <typename ST, int J>     // ST: storage type of the rows of gX (gS, W fp32)
 __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restrict__ gS, int64_t ldg,
                                                           const float* __restrict__ W, int Kp,
-                                                          float* __restrict__ gX, int64_t ldgx, int64_t N, int K,
+                                                          ST* __restrict__ gX, int64_t ldgx, int64_t N, int K,
                                                           int64_t rows_per_split, int jn, int accumulate) {
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // a block's waves sit side by side on one row: 4 KB contiguous per row
   if (k >= K) return;
@@ -2220,13 +2220,19 @@ __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < J; ++j)
       if (j < jn) fma4(d, g[j], w[j]);
-    float* xr = gX + n * ldgx + k;
-    if (accumulate) {
-      if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
-      else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
-    } else {
-      if (full) st4(xr, d);
-      else { xr[0] = d.x; if (k + 1 < K) xr[1] = d.y; if (k + 2 < K) xr[2] = d.z; }
+    ST* xr = gX + n * ldgx + k;
+    if constexpr (is_f32<ST>::value) {
+      if (accumulate) {
+        if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
+        else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
+      } else {
+        if (full) st4(xr, d);
+        else { xr[0] = d.x; if (k + 1 < K) xr[1] = d.y; if (k + 2 < K) xr[2] = d.z; }
+      }
+    } else {                            // bf16 rows: whole 4-element chunks (the row padding up to a multiple of 4 is zero filled)
+      if (accumulate) { const float4 o = ldv(xr); d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
+      d.y = k + 1 < K ? d.y : 0.f; d.z = k + 2 < K ? d.z : 0.f; d.w = k + 3 < K ? d.w : 0.f;
+      stv(xr, d);
     }
   }
 }
@@ -3280,7 +3286,7 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
 
 int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* x, int64_t x_stride, float* part,
                             int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
-  if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 8)
+  if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32)
     return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w_bf16: bad N/K/Kp/splits/J (J <= 8)");
   if (!gs || !x || !part) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w_bf16: null pointer");
   const bf16s* x_ = reinterpret_cast<const bf16s*>(x);
@@ -3290,7 +3296,8 @@ int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* 
   const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define X(JP) hipLaunchKernelGGL((scores_bwd_w_kernel<bf16s, JP>), grid, block, 0, st, gs, gs_stride, x_, x_stride, part, Kp, N, K, rps, J)
-  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; default: X(8); break; }
+  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
+                         case 24: X(24); break; default: X(32); break; }
 #undef X
   return check_launch("spgnn_scores_bwd_w_bf16");
 }
@@ -3313,11 +3320,32 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
   const int64_t rps = (N + splits - 1) / splits;
   const dim3 grid((unsigned)((K + 255) / 256), (unsigned)((N + rps - 1) / rps)), block(64);
   hipStream_t st = (hipStream_t)stream;
-#define X(JP) hipLaunchKernelGGL(scores_bwd_x_kernel<JP>, grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps, J, accumulate)
+#define X(JP) hipLaunchKernelGGL((scores_bwd_x_kernel<float, JP>), grid, block, 0, st, gs, gs_stride, w, Kp, gx, gx_stride, N, K, rps, J, accumulate)
   switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
                          case 24: X(24); break; default: X(32); break; }
 #undef X
   return check_launch("spgnn_scores_bwd_x");
+}
+
+int spgnn_scores_bwd_x_bf16(const float* gs, int64_t gs_stride, const float* w, int32_t Kp, uint16_t* gx, int64_t gx_stride,
+                            int32_t accumulate, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  if (N < 0 || K <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x_bf16: bad N/K/Kp/J");
+  if (N == 0) return SPGNN_OK;
+  if (!gs || !w || !gx) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_x_bf16: null pointer");
+  bf16s* gx_ = reinterpret_cast<bf16s*>(gx);
+  if (gx_stride < ((K + 3) & ~3) || gs_stride < J || !vec_ok_t(gx_, gx_stride) || !aligned16(w))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_x_bf16: gx rows must be 8-byte aligned with a stride that is a multiple of 4 >= K");
+  int64_t splits = SPGNN_BWDX_WAVES / ((K + 255) / 256);
+  if (splits < 1) splits = 1;
+  if (splits > N) splits = N;
+  const int64_t rps = (N + splits - 1) / splits;
+  const dim3 grid((unsigned)((K + 255) / 256), (unsigned)((N + rps - 1) / rps)), block(64);
+  hipStream_t st = (hipStream_t)stream;
+#define X(JP) hipLaunchKernelGGL((scores_bwd_x_kernel<bf16s, JP>), grid, block, 0, st, gs, gs_stride, w, Kp, gx_, gx_stride, N, K, rps, J, accumulate)
+  switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
+                         case 24: X(24); break; default: X(32); break; }
+#undef X
+  return check_launch("spgnn_scores_bwd_x_bf16");
 }
 
 int spgnn_tree_distance_encoding(const int32_t* out_indptr, const int32_t* out_indices, const int64_t* tree_ptr,

@@ -179,8 +179,11 @@ class GATConv(nn.Module):
                     and getattr(csc, "num_dst", None) is None and ops_bf16.linear_mean_supported(h, H, F_in)):
                 # output layer without activation, heads averaged: one product on [z_0 .. z_{H-1} | x] (ops._GATAggregateFn)
                 w_lr = ops.fold_scores(w_fc, self.attn_l, self.attn_r)
-                out, attn = ops_bf16.gat_layer_linear_mean(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias,
-                                                           H, D, float(self.negative_slope), p, seed)
+                args = (csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D, float(self.negative_slope), p, seed)
+                if FUSE_CLASSIFIER and classifier is not None and classifier.in_features == D:
+                    out, attn, logits = ops_bf16.gat_layer_linear_mean(*args, w_cls=classifier.weight, b_cls=classifier.bias)
+                    return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, False), logits
+                out, attn = ops_bf16.gat_layer_linear_mean(*args)
                 return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
             fuse_mean = fuse_mean and ops.can_fuse_mean(H, D)
             if fuse_out is not None:
@@ -227,8 +230,11 @@ class GATConv(nn.Module):
                 and getattr(csc, "num_dst", None) is None):
             # no activation between the projection and the head mean: the layer is linear in [z_0 .. z_{H-1} | x]
             # (ops._GATAggregateFn): one product, no per-head (N, H*D) tensors in either direction
-            out, attn = ops.gat_layer_linear_mean(csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D,
-                                                  float(self.negative_slope), p, seed)
+            args = (csc, h, w_fc, self.res_fc.weight if has_res else None, w_lr, self.bias, H, D, float(self.negative_slope), p, seed)
+            if FUSE_CLASSIFIER and classifier is not None and classifier.in_features == D:
+                out, attn, logits = ops.gat_layer_linear_mean(*args, w_cls=classifier.weight, b_cls=classifier.bias)
+                return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, False), logits
+            out, attn = ops.gat_layer_linear_mean(*args)
             return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
         if agg_first:
             # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)

@@ -545,6 +545,84 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+class _LinearClassifierFn(torch.autograd.Function):
+    """y = x W^T + b (N, C) and a skinny classifier on it, logits = y Wc^T + bc (J <= 32), as ONE autograd node (the *Net's
+    ``gnn_out`` on the output layer's head mean: reference models.py:921-933 with 320-327).  When only the logits carry a
+    gradient (the training step: the embedding is returned but not part of the loss) the (N, C) gradient of y is never
+    formed: with P = Wc W,  g_x = g_logits P,  g_W = Wc^T (g_logits^T x),  g_b = Wc^T colsum(g_logits) - two skinny passes
+    over x instead of two GEMMs over an (N, C) tensor.  Otherwise g_y + g_logits Wc takes the ordinary route."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_cls, b_cls):
+        ctx.set_materialize_grads(False)
+        x = _rowmajor(x)
+        if not _rows_aligned(x):
+            x = cat_padded((x,))
+        w = weight if weight.stride(1) == 1 else weight.contiguous()
+        if not _rows_aligned(w):
+            w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
+        sx, sw = pow2_scale(x), pow2_scale(w)
+        y = gemm_nt(x, w, sx, sw, bias=bias)
+        logits = scores_fwd(y, w_cls)
+        if b_cls is not None:
+            logits += b_cls
+        ctx.has_bias, ctx.has_bcls = bias is not None, b_cls is not None
+        ctx.save_for_backward(x, w, sx, sw, y, w_cls)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, g_y, g_logits):
+        if g_y is None and g_logits is None:
+            return None, None, None, None, None
+        x, w, sx, sw, y, w_cls = ctx.saved_tensors
+        N, K = x.shape
+        C = w.shape[0]
+        g_x = g_w = g_b = g_wcls = g_bcls = None
+        cs = None
+        if g_logits is not None:
+            g_logits = _rowmajor(g_logits)
+            if ctx.needs_input_grad[3]:
+                g_wcls = scores_bwd_w(g_logits, y)
+            if ctx.has_bcls and ctx.needs_input_grad[4] or (g_y is None and ctx.has_bias and ctx.needs_input_grad[2]):
+                cs = g_logits.sum(0)
+            g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[4] else None
+        if g_y is None:                                   # the folded route: no (N, C) gradient
+            wc = w_cls.detach()
+            if ctx.needs_input_grad[0]:
+                g_x = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :K]
+                scores_bwd_x_(g_x, g_logits, torch.mm(wc, w), accumulate=False)
+            if ctx.needs_input_grad[1]:
+                g_w = torch.mm(wc.t(), scores_bwd_w(g_logits, x))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                g_b = torch.mv(wc.t(), cs)
+            return g_x, g_w, g_b, g_wcls, g_bcls
+        g = _rowmajor(g_y)
+        if g_logits is not None:
+            g = g.clone() if g.data_ptr() == g_y.data_ptr() else g
+            if not _rows_aligned(g):
+                g = cat_padded((g,))
+            scores_bwd_x_(g, g_logits, w_cls.detach(), accumulate=True)
+        elif not _rows_aligned(g):
+            g = cat_padded((g,))
+        sg = pow2_scale(g)
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :K]
+            w_t = w.t().contiguous() if C % 4 == 0 else torch.nn.functional.pad(w.t(), (0, -C % 4)).contiguous()[:, :C]
+            gemm_nt(g, w_t, sg, sw, out=g_x)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.has_bias:
+                g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
+            else:
+                g_w = gemm_tn(g, x, sg, sx)
+        return g_x, g_w, g_b, g_wcls, g_bcls
+
+
+def linear_classifier_supported(x: torch.Tensor, weight: torch.Tensor, w_cls: torch.Tensor) -> bool:
+    return (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= 512 and weight.shape[0] >= 32
+            and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and w_cls.shape[0] <= 32 and w_cls.shape[1] == weight.shape[0] and weight.shape[0] % 4 == 0)
+
+
 class _CatDropout(torch.autograd.Function):
     """dropout(cat(tensors, dim=1), p) in one pass per source into a buffer with 16-byte rows; the keep mask is a
     counter hash of (seed, element) that the backward regenerates - no mask tensor, no separate cat copy."""
@@ -1207,17 +1285,26 @@ class _GATAggregateFn(torch.autograd.Function):
 
 
 def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
-                          seed: int = 0):
+                          seed: int = 0, w_cls=None, b_cls=None):
     """mean over heads of a GATConv WITHOUT activation (see _GATAggregateFn) -> (mean (N, D), attn (E, H)).  The weight
-    assembly below is a few tiny torch ops, so autograd hands the gradients back to ``w_fc`` / ``w_res`` / ``bias``."""
-    _require_cuda(x, w_fc, w_res, w_lr, bias)
+    assembly below is a few tiny torch ops, so autograd hands the gradients back to ``w_fc`` / ``w_res`` / ``bias``.
+    With a classifier (``w_cls`` (J, D), ``b_cls``): -> (mean, attn, logits), the classifier joined to the product's node
+    (_LinearClassifierFn) when its shapes allow, a plain ``linear`` after it otherwise."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias, w_cls, b_cls)
     F_ = x.shape[1]
     zx, attn = _GATAggregateFn.apply(x, w_lr, csc, H, slope, p_drop, seed)
     parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
     parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
     w_comb = torch.cat(parts, dim=1) * (1.0 / H)
     b_mean = bias.view(H, D).mean(0) if bias is not None else None
-    return linear(zx, w_comb, b_mean), attn
+    if w_cls is None:
+        return linear(zx, w_comb, b_mean), attn
+    if linear_classifier_supported(zx, w_comb, w_cls):
+        out, logits = _LinearClassifierFn.apply(zx, w_comb, b_mean, w_cls, b_cls)
+    else:
+        out = linear(zx, w_comb, b_mean)
+        logits = torch.nn.functional.linear(out, w_cls, b_cls)
+    return out, attn, logits
 
 
 def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, act: int,

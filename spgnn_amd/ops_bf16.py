@@ -19,8 +19,9 @@ import torch
 
 from . import _capi
 from .graph import DeviceCSC
-from .ops import (ACT_NONE, _ell, _pad16, _padded_rows, _ptr, _require_cuda, _seed_off_ptr, _stream, _timed, scores_from_parts,
-                  sum_partials)
+from .ops import (ACT_NONE, _ell, _pad16, _padded_rows, _ptr, _require_cuda, _rowmajor, _seed_off_ptr, _stream, _timed,
+                  scores_from_parts, sum_partials)
+from . import ops as _ops
 
 BF16 = torch.bfloat16
 
@@ -413,18 +414,95 @@ class _LinearBf16Fn(torch.autograd.Function):
         return g_x, g_w, g_b
 
 
+def scores_bwd_x(g_s: torch.Tensor, w: torch.Tensor, K: int) -> torch.Tensor:
+    """g_x = g_s @ w (N, K) as bf16 rows; g_s (N, J <= 32) fp32, w (J, K) fp32."""
+    N, J = g_s.shape
+    Kp = _pad16(K)
+    w_p = _padded_rows(w, Kp)
+    g_x = torch.empty((N, _pad8(K)), dtype=BF16, device=g_s.device)
+    if _pad8(K) > (K + 3) // 4 * 4:
+        g_x[:, (K + 3) // 4 * 4:].zero_()
+    with torch.cuda.device(g_s.device), _timed("scores_bwd_x_bf16", (N, K, J)):
+        _capi.check(_capi.load().spgnn_scores_bwd_x_bf16(g_s.data_ptr(), g_s.stride(0), w_p.data_ptr(), Kp, g_x.data_ptr(), g_x.stride(0),
+                                                         0, N, K, J, _stream(g_s)), "spgnn_scores_bwd_x_bf16")
+    return g_x[:, :K]
+
+
+class _LinearClassifierBf16Fn(torch.autograd.Function):
+    """ops._LinearClassifierFn on bf16 rows: y = x W^T + b as an fp32 (N, C) tensor (bf16 MFMA) and logits = y Wc^T + bc
+    (fp32 skinny kernel).  When only the logits carry a gradient, g_x = g_logits (Wc W) is written as bf16 rows straight
+    from the fp32 logit gradient and g_W = Wc^T (g_logits^T x): no (N, C) gradient, no rounding of it.  W here is the bf16
+    operand the forward product used, so the gradients are those of the function as evaluated."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_cls, b_cls):
+        ctx.set_materialize_grads(False)
+        w, w_t = weight_operands(weight, None, want_t=ctx.needs_input_grad[0])
+        y = gemm_nt(x, w, out_f32=True, bias=bias)
+        logits = _ops.scores_fwd(y, w_cls)
+        if b_cls is not None:
+            logits += b_cls
+        ctx.has_bias, ctx.has_bcls = bias is not None, b_cls is not None
+        ctx.save_for_backward(x, w, w_t, y, w_cls)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, g_y, g_logits):
+        if g_y is None and g_logits is None:
+            return None, None, None, None, None
+        x, w, w_t, y, w_cls = ctx.saved_tensors
+        K = x.shape[1]
+        g_x = g_w = g_b = g_wcls = g_bcls = cs = None
+        if g_logits is not None:
+            g_logits = _rowmajor(g_logits)
+            if ctx.needs_input_grad[3]:
+                g_wcls = _ops.scores_bwd_w(g_logits, y)
+            if ctx.has_bcls and ctx.needs_input_grad[4] or (g_y is None and ctx.has_bias and ctx.needs_input_grad[2]):
+                cs = g_logits.sum(0)
+            g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[4] else None
+        if g_y is None:
+            wc = w_cls.detach()
+            if ctx.needs_input_grad[0]:
+                g_x = scores_bwd_x(g_logits, torch.mm(wc, w.float()), K)
+            if ctx.needs_input_grad[1]:
+                g_w = torch.mm(wc.t(), scores_bwd_w(g_logits, x))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                g_b = torch.mv(wc.t(), cs)
+            return g_x, g_w, g_b, g_wcls, g_bcls
+        g = g_y if g_y.dtype == torch.float32 else g_y.float()
+        if g_logits is not None:
+            g = torch.addmm(g, g_logits, w_cls.detach())
+        gb = cast_rows(g)
+        if ctx.needs_input_grad[0]:
+            g_x = gemm_nt(gb, w_t)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.has_bias:
+                g_w, g_b = gemm_tn(gb, x, want_colsum=True)
+            else:
+                g_w = gemm_tn(gb, x)
+        return g_x, g_w, g_b, g_wcls, g_bcls
+
+
 def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
-                          seed: int = 0):
-    """ops.gat_layer_linear_mean on bf16 rows -> (mean (N, D) fp32, attn (E, H) fp32).  The combined weight is assembled
-    from the fp32 parameters by a few tiny torch ops (autograd hands its fp32 gradient back to w_fc / w_res / bias)."""
-    _require_cuda(x, w_fc, w_res, w_lr, bias)
+                          seed: int = 0, w_cls=None, b_cls=None):
+    """ops.gat_layer_linear_mean on bf16 rows -> (mean (N, D) fp32, attn (E, H) fp32[, logits (N, J) fp32]).  The combined
+    weight is assembled from the fp32 parameters by a few tiny torch ops (autograd hands its fp32 gradient back to
+    w_fc / w_res / bias).  ``w_cls`` (J <= 32, D), ``b_cls``: the classifier joined to the product's node."""
+    _require_cuda(x, w_fc, w_res, w_lr, bias, w_cls, b_cls)
     F_ = x.shape[1]
     zx, attn = _GATAggregateBf16Fn.apply(as_rows(x), w_lr, csc, H, slope, p_drop, seed)
     parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
     parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
     w_comb = torch.cat(parts, dim=1) * (1.0 / H)
     b_mean = bias.view(H, D).mean(0) if bias is not None else None
-    return _LinearBf16Fn.apply(zx, w_comb, b_mean), attn
+    if w_cls is None:
+        return _LinearBf16Fn.apply(zx, w_comb, b_mean), attn
+    if w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 4 == 0:
+        out, logits = _LinearClassifierBf16Fn.apply(zx, w_comb, b_mean, w_cls, b_cls)
+    else:
+        out = _LinearBf16Fn.apply(zx, w_comb, b_mean)
+        logits = torch.nn.functional.linear(out, w_cls, b_cls)
+    return out, attn, logits
 
 
 class _CatDropoutBf16(torch.autograd.Function):

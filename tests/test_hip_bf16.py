@@ -189,6 +189,34 @@ def test_gat_layer_bf16_matches_storage_model(F_in, H, D, res, act, mean):
         _close_to_model(p.grad, sd[k].grad, k, frac=1.0 if k.startswith("attn") else 0.05)
 
 
+@pytest.mark.parametrize("emb_in_loss", [False, True])
+def test_linear_with_joined_classifier_bf16(emb_in_loss):
+    """ops_bf16._LinearClassifierBf16Fn against fp64 on the SAME bf16 operands: folded route (no (N, C) gradient, nothing
+    rounded but the bf16 gradient rows g_x) and ordinary route (the (N, C) gradient rounded to bf16 once)."""
+    torch.manual_seed(5 + emb_in_loss)
+    N, K, C, J = 700, 384, 1024, 22
+    x32 = torch.randn(N, K).to(BF).float()
+    xb = _rows(x32).requires_grad_()
+    w = (torch.randn(C, K, device="cuda") / 16).requires_grad_()
+    b = torch.randn(C, device="cuda", requires_grad=True)
+    wc = (torch.randn(J, C, device="cuda") / 32).requires_grad_()
+    bc = torch.randn(J, device="cuda", requires_grad=True)
+    y, logits = ops_bf16._LinearClassifierBf16Fn.apply(xb, w, b, wc, bc)
+    cl, cy = torch.randn(N, J, device="cuda"), torch.randn(N, C, device="cuda")
+    ((logits * cl).sum() + ((y * cy).sum() if emb_in_loss else 0.0)).backward()
+    S = O.Bf16Storage
+    rx, rw, rb_, rwc, rbc = (t.detach().double().cpu().requires_grad_() for t in (x32, w, b, wc, bc))
+    ry = S.round_grad(rx) @ S.store_fwd(rw).t() + rb_
+    if emb_in_loss:
+        ry = S.round_grad(ry)
+    rl = ry @ rwc.t() + rbc
+    ((rl * cl.double().cpu()).sum() + ((ry * cy.double().cpu()).sum() if emb_in_loss else 0.0)).backward()
+    assert rel_err(y, ry) < 1e-5 and rel_err(logits, rl) < 1e-5
+    _close_to_model(xb.grad, rx.grad, "g_x")
+    for name, got, want in (("w", w, rw), ("b", b, rb_), ("w_cls", wc, rwc), ("b_cls", bc, rbc)):
+        assert rel_err(got.grad, want.grad) < (2 * ULP if emb_in_loss else 1e-4), name
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # model level: st_gat_6 (BASELINE config 4) and st_gat_3
 # ----------------------------------------------------------------------------------------------------------------
@@ -267,7 +295,6 @@ def test_bf16_output_layer_exact_on_its_own_inputs(name):
         cap["x"] = feat.detach().float().cpu()
         out = inner(graph, feat, *a, **k)
         t = out[0] if isinstance(out, tuple) else out
-        t.register_hook(lambda gr: cap.__setitem__("g", gr.detach().float().cpu()))
         cap["out"] = t.detach().float().cpu()
         return out
 
@@ -275,17 +302,21 @@ def test_bf16_output_layer_exact_on_its_own_inputs(name):
     y = g.ndata["y"]
     mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5
     logits, _ = model(g)
+    logits.register_hook(lambda gr: cap.__setitem__("g", gr.detach().float().cpu()))
     masked_weighted_ce(logits, y, mask.cuda(), torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS)).cuda()).backward()
     src, dst = g.cpu().edges()
     sd = {k: v.detach().cpu().double().requires_grad_() for k, v in layer.state_dict().items()}
+    wc, bc = (t.detach().cpu().double().requires_grad_() for t in (model.gnn_out.weight, model.gnn_out.bias))
     _, H, D = sd["attn_l"].shape
     assert O.linear_mean_form(H, D, cap["x"].shape[1], "res_fc.weight" in sd)
+    # the *Net's classifier is joined to the layer's node: only the logits carry a gradient, the product's is never stored
     r = O.gat_conv_linear_mean(src, dst, g.number_of_nodes(), cap["x"].double(), sd["fc.weight"], sd["attn_l"], sd["attn_r"],
-                               sd.get("res_fc.weight"), sd["bias"], 0.2, storage=O.Bf16Storage)[0]
-    r.backward(cap["g"].double())
+                               sd.get("res_fc.weight"), sd["bias"], 0.2, storage=O.Bf16Storage, round_out_grad=False)[0]
+    F.linear(r, wc, bc).backward(cap["g"].double())
     assert rel_err(cap["out"], r) < 2e-4          # a stored z element may sit on a bf16 rounding boundary (fp32 vs fp64 sums)
     for k, p in layer.named_parameters():
         assert rel_err(p.grad, sd[k].grad) < 1e-3, (k, rel_err(p.grad, sd[k].grad))
+    assert rel_err(model.gnn_out.weight.grad, wc.grad) < 1e-3 and rel_err(model.gnn_out.bias.grad, bc.grad) < 1e-5
 
 
 def test_bf16_train_step_tracks_fp32_and_replays():

@@ -251,6 +251,33 @@ def test_linear_mean_output_layer_matches_per_head_form_and_oracle(monkeypatch, 
             assert rel_err(got, w) < (FWD_TOL if name == "out" else GRAD_TOL), (form, name)
 
 
+@pytest.mark.parametrize("emb_in_loss", [False, True])
+def test_linear_with_joined_classifier_both_routes(emb_in_loss):
+    """ops._LinearClassifierFn (the *Net's gnn_out joined to the linear-mean output product, reference models.py:921-933):
+    y = x W^T + b and logits = y Wc^T + bc against fp64, forward and every gradient - by the folded route (only the
+    logits in the loss: no (N, C) gradient is formed) and by the ordinary one (the embedding in the loss as well)."""
+    torch.manual_seed(3 + emb_in_loss)
+    N, K, C, J = 700, 384, 1024, 22
+    x = torch.randn(N, K, device="cuda", requires_grad=True)
+    w = (torch.randn(C, K, device="cuda") / 16).requires_grad_()
+    b = torch.randn(C, device="cuda", requires_grad=True)
+    wc = (torch.randn(J, C, device="cuda") / 32).requires_grad_()
+    bc = torch.randn(J, device="cuda", requires_grad=True)
+    assert ops.linear_classifier_supported(x, w, wc)
+    y, logits = ops._LinearClassifierFn.apply(x, w, b, wc, bc)
+    cl, cy = torch.randn(N, J, device="cuda"), torch.randn(N, C, device="cuda")
+    loss = (logits * cl).sum() + ((y * cy).sum() if emb_in_loss else 0.0)
+    loss.backward()
+    leaves = [x, w, b, wc, bc]
+    ref = [t.detach().double().cpu().requires_grad_() for t in leaves]
+    ry = ref[0] @ ref[1].t() + ref[2]
+    rl = ry @ ref[3].t() + ref[4]
+    ((rl * cl.double().cpu()).sum() + ((ry * cy.double().cpu()).sum() if emb_in_loss else 0.0)).backward()
+    assert rel_err(y, ry) < FWD_TOL and rel_err(logits, rl) < FWD_TOL
+    for name, got, want in zip(["x", "w", "b", "w_cls", "b_cls"], leaves, ref):
+        assert rel_err(got.grad, want.grad) < GRAD_TOL, name
+
+
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_ELU, ops.ACT_TANH, ops.ACT_RELU])
 def test_epilogue_and_derivative_kernels_of_the_aggregate_first_form(act):
     """spgnn_gemm_nt's bias + activation epilogue (on column-slice outputs), spgnn_head_mean and spgnn_act_bwd."""
