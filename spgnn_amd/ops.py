@@ -547,10 +547,12 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 class _LinearClassifierFn(torch.autograd.Function):
     """y = x W^T + b (N, C) and a skinny classifier on it, logits = y Wc^T + bc (J <= 32), as ONE autograd node (the *Net's
-    ``gnn_out`` on the output layer's head mean: reference models.py:921-933 with 320-327).  When only the logits carry a
-    gradient (the training step: the embedding is returned but not part of the loss) the (N, C) gradient of y is never
-    formed: with P = Wc W,  g_x = g_logits P,  g_W = Wc^T (g_logits^T x),  g_b = Wc^T colsum(g_logits) - two skinny passes
-    over x instead of two GEMMs over an (N, C) tensor.  Otherwise g_y + g_logits Wc takes the ordinary route."""
+    ``gnn_out`` on the output layer's head mean: reference models.py:921-933 with 320-327).  The classifier is folded
+    through the product: with P = Wc W (J, K),  logits = x P^T + (Wc b + bc)  - a skinny pass over x instead of one over
+    the (N, C) result - and  g_Wc = (g_logits^T x) W^T + colsum(g_logits) b^T  needs no pass over y either.  When only
+    the logits carry a gradient (the training step: the embedding is returned but not part of the loss) the (N, C)
+    gradient of y is never formed:  g_x = g_logits P,  g_W = Wc^T (g_logits^T x),  g_b = Wc^T colsum(g_logits).
+    Otherwise g_y + g_logits Wc takes the ordinary route."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_cls, b_cls):
@@ -563,36 +565,42 @@ class _LinearClassifierFn(torch.autograd.Function):
             w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
         sx, sw = pow2_scale(x), pow2_scale(w)
         y = gemm_nt(x, w, sx, sw, bias=bias)
-        logits = scores_fwd(y, w_cls)
-        if b_cls is not None:
-            logits += b_cls
+        wc = w_cls.detach()
+        P = torch.mm(wc, w.detach())
+        logits = scores_fwd(x, P)
+        c0 = b_cls
+        if bias is not None:
+            c0 = torch.mv(wc, bias.detach()) if c0 is None else torch.addmv(c0.detach(), wc, bias.detach())
+        if c0 is not None:
+            logits += c0
         ctx.has_bias, ctx.has_bcls = bias is not None, b_cls is not None
-        ctx.save_for_backward(x, w, sx, sw, y, w_cls)
+        ctx.save_for_backward(x, w, sx, sw, P, w_cls, bias)
         return y, logits
 
     @staticmethod
     def backward(ctx, g_y, g_logits):
         if g_y is None and g_logits is None:
             return None, None, None, None, None
-        x, w, sx, sw, y, w_cls = ctx.saved_tensors
+        x, w, sx, sw, P, w_cls, bias = ctx.saved_tensors
         N, K = x.shape
         C = w.shape[0]
-        g_x = g_w = g_b = g_wcls = g_bcls = None
-        cs = None
+        wc = w_cls.detach()
+        g_x = g_w = g_b = g_wcls = g_bcls = cs = M1 = None
         if g_logits is not None:
             g_logits = _rowmajor(g_logits)
+            cs = g_logits.sum(0)
+            M1 = scores_bwd_w(g_logits, x)                               # g_logits^T x  (J, K)
             if ctx.needs_input_grad[3]:
-                g_wcls = scores_bwd_w(g_logits, y)
-            if ctx.has_bcls and ctx.needs_input_grad[4] or (g_y is None and ctx.has_bias and ctx.needs_input_grad[2]):
-                cs = g_logits.sum(0)
+                g_wcls = torch.mm(M1, w.t())
+                if ctx.has_bias:
+                    g_wcls.addr_(cs, bias.detach())
             g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[4] else None
         if g_y is None:                                   # the folded route: no (N, C) gradient
-            wc = w_cls.detach()
             if ctx.needs_input_grad[0]:
                 g_x = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :K]
-                scores_bwd_x_(g_x, g_logits, torch.mm(wc, w), accumulate=False)
+                scores_bwd_x_(g_x, g_logits, P, accumulate=False)
             if ctx.needs_input_grad[1]:
-                g_w = torch.mm(wc.t(), scores_bwd_w(g_logits, x))
+                g_w = torch.mm(wc.t(), M1)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 g_b = torch.mv(wc.t(), cs)
             return g_x, g_w, g_b, g_wcls, g_bcls
@@ -601,7 +609,7 @@ class _LinearClassifierFn(torch.autograd.Function):
             g = g.clone() if g.data_ptr() == g_y.data_ptr() else g
             if not _rows_aligned(g):
                 g = cat_padded((g,))
-            scores_bwd_x_(g, g_logits, w_cls.detach(), accumulate=True)
+            scores_bwd_x_(g, g_logits, wc, accumulate=True)
         elif not _rows_aligned(g):
             g = cat_padded((g,))
         sg = pow2_scale(g)

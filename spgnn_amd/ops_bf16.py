@@ -429,49 +429,58 @@ def scores_bwd_x(g_s: torch.Tensor, w: torch.Tensor, K: int) -> torch.Tensor:
 
 
 class _LinearClassifierBf16Fn(torch.autograd.Function):
-    """ops._LinearClassifierFn on bf16 rows: y = x W^T + b as an fp32 (N, C) tensor (bf16 MFMA) and logits = y Wc^T + bc
-    (fp32 skinny kernel).  When only the logits carry a gradient, g_x = g_logits (Wc W) is written as bf16 rows straight
-    from the fp32 logit gradient and g_W = Wc^T (g_logits^T x): no (N, C) gradient, no rounding of it.  W here is the bf16
-    operand the forward product used, so the gradients are those of the function as evaluated."""
+    """ops._LinearClassifierFn on bf16 rows: y = x W^T + b as an fp32 (N, C) tensor (bf16 MFMA) and the classifier folded
+    through the product, logits = x (Wc W)^T + (Wc b + bc) (fp32 skinny kernel on the bf16 rows).  When only the logits
+    carry a gradient, g_x = g_logits (Wc W) is written as bf16 rows straight from the fp32 logit gradient and
+    g_W = Wc^T (g_logits^T x): no (N, C) gradient, no rounding of it.  W here is the bf16 operand the forward product
+    used, so the gradients are those of the function as evaluated."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_cls, b_cls):
         ctx.set_materialize_grads(False)
         w, w_t = weight_operands(weight, None, want_t=ctx.needs_input_grad[0])
         y = gemm_nt(x, w, out_f32=True, bias=bias)
-        logits = _ops.scores_fwd(y, w_cls)
-        if b_cls is not None:
-            logits += b_cls
+        wc = w_cls.detach()
+        wf = w.float()
+        P = torch.mm(wc, wf)
+        logits = scores_fwd(x, P)
+        c0 = b_cls
+        if bias is not None:
+            c0 = torch.mv(wc, bias.detach()) if c0 is None else torch.addmv(c0.detach(), wc, bias.detach())
+        if c0 is not None:
+            logits += c0
         ctx.has_bias, ctx.has_bcls = bias is not None, b_cls is not None
-        ctx.save_for_backward(x, w, w_t, y, w_cls)
+        ctx.save_for_backward(x, wf, w_t, P, w_cls, bias)
         return y, logits
 
     @staticmethod
     def backward(ctx, g_y, g_logits):
         if g_y is None and g_logits is None:
             return None, None, None, None, None
-        x, w, w_t, y, w_cls = ctx.saved_tensors
+        x, wf, w_t, P, w_cls, bias = ctx.saved_tensors
         K = x.shape[1]
-        g_x = g_w = g_b = g_wcls = g_bcls = cs = None
+        wc = w_cls.detach()
+        g_x = g_w = g_b = g_wcls = g_bcls = cs = M1 = None
         if g_logits is not None:
             g_logits = _rowmajor(g_logits)
+            cs = g_logits.sum(0)
+            M1 = scores_bwd_w(g_logits, x)
             if ctx.needs_input_grad[3]:
-                g_wcls = _ops.scores_bwd_w(g_logits, y)
-            if ctx.has_bcls and ctx.needs_input_grad[4] or (g_y is None and ctx.has_bias and ctx.needs_input_grad[2]):
-                cs = g_logits.sum(0)
+                g_wcls = torch.mm(M1, wf.t())
+                if ctx.has_bias:
+                    g_wcls.addr_(cs, bias.detach())
             g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[4] else None
         if g_y is None:
-            wc = w_cls.detach()
             if ctx.needs_input_grad[0]:
-                g_x = scores_bwd_x(g_logits, torch.mm(wc, w.float()), K)
+                g_x = scores_bwd_x(g_logits, P, K)
             if ctx.needs_input_grad[1]:
-                g_w = torch.mm(wc.t(), scores_bwd_w(g_logits, x))
+                g_w = torch.mm(wc.t(), M1)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 g_b = torch.mv(wc.t(), cs)
             return g_x, g_w, g_b, g_wcls, g_bcls
         g = g_y if g_y.dtype == torch.float32 else g_y.float()
         if g_logits is not None:
-            g = torch.addmm(g, g_logits, w_cls.detach())
+            g = torch.addmm(g, g_logits, wc)
         gb = cast_rows(g)
         if ctx.needs_input_grad[0]:
             g_x = gemm_nt(gb, w_t)
