@@ -538,20 +538,6 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
     *reinterpret_cast<uint2*>((IMG0_) + woff + (I_) * 64 * PITCH) = h_;                                      \
     *reinterpret_cast<uint2*>((IMG0_) + IMG + woff + (I_) * 64 * PITCH) = l_;                                \
   }
-#if defined(SPGNN_EXP_NOCVT_B) || defined(SPGNN_EXP_NOCVT_AB)   /* timing experiment: staged without the split arithmetic (wrong results) */
-#define SPGNN_CVTB(IMG0_, R_, I_, S_)                                                                        \
-  {                                                                                                          \
-    *reinterpret_cast<uint2*>((IMG0_) + woff + (I_) * 64 * PITCH) = make_uint2(R_[0], R_[1]);                \
-    *reinterpret_cast<uint2*>((IMG0_) + IMG + woff + (I_) * 64 * PITCH) = make_uint2(R_[2], R_[3]);          \
-  }
-#else
-#define SPGNN_CVTB SPGNN_CVT
-#endif
-#if defined(SPGNN_EXP_NOCVT_AB)
-#define SPGNN_CVTA SPGNN_CVTB
-#else
-#define SPGNN_CVTA SPGNN_CVT
-#endif
 #define SPGNN_MASK(R_, K0_)                                                                                  \
   {                                                                                                          \
     const int k_ = (K0_) + kq;                                                                               \
@@ -625,10 +611,10 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
             const int slot = ks * 4 + h * 2 + c / 6;                       /* 8 slots = 4 A + 4 B registers */ \
             const int k2 = ((T_) + 2) * BK;                                                                  \
             if (slot < 4) {                                                                                  \
-              SPGNN_CVTA(nbuf, ra[slot], slot, sA)                                                           \
+              SPGNN_CVT(nbuf, ra[slot], slot, sA)                                                            \
               ra[slot] = SPGNN_LDA(slot, k2);                                                                \
             } else {                                                                                         \
-              SPGNN_CVTB(nbuf + 2 * IMG, rb[slot - 4], slot - 4, sB)                                         \
+              SPGNN_CVT(nbuf + 2 * IMG, rb[slot - 4], slot - 4, sB)                                          \
               rb[slot - 4] = SPGNN_LDB(slot - 4, k2);                                                        \
             }                                                                                                \
           }                                                                                                  \
@@ -655,18 +641,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
 #undef SPGNN_CVT
 #undef SPGNN_MASK
 
-#if defined(SPGNN_EXP_NOEPI)        /* timing experiment: K loop only (the accumulators stay live, nothing is stored) */
-  float t_ = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) t_ += acc[i][j][e];
-  if (t_ == 1.2345e30f) a.C[0] = t_;
-#else
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
-#endif
 }
 
 // A phase-skewed form of this kernel (the two waves of every SIMD one phase apart - R: fragment reads + wait, M: twelve
@@ -724,11 +699,7 @@ __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, 
   const int idx = threadIdx.x + kThreads * i;
   const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
   uint2 h, l;
-#if defined(SPGNN_EXP_NOCVT_TN)     /* timing experiment (wrong results) */
-  h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); l = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
-#else
   split4_pk(v, s, h, l);
-#endif
   *reinterpret_cast<uint2*>(hi_img + off) = h;
   *reinterpret_cast<uint2*>(lo_img + off) = l;
 }
