@@ -169,6 +169,7 @@ class GATConv(nn.Module):
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
         p = float(self.attn_drop.p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
+        drop = (p, seed) if p > 0.0 else None
         fuse_mean = mean_heads and fuse_epilogue
         if h.dtype == torch.bfloat16:
             # bf16-storage path (BASELINE config 4): project-first on the bf16 matrix cores, fp32 parameters and scores
@@ -184,7 +185,7 @@ class GATConv(nn.Module):
                     out, attn, logits = ops_bf16.gat_layer_linear_mean(*args, w_cls=classifier.weight, b_cls=classifier.bias)
                     return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, False), logits
                 out, attn = ops_bf16.gat_layer_linear_mean(*args)
-                return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
+                return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention, drop=drop)
             fuse_mean = fuse_mean and ops.can_fuse_mean(H, D)
             if fuse_out is not None:
                 total, fp, fseed, extra = fuse_out
@@ -196,7 +197,7 @@ class GATConv(nn.Module):
             out, attn = ops_bf16.gat_layer(csc, h, w_fc, self.res_fc.weight if has_res else None, self.attn_l, self.attn_r,
                                            self.bias if fuse_epilogue else None, H, D, float(self.negative_slope),
                                            act if fuse_epilogue else ops.ACT_NONE, p, seed, mean=fuse_mean)
-            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
+            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=drop)
         agg_first = (AGGREGATE_FIRST and fuse_epilogue and h.shape[1] < D and ops.GEMM_MODE == "f16x3" and h.shape[0] > 0
                      and ops.agg_first_supported(H, h.shape[1]))
         w_cat = None
@@ -224,7 +225,7 @@ class GATConv(nn.Module):
                                                      self.bias if fuse_epilogue else None, H, D, has_res,
                                                      float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p,
                                                      seed, mean=fuse_mean)
-            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
+            return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=drop)
         w_lr = ops.fold_scores(w_fc, self.attn_l, self.attn_r)
         if (agg_first and LINEAR_MEAN and fuse_mean and act == ops.ACT_NONE and (H + 1) * h.shape[1] <= H * D
                 and getattr(csc, "num_dst", None) is None):
@@ -235,7 +236,7 @@ class GATConv(nn.Module):
                 out, attn, logits = ops.gat_layer_linear_mean(*args, w_cls=classifier.weight, b_cls=classifier.bias)
                 return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, False), logits
             out, attn = ops.gat_layer_linear_mean(*args)
-            return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention)
+            return self._finish(out, attn, csc, h, H, D, True, fuse_epilogue, identity_res, True, get_attention, drop=drop)
         if agg_first:
             # input narrower than one head's output: aggregate the input rows, then project (ops._GATAggFirstFn)
             fuse_cls = (FUSE_CLASSIFIER and classifier is not None and fuse_mean and classifier.out_features <= 32
@@ -251,9 +252,10 @@ class GATConv(nn.Module):
             out, attn = ops.gat_layer(csc, h, w_cat, w_lr, self.bias if fuse_epilogue else None, H, D, has_res,
                                       float(self.negative_slope), act if fuse_epilogue else ops.ACT_NONE, p, seed,
                                       mean=fuse_mean)
-        return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention)
+        return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=drop)
 
-    def _finish(self, out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention):
+    def _finish(self, out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=None):
+        """``drop`` = (p, seed) of the attention dropout this forward used (training mode, p > 0), else None."""
         rst = out if fuse_mean else out.view(-1, H, D)
         if not fuse_epilogue:
             if identity_res:
@@ -268,6 +270,8 @@ class GATConv(nn.Module):
         if nd is not None:
             rst = rst[:nd]
         if get_attention:
+            if drop is not None:                       # DGL hands back attn_drop(edge_softmax(e)): what the aggregation used
+                attn = attn * ops.attn_dropout_multiplier(attn.shape[0], H, drop[0], drop[1], attn.device)
             a = torch.empty_like(attn)
             a[csc.eid.long()] = attn                   # CSC slot order -> edge id order
             return rst, a.unsqueeze(-1)

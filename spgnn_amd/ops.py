@@ -35,6 +35,28 @@ def _seed_off_ptr(device) -> int:
     return t.data_ptr() if t is not None and t.device == device else 0
 
 
+def _s64(c: int) -> int:
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def attn_dropout_multiplier(E: int, H: int, p: float, seed: int, device) -> torch.Tensor:
+    """(E, H) multiplier of the attention dropout the GAT kernels apply: 1/(1-p) where CSC slot e, head h is kept, 0 where
+    it is dropped - the kernels' counter hash keep_scale(seed, e*H + h) restated in int64 tensor arithmetic (wrap-around
+    multiplies, logical shifts), for ``get_attention=True`` in training mode (DGL returns attn_drop(edge_softmax(e)))."""
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+    idx = torch.arange(E * H, dtype=torch.int64, device=device) + 1
+    z = idx * _s64(0x9E3779B97F4A7C15) + _s64(seed & ((1 << 64) - 1))
+    if DROPOUT_SEED_OFFSET is not None and DROPOUT_SEED_OFFSET.device == idx.device:
+        z = z + DROPOUT_SEED_OFFSET.view(torch.int64)[0]
+    z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    u = lsr(z, 40).to(torch.float32) * (1.0 / 16777216.0)
+    keep = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(p, dtype=torch.float32))
+    return torch.where(u >= p, keep.to(device), torch.zeros((), device=device)).view(E, H)
+
+
 class KernelTimer:
     """Optional per-launch HIP-event timing of the message-passing kernels (bench.py's roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""

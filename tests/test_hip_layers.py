@@ -159,6 +159,11 @@ def test_attention_dropout_matches_oracle_with_same_mask(monkeypatch):
     assert rel_err(x.grad, xo.grad) < GRAD_TOL
     for name, prm in layer.named_parameters():
         assert rel_err(prm.grad, sd[name].grad) < GRAD_TOL, name
+    # get_attention=True in training mode returns attn_drop(edge_softmax(e)) per edge id, as DGL does (what was aggregated)
+    _, a_ret = layer(g, x.detach(), get_attention=True)
+    a_ref = _oracle_gat(layer, src, dst, n, x, F.elu, attn_keep=torch.from_numpy(keep_edge))[1] * torch.from_numpy(keep_edge)
+    assert a_ret.shape == (E, H, 1) and rel_err(a_ret.squeeze(-1), a_ref) < FWD_TOL
+    assert ((a_ret.squeeze(-1) == 0).cpu() == torch.from_numpy(keep_edge == 0)).all()
     monkeypatch.undo()
     # fresh seeds per call in train mode -> different masks; eval mode -> no dropout, deterministic
     a = layer(g, x.detach()); b = layer(g, x.detach())

@@ -187,3 +187,17 @@ def test_checkpoint_filter_follows_reference_rule(tmp_path):
     states = checkpoint.load_pretrained_model(path, [net2, opt2, sched2], ["model_dict", "optimizer_dict", "scheduler_dict"], device="cpu")
     assert states["iteration"] == 3 and states["epoch_n"] == 1
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+
+
+def test_attention_dropout_multiplier_is_the_kernels_hash():
+    """ops.attn_dropout_multiplier (what get_attention=True applies in training mode) restates the kernels' counter hash in
+    int64 tensor arithmetic; tests/util.keep_scale_host is its bit-exact numpy copy (checked against the kernels on the GPU)."""
+    import numpy as np
+    import torch
+    from spgnn_amd import ops
+    from tests.util import keep_scale_host
+    for seed, p in ((0, 0.1), (192837465, 0.5), (2 ** 62 - 3, 0.25), (2 ** 63 + 12345, 0.1)):
+        E, H = 777, 3
+        got = ops.attn_dropout_multiplier(E, H, p, seed, torch.device("cpu")).numpy()
+        want = keep_scale_host(seed % 2 ** 64, np.arange(E * H), p).reshape(E, H)
+        assert np.array_equal(got, want), (seed, p)
