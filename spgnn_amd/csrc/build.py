@@ -14,6 +14,11 @@ OBJ_DIR = os.path.join(ROOT, "build", "obj")
 SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
 HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE]
+# Per-source flags.  The row kernels are built WITHOUT the SLP vectorizer: the packed fp32 ops it forms (v_pk_fma_f32 fed by
+# v_pk_mov_b32 op_sel shuffles) gave transiently wrong per-edge dots in gat_bwd_dst when a second process shared the GPU
+# (spgnn_kernels.hip, SPGNN_DIST_DST; tools/dbg_dst_repro.py); scalar fp32 code is as fast there.  The GEMM files keep it:
+# their packed conversions are what the split costs least with, and their cross-lane reads are guarded by hand.
+EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _obj(src: str) -> str:
@@ -27,10 +32,10 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
-    todo = [s for s in SOURCES if force or _stale(_obj(s), [s] + HEADERS)]
+    todo = [s for s in SOURCES if force or _stale(_obj(s), [s, os.path.abspath(__file__)] + HEADERS)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -308,12 +308,17 @@ constexpr int kMaxFast = 8;
 #define SPGNN_DIST_FWD SPGNN_DIST_SOFTMAX
 #endif
 #ifndef SPGNN_DIST_DST
-// The dst-major backward half keeps the table-per-lane form.  Its entry-per-lane form (reduce-scatter of the per-edge dots,
-// below) measured 9 % faster and is bitwise repeatable kernel by kernel, alone and under contention
-// (tools/stress_determinism.py), but with it the 2-rank training step (two processes on one GPU) stopped being bitwise
-// repeatable run to run (tools/dbg_replay2.py: 3 of 5 trials, ~1e-5 on the parameters; never with it compiled out, never
-// with only the forward / src-major halves in that form).  Unresolved, so it stays off.
-#define SPGNN_DIST_DST 0
+// The dst-major backward half in the entry-per-lane form (reduce-scatter of the per-edge dots, below): 7 % off the GAT
+// kernels' time.  It REQUIRES this file to be compiled with -fno-slp-vectorize (csrc/build.py does).  With hipcc's SLP
+// vectorizer on (ROCm 7.2, gfx950) the per-edge dots of this form are computed by packed fp32 ops (v_pk_fma_f32 /
+// v_pk_mul_f32 fed by v_pk_mov_b32 op_sel shuffles), and when a second process shares the GPU a few launches per hundred
+// produced a wrong dot for ALL 16 lanes of one team - one 16-lane pass of one instruction - with every operand in memory
+// and in registers verified correct (tools/dbg_dst_repro.py: the row chunks dumped after the dots were right, draining
+// vmcnt / lgkmcnt or padding the cross-lane reads with s_nop changed nothing, the reduce-scatter was not involved).
+// Without the vectorizer: 0 of 400 repetitions in either process, and the row kernels run as fast (K1-K3 1.24 vs 1.26 ms).
+// The same class of problem as single_pass() above: multi-pass packed ops next to instructions that assume single-pass
+// timing.  Alone on the GPU every build was bitwise repeatable.
+#define SPGNN_DIST_DST SPGNN_DIST_SOFTMAX
 #endif
 #ifndef SPGNN_DST_SEL
 #define SPGNN_DST_SEL(NS_, WAVE_) true
