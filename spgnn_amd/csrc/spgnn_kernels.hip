@@ -2037,18 +2037,26 @@ __global__ void spmm_max_bwd_scalar(SpmmMaxBwd a) {
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <typename ST, int NG>      // NG 16-column groups: J <= 16 * NG; ST: storage type of the rows of X (W, S fp32)
+// NG 16-column groups (J <= 16 * NG), RG 16-row groups per wave; ST: storage type of the rows of X (W, S fp32).
+// A wave keeps its W fragments in registers across its RG row groups: with one group per wave the 22 x 1024 classifier
+// weights were re-read from L1 for every 16 rows - twice the bytes of x (1024 -> 22: 2.7 TB/s of x).
+template <typename ST, int NG, int RG>
 __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
                                                           float* __restrict__ absmax) {
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  const int64_t row0 = wave * 16;
+  const int64_t row0 = wave * (16 * RG);
   if (row0 >= N) return;
   const int r = lane & 15, q = lane >> 4;
-  const bool rv = row0 + r < N;
-  const ST* xp = X + (rv ? row0 + r : 0) * ldx + 4 * q;
+  bool rv[RG]; const ST* xp[RG]; float rvf[RG];
+#pragma unroll
+  for (int t = 0; t < RG; ++t) {
+    rv[t] = row0 + 16 * t + r < N;
+    xp[t] = X + (rv[t] ? row0 + 16 * t + r : 0) * ldx + 4 * q;
+    rvf[t] = rv[t] ? 1.f : 0.f;
+  }
   bool wv[NG]; const float* wp[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -2056,85 +2064,108 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
     wp[g] = W + (int64_t)(wv[g] ? r + 16 * g : 0) * Kp + 4 * q;
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  f32x4 acc[NG];
+  f32x4 acc[RG][NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float amx = 0.f;                    // every element of x passes through this kernel: its absmax is free
+  for (int t = 0; t < RG; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float amx[RG];                      // every element of x passes through this kernel: its absmax is free
+#pragma unroll
+  for (int t = 0; t < RG; ++t) amx[t] = 0.f;
   const int kfull = K & ~15;
-  // main loop: straight-line body (one X load, NG W loads, 4 NG MFMAs), unrolled so that several row loads are in flight
+  // main loop: straight-line body, unrolled so that all row loads of a trip are in flight before the first MFMA.
   // Loads are unconditional: rows past N and columns past J read row 0 / column 0 (valid memory) and only feed
   // outputs that are never stored.  A per-lane test around a load (or around the absmax update) is a branch to hipcc:
-  // the loop was not unrolled and every trip waited vmcnt(0) for its own three loads - one load in flight per wave.
-  // Now four k16 steps per trip, all twelve loads issued before the first MFMA.
-  const float rvf = rv ? 1.f : 0.f;
+  // the loop was not unrolled and every trip waited vmcnt(0) for its own loads - one load in flight per wave.
+  constexpr int UK = RG >= 4 ? 2 : 4;  // k16 steps per trip (4 RG UK / 4 ... row loads + NG UK weight loads in flight)
   int k0 = 0;
-  for (; k0 + 64 <= kfull; k0 += 64) {
-    float4 xa[4], wb[NG][4];
+  for (; k0 + 16 * UK <= kfull; k0 += 16 * UK) {
+    float4 xa[RG][UK], wb[NG][UK];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xa[u] = ldv(xp + k0 + 16 * u);
+    for (int t = 0; t < RG; ++t)
+#pragma unroll
+      for (int u = 0; u < UK; ++u) xa[t][u] = ldv(xp[t] + k0 + 16 * u);
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wb[g][u] = ld4(wp[g] + k0 + 16 * u);
+      for (int u = 0; u < UK; ++u) wb[g][u] = ld4(wp[g] + k0 + 16 * u);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      amx = fmaxf(amx, rvf * fmaxf(fmaxf(fabsf(xa[u].x), fabsf(xa[u].y)), fmaxf(fabsf(xa[u].z), fabsf(xa[u].w))));
+    for (int u = 0; u < UK; ++u)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].x, wb[g][u].x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].y, wb[g][u].y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].z, wb[g][u].z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].w, wb[g][u].w, acc[g], 0, 0, 0);
+      for (int t = 0; t < RG; ++t) {
+        amx[t] = fmaxf(amx[t], rvf[t] * fmaxf(fmaxf(fabsf(xa[t][u].x), fabsf(xa[t][u].y)), fmaxf(fabsf(xa[t][u].z), fabsf(xa[t][u].w))));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][u].x, wb[g][u].x, acc[t][g], 0, 0, 0);
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][u].y, wb[g][u].y, acc[t][g], 0, 0, 0);
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][u].z, wb[g][u].z, acc[t][g], 0, 0, 0);
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][u].w, wb[g][u].w, acc[t][g], 0, 0, 0);
+        }
       }
-    }
   }
   for (; k0 < kfull; k0 += 16) {
-    const float4 xa = ldv(xp + k0);
-    amx = fmaxf(amx, rvf * fmaxf(fmaxf(fabsf(xa.x), fabsf(xa.y)), fmaxf(fabsf(xa.z), fabsf(xa.w))));
+    float4 wb[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const float4 wb = ld4(wp[g] + k0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
+    for (int g = 0; g < NG; ++g) wb[g] = ld4(wp[g] + k0);
+#pragma unroll
+    for (int t = 0; t < RG; ++t) {
+      const float4 xa = ldv(xp[t] + k0);
+      amx[t] = fmaxf(amx[t], rvf[t] * fmaxf(fmaxf(fabsf(xa.x), fabsf(xa.y)), fmaxf(fabsf(xa.z), fabsf(xa.w))));
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb[g].x, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb[g].y, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb[g].z, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb[g].w, acc[t][g], 0, 0, 0);
+      }
     }
   }
   if (kfull < K) {                      // ragged tail: element-wise guards on X (W is zero padded)
-    const int k0 = kfull, k = k0 + 4 * q;
-    float4 xa = z4;
-    if (rv && k < K) {                  // the row stride is a multiple of 4 >= K: the whole chunk at k < K is inside the row
-      const float4 t_ = ldv(xp + k0);
-      if (k + 0 < K) xa.x = t_.x;
-      if (k + 1 < K) xa.y = t_.y;
-      if (k + 2 < K) xa.z = t_.z;
-      if (k + 3 < K) xa.w = t_.w;
-    }
-    amx = absmax4(amx, xa);
+    const int kt = kfull, k = kt + 4 * q;
+    float4 wb[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const float4 wb = wv[g] ? ld4(wp[g] + k0) : z4;
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
-    }
-  }
-  if (absmax) {
-    for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
-    if (lane == 0) absmax[wave] = amx;
-  }
-  // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    for (int g = 0; g < NG; ++g) wb[g] = wv[g] ? ld4(wp[g] + kt) : z4;
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (r + 16 * g < J) {
+    for (int t = 0; t < RG; ++t) {
+      float4 xa = z4;
+      if (rv[t] && k < K) {             // the row stride is a multiple of 4 >= K: the whole chunk at k < K is inside the row
+        const float4 t_ = ldv(xp[t] + kt);
+        if (k + 0 < K) xa.x = t_.x;
+        if (k + 1 < K) xa.y = t_.y;
+        if (k + 2 < K) xa.z = t_.z;
+        if (k + 3 < K) xa.w = t_.w;
+      }
+      amx[t] = absmax4(amx[t], xa);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t orow = row0 + q * 4 + j;
-        if (orow < N) S[orow * lds_ + r + 16 * g] = acc[g][j];
+      for (int g = 0; g < NG; ++g) {
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb[g].x, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb[g].y, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb[g].z, acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb[g].w, acc[t][g], 0, 0, 0);
       }
     }
   }
+  if (absmax) {                         // one entry per 16 rows, as the callers size the array
+#pragma unroll
+    for (int t = 0; t < RG; ++t) {
+      float m = amx[t];
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0 && row0 + 16 * t < N) absmax[wave * RG + t] = m;
+    }
+  }
+  // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int t = 0; t < RG; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (r + 16 * g < J) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t orow = row0 + 16 * t + q * 4 + j;
+          if (orow < N) S[orow * lds_ + r + 16 * g] = acc[t][g][j];
+        }
+      }
+    }
 }
 
 // one wave per 256 columns x one row range (four waves of a block side by side: a row is then read as one 4 KB
@@ -3237,6 +3268,30 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   return check_launch("spgnn_spmm_max_bwd");
 }
 
+}  // extern "C"
+
+// Rows per wave.  Measured at N = 76 410 (tools/scores_ab.py): the 22-column classifier product (two column groups, K = 1024)
+// 105 us with 16 rows per wave, 91 with 32, 101 with 64 (too few waves); the 2H <= 16 column score products are fastest
+// with 16 (K = 1063: 82 / 89 / 104 us) - their W fragment is one group, there is little to reuse.
+#ifndef SPGNN_SCORES_RG
+#define SPGNN_SCORES_RG 2
+#endif
+template <typename ST>
+static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride, int64_t N,
+                              int32_t K, int32_t J, float* absmax, hipStream_t st) {
+  const bool wide = SPGNN_SCORES_RG > 1 && J > 16 && N >= 16 * SPGNN_SCORES_RG * 1024;   // >= 1024 waves of the wide form
+  const int rg = wide ? SPGNN_SCORES_RG : 1;
+  const int64_t waves = (N + 16 * rg - 1) / (16 * rg);
+  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
+#define X(NG_, RG_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax)
+  if (J <= 16) X(1, 1);
+  else if (wide) X(2, SPGNN_SCORES_RG);
+  else X(2, 1);
+#undef X
+}
+
+extern "C" {
+
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
                      float* absmax, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || J <= 0 || J > 32 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd: bad N/K/Kp/J");
@@ -3244,12 +3299,7 @@ int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t K
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd: x rows and w must be 16-byte aligned (stride % 4 == 0)");
-  const int64_t waves = (N + 15) / 16;          // one wave per 16 rows (the kernel derives its rows from kBlock too)
-  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
-  if (J <= 16)
-    hipLaunchKernelGGL((scores_fwd_mfma<float, 1>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
-  else
-    hipLaunchKernelGGL((scores_fwd_mfma<float, 2>), grid, block, 0, (hipStream_t)stream, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax);
+  scores_fwd_launch<float>(x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, (hipStream_t)stream);
   return check_launch("spgnn_scores_fwd");
 }
 
@@ -3260,13 +3310,7 @@ int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, i
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd_bf16: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 7) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd_bf16: x rows must be 8-byte aligned (stride % 4 == 0), w 16-byte aligned");
-  const int64_t waves = (N + 15) / 16;
-  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
-  const bf16s* xb = reinterpret_cast<const bf16s*>(x);
-  if (J <= 16)
-    hipLaunchKernelGGL((scores_fwd_mfma<bf16s, 1>), grid, block, 0, (hipStream_t)stream, xb, x_stride, w, Kp, s, s_stride, N, K, J, nullptr);
-  else
-    hipLaunchKernelGGL((scores_fwd_mfma<bf16s, 2>), grid, block, 0, (hipStream_t)stream, xb, x_stride, w, Kp, s, s_stride, N, K, J, nullptr);
+  scores_fwd_launch<bf16s>(reinterpret_cast<const bf16s*>(x), x_stride, w, Kp, s, s_stride, N, K, J, nullptr, (hipStream_t)stream);
   return check_launch("spgnn_scores_fwd_bf16");
 }
 

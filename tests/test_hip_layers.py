@@ -444,6 +444,21 @@ def test_score_projection_kernels(K, J):
     assert rel_err(ops.scores_fwd(xu, w), xu.double() @ w.double().t()) < 2e-6
 
 
+@pytest.mark.parametrize("K,J", [(1024, 22), (600, 22), (100, 17), (384, 32)])
+def test_score_projection_forward_two_row_groups_per_wave(K, J):
+    """spgnn_scores_fwd with J > 16 on >= 32 768 rows takes the form with two 16-row groups per wave (W fragments reused):
+    ragged row count, ragged K, the absmax by-product, fp32 and bf16 rows."""
+    torch.manual_seed(K * J)
+    N = 33000 + 13
+    x = torch.randn(N, (K + 3) // 4 * 4 + 4, device="cuda")[:, :K]
+    w = torch.randn(J, K, device="cuda")
+    s, scale = ops.scores_fwd(x, w, want_scale=True)
+    assert rel_err(s, x.double() @ w.double().t()) < 2e-6 and torch.equal(scale, ops.pow2_scale(x))
+    from spgnn_amd import ops_bf16
+    xb = ops_bf16.cast_rows(x.contiguous())
+    assert rel_err(ops_bf16.scores_fwd(xb, w), xb.double() @ w.double().t()) < 2e-6
+
+
 @pytest.mark.parametrize("K,J", [(1024, 22), (100, 17), (64, 32), (1024, 6)])
 def test_skinny_linear_matches_nn_linear(K, J):
     """The classifier head gnn_out = Linear(1024, 22) on the streaming kernels: same parameters, same results."""
