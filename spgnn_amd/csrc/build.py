@@ -18,7 +18,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.jo
 # v_pk_mov_b32 op_sel shuffles) gave transiently wrong per-edge dots in gat_bwd_dst when a second process shared the GPU
 # (spgnn_kernels.hip, SPGNN_DIST_DST; tools/dbg_dst_repro.py); scalar fp32 code is as fast there.  The GEMM files keep it:
 # their packed conversions are what the split costs least with, and their cross-lane reads are guarded by hand.
-EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]}
 
 
 def _obj(src: str) -> str:

@@ -320,6 +320,9 @@ constexpr int kMaxFast = 8;
 // timing.  Alone on the GPU every build was bitwise repeatable.
 #define SPGNN_DIST_DST SPGNN_DIST_SOFTMAX
 #endif
+#if SPGNN_DIST_DST && !defined(SPGNN_NO_SLP_VECTORIZE)
+#error "spgnn_kernels.hip must be compiled with -fno-slp-vectorize -DSPGNN_NO_SLP_VECTORIZE (see the comment above and csrc/build.py)"
+#endif
 #ifndef SPGNN_DST_SEL
 #define SPGNN_DST_SEL(NS_, WAVE_) true
 #endif

@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; unit=$2; shift; shift
-extra=""; if [ $unit == kernels ]; then extra="-fno-slp-vectorize"; fi      # as csrc/build.py (pass -fslp-vectorize to undo)
+extra=""; if [ $unit == kernels ]; then extra="-fno-slp-vectorize -DSPGNN_NO_SLP_VECTORIZE"; fi      # as csrc/build.py (pass -fslp-vectorize to undo)
 mkdir -p $R/build/variants $R/build/vobj
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I $R/include -I $R/spgnn_amd/csrc $extra "$@" -c $R/spgnn_amd/csrc/spgnn_$unit.hip -o $R/build/vobj/$name.o
 objs=""
