@@ -112,10 +112,12 @@ def _tn_splits(R: int, M: int, N: int) -> int:
     splits = max(1, min(64, 512 // tiles, R // 256))
     if splits >= 8 or tiles >= 16:          # one split per XCD (see ops.gemm_tn)
         splits = 32 if tiles >= 16 and R >= 32 * 512 else (splits // 8 * 8 if splits >= 8 else splits)
+        if tiles >= 64 and splits == 32:       # 1024 x 1024: 16 splits 232 us, 32: 244 (tools/tn_splits_bf16.py): the partial tiles weigh more
+            splits = 16
     return splits
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False):
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits: Optional[int] = None):
     """a (R,M)^T @ b (R,N) -> (M,N) fp32 (weight gradients): bf16 MFMA, fp32 accumulate, split over row ranges with a
     deterministic partial-sum reduction.  ``want_colsum``: also a.sum(0) (M,) fp32 from the operand stream."""
     _require_cuda(a, b)
@@ -123,7 +125,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False):
     N = b.shape[1]
     assert b.shape[0] == R and rows_ok(a) and rows_ok(b)
     lib = _capi.load()
-    splits = _tn_splits(R, M, N)
+    splits = splits or _tn_splits(R, M, N)
     ldn = (N + 3) // 4 * 4
     ldc = ldn + 4 if want_colsum else ldn
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
