@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 28
+#define SPGNN_ABI_VERSION 29
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -351,13 +351,24 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
  *   score_out[(row * (score_cols/64) + b) * 2 + 0] = <C[row, 64b:64b+64], score_l[64b:64b+64]>     (score_l = attn_l flat)
  *   score_out[(row * (score_cols/64) + b) * 2 + 1] = <C[row, 64b:64b+64], score_r[64b:64b+64]>
  * computed on the raw product (before rank-J / bias / activation); spgnn_scores_from_parts sums a head's blocks.
+ * b_presplit = 1: B is the PRE-SPLIT form of the operand written by spgnn_presplit with scale_b (same shape and strides;
+ * every 16-byte group of four fp32 values replaced by the packed fp16 pairs [hi01, hi23, lo01, lo23] the kernel would
+ * otherwise form itself for every row tile).  Bit-identical results; weights are split once per step this way.
  */
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                   const float* bias, int32_t activation,
                   const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
-                  spgnn_stream_t stream);
+                  int32_t b_presplit, spgnn_stream_t stream);
+
+/* Pre-split form of up to two fp32 matrices sharing ONE power-of-two scale (a weight operand and its transpose): dst has
+ * the shape and row stride of src (16-byte rows, stride >= the width rounded up to 4; the pad columns are written as zero).
+ * The scale is either given (scale_in, device scalar) or derived from block maxima partials[0..n_partials) exactly as
+ * spgnn_scale_from_partials would (then scale_in = null); scale_out (nullable) receives it.  src1 / dst1 nullable. */
+int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale_in, float* scale_out,
+                   const float* src0, int64_t ld0, int64_t R0, int64_t K0, float* dst0,
+                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, spgnn_stream_t stream);
 
 /* spgnn_gemm_nt for the SECOND head of a two-head layer whose heads are averaged (the reference's output GATConv,
  * `.mean(1)` at models.py:327 / 482): besides C = act(A B^T + bias) it writes
@@ -368,7 +379,7 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
                            int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                            const float* bias, int32_t activation,
                            const float* other_head, int64_t other_head_stride, float* mean_out, int64_t mean_out_stride,
-                           spgnn_stream_t stream);
+                           int32_t b_presplit, spgnn_stream_t stream);
 
 /* spgnn_gemm_nt with the block tile pinned: tile = 0 chosen from the shape (= spgnn_gemm_nt), 2 = 128 x 128,
  * 4 = 256 x 128, 5 = 256 x 256 (operand extents below 2^31 bytes).  Every tile shape performs the same arithmetic in the
@@ -378,7 +389,7 @@ int spgnn_gemm_nt_tile(const float* A, int64_t lda, const float* B, int64_t ldb,
                        const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
                        const float* bias, int32_t activation,
                        const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
-                       int32_t tile, spgnn_stream_t stream);
+                       int32_t tile, int32_t b_presplit, spgnn_stream_t stream);
 
 /* out[i] = sum over s < splits of partials[s * split_stride + i], i < n (n % 4 == 0, 16-byte aligned): the deterministic
  * reduction of the split-K partial tiles of spgnn_gemm_tn and spgnn_scores_bwd_w (fixed summation order). */

@@ -54,6 +54,10 @@ struct Args {
   // mean_other[row, col]) - the second head's product also writes the mean over heads (replaces a pass over both heads)
   const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
 };
+// B may arrive PRE-SPLIT (spgnn_presplit): every group of four fp32 values replaced, in place, by its packed fp16 pairs
+// [hi01, hi23, lo01, lo23] of s*x (the 16 bytes split4_pk would produce), rows zero padded to a multiple of four columns.
+// Weights are split once per step instead of once per row tile of every product that reads them (299 times at 512 trees):
+// the B half of the in-kernel conversion disappears (template flag BPS: staged words go to LDS as they are).
 
 // -------------------------------------------------------------------------------------------------
 // NT kernel, second generation: (64*WM) x 128 block tile, 2*WM waves, double-buffered LDS, ONE barrier per
@@ -150,6 +154,21 @@ struct TileIO {
       r[i].w = k + 3 < K ? r[i].w : 0.f;
     }
   }
+  // pre-split operand (see Args): groups at or beyond K were fetched from column 0 and are dropped whole; a group that
+  // straddles K is already zero padded in memory
+  static __device__ __forceinline__ void mask_groups(float4 (&r)[NL], int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int k = k0 + ((threadIdx.x + NT * i) & 7) * 4;
+      if (!(k < K)) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  static __device__ __forceinline__ void store_raw(_Float16* hi_img, _Float16* lo_img, const float4& v, int i) {
+    const int idx = threadIdx.x + NT * i;
+    const int off = pair_row(idx >> 3) * PITCH + (idx & 7) * 4;
+    *reinterpret_cast<uint2*>(hi_img + off) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+    *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+  }
   // convert + store float4 #i (called between MFMAs)
   static __device__ __forceinline__ void store_one(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
     const int idx = threadIdx.x + NT * i;
@@ -158,6 +177,14 @@ struct TileIO {
     split4_pk(v, s, h, l);
     *reinterpret_cast<uint2*>(hi_img + off) = h;
     *reinterpret_cast<uint2*>(lo_img + off) = l;
+  }
+  template <bool RAW>
+  static __device__ __forceinline__ void put(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
+    if constexpr (RAW) store_raw(hi_img, lo_img, v, i); else store_one(hi_img, lo_img, v, i, s);
+  }
+  template <bool RAW>
+  static __device__ __forceinline__ void mask_as(float4 (&r)[NL], int k0, int K) {
+    if constexpr (RAW) mask_groups(r, k0, K); else mask(r, k0, K);
   }
 };
 
@@ -374,7 +401,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   static_assert(MI == 2 || MI == 4, "wave tile is 64 or 128 rows");
 }
 
-template <int WM>
+template <int WM, bool BPS>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
   constexpr int TBM = 64 * WM, NT = 128 * WM;
   constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
@@ -413,11 +440,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
   {
     _Float16* st = smem;
     AIO::mask(ra0, 0, a.K);
-    BIO::mask(rb0, 0, a.K);
+    BIO::template mask_as<BPS>(rb0, 0, a.K);
 #pragma unroll
     for (int i = 0; i < NLA; ++i) AIO::store_one(st, st + A_IMG, ra0[i], i, sA);
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) BIO::store_one(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
+    for (int i = 0; i < NLB; ++i) BIO::template put<BPS>(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
   }
   __syncthreads();
 
@@ -432,7 +459,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
     const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
     if (!(STEADY_) && has_next) {                                                                            \
       AIO::mask(RA, ((T_) + 1) * BK, a.K);                                                                   \
-      BIO::mask(RB, ((T_) + 1) * BK, a.K);                                                                   \
+      BIO::template mask_as<BPS>(RB, ((T_) + 1) * BK, a.K);                                                                  \
     }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
       half8 ah[2], al[2], bh[2], bl[2];                                                                      \
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
               AIO::store_one(nbuf, nbuf + A_IMG, RA[q], q, sA);                                              \
           _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                    \
             if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                           \
-              BIO::store_one(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                      \
+              BIO::template put<BPS>(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                    \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -501,6 +528,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
 // (B once, A for two of the four row tiles at a time) to stay inside 256 registers.  LDS: 2 stages x 4 images of
 // 256 rows x 80 bytes = 160 KB.
 // -------------------------------------------------------------------------------------------------
+template <bool BPS>
 __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
   constexpr int TB = 256;
   constexpr int IMG = TB * PITCH;                               // halves per image
@@ -538,6 +566,17 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
     *reinterpret_cast<uint2*>((IMG0_) + woff + (I_) * 64 * PITCH) = h_;                                      \
     *reinterpret_cast<uint2*>((IMG0_) + IMG + woff + (I_) * 64 * PITCH) = l_;                                \
   }
+#define SPGNN_RAW(IMG0_, R_, I_)                                                                             \
+  {                                                                                                          \
+    *reinterpret_cast<uint2*>((IMG0_) + woff + (I_) * 64 * PITCH) = make_uint2(R_[0], R_[1]);                \
+    *reinterpret_cast<uint2*>((IMG0_) + IMG + woff + (I_) * 64 * PITCH) = make_uint2(R_[2], R_[3]);          \
+  }
+#define SPGNN_PUTB(IMG0_, R_, I_)                                                                            \
+  { if constexpr (BPS) SPGNN_RAW(IMG0_, R_, I_) else SPGNN_CVT(IMG0_, R_, I_, sB) }
+#define SPGNN_MASKG(R_, K0_)                                                                                 \
+  {                                                                                                          \
+    if (!((K0_) + kq < a.K)) { _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) R_[q_] = u32x4{0u, 0u, 0u, 0u}; } \
+  }
 #define SPGNN_MASK(R_, K0_)                                                                                  \
   {                                                                                                          \
     const int k_ = (K0_) + kq;                                                                               \
@@ -562,11 +601,11 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) rb[i] = SPGNN_LDB(i, 0);
   SPGNN_MASK(ra, 0)
-  SPGNN_MASK(rb, 0)
+  if constexpr (BPS) SPGNN_MASKG(rb, 0) else SPGNN_MASK(rb, 0)
 #pragma unroll
   for (int i = 0; i < 4; ++i) SPGNN_CVT(smem, ra[i], i, sA)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) SPGNN_CVT(smem + 2 * IMG, rb[i], i, sB)
+  for (int i = 0; i < 4; ++i) SPGNN_PUTB(smem + 2 * IMG, rb[i], i)
 #pragma unroll
   for (int i = 0; i < 4; ++i) ra[i] = SPGNN_LDA(i, BK);
 #pragma unroll
@@ -584,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
     const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
     if (!(STEADY_) && has_next) {                                                                            \
       SPGNN_MASK(ra, ((T_) + 1) * BK)                                                                        \
-      SPGNN_MASK(rb, ((T_) + 1) * BK)                                                                        \
+      if constexpr (BPS) SPGNN_MASKG(rb, ((T_) + 1) * BK) else SPGNN_MASK(rb, ((T_) + 1) * BK)               \
     }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
       half8 bh[2], bl[2];                                                                                    \
@@ -614,7 +653,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
               SPGNN_CVT(nbuf, ra[slot], slot, sA)                                                            \
               ra[slot] = SPGNN_LDA(slot, k2);                                                                \
             } else {                                                                                         \
-              SPGNN_CVT(nbuf + 2 * IMG, rb[slot - 4], slot - 4, sB)                                          \
+              SPGNN_PUTB(nbuf + 2 * IMG, rb[slot - 4], slot - 4)                                             \
               rb[slot - 4] = SPGNN_LDB(slot - 4, k2);                                                        \
             }                                                                                                \
           }                                                                                                  \
@@ -640,6 +679,9 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
 #undef SPGNN_LDB
 #undef SPGNN_CVT
 #undef SPGNN_MASK
+#undef SPGNN_MASKG
+#undef SPGNN_PUTB
+#undef SPGNN_RAW
 
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
@@ -1116,6 +1158,44 @@ __global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __res
   }
 }
 
+// spgnn_presplit: up to two row-major fp32 matrices (a weight operand and its transpose) -> their pre-split form (see
+// Args), with the operand's power-of-two scale either given (scale_in) or derived here from the block maxima a producer
+// left (partial[0..n), as scale_from_partials would): every block reduces the short array itself, block 0 publishes the
+// scale.  One launch replaces the scale reduction of spgnn_weight_cat's operand and adds the split.
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ partial, int n, const float* __restrict__ scale_in,
+                                                       float* __restrict__ scale_out,
+                                                       const float* __restrict__ s0, int64_t ld0, int R0, int K0, float* __restrict__ d0,
+                                                       const float* __restrict__ s1, int64_t ld1, int R1, int K1, float* __restrict__ d1) {
+  __shared__ float red[4];
+  float sc;
+  if (scale_in) {
+    sc = scale_in[0];
+  } else {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    sc = pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  }
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = sc;
+  const int g0 = (K0 + 3) >> 2, g1 = s1 ? (K1 + 3) >> 2 : 0;           // float4 groups per row
+  const int64_t n0 = (int64_t)R0 * g0, tot = n0 + (int64_t)R1 * g1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const bool first = i < n0;
+    const int64_t j = first ? i : i - n0;
+    const int g = first ? g0 : g1, K = first ? K0 : K1;
+    const int64_t ld = first ? ld0 : ld1;
+    const int r = (int)(j / g), c = (int)(j % g) * 4;
+    const float* src = (first ? s0 : s1) + (int64_t)r * ld + c;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    v.y = c + 1 < K ? v.y : 0.f; v.z = c + 2 < K ? v.z : 0.f; v.w = c + 3 < K ? v.w : 0.f;
+    uint2 h, l;
+    split4_pk(v, sc, h, l);
+    *reinterpret_cast<uint4*>((first ? d0 : d1) + (int64_t)r * ld + c) = make_uint4(h.x, h.y, l.x, l.y);
+  }
+}
+
 }  // namespace gemm
 
 extern "C" {
@@ -1127,8 +1207,9 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                         int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                         int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
-                        int32_t tile, spgnn_stream_t stream) {
+                        int32_t tile, int32_t b_presplit, spgnn_stream_t stream) {
   if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (mean_out) {
     if (!mean_other) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
@@ -1173,8 +1254,10 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                    mean_other, mean_other_stride, mean_out, mean_out_stride};
       int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
       const size_t lds_bytes = 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16);       // 160 KB
-      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v3, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v3, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
+#define SPGNN_LAUNCH_NT(KERNEL_, THREADS_)                                                                    \
+      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; } \
+      hipLaunchKernelGGL((KERNEL_), dim3((unsigned)tiles), dim3(THREADS_), lds_bytes, st, a);
+      if (b_presplit) { SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<true>, 512) } else { SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<false>, 512) }
       return spgnn_detail::check_launch("spgnn_gemm");
     }
     const int WM = tile == 4 ? 4 : (tile == 2 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
@@ -1186,12 +1269,11 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
     int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
     const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
     if (WM == 4) {
-      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v2<4>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<4>, dim3((unsigned)tiles), dim3(512), lds_bytes, st, a);
+      if (b_presplit) { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, true>), 512) } else { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, false>), 512) }
     } else {
-      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_nt_f16x3_v2<2>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-      hipLaunchKernelGGL(gemm::gemm_nt_f16x3_v2<2>, dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
+      if (b_presplit) { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, true>), 256) } else { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, false>), 256) }
     }
+#undef SPGNN_LAUNCH_NT
   }
   return spgnn_detail::check_launch("spgnn_gemm");
 }
@@ -1200,27 +1282,47 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
                   int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                   int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
-                  spgnn_stream_t stream) {
+                  int32_t b_presplit, spgnn_stream_t stream) {
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
-                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, 0, stream);
+                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, 0, b_presplit, stream);
 }
 
 int spgnn_gemm_nt_tile(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                        int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
                        int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                        int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
-                       int32_t tile, spgnn_stream_t stream) {
+                       int32_t tile, int32_t b_presplit, spgnn_stream_t stream) {
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
-                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, tile, stream);
+                      activation, score_l, score_r, score_out, score_cols, nullptr, 0, nullptr, 0, tile, b_presplit, stream);
 }
 
 int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                            int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* bias,
                            int32_t activation, const float* other_head, int64_t other_head_stride, float* mean_out,
-                           int64_t mean_out_stride, spgnn_stream_t stream) {
+                           int64_t mean_out_stride, int32_t b_presplit, spgnn_stream_t stream) {
   if (!other_head || !mean_out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
-                      nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, 0, stream);
+                      nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, 0, b_presplit, stream);
+}
+
+int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale_in, float* scale_out,
+                   const float* src0, int64_t ld0, int64_t R0, int64_t K0, float* dst0,
+                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, spgnn_stream_t stream) {
+  if ((!partials || n_partials <= 0) == (scale_in == nullptr)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);   // exactly one source of the scale
+  if (n_partials > INT32_MAX || R0 < 0 || K0 <= 0 || R0 > INT32_MAX || K0 > INT32_MAX || (src1 && (R1 < 0 || K1 <= 0 || R1 > INT32_MAX || K1 > INT32_MAX)))
+    return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!src0 || !dst0 || (src1 && !dst1)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (ld0 < ((K0 + 3) & ~int64_t(3)) || (ld0 & 3) || (reinterpret_cast<uintptr_t>(src0) & 15) || (reinterpret_cast<uintptr_t>(dst0) & 15) ||
+      (src1 && (ld1 < ((K1 + 3) & ~int64_t(3)) || (ld1 & 3) || (reinterpret_cast<uintptr_t>(src1) & 15) || (reinterpret_cast<uintptr_t>(dst1) & 15))))
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);        // rows 16-byte aligned, stride >= the width rounded up to 4; dst uses the same strides
+  const int64_t groups = R0 * ((K0 + 3) / 4) + (src1 ? R1 * ((K1 + 3) / 4) : 0);
+  if (groups == 0) return SPGNN_OK;
+  int64_t blocks = (groups + 1023) / 1024;                         // four groups per thread
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gemm::presplit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, (int)n_partials, scale_in,
+                     scale_out, src0, ld0, (int)R0, (int)K0, dst0, src1, ld1, (int)R1, (int)(src1 ? K1 : 0), dst1);
+  return spgnn_detail::check_launch("spgnn_presplit");
 }
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,

@@ -730,6 +730,16 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+PRESPLIT_B = True      # weight operands of the NT products pre-split once per step (spgnn_presplit); False: fp32 rows, split per tile
+
+
+def _b_operand(w: torch.Tensor):
+    """(tensor, b_presplit) to pass as the ``b`` operand of gemm_nt for a weight operand: its pre-split form when
+    weight_cat attached one, else the fp32 rows themselves."""
+    ps = getattr(w, "_spgnn_ps", None) if PRESPLIT_B else None
+    return (ps, True) if ps is not None else (w, False)
+
+
 class _WeightCat(torch.autograd.Function):
     """[w_a ; w_b] (rows of fc.weight, then of res_fc.weight) as ONE GEMM operand with 16-byte rows, its transpose (the
     operand of the input-gradient product) and its split-GEMM scale: one kernel + the scale kernel per layer and step
@@ -753,10 +763,12 @@ class _WeightCat(torch.autograd.Function):
             _capi.check(lib.spgnn_weight_cat(wa.data_ptr(), wa.stride(0), R1, _ptr(wb), 0 if wb is None else wb.stride(0), R2, K,
                                              buf.data_ptr(), Kp, _ptr(buf_t), Rp if want_t else 0, part.data_ptr(),
                                              _stream(w_a)), "spgnn_weight_cat")
-        scale = scale_from_partials(part)
-        ctx.rows = (R1, R2)
         out = buf[:, :K]
-        outs = (out, scale) + ((buf_t[:, :R],) if want_t else ())
+        out_t = buf_t[:, :R] if want_t else None
+        # the operand's scale and the pre-split forms of W and W^T in ONE launch (it replaces the scale reduction)
+        ps, ps_t, scale = presplit(out, partials=part, w2=out_t)
+        ctx.rows = (R1, R2)
+        outs = (out, scale, ps) + ((out_t, ps_t) if want_t else ())
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -769,13 +781,16 @@ class _WeightCat(torch.autograd.Function):
 
 
 def weight_cat(w_a: torch.Tensor, w_b: Optional[torch.Tensor] = None, want_t: bool = True) -> torch.Tensor:
-    """-> w_cat (R, K) view of a 16-byte-row buffer; carries ``_spgnn_scale`` (its GEMM scale) and, with ``want_t``,
-    ``_spgnn_t`` = w_cat^T (K, R) with 16-byte rows."""
+    """-> w_cat (R, K) view of a 16-byte-row buffer; carries ``_spgnn_scale`` (its GEMM scale), ``_spgnn_ps`` (its pre-split
+    form, the ``b`` operand of the forward product) and, with ``want_t``, ``_spgnn_t`` = w_cat^T (K, R) with 16-byte rows
+    and ``_spgnn_t_ps`` (pre-split: the ``b`` operand of the input-gradient product)."""
     _require_cuda(w_a, w_b)
     outs = _WeightCat.apply(w_a, w_b, want_t)
     w = outs[0]
     w._spgnn_scale = (w._version, outs[1])
-    w._spgnn_t = outs[2] if want_t else None
+    w._spgnn_ps = outs[2]
+    w._spgnn_t = outs[3] if want_t else None
+    w._spgnn_t_ps = outs[4] if want_t else None
     return w
 
 
@@ -794,7 +809,8 @@ class _GATLayerFn(torch.autograd.Function):
         if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
             s, sx = scores_fwd(x, w_lr, want_scale=True)   # (N, 2H) = [el | er]; the scale of x comes for free
             sw = operand_scale(w_cat)                      # attached by weight_cat, else one absmax pass
-            y = gemm_nt(x, w_cat, sx, sw)
+            wb, ps = _b_operand(w_cat)
+            y = gemm_nt(x, wb, sx, sw, b_presplit=ps)
         else:
             sx = sw = None
             y = torch.mm(x, w_cat.t())
@@ -806,6 +822,7 @@ class _GATLayerFn(torch.autograd.Function):
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
         ctx.w_t = getattr(w_cat, "_spgnn_t", None)     # W^T with 16-byte rows, written by weight_cat alongside W
+        ctx.w_t_ps = getattr(w_cat, "_spgnn_t_ps", None) if PRESPLIT_B else None
         ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx, sw)
         ctx.mark_non_differentiable(attn)
         return (out_mean if mean else out), attn
@@ -851,13 +868,14 @@ class _GATLayerFn(torch.autograd.Function):
             Kp = (K + 3) // 4 * 4                      # 16-byte rows for the vector kernels downstream
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
             if split:
-                w_t = ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous()   # (K, C): an NT product with W^T
+                ps = ctx.w_t_ps is not None
+                w_t = ctx.w_t_ps if ps else (ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous())   # (K, C): an NT product with W^T
                 J = g_s.shape[1]
                 if J <= 32:                            # + g_S @ W_lr as an exact fp32 rank-2H update in the epilogue
                     w_lr_p = _padded_rows(w_lr, _pad16(K))
-                    gemm_nt(g_y, w_t, sg, sw, out=g_x, upd_u=g_s, upd_v=w_lr_p)   # W^T shares W's scale
+                    gemm_nt(g_y, w_t, sg, sw, out=g_x, upd_u=g_s, upd_v=w_lr_p, b_presplit=ps)   # W^T shares W's scale
                 else:
-                    gemm_nt(g_y, w_t, sg, sw, out=g_x)
+                    gemm_nt(g_y, w_t, sg, sw, out=g_x, b_presplit=ps)
                     scores_bwd_x_(g_x, g_s, w_lr)
             else:
                 torch.mm(g_y, w_cat, out=g_x)
@@ -897,10 +915,12 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             sx = pow2_scale(x)
         sw = operand_scale(w_cat)                  # attached by weight_cat, else one absmax pass
         ctx.w_t = getattr(w_cat, "_spgnn_t", None)
+        ctx.w_t_ps = getattr(w_cat, "_spgnn_t_ps", None) if PRESPLIT_B else None
         ctx.attn_shape = attn_l.shape              # (H, D) or the parameter's own (1, H, D): no select / stack autograd nodes
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
-        y = gemm_nt(x, w_cat, sx, sw, score_l=al, score_r=ar, score_out=parts)
+        wb, ps = _b_operand(w_cat)
+        y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=parts, b_presplit=ps)
         s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
@@ -974,7 +994,10 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4
             g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
-            gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=g_x)
+            if ctx.w_t_ps is not None:
+                gemm_nt(g_y, ctx.w_t_ps, sg, sw, out=g_x, b_presplit=True)
+            else:
+                gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=g_x)
         return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1155,16 +1178,18 @@ class _GATAggFirstFn(torch.autograd.Function):
         w3 = w_fc.view(H, D, F_)
         wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
         sw = pow2_scale(wc.view(H * D, zs))
+        wc_ps = presplit(wc.view(H * D, zs), scale=sw)[0].view(H, D, zs) if (PRESPLIT_B and zs % 4 == 0) else None   # the products' b operand, split once
         out = torch.empty((N, H * D), dtype=torch.float32, device=x.device)
         fuse_mean = mean and headmean_fusable(out, H, D)
         rst = None
+        wb, ps = (wc_ps, True) if wc_ps is not None else (wc, False)
         for h in range(H):
             bh_ = bias[h * D:(h + 1) * D] if bias is not None else None
             if fuse_mean and h == 1:                   # the second head's tiles also write 0.5 * (head 0 + head 1)
                 rst = torch.empty((N, D), dtype=torch.float32, device=x.device)
-                gemm_nt_headmean(z[:, zs:2 * zs], wc[1], sz, sw, out[:, D:2 * D], out[:, :D], rst, bias=bh_, act=act)
+                gemm_nt_headmean(z[:, zs:2 * zs], wb[1], sz, sw, out[:, D:2 * D], out[:, :D], rst, bias=bh_, act=act, b_presplit=ps)
             else:
-                gemm_nt(z[:, h * zs:(h + 1) * zs], wc[h], sz, sw, out=out[:, h * D:(h + 1) * D], bias=bh_, act=act)
+                gemm_nt(z[:, h * zs:(h + 1) * zs], wb[h], sz, sw, out=out[:, h * D:(h + 1) * D], bias=bh_, act=act, b_presplit=ps)
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
         if rst is None:
@@ -1218,9 +1243,13 @@ class _GATAggFirstFn(torch.autograd.Function):
         g_wfc = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if need_w else None
         g_wres = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if (need_w and has_res) else None
         g_bias = torch.empty((H * D,), dtype=torch.float32, device=x.device) if need_bias else None
+        wct = wc.transpose(1, 2).contiguous()          # (H, zs, D): every head's W^T in one copy
+        ps = PRESPLIT_B and D % 4 == 0
+        if ps:
+            wct = presplit(wct.view(H * zs, D), scale=sw)[0].view(H, zs, D)
         for h in range(H):
             gp_h = g_pre[:, h * D:(h + 1) * D]
-            gemm_nt(gp_h, wc[h].t().contiguous(), sg, sw, out=g_z[:, h * zs:(h + 1) * zs])
+            gemm_nt(gp_h, wct[h], sg, sw, out=g_z[:, h * zs:(h + 1) * zs], b_presplit=ps)
             if need_w:                                 # [g_W_fc,h | g_W_res,h] (D, 2F) straight into the two parameters' row blocks
                 gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=need_bias, out=g_wfc[h * D:(h + 1) * D],
                         out2=g_wres[h * D:(h + 1) * D] if has_res else None,
@@ -1462,14 +1491,37 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
     return buf[:1]
 
 
+def presplit(w: torch.Tensor, scale: Optional[torch.Tensor] = None, partials: Optional[torch.Tensor] = None,
+             w2: Optional[torch.Tensor] = None):
+    """Pre-split form of a GEMM ``b`` operand (spgnn_presplit): ``w`` (R, K) fp32 with 16-byte rows -> a tensor of the same
+    shape and strides holding, per group of four columns, the packed fp16 hi / lo pairs of scale * w.  The scale is given
+    (``scale``) or derived from ``partials`` (block maxima) - then it is returned too.  ``w2``: a second matrix under the same
+    scale (the transpose), split by the same launch.  -> (w_ps, w2_ps or None, scale)."""
+    _require_cuda(w, w2)
+    assert (scale is None) != (partials is None) and _rows_aligned(w) and (w2 is None or _rows_aligned(w2))
+    def like(t):
+        buf = torch.empty((t.shape[0], t.stride(0)), dtype=torch.float32, device=t.device)
+        return buf[:, :t.shape[1]]
+    w_ps, w2_ps = like(w), (like(w2) if w2 is not None else None)
+    sc_out = torch.empty(1, dtype=torch.float32, device=w.device) if scale is None else None
+    with torch.cuda.device(w.device):
+        _capi.check(_capi.load().spgnn_presplit(_ptr(partials), partials.numel() if partials is not None else 0, _ptr(scale), _ptr(sc_out),
+                                                w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], w_ps.data_ptr(),
+                                                _ptr(w2), w2.stride(0) if w2 is not None else 0, w2.shape[0] if w2 is not None else 0,
+                                                w2.shape[1] if w2 is not None else 0, _ptr(w2_ps), _stream(w)), "spgnn_presplit")
+    return w_ps, w2_ps, (scale if scale is not None else sc_out)
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, act: int = 0, score_l: Optional[torch.Tensor] = None,
-            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0,
+            b_presplit: bool = False) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
     in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias).  ``score_out``
-    (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns."""
+    (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns.
+    ``b_presplit``: ``b`` is the pre-split form of the operand (:func:`presplit`, made with ``scale_b``)."""
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -1488,14 +1540,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
             _ptr(score_l), _ptr(score_r), _ptr(score_out), score_l.numel() if score_out is not None else 0)
     with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
         if tile:                                       # block tile pinned by the caller (2 / 4 / 5): bit-identical results
-            _capi.check(_capi.load().spgnn_gemm_nt_tile(*args, tile, _stream(a)), "spgnn_gemm_nt_tile")
+            _capi.check(_capi.load().spgnn_gemm_nt_tile(*args, tile, int(b_presplit), _stream(a)), "spgnn_gemm_nt_tile")
         else:
-            _capi.check(_capi.load().spgnn_gemm_nt(*args, _stream(a)), "spgnn_gemm_nt")
+            _capi.check(_capi.load().spgnn_gemm_nt(*args, int(b_presplit), _stream(a)), "spgnn_gemm_nt")
     return out
 
 
 def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: torch.Tensor, other: torch.Tensor,
-                     mean_out: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0) -> None:
+                     mean_out: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, b_presplit: bool = False) -> None:
     """out = act(a @ b^T + bias) and mean_out = 0.5 * (out + other): the second head's projection of a two-head layer also
     writes the mean over heads from its tiles (spgnn_gemm_nt_headmean)."""
     _require_cuda(a, b, out, other, mean_out)
@@ -1506,7 +1558,7 @@ def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: to
         _capi.check(_capi.load().spgnn_gemm_nt_headmean(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                                                         out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act,
                                                         other.data_ptr(), other.stride(0), mean_out.data_ptr(),
-                                                        mean_out.stride(0), _stream(out)), "spgnn_gemm_nt_headmean")
+                                                        mean_out.stride(0), int(b_presplit), _stream(out)), "spgnn_gemm_nt_headmean")
 
 
 def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:

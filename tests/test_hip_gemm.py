@@ -65,6 +65,32 @@ def test_gemm_nt_256x256_kernel(M, N, K):
     assert torch.equal(exact, ai @ bi.t())
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 384, 1063), (300, 130, 39), (1030, 1024, 384), (513, 260, 100)])
+def test_gemm_nt_presplit_b_is_bit_identical(M, N, K):
+    """b_presplit: the weight operand split once by spgnn_presplit (packed fp16 hi / lo pairs in place of every four fp32
+    values, ragged widths zero padded) gives bit for bit what the in-kernel conversion gives, in every tile variant; the
+    scale derived from block maxima equals pow2_scale; a second matrix (the transpose) rides in the same launch."""
+    torch.manual_seed(M + N + K)
+    Kp, Mp = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+    a = torch.randn(M, Kp + 4, device="cuda")[:, :K]
+    b = (torch.randn(N, Kp, device="cuda") / 7)[:, :K]
+    bt = b.t().contiguous() if N % 4 == 0 else torch.nn.functional.pad(b.t(), (0, Mp - N)).contiguous()[:, :N]
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    part = b.abs().amax(1).contiguous()                       # any set of block maxima covering the matrix
+    b_ps, bt_ps, sc = ops.presplit(b, partials=part, w2=bt)
+    assert torch.equal(sc, sb)
+    b_ps2 = ops.presplit(b, scale=sb)[0]
+    assert torch.equal(b_ps.view(torch.int32), b_ps2.view(torch.int32))
+    ref = ops.gemm_nt(a, b, sa, sb)
+    assert rel_err(ref, a.double() @ b.double().t()) < 2e-6
+    for tile in (0, 2, 4, 5):
+        got = ops.gemm_nt(a, b_ps, sa, sb, tile=tile, b_presplit=True)
+        assert torch.equal(got, ref), tile
+    g = torch.randn(M, Mp + 4, device="cuda")[:, :N]          # the input-gradient product reads W^T pre-split
+    sg = ops.pow2_scale(g)
+    assert torch.equal(ops.gemm_nt(g, bt_ps, sg, sb, b_presplit=True), ops.gemm_nt(g, bt, sg, sb))
+
+
 def test_gemm_scaling_keeps_extreme_magnitudes():
     """Values far outside fp16's range (1e-9 .. 1e+7) survive through the power-of-two scales."""
     for mag_a, mag_b in [(1e-9, 1e-3), (1e7, 1e3), (1e-12, 1e6)]:
