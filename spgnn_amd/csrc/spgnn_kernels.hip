@@ -3327,7 +3327,8 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
   if (x_stride < K || gs_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(part))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w: x rows must be 16-byte aligned (stride % 4 == 0)");
   const int64_t rps = (N + splits - 1) / splits;
-  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
+  const int bw = K >= 1024 ? 4 : (K + 255) / 256;        // waves per block = 256-column pieces of a row (narrow rows: no idle waves)
+  const dim3 grid((unsigned)((K + 256 * bw - 1) / (256 * bw)), (unsigned)splits), block(64 * bw);
   hipStream_t st = (hipStream_t)stream;
 #define X(JP) hipLaunchKernelGGL((scores_bwd_w_kernel<float, JP>), grid, block, 0, st, gs, gs_stride, x, x_stride, part, Kp, N, K, rps, J)
   switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
@@ -3345,7 +3346,8 @@ int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* 
   if (x_stride < K || gs_stride < J || !vec_ok_t(x_, x_stride) || !aligned16(part))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w_bf16: x rows must be 8-byte aligned (stride % 4 == 0)");
   const int64_t rps = (N + splits - 1) / splits;
-  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)splits), block(256);
+  const int bw = K >= 1024 ? 4 : (K + 255) / 256;        // waves per block = 256-column pieces of a row (narrow rows: no idle waves)
+  const dim3 grid((unsigned)((K + 256 * bw - 1) / (256 * bw)), (unsigned)splits), block(64 * bw);
   hipStream_t st = (hipStream_t)stream;
 #define X(JP) hipLaunchKernelGGL((scores_bwd_w_kernel<bf16s, JP>), grid, block, 0, st, gs, gs_stride, x_, x_stride, part, Kp, N, K, rps, J)
   switch (padded_j(J)) { case 2: X(2); break; case 4: X(4); break; case 8: X(8); break; case 16: X(16); break;
