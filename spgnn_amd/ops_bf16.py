@@ -314,7 +314,7 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     N, K = x.shape
     J = g_s.shape[1]
     Kp = _pad16(K)
-    splits = max(1, min(1024 // ((K + 255) // 256), N // 16))
+    splits = max(1, min((2048 if J > 8 else 1024) // ((K + 255) // 256), N // 16))      # as ops.scores_bwd_w
     part = torch.empty((splits, J, Kp), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("scores_bwd_w_bf16", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_bwd_w_bf16(g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(),
