@@ -63,6 +63,39 @@ def spmm_case(name, ns, F_, seed):
                         weight=w.numpy(), gcn=gcn.numpy(), gin_eps03=gin.numpy(), max=mx.numpy())
 
 
+def bf16_storage_case(name, ns, fin, H, D, act, mean, seed):
+    """The build's bf16-STORAGE path (BASELINE config 4) has no reference result; what is pinned is the oracle's storage
+    model (oracle.dgl_cpu.Bf16Storage, fp64 arithmetic with bf16 rounding at the product's storage points): a hidden layer
+    (project-first form) or, with ``mean`` and no activation, the output layer in its linear-mean form."""
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    srcs, dsts, off = [], [], 0
+    for n in ns:
+        u, v = edges_from_adj(synthetic.random_tree_adj(n, rng))
+        srcs.append(u + off); dsts.append(v + off); off += n
+    src, dst = torch.from_numpy(np.concatenate(srcs)), torch.from_numpy(np.concatenate(dsts))
+    mk = lambda *s_: (torch.randn(*s_, generator=gen, dtype=torch.float64) * 0.5)
+    x = O._rb(mk(off, fin)).requires_grad_(True)                    # the input rows are bf16 values
+    w, al, ar, b, wr = (mk(H * D, fin) * 0.3).requires_grad_(True), mk(1, H, D).requires_grad_(True), mk(1, H, D).requires_grad_(True), \
+        (mk(H * D) * 0.1).requires_grad_(True), (mk(H * D, fin) * 0.3).requires_grad_(True)
+    actf = {"elu": F.elu, "none": None}[act]
+    if mean:
+        assert act == "none" and O.linear_mean_form(H, D, fin, True)
+        rst = O.gat_conv_linear_mean(src, dst, off, x, w, al, ar, wr, b, 0.2, storage=O.Bf16Storage)[0]
+    else:
+        rst = O.gat_conv(src, dst, off, x, w, al, ar, wr, b, 0.2, actf, storage=O.Bf16Storage)[0].flatten(1)
+    cot = torch.randn(rst.shape, generator=gen, dtype=torch.float64)
+    if not mean:
+        cot = O._rb(cot)                                            # the gradient of stored rows arrives as bf16
+    leaves = dict(x=x, fc_weight=w, attn_l=al, attn_r=ar, res_fc_weight=wr, bias=b)
+    grads = torch.autograd.grad((rst * cot).sum(), list(leaves.values()))
+    out = dict(src=src.numpy(), dst=dst.numpy(), num_nodes=off, H=H, D=D, act=act, mean=int(mean), rst=rst.detach().numpy(),
+               cot=cot.numpy(), **{k: v.detach().numpy() for k, v in leaves.items()})
+    for k, gr in zip(leaves, grads):
+        out["grad_" + k] = (O._rb(gr) if k == "x" else gr).numpy()   # g_x is stored as bf16 rows
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def config1_case():
     """BASELINE.json configs[0]: st_gcn_3 forward on one 128-node synthetic tree.  Inputs and weights are
     regenerated from seeds (torch CPU generator); the expected logits are stored."""
@@ -85,6 +118,8 @@ if __name__ == "__main__":
     gat_layer_case("gat_layer_h1_d64_res_tanh", [12, 30], 39, 1, 64, True, "tanh", 2)
     gat_layer_case("gat_layer_h2_d64_nores_none", [25], 16, 2, 64, False, "none", 3)
     spmm_case("spmm_f64", [10, 21, 3], 64, 4)
+    bf16_storage_case("bf16_storage_hidden_h2_d64_elu", [14, 23], 32, 2, 64, "elu", False, 5)
+    bf16_storage_case("bf16_storage_output_h2_d128_linear_mean", [9, 30], 32, 2, 128, "none", True, 6)
     config1_case()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

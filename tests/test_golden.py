@@ -111,3 +111,57 @@ def test_hip_matches_golden_spmm_and_config1():
     with torch.no_grad():
         out, emb = m(gb)
     assert np.abs(out.cpu().numpy() - z["logits"]).max() / np.abs(z["logits"]).max() < 1e-5
+
+
+BF16_FILES = ["bf16_storage_hidden_h2_d64_elu", "bf16_storage_output_h2_d128_linear_mean"]
+
+
+def _bf16_model(z):
+    src, dst, n = _t(z["src"]), _t(z["dst"]), int(z["num_nodes"])
+    leaves = {k: _t(z[k], True) for k in ("x", "fc_weight", "attn_l", "attn_r", "res_fc_weight", "bias")}
+    if int(z["mean"]):
+        rst = O.gat_conv_linear_mean(src, dst, n, leaves["x"], leaves["fc_weight"], leaves["attn_l"], leaves["attn_r"],
+                                     leaves["res_fc_weight"], leaves["bias"], 0.2, storage=O.Bf16Storage)[0]
+    else:
+        rst = O.gat_conv(src, dst, n, leaves["x"], leaves["fc_weight"], leaves["attn_l"], leaves["attn_r"], leaves["res_fc_weight"],
+                         leaves["bias"], 0.2, ACT[str(z["act"])], storage=O.Bf16Storage)[0].flatten(1)
+    return rst, leaves
+
+
+@pytest.mark.parametrize("name", BF16_FILES)
+def test_oracle_storage_model_reproduces_golden(name):
+    """BASELINE config 4 (bf16 storage): the oracle's storage model keeps reproducing its committed vectors."""
+    z = _load(name)
+    rst, leaves = _bf16_model(z)
+    assert np.allclose(rst.detach().numpy(), z["rst"], rtol=1e-12, atol=1e-12)
+    (rst * _t(z["cot"])).sum().backward()
+    for k, t in leaves.items():
+        got = O._rb(t.grad) if k == "x" else t.grad
+        assert np.allclose(got.numpy(), z["grad_" + k], rtol=1e-10, atol=1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BF16_FILES)
+def test_hip_bf16_matches_golden_storage_model(name):
+    """The HIP bf16-storage layer against the committed storage-model vectors: within two bf16 ulps (2^-7) normwise - the
+    path may differ from the model only where fp32 accumulation order moves a value across a rounding boundary."""
+    from spgnn_amd import nn as snn, ops_bf16
+    from spgnn_amd.graph import TreeGraph
+    z = _load(name)
+    H, D, fin, mean = int(z["H"]), int(z["D"]), z["x"].shape[1], bool(int(z["mean"]))
+    g = TreeGraph((z["src"], z["dst"]), int(z["num_nodes"])).to("cuda")
+    layer = snn.GATConv(fin, D, H, 0.0, 0.0, 0.2, True, ACT[str(z["act"])]).cuda()
+    layer.load_state_dict({"fc.weight": _t(z["fc_weight"]).float(), "attn_l": _t(z["attn_l"]).float(), "attn_r": _t(z["attn_r"]).float(),
+                           "bias": _t(z["bias"]).float(), "res_fc.weight": _t(z["res_fc_weight"]).float()})
+    x = ops_bf16.cast_rows(_t(z["x"]).float().cuda()).requires_grad_(True)
+    out = layer(g, x, mean_heads=mean)
+    out = out if mean else out.flatten(1)
+    assert out.dtype == (torch.float32 if mean else torch.bfloat16)
+    ulp2 = 2.0 ** -7
+    assert np.abs(out.detach().float().cpu().numpy() - z["rst"]).max() <= ulp2 * np.abs(z["rst"]).max()
+    out.backward(_t(z["cot"]).to(out.dtype).cuda())
+    got = {"x": x.grad.float(), "fc_weight": layer.fc.weight.grad, "attn_l": layer.attn_l.grad, "attn_r": layer.attn_r.grad,
+           "res_fc_weight": layer.res_fc.weight.grad, "bias": layer.bias.grad}
+    for k, t in got.items():
+        ref = z["grad_" + k]
+        assert np.abs(t.cpu().numpy().reshape(ref.shape) - ref).max() <= ulp2 * np.abs(ref).max(), k
