@@ -317,7 +317,12 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
       float* dst0 = a.C + (int64_t)(row0 + wm * (32 * MI) + i * 32 + r_in) * a.ldc + col;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        *reinterpret_cast<float4*>(dst0 + (int64_t)(it * 4) * a.ldc) = vv[it];
+        // streaming store: the (M, N) result is far larger than the caches and is next read by another kernel; without the
+        // temporal hint the store bursts at the end of every round of tiles are 2-5 % of a product (timing-only build
+        // without the stores: 515 -> 483 us at K = 1063, 217 -> 186 at K = 384; with this hint 504 / 206; the consumers'
+        // times do not move: tools/bench_variants.sh)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{vv[it].x, vv[it].y, vv[it].z, vv[it].w}, reinterpret_cast<f4v*>(dst0 + (int64_t)(it * 4) * a.ldc));
       }
     } else {
     float uu[8][4];
