@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 29
+#define SPGNN_ABI_VERSION 30
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -629,6 +629,12 @@ int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
                        int32_t c_is_f32, int64_t M, int64_t N, int64_t K, const float* bias, int32_t activation,
                        const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                        spgnn_stream_t stream);
+/* The same product with the block tile named (tests): 0 = chosen from the shape, 2 = 128 x 128, 4 = 256 x 128,
+ * 5 = 256 x 256 (waves of 128 x 64).  Every tile performs the same arithmetic per output element: bit-identical results. */
+int spgnn_gemm_nt_bf16_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                            int32_t c_is_f32, int64_t M, int64_t N, int64_t K, const float* bias, int32_t activation,
+                            const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                            int32_t tile, spgnn_stream_t stream);
 
 /*
  * Weight gradients: partial[s] (M, N; row stride ldc; fp32) = A[rows of split s, :M]^T * B[rows of split s, :N] for

@@ -114,18 +114,21 @@ __device__ __forceinline__ bf16x8 frag_swz(const uint16_t* img, int row, int chu
   return *reinterpret_cast<const bf16x8*>(img + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
 }
 
-template <int WM> constexpr int nt_lds_bytes() {
-  const int stages = 2 * KSUB * (64 * WM * SUB + BN * SUB) * 2, slabs = 2 * WM * 32 * 68 * 4;
+template <int WM, int WN, int MI> constexpr int nt_lds_bytes() {
+  const int stages = 2 * KSUB * (32 * MI * WM * SUB + 64 * WN * SUB) * 2, slabs = WM * WN * 32 * 68 * 4;
   return stages > slabs ? stages : slabs;
 }
 
-// WM row waves (64 rows each) x 2 column waves: tile (64 WM) x 128, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
-template <int WM, bool F32OUT>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT a) {
-  constexpr int TBM = 64 * WM, NT = 128 * WM;
-  constexpr int A_IMG = TBM * SUB, B_IMG = BN * SUB;              // elements per sub-image
+// WM row waves x WN column waves, each wave (32 MI) x 64 = MI x 2 MFMA tiles of 32 x 32: block tile (32 MI WM) x (64 WN).
+//   <2, 2, 2> 128 x 128 (4 waves, two blocks per CU), <4, 2, 2> 256 x 128 (8 waves), <2, 4, 4> 256 x 256 (8 waves of
+//   128 x 64: per MFMA 3/4 of the LDS fragment bytes of the 64 x 64 wave tile - with 64 x 64 wave tiles the fragment reads
+//   of a stage take as many LDS cycles as its MFMAs take matrix-pipe cycles - and half the DMA bytes of the 256 x 128 tile).
+template <int WM, int WN, int MI, bool F32OUT>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_bf16(ArgsNT a) {
+  constexpr int TBM = 32 * MI * WM, TBN = 64 * WN, NT = 64 * WM * WN;
+  constexpr int A_IMG = TBM * SUB, B_IMG = TBN * SUB;             // elements per sub-image
   constexpr int STAGE = KSUB * (A_IMG + B_IMG);
-  constexpr int LOADS = KSUB * (TBM * 4 / NT + BN * 4 / NT);      // DMA instructions per thread and stage
+  constexpr int LOADS = KSUB * (TBM * 4 / NT + TBN * 4 / NT);     // DMA instructions per thread and stage
   constexpr int EP = 68;                                          // epilogue slab pitch (floats)
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];      // ONE LDS object: stages, then the epilogue slabs
 
@@ -133,14 +136,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
   const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);          // XCD-aware: an XCD walks consecutive tiles, column fastest
   if (tile >= (unsigned)(a.nbm * a.nbn)) return;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
-  const int row0 = bm * TBM, col0 = bn * BN;
+  const int row0 = bm * TBM, col0 = bn * TBN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 31, fh = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
     uint16_t* sb_ = smem + ((T_) & 1) * STAGE;                                                               \
     _Pragma("unroll") for (int u_ = 0; u_ < KSUB; ++u_) {                                                    \
       stage_image<TBM, NT>(a.A, a.lda, row0, a.M, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG)); \
-      stage_image<BN, NT>(a.B, a.ldb, col0, a.N, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG) + A_IMG); \
+      stage_image<TBN, NT>(a.B, a.ldb, col0, a.N, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG) + A_IMG); \
     }                                                                                                        \
   }
   SPGNN_STAGE_IN(0)
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
       const uint16_t* bi = ai + A_IMG;
 #pragma unroll
       for (int ks = 0; ks < SUB / 16; ++ks) {
-        bf16x8 af[2], bf[2];
+        bf16x8 af[MI], bf[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = frag_swz(ai, wm * 64 + i * 32 + fr, ks * 2 + fh);
+        for (int i = 0; i < MI; ++i) af[i] = frag_swz(ai, wm * (32 * MI) + i * 32 + fr, ks * 2 + fh);
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[j] = frag_swz(bi, wn * 64 + j * 32 + fr, ks * 2 + fh);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -203,8 +206,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
     sl = make_float4(a.sc_l[col], a.sc_l[col + 1], a.sc_l[col + 2], a.sc_l[col + 3]);
     sr = make_float4(a.sc_r[col], a.sc_r[col + 1], a.sc_r[col + 2], a.sc_r[col + 3]);
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  // every 32-row half is a literal call: as a loop over i the body (two large paths) is no longer unrolled, and acc[i]
+  // with a run-time i puts the accumulators in scratch memory
+  auto do_half = [&](const int i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
     // Interior halves (all 32 rows and 64 columns exist) take a path without per-row / per-column tests, the activation
     // chosen once, and streaming stores (the result is far larger than the caches and is read next by another kernel) -
     // the two changes that took 30 % off short products in the fp32 kernel (spgnn_gemm.hip, store_tile_through_lds).
-    if (row0 + wm * 64 + i * 32 + 32 <= a.M && col0 + wn * 64 + 64 <= a.N) {
+    if (row0 + wm * (32 * MI) + i * 32 + 32 <= a.M && col0 + wn * 64 + 64 <= a.N) {
       if (!use_sc) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) { vv[it].x += bq.x; vv[it].y += bq.y; vv[it].z += bq.z; vv[it].w += bq.w; }
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
           for (int it = 0; it < 8; ++it) { vv[it].x = fmaxf(vv[it].x, 0.f); vv[it].y = fmaxf(vv[it].y, 0.f); vv[it].z = fmaxf(vv[it].z, 0.f); vv[it].w = fmaxf(vv[it].w, 0.f); }
         }
       }
-      const int64_t rbase = row0 + wm * 64 + i * 32 + r_in;
+      const int64_t rbase = row0 + wm * (32 * MI) + i * 32 + r_in;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int64_t row = rbase + it * 4;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
     } else
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = row0 + wm * 64 + i * 32 + it * 4 + r_in;
+      const int row = row0 + wm * (32 * MI) + i * 32 + it * 4 + r_in;
       float4 v = vv[it];
       if (!use_sc) {                                        // act(C + bias); never combined with the score partials
         v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
@@ -285,7 +289,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_bf16(ArgsNT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  };
+  do_half(0);
+  do_half(1);
+  if constexpr (MI == 4) { do_half(2); do_half(3); }
+  static_assert(MI == 2 || MI == 4, "wave tile is 64 or 128 rows");
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -502,10 +510,11 @@ __global__ __launch_bounds__(256) void cast_rows_bf16_kernel(const float* __rest
 
 extern "C" {
 
-int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
-                       int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
-                       const float* score_r, float* score_out, int32_t score_cols, spgnn_stream_t stream) {
+static int gemm_nt_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
+                             int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
+                             const float* score_r, float* score_out, int32_t score_cols, int32_t tile, spgnn_stream_t stream) {
   using namespace bfg;
+  if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return fail(SPGNN_ERR_ENUM, "spgnn_gemm_nt_bf16: tile must be 0, 2, 4 or 5");
   if (M < 0 || N <= 0 || K <= 0 || N > (1 << 24) || K > (1 << 24)) return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_bf16: bad M/N/K");
   if (M == 0) return SPGNN_OK;
   if (!A || !B || !C) return fail(SPGNN_ERR_NULLPTR, "spgnn_gemm_nt_bf16: null pointer");
@@ -520,9 +529,15 @@ int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     if (!score_l || !score_r || score_cols <= 0 || (score_cols & 63) || score_cols > N || bias || act != SPGNN_ACT_NONE)
       return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_bf16: score partials need score_l/r, score_cols % 64 == 0 <= N, no bias/act");
   }
-  // 256-row tiles when they still give every CU two rounds of work, 128-row tiles (two workgroups per CU) otherwise
-  const int64_t nbn = (N + BN - 1) / BN;
-  const bool big = ((M + 255) / 256) * nbn >= 1024;
+  // 256 x 256 tiles for deep products whose rounds over the 256 CUs come out nearly full (<= 8 % of the last round idle, as
+  // the fp32 kernel's rule; measured at M = 76 410: 1024 x 1024 255 -> 237 us, but 384 -> 1024 124 -> 130 us: 12 stages do
+  // not repay the larger tile's prologue and epilogue); else 256-row tiles when they still give every CU two rounds of
+  // work; else 128-row tiles (two blocks per CU)
+  const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
+  const bool sq = tile == 5 || (tile == 0 && M >= 4096 && K >= 512 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3);
+  const int tbn = sq ? 256 : BN;
+  const int64_t nbn = (N + tbn - 1) / tbn;
+  const bool big = sq || tile == 4 || (tile == 0 && ((M + 255) / 256) * nbn >= 1024);
   const int tbm = big ? 256 : 128;
   const int64_t nbm = (M + tbm - 1) / tbm;
   if (nbm * nbn > (1ll << 30)) return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_bf16: too many tiles");
@@ -530,20 +545,34 @@ int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
            score_out ? score_cols : 0};
   const unsigned grid = (unsigned)((nbm * nbn + 7) / 8 * 8);
   hipStream_t st = (hipStream_t)stream;
-#define SPGNN_NT_LAUNCH(WM_, F32_)                                                                            \
+#define SPGNN_NT_LAUNCH(WM_, WN_, MI_, F32_)                                                                  \
   {                                                                                                          \
-    constexpr int lds_ = nt_lds_bytes<WM_>();                                                                \
-    const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm_nt_bf16<WM_, F32_>, lds_);            \
+    constexpr int lds_ = nt_lds_bytes<WM_, WN_, MI_>();                                                      \
+    const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm_nt_bf16<WM_, WN_, MI_, F32_>, lds_);  \
     if (rc_ != SPGNN_OK) return rc_;                                                                         \
-    hipLaunchKernelGGL((gemm_nt_bf16<WM_, F32_>), dim3(grid), dim3(128 * WM_), lds_, st, a);                 \
+    hipLaunchKernelGGL((gemm_nt_bf16<WM_, WN_, MI_, F32_>), dim3(grid), dim3(64 * WM_ * WN_), lds_, st, a);  \
   }
-  if (big) {
-    if (c_is_f32) SPGNN_NT_LAUNCH(4, true) else SPGNN_NT_LAUNCH(4, false)
+  if (sq) {
+    if (c_is_f32) SPGNN_NT_LAUNCH(2, 4, 4, true) else SPGNN_NT_LAUNCH(2, 4, 4, false)
+  } else if (big) {
+    if (c_is_f32) SPGNN_NT_LAUNCH(4, 2, 2, true) else SPGNN_NT_LAUNCH(4, 2, 2, false)
   } else {
-    if (c_is_f32) SPGNN_NT_LAUNCH(2, true) else SPGNN_NT_LAUNCH(2, false)
+    if (c_is_f32) SPGNN_NT_LAUNCH(2, 2, 2, true) else SPGNN_NT_LAUNCH(2, 2, 2, false)
   }
 #undef SPGNN_NT_LAUNCH
   return check_launch("spgnn_gemm_nt_bf16");
+}
+
+int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
+                       int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
+                       const float* score_r, float* score_out, int32_t score_cols, spgnn_stream_t stream) {
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, 0, stream);
+}
+
+int spgnn_gemm_nt_bf16_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
+                            int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
+                            const float* score_r, float* score_out, int32_t score_cols, int32_t tile, spgnn_stream_t stream) {
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, tile, stream);
 }
 
 int spgnn_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

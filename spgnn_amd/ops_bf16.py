@@ -86,7 +86,7 @@ def weight_operands(w_a: torch.Tensor, w_b: Optional[torch.Tensor], want_t: bool
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, out_f32: bool = False,
             bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, score_l: Optional[torch.Tensor] = None,
-            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T -> (M,N) bf16 rows (or fp32 with ``out_f32``); bf16 MFMA, fp32 accumulate.  ``bias`` (N,) fp32 /
     ``act``: epilogue act(C + bias).  ``score_out`` (M, C/64, 2) fp32 with ``score_l`` / ``score_r`` (C,) fp32: per
     64-column block dot products of the first C output columns, taken from the values as stored."""
@@ -99,11 +99,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         out = torch.empty((M, N), dtype=torch.float32, device=a.device) if out_f32 else empty_rows(M, N, a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == (torch.float32 if out_f32 else BF16)
     with torch.cuda.device(a.device), _timed("gemm_nt_bf16", (M, N, K)):
-        _capi.check(_capi.load().spgnn_gemm_nt_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-                                                    out.stride(0), int(out_f32), M, N, K, _ptr(bias), act, _ptr(score_l),
-                                                    _ptr(score_r), _ptr(score_out),
-                                                    score_l.numel() if score_out is not None else 0, _stream(a)),
-                    "spgnn_gemm_nt_bf16")
+        args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), int(out_f32), M, N, K, _ptr(bias),
+                act, _ptr(score_l), _ptr(score_r), _ptr(score_out), score_l.numel() if score_out is not None else 0)
+        if tile:                                   # block tile pinned by the caller (2 / 4 / 5): bit-identical results
+            _capi.check(_capi.load().spgnn_gemm_nt_bf16_tile(*args, tile, _stream(a)), "spgnn_gemm_nt_bf16_tile")
+        else:
+            _capi.check(_capi.load().spgnn_gemm_nt_bf16(*args, _stream(a)), "spgnn_gemm_nt_bf16")
     return out
 
 

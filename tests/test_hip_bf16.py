@@ -47,6 +47,32 @@ def test_gemm_nt_bf16_exact_on_integers(M, N, K):
     assert out16.dtype == BF and torch.equal(out16.float().cpu(), (a @ b.t()).to(BF).float())
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 512, 1063), (2049, 132, 40), (777, 1024, 200), (260, 260, 264)])
+def test_gemm_nt_bf16_every_tile_variant(M, N, K):
+    """128 x 128, 256 x 128 and 256 x 256 (waves of 128 x 64) block tiles: exact on integers, bit-identical to each other on
+    random data with bias + ELU and with the score partials, fp32 and bf16 results, ragged rows / columns / K."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float()
+    for tile in (2, 4, 5):
+        assert torch.equal(ops_bf16.gemm_nt(_rows(a), _rows(b), out_f32=True, tile=tile).cpu(), a @ b.t()), tile
+    ar, br = _rows(torch.randn(M, K, generator=g)), _rows(torch.randn(N, K, generator=g) / 8)
+    bias = torch.randn(N, generator=g).cuda()
+    ref32 = ops_bf16.gemm_nt(ar, br, out_f32=True, bias=bias, act=ops.ACT_ELU, tile=2)
+    ref16 = ops_bf16.gemm_nt(ar, br, bias=bias, act=ops.ACT_ELU, tile=2)
+    for tile in (4, 5):
+        assert torch.equal(ops_bf16.gemm_nt(ar, br, out_f32=True, bias=bias, act=ops.ACT_ELU, tile=tile), ref32), tile
+        assert torch.equal(ops_bf16.gemm_nt(ar, br, bias=bias, act=ops.ACT_ELU, tile=tile).view(torch.int16), ref16.view(torch.int16)), tile
+    C = N // 64 * 64
+    if C:
+        sl, sr = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+        parts = {}
+        for tile in (2, 4, 5):
+            parts[tile] = torch.empty((M, C // 64, 2), dtype=torch.float32, device="cuda")
+            ops_bf16.gemm_nt(ar, br, score_l=sl, score_r=sr, score_out=parts[tile], tile=tile)
+        assert torch.equal(parts[4], parts[2]) and torch.equal(parts[5], parts[2])
+
+
 def test_gemm_nt_bf16_asymmetric_identity():
     """A = I with an asymmetric B: catches a transposed output / fragment map (cdna_hip_programming.md §3)."""
     n = 256
