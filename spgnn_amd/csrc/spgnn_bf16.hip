@@ -445,6 +445,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16(ArgsTN a) {
     }
   }
   float* Cp = a.C + (int64_t)split * a.split_stride;
+  if (m0 + TM <= a.M && n0 + BN <= a.N) {         // interior tile (block-uniform): straight-line stores, no per-element tests
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* cp = Cp + (int64_t)(m0 + wm * 64 + i * 32 + 4 * fh) * a.ldc + n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cp[(int64_t)((e & 3) + 8 * (e >> 2)) * a.ldc] = acc[i][j][e];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
