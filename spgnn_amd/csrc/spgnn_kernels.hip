@@ -253,6 +253,43 @@ __device__ __forceinline__ float single_pass(float x) {
   asm volatile("v_mov_b32 %0, %0" : "+v"(x));
   return x;
 }
+// Row-local lane permutations as DPP modifiers (VALU: no trip through the LDS crossbar that ds_bpermute takes): quad_perm
+// [1,0,3,2] = xor 1, [2,3,0,1] = xor 2, row_half_mirror = i <-> 7 - i inside 8 lanes, row_mirror = i <-> 15 - i.  Applied in
+// this order they fold pairs, quads, groups of 8 and the 16-lane row: after each step the partial result is uniform in the
+// group it covers (fp addition and max are commutative), so the mirrors combine two uniform halves exactly as xor 4 / xor 8 do.
+template <int CTRL> __device__ __forceinline__ float dpp_row(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+#ifndef SPGNN_DPP_REDUCE
+#define SPGNN_DPP_REDUCE 1
+#endif
+// sum / max over aligned groups of 8 lanes, result in every lane (bit-identical to the xor 1, 2, 4 butterfly)
+__device__ __forceinline__ float group8_sum(float x) {
+#if SPGNN_DPP_REDUCE
+  x = single_pass(x);
+  x = single_pass(x + dpp_row<0xB1>(x));
+  x = single_pass(x + dpp_row<0x4E>(x));
+  x = single_pass(x + dpp_row<0x141>(x));
+  return x;
+#else
+  x = single_pass(x);
+  for (int off = 1; off < 8; off <<= 1) x = single_pass(x + __shfl_xor(x, off, 64));
+  return x;
+#endif
+}
+__device__ __forceinline__ float group8_max(float x) {
+#if SPGNN_DPP_REDUCE
+  x = single_pass(x);
+  x = single_pass(fmaxf(x, dpp_row<0xB1>(x)));
+  x = single_pass(fmaxf(x, dpp_row<0x4E>(x)));
+  x = single_pass(fmaxf(x, dpp_row<0x141>(x)));
+  return x;
+#else
+  x = single_pass(x);
+  for (int off = 1; off < 8; off <<= 1) x = single_pass(fmaxf(x, __shfl_xor(x, off, 64)));
+  return x;
+#endif
+}
 template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
   x = single_pass(x);
 #pragma unroll
@@ -261,6 +298,12 @@ template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
 }
 __device__ __forceinline__ float team_max(float x, int width) {
   x = single_pass(x);
+  if (SPGNN_DPP_REDUCE && width == 16) {
+    x = single_pass(fmaxf(x, dpp_row<0xB1>(x)));
+    x = single_pass(fmaxf(x, dpp_row<0x4E>(x)));
+    x = single_pass(fmaxf(x, dpp_row<0x141>(x)));
+    return single_pass(fmaxf(x, dpp_row<0x140>(x)));
+  }
   for (int off = width >> 1; off > 0; off >>= 1) x = single_pass(fmaxf(x, __shfl_xor(x, off, 64)));
   return x;
 }
@@ -269,6 +312,12 @@ __device__ __forceinline__ float absmax4(float m, float4 v) {
 }
 __device__ __forceinline__ float team_sum(float x, int width) {
   x = single_pass(x);
+  if (SPGNN_DPP_REDUCE && width == 16) {
+    x = single_pass(x + dpp_row<0xB1>(x));
+    x = single_pass(x + dpp_row<0x4E>(x));
+    x = single_pass(x + dpp_row<0x141>(x));
+    return single_pass(x + dpp_row<0x140>(x));
+  }
   for (int off = width >> 1; off > 0; off >>= 1) x = single_pass(x + __shfl_xor(x, off, 64));
   return x;
 }
@@ -441,13 +490,9 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
         const int ue = ell ? a.nbr8[v * 8 + k] : a.indices[beg + kk];
         float x = a.el[(int64_t)ue * a.s_ld + hh] + a.er[v * a.s_ld + hh];
         x = valid ? lrelu(x, a.slope) : -INFINITY;
-        float mx = single_pass(x);
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) mx = single_pass(fmaxf(mx, __shfl_xor(mx, off, 64)));
+        float mx = group8_max(x);
         const float ex = valid ? expf(x - mx) : 0.f;
-        float sm = single_pass(ex);
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) sm = single_pass(sm + __shfl_xor(sm, off, 64));
+        float sm = group8_sum(ex);
         float a_ = ex / sm;
         if (valid) a.attn[(int64_t)(beg + k) * a.H + hh] = a_;
         if (a.p > 0.f) a_ *= keep_scale(a.seed, (int64_t)(beg + kk) * a.H + hh, a.p, a.inv_keep);
@@ -776,17 +821,13 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
       const float epre = a.el[(int64_t)ue * a.s_ld + hh] + a.er[v * a.s_ld + hh];
       al = valid ? al : 0.f;
       if (a.p > 0.f) ga *= keep_scale(a.seed, slot, a.p, a.inv_keep);
-      float S = single_pass(valid ? al * ga : 0.f);
-#pragma unroll
-      for (int off = 1; off < 8; off <<= 1) S = single_pass(S + __shfl_xor(S, off, 64));
+      float S = group8_sum(valid ? al * ga : 0.f);
       float ge = al * ga - al * S;
       ge = epre > 0.f ? ge : ge * a.slope;
       ge = valid ? ge : 0.f;
       const bool writer = lane < NENT;                         // wider teams hold identical copies of the table
       if (writer && valid) a.g_e[slot] = ge;
-      float ger = single_pass(ge);
-#pragma unroll
-      for (int off = 1; off < 8; off <<= 1) ger = single_pass(ger + __shfl_xor(ger, off, 64));
+      float ger = group8_sum(ge);
       if (writer && k == 0) a.g_er[v * a.gs_ld + hh] = ger;
       return;
     }
@@ -1008,9 +1049,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
         const float gq = a.g_e[slot];
         if (a.p > 0.f) x *= keep_scale(a.seed, slot, a.p, a.inv_keep);
         wv[i] = valid ? x : 0.f;
-        float gs = single_pass(valid ? gq : 0.f);
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) gs = single_pass(gs + __shfl_xor(gs, off, 64));
+        float gs = group8_sum(valid ? gq : 0.f);
         gsum[i] = gs;
       }
 #pragma unroll
