@@ -71,8 +71,8 @@ def masked_weighted_ce(logits, labels, mask, class_weight) -> torch.Tensor:
 class FlatBucket:
     """All trainable parameters, their gradients and momentum buffers as three flat fp32 tensors.
     ``p.data`` / ``p.grad`` become views, so autograd accumulates straight into the bucket and one
-    all-reduce + one fused SGD launch cover the whole model.  The last slot of the gradient bucket
-    carries the class-weight sum of the step."""
+    all-reduce + one fused SGD launch cover the whole model.  Two extra slots behind the gradients carry the step's
+    class-weight sum and loss numerator, so the exchange between ranks is exactly ONE collective."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
@@ -80,7 +80,7 @@ class FlatBucket:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
-        total = (self.numel + 1 + 3) // 4 * 4
+        total = (self.numel + 2 + 3) // 4 * 4
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -92,6 +92,7 @@ class FlatBucket:
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             off += n
         self.wsum_slot = self.flat_grad[self.numel:self.numel + 1]
+        self.loss_slot = self.flat_grad[self.numel + 1:self.numel + 2]
         self.steps = 0
 
         self._views = [p.grad for p in self.params]
@@ -184,15 +185,14 @@ class TrainStep:
             ops.DROPOUT_SEED_OFFSET = prev_off
         b.gather_grads()
         b.wsum_slot.copy_(den.detach().reshape(1))
-        return num.detach()
+        b.loss_slot.copy_(num.detach().reshape(1))
+        return b.loss_slot
 
     def _reduce(self, loss_num: torch.Tensor) -> torch.Tensor:
-        """The step's only exchange: one sum all-reduce of the flat gradient bucket (RCCL), one of the loss numerator."""
+        """The step's only exchange: ONE sum all-reduce of the flat gradient bucket (RCCL); the class-weight sum and the loss
+        numerator ride in its last two slots."""
         if self.world > 1:
             dist.all_reduce(self.bucket.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            if loss_num.data_ptr() != getattr(self, "_loss_buf_ptr", 0):
-                loss_num = loss_num.clone()
-            dist.all_reduce(loss_num, op=dist.ReduceOp.SUM, group=self.pg)
         return loss_num
 
     def _back(self, loss_num: torch.Tensor) -> torch.Tensor:
@@ -200,7 +200,7 @@ class TrainStep:
         inv = torch.reciprocal(b.wsum_slot)
         self._apply_update(inv)
         b.steps += 1
-        return loss_num * inv[0]
+        return loss_num.reshape(()) * inv[0]
 
     def _apply_update(self, inv: torch.Tensor) -> None:
         """Fused SGD(momentum) over the flat bucket: one HIP launch (spgnn_sgd_momentum_step)."""
@@ -228,8 +228,6 @@ class TrainStep:
         self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
         self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)     # installed as ops.DROPOUT_SEED_OFFSET inside _front only
         self._use_default_rng = True
-        self._loss_buf = torch.zeros((), dtype=torch.float32, device=dev)      # local loss numerator, all-reduced in place
-        self._loss_buf_ptr = self._loss_buf.data_ptr()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -240,14 +238,14 @@ class TrainStep:
         # thread-local capture mode: other threads (the process group's watchdog) may touch the runtime meanwhile
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._loss_buf.copy_(self._front(g))
+            self._front(g)
         self._graph_back = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
-            self._static_loss = self._back(self._loss_buf)
+            self._static_loss = self._back(self.bucket.loss_slot)
         return self
 
     def replay(self) -> torch.Tensor:
         self._graph.replay()
-        self._reduce(self._loss_buf)
+        self._reduce(self.bucket.loss_slot)
         self._graph_back.replay()
         return self._static_loss
