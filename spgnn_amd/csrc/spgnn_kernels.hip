@@ -2285,33 +2285,54 @@ __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restric
                                                           ST* __restrict__ gX, int64_t ldgx, int64_t N, int K,
                                                           int64_t rows_per_split, int jn, int accumulate) {
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // a block's waves sit side by side on one row: 4 KB contiguous per row
-  if (k >= K) return;
-  const bool full = k + 3 < K;
+  if ((k & ~255) >= K) return;          // a wave with no column at all (wave-uniform)
+  // every lane of a live wave stays in the loop: the gS rows travel through lanes (below); lanes past the width read
+  // column 0 of W and store nothing
+  const bool live = k < K, full = k + 3 < K;
+  const int kk = live ? k : 0;
   const int64_t n0 = (int64_t)blockIdx.y * rows_per_split;
   const int64_t n1 = n0 + rows_per_split < N ? n0 + rows_per_split : N;
+  if (n0 >= n1) return;
   float4 w[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) w[j] = j < jn ? ld4(W + (int64_t)j * Kp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t n = n0; n < n1; ++n) {
-    const float* g = gS + n * ldg;
-    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < J; ++j) w[j] = j < jn ? ld4(W + (int64_t)j * Kp + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // Two gS rows arrive as ONE vector load (lanes 0-31: row n, lanes 32-63: row n + 1; J <= 32), issued one pair ahead,
+  // and are broadcast by v_readlane instead of J scalar loads per row at the point of use.  Measured: K = 384, J = 22
+  // 61 -> 58 us, K = 1024 118 -> 116 us - the kernel is bound by its J fma4 per row and lane (3.4 GFLOP at K = 1024:
+  // ~30 TFLOP/s of plain fp32 VALU) and its stores, not by those loads; the fp32 MFMA form of spgnn_scores_fwd is the next step.
+  const int gl = threadIdx.x & 63;
+  const int gj = (gl & 31) < jn ? (gl & 31) : 0, gh = gl >> 5;
+  const int64_t last = n1 - 1;
+  auto grow = [&](int64_t n) { const int64_t r = n + gh; return gS[(r < last ? r : last) * ldg + gj]; };
+  float ga = grow(n0);
+  for (int64_t n = n0; n < n1; n += 2) {
+    const float gnext = grow(n + 2 < n1 ? n + 2 : last);
 #pragma unroll
-    for (int j = 0; j < J; ++j)
-      if (j < jn) fma4(d, g[j], w[j]);
-    ST* xr = gX + n * ldgx + k;
-    if constexpr (is_f32<ST>::value) {
-      if (accumulate) {
-        if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
-        else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
-      } else {
-        if (full) st4(xr, d);
-        else { xr[0] = d.x; if (k + 1 < K) xr[1] = d.y; if (k + 2 < K) xr[2] = d.z; }
+    for (int half = 0; half < 2; ++half) {
+      const int64_t row = n + half;
+      if (row >= n1) break;             // wave-uniform
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (j < jn) fma4(d, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ga), 32 * half + j)), w[j]);
+      if (live) {
+        ST* xr = gX + row * ldgx + k;
+        if constexpr (is_f32<ST>::value) {
+          if (accumulate) {
+            if (full) { float4 o = ld4(xr); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; st4(xr, o); }
+            else { xr[0] += d.x; if (k + 1 < K) xr[1] += d.y; if (k + 2 < K) xr[2] += d.z; }
+          } else {
+            if (full) st4(xr, d);
+            else { xr[0] = d.x; if (k + 1 < K) xr[1] = d.y; if (k + 2 < K) xr[2] = d.z; }
+          }
+        } else {                        // bf16 rows: whole 4-element chunks (the row padding up to a multiple of 4 is zero filled)
+          if (accumulate) { const float4 o = ldv(xr); d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
+          d.y = k + 1 < K ? d.y : 0.f; d.z = k + 2 < K ? d.z : 0.f; d.w = k + 3 < K ? d.w : 0.f;
+          stv(xr, d);
+        }
       }
-    } else {                            // bf16 rows: whole 4-element chunks (the row padding up to a multiple of 4 is zero filled)
-      if (accumulate) { const float4 o = ldv(xr); d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
-      d.y = k + 1 < K ? d.y : 0.f; d.z = k + 2 < K ? d.z : 0.f; d.w = k + 3 < K ? d.w : 0.f;
-      stv(xr, d);
     }
+    ga = gnext;
   }
 }
 
