@@ -27,5 +27,5 @@ for (M, N) in [(1024, 1063), (1024, 384), (512, 768), (256, 384), (256, 256)]:
     sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     cur = max(1, min(64, 512 // tiles, R // 256))
-    cand = sorted(set([cur, 8, 16, 24, 32, 40, 48, 64, 7, 14, 21]))
+    cand = sorted(set([cur, 16, 24, 32, 40, 48, 56, 64]))
     print(f"M={M} N={N} tiles={tiles} current={cur}: " + " | ".join(f"{s}:{run(a, b, sa, sb, s)*1e3:.0f}us" for s in cand), flush=True)
