@@ -44,6 +44,8 @@ FP32_MATRIX_PEAK = 157.3    # native fp32 MFMA TFLOP/s (the pipe an fp32 GEMM wo
 GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16")
 HELPER_NAMES = ("absmax", "split_rows")
 GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg")
+# roofline.traffic is NOT measured by this run: PMC counters need rocprofv3 passes of their own
+TRAFFIC_SOURCE = "profiles/traffic_latest.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this step, per launch; not measured in this run)"
 
 
 def algorithmic_bytes(key) -> float:
@@ -205,65 +207,27 @@ def pct(xs, q):
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="st_pgat_spgnn_3")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage dtype of node-feature rows inside the GNN head")
-    ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
-    ap.add_argument("--eager", action="store_true",
-                    help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
-    ap.add_argument("--no-eager-leg", action="store_true", help="graph mode: skip the eager steps after the timed region "
-                    "(they carry the HIP events around the roofline kernels)")
-    ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trees", type=int, default=64)
-    ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the message-passing path has no CPU fallback)")
-    # Rehearsal of the N > 1 flow on a one-GPU box: SPGNN_BENCH_REHEARSAL=1 puts every rank on device 0 and moves the
-    # tensors with gloo (RCCL refuses two ranks per device).  Never set by the driver; numbers from it mean nothing.
-    rehearsal = os.environ.get("SPGNN_BENCH_REHEARSAL", "0") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-
+def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=False, no_eager_leg=False, no_dropout=False,
+            no_kernel_timers=False, copy_bw=None):
+    """One measured workload: build the model and the batch, warm up, capture, time ``steps`` steps between barrier +
+    synchronize, then the instrumented eager leg.  -> (the JSON object on rank 0 else None, (cfg, model, samples))."""
     from spgnn_amd import _capi, models, ops, synthetic
     from spgnn_amd.configs import class_weight_list, get_config
     from spgnn_amd.train import TrainStep
     _capi.load()                                              # fail loudly if the HIP library is missing
 
-    cfg = get_config(args.config)
+    cfg = get_config(config)
     torch.manual_seed(0)                                      # identical replicas on every rank
     model = models.build_model(cfg.MODEL).to(dev)
     model.init(None)
     model.set_gcn_only()
-    model.train(not args.no_dropout)
-    bf16 = args.dtype == "bf16"
+    model.train(not no_dropout)
+    bf16 = dtype == "bf16"
     if bf16:
         models.set_storage_dtype(model, torch.bfloat16)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
 
-    samples = synthetic.synthetic_trees(args.trees, rank=rank)
+    samples = synthetic.synthetic_trees(trees, rank=rank)
     g = synthetic.batch_from_samples(samples, dev, cfg.POS_ENC_DIM)
     g.csc(dev)                                                # CSC/CSR built once per loader batch (static for all steps)
     N, E = g.number_of_nodes(), g.number_of_edges()
@@ -279,8 +243,8 @@ def main():
     # Warm-up.  Its last two steps are fully instrumented (HIP events around every hand-written kernel launch): they give
     # the per-kernel breakdown.  Recording ~140 event pairs per step perturbs the step, so they are never inside the
     # timed region; the roofline kernels are re-timed on their own (few events per step) after it.
-    probe = 0 if args.no_kernel_timers else min(2, args.warmup)
-    for _ in range(args.warmup - probe):
+    probe = 0 if no_kernel_timers else min(2, warmup)
+    for _ in range(warmup - probe):
         loss = step.step(g)
     kt_all = {}
     if probe:
@@ -299,7 +263,7 @@ def main():
     # all-reduce, TrainStep.capture) - eagerly the launches and autograd's host work per step take the host as long as
     # the GPU needs for the kernels, so a slow host core would be what is measured.  --eager times eagerly issued steps.
     launch, capture_error = "eager", None
-    if not args.eager:
+    if not eager:
         try:
             step.capture(g)
             launch = "hip-graph replay"
@@ -314,20 +278,20 @@ def main():
     for _ in range(3):                              # replays of the fresh graphs before the clock starts
         loss = run_step()
     sync()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = run_step()
         marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     kt_dom, eager_leg = {}, None
-    if not args.no_eager_leg and not args.no_kernel_timers:
+    if not no_eager_leg and not no_kernel_timers:
         # a replay cannot carry HIP events per launch: the roofline kernels' launches are bracketed in eagerly issued
         # steps right after the timed region (same kernels, same operands, same stream; only these kernels carry events)
-        n_leg = min(args.steps, 20)
+        n_leg = min(steps, 20)
         ops.KernelTimer.start(only=bracket or None)
         t1 = time.perf_counter()
         for _ in range(n_leg):
@@ -338,7 +302,8 @@ def main():
         if not kt_all:
             kt_all, probe = dict(kt_dom), n_leg
     loss_val = float(loss)
-    copy_bw = copy_bandwidth(dev) if rank == 0 else None
+    if copy_bw is None and rank == 0:
+        copy_bw = copy_bandwidth(dev)
 
     tot = torch.tensor([elapsed, float(E), float(N)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -350,23 +315,23 @@ def main():
 
     if rank == 0:
         L = cfg.CONV_LAYERS
-        ms = elapsed / args.steps * 1e3
-        value = E_all * L * args.steps / elapsed
+        ms = elapsed / steps * 1e3
+        value = E_all * L * steps / elapsed
         s_row = 2 if bf16 else 4
         gemm_desc = ("bf16 MFMA, single product, fp32 accumulate (bf16 storage)" if bf16 else
                      "split-fp16 x3 MFMA, fp32 accumulate (fp32-GEMM accuracy)" if ops.GEMM_MODE == "f16x3"
                      else "fp32 (rocBLAS/hipBLASLt via torch.mm)")
         out = {
             "metric": "message-passing edges/sec (fwd+bwd), batched trees", "value": value, "unit": "layer-edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.config} training step (fwd+loss+bwd+allreduce+SGD), {args.trees} trees/GPU, "
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{config} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
                                    f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
-                                   f"dropout {'off' if args.no_dropout else 'on'}",
-                       "trees_per_gpu": args.trees, "global_trees": args.trees * world, "nodes": int(N_all),
+                                   f"dropout {'off' if no_dropout else 'on'}",
+                       "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
                        "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc},
-            "graph_edges_per_s": E_all * args.steps / elapsed, "loss": loss_val,
+            "graph_edges_per_s": E_all * steps / elapsed, "loss": loss_val,
             "step_ms": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
                         "n": len(step_ms), "how": "HIP events on the compute stream around every timed step (rank 0)"},
             "copy_bandwidth": copy_bw,
@@ -477,7 +442,7 @@ def main():
                     tr = traffic_of(rkeys)
                     out["roofline"] = {"bound": "hbm", "kernel": "spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the "
                                        "output layer's spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBPS, "traffic": tr,
+                                       "frac": ach / HBM_PEAK_GBPS, "traffic": tr, "traffic_source": TRAFFIC_SOURCE if tr is not None else None,
                                        "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
                                        "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,
                                        "avg_launch_ms": r_ms / r_n, "measured_in": where}
@@ -487,7 +452,7 @@ def main():
                     out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt (all launches of a step: forward projections and "
                                        "input gradients)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
                                        "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
-                                       "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys),
+                                       "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys), "traffic_source": TRAFFIC_SOURCE,
                                        "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,
                                        "avg_launch_ms": r_ms / r_n, "measured_in": where,
                                        "note": "achieved = ALGORITHMIC flops (2MNK of the fp32 product) / time; the kernel executes "
@@ -519,8 +484,94 @@ def main():
             eager_leg["value"] = E_all * L / (eager_leg["ms_per_step"] * 1e-3) if world == 1 else None
             eager_leg["note"] = "same step issued eagerly after the timed region (host-paced when the host is slower than the GPU)"
             out["eager"] = eager_leg
+        return out, (cfg, model, samples)
+    return None, (cfg, model, samples)
+
+
+# BASELINE.json configs 2-4 beside the headline (config 5 at N = 1): run after it, short, inside the same JSON line
+SECONDARY_LEGS = (("st_gat_6_bf16_512", "st_gat_6", "bf16", 512),
+                  ("st_pgat_spgnn_3_f32_64", "st_pgat_spgnn_3", "f32", 64),
+                  ("st_gat_3_f32_64", "st_gat_3", "f32", 64))
+SECONDARY_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "step_ms", "roofline", "roofline_k123", "loss")
+
+
+def secondary_summary(out):
+    """What a secondary leg contributes to the line: its time, its launch mode and its roofline objects."""
+    s = {k: out[k] for k in SECONDARY_KEYS if k in out}
+    s["launch"] = out["config"]["launch"]
+    s["workload"] = out["config"]["workload"]
+    s["nodes"], s["edges"], s["conv_layers"] = out["config"]["nodes"], out["config"]["edges"], out["config"]["conv_layers"]
+    for k in ("gemm", "message_passing"):
+        if k in out:
+            s[k] = {q: out[k][q] for q in ("ms_per_step", "frac_of_hbm_peak", "achieved_GBps", "algorithmic_TFLOPs",
+                                          "executed_mfma_TFLOPs") if q in out[k]}
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="st_pgat_spgnn_3")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage dtype of node-feature rows inside the GNN head")
+    ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
+    ap.add_argument("--eager", action="store_true",
+                    help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
+    ap.add_argument("--no-eager-leg", action="store_true", help="graph mode: skip the eager steps after the timed region "
+                    "(they carry the HIP events around the roofline kernels)")
+    ap.add_argument("--no-dropout", action="store_true", help="eval-mode arithmetic (parity runs); default keeps dropout on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short legs for BASELINE configs 2-4 after the headline")
+    ap.add_argument("--cpu-trees", type=int, default=64)
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the message-passing path has no CPU fallback)")
+    # Rehearsal of the N > 1 flow on a one-GPU box: SPGNN_BENCH_REHEARSAL=1 puts every rank on device 0 and moves the
+    # tensors with gloo (RCCL refuses two ranks per device).  Never set by the driver; numbers from it mean nothing.
+    rehearsal = os.environ.get("SPGNN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
+                                         eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
+                                         no_kernel_timers=args.no_kernel_timers)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees))
+        headline = args.config == "st_pgat_spgnn_3" and args.dtype == "f32" and args.trees == 512
+        if world == 1 and headline and not args.no_secondary:
+            del model, samples
+            sec = {}
+            for name, c_, d_, t_ in SECONDARY_LEGS:
+                torch.cuda.empty_cache()
+                try:
+                    o2, _ctx = run_leg(c_, d_, t_, min(args.steps, 20), min(args.warmup, 5), rank=0, world=1, dev=dev,
+                                       no_dropout=args.no_dropout, no_kernel_timers=args.no_kernel_timers,
+                                       copy_bw=out.get("copy_bandwidth"))
+                    sec[name] = secondary_summary(o2)
+                    del o2, _ctx
+                except Exception as e:                  # never lose the headline to a secondary leg
+                    sec[name] = {"error": repr(e)[:300]}
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -39,6 +39,9 @@ def filter_state(current: Dict[str, torch.Tensor], saved: Dict[str, torch.Tensor
 
 def reload_state(obj, saved: Dict, overwrite: bool = False, ignored_keys: Iterable[str] = ()) -> List[str]:
     """Merge ``saved`` into ``obj.state_dict()`` (filtered unless ``overwrite``) and load it; returns the keys taken."""
+    if hasattr(obj, "bucket") and hasattr(obj, "load_state_dict") and "param_groups" in saved:
+        obj.load_state_dict(saved)               # train.TrainStep: an optimizer-style state (its own or torch.optim.SGD's)
+        return sorted(saved)
     current = obj.state_dict()
     matched = dict(saved) if overwrite else filter_state(current, saved, ignored_keys)
     current.update(matched)
@@ -46,11 +49,28 @@ def reload_state(obj, saved: Dict, overwrite: bool = False, ignored_keys: Iterab
     return sorted(matched)
 
 
+def _load_file(cpk_path, map_location, trusted: bool):
+    """``torch.load`` restricted to tensors and plain containers (``weights_only=True``).  A checkpoint that pickles other
+    objects (the reference stores its metric object's ``state_dict``, plain data, but older files may hold more) is only
+    unpickled in full when the caller says the file is ``trusted``: unpickling runs arbitrary code from the file."""
+    try:
+        return torch.load(cpk_path, map_location=map_location, weights_only=True)
+    except Exception as e:                   # pickle.UnpicklingError and friends: something outside the allow-list
+        if not trusted:
+            raise RuntimeError(f"{cpk_path}: the checkpoint holds objects beyond tensors and plain containers ({e}); pass "
+                               "trusted=True to unpickle it in full (only for files you wrote yourself), or allow-list "
+                               "its classes with torch.serialization.add_safe_globals") from e
+        log.warning("%s: falling back to a full unpickle (trusted=True)", cpk_path)
+        return torch.load(cpk_path, map_location=map_location, weights_only=False)
+
+
 def load_pretrained_model(cpk_path, reload_objects: Sequence, state_keys: Sequence[str], ignored_keys: Iterable[str] = (),
-                          device: str = "cuda") -> Dict:
+                          device: str = "cuda", trusted: bool = False) -> Dict:
     """Same contract as the reference function of this name: ``reload_objects[n]`` is restored from
-    ``saved_states[state_keys[n]]`` when that key exists ("metric" is taken as it is, everything else filtered)."""
-    saved_states = torch.load(cpk_path, map_location="cpu" if device == "cpu" else None, weights_only=False)
+    ``saved_states[state_keys[n]]`` when that key exists ("metric" is taken as it is, everything else filtered).
+    ``reload_objects`` may hold a :class:`spgnn_amd.train.TrainStep` under "optimizer_dict": it takes a
+    ``torch.optim.SGD`` state dict (the reference's) as well as its own.  ``trusted``: see :func:`_load_file`."""
+    saved_states = _load_file(cpk_path, "cpu" if device == "cpu" else None, trusted)
     for obj, key in zip(reload_objects, state_keys):
         if key in saved_states:
             reload_state(obj, saved_states[key], overwrite=(key == "metric"), ignored_keys=ignored_keys)

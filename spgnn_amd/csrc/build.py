@@ -18,7 +18,12 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.jo
 # v_pk_mov_b32 op_sel shuffles) gave transiently wrong per-edge dots in gat_bwd_dst when a second process shared the GPU
 # (spgnn_kernels.hip, SPGNN_DIST_DST; tools/dbg_dst_repro.py); scalar fp32 code is as fast there.  The GEMM files keep it:
 # their packed conversions are what the split costs least with, and their cross-lane reads are guarded by hand.
-EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]}
+# -fno-vectorize as well: the loop vectorizer paired the general-degree fallback loops into the same packed ops (645 of them in
+# gat_fwd_vec / gat_agg_fwd); with both vectorizers off the object holds NO packed fp32 arithmetic, and _check_isa() below
+# keeps it that way (the mechanism of the hazard is unconfirmed, so the fence is "no such instruction in this file").
+EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize", "-fno-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]}
+NO_PACKED_FP32 = ("spgnn_kernels.hip",)     # objects that must not contain v_pk_{fma,mul,add}_f32 at all
+LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
 def _obj(src: str) -> str:
@@ -27,6 +32,64 @@ def _obj(src: str) -> str:
 
 def _stale(target: str, deps) -> bool:
     return not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
+
+
+def device_isa(obj: str) -> str:
+    """Disassembly of the gfx950 code object bundled in ``obj``."""
+    import glob
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="spgnn_isa_")
+    try:
+        local = os.path.join(tmp, "o.o")
+        shutil.copy(obj, local)
+        subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], cwd=tmp,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = glob.glob(local + ".*gfx950*")
+        if not cos:
+            raise RuntimeError(f"{obj}: no gfx950 code object found")
+        return subprocess.check_output([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", cos[0]], text=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def packed_fp32_report(obj: str) -> dict:
+    """{function: (packed fp32 ops, cross-lane reads)} for every function of ``obj`` that has packed fp32 arithmetic
+    (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); cross-lane reads = DPP modifiers, ds_bpermute / ds_swizzle, v_readlane,
+    v_permlane."""
+    import re
+    fn, pk, xl = None, {}, {}
+    for line in device_isa(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            fn = m.group(1)
+            continue
+        t = line.split()
+        if fn is None or len(t) < 2:
+            continue
+        op = t[0]
+        if re.match(r"v_pk_(fma|mul|add)_f32", op):
+            pk[fn] = pk.get(fn, 0) + 1
+        if "dpp" in line or op.startswith(("ds_bpermute", "ds_swizzle", "v_readlane", "v_permlane")):
+            xl[fn] = xl.get(fn, 0) + 1
+    return {f: (n, xl.get(f, 0)) for f, n in pk.items()}
+
+
+def _check_isa(src: str, verbose: bool) -> None:
+    """The fence behind DESIGN.md section 4.1's hazard: packed fp32 ops next to cross-lane reads gave transiently wrong
+    values when a second process shared the GPU.  The row kernels' object must hold none at all (build error otherwise);
+    for the GEMM objects, whose cross-lane sums are guarded by hand, the functions where both occur are listed."""
+    rep = packed_fp32_report(_obj(src))
+    base = os.path.basename(src)
+    if base in NO_PACKED_FP32:
+        if rep:
+            worst = sorted(rep.items(), key=lambda kv: -kv[1][0])[:5]
+            raise RuntimeError(f"{base}: packed fp32 arithmetic in {len(rep)} function(s) of an object that must have none "
+                               f"(-fno-slp-vectorize -fno-vectorize lost?): {worst}")
+    elif verbose:
+        both = {f: v for f, v in rep.items() if v[1]}
+        print(f"{base}: packed fp32 ops in {len(rep)} function(s), {len(both)} of them also read across lanes "
+              f"(guarded by hand: single_pass / empty asm between the chains)", flush=True)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -43,6 +106,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if todo:
         with ThreadPoolExecutor(max_workers=len(todo)) as ex:
             list(ex.map(compile_one, todo))
+        for src in todo:
+            _check_isa(src, verbose)
     objs = [_obj(s) for s in SOURCES]
     if todo or _stale(OUT, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

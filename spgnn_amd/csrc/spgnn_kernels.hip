@@ -89,12 +89,7 @@ static_assert(kBlock % 64 == 0 && kBlock >= 64 && kBlock <= 1024, "whole waves p
 // the kernels latency-bound - a wave walks one dependent index -> score -> row chain per node - and four chains per
 // wave hide more of it than the SGPR savings of a whole-wave team are worth: measured for single-head layers
 // (1x256: fwd 51 -> 42, bwd 68 -> 59 / 35 -> 27 us; 1x128: 33 -> 25, 39 -> 30, 20 -> 17 us), not for two-head ones.
-#ifndef SPGNN_ABP_ROWS
-#define SPGNN_ABP_ROWS 4          // rows per trip of act_bwd_proj (2 measured slower: see DESIGN.md)
-#endif
-#ifndef SPGNN_NARROW_TEAMS
-#define SPGNN_NARROW_TEAMS 2      // 1: 16-lane teams for one-head layers up to 256 columns; 2: two-head layers too; 3: and 32 lanes at 512
-#endif
+constexpr int kAbpRows = 4;       // rows per trip of act_bwd_proj (2 measured slower: see DESIGN.md)
 bool pick_team(int64_t width, int& T, int& R, bool narrow = false) {
   if (width <= 0 || (width & 3)) return false;
   int64_t q = width >> 2;
@@ -102,7 +97,6 @@ bool pick_team(int64_t width, int& T, int& R, bool narrow = false) {
     const int64_t r = q / 16;
     if (r == 1 || r == 2 || r == 4) { T = 16; R = (int)r; return true; }
   }
-  if (narrow && SPGNN_NARROW_TEAMS >= 3 && q == 128) { T = 32; R = 4; return true; }
   const int ts[3] = {64, 32, 16};
   for (int t : ts) {
     if (q % t) continue;
@@ -260,35 +254,20 @@ __device__ __forceinline__ float single_pass(float x) {
 template <int CTRL> __device__ __forceinline__ float dpp_row(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
-#ifndef SPGNN_DPP_REDUCE
-#define SPGNN_DPP_REDUCE 1
-#endif
 // sum / max over aligned groups of 8 lanes, result in every lane (bit-identical to the xor 1, 2, 4 butterfly)
 __device__ __forceinline__ float group8_sum(float x) {
-#if SPGNN_DPP_REDUCE
   x = single_pass(x);
   x = single_pass(x + dpp_row<0xB1>(x));
   x = single_pass(x + dpp_row<0x4E>(x));
   x = single_pass(x + dpp_row<0x141>(x));
   return x;
-#else
-  x = single_pass(x);
-  for (int off = 1; off < 8; off <<= 1) x = single_pass(x + __shfl_xor(x, off, 64));
-  return x;
-#endif
 }
 __device__ __forceinline__ float group8_max(float x) {
-#if SPGNN_DPP_REDUCE
   x = single_pass(x);
   x = single_pass(fmaxf(x, dpp_row<0xB1>(x)));
   x = single_pass(fmaxf(x, dpp_row<0x4E>(x)));
   x = single_pass(fmaxf(x, dpp_row<0x141>(x)));
   return x;
-#else
-  x = single_pass(x);
-  for (int off = 1; off < 8; off <<= 1) x = single_pass(fmaxf(x, __shfl_xor(x, off, 64)));
-  return x;
-#endif
 }
 template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
   x = single_pass(x);
@@ -298,7 +277,7 @@ template <int W> __device__ __forceinline__ float team_sum_fixed(float x) {
 }
 __device__ __forceinline__ float team_max(float x, int width) {
   x = single_pass(x);
-  if (SPGNN_DPP_REDUCE && width == 16) {
+  if (width == 16) {
     x = single_pass(fmaxf(x, dpp_row<0xB1>(x)));
     x = single_pass(fmaxf(x, dpp_row<0x4E>(x)));
     x = single_pass(fmaxf(x, dpp_row<0x141>(x)));
@@ -312,7 +291,7 @@ __device__ __forceinline__ float absmax4(float m, float4 v) {
 }
 __device__ __forceinline__ float team_sum(float x, int width) {
   x = single_pass(x);
-  if (SPGNN_DPP_REDUCE && width == 16) {
+  if (width == 16) {
     x = single_pass(x + dpp_row<0xB1>(x));
     x = single_pass(x + dpp_row<0x4E>(x));
     x = single_pass(x + dpp_row<0x141>(x));
@@ -334,49 +313,25 @@ __device__ __forceinline__ float team_sum(float x, int width) {
 // registers; larger degrees fall back to multi-pass loops of identical arithmetic.
 // =================================================================================================
 constexpr int kMaxFast = 8;
-// A/B switches (tools/ab_kernels.py, MI355X, 512 trees).  With exec-masked per-edge branches (one s_waitcnt per
-// load) the up-front path only paid off for the forward; written as unconditional clamped loads + wave-uniform
-// scalars it wins everywhere: fwd 1213 -> 692 us, bwd_dst 1162 -> 779 us, bwd_src 540 -> 451 us summed over the
-// seven st_pgat_spgnn_3 layer shapes (2x1024 forward alone 770 -> 385 us = 5.7 TB/s algorithmic).
-#ifndef SPGNN_FWD_FAST
-#define SPGNN_FWD_FAST 1
-#endif
-#ifndef SPGNN_GATHER8
-#define SPGNN_GATHER8 1
-#endif
-#ifndef SPGNN_DST_FAST
-#define SPGNN_DST_FAST 1
-#endif
-#ifndef SPGNN_SRC_FAST
-#define SPGNN_SRC_FAST 1
-#endif
-#ifndef SPGNN_DIST_SOFTMAX
-#define SPGNN_DIST_SOFTMAX 1      // one (slot, head) attention entry per lane + broadcast instead of the whole table per lane
-#endif
-#ifndef SPGNN_DIST_FWD
-#define SPGNN_DIST_FWD SPGNN_DIST_SOFTMAX
-#endif
-#ifndef SPGNN_DIST_DST
-// The dst-major backward half in the entry-per-lane form (reduce-scatter of the per-edge dots, below): 7 % off the GAT
-// kernels' time.  It REQUIRES this file to be compiled with -fno-slp-vectorize (csrc/build.py does).  With hipcc's SLP
-// vectorizer on (ROCm 7.2, gfx950) the per-edge dots of this form are computed by packed fp32 ops (v_pk_fma_f32 /
-// v_pk_mul_f32 fed by v_pk_mov_b32 op_sel shuffles), and when a second process shares the GPU a few launches per hundred
-// produced a wrong dot for ALL 16 lanes of one team - one 16-lane pass of one instruction - with every operand in memory
-// and in registers verified correct (tools/dbg_dst_repro.py: the row chunks dumped after the dots were right, draining
-// vmcnt / lgkmcnt or padding the cross-lane reads with s_nop changed nothing, the reduce-scatter was not involved).
-// Without the vectorizer: 0 of 400 repetitions in either process, and the row kernels run as fast (K1-K3 1.24 vs 1.26 ms).
-// The same class of problem as single_pass() above: multi-pass packed ops next to instructions that assume single-pass
-// timing.  Alone on the GPU every build was bitwise repeatable.
-#define SPGNN_DIST_DST SPGNN_DIST_SOFTMAX
-#endif
-#if SPGNN_DIST_DST && !defined(SPGNN_NO_SLP_VECTORIZE)
+// Code shape (measured with tools/ab_kernels.py, MI355X, 512 trees; the losing forms are not in the tree).  With exec-masked
+// per-edge branches (one s_waitcnt per load) the up-front path only paid off for the forward; written as unconditional
+// clamped loads + wave-uniform scalars it wins everywhere: fwd 1213 -> 692 us, bwd_dst 1162 -> 779 us, bwd_src 540 -> 451 us
+// summed over the seven st_pgat_spgnn_3 layer shapes (2x1024 forward alone 770 -> 385 us = 5.7 TB/s algorithmic).  When a
+// head is at least a team wide (CH >= 1) the softmax runs one (edge slot, head) ENTRY per lane with the weights broadcast
+// back, instead of the whole table in every lane (7 % off the GAT kernels' time).
+//
+// The dst-major backward half in that entry-per-lane form (reduce-scatter of the per-edge dots, below) REQUIRES this file to
+// be compiled with -fno-slp-vectorize (csrc/build.py does).  With hipcc's SLP vectorizer on (ROCm 7.2, gfx950) the per-edge
+// dots of this form are computed by packed fp32 ops (v_pk_fma_f32 / v_pk_mul_f32 fed by v_pk_mov_b32 op_sel shuffles), and
+// when a second process shares the GPU a few launches per hundred produced a wrong dot for ALL 16 lanes of one team - one
+// 16-lane pass of one instruction - with every operand in memory and in registers verified correct (the row chunks dumped
+// after the dots were right, draining vmcnt / lgkmcnt or padding the cross-lane reads with s_nop changed nothing, the
+// reduce-scatter was not involved).  Without the vectorizer: 0 of 400 repetitions in either process, and the row kernels run
+// as fast (K1-K3 1.24 vs 1.26 ms).  The mechanism is NOT confirmed (same class as single_pass() above: multi-pass packed ops
+// next to instructions that assume single-pass timing); csrc/build.py also fails the build if a packed fp32 op shows up in
+// a kernel of this file that reads across lanes, and tests/test_two_process.py repeats the stress inside the GPU suite.
+#if !defined(SPGNN_NO_SLP_VECTORIZE)
 #error "spgnn_kernels.hip must be compiled with -fno-slp-vectorize -DSPGNN_NO_SLP_VECTORIZE (see the comment above and csrc/build.py)"
-#endif
-#ifndef SPGNN_DST_SEL
-#define SPGNN_DST_SEL(NS_, WAVE_) true
-#endif
-#ifndef SPGNN_DIST_SRC
-#define SPGNN_DIST_SRC SPGNN_DIST_SOFTMAX
 #endif
 
 template <int R, int CH> struct Slots {
@@ -459,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.nbr8[v * 8 + k]);
   }
-  if (SPGNN_FWD_FAST && deg > 0 && deg <= kMaxFast) {
+  if (deg > 0 && deg <= kMaxFast) {
     // Straight-line loads: every index / score load is unconditional (slot k >= deg re-reads the last edge and
     // gets weight 0), so they issue back to back instead of one exec-masked branch and one s_waitcnt per edge;
     // neighbour rows then arrive in batches of kGather edges behind a wave-uniform test.
@@ -468,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
       for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
     }
     float w[kMaxFast][NS];
-    if constexpr (SPGNN_DIST_FWD && CH >= 1) {
+    if constexpr (CH >= 1) {
       // One (edge slot, head) ENTRY per lane instead of the whole 8 x NS table in every lane.  With a head at least a
       // team wide (CH >= 1) every lane of the team needs the same NS x 8 attention weights; computing the table
       // redundantly per lane made the narrow layers (<= 128 columns, 16-lane teams) VALU-bound: 16 expf, 16 divisions
@@ -550,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) w[k][s] = uni<UW>(w[k][s]);
     }
-    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);   // edges per batch (8 float4 in flight for R >= 2)
+    constexpr int kGather = (R >= 8 ? 1 : R == 4 ? 2 : 4);   // edges per batch (8 float4 in flight for R >= 2)
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
       if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -767,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
     wr[s] = (CH == 0) ? (c0 % a.D == 0) : (lane == 0);
   }
 
-  if (SPGNN_DST_FAST && deg > 0 && deg <= kMaxFast) {
+  if (deg > 0 && deg <= kMaxFast) {
     // unconditional, batched loads (slot k >= deg repeats the last edge with attention 0): see gat_fwd_vec
     int u[kMaxFast];
     if (a.nbr8) {                        // ids from the padded neighbour rows: they depend on v only (fetched with indptr[v])
@@ -777,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
 #pragma unroll
       for (int k = 0; k < kMaxFast; ++k) u[k] = uni<WAVE>(a.indices[beg + (k < deg ? k : deg - 1)]);
     }
-    if constexpr (SPGNN_DIST_DST && CH >= 1 && (NS & (NS - 1)) == 0 && (WAVE || NS * 8 <= 16) && SPGNN_DST_SEL(NS, WAVE)) {   // the table must fit the team
+    if constexpr (CH >= 1 && (NS & (NS - 1)) == 0 && (WAVE || NS * 8 <= 16)) {   // the table must fit the team
       // One (edge slot, head) entry per lane (see gat_fwd_vec).  The NS x 8 per-edge dots <ft[u], g_pre[v]> are summed
       // over the team by a reduce-scatter - each round halves the values a lane carries, 8 NS - 1 shuffles in all instead
       // of log2(T) per value - which leaves entry e = s * 8 + k complete in lane e; the softmax / LeakyReLU backward, the
@@ -786,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
       float pd[NENT];
 #pragma unroll
       for (int e = 0; e < NENT; ++e) pd[e] = 0.f;
-      constexpr int kGatherD = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
+      constexpr int kGatherD = (R >= 8 ? 1 : R == 4 ? 2 : 4);
 #pragma unroll
       for (int k0 = 0; k0 < kMaxFast; k0 += kGatherD) {
         if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -846,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
     for (int k = 0; k < kMaxFast; ++k)
 #pragma unroll
       for (int s = 0; s < NS; ++s) ga[k][s] = 0.f;
-    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
+    constexpr int kGather = (R >= 8 ? 1 : R == 4 ? 2 : 4);
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
       if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -1012,7 +967,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  if (SPGNN_SRC_FAST && deg > 0 && deg <= kMaxFast) {
+  if (deg > 0 && deg <= kMaxFast) {
     // unconditional, batched loads (slot k >= deg repeats the last edge with weight 0): see gat_fwd_vec
     int vv[kMaxFast], pp[kMaxFast];
     if (a.out_nbr8) {                    // padded out-neighbour rows: ids and slots depend on u only
@@ -1029,7 +984,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
       }
     }
     float w[kMaxFast][NS];
-    if constexpr (SPGNN_DIST_SRC && CH >= 1) {
+    if constexpr (CH >= 1) {
       // one (edge slot, head) entry per lane (see gat_fwd_vec): attention weight, dropout hash and score gradient are read /
       // formed once per entry, g_el is an 8-lane sum, the NS x 8 weights are broadcast for the row phase
       constexpr int NENT = NS * 8;
@@ -1092,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
         gel[s] += k < deg ? ge[k][s] : 0.f;
       }
     }
-    constexpr int kGather = SPGNN_GATHER8 * (R >= 8 ? 1 : R == 4 ? 2 : 4);
+    constexpr int kGather = (R >= 8 ? 1 : R == 4 ? 2 : 4);
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
       if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -2668,7 +2623,7 @@ const char* spgnn_last_error(void) { return g_err; }
 // 2/8/24/50 % slower - many short-lived workgroups hide the dependent index -> score -> row chain better.
 static bool pick_gat(int H, int D, int& T, int& R, int& CH, int& W) {
   if (D % 4) return false;
-  if (!pick_team((int64_t)H * D, T, R, SPGNN_NARROW_TEAMS && (H == 1 || (SPGNN_NARROW_TEAMS >= 2 && H == 2)))) return false;
+  if (!pick_team((int64_t)H * D, T, R, H == 1 || H == 2)) return false;
   const int team_floats = 4 * T;
   W = T;
   if (D % team_floats == 0) {
@@ -2945,10 +2900,7 @@ int spgnn_gat_agg_supported(int32_t H, int32_t F) {
     default: return fail(SPGNN_ERR_SHAPE, "aggregate-first GAT: H must be 1, 2 or 4 and F <= 1024");  \
   }
 static int agg_chunks(int F) { return F <= 256 ? 1 : F <= 512 ? 2 : 4; }
-#ifndef SPGNN_AGG_TEAM16
-#define SPGNN_AGG_TEAM16 1        // 0: one node per wave for every width (A/B)
-#endif
-static bool agg_team16(int F) { return SPGNN_AGG_TEAM16 && F <= 192; }
+static bool agg_team16(int F) { return F <= 192; }
 #define SPGNN_FOR_H_R16(H_, R_, X)                                                                  \
   switch ((H_) * 16 + (R_)) {                                                                       \
     case 1 * 16 + 1: X(1, 1); break;  case 1 * 16 + 2: X(1, 2); break;  case 1 * 16 + 3: X(1, 3); break; \
@@ -3181,7 +3133,7 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
   const int32_t blocks = spgnn_act_bwd_proj_blocks(N);
   const int64_t rpb = (N + blocks - 1) / blocks;
   hipStream_t st = (hipStream_t)stream;
-#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, SPGNN_ABP_ROWS>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
+#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
                                       (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation)
 #define X(JP) { if (H == 2) XH(JP, 2); else if (H == 1) XH(JP, 1); else XH(JP, 0); }
   if (J <= 8) X(8) else if (J <= 16) X(16) else if (J <= 24) X(24) else X(32)
@@ -3336,19 +3288,17 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
 // Rows per wave.  Measured at N = 76 410 (tools/scores_ab.py): the 22-column classifier product (two column groups, K = 1024)
 // 105 us with 16 rows per wave, 91 with 32, 101 with 64 (too few waves); the 2H <= 16 column score products are fastest
 // with 16 (K = 1063: 82 / 89 / 104 us) - their W fragment is one group, there is little to reuse.
-#ifndef SPGNN_SCORES_RG
-#define SPGNN_SCORES_RG 2
-#endif
+constexpr int kScoresRG = 2;      // row groups of 16 per wave in the wide form
 template <typename ST>
 static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride, int64_t N,
                               int32_t K, int32_t J, float* absmax, hipStream_t st) {
-  const bool wide = SPGNN_SCORES_RG > 1 && J > 16 && N >= 16 * SPGNN_SCORES_RG * 1024;   // >= 1024 waves of the wide form
-  const int rg = wide ? SPGNN_SCORES_RG : 1;
+  const bool wide = kScoresRG > 1 && J > 16 && N >= 16 * kScoresRG * 1024;   // >= 1024 waves of the wide form
+  const int rg = wide ? kScoresRG : 1;
   const int64_t waves = (N + 16 * rg - 1) / (16 * rg);
   const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
 #define X(NG_, RG_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax)
   if (J <= 16) X(1, 1);
-  else if (wide) X(2, SPGNN_SCORES_RG);
+  else if (wide) X(2, kScoresRG);
   else X(2, 1);
 #undef X
 }
@@ -3416,9 +3366,7 @@ int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* 
   return check_launch("spgnn_scores_bwd_w_bf16");
 }
 
-#ifndef SPGNN_BWDX_WAVES
-#define SPGNN_BWDX_WAVES 8192
-#endif
+constexpr int64_t kBwdXWaves = 8192;
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp, float* gx, int64_t gx_stride,
                        int32_t accumulate, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_x: bad N/K/Kp/J");
@@ -3428,7 +3376,7 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_x: gx rows must be 16-byte aligned (stride % 4 == 0)");
   // every row waits for its own scalar score loads, so the latency is hidden by waves, not by unrolling (measured):
   // ~8 waves per SIMD
-  int64_t splits = SPGNN_BWDX_WAVES / ((K + 255) / 256);
+  int64_t splits = kBwdXWaves / ((K + 255) / 256);
   if (splits < 1) splits = 1;
   if (splits > N) splits = N;
   const int64_t rps = (N + splits - 1) / splits;
@@ -3449,7 +3397,7 @@ int spgnn_scores_bwd_x_bf16(const float* gs, int64_t gs_stride, const float* w, 
   bf16s* gx_ = reinterpret_cast<bf16s*>(gx);
   if (gx_stride < ((K + 3) & ~3) || gs_stride < J || !vec_ok_t(gx_, gx_stride) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_x_bf16: gx rows must be 8-byte aligned with a stride that is a multiple of 4 >= K");
-  int64_t splits = SPGNN_BWDX_WAVES / ((K + 255) / 256);
+  int64_t splits = kBwdXWaves / ((K + 255) / 256);
   if (splits < 1) splits = 1;
   if (splits > N) splits = N;
   const int64_t rps = (N + splits - 1) / splits;

@@ -733,11 +733,24 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
 PRESPLIT_B = True      # weight operands of the NT products pre-split once per step (spgnn_presplit); False: fp32 rows, split per tile
 
 
+def _tagged(w: torch.Tensor, name: str):
+    """An attachment weight_cat left on ``w`` under ``name`` as ``(w._version, tensor)``, or None when it is absent or
+    ``w`` was written since (the pre-split form and the scale must describe the same values)."""
+    tag = getattr(w, name, None)
+    return tag[1] if tag is not None and tag[0] == w._version else None
+
+
 def _b_operand(w: torch.Tensor):
     """(tensor, b_presplit) to pass as the ``b`` operand of gemm_nt for a weight operand: its pre-split form when
-    weight_cat attached one, else the fp32 rows themselves."""
-    ps = getattr(w, "_spgnn_ps", None) if PRESPLIT_B else None
+    weight_cat attached one (and ``w`` is unchanged since), else the fp32 rows themselves."""
+    ps = _tagged(w, "_spgnn_ps") if PRESPLIT_B else None
     return (ps, True) if ps is not None else (w, False)
+
+
+def _bt_operand(w: torch.Tensor, use_ps: bool):
+    """(W^T with 16-byte rows or None, its pre-split form or None) as attached by weight_cat; ``use_ps`` is the decision the
+    FORWARD product took (one form per autograd node, whatever PRESPLIT_B is by the time backward runs)."""
+    return _tagged(w, "_spgnn_t"), (_tagged(w, "_spgnn_t_ps") if use_ps else None)
 
 
 class _WeightCat(torch.autograd.Function):
@@ -788,9 +801,9 @@ def weight_cat(w_a: torch.Tensor, w_b: Optional[torch.Tensor] = None, want_t: bo
     outs = _WeightCat.apply(w_a, w_b, want_t)
     w = outs[0]
     w._spgnn_scale = (w._version, outs[1])
-    w._spgnn_ps = outs[2]
-    w._spgnn_t = outs[3] if want_t else None
-    w._spgnn_t_ps = outs[4] if want_t else None
+    w._spgnn_ps = (w._version, outs[2])
+    w._spgnn_t = (w._version, outs[3]) if want_t else None
+    w._spgnn_t_ps = (w._version, outs[4]) if want_t else None
     return w
 
 
@@ -813,6 +826,7 @@ class _GATLayerFn(torch.autograd.Function):
             y = gemm_nt(x, wb, sx, sw, b_presplit=ps)
         else:
             sx = sw = None
+            ps = False
             y = torch.mm(x, w_cat.t())
             s = scores_fwd(x, w_lr)
         ft = y[:, :HD]
@@ -821,8 +835,7 @@ class _GATLayerFn(torch.autograd.Function):
                                           mean=mean, need_out=(act != ACT_NONE))
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
         ctx.has_bias = bias is not None
-        ctx.w_t = getattr(w_cat, "_spgnn_t", None)     # W^T with 16-byte rows, written by weight_cat alongside W
-        ctx.w_t_ps = getattr(w_cat, "_spgnn_t_ps", None) if PRESPLIT_B else None
+        ctx.w_t, ctx.w_t_ps = _bt_operand(w_cat, split and ps)     # W^T with 16-byte rows, written by weight_cat alongside W
         ctx.save_for_backward(x, w_cat, w_lr, y, s, attn, out if act != ACT_NONE else None, sx, sw)
         ctx.mark_non_differentiable(attn)
         return (out_mean if mean else out), attn
@@ -914,12 +927,11 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         if sx is None:
             sx = pow2_scale(x)
         sw = operand_scale(w_cat)                  # attached by weight_cat, else one absmax pass
-        ctx.w_t = getattr(w_cat, "_spgnn_t", None)
-        ctx.w_t_ps = getattr(w_cat, "_spgnn_t_ps", None) if PRESPLIT_B else None
         ctx.attn_shape = attn_l.shape              # (H, D) or the parameter's own (1, H, D): no select / stack autograd nodes
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
         wb, ps = _b_operand(w_cat)
+        ctx.w_t, ctx.w_t_ps = _bt_operand(w_cat, ps)
         y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=parts, b_presplit=ps)
         s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
@@ -1191,7 +1203,7 @@ class _GATAggFirstFn(torch.autograd.Function):
             else:
                 gemm_nt(z[:, h * zs:(h + 1) * zs], wb[h], sz, sw, out=out[:, h * D:(h + 1) * D], bias=bh_, act=act, b_presplit=ps)
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.presplit = bias is not None, wc_ps is not None
         if rst is None:
             rst = head_mean(out, H, D) if mean else out
         has_cls = w_cls is not None and mean
@@ -1244,7 +1256,7 @@ class _GATAggFirstFn(torch.autograd.Function):
         g_wres = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if (need_w and has_res) else None
         g_bias = torch.empty((H * D,), dtype=torch.float32, device=x.device) if need_bias else None
         wct = wc.transpose(1, 2).contiguous()          # (H, zs, D): every head's W^T in one copy
-        ps = PRESPLIT_B and D % 4 == 0
+        ps = ctx.presplit and D % 4 == 0       # the forward's decision: one operand form per autograd node
         if ps:
             wct = presplit(wct.view(H * zs, D), scale=sw)[0].view(H, zs, D)
         for h in range(H):

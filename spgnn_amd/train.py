@@ -205,13 +205,76 @@ class TrainStep:
     def _apply_update(self, inv: torch.Tensor) -> None:
         """Fused SGD(momentum) over the flat bucket: one HIP launch (spgnn_sgd_momentum_step)."""
         b = self.bucket
-        ops.sgd_momentum_step_(b.flat_param, b.flat_grad, b.flat_mom, self.lr, self.momentum, self.weight_decay,
+        n = b.numel                          # the parameters only: the bucket's tail slots carry the weight sum and the loss
+        ops.sgd_momentum_step_(b.flat_param[:n], b.flat_grad[:n], b.flat_mom[:n], self.lr, self.momentum, self.weight_decay,
                                first_step=(b.steps == 0), grad_scale=inv, lr_dev=self._lr_dev)
 
     def set_lr(self, lr: float):
         self.lr = lr
         if self._lr_dev is not None:
             self._lr_dev.fill_(lr)
+
+    # ---- checkpointing: the layout of torch.optim.SGD's state_dict (the reference's ``optimizer_dict``) -----
+    def state_dict(self) -> dict:
+        """``{"state": {i: {"momentum_buffer": tensor}}, "param_groups": [...]}`` as ``torch.optim.SGD`` over the same
+        parameter list writes it (reference job_runner.py:336-343 stores ``optimizer.state_dict()``), so either side can
+        load the other's file; plus ``"spgnn"``: the step count, the attention-dropout seed counter and the mask
+        generator's state, which a resumed run needs to continue the same random streams."""
+        b = self.bucket
+        state, off = {}, 0
+        for i, p in enumerate(b.params):
+            n = p.numel()
+            if b.steps > 0:                      # torch creates the buffer at the first step
+                state[i] = {"momentum_buffer": b.flat_mom[off:off + n].view_as(p).detach().clone()}
+            off += n
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
+                 "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(b.params)))}
+        ctr = getattr(self, "_seed_ctr", None)
+        return {"state": state, "param_groups": [group],
+                "spgnn": {"steps": b.steps, "seed_ctr": int(ctr.item()) if ctr is not None else 0,
+                          "generator": self.gen.get_state().clone()}}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Inverse of :meth:`state_dict`; also takes a plain ``torch.optim.SGD`` state dict (no ``"spgnn"`` entry: the
+        step count is then 1 when momentum buffers exist, else 0).  Works on a captured step too: momentum, learning
+        rate and counters live in device tensors the graphs read."""
+        b = self.bucket
+        groups = sd.get("param_groups", [])
+        if len(groups) != 1 or len(groups[0].get("params", [])) != len(b.params):
+            raise ValueError("optimizer state does not match this model: expected one parameter group of "
+                             f"{len(b.params)} parameters")
+        g0 = groups[0]
+        if g0.get("nesterov") or g0.get("dampening", 0) != 0 or g0.get("maximize"):
+            raise ValueError("only plain SGD with momentum is supported (nesterov / dampening / maximize are set)")
+        state = sd.get("state", {})
+        ids = g0["params"]
+        off, have = 0, 0
+        for i, p in enumerate(b.params):
+            n = p.numel()
+            st = state.get(ids[i], state.get(str(ids[i])))
+            buf = None if st is None else st.get("momentum_buffer")
+            if buf is not None:
+                if buf.numel() != n:
+                    raise ValueError(f"momentum buffer {i} has {buf.numel()} elements, the parameter {n}")
+                b.flat_mom[off:off + n].copy_(buf.reshape(-1).to(b.flat_mom.device, torch.float32))
+                have += 1
+            else:
+                b.flat_mom[off:off + n].zero_()
+            off += n
+        self.momentum, self.weight_decay = float(g0.get("momentum", self.momentum)), float(g0.get("weight_decay", self.weight_decay))
+        self.set_lr(float(g0.get("lr", self.lr)))
+        extra = sd.get("spgnn")
+        b.steps = int(extra["steps"]) if extra else (1 if have else 0)
+        if have and b.steps == 0:
+            b.steps = 1                          # buffers exist: the next step must accumulate into them, not overwrite
+        if extra:
+            self.gen.set_state(extra["generator"].cpu())
+            ctr = getattr(self, "_seed_ctr", None)
+            if ctr is not None:
+                ctr.fill_(int(extra["seed_ctr"]))
+        # (steps == 0 with zeroed buffers is exact under a captured graph too: the kernel's first-step form equals
+        # momentum * 0 + g)
 
     # ---- HIP-graph replay of the static-graph step ---------------------------------------------------------
     def capture(self, g, warmup: int = 3):

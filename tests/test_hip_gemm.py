@@ -226,13 +226,18 @@ def test_weight_cat(R1, R2, K):
     assert torch.equal(w, ref.detach()) and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
     buf = w._base if w._base is not None else w
     assert float(buf[:, K:].abs().sum()) == 0.0                                  # pad columns are zero
-    wt = w._spgnn_t
+    wt = ops._tagged(w, "_spgnn_t")
+    assert ops._tagged(w, "_spgnn_ps") is not None and ops._tagged(w, "_spgnn_t_ps") is not None
     assert torch.equal(wt, ref.detach().t()) and wt.stride(0) % 4 == 0
     assert float(ops.operand_scale(w)) == float(ops.pow2_scale(ref.detach().contiguous() if K % 4 == 0 else
                                                                torch.nn.functional.pad(ref.detach(), (0, -K % 4))))
     g = torch.randn(R1 + R2, K, device="cuda")
     w.backward(g)
     assert torch.equal(wa.grad, g[:R1]) and (wb is None or torch.equal(wb.grad, g[R1:]))
+    # an in-place write to the operand invalidates what weight_cat attached (the split form and the scale describe old values)
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert ops._tagged(w, "_spgnn_ps") is None and ops._tagged(w, "_spgnn_t_ps") is None and ops._b_operand(w)[1] is False
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 1024, 384), (257, 128, 96), (4100, 512, 64)])

@@ -52,7 +52,7 @@ def test_config_forward_matches_oracle(name):
     assert outs[0].shape == (g.number_of_nodes(), 22)
 
 
-@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3", "st_gat_6_nr"])
+@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_pgat_spgnnnl_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3", "st_gat_6_nr"])
 def test_config_loss_gradients_match_oracle(name):
     cfg, model = _build(name, seed=1)
     g = synthetic.make_batch(2, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)

@@ -146,6 +146,141 @@ def test_data_parallel_step_equals_single_rank_step():
     assert torch.equal(ret[0][1], ret[1][1])                        # replicas stay identical
 
 
+def _uneven_setup():
+    """Five trees: rank 0 gets the four larger ones (>= 3 x rank 1's node count), rank 1 one small tree WITHOUT labels whose
+    draws all miss the sampling rate - its mask keeps no node, its local weight sum and loss numerator are 0."""
+    from spgnn_amd import synthetic
+    big = synthetic.synthetic_trees(4, rank=0, fv_dim=8, n_lo=40, n_hi=60)
+    small = synthetic.synthetic_trees(1, rank=1, fv_dim=8, n_lo=21, n_hi=24)
+    small[0]["labels"] = np.zeros_like(small[0]["labels"])
+    return big, small
+
+
+def _dp_worker_uneven(rank, world, port, ret):
+    from spgnn_amd import configs as c, synthetic, train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    train.TrainStep._apply_update = _cpu_update
+    torch.manual_seed(0)
+    model = _TinyNet()
+    big, small = _uneven_setup()
+    g = synthetic.batch_from_samples(big if rank == 0 else small, "cpu", None)
+    n_big = sum(s_["fvs"].shape[0] for s_ in big)
+    n_all = n_big + small[0]["fvs"].shape[0]
+    draws_full = torch.rand(3, n_all, generator=torch.Generator().manual_seed(9))
+    draws_full[:, n_big:] = 0.99                                    # rank 1: every draw misses SAMPLING_RATE = 0.15
+    ts = train.TrainStep(model, c.class_weight_list(c.CLASS_WEIGHTS), 0.15, 0.05, 0.9)
+    mine = draws_full[:, :n_big] if rank == 0 else draws_full[:, n_big:]
+    losses, wsums = [], []
+    for i in range(3):
+        ts._front(g, mine[i])
+        wsums.append(float(ts.bucket.wsum_slot))                   # the LOCAL class-weight sum, before the exchange
+        losses.append(float(ts._back(ts._reduce(ts.bucket.loss_slot))))
+    ret[rank] = (losses, ts.bucket.flat_param[:ts.bucket.numel].clone(), wsums, g.number_of_nodes())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_uneven_ranks_and_empty_mask():
+    """ranks with clearly unequal node counts, and a rank whose mask keeps no node (local weight sum 0): the
+    step must still equal the one-rank step on all trees - the reciprocal is taken of the GLOBAL weight sum."""
+    from spgnn_amd import configs as c, synthetic, train
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_worker_uneven, args=(2, port, ret), nprocs=2, join=True)
+    orig = train.TrainStep._apply_update
+    train.TrainStep._apply_update = _cpu_update
+    try:
+        torch.manual_seed(0)
+        model = _TinyNet()
+        big, small = _uneven_setup()
+        full = synthetic.batch_from_samples(big + small, "cpu", None)
+        n_big = sum(s_["fvs"].shape[0] for s_ in big)
+        draws_full = torch.rand(3, full.number_of_nodes(), generator=torch.Generator().manual_seed(9))
+        draws_full[:, n_big:] = 0.99
+        ts = train.TrainStep(model, c.class_weight_list(c.CLASS_WEIGHTS), 0.15, 0.05, 0.9)
+        losses = [float(ts.step(full, draws_full[i])) for i in range(3)]
+        flat = ts.bucket.flat_param[:ts.bucket.numel]
+    finally:
+        train.TrainStep._apply_update = orig
+    assert ret[0][3] >= 3 * ret[1][3]                               # node counts differ by >= 3 x
+    assert ret[1][2] == [0.0, 0.0, 0.0] and all(w > 0 for w in ret[0][2])   # rank 1 contributed nothing, rank 0 did
+    for r in range(2):
+        assert np.all(np.isfinite(ret[r][0])) and np.allclose(ret[r][0], losses, rtol=1e-5)
+        assert torch.allclose(ret[r][1], flat, rtol=1e-5, atol=1e-7)
+    assert torch.equal(ret[0][1], ret[1][1])
+
+
+def test_train_step_state_dict_round_trip_matches_torch_sgd_layout():
+    """TrainStep.state_dict() has torch.optim.SGD's layout (the reference's ``optimizer_dict``,
+    job_runner.py:336-343); save -> reload -> step continues exactly; a torch.optim.SGD state loads too."""
+    from spgnn_amd import configs as c, synthetic, train
+    orig = train.TrainStep._apply_update
+    train.TrainStep._apply_update = _cpu_update
+    try:
+        g = synthetic.batch_from_samples(synthetic.synthetic_trees(3, rank=0, fv_dim=8, n_lo=21, n_hi=30), "cpu", None)
+        draws = torch.rand(6, g.number_of_nodes(), generator=torch.Generator().manual_seed(3))
+        w = c.class_weight_list(c.CLASS_WEIGHTS)
+
+        def fresh():
+            torch.manual_seed(0)
+            return _TinyNet()
+        a = train.TrainStep(fresh(), w, 0.15, 0.05, 0.9)
+        for i in range(3):
+            a.step(g, draws[i])
+        sd = a.state_dict()
+        model_sd = {k: v.clone() for k, v in a.model.state_dict().items()}
+        # layout: what torch.optim.SGD over the same parameters writes
+        opt = torch.optim.SGD(list(fresh().parameters()), lr=0.05, momentum=0.9)
+        assert set(sd["param_groups"][0]) >= set(opt.state_dict()["param_groups"][0])
+        assert sorted(sd["state"]) == list(range(4)) and all("momentum_buffer" in v for v in sd["state"].values())
+        for i in range(3, 6):
+            a.step(g, draws[i])
+        # resume in a new TrainStep
+        m2 = fresh(); m2.load_state_dict(model_sd)
+        b = train.TrainStep(m2, w, 0.15, 0.01, 0.5)                 # wrong lr / momentum on purpose: the state overrides them
+        b.load_state_dict(sd)
+        assert b.bucket.steps == 3 and b.lr == 0.05 and b.momentum == 0.9
+        for i in range(3, 6):
+            b.step(g, draws[i])
+        assert torch.equal(a.bucket.flat_param[:a.bucket.numel], b.bucket.flat_param[:b.bucket.numel])
+        # a reference-side optimizer state (torch.optim.SGD after real steps) loads, and a torch optimizer loads ours
+        m3 = fresh()
+        opt3 = torch.optim.SGD(list(m3.parameters()), lr=0.05, momentum=0.9)
+        m3(g)[0].sum().backward(); opt3.step()
+        c3 = train.TrainStep(fresh(), w, 0.15, 0.05, 0.9)
+        c3.load_state_dict(opt3.state_dict())
+        assert c3.bucket.steps == 1
+        off = 0
+        for i, p in enumerate(m3.parameters()):
+            assert torch.equal(c3.bucket.flat_mom[off:off + p.numel()].view_as(p), opt3.state[p]["momentum_buffer"])
+            off += p.numel()
+        opt4 = torch.optim.SGD(list(fresh().parameters()), lr=0.05, momentum=0.9)
+        opt4.load_state_dict({k: v for k, v in sd.items() if k != "spgnn"})
+        with pytest.raises(ValueError):
+            c3.load_state_dict({"state": {}, "param_groups": [{"params": [0, 1]}]})
+        # the bucket's tail slots (weight sum, loss numerator) are not part of the optimizer's arithmetic
+        assert float(a.bucket.flat_mom[a.bucket.numel:].abs().sum()) == 0.0
+    finally:
+        train.TrainStep._apply_update = orig
+
+
+class _Odd:                                                         # a class torch's weights-only unpickler does not allow
+    def __init__(self):
+        self.v = 3
+
+
+def test_checkpoint_load_is_weights_only_unless_trusted(tmp_path):
+    """load_pretrained_model unpickles tensors and plain containers only; a file with other objects needs trusted=True."""
+    from spgnn_amd import checkpoint
+    net = torch.nn.Linear(3, 2)
+    path = str(tmp_path / "c.pt")
+    torch.save({"model_dict": net.state_dict(), "metric": _Odd()}, path)
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        checkpoint.load_pretrained_model(path, [net], ["model_dict"], device="cpu")
+    states = checkpoint.load_pretrained_model(path, [net], ["model_dict"], device="cpu", trusted=True)
+    assert states["metric"].v == 3
+
+
 def test_balanced_tree_partition_balances_node_counts():
     """shard trees over ranks by node count.  4096 trees of U[120,180] nodes over 8 ranks (BASELINE config 5):
     per-rank node sums within 1 % of each other; every tree exactly once; deterministic."""
