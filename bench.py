@@ -43,7 +43,7 @@ MFMA_F16_PEAK = 2500.0      # dense fp16 / bf16 TFLOP/s
 FP32_MATRIX_PEAK = 157.3    # native fp32 MFMA TFLOP/s (the pipe an fp32 GEMM would otherwise use)
 GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16")
 HELPER_NAMES = ("absmax", "split_rows")
-GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg")
+GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg", "lspe_")
 # roofline.traffic is NOT measured by this run: PMC counters need rocprofv3 passes of their own
 TRAFFIC_SOURCE = "profiles/traffic_latest.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this step, per launch; not measured in this run)"
 
@@ -66,6 +66,15 @@ def algorithmic_bytes(key) -> float:
     if base == "gat_bwd_src":        # read g_pre, write g_ft; read a, g_e; write g_el; CSR + slot map
         _, N, E, H, D = key
         return s * 2 * N * H * D + 4 * (N * H + 2 * E * H) + 4 * (N + 1 + 2 * E)
+    if base == "lspe_fwd":           # one level, three heads of D: read ft + res (3D each), write the next structure input (3D)
+        _, N, E, D = key             # and the next position input (D); el, er in, a out (3 heads); CSC
+        return 4 * 10 * N * D + 4 * (2 * 3 * N + 3 * E) + 4 * (N + 1 + E)
+    if base == "lspe_bwd_dst":       # read g_buf, out (3D each), [g_xp,] xp (D each), gather ft (3D); write g_pre (3D);
+        _, N, E, D, has_g2 = key     # el, er, a in; g_e, g_er out; CSC
+        return 4 * (13 + has_g2) * N * D + 4 * (3 * 3 * N + 2 * 3 * E) + 4 * (N + 1 + E)
+    if base == "lspe_bwd_src":       # gather g_pre (3D), write g_ft (3D); a, g_e, g_er in; g_el out; CSR + slot map
+        _, N, E, D = key
+        return 4 * 6 * N * D + 4 * (2 * 3 * N + 2 * 3 * E) + 4 * (N + 1 + 2 * E)
     if base == "scores_fwd":         # read x; write S
         _, N, K, J = key
         return s * N * K + 4 * N * J
@@ -409,6 +418,9 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                     base = k[0][:-5] if k[0].endswith("_bf16") else k[0]
                     if base == "gat_fwd":
                         fwd_layers.append(((k[0],) + tuple(k[1:5]), per_step(k)[1]))
+                    elif base == "lspe_fwd":         # a fused level = a two-head structure layer + a one-head position layer
+                        fwd_layers.append((("gat_fwd", k[1], k[2], 2, k[3]), per_step(k)[1]))
+                        fwd_layers.append((("gat_fwd", k[1], k[2], 1, k[3]), per_step(k)[1]))
                     elif base == "gat_agg_fwd":
                         fwd_layers.append((("gat_fwd", k[1], k[2], k[3], cfg.MODEL.get("node_embed_dim", 1024)), per_step(k)[1]))
                 sv_bytes = survey_k123_bytes(fwd_layers, s_row)

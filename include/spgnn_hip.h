@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 30
+#define SPGNN_ABI_VERSION 31
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -656,6 +656,78 @@ int spgnn_weight_cat_bf16(const float* w_a, int64_t a_stride, int32_t rows_a, co
  * converted once per loader batch. */
 int spgnn_cast_rows_bf16(const float* x, int64_t x_stride, int64_t N, int32_t K, uint16_t* y, int64_t y_stride,
                          spgnn_stream_t stream);
+
+/* =================================================================================================
+ * One traversal per SPGNN level (LSPE): the structure GATConv (two heads) and the position GATConv (one head) of
+ * reference models.py:472-484 - `h_s = gat_layers[l](g, cat[h_s, h_p])`, `h_p = pgnn_layers[l](g, h_p)` - walk the batched CSC
+ * together.  Replaces, per level, two spgnn_gat_fwd / two spgnn_gat_bwd_dst / two spgnn_gat_bwd_src launches, the
+ * concatenation + feature-dropout passes over the position rows (spgnn_cat_dropout forward and backward) and the addition
+ * of h_p's two gradient contributions.  groups[0] = the structure layer (H = 2), groups[1] = the position layer (H = 1);
+ * both have out_feats = D, D in {64, 128, 256} (spgnn_lspe_supported).  Every node must have 1 <= degree <= 8 in both
+ * directions and the padded neighbour rows (nbr8 / out_nbr8 / out_pos8, see spgnn_gat_fwd) are required.
+ *
+ * Per group: ft / res (N, H*D) projected and residual rows (both required: the reference's position layer always has a residual
+ * and so has every structure layer of its configs), bias (H*D, nullable), el / er (N, H) with row
+ * stride s_stride, attn (E, H) (written by the forward, read by the backward), activation, LeakyReLU slope, attention dropout
+ * (p_drop, seed) with the same counter hash as spgnn_gat_fwd (index slot * H + h), so a level gives exactly the masks the
+ * two layers would have drawn on their own.
+ * ================================================================================================= */
+typedef struct spgnn_lspe_fwd_group {
+  const float* ft; int64_t ft_stride; const float* res; int64_t res_stride; const float* bias;
+  const float* el; const float* er; int64_t s_stride; float* attn;
+  int32_t H; int32_t act; float slope; float p_drop; uint64_t seed;
+} spgnn_lspe_fwd_group;
+
+int spgnn_lspe_supported(int32_t D);
+
+/*
+ * out (N, 3D): [structure head 0 | structure head 1 | position head], activated, stored under the NEXT structure layer's
+ * feature dropout (out_drop_p, out_drop_seed; mask of spgnn_cat_dropout for a 3D-wide concatenation: the reference's
+ * `dropout(cat[h_s, h_p])`, models.py:477-481 + GATConv.feat_drop) - that layer's input buffer, written once.
+ * out2 (N, D): the position head once more under the next POSITION layer's feature dropout (out2_drop_p = 0: plain, e.g. the
+ * model's h_p output) - that layer's input.  out_absmax / out2_absmax (N, nullable): per-node maxima of the stored
+ * rows (operand scales of the next projections).
+ */
+int spgnn_lspe_fwd(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_fwd_group* groups /* [2] */, float* out,
+                   int64_t out_stride, float out_drop_p, uint64_t out_drop_seed, float* out2, int64_t out2_stride,
+                   float out2_drop_p, uint64_t out2_drop_seed, float* out_absmax, float* out2_absmax, int64_t N, int64_t E,
+                   int32_t D, const uint64_t* seed_offset, spgnn_stream_t stream);
+
+typedef struct spgnn_lspe_bwd_dst_group {
+  const float* ft; int64_t ft_stride; const float* el; const float* er; int64_t s_stride; const float* attn;
+  float* g_pre; int64_t g_pre_stride;      /* out: gradient of the pre-activation rows (N, H*D) */
+  float* g_e;                               /* out: (E, H) */
+  float* g_er; int64_t gs_stride;           /* out: (N, H) */
+  float* absmax;                            /* out, nullable: (N,) per-node maxima of |g_pre| */
+  int32_t H; int32_t act; float slope; float p_drop; uint64_t seed;
+} spgnn_lspe_bwd_dst_group;
+
+/*
+ * dst-major half of the level's backward pass.  g_out (N, 3D): gradient of the buffer spgnn_lspe_fwd wrote; g_out2 (N, D;
+ * nullable): gradient of the position head's second copy - the position rows have two consumers and their gradient is the
+ * sum of both, each under its own mask.  out / out2: the stored rows (for the activation derivative; kept elements are
+ * recovered as stored * (1 - p), and where a position element was dropped in `out` it is taken from `out2`).
+ */
+int spgnn_lspe_bwd_dst(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_bwd_dst_group* groups /* [2] */,
+                       const float* g_out, int64_t g_out_stride, const float* g_out2, int64_t g_out2_stride, const float* out,
+                       int64_t out_stride, float out_drop_p, uint64_t out_drop_seed, const float* out2, int64_t out2_stride,
+                       float out2_drop_p, uint64_t out2_drop_seed, int64_t N, int64_t E, int32_t D,
+                       const uint64_t* seed_offset, spgnn_stream_t stream);
+
+typedef struct spgnn_lspe_bwd_src_group {
+  const float* attn; const float* g_e;      /* (E, H) in CSC slot order */
+  const float* g_pre; int64_t g_pre_stride;
+  float* g_ft; int64_t g_ft_stride;         /* out: gradient of the projected rows (N, H*D) */
+  float* g_el; const float* g_er; int64_t gs_stride;   /* g_el out, g_er in: (N, H) */
+  const float* score_l; const float* score_r;           /* attn_l / attn_r (H*D), both or neither: the score term */
+  float* absmax;                            /* out, nullable: (N,) per-node maxima of |g_ft| */
+  int32_t H; float p_drop; uint64_t seed;
+} spgnn_lspe_bwd_src_group;
+
+/* src-major half: g_ft[u, h, :] = sum over out-edges of drop(a) * g_pre[v, h, :] + g_el[u, h] attn_l[h, :] + g_er[u, h] attn_r[h, :]. */
+int spgnn_lspe_bwd_src(const int32_t* out_indptr, const int32_t* out_nbr8, const int32_t* out_pos8,
+                       const spgnn_lspe_bwd_src_group* groups /* [2] */, int64_t N, int64_t E, int32_t D,
+                       const uint64_t* seed_offset, spgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,14 +12,39 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
 _i64, _i32, _f32, _u64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p
 
+
+
+class LspeFwdGroup(C.Structure):          # spgnn_lspe_fwd_group
+    _fields_ = [("ft", _vp), ("ft_stride", _i64), ("res", _vp), ("res_stride", _i64), ("bias", _vp), ("el", _vp), ("er", _vp),
+                ("s_stride", _i64), ("attn", _vp), ("H", _i32), ("act", _i32), ("slope", _f32), ("p_drop", _f32), ("seed", _u64)]
+
+
+class LspeBwdDstGroup(C.Structure):       # spgnn_lspe_bwd_dst_group
+    _fields_ = [("ft", _vp), ("ft_stride", _i64), ("el", _vp), ("er", _vp), ("s_stride", _i64), ("attn", _vp), ("g_pre", _vp),
+                ("g_pre_stride", _i64), ("g_e", _vp), ("g_er", _vp), ("gs_stride", _i64), ("absmax", _vp), ("H", _i32), ("act", _i32),
+                ("slope", _f32), ("p_drop", _f32), ("seed", _u64)]
+
+
+class LspeBwdSrcGroup(C.Structure):       # spgnn_lspe_bwd_src_group
+    _fields_ = [("attn", _vp), ("g_e", _vp), ("g_pre", _vp), ("g_pre_stride", _i64), ("g_ft", _vp), ("g_ft_stride", _i64),
+                ("g_el", _vp), ("g_er", _vp), ("gs_stride", _i64), ("score_l", _vp), ("score_r", _vp), ("absmax", _vp), ("H", _i32),
+                ("p_drop", _f32), ("seed", _u64)]
+
+
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
 SIGNATURES = {
+    "spgnn_lspe_supported": [_i32],
+    "spgnn_lspe_fwd": [_i32p, _i32p, C.POINTER(LspeFwdGroup), _f32p, _i64, _f32, _u64, _f32p, _i64, _f32, _u64, _f32p, _f32p, _i64, _i64,
+                       _i32, _vp, _vp],
+    "spgnn_lspe_bwd_dst": [_i32p, _i32p, C.POINTER(LspeBwdDstGroup), _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32, _u64, _f32p, _i64, _f32,
+                           _u64, _i64, _i64, _i32, _vp, _vp],
+    "spgnn_lspe_bwd_src": [_i32p, _i32p, _i32p, C.POINTER(LspeBwdSrcGroup), _i64, _i64, _i32, _vp, _vp],
     "spgnn_abi_version": [],
     "spgnn_last_error": [],
     "spgnn_gat_fwd": [_i32p, _i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64,

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libspgnn_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
-SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
-HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h")]
+SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
+HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h"), os.path.join(HERE, "spgnn_rows.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE]
 # Per-source flags.  The row kernels are built WITHOUT the SLP vectorizer: the packed fp32 ops it forms (v_pk_fma_f32 fed by
 # v_pk_mov_b32 op_sel shuffles) gave transiently wrong per-edge dots in gat_bwd_dst when a second process shared the GPU
@@ -21,8 +21,9 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.jo
 # -fno-vectorize as well: the loop vectorizer paired the general-degree fallback loops into the same packed ops (645 of them in
 # gat_fwd_vec / gat_agg_fwd); with both vectorizers off the object holds NO packed fp32 arithmetic, and _check_isa() below
 # keeps it that way (the mechanism of the hazard is unconfirmed, so the fence is "no such instruction in this file").
-EXTRA_FLAGS = {"spgnn_kernels.hip": ["-fno-slp-vectorize", "-fno-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]}
-NO_PACKED_FP32 = ("spgnn_kernels.hip",)     # objects that must not contain v_pk_{fma,mul,add}_f32 at all
+_ROW_FLAGS = ["-fno-slp-vectorize", "-fno-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]
+EXTRA_FLAGS = {"spgnn_kernels.hip": _ROW_FLAGS, "spgnn_lspe.hip": _ROW_FLAGS}
+NO_PACKED_FP32 = ("spgnn_kernels.hip", "spgnn_lspe.hip")     # objects that must not contain v_pk_{fma,mul,add}_f32 at all
 LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 

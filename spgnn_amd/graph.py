@@ -95,6 +95,7 @@ class DeviceCSC:
         self.max_in_degree = int((ind[1:] - ind[:-1]).max()) if num_nodes else 0
         self.max_out_degree = int((oind[1:] - oind[:-1]).max()) if num_nodes else 0
         self.min_in_degree = int((ind[1:] - ind[:-1]).min()) if num_nodes else 0
+        self.min_out_degree = int((oind[1:] - oind[:-1]).min()) if num_nodes else 0
         # degree-derived edge weights are computed lazily by ops (GraphConv/GIN)
         self._cache: Dict[str, torch.Tensor] = {}
 
@@ -117,6 +118,7 @@ class DeviceCSC:
                 raise ValueError(f"DeviceCSC.from_tensors: {k} length != num_edges")
         self.device = self.indptr.device
         self.min_in_degree, self.max_in_degree, self.max_out_degree = int(min_in_degree), int(max_in_degree), int(max_out_degree)
+        self.min_out_degree = 0                 # unknown without a host read (blocks: sources without out-edges exist)
         self._cache = {}
         return self
 

@@ -39,21 +39,22 @@ def _cat_for(layer, a: torch.Tensor, b: torch.Tensor):
     return ops.cat_dropout((a, b), p, _draw_seed() if p > 0.0 else 0), True
 
 
-def _drop_for(layer, x: torch.Tensor):
+def _drop_for(layer, x: torch.Tensor, seed: Optional[int] = None):
     """(x with ``layer``'s feature dropout applied by the hash-mask kernel, True) on the GPU in training mode."""
     p = float(layer.feat_drop.p) if layer.training else 0.0
     if not x.is_cuda or p == 0.0:
         return x, False
+    seed = _draw_seed() if seed is None else seed
     if x.dtype == torch.bfloat16:
-        return ops_bf16.cat_dropout((x,), p, _draw_seed()), True
-    return ops.cat_dropout((x,), p, _draw_seed()), True
+        return ops_bf16.cat_dropout((x,), p, seed), True
+    return ops.cat_dropout((x,), p, seed), True
 
 
 FUSE_OUTPUT_DROPOUT = True     # hidden GATConvs write their rows straight into the next layer's input buffer, already under that
                                # layer's feature dropout (nn.GATConv fuse_out); False: separate concat + dropout pass (tests flip it)
 
 
-def _fuse_plan(layer, nxt, x: torch.Tensor, extra_width: int):
+def _fuse_plan(layer, nxt, x: torch.Tensor, extra_width: int, seed: Optional[int] = None):
     """(total, p, seed, extra) for ``layer(g, x, fuse_out=...)`` feeding ``nxt`` together with ``extra_width`` more columns,
     or None when the fused form is not available."""
     if not (FUSE_OUTPUT_DROPOUT and layer.can_fuse_out(x)):
@@ -62,7 +63,10 @@ def _fuse_plan(layer, nxt, x: torch.Tensor, extra_width: int):
     if total % 4 or (extra_width and ((layer._num_heads * layer._out_feats) % 4 or x.dtype != torch.float32)):
         return None
     p = float(nxt.feat_drop.p) if nxt.training else 0.0
-    return total, p, (_draw_seed() if p > 0.0 else 0), ops.fused_extra_partials(x.shape[0], extra_width)
+    return total, p, ((_draw_seed() if seed is None else seed) if p > 0.0 else 0), ops.fused_extra_partials(x.shape[0], extra_width)
+
+
+FUSE_LSPE = True               # GATPSPGNN: structure + position GATConv of a level in ONE traversal (ops.lspe_level); False: two layers
 
 
 def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -256,26 +260,87 @@ class GATPSPGNN(nn.Module):
         for layer in list(self.gat_layers) + list(self.pgnn_layers):
             layer.reset_parameters()
 
+    def _seed_plan(self):
+        """Every dropout seed of one forward pass, drawn up front in a fixed order (per level: the next structure layer's
+        feature dropout, the structure layer's attention dropout, the position layer's attention dropout, the next position
+        layer's feature dropout; only where the rate is non-zero in the current mode) - so the fused and the two-layer form
+        of a level use identical masks under one ``torch.manual_seed``."""
+        L = self.num_layers
+        plan = []
+        for l in range(L):
+            s_layer, p_layer, nxt_s = self.gat_layers[l], self.pgnn_layers[l], self.gat_layers[l + 1]
+            nxt_p = self.pgnn_layers[l + 1] if l + 1 < L else None
+            def rate(m, which):
+                return float(getattr(m, which).p) if (m is not None and m.training) else 0.0
+            d = {"fp": rate(nxt_s, "feat_drop"), "ps": rate(s_layer, "attn_drop"), "pp": rate(p_layer, "attn_drop"),
+                 "fp2": rate(nxt_p, "feat_drop")}
+            for k, sk in (("fp", "fseed"), ("ps", "seed_s"), ("pp", "seed_p"), ("fp2", "fseed2")):
+                d[sk] = _draw_seed() if d[k] > 0.0 else 0
+            plan.append(d)
+        return plan
+
+    def _lspe_ok(self, g, x: torch.Tensor, h_p: torch.Tensor) -> bool:
+        """The fused level needs two structure heads and one position head of the same width, Linear residuals and fusable
+        activations in every level (all reference configs), fp32 rows, and a graph the kernels take (ops.lspe_level_supported)."""
+        from . import nn as _nn
+        from .nn import Identity, _act_code
+        if not (FUSE_LSPE and x.is_cuda and _nn.SCORES_FROM_FT and x.dtype == torch.float32):
+            return False
+        for s_layer, p_layer in zip(self.gat_layers[:-1], self.pgnn_layers):
+            if not (s_layer._num_heads == 2 and p_layer._num_heads == 1 and s_layer._out_feats == p_layer._out_feats
+                    and isinstance(s_layer.res_fc, nn.Linear) and isinstance(p_layer.res_fc, nn.Linear)
+                    and _act_code(s_layer.activation) is not None and _act_code(p_layer.activation) is not None
+                    and not isinstance(s_layer.res_fc, Identity)):
+                return False
+        csc = g.csc(x.device)
+        return all(ops.lspe_level_supported(csc, x, h_p, s_layer._out_feats) for s_layer in self.gat_layers[:-1])
+
+    def _forward_lspe(self, g, x, xp, plan):
+        """All hidden levels through ops.lspe_level: -> (input of the output layer (N, 3 D_last), h_p (N, D_last))."""
+        from .nn import _act_code
+        csc = g.csc(x.device)
+        for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
+            d = plan[l]
+            w_s = ops.weight_cat(s_layer.fc.weight, s_layer.res_fc.weight, want_t=x.requires_grad)
+            w_p = ops.weight_cat(p_layer.fc.weight, p_layer.res_fc.weight, want_t=xp.requires_grad)
+            cfg = {"res_s": True, "res_p": True, "act": (_act_code(s_layer.activation), _act_code(p_layer.activation)),
+                   "slope": (float(s_layer.negative_slope), float(p_layer.negative_slope)), "p_attn": (d["ps"], d["pp"]),
+                   "seed_attn": (d["seed_s"], d["seed_p"]), "fp": d["fp"], "fseed": d["fseed"], "fp2": d["fp2"], "fseed2": d["fseed2"]}
+            x, xp = ops.lspe_level(csc, x, xp, w_s, w_p, (s_layer.attn_l, s_layer.attn_r), (p_layer.attn_l, p_layer.attn_r),
+                                   s_layer.bias, p_layer.bias, s_layer._out_feats, cfg)
+        return x, xp
+
     def forward(self, g, classifier=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h_s, h_p, classifier(h_s))`` with the
         classifier joined to the output layer's autograd node."""
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         x, dropped = _data_cat(g, h_s, h_p), False
+        plan = self._seed_plan() if x.is_cuda else None
+        if plan is not None and self._lspe_ok(g, x, h_p):
+            # one traversal per level (a graph with 0-in-degree nodes never gets here: the layers below raise DGLError for it)
+            x, h_p = self._forward_lspe(g, x, _data_aligned(g, h_p), plan)
+            dropped = True
+            return self._output(g, x, h_p, dropped, classifier)
         for l, (s_layer, p_layer) in enumerate(zip(self.gat_layers[:-1], self.pgnn_layers)):
+            sd = plan[l] if plan is not None else {}
             nxt = self.gat_layers[l + 1]
             w_p = p_layer._num_heads * p_layer._out_feats
-            plan = _fuse_plan(s_layer, nxt, x, w_p)
-            if plan is not None:       # the structure rows go straight into the next layer's input, under its feature dropout
-                buf, amax = s_layer(g, x, feat_dropped=dropped, fuse_out=plan)
+            fplan = _fuse_plan(s_layer, nxt, x, w_p, seed=sd.get("fseed"))
+            if fplan is not None:      # the structure rows go straight into the next layer's input, under its feature dropout
+                buf, amax = s_layer(g, x, feat_dropped=dropped, fuse_out=fplan, attn_seed=sd.get("seed_s"))
             else:
-                h_s = s_layer(g, x, feat_dropped=dropped).flatten(1)
-            xp, dropped_p = (_data_aligned(g, h_p), False) if l == 0 else _drop_for(p_layer, h_p)
-            h_p = p_layer(g, xp, feat_dropped=dropped_p).flatten(1)
-            if plan is not None:       # ... and the position rows complete it (same seed: one mask over the concatenation)
-                total, p, seed, _ = plan
+                h_s = s_layer(g, x, feat_dropped=dropped, attn_seed=sd.get("seed_s")).flatten(1)
+            xp, dropped_p = (_data_aligned(g, h_p), False) if l == 0 else \
+                _drop_for(p_layer, h_p, seed=plan[l - 1]["fseed2"] if plan is not None else None)
+            h_p = p_layer(g, xp, feat_dropped=dropped_p, attn_seed=sd.get("seed_p")).flatten(1)
+            if fplan is not None:      # ... and the position rows complete it (same seed: one mask over the concatenation)
+                total, p, seed, _ = fplan
                 x, dropped = ops.fill_cols_dropout(buf, h_p, total - w_p, total, p, seed, amax), True
             else:
                 x, dropped = _cat_for(nxt, h_s, h_p)
+        return self._output(g, x, h_p, dropped, classifier)
+
+    def _output(self, g, x, h_p, dropped, classifier):
         if classifier is not None:
             h_s, logits = self.gat_layers[-1](g, x, mean_heads=True, feat_dropped=dropped, classifier=classifier)
             return h_s, h_p, logits

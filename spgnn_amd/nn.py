@@ -126,7 +126,7 @@ class GATConv(nn.Module):
                 and ops.GEMM_MODE == "f16x3" and (H * D) % 4 == 0)
 
     def forward(self, graph: TreeGraph, feat: torch.Tensor, get_attention: bool = False, mean_heads: bool = False,
-                feat_dropped: bool = False, classifier: Optional[nn.Linear] = None, fuse_out=None):
+                feat_dropped: bool = False, classifier: Optional[nn.Linear] = None, fuse_out=None, attn_seed: Optional[int] = None):
         """DGL signature; ``mean_heads=True`` (extension) returns ``rst.mean(1)`` (N, D) with the mean fused
         into the kernel epilogue — what the reference applies to the output layer (models.py:327, 482).
         ``feat_dropped=True`` (extension): the caller already applied this layer's feature dropout while assembling
@@ -137,7 +137,10 @@ class GATConv(nn.Module):
         ``fuse_out`` = (total, p, seed, extra) (extension; see ``can_fuse_out``): the flattened output is written, already
         under the NEXT layer's feature dropout (p, seed), into columns [0, H*D) of a fresh (N, total) buffer - that
         layer's input, completed by ``ops.fill_cols_dropout`` when total > H*D - and ``(buffer, maxima)`` is returned
-        (reference models.py:477-481: ``h_s = cat[h_s, h_p]`` then ``GATConv.feat_drop``, without the separate pass)."""
+        (reference models.py:477-481: ``h_s = cat[h_s, h_p]`` then ``GATConv.feat_drop``, without the separate pass).
+        ``attn_seed`` (extension): the attention-dropout seed to use instead of drawing one (a caller that draws all seeds
+        of a forward pass up front, models.GATPSPGNN)."""
+        self._attn_seed = attn_seed
         if fuse_out is not None:
             if classifier is not None or mean_heads or get_attention or not self.can_fuse_out(feat):
                 raise ValueError("fuse_out= needs can_fuse_out(feat) and none of classifier / mean_heads / get_attention")
@@ -147,6 +150,8 @@ class GATConv(nn.Module):
                 raise ValueError("classifier= needs mean_heads=True and get_attention=False")
             return self._forward_with_classifier(graph, feat, feat_dropped, classifier)
         return self._forward(graph, feat, get_attention, mean_heads, feat_dropped, None)
+
+    _attn_seed: Optional[int] = None
 
     def _forward_with_classifier(self, graph, feat, feat_dropped, classifier):
         res = self._forward(graph, feat, False, True, feat_dropped, classifier)
@@ -168,7 +173,8 @@ class GATConv(nn.Module):
         w_fc = self.fc.weight
         # el = (fc(x) * attn_l).sum(-1) = x @ (attn_l . W_h)^T : fold the score vectors through fc
         p = float(self.attn_drop.p) if self.training else 0.0
-        seed = _draw_seed() if p > 0.0 else 0
+        seed = (self._attn_seed if self._attn_seed is not None else _draw_seed()) if p > 0.0 else 0
+        self._attn_seed = None
         drop = (p, seed) if p > 0.0 else None
         fuse_mean = mean_heads and fuse_epilogue
         if h.dtype == torch.bfloat16:

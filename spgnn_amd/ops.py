@@ -1104,6 +1104,164 @@ def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: boo
 
 
 # --------------------------------------------------------------------------------------------
+# one SPGNN level (structure GATConv + position GATConv, LSPE) in one traversal
+# --------------------------------------------------------------------------------------------
+def lspe_level_supported(csc: DeviceCSC, x_s: torch.Tensor, x_p: torch.Tensor, D: int) -> bool:
+    """The fused level (spgnn_lspe_*) needs fp32 rows on a ROCm device, out_feats D in {64, 128, 256} for both layers, the
+    padded neighbour rows and 1 <= degree <= 8 in both directions (airway trees: <= 5 + the self loop)."""
+    return (x_s.is_cuda and x_s.dtype == torch.float32 and x_p.dtype == torch.float32 and x_s.dim() == 2 and x_s.shape[0] > 0
+            and GEMM_MODE == "f16x3" and USE_ELL and getattr(csc, "num_dst", None) is None
+            and 1 <= csc.min_in_degree and csc.max_in_degree <= 8 and 1 <= getattr(csc, "min_out_degree", 0)
+            and csc.max_out_degree <= 8 and bool(_capi.load().spgnn_lspe_supported(int(D))))
+
+
+class _LspeLevelFn(torch.autograd.Function):
+    """One level of GATPSPGNN (reference models.py:472-484): the structure GATConv (2 heads) on x_s = dropout(cat[h_s, h_p]) and
+    the position GATConv (1 head, tanh, residual) on x_p = dropout(h_p), both project-first with el / er from the projection
+    GEMMs' epilogues, aggregated by ONE traversal of the graph (spgnn_lspe_fwd) that writes the next level's two inputs:
+    buf (N, 3D) = [h_s' | h_p'] under the next structure layer's feature dropout and xp (N, D) = h_p' under the next position
+    layer's.  Backward: spgnn_lspe_bwd_dst + spgnn_lspe_bwd_src straight into the GEMM-gradient buffers of both layers, then
+    their weight / input gradient products."""
+
+    @staticmethod
+    def forward(ctx, x_s, x_p, w_s, w_p, al_s, ar_s, al_p, ar_p, bias_s, bias_p, csc: DeviceCSC, D: int, cfg: dict):
+        ctx.set_materialize_grads(False)
+        N = x_s.shape[0]
+        E = csc.num_edges
+        dev = x_s.device
+        lib = _capi.load()
+        ys, ss, parts, scales, wts = [], [], [], [], []
+        ctx.attn_shapes = (al_s.shape, al_p.shape)
+        vecs = [(al_s.reshape(-1).contiguous(), ar_s.reshape(-1).contiguous()), (al_p.reshape(-1).contiguous(), ar_p.reshape(-1).contiguous())]
+        for x, w, (al, ar), H in ((x_s, w_s, vecs[0], 2), (x_p, w_p, vecs[1], 1)):
+            sx, sw = operand_scale(x), operand_scale(w)
+            wb, ps = _b_operand(w)
+            pt = torch.empty((N, H * D // 64, 2), dtype=torch.float32, device=dev)
+            y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps)
+            ys.append(y); ss.append(scores_from_parts(pt, H, D)); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+        buf = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
+        xp = torch.empty((N, D), dtype=torch.float32, device=dev)
+        Np = (N + 3) // 4 * 4                    # both halves 16-byte aligned (the multi-block scale reduction needs it)
+        amax = torch.empty((2 * Np,), dtype=torch.float32, device=dev)
+        attn = [torch.empty((E, 2), dtype=torch.float32, device=dev), torch.empty((E, 1), dtype=torch.float32, device=dev)]
+        nbr8 = csc.ell()[0]
+        G = (_capi.LspeFwdGroup * 2)()
+        for i, (H, has_res, bias) in enumerate(((2, cfg["res_s"], bias_s), (1, cfg["res_p"], bias_p))):
+            y, s_ = ys[i], ss[i]
+            g = G[i]
+            g.ft, g.ft_stride = y.data_ptr(), y.stride(0)
+            g.res, g.res_stride = (y[:, H * D:].data_ptr(), y.stride(0)) if has_res else (0, 0)
+            g.bias = _ptr(bias)
+            g.el, g.er, g.s_stride = s_.data_ptr(), s_[:, H:].data_ptr(), s_.stride(0)
+            g.attn = attn[i].data_ptr()
+            g.H, g.act, g.slope, g.p_drop, g.seed = H, cfg["act"][i], cfg["slope"][i], cfg["p_attn"][i], cfg["seed_attn"][i]
+        with torch.cuda.device(dev), _timed("lspe_fwd", (N, E, D)):
+            _capi.check(lib.spgnn_lspe_fwd(csc.indptr.data_ptr(), nbr8.data_ptr(), G, buf.data_ptr(), buf.stride(0), cfg["fp"], cfg["fseed"],
+                                           xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], amax.data_ptr(), amax[Np:].data_ptr(),
+                                           N, E, D, _seed_off_ptr(dev), _stream(x_s)), "spgnn_lspe_fwd")
+        ctx.csc, ctx.D, ctx.cfg, ctx.wts, ctx.has_bias = csc, D, cfg, wts, (bias_s is not None, bias_p is not None)
+        ctx.save_for_backward(x_s, x_p, w_s, w_p, vecs[0][0], vecs[0][1], vecs[1][0], vecs[1][1], ys[0], ys[1], ss[0], ss[1], attn[0], attn[1],
+                              scales[0][0], scales[0][1], scales[1][0], scales[1][1], buf, xp)
+        ctx.mark_non_differentiable(attn[0], attn[1], amax)
+        return buf, xp, attn[0], attn[1], amax
+
+    @staticmethod
+    def backward(ctx, g_buf, g_xp, *_unused):
+        if g_buf is None and g_xp is None:
+            return (None,) * 13
+        (x_s, x_p, w_s, w_p, al_s, ar_s, al_p, ar_p, y_s, y_p, s_s, s_p, attn_s, attn_p, sx_s, sw_s, sx_p, sw_p, buf, xp) = ctx.saved_tensors
+        csc, D, cfg = ctx.csc, ctx.D, ctx.cfg
+        N, E = x_s.shape[0], csc.num_edges
+        dev = x_s.device
+        lib = _capi.load()
+        if g_buf is None:
+            g_buf = torch.zeros_like(buf)
+        g_buf = _rowmajor(g_buf)
+        if not _rows_aligned(g_buf):
+            g_buf = g_buf.contiguous()
+        if g_xp is not None:
+            g_xp = _rowmajor(g_xp)
+            if not _rows_aligned(g_xp):
+                g_xp = g_xp.contiguous()
+        xs, ws, ys, ss, attns = (x_s, x_p), (w_s, w_p), (y_s, y_p), (s_s, s_p), (attn_s, attn_p)
+        vecs, scl = ((al_s, ar_s), (al_p, ar_p)), ((sx_s, sw_s), (sx_p, sw_p))
+        Hs, res = (2, 1), (cfg["res_s"], cfg["res_p"])
+        g_y = [torch.empty_like(y) for y in ys]
+        g_s = [torch.empty_like(s_) for s_ in ss]
+        g_e = [torch.empty((E, H), dtype=torch.float32, device=dev) for H in Hs]
+        amax = [torch.empty((2 * N,), dtype=torch.float32, device=dev) for _ in Hs]
+        g_pre = [g_y[i][:, Hs[i] * D:] if res[i] else torch.empty((N, Hs[i] * D), dtype=torch.float32, device=dev) for i in range(2)]
+        nbr8, out_nbr8, out_pos8 = csc.ell()
+        GD = (_capi.LspeBwdDstGroup * 2)()
+        GS = (_capi.LspeBwdSrcGroup * 2)()
+        for i, H in enumerate(Hs):
+            d, q = GD[i], GS[i]
+            d.ft, d.ft_stride = ys[i].data_ptr(), ys[i].stride(0)
+            d.el, d.er, d.s_stride, d.attn = ss[i].data_ptr(), ss[i][:, H:].data_ptr(), ss[i].stride(0), attns[i].data_ptr()
+            d.g_pre, d.g_pre_stride = g_pre[i].data_ptr(), g_pre[i].stride(0)
+            d.g_e, d.g_er, d.gs_stride, d.absmax = g_e[i].data_ptr(), g_s[i][:, H:].data_ptr(), g_s[i].stride(0), amax[i].data_ptr()
+            d.H, d.act, d.slope, d.p_drop, d.seed = H, cfg["act"][i], cfg["slope"][i], cfg["p_attn"][i], cfg["seed_attn"][i]
+            q.attn, q.g_e, q.g_pre, q.g_pre_stride = attns[i].data_ptr(), g_e[i].data_ptr(), g_pre[i].data_ptr(), g_pre[i].stride(0)
+            q.g_ft, q.g_ft_stride = g_y[i].data_ptr(), g_y[i].stride(0)
+            q.g_el, q.g_er, q.gs_stride = g_s[i].data_ptr(), g_s[i][:, H:].data_ptr(), g_s[i].stride(0)
+            q.score_l, q.score_r, q.absmax = vecs[i][0].data_ptr(), vecs[i][1].data_ptr(), amax[i][N:].data_ptr()
+            q.H, q.p_drop, q.seed = H, cfg["p_attn"][i], cfg["seed_attn"][i]
+        with torch.cuda.device(dev):
+            st = _stream(x_s)
+            with _timed("lspe_bwd_dst", (N, E, D, int(g_xp is not None))):
+                _capi.check(lib.spgnn_lspe_bwd_dst(csc.indptr.data_ptr(), nbr8.data_ptr(), GD, g_buf.data_ptr(), g_buf.stride(0), _ptr(g_xp),
+                                                   g_xp.stride(0) if g_xp is not None else 0, buf.data_ptr(), buf.stride(0), cfg["fp"],
+                                                   cfg["fseed"], xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], N, E, D,
+                                                   _seed_off_ptr(dev), st), "spgnn_lspe_bwd_dst")
+            with _timed("lspe_bwd_src", (N, E, D)):
+                _capi.check(lib.spgnn_lspe_bwd_src(csc.out_indptr.data_ptr(), out_nbr8.data_ptr(), out_pos8.data_ptr(), GS, N, E, D,
+                                                   _seed_off_ptr(dev), st), "spgnn_lspe_bwd_src")
+        grads_x, grads_w, grads_al, grads_ar, grads_b = [None, None], [None, None], [None, None], [None, None], [None, None]
+        for i, H in enumerate(Hs):
+            HD = H * D
+            x, K = xs[i], xs[i].shape[1]
+            sx, sw = scl[i]
+            sg = scale_from_partials(amax[i] if res[i] else amax[i][N:])
+            need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
+            if ctx.needs_input_grad[2 + i]:
+                if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
+                    if need_bias and res[i]:
+                        grads_w[i], cs = gemm_tn(g_y[i], x, sg, sx, want_colsum=True)
+                        grads_b[i] = cs[HD:]
+                    else:
+                        grads_w[i] = gemm_tn(g_y[i], x, sg, sx)
+                else:
+                    grads_w[i] = _dw_gemm(g_y[i], x)
+            if need_bias and grads_b[i] is None:
+                grads_b[i] = g_pre[i].sum(0)
+            if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
+                m = scores_bwd_w(g_s[i], ys[i][:, :HD], blockdiag_heads=H)
+                grads_al[i], grads_ar[i] = m[0].view(ctx.attn_shapes[i]), m[1].view(ctx.attn_shapes[i])
+            if ctx.needs_input_grad[i]:
+                gx = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :K]
+                w_t, w_t_ps = ctx.wts[i]
+                if w_t_ps is not None:
+                    gemm_nt(g_y[i], w_t_ps, sg, sw, out=gx, b_presplit=True)
+                else:
+                    gemm_nt(g_y[i], w_t if w_t is not None else ws[i].t().contiguous(), sg, sw, out=gx)
+                grads_x[i] = gx
+        return (grads_x[0], grads_x[1], grads_w[0], grads_w[1], grads_al[0], grads_ar[0], grads_al[1], grads_ar[1], grads_b[0], grads_b[1],
+                None, None, None)
+
+
+def lspe_level(csc: DeviceCSC, x_s: torch.Tensor, x_p: torch.Tensor, w_s, w_p, attn_s, attn_p, bias_s, bias_p, D: int, cfg: dict):
+    """-> (buf (N, 3D), xp (N, D)): the next level's structure and position inputs (see _LspeLevelFn), each carrying its
+    split-GEMM operand scale.  ``w_s`` / ``w_p``: weight_cat operands [W_fc; W_res]; ``attn_s`` / ``attn_p``: (attn_l, attn_r)."""
+    _require_cuda(x_s, x_p, w_s, w_p)
+    N = x_s.shape[0]
+    buf, xp, _a0, _a1, amax = _LspeLevelFn.apply(x_s, x_p, w_s, w_p, attn_s[0], attn_s[1], attn_p[0], attn_p[1], bias_s, bias_p, csc, int(D), cfg)
+    Np = amax.numel() // 2
+    buf._spgnn_scale = (buf._version, scale_from_partials(amax[:N]))
+    xp._spgnn_scale = (xp._version, scale_from_partials(amax[Np:Np + N]))
+    return buf, xp
+
+
+# --------------------------------------------------------------------------------------------
 # aggregate-first GAT layer (input narrower than one head's output)
 # --------------------------------------------------------------------------------------------
 def agg_first_supported(H: int, F_in: int) -> bool:
