@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 31
+#define SPGNN_ABI_VERSION 32
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -728,6 +728,25 @@ typedef struct spgnn_lspe_bwd_src_group {
 int spgnn_lspe_bwd_src(const int32_t* out_indptr, const int32_t* out_nbr8, const int32_t* out_pos8,
                        const spgnn_lspe_bwd_src_group* groups /* [2] */, int64_t N, int64_t E, int32_t D,
                        const uint64_t* seed_offset, spgnn_stream_t stream);
+
+/* =================================================================================================
+ * Batch assembly on the device (reference job_runner.py:1319-1344, 1779-1801 and dgl.batch at 1390 / 1882): from the packed
+ * adjacency matrices of a loader batch - tree t is the n_t x n_t uint8 matrix at adj + adj_ptr[t] (row-major), its nodes are
+ * tree_ptr[t] .. tree_ptr[t+1]-1 of the batch - to the batched edge list in the reference's edge-id order (per tree: the
+ * off-diagonal non-zeros (u, v) sorted by (u, v), then the n self loops) and the int32 index structures every kernel of this
+ * library takes: CSC (indptr, indices, eid; in-lists in ascending edge id) and CSR (out_indptr, out_indices, out_pos =
+ * the CSC slot of the same edge).  The diagonal of adj is ignored (the rule drops it and appends the self loops).
+ *
+ *   1. spgnn_build_csc_count: row_count[i] / col_count[i] = off-diagonal non-zeros in node i's row / column;
+ *   2. the caller forms the exclusive prefix sums row_start / col_start (N + 1 entries, int64) and E = row_start[N] + N;
+ *   3. spgnn_build_csc fills src / dst (E), indptr / out_indptr (N + 1), indices / eid / out_indices / out_pos (E).
+ * ================================================================================================= */
+int spgnn_build_csc_count(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,
+                          int32_t* row_count, int32_t* col_count, spgnn_stream_t stream);
+int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,
+                    const int64_t* row_start, const int64_t* col_start, int32_t* src, int32_t* dst, int32_t* indptr,
+                    int32_t* indices, int32_t* eid, int32_t* out_indptr, int32_t* out_indices, int32_t* out_pos, int64_t N,
+                    int64_t E, spgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

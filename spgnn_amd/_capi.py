@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -39,6 +39,8 @@ class LspeBwdSrcGroup(C.Structure):       # spgnn_lspe_bwd_src_group
 
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
 SIGNATURES = {
+    "spgnn_build_csc_count": [_vp, _vp, _vp, _i64, _i32p, _i32p, _vp],
+    "spgnn_build_csc": [_vp, _vp, _vp, _i64, _vp, _vp, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i64, _i64, _vp],
     "spgnn_lspe_supported": [_i32],
     "spgnn_lspe_fwd": [_i32p, _i32p, C.POINTER(LspeFwdGroup), _f32p, _i64, _f32, _u64, _f32p, _i64, _f32, _u64, _f32p, _f32p, _i64, _i64,
                        _i32, _vp, _vp],

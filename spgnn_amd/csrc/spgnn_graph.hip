@@ -1,0 +1,139 @@
+// spgnn_graph.hip — batch assembly on the device: from the per-tree adjacency matrices of a loader batch to the batched
+// edge list, CSC and CSR the message-passing kernels walk (SURVEY.md section 8a-G / 8b `spgnn_build_csc`).
+//
+// Reference rule (job_runner.py:1319-1344 and 1779-1801, batching by dgl.batch at 1390 / 1882), per tree with adjacency
+// `adj` (n x n uint8, dataset.py:418-419): `DGLGraph(nx.DiGraph(adj))` enumerates the non-zero entries row by row, i.e. the
+// directed pairs (u, v) sorted by (u, v); `dgl.remove_self_loop` drops the diagonal keeping that order; then
+// `g.add_edges(g.nodes(), g.nodes())` appends the n self loops (i, i); `dgl.batch` offsets node ids by the running node count
+// and concatenates the trees' edge lists.  Edge ids are therefore, for tree t with first node f_t and nnz_t off-diagonal
+// non-zeros:   id(u, v) = [sum over earlier trees of (nnz + n)] + (off-diagonal non-zeros before (u, v) in row-major order),
+//              id(i, i) = [the same base] + nnz_t + i.
+// DGL's COO -> CSC conversion is stable in the edge id, so the in-list of v is its off-diagonal column in ascending u followed
+// by the self loop, and the out-list of u its off-diagonal row in ascending v followed by the self loop.
+//
+// Two kernels, one workgroup per tree: `count` (off-diagonal non-zeros per row and per column) and, after two prefix sums
+// over the node arrays, `fill` (edge list, both index structures and the CSR -> CSC slot map out_pos).  The adjacency bytes
+// of a tree (<= 32 KB for 180 branches) are read from L1 / L2; nothing is staged.  All integer work: results are bit-exact
+// against oracle/graph_rule_nx.py (tests/test_data.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spgnn_hip.h"
+#include "spgnn_internal.h"
+
+namespace {
+
+using spgnn_detail::check_launch;
+using spgnn_detail::fail;
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void build_csc_count_kernel(const uint8_t* __restrict__ adj, const int64_t* __restrict__ adj_ptr,
+                                                                  const int64_t* __restrict__ tree_ptr, int32_t* __restrict__ row_count,
+                                                                  int32_t* __restrict__ col_count) {
+  const int64_t t = blockIdx.x;
+  const int64_t first = tree_ptr[t];
+  const int n = (int)(tree_ptr[t + 1] - first);
+  const uint8_t* a = adj + adj_ptr[t];
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    int r = 0, c = 0;
+    for (int j = 0; j < n; ++j) {
+      r += (j != i && a[(int64_t)i * n + j] != 0) ? 1 : 0;        // row i: out-edges of i
+      c += (j != i && a[(int64_t)j * n + i] != 0) ? 1 : 0;        // column i: in-edges of i (coalesced across threads)
+    }
+    row_count[first + i] = r;
+    col_count[first + i] = c;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void build_csc_fill_kernel(const uint8_t* __restrict__ adj, const int64_t* __restrict__ adj_ptr,
+                                                                 const int64_t* __restrict__ tree_ptr, int64_t num_trees,
+                                                                 const int64_t* __restrict__ row_start, const int64_t* __restrict__ col_start,
+                                                                 int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                                 int32_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                                 int32_t* __restrict__ eid, int32_t* __restrict__ out_indptr,
+                                                                 int32_t* __restrict__ out_indices, int32_t* __restrict__ out_pos,
+                                                                 int64_t N, int64_t E) {
+  const int64_t t = blockIdx.x;
+  const int64_t first = tree_ptr[t];
+  const int n = (int)(tree_ptr[t + 1] - first);
+  const uint8_t* a = adj + adj_ptr[t];
+  // ids of this tree's edges start at row_start[first] (off-diagonal edges of earlier trees) + first (their self loops)
+  const int64_t self_base = row_start[first + n] + first;         // id of (0, 0): after the tree's off-diagonal edges
+  // phase A, one thread per row u: edge list entries and the out-list (ascending v, self loop last)
+  for (int u = threadIdx.x; u < n; u += kThreads) {
+    const int64_t ug = first + u;
+    const int64_t id0 = row_start[ug] + first;                    // id of the first off-diagonal edge of row u
+    const int64_t o0 = row_start[ug] + ug;                        // out_indptr[ug]
+    const int64_t i0 = col_start[ug] + ug;                        // indptr[ug]
+    out_indptr[ug] = (int32_t)o0;
+    indptr[ug] = (int32_t)i0;
+    int r = 0;
+    for (int v = 0; v < n; ++v) {
+      if (v != u && a[(int64_t)u * n + v] != 0) {
+        src[id0 + r] = (int32_t)ug;
+        dst[id0 + r] = (int32_t)(first + v);
+        out_indices[o0 + r] = (int32_t)(first + v);
+        ++r;
+      }
+    }
+    const int64_t sid = self_base + u;
+    src[sid] = (int32_t)ug; dst[sid] = (int32_t)ug;
+    out_indices[o0 + r] = (int32_t)ug;
+    const int cin = (int)(col_start[ug + 1] - col_start[ug]);
+    out_pos[o0 + r] = (int32_t)(i0 + cin);                        // the self loop is the last in-edge of u
+    indices[i0 + cin] = (int32_t)ug;
+    eid[i0 + cin] = (int32_t)sid;
+  }
+  if (t == num_trees - 1 && threadIdx.x == 0) { indptr[N] = (int32_t)E; out_indptr[N] = (int32_t)E; }
+  __threadfence_block();
+  __syncthreads();                                                // phase B reads the out-lists written above
+  // phase B, one thread per column v: the in-list (ascending u), its edge ids, and the CSR -> CSC slot map
+  for (int v = threadIdx.x; v < n; v += kThreads) {
+    const int64_t vg = first + v;
+    const int64_t i0 = col_start[vg] + vg;
+    int c = 0;
+    for (int u = 0; u < n; ++u) {
+      if (u != v && a[(int64_t)u * n + v] != 0) {
+        const int64_t ug = first + u;
+        const int64_t o0 = row_start[ug] + ug;
+        const int cnt = (int)(row_start[ug + 1] - row_start[ug]);
+        int r = 0;                                                // rank of v in row u: its place in u's sorted out-list
+        while (r < cnt && out_indices[o0 + r] != (int32_t)vg) ++r;
+        indices[i0 + c] = (int32_t)ug;
+        eid[i0 + c] = (int32_t)(row_start[ug] + first + r);
+        out_pos[o0 + r] = (int32_t)(i0 + c);
+        ++c;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spgnn_build_csc_count(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,
+                          int32_t* row_count, int32_t* col_count, spgnn_stream_t stream) {
+  if (num_trees < 0 || num_trees > (1ll << 30)) return fail(SPGNN_ERR_SHAPE, "spgnn_build_csc_count: bad num_trees");
+  if (num_trees == 0) return SPGNN_OK;
+  if (!adj || !adj_ptr || !tree_ptr || !row_count || !col_count) return fail(SPGNN_ERR_NULLPTR, "spgnn_build_csc_count: null pointer");
+  hipLaunchKernelGGL(build_csc_count_kernel, dim3((unsigned)num_trees), dim3(kThreads), 0, (hipStream_t)stream, adj, adj_ptr, tree_ptr,
+                     row_count, col_count);
+  return check_launch("spgnn_build_csc_count");
+}
+
+int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees, const int64_t* row_start,
+                    const int64_t* col_start, int32_t* src, int32_t* dst, int32_t* indptr, int32_t* indices, int32_t* eid,
+                    int32_t* out_indptr, int32_t* out_indices, int32_t* out_pos, int64_t N, int64_t E, spgnn_stream_t stream) {
+  if (num_trees < 0 || num_trees > (1ll << 30) || N < 0 || E < N || E >= (1ll << 31)) return fail(SPGNN_ERR_SHAPE, "spgnn_build_csc: bad num_trees / N / E");
+  if (!indptr || !out_indptr) return fail(SPGNN_ERR_NULLPTR, "spgnn_build_csc: null pointer");
+  if (num_trees == 0) return SPGNN_OK;
+  if (!adj || !adj_ptr || !tree_ptr || !row_start || !col_start || !src || !dst || !indices || !eid || !out_indices || !out_pos)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_build_csc: null pointer");
+  hipLaunchKernelGGL(build_csc_fill_kernel, dim3((unsigned)num_trees), dim3(kThreads), 0, (hipStream_t)stream, adj, adj_ptr, tree_ptr,
+                     num_trees, row_start, col_start, src, dst, indptr, indices, eid, out_indptr, out_indices, out_pos, N, E);
+  return check_launch("spgnn_build_csc");
+}
+
+}  // extern "C"

@@ -92,22 +92,28 @@ def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: O
     N = int(sum(ns))
     fv_dim = int(np.asarray(samples[0]["fvs"]).shape[1]); n_cls = int(np.asarray(samples[0]["fvs_out"]).shape[1])
     fvs_h, out_h, y_h = _pinned((N, fv_dim), torch.float32, pin), _pinned((N, n_cls), torch.float32, pin), _pinned((N,), torch.int64, pin)
-    fvs_np, out_np, y_np = fvs_h.numpy(), out_h.numpy(), y_h.numpy()
-    srcs, dsts, pes, off = [], [], [], 0
-    for s, n in zip(samples, ns):
-        adj = np.asarray(s["adj"])
-        fvs_np[off:off + n] = s["fvs"]                       # float64 -> float32 while filling the pinned buffer
-        out_np[off:off + n] = s["fvs_out"]
-        y_np[off:off + n] = s["labels"]
-        u, v = G.edges_from_adj(adj, add_self_loops=True)
-        srcs.append(u + off); dsts.append(v + off)
-        if pos_enc_dim and not on_gpu:                       # host path (CPU graphs): per-tree anchors + BFS in Python
-            anc = anchors_from_cnn_prediction(np.asarray(s["fvs_out"], dtype=np.float32), adj, pos_enc_dim)
-            pes.append(distance_pos_enc(adj, anc)[0])
-        off += n
-    g = G.TreeGraph((np.concatenate(srcs), np.concatenate(dsts)), N, dev)
-    g.batch_num_nodes_list = ns
-    g.batch_num_edges_list = [int(x.shape[0]) for x in srcs]
+    # node arrays: one concatenation each, converting float64 -> float32 / uint8 -> int64 while filling the pinned buffers
+    np.concatenate([np.asarray(s["fvs"]) for s in samples], axis=0, out=fvs_h.numpy(), casting="same_kind")
+    np.concatenate([np.asarray(s["fvs_out"]) for s in samples], axis=0, out=out_h.numpy(), casting="same_kind")
+    np.concatenate([np.asarray(s["labels"]).reshape(-1) for s in samples], axis=0, out=y_h.numpy(), casting="unsafe")
+    pes = []
+    if on_gpu:
+        # edge list, CSC and CSR of the whole batch on the device, from the packed adjacency matrices (spgnn_build_csc)
+        src, dst, csc, nn_, ne_ = G.build_csc_device([s["adj"] for s in samples], dev, pin=pin)
+        g = G.TreeGraph.from_device(src, dst, N, csc, nn_, ne_)
+    else:
+        srcs, dsts, off = [], [], 0
+        for s, n in zip(samples, ns):
+            adj = np.asarray(s["adj"])
+            u, v = G.edges_from_adj(adj, add_self_loops=True)
+            srcs.append(u + off); dsts.append(v + off)
+            if pos_enc_dim:                                  # host path (CPU graphs): per-tree anchors + BFS in Python
+                anc = anchors_from_cnn_prediction(np.asarray(s["fvs_out"], dtype=np.float32), adj, pos_enc_dim)
+                pes.append(distance_pos_enc(adj, anc)[0])
+            off += n
+        g = G.TreeGraph((np.concatenate(srcs), np.concatenate(dsts)), N, dev)
+        g.batch_num_nodes_list = ns
+        g.batch_num_edges_list = [int(x.shape[0]) for x in srcs]
     g.ndata["fvs"] = fvs_h.to(dev, non_blocking=True)
     g.ndata["fvs_out"] = out_h.to(dev, non_blocking=True)
     g.ndata["y"] = y_h.to(dev, non_blocking=True)

@@ -32,7 +32,7 @@ import torch
 
 __all__ = [
     "edges_from_adj", "TreeGraph", "DGLGraph", "batch", "unbatch", "remove_self_loop",
-    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy", "Block", "DeviceBlock", "to_block",
+    "to_networkx", "graph_from_adj", "DeviceCSC", "build_csc_numpy", "build_csc_device", "Block", "DeviceBlock", "to_block",
 ]
 
 
@@ -152,6 +152,66 @@ class DeviceCSC:
         return self._cache["out_deg"]
 
 
+def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True):
+    """Edge list + CSC + CSR of a loader batch built ON THE DEVICE from the trees' adjacency matrices (reference rule:
+    job_runner.py:1779-1801 + dgl.batch, restated in csrc/spgnn_graph.hip): the n x n uint8 matrices are packed into one
+    (pinned) buffer, uploaded once, and two kernels + two prefix sums produce every index array; the host reads back five
+    integers (E and the degree bounds).  -> (src, dst int32 device tensors, DeviceCSC, nodes per tree, edges per tree)."""
+    from . import _capi
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("build_csc_device needs a ROCm device (host graphs: edges_from_adj + build_csc_numpy)")
+    lib = _capi.load()
+    mats = [np.ascontiguousarray(a, dtype=np.uint8) for a in adjs]
+    for a in mats:
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError(f"adj must be square, got {a.shape}")
+    ns = np.array([a.shape[0] for a in mats], dtype=np.int64)
+    T, N = len(mats), int(ns.sum())
+    tree_ptr = np.zeros(T + 1, dtype=np.int64); np.cumsum(ns, out=tree_ptr[1:])
+    adj_ptr = np.zeros(T + 1, dtype=np.int64); np.cumsum(ns * ns, out=adj_ptr[1:])
+    packed = torch.empty((int(adj_ptr[-1]),), dtype=torch.uint8)
+    if pin and packed.numel():
+        packed = packed.pin_memory()
+    if T:
+        np.concatenate([a.reshape(-1) for a in mats], out=packed.numpy())
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        adj_d = packed.to(dev, non_blocking=True)
+        tp_d, ap_d = torch.from_numpy(tree_ptr).to(dev), torch.from_numpy(adj_ptr).to(dev)
+        rc = torch.empty((N,), dtype=torch.int32, device=dev)
+        cc = torch.empty((N,), dtype=torch.int32, device=dev)
+        _capi.check(lib.spgnn_build_csc_count(adj_d.data_ptr(), ap_d.data_ptr(), tp_d.data_ptr(), T, rc.data_ptr(), cc.data_ptr(), st),
+                    "spgnn_build_csc_count")
+        zero = torch.zeros((1,), dtype=torch.int64, device=dev)
+        row_start = torch.cat([zero, torch.cumsum(rc, 0, dtype=torch.int64)])
+        col_start = torch.cat([zero, torch.cumsum(cc, 0, dtype=torch.int64)])
+        if N:
+            stats = torch.stack([row_start[-1], col_start[-1], cc.min().long(), cc.max().long(), rc.min().long(), rc.max().long()]).tolist()
+        else:
+            stats = [0, 0, -1, -1, -1, -1]
+        if stats[0] != stats[1]:
+            raise RuntimeError("build_csc_device: row and column counts disagree (internal error)")
+        E = int(stats[0]) + N
+        if E >= 2 ** 31:
+            raise ValueError("graph too large for int32 indexing")
+        i32 = lambda n: torch.empty((n,), dtype=torch.int32, device=dev)
+        src, dst = i32(E), i32(E)
+        t = dict(indptr=i32(N + 1), indices=i32(E), eid=i32(E), out_indptr=i32(N + 1), out_indices=i32(E), out_pos=i32(E))
+        if T == 0:
+            t["indptr"].zero_(); t["out_indptr"].zero_()
+        _capi.check(lib.spgnn_build_csc(adj_d.data_ptr(), ap_d.data_ptr(), tp_d.data_ptr(), T, row_start.data_ptr(), col_start.data_ptr(),
+                                        src.data_ptr(), dst.data_ptr(), t["indptr"].data_ptr(), t["indices"].data_ptr(), t["eid"].data_ptr(),
+                                        t["out_indptr"].data_ptr(), t["out_indices"].data_ptr(), t["out_pos"].data_ptr(), N, E, st),
+                    "spgnn_build_csc")
+    csc = DeviceCSC.from_tensors(t, N, E, min_in_degree=stats[2] + 1, max_in_degree=stats[3] + 1, max_out_degree=stats[5] + 1)
+    csc.min_out_degree = stats[4] + 1
+    # per-tree edge counts: off-diagonal non-zeros + one self loop per node (host arithmetic on T + 1 numbers read back once)
+    rs = row_start[torch.from_numpy(tree_ptr).to(dev)].cpu().numpy() if T else np.zeros(1, dtype=np.int64)
+    edges_per_tree = (rs[1:] - rs[:-1] + ns).tolist()
+    return src, dst, csc, ns.tolist(), edges_per_tree
+
+
 class _NData(dict):
     """``g.ndata`` — a dict of node tensors that checks the leading dimension."""
 
@@ -206,7 +266,9 @@ class TreeGraph:
             n = num_nodes if num_nodes is not None else (int(max(src.max(initial=-1), dst.max(initial=-1))) + 1)
         else:
             src, dst, n = _edges_from_networkx(data)
-        self._src, self._dst, self._n = src, dst, int(n)
+        self._src_np, self._dst_np, self._n = src, dst, int(n)
+        self._edges_dev = None                                 # (src, dst) int32 device tensors of a graph built on the device
+        self._num_edges = int(src.shape[0])
         self.batch_num_nodes_list: List[int] = [self._n]
         self.batch_num_edges_list: List[int] = [int(src.shape[0])]
         self.ndata = _NData(self)
@@ -214,6 +276,48 @@ class TreeGraph:
         self._tensor_cache: Dict[tuple, torch.Tensor] = {}     # per-batch constants derived from node data
 
     is_block = False      # Block (below) is the bipartite message-flow graph of neighbour-sampled training
+
+    # host copies of the edge list: a graph assembled on the device (build_csc_device) downloads them on first use only
+    def _host_edges(self):
+        if self._src_np is None:
+            s_, d_ = self._edges_dev
+            self._src_np, self._dst_np = s_.cpu().numpy().astype(np.int64), d_.cpu().numpy().astype(np.int64)
+        return self._src_np, self._dst_np
+
+    @property
+    def _src(self):
+        return self._host_edges()[0]
+
+    @_src.setter
+    def _src(self, v):
+        self._src_np = v
+        self._num_edges = int(v.shape[0])
+        self._edges_dev = None
+
+    @property
+    def _dst(self):
+        return self._host_edges()[1]
+
+    @_dst.setter
+    def _dst(self, v):
+        self._dst_np = v
+        self._edges_dev = None
+
+    @classmethod
+    def from_device(cls, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, csc: "DeviceCSC", batch_num_nodes: Sequence[int],
+                    batch_num_edges: Sequence[int]) -> "TreeGraph":
+        """A batched graph whose edge list and index structures were built on the device (:func:`build_csc_device`)."""
+        g = cls(None, num_nodes, src.device)
+        g._src_np = g._dst_np = None
+        g._edges_dev = (src, dst)
+        g._num_edges = int(src.shape[0])
+        g.batch_num_nodes_list = [int(x) for x in batch_num_nodes]
+        g.batch_num_edges_list = [int(x) for x in batch_num_edges]
+        dev = src.device
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        g._csc[str(dev)] = csc
+        return g
 
     # ---- structure -------------------------------------------------------------------
     def number_of_nodes(self) -> int:
@@ -224,7 +328,7 @@ class TreeGraph:
     number_of_dst_nodes = num_dst_nodes = number_of_nodes
 
     def number_of_edges(self) -> int:
-        return int(self._src.shape[0])
+        return self._num_edges
 
     num_edges = number_of_edges
 
@@ -232,6 +336,8 @@ class TreeGraph:
         return torch.arange(self._n, dtype=torch.int64, device=self.device)
 
     def edges(self):
+        if self._edges_dev is not None and self._edges_dev[0].device == self.device:
+            return self._edges_dev[0].long(), self._edges_dev[1].long()
         return (torch.from_numpy(self._src).to(self.device), torch.from_numpy(self._dst).to(self.device))
 
     def add_edges(self, u, v) -> None:
@@ -284,6 +390,8 @@ class TreeGraph:
     def csc(self, device=None) -> DeviceCSC:
         """int32 CSC + CSR of the current edge list on ``device`` (built once, cached)."""
         device = torch.device(device) if device is not None else self.device
+        if device.type == "cuda" and device.index is None:        # "cuda" and "cuda:<current>" are one cache entry
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         key = str(device)
         if key not in self._csc:
             arrays = build_csc_numpy(self._src, self._dst, self._n)
@@ -388,6 +496,8 @@ class Block(TreeGraph):
 
     def csc(self, device=None) -> DeviceCSC:
         device = torch.device(device) if device is not None else self.device
+        if device.type == "cuda" and device.index is None:        # "cuda" and "cuda:<current>" are one cache entry
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         key = str(device)
         if key not in self._csc:
             c = super().csc(device)

@@ -139,3 +139,55 @@ def test_device_anchor_selection_matches_networkx_oracle_including_ties():
         off += n
     anc21 = anchors_device(bg, bg.ndata["fvs_out"], 21).cpu().numpy()
     assert anc21.shape[1] == 21 and np.array_equal(anc21, anc[:, :21])
+
+
+@pytest.mark.gpu
+def test_build_csc_device_bit_exact_at_512_trees():
+    """the batch's edge list, CSC, CSR and slot map built on the device (spgnn_build_csc) from the packed
+    adjacency matrices - bit-exact against the networkx oracle of the reference rule (oracle/graph_rule_nx.py) at the
+    bench's batch size, and against the host builder for matrices the reference never produces (asymmetric, zero diagonal,
+    a single-node tree): the rule is `non-zero off-diagonal entries in row-major order, then the self loops`."""
+    import time
+    from oracle import graph_rule_nx as R
+    from spgnn_amd import graph as G
+    samples = synthetic.synthetic_trees(512, rank=1)
+    adjs = [s["adj"] for s in samples]
+    ns = [a.shape[0] for a in adjs]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    src, dst, csc, nn_, ne_ = G.build_csc_device(adjs, "cuda")
+    torch.cuda.synchronize()
+    t_dev = time.perf_counter() - t0
+    e_src, e_dst = R.batch_edges([R.edges_spgnn(a) for a in adjs], ns)
+    assert np.array_equal(src.cpu().numpy(), e_src) and np.array_equal(dst.cpu().numpy(), e_dst)
+    assert nn_ == ns and ne_ == [3 * n - 2 for n in ns]            # trees: 2 (n - 1) directed edges + n self loops
+    indptr, indices, eid = R.csc_stable(e_src, e_dst, sum(ns))
+    assert np.array_equal(csc.indptr.cpu().numpy(), indptr) and np.array_equal(csc.indices.cpu().numpy(), indices)
+    assert np.array_equal(csc.eid.cpu().numpy(), eid)
+    t0 = time.perf_counter()
+    ref = G.build_csc_numpy(e_src, e_dst, sum(ns))
+    t_host = time.perf_counter() - t0
+    for k in ("indptr", "indices", "eid", "out_indptr", "out_indices", "out_pos"):
+        assert np.array_equal(getattr(csc, k).cpu().numpy(), ref[k]), k
+    assert (csc.min_in_degree, csc.max_in_degree) == (int(np.diff(ref["indptr"]).min()), int(np.diff(ref["indptr"]).max()))
+    assert (csc.min_out_degree, csc.max_out_degree) == (int(np.diff(ref["out_indptr"]).min()), int(np.diff(ref["out_indptr"]).max()))
+    print(f"build_csc_device 512 trees (N={sum(ns)}, E={src.numel()}): {t_dev * 1e3:.1f} ms incl. upload; host CSC alone {t_host * 1e3:.1f} ms")
+    # general matrices
+    rng = np.random.default_rng(0)
+    odd = [(rng.random((n, n)) < 0.15).astype(np.uint8) for n in (1, 2, 7, 33, 300)]
+    odd.append(np.triu(adjs[0]))                                    # the reference's unused `tree_downstream` form
+    odd.append(np.zeros((5, 5), dtype=np.uint8))                    # no edges at all: only the self loops
+    src, dst, csc, nn_, ne_ = G.build_csc_device(odd, "cuda")
+    us, vs, off = [], [], 0
+    for a in odd:
+        u, v = G.edges_from_adj(a)
+        us.append(u + off); vs.append(v + off); off += a.shape[0]
+    e_src, e_dst = np.concatenate(us), np.concatenate(vs)
+    assert np.array_equal(src.cpu().numpy(), e_src) and np.array_equal(dst.cpu().numpy(), e_dst)
+    ref = G.build_csc_numpy(e_src, e_dst, off)
+    for k in ("indptr", "indices", "eid", "out_indptr", "out_indices", "out_pos"):
+        assert np.array_equal(getattr(csc, k).cpu().numpy(), ref[k]), k
+    assert ne_ == [int(x.shape[0]) for x in us]
+    g = G.TreeGraph.from_device(src, dst, off, csc, nn_, ne_)
+    assert g.csc("cuda") is csc and g.number_of_edges() == e_src.shape[0] and np.array_equal(g._src, e_src)
+    assert torch.equal(g.edges()[0].cpu(), torch.from_numpy(e_src))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> <kernels|lspe|gemm|bf16> [-DSWITCH=v ...]   ->  build/variants/<name>.so
+# usage: tools/build_variant.sh <name> <kernels|lspe|graph|gemm|bf16> [-DSWITCH=v ...]   ->  build/variants/<name>.so
 # (the named translation unit rebuilt with the switches, the other objects taken from build/obj)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,7 +8,7 @@ extra=""; if [ $unit == kernels ] || [ $unit == lspe ]; then extra="-fno-slp-vec
 mkdir -p $R/build/variants $R/build/vobj
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I $R/include -I $R/spgnn_amd/csrc $extra "$@" -c $R/spgnn_amd/csrc/spgnn_$unit.hip -o $R/build/vobj/$name.o
 objs=""
-for u in kernels lspe gemm bf16; do
+for u in kernels lspe graph gemm bf16; do
   if [ $u == $unit ]; then objs="$objs $R/build/vobj/$name.o"; else objs="$objs $R/build/obj/spgnn_$u.hip.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/variants/$name.so $objs
