@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 32
+#define SPGNN_ABI_VERSION 33
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -747,6 +747,29 @@ int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* t
                     const int64_t* row_start, const int64_t* col_start, int32_t* src, int32_t* dst, int32_t* indptr,
                     int32_t* indices, int32_t* eid, int32_t* out_indptr, int32_t* out_indices, int32_t* out_pos, int64_t N,
                     int64_t E, spgnn_stream_t stream);
+
+/* =================================================================================================
+ * Weight operands of every projection layer of a model, per training step, in one call (two kernel launches + a 4-byte-per-
+ * layer memset) instead of spgnn_weight_cat + spgnn_presplit per layer.  `table` (DEVICE memory, n_layers entries): per layer
+ * the two row blocks a (rows_a x K) / b (rows_b x K, nullable) - fc.weight and res_fc.weight of a GATConv (reference
+ * models.py:425-456) - and the outputs: dst = [a; b] with 16-byte rows (row stride dst_stride = K rounded up to 4, pad
+ * columns zero), dst_t = its transpose (K rows, row stride dst_t_stride = rows rounded up to 4; nullable together with ps_t),
+ * ps / ps_t = the same two matrices in the pre-split form spgnn_gemm_nt takes with b_presplit, scale = the operand's
+ * power-of-two scale (one float).  first_block = running sum of spgnn_weight_prep_blocks over the earlier entries;
+ * total_blocks = the sum over all; maxwords: n_layers words of scratch.  Results are bit-identical to the per-layer calls.
+ * ================================================================================================= */
+typedef struct spgnn_weight_prep_layer {
+  const float* a; int64_t a_stride; const float* b; int64_t b_stride;
+  float* dst; float* ps; int64_t dst_stride;
+  float* dst_t; float* ps_t; int64_t dst_t_stride;
+  float* scale;
+  int64_t first_block;
+  int32_t rows_a; int32_t rows_b; int32_t K; int32_t reserved;
+} spgnn_weight_prep_layer;
+
+int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride);
+int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, uint32_t* maxwords,
+                      spgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

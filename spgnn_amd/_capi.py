@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -37,8 +37,16 @@ class LspeBwdSrcGroup(C.Structure):       # spgnn_lspe_bwd_src_group
                 ("p_drop", _f32), ("seed", _u64)]
 
 
+class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
+    _fields_ = [("a", _vp), ("a_stride", _i64), ("b", _vp), ("b_stride", _i64), ("dst", _vp), ("ps", _vp), ("dst_stride", _i64),
+                ("dst_t", _vp), ("ps_t", _vp), ("dst_t_stride", _i64), ("scale", _vp), ("first_block", _i64), ("rows_a", _i32),
+                ("rows_b", _i32), ("K", _i32), ("reserved", _i32)]
+
+
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
 SIGNATURES = {
+    "spgnn_weight_prep_blocks": [_i32, _i64, _i64],
+    "spgnn_weight_prep": [_vp, _i32, _i64, _vp, _vp],
     "spgnn_build_csc_count": [_vp, _vp, _vp, _i64, _i32p, _i32p, _vp],
     "spgnn_build_csc": [_vp, _vp, _vp, _i64, _vp, _vp, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i64, _i64, _vp],
     "spgnn_lspe_supported": [_i32],
@@ -148,7 +156,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials", "spgnn_tree_anchors_workspace") else C.c_int
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials", "spgnn_tree_anchors_workspace", "spgnn_weight_prep_blocks") else C.c_int
     ver = lib.spgnn_abi_version()
     if ver != ABI_VERSION:
         raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")

@@ -1201,6 +1201,68 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// spgnn_weight_prep: the weight operands of EVERY projection layer of a model in two launches per step instead of two per
+// layer (spgnn_weight_cat + spgnn_presplit each): a table of layers, one 32 x 32 tile per workgroup, the table entry found
+// from the block index.  Pass 0 folds |max| of each layer's [A; B] into one word per layer (atomicMax on the bit pattern of
+// a non-negative float: order-independent, so the scale is deterministic); pass 1 derives the power-of-two scale from it and
+// writes the four images the GEMMs take: [A; B] with 16-byte rows, its transpose, and both in pre-split form.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_prep_layer* __restrict__ tab, int n_layers,
+                                                          unsigned* __restrict__ maxwords, int pass) {
+  __shared__ float tile[32][33];
+  __shared__ float red[4];
+  int l = 0;
+  while (l + 1 < n_layers && (int64_t)blockIdx.x >= tab[l + 1].first_block) ++l;
+  const spgnn_weight_prep_layer L = tab[l];
+  const int R = L.rows_a + L.rows_b, K = L.K;
+  const int tiles_x = (int)((L.dst_stride + 31) / 32);
+  const int b = (int)(blockIdx.x - L.first_block);
+  const int r0 = (b / tiles_x) * 32, c0 = (b % tiles_x) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < K) v = r < L.rows_a ? L.a[(int64_t)r * L.a_stride + c] : L.b[(int64_t)(r - L.rows_a) * L.b_stride + c];
+    tile[ty + 8 * i][tx] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  if (pass == 0) {
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&maxwords[l], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    return;
+  }
+  const float sc = pow2_scale_of(__uint_as_float(maxwords[l]));
+  if (b == 0 && threadIdx.x == 0) L.scale[0] = sc;
+  __syncthreads();
+  // one group of four per thread: rows of the tile for dst / ps, columns of the tile (rows of the transpose) for dst_t / ps_t
+  const int gr = threadIdx.x >> 3, gc = (threadIdx.x & 7) * 4;
+  {
+    const int r = r0 + gr, c = c0 + gc;
+    if (r < R && c < L.dst_stride) {
+      const float4 v = make_float4(tile[gr][gc], tile[gr][gc + 1], tile[gr][gc + 2], tile[gr][gc + 3]);     // beyond K: zeros
+      *reinterpret_cast<float4*>(L.dst + (int64_t)r * L.dst_stride + c) = v;
+      uint2 h, lo;
+      split4_pk(v, sc, h, lo);
+      *reinterpret_cast<uint4*>(L.ps + (int64_t)r * L.dst_stride + c) = make_uint4(h.x, h.y, lo.x, lo.y);
+    }
+  }
+  if (L.dst_t) {
+    const int c = c0 + gr, r = r0 + gc;                           // row c of the transpose, its columns r .. r + 3
+    if (c < K && r < L.dst_t_stride) {
+      const float4 v = make_float4(tile[gc][gr], tile[gc + 1][gr], tile[gc + 2][gr], tile[gc + 3][gr]);     // beyond R: zeros
+      *reinterpret_cast<float4*>(L.dst_t + (int64_t)c * L.dst_t_stride + r) = v;
+      uint2 h, lo;
+      split4_pk(v, sc, h, lo);
+      *reinterpret_cast<uint4*>(L.ps_t + (int64_t)c * L.dst_t_stride + r) = make_uint4(h.x, h.y, lo.x, lo.y);
+    }
+  }
+}
+
 }  // namespace gemm
 
 extern "C" {
@@ -1450,6 +1512,24 @@ int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, fl
     hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, partials, (int)n, factor, scale);
   }
   return spgnn_detail::check_launch("spgnn_gemm");
+}
+
+int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride) {
+  const int64_t tall = dst_t_stride > rows ? dst_t_stride : rows;
+  return ((dst_stride + 31) / 32) * ((tall + 31) / 32);
+}
+
+int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, uint32_t* maxwords,
+                      spgnn_stream_t stream) {
+  if (n_layers < 0 || total_blocks < 0 || total_blocks > (1ll << 30)) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (n_layers == 0 || total_blocks == 0) return SPGNN_OK;
+  if (!table || !maxwords) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(maxwords, 0, sizeof(uint32_t) * (size_t)n_layers, st);
+  if (e != hipSuccess) return spgnn_detail::fail_at(-(1000 + (int)e), __func__, __LINE__);
+  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, maxwords, 0);
+  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, maxwords, 1);
+  return spgnn_detail::check_launch("spgnn_weight_prep");
 }
 
 }  // extern "C"

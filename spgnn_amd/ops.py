@@ -753,6 +753,84 @@ def _bt_operand(w: torch.Tensor, use_ps: bool):
     return _tagged(w, "_spgnn_t"), (_tagged(w, "_spgnn_t_ps") if use_ps else None)
 
 
+class _WeightPrep:
+    """Persistent operand buffers and the device table of spgnn_weight_prep for one list of projection layers."""
+
+    def __init__(self, specs, device):
+        import ctypes
+        lib = _capi.load()
+        self.n = len(specs)
+        self.entries, self.keep = [], []
+        tab = (_capi.WeightPrepLayer * self.n)()
+        first = 0
+        for i, (w_a, w_b, want_t) in enumerate(specs):
+            R1, K = w_a.shape
+            R2 = 0 if w_b is None else w_b.shape[0]
+            R, Kp, Rp = R1 + R2, (K + 3) // 4 * 4, (R1 + R2 + 3) // 4 * 4
+            dst = torch.empty((R, Kp), dtype=torch.float32, device=device)
+            ps = torch.empty((R, Kp), dtype=torch.float32, device=device)
+            dst_t = torch.empty((K, Rp), dtype=torch.float32, device=device) if want_t else None
+            ps_t = torch.empty((K, Rp), dtype=torch.float32, device=device) if want_t else None
+            scale = torch.empty((1,), dtype=torch.float32, device=device)
+            t = tab[i]
+            t.a, t.a_stride = w_a.data_ptr(), w_a.stride(0)
+            t.b, t.b_stride = (w_b.data_ptr(), w_b.stride(0)) if w_b is not None else (0, 0)
+            t.dst, t.ps, t.dst_stride = dst.data_ptr(), ps.data_ptr(), Kp
+            t.dst_t, t.ps_t, t.dst_t_stride = (dst_t.data_ptr(), ps_t.data_ptr(), Rp) if want_t else (0, 0, 0)
+            t.scale, t.first_block, t.rows_a, t.rows_b, t.K = scale.data_ptr(), first, R1, R2, K
+            first += int(lib.spgnn_weight_prep_blocks(R, Kp, Rp if want_t else 0))
+            self.entries.append((dst, ps, dst_t, ps_t, scale, (R1, R2, K, R)))
+        self.blocks = first
+        raw = bytes(memoryview(tab))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.maxwords = torch.zeros((max(self.n, 1),), dtype=torch.int32, device=device)
+
+    def run(self):
+        with torch.cuda.device(self.table.device):
+            _capi.check(_capi.load().spgnn_weight_prep(self.table.data_ptr(), self.n, self.blocks, self.maxwords.data_ptr(),
+                                                       _stream(self.table)), "spgnn_weight_prep")
+
+
+_PREP_CACHE: dict = {}       # layout key -> _WeightPrep (buffers and table are reused by every forward pass)
+_PREP_ACTIVE: dict = {}      # (id(w_a), id(w_b)) -> (entry, want_t): installed for the duration of one model forward
+BATCH_WEIGHT_PREP = True     # all projection layers' operands in one spgnn_weight_prep call per forward; False: per layer
+
+
+class prepared_weights:
+    """``with prepared_weights(specs):`` - ``specs`` = [(w_a, w_b or None, want_t), ...] of every project-first GATConv a
+    forward pass will run.  One spgnn_weight_prep call builds all their GEMM operands ([W_fc; W_res] with 16-byte rows, its
+    transpose, both pre-split, the scale); inside the block :func:`weight_cat` hands them out without launching anything.
+    Values are those of the parameters at entry (the block must not update them)."""
+
+    def __init__(self, specs):
+        self.specs = [sp for sp in specs if sp[0].is_cuda and sp[0].dtype == torch.float32 and sp[0].stride(1) == 1
+                      and (sp[1] is None or sp[1].stride(1) == 1)] if (BATCH_WEIGHT_PREP and GEMM_MODE == "f16x3") else []
+        self.prev = None
+
+    def __enter__(self):
+        global _PREP_ACTIVE
+        self.prev = _PREP_ACTIVE
+        if not self.specs:
+            return self
+        dev = self.specs[0][0].device
+        key = (str(dev),) + tuple((a.data_ptr(), a.stride(0), tuple(a.shape), 0 if b is None else b.data_ptr(),
+                                   0 if b is None else b.stride(0), None if b is None else tuple(b.shape), bool(t))
+                                  for a, b, t in self.specs)
+        prep = _PREP_CACHE.get(key)
+        if prep is None:
+            if len(_PREP_CACHE) > 8:
+                _PREP_CACHE.clear()
+            prep = _PREP_CACHE[key] = _WeightPrep(self.specs, dev)
+        prep.run()
+        _PREP_ACTIVE = {(id(a), id(b) if b is not None else 0): (e, bool(t)) for (a, b, t), e in zip(self.specs, prep.entries)}
+        return self
+
+    def __exit__(self, *exc):
+        global _PREP_ACTIVE
+        _PREP_ACTIVE = self.prev
+        return False
+
+
 class _WeightCat(torch.autograd.Function):
     """[w_a ; w_b] (rows of fc.weight, then of res_fc.weight) as ONE GEMM operand with 16-byte rows, its transpose (the
     operand of the input-gradient product) and its split-GEMM scale: one kernel + the scale kernel per layer and step
@@ -765,6 +843,13 @@ class _WeightCat(torch.autograd.Function):
         R1, K = w_a.shape
         R2 = 0 if w_b is None else w_b.shape[0]
         R, Kp, Rp = R1 + R2, (K + 3) // 4 * 4, (R1 + R2 + 3) // 4 * 4
+        hit = _PREP_ACTIVE.get((id(w_a), id(w_b) if w_b is not None else 0))
+        if hit is not None and (hit[1] or not want_t) and hit[0][5] == (R1, R2, K, R):
+            dst, ps, dst_t, ps_t, scale, _ = hit[0]          # built by spgnn_weight_prep for this forward pass: nothing to launch
+            ctx.rows = (R1, R2)
+            outs = (dst[:, :K], scale, ps[:, :K]) + ((dst_t[:, :R], ps_t[:, :R]) if want_t else ())
+            ctx.mark_non_differentiable(*outs[1:])
+            return outs
         wa = w_a if w_a.stride(1) == 1 else w_a.contiguous()
         wb = None if w_b is None else (w_b if w_b.stride(1) == 1 else w_b.contiguous())
         buf = torch.empty((R, Kp), dtype=torch.float32, device=w_a.device)

@@ -253,3 +253,32 @@ def test_gemm_nt_headmean(M, N, K):
     ops.gemm_nt_headmean(a, b, sa, sb, out, other, mean, bias=bias, act=ops.ACT_ELU)
     assert torch.equal(out, ref)
     assert torch.equal(mean, 0.5 * (ref + other))
+
+
+def test_weight_prep_batched_equals_per_layer():
+    """spgnn_weight_prep (every layer's operands in one call) against spgnn_weight_cat + spgnn_presplit per layer: [W_fc; W_res]
+    with 16-byte rows, its transpose, both pre-split forms and the scale, bit for bit; shapes of st_pgat_spgnn_3 plus ragged ones."""
+    torch.manual_seed(0)
+    shapes = [(512, 512, 1063, False), (256, 256, 39, False), (256, 256, 768, True), (128, 128, 256, True), (64, 0, 128, True),
+              (5, 3, 7, True), (33, 31, 70, False)]
+    params = [(torch.randn(r1, k, device="cuda") * (0.05 + i), torch.randn(r2, k, device="cuda") if r2 else None, t)
+              for i, (r1, r2, k, t) in enumerate(shapes)]
+    ref = []
+    for a, b, t in params:
+        w = ops.weight_cat(a, b, want_t=t)
+        ref.append((w.clone(), ops.operand_scale(w).clone(), ops._tagged(w, "_spgnn_ps").clone(),
+                    ops._tagged(w, "_spgnn_t").clone() if t else None, ops._tagged(w, "_spgnn_t_ps").clone() if t else None))
+    for rep in range(2):                                       # the second pass reuses the cached buffers and table
+        with ops.prepared_weights(params):
+            assert len(ops._PREP_ACTIVE) == len(params)
+            for (a, b, t), (w0, s0, ps0, t0, tps0) in zip(params, ref):
+                w = ops.weight_cat(a, b, want_t=t)
+                assert torch.equal(w, w0) and float(ops.operand_scale(w)) == float(s0)
+                assert torch.equal(ops._tagged(w, "_spgnn_ps").view(torch.int32), ps0.view(torch.int32))
+                if t:
+                    assert torch.equal(ops._tagged(w, "_spgnn_t"), t0)
+                    assert torch.equal(ops._tagged(w, "_spgnn_t_ps").view(torch.int32), tps0.view(torch.int32))
+                base = w._base if w._base is not None else w
+                assert float(base[:, w.shape[1]:].abs().sum()) == 0.0          # pad columns are zero
+        assert not ops._PREP_ACTIVE
+    assert len(ops._PREP_CACHE) >= 1
