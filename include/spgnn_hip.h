@@ -98,7 +98,7 @@ int spgnn_gat_fwd(const int32_t* indptr, const int32_t* indices,
                   float negative_slope, int32_t activation,
                   float p_drop, uint64_t seed, const uint64_t* seed_offset /* nullable device word added to seed */,
                   float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
-                  float* out_absmax /* nullable: out_absmax[v] = max |out[v,:]| as stored (split-GEMM scale of the consumer) */,
+                  float* out_absmax /* nullable: SCALE BLOCK (see spgnn_gemm_nt) that takes max |out| as stored: the consumer GEMM's operand scale */,
                   spgnn_stream_t stream);
 
 /* 1 if the vector kernel fuses the head mean for this (H, D) (a head is at least one team wide). */
@@ -127,7 +127,7 @@ int spgnn_gat_bwd_dst(const int32_t* indptr, const int32_t* indices,
                       float* g_pre, int64_t g_pre_stride,
                       float* g_e,
                       float* g_er, int64_t g_s_stride,
-                      float* absmax /* nullable: absmax[v] = max|g_pre[v,:]| */,
+                      float* absmax /* nullable: scale block taking max |g_pre| */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float negative_slope, int32_t activation,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
@@ -150,7 +150,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       const float* g_pre, int64_t g_pre_stride,
                       float* g_ft, int64_t g_ft_stride,
                       float* g_el, int64_t g_s_stride,
-                      float* absmax /* nullable: absmax[u] = max|g_ft[u,:]| */,
+                      float* absmax /* nullable: scale block taking max |g_ft| (the same block as spgnn_gat_bwd_dst's: [g_ft | g_pre] is one operand) */,
                       const float* score_l, const float* score_r /* nullable: attn_l, attn_r flat (H*D) */,
                       const float* g_er /* with score_l: (N, H) at stride g_s_stride, from spgnn_gat_bwd_dst */,
                       int64_t N, int64_t E, int32_t H, int32_t D,
@@ -167,7 +167,7 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
  *   a_uv        = edge softmax of LeakyReLU(el[u,h] + er[v,h])                      -> attn[slot,h]
  *   z[v, h*head_stride + f]                 = sum_{u in in(v)} drop(a_uv) * x[u,f]     f in [0,F)
  *   z[v, h*head_stride + x_copy_offset + f] = x[v,f]        (x_copy_offset >= F; < 0: no residual operand copy)
- *   absmax[v] (nullable) = max |z[v,:]| over the columns written (split-GEMM scale of the operand)
+ *   absmax (nullable): scale block taking max |z| over the columns written (split-GEMM scale of the operand)
  *
  * H in {1,2,4}, F % 4 == 0, F <= 1024 (spgnn_gat_agg_supported); rows 16-byte aligned; head_stride % 4 == 0.
  */
@@ -214,7 +214,7 @@ int spgnn_head_mean(const float* out, int64_t out_stride, float* out_mean, int64
                     int64_t N, int32_t H, int32_t D, spgnn_stream_t stream);
 
 /* g_pre[v,c] = g_out[v, mean_heads ? c % D : c] * (mean_heads ? 1/H : 1) * act'(out[v,c]) (the first phase of
- * spgnn_gat_bwd_dst as an entry point of its own); absmax[v] (nullable) = max_c |g_pre[v,c]|.  D % 4 == 0. */
+ * spgnn_gat_bwd_dst as an entry point of its own); absmax (nullable): scale block taking max |g_pre|.  D % 4 == 0. */
 int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                   const float* out, int64_t out_stride,
                   float* g_pre, int64_t g_pre_stride, float* absmax,
@@ -224,7 +224,7 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
  * `gnn_out = nn.Linear(node_embed_dim, out_ch)`, models.py:1125, on the head mean of models.py:482), with that
  * Linear's input gradient formed on the fly instead of written by spgnn_scores_bwd_x and re-read:
  *   g_pre[v, h*D + c] = (1/H) * (sum_j g_s[v, j] * w[j, c]) * act'(out[v, h*D + c]),  j < J <= 32, H <= 4, D <= 1024.
- * absmax_partials receives spgnn_act_bwd_proj_blocks(N) block maxima of |g_pre| (for spgnn_scale_from_partials).
+ * absmax_partials: scale block taking max |g_pre| (spgnn_act_bwd_proj_blocks(N) = the number of workgroups, informational).
  * `out` may be NULL when activation == SPGNN_ACT_NONE. */
 int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
                        int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
@@ -242,7 +242,7 @@ int32_t spgnn_act_bwd_proj_blocks(int64_t N);
 int spgnn_cat_dropout(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t N, int32_t width,
                       int32_t col_offset, int32_t total_width, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       int32_t backward,
-                      float* absmax_partials /* nullable: spgnn_cat_dropout_blocks(N, width) maxima of |dst| (GEMM operand scale) */,
+                      float* absmax_partials /* nullable: scale block taking max |dst| (GEMM operand scale) */,
                       spgnn_stream_t stream);
 int64_t spgnn_cat_dropout_blocks(int64_t N, int32_t width);
 
@@ -282,7 +282,7 @@ int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l,
  * `gnn_out = Linear(1024, 22)` (reference models.py:1125, 1169): a 22-column projection of 76k rows.
  */
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
-                     float* s, int64_t s_stride, float* absmax /* nullable: ceil(N/16) per-wave maxima of |x| */,
+                     float* s, int64_t s_stride, float* absmax /* nullable: scale block taking max |x| */,
                      int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride,
                        float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
@@ -337,8 +337,13 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
  *   C[M,N] = A[M,K] * B[N,K]^T            A, B, C fp32 row-major with row strides lda, ldb, ldc
  *
  * Every operand value is split on the fly into two fp16 terms after multiplication by a per-tensor
- * power-of-two scale (*scale_a, *scale_b: device scalars from spgnn_pow2_scale, or NULL = 1) and the three
+ * power-of-two scale (scale_a, scale_b: SCALE BLOCKS in device memory, or NULL = 1) and the three
  * leading products are accumulated in fp32 (v_mfma_f32_32x32x16_f16); the result carries fp32-GEMM accuracy.
+ * A scale block is either {s}: one positive float, the scale itself (spgnn_pow2_scale, spgnn_weight_prep), or
+ * {-256, 0, 0, 0, m_1 ... m_256}: 256 "slots" of maxima which the kernels that PRODUCE the operand fold their rows'
+ * largest magnitudes into (their `absmax` arguments; one result-free atomicMax per node team - max is order-independent,
+ * so the scale is deterministic); the GEMM derives s = 2^(14 - e), max_i m_i <= 2^e, itself.  The slots must be zero
+ * before the first producer runs.  This replaces one reduction launch per operand and step.
  * A and B rows must be 16-byte aligned (lda, ldb multiples of 4); K may be ragged.
  * Optional exact fp32 rank-J update fused into the epilogue: C += U[M,J] * V[J,N] (upd_j <= 32; V rows
  * 16-byte aligned and zero padded to a multiple of 4 columns; upd_j = 0 disables it).  The layer uses it for
@@ -685,7 +690,7 @@ int spgnn_lspe_supported(int32_t D);
  * feature dropout (out_drop_p, out_drop_seed; mask of spgnn_cat_dropout for a 3D-wide concatenation: the reference's
  * `dropout(cat[h_s, h_p])`, models.py:477-481 + GATConv.feat_drop) - that layer's input buffer, written once.
  * out2 (N, D): the position head once more under the next POSITION layer's feature dropout (out2_drop_p = 0: plain, e.g. the
- * model's h_p output) - that layer's input.  out_absmax / out2_absmax (N, nullable): per-node maxima of the stored
+ * model's h_p output) - that layer's input.  out_absmax / out2_absmax (nullable): scale blocks taking the maxima of the stored
  * rows (operand scales of the next projections).
  */
 int spgnn_lspe_fwd(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_fwd_group* groups /* [2] */, float* out,
@@ -698,7 +703,7 @@ typedef struct spgnn_lspe_bwd_dst_group {
   float* g_pre; int64_t g_pre_stride;      /* out: gradient of the pre-activation rows (N, H*D) */
   float* g_e;                               /* out: (E, H) */
   float* g_er; int64_t gs_stride;           /* out: (N, H) */
-  float* absmax;                            /* out, nullable: (N,) per-node maxima of |g_pre| */
+  float* absmax;                            /* nullable: scale block of [g_ft | g_pre] (max |g_pre| folded in) */
   int32_t H; int32_t act; float slope; float p_drop; uint64_t seed;
 } spgnn_lspe_bwd_dst_group;
 
@@ -720,7 +725,7 @@ typedef struct spgnn_lspe_bwd_src_group {
   float* g_ft; int64_t g_ft_stride;         /* out: gradient of the projected rows (N, H*D) */
   float* g_el; const float* g_er; int64_t gs_stride;   /* g_el out, g_er in: (N, H) */
   const float* score_l; const float* score_r;           /* attn_l / attn_r (H*D), both or neither: the score term */
-  float* absmax;                            /* out, nullable: (N,) per-node maxima of |g_ft| */
+  float* absmax;                            /* nullable: the same scale block (max |g_ft| folded in) */
   int32_t H; float p_drop; uint64_t seed;
 } spgnn_lspe_bwd_src_group;
 

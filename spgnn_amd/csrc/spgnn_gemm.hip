@@ -40,7 +40,7 @@ struct Args {
   const float* B; int64_t ldb;
   float* C; int64_t ldc;
   int M, N, K;
-  const float* sA; const float* sB;             // device scalars (power-of-two scales) or null (= 1)
+  const float* sA; const float* sB;             // scale blocks (spgnn_internal.h) or null (= 1)
   int nbm, nbn;
   // optional exact fp32 rank-J update applied in the epilogue: C += U[M,J] * V[J,N]  (J <= 16; the score
   // gradient term g_S * W_lr of the input gradient, which otherwise costs a read-modify-write pass over C)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
 
   // Operand tiles come through buffer descriptors: one 32-bit per-thread offset per operand, everything else (tile
   // row, staging register, stage) in the scalar offset; rows past the end read as zero (no clamps, no 64-bit address
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = a.sA ? a.sA[0] : 1.f, sB = a.sB ? a.sB[0] : 1.f;
+  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -1123,11 +1123,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 // scale[0] = 2^(14 - e) with max <= 2^e ; optional multiplicative bound factor (e.g. 1/(1-p) for dropout)
-__device__ __forceinline__ float pow2_scale_of(float m) {
-  float s = 1.f;
-  if (m > 0.f && m < INFINITY) { int e; frexpf(m, &e); s = ldexpf(1.f, 14 - e); }
-  return s;
-}
+using spgnn_detail::pow2_scale_of;
 // small inputs: one block
 __global__ void scale_from_partials(const float* __restrict__ partial, int n, float factor, float* __restrict__ scale) {
   float m = 0.f;
@@ -1174,7 +1170,7 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
   __shared__ float red[4];
   float sc;
   if (scale_in) {
-    sc = scale_in[0];
+    sc = spgnn_detail::load_scale(scale_in);
   } else {
     float m = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);

@@ -13,3 +13,39 @@ int fail_at(int code, const char* func, int line);
 // device, so it is remembered per (function, device)
 int ensure_dynamic_lds(const void* func, int bytes);
 }  // namespace spgnn_detail
+
+// ---- scale blocks ----------------------------------------------------------------------------------------------------
+// The power-of-two operand scales of the split GEMMs (spgnn_gemm.hip) travel as device pointers to a SCALE BLOCK:
+//   {s}                          one positive float: the scale itself, or
+//   {-n, 0, 0, 0, m_1 ... m_n}   n = 256 maxima ("slots"): the operand's largest magnitude is max_i m_i and its scale
+//                                2^(14 - e) with max <= 2^e is derived by the consuming kernel.
+// Producers of an activation tensor fold the maxima of their rows into the slots with one result-free atomicMax per node
+// team (non-negative floats order like their bit patterns; max is order-independent, so the scale is deterministic), which
+// replaces a reduction launch per operand.  The slots must be zero when the first producer runs (ops.ScalePool).
+namespace spgnn_detail {
+constexpr int kScaleSlots = 256, kScaleHeader = 4;
+__device__ __forceinline__ float pow2_scale_of(float m) {
+  float s = 1.f;
+  if (m > 0.f && m < INFINITY) { int e; frexpf(m, &e); s = ldexpf(1.f, 14 - e); }
+  return s;
+}
+// call with all 64 lanes of the wave active (top of a kernel)
+__device__ __forceinline__ float load_scale(const float* __restrict__ p) {
+  if (!p) return 1.f;
+  const float h = p[0];
+  if (h > 0.f) return h;
+  const int lane = threadIdx.x & 63;
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < kScaleSlots / 64; ++i) m = fmaxf(m, p[kScaleHeader + lane + 64 * i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  return pow2_scale_of(m);
+}
+// one lane per team / block: fold m >= 0 into slot idx of a scale block
+__device__ __forceinline__ void slots_max(float* block, float m, unsigned idx) {
+  unsigned* w = reinterpret_cast<unsigned*>(block + kScaleHeader) + (idx & (kScaleSlots - 1));
+  // unconditional and result-free: a fire-and-forget atomic costs the wave ~5 us less than first reading the slot to skip it
+  // (the read is a dependent memory round trip at the very end of the wave's life; measured on the three lspe kernels)
+  atomicMax(w, __float_as_uint(m));
+}
+}  // namespace spgnn_detail

@@ -128,7 +128,7 @@ template <typename ST> struct GatFwdT {
   // optional feature dropout of the CONSUMER applied to the stored per-head output (spgnn_gat_fwd: out_drop_*): the
   // rows land in the next layer's input buffer already dropped, mask = spgnn_cat_dropout's for (fseed, ftotal, foff)
   float fp; float finv; uint64_t fseed; int ftotal; int foff;
-  float* absmax;                         // optional: absmax[v] = max |stored out[v, :]| (the consumer GEMM's operand scale)
+  float* absmax;                         // optional scale block (spgnn_internal.h): max |stored out| is folded into its slots
 };
 using GatFwd = GatFwdT<float>;
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_vec(GatFwdT<ST> a) {
     }
     if (a.absmax) {
       amx = team_max(amx, T);
-      if (lane == 0) a.absmax[v] = amx;
+      if (lane == 0) spgnn_detail::slots_max(a.absmax, amx, (unsigned)v);
     }
   }
   if (MEAN) {   // heads live in chunks r, r+CH, r+2CH, ... of the same lane (CH >= 1): mean is lane-local
@@ -407,7 +407,7 @@ template <typename ST> struct GatBwdDstT {
   ST* g_pre; int64_t g_pre_ld;
   float* g_e;
   float* g_er; int64_t gs_ld;
-  float* absmax;                         // optional: absmax[v] = max |g_pre[v,:]| (feeds the split-GEMM scale)
+  float* absmax;                         // optional scale block: max |g_pre| is folded into its slots
   int64_t N; int H; int D; int T; int W; int mean;
   float slope; int act; float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_vec(GatBwdDstT<ST> a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) mx = absmax4(mx, g[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.absmax[v] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, mx, (unsigned)v);
   }
   int hs[NS]; bool wr[NS];
 #pragma unroll
@@ -669,7 +669,7 @@ __global__ void gat_bwd_dst_scalar(GatBwdDst a) {
     a.g_pre[v * a.g_pre_ld + base + d] = q;
     amx = fmaxf(amx, fabsf(q));
   }
-  if (a.absmax) atomicMax(reinterpret_cast<unsigned*>(a.absmax + v), __float_as_uint(amx));   // H threads per node
+  if (a.absmax) spgnn_detail::slots_max(a.absmax, amx, (unsigned)v);
   float S = 0.f;
   for (int j = beg; j < end; ++j) {
     const int64_t u = a.indices[j];
@@ -704,7 +704,7 @@ template <typename ST> struct GatBwdSrcT {
   const ST* g_pre; int64_t g_pre_ld;
   ST* g_ft; int64_t g_ft_ld;
   float* g_el; int64_t gs_ld;
-  float* absmax;                         // optional: absmax[u] = max |g_ft[u,:]|
+  float* absmax;                         // optional scale block: max |g_ft| is folded into its slots
   int64_t N; int H; int D; int T;
   float p; float inv_keep; uint64_t seed;
   const uint64_t* seed_off;
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_vec(GatBwdSrcT<ST> a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) mx = absmax4(mx, acc[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.absmax[u] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, mx, (unsigned)u);
   }
 }
 
@@ -895,7 +895,7 @@ __global__ void gat_bwd_src_scalar(GatBwdSrc a) {
   if (a.sc_l) acc = fmaf(gel, a.sc_l[col], fmaf(a.g_er[u * a.gs_ld + h], a.sc_r[col], acc));
   a.g_ft[u * a.g_ft_ld + col] = acc;
   if (col % a.D == 0) a.g_el[u * a.gs_ld + h] = gel;
-  if (a.absmax) atomicMax(reinterpret_cast<unsigned*>(a.absmax + u), __float_as_uint(fabsf(acc)));   // caller zeroes it
+  if (a.absmax) spgnn_detail::slots_max(a.absmax, fabsf(acc), (unsigned)u);
 }
 
 // =================================================================================================
@@ -916,7 +916,7 @@ template <typename ST> struct GatAggFwdT {
   const float* el; const float* er; int64_t s_ld;
   float* attn;
   ST* z; int64_t z_ld; int zs; int xoff;
-  float* absmax;                         // optional: absmax[v] = max |z row v| (split-GEMM scale of the operand)
+  float* absmax;                         // optional scale block: max |z| is folded into its slots
   int64_t N; int F;
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
 };
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwdT<ST> a) {
     }
   if (a.absmax) {
     mxv = team_max(mxv, T);
-    if (lane == 0) a.absmax[v] = mxv;
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, mxv, (unsigned)v);
   }
 }
 
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
   }
   if (absmax) {
     mx = team_max(mx, 64);
-    if (lane == 0) absmax[v] = mx;
+    if (lane == 0) spgnn_detail::slots_max(absmax, mx, (unsigned)v);
   }
 }
 
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
   mx = team_max(mx, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) absmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) spgnn_detail::slots_max(absmax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), blockIdx.x);
 }
 
 // =================================================================================================
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(kBlock) void cat_dropout_kernel(const ST* __restric
       float m = red[0];
 #pragma unroll
       for (int q = 1; q < kBlock / 64; ++q) m = fmaxf(m, red[q]);
-      absmax[blockIdx.x] = m;
+      spgnn_detail::slots_max(absmax, m, blockIdx.x);
     }
   }
 }
@@ -1917,7 +1917,7 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
     for (int t = 0; t < RG; ++t) {
       float m = amx[t];
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-      if (lane == 0 && row0 + 16 * t < N) absmax[wave * RG + t] = m;
+      if (lane == 0 && row0 + 16 * t < N) spgnn_detail::slots_max(absmax, m, (unsigned)(wave * RG + t));
     }
   }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -2558,7 +2558,6 @@ static int gat_bwd_dst_impl(const int32_t* indptr, const int32_t* indices, const
   } else if (out_drop_p > 0.f) {
     return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst: out_drop_p needs a vector geometry (H*D = 4*T*R, aligned rows)");
   } else if constexpr (is_f32<ST>::value) {
-    if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);       // scalar path maxes with atomics
     hipLaunchKernelGGL(gat_bwd_dst_scalar, dim3(scalar_grid(N * H)), dim3(kBlock), 0, st, a);
   } else {
     return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_dst_bf16: needs a vector geometry (H*D = 4*T*R) and 8-byte aligned rows");
@@ -2627,7 +2626,6 @@ static int gat_bwd_src_impl(const int32_t* out_indptr, const int32_t* out_indice
     SPGNN_FOR_R_CH(R, CH, X)
 #undef X
   } else if constexpr (is_f32<ST>::value) {
-    if (absmax) (void)hipMemsetAsync(absmax, 0, sizeof(float) * N, st);
     hipLaunchKernelGGL(gat_bwd_src_scalar, dim3(scalar_grid(N * HD)), dim3(kBlock), 0, st, a);
   } else {
     return fail(SPGNN_ERR_SHAPE, "spgnn_gat_bwd_src_bf16: needs a vector geometry (H*D = 4*T*R) and 8-byte aligned rows");

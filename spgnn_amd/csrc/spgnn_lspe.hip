@@ -195,8 +195,8 @@ __global__ __launch_bounds__(kBlock) void lspe_fwd_kernel(LspeFwd a) {
       amx2 = absmax4(amx2, d);
     }
   }
-  if (a.absmax) { amx = team_max(amx, T); if (lane == 0) a.absmax[v] = amx; }
-  if (a.absmax2) { amx2 = team_max(amx2, T); if (lane == 0) a.absmax2[v] = amx2; }
+  if (a.absmax) { amx = team_max(amx, T); if (lane == 0) spgnn_detail::slots_max(a.absmax, amx, (unsigned)v); }
+  if (a.absmax2) { amx2 = team_max(amx2, T); if (lane == 0) spgnn_detail::slots_max(a.absmax2, amx2, (unsigned)v); }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -285,14 +285,14 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_dst_kernel(LspeBwdDst a) {
 #pragma unroll
     for (int r = 0; r < kHeads0; ++r) mx = absmax4(mx, g[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.g[0].absmax[v] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.g[0].absmax, mx, (unsigned)v);
   }
   if (a.g[1].absmax) {
     float mx = 0.f;
 #pragma unroll
     for (int r = kHeads0; r < kNS; ++r) mx = absmax4(mx, g[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.g[1].absmax[v] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.g[1].absmax, mx, (unsigned)v);
   }
 
   int u[kMaxFast];
@@ -483,14 +483,14 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
 #pragma unroll
     for (int r = 0; r < kHeads0; ++r) mx = absmax4(mx, acc[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.g[0].absmax[u] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.g[0].absmax, mx, (unsigned)u);
   }
   if (a.g[1].absmax) {
     float mx = 0.f;
 #pragma unroll
     for (int r = kHeads0; r < kNS; ++r) mx = absmax4(mx, acc[r]);
     mx = team_max(mx, T);
-    if (lane == 0) a.g[1].absmax[u] = mx;
+    if (lane == 0) spgnn_detail::slots_max(a.g[1].absmax, mx, (unsigned)u);
   }
 }
 

@@ -225,7 +225,7 @@ class GATConv(nn.Module):
                 buf, attn, amax = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l, self.attn_r, self.bias, H, D, has_res,
                                                                float(self.negative_slope), act, p, seed, fuse=fuse_out)
                 if extra == 0:                         # nothing to add: the buffer is complete, its GEMM scale known
-                    buf._spgnn_scale = (buf._version, ops.scale_from_partials(amax))
+                    buf._spgnn_scale = (buf._version, amax)          # the layer's scale block
                 return buf, amax
             out, attn = ops.gat_layer_scores_from_ft(csc, h, w_cat, self.attn_l, self.attn_r,
                                                      self.bias if fuse_epilogue else None, H, D, has_res,

@@ -150,8 +150,8 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
     (fused into the epilogue when the geometry allows); ``need_out=False`` lets the per-head output be
     skipped when only the mean is consumed and nothing in the backward needs it.
     ``out_drop`` = (p, seed, total, offset): store the consumer's feature dropout of the output (``out`` = the column
-    block [offset, offset + H*D) of the consumer's (N, total) input buffer); ``out_absmax`` (N,): per-node maxima of the
-    stored rows."""
+    block [offset, offset + H*D) of the consumer's (N, total) input buffer); ``out_absmax``: a scale block
+    (new_scale_block) that takes the maxima of the stored rows."""
     _require_cuda(ft, el, er, res, bias)
     N, E = csc.num_nodes, csc.num_edges
     assert ft.shape[0] == N and ft.shape[1] == H * D and ft.stride(1) == 1
@@ -180,10 +180,11 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
 def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, slope: float, act: int,
                 p_drop: float, seed: int, g_pre: torch.Tensor, g_ft: torch.Tensor, g_el: torch.Tensor,
                 g_er: torch.Tensor, mean: bool = False, absmax: Optional[torch.Tensor] = None,
-                score_l: Optional[torch.Tensor] = None, score_r: Optional[torch.Tensor] = None, out_drop=None) -> torch.Tensor:
+                score_l: Optional[torch.Tensor] = None, score_r: Optional[torch.Tensor] = None, out_drop=None,
+                absmax_dst: bool = True) -> torch.Tensor:
     """Runs both backward halves. g_pre/g_ft (N,H*D), g_el/g_er (N,H) are written in place
-    (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.  ``absmax`` (2N floats):
-    per-node maxima of |g_pre| then |g_ft| (for the split-GEMM scale of [g_ft | g_pre]).
+    (may be strided views). ``mean``: g_out is the (N,D) gradient of the head mean.  ``absmax``: scale block taking the
+    maxima of |g_pre| and |g_ft| (the split-GEMM scale of [g_ft | g_pre]); ``absmax_src=False``: of |g_pre| only.
     Returns g_e (E,H) in CSC slot order."""
     _require_cuda(ft, g_out)
     N, E = csc.num_nodes, csc.num_edges
@@ -198,7 +199,7 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
                                           el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
                                           g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                           out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
-                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax), N, E, H, D, slope,
+                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax) if absmax_dst else 0, N, E, H, D, slope,
                                           act, p_drop, seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), st),
                     "spgnn_gat_bwd_dst")
         t_dst.__exit__()
@@ -206,7 +207,7 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
         _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
                                           csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                           g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
-                                          g_el.stride(0), _ptr(absmax[N:]) if absmax is not None else 0, _ptr(score_l),
+                                          g_el.stride(0), _ptr(absmax), _ptr(score_l),
                                           _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, E, H, D,
                                           p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src")
         t_src.__exit__()
@@ -263,6 +264,74 @@ def sum_partials(part: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(part.device):
         _capi.check(_capi.load().spgnn_sum_partials(part.data_ptr(), n, S, n, out.data_ptr(), _stream(part)), "spgnn_sum_partials")
     return out
+
+
+SCALE_SLOTS, SCALE_HEADER = 256, 4          # spgnn_internal.h: {-256, 0, 0, 0, m_1 ... m_256}
+_SCALE_TEMPLATE: dict = {}
+
+
+def _scale_template(device, rows: int) -> torch.Tensor:
+    key = (str(device), rows)
+    t = _SCALE_TEMPLATE.get(key)
+    if t is None:
+        t = torch.zeros((rows, SCALE_HEADER + SCALE_SLOTS), dtype=torch.float32, device=device)
+        t[:, 0] = -float(SCALE_SLOTS)
+        _SCALE_TEMPLATE[key] = t
+    return t
+
+
+class ScalePool:
+    """The scale blocks of one training step (include/spgnn_hip.h, spgnn_gemm_nt): ``begin()`` re-initialises every block
+    with ONE copy launch and hands them out in request order, so a step that is captured into a HIP graph always finds the
+    same addresses; requests beyond the capacity, or outside ``begin() ... end()``, get a block of their own (one clone)."""
+
+    def __init__(self, device, capacity: int = 128):
+        self.device = torch.device(device)
+        self.capacity = capacity
+        self.buf = _scale_template(self.device, capacity).clone()
+        self.cursor, self.active = 0, False
+
+    def begin(self):
+        self.buf.copy_(_scale_template(self.device, self.capacity))
+        self.cursor, self.active = 0, True
+
+    def end(self):
+        self.active = False
+
+    def take(self) -> Optional[torch.Tensor]:
+        if not self.active or self.cursor >= self.capacity:
+            return None
+        b = self.buf[self.cursor]
+        self.cursor += 1
+        return b
+
+
+_SCALE_POOLS: dict = {}
+
+
+def scale_pool(device) -> ScalePool:
+    key = str(torch.device(device))
+    p = _SCALE_POOLS.get(key)
+    if p is None:
+        p = _SCALE_POOLS[key] = ScalePool(device)
+    return p
+
+
+def new_scale_block(device) -> torch.Tensor:
+    """A zeroed scale block for the producers of one GEMM operand to fold their maxima into; the tensor itself is then
+    passed wherever a scale is taken (gemm_nt / gemm_tn ``scale_*``, ``_spgnn_scale``)."""
+    p = _SCALE_POOLS.get(str(torch.device(device)))
+    b = p.take() if p is not None else None
+    return b if b is not None else _scale_template(device, 1)[0].clone()
+
+
+def scale_value(scale: torch.Tensor) -> float:
+    """Host value of a scale operand (tests, diagnostics): the scalar itself or 2^(14 - e) of a block's largest slot."""
+    import math
+    if scale.numel() == 1:
+        return float(scale)
+    m = float(scale[SCALE_HEADER:].max())
+    return 1.0 if not (m > 0.0 and math.isfinite(m)) else math.ldexp(1.0, 14 - math.frexp(m)[1])
 
 
 def scale_from_partials(partials: torch.Tensor, factor: float = 1.0) -> torch.Tensor:
@@ -340,11 +409,11 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     Kp = _pad16(K)
     w_p = _padded_rows(w_lr, Kp)
     s = torch.empty((N, J), dtype=torch.float32, device=x.device)
-    part = torch.empty(((N + 15) // 16,), dtype=torch.float32, device=x.device) if want_scale else None
+    part = new_scale_block(x.device) if want_scale else None
     with torch.cuda.device(x.device), _timed("scores_fwd", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_fwd(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
                                                   _ptr(part), N, K, J, _stream(x)), "spgnn_scores_fwd")
-    return (s, scale_from_partials(part)) if want_scale else s
+    return (s, part) if want_scale else s
 
 
 _SCORES_SPLIT_WAVES = 2048   # row ranges x column groups of scores_bwd_w: 2048 measured best (7.38 vs 7.46 ms/step at 4096: half the partials; 1024: 7.43, 512: 7.65)
@@ -528,8 +597,7 @@ class _LinearFn(torch.autograd.Function):
         C = w.shape[0]
         g = _rowmajor(g)
         if ctx.act != ACT_NONE and C % 4 == 0:
-            g, amax = act_bwd(g, y, 1, C, ctx.act, False)
-            sg = scale_from_partials(amax)
+            g, sg = act_bwd(g, y, 1, C, ctx.act, False)
         else:
             if ctx.act != ACT_NONE:
                 g = g * {ACT_ELU: torch.where(y > 0, torch.ones_like(y), y + 1), ACT_TANH: 1 - y * y,
@@ -668,19 +736,16 @@ class _CatDropout(torch.autograd.Function):
         if Fp > F_:
             buf[:, F_:].zero_()
         lib = _capi.load()
-        nblk = [int(lib.spgnn_cat_dropout_blocks(N, w)) for w in widths]
-        part = torch.empty((sum(nblk),), dtype=torch.float32, device=buf.device)     # per-block maxima of |output|
-        off = boff = 0
+        scale = new_scale_block(buf.device)                # every source folds the maxima of what it writes into it
+        off = 0
         with torch.cuda.device(buf.device):
-            for t, nb in zip(tensors, nblk):
+            for t in tensors:
                 t = t if t.stride(1) == 1 else t.contiguous()
                 _capi.check(lib.spgnn_cat_dropout(t.data_ptr(), t.stride(0), buf.data_ptr(), buf.stride(0), N, t.shape[1], off, F_,
-                                                  p, seed, _seed_off_ptr(buf.device), 0, part[boff:].data_ptr(), _stream(buf)),
+                                                  p, seed, _seed_off_ptr(buf.device), 0, scale.data_ptr(), _stream(buf)),
                             "spgnn_cat_dropout")
                 off += t.shape[1]
-                boff += nb
         ctx.widths, ctx.p, ctx.seed = widths, p, seed
-        scale = scale_from_partials(part) if N > 0 else torch.ones(1, dtype=torch.float32, device=buf.device)
         ctx.mark_non_differentiable(scale)
         return buf[:, :F_], scale
 
@@ -939,11 +1004,10 @@ class _GATLayerFn(torch.autograd.Function):
         g_s = torch.empty_like(s)
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
         split = sx is not None
-        amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device) if split else None
-        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
-                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax)
+        sg = new_scale_block(x.device) if split else None
         # [g_ft | g_pre] fills g_y when the layer has a residual; without one only g_ft does
-        sg = scale_from_partials(amax if has_res else amax[N:]) if split else None
+        gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=sg, absmax_dst=has_res)
         need_bias = ctx.has_bias and ctx.needs_input_grad[3]
         g_bias = None
         g_wcat = None
@@ -1004,7 +1068,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         dropout (p, seed), into columns [0, H*D) of a fresh (N, total) buffer - the next layer's input, whose remaining
         columns ``fill_cols_dropout`` adds in place - and that buffer is returned instead of the (N, H*D) rows, together
         with a third output: per-node maxima of the stored rows followed by ``extra`` free slots for the filler's maxima
-        (the buffer's split-GEMM scale needs no extra pass)."""
+        (the buffer's split-GEMM scale needs no extra pass).  The third output is the buffer's scale block."""
         ctx.set_materialize_grads(False)       # no zero tensor for the unused gradient of `attn`
         HD = H * D
         x = _rowmajor(x)
@@ -1027,7 +1091,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             assert not mean and total >= HD
             assert total % 4 == 0                  # (the buffer itself is returned, never a view of it: it is completed in place)
             buf = torch.empty((N, total), dtype=torch.float32, device=x.device)
-            amax = torch.empty((N + extra,), dtype=torch.float32, device=x.device)
+            amax = new_scale_block(x.device)
             od = (float(fp), int(fseed), int(total), 0)
             out, _, attn = gat_fwd_raw(csc, ft, s[:, :H], s[:, H:], res, bias, H, D, slope, act, p_drop, seed, out=buf[:, :HD],
                                        out_drop=od, out_absmax=amax)
@@ -1065,10 +1129,10 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         g_y = torch.empty_like(y)
         g_s = torch.empty_like(s)
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
-        amax = torch.empty((2 * N,), dtype=torch.float32, device=x.device)
+        sg = new_scale_block(x.device)
         gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
-                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=amax, score_l=al, score_r=ar, out_drop=out_drop)
-        sg = scale_from_partials(amax if has_res else amax[N:])
+                    g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=sg, score_l=al, score_r=ar, out_drop=out_drop,
+                    absmax_dst=has_res)
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_bias = g_wcat = None
         if ctx.needs_input_grad[1]:
@@ -1160,25 +1224,20 @@ class _FillColsDropout(torch.autograd.Function):
 def fill_cols_dropout(buf: torch.Tensor, src: torch.Tensor, off: int, total: int, p: float, seed: int,
                       amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Complete a fused GATConv's output buffer (see _GATLayerScoresFromFtFn.forward): columns [off, off + w) = dropout(src).
-    ``amax``: the maxima tensor the layer returned; its tail takes this block's maxima and the buffer's split-GEMM scale
-    is attached to the result."""
+    ``amax``: the scale block the layer returned; it takes this block's maxima too and is attached to the result as the
+    buffer's split-GEMM scale."""
     _require_cuda(buf, src)
     N, w = src.shape
     lib = _capi.load()
-    part = None
-    if amax is not None:
-        nb = int(lib.spgnn_cat_dropout_blocks(N, w))
-        assert amax.numel() >= N + nb
-        part = amax[N:N + nb]
-    y = _FillColsDropout.apply(buf, src, int(off), int(total), float(p), int(seed), part)
+    y = _FillColsDropout.apply(buf, src, int(off), int(total), float(p), int(seed), amax)
     if amax is not None and N > 0:
-        y._spgnn_scale = (y._version, scale_from_partials(amax[:N + nb]))
+        y._spgnn_scale = (y._version, amax)            # the layer's scale block, now holding this block's maxima too
     return y
 
 
 def fused_extra_partials(N: int, width: int) -> int:
-    """Slots the maxima tensor of a fused layer must reserve for a later fill_cols_dropout of ``width`` columns."""
-    return int(_capi.load().spgnn_cat_dropout_blocks(N, width)) if width > 0 else 0
+    """(kept for callers of the round-2 interface: the fused layer's maxima now live in one scale block, nothing to reserve)"""
+    return 0
 
 
 def gat_layer(csc: DeviceCSC, x, w_cat, w_lr, bias, H: int, D: int, has_res: bool, slope: float, act: int,
@@ -1226,8 +1285,7 @@ class _LspeLevelFn(torch.autograd.Function):
             ys.append(y); ss.append(scores_from_parts(pt, H, D)); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
         buf = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
         xp = torch.empty((N, D), dtype=torch.float32, device=dev)
-        Np = (N + 3) // 4 * 4                    # both halves 16-byte aligned (the multi-block scale reduction needs it)
-        amax = torch.empty((2 * Np,), dtype=torch.float32, device=dev)
+        sc_buf, sc_xp = new_scale_block(dev), new_scale_block(dev)
         attn = [torch.empty((E, 2), dtype=torch.float32, device=dev), torch.empty((E, 1), dtype=torch.float32, device=dev)]
         nbr8 = csc.ell()[0]
         G = (_capi.LspeFwdGroup * 2)()
@@ -1242,13 +1300,13 @@ class _LspeLevelFn(torch.autograd.Function):
             g.H, g.act, g.slope, g.p_drop, g.seed = H, cfg["act"][i], cfg["slope"][i], cfg["p_attn"][i], cfg["seed_attn"][i]
         with torch.cuda.device(dev), _timed("lspe_fwd", (N, E, D)):
             _capi.check(lib.spgnn_lspe_fwd(csc.indptr.data_ptr(), nbr8.data_ptr(), G, buf.data_ptr(), buf.stride(0), cfg["fp"], cfg["fseed"],
-                                           xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], amax.data_ptr(), amax[Np:].data_ptr(),
+                                           xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], sc_buf.data_ptr(), sc_xp.data_ptr(),
                                            N, E, D, _seed_off_ptr(dev), _stream(x_s)), "spgnn_lspe_fwd")
         ctx.csc, ctx.D, ctx.cfg, ctx.wts, ctx.has_bias = csc, D, cfg, wts, (bias_s is not None, bias_p is not None)
         ctx.save_for_backward(x_s, x_p, w_s, w_p, vecs[0][0], vecs[0][1], vecs[1][0], vecs[1][1], ys[0], ys[1], ss[0], ss[1], attn[0], attn[1],
                               scales[0][0], scales[0][1], scales[1][0], scales[1][1], buf, xp)
-        ctx.mark_non_differentiable(attn[0], attn[1], amax)
-        return buf, xp, attn[0], attn[1], amax
+        ctx.mark_non_differentiable(attn[0], attn[1], sc_buf, sc_xp)
+        return buf, xp, attn[0], attn[1], sc_buf, sc_xp
 
     @staticmethod
     def backward(ctx, g_buf, g_xp, *_unused):
@@ -1274,7 +1332,7 @@ class _LspeLevelFn(torch.autograd.Function):
         g_y = [torch.empty_like(y) for y in ys]
         g_s = [torch.empty_like(s_) for s_ in ss]
         g_e = [torch.empty((E, H), dtype=torch.float32, device=dev) for H in Hs]
-        amax = [torch.empty((2 * N,), dtype=torch.float32, device=dev) for _ in Hs]
+        amax = [new_scale_block(dev) for _ in Hs]           # one block per layer: [g_ft | g_pre] is one operand
         g_pre = [g_y[i][:, Hs[i] * D:] if res[i] else torch.empty((N, Hs[i] * D), dtype=torch.float32, device=dev) for i in range(2)]
         nbr8, out_nbr8, out_pos8 = csc.ell()
         GD = (_capi.LspeBwdDstGroup * 2)()
@@ -1289,7 +1347,7 @@ class _LspeLevelFn(torch.autograd.Function):
             q.attn, q.g_e, q.g_pre, q.g_pre_stride = attns[i].data_ptr(), g_e[i].data_ptr(), g_pre[i].data_ptr(), g_pre[i].stride(0)
             q.g_ft, q.g_ft_stride = g_y[i].data_ptr(), g_y[i].stride(0)
             q.g_el, q.g_er, q.gs_stride = g_s[i].data_ptr(), g_s[i][:, H:].data_ptr(), g_s[i].stride(0)
-            q.score_l, q.score_r, q.absmax = vecs[i][0].data_ptr(), vecs[i][1].data_ptr(), amax[i][N:].data_ptr()
+            q.score_l, q.score_r, q.absmax = vecs[i][0].data_ptr(), vecs[i][1].data_ptr(), amax[i].data_ptr()
             q.H, q.p_drop, q.seed = H, cfg["p_attn"][i], cfg["seed_attn"][i]
         with torch.cuda.device(dev):
             st = _stream(x_s)
@@ -1306,7 +1364,7 @@ class _LspeLevelFn(torch.autograd.Function):
             HD = H * D
             x, K = xs[i], xs[i].shape[1]
             sx, sw = scl[i]
-            sg = scale_from_partials(amax[i] if res[i] else amax[i][N:])
+            sg = amax[i]
             need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
             if ctx.needs_input_grad[2 + i]:
                 if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
@@ -1339,10 +1397,10 @@ def lspe_level(csc: DeviceCSC, x_s: torch.Tensor, x_p: torch.Tensor, w_s, w_p, a
     split-GEMM operand scale.  ``w_s`` / ``w_p``: weight_cat operands [W_fc; W_res]; ``attn_s`` / ``attn_p``: (attn_l, attn_r)."""
     _require_cuda(x_s, x_p, w_s, w_p)
     N = x_s.shape[0]
-    buf, xp, _a0, _a1, amax = _LspeLevelFn.apply(x_s, x_p, w_s, w_p, attn_s[0], attn_s[1], attn_p[0], attn_p[1], bias_s, bias_p, csc, int(D), cfg)
-    Np = amax.numel() // 2
-    buf._spgnn_scale = (buf._version, scale_from_partials(amax[:N]))
-    xp._spgnn_scale = (xp._version, scale_from_partials(amax[Np:Np + N]))
+    buf, xp, _a0, _a1, sc_buf, sc_xp = _LspeLevelFn.apply(x_s, x_p, w_s, w_p, attn_s[0], attn_s[1], attn_p[0], attn_p[1], bias_s, bias_p, csc,
+                                                          int(D), cfg)
+    buf._spgnn_scale = (buf._version, sc_buf)
+    xp._spgnn_scale = (xp._version, sc_xp)
     return buf, xp
 
 
@@ -1355,14 +1413,14 @@ def agg_first_supported(H: int, F_in: int) -> bool:
 
 def gat_agg_fwd_raw(csc: DeviceCSC, x, el, er, H: int, slope: float, p_drop: float, seed: int, with_x_copy: bool,
                     out: Optional[torch.Tensor] = None):
-    """-> (z (N, H*zs), attn (E,H), absmax (N,)); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F).  ``out``: a
+    """-> (z (N, H*zs), attn (E,H), scale block of z); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F).  ``out``: a
     buffer at least (N, H*zs) wide to write the blocks into (its row stride is used)."""
     N, E = csc.num_nodes, csc.num_edges
     F_ = x.shape[1]
     zs = 2 * F_ if with_x_copy else F_
     z = out if out is not None else torch.empty((N, H * zs), dtype=torch.float32, device=x.device)
     attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
-    amax = torch.empty((N,), dtype=torch.float32, device=x.device)
+    amax = new_scale_block(x.device)
     with torch.cuda.device(x.device), _timed("gat_agg_fwd", (N, E, H, F_, int(with_x_copy))):
         _capi.check(_capi.load().spgnn_gat_agg_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
                                                    el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(), z.data_ptr(),
@@ -1382,10 +1440,10 @@ def head_mean(out: torch.Tensor, H: int, D: int) -> torch.Tensor:
 
 
 def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int, mean: bool):
-    """-> (g_pre (N, H*D), absmax (N,))."""
+    """-> (g_pre (N, H*D), its scale block)."""
     N = g_out.shape[0]
     g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_out.device)
-    amax = torch.empty((N,), dtype=torch.float32, device=g_out.device)
+    amax = new_scale_block(g_out.device)
     with torch.cuda.device(g_out.device), _timed("act_bwd", (N, H, D, act, int(mean))):
         _capi.check(_capi.load().spgnn_act_bwd(g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                                out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
@@ -1395,11 +1453,11 @@ def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, ac
 
 def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int):
     """act_bwd of a mean-over-heads layer whose mean feeds a skinny Linear (weight ``w`` (J, D)), with that Linear's
-    input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), block maxima of |g_pre|)."""
+    input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), its scale block)."""
     N, J = g_s.shape
     lib = _capi.load()
     g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_s.device)
-    part = torch.empty((lib.spgnn_act_bwd_proj_blocks(N),), dtype=torch.float32, device=g_s.device)
+    part = new_scale_block(g_s.device)
     with torch.cuda.device(g_s.device), _timed("act_bwd_proj", (N, H, D, act, J)):
         _capi.check(lib.spgnn_act_bwd_proj(g_s.data_ptr(), g_s.stride(0), J, w.data_ptr(), w.stride(0), _ptr(out),
                                            out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
@@ -1427,9 +1485,8 @@ class _GATAggFirstFn(torch.autograd.Function):
         N, F_ = x.shape
         has_res = w_res is not None
         s = scores_fwd(x, w_lr)
-        z, attn, amax = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, has_res)
+        z, attn, sz = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, has_res)
         zs = z.shape[1] // H
-        sz = scale_from_partials(amax)
         w3 = w_fc.view(H, D, F_)
         wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
         sw = pow2_scale(wc.view(H * D, zs))
@@ -1491,7 +1548,7 @@ class _GATAggFirstFn(torch.autograd.Function):
                 g_pre, amax = act_bwd(g_mean, out, H, D, act, mean)
         else:
             g_pre, amax = act_bwd(_rowmajor(g_out), out, H, D, act, mean)
-        sg = scale_from_partials(amax)
+        sg = amax
         need_w = ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2])
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_z = torch.empty_like(z)

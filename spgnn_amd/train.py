@@ -161,6 +161,9 @@ class TrainStep:
         b.detach_grads()
         y = g.ndata["y"]
         p = self._sampling(g)
+        pool = ops.scale_pool(b.flat_param.device) if b.flat_param.is_cuda else None
+        if pool is not None:
+            pool.begin()                     # ONE launch re-arms every GEMM operand's scale block of this step
         if draws is None:
             if getattr(self, "_use_default_rng", False):       # graph capture: torch's default generator is graph-safe
                 draws = torch.rand(p.shape, device=p.device)
@@ -183,6 +186,8 @@ class TrainStep:
             num.backward()
         finally:
             ops.DROPOUT_SEED_OFFSET = prev_off
+            if pool is not None:
+                pool.end()
         b.gather_grads()
         b.wsum_slot.copy_(den.detach().reshape(1))
         b.loss_slot.copy_(num.detach().reshape(1))

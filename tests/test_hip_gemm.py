@@ -282,3 +282,34 @@ def test_weight_prep_batched_equals_per_layer():
                 assert float(base[:, w.shape[1]:].abs().sum()) == 0.0          # pad columns are zero
         assert not ops._PREP_ACTIVE
     assert len(ops._PREP_CACHE) >= 1
+
+
+def test_gemm_takes_scale_blocks():
+    """A GEMM operand's scale as a SCALE BLOCK (include/spgnn_hip.h): {-256, 0, 0, 0, m_1 .. m_256} whose largest slot the
+    kernel turns into the power-of-two scale itself - bit-identical to passing the scalar scale, for every tile variant of
+    the NT product and for the TN product; and ops.ScalePool hands out re-armed blocks in a fixed order."""
+    torch.manual_seed(3)
+    a, b = _mat(1000, 200), _mat(512, 200, 0.05)
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    blk = ops.new_scale_block("cuda")
+    assert blk.numel() == 260 and float(blk[0]) == -256.0 and float(blk[1:].abs().sum()) == 0.0
+    rows = a.abs().amax(1)
+    blk[ops.SCALE_HEADER + 7] = rows.max(); blk[ops.SCALE_HEADER + 200] = rows.min()      # any slots, any order
+    assert ops.scale_value(blk) == float(sa)
+    ref = ops.gemm_nt(a, b, sa, sb)
+    for tile in (0, 2, 4, 5):
+        assert torch.equal(ops.gemm_nt(a, b, blk, sb, tile=tile), ref), tile
+    g = _mat(1000, 128, 1e-3)
+    sg = ops.pow2_scale(g)
+    gb = ops.new_scale_block("cuda"); gb[ops.SCALE_HEADER] = g.abs().max()
+    assert torch.equal(ops.gemm_tn(g, a, gb, blk), ops.gemm_tn(g, a, sg, sa))
+    pool = ops.scale_pool("cuda")
+    pool.begin()
+    b0, b1 = ops.new_scale_block("cuda"), ops.new_scale_block("cuda")
+    b0[ops.SCALE_HEADER + 1] = 5.0
+    pool.end()
+    assert ops.new_scale_block("cuda").data_ptr() not in (b0.data_ptr(), b1.data_ptr())     # outside a step: a block of its own
+    pool.begin()
+    c0 = ops.new_scale_block("cuda")
+    pool.end()
+    assert c0.data_ptr() == b0.data_ptr() and float(c0[ops.SCALE_HEADER:].abs().sum()) == 0.0 and float(c0[0]) == -256.0

@@ -305,7 +305,11 @@ def test_epilogue_and_derivative_kernels_of_the_aggregate_first_form(act):
         d = {ops.ACT_NONE: torch.ones_like(out), ops.ACT_ELU: torch.where(out > 0, torch.ones_like(out), out + 1),
              ops.ACT_TANH: 1 - out * out, ops.ACT_RELU: (out > 0).float()}[act]
         want = (g / H).repeat(1, H) * d if mean else g * d
-        assert rel_err(gp, want) < 1e-6 and rel_err(amax, want.abs().amax(1)) < 1e-6
+        assert rel_err(gp, want) < 1e-6
+        # the scale block: its largest slot is max |g_pre| exactly (a maximum of stored values), and the scale derived from it
+        assert amax.numel() == ops.SCALE_HEADER + ops.SCALE_SLOTS and float(amax[0]) == -ops.SCALE_SLOTS
+        assert float(amax[ops.SCALE_HEADER:].max()) == float(gp.abs().max())
+        assert ops.scale_value(amax) == float(ops.pow2_scale(gp.contiguous()))
 
 
 def test_cat_dropout_is_cat_then_dropout_with_a_regenerated_mask():
@@ -430,7 +434,7 @@ def test_score_projection_kernels(K, J):
     s = ops.scores_fwd(x, w)
     assert rel_err(s, x.double() @ w.double().t()) < 2e-6
     s2, scale = ops.scores_fwd(x, w, want_scale=True)      # the absmax the kernel collects on the way (K >= 512: four waves per row group)
-    assert torch.equal(s2, s) and torch.equal(scale, ops.pow2_scale(x))
+    assert torch.equal(s2, s) and ops.scale_value(scale) == float(ops.pow2_scale(x))
     gs = torch.randn(N, J, device="cuda")
     assert rel_err(ops.scores_bwd_w(gs, x), gs.double().t() @ x.double()) < 2e-6
     gbuf = torch.randn(N, (K + 3) // 4 * 4, device="cuda")
@@ -453,7 +457,8 @@ def test_score_projection_forward_two_row_groups_per_wave(K, J):
     x = torch.randn(N, (K + 3) // 4 * 4 + 4, device="cuda")[:, :K]
     w = torch.randn(J, K, device="cuda")
     s, scale = ops.scores_fwd(x, w, want_scale=True)
-    assert rel_err(s, x.double() @ w.double().t()) < 2e-6 and torch.equal(scale, ops.pow2_scale(x))
+    assert rel_err(s, x.double() @ w.double().t()) < 2e-6 and ops.scale_value(scale) == float(ops.pow2_scale(x))
+    assert float(scale[ops.SCALE_HEADER:].max()) == float(x.abs().max())
     from spgnn_amd import ops_bf16
     xb = ops_bf16.cast_rows(x.contiguous())
     assert rel_err(ops_bf16.scores_fwd(xb, w), xb.double() @ w.double().t()) < 2e-6
