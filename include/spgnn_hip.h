@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 33
+#define SPGNN_ABI_VERSION 34
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -679,7 +679,10 @@ int spgnn_cast_rows_bf16(const float* x, int64_t x_stride, int64_t N, int32_t K,
  * ================================================================================================= */
 typedef struct spgnn_lspe_fwd_group {
   const float* ft; int64_t ft_stride; const float* res; int64_t res_stride; const float* bias;
-  const float* el; const float* er; int64_t s_stride; float* attn;
+  float* el; float* er; int64_t s_stride; float* attn;
+  /* nullable (both groups or neither): spgnn_gemm_nt's score partials of this layer's projection, (N, H*D/64, 2).  The kernel
+   * then forms el / er itself (the sums of spgnn_scores_from_parts, same order) and WRITES them to el / er for the backward. */
+  const float* score_parts;
   int32_t H; int32_t act; float slope; float p_drop; uint64_t seed;
 } spgnn_lspe_fwd_group;
 
@@ -775,6 +778,23 @@ typedef struct spgnn_weight_prep_layer {
 int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride);
 int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, uint32_t* maxwords,
                       spgnn_stream_t stream);
+
+/* Up to 8 of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two attention-vector
+ * gradients come out of four spgnn_gemm_tn / spgnn_scores_bwd_w calls whose partial sums were four more launches).  `jobs`
+ * is a HOST array; kind 0 = spgnn_sum_partials (n, out), 1 = spgnn_sum_partials_blockdiag (H, D, ld, out), 2 =
+ * spgnn_sum_partials_compact (M, N, ld_in, out / out_stride, out2 / out2_stride / split_col, extra / extra_col); the fields
+ * have the meaning of the same-named arguments there and results are bit-identical to the single calls. */
+typedef struct spgnn_sum_job {
+  int32_t kind; int32_t splits;
+  const float* partials; int64_t split_stride;
+  float* out; int64_t out_stride;
+  int64_t n;
+  int32_t H; int32_t D; int32_t ld; int32_t M; int32_t N; int32_t split_col;
+  int64_t ld_in;
+  float* out2; int64_t out2_stride;
+  float* extra; int32_t extra_col; int32_t reserved;
+} spgnn_sum_job;
+int spgnn_sum_partials_multi(const spgnn_sum_job* jobs, int32_t n_jobs, spgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -22,7 +22,8 @@ _i64, _i32, _f32, _u64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_v
 
 class LspeFwdGroup(C.Structure):          # spgnn_lspe_fwd_group
     _fields_ = [("ft", _vp), ("ft_stride", _i64), ("res", _vp), ("res_stride", _i64), ("bias", _vp), ("el", _vp), ("er", _vp),
-                ("s_stride", _i64), ("attn", _vp), ("H", _i32), ("act", _i32), ("slope", _f32), ("p_drop", _f32), ("seed", _u64)]
+                ("s_stride", _i64), ("attn", _vp), ("score_parts", _vp), ("H", _i32), ("act", _i32), ("slope", _f32), ("p_drop", _f32),
+                ("seed", _u64)]
 
 
 class LspeBwdDstGroup(C.Structure):       # spgnn_lspe_bwd_dst_group
@@ -37,6 +38,12 @@ class LspeBwdSrcGroup(C.Structure):       # spgnn_lspe_bwd_src_group
                 ("p_drop", _f32), ("seed", _u64)]
 
 
+class SumJob(C.Structure):               # spgnn_sum_job
+    _fields_ = [("kind", _i32), ("splits", _i32), ("partials", _vp), ("split_stride", _i64), ("out", _vp), ("out_stride", _i64),
+                ("n", _i64), ("H", _i32), ("D", _i32), ("ld", _i32), ("M", _i32), ("N", _i32), ("split_col", _i32), ("ld_in", _i64),
+                ("out2", _vp), ("out2_stride", _i64), ("extra", _vp), ("extra_col", _i32), ("reserved", _i32)]
+
+
 class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
     _fields_ = [("a", _vp), ("a_stride", _i64), ("b", _vp), ("b_stride", _i64), ("dst", _vp), ("ps", _vp), ("dst_stride", _i64),
                 ("dst_t", _vp), ("ps_t", _vp), ("dst_t_stride", _i64), ("scale", _vp), ("first_block", _i64), ("rows_a", _i32),
@@ -45,6 +52,7 @@ class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
 
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
 SIGNATURES = {
+    "spgnn_sum_partials_multi": [C.POINTER(SumJob), _i32, _vp],
     "spgnn_weight_prep_blocks": [_i32, _i64, _i64],
     "spgnn_weight_prep": [_vp, _i32, _i64, _vp, _vp],
     "spgnn_build_csc_count": [_vp, _vp, _vp, _i64, _i32p, _i32p, _vp],

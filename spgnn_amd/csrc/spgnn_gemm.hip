@@ -947,13 +947,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
 // out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
 // score-weight gradients).  One float4 per thread; SL threads share a float4 and take every SL-th split (fixed order,
 // folded through LDS), so a reduction over thousands of small partials still fills the chip.
+// (the three reductions are device functions of a block index, so that spgnn_sum_partials_multi can run several of them in
+// one launch with exactly the arithmetic of the single-job kernels)
 template <int SL>
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int64_t stride4, int S, int64_t n4,
-                                                           float* __restrict__ out) {
+__device__ __forceinline__ void sum_partials_body(const float* __restrict__ part, int64_t stride4, int S, int64_t n4,
+                                                  float* __restrict__ out, unsigned bid, float4* red) {
   constexpr int QB = 256 / SL;
-  __shared__ float4 red[256];
   const int q = threadIdx.x % QB, l = threadIdx.x / QB;
-  const int64_t i = (int64_t)blockIdx.x * QB + q;
+  const int64_t i = (int64_t)bid * QB + q;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* p = reinterpret_cast<const float4*>(part) + i;
@@ -980,18 +981,23 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     reinterpret_cast<float4*>(out)[i] = acc;
   }
 }
+template <int SL>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int64_t stride4, int S, int64_t n4,
+                                                           float* __restrict__ out) {
+  __shared__ float4 red[256];
+  sum_partials_body<SL>(part, stride4, S, n4, out, blockIdx.x, red);
+}
 
 // Block diagonal of the summed (2H, H*D) score-weight gradient, as (2, H, D): out[(w*H + h)*D + d] = sum_s part[s][w*H + h][h*D + d]
 // - the attention vectors' gradients g_attn_l (w = 0) and g_attn_r (w = 1) of a GATConv whose scores come from ft; the
 // off-diagonal blocks (other heads' columns) are never needed, so they are neither summed nor copied.
-__global__ __launch_bounds__(256) void sum_partials_blockdiag_kernel(const float* __restrict__ part, int64_t stride, int S, int H,
-                                                                     int D, int ld, float* __restrict__ out) {
+__device__ __forceinline__ void sum_partials_blockdiag_body(const float* __restrict__ part, int64_t stride, int S, int H, int D, int ld,
+                                                            float* __restrict__ out, unsigned bid, float* red) {
   // 32 lanes per output element, eight loads in flight per lane: with 16 lanes and a rolled loop (one load at a time, 32 trips
   // at 512 splits) this launch took 19 us, six times per step
   constexpr int SL = 32, QB = 256 / SL;
-  __shared__ float red[256];
   const int q = threadIdx.x % QB, l = threadIdx.x / QB;
-  const int i = blockIdx.x * QB + q, n = 2 * H * D;
+  const int i = (int)bid * QB + q, n = 2 * H * D;
   float acc = 0.f;
   if (i < n) {
     const int row = i / D, d = i - row * D, h = row % H;
@@ -1013,20 +1019,24 @@ __global__ __launch_bounds__(256) void sum_partials_blockdiag_kernel(const float
     out[i] = acc;
   }
 }
+__global__ __launch_bounds__(256) void sum_partials_blockdiag_kernel(const float* __restrict__ part, int64_t stride, int S, int H,
+                                                                     int D, int ld, float* __restrict__ out) {
+  __shared__ float red[256];
+  sum_partials_blockdiag_body(part, stride, S, H, D, ld, out, blockIdx.x, red);
+}
 
 // The same reduction for the weight-gradient tiles, written COMPACT: out (M, N) contiguous, plus one extra column of the
 // partial rows (the bias column sums that ride in a spare column) as its own vector.  Contiguous gradients are taken
 // over by autograd's accumulation as they are; row-strided views (N + 4 floats per row) were cloned once per parameter.
-__global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride4, int S, int M,
-                                                                   int N, int ldi4, float* __restrict__ out, int64_t ldo,
-                                                                   float* __restrict__ out2, int64_t ldo2, int split_col,
-                                                                   float* __restrict__ extra, int extra_col) {
+__device__ __forceinline__ void sum_partials_compact_body(const float* __restrict__ part, int64_t stride4, int S, int M, int N, int ldi4,
+                                                          float* __restrict__ out, int64_t ldo, float* __restrict__ out2, int64_t ldo2,
+                                                          int split_col, float* __restrict__ extra, int extra_col, unsigned bid,
+                                                          float4* red) {
   // one float4 of a partial row per four threads (each takes every fourth split, folded through LDS in a fixed order),
   // as sum_partials_kernel<4>; the destination of each of its four columns is looked up afterwards
   constexpr int SL = 4, QB = 256 / SL;
-  __shared__ float4 red[256];
   const int q = threadIdx.x % QB, l = threadIdx.x / QB;
-  const int64_t i = (int64_t)blockIdx.x * QB + q, n4 = (int64_t)M * ldi4;
+  const int64_t i = (int64_t)bid * QB + q, n4 = (int64_t)M * ldi4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* p = reinterpret_cast<const float4*>(part) + i;
@@ -1058,6 +1068,35 @@ __global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* 
       if (out2 && cc >= split_col) out2[r * ldo2 + (cc - split_col)] = v[j];
       else out[r * ldo + cc] = v[j];
     } else if (extra && cc == extra_col) extra[r] = v[j];
+  }
+}
+__global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* __restrict__ part, int64_t stride4, int S, int M,
+                                                                   int N, int ldi4, float* __restrict__ out, int64_t ldo,
+                                                                   float* __restrict__ out2, int64_t ldo2, int split_col,
+                                                                   float* __restrict__ extra, int extra_col) {
+  __shared__ float4 red[256];
+  sum_partials_compact_body(part, stride4, S, M, N, ldi4, out, ldo, out2, ldo2, split_col, extra, extra_col, blockIdx.x, red);
+}
+
+// several reductions of the three kinds above in ONE launch (spgnn_sum_partials_multi): the job is found from the block index
+constexpr int kMaxSumJobs = 8;
+struct SumJobs { spgnn_sum_job j[kMaxSumJobs]; unsigned first[kMaxSumJobs + 1]; int n; };
+__global__ __launch_bounds__(256) void sum_jobs_kernel(SumJobs a) {
+  __shared__ float4 red[256];
+  int k = 0;
+  while (k + 1 < a.n && blockIdx.x >= a.first[k + 1]) ++k;
+  const spgnn_sum_job& j = a.j[k];
+  const unsigned bid = blockIdx.x - a.first[k];
+  if (j.kind == 2) {
+    sum_partials_compact_body(j.partials, j.split_stride / 4, j.splits, j.M, j.N, (int)(j.ld_in / 4), j.out, j.out_stride, j.out2,
+                              j.out2_stride, j.split_col, j.extra, j.extra_col, bid, red);
+  } else if (j.kind == 1) {
+    sum_partials_blockdiag_body(j.partials, j.split_stride, j.splits, j.H, j.D, j.ld, j.out, bid, reinterpret_cast<float*>(red));
+  } else {
+    const int64_t n4 = j.n / 4;
+    if (j.splits <= 8) sum_partials_body<1>(j.partials, j.split_stride / 4, j.splits, n4, j.out, bid, red);
+    else if (j.splits <= 128) sum_partials_body<4>(j.partials, j.split_stride / 4, j.splits, n4, j.out, bid, red);
+    else sum_partials_body<16>(j.partials, j.split_stride / 4, j.splits, n4, j.out, bid, red);
   }
 }
 
@@ -1508,6 +1547,42 @@ int spgnn_scale_from_partials(const float* partials, int64_t n, float factor, fl
     hipLaunchKernelGGL(gemm::scale_from_partials, dim3(1), dim3(64), 0, st, partials, (int)n, factor, scale);
   }
   return spgnn_detail::check_launch("spgnn_gemm");
+}
+
+int spgnn_sum_partials_multi(const spgnn_sum_job* jobs, int32_t n_jobs, spgnn_stream_t stream) {
+  if (n_jobs < 0 || n_jobs > gemm::kMaxSumJobs) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (n_jobs == 0) return SPGNN_OK;
+  if (!jobs) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  gemm::SumJobs a{};
+  unsigned total = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const spgnn_sum_job& j = jobs[i];
+    if (!j.partials || !j.out || j.splits <= 0) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+    int64_t blocks;
+    if (j.kind == 0) {
+      if (j.n <= 0 || (j.n & 3) || (j.split_stride & 3) || j.split_stride < j.n || (reinterpret_cast<uintptr_t>(j.partials) & 15) ||
+          (reinterpret_cast<uintptr_t>(j.out) & 15)) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+      const int64_t n4 = j.n / 4;
+      blocks = j.splits <= 8 ? (n4 + 255) / 256 : j.splits <= 128 ? (n4 + 63) / 64 : (n4 + 15) / 16;
+    } else if (j.kind == 1) {
+      if (j.H <= 0 || j.D <= 0 || j.ld < j.H * j.D || j.split_stride < (int64_t)2 * j.H * j.ld) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+      blocks = (2 * j.H * j.D + 7) / 8;
+    } else if (j.kind == 2) {
+      if (j.M <= 0 || j.N <= 0 || j.ld_in < j.N || j.split_stride < (int64_t)j.M * j.ld_in || (j.extra && (j.extra_col < 0 || j.extra_col >= j.ld_in)))
+        return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+      if (j.out2 ? (j.split_col <= 0 || j.split_col >= j.N || j.out_stride < j.split_col || j.out2_stride < j.N - j.split_col) : j.out_stride < j.N)
+        return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+      if ((j.ld_in & 3) || (j.split_stride & 3) || (reinterpret_cast<uintptr_t>(j.partials) & 15)) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+      blocks = ((int64_t)j.M * (j.ld_in / 4) + 63) / 64;
+    } else {
+      return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+    }
+    if (blocks <= 0 || total + blocks > (1u << 30)) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+    a.j[i] = j; a.first[i] = total; total += (unsigned)blocks;
+  }
+  a.first[n_jobs] = total; a.n = n_jobs;
+  hipLaunchKernelGGL(gemm::sum_jobs_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+  return spgnn_detail::check_launch("spgnn_sum_partials_multi");
 }
 
 int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride) {

@@ -79,7 +79,8 @@ __device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4
 // -------------------------------------------------------------------------------------------------
 struct GrpF {
   const float* ft; int64_t ft_ld; const float* res; int64_t res_ld; const float* bias;
-  const float* el; const float* er; int64_t s_ld; float* attn;
+  float* el; float* er; int64_t s_ld; float* attn;
+  const float* parts;                    // PARTS kernels: the projection GEMM's score partials (N, H*D/64, 2); el / er are then OUTPUTS
   int H; int act; float slope; float p; float inv_keep; uint64_t seed;
 };
 struct LspeFwd {
@@ -91,8 +92,11 @@ struct LspeFwd {
   int64_t N; int D; const uint64_t* seed_off;
 };
 
-// T lanes per node, D = 4 T: chunk r of a lane = head r (heads 0, 1: group 0; head 2: group 1)
-template <int T>
+// T lanes per node, D = 4 T: chunk r of a lane = head r (heads 0, 1: group 0; head 2: group 1).
+// PARTS: el / er are summed here from the projection GEMMs' per-64-column score partials (D / 64 = T / 16 of them per head, in
+// ascending order: the arithmetic of spgnn_scores_from_parts, which this replaces) and the node's own pair is written out for
+// the backward kernels.
+template <int T, bool PARTS>
 __global__ __launch_bounds__(kBlock) void lspe_fwd_kernel(LspeFwd a) {
   constexpr bool WAVE = T == 64;
   constexpr int NREG = T >= 32 ? 1 : 2;
@@ -132,15 +136,31 @@ __global__ __launch_bounds__(kBlock) void lspe_fwd_kernel(LspeFwd a) {
     const int kk = k < deg ? k : deg - 1;
     const bool g1 = own && s_ >= kHeads0;
     const int hl = (own && !g1) ? s_ : 0;
-    const float* elp = g1 ? a.g[1].el : a.g[0].el;
-    const float* erp = g1 ? a.g[1].er : a.g[0].er;
+    float* elp = g1 ? a.g[1].el : a.g[0].el;
+    float* erp = g1 ? a.g[1].er : a.g[0].er;
     const int64_t sld = g1 ? a.g[1].s_ld : a.g[0].s_ld;
     const int Hg = g1 ? a.g[1].H : a.g[0].H;
     const float slope = g1 ? a.g[1].slope : a.g[0].slope, p = g1 ? a.g[1].p : a.g[0].p, ik = g1 ? a.g[1].inv_keep : a.g[0].inv_keep;
     float* attn = g1 ? a.g[1].attn : a.g[0].attn;
     const uint64_t sd = g1 ? seed_g[1] : seed_g[0];
     const int ue = a.nbr8[v * 8 + k];
-    float x = elp[(int64_t)ue * sld + hl] + erp[v * sld + hl];
+    float x;
+    if constexpr (PARTS) {
+      constexpr int NB = T / 16;                       // 64-column blocks per head
+      const float2* pp = reinterpret_cast<const float2*>(g1 ? a.g[1].parts : a.g[0].parts);
+      const float2* pu = pp + ((int64_t)ue * Hg + hl) * NB;
+      const float2* pv = pp + (v * Hg + hl) * NB;
+      float2 qu[NB], qv[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { qu[b] = pu[b]; qv[b] = pv[b]; }
+      float elu = 0.f, elv = 0.f, erv = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { elu += qu[b].x; elv += qv[b].x; erv += qv[b].y; }
+      x = elu + erv;
+      if (own && k == 0) { elp[v * sld + hl] = elv; erp[v * sld + hl] = erv; }
+    } else {
+      x = elp[(int64_t)ue * sld + hl] + erp[v * sld + hl];
+    }
     x = valid ? lrelu(x, slope) : -INFINITY;
     const float mx = group8_max(x);
     const float ex = valid ? expf(x - mx) : 0.f;
@@ -542,6 +562,7 @@ int spgnn_lspe_fwd(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_
   if (out2 && (rc = check_rows(out2, out2_stride, D)) != SPGNN_OK) return spgnn_detail::fail_at(rc, __func__, __LINE__);
   LspeFwd a{};
   a.indptr = indptr; a.nbr8 = nbr8;
+  const bool parts = groups[0].score_parts != nullptr;
   for (int i = 0; i < 2; ++i) {
     const spgnn_lspe_fwd_group& s = groups[i];
     const int64_t w = (int64_t)s.H * D;
@@ -550,15 +571,18 @@ int spgnn_lspe_fwd(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_
     LSPE_CHECK(s.el && s.er && s.attn && s.s_stride >= s.H, SPGNN_ERR_NULLPTR);
     LSPE_CHECK(!s.bias || !(reinterpret_cast<uintptr_t>(s.bias) & 15), SPGNN_ERR_STRIDE);
     LSPE_CHECK(s.act >= SPGNN_ACT_NONE && s.act <= SPGNN_ACT_RELU && s.p_drop >= 0.f && s.p_drop < 1.f, SPGNN_ERR_ENUM);
-    a.g[i] = GrpF{s.ft, s.ft_stride, s.res, s.res_stride, s.bias, s.el, s.er, s.s_stride, s.attn, s.H, s.act, s.slope, s.p_drop,
-                  1.f / (1.f - s.p_drop), s.seed};
+    LSPE_CHECK((s.score_parts != nullptr) == parts && !(reinterpret_cast<uintptr_t>(s.score_parts) & 7), SPGNN_ERR_NULLPTR);
+    a.g[i] = GrpF{s.ft, s.ft_stride, s.res, s.res_stride, s.bias, s.el, s.er, s.s_stride, s.attn, s.score_parts, s.H, s.act, s.slope,
+                  s.p_drop, 1.f / (1.f - s.p_drop), s.seed};
   }
   a.out = out; a.out_ld = out_stride; a.fp = out_drop_p; a.finv = 1.f / (1.f - out_drop_p); a.fseed = out_drop_seed;
   a.ftotal = kNS * D;
   a.out2 = out2; a.out2_ld = out2_stride; a.fp2 = out2_drop_p; a.finv2 = 1.f / (1.f - out2_drop_p); a.fseed2 = out2_drop_seed;
   a.absmax = out_absmax; a.absmax2 = out2 ? out2_absmax : nullptr;
   a.N = N; a.D = D; a.seed_off = seed_offset;
-  return launch_lspe(a, T, (hipStream_t)stream, lspe_fwd_kernel<16>, lspe_fwd_kernel<32>, lspe_fwd_kernel<64>, "spgnn_lspe_fwd");
+  if (parts)
+    return launch_lspe(a, T, (hipStream_t)stream, lspe_fwd_kernel<16, true>, lspe_fwd_kernel<32, true>, lspe_fwd_kernel<64, true>, "spgnn_lspe_fwd");
+  return launch_lspe(a, T, (hipStream_t)stream, lspe_fwd_kernel<16, false>, lspe_fwd_kernel<32, false>, lspe_fwd_kernel<64, false>, "spgnn_lspe_fwd");
 }
 
 int spgnn_lspe_bwd_dst(const int32_t* indptr, const int32_t* nbr8, const spgnn_lspe_bwd_dst_group* groups, const float* g_out,

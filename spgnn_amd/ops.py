@@ -251,6 +251,30 @@ _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-bloc
 _TN_MIN_ELEMS = 16384   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
 
 
+class SumJobs:
+    """Deferred split-K reductions: gemm_tn / scores_bwd_w append their partial-sum step here instead of launching it, and
+    ``flush()`` runs up to eight of them in ONE launch (spgnn_sum_partials_multi; bit-identical to the single launches).
+    The outputs the producers returned are filled by the flush."""
+
+    def __init__(self, device):
+        self.device, self.jobs, self.keep = device, [], []
+
+    def add(self, job, *tensors):
+        self.jobs.append(job)
+        self.keep.extend(tensors)
+        if len(self.jobs) == 8:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        arr = (_capi.SumJob * len(self.jobs))(*self.jobs)
+        with torch.cuda.device(self.device):
+            _capi.check(_capi.load().spgnn_sum_partials_multi(arr, len(self.jobs), torch.cuda.current_stream(self.device).cuda_stream),
+                        "spgnn_sum_partials_multi")
+        self.jobs, self.keep = [], []
+
+
 def sum_partials(part: torch.Tensor) -> torch.Tensor:
     """part (S, ...) contiguous -> part.sum(0) in a fixed order, one launch that fills the chip for any S
     (torch's reduction took 16-47 us on the thousands of small score-gradient partials)."""
@@ -422,7 +446,7 @@ _SCORES_SPLIT_WAVES = 2048   # row ranges x column groups of scores_bwd_w: 2048 
 _SCORES_SPLIT_WAVES_SMALL = 1024   # the same for J <= 8 (attention-vector gradients)
 
 
-def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0) -> torch.Tensor:
+def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0, defer: Optional["SumJobs"] = None) -> torch.Tensor:
     """g_w_lr = g_s^T @ x (J, K).  ``blockdiag_heads`` = H (J = 2H, K = H*D): only the (2, H, D) block diagonal
     [w, h, :] = (g_s[:, w*H + h]^T @ x)[h*D:(h+1)*D] - the attention vectors' gradients."""
     N, K = x.shape
@@ -444,10 +468,18 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0) -
     if blockdiag_heads:
         H = blockdiag_heads; D = K // H
         out = torch.empty((2, H, D), dtype=torch.float32, device=x.device)
+        if defer is not None:
+            j = _capi.SumJob(kind=1, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), H=H, D=D, ld=Kp)
+            defer.add(j, part, out)
+            return out
         with torch.cuda.device(x.device):
             _capi.check(_capi.load().spgnn_sum_partials_blockdiag(part.data_ptr(), J * Kp, splits, H, D, Kp, out.data_ptr(),
                                                                   _stream(x)), "spgnn_sum_partials_blockdiag")
         return out
+    if defer is not None and splits > 1 and (J * Kp) % 4 == 0:
+        out = torch.empty((J, Kp), dtype=torch.float32, device=x.device)
+        defer.add(_capi.SumJob(kind=0, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), n=J * Kp), part, out)
+        return out[:, :K]
     return sum_partials(part)[:, :K]
 
 
@@ -535,8 +567,12 @@ class _MaskedCE(torch.autograd.Function):
     """(logits, labels, draws, sampling_p, class_weight) -> [numerator, denominator] of the masked class-weighted
     cross entropy (train.weighted_nll_sums) in one kernel that also leaves the numerator's gradient behind."""
 
+    _out = None          # (2,) fp32 slot for [num, den], set by masked_ce_sums for one call (not an autograd input: the outputs
+                         # would otherwise count as views of an input)
+
     @staticmethod
     def forward(ctx, logits, labels, draws, sampling_p, class_weight):
+        out, _MaskedCE._out = _MaskedCE._out, None
         N, C = logits.shape
         if logits.stride(1) != 1:
             logits = logits.contiguous()
@@ -551,7 +587,7 @@ class _MaskedCE(torch.autograd.Function):
                                                      C, N, C, _stream(logits)), "spgnn_masked_ce")
         ctx.save_for_backward(g)
         ctx.set_materialize_grads(False)
-        s = part.sum(0)
+        s = part.sum(0) if out is None else torch.sum(part, 0, out=out)     # ``out``: the caller's (2,) slot for [num, den]
         num, den = s[0], s[1]                   # two outputs: indexing ONE output outside would add a select node whose
         ctx.mark_non_differentiable(den)        # backward is a zero fill + a copy
         return num, den
@@ -563,10 +599,12 @@ class _MaskedCE(torch.autograd.Function):
 
 
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: torch.Tensor, sampling_p: torch.Tensor,
-                   class_weight: torch.Tensor):
-    """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900)."""
+                   class_weight: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900).
+    ``out`` (2,) fp32, optional: where the two sums are to be written (train.FlatBucket's tail slots)."""
     _require_cuda(logits, labels, draws, sampling_p, class_weight)
     assert labels.dtype == torch.int64 and logits.dtype == torch.float32
+    _MaskedCE._out = out
     return _MaskedCE.apply(logits, labels.contiguous(), draws.contiguous(), sampling_p.contiguous(), class_weight.contiguous())
 
 
@@ -1130,6 +1168,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         g_s = torch.empty_like(s)
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=torch.float32, device=x.device)
         sg = new_scale_block(x.device)
+        jobs = SumJobs(x.device)
         gat_bwd_raw(csc, y[:, :HD], s[:, :H], s[:, H:], attn, g_out, out, H, D, slope, act, p_drop, seed,
                     g_pre, g_y[:, :HD], g_s[:, :H], g_s[:, H:], mean=mean, absmax=sg, score_l=al, score_r=ar, out_drop=out_drop,
                     absmax_dst=has_res)
@@ -1139,18 +1178,19 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             big = g_y.shape[1] * K >= _TN_MIN_ELEMS
             if big:
                 if need_bias and has_res:
-                    g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True)
+                    g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True, defer=jobs)
                     g_bias = cs[HD:]
                 else:
-                    g_wcat = gemm_tn(g_y, x, sg, sx)
+                    g_wcat = gemm_tn(g_y, x, sg, sx, defer=jobs)
             else:
                 g_wcat = _dw_gemm(g_y, x)
         if need_bias and g_bias is None:
             g_bias = g_pre.sum(0)
         g_al = g_ar = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            m = scores_bwd_w(g_s, y[:, :HD], blockdiag_heads=H)  # (2, H, D): [0] = g_attn_l, [1] = g_attn_r (contiguous views)
+            m = scores_bwd_w(g_s, y[:, :HD], blockdiag_heads=H, defer=jobs)  # (2, H, D): [0] = g_attn_l, [1] = g_attn_r (contiguous views)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
+        jobs.flush()                               # the two split-K reductions in one launch
         g_x = None
         if ctx.needs_input_grad[0]:
             Kp = (K + 3) // 4 * 4
@@ -1259,6 +1299,9 @@ def lspe_level_supported(csc: DeviceCSC, x_s: torch.Tensor, x_p: torch.Tensor, D
             and csc.max_out_degree <= 8 and bool(_capi.load().spgnn_lspe_supported(int(D))))
 
 
+LSPE_SCORES_IN_KERNEL = True     # spgnn_lspe_fwd sums el / er from the GEMMs' score partials itself; False: spgnn_scores_from_parts
+
+
 class _LspeLevelFn(torch.autograd.Function):
     """One level of GATPSPGNN (reference models.py:472-484): the structure GATConv (2 heads) on x_s = dropout(cat[h_s, h_p]) and
     the position GATConv (1 head, tanh, residual) on x_p = dropout(h_p), both project-first with el / er from the projection
@@ -1282,7 +1325,8 @@ class _LspeLevelFn(torch.autograd.Function):
             wb, ps = _b_operand(w)
             pt = torch.empty((N, H * D // 64, 2), dtype=torch.float32, device=dev)
             y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps)
-            ys.append(y); ss.append(scores_from_parts(pt, H, D)); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+            ys.append(y); parts.append(pt); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+            ss.append(scores_from_parts(pt, H, D) if not LSPE_SCORES_IN_KERNEL else torch.empty((N, 2 * H), dtype=torch.float32, device=dev))
         buf = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
         xp = torch.empty((N, D), dtype=torch.float32, device=dev)
         sc_buf, sc_xp = new_scale_block(dev), new_scale_block(dev)
@@ -1297,6 +1341,7 @@ class _LspeLevelFn(torch.autograd.Function):
             g.bias = _ptr(bias)
             g.el, g.er, g.s_stride = s_.data_ptr(), s_[:, H:].data_ptr(), s_.stride(0)
             g.attn = attn[i].data_ptr()
+            g.score_parts = parts[i].data_ptr() if LSPE_SCORES_IN_KERNEL else 0      # el / er summed (and written) by the kernel
             g.H, g.act, g.slope, g.p_drop, g.seed = H, cfg["act"][i], cfg["slope"][i], cfg["p_attn"][i], cfg["seed_attn"][i]
         with torch.cuda.device(dev), _timed("lspe_fwd", (N, E, D)):
             _capi.check(lib.spgnn_lspe_fwd(csc.indptr.data_ptr(), nbr8.data_ptr(), G, buf.data_ptr(), buf.stride(0), cfg["fp"], cfg["fseed"],
@@ -1360,6 +1405,7 @@ class _LspeLevelFn(torch.autograd.Function):
                 _capi.check(lib.spgnn_lspe_bwd_src(csc.out_indptr.data_ptr(), out_nbr8.data_ptr(), out_pos8.data_ptr(), GS, N, E, D,
                                                    _seed_off_ptr(dev), st), "spgnn_lspe_bwd_src")
         grads_x, grads_w, grads_al, grads_ar, grads_b = [None, None], [None, None], [None, None], [None, None], [None, None]
+        jobs = SumJobs(dev)                        # the level's four split-K reductions run as one launch at the end
         for i, H in enumerate(Hs):
             HD = H * D
             x, K = xs[i], xs[i].shape[1]
@@ -1369,16 +1415,16 @@ class _LspeLevelFn(torch.autograd.Function):
             if ctx.needs_input_grad[2 + i]:
                 if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
                     if need_bias and res[i]:
-                        grads_w[i], cs = gemm_tn(g_y[i], x, sg, sx, want_colsum=True)
+                        grads_w[i], cs = gemm_tn(g_y[i], x, sg, sx, want_colsum=True, defer=jobs)
                         grads_b[i] = cs[HD:]
                     else:
-                        grads_w[i] = gemm_tn(g_y[i], x, sg, sx)
+                        grads_w[i] = gemm_tn(g_y[i], x, sg, sx, defer=jobs)
                 else:
                     grads_w[i] = _dw_gemm(g_y[i], x)
             if need_bias and grads_b[i] is None:
                 grads_b[i] = g_pre[i].sum(0)
             if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
-                m = scores_bwd_w(g_s[i], ys[i][:, :HD], blockdiag_heads=H)
+                m = scores_bwd_w(g_s[i], ys[i][:, :HD], blockdiag_heads=H, defer=jobs)
                 grads_al[i], grads_ar[i] = m[0].view(ctx.attn_shapes[i]), m[1].view(ctx.attn_shapes[i])
             if ctx.needs_input_grad[i]:
                 gx = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :K]
@@ -1388,6 +1434,7 @@ class _LspeLevelFn(torch.autograd.Function):
                 else:
                     gemm_nt(g_y[i], w_t if w_t is not None else ws[i].t().contiguous(), sg, sw, out=gx)
                 grads_x[i] = gx
+        jobs.flush()
         return (grads_x[0], grads_x[1], grads_w[0], grads_w[1], grads_al[0], grads_ar[0], grads_al[1], grads_ar[1], grads_b[0], grads_b[1],
                 None, None, None)
 
@@ -1533,10 +1580,11 @@ class _GATAggFirstFn(torch.autograd.Function):
         E = csc.num_edges
         zs = z.shape[1] // H
         g_wcls = g_bcls = None
+        jobs = SumJobs(x.device)                   # every split-K reduction of this node in one launch at the end
         if ctx.has_cls and g_logits is not None:
             g_logits = g_logits.contiguous()
             if ctx.needs_input_grad[5]:
-                g_wcls = scores_bwd_w(g_logits, rst)
+                g_wcls = scores_bwd_w(g_logits, rst, defer=jobs)
             if ctx.has_cls_bias and ctx.needs_input_grad[6]:
                 g_bcls = g_logits.sum(0)
             if g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls):
@@ -1565,7 +1613,7 @@ class _GATAggFirstFn(torch.autograd.Function):
             if need_w:                                 # [g_W_fc,h | g_W_res,h] (D, 2F) straight into the two parameters' row blocks
                 gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=need_bias, out=g_wfc[h * D:(h + 1) * D],
                         out2=g_wres[h * D:(h + 1) * D] if has_res else None,
-                        colsum_out=g_bias[h * D:(h + 1) * D] if need_bias else None)
+                        colsum_out=g_bias[h * D:(h + 1) * D] if need_bias else None, defer=jobs)
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
         g_s = torch.empty_like(s)
@@ -1590,7 +1638,8 @@ class _GATAggFirstFn(torch.autograd.Function):
                                                       w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
                                                       g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
                                                       _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
-        g_wlr = scores_bwd_w(g_s, x) if ctx.needs_input_grad[3] else None
+        g_wlr = scores_bwd_w(g_s, x, defer=jobs) if ctx.needs_input_grad[3] else None
+        jobs.flush()
         return ((g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, g_wcls, g_bcls, None, None, None, None, None, None,
                 None, None)
 
@@ -1879,7 +1928,7 @@ def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
-            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None):
+            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
     over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
     accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
@@ -1915,11 +1964,17 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     assert out.stride(1) == 1 and out.shape[0] == M and (out2 is None or (out2.stride(1) == 1 and out2.shape == (M, N - split_col)))
     cs = (colsum_out if colsum_out is not None else torch.empty((M,), dtype=torch.float32, device=a.device)) if want_colsum else None
     assert cs is None or cs.is_contiguous()
-    with torch.cuda.device(a.device):
-        _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
-                                                            _ptr(out2), out2.stride(0) if out2 is not None else 0, split_col,
-                                                            _ptr(cs), ldn if want_colsum else 0, _stream(a)),
-                    "spgnn_sum_partials_compact")
+    if defer is not None:
+        defer.add(_capi.SumJob(kind=2, splits=splits, partials=part.data_ptr(), split_stride=M * ldc, out=out.data_ptr(),
+                               out_stride=out.stride(0), M=M, N=N, ld_in=ldc, out2=_ptr(out2),
+                               out2_stride=out2.stride(0) if out2 is not None else 0, split_col=split_col, extra=_ptr(cs),
+                               extra_col=ldn if want_colsum else 0), part, out, out2, cs)
+    else:
+        with torch.cuda.device(a.device):
+            _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
+                                                                _ptr(out2), out2.stride(0) if out2 is not None else 0, split_col,
+                                                                _ptr(cs), ldn if want_colsum else 0, _stream(a)),
+                        "spgnn_sum_partials_compact")
     if want_colsum:
         return out, cs
     return out

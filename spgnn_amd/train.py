@@ -91,8 +91,9 @@ class FlatBucket:
             p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             off += n
-        self.wsum_slot = self.flat_grad[self.numel:self.numel + 1]
-        self.loss_slot = self.flat_grad[self.numel + 1:self.numel + 2]
+        self.loss_slot = self.flat_grad[self.numel:self.numel + 1]          # [loss numerator, class-weight sum]: the order
+        self.wsum_slot = self.flat_grad[self.numel + 1:self.numel + 2]      # ops.masked_ce_sums writes them in
+        self.sums_slot = self.flat_grad[self.numel:self.numel + 2]
         self.steps = 0
 
         self._views = [p.grad for p in self.params]
@@ -178,8 +179,9 @@ class TrainStep:
                 ops.DROPOUT_SEED_OFFSET = ctr
                 ctr.add_(1)
             logits = self.model(g)[0]
-            if logits.is_cuda:               # one kernel: mask, log-softmax, weighted NLL sums and the gradient
-                nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight)
+            direct = logits.is_cuda
+            if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
+                nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot)   # land in the bucket's tail
                 num, den = nd[0], nd[1]
             else:
                 num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
@@ -189,8 +191,9 @@ class TrainStep:
             if pool is not None:
                 pool.end()
         b.gather_grads()
-        b.wsum_slot.copy_(den.detach().reshape(1))
-        b.loss_slot.copy_(num.detach().reshape(1))
+        if not direct:
+            b.wsum_slot.copy_(den.detach().reshape(1))
+            b.loss_slot.copy_(num.detach().reshape(1))
         return b.loss_slot
 
     def _reduce(self, loss_num: torch.Tensor) -> torch.Tensor:

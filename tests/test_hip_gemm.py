@@ -313,3 +313,31 @@ def test_gemm_takes_scale_blocks():
     c0 = ops.new_scale_block("cuda")
     pool.end()
     assert c0.data_ptr() == b0.data_ptr() and float(c0[ops.SCALE_HEADER:].abs().sum()) == 0.0 and float(c0[0]) == -256.0
+
+
+def test_deferred_partial_sums_equal_single_launches():
+    """ops.SumJobs (spgnn_sum_partials_multi): a weight gradient with column sums, one split into two outputs, an
+    attention-vector gradient (block diagonal) and a plain skinny gradient reduced in ONE launch - bit-identical to the four
+    separate reductions."""
+    torch.manual_seed(5)
+    R = 20000
+    g, x = _mat(R, 512, 1e-3), _mat(R, 200)
+    sg, sx = ops.pow2_scale(g), ops.pow2_scale(x)
+    ref_w, ref_cs = ops.gemm_tn(g, x, sg, sx, want_colsum=True)
+    o1, o2 = torch.empty(512, 120, device="cuda"), torch.empty(512, 80, device="cuda")
+    ops.gemm_tn(g, x, sg, sx, out=o1, out2=o2)
+    gs, ft = torch.randn(R, 4, device="cuda"), _mat(R, 256)
+    ref_bd = ops.scores_bwd_w(gs, ft, blockdiag_heads=2)
+    g22, x1 = torch.randn(R, 22, device="cuda"), _mat(R, 1024)
+    ref_pl = ops.scores_bwd_w(g22, x1)
+    jobs = ops.SumJobs(torch.device("cuda", 0))
+    w, cs = ops.gemm_tn(g, x, sg, sx, want_colsum=True, defer=jobs)
+    p1, p2 = torch.empty(512, 120, device="cuda"), torch.empty(512, 80, device="cuda")
+    ops.gemm_tn(g, x, sg, sx, out=p1, out2=p2, defer=jobs)
+    bd = ops.scores_bwd_w(gs, ft, blockdiag_heads=2, defer=jobs)
+    pl = ops.scores_bwd_w(g22, x1, defer=jobs)
+    assert len(jobs.jobs) == 4
+    jobs.flush()
+    assert not jobs.jobs
+    assert torch.equal(w, ref_w) and torch.equal(cs, ref_cs) and torch.equal(p1, o1) and torch.equal(p2, o2)
+    assert torch.equal(bd, ref_bd) and torch.equal(pl, ref_pl)
