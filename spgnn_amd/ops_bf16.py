@@ -118,7 +118,7 @@ def _tn_splits(R: int, M: int, N: int) -> int:
     return splits
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits: Optional[int] = None):
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits: Optional[int] = None, defer=None):
     """a (R,M)^T @ b (R,N) -> (M,N) fp32 (weight gradients): bf16 MFMA, fp32 accumulate, split over row ranges with a
     deterministic partial-sum reduction.  ``want_colsum``: also a.sum(0) (M,) fp32 from the operand stream."""
     _require_cuda(a, b)
@@ -136,14 +136,19 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits:
                                            splits, R, M, N, cs_ptr, ldc, M * ldc, _stream(a)), "spgnn_gemm_tn_bf16")
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     cs = torch.empty((M,), dtype=torch.float32, device=a.device) if want_colsum else None
-    with torch.cuda.device(a.device):
-        _capi.check(lib.spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
-                                                   0, 0, 0, _ptr(cs), ldn if want_colsum else 0, _stream(a)),
-                    "spgnn_sum_partials_compact")
+    if defer is not None:                     # ops.SumJobs: the reduction joins the caller's other ones in one launch
+        defer.add(_capi.SumJob(kind=2, splits=splits, partials=part.data_ptr(), split_stride=M * ldc, out=out.data_ptr(),
+                               out_stride=out.stride(0), M=M, N=N, ld_in=ldc, extra=_ptr(cs), extra_col=ldn if want_colsum else 0),
+                  part, out, cs)
+    else:
+        with torch.cuda.device(a.device):
+            _capi.check(lib.spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
+                                                       0, 0, 0, _ptr(cs), ldn if want_colsum else 0, _stream(a)),
+                        "spgnn_sum_partials_compact")
     return (out, cs) if want_colsum else out
 
 
-def attn_vector_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int) -> torch.Tensor:
+def attn_vector_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int, defer=None) -> torch.Tensor:
     """(2, H, D): [w, h, :] = g_s[:, w*H + h]^T @ ft[:, h*D:(h+1)*D] - the gradients of attn_l / attn_r (fp32), ft bf16."""
     N, K = ft.shape
     J = g_s.shape[1]
@@ -156,8 +161,12 @@ def attn_vector_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int) -> torch.Tens
     with torch.cuda.device(ft.device), _timed("scores_bwd_w_bf16", (N, K, J)):
         _capi.check(lib.spgnn_scores_bwd_w_bf16(g_s.data_ptr(), g_s.stride(0), ft.data_ptr(), ft.stride(0), part.data_ptr(), splits,
                                                 Kp, N, K, J, _stream(ft)), "spgnn_scores_bwd_w_bf16")
-        _capi.check(lib.spgnn_sum_partials_blockdiag(part.data_ptr(), J * Kp, splits, H, D, Kp, out.data_ptr(), _stream(ft)),
-                    "spgnn_sum_partials_blockdiag")
+        if defer is not None:
+            defer.add(_capi.SumJob(kind=1, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), H=H, D=D, ld=Kp),
+                      part, out)
+        else:
+            _capi.check(lib.spgnn_sum_partials_blockdiag(part.data_ptr(), J * Kp, splits, H, D, Kp, out.data_ptr(), _stream(ft)),
+                        "spgnn_sum_partials_blockdiag")
     return out
 
 
@@ -258,20 +267,23 @@ class _GATLayerBf16Fn(torch.autograd.Function):
                                                        p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_src_bf16")
         need_bias = ctx.has_bias and ctx.needs_input_grad[5]
         g_wfc = g_wres = g_bias = None
+        from .ops import SumJobs
+        jobs = SumJobs(x.device)                        # the layer's two split-K reductions in one launch
         if ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2]):
             if need_bias and has_res:                   # column sums of g_pre ride along with the operand stream
-                g_w, cs = gemm_tn(g_y, x, want_colsum=True)
+                g_w, cs = gemm_tn(g_y, x, want_colsum=True, defer=jobs)
                 g_bias = cs[HD:]
             else:
-                g_w = gemm_tn(g_y, x)
+                g_w = gemm_tn(g_y, x, defer=jobs)
             g_wfc = g_w[:HD]
             g_wres = g_w[HD:] if has_res else None
         if need_bias and g_bias is None:
             g_bias = g_pre.float().sum(0)
         g_al = g_ar = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            m = attn_vector_grads(g_s, y[:, :HD], H)
+            m = attn_vector_grads(g_s, y[:, :HD], H, defer=jobs)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
+        jobs.flush()
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = gemm_nt(g_y, w_t)
