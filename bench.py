@@ -263,8 +263,9 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             loss = step.step(g)
         kt_all = ops.KernelTimer.stop()
     # The roofline kernel is FIXED per dtype (not "whichever shape won this run"): all launches of it in a step.
+    spmm_model = cfg.KIND in ("gcn", "gin", "sage")           # rows D / E / F: the SpMM kernels are the roofline kernel (HBM-bound)
     roof_names = (("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16", "gat_agg_fwd_bf16", "gat_agg_bwd_dst_bf16",
-                   "gat_agg_bwd_src_bf16") if bf16 else ("gemm_nt",))
+                   "gat_agg_bwd_src_bf16") if bf16 else ("spmm_sum", "spmm_max_fwd", "spmm_max_bwd") if spmm_model else ("gemm_nt",))
     gat_names = tuple(k for k in {k[0] for k in kt_all} if k.startswith(GAT_PREFIXES))
     bracket = [k for k in kt_all if k[0] in roof_names or k[0] in gat_names or k[0] in GEMM_NAMES]
     sync()
@@ -448,12 +449,14 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             if rkeys:
                 r_ms = sum(per_step(k)[0] for k in rkeys)
                 r_n = sum(per_step(k)[1] for k in rkeys)
-                if bf16:
+                if bf16 or spmm_model:
                     r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
                     ach = r_bytes / (r_ms * 1e-3) / 1e9
                     tr = traffic_of(rkeys)
-                    out["roofline"] = {"bound": "hbm", "kernel": "spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the "
-                                       "output layer's spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    what = ("spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the output layer's "
+                            "spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)") if bf16 else \
+                           "the SpMM kernels " + " + ".join(sorted({"spgnn_" + k[0] for k in rkeys})) + " (all launches of a step, forward and backward)"
+                    out["roofline"] = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBPS, "traffic": tr, "traffic_source": TRAFFIC_SOURCE if tr is not None else None,
                                        "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
                                        "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,

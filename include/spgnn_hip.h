@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 34
+#define SPGNN_ABI_VERSION 35
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -46,6 +46,8 @@ extern "C" {
 #define SPGNN_ACT_ELU  1
 #define SPGNN_ACT_TANH 2
 #define SPGNN_ACT_RELU 3
+#define SPGNN_ACT_LRELU 4   /* LeakyReLU with torch.nn.LeakyReLU's default slope 0.01 (the reference's GIN MLPs, models.py:236-246): the
+                               * GEMM epilogue (spgnn_gemm_nt), spgnn_spmm_sum and spgnn_act_bwd take it; the GAT kernels do not */
 
 typedef void* spgnn_stream_t;   /* hipStream_t */
 
@@ -300,10 +302,13 @@ int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32
  * w_src, w_dst: per-node scales (N) or NULL (= 1).  self_eps: device pointer to GINConv's `eps`
  * (self_coef = 1 + *self_eps) or NULL (self_coef = 0).  The backward w.r.t. x is the same call
  * on the transposed structure (out_indptr/out_indices) with w_src and w_dst swapped.
+ * Optional epilogue out = act(out + bias[col]) (bias nullable, F floats; activation = SPGNN_ACT_*): GraphConv's bias and
+ * activation when the aggregation FOLLOWS the projection (in_feats > out_feats, reference models.py:172-182).
  */
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices,
                    const float* x, int64_t x_stride,
                    const float* w_src, const float* w_dst, const float* self_eps,
+                   const float* bias, int32_t activation,
                    float* out, int64_t out_stride,
                    int64_t N, int64_t E, int32_t F,
                    spgnn_stream_t stream);
@@ -385,6 +390,13 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
                            const float* bias, int32_t activation,
                            const float* other_head, int64_t other_head_stride, float* mean_out, int64_t mean_out_stride,
                            int32_t b_presplit, spgnn_stream_t stream);
+
+/* C = act(A B^T + bias + addend): the second of two products that share an output adds the first one's result in its epilogue
+ * (SAGEConv: fc_self(h) + fc_neigh(neigh), reference models.py:668-679) - no separate addition and activation passes.
+ * addend: (M, N) fp32, 16-byte aligned rows (may be C itself). */
+int spgnn_gemm_nt_add(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                      int64_t K, const float* scale_a, const float* scale_b, const float* bias, int32_t activation,
+                      const float* addend, int64_t addend_stride, int32_t b_presplit, spgnn_stream_t stream);
 
 /* spgnn_gemm_nt with the block tile pinned: tile = 0 chosen from the shape (= spgnn_gemm_nt), 2 = 128 x 128,
  * 4 = 256 x 128, 5 = 256 x 256 (operand extents below 2^31 bytes).  Every tile shape performs the same arithmetic in the

@@ -51,7 +51,9 @@ struct Args {
   // <C[row, 64b : 64b+64], sc_l / sc_r[64b : 64b+64]>  (raw product, before rank-J / bias / activation)
   const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
   // optional head mean of a two-head layer (pipelined kernels): mean_out[row, col] = 0.5 * (this tile's final value +
-  // mean_other[row, col]) - the second head's product also writes the mean over heads (replaces a pass over both heads)
+  // mean_other[row, col]) - the second head's product also writes the mean over heads (replaces a pass over both heads).
+  // mean_other WITHOUT mean_out is an ADDEND: C = act(A B^T + bias + mean_other) - the second of two products that share an
+  // output (SAGEConv: fc_self(h) + fc_neigh(neigh), reference models.py:668-679) adds the first one's result in its epilogue
   const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
 };
 // B may arrive PRE-SPLIT (spgnn_presplit): every group of four fp32 values replaced, in place, by its packed fp16 pairs
@@ -286,6 +288,14 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) { vv[it].x += bq.x; vv[it].y += bq.y; vv[it].z += bq.z; vv[it].w += bq.w; }
+      if (a.mean_other && !a.mean_out) {                // addend: the other product of the pair
+        const int64_t r0_ = row0 + wm * (32 * MI) + i * 32 + r_in;
+        float4 oo[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) oo[it] = *reinterpret_cast<const float4*>(a.mean_other + (r0_ + it * 4) * a.ld_mo + col);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { vv[it].x += oo[it].x; vv[it].y += oo[it].y; vv[it].z += oo[it].z; vv[it].w += oo[it].w; }
+      }
       if (a.act == SPGNN_ACT_ELU) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -300,6 +310,12 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           vv[it].x = fmaxf(vv[it].x, 0.f); vv[it].y = fmaxf(vv[it].y, 0.f); vv[it].z = fmaxf(vv[it].z, 0.f); vv[it].w = fmaxf(vv[it].w, 0.f);
+        }
+      } else if (a.act == SPGNN_ACT_LRELU) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          vv[it].x = vv[it].x > 0.f ? vv[it].x : 0.01f * vv[it].x; vv[it].y = vv[it].y > 0.f ? vv[it].y : 0.01f * vv[it].y;
+          vv[it].z = vv[it].z > 0.f ? vv[it].z : 0.01f * vv[it].z; vv[it].w = vv[it].w > 0.f ? vv[it].w : 0.01f * vv[it].w;
         }
       }
       if (a.mean_out) {
@@ -358,12 +374,22 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
           }
         }
         v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+        if (a.mean_other && !a.mean_out) {
+          const float* op = a.mean_other + (int64_t)row * a.ld_mo + col;
+          if (col < a.N) v.x += op[0];
+          if (col + 1 < a.N) v.y += op[1];
+          if (col + 2 < a.N) v.z += op[2];
+          if (col + 3 < a.N) v.w += op[3];
+        }
         if (a.act == SPGNN_ACT_ELU) {
           v.x = elu_fwd_nb(v.x); v.y = elu_fwd_nb(v.y); v.z = elu_fwd_nb(v.z); v.w = elu_fwd_nb(v.w);
         } else if (a.act == SPGNN_ACT_TANH) {
           v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
         } else if (a.act == SPGNN_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (a.act == SPGNN_ACT_LRELU) {
+          v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+          v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
         }
         if (a.mean_out) {
           const float vq[4] = {v.x, v.y, v.z, v.w};
@@ -1317,6 +1343,9 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
     if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
         (reinterpret_cast<uintptr_t>(mean_other) & 15) || (reinterpret_cast<uintptr_t>(mean_out) & 15))
       return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+  } else if (mean_other) {                                  // addend (spgnn_gemm_nt_add)
+    if (mean_other_stride < N || (mean_other_stride & 3) || (reinterpret_cast<uintptr_t>(mean_other) & 15))
+      return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   }
   if (M < 0 || N < 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (score_out) {
@@ -1326,7 +1355,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
         (reinterpret_cast<uintptr_t>(score_out) & 7))
       return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   }
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (upd_j < 0 || upd_j > 32) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (upd_j > 0) {
     if (!upd_u || !upd_v) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
@@ -1405,6 +1434,14 @@ int spgnn_gemm_nt_headmean(const float* A, int64_t lda, const float* B, int64_t 
   if (!other_head || !mean_out) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
                       nullptr, nullptr, 0, other_head, other_head_stride, mean_out, mean_out_stride, 0, b_presplit, stream);
+}
+
+int spgnn_gemm_nt_add(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                      int64_t K, const float* scale_a, const float* scale_b, const float* bias, int32_t activation,
+                      const float* addend, int64_t addend_stride, int32_t b_presplit, spgnn_stream_t stream) {
+  if (!addend) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, nullptr, 0, nullptr, 0, 0, bias, activation, nullptr,
+                      nullptr, nullptr, 0, addend, addend_stride, nullptr, 0, 0, b_presplit, stream);
 }
 
 int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale_in, float* scale_out,

@@ -1321,6 +1321,32 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
   }
 }
 
+// The same without the head mean, as a flat pass over 16-byte chunks (one wave per node left 3/4 of the lanes idle on rows
+// of 64 columns and made the kernel as slow for (N, 64) as for (N, 1024): 100 us): grid-stride over N * W / 4 chunks, the
+// wave's maximum folded into the scale block once per wave.
+__global__ __launch_bounds__(kBlock) void act_bwd_flat_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
+                                                              int64_t out_ld, float* __restrict__ g_pre, int64_t gp_ld,
+                                                              float* __restrict__ absmax, int64_t N, int W, int act) {
+  const int w4 = W >> 2;
+  const int64_t total = N * w4;
+  float mx = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = i / w4; const int c = (int)(i - v * w4) * 4;
+    float4 q = ld4(g + v * g_ld + c);
+    if (act != SPGNN_ACT_NONE) {
+      const float4 o = ld4(out + v * out_ld + c);
+      q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
+      q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+    }
+    st4(g_pre + v * gp_ld + c, q);
+    mx = absmax4(mx, q);
+  }
+  if (absmax) {                                       // (every lane of the wave is here: no early return above)
+    mx = team_max(mx, 64);
+    if ((threadIdx.x & 63) == 0) spgnn_detail::slots_max(absmax, mx, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  }
+}
+
 // act_bwd with the classifier's input gradient formed on the fly (mean-over-heads output layer followed by a skinny
 // Linear, reference models.py:1125 `gnn_out`):
 //   g_pre[v, h*D + c] = (1/H) * (sum_j gS[v, j] * W[j, c]) * act'(out[v, h*D + c])
@@ -1553,6 +1579,7 @@ struct SpmmSum {
   const float* w_src; const float* w_dst; const float* self_eps;
   float* out; int64_t out_ld;
   int64_t N; int F; int T;
+  const float* bias; int act;            // optional epilogue out = act(... + bias[col]) (GraphConv: reference models.py:172-182)
 };
 
 // TT = 64: one node per wave with wave-uniform index / weight values in SGPRs; TT = 0: run-time team width
@@ -1608,6 +1635,8 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
     const int c = (r * T + lane) * 4;
     float4 o = make_float4(acc[r].x * wd, acc[r].y * wd, acc[r].z * wd, acc[r].w * wd);
     if (a.self_eps) fma4(o, sc, ld4(a.x + v * a.x_ld + c));
+    if (a.bias) { const float4 b = ld4(a.bias + c); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+    if (a.act != SPGNN_ACT_NONE) { o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act); }
     st4(a.out + v * a.out_ld + c, o);
   }
 }
@@ -1623,7 +1652,8 @@ __global__ void spmm_sum_scalar(SpmmSum a) {
   }
   acc *= a.w_dst ? a.w_dst[v] : 1.f;
   if (a.self_eps) acc = fmaf(1.f + a.self_eps[0], a.x[v * a.x_ld + col], acc);
-  a.out[v * a.out_ld + col] = acc;
+  if (a.bias) acc += a.bias[col];
+  a.out[v * a.out_ld + col] = act_fwd(acc, a.act);
 }
 
 struct SpmmMaxFwd {
@@ -2864,7 +2894,7 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
                   float* g_pre, int64_t g_pre_stride, float* absmax, int64_t N, int32_t H, int32_t D, int32_t activation,
                   spgnn_stream_t stream) {
   if (N < 0 || H <= 0 || D <= 0 || D % 4) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd: bad N/H/D (D must be a multiple of 4)");
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd: activation");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd: activation");
   if (N == 0) return SPGNN_OK;
   if (!g_out || !g_pre || (activation != SPGNN_ACT_NONE && !out)) return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd: null pointer");
   const int64_t HD = (int64_t)H * D;
@@ -2872,6 +2902,13 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
     return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd: row stride smaller than row");
   if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)))
     return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd: rows must be 16-byte aligned");
+  if (!mean_heads) {
+    int64_t blocks = (N * (HD / 4) + kBlock - 1) / kBlock;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
+                       out_stride, g_pre, g_pre_stride, absmax, N, (int)HD, activation);
+    return check_launch("spgnn_act_bwd");
+  }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((N + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                      (hipStream_t)stream, g_out, g_out_stride, mean_heads ? 1 : 0, out, out_stride, g_pre, g_pre_stride, absmax,
                      N, H, D, activation);
@@ -2993,16 +3030,17 @@ int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int6
 }
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
-                   const float* w_dst, const float* self_eps, float* out, int64_t out_stride, int64_t N, int64_t E,
-                   int32_t F, spgnn_stream_t stream) {
+                   const float* w_dst, const float* self_eps, const float* bias, int32_t activation, float* out,
+                   int64_t out_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_sum: bad N/E/F");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_spmm_sum: activation");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !out || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_sum: null pointer");
   if (x_stride < F || out_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_sum: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0};
+  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation};
   int T, R;
-  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride)) {
+  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && (!bias || aligned16(bias))) {
     a.T = T;
     DISPATCH_R(T, R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {

@@ -115,6 +115,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     case SPGNN_ACT_ELU:  return elu_fwd(x);
     case SPGNN_ACT_TANH: return tanhf(x);
     case SPGNN_ACT_RELU: return x > 0.f ? x : 0.f;
+    case SPGNN_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
     default:             return x;
   }
 }
@@ -126,6 +127,7 @@ template <int R> __device__ __forceinline__ void act_fwd_rows(float4 (&o)[R], in
   if (act == SPGNN_ACT_ELU) { SPGNN_ROWS(elu_fwd(x)) }
   else if (act == SPGNN_ACT_TANH) { SPGNN_ROWS(tanhf(x)) }
   else if (act == SPGNN_ACT_RELU) { SPGNN_ROWS(x > 0.f ? x : 0.f) }
+  else if (act == SPGNN_ACT_LRELU) { SPGNN_ROWS(x > 0.f ? x : 0.01f * x) }
 #undef SPGNN_ROWS
 }
 // derivative expressed through the OUTPUT y = act(x) (what the forward saved)
@@ -134,6 +136,7 @@ __device__ __forceinline__ float act_bwd_from_out(float y, int act) {
     case SPGNN_ACT_ELU:  return y > 0.f ? 1.f : y + 1.f;
     case SPGNN_ACT_TANH: return 1.f - y * y;
     case SPGNN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case SPGNN_ACT_LRELU: return y > 0.f ? 1.f : 0.01f;
     default:             return 1.f;
   }
 }
@@ -145,6 +148,7 @@ template <int R> __device__ __forceinline__ void act_bwd_rows(float4 (&g)[R], co
   if (act == SPGNN_ACT_ELU) { SPGNN_ROWS(y > 0.f ? 1.f : y + 1.f) }
   else if (act == SPGNN_ACT_TANH) { SPGNN_ROWS(1.f - y * y) }
   else if (act == SPGNN_ACT_RELU) { SPGNN_ROWS(y > 0.f ? 1.f : 0.f) }
+  else if (act == SPGNN_ACT_LRELU) { SPGNN_ROWS(y > 0.f ? 1.f : 0.01f) }
 #undef SPGNN_ROWS
 }
 

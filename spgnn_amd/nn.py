@@ -51,6 +51,13 @@ def _act_code(fn) -> Optional[int]:
     return None
 
 
+def _act_code_dense(fn) -> Optional[int]:
+    """As _act_code, plus LeakyReLU(0.01) - an epilogue of the dense products and of spmm_sum only (not of the GAT kernels)."""
+    if isinstance(fn, nn.LeakyReLU) and fn.negative_slope == 0.01:
+        return ops.ACT_LRELU
+    return _act_code(fn)
+
+
 def _draw_seed() -> int:
     # host-side draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -328,13 +335,21 @@ class GraphConv(nn.Module):
         if self._norm in ("right", "both"):
             d = csc.in_degrees_f().clamp(min=1)
             w_dst = d.pow(-0.5) if self._norm == "both" else 1.0 / d
+        # bias and activation ride in the epilogue of whichever kernel comes last (FUSE_EPILOGUES): the SpMM when the
+        # projection comes first (in_feats > out_feats), else the projection GEMM
+        act = _act_code_dense(self._activation)
+        fuse = FUSE_EPILOGUES and feat.is_cuda and act is not None and getattr(csc, "num_dst", None) is None and self._out_feats % 4 == 0
         if self._in_feats > self._out_feats:       # mult W first to reduce the aggregated width
             if weight is not None:
                 feat = ops.linear(feat, weight.t())
+            if fuse:
+                return ops.spmm_sum(csc, feat, w_src, w_dst, bias=self.bias, act=act)
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
         else:
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
             if weight is not None:
+                if fuse:
+                    return ops.linear(rst, weight.t(), self.bias, act)
                 rst = ops.linear(rst, weight.t())
         if self.bias is not None:
             rst = rst + self.bias
@@ -350,14 +365,36 @@ def _dst_rows(csc, x: torch.Tensor) -> torch.Tensor:
     return x if nd is None else x[:nd]
 
 
+FUSE_EPILOGUES = True     # bias / activation of GraphConv, the GIN MLP and SAGEConv inside the producing kernel's epilogue
+
+
 def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """``module(x)`` with every plain ``nn.Linear`` (also inside an ``nn.Sequential``, e.g. the reference's GIN MLP,
-    models.py:236-246) evaluated by ops.linear on the matrix-core GEMMs; any other module runs as it is."""
+    models.py:236-246: Linear, Dropout, LeakyReLU, Linear, LeakyReLU) evaluated by ops.linear on the matrix-core GEMMs; any
+    other module runs as it is.  An activation that follows a Linear - directly or behind a Dropout - goes into that
+    product's epilogue: dropout multiplies by 0 or 1 / (1 - p) >= 0 and LeakyReLU / ReLU are positively homogeneous, so
+    ``act(dropout(y)) == dropout(act(y))`` (to the last bit but one: the two scalings swap)."""
     if type(module) is nn.Linear:
         return ops.linear(x, module.weight, module.bias)
     if type(module) is nn.Sequential:
-        for m in module:
+        mods = list(module)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if type(m) is nn.Linear and FUSE_EPILOGUES and x.is_cuda:
+                j = i + 1
+                drop = None
+                if j < len(mods) and type(mods[j]) is nn.Dropout:
+                    drop, j = mods[j], j + 1
+                code = _act_code_dense(mods[j]) if j < len(mods) and isinstance(mods[j], (nn.LeakyReLU, nn.ReLU)) else None
+                if code is not None:
+                    x = ops.linear(x, m.weight, m.bias, code)
+                    if drop is not None:
+                        x = drop(x)
+                    i = j + 1
+                    continue
             x = _apply_fast_linear(m, x)
+            i += 1
         return x
     return module(x)
 
@@ -438,12 +475,17 @@ class SAGEConv(nn.Module):
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
         h = self.feat_drop(feat)
-        if self._aggre_type == "pool":
-            neigh = _dst_rows(csc, ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)))
-            rst = (ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias)
-                   + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias))
-        elif self._aggre_type == "mean":
-            neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1)))
+        act = _act_code_dense(self.activation)
+        fuse = FUSE_EPILOGUES and h.is_cuda and act is not None and self._out_feats % 4 == 0
+        if self._aggre_type in ("pool", "mean"):
+            if self._aggre_type == "pool":
+                neigh = _dst_rows(csc, ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)))
+            else:
+                neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1)))
+            if fuse:        # fc_neigh's product adds fc_self's result and applies the activation in its epilogue
+                rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias, act,
+                                 addend=ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias))
+                return rst if self.norm is None else self.norm(rst)
             rst = (ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias)
                    + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias))
         else:  # gcn: (sum_in x_u + x_v) / (deg + 1)

@@ -18,7 +18,7 @@ import torch
 from . import _capi
 from .graph import DeviceCSC
 
-ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU, ACT_LRELU = 0, 1, 2, 3, 4      # ACT_LRELU: slope 0.01 (nn.LeakyReLU default); GEMM / SpMM epilogues only
 
 # Projection GEMMs: "f16x3" = hand-written split-fp16 MFMA kernels (spgnn_gemm.hip; fp32-GEMM accuracy), "fp32" =
 # rocBLAS/hipBLASLt SGEMM through torch.mm (kept as the arithmetic cross-check of tests/test_hip_gemm.py).
@@ -615,16 +615,19 @@ class _LinearFn(torch.autograd.Function):
     by-product of the operand stream."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, addend=None):
         x = _rowmajor(x)
         if not _rows_aligned(x):
             x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
         w = weight if weight.stride(1) == 1 else weight.contiguous()      # e.g. GraphConv's (in, out) weight seen as W^T
         if not _rows_aligned(w):
             w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
-        sx, sw = pow2_scale(x), pow2_scale(w)
-        y = gemm_nt(x, w, sx, sw, bias=bias, act=act)
-        ctx.act, ctx.has_bias = act, bias is not None
+        sx, sw = operand_scale(x), pow2_scale(w)
+        if addend is not None:                                             # act(x W^T + b + addend) in one epilogue
+            y = gemm_nt_add(x, w, sx, sw, _rowmajor(addend), bias=bias, act=act)
+        else:
+            y = gemm_nt(x, w, sx, sw, bias=bias, act=act)
+        ctx.act, ctx.has_bias, ctx.has_addend = act, bias is not None, addend is not None
         ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
         return y
 
@@ -639,7 +642,7 @@ class _LinearFn(torch.autograd.Function):
         else:
             if ctx.act != ACT_NONE:
                 g = g * {ACT_ELU: torch.where(y > 0, torch.ones_like(y), y + 1), ACT_TANH: 1 - y * y,
-                         ACT_RELU: (y > 0).to(y.dtype)}[ctx.act]
+                         ACT_RELU: (y > 0).to(y.dtype), ACT_LRELU: torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))}[ctx.act]
             if not _rows_aligned(g):
                 g = cat_padded((g,))
             sg = pow2_scale(g)
@@ -653,17 +656,23 @@ class _LinearFn(torch.autograd.Function):
                 g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
             else:
                 g_w = gemm_tn(g, x, sg, sx)
-        return g_x, g_w, g_b, None
+        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None)
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
-    """act(F.linear(x, weight, bias)).  Tall operands (>= 512 rows, both widths >= 32) on a ROCm device take the
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+           addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(F.linear(x, weight, bias) + addend).  Tall operands (>= 512 rows, both widths >= 32) on a ROCm device take the
     matrix-core GEMM path; anything else goes to torch (tiny products are launch-bound either way)."""
     N = x.shape[0] if x.dim() == 2 else 0
     if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32 and weight.shape[1] >= 32
-            and x.dtype == torch.float32 and weight.dtype == torch.float32):
-        return _LinearFn.apply(x, weight, bias, act)
+            and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and (addend is None or (weight.shape[0] % 4 == 0 and addend.shape == (N, weight.shape[0])))):
+        return _LinearFn.apply(x, weight, bias, act, addend)
     y = torch.nn.functional.linear(x, weight, bias)
+    if addend is not None:
+        y = y + addend
+    if act == ACT_LRELU:
+        y = torch.nn.functional.leaky_relu(y, 0.01)
     if act == ACT_ELU:
         y = torch.nn.functional.elu(y)
     elif act == ACT_TANH:
@@ -1741,45 +1750,57 @@ def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: i
 # --------------------------------------------------------------------------------------------
 # SpMM sum / max
 # --------------------------------------------------------------------------------------------
-def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int) -> torch.Tensor:
-    _require_cuda(x, w_src, w_dst, eps)
+def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=None, act: int = ACT_NONE) -> torch.Tensor:
+    _require_cuda(x, w_src, w_dst, eps, bias)
     F_ = x.shape[1]
     out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device), _timed("spmm_sum", (N, E, F_)):
         _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
-                                       _ptr(w_dst), _ptr(eps), out.data_ptr(), out.stride(0), N, E, F_, _stream(x)),
+                                       _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_, _stream(x)),
                     "spgnn_spmm_sum")
     return out
 
 
 class _SpmmSumFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst):
+    def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst, bias=None, act: int = ACT_NONE):
         x = _rowmajor(x)
-        out = spmm_sum_raw(csc.indptr, csc.indices, x, w_src, w_dst, eps, csc.num_nodes, csc.num_edges)
-        ctx.csc, ctx.w = csc, (w_src, w_dst)
-        ctx.save_for_backward(x if eps is not None else None, eps)
+        fuse = (bias is not None or act != ACT_NONE) and x.shape[1] % 4 == 0
+        out = spmm_sum_raw(csc.indptr, csc.indices, x, w_src, w_dst, eps, csc.num_nodes, csc.num_edges, bias if fuse else None,
+                           act if fuse else ACT_NONE)
+        if not fuse and (bias is not None or act != ACT_NONE):
+            raise RuntimeError("spmm_sum: the bias / activation epilogue needs a width that is a multiple of 4")
+        ctx.csc, ctx.w, ctx.act, ctx.has_bias = csc, (w_src, w_dst), act, bias is not None
+        ctx.save_for_backward(x if eps is not None else None, eps, out if act != ACT_NONE else None)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, eps = ctx.saved_tensors
+        x, eps, out = ctx.saved_tensors
         csc = ctx.csc
         w_src, w_dst = ctx.w
         g_out = _rowmajor(g_out)
+        g_bias = None
+        if ctx.act != ACT_NONE:                     # gradient of the pre-activation rows: one flat pass (spgnn_act_bwd)
+            g_out, _ = act_bwd(g_out if _rows_aligned(g_out) else g_out.contiguous(), out, 1, out.shape[1], ctx.act, False)
+        if ctx.has_bias and ctx.needs_input_grad[5]:
+            g_bias = g_out.sum(0)
         g_x = g_eps = None
         if ctx.needs_input_grad[0]:   # transpose: swap the roles of the two scalings
             g_x = spmm_sum_raw(csc.out_indptr, csc.out_indices, g_out, w_dst, w_src, eps, csc.num_nodes, csc.num_edges)
         if eps is not None and ctx.needs_input_grad[1]:
-            g_eps = (g_out * x).sum().reshape(eps.shape)
-        return g_x, g_eps, None, None, None
+            if g_out.is_contiguous() and x.is_contiguous():      # one pass over both tensors, no (N, F) temporary
+                g_eps = torch.dot(g_out.reshape(-1), x.reshape(-1)).reshape(eps.shape)
+            else:
+                g_eps = (g_out * x).sum().reshape(eps.shape)
+        return g_x, g_eps, None, None, None, g_bias, None
 
 
-def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None) -> torch.Tensor:
-    """out[v] = (1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u]."""
+def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None, bias=None, act: int = ACT_NONE) -> torch.Tensor:
+    """out[v] = act((1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u] + bias)."""
     _require_cuda(x)
-    return _SpmmSumFn.apply(x, eps, csc, w_src, w_dst)
+    return _SpmmSumFn.apply(x, eps, csc, w_src, w_dst, bias, act)
 
 
 class _SpmmMaxFn(torch.autograd.Function):
@@ -1920,6 +1941,21 @@ def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: to
                                                         out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act,
                                                         other.data_ptr(), other.stride(0), mean_out.data_ptr(),
                                                         mean_out.stride(0), int(b_presplit), _stream(out)), "spgnn_gemm_nt_headmean")
+
+
+def gemm_nt_add(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, addend: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                act: int = 0, b_presplit: bool = False) -> torch.Tensor:
+    """act(a @ b^T + bias + addend): the second product of a pair that shares its output (spgnn_gemm_nt_add)."""
+    _require_cuda(a, b, addend)
+    M, K = a.shape
+    N = b.shape[0]
+    assert _rows_aligned(a) and _rows_aligned(b) and addend.shape == (M, N) and _rows_aligned(addend)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
+        _capi.check(_capi.load().spgnn_gemm_nt_add(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                                   M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act, addend.data_ptr(),
+                                                   addend.stride(0), int(b_presplit), _stream(a)), "spgnn_gemm_nt_add")
+    return out
 
 
 def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:

@@ -420,7 +420,7 @@ def test_c_abi_argument_errors_are_reported():
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 2, 4, 0.2, 0, 0.0, 0, 0, 0.0, 0, 0, 0, 0, 0) == -1   # null pointers
     assert b"null" in lib.spgnn_last_error()
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0, 0.0, 0, 0, 0, 0, 0) == -2  # bad shape
-    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op
+    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op
 
 
 @pytest.mark.parametrize("K,J", [(1063, 4), (1064, 4), (39, 2), (768, 4), (192, 4), (256, 2), (64, 16), (100, 8), (17, 4), (600, 22), (520, 4), (1024, 22)])
@@ -522,3 +522,43 @@ def test_act_bwd_with_the_classifier_gradient_formed_on_the_fly(N, H, D, J, act)
     ref = g_mean.repeat(1, H) * dact
     assert rel_err(g_pre, ref) < 2e-6
     assert abs(float(part.max()) - float(g_pre.abs().max())) <= 1e-6 * float(g_pre.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["gcn_hidden", "gcn_out", "gin", "sage_pool", "sage_mean"])
+def test_fused_epilogues_equal_separate_passes(kind, monkeypatch):
+    """bias / activation of GraphConv inside spgnn_spmm_sum's or the GEMM's epilogue, the GIN MLP's
+    LeakyReLUs inside its two products (SPGNN_ACT_LRELU; across the Dropout: act(dropout(y)) == dropout(act(y))), SAGEConv's
+    fc_self + fc_neigh with the addition and the activation in the second product's epilogue - against the same layers with
+    the epilogues as separate torch passes (nn.FUSE_EPILOGUES = False): forward and every gradient within fp32 rounding."""
+    from spgnn_amd import models, synthetic
+    torch.manual_seed(11)
+    g = synthetic.make_batch(6, rank=1, device="cuda", pos_enc_dim=None, fv_dim=8)
+    N = g.number_of_nodes()
+    if kind == "gcn_hidden":
+        layer, fin = snn.GraphConv(256, 128, activation=F.elu).cuda(), 256
+    elif kind == "gcn_out":
+        layer, fin = snn.GraphConv(64, 256, activation=torch.tanh).cuda(), 64
+    elif kind == "gin":
+        layer, fin = snn.GINConv(models._gin_mlp(128, 256), "mean", learn_eps=True).cuda(), 128
+        layer.eval()                                            # (the Dropout inside the MLP draws from torch's generator)
+    else:
+        layer, fin = snn.SAGEConv(128, 64, aggregator_type=kind.split("_")[1], activation=F.elu).cuda(), 128
+    with torch.no_grad():
+        for n_, p in layer.named_parameters():
+            if n_.endswith("bias"):
+                p.normal_(0, 0.1)
+    x0 = torch.randn(N, fin, device="cuda")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(snn, "FUSE_EPILOGUES", fused)
+        x = x0.clone().requires_grad_(True)
+        for p in layer.parameters():
+            p.grad = None
+        y = layer(g, x)
+        (y * torch.linspace(-1, 1, y.shape[1], device="cuda")).sum().backward()
+        res[fused] = (y.detach(), x.grad.detach(), {n_: p.grad.detach().clone() for n_, p in layer.named_parameters() if p.grad is not None})
+    y1, gx1, gp1 = res[True]; y0, gx0, gp0 = res[False]
+    assert rel_err(y1, y0) < 2e-6 and rel_err(gx1, gx0) < 5e-6
+    assert set(gp1) == set(gp0)
+    for n_ in gp0:
+        assert rel_err(gp1[n_], gp0[n_]) < 5e-6, n_
