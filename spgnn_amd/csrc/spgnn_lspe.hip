@@ -176,7 +176,10 @@ __global__ __launch_bounds__(kBlock) void lspe_fwd_kernel(LspeFwd a) {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) w[k][s] = table_get<T, NREG>(al, s * 8 + k, tbase);
 
-  constexpr int kGather = 2;                          // edges per batch: 6 float4 in flight per lane
+#ifndef LSPE_G_FWD
+#define LSPE_G_FWD 2
+#endif
+  constexpr int kGather = LSPE_G_FWD;                 // edges per batch: 6 float4 in flight per lane
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -322,7 +325,10 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_dst_kernel(LspeBwdDst a) {
   float pd[kEnt];
 #pragma unroll
   for (int e = 0; e < kEnt; ++e) pd[e] = 0.f;
-  constexpr int kGather = 2;
+#ifndef LSPE_G_DST
+#define LSPE_G_DST 2
+#endif
+  constexpr int kGather = LSPE_G_DST;
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -469,7 +475,10 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
   float4 acc[kNS];
 #pragma unroll
   for (int r = 0; r < kNS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int kGather = 2;
+#ifndef LSPE_G_SRC
+#define LSPE_G_SRC 2
+#endif
+  constexpr int kGather = LSPE_G_SRC;
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;

@@ -9,6 +9,8 @@ The reference is fp32 only, so there is no reference result in bf16; what is che
   (2) the distance to the true fp64 oracle, bounded by what bf16 storage costs: <= 4x the distance of the storage model
       itself to fp64 (+ a floor), stated per test.
 The fp32 path stays the parity path (tests/test_hip_models.py, 1e-5)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -289,21 +291,57 @@ def test_bf16_model_forward_and_gradients(name):
     cost = rel_err(m_logits, t_logits)
     assert rel_err(logits, t_logits) < 4 * cost + 2 * ULP, (rel_err(logits, t_logits), cost)
     assert rel_err(logits, t_logits) < 0.05            # absolute sanity bound: 7 layers of 2^-9 relative rounding noise
+    # (3) gradients: against an ENVELOPE MEASURED ON THE STORAGE MODEL ITSELF (flat bounds of 0.5 / 0.05 could hide
+    # a real error behind conditioning).  The HIP path differs from the model only by fp32 accumulation order, which moves a
+    # few per cent of the stored values across a bf16 rounding boundary (measured: 3.7 % of a layer's input elements are one
+    # ulp apart).  So the model is re-run FLIP_TRIALS times with that perturbation injected - every store rounds to nearest
+    # and then 4 % of the elements are moved one ulp up or down - and each parameter's gradient may deviate from the
+    # unperturbed model by at most ENV_FACTOR x the largest deviation those trials show for THAT tensor (floor: 2 ulp).  The
+    # attention-vector gradients (sums of g_el[n] * row[n] with sum_n g_el ~ 0: they see only differences between rows)
+    # get a wide envelope because they ARE that sensitive, every weight a tight one (< 1 %); a sign or indexing error moves a
+    # tensor by O(1) of its norm whatever its conditioning.
+    env = _flip_envelope(cfg, model, g, y, mask, w, {n: sd_m[n].grad for n, p in model.named_parameters() if p.requires_grad})
+    report = []
     for n, p in model.named_parameters():
         if not p.requires_grad:
             continue
-        gm, gt = sd_m[n].grad, sd_t[n].grad
+        gm = sd_m[n].grad
         e_model = rel_err(p.grad, gm)
-        e_true, cost_g = rel_err(p.grad, gt), rel_err(gm, gt)
-        if ".attn_" in n:
-            # attention-vector gradients are sums over all nodes of g_el[n] * row[n] with sum_n g_el ~ 0 (softmax shift
-            # invariance): they see only the DIFFERENCES between rows, so one-ulp flips of the large common part of the
-            # input rows move them far more than any other tensor (measured on st_gat_3's output layer: 3.7 % of the input
-            # elements one ulp apart -> 18 % / 27 % on attn_l / attn_r, < 1 % on every weight).  The kernels themselves are
-            # exact against the model on identical inputs: test_bf16_output_layer_exact_on_its_own_inputs below.
-            assert e_model < 0.5, (n, e_model, e_true, cost_g)
-            continue
-        assert e_model < 0.05 or e_true < 4 * cost_g + 0.02, (n, e_model, e_true, cost_g)
+        report.append((n, e_model, env[n]))
+        assert e_model < ENV_FACTOR * env[n] + 2 * ULP, (n, e_model, env[n])
+        assert e_model < 0.6, (n, e_model)                 # and never anywhere near a sign error, whatever the envelope says
+    if os.environ.get("SPGNN_BF16_REPORT"):
+        for n, e, v in report:
+            print(f"{n:45s} hip-vs-model {e:9.3e}   envelope {v:9.3e}   ratio {e / max(v, 1e-12):6.2f}")
+
+
+FLIP_RATE, FLIP_TRIALS, ENV_FACTOR = 0.04, 4, 2.0
+
+
+def _flip_envelope(cfg, model, g, y, mask, w, grads_model):
+    """Per-parameter max over FLIP_TRIALS of the gradient's normwise deviation when every bf16 store of the storage-model
+    oracle additionally moves FLIP_RATE of its elements by one ulp (what a different fp32 accumulation order does to values
+    that sit near a rounding boundary)."""
+    orig = O._rb
+    gen = torch.Generator().manual_seed(1234)
+
+    def flipping(x):
+        r = orig(x)
+        m = torch.rand(r.shape, generator=gen) < FLIP_RATE
+        up = torch.rand(r.shape, generator=gen) < 0.5
+        ulp1 = torch.ldexp(torch.ones_like(r), torch.frexp(r)[1] - 8)          # spacing of bf16 at r (8 significant bits)
+        return torch.where(m & (r != 0), orig(r + torch.where(up, ulp1, -ulp1)), r)
+    env = {n: 0.0 for n in grads_model}
+    try:
+        O._rb = flipping
+        for _ in range(FLIP_TRIALS):
+            (lg, _e), sd = _oracle_logits(cfg, model, g, torch.float64, O.Bf16Storage, grad=True)
+            O.masked_weighted_ce(lg, y.cpu(), mask, w.double()).backward()
+            for n in env:
+                env[n] = max(env[n], rel_err(sd[n].grad, grads_model[n]))
+    finally:
+        O._rb = orig
+    return env
 
 
 @pytest.mark.parametrize("name", ["st_gat_6", "st_gat_3"])

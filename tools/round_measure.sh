@@ -5,7 +5,7 @@
 #  2. bench.py under rocprofv3 --kernel-trace --stats for both -> profiles/<tag>_kernel_stats_*.{csv,md}
 #  3. the plain bench lines (with the CPU baseline) -> profiles/<tag>_bench_*.json
 # Everything judged is ALSO copied under gpurun_out/<tag>/profiles/ so it travels back.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O/profiles
 cd /tmp && export TMPDIR=/tmp
 pmc() {  # <config> <dtype>
@@ -16,19 +16,20 @@ pmc() {  # <config> <dtype>
 }
 prof() {  # <config> <dtype>
   local c=$1 dt=$2 D=$O/prof_${1}_${2}
-  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt} -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline"
-  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline > $D.log 2> $D.err) || return 1
+  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt} -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline --no-secondary"
+  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline --no-secondary > $D.log 2> $D.err) || return 1
   grep '^{' $D.log | tail -1 > $D.json
   (cd $R && python3 tools/save_profile.py $D $TAG $D.json "$CMD" > $D.summary.txt)
 }
 pmc st_pgat_spgnn_3 f32 && pmc st_gat_6 bf16 && prof st_pgat_spgnn_3 f32 && prof st_gat_6 bf16 || echo "MEASURE STEP FAILED"
 cd $R
-python bench.py > $O/bench_f32.log 2> $O/bench_f32.err; grep '^{' $O/bench_f32.log | tail -1 > profiles/${TAG}_bench_st_pgat_spgnn_3_f32.json
-python bench.py --config st_gat_6 --dtype bf16 > $O/bench_bf16.log 2> $O/bench_bf16.err; grep '^{' $O/bench_bf16.log | tail -1 > profiles/${TAG}_bench_st_gat_6_bf16.json
+python bench.py --no-secondary > $O/bench_f32.log 2> $O/bench_f32.err; grep '^{' $O/bench_f32.log | tail -1 > profiles/${TAG}_bench_st_pgat_spgnn_3_f32.json
+python bench.py --config st_gat_6 --dtype bf16 --no-secondary > $O/bench_bf16.log 2> $O/bench_bf16.err; grep '^{' $O/bench_bf16.log | tail -1 > profiles/${TAG}_bench_st_gat_6_bf16.json
 for c in st_gat_3 st_gat_6 st_gcn_3 st_gin_3 st_sage_3; do
   python bench.py --config $c --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | grep '^{' | tail -1 > $O/cfg_${c}_f32.json
 done
-python bench.py --trees 64 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/cfg_headline_64trees.json
+python bench.py --trees 64 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > $O/cfg_headline_64trees.json
+python bench.py > $O/bench_default.log 2> $O/bench_default.err; grep '^{' $O/bench_default.log | tail -1 > profiles/${TAG}_bench_default_with_secondary_legs.json
 cp profiles/${TAG}_* profiles/traffic_latest.json $O/profiles/
 python - <<P
 import json, glob, os
