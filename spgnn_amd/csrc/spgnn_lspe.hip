@@ -176,10 +176,7 @@ __global__ __launch_bounds__(kBlock) void lspe_fwd_kernel(LspeFwd a) {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) w[k][s] = table_get<T, NREG>(al, s * 8 + k, tbase);
 
-#ifndef LSPE_G_FWD
-#define LSPE_G_FWD 2
-#endif
-  constexpr int kGather = LSPE_G_FWD;                 // edges per batch: 6 float4 in flight per lane
+  constexpr int kGather = 2;                          // edges per batch: 6 float4 in flight per lane (1, 4, 8 measured: no better)
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -325,10 +322,7 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_dst_kernel(LspeBwdDst a) {
   float pd[kEnt];
 #pragma unroll
   for (int e = 0; e < kEnt; ++e) pd[e] = 0.f;
-#ifndef LSPE_G_DST
-#define LSPE_G_DST 2
-#endif
-  constexpr int kGather = LSPE_G_DST;
+  constexpr int kGather = 2;
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
@@ -475,10 +469,7 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
   float4 acc[kNS];
 #pragma unroll
   for (int r = 0; r < kNS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef LSPE_G_SRC
-#define LSPE_G_SRC 2
-#endif
-  constexpr int kGather = LSPE_G_SRC;
+  constexpr int kGather = 2;
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;

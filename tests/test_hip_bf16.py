@@ -315,7 +315,11 @@ def test_bf16_model_forward_and_gradients(name):
             print(f"{n:45s} hip-vs-model {e:9.3e}   envelope {v:9.3e}   ratio {e / max(v, 1e-12):6.2f}")
 
 
-FLIP_RATE, FLIP_TRIALS, ENV_FACTOR = 0.04, 4, 2.0
+# Twelve trials, not four: the deviation of an attention vector's gradient is dominated by DISCRETE events - a flip that moves
+# one edge's el + er across the LeakyReLU kink changes its slope from 1 to 0.2 - so its distribution over trials is bimodal
+# (st_gat_3 output layer, attn_l: median 0.02-0.05, but 0.177 in the trials where the event occurs - exactly the HIP path's
+# own deviation, 0.177; attn_r: 0.274 both ways; tools/env_diag.py).  The maximum over twelve trials at either flip rate sees it.
+FLIP_RATE, FLIP_TRIALS, ENV_FACTOR = 0.04, 12, 1.5
 
 
 def _flip_envelope(cfg, model, g, y, mask, w, grads_model):
