@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 35
+#define SPGNN_ABI_VERSION 36
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -502,6 +502,18 @@ int spgnn_tree_anchors(const float* prob, int64_t prob_stride, const int32_t* ou
 int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,
                     const float* sampling_p, const float* class_weight, float* partials,
                     float* g_logits, int64_t g_stride, int64_t N, int32_t C, spgnn_stream_t stream);
+/*
+ * The same pass as the training step issues it.  `draws` nullable: rn_i = 24 bits of the kernels' counter hash of
+ * (draw_seed + 0xD1B54A32D192ED03 * seed_offset[0], i) / 2^24 - `seed_offset` (nullable, device int64) is the step counter a
+ * captured step reads, so every replay draws a fresh mask (the reference draws its GCN_STEPS x N matrix with numpy up
+ * front, job_runner.py:1889-1890).  `sums` (nullable, 2 floats) with `ticket` (one uint32, zero before the first launch;
+ * the kernel re-arms it): the workgroup that arrives last adds the per-block pairs in block order and writes
+ * [sum m w nll, sum m w] - what `partials.sum(0)` gives, without a reduction launch, bitwise independent of arrival order.
+ */
+int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                         const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
+                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, int64_t N, int32_t C,
+                         spgnn_stream_t stream);
 
 /*
  * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's
@@ -539,6 +551,20 @@ int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf
                             const float* grad_scale, const float* lr_dev /* nullable: overrides lr (graph replay) */,
                             int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
                             spgnn_stream_t stream);
+/*
+ * The same update when the step's loss is a class-weighted MEAN: `weight_sum` (device scalar, the global sum of class
+ * weights after the all-reduce) replaces grad_scale = 1 / weight_sum, and - `loss_out` non-null - the first thread also
+ * writes loss_out[0] = loss_num[0] / weight_sum[0] (the reciprocal and the loss scalar were two launches).
+ */
+int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentum_buf, const float* weight_sum,
+                                 const float* loss_num, float* loss_out, const float* lr_dev, int64_t n, float lr,
+                                 float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream);
+/*
+ * What a training step arms before its first kernel, in one launch: `counter` (nullable, device int64: the dropout / mask
+ * stream position the kernels read through their `seed_offset` arguments) += 1, and the `n_scale_blocks` scale blocks at
+ * `scale_blocks` (260 floats each, see spgnn_gemm_nt) return to {-256, 0, 0, 0, 0 x 256}.
+ */
+int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, spgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16-storage path (BASELINE.json config 4: st_gat_6, 512 trees, bf16; reference precision hook
@@ -769,14 +795,16 @@ int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* t
                     int64_t E, spgnn_stream_t stream);
 
 /* =================================================================================================
- * Weight operands of every projection layer of a model, per training step, in one call (two kernel launches + a 4-byte-per-
- * layer memset) instead of spgnn_weight_cat + spgnn_presplit per layer.  `table` (DEVICE memory, n_layers entries): per layer
+ * Weight operands of every projection layer of a model, per training step, in one call (two kernel launches) instead of spgnn_weight_cat + spgnn_presplit per layer.  `table` (DEVICE memory, n_layers entries): per layer
  * the two row blocks a (rows_a x K) / b (rows_b x K, nullable) - fc.weight and res_fc.weight of a GATConv (reference
  * models.py:425-456) - and the outputs: dst = [a; b] with 16-byte rows (row stride dst_stride = K rounded up to 4, pad
  * columns zero), dst_t = its transpose (K rows, row stride dst_t_stride = rows rounded up to 4; nullable together with ps_t),
  * ps / ps_t = the same two matrices in the pre-split form spgnn_gemm_nt takes with b_presplit, scale = the operand's
  * power-of-two scale (one float).  first_block = running sum of spgnn_weight_prep_blocks over the earlier entries;
- * total_blocks = the sum over all; maxwords: n_layers words of scratch.  Results are bit-identical to the per-layer calls.
+ * total_blocks = the sum over all; workspace: total_blocks floats of scratch (no initialisation needed).  Results are bit-identical
+ * to the per-layer calls.  mode 0: [a; b] as above.  mode 1: the COLUMN concatenation [a | b] (rows_a rows, K = all columns,
+ * rows_b = the columns `a` contributes; b nullable with rows_b = K) - the aggregate-first output layer's per-head operand
+ * [W_fc,h | W_res,h] (spgnn_gat_agg_fwd); head h of the transpose is the column block [h D, (h+1) D) of dst_t / ps_t.
  * ================================================================================================= */
 typedef struct spgnn_weight_prep_layer {
   const float* a; int64_t a_stride; const float* b; int64_t b_stride;
@@ -784,11 +812,11 @@ typedef struct spgnn_weight_prep_layer {
   float* dst_t; float* ps_t; int64_t dst_t_stride;
   float* scale;
   int64_t first_block;
-  int32_t rows_a; int32_t rows_b; int32_t K; int32_t reserved;
+  int32_t rows_a; int32_t rows_b; int32_t K; int32_t mode;
 } spgnn_weight_prep_layer;
 
 int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride);
-int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, uint32_t* maxwords,
+int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, float* workspace,
                       spgnn_stream_t stream);
 
 /* Up to 8 of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two attention-vector

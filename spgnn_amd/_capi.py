@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -47,7 +47,7 @@ class SumJob(C.Structure):               # spgnn_sum_job
 class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
     _fields_ = [("a", _vp), ("a_stride", _i64), ("b", _vp), ("b_stride", _i64), ("dst", _vp), ("ps", _vp), ("dst_stride", _i64),
                 ("dst_t", _vp), ("ps_t", _vp), ("dst_t_stride", _i64), ("scale", _vp), ("first_block", _i64), ("rows_a", _i32),
-                ("rows_b", _i32), ("K", _i32), ("reserved", _i32)]
+                ("rows_b", _i32), ("K", _i32), ("mode", _i32)]
 
 
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
@@ -100,6 +100,9 @@ SIGNATURES = {
     "spgnn_cat_dropout_blocks": [_i64, _i32],
     "spgnn_scores_from_parts": [_f32p, _f32p, _i64, _i64, _i32, _i32, _vp],
     "spgnn_masked_ce": [_f32p, _i64, _vp, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i32, _vp],
+    "spgnn_masked_ce_step": [_f32p, _i64, _vp, _f32p, _u64, _vp, _f32p, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _i64, _i32, _vp],
+    "spgnn_sgd_momentum_step_mean": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
+    "spgnn_step_begin": [_vp, _f32p, _i32, _vp],
     "spgnn_sample_neighbors": [_i32p, _i32p, _i32p, _i64, _vp, _i64, _i32, _i32p, _u64, _i32p, _i32p, _i32p, _i32p, _vp],
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],
     "spgnn_head_mean": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _vp],

@@ -749,7 +749,7 @@ struct ArgsTN {
   int nbm, nbn;
   float* colsum;                                  // optional per-split column sums of A (bias gradient):
   int64_t cs_stride, cs_split_stride;             //   element (split, m) at colsum[split * cs_split_stride + m * cs_stride]
-  int by_xcd;                                     // pipelined kernel: 1-D grid, one split per XCD (splits % 8 == 0)
+  int splits;
 };
 
 // fragment of the 32 (m) x 16 (k) operand block whose first column is m0 and first k-row is k0
@@ -781,22 +781,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];          // 2 stages x (Ah | Al | Bh | Bl)
   constexpr int STAGE = 4 * TTILE;
 
-  // Placement.  Every tile of one split streams the same row range of both operands, so a split is given to ONE
-  // XCD (workgroups go to XCDs round-robin by linear id): the range is fetched into that XCD's L2 once and the
-  // tiles' re-reads (8-9x per operand at 128x128 tiles) are L2 hits instead of fabric traffic.  Needs
-  // splits % 8 == 0 (a.by_xcd); otherwise tiles are spread as in the NT kernel.
-  unsigned tile, split;
-  if (a.by_xcd) {
-    const unsigned L = blockIdx.x, tiles = (unsigned)(a.nbm * a.nbn);
-    const unsigned xcd = L & 7u, q = L >> 3;
-    split = xcd + 8u * (q / tiles);
-    tile = q % tiles;
-  } else {
-    const unsigned nb = gridDim.x, b = blockIdx.x;
-    tile = (b & 7u) * (nb >> 3) + (b >> 3);
-    split = blockIdx.y;
-    if (tile >= (unsigned)(a.nbm * a.nbn)) return;
-  }
+  // Placement.  Every tile of one split streams the same row range of both operands, so the (split, tile) work items,
+  // split-major, are dealt to the XCDs in eight CONTIGUOUS ranges (workgroups go to XCDs round-robin by linear id): an
+  // XCD works on one or two splits at a time, their row ranges are fetched into that XCD's L2 once and the tiles'
+  // re-reads (8-9x per operand at 128x128 tiles) are L2 hits instead of fabric traffic.  Any split count works, so the
+  // caller picks the one whose workgroup count fills whole rounds of the chip (2 per CU).  The grid is padded to a
+  // multiple of 8; the pad workgroups leave at once.
+  const unsigned tiles_ = (unsigned)(a.nbm * a.nbn);
+  const unsigned w_ = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (w_ >= tiles_ * (unsigned)a.splits) return;
+  const unsigned split = w_ / tiles_, tile = w_ % tiles_;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
   const int m0 = bm * BM, n0 = bn * BN;
   const int64_t r_beg = (int64_t)split * a.rows_per_split;
@@ -1265,18 +1259,20 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 // -------------------------------------------------------------------------------------------------
 // spgnn_weight_prep: the weight operands of EVERY projection layer of a model in two launches per step instead of two per
 // layer (spgnn_weight_cat + spgnn_presplit each): a table of layers, one 32 x 32 tile per workgroup, the table entry found
-// from the block index.  Pass 0 folds |max| of each layer's [A; B] into one word per layer (atomicMax on the bit pattern of
-// a non-negative float: order-independent, so the scale is deterministic); pass 1 derives the power-of-two scale from it and
-// writes the four images the GEMMs take: [A; B] with 16-byte rows, its transpose, and both in pre-split form.
+// from the block index.  Pass 0 leaves max |.| of every tile in one word per workgroup (plain stores: 2 400 atomicMax on a
+// dozen addresses serialised to 24 us, three times the copy itself); pass 1 folds its layer's words (a maximum: order-
+// independent, so the scale is deterministic), derives the power-of-two scale and writes the four images the GEMMs take:
+// [A; B] with 16-byte rows, its transpose, and both in pre-split form.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_prep_layer* __restrict__ tab, int n_layers,
-                                                          unsigned* __restrict__ maxwords, int pass) {
+                                                          float* __restrict__ blockmax, int pass) {
   __shared__ float tile[32][33];
   __shared__ float red[4];
   int l = 0;
   while (l + 1 < n_layers && (int64_t)blockIdx.x >= tab[l + 1].first_block) ++l;
   const spgnn_weight_prep_layer L = tab[l];
-  const int R = L.rows_a + L.rows_b, K = L.K;
+  const bool cols = L.mode == 1;                         // [a | b]: rows_b = the columns a contributes
+  const int R = cols ? L.rows_a : L.rows_a + L.rows_b, K = L.K;
   const int tiles_x = (int)((L.dst_stride + 31) / 32);
   const int b = (int)(blockIdx.x - L.first_block);
   const int r0 = (b / tiles_x) * 32, c0 = (b % tiles_x) * 32;
@@ -1286,7 +1282,10 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 8 * i, c = c0 + tx;
     float v = 0.f;
-    if (r < R && c < K) v = r < L.rows_a ? L.a[(int64_t)r * L.a_stride + c] : L.b[(int64_t)(r - L.rows_a) * L.b_stride + c];
+    if (r < R && c < K) {
+      if (cols) v = c < L.rows_b ? L.a[(int64_t)r * L.a_stride + c] : L.b[(int64_t)r * L.b_stride + c - L.rows_b];
+      else v = r < L.rows_a ? L.a[(int64_t)r * L.a_stride + c] : L.b[(int64_t)(r - L.rows_a) * L.b_stride + c];
+    }
     tile[ty + 8 * i][tx] = v;
     m = fmaxf(m, fabsf(v));
   }
@@ -1294,12 +1293,17 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&maxwords[l], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     return;
   }
-  const float sc = pow2_scale_of(__uint_as_float(maxwords[l]));
-  if (b == 0 && threadIdx.x == 0) L.scale[0] = sc;
+  const int64_t lb_end = l + 1 < n_layers ? tab[l + 1].first_block : (int64_t)gridDim.x;
+  float lm = 0.f;
+  for (int64_t q = L.first_block + threadIdx.x; q < lb_end; q += 256) lm = fmaxf(lm, blockmax[q]);
+  for (int off = 32; off > 0; off >>= 1) lm = fmaxf(lm, __shfl_xor(lm, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lm;
   __syncthreads();
+  const float sc = pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  if (b == 0 && threadIdx.x == 0) L.scale[0] = sc;
   // one group of four per thread: rows of the tile for dst / ps, columns of the tile (rows of the transpose) for dst_t / ps_t
   const int gr = threadIdx.x >> 3, gc = (threadIdx.x & 7) * 4;
   {
@@ -1477,19 +1481,12 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
   gemm::ArgsTN a{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, 0};
-  int64_t tiles = (int64_t)a.nbm * a.nbn;
-  tiles = (tiles + 7) & ~int64_t(7);
+                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, (int)splits};
+  const int64_t blocks = ((int64_t)a.nbm * a.nbn * splits + 7) & ~int64_t(7);
+  if (blocks > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
   { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-  if (splits % 8 == 0) {              // one split per XCD: its row range is fetched into that XCD's L2 once
-    a.by_xcd = 1;
-    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)((int64_t)a.nbm * a.nbn * splits)), dim3(gemm::kThreads), lds_bytes,
-                       (hipStream_t)stream, a);
-  } else {
-    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)tiles, (unsigned)splits), dim3(gemm::kThreads), lds_bytes,
-                       (hipStream_t)stream, a);
-  }
+  hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, a);
   return spgnn_detail::check_launch("spgnn_gemm");
 }
 
@@ -1627,16 +1624,14 @@ int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t
   return ((dst_stride + 31) / 32) * ((tall + 31) / 32);
 }
 
-int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, uint32_t* maxwords,
+int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, float* workspace,
                       spgnn_stream_t stream) {
   if (n_layers < 0 || total_blocks < 0 || total_blocks > (1ll << 30)) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (n_layers == 0 || total_blocks == 0) return SPGNN_OK;
-  if (!table || !maxwords) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (!table || !workspace) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(maxwords, 0, sizeof(uint32_t) * (size_t)n_layers, st);
-  if (e != hipSuccess) return spgnn_detail::fail_at(-(1000 + (int)e), __func__, __LINE__);
-  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, maxwords, 0);
-  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, maxwords, 1);
+  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, workspace, 0);
+  hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, workspace, 1);
   return spgnn_detail::check_launch("spgnn_weight_prep");
 }
 

@@ -2266,16 +2266,24 @@ __global__ __launch_bounds__(64) void distal_leafs_kernel(const int32_t* __restr
 // =================================================================================================
 // Masked, class-weighted cross entropy in one pass (reference job_runner.py:1896-1900:
 // mask = rn < sampling_t; loss = F.cross_entropy(pre[mask], y[mask], weight=w)).  One thread per node:
-//   m_i = draws[i] < sampling_p[i];  nll_i = logsumexp(logits[i,:]) - logits[i, y_i]
+//   m_i = rn_i < sampling_p[i];  nll_i = logsumexp(logits[i,:]) - logits[i, y_i]
 //   partial[block] = (sum m_i w[y_i] nll_i, sum m_i w[y_i])          (numerator, denominator of the weighted mean)
 //   g_logits[i,c]  = m_i w[y_i] (softmax(logits[i,:])_c - [c == y_i])  (gradient of the NUMERATOR)
 // No boolean indexing (no host sync), no separate log-softmax / gather / multiply / reduce launches.
+// rn_i comes from `draws`, or - `draws` null - from the kernels' counter hash: 24 bits of mix64(seed + offset, i), the
+// offset read from device memory so that a captured step draws a fresh mask on every replay (the reference draws the
+// GCN_STEPS x N matrix with numpy up front, job_runner.py:1889: neither stream can reproduce the other).
+// With `sums` the block that arrives last (ticket counter, reset by it) adds the per-block pairs in block order: the
+// two totals without a reduction launch, bitwise independent of the arrival order.
 // =================================================================================================
 __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ draws, const float* __restrict__ sampling_p,
+                                                           const float* __restrict__ draws, uint64_t draw_seed,
+                                                           const int64_t* __restrict__ seed_off, const float* __restrict__ sampling_p,
                                                            const float* __restrict__ class_w, float* __restrict__ partial,
+                                                           float* __restrict__ sums, unsigned* __restrict__ ticket,
                                                            float* __restrict__ g_logits, int64_t g_ld, int64_t N, int C) {
   __shared__ float red[2][kBlock / 64];
+  __shared__ bool last;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   float num = 0.f, den = 0.f;
   if (i < N) {
@@ -2283,7 +2291,13 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
     const int64_t yl = labels[i];
     const bool y_ok = yl >= 0 && yl < C;                     // F.cross_entropy raises for such a label; here the node gets a
     const int y = y_ok ? (int)yl : 0;                        // NaN weight, so the loss is NaN instead of an out-of-bounds read
-    const float m = draws[i] < sampling_p[i] ? 1.f : 0.f;
+    float rn;
+    if (draws) rn = draws[i];
+    else {
+      const uint64_t sd = draw_seed + (seed_off ? 0xD1B54A32D192ED03ull * (uint64_t)seed_off[0] : 0ull);
+      rn = (float)(uint32_t)(mix64(sd, i) >> 40) * (1.0f / 16777216.0f);
+    }
+    const float m = rn < sampling_p[i] ? 1.f : 0.f;
     const float w = y_ok ? m * class_w[y] : NAN;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
@@ -2306,6 +2320,30 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < kBlock / 64; ++q) { a += red[0][q]; b += red[1][q]; }
     partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = b;
+    if (sums) {
+      __threadfence();                                       // the pair is visible device-wide before the ticket is taken
+      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+  }
+  if (!sums) return;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float a = 0.f, b = 0.f;                                    // thread t: blocks t, t + 256, ... in ascending order
+  for (unsigned q = threadIdx.x; q < gridDim.x; q += kBlock) {
+    a += __hip_atomic_load(partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b += __hip_atomic_load(partial + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  a = team_sum(a, 64); b = team_sum(b, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float x = 0.f, y = 0.f;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) { x += red[0][q]; y += red[1][q]; }
+    sums[0] = x; sums[1] = y;
+    *ticket = 0u;                                            // re-armed for the next launch on the stream
   }
 }
 
@@ -2313,9 +2351,11 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
 // SGD + momentum over a flat bucket
 // =================================================================================================
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    const float* __restrict__ gscale, const float* __restrict__ lr_dev, int64_t n, float lr,
-                                    float mom, float wd, int first) {
-  const float sc = gscale ? gscale[0] : 1.f;
+                                    const float* __restrict__ gscale, const float* __restrict__ gdenom,
+                                    const float* __restrict__ loss_num, float* __restrict__ loss_out,
+                                    const float* __restrict__ lr_dev, int64_t n, float lr, float mom, float wd, int first) {
+  const float sc = gdenom ? 1.f / gdenom[0] : (gscale ? gscale[0] : 1.f);
+  if (loss_out && blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = loss_num[0] * sc;
   if (lr_dev) lr = lr_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float w = p[i];
@@ -2324,6 +2364,15 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     buf[i] = b;
     p[i] = w - lr * b;
   }
+}
+
+// The device state a training step arms before its first kernel, in one launch: the dropout / mask counter advances and
+// every scale block of the step's pool returns to {-256, 0, 0, 0, 0 x 256} (spgnn_internal.h).
+__global__ __launch_bounds__(kBlock) void step_begin_kernel(int64_t* __restrict__ counter, float* __restrict__ blocks, int64_t words) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0 && counter) counter[0] += 1;
+  constexpr int W = spgnn_detail::kScaleHeader + spgnn_detail::kScaleSlots;
+  if (i < words) blocks[i] = (i % W == 0) ? -(float)spgnn_detail::kScaleSlots : 0.f;
 }
 
 // T < 64 only occurs with R = 1 (pick_team tries 64 lanes first)
@@ -3263,12 +3312,25 @@ int spgnn_tree_anchors(const float* prob, int64_t prob_stride, const int32_t* ou
 int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws,
                     const float* sampling_p, const float* class_weight, float* partials, float* g_logits, int64_t g_stride,
                     int64_t N, int32_t C, spgnn_stream_t stream) {
+  if (!draws) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
+  return spgnn_masked_ce_step(logits, logits_stride, labels, draws, 0, nullptr, sampling_p, class_weight, partials, nullptr, nullptr,
+                              g_logits, g_stride, N, C, stream);
+}
+
+int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                         const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
+                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, int64_t N, int32_t C,
+                         spgnn_stream_t stream) {
   if (N < 0 || C <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_masked_ce: bad N/C");
-  if (N == 0) return SPGNN_OK;
-  if (!logits || !labels || !draws || !sampling_p || !class_weight || !partials) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
+  if (N == 0) {
+    if (sums) { const hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return fail(-(1000 + (int)e), "spgnn_masked_ce_step: hipMemsetAsync"); }
+    return SPGNN_OK;
+  }
+  if (!logits || !labels || !sampling_p || !class_weight || !partials || (sums && !ticket)) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
   if (logits_stride < C || (g_logits && g_stride < C)) return fail(SPGNN_ERR_STRIDE, "spgnn_masked_ce: row stride smaller than row");
   hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits,
-                     logits_stride, labels, draws, sampling_p, class_weight, partials, g_logits, g_stride, N, C);
+                     logits_stride, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, partials, sums, ticket, g_logits,
+                     g_stride, N, C);
   return check_launch("spgnn_masked_ce");
 }
 
@@ -3302,17 +3364,43 @@ int spgnn_block_relabel(const int32_t* flag, const int32_t* rank, int32_t* local
   return check_launch("spgnn_block_relabel");
 }
 
+static int sgd_launch(float* param, const float* grad, float* momentum_buf, const float* grad_scale, const float* grad_denom,
+                      const float* loss_num, float* loss_out, const float* lr_dev, int64_t n, float lr, float momentum,
+                      float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+  if (n < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sgd_momentum_step: n < 0");
+  if (n == 0 && !loss_out) return SPGNN_OK;
+  if (!param || !grad || !momentum_buf || (loss_out && !loss_num)) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step: null pointer");
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, param, grad,
+                     momentum_buf, grad_scale, grad_denom, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay, first_step);
+  return check_launch("spgnn_sgd_momentum_step");
+}
+
 int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf, const float* grad_scale,
                             const float* lr_dev, int64_t n, float lr, float momentum, float weight_decay,
                             int32_t first_step, spgnn_stream_t stream) {
-  if (n < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sgd_momentum_step: n < 0");
-  if (n == 0) return SPGNN_OK;
-  if (!param || !grad || !momentum_buf) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step: null pointer");
-  int64_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, grad_scale, lr_dev, n, lr, momentum, weight_decay, first_step);
-  return check_launch("spgnn_sgd_momentum_step");
+  return sgd_launch(param, grad, momentum_buf, grad_scale, nullptr, nullptr, nullptr, lr_dev, n, lr, momentum, weight_decay,
+                    first_step, stream);
+}
+
+int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentum_buf, const float* weight_sum,
+                                 const float* loss_num, float* loss_out, const float* lr_dev, int64_t n, float lr,
+                                 float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+  if (!weight_sum) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step_mean: null pointer");
+  return sgd_launch(param, grad, momentum_buf, nullptr, weight_sum, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay,
+                    first_step, stream);
+}
+
+int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, spgnn_stream_t stream) {
+  if (n_scale_blocks < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_step_begin: n_scale_blocks < 0");
+  if (n_scale_blocks > 0 && !scale_blocks) return fail(SPGNN_ERR_NULLPTR, "spgnn_step_begin: null pointer");
+  if (!counter && n_scale_blocks == 0) return SPGNN_OK;
+  const int64_t words = (int64_t)n_scale_blocks * (spgnn_detail::kScaleHeader + spgnn_detail::kScaleSlots);
+  const int64_t blocks = words > 0 ? (words + kBlock - 1) / kBlock : 1;
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, counter, scale_blocks, words);
+  return check_launch("spgnn_step_begin");
 }
 
 }  // extern "C"

@@ -66,18 +66,19 @@ def _fuse_plan(layer, nxt, x: torch.Tensor, extra_width: int, seed: Optional[int
     return total, p, ((_draw_seed() if seed is None else seed) if p > 0.0 else 0), ops.fused_extra_partials(x.shape[0], extra_width)
 
 
-def _prep_specs(levels, on_gpu: bool):
-    """(fc.weight, res_fc.weight or None, want_t) of the project-first layers of a forward pass, level by level (each level a
-    layer or a tuple of layers): the input of the first level is node data, so only later levels need the transposed operand
-    (their input gradient), and none does without autograd."""
+def _prep_specs(levels, on_gpu: bool, output=None):
+    """The ops.prepared_weights entries of a forward pass, level by level (each level a layer or a tuple of layers; GATConv.
+    prep_spec): the input of the first level is node data, so only later levels need the transposed operand (their input
+    gradient), and none does without autograd.  ``output``: the last layer, whose heads are averaged."""
     if not on_gpu:
         return []
     specs = []
     for l, layers in enumerate(levels):
         for layer in (layers if isinstance(layers, tuple) else (layers,)):
-            w_b = layer.res_fc.weight if isinstance(layer.res_fc, nn.Linear) else None
-            specs.append((layer.fc.weight, w_b, torch.is_grad_enabled() and l > 0))
-    return specs
+            specs.append(layer.prep_spec(torch.is_grad_enabled() and l > 0))
+    if output is not None:
+        specs.append(output.prep_spec(torch.is_grad_enabled(), mean_heads=True))
+    return [sp for sp in specs if sp is not None]
 
 
 FUSE_LSPE = True               # GATPSPGNN: structure + position GATConv of a level in ONE traversal (ops.lspe_level); False: two layers
@@ -197,7 +198,7 @@ class GAT(nn.Module):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))`` with the classifier
         joined to the output layer's autograd node (not with ``norm``: the normalisation sits in between)."""
         h = _data_in(g, g.ndata["fvs"], self.storage_dtype)
-        with ops.prepared_weights(_prep_specs(self.gat_layers[:-1], h.is_cuda and h.dtype == torch.float32)):
+        with ops.prepared_weights(_prep_specs(self.gat_layers[:-1], h.is_cuda and h.dtype == torch.float32, output=self.gat_layers[-1])):
             return self._forward(g, h, classifier)
 
     def _forward(self, g, h, classifier):
@@ -333,7 +334,7 @@ class GATPSPGNN(nn.Module):
         classifier joined to the output layer's autograd node."""
         h_p, h_s = g.ndata["pos_enc"], g.ndata["fvs"]
         x, dropped = _data_cat(g, h_s, h_p), False
-        with ops.prepared_weights(_prep_specs(zip(self.gat_layers[:-1], self.pgnn_layers), x.is_cuda)):
+        with ops.prepared_weights(_prep_specs(zip(self.gat_layers[:-1], self.pgnn_layers), x.is_cuda, output=self.gat_layers[-1])):
             return self._forward(g, x, h_p, dropped, classifier)
 
     def _forward(self, g, x, h_p, dropped, classifier):

@@ -267,6 +267,24 @@ class GATConv(nn.Module):
                                       mean=fuse_mean)
         return self._finish(out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=drop)
 
+    def prep_spec(self, want_t: bool, mean_heads: bool = False):
+        """This layer's entry for ops.prepared_weights, from its static shape (what forward() will pick for an fp32 input):
+        the aggregate-first form with an activation takes [W_fc | W_res] (``"cols"``), the linear-mean form assembles its
+        own operand (None), every other layer the row concatenation [W_fc ; W_res]."""
+        H, D, F_in = self._num_heads, self._out_feats, self._in_src_feats
+        has_res = isinstance(self.res_fc, nn.Linear)
+        act = _act_code(self.activation)
+        w_b = self.res_fc.weight if has_res else None
+        agg_first = (AGGREGATE_FIRST and act is not None and not isinstance(self.res_fc, Identity) and F_in < D
+                     and ops.agg_first_supported(H, F_in))
+        if not agg_first:
+            return (self.fc.weight, w_b, want_t)
+        if LINEAR_MEAN and mean_heads and act == ops.ACT_NONE and (H + 1) * F_in <= H * D:
+            return None
+        if F_in % 4 or D % 4:
+            return None
+        return (self.fc.weight, w_b, want_t, "cols")
+
     def _finish(self, out, attn, csc, h, H, D, fuse_mean, fuse_epilogue, identity_res, mean_heads, get_attention, drop=None):
         """``drop`` = (p, seed) of the attention dropout this forward used (training mode, p > 0), else None."""
         rst = out if fuse_mean else out.view(-1, H, D)

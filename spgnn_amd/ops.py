@@ -315,8 +315,12 @@ class ScalePool:
         self.buf = _scale_template(self.device, capacity).clone()
         self.cursor, self.active = 0, False
 
-    def begin(self):
-        self.buf.copy_(_scale_template(self.device, self.capacity))
+    def begin(self, counter: Optional[torch.Tensor] = None):
+        """Re-arm every block; ``counter`` (device int64 scalar, optional) advances by one in the same launch
+        (spgnn_step_begin): the step's dropout / mask stream position."""
+        with torch.cuda.device(self.device):
+            _capi.check(_capi.load().spgnn_step_begin(_ptr(counter), self.buf.data_ptr(), self.capacity, _stream(self.buf)),
+                        "spgnn_step_begin")
         self.cursor, self.active = 0, True
 
     def end(self):
@@ -567,27 +571,34 @@ class _MaskedCE(torch.autograd.Function):
     """(logits, labels, draws, sampling_p, class_weight) -> [numerator, denominator] of the masked class-weighted
     cross entropy (train.weighted_nll_sums) in one kernel that also leaves the numerator's gradient behind."""
 
-    _out = None          # (2,) fp32 slot for [num, den], set by masked_ce_sums for one call (not an autograd input: the outputs
-                         # would otherwise count as views of an input)
+    _opts = None         # per-call options set by masked_ce_sums (not autograd inputs: ``out`` would otherwise make the outputs
+                         # count as views of an input)
+    _tickets: dict = {}
 
     @staticmethod
     def forward(ctx, logits, labels, draws, sampling_p, class_weight):
-        out, _MaskedCE._out = _MaskedCE._out, None
+        opts, _MaskedCE._opts = (_MaskedCE._opts or {}), None
+        out, seed, unit = opts.get("out"), opts.get("draw_seed", 0), bool(opts.get("unit_grad"))
         N, C = logits.shape
         if logits.stride(1) != 1:
             logits = logits.contiguous()
+        dev = logits.device
         nb = (N + 255) // 256
-        part = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=logits.device)
-        g = torch.empty((N, C), dtype=torch.float32, device=logits.device) if ctx.needs_input_grad[0] else None
-        if N == 0:
-            part.zero_()
-        with torch.cuda.device(logits.device), _timed("masked_ce", (N, C)):
-            _capi.check(_capi.load().spgnn_masked_ce(logits.data_ptr(), logits.stride(0), labels.data_ptr(), draws.data_ptr(),
-                                                     sampling_p.data_ptr(), class_weight.data_ptr(), part.data_ptr(), _ptr(g),
-                                                     C, N, C, _stream(logits)), "spgnn_masked_ce")
+        part = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=dev)
+        g = torch.empty((N, C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        s = out if out is not None else torch.empty((2,), dtype=torch.float32, device=dev)
+        ticket = _MaskedCE._tickets.get(str(dev))
+        if ticket is None:
+            ticket = _MaskedCE._tickets[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev), _timed("masked_ce", (N, C)):
+            # the last workgroup adds the per-block pairs (block order): no reduction launch
+            _capi.check(_capi.load().spgnn_masked_ce_step(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                          _seed_off_ptr(dev) if draws is None else 0, sampling_p.data_ptr(),
+                                                          class_weight.data_ptr(), part.data_ptr(), s.data_ptr(), ticket.data_ptr(),
+                                                          _ptr(g), C, N, C, _stream(logits)), "spgnn_masked_ce_step")
         ctx.save_for_backward(g)
+        ctx.unit = unit
         ctx.set_materialize_grads(False)
-        s = part.sum(0) if out is None else torch.sum(part, 0, out=out)     # ``out``: the caller's (2,) slot for [num, den]
         num, den = s[0], s[1]                   # two outputs: indexing ONE output outside would add a select node whose
         ctx.mark_non_differentiable(den)        # backward is a zero fill + a copy
         return num, den
@@ -595,17 +606,23 @@ class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_num, _g_den):
         (g,) = ctx.saved_tensors
-        return (g * g_num if (g is not None and g_num is not None) else None), None, None, None, None
+        if g is None or g_num is None:
+            return None, None, None, None, None
+        return (g if ctx.unit else g * g_num), None, None, None, None      # unit: the caller back-propagates the numerator itself (grad 1)
 
 
-def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: torch.Tensor, sampling_p: torch.Tensor,
-                   class_weight: torch.Tensor, out: Optional[torch.Tensor] = None):
+def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[torch.Tensor], sampling_p: torch.Tensor,
+                   class_weight: torch.Tensor, out: Optional[torch.Tensor] = None, draw_seed: int = 0, unit_grad: bool = False):
     """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900).
-    ``out`` (2,) fp32, optional: where the two sums are to be written (train.FlatBucket's tail slots)."""
+    ``out`` (2,) fp32, optional: where the two sums are to be written (train.FlatBucket's tail slots).  ``draws`` None: the
+    kernel draws rn_i itself from its counter hash of (``draw_seed``, the step counter installed as DROPOUT_SEED_OFFSET, i).
+    ``unit_grad``: the caller promises to back-propagate the numerator with gradient exactly 1 (``num.backward()``), so the
+    stored gradient is handed on without the multiplication."""
     _require_cuda(logits, labels, draws, sampling_p, class_weight)
     assert labels.dtype == torch.int64 and logits.dtype == torch.float32
-    _MaskedCE._out = out
-    return _MaskedCE.apply(logits, labels.contiguous(), draws.contiguous(), sampling_p.contiguous(), class_weight.contiguous())
+    _MaskedCE._opts = {"out": out, "draw_seed": int(draw_seed), "unit_grad": unit_grad}
+    return _MaskedCE.apply(logits, labels.contiguous(), None if draws is None else draws.contiguous(), sampling_p.contiguous(),
+                           class_weight.contiguous())
 
 
 class _LinearFn(torch.autograd.Function):
@@ -875,10 +892,17 @@ class _WeightPrep:
         self.entries, self.keep = [], []
         tab = (_capi.WeightPrepLayer * self.n)()
         first = 0
-        for i, (w_a, w_b, want_t) in enumerate(specs):
+        for i, sp in enumerate(specs):
+            w_a, w_b, want_t = sp[:3]
+            cols = len(sp) > 3 and sp[3] == "cols"           # [w_a | w_b]: the aggregate-first layer's per-head operand
             R1, K = w_a.shape
             R2 = 0 if w_b is None else w_b.shape[0]
-            R, Kp, Rp = R1 + R2, (K + 3) // 4 * 4, (R1 + R2 + 3) // 4 * 4
+            if cols:
+                Ka, K = K, K + (0 if w_b is None else w_b.shape[1])
+                R = R1
+            else:
+                R = R1 + R2
+            Kp, Rp = (K + 3) // 4 * 4, (R + 3) // 4 * 4
             dst = torch.empty((R, Kp), dtype=torch.float32, device=device)
             ps = torch.empty((R, Kp), dtype=torch.float32, device=device)
             dst_t = torch.empty((K, Rp), dtype=torch.float32, device=device) if want_t else None
@@ -889,17 +913,18 @@ class _WeightPrep:
             t.b, t.b_stride = (w_b.data_ptr(), w_b.stride(0)) if w_b is not None else (0, 0)
             t.dst, t.ps, t.dst_stride = dst.data_ptr(), ps.data_ptr(), Kp
             t.dst_t, t.ps_t, t.dst_t_stride = (dst_t.data_ptr(), ps_t.data_ptr(), Rp) if want_t else (0, 0, 0)
-            t.scale, t.first_block, t.rows_a, t.rows_b, t.K = scale.data_ptr(), first, R1, R2, K
+            t.scale, t.first_block, t.rows_a, t.rows_b, t.K = scale.data_ptr(), first, R1, (Ka if cols else R2), K
+            t.mode = 1 if cols else 0
             first += int(lib.spgnn_weight_prep_blocks(R, Kp, Rp if want_t else 0))
             self.entries.append((dst, ps, dst_t, ps_t, scale, (R1, R2, K, R)))
         self.blocks = first
         raw = bytes(memoryview(tab))
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        self.maxwords = torch.zeros((max(self.n, 1),), dtype=torch.int32, device=device)
+        self.workspace = torch.empty((max(self.blocks, 1),), dtype=torch.float32, device=device)
 
     def run(self):
         with torch.cuda.device(self.table.device):
-            _capi.check(_capi.load().spgnn_weight_prep(self.table.data_ptr(), self.n, self.blocks, self.maxwords.data_ptr(),
+            _capi.check(_capi.load().spgnn_weight_prep(self.table.data_ptr(), self.n, self.blocks, self.workspace.data_ptr(),
                                                        _stream(self.table)), "spgnn_weight_prep")
 
 
@@ -909,8 +934,9 @@ BATCH_WEIGHT_PREP = True     # all projection layers' operands in one spgnn_weig
 
 
 class prepared_weights:
-    """``with prepared_weights(specs):`` - ``specs`` = [(w_a, w_b or None, want_t), ...] of every project-first GATConv a
-    forward pass will run.  One spgnn_weight_prep call builds all their GEMM operands ([W_fc; W_res] with 16-byte rows, its
+    """``with prepared_weights(specs):`` - ``specs`` = [(w_a, w_b or None, want_t[, "cols"]), ...] of every GATConv a
+    forward pass will run (project-first layers: the row concatenation; ``"cols"``: the aggregate-first layer's
+    [W_fc | W_res], whose head-h transpose is a column block of the transposed image).  One spgnn_weight_prep call builds all their GEMM operands ([W_fc; W_res] with 16-byte rows, its
     transpose, both pre-split, the scale); inside the block :func:`weight_cat` hands them out without launching anything.
     Values are those of the parameters at entry (the block must not update them)."""
 
@@ -925,16 +951,17 @@ class prepared_weights:
         if not self.specs:
             return self
         dev = self.specs[0][0].device
-        key = (str(dev),) + tuple((a.data_ptr(), a.stride(0), tuple(a.shape), 0 if b is None else b.data_ptr(),
-                                   0 if b is None else b.stride(0), None if b is None else tuple(b.shape), bool(t))
-                                  for a, b, t in self.specs)
+        key = (str(dev),) + tuple((sp[0].data_ptr(), sp[0].stride(0), tuple(sp[0].shape), 0 if sp[1] is None else sp[1].data_ptr(),
+                                   0 if sp[1] is None else sp[1].stride(0), None if sp[1] is None else tuple(sp[1].shape), bool(sp[2]),
+                                   sp[3] if len(sp) > 3 else "") for sp in self.specs)
         prep = _PREP_CACHE.get(key)
         if prep is None:
             if len(_PREP_CACHE) > 8:
                 _PREP_CACHE.clear()
             prep = _PREP_CACHE[key] = _WeightPrep(self.specs, dev)
         prep.run()
-        _PREP_ACTIVE = {(id(a), id(b) if b is not None else 0): (e, bool(t)) for (a, b, t), e in zip(self.specs, prep.entries)}
+        _PREP_ACTIVE = {(id(sp[0]), id(sp[1]) if sp[1] is not None else 0) + ((sp[3],) if len(sp) > 3 else ()): (e, bool(sp[2]))
+                        for sp, e in zip(self.specs, prep.entries)}
         return self
 
     def __exit__(self, *exc):
@@ -1543,10 +1570,18 @@ class _GATAggFirstFn(torch.autograd.Function):
         s = scores_fwd(x, w_lr)
         z, attn, sz = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, has_res)
         zs = z.shape[1] // H
-        w3 = w_fc.view(H, D, F_)
-        wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
-        sw = pow2_scale(wc.view(H * D, zs))
-        wc_ps = presplit(wc.view(H * D, zs), scale=sw)[0].view(H, D, zs) if (PRESPLIT_B and zs % 4 == 0) else None   # the products' b operand, split once
+        hit = _PREP_ACTIVE.get((id(w_fc), id(w_res) if has_res else 0, "cols")) if PRESPLIT_B else None
+        ctx.wt = None
+        if hit is not None and hit[0][5][2] == zs and hit[0][5][3] == H * D and zs % 4 == 0 and D % 4 == 0:
+            # [W_fc,h | W_res,h], its scale, its pre-split form and the transposes: built by this pass's spgnn_weight_prep
+            dst, ps, dst_t, ps_t, sw, _ = hit[0]
+            wc, wc_ps = dst.view(H, D, zs), ps.view(H, D, zs)
+            ctx.wt = (dst_t, ps_t) if hit[1] else None
+        else:
+            w3 = w_fc.view(H, D, F_)
+            wc = torch.cat([w3, w_res.view(H, D, F_)], dim=2).contiguous() if has_res else w3.contiguous()   # (H, D, zs)
+            sw = pow2_scale(wc.view(H * D, zs))
+            wc_ps = presplit(wc.view(H * D, zs), scale=sw)[0].view(H, D, zs) if (PRESPLIT_B and zs % 4 == 0) else None   # the products' b operand, split once
         out = torch.empty((N, H * D), dtype=torch.float32, device=x.device)
         fuse_mean = mean and headmean_fusable(out, H, D)
         rst = None
@@ -1612,10 +1647,13 @@ class _GATAggFirstFn(torch.autograd.Function):
         g_wfc = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if need_w else None
         g_wres = torch.empty((H * D, F_), dtype=torch.float32, device=x.device) if (need_w and has_res) else None
         g_bias = torch.empty((H * D,), dtype=torch.float32, device=x.device) if need_bias else None
-        wct = wc.transpose(1, 2).contiguous()          # (H, zs, D): every head's W^T in one copy
         ps = ctx.presplit and D % 4 == 0       # the forward's decision: one operand form per autograd node
-        if ps:
-            wct = presplit(wct.view(H * zs, D), scale=sw)[0].view(H, zs, D)
+        if ctx.wt is not None and ps:          # head h's W^T = columns [h D, (h + 1) D) of the prepared transpose
+            wct = [ctx.wt[1][:zs, h * D:(h + 1) * D] for h in range(H)]
+        else:
+            wct = wc.transpose(1, 2).contiguous()          # (H, zs, D): every head's W^T in one copy
+            if ps:
+                wct = presplit(wct.view(H * zs, D), scale=sw)[0].view(H, zs, D)
         for h in range(H):
             gp_h = g_pre[:, h * D:(h + 1) * D]
             gemm_nt(gp_h, wct[h], sg, sw, out=g_z[:, h * zs:(h + 1) * zs], b_presplit=ps)
@@ -1845,12 +1883,23 @@ def spmm_max(csc: DeviceCSC, x) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tensor, lr: float, momentum: float,
                        weight_decay: float = 0.0, first_step: bool = False,
-                       grad_scale: Optional[torch.Tensor] = None, lr_dev: Optional[torch.Tensor] = None) -> None:
-    """``lr_dev`` (device scalar) overrides ``lr`` at run time (learning-rate schedules under graph replay)."""
-    _require_cuda(param, grad, buf, grad_scale, lr_dev)
+                       grad_scale: Optional[torch.Tensor] = None, lr_dev: Optional[torch.Tensor] = None,
+                       weight_sum: Optional[torch.Tensor] = None, loss_num: Optional[torch.Tensor] = None,
+                       loss_out: Optional[torch.Tensor] = None) -> None:
+    """``lr_dev`` (device scalar) overrides ``lr`` at run time (learning-rate schedules under graph replay).  ``weight_sum``
+    (device scalar) instead of ``grad_scale``: the gradient is divided by it in the kernel, and with ``loss_num`` /
+    ``loss_out`` the same launch writes loss_out[0] = loss_num[0] / weight_sum[0] (spgnn_sgd_momentum_step_mean)."""
+    _require_cuda(param, grad, buf, grad_scale, lr_dev, weight_sum, loss_num, loss_out)
     assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
     assert param.dtype == grad.dtype == buf.dtype == torch.float32 and param.numel() == grad.numel() == buf.numel()
     lib = _capi.load()
+    if weight_sum is not None:
+        assert grad_scale is None and (loss_out is None or loss_num is not None)
+        with torch.cuda.device(param.device):
+            _capi.check(lib.spgnn_sgd_momentum_step_mean(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), weight_sum.data_ptr(),
+                                                         _ptr(loss_num), _ptr(loss_out), _ptr(lr_dev), param.numel(), lr, momentum,
+                                                         weight_decay, int(first_step), _stream(param)), "spgnn_sgd_momentum_step_mean")
+        return
     with torch.cuda.device(param.device):
         _capi.check(lib.spgnn_sgd_momentum_step(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), _ptr(grad_scale),
                                                 _ptr(lr_dev), param.numel(), lr, momentum, weight_decay,
@@ -1975,15 +2024,16 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     N = b.shape[1]
     assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, min(64, 512 // tiles, R // 256))
-    if splits >= 8 or tiles >= 16:
-        # A split count that is a multiple of 8 gives every split to ONE XCD (by_xcd placement in the kernel): its rows
-        # are fetched into one L2 only.  With few splits and more tiles than an XCD holds at once (2 x 32 workgroups)
-        # every XCD ends up streaming a whole operand (PMC: 2.7-5.3x the algorithmic bytes, profiles/r01_pmc_gemm_l2_lds.md).
-        # Measured incl. the partial-sum reduction (tools/tn_splits.py, R = 76 410): 1024 x 1063 (72 tiles) 7 splits
-        # 748 us, 16: 630, 32: 599, 64: 656; 1024 x 384 and 512 x 768 (24 tiles) 21: 235 / 224, 32: 216 / 209;
-        # 256 x 256 (4 tiles) 32: 81, 64: 54.
-        splits = 32 if tiles >= 16 and R >= 32 * 512 else (splits // 8 * 8 if splits >= 8 else splits)
+    # Split count.  The kernel deals the (split, tile) work items to the XCDs in contiguous ranges, so any count keeps a
+    # split's row range in one or two L2s.  Small products: enough splits for ~512 workgroups (two per CU), at least 256
+    # rows each.  Large ones (tools/tn_splits.py, R = 76 410, incl. the partial-sum reduction): 1024 x 1063 (72 tiles)
+    # 7 splits 704 us, 14: 634, 21: 609, 28: 605, 32: 598, 35: 608 - whole rounds of workgroups do not matter (the
+    # kernel is bound chip-wide, not per CU), fewer splits lose to the shorter pipeline per byte of L2 refill;
+    # 1024 x 384 / 512 x 768 (24 tiles) 21: 209 / 209, 32: 215 / 213, 42: 216 / 215, 64: 229 / 226;
+    # 256 x 384 (6) 64: 72, 85: 65, 128: 70; 256 x 256 (4) 64: 52, 128: 48, 256: 60; 128 x 128 (1) 64: 41, 256: 26, 512: 29.
+    splits = max(1, min(256, 512 // tiles, R // 256))
+    if tiles >= 16 and R >= 32 * 512:
+        splits = 32 if tiles >= 48 else 21
     ldn = (N + 3) // 4 * 4
     ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)

@@ -144,6 +144,9 @@ class TrainStep:
         self._sampling_cache = None
         self._graph = None
         self._lr_dev = None
+        self._one = self._loss_out = None
+        # seed of the mask stream a captured step draws inside its loss kernel (spgnn_masked_ce_step); eager steps use self.gen
+        self._mask_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & ((1 << 62) - 1)
 
     def _sampling(self, g):
         y = g.ndata["y"]
@@ -162,30 +165,39 @@ class TrainStep:
         b.detach_grads()
         y = g.ndata["y"]
         p = self._sampling(g)
-        pool = ops.scale_pool(b.flat_param.device) if b.flat_param.is_cuda else None
-        if pool is not None:
-            pool.begin()                     # ONE launch re-arms every GEMM operand's scale block of this step
-        if draws is None:
-            if getattr(self, "_use_default_rng", False):       # graph capture: torch's default generator is graph-safe
-                draws = torch.rand(p.shape, device=p.device)
-            else:
-                draws = torch.rand(p.shape, device=p.device, generator=self.gen)
+        on_gpu = b.flat_param.is_cuda
+        pool = ops.scale_pool(b.flat_param.device) if on_gpu else None
         # the dropout seed offset belongs to THIS step object: it is visible to the kernels only while this step's forward
         # and backward are being issued (a captured step leaves no offset behind for other models / eager layers)
         prev_off = ops.DROPOUT_SEED_OFFSET
         ctr = getattr(self, "_seed_ctr", None)
+        if pool is not None:
+            pool.begin(counter=ctr)          # ONE launch: every GEMM operand's scale block of this step re-armed, the counter advanced
+        elif ctr is not None:
+            ctr.add_(1)
+        draw_seed = 0
+        if draws is None:
+            if getattr(self, "_use_default_rng", False) and on_gpu and ctr is not None:
+                # captured step: the loss kernel draws the mask itself from (seed, step counter, node) - no generator state
+                # to restore before a replay, no launch of its own
+                draw_seed = self._mask_seed
+            else:
+                draws = torch.rand(p.shape, device=p.device, generator=self.gen)
         try:
             if ctr is not None:
                 ops.DROPOUT_SEED_OFFSET = ctr
-                ctr.add_(1)
             logits = self.model(g)[0]
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
-                nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot)   # land in the bucket's tail
+                nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot, draw_seed=draw_seed,
+                                        unit_grad=True)                               # land in the bucket's tail
                 num, den = nd[0], nd[1]
+                if self._one is None or self._one.device != num.device:
+                    self._one = torch.ones((), dtype=torch.float32, device=num.device)
+                torch.autograd.backward(num, self._one)      # gradient exactly 1 (unit_grad), from a tensor that needs no fill
             else:
                 num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
-            num.backward()
+                num.backward()
         finally:
             ops.DROPOUT_SEED_OFFSET = prev_off
             if pool is not None:
@@ -205,6 +217,15 @@ class TrainStep:
 
     def _back(self, loss_num: torch.Tensor) -> torch.Tensor:
         b = self.bucket
+        if b.flat_param.is_cuda:             # ONE launch: 1 / weight sum, the fused SGD and the loss scalar
+            n = b.numel
+            if self._loss_out is None:
+                self._loss_out = torch.zeros((1,), dtype=torch.float32, device=b.flat_param.device)
+            ops.sgd_momentum_step_(b.flat_param[:n], b.flat_grad[:n], b.flat_mom[:n], self.lr, self.momentum, self.weight_decay,
+                                   first_step=(b.steps == 0), lr_dev=self._lr_dev, weight_sum=b.wsum_slot, loss_num=b.loss_slot,
+                                   loss_out=self._loss_out)
+            b.steps += 1
+            return self._loss_out.reshape(())
         inv = torch.reciprocal(b.wsum_slot)
         self._apply_update(inv)
         b.steps += 1
@@ -241,7 +262,7 @@ class TrainStep:
         ctr = getattr(self, "_seed_ctr", None)
         return {"state": state, "param_groups": [group],
                 "spgnn": {"steps": b.steps, "seed_ctr": int(ctr.item()) if ctr is not None else 0,
-                          "generator": self.gen.get_state().clone()}}
+                          "generator": self.gen.get_state().clone(), "mask_seed": self._mask_seed}}
 
     def load_state_dict(self, sd: dict) -> None:
         """Inverse of :meth:`state_dict`; also takes a plain ``torch.optim.SGD`` state dict (no ``"spgnn"`` entry: the
@@ -278,6 +299,7 @@ class TrainStep:
             b.steps = 1                          # buffers exist: the next step must accumulate into them, not overwrite
         if extra:
             self.gen.set_state(extra["generator"].cpu())
+            self._mask_seed = int(extra.get("mask_seed", self._mask_seed))
             ctr = getattr(self, "_seed_ctr", None)
             if ctr is not None:
                 ctr.fill_(int(extra["seed_ctr"]))
@@ -292,9 +314,10 @@ class TrainStep:
         replay is two graph launches.  Two graphs, split where the ranks exchange: ``front`` = mask draw, forward, loss,
         backward, gradient gather; [eager: the RCCL all-reduces of ``_reduce``]; ``back`` = SGD update and the loss
         scalar.  One process runs the same two graphs with nothing in between.
-        Randomness stays fresh per replay: the node-mask draws and feature dropout use torch's graph-safe Philox
-        offsets, attention dropout adds a device counter (ops.DROPOUT_SEED_OFFSET) that the captured step increments;
-        the learning rate is read from a device scalar (``set_lr`` keeps working)."""
+        Randomness stays fresh per replay: every mask of the step (node sampling, feature and attention dropout) is a
+        counter hash of a host seed frozen at capture plus a device counter (ops.DROPOUT_SEED_OFFSET) that the captured
+        step advances in its first launch (spgnn_step_begin) - no generator state to restore before a replay; the
+        learning rate is read from a device scalar (``set_lr`` keeps working)."""
         dev = self.bucket.flat_param.device
         self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
         self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)     # installed as ops.DROPOUT_SEED_OFFSET inside _front only

@@ -284,6 +284,45 @@ def test_weight_prep_batched_equals_per_layer():
     assert len(ops._PREP_CACHE) >= 1
 
 
+def test_weight_prep_column_mode_feeds_the_aggregate_first_layer():
+    """spgnn_weight_prep mode 1: [W_fc | W_res] (the aggregate-first layer's per-head operand), its scale, pre-split form and
+    transpose - and a model step that takes them from the prepared pass equals, bit for bit, the step that assembles them
+    with torch ops."""
+    torch.manual_seed(2)
+    H, D, F_ = 2, 64, 24
+    wa, wb = torch.randn(H * D, F_, device="cuda") * 0.3, torch.randn(H * D, F_, device="cuda") * 0.1
+    for b in (wb, None):
+        with ops.prepared_weights([(wa, b, True, "cols")]):
+            (dst, ps, dst_t, ps_t, scale, meta), want_t = ops._PREP_ACTIVE[(id(wa), id(b) if b is not None else 0, "cols")]
+            ref = torch.cat([wa, b], dim=1) if b is not None else wa
+            K = ref.shape[1]
+            assert meta == (H * D, 0 if b is None else H * D, K, H * D) and want_t
+            assert torch.equal(dst[:, :K], ref) and torch.equal(dst_t[:K, :H * D], ref.t())
+            s0 = ops.pow2_scale(ref)
+            assert float(scale) == float(s0)
+            assert torch.equal(ps[:, :K].contiguous().view(torch.int32), ops.presplit(ref.contiguous(), scale=s0)[0].view(torch.int32))
+            assert torch.equal(ps_t[:K, :H * D].contiguous().view(torch.int32),
+                               ops.presplit(ref.t().contiguous(), scale=s0)[0].view(torch.int32))
+    from spgnn_amd import models, synthetic
+    from spgnn_amd.configs import get_config
+    cfg = get_config("st_pgat_spgnn_3")
+    g = synthetic.make_batch(3, rank=4, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model = models.build_model(cfg.MODEL).cuda().eval()
+    outs = []
+    for batch in (True, False):
+        ops.BATCH_WEIGHT_PREP = batch
+        try:
+            model.zero_grad(set_to_none=True)
+            logits = model(g)[0]
+            logits.square().sum().backward()
+            outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+        finally:
+            ops.BATCH_WEIGHT_PREP = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_gemm_takes_scale_blocks():
     """A GEMM operand's scale as a SCALE BLOCK (include/spgnn_hip.h): {-256, 0, 0, 0, m_1 .. m_256} whose largest slot the
     kernel turns into the power-of-two scale itself - bit-identical to passing the scalar scale, for every tile variant of

@@ -414,6 +414,34 @@ def test_sgd_momentum_step_matches_torch():
         assert rel_err(p, ref) < 1e-6
 
 
+def test_sgd_mean_form_and_step_begin():
+    """spgnn_sgd_momentum_step_mean (gradient divided by a device weight sum, loss scalar written by the same launch) against
+    torch.optim.SGD; spgnn_step_begin re-arms the scale pool and advances the counter in one launch."""
+    torch.manual_seed(1)
+    p = torch.randn(50001, device="cuda"); ref = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    buf = torch.zeros_like(p)
+    wsum, num, loss = torch.tensor([7.25], device="cuda"), torch.tensor([3.5], device="cuda"), torch.zeros(1, device="cuda")
+    for step in range(3):
+        gr = torch.randn_like(p)
+        ref.grad = gr / 7.25
+        opt.step()
+        ops.sgd_momentum_step_(p, gr, buf, 0.05, 0.9, 1e-4, first_step=(step == 0), weight_sum=wsum, loss_num=num, loss_out=loss)
+        assert rel_err(p, ref) < 1e-6
+    assert abs(float(loss) - 3.5 / 7.25) < 1e-7
+    pool = ops.scale_pool("cuda")
+    ctr = torch.tensor([41], dtype=torch.int64, device="cuda")
+    pool.buf.fill_(3.0)
+    pool.begin(counter=ctr)
+    try:
+        assert int(ctr) == 42
+        assert torch.equal(pool.buf, ops._scale_template(pool.device, pool.capacity))
+        blk = ops.new_scale_block("cuda")
+        assert blk.data_ptr() == pool.buf.data_ptr()
+    finally:
+        pool.end()
+
+
 def test_c_abi_argument_errors_are_reported():
     from spgnn_amd import _capi
     lib = _capi.load()

@@ -324,6 +324,61 @@ def test_fused_masked_ce_matches_cross_entropy(N, C):
     assert rel_err(loss, ref_t) < 1e-6 and rel_err(logits.grad, lt.grad) < 1e-5
 
 
+def _mask_draws_host(seed: int, offset: int, n: int) -> np.ndarray:
+    """Host restatement of spgnn_masked_ce_step's draw: 24 bits of mix64(seed + 0xD1B54A32D192ED03 * offset, i) / 2^24."""
+    M = (1 << 64) - 1
+    out = np.empty(n, dtype=np.float32)
+    sd = (seed + 0xD1B54A32D192ED03 * offset) & M
+    for i in range(n):
+        z = (sd + 0x9E3779B97F4A7C15 * (i + 1)) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out[i] = np.float32(z >> 40) * np.float32(1.0 / 16777216.0)
+    return out
+
+
+def test_masked_ce_draws_its_own_mask_and_sums_in_the_last_workgroup():
+    """draws=None: the kernel's counter-hash mask (restated on the host) gives the sums of the explicit-draws call bit for
+    bit, moves with the device step counter, is uniform, and the last-workgroup totals are repeatable launch after launch."""
+    from spgnn_amd import ops
+    torch.manual_seed(5)
+    N, C = 5000, 22
+    logits = torch.randn(N, C, device="cuda") * 2
+    y = torch.randint(0, C, (N,), device="cuda")
+    w = torch.rand(C, device="cuda") + 0.1
+    p = torch.where(y != 0, torch.tensor(1.0, device="cuda"), torch.tensor(0.15, device="cuda"))
+    ctr = torch.tensor([3], dtype=torch.int64, device="cuda")
+    seed = 0x1234567890ABCDEF & ((1 << 62) - 1)
+    prev = ops.DROPOUT_SEED_OFFSET
+    try:
+        ops.DROPOUT_SEED_OFFSET = ctr
+        out = torch.zeros(2, device="cuda")
+        a = [t.clone() for t in ops.masked_ce_sums(logits, y, None, p, w, out=out, draw_seed=seed)]
+        host = torch.from_numpy(_mask_draws_host(seed, 3, N)).cuda()
+        b = ops.masked_ce_sums(logits, y, host, p, w)
+        assert float(a[0]) == float(b[0]) and float(a[1]) == float(b[1]) and float(out[1]) == float(a[1])
+        for _ in range(20):                                       # arrival order of the workgroups must not show
+            c = ops.masked_ce_sums(logits, y, None, p, w, draw_seed=seed)
+            assert float(c[0]) == float(a[0]) and float(c[1]) == float(a[1])
+        ctr.add_(1)
+        d = ops.masked_ce_sums(logits, y, None, p, w, draw_seed=seed)
+        assert float(d[1]) != float(a[1])
+    finally:
+        ops.DROPOUT_SEED_OFFSET = prev
+    u = _mask_draws_host(seed, 0, 20000)
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float((u < 0.15).mean()) - 0.15) < 0.01 and u.min() >= 0.0 and u.max() < 1.0
+    ref = O.masked_weighted_ce(logits.cpu().double(), y.cpu(), (host < p).cpu(), w.cpu().double())
+    assert rel_err(a[0] / a[1], ref) < 1e-6
+    # unit_grad: the stored gradient is handed on as it is
+    lg = logits.clone().requires_grad_(True)
+    n1 = ops.masked_ce_sums(lg, y, host, p, w, unit_grad=True)[0]
+    torch.autograd.backward(n1, torch.ones((), device="cuda"))
+    lg2 = logits.clone().requires_grad_(True)
+    ops.masked_ce_sums(lg2, y, host, p, w)[0].backward()
+    assert torch.equal(lg.grad, lg2.grad)
+
+
 # ---- the N > 1 step as HIP-graph replays: two processes on the one GPU, gloo carrying the CUDA tensors ----------------
 def _dp_graph_worker(rank, world, port, ret):
     import torch.distributed as dist

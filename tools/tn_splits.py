@@ -21,11 +21,13 @@ def run(a, b, sa, sb, splits):
         for _ in range(4): fn()
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 4)
     return sorted(ts)[2]
-for (M, N) in [(1024, 1063), (1024, 384), (512, 768), (256, 384), (256, 256)]:
+R = int(sys.argv[1]) if len(sys.argv) > 1 else R
+CAND = {72: [7, 14, 21, 28, 32, 35], 24: [21, 32, 42, 63, 64], 6: [42, 64, 85, 128, 170], 4: [64, 96, 128, 192, 256], 1: [64, 128, 256, 512]}
+for (M, N) in [(1024, 1063), (1024, 384), (512, 768), (256, 384), (256, 256), (512, 39), (128, 128)]:
     Np = (N + 3) // 4 * 4
     a = torch.randn(R, M, device=dev); b = torch.randn(R, Np, device=dev)[:, :N]
     sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     cur = max(1, min(64, 512 // tiles, R // 256))
-    cand = sorted(set([cur, 16, 24, 32, 40, 48, 56, 64]))
+    cand = sorted(set([cur] + [c for c in CAND.get(tiles, [16, 32, 64]) if c <= R // 64]))
     print(f"M={M} N={N} tiles={tiles} current={cur}: " + " | ".join(f"{s}:{run(a, b, sa, sb, s)*1e3:.0f}us" for s in cand), flush=True)
