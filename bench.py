@@ -41,7 +41,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_F16_PEAK = 2500.0      # dense fp16 / bf16 TFLOP/s
 FP32_MATRIX_PEAK = 157.3    # native fp32 MFMA TFLOP/s (the pipe an fp32 GEMM would otherwise use)
-GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16")
+GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair", "gemm_nt_bf16", "gemm_tn_bf16")
 HELPER_NAMES = ("absmax", "split_rows")
 GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg", "lspe_")
 # roofline.traffic is NOT measured by this run: PMC counters need rocprofv3 passes of their own
@@ -110,7 +110,7 @@ def algorithmic_bytes(key) -> float:
     if base == "masked_ce":
         _, N, C = key
         return 4 * 2 * N * C + 4 * 4 * N
-    if base in ("gemm_nt", "gemm_tn") or base in HELPER_NAMES:
+    if base in ("gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair") or base in HELPER_NAMES:
         return 0.0                    # compute-side kernels: accounted in "gemm" / "composite", not in the message-passing bytes
     if base == "spmm_sum":
         _, N, E, F = key
@@ -125,12 +125,23 @@ def algorithmic_bytes(key) -> float:
 
 
 def gemm_bytes(key) -> float:
-    """Algorithmic HBM bytes of one projection product: both operands once + the result once."""
-    name, a, b, c = key
+    """Algorithmic HBM bytes of one projection product: both operands once + the result once.  A pair launch
+    (``gemm_nt_pair`` / ``gemm_tn_pair``: two independent products, key = both shapes) is the sum of its two products."""
+    name = key[0]
+    if name.endswith("_pair"):
+        return gemm_bytes((name[:-5],) + tuple(key[1:4])) + gemm_bytes((name[:-5],) + tuple(key[4:7]))
+    _, a, b, c = key
     s = 2 if name.endswith("_bf16") else 4
     if name.startswith("gemm_nt"):           # (M, N, K): A (M,K), B (N,K) -> C (M,N) in the storage dtype
         return s * (a * c + b * c + a * b)
     return s * (a * b + a * c) + 4 * b * c   # gemm_tn (R, M, N): A (R,M), B (R,N) -> fp32 C (M,N)
+
+
+def gemm_flops(key) -> float:
+    """Algorithmic flops (2 M N K of the fp32 product) of one launch."""
+    if key[0].endswith("_pair"):
+        return 2.0 * key[1] * key[2] * key[3] + 2.0 * key[4] * key[5] * key[6]
+    return 2.0 * key[1] * key[2] * key[3]
 
 
 def survey_k123_bytes(gat_keys, dtype_bytes) -> float:
@@ -265,7 +276,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     # The roofline kernel is FIXED per dtype (not "whichever shape won this run"): all launches of it in a step.
     spmm_model = cfg.KIND in ("gcn", "gin", "sage")           # rows D / E / F: the SpMM kernels are the roofline kernel (HBM-bound)
     roof_names = (("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16", "gat_agg_fwd_bf16", "gat_agg_bwd_dst_bf16",
-                   "gat_agg_bwd_src_bf16") if bf16 else ("spmm_sum", "spmm_max_fwd", "spmm_max_bwd") if spmm_model else ("gemm_nt",))
+                   "gat_agg_bwd_src_bf16") if bf16 else ("spmm_sum", "spmm_max_fwd", "spmm_max_bwd") if spmm_model else ("gemm_nt", "gemm_nt_pair"))
     gat_names = tuple(k for k in {k[0] for k in kt_all} if k.startswith(GAT_PREFIXES))
     bracket = [k for k in kt_all if k[0] in roof_names or k[0] in gat_names or k[0] in GEMM_NAMES]
     sync()
@@ -289,13 +300,19 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         loss = run_step()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(steps):
-        loss = run_step()
-        marks[i + 1].record()
-    sync()
-    elapsed = time.perf_counter() - t0
+    import gc
+    gc.collect()                                    # a collection of the previous leg's objects inside a 20-step leg showed up
+    gc.disable()                                    # as 1.54 ms wall against 1.11 ms by events (r03): keep the host out of it
+    try:
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            loss = run_step()
+            marks[i + 1].record()
+        sync()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     kt_dom, eager_leg = {}, None
     if not no_eager_leg and not no_kernel_timers:
@@ -384,7 +401,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             per_name = {}
             for k in gemm_keys:
                 t, n = per_step(k)
-                fl = 2.0 * k[1] * k[2] * k[3] * n
+                fl = gemm_flops(k) * n
                 g_ms += t; g_fl += fl; g_by += gemm_bytes(k) * n
                 d = per_name.setdefault(k[0], [0.0, 0.0, 0.0, 0])
                 d[0] += t; d[1] += fl; d[2] += gemm_bytes(k) * n; d[3] += n
@@ -399,7 +416,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                     "mfma_products_per_fp32_product": products,
                     # per shape: launches per step, mean ms per launch, algorithmic TFLOP/s
                     "per_shape": {"_".join(str(x) for x in k): [round(per_step(k)[1], 2), round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 4),
-                                                                round(2.0 * k[1] * k[2] * k[3] * per_step(k)[1] / (per_step(k)[0] * 1e-3) / 1e12, 1)]
+                                                                round(gemm_flops(k) * per_step(k)[1] / (per_step(k)[0] * 1e-3) / 1e12, 1)]
                                   for k in sorted(gemm_keys, key=lambda kk: -per_step(kk)[0])},
                     "measured_in": where}
 
@@ -462,10 +479,10 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                                        "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,
                                        "avg_launch_ms": r_ms / r_n, "measured_in": where}
                 else:
-                    r_fl = sum(2.0 * k[1] * k[2] * k[3] * per_step(k)[1] for k in rkeys)
+                    r_fl = sum(gemm_flops(k) * per_step(k)[1] for k in rkeys)
                     ach = r_fl / (r_ms * 1e-3) / 1e12
-                    out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt (all launches of a step: forward projections and "
-                                       "input gradients)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
+                    out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt / spgnn_gemm_nt_pair (all launches of a step: forward projections and "
+                                       "input gradients; a pair = a level's structure + position products in one launch)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
                                        "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
                                        "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys), "traffic_source": TRAFFIC_SOURCE,
                                        "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,

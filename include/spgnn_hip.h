@@ -460,6 +460,27 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   const float* scale_a, const float* scale_b,
                   float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream);
 
+/* Two INDEPENDENT products in one launch each: workgroups [0, b0) run the first product, the rest the second, each with
+ * the arithmetic and tile order it has in a launch of its own (results bit-identical to two calls).  A GATConv level's
+ * structure and position layers (reference models.py:472-484: `self.gat_layers[l](g, h)`, `self.pgnn_layers[l](g, p)`)
+ * project independently; the small product's memory-bound tiles then run on the CUs the large one's last round of tiles
+ * leaves idle instead of in a launch of their own.  Fields = the arguments of spgnn_gemm_nt / spgnn_gemm_tn.  The NT
+ * pair runs both products with the block tile spgnn_gemm_nt would choose for `first` (pass the larger one first). */
+typedef struct spgnn_gemm_nt_problem {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t M; int64_t N; int64_t K;
+  const float* scale_a; const float* scale_b; const float* upd_u; int64_t upd_u_stride; const float* upd_v; int64_t upd_v_stride;
+  const float* bias; const float* score_l; const float* score_r; float* score_out;
+  int32_t upd_j; int32_t activation; int32_t score_cols; int32_t reserved;
+} spgnn_gemm_nt_problem;
+typedef struct spgnn_gemm_tn_problem {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t split_stride; int64_t R; int64_t M; int64_t N;
+  const float* scale_a; const float* scale_b; float* colsum_a; int64_t colsum_stride; int64_t colsum_split_stride;
+  int32_t splits; int32_t reserved;
+} spgnn_gemm_tn_problem;
+int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
+                       spgnn_stream_t stream);
+int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);
+
 /* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */
 int spgnn_pow2_scale(const float* x, int64_t x_stride, int64_t rows, int64_t cols, float* scale,

@@ -433,7 +433,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
 }
 
 template <int WM, bool BPS>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
+__device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, const unsigned nb) {   // workgroup b of the nb this product owns
   constexpr int TBM = 64 * WM, NT = 128 * WM;
   constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
   constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;                 // halves per stage: Ah | Al | Bh | Bl
@@ -442,7 +442,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
   using BIO = TileIO<BN, NT>;
   constexpr int NLA = AIO::NL, NLB = BIO::NL;
 
-  const unsigned nb = gridDim.x, b = blockIdx.x;
   const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
   if (tile >= (unsigned)(a.nbm * a.nbn)) return;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
@@ -550,6 +549,22 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
 
+// Two independent products in ONE launch (spgnn_gemm_nt_pair): workgroups [0, nb0) run product 0, the rest product 1,
+// each with the tile order it has alone.  A GATConv level's structure and position projections (reference
+// models.py:472-484) are such a pair: the small one's memory-bound tiles run in the CUs the large one's last round
+// leaves idle instead of in a launch of their own.
+struct PairArgs { Args p[2]; unsigned nb0; };
+
+template <int WM, bool BPS>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
+  nt_v2_body<WM, BPS>(a, blockIdx.x, gridDim.x);
+}
+template <int WM, bool BPS>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(PairArgs pa) {
+  const bool second = blockIdx.x >= pa.nb0;                 // block-uniform: the arguments are read from one half of the kernarg
+  nt_v2_body<WM, BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+}
+
 // -------------------------------------------------------------------------------------------------
 // NT kernel, third generation: 256 x 256 block tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA
 // tiles (128 accumulator registers), one workgroup per CU.  Per MFMA it moves 2/3 of the operand bytes, converts
@@ -560,13 +575,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Ar
 // 256 rows x 80 bytes = 160 KB.
 // -------------------------------------------------------------------------------------------------
 template <bool BPS>
-__global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
+__device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, const unsigned nb) {
   constexpr int TB = 256;
   constexpr int IMG = TB * PITCH;                               // halves per image
   constexpr int STAGE = 4 * IMG;                                // Ah | Al | Bh | Bl
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
 
-  const unsigned nb = gridDim.x, b = blockIdx.x;
   const unsigned tile = (b & 7u) * (nb >> 3) + (b >> 3);
   if (tile >= (unsigned)(a.nbm * a.nbn)) return;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
@@ -716,6 +730,15 @@ __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
 
   store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
+template <bool BPS>
+__global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
+  nt_v3_body<BPS>(a, blockIdx.x, gridDim.x);
+}
+template <bool BPS>
+__global__ __launch_bounds__(512) void gemm_nt_pair_v3(PairArgs pa) {
+  const bool second = blockIdx.x >= pa.nb0;
+  nt_v3_body<BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+}
 
 // A phase-skewed form of this kernel (the two waves of every SIMD one phase apart - R: fragment reads + wait, M: twelve
 // MFMAs with the conversions between them - so that one of them is always in its MFMA cluster; eight barriers per stage,
@@ -777,7 +800,7 @@ __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, 
   *reinterpret_cast<uint2*>(lo_img + off) = l;
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
+__device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, const unsigned nblocks) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];          // 2 stages x (Ah | Al | Bh | Bl)
   constexpr int STAGE = 4 * TTILE;
 
@@ -788,7 +811,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
   // caller picks the one whose workgroup count fills whole rounds of the chip (2 per CU).  The grid is padded to a
   // multiple of 8; the pad workgroups leave at once.
   const unsigned tiles_ = (unsigned)(a.nbm * a.nbn);
-  const unsigned w_ = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const unsigned w_ = (bid & 7u) * (nblocks >> 3) + (bid >> 3);
   if (w_ >= tiles_ * (unsigned)a.splits) return;
   const unsigned split = w_ / tiles_, tile = w_ % tiles_;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
@@ -962,6 +985,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) {
         if (row < a.M) Cp[(int64_t)row * a.ldc + col] = acc[i][j][e] * alpha;
       }
     }
+}
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) { tn_v2_body(a, blockIdx.x, gridDim.x); }
+struct PairArgsTN { ArgsTN p[2]; unsigned nb0; };
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_pair_v2(PairArgsTN pa) {          // see gemm_nt_pair_v2
+  const bool second = blockIdx.x >= pa.nb0;
+  tn_v2_body(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
@@ -1334,14 +1363,17 @@ extern "C" {
 
 // `tile`: 0 = chosen from the shape (below); 2 = 128 x 128, 4 = 256 x 128, 5 = 256 x 256 block tiles.  Every tile shape
 // performs the same arithmetic in the same order per output element: results are bit-identical (tests/test_hip_gemm.py).
-static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+// One NT product as the kernels take it, after validation.  variant: 5 = 256 x 256 (gemm_nt_f16x3_v3), 4 = 256 x 128, 2 = 128 x 128.
+struct NtPlan { gemm::Args a; int variant; int64_t blocks; };
+
+static int gemm_nt_plan(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                         int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
                         int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                         int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
-                        int32_t tile, int32_t b_presplit, spgnn_stream_t stream) {
+                        int32_t tile, NtPlan* plan) {
+  plan->blocks = 0;
   if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
-  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (mean_out) {
     if (!mean_other) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
     if (mean_other_stride < N || mean_out_stride < N || (mean_other_stride & 3) || (mean_out_stride & 3) ||
@@ -1367,50 +1399,108 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
         (reinterpret_cast<uintptr_t>(upd_v) & 15))
       return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);        // V rows: 16-byte aligned, zero padded to a multiple of 4 columns
   }
-  if (M == 0 || N == 0) return SPGNN_OK;
+  if (M == 0 || N == 0) return SPGNN_OK;                    // plan->blocks stays 0: nothing to launch
   if (!A || !B || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (lda < K || ldb < K || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15))
     return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
-  hipStream_t st = (hipStream_t)stream;
-  {
-    // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
-    // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones when the tiles fill whole rounds
-    // over the 256 CUs, and lose to the larger quantisation otherwise (measured at M = 76 410: N = 1024 / 1063, 4.67 /
-    // 5.84 rounds, win 12 % / 3 %; N = 768 / 512, 3.50 / 2.34 rounds, lose 7 % / 10 %): take it when at most 8 % of the
-    // last round is idle.  Offsets inside that kernel are 32-bit.
-    const bool fits31 = M * lda * 4 < (int64_t(1) << 31) && N * ldb * 4 < (int64_t(1) << 31);
-    const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
-    const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3;
-    if (fits31 && (tile == 5 || (tile == 0 && v3_wins))) {
-      gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                   (int)((M + 255) / 256), (int)((N + 255) / 256), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                   (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
-                   mean_other, mean_other_stride, mean_out, mean_out_stride};
-      int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
-      const size_t lds_bytes = 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16);       // 160 KB
-#define SPGNN_LAUNCH_NT(KERNEL_, THREADS_)                                                                    \
-      { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; } \
-      hipLaunchKernelGGL((KERNEL_), dim3((unsigned)tiles), dim3(THREADS_), lds_bytes, st, a);
-      if (b_presplit) { SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<true>, 512) } else { SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<false>, 512) }
-      return spgnn_detail::check_launch("spgnn_gemm");
-    }
-    const int WM = tile == 4 ? 4 : (tile == 2 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
-    const int TBM = 64 * WM;
-    gemm::Args a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
-                 (int)((M + TBM - 1) / TBM), (int)((N + gemm::BN - 1) / gemm::BN), upd_u, upd_u_stride, upd_v, upd_v_stride,
-                 (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
-                   mean_other, mean_other_stride, mean_out, mean_out_stride};
-    int64_t tiles = ((int64_t)a.nbm * a.nbn + 7) & ~int64_t(7);
-    const size_t lds_bytes = 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
-    if (WM == 4) {
-      if (b_presplit) { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, true>), 512) } else { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, false>), 512) }
-    } else {
-      if (b_presplit) { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, true>), 256) } else { SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, false>), 256) }
-    }
-#undef SPGNN_LAUNCH_NT
+  // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
+  // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones when the tiles fill whole rounds
+  // over the 256 CUs, and lose to the larger quantisation otherwise (measured at M = 76 410: N = 1024 / 1063, 4.67 /
+  // 5.84 rounds, win 12 % / 3 %; N = 768 / 512, 3.50 / 2.34 rounds, lose 7 % / 10 %): take it when at most 8 % of the
+  // last round is idle.  Offsets inside that kernel are 32-bit.
+  const bool fits31 = M * lda * 4 < (int64_t(1) << 31) && N * ldb * 4 < (int64_t(1) << 31);
+  const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
+  const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3;
+  int variant;
+  if (tile == 5 || (tile == 0 && v3_wins)) variant = fits31 ? 5 : 4;
+  else variant = tile == 4 ? 4 : (tile == 2 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
+  const int TBM = variant == 2 ? 128 : 256, TBN = variant == 5 ? 256 : gemm::BN;
+  plan->a = gemm::Args{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
+                       (int)((M + TBM - 1) / TBM), (int)((N + TBN - 1) / TBN), upd_u, upd_u_stride, upd_v, upd_v_stride,
+                       (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
+                       mean_other, mean_other_stride, mean_out, mean_out_stride};
+  plan->variant = variant;
+  plan->blocks = ((int64_t)plan->a.nbm * plan->a.nbn + 7) & ~int64_t(7);
+  return SPGNN_OK;
+}
+
+// the tile counts of `a` for another variant (a pair runs both products in the first one's kernel)
+static void gemm_nt_retile(NtPlan* p, int variant) {
+  const int TBM = variant == 2 ? 128 : 256, TBN = variant == 5 ? 256 : gemm::BN;
+  p->a.nbm = (p->a.M + TBM - 1) / TBM;
+  p->a.nbn = (p->a.N + TBN - 1) / TBN;
+  p->variant = variant;
+  p->blocks = ((int64_t)p->a.nbm * p->a.nbn + 7) & ~int64_t(7);
+}
+
+static size_t gemm_nt_lds(int variant) {
+  const int TBM = variant == 2 ? 128 : 256;
+  return variant == 5 ? 2 * 4 * 256 * gemm::PITCH * sizeof(_Float16)                       // 160 KB
+                      : 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
+}
+
+static int gemm_nt_launch(const NtPlan& p0, const NtPlan* p1, int32_t b_presplit, hipStream_t st) {
+  const int variant = p0.variant;
+  const size_t lds_bytes = gemm_nt_lds(variant);
+  const int threads = variant == 2 ? 256 : 512;
+#define SPGNN_LAUNCH_NT(KERNEL_, BLOCKS_, ARG_)                                                                \
+  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; \
+    hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(BLOCKS_)), dim3(threads), lds_bytes, st, ARG_); }
+  if (!p1) {
+    if (variant == 5) { if (b_presplit) SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<true>, p0.blocks, p0.a) else SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<false>, p0.blocks, p0.a) }
+    else if (variant == 4) { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, true>), p0.blocks, p0.a) else SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, false>), p0.blocks, p0.a) }
+    else { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, true>), p0.blocks, p0.a) else SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, false>), p0.blocks, p0.a) }
+  } else {
+    gemm::PairArgs pa{{p0.a, p1->a}, (unsigned)p0.blocks};
+    const int64_t blocks = p0.blocks + p1->blocks;
+    if (variant == 5) { if (b_presplit) SPGNN_LAUNCH_NT(gemm::gemm_nt_pair_v3<true>, blocks, pa) else SPGNN_LAUNCH_NT(gemm::gemm_nt_pair_v3<false>, blocks, pa) }
+    else if (variant == 4) { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<4, true>), blocks, pa) else SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<4, false>), blocks, pa) }
+    else { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<2, true>), blocks, pa) else SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<2, false>), blocks, pa) }
   }
+#undef SPGNN_LAUNCH_NT
   return spgnn_detail::check_launch("spgnn_gemm");
+}
+
+static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                        int64_t N, int64_t K, const float* scale_a, const float* scale_b, const float* upd_u,
+                        int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
+                        int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
+                        const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
+                        int32_t tile, int32_t b_presplit, spgnn_stream_t stream) {
+  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  NtPlan p;
+  const int rc = gemm_nt_plan(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
+                              activation, score_l, score_r, score_out, score_cols, mean_other, mean_other_stride, mean_out,
+                              mean_out_stride, tile, &p);
+  if (rc != SPGNN_OK || p.blocks == 0) return rc;
+  return gemm_nt_launch(p, nullptr, b_presplit, (hipStream_t)stream);
+}
+
+static int nt_plan_of(const spgnn_gemm_nt_problem* q, NtPlan* p) {
+  return gemm_nt_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->M, q->N, q->K, q->scale_a, q->scale_b, q->upd_u, q->upd_u_stride,
+                      q->upd_v, q->upd_v_stride, q->upd_j, q->bias, q->activation, q->score_l, q->score_r, q->score_out, q->score_cols,
+                      nullptr, 0, nullptr, 0, 0, p);
+}
+
+int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
+                       spgnn_stream_t stream) {
+  if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  NtPlan p0, p1;
+  int rc = nt_plan_of(first, &p0);
+  if (rc != SPGNN_OK) return rc;
+  rc = nt_plan_of(second, &p1);
+  if (rc != SPGNN_OK) return rc;
+  if (p0.blocks == 0 && p1.blocks == 0) return SPGNN_OK;
+  if (p0.blocks == 0) return gemm_nt_launch(p1, nullptr, b_presplit, (hipStream_t)stream);
+  if (p1.blocks == 0) return gemm_nt_launch(p0, nullptr, b_presplit, (hipStream_t)stream);
+  if (p1.variant != p0.variant) {                              // both in the first product's kernel
+    if (p0.variant == 5 && !((int64_t)second->M * second->lda * 4 < (int64_t(1) << 31) && (int64_t)second->N * second->ldb * 4 < (int64_t(1) << 31)))
+      return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+    gemm_nt_retile(&p1, p0.variant);
+  }
+  return gemm_nt_launch(p0, &p1, b_presplit, (hipStream_t)stream);
 }
 
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1468,9 +1558,9 @@ int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale
   return spgnn_detail::check_launch("spgnn_presplit");
 }
 
-int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
-                  int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
-                  float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
+static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
+                        int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
+                        float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, gemm::ArgsTN* a, int64_t* blocks) {
   if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   if (!A || !B || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
@@ -1480,13 +1570,42 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   int64_t rps = (R + splits - 1) / splits;
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
-  gemm::ArgsTN a{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                 (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, (int)splits};
-  const int64_t blocks = ((int64_t)a.nbm * a.nbn * splits + 7) & ~int64_t(7);
-  if (blocks > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  *a = gemm::ArgsTN{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
+                    (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, (int)splits};
+  *blocks = ((int64_t)a->nbm * a->nbn * splits + 7) & ~int64_t(7);
+  if (*blocks > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  return SPGNN_OK;
+}
+
+int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
+                  int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
+                  float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
+  gemm::ArgsTN a; int64_t blocks;
+  const int rc = gemm_tn_plan(A, lda, B, ldb, C, ldc, split_stride, splits, R, M, N, scale_a, scale_b, colsum_a, colsum_stride,
+                              colsum_split_stride, &a, &blocks);
+  if (rc != SPGNN_OK) return rc;
   const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
   { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
   hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, a);
+  return spgnn_detail::check_launch("spgnn_gemm");
+}
+
+int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream) {
+  if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  gemm::PairArgsTN pa; int64_t b0, b1;
+  const spgnn_gemm_tn_problem* q[2] = {first, second};
+  int64_t* bl[2] = {&b0, &b1};
+  for (int i = 0; i < 2; ++i) {
+    const int rc = gemm_tn_plan(q[i]->A, q[i]->lda, q[i]->B, q[i]->ldb, q[i]->C, q[i]->ldc, q[i]->split_stride, q[i]->splits, q[i]->R,
+                                q[i]->M, q[i]->N, q[i]->scale_a, q[i]->scale_b, q[i]->colsum_a, q[i]->colsum_stride,
+                                q[i]->colsum_split_stride, &pa.p[i], bl[i]);
+    if (rc != SPGNN_OK) return rc;
+  }
+  if (b0 + b1 > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  pa.nb0 = (unsigned)b0;
+  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
+  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+  hipLaunchKernelGGL(gemm::gemm_tn_pair_v2, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
   return spgnn_detail::check_launch("spgnn_gemm");
 }
 

@@ -1356,12 +1356,15 @@ class _LspeLevelFn(torch.autograd.Function):
         ys, ss, parts, scales, wts = [], [], [], [], []
         ctx.attn_shapes = (al_s.shape, al_p.shape)
         vecs = [(al_s.reshape(-1).contiguous(), ar_s.reshape(-1).contiguous()), (al_p.reshape(-1).contiguous(), ar_p.reshape(-1).contiguous())]
+        prods = []
         for x, w, (al, ar), H in ((x_s, w_s, vecs[0], 2), (x_p, w_p, vecs[1], 1)):
             sx, sw = operand_scale(x), operand_scale(w)
             wb, ps = _b_operand(w)
             pt = torch.empty((N, H * D // 64, 2), dtype=torch.float32, device=dev)
-            y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps)
-            ys.append(y); parts.append(pt); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+            prods.append(NtProblem(x, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps))
+            parts.append(pt); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+        ys = list(gemm_nt_pair(prods[0], prods[1]))        # the two projections: one launch
+        for pt, H in zip(parts, (2, 1)):
             ss.append(scores_from_parts(pt, H, D) if not LSPE_SCORES_IN_KERNEL else torch.empty((N, 2 * H), dtype=torch.float32, device=dev))
         buf = torch.empty((N, 3 * D), dtype=torch.float32, device=dev)
         xp = torch.empty((N, D), dtype=torch.float32, device=dev)
@@ -1442,6 +1445,7 @@ class _LspeLevelFn(torch.autograd.Function):
                                                    _seed_off_ptr(dev), st), "spgnn_lspe_bwd_src")
         grads_x, grads_w, grads_al, grads_ar, grads_b = [None, None], [None, None], [None, None], [None, None], [None, None]
         jobs = SumJobs(dev)                        # the level's four split-K reductions run as one launch at the end
+        tn, nt = [None, None], [None, None]        # the weight-gradient and input-gradient products of both layers: one launch each
         for i, H in enumerate(Hs):
             HD = H * D
             x, K = xs[i], xs[i].shape[1]
@@ -1450,26 +1454,40 @@ class _LspeLevelFn(torch.autograd.Function):
             need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
             if ctx.needs_input_grad[2 + i]:
                 if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
-                    if need_bias and res[i]:
-                        grads_w[i], cs = gemm_tn(g_y[i], x, sg, sx, want_colsum=True, defer=jobs)
-                        grads_b[i] = cs[HD:]
-                    else:
-                        grads_w[i] = gemm_tn(g_y[i], x, sg, sx, defer=jobs)
+                    tn[i] = TnProblem(g_y[i], x, sg, sx, want_colsum=bool(need_bias and res[i]), defer=jobs)
                 else:
                     grads_w[i] = _dw_gemm(g_y[i], x)
-            if need_bias and grads_b[i] is None:
-                grads_b[i] = g_pre[i].sum(0)
-            if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
-                m = scores_bwd_w(g_s[i], ys[i][:, :HD], blockdiag_heads=H, defer=jobs)
-                grads_al[i], grads_ar[i] = m[0].view(ctx.attn_shapes[i]), m[1].view(ctx.attn_shapes[i])
             if ctx.needs_input_grad[i]:
                 gx = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :K]
                 w_t, w_t_ps = ctx.wts[i]
                 if w_t_ps is not None:
-                    gemm_nt(g_y[i], w_t_ps, sg, sw, out=gx, b_presplit=True)
+                    nt[i] = NtProblem(g_y[i], w_t_ps, sg, sw, out=gx, b_presplit=True)
                 else:
-                    gemm_nt(g_y[i], w_t if w_t is not None else ws[i].t().contiguous(), sg, sw, out=gx)
+                    nt[i] = NtProblem(g_y[i], w_t if w_t is not None else ws[i].t().contiguous(), sg, sw, out=gx)
                 grads_x[i] = gx
+        if tn[0] is not None and tn[1] is not None:
+            r = gemm_tn_pair(tn[0], tn[1])
+        else:
+            r = [t.launch().finish() if t is not None else None for t in tn]
+        for i, H in enumerate(Hs):
+            if tn[i] is not None:
+                if tn[i].want_colsum:
+                    grads_w[i], cs = r[i]
+                    grads_b[i] = cs[H * D:]
+                else:
+                    grads_w[i] = r[i]
+            need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
+            if need_bias and grads_b[i] is None:
+                grads_b[i] = g_pre[i].sum(0)
+            if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
+                m = scores_bwd_w(g_s[i], ys[i][:, :H * D], blockdiag_heads=H, defer=jobs)
+                grads_al[i], grads_ar[i] = m[0].view(ctx.attn_shapes[i]), m[1].view(ctx.attn_shapes[i])
+        if nt[0] is not None and nt[1] is not None:
+            gemm_nt_pair(nt[0], nt[1])
+        else:
+            for q in nt:
+                if q is not None:
+                    q.run()
         jobs.flush()
         return (grads_x[0], grads_x[1], grads_w[0], grads_w[1], grads_al[0], grads_ar[0], grads_al[1], grads_ar[1], grads_b[0], grads_b[1],
                 None, None, None)
@@ -1977,6 +1995,45 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     return out
 
 
+PAIR_GEMMS = True       # a level's structure + position products as ONE launch each (spgnn_gemm_nt_pair / _tn_pair); False: two
+
+
+class NtProblem:
+    """One gemm_nt call, described but not launched (see :func:`gemm_nt_pair`); ``out`` is allocated here."""
+
+    def __init__(self, a, b, scale_a=None, scale_b=None, out=None, score_l=None, score_r=None, score_out=None, b_presplit=False):
+        _require_cuda(a, b)
+        M, K = a.shape
+        N = b.shape[0]
+        assert b.shape[1] == K and _rows_aligned(a) and _rows_aligned(b)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        assert out.shape == (M, N) and out.stride(1) == 1
+        self.out, self.shape, self.b_presplit = out, (M, N, K), bool(b_presplit)
+        self.kw = dict(scale_a=scale_a, scale_b=scale_b, out=out, score_l=score_l, score_r=score_r, score_out=score_out, b_presplit=b_presplit)
+        self.a, self.b = a, b
+        q = self.c = _capi.GemmNtProblem()
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K
+        q.scale_a, q.scale_b = _ptr(scale_a), _ptr(scale_b)
+        q.score_l, q.score_r, q.score_out = _ptr(score_l), _ptr(score_r), _ptr(score_out)
+        q.score_cols = score_l.numel() if score_out is not None else 0
+
+    def run(self) -> torch.Tensor:
+        return gemm_nt(self.a, self.b, **self.kw)
+
+
+def gemm_nt_pair(first: NtProblem, second: NtProblem):
+    """Both products in one launch (spgnn_gemm_nt_pair; pass the larger one first: its block tile is used for both) -
+    bit-identical to ``first.run(); second.run()``, which is what happens when PAIR_GEMMS is off or the operand forms differ."""
+    if not PAIR_GEMMS or first.b_presplit != second.b_presplit or first.a.device != second.a.device:
+        return first.run(), second.run()
+    import ctypes
+    with torch.cuda.device(first.a.device), _timed("gemm_nt_pair", first.shape + second.shape):
+        _capi.check(_capi.load().spgnn_gemm_nt_pair(ctypes.byref(first.c), ctypes.byref(second.c), int(first.b_presplit),
+                                                    _stream(first.a)), "spgnn_gemm_nt_pair")
+    return first.out, second.out
+
+
 def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: torch.Tensor, other: torch.Tensor,
                      mean_out: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, b_presplit: bool = False) -> None:
     """out = act(a @ b^T + bias) and mean_out = 0.5 * (out + other): the second head's projection of a two-head layer also
@@ -2011,19 +2068,7 @@ def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
     return H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and GEMM_MODE == "f16x3"
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
-            scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
-            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
-    """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
-    over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
-    accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
-    stride): write the result there - with ``out2`` columns [0, out.shape[1]) to ``out`` and the rest to ``out2``;
-    ``colsum_out`` (M,) contiguous likewise for the column sums."""
-    _require_cuda(a, b)
-    R, M = a.shape
-    N = b.shape[1]
-    assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+def _tn_splits(tiles: int, R: int) -> int:
     # Split count.  The kernel deals the (split, tile) work items to the XCDs in contiguous ranges, so any count keeps a
     # split's row range in one or two L2s.  Small products: enough splits for ~512 workgroups (two per CU), at least 256
     # rows each.  Large ones (tools/tn_splits.py, R = 76 410, incl. the partial-sum reduction): 1024 x 1063 (72 tiles)
@@ -2034,33 +2079,83 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     splits = max(1, min(256, 512 // tiles, R // 256))
     if tiles >= 16 and R >= 32 * 512:
         splits = 32 if tiles >= 48 else 21
-    ldn = (N + 3) // 4 * 4
-    ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
-    part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
-    cs_ptr = part[0, 0, ldn:].data_ptr() if want_colsum else 0
-    with torch.cuda.device(a.device), _timed("gemm_tn", (R, M, N)):
-        _capi.check(_capi.load().spgnn_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc,
-                                               M * ldc, splits, R, M, N, _ptr(scale_a), _ptr(scale_b), cs_ptr, ldc, M * ldc,
-                                               _stream(a)), "spgnn_gemm_tn")
-    # compact outputs: (M, N) contiguous and the column sums as their own vector - autograd takes contiguous gradients
-    # over as they are, the row-strided views of the padded tile were cloned once per parameter (18 copies per step)
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    split_col = out.shape[1] if out2 is not None else 0
-    assert out.stride(1) == 1 and out.shape[0] == M and (out2 is None or (out2.stride(1) == 1 and out2.shape == (M, N - split_col)))
-    cs = (colsum_out if colsum_out is not None else torch.empty((M,), dtype=torch.float32, device=a.device)) if want_colsum else None
-    assert cs is None or cs.is_contiguous()
-    if defer is not None:
-        defer.add(_capi.SumJob(kind=2, splits=splits, partials=part.data_ptr(), split_stride=M * ldc, out=out.data_ptr(),
-                               out_stride=out.stride(0), M=M, N=N, ld_in=ldc, out2=_ptr(out2),
-                               out2_stride=out2.stride(0) if out2 is not None else 0, split_col=split_col, extra=_ptr(cs),
-                               extra_col=ldn if want_colsum else 0), part, out, out2, cs)
-    else:
-        with torch.cuda.device(a.device):
-            _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, splits, M, N, ldc, out.data_ptr(), out.stride(0),
-                                                                _ptr(out2), out2.stride(0) if out2 is not None else 0, split_col,
-                                                                _ptr(cs), ldn if want_colsum else 0, _stream(a)),
-                        "spgnn_sum_partials_compact")
-    if want_colsum:
-        return out, cs
-    return out
+    return splits
+
+
+class TnProblem:
+    """One gemm_tn call: the partial-tile buffer and outputs are allocated here; ``launch()`` (or :func:`gemm_tn_pair`) runs
+    the product, ``finish()`` issues or defers the deterministic partial sums and returns gemm_tn's result."""
+
+    def __init__(self, a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+                 scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
+                 out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
+        _require_cuda(a, b)
+        R, M = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = _tn_splits(tiles, R)
+        ldn = (N + 3) // 4 * 4
+        ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
+        part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
+        cs_ptr = part[0, 0, ldn:].data_ptr() if want_colsum else 0
+        # compact outputs: (M, N) contiguous and the column sums as their own vector - autograd takes contiguous gradients
+        # over as they are, the row-strided views of the padded tile were cloned once per parameter (18 copies per step)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        split_col = out.shape[1] if out2 is not None else 0
+        assert out.stride(1) == 1 and out.shape[0] == M and (out2 is None or (out2.stride(1) == 1 and out2.shape == (M, N - split_col)))
+        cs = (colsum_out if colsum_out is not None else torch.empty((M,), dtype=torch.float32, device=a.device)) if want_colsum else None
+        assert cs is None or cs.is_contiguous()
+        self.a, self.b, self.part, self.out, self.out2, self.cs, self.defer = a, b, part, out, out2, cs, defer
+        self.shape, self.splits, self.ldc, self.ldn, self.split_col, self.want_colsum = (R, M, N), splits, ldc, ldn, split_col, want_colsum
+        self.scales = (scale_a, scale_b)
+        q = self.c = _capi.GemmTnProblem()
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.split_stride = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc
+        q.R, q.M, q.N, q.scale_a, q.scale_b = R, M, N, _ptr(scale_a), _ptr(scale_b)
+        q.colsum_a, q.colsum_stride, q.colsum_split_stride, q.splits = cs_ptr, ldc, M * ldc, splits
+
+    def launch(self):
+        q = self.c
+        with torch.cuda.device(self.a.device), _timed("gemm_tn", self.shape):
+            _capi.check(_capi.load().spgnn_gemm_tn(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.split_stride, q.splits, q.R, q.M, q.N,
+                                                   q.scale_a, q.scale_b, q.colsum_a, q.colsum_stride, q.colsum_split_stride,
+                                                   _stream(self.a)), "spgnn_gemm_tn")
+        return self
+
+    def finish(self):
+        (R, M, N), part, out, out2, cs, ldc = self.shape, self.part, self.out, self.out2, self.cs, self.ldc
+        if self.defer is not None:
+            self.defer.add(_capi.SumJob(kind=2, splits=self.splits, partials=part.data_ptr(), split_stride=M * ldc, out=out.data_ptr(),
+                                        out_stride=out.stride(0), M=M, N=N, ld_in=ldc, out2=_ptr(out2),
+                                        out2_stride=out2.stride(0) if out2 is not None else 0, split_col=self.split_col, extra=_ptr(cs),
+                                        extra_col=self.ldn if self.want_colsum else 0), part, out, out2, cs)
+        else:
+            with torch.cuda.device(self.a.device):
+                _capi.check(_capi.load().spgnn_sum_partials_compact(part.data_ptr(), M * ldc, self.splits, M, N, ldc, out.data_ptr(),
+                                                                    out.stride(0), _ptr(out2), out2.stride(0) if out2 is not None else 0,
+                                                                    self.split_col, _ptr(cs), self.ldn if self.want_colsum else 0,
+                                                                    _stream(self.a)), "spgnn_sum_partials_compact")
+        return (out, cs) if self.want_colsum else out
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+            scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
+            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
+    """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
+    over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
+    accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
+    stride): write the result there - with ``out2`` columns [0, out.shape[1]) to ``out`` and the rest to ``out2``;
+    ``colsum_out`` (M,) contiguous likewise for the column sums."""
+    return TnProblem(a, b, scale_a, scale_b, want_colsum, out, out2, colsum_out, defer).launch().finish()
+
+
+def gemm_tn_pair(first: TnProblem, second: TnProblem):
+    """Both weight-gradient products in one launch (spgnn_gemm_tn_pair), then each one's ``finish()`` - bit-identical to two
+    gemm_tn calls, which is what runs when PAIR_GEMMS is off."""
+    if not PAIR_GEMMS or first.a.device != second.a.device:
+        return first.launch().finish(), second.launch().finish()
+    import ctypes
+    with torch.cuda.device(first.a.device), _timed("gemm_tn_pair", first.shape + second.shape):
+        _capi.check(_capi.load().spgnn_gemm_tn_pair(ctypes.byref(first.c), ctypes.byref(second.c), _stream(first.a)), "spgnn_gemm_tn_pair")
+    return first.finish(), second.finish()

@@ -323,6 +323,51 @@ def test_weight_prep_column_mode_feeds_the_aggregate_first_layer():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M,shapes", [(9641, ((1024, 1063), (512, 39))), (9641, ((512, 768), (256, 256))), (3000, ((256, 384), (128, 128))),
+                                      (20000, ((1024, 1063), (512, 39))), (777, ((130, 70), (64, 8)))])
+def test_pair_launches_equal_two_launches(M, shapes):
+    """spgnn_gemm_nt_pair / spgnn_gemm_tn_pair (a level's structure and position products in one launch) against two
+    launches, bit for bit: forward form with score partials and pre-split weights, and the weight-gradient form with column sums
+    and deferred partial sums; the second product runs in the first one's block tile (256 x 256 at M = 20 000)."""
+    torch.manual_seed(M)
+    xs = [_mat(M, (k + 3) // 4 * 4)[:, :k] for _, k in shapes]
+    ws = [_mat(n, (k + 3) // 4 * 4, 0.05)[:, :k] for n, k in shapes]
+    sx, sw = [ops.pow2_scale(x) for x in xs], [ops.pow2_scale(w) for w in ws]
+    ps = [ops.presplit(w, scale=s_)[0] for w, s_ in zip(ws, sw)]
+    vec = [(torch.randn(n // 64 * 64, device="cuda"), torch.randn(n // 64 * 64, device="cuda")) for n, _ in shapes]
+
+    def problems(presplit):
+        out = []
+        for i, (n, k) in enumerate(shapes):
+            sc = n // 64 * 64
+            pt = torch.zeros((M, sc // 64, 2), device="cuda") if sc else None
+            out.append(ops.NtProblem(xs[i], ps[i] if presplit else ws[i], sx[i], sw[i], score_l=vec[i][0] if sc else None,
+                                     score_r=vec[i][1] if sc else None, score_out=pt, b_presplit=presplit))
+        return out
+    for presplit in (True, False):
+        a = problems(presplit); b = problems(presplit)
+        ya = ops.gemm_nt_pair(a[0], a[1])
+        yb = (b[0].run(), b[1].run())
+        for i in range(2):
+            assert torch.equal(ya[i], yb[i])
+            if a[i].kw["score_out"] is not None:
+                assert torch.equal(a[i].kw["score_out"], b[i].kw["score_out"])
+    # weight gradients: g (M, n)^T x (M, k)
+    gs = [_mat(M, n) for n, _ in shapes]
+    sg = [ops.pow2_scale(g_) for g_ in gs]
+    res = []
+    for pair in (True, False):
+        jobs = ops.SumJobs("cuda")
+        t = [ops.TnProblem(gs[i], xs[i], sg[i], sx[i], want_colsum=(i == 0), defer=jobs) for i in range(2)]
+        r = ops.gemm_tn_pair(t[0], t[1]) if pair else (t[0].launch().finish(), t[1].launch().finish())
+        jobs.flush()
+        res.append((r[0][0].clone(), r[0][1].clone(), r[1].clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    ref = gs[0].double().t() @ xs[0].double()
+    assert rel_err(res[0][0], ref) < 3e-6 and rel_err(res[0][1], gs[0].double().sum(0)) < 1e-5
+
+
 def test_gemm_takes_scale_blocks():
     """A GEMM operand's scale as a SCALE BLOCK (include/spgnn_hip.h): {-256, 0, 0, 0, m_1 .. m_256} whose largest slot the
     kernel turns into the power-of-two scale itself - bit-identical to passing the scalar scale, for every tile variant of

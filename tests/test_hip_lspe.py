@@ -78,6 +78,26 @@ def test_fused_level_equals_two_layer_form(train, monkeypatch):
         assert rel_err(g_f[n], g_u[n]) < (4 * GRAD_TOL if train else GRAD_TOL) or tiny, (n, rel_err(g_f[n], g_u[n]))
 
 
+def test_pair_launches_leave_the_step_bitwise_unchanged(monkeypatch):
+    """ops.PAIR_GEMMS: a level's two projections / weight gradients / input gradients as one launch each - outputs and every
+    gradient equal the separate launches bit for bit, and the paired step has the fewer launches."""
+    cfg, model = _model(3)
+    g = synthetic.make_batch(4, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    res, names = [], []
+    for pair in (True, False):
+        monkeypatch.setattr(ops, "PAIR_GEMMS", pair)
+        ops.KernelTimer.start()
+        res.append(_run(model, g, cfg, True, True, monkeypatch))
+        names.append([k[0] for k in ops.KernelTimer.sequence])
+        ops.KernelTimer.stop()
+    assert "gemm_nt_pair" in names[0] and "gemm_tn_pair" in names[0] and "gemm_nt_pair" not in names[1]
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert set(res[0][1]) == set(res[1][1])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
 def test_fused_level_matches_oracle_gradients(monkeypatch):
     """fwd + all parameter gradients of the fused path against the CPU oracle (eval-mode arithmetic), with the position
     output inside the loss so that the second gradient path of every level is exercised."""

@@ -9,7 +9,7 @@ in launch order and the stem is checked row by row."""
 import glob, json, re, sys
 import pandas as pd
 
-STEM_RE = re.compile(r"\b(gat_fwd|gat_bwd_dst|gat_bwd_src|gat_agg_fwd|gat_agg_bwd_dst|gat_agg_bwd_src|lspe_fwd|lspe_bwd_dst|lspe_bwd_src|gemm_nt|gemm_tn)")
+STEM_RE = re.compile(r"\b(gat_fwd|gat_bwd_dst|gat_bwd_src|gat_agg_fwd|gat_agg_bwd_dst|gat_agg_bwd_src|lspe_fwd|lspe_bwd_dst|lspe_bwd_src|gemm_nt_pair|gemm_tn_pair|gemm_nt|gemm_tn)")
 
 
 def stem_of(name):

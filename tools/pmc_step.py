@@ -13,7 +13,7 @@ from spgnn_amd.configs import class_weight_list, get_config
 from spgnn_amd.train import TrainStep
 
 STEMS = ("gat_fwd", "gat_bwd_dst", "gat_bwd_src", "gat_agg_fwd", "gat_agg_bwd_dst", "gat_agg_bwd_src", "lspe_fwd", "lspe_bwd_dst",
-         "lspe_bwd_src", "gemm_nt", "gemm_tn")
+         "lspe_bwd_src", "gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair")
 
 name, dtype, trees, mpath = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 cfg = get_config(name)
