@@ -311,6 +311,7 @@ int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices,
                    const float* bias, int32_t activation,
                    float* out, int64_t out_stride,
                    int64_t N, int64_t E, int32_t F,
+                   float* absmax_out /* nullable scale block (see spgnn_gemm_nt): max |out| folded into its slots */,
                    spgnn_stream_t stream);
 
 /*
@@ -470,6 +471,9 @@ typedef struct spgnn_gemm_nt_problem {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t M; int64_t N; int64_t K;
   const float* scale_a; const float* scale_b; const float* upd_u; int64_t upd_u_stride; const float* upd_v; int64_t upd_v_stride;
   const float* bias; const float* score_l; const float* score_r; float* score_out;
+  const float* addend; int64_t addend_stride;      /* nullable: C = act(A B^T + bias + addend), as spgnn_gemm_nt_add */
+  float* absmax_out;                               /* nullable scale block: max |C| is folded into its slots, so the result
+                                                      can be the next product's operand without an absmax pass over it */
   int32_t upd_j; int32_t activation; int32_t score_cols; int32_t reserved;
 } spgnn_gemm_nt_problem;
 typedef struct spgnn_gemm_tn_problem {
@@ -477,6 +481,7 @@ typedef struct spgnn_gemm_tn_problem {
   const float* scale_a; const float* scale_b; float* colsum_a; int64_t colsum_stride; int64_t colsum_split_stride;
   int32_t splits; int32_t reserved;
 } spgnn_gemm_tn_problem;
+int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream);   /* one product, every option */
 int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
                        spgnn_stream_t stream);
 int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);

@@ -23,8 +23,8 @@ _i64, _i32, _f32, _u64, _vp = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_v
 class GemmNtProblem(C.Structure):         # spgnn_gemm_nt_problem
     _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("M", _i64), ("N", _i64), ("K", _i64),
                 ("scale_a", _vp), ("scale_b", _vp), ("upd_u", _vp), ("upd_u_stride", _i64), ("upd_v", _vp), ("upd_v_stride", _i64),
-                ("bias", _vp), ("score_l", _vp), ("score_r", _vp), ("score_out", _vp),
-                ("upd_j", _i32), ("activation", _i32), ("score_cols", _i32), ("reserved", _i32)]
+                ("bias", _vp), ("score_l", _vp), ("score_r", _vp), ("score_out", _vp), ("addend", _vp), ("addend_stride", _i64),
+                ("absmax_out", _vp), ("upd_j", _i32), ("activation", _i32), ("score_cols", _i32), ("reserved", _i32)]
 
 
 class GemmTnProblem(C.Structure):         # spgnn_gemm_tn_problem
@@ -89,7 +89,7 @@ SIGNATURES = {
     "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
     "spgnn_scores_bwd_w": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
     "spgnn_scores_bwd_x": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _i32, _i64, _i32, _i32, _vp],
-    "spgnn_spmm_sum": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _i64, _i64, _i32, _vp],
+    "spgnn_spmm_sum": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _i64, _i64, _i32, _f32p, _vp],
     "spgnn_spmm_max_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _i32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_bwd": [_i32p, _i32p, _i32p, _f32p, _i64, _i32p, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
@@ -117,6 +117,7 @@ SIGNATURES = {
     "spgnn_sgd_momentum_step_mean": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
     "spgnn_step_begin": [_vp, _f32p, _i32, _vp],
     "spgnn_gemm_nt_pair": [_vp, _vp, _i32, _vp],
+    "spgnn_gemm_nt_problem_run": [_vp, _i32, _vp],
     "spgnn_gemm_tn_pair": [_vp, _vp, _vp],
     "spgnn_sample_neighbors": [_i32p, _i32p, _i32p, _i64, _vp, _i64, _i32, _i32p, _u64, _i32p, _i32p, _i32p, _i32p, _vp],
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],

@@ -55,6 +55,9 @@ struct Args {
   // mean_other WITHOUT mean_out is an ADDEND: C = act(A B^T + bias + mean_other) - the second of two products that share an
   // output (SAGEConv: fc_self(h) + fc_neigh(neigh), reference models.py:668-679) adds the first one's result in its epilogue
   const float* mean_other; int64_t ld_mo; float* mean_out; int64_t ld_mn;
+  // optional scale block (spgnn_internal.h): max |stored value| of every tile is folded into its slots - the result's GEMM
+  // operand scale for the next product, without a pass over it
+  float* absmax;
 };
 // B may arrive PRE-SPLIT (spgnn_presplit): every group of four fp32 values replaced, in place, by its packed fp16 pairs
 // [hi01, hi23, lo01, lo23] of s*x (the 16 bytes split4_pk would produce), rows zero padded to a multiple of four columns.
@@ -240,6 +243,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   for (int jj = 0; jj < 4; ++jj)
     wv[jj] = (use_j && small_j && jj < a.J) ? *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  float amx = 0.f;                                       // max |stored value| of this lane (a.absmax)
   // one 32-row half of the wave's tile; called with a literal i per half (a loop over i is not unrolled once its body has
   // two large paths, and acc[i] with a run-time i puts the accumulators in scratch memory: 7x slower)
   auto do_half = [&](const int i) __attribute__((always_inline)) {
@@ -332,6 +336,9 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
       }
       float* dst0 = a.C + (int64_t)(row0 + wm * (32 * MI) + i * 32 + r_in) * a.ldc + col;
 #pragma unroll
+      for (int it = 0; it < 8; ++it)
+        amx = fmaxf(amx, fmaxf(fmaxf(fabsf(vv[it].x), fabsf(vv[it].y)), fmaxf(fabsf(vv[it].z), fabsf(vv[it].w))));
+#pragma unroll
       for (int it = 0; it < 8; ++it) {
         // streaming store: the (M, N) result is far larger than the caches and is next read by another kernel; without the
         // temporal hint the store bursts at the end of every round of tiles are 2-5 % of a product (timing-only build
@@ -399,6 +406,8 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
               a.mean_out[(int64_t)row * a.ld_mn + col + q_] = 0.5f * (vq[q_] + a.mean_other[(int64_t)row * a.ld_mo + col + q_]);
         }
         float* dst = a.C + (int64_t)row * a.ldc + col;
+        amx = fmaxf(amx, fmaxf(fmaxf(col < a.N ? fabsf(v.x) : 0.f, col + 1 < a.N ? fabsf(v.y) : 0.f),
+                               fmaxf(col + 2 < a.N ? fabsf(v.z) : 0.f, col + 3 < a.N ? fabsf(v.w) : 0.f)));
         if (vec_ok && col + 3 < a.N) *reinterpret_cast<float4*>(dst) = v;
         else {
           if (col < a.N) dst[0] = v.x;
@@ -430,6 +439,10 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   do_half(1);
   if constexpr (MI == 4) { do_half(2); do_half(3); }
   static_assert(MI == 2 || MI == 4, "wave tile is 64 or 128 rows");
+  if (a.absmax) {                                        // block-uniform
+    for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, amx, (unsigned)((row0 >> 5) + (col0 >> 6) + wave));
+  }
 }
 
 template <int WM, bool BPS>
@@ -1371,7 +1384,7 @@ static int gemm_nt_plan(const float* A, int64_t lda, const float* B, int64_t ldb
                         int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j, const float* bias,
                         int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
-                        int32_t tile, NtPlan* plan) {
+                        float* absmax_out, int32_t tile, NtPlan* plan) {
   plan->blocks = 0;
   if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (mean_out) {
@@ -1419,7 +1432,7 @@ static int gemm_nt_plan(const float* A, int64_t lda, const float* B, int64_t ldb
   plan->a = gemm::Args{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, scale_a, scale_b,
                        (int)((M + TBM - 1) / TBM), (int)((N + TBN - 1) / TBN), upd_u, upd_u_stride, upd_v, upd_v_stride,
                        (int)upd_j, bias, (int)activation, score_l, score_r, score_out, score_out ? (int)score_cols : 0,
-                       mean_other, mean_other_stride, mean_out, mean_out_stride};
+                       mean_other, mean_other_stride, mean_out, mean_out_stride, absmax_out};
   plan->variant = variant;
   plan->blocks = ((int64_t)plan->a.nbm * plan->a.nbn + 7) & ~int64_t(7);
   return SPGNN_OK;
@@ -1472,7 +1485,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
   NtPlan p;
   const int rc = gemm_nt_plan(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
                               activation, score_l, score_r, score_out, score_cols, mean_other, mean_other_stride, mean_out,
-                              mean_out_stride, tile, &p);
+                              mean_out_stride, nullptr, tile, &p);
   if (rc != SPGNN_OK || p.blocks == 0) return rc;
   return gemm_nt_launch(p, nullptr, b_presplit, (hipStream_t)stream);
 }
@@ -1480,7 +1493,16 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
 static int nt_plan_of(const spgnn_gemm_nt_problem* q, NtPlan* p) {
   return gemm_nt_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->M, q->N, q->K, q->scale_a, q->scale_b, q->upd_u, q->upd_u_stride,
                       q->upd_v, q->upd_v_stride, q->upd_j, q->bias, q->activation, q->score_l, q->score_r, q->score_out, q->score_cols,
-                      nullptr, 0, nullptr, 0, 0, p);
+                      q->addend, q->addend_stride, nullptr, 0, q->absmax_out, 0, p);
+}
+
+int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream) {
+  if (!problem) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  NtPlan p;
+  const int rc = nt_plan_of(problem, &p);
+  if (rc != SPGNN_OK || p.blocks == 0) return rc;
+  return gemm_nt_launch(p, nullptr, b_presplit, (hipStream_t)stream);
 }
 
 int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,

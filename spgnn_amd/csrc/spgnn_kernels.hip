@@ -380,7 +380,9 @@ __global__ void gat_fwd_scalar(GatFwd a) {
   }
   if (a.res) acc += a.res[v * a.res_ld + col];
   if (a.bias) acc += a.bias[col];
-  a.out[v * a.out_ld + col] = act_fwd(acc, a.act);
+  acc = act_fwd(acc, a.act);
+  a.out[v * a.out_ld + col] = acc;
+  if (a.absmax) spgnn_detail::slots_max(a.absmax, fabsf(acc), (unsigned)v);
 }
 
 // head mean for shapes the vector kernel cannot fuse: out_mean[v,d] = mean_h out[v,h,d]
@@ -1580,6 +1582,7 @@ struct SpmmSum {
   float* out; int64_t out_ld;
   int64_t N; int F; int T;
   const float* bias; int act;            // optional epilogue out = act(... + bias[col]) (GraphConv: reference models.py:172-182)
+  float* absmax;                         // optional scale block: max |out| folded into its slots (the result as a GEMM operand)
 };
 
 // TT = 64: one node per wave with wave-uniform index / weight values in SGPRs; TT = 0: run-time team width
@@ -1630,6 +1633,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
   }
   const float wd = a.w_dst ? a.w_dst[v] : 1.f;
   const float sc = a.self_eps ? 1.f + a.self_eps[0] : 0.f;
+  float amx = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int c = (r * T + lane) * 4;
@@ -1638,6 +1642,11 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
     if (a.bias) { const float4 b = ld4(a.bias + c); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
     if (a.act != SPGNN_ACT_NONE) { o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act); }
     st4(a.out + v * a.out_ld + c, o);
+    amx = absmax4(amx, o);
+  }
+  if (a.absmax) {
+    amx = team_max(amx, T);
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, amx, (unsigned)v);
   }
 }
 
@@ -3080,14 +3089,14 @@ int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int6
 
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
                    const float* w_dst, const float* self_eps, const float* bias, int32_t activation, float* out,
-                   int64_t out_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
+                   int64_t out_stride, int64_t N, int64_t E, int32_t F, float* absmax_out, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_sum: bad N/E/F");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_spmm_sum: activation");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !out || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_sum: null pointer");
   if (x_stride < F || out_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_sum: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation};
+  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation, absmax_out};
   int T, R;
   if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && (!bias || aligned16(bias))) {
     a.T = T;

@@ -151,6 +151,15 @@ class DeviceCSC:
             self._cache["out_deg"] = (self.out_indptr[1:] - self.out_indptr[:-1]).to(torch.float32)
         return self._cache["out_deg"]
 
+    def degree_scale(self, which: str, power: float) -> torch.Tensor:
+        """clamp(in- or out-degree, min=1) ** power, cached: the degree normalisations of GraphConv ('both': -0.5, 'right' /
+        'left': -1), GIN-mean and SAGE-mean are properties of the graph, not of the step (three launches each, every layer)."""
+        key = ("deg_scale", which, float(power))
+        if key not in self._cache:
+            d = (self.in_degrees_f() if which == "in" else self.out_degrees_f()).clamp(min=1)
+            self._cache[key] = d.pow(power) if power != -1.0 else 1.0 / d
+        return self._cache[key]
+
 
 def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True):
     """Edge list + CSC + CSR of a loader batch built ON THE DEVICE from the trees' adjacency matrices (reference rule:

@@ -81,6 +81,16 @@ def _prep_specs(levels, on_gpu: bool, output=None):
     return [sp for sp in specs if sp is not None]
 
 
+def _linear_specs(module: nn.Module, x: torch.Tensor):
+    """ops.prepared_weights entries for every ``nn.Linear`` under ``module`` (the GIN MLPs, SAGEConv's fc_pool / fc_self /
+    fc_neigh; reference models.py:236-246, 668-679): their padded rows, transposes, pre-split forms and scales come out of
+    one spgnn_weight_prep call per forward pass instead of two absmax + two scale launches per Linear."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return []
+    want_t = torch.is_grad_enabled()
+    return [(m.weight, None, want_t) for m in module.modules() if type(m) is nn.Linear and m.weight.is_cuda]
+
+
 FUSE_LSPE = True               # GATPSPGNN: structure + position GATConv of a level in ONE traversal (ops.lspe_level); False: two layers
 
 
@@ -238,8 +248,9 @@ class GIN(nn.Module):
 
     def forward(self, g):
         h = g.ndata["fvs"]
-        for layer in self.gin_layers:
-            h = layer(g, h)
+        with ops.prepared_weights(_linear_specs(self, h)):
+            for layer in self.gin_layers:
+                h = layer(g, h)
         return F.normalize(h, p=2, dim=1) if self.norm else h
 
     def forward_batch(self, blocks, x):
@@ -433,8 +444,9 @@ class SAGE(nn.Module):
 
     def forward(self, g):
         h = g.ndata["fvs"]
-        for layer in self.g_layers:
-            h = layer(g, h)
+        with ops.prepared_weights(_linear_specs(self, h)):
+            for layer in self.g_layers:
+                h = layer(g, h)
         return h
 
 

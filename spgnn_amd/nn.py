@@ -348,11 +348,9 @@ class GraphConv(nn.Module):
         weight = self.weight if weight is None else weight
         w_src = w_dst = None
         if self._norm in ("left", "both"):
-            d = csc.out_degrees_f().clamp(min=1)
-            w_src = d.pow(-0.5) if self._norm == "both" else 1.0 / d
+            w_src = csc.degree_scale("out", -0.5 if self._norm == "both" else -1.0)
         if self._norm in ("right", "both"):
-            d = csc.in_degrees_f().clamp(min=1)
-            w_dst = d.pow(-0.5) if self._norm == "both" else 1.0 / d
+            w_dst = csc.degree_scale("in", -0.5 if self._norm == "both" else -1.0)
         # bias and activation ride in the epilogue of whichever kernel comes last (FUSE_EPILOGUES): the SpMM when the
         # projection comes first (in_feats > out_feats), else the projection GEMM
         act = _act_code_dense(self._activation)
@@ -383,6 +381,17 @@ def _dst_rows(csc, x: torch.Tensor) -> torch.Tensor:
     return x if nd is None else x[:nd]
 
 
+def _hash_dropout(drop: nn.Dropout, x: torch.Tensor) -> torch.Tensor:
+    """``drop(x)`` by the counter-hash kernel on the GPU (spgnn_cat_dropout: no mask tensor, the backward regenerates it, and
+    the result carries its GEMM operand scale); torch's dropout elsewhere.  fp32 rows of 16-byte-aligned width only."""
+    p = float(drop.p) if drop.training else 0.0
+    if p == 0.0:
+        return x
+    if not (FUSE_EPILOGUES and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and p < 1.0):
+        return drop(x)
+    return ops.cat_dropout((x,), p, _draw_seed())
+
+
 FUSE_EPILOGUES = True     # bias / activation of GraphConv, the GIN MLP and SAGEConv inside the producing kernel's epilogue
 
 
@@ -408,7 +417,7 @@ def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
                 if code is not None:
                     x = ops.linear(x, m.weight, m.bias, code)
                     if drop is not None:
-                        x = drop(x)
+                        x = _hash_dropout(drop, x)
                     i = j + 1
                     continue
             x = _apply_fast_linear(m, x)
@@ -440,7 +449,7 @@ class GINConv(nn.Module):
         if self._aggregator_type == "max":
             rst = _dst_rows(csc, (1 + self.eps) * feat + ops.spmm_max(csc, feat))
         else:
-            w_dst = (1.0 / csc.in_degrees_f().clamp(min=1)) if self._aggregator_type == "mean" else None
+            w_dst = csc.degree_scale("in", -1.0) if self._aggregator_type == "mean" else None
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, None, w_dst, self.eps))     # (1+eps)*x fused into the SpMM
         if self.apply_func is not None:
             rst = _apply_fast_linear(self.apply_func, rst)
@@ -492,14 +501,20 @@ class SAGEConv(nn.Module):
         if edge_weight is not None:
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
-        h = self.feat_drop(feat)
+        h = _hash_dropout(self.feat_drop, feat)
         act = _act_code_dense(self.activation)
         fuse = FUSE_EPILOGUES and h.is_cuda and act is not None and self._out_feats % 4 == 0
         if self._aggre_type in ("pool", "mean"):
             if self._aggre_type == "pool":
-                neigh = _dst_rows(csc, ops.spmm_max(csc, ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)))
+                pool = ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)
+                neigh = _dst_rows(csc, ops.spmm_max(csc, pool))
+                tag = getattr(pool, "_spgnn_scale", None)
+                if tag is not None and tag[0] == pool._version and neigh.is_cuda:
+                    # every element of the neighbourhood maximum is an element of ``pool`` (or 0): pool's operand scale,
+                    # which its product's epilogue left behind, bounds it - no absmax pass over ``neigh``
+                    neigh._spgnn_scale = (neigh._version, tag[1])
             else:
-                neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, 1.0 / csc.in_degrees_f().clamp(min=1)))
+                neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, csc.degree_scale("in", -1.0)))
             if fuse:        # fc_neigh's product adds fc_self's result and applies the activation in its epilogue
                 rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias, act,
                                  addend=ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias))

@@ -636,15 +636,33 @@ class _LinearFn(torch.autograd.Function):
         x = _rowmajor(x)
         if not _rows_aligned(x):
             x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
-        w = weight if weight.stride(1) == 1 else weight.contiguous()      # e.g. GraphConv's (in, out) weight seen as W^T
-        if not _rows_aligned(w):
-            w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
-        sx, sw = operand_scale(x), pow2_scale(w)
-        if addend is not None:                                             # act(x W^T + b + addend) in one epilogue
-            y = gemm_nt_add(x, w, sx, sw, _rowmajor(addend), bias=bias, act=act)
+        N, K = x.shape
+        C = weight.shape[0]
+        hit = _PREP_ACTIVE.get((id(weight), 0)) if PRESPLIT_B else None
+        ctx.wt = None
+        if hit is not None and hit[0][5] == (C, 0, K, C):
+            # padded rows, scale, pre-split form and the transposes: built by this pass's spgnn_weight_prep
+            dst, ps, dst_t, ps_t, sw, _ = hit[0]
+            w, wb, bps = dst[:, :K], ps[:, :K], True
+            ctx.wt = (dst_t[:, :C], ps_t[:, :C]) if hit[1] else None
         else:
-            y = gemm_nt(x, w, sx, sw, bias=bias, act=act)
-        ctx.act, ctx.has_bias, ctx.has_addend = act, bias is not None, addend is not None
+            w = weight if weight.stride(1) == 1 else weight.contiguous()      # e.g. GraphConv's (in, out) weight seen as W^T
+            if not _rows_aligned(w):
+                w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
+            sw, wb, bps = pow2_scale(w), w, False
+        sx = operand_scale(x)
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        blk = new_scale_block(x.device) if EMIT_SCALES else None            # max |y| from the product's own epilogue
+        q = NtProblem(x, wb, sx, sw, out=y, b_presplit=bps)
+        q.c.bias, q.c.activation, q.c.absmax_out = _ptr(bias), int(act), _ptr(blk)
+        if addend is not None:                                             # act(x W^T + b + addend) in one epilogue
+            addend = _rowmajor(addend)
+            assert addend.shape == (N, C) and _rows_aligned(addend)
+            q.c.addend, q.c.addend_stride = addend.data_ptr(), addend.stride(0)
+        import ctypes
+        with torch.cuda.device(x.device), _timed("gemm_nt", (N, C, K)):
+            _capi.check(_capi.load().spgnn_gemm_nt_problem_run(ctypes.byref(q.c), int(bps), _stream(x)), "spgnn_gemm_nt_problem_run")
+        ctx.act, ctx.has_bias, ctx.has_addend, ctx.scale_block = act, bias is not None, addend is not None, blk
         ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
         return y
 
@@ -662,12 +680,15 @@ class _LinearFn(torch.autograd.Function):
                          ACT_RELU: (y > 0).to(y.dtype), ACT_LRELU: torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))}[ctx.act]
             if not _rows_aligned(g):
                 g = cat_padded((g,))
-            sg = pow2_scale(g)
+            sg = operand_scale(g)
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
             g_x = torch.empty((N, (K + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :K]
-            w_t = w.t().contiguous() if C % 4 == 0 else torch.nn.functional.pad(w.t(), (0, -C % 4)).contiguous()[:, :C]
-            gemm_nt(g, w_t, sg, sw, out=g_x)
+            if ctx.wt is not None:
+                gemm_nt(g, ctx.wt[1], sg, sw, out=g_x, b_presplit=True)
+            else:
+                w_t = w.t().contiguous() if C % 4 == 0 else torch.nn.functional.pad(w.t(), (0, -C % 4)).contiguous()[:, :C]
+                gemm_nt(g, w_t, sg, sw, out=g_x)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if ctx.has_bias:
                 g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
@@ -684,7 +705,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32 and weight.shape[1] >= 32
             and x.dtype == torch.float32 and weight.dtype == torch.float32
             and (addend is None or (weight.shape[0] % 4 == 0 and addend.shape == (N, weight.shape[0])))):
-        return _LinearFn.apply(x, weight, bias, act, addend)
+        y = _LinearFn.apply(x, weight, bias, act, addend)
+        blk = getattr(y.grad_fn, "scale_block", None) if y.grad_fn is not None else None
+        if blk is not None:
+            y._spgnn_scale = (y._version, blk)          # the result's GEMM operand scale, from the product's epilogue
+        return y
     y = torch.nn.functional.linear(x, weight, bias)
     if addend is not None:
         y = y + addend
@@ -859,6 +884,7 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+EMIT_SCALES = True     # spmm_sum and ops.linear leave max |result| in a scale block (no absmax pass when the result feeds a product)
 PRESPLIT_B = True      # weight operands of the NT products pre-split once per step (spgnn_presplit); False: fp32 rows, split per tile
 
 
@@ -1806,15 +1832,16 @@ def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: i
 # --------------------------------------------------------------------------------------------
 # SpMM sum / max
 # --------------------------------------------------------------------------------------------
-def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=None, act: int = ACT_NONE) -> torch.Tensor:
+def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=None, act: int = ACT_NONE, absmax=None) -> torch.Tensor:
+    """``absmax``: a scale block the kernel folds max |out| into (the result as the next product's operand)."""
     _require_cuda(x, w_src, w_dst, eps, bias)
     F_ = x.shape[1]
     out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device), _timed("spmm_sum", (N, E, F_)):
         _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
-                                       _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_, _stream(x)),
-                    "spgnn_spmm_sum")
+                                       _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_, _ptr(absmax),
+                                       _stream(x)), "spgnn_spmm_sum")
     return out
 
 
@@ -1823,8 +1850,10 @@ class _SpmmSumFn(torch.autograd.Function):
     def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst, bias=None, act: int = ACT_NONE):
         x = _rowmajor(x)
         fuse = (bias is not None or act != ACT_NONE) and x.shape[1] % 4 == 0
+        blk = new_scale_block(x.device) if (EMIT_SCALES and x.shape[1] % 4 == 0) else None
         out = spmm_sum_raw(csc.indptr, csc.indices, x, w_src, w_dst, eps, csc.num_nodes, csc.num_edges, bias if fuse else None,
-                           act if fuse else ACT_NONE)
+                           act if fuse else ACT_NONE, absmax=blk)
+        ctx.scale_block = blk
         if not fuse and (bias is not None or act != ACT_NONE):
             raise RuntimeError("spmm_sum: the bias / activation epilogue needs a width that is a multiple of 4")
         ctx.csc, ctx.w, ctx.act, ctx.has_bias = csc, (w_src, w_dst), act, bias is not None
@@ -1856,7 +1885,11 @@ class _SpmmSumFn(torch.autograd.Function):
 def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None, bias=None, act: int = ACT_NONE) -> torch.Tensor:
     """out[v] = act((1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u] + bias)."""
     _require_cuda(x)
-    return _SpmmSumFn.apply(x, eps, csc, w_src, w_dst, bias, act)
+    out = _SpmmSumFn.apply(x, eps, csc, w_src, w_dst, bias, act)
+    blk = getattr(out.grad_fn, "scale_block", None) if out.grad_fn is not None else None
+    if blk is not None:
+        out._spgnn_scale = (out._version, blk)          # its GEMM operand scale, emitted by the kernel itself
+    return out
 
 
 class _SpmmMaxFn(torch.autograd.Function):

@@ -448,7 +448,7 @@ def test_c_abi_argument_errors_are_reported():
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 5, 2, 4, 0.2, 0, 0.0, 0, 0, 0.0, 0, 0, 0, 0, 0) == -1   # null pointers
     assert b"null" in lib.spgnn_last_error()
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, 0, 2, 4, 0.2, 0, 0.0, 0, 0, 0.0, 0, 0, 0, 0, 0) == -2  # bad shape
-    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0) == 0                                   # N == 0 is a no-op
+    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 0) == 0                                   # N == 0 is a no-op
 
 
 @pytest.mark.parametrize("K,J", [(1063, 4), (1064, 4), (39, 2), (768, 4), (192, 4), (256, 2), (64, 16), (100, 8), (17, 4), (600, 22), (520, 4), (1024, 22)])

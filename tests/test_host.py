@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     # argument validation happens before any device work, so it can be exercised without a GPU
     assert lib.spgnn_gat_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 4, 0.2, 0, 0.0, 0, 0, 0.0, 0, 0, 0, 0, 0) == -1
     assert b"null pointer" in lib.spgnn_last_error()
-    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -3, 0, 8, 0) == -2
+    assert lib.spgnn_spmm_sum(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -3, 0, 8, 0, 0) == -2
     assert lib.spgnn_gat_bwd_src(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 4, 0.0, 0, 0, 0) == 0    # N == 0: no-op
 
 
