@@ -1417,14 +1417,16 @@ static int gemm_nt_plan(const float* A, int64_t lda, const float* B, int64_t ldb
   if (lda < K || ldb < K || ldc < N || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
       (reinterpret_cast<uintptr_t>(B) & 15))
     return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
-  // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU
-  // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones when the tiles fill whole rounds
-  // over the 256 CUs, and lose to the larger quantisation otherwise (measured at M = 76 410: N = 1024 / 1063, 4.67 /
-  // 5.84 rounds, win 12 % / 3 %; N = 768 / 512, 3.50 / 2.34 rounds, lose 7 % / 10 %): take it when at most 8 % of the
-  // last round is idle.  Offsets inside that kernel are 32-bit.
+  // 256-row tiles (8 waves, 1 block/CU) pay off only for deep, wide products; otherwise 128-row tiles, 2 blocks/CU.
+  // 256 x 256 tiles (gemm_nt_f16x3_v3) run ~13 % faster per flop than 256 x 128 ones, but quantise coarser: compare whole
+  // rounds of tiles over the 256 CUs, a 256 x 128 tile costing half a 256 x 256 one (tools/gemm_tiles.py, one process,
+  // M = 76 410: N = 1024 K = 1063 4.67 -> 5 rounds vs 9.34 -> 10 halves: 481 vs 571 us; N = 768 K = 512 3.50 -> 4 vs
+  // 7.01 -> 8: 193 vs 214; N = 512 K = 768 2.34 -> 3 vs 4.67 -> 5: 199 vs 194; M = 9 641: N = 1024 one partial round
+  // vs 1.19 -> 2: 85 vs 98 us; N = 768 one round of either: 39 vs 29).  Offsets inside that kernel are 32-bit.
   const bool fits31 = M * lda * 4 < (int64_t(1) << 31) && N * ldb * 4 < (int64_t(1) << 31);
-  const double r3 = (double)(((M + 255) / 256) * ((N + 255) / 256)) / 256.0;
-  const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)(int64_t)(r3 + 0.999999) <= 1.08 * r3;
+  const int64_t rounds3 = (((M + 255) / 256) * ((N + 255) / 256) + 255) / 256;
+  const int64_t rounds4 = (((M + 255) / 256) * ((N + 127) / 128) + 255) / 256;
+  const bool v3_wins = M >= 4096 && K >= 256 && N >= 512 && (double)rounds3 / 1.13 <= 0.5 * (double)rounds4;
   int variant;
   if (tile == 5 || (tile == 0 && v3_wins)) variant = fits31 ? 5 : 4;
   else variant = tile == 4 ? 4 : (tile == 2 || M < 4096 || K < 512 || N < 512) ? 2 : 4;
