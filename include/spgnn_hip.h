@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 36
+#define SPGNN_ABI_VERSION 37
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -221,6 +221,13 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
                   const float* out, int64_t out_stride,
                   float* g_pre, int64_t g_pre_stride, float* absmax,
                   int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+/* The flat form (no head mean) behind a feature dropout: g_out is the gradient of dropout(act(pre), p_drop) under
+ * spgnn_cat_dropout's counter-hash mask (seed [+ *seed_offset], element = row * W + column; total width W, offset 0), which is
+ * regenerated:  g_pre = g_out * keep / (1 - p) * act'(out)  - the dropout's backward and the activation's in one pass (the
+ * GIN MLP's Linear, Dropout, LeakyReLU, reference models.py:236-246).  `out` = act(pre), BEFORE the dropout. */
+int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
+                          int64_t g_pre_stride, float* absmax /* nullable scale block */, int64_t N, int32_t W,
+                          int32_t activation, float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
 
 /* spgnn_act_bwd for a mean-over-heads output layer that feeds a skinny Linear (the reference's classifier
  * `gnn_out = nn.Linear(node_embed_dim, out_ch)`, models.py:1125, on the head mean of models.py:482), with that

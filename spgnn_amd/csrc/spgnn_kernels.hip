@@ -1326,15 +1326,25 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
 // The same without the head mean, as a flat pass over 16-byte chunks (one wave per node left 3/4 of the lanes idle on rows
 // of 64 columns and made the kernel as slow for (N, 64) as for (N, 1024): 100 us): grid-stride over N * W / 4 chunks, the
 // wave's maximum folded into the scale block once per wave.
+// drop_p > 0: `g` is the gradient of dropout(act(pre)) under spgnn_cat_dropout's mask (seed, row * W + column): the mask is
+// regenerated and applied first - the dropout's backward pass and the activation's in one (the GIN MLP's Linear, Dropout,
+// LeakyReLU: reference models.py:236-246).
 __global__ __launch_bounds__(kBlock) void act_bwd_flat_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
                                                               int64_t out_ld, float* __restrict__ g_pre, int64_t gp_ld,
-                                                              float* __restrict__ absmax, int64_t N, int W, int act) {
+                                                              float* __restrict__ absmax, int64_t N, int W, int act, float drop_p,
+                                                              uint64_t seed, const uint64_t* __restrict__ seed_off) {
   const int w4 = W >> 2;
   const int64_t total = N * w4;
   float mx = 0.f;
+  if (seed_off) seed += seed_off[0];
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int64_t v = i / w4; const int c = (int)(i - v * w4) * 4;
     float4 q = ld4(g + v * g_ld + c);
+    if (drop_p > 0.f) {
+      const float4 k = feat_keep4(seed, v * W + c, drop_p, inv_keep);
+      q.x *= k.x; q.y *= k.y; q.z *= k.z; q.w *= k.w;
+    }
     if (act != SPGNN_ACT_NONE) {
       const float4 o = ld4(out + v * out_ld + c);
       q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
@@ -2293,10 +2303,24 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
                                                            float* __restrict__ g_logits, int64_t g_ld, int64_t N, int C) {
   __shared__ float red[2][kBlock / 64];
   __shared__ bool last;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // C <= 32 (the 22 airway labels): the block's 256 rows go through LDS, so that the global loads and the gradient stores are
+  // contiguous across the block instead of one 88-byte row per lane (39 -> 12 us at 76 410 nodes); odd pitch: conflict-free
+  __shared__ float tile[kBlock * 33];
+  const bool staged = C <= 32;
+  const int P = C | 1;
+  const int64_t base = (int64_t)blockIdx.x * kBlock;
+  const int rows = (int)(N - base < kBlock ? N - base : kBlock);
+  if (staged) {
+    for (int e = threadIdx.x; e < rows * C; e += kBlock) {
+      const int r = e / C, c = e - r * C;
+      tile[r * P + c] = logits[(base + r) * ld + c];
+    }
+    __syncthreads();
+  }
+  const int64_t i = base + threadIdx.x;
   float num = 0.f, den = 0.f;
   if (i < N) {
-    const float* row = logits + i * ld;
+    const float* row = staged ? tile + threadIdx.x * P : logits + i * ld;
     const int64_t yl = labels[i];
     const bool y_ok = yl >= 0 && yl < C;                     // F.cross_entropy raises for such a label; here the node gets a
     const int y = y_ok ? (int)yl : 0;                        // NaN weight, so the loss is NaN instead of an out-of-bounds read
@@ -2316,9 +2340,16 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
     num = w * (lse - row[y]);
     den = w;
     if (g_logits) {
-      float* g = g_logits + i * g_ld;
+      float* g = staged ? tile + threadIdx.x * P : g_logits + i * g_ld;      // staged: in place, the row is this lane's own
       const float inv = 1.f / se;
       for (int c = 0; c < C; ++c) g[c] = w * (expf(row[c] - mx) * inv - (c == y ? 1.f : 0.f));
+    }
+  }
+  if (staged && g_logits) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * C; e += kBlock) {
+      const int r = e / C, c = e - r * C;
+      g_logits[(base + r) * g_ld + c] = tile[r * P + c];
     }
   }
   num = team_sum(num, 64); den = team_sum(den, 64);
@@ -2964,13 +2995,32 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
     int64_t blocks = (N * (HD / 4) + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
-                       out_stride, g_pre, g_pre_stride, absmax, N, (int)HD, activation);
+                       out_stride, g_pre, g_pre_stride, absmax, N, (int)HD, activation, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
     return check_launch("spgnn_act_bwd");
   }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((N + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                      (hipStream_t)stream, g_out, g_out_stride, mean_heads ? 1 : 0, out, out_stride, g_pre, g_pre_stride, absmax,
                      N, H, D, activation);
   return check_launch("spgnn_act_bwd");
+}
+
+int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
+                          int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
+                          uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (N < 0 || W <= 0 || W % 4) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_dropout: bad N/W (W must be a multiple of 4)");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_dropout: activation");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_dropout: p_drop outside [0, 1)");
+  if (N == 0) return SPGNN_OK;
+  if (!g_out || !g_pre || (activation != SPGNN_ACT_NONE && !out)) return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_dropout: null pointer");
+  if (g_out_stride < W || g_pre_stride < W || (activation != SPGNN_ACT_NONE && out_stride < W))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_dropout: row stride smaller than row");
+  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_dropout: rows must be 16-byte aligned");
+  int64_t blocks = (N * (W / 4) + kBlock - 1) / kBlock;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
+                     out_stride, g_pre, g_pre_stride, absmax, N, (int)W, activation, p_drop, seed, seed_offset);
+  return check_launch("spgnn_act_bwd_dropout");
 }
 
 int32_t spgnn_act_bwd_proj_blocks(int64_t N) {

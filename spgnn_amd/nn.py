@@ -415,9 +415,14 @@ def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
                     drop, j = mods[j], j + 1
                 code = _act_code_dense(mods[j]) if j < len(mods) and isinstance(mods[j], (nn.LeakyReLU, nn.ReLU)) else None
                 if code is not None:
-                    x = ops.linear(x, m.weight, m.bias, code)
-                    if drop is not None:
-                        x = _hash_dropout(drop, x)
+                    pd = float(drop.p) if (drop is not None and drop.training) else 0.0
+                    if 0.0 < pd < 1.0 and ops.linear_drop_supported(x, m.weight):
+                        # dropout rides with the product's autograd node: its backward and the activation's are one pass
+                        x = ops.linear(x, m.weight, m.bias, code, drop=(pd, _draw_seed()))
+                    else:
+                        x = ops.linear(x, m.weight, m.bias, code)
+                        if drop is not None:
+                            x = _hash_dropout(drop, x)
                     i = j + 1
                     continue
             x = _apply_fast_linear(m, x)

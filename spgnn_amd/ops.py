@@ -632,7 +632,9 @@ class _LinearFn(torch.autograd.Function):
     by-product of the operand stream."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, addend=None):
+    def forward(ctx, x, weight, bias, act, addend=None, drop=None):
+        """``drop`` = (p, seed): the result is dropout(act(...), p) under spgnn_cat_dropout's hash mask; the backward pass
+        then undoes dropout and activation in ONE pass (spgnn_act_bwd_dropout)."""
         x = _rowmajor(x)
         if not _rows_aligned(x):
             x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
@@ -662,7 +664,18 @@ class _LinearFn(torch.autograd.Function):
         import ctypes
         with torch.cuda.device(x.device), _timed("gemm_nt", (N, C, K)):
             _capi.check(_capi.load().spgnn_gemm_nt_problem_run(ctypes.byref(q.c), int(bps), _stream(x)), "spgnn_gemm_nt_problem_run")
-        ctx.act, ctx.has_bias, ctx.has_addend, ctx.scale_block = act, bias is not None, addend is not None, blk
+        ctx.act, ctx.has_bias, ctx.has_addend, ctx.scale_block, ctx.drop = act, bias is not None, addend is not None, blk, None
+        if drop is not None and drop[0] > 0.0 and C % 4 == 0:
+            yd = torch.empty_like(y)
+            blk = new_scale_block(x.device)
+            with torch.cuda.device(x.device):
+                _capi.check(_capi.load().spgnn_cat_dropout(y.data_ptr(), y.stride(0), yd.data_ptr(), yd.stride(0), N, C, 0, C, float(drop[0]),
+                                                           int(drop[1]), _seed_off_ptr(x.device), 0, blk.data_ptr(), _stream(x)),
+                            "spgnn_cat_dropout")
+            ctx.drop, ctx.scale_block = (float(drop[0]), int(drop[1])), blk
+            ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
+            return yd
+        assert drop is None or drop[0] == 0.0, "linear(drop=...): the output width must be a multiple of 4"
         ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
         return y
 
@@ -672,7 +685,18 @@ class _LinearFn(torch.autograd.Function):
         N, K = x.shape
         C = w.shape[0]
         g = _rowmajor(g)
-        if ctx.act != ACT_NONE and C % 4 == 0:
+        if ctx.drop is not None:                        # dropout's and the activation's backward in one pass, mask regenerated
+            if not _rows_aligned(g):
+                g = g.contiguous()
+            g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
+            sg = new_scale_block(g.device)
+            with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
+                _capi.check(_capi.load().spgnn_act_bwd_dropout(g.data_ptr(), g.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+                                                               g_pre.data_ptr(), g_pre.stride(0), sg.data_ptr(), N, C, ctx.act,
+                                                               ctx.drop[0], ctx.drop[1], _seed_off_ptr(g.device), _stream(g)),
+                            "spgnn_act_bwd_dropout")
+            g = g_pre
+        elif ctx.act != ACT_NONE and C % 4 == 0:
             g, sg = act_bwd(g, y, 1, C, ctx.act, False)
         else:
             if ctx.act != ACT_NONE:
@@ -694,22 +718,31 @@ class _LinearFn(torch.autograd.Function):
                 g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
             else:
                 g_w = gemm_tn(g, x, sg, sx)
-        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None)
+        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None), None
+
+
+def linear_drop_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Whether linear(x, weight, ..., drop=...) can run: the matrix-core path and an output width that is a multiple of 4."""
+    return bool(x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= 512 and weight.shape[0] >= 32
+                and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
-           addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+           addend: Optional[torch.Tensor] = None, drop=None) -> torch.Tensor:
     """act(F.linear(x, weight, bias) + addend).  Tall operands (>= 512 rows, both widths >= 32) on a ROCm device take the
-    matrix-core GEMM path; anything else goes to torch (tiny products are launch-bound either way)."""
+    matrix-core GEMM path; anything else goes to torch (tiny products are launch-bound either way).  ``drop`` = (p, seed):
+    dropout of the result under the hash mask (matrix-core path with a width that is a multiple of 4 only; see
+    :func:`linear_drop_supported`)."""
     N = x.shape[0] if x.dim() == 2 else 0
     if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32 and weight.shape[1] >= 32
             and x.dtype == torch.float32 and weight.dtype == torch.float32
             and (addend is None or (weight.shape[0] % 4 == 0 and addend.shape == (N, weight.shape[0])))):
-        y = _LinearFn.apply(x, weight, bias, act, addend)
+        y = _LinearFn.apply(x, weight, bias, act, addend, drop)
         blk = getattr(y.grad_fn, "scale_block", None) if y.grad_fn is not None else None
         if blk is not None:
             y._spgnn_scale = (y._version, blk)          # the result's GEMM operand scale, from the product's epilogue
         return y
+    assert drop is None, "linear(drop=...) needs the matrix-core path (linear_drop_supported)"
     y = torch.nn.functional.linear(x, weight, bias)
     if addend is not None:
         y = y + addend
@@ -1698,13 +1731,24 @@ class _GATAggFirstFn(torch.autograd.Function):
             wct = wc.transpose(1, 2).contiguous()          # (H, zs, D): every head's W^T in one copy
             if ps:
                 wct = presplit(wct.view(H * zs, D), scale=sw)[0].view(H, zs, D)
+        nts, tns = [], []
         for h in range(H):
             gp_h = g_pre[:, h * D:(h + 1) * D]
-            gemm_nt(gp_h, wct[h], sg, sw, out=g_z[:, h * zs:(h + 1) * zs], b_presplit=ps)
+            nts.append(NtProblem(gp_h, wct[h], sg, sw, out=g_z[:, h * zs:(h + 1) * zs], b_presplit=ps))
             if need_w:                                 # [g_W_fc,h | g_W_res,h] (D, 2F) straight into the two parameters' row blocks
-                gemm_tn(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=need_bias, out=g_wfc[h * D:(h + 1) * D],
-                        out2=g_wres[h * D:(h + 1) * D] if has_res else None,
-                        colsum_out=g_bias[h * D:(h + 1) * D] if need_bias else None, defer=jobs)
+                tns.append(TnProblem(gp_h, z[:, h * zs:(h + 1) * zs], sg, sz, want_colsum=need_bias, out=g_wfc[h * D:(h + 1) * D],
+                                     out2=g_wres[h * D:(h + 1) * D] if has_res else None,
+                                     colsum_out=g_bias[h * D:(h + 1) * D] if need_bias else None, defer=jobs))
+        # the heads' products are independent and equal in shape: two per launch (the second head's tiles fill the first's
+        # last round: 2 x 3.5 rounds of 128 x 128 tiles become 7)
+        for q in range(0, H - 1, 2):
+            gemm_nt_pair(nts[q], nts[q + 1])
+            if tns:
+                gemm_tn_pair(tns[q], tns[q + 1])
+        if H % 2:
+            nts[-1].run()
+            if tns:
+                tns[-1].launch().finish()
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
         g_s = torch.empty_like(s)

@@ -442,6 +442,31 @@ def test_sgd_mean_form_and_step_begin():
         pool.end()
 
 
+def test_linear_with_dropout_equals_linear_then_hash_dropout():
+    """ops.linear(..., drop=(p, seed)): the product's node applies the hash dropout itself and undoes dropout + activation in
+    one backward pass (spgnn_act_bwd_dropout) - values and gradients equal linear followed by ops.cat_dropout bit for bit."""
+    torch.manual_seed(4)
+    N, K, C = 3000, 96, 128
+    x0 = torch.randn(N, K, device="cuda")
+    w0, b0 = torch.randn(C, K, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
+    gout = torch.randn(N, C, device="cuda")
+    res = []
+    for fused in (True, False):
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        if fused:
+            y = ops.linear(x, w, b, ops.ACT_LRELU, drop=(0.1, 777))
+        else:
+            y = ops.cat_dropout((ops.linear(x, w, b, ops.ACT_LRELU),), 0.1, 777)
+        assert getattr(y, "_spgnn_scale", None) is not None
+        (y * gout).sum().backward()
+        res.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone(), ops.scale_value(y._spgnn_scale[1])))
+    for a, b_ in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b_)
+    assert res[0][4] == res[1][4]
+    kept = float((res[0][0] != 0).float().mean())
+    assert 0.85 < kept < 0.95
+
+
 def test_c_abi_argument_errors_are_reported():
     from spgnn_amd import _capi
     lib = _capi.load()
