@@ -442,12 +442,14 @@ class SAGE(nn.Module):
             h = layer(block, h)
         return h
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
+        (linear) output layer's product."""
         h = g.ndata["fvs"]
         with ops.prepared_weights(_linear_specs(self, h)):
-            for layer in self.g_layers:
+            for layer in self.g_layers[:-1]:
                 h = layer(g, h)
-        return h
+            return self.g_layers[-1](g, h, classifier=classifier)
 
 
 # =================================================================================================
@@ -583,8 +585,8 @@ class SAGENet(_GraphNetBase):
         self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
-        n_embed = self.sage(g)
-        return self.gnn_out(n_embed), n_embed
+        n_embed, n_out = self.sage(g, classifier=self.gnn_out)
+        return n_out, n_embed
 
     def forward_batch(self, blocks, x):
         n_embed = self.sage.forward_batch(blocks, x)

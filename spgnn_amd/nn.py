@@ -502,7 +502,15 @@ class SAGEConv(nn.Module):
                 state_dict[prefix + "fc_self.bias"] = torch.zeros_like(b)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None, classifier: Optional[nn.Linear] = None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(rst, classifier(rst))`` - joined to this layer's
+        product when the layer is linear (no activation, no norm) and takes the K-concatenated form below."""
+        if classifier is None:
+            return self._forward(graph, feat, edge_weight, None)
+        res = self._forward(graph, feat, edge_weight, classifier)
+        return res if isinstance(res, tuple) else (res, classifier(res))
+
+    def _forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight, classifier):
         if edge_weight is not None:
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
@@ -520,6 +528,22 @@ class SAGEConv(nn.Module):
                     neigh._spgnn_scale = (neigh._version, tag[1])
             else:
                 neigh = _dst_rows(csc, ops.spmm_sum(csc, h, None, csc.degree_scale("in", -1.0)))
+            F_in = self._in_src_feats
+            if (fuse and self._out_feats >= 2 * F_in and F_in % 4 == 0 and getattr(csc, "num_dst", None) is None
+                    and ops.linear_drop_supported(h, self.fc_neigh.weight) and 2 * F_in >= 32):
+                # Output wider than both inputs together (64 -> 1024): ONE product on [neigh | h] with [W_neigh | W_self]
+                # (the addend form writes, re-reads and re-writes the (N, out) result: 0.94 GB against 0.35 GB here)
+                xc = ops.cat_dropout((neigh, h), 0.0, 0)
+                wc = torch.cat([self.fc_neigh.weight, self.fc_self.weight], dim=1)
+                bs = [b for b in (self.fc_neigh.bias, self.fc_self.bias) if b is not None]
+                bc = (bs[0] + bs[1] if len(bs) == 2 else bs[0]) if bs else None
+                if (classifier is not None and act == ops.ACT_NONE and self.norm is None
+                        and ops.linear_classifier_supported(xc, wc, classifier.weight)):
+                    # linear layer: the classifier folds through the product (ops._LinearClassifierFn) - no pass over the
+                    # (N, out) result for the logits, no (N, out) gradient in the backward pass
+                    return ops._LinearClassifierFn.apply(xc, wc, bc, classifier.weight, classifier.bias)
+                rst = ops.linear(xc, wc, bc, act)
+                return rst if self.norm is None else self.norm(rst)
             if fuse:        # fc_neigh's product adds fc_self's result and applies the activation in its epilogue
                 rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias, act,
                                  addend=ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias))

@@ -775,7 +775,7 @@ class _LinearClassifierFn(torch.autograd.Function):
         w = weight if weight.stride(1) == 1 else weight.contiguous()
         if not _rows_aligned(w):
             w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
-        sx, sw = pow2_scale(x), pow2_scale(w)
+        sx, sw = operand_scale(x), pow2_scale(w)
         y = gemm_nt(x, w, sx, sw, bias=bias)
         wc = w_cls.detach()
         P = torch.mm(wc, w.detach())

@@ -52,10 +52,15 @@ def test_config_forward_matches_oracle(name):
     assert outs[0].shape == (g.number_of_nodes(), 22)
 
 
-@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_pgat_spgnnnl_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3", "st_gat_6_nr"])
-def test_config_loss_gradients_match_oracle(name):
+@pytest.mark.parametrize("name,trees", [("st_pgat_spgnn_3", 2), ("st_pgat_spgnnnl_3", 2), ("st_gat_3", 2), ("st_gcn_3", 2), ("st_gin_3", 2),
+                                        ("st_sage_3", 2), ("st_gat_6_nr", 2),
+                                        # >= 512 nodes: the dense layers of rows D / E / F take the matrix-core products with their
+                                        # epilogues, emitted scales, prepared weights, SAGE's K-concatenated output layer and folded classifier
+                                        ("st_gcn_3", 5), ("st_gin_3", 5), ("st_sage_3", 5)])
+def test_config_loss_gradients_match_oracle(name, trees):
     cfg, model = _build(name, seed=1)
-    g = synthetic.make_batch(2, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    g = synthetic.make_batch(trees, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    assert trees == 2 or g.number_of_nodes() >= 512
     model.eval()                                  # dropout off; gradients still flow
     w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
     y = g.ndata["y"]
