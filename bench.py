@@ -364,152 +364,155 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             "copy_bandwidth": copy_bw,
         }
         if kt_all:
-            nprobe = max(probe, 1)
-            n_leg = eager_leg["steps"] if eager_leg else nprobe
+            try:                                    # never lose the bench line to the accounting of an unknown kernel key
+                nprobe = max(probe, 1)
+                n_leg = eager_leg["steps"] if eager_leg else nprobe
 
-            def per_step(key):
-                """(ms per step, launches per step) of one (kernel, shape): from the dedicated leg when it was bracketed there."""
-                if key in kt_dom:
-                    return sum(kt_dom[key]) / n_leg, len(kt_dom[key]) / n_leg
-                return sum(kt_all[key]) / nprobe, len(kt_all[key]) / nprobe
+                def per_step(key):
+                    """(ms per step, launches per step) of one (kernel, shape): from the dedicated leg when it was bracketed there."""
+                    if key in kt_dom:
+                        return sum(kt_dom[key]) / n_leg, len(kt_dom[key]) / n_leg
+                    return sum(kt_all[key]) / nprobe, len(kt_all[key]) / nprobe
 
-            where = ("eagerly issued steps right after the timed region, HIP events on the launch stream around the launches "
-                     "of the roofline / GAT / GEMM kernels only") if kt_dom else f"{nprobe} fully instrumented warm-up step(s)"
-            traffic_tab = {}
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic_tab = json.load(open(tpath))
-                except Exception:
-                    traffic_tab = {}
+                where = ("eagerly issued steps right after the timed region, HIP events on the launch stream around the launches "
+                         "of the roofline / GAT / GEMM kernels only") if kt_dom else f"{nprobe} fully instrumented warm-up step(s)"
+                traffic_tab = {}
+                tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+                if os.path.exists(tpath):
+                    try:
+                        traffic_tab = json.load(open(tpath))
+                    except Exception:
+                        traffic_tab = {}
 
-            def traffic_of(keys):
-                """PMC HBM bytes per step of these (kernel, shape) keys, from the committed rocprofv3 --pmc pass, or None."""
-                tot_, seen = 0.0, False
-                for k in keys:
-                    t = traffic_tab.get("_".join(str(x) for x in k))
-                    if t is None:
-                        return None
-                    tot_ += t * per_step(k)[1]
-                    seen = True
-                return tot_ if seen else None
+                def traffic_of(keys):
+                    """PMC HBM bytes per step of these (kernel, shape) keys, from the committed rocprofv3 --pmc pass, or None."""
+                    tot_, seen = 0.0, False
+                    for k in keys:
+                        t = traffic_tab.get("_".join(str(x) for x in k))
+                        if t is None:
+                            return None
+                        tot_ += t * per_step(k)[1]
+                        seen = True
+                    return tot_ if seen else None
 
-            # ---- projection GEMMs ---------------------------------------------------------------------------------
-            gemm_keys = [k for k in kt_all if k[0] in GEMM_NAMES]
-            products = 1 if bf16 else 3
-            g_ms = g_fl = g_by = 0.0
-            per_name = {}
-            for k in gemm_keys:
-                t, n = per_step(k)
-                fl = gemm_flops(k) * n
-                g_ms += t; g_fl += fl; g_by += gemm_bytes(k) * n
-                d = per_name.setdefault(k[0], [0.0, 0.0, 0.0, 0])
-                d[0] += t; d[1] += fl; d[2] += gemm_bytes(k) * n; d[3] += n
-            if gemm_keys:
-                out["gemm"] = {
-                    "kernels": {nm: {"ms_per_step": d[0], "launches_per_step": d[3], "algorithmic_TFLOPs": d[1] / (d[0] * 1e-3) / 1e12,
-                                     "executed_mfma_TFLOPs": products * d[1] / (d[0] * 1e-3) / 1e12,
-                                     "algorithmic_GBps": d[2] / (d[0] * 1e-3) / 1e9}
-                                for nm, d in per_name.items()},
-                    "ms_per_step": g_ms, "algorithmic_TFLOP_per_step": g_fl / 1e12, "algorithmic_GB_per_step": g_by / 1e9,
-                    "algorithmic_TFLOPs": g_fl / (g_ms * 1e-3) / 1e12, "executed_mfma_TFLOPs": products * g_fl / (g_ms * 1e-3) / 1e12,
-                    "mfma_products_per_fp32_product": products,
-                    # per shape: launches per step, mean ms per launch, algorithmic TFLOP/s
-                    "per_shape": {"_".join(str(x) for x in k): [round(per_step(k)[1], 2), round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 4),
-                                                                round(gemm_flops(k) * per_step(k)[1] / (per_step(k)[0] * 1e-3) / 1e12, 1)]
-                                  for k in sorted(gemm_keys, key=lambda kk: -per_step(kk)[0])},
-                    "measured_in": where}
-
-            # ---- message passing (every hand-written non-GEMM kernel) ---------------------------------------------
-            mp_keys = [k for k in kt_all if k[0] not in GEMM_NAMES and k[0] not in HELPER_NAMES]
-            mp_ms = sum(per_step(k)[0] for k in mp_keys)
-            mp_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in mp_keys)
-            gat_keys = [k for k in mp_keys if k[0].startswith(GAT_PREFIXES)]
-            k123 = None
-            if gat_keys:
-                k_ms = sum(per_step(k)[0] for k in gat_keys)
-                k_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in gat_keys)
-                # the survey's figure needs (H, D) per layer: the aggregate-first output layer (F -> H x D) is entered with
-                # its projected width, as the survey counts it
-                fwd_layers = []
-                for k in gat_keys:
-                    base = k[0][:-5] if k[0].endswith("_bf16") else k[0]
-                    if base == "gat_fwd":
-                        fwd_layers.append(((k[0],) + tuple(k[1:5]), per_step(k)[1]))
-                    elif base == "lspe_fwd":         # a fused level = a two-head structure layer + a one-head position layer
-                        fwd_layers.append((("gat_fwd", k[1], k[2], 2, k[3]), per_step(k)[1]))
-                        fwd_layers.append((("gat_fwd", k[1], k[2], 1, k[3]), per_step(k)[1]))
-                    elif base == "gat_agg_fwd":
-                        fwd_layers.append((("gat_fwd", k[1], k[2], k[3], cfg.MODEL.get("node_embed_dim", 1024)), per_step(k)[1]))
-                sv_bytes = survey_k123_bytes(fwd_layers, s_row)
-                k123 = {"kernels": sorted({k[0] for k in gat_keys}), "ms_per_step": k_ms,
-                        "layer_edges_per_s": E * L / (k_ms * 1e-3),
-                        "own_algorithmic_GB_per_step": k_bytes / 1e9, "own_achieved_GBps": k_bytes / (k_ms * 1e-3) / 1e9,
-                        "own_frac_of_hbm_peak": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                        "survey_algorithmic_GB_per_step": sv_bytes / 1e9,
-                        "survey_roofline_layer_edges_per_s": E * L / (sv_bytes / (HBM_PEAK_GBPS * 1e9)) if sv_bytes else None,
-                        "frac_of_survey_roofline": (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (k_ms * 1e-3) if sv_bytes else None,
-                        "traffic_GB_per_step": (lambda t: t / 1e9 if t is not None else None)(traffic_of(gat_keys)),
+                # ---- projection GEMMs ---------------------------------------------------------------------------------
+                gemm_keys = [k for k in kt_all if k[0] in GEMM_NAMES]
+                products = 1 if bf16 else 3
+                g_ms = g_fl = g_by = 0.0
+                per_name = {}
+                for k in gemm_keys:
+                    t, n = per_step(k)
+                    fl = gemm_flops(k) * n
+                    g_ms += t; g_fl += fl; g_by += gemm_bytes(k) * n
+                    d = per_name.setdefault(k[0], [0.0, 0.0, 0.0, 0])
+                    d[0] += t; d[1] += fl; d[2] += gemm_bytes(k) * n; d[3] += n
+                if gemm_keys:
+                    out["gemm"] = {
+                        "kernels": {nm: {"ms_per_step": d[0], "launches_per_step": d[3], "algorithmic_TFLOPs": d[1] / (d[0] * 1e-3) / 1e12,
+                                         "executed_mfma_TFLOPs": products * d[1] / (d[0] * 1e-3) / 1e12,
+                                         "algorithmic_GBps": d[2] / (d[0] * 1e-3) / 1e9}
+                                    for nm, d in per_name.items()},
+                        "ms_per_step": g_ms, "algorithmic_TFLOP_per_step": g_fl / 1e12, "algorithmic_GB_per_step": g_by / 1e9,
+                        "algorithmic_TFLOPs": g_fl / (g_ms * 1e-3) / 1e12, "executed_mfma_TFLOPs": products * g_fl / (g_ms * 1e-3) / 1e12,
+                        "mfma_products_per_fp32_product": products,
+                        # per shape: launches per step, mean ms per launch, algorithmic TFLOP/s
+                        "per_shape": {"_".join(str(x) for x in k): [round(per_step(k)[1], 2), round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 4),
+                                                                    round(gemm_flops(k) * per_step(k)[1] / (per_step(k)[0] * 1e-3) / 1e12, 1)]
+                                      for k in sorted(gemm_keys, key=lambda kk: -per_step(kk)[0])},
                         "measured_in": where}
-                out["roofline_k123"] = k123
-            out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
-                                      "algorithmic_GB_per_step": mp_bytes / 1e9,
-                                      "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms else None,
-                                      "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if mp_ms else None,
-                                      "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3) if mp_ms else None,
-                                      "measured_in": f"{nprobe} fully instrumented warm-up step(s); GAT kernels: " + where,
-                                      "per_kernel_ms": {"_".join(str(x) for x in k): round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 5)
-                                                        for k in sorted(mp_keys)}}
 
-            # ---- the roofline object: fixed kernel per dtype ------------------------------------------------------
-            rkeys = [k for k in kt_all if k[0] in roof_names]
-            if rkeys:
-                r_ms = sum(per_step(k)[0] for k in rkeys)
-                r_n = sum(per_step(k)[1] for k in rkeys)
-                if bf16 or spmm_model:
-                    r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
-                    ach = r_bytes / (r_ms * 1e-3) / 1e9
-                    tr = traffic_of(rkeys)
-                    what = ("spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the output layer's "
-                            "spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)") if bf16 else \
-                           "the SpMM kernels " + " + ".join(sorted({"spgnn_" + k[0] for k in rkeys})) + " (all launches of a step, forward and backward)"
-                    out["roofline"] = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBPS, "traffic": tr, "traffic_source": TRAFFIC_SOURCE if tr is not None else None,
-                                       "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
-                                       "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,
-                                       "avg_launch_ms": r_ms / r_n, "measured_in": where}
-                else:
-                    r_fl = sum(gemm_flops(k) * per_step(k)[1] for k in rkeys)
-                    ach = r_fl / (r_ms * 1e-3) / 1e12
-                    out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt / spgnn_gemm_nt_pair (all launches of a step: forward projections and "
-                                       "input gradients; a pair = a level's structure + position products in one launch)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
-                                       "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
-                                       "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys), "traffic_source": TRAFFIC_SOURCE,
-                                       "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,
-                                       "avg_launch_ms": r_ms / r_n, "measured_in": where,
-                                       "note": "achieved = ALGORITHMIC flops (2MNK of the fp32 product) / time; the kernel executes "
-                                               "three fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi): "
-                                               "executed_mfma_frac = 3 x frac; against the native fp32 matrix pipe (157.3 TFLOP/s) "
-                                               "the same rate is frac_of_fp32_matrix_peak"}
+                # ---- message passing (every hand-written non-GEMM kernel) ---------------------------------------------
+                mp_keys = [k for k in kt_all if k[0] not in GEMM_NAMES and k[0] not in HELPER_NAMES]
+                mp_ms = sum(per_step(k)[0] for k in mp_keys)
+                mp_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in mp_keys)
+                gat_keys = [k for k in mp_keys if k[0].startswith(GAT_PREFIXES)]
+                k123 = None
+                if gat_keys:
+                    k_ms = sum(per_step(k)[0] for k in gat_keys)
+                    k_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in gat_keys)
+                    # the survey's figure needs (H, D) per layer: the aggregate-first output layer (F -> H x D) is entered with
+                    # its projected width, as the survey counts it
+                    fwd_layers = []
+                    for k in gat_keys:
+                        base = k[0][:-5] if k[0].endswith("_bf16") else k[0]
+                        if base == "gat_fwd":
+                            fwd_layers.append(((k[0],) + tuple(k[1:5]), per_step(k)[1]))
+                        elif base == "lspe_fwd":         # a fused level = a two-head structure layer + a one-head position layer
+                            fwd_layers.append((("gat_fwd", k[1], k[2], 2, k[3]), per_step(k)[1]))
+                            fwd_layers.append((("gat_fwd", k[1], k[2], 1, k[3]), per_step(k)[1]))
+                        elif base == "gat_agg_fwd":
+                            fwd_layers.append((("gat_fwd", k[1], k[2], k[3], cfg.MODEL.get("node_embed_dim", 1024)), per_step(k)[1]))
+                    sv_bytes = survey_k123_bytes(fwd_layers, s_row)
+                    k123 = {"kernels": sorted({k[0] for k in gat_keys}), "ms_per_step": k_ms,
+                            "layer_edges_per_s": E * L / (k_ms * 1e-3),
+                            "own_algorithmic_GB_per_step": k_bytes / 1e9, "own_achieved_GBps": k_bytes / (k_ms * 1e-3) / 1e9,
+                            "own_frac_of_hbm_peak": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "survey_algorithmic_GB_per_step": sv_bytes / 1e9,
+                            "survey_roofline_layer_edges_per_s": E * L / (sv_bytes / (HBM_PEAK_GBPS * 1e9)) if sv_bytes else None,
+                            "frac_of_survey_roofline": (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (k_ms * 1e-3) if sv_bytes else None,
+                            "traffic_GB_per_step": (lambda t: t / 1e9 if t is not None else None)(traffic_of(gat_keys)),
+                            "measured_in": where}
+                    out["roofline_k123"] = k123
+                out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
+                                          "algorithmic_GB_per_step": mp_bytes / 1e9,
+                                          "achieved_GBps": mp_bytes / (mp_ms * 1e-3) / 1e9 if mp_ms else None,
+                                          "frac_of_hbm_peak": mp_bytes / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if mp_ms else None,
+                                          "layer_edges_per_s_mp_only": E * L / (mp_ms * 1e-3) if mp_ms else None,
+                                          "measured_in": f"{nprobe} fully instrumented warm-up step(s); GAT kernels: " + where,
+                                          "per_kernel_ms": {"_".join(str(x) for x in k): round(per_step(k)[0] / max(per_step(k)[1], 1e-9), 5)
+                                                            for k in sorted(mp_keys)}}
 
-            # ---- composite roofline (SURVEY.md 8d / BASELINE.md 2): t_graph + max(t_gemm_bytes, t_gemm_flops) -----
-            t_graph = mp_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
-            t_gb = g_by / (HBM_PEAK_GBPS * 1e9) * 1e3
-            t_gf32 = g_fl / (FP32_MATRIX_PEAK * 1e12) * 1e3
-            t_gf16 = g_fl / (MFMA_F16_PEAK * 1e12) * 1e3
-            comp_hbm = t_graph + t_gb
-            comp_f32 = t_graph + max(t_gb, t_gf32)
-            comp_16 = t_graph + max(t_gb, t_gf16 * products)
-            out["composite"] = {"t_graph_ms": t_graph, "t_gemm_bytes_ms": t_gb, "t_gemm_flops_fp32_matrix_ms": t_gf32,
-                                "t_gemm_flops_16bit_mfma_ms": t_gf16 * products,
-                                "hbm_only_ms": comp_hbm, "fp32_matrix_ms": comp_f32, "as_executed_ms": comp_16,
-                                "step_vs_hbm_only": comp_hbm / ms, "step_vs_fp32_matrix": comp_f32 / ms, "step_vs_as_executed": comp_16 / ms,
-                                "layer_edges_per_s_at_hbm_only": E * L / (comp_hbm * 1e-3),
-                                "layer_edges_per_s_at_fp32_matrix": E * L / (comp_f32 * 1e-3),
-                                "note": "roofline step time = message-passing algorithmic bytes at 8 TB/s + max(GEMM algorithmic bytes at "
-                                        "8 TB/s, GEMM flops at the named matrix peak); 'as_executed' prices the flops at the 2.5 PFLOP/s "
-                                        f"16-bit MFMA peak times the {products} product(s) this precision executes per algorithmic product; "
-                                        "step_vs_* = that time / the measured ms_per_step"}
+                # ---- the roofline object: fixed kernel per dtype ------------------------------------------------------
+                rkeys = [k for k in kt_all if k[0] in roof_names]
+                if rkeys:
+                    r_ms = sum(per_step(k)[0] for k in rkeys)
+                    r_n = sum(per_step(k)[1] for k in rkeys)
+                    if bf16 or spmm_model:
+                        r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
+                        ach = r_bytes / (r_ms * 1e-3) / 1e9
+                        tr = traffic_of(rkeys)
+                        what = ("spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the output layer's "
+                                "spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)") if bf16 else \
+                               "the SpMM kernels " + " + ".join(sorted({"spgnn_" + k[0] for k in rkeys})) + " (all launches of a step, forward and backward)"
+                        out["roofline"] = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                           "frac": ach / HBM_PEAK_GBPS, "traffic": tr, "traffic_source": TRAFFIC_SOURCE if tr is not None else None,
+                                           "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
+                                           "algorithmic_bytes_per_step": r_bytes, "ms_per_step": r_ms, "launches_per_step": r_n,
+                                           "avg_launch_ms": r_ms / r_n, "measured_in": where}
+                    else:
+                        r_fl = sum(gemm_flops(k) * per_step(k)[1] for k in rkeys)
+                        ach = r_fl / (r_ms * 1e-3) / 1e12
+                        out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt / spgnn_gemm_nt_pair (all launches of a step: forward projections and "
+                                           "input gradients; a pair = a level's structure + position products in one launch)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
+                                           "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
+                                           "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys), "traffic_source": TRAFFIC_SOURCE,
+                                           "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,
+                                           "avg_launch_ms": r_ms / r_n, "measured_in": where,
+                                           "note": "achieved = ALGORITHMIC flops (2MNK of the fp32 product) / time; the kernel executes "
+                                                   "three fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi): "
+                                                   "executed_mfma_frac = 3 x frac; against the native fp32 matrix pipe (157.3 TFLOP/s) "
+                                                   "the same rate is frac_of_fp32_matrix_peak"}
+
+                # ---- composite roofline (SURVEY.md 8d / BASELINE.md 2): t_graph + max(t_gemm_bytes, t_gemm_flops) -----
+                t_graph = mp_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
+                t_gb = g_by / (HBM_PEAK_GBPS * 1e9) * 1e3
+                t_gf32 = g_fl / (FP32_MATRIX_PEAK * 1e12) * 1e3
+                t_gf16 = g_fl / (MFMA_F16_PEAK * 1e12) * 1e3
+                comp_hbm = t_graph + t_gb
+                comp_f32 = t_graph + max(t_gb, t_gf32)
+                comp_16 = t_graph + max(t_gb, t_gf16 * products)
+                out["composite"] = {"t_graph_ms": t_graph, "t_gemm_bytes_ms": t_gb, "t_gemm_flops_fp32_matrix_ms": t_gf32,
+                                    "t_gemm_flops_16bit_mfma_ms": t_gf16 * products,
+                                    "hbm_only_ms": comp_hbm, "fp32_matrix_ms": comp_f32, "as_executed_ms": comp_16,
+                                    "step_vs_hbm_only": comp_hbm / ms, "step_vs_fp32_matrix": comp_f32 / ms, "step_vs_as_executed": comp_16 / ms,
+                                    "layer_edges_per_s_at_hbm_only": E * L / (comp_hbm * 1e-3),
+                                    "layer_edges_per_s_at_fp32_matrix": E * L / (comp_f32 * 1e-3),
+                                    "note": "roofline step time = message-passing algorithmic bytes at 8 TB/s + max(GEMM algorithmic bytes at "
+                                            "8 TB/s, GEMM flops at the named matrix peak); 'as_executed' prices the flops at the 2.5 PFLOP/s "
+                                            f"16-bit MFMA peak times the {products} product(s) this precision executes per algorithmic product; "
+                                            "step_vs_* = that time / the measured ms_per_step"}
+            except Exception as e:
+                out["accounting_error"] = repr(e)[:300]
         if capture_error:
             out["config"]["capture_error"] = capture_error
         if eager_leg:

@@ -336,3 +336,27 @@ def test_attention_dropout_multiplier_is_the_kernels_hash():
         got = ops.attn_dropout_multiplier(E, H, p, seed, torch.device("cpu")).numpy()
         want = keep_scale_host(seed % 2 ** 64, np.arange(E * H), p).reshape(E, H)
         assert np.array_equal(got, want), (seed, p)
+
+
+def test_bench_accounting_knows_every_kernel_key():
+    """bench.py prices every (kernel, shape) key the ops record: a new kernel whose key it cannot price must not cost the
+    driver its JSON line (the accounting is wrapped, and this test names the forms)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    N, E = 1000, 2990
+    keys = [("gat_fwd", N, E, 2, 64, 1, 0, 1), ("gat_bwd_dst", N, E, 2, 64, 1, 0), ("gat_bwd_src", N, E, 2, 64),
+            ("lspe_fwd", N, E, 64), ("lspe_bwd_dst", N, E, 64, 1), ("lspe_bwd_src", N, E, 64),
+            ("gat_agg_fwd", N, E, 2, 192, 1), ("gat_agg_bwd_dst", N, E, 2, 192), ("gat_agg_bwd_src", N, E, 2, 192),
+            ("scores_fwd", N, 1024, 22), ("scores_bwd_w", N, 1024, 22), ("scores_bwd_x", N, 1024, 22),
+            ("act_bwd", N, 1, 64, 4, 0), ("act_bwd_proj", N, 2, 1024, 1, 22), ("masked_ce", N, 22),
+            ("spmm_sum", N, E, 64), ("spmm_max_fwd", N, E, 64), ("spmm_max_bwd", N, E, 64),
+            ("gat_fwd_bf16", N, E, 2, 64, 1, 0, 1)]
+    for k in keys:
+        assert bench.algorithmic_bytes(k) > 0, k
+    single = bench.gemm_flops(("gemm_nt", N, 512, 768)) + bench.gemm_flops(("gemm_nt", N, 256, 256))
+    assert bench.gemm_flops(("gemm_nt_pair", N, 512, 768, N, 256, 256)) == single
+    assert bench.gemm_bytes(("gemm_tn_pair", N, 512, 768, N, 256, 256)) == \
+        bench.gemm_bytes(("gemm_tn", N, 512, 768)) + bench.gemm_bytes(("gemm_tn", N, 256, 256))
+    assert set(bench.GEMM_NAMES) >= {"gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair"}
+    assert len(bench.SECONDARY_LEGS) == 3
