@@ -467,6 +467,24 @@ def test_linear_with_dropout_equals_linear_then_hash_dropout():
     assert 0.85 < kept < 0.95
 
 
+def test_emitted_scales_equal_an_absmax_pass():
+    """The scale block a product's epilogue (absmax_out) or spgnn_spmm_sum leaves behind gives exactly the power-of-two scale
+    an absmax pass over the result gives - interior and ragged tiles, with and without an activation."""
+    torch.manual_seed(9)
+    for N, K, C, act in [(3000, 96, 128, ops.ACT_NONE), (2049, 200, 260, ops.ACT_LRELU), (700, 64, 1024, ops.ACT_ELU)]:
+        x = torch.randn(N, K, device="cuda").requires_grad_(True)
+        w, b = torch.randn(C, K, device="cuda") * 0.2, torch.randn(C, device="cuda")
+        y = ops.linear(x, w, b, act)
+        tag = getattr(y, "_spgnn_scale", None)
+        assert tag is not None and tag[0] == y._version
+        assert ops.scale_value(tag[1]) == float(ops.pow2_scale(y.detach()))
+    g, _, _, n = _graph([41, 57, 33], seed=3)
+    csc = g.csc("cuda")
+    xs = (torch.randn(n, 64, device="cuda") * 3).requires_grad_(True)
+    ys = ops.spmm_sum(csc, xs, None, csc.degree_scale("in", -1.0))
+    assert ops.scale_value(ys._spgnn_scale[1]) == float(ops.pow2_scale(ys.detach()))
+
+
 def test_c_abi_argument_errors_are_reported():
     from spgnn_amd import _capi
     lib = _capi.load()
