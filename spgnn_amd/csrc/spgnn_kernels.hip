@@ -2359,16 +2359,21 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int q = 0; q < kBlock / 64; ++q) { a += red[0][q]; b += red[1][q]; }
-    partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = b;
     if (sums) {
-      __threadfence();                                       // the pair is visible device-wide before the ticket is taken
-      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+      // The pair goes out as two device-scope atomic stores (write-through past this XCD's L2) and is waited for before the
+      // ticket is taken; the block that arrives last reads all pairs with device-scope atomic loads.  A __threadfence()
+      // here instead is an L2 write-back per workgroup (the block's gradient rows are dirty in it): +10 us on 299 blocks.
+      __hip_atomic_store(partial + 2 * blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + 2 * blockIdx.x + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    } else {
+      partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = b;
     }
   }
   if (!sums) return;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   float a = 0.f, b = 0.f;                                    // thread t: blocks t, t + 256, ... in ascending order
   for (unsigned q = threadIdx.x; q < gridDim.x; q += kBlock) {
     a += __hip_atomic_load(partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
