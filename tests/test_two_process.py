@@ -41,11 +41,12 @@ def _run_pair(tmp_path, config, dtype, trees=64, reps=200):
     return outs
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_two_processes_share_the_gpu_bitwise_repeatable(tmp_path, dtype):
+@pytest.mark.parametrize("config,dtype", [("st_pgat_spgnn_3", "f32"),     # the fused level kernels (spgnn_lspe.hip) + aggregate-first layer
+                                          ("st_gat_6", "bf16"),           # bf16 rows: BASELINE config 4's model
+                                          ("st_gat_3", "f32")])           # the fp32 gat_fwd / gat_bwd_dst / gat_bwd_src instantiations
+def test_two_processes_share_the_gpu_bitwise_repeatable(tmp_path, config, dtype):
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
-    config = "st_pgat_spgnn_3" if dtype == "f32" else "st_gat_6"     # bf16 rows: BASELINE config 4's model
     outs = _run_pair(tmp_path, config, dtype)
     for rc, res in outs:
         assert res["finite"], res
