@@ -175,11 +175,15 @@ class GCN(nn.Module):
         for layer in self.gcn_layers:
             layer.reset_parameters()
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
+        (linear) output layer's product."""
         h = g.ndata["fvs"]
-        for layer in self.gcn_layers:
-            h = layer(g, h)
-        return h
+        specs = [(l.weight, None, True) for l in self.gcn_layers if l.weight is not None] if (h.is_cuda and h.dtype == torch.float32) else []
+        with ops.prepared_weights(specs):       # GraphConv's (in, out) weights: the product reads the TRANSPOSED image
+            for layer in self.gcn_layers[:-1]:
+                h = layer(g, h)
+            return self.gcn_layers[-1](g, h, classifier=classifier)
 
 
 class GAT(nn.Module):
@@ -561,8 +565,8 @@ class GCNNet(_GraphNetBase):
         self.gnn_out = SkinnyLinear(node_embed_dim, out_ch)
 
     def forward(self, g):
-        n_embed = self.gcn(g)
-        return self.gnn_out(n_embed), n_embed
+        n_embed, n_out = self.gcn(g, classifier=self.gnn_out)
+        return n_out, n_embed
 
 
 class SAGENet(_GraphNetBase):

@@ -339,7 +339,15 @@ class GraphConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, weight=None):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, weight=None, classifier: Optional[nn.Linear] = None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(rst, classifier(rst))`` - folded through the
+        layer's product when the layer is linear and projects after aggregating (ops._LinearClassifierFn)."""
+        if classifier is None:
+            return self._forward(graph, feat, weight, None)
+        res = self._forward(graph, feat, weight, classifier)
+        return res if isinstance(res, tuple) else (res, classifier(res))
+
+    def _forward(self, graph: TreeGraph, feat: torch.Tensor, weight, classifier):
         csc = graph.csc(feat.device)
         if not self._allow_zero_in_degree and csc.min_in_degree == 0:
             raise DGLError("There are 0-in-degree nodes in the graph.")
@@ -364,6 +372,11 @@ class GraphConv(nn.Module):
         else:
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
             if weight is not None:
+                if (fuse and classifier is not None and act == ops.ACT_NONE
+                        and ops.linear_classifier_supported(rst, weight.t(), classifier.weight)):
+                    # a linear output layer: the classifier folds through the product - no pass over the (N, out) result for
+                    # the logits and no (N, out) gradient in the backward pass
+                    return ops._LinearClassifierFn.apply(rst, weight.t(), self.bias, classifier.weight, classifier.bias)
                 if fuse:
                     return ops.linear(rst, weight.t(), self.bias, act)
                 rst = ops.linear(rst, weight.t())

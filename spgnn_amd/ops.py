@@ -625,6 +625,26 @@ def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[t
                            class_weight.contiguous())
 
 
+def _prepared_linear_operands(weight: torch.Tensor, C: int, K: int):
+    """(w, w_ps, scale, (w_t, w_t_ps) or None) for ``weight`` (C, K) when this forward pass prepared it (prepared_weights) -
+    either the parameter itself, or the transposed view ``p.t()`` of a prepared (K, C) parameter (GraphConv stores its weight
+    as (in, out)): then the prepared TRANSPOSE is the product's operand and the prepared matrix its transpose.  Else None."""
+    if not PRESPLIT_B:
+        return None
+    hit = _PREP_ACTIVE.get((id(weight), 0))
+    if hit is not None and hit[0][5] == (C, 0, K, C):
+        dst, ps, dst_t, ps_t, sw, _ = hit[0]
+        return dst[:, :K], ps[:, :K], sw, ((dst_t[:, :C], ps_t[:, :C]) if hit[1] else None)
+    base = weight._base
+    if base is not None and base.dim() == 2 and tuple(weight.shape) == (base.shape[1], base.shape[0]) \
+            and weight.stride() == (base.stride(1), base.stride(0)) and weight.data_ptr() == base.data_ptr():
+        hit = _PREP_ACTIVE.get((id(base), 0))
+        if hit is not None and hit[1] and hit[0][5] == (K, 0, C, K):
+            dst, ps, dst_t, ps_t, sw, _ = hit[0]                       # dst = base (K, C); dst_t = base^T = weight (C, K)
+            return dst_t[:, :K], ps_t[:, :K], sw, (dst[:, :C], ps[:, :C])
+    return None
+
+
 class _LinearFn(torch.autograd.Function):
     """act(x @ W^T + b) for tall x on the fp32-accurate matrix-core GEMMs (the nn.Linear / weight products inside
     GraphConv, GINConv and SAGEConv; reference models.py:172-182, 236-246, 668-679): forward and input gradient on
@@ -640,13 +660,12 @@ class _LinearFn(torch.autograd.Function):
             x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
         N, K = x.shape
         C = weight.shape[0]
-        hit = _PREP_ACTIVE.get((id(weight), 0)) if PRESPLIT_B else None
+        prep = _prepared_linear_operands(weight, C, K)
         ctx.wt = None
-        if hit is not None and hit[0][5] == (C, 0, K, C):
+        if prep is not None:
             # padded rows, scale, pre-split form and the transposes: built by this pass's spgnn_weight_prep
-            dst, ps, dst_t, ps_t, sw, _ = hit[0]
-            w, wb, bps = dst[:, :K], ps[:, :K], True
-            ctx.wt = (dst_t[:, :C], ps_t[:, :C]) if hit[1] else None
+            w, wb, sw, ctx.wt = prep
+            bps = True
         else:
             w = weight if weight.stride(1) == 1 else weight.contiguous()      # e.g. GraphConv's (in, out) weight seen as W^T
             if not _rows_aligned(w):
@@ -772,11 +791,17 @@ class _LinearClassifierFn(torch.autograd.Function):
         x = _rowmajor(x)
         if not _rows_aligned(x):
             x = cat_padded((x,))
-        w = weight if weight.stride(1) == 1 else weight.contiguous()
-        if not _rows_aligned(w):
-            w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
-        sx, sw = operand_scale(x), pow2_scale(w)
-        y = gemm_nt(x, w, sx, sw, bias=bias)
+        prep = _prepared_linear_operands(weight, weight.shape[0], weight.shape[1])
+        if prep is not None:
+            w, w_ps, sw, _wt = prep
+            sx = operand_scale(x)
+            y = gemm_nt(x, w_ps, sx, sw, bias=bias, b_presplit=True)
+        else:
+            w = weight if weight.stride(1) == 1 else weight.contiguous()
+            if not _rows_aligned(w):
+                w = torch.nn.functional.pad(w, (0, -w.shape[1] % 4)).contiguous()[:, :w.shape[1]]
+            sx, sw = operand_scale(x), pow2_scale(w)
+            y = gemm_nt(x, w, sx, sw, bias=bias)
         wc = w_cls.detach()
         P = torch.mm(wc, w.detach())
         logits = scores_fwd(x, P)
