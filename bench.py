@@ -85,8 +85,8 @@ def algorithmic_bytes(key) -> float:
         _, N, K, J = key
         return 4 * 2 * N * K + 4 * N * J
     if base == "gat_agg_fwd":        # read x; write the z blocks [with a copy of x per head]; el, er, a; CSC
-        _, N, E, H, F_, xcopy = key
-        return s * N * F_ + s * N * H * F_ * (2 if xcopy else 1) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
+        _, N, E, H, F_, xcopy = key      # xcopy: 0 none, 1 a copy of x in every head's block, 2 one copy behind the last block
+        return s * N * F_ + s * N * F_ * (2 * H if xcopy == 1 else H + 1 if xcopy == 2 else H) + 4 * (2 * N * H + E * H) + 4 * (N + 1 + E)
     if base == "gat_agg_bwd_dst":    # read the z part of g_z and x; el, er, a; write g_e, g_er; CSC
         _, N, E, H, F_ = key
         return s * N * (H + 1) * F_ + 4 * (3 * N * H + 2 * E * H) + 4 * (N + 1 + E)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 37
+#define SPGNN_ABI_VERSION 38
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -168,7 +168,9 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
  *
  *   a_uv        = edge softmax of LeakyReLU(el[u,h] + er[v,h])                      -> attn[slot,h]
  *   z[v, h*head_stride + f]                 = sum_{u in in(v)} drop(a_uv) * x[u,f]     f in [0,F)
- *   z[v, h*head_stride + x_copy_offset + f] = x[v,f]        (x_copy_offset >= F; < 0: no residual operand copy)
+ *   z[v, h*head_stride + x_copy_offset + f] = x[v,f]        (x_copy_offset >= F; -1: no residual operand copy;
+ *                                                            -2: ONE copy behind the last head's block, z[v, H*head_stride + f] -
+ *                                                            the [z_0 | ... | z_{H-1} | x] operand of the linear-mean form)
  *   absmax (nullable): scale block taking max |z| over the columns written (split-GEMM scale of the operand)
  *
  * H in {1,2,4}, F % 4 == 0, F <= 1024 (spgnn_gat_agg_supported); rows 16-byte aligned; head_stride % 4 == 0.
@@ -851,6 +853,33 @@ typedef struct spgnn_weight_prep_layer {
 int64_t spgnn_weight_prep_blocks(int32_t rows, int64_t dst_stride, int64_t dst_t_stride);
 int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, int64_t total_blocks, float* workspace,
                       spgnn_stream_t stream);
+
+/* =================================================================================================
+ * The weight-space half of an output GATConv WITHOUT activation whose heads are averaged and whose classifier is folded
+ * through the product (reference models.py:320-327 `self.gat_layers[-1](g, h).mean(1)` with the *Net's `gnn_out`,
+ * models.py:921-933): with Zx = [z_0 | ... | z_{H-1} | x] (spgnn_gat_agg_fwd), mean_h out_h = Zx W_comb^T + b_mean and
+ * logits = Zx P^T + c0.  One launch each way instead of ~28 tiny ones.
+ *   fwd:  W_comb[d, h F + f] = W_fc[h D + d, f] / H,  W_comb[d, H F + f] = sum_h W_res[h D + d, f] / H  (w_res nullable: 0),
+ *         b_mean[d] = sum_h bias[h D + d] / H (bias nullable: 0; b_mean nullable),  P = w_cls W_comb (J x Kc, J <= 32),
+ *         c0 = w_cls b_mean + b_cls (b_cls nullable).  Kc = (H + 1) F; every image is written zero padded to Kp = Kc rounded up
+ *         to 16 columns (strides >= Kp).  w_comb_bf16 (nullable, uint16 bf16 bits): the combined weight is rounded to bf16
+ *         first, that image is written too, and w_comb / P hold the ROUNDED values (the function as the bf16 product evaluates
+ *         it).  absmax_out (nullable): a scale block taking max |W_comb|.
+ *   bwd:  from M1 = g_logits^T Zx (J x Kc) and cs = colsum(g_logits) (J):  g_W_fc, g_W_res (nullable) <- (w_cls^T M1) / H,
+ *         g_bias (nullable) <- (w_cls^T cs) / H (every head's copy),  g_w_cls (nullable) = M1 W_comb^T + cs b_mean^T.
+ * ================================================================================================= */
+int spgnn_linear_mean_fold_fwd(const float* w_fc, int64_t w_fc_stride, const float* w_res, int64_t w_res_stride, const float* bias,
+                               const float* w_cls, int64_t w_cls_stride, const float* b_cls, int32_t H, int32_t D, int32_t F, int32_t J,
+                               float* w_comb, int64_t w_comb_stride, uint16_t* w_comb_bf16, int64_t w_comb_bf16_stride,
+                               float* b_mean, float* P, int64_t P_stride, float* c0, float* absmax_out,
+                               float* workspace /* spgnn_linear_mean_fold_workspace floats */,
+                               uint32_t* tickets /* Kp / 32 + 1 words, zero before the first call; re-armed by the kernel */,
+                               spgnn_stream_t stream);
+int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F);
+int spgnn_linear_mean_fold_bwd(const float* M1, int64_t M1_stride, const float* cs, const float* w_cls, int64_t w_cls_stride,
+                               const float* w_comb, int64_t w_comb_stride, const float* b_mean, int32_t H, int32_t D, int32_t F,
+                               int32_t J, float* g_w_fc, int64_t g_w_fc_stride, float* g_w_res, int64_t g_w_res_stride, float* g_bias,
+                               float* g_w_cls, int64_t g_w_cls_stride, spgnn_stream_t stream);
 
 /* Up to 8 of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two attention-vector
  * gradients come out of four spgnn_gemm_tn / spgnn_scores_bwd_w calls whose partial sums were four more launches).  `jobs`

@@ -1370,6 +1370,240 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The weight-space half of "output GATConv without activation, heads averaged, classifier folded through"
+// (ops.gat_layer_linear_mean; reference models.py:320-327 with 921-933) - ~28 tiny torch / rocBLAS launches per step before:
+//   W_comb[d, h F + f] = W_fc[h D + d, f] / H,   W_comb[d, H F + f] = sum_h W_res[h D + d, f] / H,   b_mean = sum_h bias[h] / H
+//   P = Wc W_comb  (J, (H+1) F),   c0 = Wc b_mean + bc
+// and, backward, from M1 = g_logits^T Zx (J, Kc) and cs = colsum(g_logits):
+//   g_W_comb = Wc^T M1 -> g_W_fc, g_W_res (/ H);   g_bias = Wc^T cs / H;   g_Wc = M1 W_comb^T + cs b_mean^T
+// Forward: one workgroup of 1024 threads per 32 columns of W_comb (all D rows: no cross-workgroup reduction, fixed summation
+// order) + one for b_mean / c0.  With `wbf` the combined weight is rounded to bf16 first (bf16-storage path): the image the
+// bf16 product reads is written too, and P / the fp32 image hold the rounded values - the function as evaluated.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_rne(float x, unsigned short& bits) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  bits = (unsigned short)(u >> 16);
+  return __uint_as_float(u & 0xFFFF0000u);
+}
+
+struct FoldFwd {
+  const float* w_fc; int64_t ld_fc; const float* w_res; int64_t ld_res; const float* bias;
+  const float* wc; int64_t ld_wc; const float* bc;
+  float* w_comb; int64_t ld_w; unsigned short* wbf; int64_t ld_wbf; float* b_mean; float* P; int64_t ld_p; float* c0; float* absmax;
+  float* part; unsigned* tickets;                            // (column chunk, row quarter, JP, 32) partial sums of P; one ticket per column chunk
+  int H, D, F, J, Kc, Kp;
+};
+constexpr int kFoldQ = 4;                                   // row quarters of D per column chunk: 4 x more workgroups share the work
+constexpr int kFoldJ = 32;                                  // classifier outputs at most
+
+// sum over the 32 row groups of `v[j]` (32 values per thread) -> out(j, column) for the threads of group j % 8, eight j at a time
+template <int JP, class STORE>
+__device__ __forceinline__ void fold_reduce32(float (&v)[JP], float (&red)[32][8][33], int tg, int tk, STORE store) {
+#pragma unroll
+  for (int r = 0; r < JP / 8; ++r) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) red[tg][jj][tk] = v[r * 8 + jj];
+    __syncthreads();
+    if (tg < 8) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) s_ += red[g][tg][tk];
+      store(r * 8 + tg, s_);
+    }
+    __syncthreads();
+  }
+}
+
+// JP: J rounded up to 8 (compile time): the classifier-row loops are unrolled with UNCONDITIONAL loads (rows beyond J re-read
+// row J - 1 and feed sums that are never stored) - with a test around them hipcc drained the memory queue after every load and
+// the 22 x 32 loads of a thread ran one after the other: 193 us instead of 12.
+template <int JP>
+__global__ __launch_bounds__(1024) void linear_mean_fold_fwd_kernel(FoldFwd a) {
+  __shared__ float red[32][8][33];
+  __shared__ float mxs[16];
+  const int tk = threadIdx.x & 31, tg = threadIdx.x >> 5;
+  const int nkc = (a.Kp + 31) / 32;
+  const float invH = 1.f / (float)a.H;
+  __shared__ bool last;
+  float v[JP];
+#pragma unroll
+  for (int j = 0; j < JP; ++j) v[j] = 0.f;
+  const float* wcj[JP];                                    // row pointers of the classifier weight, clamped to the last row
+#pragma unroll
+  for (int j = 0; j < JP; ++j) wcj[j] = a.wc + (int64_t)(j < a.J ? j : a.J - 1) * a.ld_wc;
+  if ((int)blockIdx.x < nkc * kFoldQ) {
+    const int kc = blockIdx.x / kFoldQ, dq = blockIdx.x - kc * kFoldQ;
+    const int dchunk = ((a.D + kFoldQ - 1) / kFoldQ + 31) / 32 * 32;
+    const int d_beg = dq * dchunk, d_end = d_beg + dchunk < a.D ? d_beg + dchunk : a.D;
+    const int k = kc * 32 + tk;
+    const bool kin = k < a.Kc, kst = k < a.Kp;
+    const int HF = a.H * a.F;
+    const bool fc = k < HF;
+    const int h = fc ? k / a.F : 0, f = fc ? k - h * a.F : k - HF;
+    const float* rsrc = a.w_res ? a.w_res : a.w_fc;        // (no residual: read W_fc instead, the value is dropped)
+    const int64_t rld = a.w_res ? a.ld_res : a.ld_fc;
+    float mx = 0.f;
+    for (int d = d_beg + tg; d < d_end; d += 32) {
+      // (loads without a test around them: a column that does not exist reads element (d, 0) of the same matrix)
+      const float* src = fc ? a.w_fc : rsrc;
+      const int64_t ld_ = fc ? a.ld_fc : rld;
+      const int fq = kin ? f : 0;
+      float w = src[(int64_t)((fc ? h : 0) * a.D + d) * ld_ + fq];
+      if (!fc) {
+        for (int hh = 1; hh < a.H; ++hh) w += src[(int64_t)(hh * a.D + d) * ld_ + fq];
+      }
+      w = (kin && (fc || a.w_res)) ? w * invH : 0.f;
+      unsigned short bits = 0;
+      if (a.wbf) w = bf16_rne(w, bits);
+      if (kst) {
+        a.w_comb[(int64_t)d * a.ld_w + k] = w;
+        if (a.wbf) a.wbf[(int64_t)d * a.ld_wbf + k] = bits;
+      }
+      mx = fmaxf(mx, fabsf(w));
+      float c[JP];
+#pragma unroll
+      for (int j = 0; j < JP; ++j) c[j] = wcj[j][d];
+#pragma unroll
+      for (int j = 0; j < JP; ++j) v[j] = fmaf(c[j], w, v[j]);
+    }
+    // this quarter's sums -> device-visible partials; the workgroup that arrives last for the column chunk adds the four
+    // quarters in order (see masked_ce_kernel for the store / ticket protocol)
+    float* mine = a.part + ((int64_t)blockIdx.x * JP) * 32;
+    fold_reduce32<JP>(v, red, tg, tk, [&](int j, float s_) {
+      __hip_atomic_store(mine + j * 32 + tk, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.tickets + kc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kFoldQ - 1;
+    __syncthreads();
+    if (last) {
+      if (threadIdx.x < JP * 32) {
+        const int j = threadIdx.x >> 5;
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < kFoldQ; ++q)
+          s_ += __hip_atomic_load(a.part + (((int64_t)(kc * kFoldQ + q) * JP + j) * 32 + tk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < a.J && kst) a.P[(int64_t)j * a.ld_p + k] = s_;
+      }
+      if (threadIdx.x == 0) a.tickets[kc] = 0u;
+    }
+    if (a.absmax) {
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      if ((threadIdx.x & 63) == 0) mxs[threadIdx.x >> 6] = mx;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m = fmaxf(m, mxs[q]);
+        spgnn_detail::slots_max(a.absmax, m, blockIdx.x);
+      }
+    }
+    return;
+  }
+  // the last workgroup: b_mean and c0 = Wc b_mean + bc
+  for (int d = threadIdx.x; d < a.D; d += 1024) {
+    float b = 0.f;
+    if (a.bias) {
+      for (int hh = 0; hh < a.H; ++hh) b += a.bias[hh * a.D + d];
+      b *= invH;
+    }
+    if (a.b_mean) a.b_mean[d] = b;
+    float c[JP];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) c[j] = wcj[j][d];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) v[j] = fmaf(c[j], b, v[j]);
+  }
+  fold_reduce32<JP>(v, red, tg, tk, [&](int j, float s_) {
+    for (int off = 16; off > 0; off >>= 1) s_ += __shfl_xor(s_, off, 32);     // the 32 columns of group j (lanes of one half-wave)
+    if (tk == 0 && j < a.J) a.c0[j] = s_ + (a.bc ? a.bc[j] : 0.f);
+  });
+}
+
+struct FoldBwd {
+  const float* M1; int64_t ld_m; const float* cs; const float* wc; int64_t ld_wc; const float* w_comb; int64_t ld_w; const float* b_mean;
+  float* g_fc; int64_t ld_gfc; float* g_res; int64_t ld_gres; float* g_bias; float* g_wc; int64_t ld_gwc;
+  int H, D, F, J, Kc; unsigned blocksA;
+};
+
+template <int JP>
+__global__ __launch_bounds__(256) void linear_mean_fold_bwd_kernel(FoldBwd a) {
+  const float invH = 1.f / (float)a.H;
+  if (blockIdx.x < a.blocksA) {                              // g_W_comb = Wc^T M1, scattered into the two parameters' gradients
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.D * a.Kc) return;
+    const int d = (int)(idx / a.Kc), k = (int)(idx - (int64_t)d * a.Kc);
+    float cw[JP], cm[JP];                                    // unconditional loads (see the forward kernel); rows beyond J weigh 0
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+      const int jc = j < a.J ? j : a.J - 1;
+      cw[j] = a.wc[(int64_t)jc * a.ld_wc + d];
+      cm[j] = a.M1[(int64_t)jc * a.ld_m + k];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) acc = fmaf(j < a.J ? cw[j] : 0.f, cm[j], acc);
+    acc *= invH;
+    const int HF = a.H * a.F;
+    if (k < HF) {
+      const int h = k / a.F, f = k - h * a.F;
+      a.g_fc[(int64_t)(h * a.D + d) * a.ld_gfc + f] = acc;
+    } else if (a.g_res) {
+      const int f = k - HF;
+      for (int hh = 0; hh < a.H; ++hh) a.g_res[(int64_t)(hh * a.D + d) * a.ld_gres + f] = acc;
+    }
+    return;
+  }
+  // g_Wc[j, d] = sum_k M1[j, k] W_comb[d, k] + cs[j] b_mean[d] for 32 rows d of W_comb; g_bias = Wc^T cs / H
+  __shared__ __attribute__((aligned(16))) float wt[32][68], m1s[32][68];     // pitch 68: rows stay 16-byte aligned for ds_read_b128
+  const int d0 = (int)(blockIdx.x - a.blocksA) * 32;
+  const int dl = threadIdx.x & 31, jg = threadIdx.x >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < a.Kc; k0 += 64) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + 256 * i, r = idx >> 6, c = idx & 63;
+      const bool cin = k0 + c < a.Kc;
+      const int cc = cin ? k0 + c : 0;
+      const float wv = a.w_comb[(int64_t)(d0 + r < a.D ? d0 + r : a.D - 1) * a.ld_w + cc];     // unconditional, clamped
+      const float mv = a.M1[(int64_t)(r < a.J ? r : a.J - 1) * a.ld_m + cc];
+      wt[r][c] = (d0 + r < a.D && cin) ? wv : 0.f;
+      m1s[r][c] = (r < a.J && cin) ? mv : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 64; c += 4) {
+      const float4 w = *reinterpret_cast<const float4*>(&wt[dl][c]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 m = *reinterpret_cast<const float4*>(&m1s[jg + 8 * q][c]);
+        acc[q] = fmaf(w.x, m.x, acc[q]); acc[q] = fmaf(w.y, m.y, acc[q]); acc[q] = fmaf(w.z, m.z, acc[q]); acc[q] = fmaf(w.w, m.w, acc[q]);
+      }
+    }
+    __syncthreads();
+  }
+  const int d = d0 + dl;
+  if (d >= a.D) return;
+  const float bm = a.b_mean ? a.b_mean[d] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = jg + 8 * q;
+    if (j < a.J && a.g_wc) a.g_wc[(int64_t)j * a.ld_gwc + d] = fmaf(a.cs[j], bm, acc[q]);
+  }
+  if (jg == 0 && a.g_bias) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+      const int jc = j < a.J ? j : a.J - 1;
+      s_ = fmaf(j < a.J ? a.wc[(int64_t)jc * a.ld_wc + d] : 0.f, a.cs[jc], s_);
+    }
+    s_ *= invH;
+    for (int hh = 0; hh < a.H; ++hh) a.g_bias[hh * a.D + d] = s_;
+  }
+}
+
 }  // namespace gemm
 
 extern "C" {
@@ -1776,6 +2010,56 @@ int spgnn_weight_prep(const spgnn_weight_prep_layer* table, int32_t n_layers, in
   hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, workspace, 0);
   hipLaunchKernelGGL(gemm::weight_prep_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, (int)n_layers, workspace, 1);
   return spgnn_detail::check_launch("spgnn_weight_prep");
+}
+
+int spgnn_linear_mean_fold_fwd(const float* w_fc, int64_t w_fc_stride, const float* w_res, int64_t w_res_stride, const float* bias,
+                               const float* w_cls, int64_t w_cls_stride, const float* b_cls, int32_t H, int32_t D, int32_t F, int32_t J,
+                               float* w_comb, int64_t w_comb_stride, uint16_t* w_comb_bf16, int64_t w_comb_bf16_stride,
+                               float* b_mean, float* P, int64_t P_stride, float* c0, float* absmax_out, float* workspace,
+                               uint32_t* tickets, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!w_fc || !w_cls || !w_comb || !P || !c0 || !workspace || !tickets) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  const int64_t Kc = (int64_t)(H + 1) * F;
+  const int64_t Kp = (Kc + 15) / 16 * 16;                   // every image is written (zero padded) up to a multiple of 16 columns
+  if (Kp > INT32_MAX || w_fc_stride < F || (w_res && w_res_stride < F) || w_cls_stride < D || w_comb_stride < Kp || P_stride < Kp ||
+      (w_comb_bf16 && w_comb_bf16_stride < Kp))
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+  gemm::FoldFwd a{w_fc, w_fc_stride, w_res, w_res_stride, bias, w_cls, w_cls_stride, b_cls, w_comb, w_comb_stride,
+                  w_comb_bf16, w_comb_bf16_stride, b_mean, P, P_stride, c0, absmax_out, workspace, tickets, (int)H, (int)D, (int)F, (int)J,
+                  (int)Kc, (int)Kp};
+  const dim3 grid((unsigned)(((Kp + 31) / 32) * gemm::kFoldQ + 1));
+  if (J <= 8) hipLaunchKernelGGL(gemm::linear_mean_fold_fwd_kernel<8>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  else if (J <= 16) hipLaunchKernelGGL(gemm::linear_mean_fold_fwd_kernel<16>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  else if (J <= 24) hipLaunchKernelGGL(gemm::linear_mean_fold_fwd_kernel<24>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm::linear_mean_fold_fwd_kernel<32>, grid, dim3(1024), 0, (hipStream_t)stream, a);
+  return spgnn_detail::check_launch("spgnn_linear_mean_fold_fwd");
+}
+
+int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F) {       // floats of `workspace`; `tickets`: one uint32 per 32 columns of Kp, zero before the first call
+  const int64_t Kp = (((int64_t)(H + 1) * F) + 15) / 16 * 16;
+  return (Kp / 32 + 1) * gemm::kFoldQ * gemm::kFoldJ * 32;
+}
+
+int spgnn_linear_mean_fold_bwd(const float* M1, int64_t M1_stride, const float* cs, const float* w_cls, int64_t w_cls_stride,
+                               const float* w_comb, int64_t w_comb_stride, const float* b_mean, int32_t H, int32_t D, int32_t F,
+                               int32_t J, float* g_w_fc, int64_t g_w_fc_stride, float* g_w_res, int64_t g_w_res_stride, float* g_bias,
+                               float* g_w_cls, int64_t g_w_cls_stride, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if (!M1 || !cs || !w_cls || !w_comb || !g_w_fc) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  const int64_t Kc = (int64_t)(H + 1) * F;
+  if (M1_stride < Kc || w_cls_stride < D || w_comb_stride < Kc || g_w_fc_stride < F || (g_w_res && g_w_res_stride < F) ||
+      (g_w_cls && g_w_cls_stride < D))
+    return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
+  const int64_t blocksA = ((int64_t)D * Kc + 255) / 256, blocksB = (D + 31) / 32;
+  if (blocksA + blocksB > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  gemm::FoldBwd a{M1, M1_stride, cs, w_cls, w_cls_stride, w_comb, w_comb_stride, b_mean, g_w_fc, g_w_fc_stride, g_w_res, g_w_res_stride,
+                  g_bias, g_w_cls, g_w_cls_stride, (int)H, (int)D, (int)F, (int)J, (int)Kc, (unsigned)blocksA};
+  const dim3 grid((unsigned)(blocksA + blocksB));
+  if (J <= 8) hipLaunchKernelGGL(gemm::linear_mean_fold_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (J <= 16) hipLaunchKernelGGL(gemm::linear_mean_fold_bwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (J <= 24) hipLaunchKernelGGL(gemm::linear_mean_fold_bwd_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm::linear_mean_fold_bwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return spgnn_detail::check_launch("spgnn_linear_mean_fold_bwd");
 }
 
 }  // extern "C"

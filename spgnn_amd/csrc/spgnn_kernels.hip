@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_fwd(GatAggFwdT<ST> a) {
       stv(dst, acc[h][r]);
       mxv = absmax4(mxv, acc[h][r]);
       if (a.xoff >= 0) { stv(dst + a.xoff, xs[r]); mxv = absmax4(mxv, xs[r]); }
+      else if (a.xoff == -2 && h == H - 1) { stv(dst + a.zs, xs[r]); mxv = absmax4(mxv, xs[r]); }   // ONE copy of x behind the last block
     }
   if (a.absmax) {
     mxv = team_max(mxv, T);
@@ -2813,7 +2814,9 @@ static int gat_agg_fwd_impl(const char* name, const int32_t* indptr, const int32
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !el || !er || !attn || !z || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_fwd: null pointer");
   const int64_t need = x_copy_offset >= 0 ? (int64_t)x_copy_offset + F : F;
-  if (x_stride < F || s_stride < H || head_stride < need || z_stride < (int64_t)H * head_stride || x_copy_offset >= 0 && x_copy_offset < F)
+  if (x_copy_offset < -2) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_fwd: x_copy_offset");
+  if (x_stride < F || s_stride < H || head_stride < need || z_stride < (int64_t)H * head_stride + (x_copy_offset == -2 ? F : 0) ||
+      (x_copy_offset >= 0 && x_copy_offset < F))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: row stride / block layout too small");
   if (!vec_ok_t(x, x_stride) || !vec_ok_t(z, z_stride) || (head_stride & 3) || (x_copy_offset > 0 && (x_copy_offset & 3)))
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_fwd: rows must be 16-byte aligned");

@@ -1597,19 +1597,21 @@ def agg_first_supported(H: int, F_in: int) -> bool:
 
 
 def gat_agg_fwd_raw(csc: DeviceCSC, x, el, er, H: int, slope: float, p_drop: float, seed: int, with_x_copy: bool,
-                    out: Optional[torch.Tensor] = None):
+                    out: Optional[torch.Tensor] = None, x_tail: bool = False):
     """-> (z (N, H*zs), attn (E,H), scale block of z); head h's block: [z_h | x] (zs = 2F) or [z_h] (zs = F).  ``out``: a
-    buffer at least (N, H*zs) wide to write the blocks into (its row stride is used)."""
+    buffer at least (N, H*zs) wide to write the blocks into (its row stride is used).  ``x_tail`` (with zs = F): one copy of
+    x behind the last block, [z_0 | ... | z_{H-1} | x] (``out`` at least (N, (H+1) F)); the scale block covers it."""
     N, E = csc.num_nodes, csc.num_edges
     F_ = x.shape[1]
     zs = 2 * F_ if with_x_copy else F_
-    z = out if out is not None else torch.empty((N, H * zs), dtype=torch.float32, device=x.device)
+    assert not (x_tail and with_x_copy)
+    z = out if out is not None else torch.empty((N, H * zs + (F_ if x_tail else 0)), dtype=torch.float32, device=x.device)
     attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
     amax = new_scale_block(x.device)
-    with torch.cuda.device(x.device), _timed("gat_agg_fwd", (N, E, H, F_, int(with_x_copy))):
+    with torch.cuda.device(x.device), _timed("gat_agg_fwd", (N, E, H, F_, 2 if x_tail else int(with_x_copy))):
         _capi.check(_capi.load().spgnn_gat_agg_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
                                                    el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(), z.data_ptr(),
-                                                   z.stride(0), zs, F_ if with_x_copy else -1, amax.data_ptr(), N, E, H, F_,
+                                                   z.stride(0), zs, -2 if x_tail else (F_ if with_x_copy else -1), amax.data_ptr(), N, E, H, F_,
                                                    slope, p_drop, seed, _seed_off_ptr(x.device), _stream(x)),
                     "spgnn_gat_agg_fwd")
     return z, attn, amax
@@ -1819,9 +1821,8 @@ class _GATAggregateFn(torch.autograd.Function):
         N, F_ = x.shape
         s = scores_fwd(x, w_lr)
         zx = torch.empty((N, (H + 1) * F_), dtype=torch.float32, device=x.device)
-        _, attn, _amax = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, False, out=zx)
-        zx[:, H * F_:].copy_(x)
-        ctx.csc, ctx.cfg = csc, (H, slope, p_drop, seed)
+        _, attn, amax = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, False, out=zx, x_tail=True)
+        ctx.csc, ctx.cfg, ctx.scale_block = csc, (H, slope, p_drop, seed), amax      # x's copy is the kernel's own: its maxima too
         ctx.save_for_backward(x, w_lr, s, attn)
         ctx.mark_non_differentiable(attn)
         return zx, attn
@@ -1864,6 +1865,130 @@ class _GATAggregateFn(torch.autograd.Function):
         return (g_x if ctx.needs_input_grad[0] else None), g_wlr, None, None, None, None, None
 
 
+_FOLD_WS: dict = {}
+FUSE_LINEAR_MEAN_FOLD = True     # the weight-space half of gat_layer_linear_mean + classifier as two launches (spgnn_linear_mean_fold_*)
+
+
+def linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H: int, D: int, bf16: bool = False):
+    """One spgnn_linear_mean_fold_fwd call -> (w_comb (D, Kp) fp32, its scale block, w_comb as bf16 rows or None, b_mean or
+    None, P (J, Kp), c0 (J,)); Kc = (H + 1) F real columns, every image zero padded to Kp = Kc rounded up to 16."""
+    F_, J = w_fc.shape[1], w_cls.shape[0]
+    Kp = _pad16((H + 1) * F_)
+    dev = w_fc.device
+    w_comb = torch.empty((D, Kp), dtype=torch.float32, device=dev)
+    w_bf = torch.empty((D, Kp), dtype=torch.bfloat16, device=dev) if bf16 else None
+    b_mean = torch.empty((D,), dtype=torch.float32, device=dev) if bias is not None else None
+    P = torch.empty((J, Kp), dtype=torch.float32, device=dev)
+    c0 = torch.empty((J,), dtype=torch.float32, device=dev)
+    blk = None if bf16 else new_scale_block(dev)
+    ws = _FOLD_WS.get((str(dev), H, F_))
+    if ws is None:                                          # persistent scratch: partial sums and the (self re-arming) tickets
+        n = int(_capi.load().spgnn_linear_mean_fold_workspace(H, F_))
+        ws = _FOLD_WS[(str(dev), H, F_)] = (torch.empty((n,), dtype=torch.float32, device=dev),
+                                            torch.zeros((Kp // 32 + 2,), dtype=torch.int32, device=dev))
+    wf = w_fc if w_fc.stride(1) == 1 else w_fc.contiguous()
+    wr = None if w_res is None else (w_res if w_res.stride(1) == 1 else w_res.contiguous())
+    wc = w_cls if w_cls.stride(1) == 1 else w_cls.contiguous()
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().spgnn_linear_mean_fold_fwd(wf.data_ptr(), wf.stride(0), _ptr(wr), wr.stride(0) if wr is not None else 0,
+                                                            _ptr(bias), wc.data_ptr(), wc.stride(0), _ptr(b_cls), H, D, F_, J,
+                                                            w_comb.data_ptr(), Kp, _ptr(w_bf), Kp, _ptr(b_mean), P.data_ptr(), Kp,
+                                                            c0.data_ptr(), _ptr(blk), ws[0].data_ptr(), ws[1].data_ptr(), _stream(w_comb)),
+                    "spgnn_linear_mean_fold_fwd")
+    return w_comb, blk, w_bf, b_mean, P, c0
+
+
+def linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H: int, D: int, F_: int, has_res: bool, has_bias: bool):
+    """One spgnn_linear_mean_fold_bwd call -> (g_w_fc, g_w_res or None, g_bias or None, g_w_cls)."""
+    dev = M1.device
+    J = w_cls.shape[0]
+    g_fc = torch.empty((H * D, F_), dtype=torch.float32, device=dev)
+    g_res = torch.empty((H * D, F_), dtype=torch.float32, device=dev) if has_res else None
+    g_bias = torch.empty((H * D,), dtype=torch.float32, device=dev) if has_bias else None
+    g_wc = torch.empty((J, D), dtype=torch.float32, device=dev)
+    wc = w_cls if w_cls.stride(1) == 1 else w_cls.contiguous()
+    m1 = M1 if M1.stride(1) == 1 else M1.contiguous()
+    cs = cs.contiguous()
+    with torch.cuda.device(dev):
+        _capi.check(_capi.load().spgnn_linear_mean_fold_bwd(m1.data_ptr(), m1.stride(0), cs.data_ptr(), wc.data_ptr(), wc.stride(0),
+                                                            w_comb.data_ptr(), w_comb.stride(0), _ptr(b_mean), H, D, F_, J,
+                                                            g_fc.data_ptr(), F_, _ptr(g_res), F_, _ptr(g_bias), g_wc.data_ptr(), D,
+                                                            _stream(m1)), "spgnn_linear_mean_fold_bwd")
+    return g_fc, g_res, g_bias, g_wc
+
+
+def _linear_mean_general_grads(g, zx, sg, sx, w_comb, Kc, H, D, F_, has_res, has_bias):
+    """The ordinary route (the embedding carries a gradient too): g (N, D) -> (g_zx, g_w_fc, g_w_res, g_bias) through W_comb."""
+    N = zx.shape[0]
+    g_zx = torch.empty((N, (Kc + 3) // 4 * 4), dtype=torch.float32, device=zx.device)[:, :Kc]
+    gemm_nt(g, w_comb[:, :Kc].t().contiguous(), sg, pow2_scale(w_comb), out=g_zx)
+    if has_bias:
+        g_wc_, g_bm = gemm_tn(g, zx, sg, sx, want_colsum=True)
+    else:
+        g_wc_, g_bm = gemm_tn(g, zx, sg, sx), None
+    g_wc_ = g_wc_ * (1.0 / H)
+    g_fc = g_wc_[:, :H * F_].reshape(D, H, F_).permute(1, 0, 2).reshape(H * D, F_)
+    g_res = g_wc_[:, H * F_:].unsqueeze(0).expand(H, D, F_).reshape(H * D, F_) if has_res else None
+    g_bias = (g_bm * (1.0 / H)).repeat(H) if has_bias else None
+    return g_zx, g_fc, g_res, g_bias
+
+
+class _LinearMeanClassifierFn(torch.autograd.Function):
+    """(Zx, W_fc, W_res, bias, Wc, bc) -> (mean_h out_h = Zx W_comb^T + b_mean, logits = Zx P^T + c0): _LinearClassifierFn with
+    the assembly of W_comb / b_mean / P / c0 from the layer's parameters and the way back to their gradients inside the
+    node - one launch each (spgnn_linear_mean_fold_fwd / _bwd) instead of ~28 tiny torch / rocBLAS launches per step."""
+
+    @staticmethod
+    def forward(ctx, zx, w_fc, w_res, bias, w_cls, b_cls, H, D):
+        ctx.set_materialize_grads(False)
+        zx = _rowmajor(zx)
+        if not _rows_aligned(zx):
+            zx = cat_padded((zx,))
+        Kc = zx.shape[1]
+        w_comb, blk, _, b_mean, P, c0 = linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D)
+        sx = operand_scale(zx)
+        y = gemm_nt(zx, w_comb[:, :Kc], sx, blk, bias=b_mean)
+        logits = scores_fwd(zx, P[:, :Kc])
+        logits += c0
+        ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
+        ctx.save_for_backward(zx, w_comb, sx, blk, P, w_cls, b_mean)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, g_y, g_logits):
+        if g_y is None and g_logits is None:
+            return (None,) * 8
+        zx, w_comb, sx, blk, P, w_cls, b_mean = ctx.saved_tensors
+        H, D, F_, Kc, has_res, has_bias, has_bcls = ctx.cfg
+        N = zx.shape[0]
+        g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
+        cs = M1 = None
+        if g_logits is not None:
+            g_logits = _rowmajor(g_logits)
+            cs = g_logits.sum(0)
+            M1 = scores_bwd_w(g_logits, zx)                              # g_logits^T Zx (J, Kc)
+            g_bcls = cs if has_bcls else None
+        if g_y is None:                                   # the folded route (the training step): no (N, D) gradient exists
+            if ctx.needs_input_grad[0]:
+                g_zx = torch.empty((N, (Kc + 3) // 4 * 4), dtype=torch.float32, device=zx.device)[:, :Kc]
+                scores_bwd_x_(g_zx, g_logits, P[:, :Kc], accumulate=False)
+            g_fc, g_res, g_bias, g_wcls = linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H, D, F_, has_res, has_bias)
+            return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+        g = _rowmajor(g_y)
+        if g_logits is not None:
+            g = g.clone() if g.data_ptr() == g_y.data_ptr() else g
+            if not _rows_aligned(g):
+                g = cat_padded((g,))
+            scores_bwd_x_(g, g_logits, w_cls.detach(), accumulate=True)
+            g_wcls = torch.mm(M1, w_comb[:, :Kc].t())
+            if has_bias:
+                g_wcls.addr_(cs, b_mean)
+        elif not _rows_aligned(g):
+            g = cat_padded((g,))
+        g_zx, g_fc, g_res, g_bias = _linear_mean_general_grads(g, zx, pow2_scale(g), sx, w_comb, Kc, H, D, F_, has_res, has_bias)
+        return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+
+
 def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
                           seed: int = 0, w_cls=None, b_cls=None):
     """mean over heads of a GATConv WITHOUT activation (see _GATAggregateFn) -> (mean (N, D), attn (E, H)).  The weight
@@ -1873,6 +1998,13 @@ def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D:
     _require_cuda(x, w_fc, w_res, w_lr, bias, w_cls, b_cls)
     F_ = x.shape[1]
     zx, attn = _GATAggregateFn.apply(x, w_lr, csc, H, slope, p_drop, seed)
+    blk = getattr(zx.grad_fn, "scale_block", None) if zx.grad_fn is not None else None
+    if blk is not None:
+        zx._spgnn_scale = (zx._version, blk)
+    if (FUSE_LINEAR_MEAN_FOLD and w_cls is not None and w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 4 == 0
+            and zx.shape[0] >= 512 and GEMM_MODE == "f16x3" and zx.dtype == torch.float32):
+        out, logits = _LinearMeanClassifierFn.apply(zx, w_fc, w_res, bias, w_cls, b_cls, H, D)
+        return out, attn, logits
     parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
     parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
     w_comb = torch.cat(parts, dim=1) * (1.0 / H)

@@ -353,12 +353,11 @@ class _GATAggregateBf16Fn(torch.autograd.Function):
         s = scores_fwd(x, w_lr)
         zx = empty_rows(N, (H + 1) * F_, x.device)
         attn = torch.empty((E, H), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device), _timed("gat_agg_fwd_bf16", (N, E, H, F_, 0)):
+        with torch.cuda.device(x.device), _timed("gat_agg_fwd_bf16", (N, E, H, F_, 2)):
             _capi.check(_capi.load().spgnn_gat_agg_fwd_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
                                                             s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
-                                                            zx.data_ptr(), zx.stride(0), F_, -1, N, E, H, F_, slope, p_drop, seed,
-                                                            _seed_off_ptr(x.device), _stream(x)), "spgnn_gat_agg_fwd_bf16")
-        zx[:, H * F_:].copy_(x)
+                                                            zx.data_ptr(), zx.stride(0), F_, -2, N, E, H, F_, slope, p_drop, seed,
+                                                            _seed_off_ptr(x.device), _stream(x)), "spgnn_gat_agg_fwd_bf16")   # -2: x's copy behind the last block
         ctx.csc, ctx.cfg = csc, (H, slope, p_drop, seed)
         ctx.save_for_backward(x, w_lr, s, attn)
         ctx.mark_non_differentiable(attn)
@@ -507,6 +506,64 @@ class _LinearClassifierBf16Fn(torch.autograd.Function):
         return g_x, g_w, g_b, g_wcls, g_bcls
 
 
+class _LinearMeanClassifierBf16Fn(torch.autograd.Function):
+    """ops._LinearMeanClassifierFn on bf16 rows: W_comb is rounded to bf16 inside spgnn_linear_mean_fold_fwd (the image the bf16
+    product reads), P / c0 / every gradient use the rounded values - the function as evaluated, as _LinearClassifierBf16Fn."""
+
+    @staticmethod
+    def forward(ctx, zx, w_fc, w_res, bias, w_cls, b_cls, H, D):
+        from . import ops
+        ctx.set_materialize_grads(False)
+        Kc = zx.shape[1]
+        w_comb, _, w_bf, b_mean, P, c0 = ops.linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D, bf16=True)
+        y = gemm_nt(zx, w_bf[:, :Kc], out_f32=True, bias=b_mean)
+        logits = scores_fwd(zx, P[:, :Kc])
+        logits += c0
+        ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
+        ctx.save_for_backward(zx, w_comb, w_bf, P, w_cls, b_mean)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, g_y, g_logits):
+        from . import ops
+        if g_y is None and g_logits is None:
+            return (None,) * 8
+        zx, w_comb, w_bf, P, w_cls, b_mean = ctx.saved_tensors
+        H, D, F_, Kc, has_res, has_bias, has_bcls = ctx.cfg
+        g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
+        cs = M1 = None
+        if g_logits is not None:
+            g_logits = _rowmajor(g_logits)
+            cs = g_logits.sum(0)
+            M1 = scores_bwd_w(g_logits, zx)
+            g_bcls = cs if has_bcls else None
+        if g_y is None:                                   # folded route: g_Zx as bf16 rows straight from the fp32 logit gradient
+            if ctx.needs_input_grad[0]:
+                g_zx = scores_bwd_x(g_logits, P[:, :Kc], Kc)
+            g_fc, g_res, g_bias, g_wcls = ops.linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H, D, F_, has_res, has_bias)
+            return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+        g = g_y if g_y.dtype == torch.float32 else g_y.float()
+        if g_logits is not None:
+            g = torch.addmm(g, g_logits, w_cls.detach())
+            g_wcls = torch.mm(M1, w_comb[:, :Kc].t())
+            if has_bias:
+                g_wcls.addr_(cs, b_mean)
+        gb = cast_rows(g)
+        if ctx.needs_input_grad[0]:
+            w_t = torch.zeros((Kc, _pad8(D)), dtype=BF16, device=zx.device)
+            w_t[:, :D] = w_bf[:, :Kc].t()
+            g_zx = gemm_nt(gb, w_t[:, :D])
+        if has_bias:
+            g_wc_, g_bm = gemm_tn(gb, zx, want_colsum=True)
+        else:
+            g_wc_, g_bm = gemm_tn(gb, zx), None
+        g_wc_ = g_wc_ * (1.0 / H)
+        g_fc = g_wc_[:, :H * F_].reshape(D, H, F_).permute(1, 0, 2).reshape(H * D, F_)
+        g_res = g_wc_[:, H * F_:].unsqueeze(0).expand(H, D, F_).reshape(H * D, F_) if has_res else None
+        g_bias = (g_bm * (1.0 / H)).repeat(H) if has_bias else None
+        return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+
+
 def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
                           seed: int = 0, w_cls=None, b_cls=None):
     """ops.gat_layer_linear_mean on bf16 rows -> (mean (N, D) fp32, attn (E, H) fp32[, logits (N, J) fp32]).  The combined
@@ -515,6 +572,11 @@ def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D:
     _require_cuda(x, w_fc, w_res, w_lr, bias, w_cls, b_cls)
     F_ = x.shape[1]
     zx, attn = _GATAggregateBf16Fn.apply(as_rows(x), w_lr, csc, H, slope, p_drop, seed)
+    from . import ops as _ops
+    if (_ops.FUSE_LINEAR_MEAN_FOLD and w_cls is not None and w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 8 == 0
+            and ((H + 1) * F_) % 8 == 0):
+        out, logits = _LinearMeanClassifierBf16Fn.apply(zx, w_fc, w_res, bias, w_cls, b_cls, H, D)
+        return out, attn, logits
     parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
     parts.append(w_res.view(H, D, F_).sum(0) if w_res is not None else w_fc.new_zeros((D, F_)))
     w_comb = torch.cat(parts, dim=1) * (1.0 / H)

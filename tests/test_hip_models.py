@@ -101,6 +101,41 @@ def test_config_loss_gradients_match_oracle(name, trees):
             assert e32 < 1e-4 or tiny or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6, (n, e32)
 
 
+@pytest.mark.parametrize("embedding_in_loss", [False, True])
+def test_linear_mean_fold_kernels_equal_the_torch_assembly(embedding_in_loss, monkeypatch):
+    """ops.FUSE_LINEAR_MEAN_FOLD: W_comb / b_mean / P / c0 and the way back to g_W_fc / g_W_res / g_bias / g_Wc in one launch
+    each (spgnn_linear_mean_fold_fwd / _bwd) against the torch / rocBLAS assembly they replace - logits, embedding and every
+    parameter gradient, on the folded route (only the logits in the loss) and the ordinary one (the embedding too)."""
+    from spgnn_amd import ops
+    cfg, model = _build("st_gat_3", seed=2)
+    g = synthetic.make_batch(5, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    assert g.number_of_nodes() >= 512
+    model.eval()
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS), device="cuda")
+    y = g.ndata["y"]
+    mask = (torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSE_LINEAR_MEAN_FOLD", fused)
+        for p_ in model.parameters():
+            p_.grad = None
+        ops.KernelTimer.start()
+        out = model(g)
+        loss = masked_weighted_ce(out[0], y, mask, w)
+        if embedding_in_loss:
+            loss = loss + 1e-3 * out[1].square().mean()
+        loss.backward()
+        ops.KernelTimer.stop()
+        res.append(([o.detach().clone() for o in out[:2]], {n: p_.grad.clone() for n, p_ in model.named_parameters() if p_.grad is not None}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert rel_err(a, b) < 2e-6
+    assert set(res[0][1]) == set(res[1][1])
+    gmax = max(float(v.abs().max()) for v in res[1][1].values())
+    for n in res[1][1]:
+        a, b = res[0][1][n], res[1][1][n]
+        assert rel_err(a, b) < 2e-5 or float((a - b).abs().max()) < 1e-7 * gmax, (n, rel_err(a, b))
+
+
 def test_st_gat_3_with_eight_heads_matches_oracle():
     """BASELINE.json words config 2 as "st_gat_3 (3-layer 8-head GAT)"; the reference's st_gat_3 has 2 heads
     (exp_settings/st_gat_3.py:101-102).  H is a run-time parameter here: the same model with num_heads = 8 (hidden layers
