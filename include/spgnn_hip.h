@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 38
+#define SPGNN_ABI_VERSION 39
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -547,8 +547,11 @@ int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* l
  */
 int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
                          const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
-                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, int64_t N, int32_t C,
-                         spgnn_stream_t stream);
+                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride,
+                         float* colsum_partials /* nullable: 32 floats per 256-node block */,
+                         float* g_colsum /* nullable, C <= 32, needs sums + g_logits: sum_i g_logits[i, :] - the gradient of a classifier
+                                            bias - added by the last workgroup in block order */,
+                         int64_t N, int32_t C, spgnn_stream_t stream);
 
 /*
  * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's

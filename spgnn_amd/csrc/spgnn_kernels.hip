@@ -2301,7 +2301,8 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
                                                            const int64_t* __restrict__ seed_off, const float* __restrict__ sampling_p,
                                                            const float* __restrict__ class_w, float* __restrict__ partial,
                                                            float* __restrict__ sums, unsigned* __restrict__ ticket,
-                                                           float* __restrict__ g_logits, int64_t g_ld, int64_t N, int C) {
+                                                           float* __restrict__ g_logits, int64_t g_ld, float* __restrict__ colpart,
+                                                           float* __restrict__ colsum, int64_t N, int C) {
   __shared__ float red[2][kBlock / 64];
   __shared__ bool last;
   // C <= 32 (the 22 airway labels): the block's 256 rows go through LDS, so that the global loads and the gradient stores are
@@ -2352,6 +2353,11 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
       const int r = e / C, c = e - r * C;
       g_logits[(base + r) * g_ld + c] = tile[r * P + c];
     }
+    if (colpart && threadIdx.x < C) {                        // column sums of the block's gradient rows (the classifier bias' gradient)
+      float cs_ = 0.f;
+      for (int r = 0; r < rows; ++r) cs_ += tile[r * P + threadIdx.x];
+      __hip_atomic_store(colpart + (int64_t)blockIdx.x * 32 + threadIdx.x, cs_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   num = team_sum(num, 64); den = team_sum(den, 64);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
@@ -2375,6 +2381,12 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
   if (!sums) return;
   __syncthreads();
   if (!last) return;
+  if (colpart && colsum && staged && g_logits && threadIdx.x < C) {      // block order: bitwise independent of the arrival order
+    float cs_ = 0.f;
+    for (unsigned q = 0; q < gridDim.x; ++q)
+      cs_ += __hip_atomic_load(colpart + (int64_t)q * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    colsum[threadIdx.x] = cs_;
+  }
   float a = 0.f, b = 0.f;                                    // thread t: blocks t, t + 256, ... in ascending order
   for (unsigned q = threadIdx.x; q < gridDim.x; q += kBlock) {
     a += __hip_atomic_load(partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3381,13 +3393,13 @@ int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* l
                     int64_t N, int32_t C, spgnn_stream_t stream) {
   if (!draws) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
   return spgnn_masked_ce_step(logits, logits_stride, labels, draws, 0, nullptr, sampling_p, class_weight, partials, nullptr, nullptr,
-                              g_logits, g_stride, N, C, stream);
+                              g_logits, g_stride, nullptr, nullptr, N, C, stream);
 }
 
 int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
                          const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
-                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, int64_t N, int32_t C,
-                         spgnn_stream_t stream) {
+                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum,
+                         int64_t N, int32_t C, spgnn_stream_t stream) {
   if (N < 0 || C <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_masked_ce: bad N/C");
   if (N == 0) {
     if (sums) { const hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return fail(-(1000 + (int)e), "spgnn_masked_ce_step: hipMemsetAsync"); }
@@ -3397,7 +3409,7 @@ int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64
   if (logits_stride < C || (g_logits && g_stride < C)) return fail(SPGNN_ERR_STRIDE, "spgnn_masked_ce: row stride smaller than row");
   hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits,
                      logits_stride, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, partials, sums, ticket, g_logits,
-                     g_stride, N, C);
+                     g_stride, (sums && g_colsum && C <= 32) ? colsum_partials : nullptr, g_colsum, N, C);
   return check_launch("spgnn_masked_ce");
 }
 

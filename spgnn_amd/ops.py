@@ -522,6 +522,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         x, weight = ctx.saved_tensors
+        cs_ = column_sums(g_y) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         g_y = g_y.contiguous()
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
@@ -529,8 +530,8 @@ class _SkinnyLinearFn(torch.autograd.Function):
             scores_bwd_x_(g_x, g_y, weight, accumulate=False)
         if ctx.needs_input_grad[1]:
             g_w = scores_bwd_w(g_y, x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            g_b = g_y.sum(0)
+        if cs_ is not None:
+            g_b = cs_
         return g_x, g_w, g_b
 
 
@@ -590,13 +591,17 @@ class _MaskedCE(torch.autograd.Function):
         ticket = _MaskedCE._tickets.get(str(dev))
         if ticket is None:
             ticket = _MaskedCE._tickets[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        # unit gradient: the column sums of g ARE the gradient of a classifier bias - the last workgroup adds them too
+        colsum = torch.empty((C,), dtype=torch.float32, device=dev) if (unit and g is not None and C <= 32 and N > 0) else None
+        colpart = torch.empty((max(nb, 1), 32), dtype=torch.float32, device=dev) if colsum is not None else None
         with torch.cuda.device(dev), _timed("masked_ce", (N, C)):
             # the last workgroup adds the per-block pairs (block order): no reduction launch
             _capi.check(_capi.load().spgnn_masked_ce_step(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                           _seed_off_ptr(dev) if draws is None else 0, sampling_p.data_ptr(),
                                                           class_weight.data_ptr(), part.data_ptr(), s.data_ptr(), ticket.data_ptr(),
-                                                          _ptr(g), C, N, C, _stream(logits)), "spgnn_masked_ce_step")
-        ctx.save_for_backward(g)
+                                                          _ptr(g), C, _ptr(colpart), _ptr(colsum), N, C, _stream(logits)),
+                        "spgnn_masked_ce_step")
+        ctx.save_for_backward(g, colsum)
         ctx.unit = unit
         ctx.set_materialize_grads(False)
         num, den = s[0], s[1]                   # two outputs: indexing ONE output outside would add a select node whose
@@ -605,10 +610,21 @@ class _MaskedCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_num, _g_den):
-        (g,) = ctx.saved_tensors
+        g, colsum = ctx.saved_tensors
         if g is None or g_num is None:
             return None, None, None, None, None
-        return (g if ctx.unit else g * g_num), None, None, None, None      # unit: the caller back-propagates the numerator itself (grad 1)
+        if ctx.unit:                   # the caller back-propagates the numerator itself (grad 1): the stored gradient as it is
+            if colsum is not None:
+                g._spgnn_colsum = colsum          # read by the node that produced the logits, if it is the direct consumer (column_sums)
+            return g, None, None, None, None
+        return g * g_num, None, None, None, None
+
+
+def column_sums(g: torch.Tensor) -> torch.Tensor:
+    """g.sum(0) - or, when ``g`` is the logit gradient the loss kernel just handed over, the column sums that kernel's last
+    workgroup already formed (the attribute exists only on that very tensor: any op in between makes a new one)."""
+    cs = getattr(g, "_spgnn_colsum", None)
+    return cs if cs is not None and cs.shape[0] == g.shape[1] else g.sum(0)
 
 
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[torch.Tensor], sampling_p: torch.Tensor,
@@ -824,8 +840,8 @@ class _LinearClassifierFn(torch.autograd.Function):
         wc = w_cls.detach()
         g_x = g_w = g_b = g_wcls = g_bcls = cs = M1 = None
         if g_logits is not None:
+            cs = column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
-            cs = g_logits.sum(0)
             M1 = scores_bwd_w(g_logits, x)                               # g_logits^T x  (J, K)
             if ctx.needs_input_grad[3]:
                 g_wcls = torch.mm(M1, w.t())
@@ -1730,11 +1746,12 @@ class _GATAggFirstFn(torch.autograd.Function):
         g_wcls = g_bcls = None
         jobs = SumJobs(x.device)                   # every split-K reduction of this node in one launch at the end
         if ctx.has_cls and g_logits is not None:
+            cs_ = column_sums(g_logits) if (ctx.has_cls_bias and ctx.needs_input_grad[6]) else None
             g_logits = g_logits.contiguous()
             if ctx.needs_input_grad[5]:
                 g_wcls = scores_bwd_w(g_logits, rst, defer=jobs)
-            if ctx.has_cls_bias and ctx.needs_input_grad[6]:
-                g_bcls = g_logits.sum(0)
+            if cs_ is not None:
+                g_bcls = cs_
             if g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls):
                 # the usual training case (only the logits reach the loss): g_mean = g_logits W is formed inside act_bwd
                 g_pre, amax = act_bwd_proj(g_logits, w_cls, out, H, D, act)
@@ -1964,8 +1981,8 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
         g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
         cs = M1 = None
         if g_logits is not None:
+            cs = column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
-            cs = g_logits.sum(0)
             M1 = scores_bwd_w(g_logits, zx)                              # g_logits^T Zx (J, Kc)
             g_bcls = cs if has_bcls else None
         if g_y is None:                                   # the folded route (the training step): no (N, D) gradient exists

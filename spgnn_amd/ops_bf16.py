@@ -476,8 +476,8 @@ class _LinearClassifierBf16Fn(torch.autograd.Function):
         wc = w_cls.detach()
         g_x = g_w = g_b = g_wcls = g_bcls = cs = M1 = None
         if g_logits is not None:
+            cs = _ops.column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
-            cs = g_logits.sum(0)
             M1 = scores_bwd_w(g_logits, x)
             if ctx.needs_input_grad[3]:
                 g_wcls = torch.mm(M1, wf.t())
@@ -533,8 +533,8 @@ class _LinearMeanClassifierBf16Fn(torch.autograd.Function):
         g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
         cs = M1 = None
         if g_logits is not None:
+            cs = _ops.column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
-            cs = g_logits.sum(0)
             M1 = scores_bwd_w(g_logits, zx)
             g_bcls = cs if has_bcls else None
         if g_y is None:                                   # folded route: g_Zx as bf16 rows straight from the fp32 logit gradient

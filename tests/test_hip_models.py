@@ -417,6 +417,27 @@ def test_masked_ce_draws_its_own_mask_and_sums_in_the_last_workgroup():
     lg2 = logits.clone().requires_grad_(True)
     ops.masked_ce_sums(lg2, y, host, p, w)[0].backward()
     assert torch.equal(lg.grad, lg2.grad)
+    # ... and, for the node that produced the logits, carries its own column sums (the classifier bias' gradient), formed by the
+    # kernel's last workgroup in block order
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g_):
+            seen["attr"] = getattr(g_, "_spgnn_colsum", None)
+            seen["cs"] = ops.column_sums(g_)
+            return g_
+
+    lg3 = logits.clone().requires_grad_(True)
+    n3 = ops.masked_ce_sums(Probe.apply(lg3), y, host, p, w, unit_grad=True)[0]
+    torch.autograd.backward(n3, torch.ones((), device="cuda"))
+    assert seen["attr"] is not None and seen["cs"] is seen["attr"]
+    assert rel_err(seen["cs"], lg2.grad.double().sum(0)) < 1e-6
+    assert ops.column_sums(lg2.grad).shape == (C,) and getattr(lg2.grad, "_spgnn_colsum", None) is None
 
 
 # ---- the N > 1 step as HIP-graph replays: two processes on the one GPU, gloo carrying the CUDA tensors ----------------
