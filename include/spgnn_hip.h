@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 39
+#define SPGNN_ABI_VERSION 40
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -294,6 +294,7 @@ int spgnn_fold_scores_bwd(const float* W, int64_t w_stride, const float* attn_l,
  */
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp,
                      float* s, int64_t s_stride, float* absmax /* nullable: scale block taking max |x| */,
+                     const float* bias /* nullable, J floats: s += bias (a skinny Linear's bias, e.g. the classifier's) */,
                      int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride,
                        float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
@@ -681,7 +682,8 @@ int spgnn_gat_agg_bwd_src_bf16(const int32_t* out_indptr, const int32_t* out_ind
                                float p_drop, uint64_t seed, const uint64_t* seed_offset,
                                spgnn_stream_t stream);
 int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp,
-                          float* s, int64_t s_stride, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+                          float* s, int64_t s_stride, const float* bias /* nullable */, int64_t N, int32_t K, int32_t J,
+                          spgnn_stream_t stream);
 
 /* spgnn_scores_bwd_x writing (or accumulating into) bf16 rows g_x; the row padding up to a multiple of 4 is written as zeros. */
 int spgnn_scores_bwd_x_bf16(const float* g_s, int64_t g_s_stride, const float* w, int32_t Kp, uint16_t* g_x, int64_t g_x_stride,

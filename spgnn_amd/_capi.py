@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -85,7 +85,7 @@ SIGNATURES = {
                           _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp],
     "spgnn_gat_bwd_src": [_i32p, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _f32p, _f32p,
                           _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
-    "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
+    "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
     "spgnn_scores_bwd_w": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
     "spgnn_scores_bwd_x": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _i32, _i64, _i32, _i32, _vp],
@@ -155,7 +155,7 @@ SIGNATURES = {
                                    _i64, _i64, _i32, _i32, _f32, _f32, _u64, _vp, _vp],
     "spgnn_gat_agg_bwd_src_bf16": [_i32p, _i32p, _i32p, _f32p, _f32p, _vp, _i64, _i32, _i32, _f32p, _f32p, _i64, _vp, _i64,
                                    _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
-    "spgnn_scores_fwd_bf16": [_vp, _i64, _f32p, _i32, _f32p, _i64, _i64, _i32, _i32, _vp],
+    "spgnn_scores_fwd_bf16": [_vp, _i64, _f32p, _i32, _f32p, _i64, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_scores_bwd_x_bf16": [_f32p, _i64, _f32p, _i32, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
     "spgnn_scores_bwd_w_bf16": [_f32p, _i64, _vp, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
     "spgnn_cat_dropout_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _vp],

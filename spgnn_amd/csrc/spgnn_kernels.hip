@@ -1861,7 +1861,7 @@ template <typename ST, int NG, int RG>
 __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
-                                                          float* __restrict__ absmax) {
+                                                          float* __restrict__ absmax, const float* __restrict__ bias) {
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = wave * (16 * RG);
@@ -1976,10 +1976,11 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (r + 16 * g < J) {
+        const float bcol = bias ? bias[r + 16 * g] : 0.f;           // optional S += bias[column] (a skinny Linear's bias)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t orow = row0 + 16 * t + q * 4 + j;
-          if (orow < N) S[orow * lds_ + r + 16 * g] = acc[t][g][j];
+          if (orow < N) S[orow * lds_ + r + 16 * g] = acc[t][g][j] + bcol;
         }
       }
     }
@@ -3225,12 +3226,12 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
 constexpr int kScoresRG = 2;      // row groups of 16 per wave in the wide form
 template <typename ST>
 static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride, int64_t N,
-                              int32_t K, int32_t J, float* absmax, hipStream_t st) {
+                              int32_t K, int32_t J, float* absmax, const float* bias, hipStream_t st) {
   const bool wide = kScoresRG > 1 && J > 16 && N >= 16 * kScoresRG * 1024;   // >= 1024 waves of the wide form
   const int rg = wide ? kScoresRG : 1;
   const int64_t waves = (N + 16 * rg - 1) / (16 * rg);
   const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
-#define X(NG_, RG_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax)
+#define X(NG_, RG_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, bias)
   if (J <= 16) X(1, 1);
   else if (wide) X(2, kScoresRG);
   else X(2, 1);
@@ -3240,24 +3241,24 @@ static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int
 extern "C" {
 
 int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
-                     float* absmax, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+                     float* absmax, const float* bias, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || J <= 0 || J > 32 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd: bad N/K/Kp/J");
   if (N == 0) return SPGNN_OK;
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || !aligned16(x) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd: x rows and w must be 16-byte aligned (stride % 4 == 0)");
-  scores_fwd_launch<float>(x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, (hipStream_t)stream);
+  scores_fwd_launch<float>(x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, bias, (hipStream_t)stream);
   return check_launch("spgnn_scores_fwd");
 }
 
 int spgnn_scores_fwd_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp, float* s, int64_t s_stride,
-                          int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+                          const float* bias, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || J <= 0 || J > 32 || Kp < K || (Kp & 15)) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_fwd_bf16: bad N/K/Kp/J");
   if (N == 0) return SPGNN_OK;
   if (!x || !w || !s) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_fwd_bf16: null pointer");
   if (x_stride < K || s_stride < J || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 7) || !aligned16(w))
     return fail(SPGNN_ERR_STRIDE, "spgnn_scores_fwd_bf16: x rows must be 8-byte aligned (stride % 4 == 0), w 16-byte aligned");
-  scores_fwd_launch<bf16s>(reinterpret_cast<const bf16s*>(x), x_stride, w, Kp, s, s_stride, N, K, J, nullptr, (hipStream_t)stream);
+  scores_fwd_launch<bf16s>(reinterpret_cast<const bf16s*>(x), x_stride, w, Kp, s, s_stride, N, K, J, nullptr, bias, (hipStream_t)stream);
   return check_launch("spgnn_scores_fwd_bf16");
 }
 

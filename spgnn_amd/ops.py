@@ -425,7 +425,7 @@ def _padded_rows(w: torch.Tensor, Kp: int) -> torch.Tensor:
     return torch.nn.functional.pad(w, (0, Kp - w.shape[1])).contiguous()
 
 
-def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
+def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False, bias: Optional[torch.Tensor] = None):
     """S = x @ w_lr^T (N, J), J = 2H: the MFMA streaming kernel when the rows of x are 16-byte aligned and
     J <= 16, rocBLAS otherwise.  ``want_scale``: also return the split-GEMM scale of x — the kernel reads every
     element of x anyway, so its absmax costs nothing extra."""
@@ -433,14 +433,17 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, want_scale: bool = False):
     J = w_lr.shape[0]
     if not (_rows_aligned(x) and J <= 32) or N == 0:
         s = torch.mm(x, w_lr.t())
+        if bias is not None:
+            s += bias
         return (s, pow2_scale(x) if N > 0 else None) if want_scale else s
     Kp = _pad16(K)
     w_p = _padded_rows(w_lr, Kp)
     s = torch.empty((N, J), dtype=torch.float32, device=x.device)
     part = new_scale_block(x.device) if want_scale else None
+    bias_c = None if bias is None else bias.detach().contiguous()          # (J,) added by the kernel: no launch of its own
     with torch.cuda.device(x.device), _timed("scores_fwd", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_fwd(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
-                                                  _ptr(part), N, K, J, _stream(x)), "spgnn_scores_fwd")
+                                                  _ptr(part), _ptr(bias_c), N, K, J, _stream(x)), "spgnn_scores_fwd")
     return (s, part) if want_scale else s
 
 
@@ -512,9 +515,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = _rowmajor(x)
-        y = scores_fwd(x, weight)
-        if bias is not None:
-            y = y + bias
+        y = scores_fwd(x, weight, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -820,12 +821,10 @@ class _LinearClassifierFn(torch.autograd.Function):
             y = gemm_nt(x, w, sx, sw, bias=bias)
         wc = w_cls.detach()
         P = torch.mm(wc, w.detach())
-        logits = scores_fwd(x, P)
         c0 = b_cls
         if bias is not None:
             c0 = torch.mv(wc, bias.detach()) if c0 is None else torch.addmv(c0.detach(), wc, bias.detach())
-        if c0 is not None:
-            logits += c0
+        logits = scores_fwd(x, P, bias=c0)
         ctx.has_bias, ctx.has_bcls = bias is not None, b_cls is not None
         ctx.save_for_backward(x, w, sx, sw, P, w_cls, bias)
         return y, logits
@@ -1720,9 +1719,7 @@ class _GATAggFirstFn(torch.autograd.Function):
         has_cls = w_cls is not None and mean
         logits = None
         if has_cls:
-            logits = scores_fwd(rst, w_cls)
-            if b_cls is not None:
-                logits = logits + b_cls
+            logits = scores_fwd(rst, w_cls, bias=b_cls)
         ctx.has_cls, ctx.has_cls_bias = has_cls, has_cls and b_cls is not None
         ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw,
                               rst if has_cls else None, w_cls if has_cls else None)
@@ -1965,8 +1962,7 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
         w_comb, blk, _, b_mean, P, c0 = linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D)
         sx = operand_scale(zx)
         y = gemm_nt(zx, w_comb[:, :Kc], sx, blk, bias=b_mean)
-        logits = scores_fwd(zx, P[:, :Kc])
-        logits += c0
+        logits = scores_fwd(zx, P[:, :Kc], bias=c0)
         ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
         ctx.save_for_backward(zx, w_comb, sx, blk, P, w_cls, b_mean)
         return y, logits

@@ -309,7 +309,7 @@ def gat_layer(csc: DeviceCSC, x, w_fc, w_res, attn_l, attn_r, bias, H: int, D: i
 # --------------------------------------------------------------------------------------------
 # GAT output layer without activation, heads averaged: one product on [z_0 | .. | z_{H-1} | x]  (ops._GATAggregateFn)
 # --------------------------------------------------------------------------------------------
-def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor) -> torch.Tensor:
+def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """S = x @ w_lr^T (N, J) fp32, x bf16 rows, w_lr (J, K) fp32 (the attention vectors folded through W_fc)."""
     N, K = x.shape
     J = w_lr.shape[0]
@@ -318,7 +318,8 @@ def scores_fwd(x: torch.Tensor, w_lr: torch.Tensor) -> torch.Tensor:
     s = torch.empty((N, J), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("scores_fwd_bf16", (N, K, J)):
         _capi.check(_capi.load().spgnn_scores_fwd_bf16(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, s.data_ptr(), s.stride(0),
-                                                       N, K, J, _stream(x)), "spgnn_scores_fwd_bf16")
+                                                       _ptr(None if bias is None else bias.detach().contiguous()), N, K, J, _stream(x)),
+                    "spgnn_scores_fwd_bf16")
     return s
 
 
@@ -517,8 +518,7 @@ class _LinearMeanClassifierBf16Fn(torch.autograd.Function):
         Kc = zx.shape[1]
         w_comb, _, w_bf, b_mean, P, c0 = ops.linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D, bf16=True)
         y = gemm_nt(zx, w_bf[:, :Kc], out_f32=True, bias=b_mean)
-        logits = scores_fwd(zx, P[:, :Kc])
-        logits += c0
+        logits = scores_fwd(zx, P[:, :Kc], bias=c0)
         ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
         ctx.save_for_backward(zx, w_comb, w_bf, P, w_cls, b_mean)
         return y, logits

@@ -506,6 +506,8 @@ def test_score_projection_kernels(K, J):
     assert rel_err(s, x.double() @ w.double().t()) < 2e-6
     s2, scale = ops.scores_fwd(x, w, want_scale=True)      # the absmax the kernel collects on the way (K >= 512: four waves per row group)
     assert torch.equal(s2, s) and ops.scale_value(scale) == float(ops.pow2_scale(x))
+    bias = torch.randn(J, device="cuda")                   # the optional bias rides in the store: s + bias exactly
+    assert torch.equal(ops.scores_fwd(x, w, bias=bias), s + bias)
     gs = torch.randn(N, J, device="cuda")
     assert rel_err(ops.scores_bwd_w(gs, x), gs.double().t() @ x.double()) < 2e-6
     gbuf = torch.randn(N, (K + 3) // 4 * 4, device="cuda")
@@ -533,6 +535,9 @@ def test_score_projection_forward_two_row_groups_per_wave(K, J):
     from spgnn_amd import ops_bf16
     xb = ops_bf16.cast_rows(x.contiguous())
     assert rel_err(ops_bf16.scores_fwd(xb, w), xb.double() @ w.double().t()) < 2e-6
+    bias = torch.randn(J, device="cuda")
+    assert torch.equal(ops.scores_fwd(x, w, bias=bias), s + bias)
+    assert torch.equal(ops_bf16.scores_fwd(xb, w, bias=bias), ops_bf16.scores_fwd(xb, w) + bias)
 
 
 @pytest.mark.parametrize("K,J", [(1024, 22), (100, 17), (64, 32), (1024, 6)])
