@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 40
+#define SPGNN_ABI_VERSION 41
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -879,12 +879,15 @@ int spgnn_linear_mean_fold_fwd(const float* w_fc, int64_t w_fc_stride, const flo
                                float* b_mean, float* P, int64_t P_stride, float* c0, float* absmax_out,
                                float* workspace /* spgnn_linear_mean_fold_workspace floats */,
                                uint32_t* tickets /* Kp / 32 + 1 words, zero before the first call; re-armed by the kernel */,
+                               int32_t x_block /* 1: Kc = (H + 1) F as above; 0: Kc = H F, no x block (w_res must be null) - with H = 1
+                                                  a plain Linear + classifier (GraphConv's linear output layer); with H = 1 and
+                                                  x_block = 1, [W_fc | W_res] is SAGEConv's [fc_neigh | fc_self] on [neigh | h] */,
                                spgnn_stream_t stream);
 int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F);
 int spgnn_linear_mean_fold_bwd(const float* M1, int64_t M1_stride, const float* cs, const float* w_cls, int64_t w_cls_stride,
                                const float* w_comb, int64_t w_comb_stride, const float* b_mean, int32_t H, int32_t D, int32_t F,
                                int32_t J, float* g_w_fc, int64_t g_w_fc_stride, float* g_w_res, int64_t g_w_res_stride, float* g_bias,
-                               float* g_w_cls, int64_t g_w_cls_stride, spgnn_stream_t stream);
+                               float* g_w_cls, int64_t g_w_cls_stride, int32_t x_block, spgnn_stream_t stream);
 
 /* Up to 8 of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two attention-vector
  * gradients come out of four spgnn_gemm_tn / spgnn_scores_bwd_w calls whose partial sums were four more launches).  `jobs`

@@ -2016,10 +2016,11 @@ int spgnn_linear_mean_fold_fwd(const float* w_fc, int64_t w_fc_stride, const flo
                                const float* w_cls, int64_t w_cls_stride, const float* b_cls, int32_t H, int32_t D, int32_t F, int32_t J,
                                float* w_comb, int64_t w_comb_stride, uint16_t* w_comb_bf16, int64_t w_comb_bf16_stride,
                                float* b_mean, float* P, int64_t P_stride, float* c0, float* absmax_out, float* workspace,
-                               uint32_t* tickets, spgnn_stream_t stream) {
-  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+                               uint32_t* tickets, int32_t x_block, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ || (x_block != 0 && x_block != 1) || (!x_block && w_res))
+    return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (!w_fc || !w_cls || !w_comb || !P || !c0 || !workspace || !tickets) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  const int64_t Kc = (int64_t)(H + 1) * F;
+  const int64_t Kc = (int64_t)(H + x_block) * F;
   const int64_t Kp = (Kc + 15) / 16 * 16;                   // every image is written (zero padded) up to a multiple of 16 columns
   if (Kp > INT32_MAX || w_fc_stride < F || (w_res && w_res_stride < F) || w_cls_stride < D || w_comb_stride < Kp || P_stride < Kp ||
       (w_comb_bf16 && w_comb_bf16_stride < Kp))
@@ -2035,7 +2036,7 @@ int spgnn_linear_mean_fold_fwd(const float* w_fc, int64_t w_fc_stride, const flo
   return spgnn_detail::check_launch("spgnn_linear_mean_fold_fwd");
 }
 
-int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F) {       // floats of `workspace`; `tickets`: one uint32 per 32 columns of Kp, zero before the first call
+int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F) {       // floats of `workspace` (either x_block); `tickets`: one uint32 per 32 columns of Kp, zero before the first call
   const int64_t Kp = (((int64_t)(H + 1) * F) + 15) / 16 * 16;
   return (Kp / 32 + 1) * gemm::kFoldQ * gemm::kFoldJ * 32;
 }
@@ -2043,10 +2044,11 @@ int64_t spgnn_linear_mean_fold_workspace(int32_t H, int32_t F) {       // floats
 int spgnn_linear_mean_fold_bwd(const float* M1, int64_t M1_stride, const float* cs, const float* w_cls, int64_t w_cls_stride,
                                const float* w_comb, int64_t w_comb_stride, const float* b_mean, int32_t H, int32_t D, int32_t F,
                                int32_t J, float* g_w_fc, int64_t g_w_fc_stride, float* g_w_res, int64_t g_w_res_stride, float* g_bias,
-                               float* g_w_cls, int64_t g_w_cls_stride, spgnn_stream_t stream) {
-  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+                               float* g_w_cls, int64_t g_w_cls_stride, int32_t x_block, spgnn_stream_t stream) {
+  if (H <= 0 || D <= 0 || F <= 0 || J <= 0 || J > gemm::kFoldJ || (x_block != 0 && x_block != 1) || (!x_block && g_w_res))
+    return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (!M1 || !cs || !w_cls || !w_comb || !g_w_fc) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  const int64_t Kc = (int64_t)(H + 1) * F;
+  const int64_t Kc = (int64_t)(H + x_block) * F;
   if (M1_stride < Kc || w_cls_stride < D || w_comb_stride < Kc || g_w_fc_stride < F || (g_w_res && g_w_res_stride < F) ||
       (g_w_cls && g_w_cls_stride < D))
     return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);

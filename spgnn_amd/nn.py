@@ -376,6 +376,10 @@ class GraphConv(nn.Module):
                         and ops.linear_classifier_supported(rst, weight.t(), classifier.weight)):
                     # a linear output layer: the classifier folds through the product - no pass over the (N, out) result for
                     # the logits and no (N, out) gradient in the backward pass
+                    if ops.FUSE_LINEAR_MEAN_FOLD and rst.shape[1] % 4 == 0:
+                        # ... with P = Wc W, c0 and the parameters' gradients from the one-head, no-x-block case of the fold kernels
+                        return ops._LinearMeanClassifierFn.apply(rst, weight.t(), None, self.bias, classifier.weight, classifier.bias,
+                                                                 1, self._out_feats, False)
                     return ops._LinearClassifierFn.apply(rst, weight.t(), self.bias, classifier.weight, classifier.bias)
                 if fuse:
                     return ops.linear(rst, weight.t(), self.bias, act)
@@ -547,13 +551,18 @@ class SAGEConv(nn.Module):
                 # Output wider than both inputs together (64 -> 1024): ONE product on [neigh | h] with [W_neigh | W_self]
                 # (the addend form writes, re-reads and re-writes the (N, out) result: 0.94 GB against 0.35 GB here)
                 xc = ops.cat_dropout((neigh, h), 0.0, 0)
-                wc = torch.cat([self.fc_neigh.weight, self.fc_self.weight], dim=1)
                 bs = [b for b in (self.fc_neigh.bias, self.fc_self.bias) if b is not None]
                 bc = (bs[0] + bs[1] if len(bs) == 2 else bs[0]) if bs else None
+                if (classifier is not None and act == ops.ACT_NONE and self.norm is None and classifier.weight.shape[0] <= 32
+                        and classifier.weight.shape[1] == self._out_feats and ops.FUSE_LINEAR_MEAN_FOLD):
+                    # linear layer: the classifier folds through the product - no pass over the (N, out) result for the logits,
+                    # no (N, out) gradient in the backward pass; [W_neigh | W_self], P, c0 and the way back to the parameters'
+                    # gradients are the one-head case of spgnn_linear_mean_fold_fwd / _bwd (two launches)
+                    return ops._LinearMeanClassifierFn.apply(xc, self.fc_neigh.weight, self.fc_self.weight, bc, classifier.weight,
+                                                             classifier.bias, 1, self._out_feats, True)
+                wc = torch.cat([self.fc_neigh.weight, self.fc_self.weight], dim=1)
                 if (classifier is not None and act == ops.ACT_NONE and self.norm is None
                         and ops.linear_classifier_supported(xc, wc, classifier.weight)):
-                    # linear layer: the classifier folds through the product (ops._LinearClassifierFn) - no pass over the
-                    # (N, out) result for the logits, no (N, out) gradient in the backward pass
                     return ops._LinearClassifierFn.apply(xc, wc, bc, classifier.weight, classifier.bias)
                 rst = ops.linear(xc, wc, bc, act)
                 return rst if self.norm is None else self.norm(rst)

@@ -1883,11 +1883,11 @@ _FOLD_WS: dict = {}
 FUSE_LINEAR_MEAN_FOLD = True     # the weight-space half of gat_layer_linear_mean + classifier as two launches (spgnn_linear_mean_fold_*)
 
 
-def linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H: int, D: int, bf16: bool = False):
+def linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H: int, D: int, bf16: bool = False, x_block: bool = True):
     """One spgnn_linear_mean_fold_fwd call -> (w_comb (D, Kp) fp32, its scale block, w_comb as bf16 rows or None, b_mean or
     None, P (J, Kp), c0 (J,)); Kc = (H + 1) F real columns, every image zero padded to Kp = Kc rounded up to 16."""
     F_, J = w_fc.shape[1], w_cls.shape[0]
-    Kp = _pad16((H + 1) * F_)
+    Kp = _pad16((H + int(x_block)) * F_)
     dev = w_fc.device
     w_comb = torch.empty((D, Kp), dtype=torch.float32, device=dev)
     w_bf = torch.empty((D, Kp), dtype=torch.bfloat16, device=dev) if bf16 else None
@@ -1907,12 +1907,12 @@ def linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H: int, D: int, bf
         _capi.check(_capi.load().spgnn_linear_mean_fold_fwd(wf.data_ptr(), wf.stride(0), _ptr(wr), wr.stride(0) if wr is not None else 0,
                                                             _ptr(bias), wc.data_ptr(), wc.stride(0), _ptr(b_cls), H, D, F_, J,
                                                             w_comb.data_ptr(), Kp, _ptr(w_bf), Kp, _ptr(b_mean), P.data_ptr(), Kp,
-                                                            c0.data_ptr(), _ptr(blk), ws[0].data_ptr(), ws[1].data_ptr(), _stream(w_comb)),
-                    "spgnn_linear_mean_fold_fwd")
+                                                            c0.data_ptr(), _ptr(blk), ws[0].data_ptr(), ws[1].data_ptr(), int(x_block),
+                                                            _stream(w_comb)), "spgnn_linear_mean_fold_fwd")
     return w_comb, blk, w_bf, b_mean, P, c0
 
 
-def linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H: int, D: int, F_: int, has_res: bool, has_bias: bool):
+def linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H: int, D: int, F_: int, has_res: bool, has_bias: bool, x_block: bool = True):
     """One spgnn_linear_mean_fold_bwd call -> (g_w_fc, g_w_res or None, g_bias or None, g_w_cls)."""
     dev = M1.device
     J = w_cls.shape[0]
@@ -1927,7 +1927,7 @@ def linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H: int, D: int, F_: in
         _capi.check(_capi.load().spgnn_linear_mean_fold_bwd(m1.data_ptr(), m1.stride(0), cs.data_ptr(), wc.data_ptr(), wc.stride(0),
                                                             w_comb.data_ptr(), w_comb.stride(0), _ptr(b_mean), H, D, F_, J,
                                                             g_fc.data_ptr(), F_, _ptr(g_res), F_, _ptr(g_bias), g_wc.data_ptr(), D,
-                                                            _stream(m1)), "spgnn_linear_mean_fold_bwd")
+                                                            int(x_block), _stream(m1)), "spgnn_linear_mean_fold_bwd")
     return g_fc, g_res, g_bias, g_wc
 
 
@@ -1953,13 +1953,20 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
     node - one launch each (spgnn_linear_mean_fold_fwd / _bwd) instead of ~28 tiny torch / rocBLAS launches per step."""
 
     @staticmethod
-    def forward(ctx, zx, w_fc, w_res, bias, w_cls, b_cls, H, D):
+    def forward(ctx, zx, w_fc, w_res, bias, w_cls, b_cls, H, D, x_block=True):
+        """``x_block`` False (with H = 1, w_res None): a plain Linear + folded classifier, W_comb = W_fc.  ``w_fc`` may be the
+        transposed view of a prepared (F, D) parameter (GraphConv): its prepared transpose image is read then."""
         ctx.set_materialize_grads(False)
         zx = _rowmajor(zx)
         if not _rows_aligned(zx):
             zx = cat_padded((zx,))
         Kc = zx.shape[1]
-        w_comb, blk, _, b_mean, P, c0 = linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D)
+        if w_fc.stride(1) != 1:
+            prep = _prepared_linear_operands(w_fc, w_fc.shape[0], w_fc.shape[1])
+            w_fc = prep[0] if prep is not None else w_fc.contiguous()
+        assert Kc == (H + int(x_block)) * w_fc.shape[1]
+        ctx.x_block = bool(x_block)
+        w_comb, blk, _, b_mean, P, c0 = linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D, x_block=x_block)
         sx = operand_scale(zx)
         y = gemm_nt(zx, w_comb[:, :Kc], sx, blk, bias=b_mean)
         logits = scores_fwd(zx, P[:, :Kc], bias=c0)
@@ -1970,7 +1977,7 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y, g_logits):
         if g_y is None and g_logits is None:
-            return (None,) * 8
+            return (None,) * 9
         zx, w_comb, sx, blk, P, w_cls, b_mean = ctx.saved_tensors
         H, D, F_, Kc, has_res, has_bias, has_bcls = ctx.cfg
         N = zx.shape[0]
@@ -1985,8 +1992,9 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 g_zx = torch.empty((N, (Kc + 3) // 4 * 4), dtype=torch.float32, device=zx.device)[:, :Kc]
                 scores_bwd_x_(g_zx, g_logits, P[:, :Kc], accumulate=False)
-            g_fc, g_res, g_bias, g_wcls = linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H, D, F_, has_res, has_bias)
-            return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+            g_fc, g_res, g_bias, g_wcls = linear_mean_fold_grads(M1, cs, w_cls, w_comb, b_mean, H, D, F_, has_res, has_bias,
+                                                                 x_block=ctx.x_block)
+            return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None, None
         g = _rowmajor(g_y)
         if g_logits is not None:
             g = g.clone() if g.data_ptr() == g_y.data_ptr() else g
@@ -1999,7 +2007,7 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
         elif not _rows_aligned(g):
             g = cat_padded((g,))
         g_zx, g_fc, g_res, g_bias = _linear_mean_general_grads(g, zx, pow2_scale(g), sx, w_comb, Kc, H, D, F_, has_res, has_bias)
-        return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None
+        return g_zx, g_fc, g_res, g_bias, g_wcls, g_bcls, None, None, None
 
 
 def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: int, slope: float, p_drop: float = 0.0,
