@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 41
+#define SPGNN_ABI_VERSION 42
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -485,6 +485,12 @@ typedef struct spgnn_gemm_nt_problem {
   float* absmax_out;                               /* nullable scale block: max |C| is folded into its slots, so the result
                                                       can be the next product's operand without an absmax pass over it */
   int32_t upd_j; int32_t activation; int32_t score_cols; int32_t reserved;
+  /* optional feature dropout of the stored result, C = dropout(act(...), drop_p), under spgnn_cat_dropout's mask for an N-wide
+   * row (counter row * N + column; seed + *drop_seed_offset when the pointer is set): the reference's GIN MLP
+   * (models.py:236-246, Linear -> Dropout -> LeakyReLU; the two commute for ReLU / LeakyReLU) without a pass over the
+   * product.  drop_p = 0: none.  Needs N % 4 == 0.  absmax_out sees the dropped values.  spgnn_act_bwd_dropout undoes
+   * both from the stored result alone (ReLU / LeakyReLU: the derivative depends on the sign only). */
+  const uint64_t* drop_seed_offset; uint64_t drop_seed; float drop_p; float reserved2;
 } spgnn_gemm_nt_problem;
 typedef struct spgnn_gemm_tn_problem {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t split_stride; int64_t R; int64_t M; int64_t N;

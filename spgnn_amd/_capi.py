@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -24,7 +24,8 @@ class GemmNtProblem(C.Structure):         # spgnn_gemm_nt_problem
     _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("M", _i64), ("N", _i64), ("K", _i64),
                 ("scale_a", _vp), ("scale_b", _vp), ("upd_u", _vp), ("upd_u_stride", _i64), ("upd_v", _vp), ("upd_v_stride", _i64),
                 ("bias", _vp), ("score_l", _vp), ("score_r", _vp), ("score_out", _vp), ("addend", _vp), ("addend_stride", _i64),
-                ("absmax_out", _vp), ("upd_j", _i32), ("activation", _i32), ("score_cols", _i32), ("reserved", _i32)]
+                ("absmax_out", _vp), ("upd_j", _i32), ("activation", _i32), ("score_cols", _i32), ("reserved", _i32),
+                ("drop_seed_offset", _vp), ("drop_seed", _u64), ("drop_p", _f32), ("reserved2", _f32)]
 
 
 class GemmTnProblem(C.Structure):         # spgnn_gemm_tn_problem

@@ -58,6 +58,9 @@ struct Args {
   // optional scale block (spgnn_internal.h): max |stored value| of every tile is folded into its slots - the result's GEMM
   // operand scale for the next product, without a pass over it
   float* absmax;
+  // optional feature dropout of the stored result (after bias / activation): spgnn_cat_dropout's mask over an N-wide row,
+  // counter row * N + column of the float4 group; drop_p == 0: none.  N % 4 == 0 (host check).
+  float drop_p, drop_inv; uint64_t drop_seed; const uint64_t* drop_seed_off;
 };
 // B may arrive PRE-SPLIT (spgnn_presplit): every group of four fp32 values replaced, in place, by its packed fp16 pairs
 // [hi01, hi23, lo01, lo23] of s*x (the 16 bytes split4_pk would produce), rows zero padded to a multiple of four columns.
@@ -216,7 +219,8 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
-template <class ARGS, int MI>
+template <bool DROP, class ARGS, int MI>   // DROP: the dropout fields of ARGS are honoured (single-product kernels only: the
+                                           // pair kernels hold two argument sets in SGPRs and have none to spare)
 __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&acc)[MI][2], _Float16* smem, int row0, int col0,
                                                        int wave, int lane, int wm, int wn, float alpha) {
   const int fr = lane & 31, fh = lane >> 5;
@@ -244,6 +248,12 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
     wv[jj] = (use_j && small_j && jj < a.J) ? *reinterpret_cast<const float4*>(a.V + (int64_t)jj * a.ldv + col)
                                             : make_float4(0.f, 0.f, 0.f, 0.f);
   float amx = 0.f;                                       // max |stored value| of this lane (a.absmax)
+  bool use_drop = false;                                 // block-uniform
+  uint64_t dseed = 0; float dp = 0.f, dinv = 1.f;
+  if constexpr (DROP) {
+    use_drop = a.drop_p > 0.f;
+    if (use_drop) { dseed = a.drop_seed + (a.drop_seed_off ? a.drop_seed_off[0] : 0); dp = a.drop_p; dinv = a.drop_inv; }
+  }
   // one 32-row half of the wave's tile; called with a literal i per half (a loop over i is not unrolled once its body has
   // two large paths, and acc[i] with a run-time i puts the accumulators in scratch memory: 7x slower)
   auto do_half = [&](const int i) __attribute__((always_inline)) {
@@ -322,6 +332,14 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
           vv[it].z = vv[it].z > 0.f ? vv[it].z : 0.01f * vv[it].z; vv[it].w = vv[it].w > 0.f ? vv[it].w : 0.01f * vv[it].w;
         }
       }
+      if (use_drop) {
+        const int64_t r0_ = row0 + wm * (32 * MI) + i * 32 + r_in;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const float4 k = spgnn_detail::feat_keep4(dseed, (r0_ + it * 4) * a.N + col, dp, dinv);
+          vv[it].x *= k.x; vv[it].y *= k.y; vv[it].z *= k.z; vv[it].w *= k.w;
+        }
+      }
       if (a.mean_out) {
         const int64_t r0_ = row0 + wm * (32 * MI) + i * 32 + r_in;
         float4 oo[8];
@@ -398,6 +416,10 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
           v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
           v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
         }
+        if (use_drop) {
+          const float4 k = spgnn_detail::feat_keep4(dseed, (int64_t)row * a.N + col, dp, dinv);
+          v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
+        }
         if (a.mean_out) {
           const float vq[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -445,7 +467,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   }
 }
 
-template <int WM, bool BPS>
+template <int WM, bool BPS, bool DROP>
 __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, const unsigned nb) {   // workgroup b of the nb this product owns
   constexpr int TBM = 64 * WM, NT = 128 * WM;
   constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
@@ -559,7 +581,7 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
   if (t < nk) SPGNN_STAGE(t, 0, ra1, rb1, 0)
 #undef SPGNN_STAGE
 
-  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
+  store_tile_through_lds<DROP>(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
 
 // Two independent products in ONE launch (spgnn_gemm_nt_pair): workgroups [0, nb0) run product 0, the rest product 1,
@@ -570,12 +592,12 @@ struct PairArgs { Args p[2]; unsigned nb0; };
 
 template <int WM, bool BPS>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
-  nt_v2_body<WM, BPS>(a, blockIdx.x, gridDim.x);
+  nt_v2_body<WM, BPS, true>(a, blockIdx.x, gridDim.x);
 }
 template <int WM, bool BPS>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(PairArgs pa) {
   const bool second = blockIdx.x >= pa.nb0;                 // block-uniform: the arguments are read from one half of the kernarg
-  nt_v2_body<WM, BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  nt_v2_body<WM, BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -587,7 +609,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(Pai
 // (B once, A for two of the four row tiles at a time) to stay inside 256 registers.  LDS: 2 stages x 4 images of
 // 256 rows x 80 bytes = 160 KB.
 // -------------------------------------------------------------------------------------------------
-template <bool BPS>
+template <bool BPS, bool DROP>
 __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, const unsigned nb) {
   constexpr int TB = 256;
   constexpr int IMG = TB * PITCH;                               // halves per image
@@ -741,16 +763,16 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
 #undef SPGNN_PUTB
 #undef SPGNN_RAW
 
-  store_tile_through_lds(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
+  store_tile_through_lds<DROP>(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
 template <bool BPS>
 __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
-  nt_v3_body<BPS>(a, blockIdx.x, gridDim.x);
+  nt_v3_body<BPS, true>(a, blockIdx.x, gridDim.x);
 }
 template <bool BPS>
 __global__ __launch_bounds__(512) void gemm_nt_pair_v3(PairArgs pa) {
   const bool second = blockIdx.x >= pa.nb0;
-  nt_v3_body<BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  nt_v3_body<BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // A phase-skewed form of this kernel (the two waves of every SIMD one phase apart - R: fragment reads + wait, M: twelve
@@ -1727,9 +1749,16 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
 }
 
 static int nt_plan_of(const spgnn_gemm_nt_problem* q, NtPlan* p) {
-  return gemm_nt_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->M, q->N, q->K, q->scale_a, q->scale_b, q->upd_u, q->upd_u_stride,
-                      q->upd_v, q->upd_v_stride, q->upd_j, q->bias, q->activation, q->score_l, q->score_r, q->score_out, q->score_cols,
-                      q->addend, q->addend_stride, nullptr, 0, q->absmax_out, 0, p);
+  if (!(q->drop_p >= 0.f && q->drop_p < 1.f) || (q->drop_p > 0.f && (q->N & 3)))
+    return spgnn_detail::fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_problem: drop_p outside [0, 1), or dropout with N % 4 != 0");
+  const int rc = gemm_nt_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->M, q->N, q->K, q->scale_a, q->scale_b, q->upd_u,
+                              q->upd_u_stride, q->upd_v, q->upd_v_stride, q->upd_j, q->bias, q->activation, q->score_l, q->score_r,
+                              q->score_out, q->score_cols, q->addend, q->addend_stride, nullptr, 0, q->absmax_out, 0, p);
+  if (rc == SPGNN_OK && q->drop_p > 0.f) {
+    p->a.drop_p = q->drop_p; p->a.drop_inv = 1.f / (1.f - q->drop_p);
+    p->a.drop_seed = q->drop_seed; p->a.drop_seed_off = q->drop_seed_offset;
+  }
+  return rc;
 }
 
 int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream) {
@@ -1745,6 +1774,8 @@ int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_p
                        spgnn_stream_t stream) {
   if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (first->drop_p > 0.f || second->drop_p > 0.f)                 // the pair kernels carry no dropout epilogue
+    return spgnn_detail::fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_pair: drop_p is a single-product option (spgnn_gemm_nt_problem_run)");
   NtPlan p0, p1;
   int rc = nt_plan_of(first, &p0);
   if (rc != SPGNN_OK) return rc;

@@ -1,6 +1,7 @@
 // Internal helpers shared by the translation units of libspgnn_hip.so (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace spgnn_detail {
 // record the message spgnn_last_error() returns (thread-local) and hand `code` back
@@ -47,5 +48,20 @@ __device__ __forceinline__ void slots_max(float* block, float m, unsigned idx) {
   // unconditional and result-free: a fire-and-forget atomic costs the wave ~5 us less than first reading the slot to skip it
   // (the read is a dependent memory round trip at the very end of the wave's life; measured on the three lspe kernels)
   atomicMax(w, __float_as_uint(m));
+}
+// Counter hash of the dropout masks (splitmix64 finaliser over seed + golden * (idx + 1)).
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// Feature-dropout keep factors of four neighbouring elements (spgnn_cat_dropout's mask: one 64-bit hash per group of four
+// columns, 16 bits per element, counter = row * total_width + column of the group's first element).
+__device__ __forceinline__ float4 feat_keep4(uint64_t seed, int64_t counter, float p, float inv_keep) {
+  const uint64_t z = mix64(seed, counter);
+  const unsigned thr = (unsigned)(p * 65536.f);
+  return make_float4(((unsigned)(z) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 16) & 0xFFFFu) >= thr ? inv_keep : 0.f,
+                     ((unsigned)(z >> 32) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 48) & 0xFFFFu) >= thr ? inv_keep : 0.f);
 }
 }  // namespace spgnn_detail

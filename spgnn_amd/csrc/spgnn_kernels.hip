@@ -3072,7 +3072,7 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
                        int32_t D, int32_t activation, spgnn_stream_t stream) {
   if (N < 0 || H <= 0 || H > 4 || D <= 0 || D % 4 || D > 1024 || J <= 0 || J > 32)
     return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_proj: bad N/H/D/J (H <= 4, D % 4 == 0, D <= 1024, J <= 32)");
-  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_RELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_proj: activation");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_proj: activation");
   if (N == 0) return SPGNN_OK;
   if (!g_s || !w || !g_pre || !absmax_partials || (activation != SPGNN_ACT_NONE && !out))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_proj: null pointer");

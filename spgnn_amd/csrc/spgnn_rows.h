@@ -163,20 +163,8 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p,
   return u >= p ? inv_keep : 0.f;
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, int64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-// Feature-dropout keep factors of four neighbouring elements (spgnn_cat_dropout's mask: one 64-bit hash per group of four
-// columns, 16 bits per element, counter = row * total_width + column of the group's first element).
-__device__ __forceinline__ float4 feat_keep4(uint64_t seed, int64_t counter, float p, float inv_keep) {
-  const uint64_t z = mix64(seed, counter);
-  const unsigned thr = (unsigned)(p * 65536.f);
-  return make_float4(((unsigned)(z) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 16) & 0xFFFFu) >= thr ? inv_keep : 0.f,
-                     ((unsigned)(z >> 32) & 0xFFFFu) >= thr ? inv_keep : 0.f, ((unsigned)(z >> 48) & 0xFFFFu) >= thr ? inv_keep : 0.f);
-}
+using spgnn_detail::mix64;          // the counter hash and the four-element feature-dropout mask live in spgnn_internal.h
+using spgnn_detail::feat_keep4;     // (the GEMM epilogue applies the same mask)
 
 // wave-uniform value -> SGPR (no-op when the template flag is off)
 template <bool ON> __device__ __forceinline__ int uni(int x) { return ON ? __builtin_amdgcn_readfirstlane(x) : x; }

@@ -250,12 +250,18 @@ class GIN(nn.Module):
         self.gin_layers = nn.ModuleList(
             [GINConv(_gin_mlp(dims[i], dims[i + 1]), "mean", learn_eps=True) for i in range(num_layers + 1)])
 
-    def forward(self, g):
+    def forward(self, g, classifier=None):
+        """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
+        last MLP's second product."""
         h = g.ndata["fvs"]
         with ops.prepared_weights(_linear_specs(self, h)):
-            for layer in self.gin_layers:
+            for layer in self.gin_layers[:-1]:
                 h = layer(g, h)
-        return F.normalize(h, p=2, dim=1) if self.norm else h
+            if classifier is not None and not self.norm:
+                return self.gin_layers[-1](g, h, classifier=classifier)
+            h = self.gin_layers[-1](g, h)
+        h = F.normalize(h, p=2, dim=1) if self.norm else h
+        return h if classifier is None else (h, classifier(h))
 
     def forward_batch(self, blocks, x):
         h = x
@@ -653,8 +659,8 @@ class GINNet(_GraphNetBase):
         set_trainable(self.gnn_lung_out, True)
 
     def forward(self, g):
-        n_embed = self.gin(g)
-        return self.gnn_out(n_embed), n_embed
+        n_embed, n_out = self.gin(g, classifier=self.gnn_out)
+        return n_out, n_embed
 
     def forward_batch(self, blocks, x):
         n_embed = self.gin.forward_batch(blocks, x)

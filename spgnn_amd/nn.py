@@ -412,39 +412,58 @@ def _hash_dropout(drop: nn.Dropout, x: torch.Tensor) -> torch.Tensor:
 FUSE_EPILOGUES = True     # bias / activation of GraphConv, the GIN MLP and SAGEConv inside the producing kernel's epilogue
 
 
-def _apply_fast_linear(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+def _apply_fast_sequence(mods, x: torch.Tensor) -> torch.Tensor:
+    """The modules of an ``nn.Sequential`` applied in order, see _apply_fast_linear."""
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if type(m) is nn.Linear and FUSE_EPILOGUES and x.is_cuda:
+            j = i + 1
+            drop = None
+            if j < len(mods) and type(mods[j]) is nn.Dropout:
+                drop, j = mods[j], j + 1
+            code = _act_code_dense(mods[j]) if j < len(mods) and isinstance(mods[j], (nn.LeakyReLU, nn.ReLU)) else None
+            if code is not None:
+                pd = float(drop.p) if (drop is not None and drop.training) else 0.0
+                if 0.0 < pd < 1.0 and ops.linear_drop_supported(x, m.weight):
+                    # dropout rides with the product: its mask in the epilogue, its backward and the activation's in one pass
+                    x = ops.linear(x, m.weight, m.bias, code, drop=(pd, _draw_seed()))
+                else:
+                    x = ops.linear(x, m.weight, m.bias, code)
+                    if drop is not None:
+                        x = _hash_dropout(drop, x)
+                i = j + 1
+                continue
+        x = _apply_fast_linear(m, x)
+        i += 1
+    return x
+
+
+def _apply_fast_linear(module: nn.Module, x: torch.Tensor, classifier: Optional[nn.Linear] = None):
     """``module(x)`` with every plain ``nn.Linear`` (also inside an ``nn.Sequential``, e.g. the reference's GIN MLP,
     models.py:236-246: Linear, Dropout, LeakyReLU, Linear, LeakyReLU) evaluated by ops.linear on the matrix-core GEMMs; any
     other module runs as it is.  An activation that follows a Linear - directly or behind a Dropout - goes into that
     product's epilogue: dropout multiplies by 0 or 1 / (1 - p) >= 0 and LeakyReLU / ReLU are positively homogeneous, so
-    ``act(dropout(y)) == dropout(act(y))`` (to the last bit but one: the two scalings swap)."""
+    ``act(dropout(y)) == dropout(act(y))`` (to the last bit but one: the two scalings swap).
+    ``classifier`` (a Linear with <= 32 outputs, the *Net's ``gnn_out``): returns ``(module(x), classifier(module(x)))``; when
+    the module ends in Linear + activation the classifier joins that product's autograd node (ops.linear_act_classifier)."""
+    if classifier is not None:
+        mods = list(module) if type(module) is nn.Sequential else [module]
+        k = len(mods) - 1
+        code = _act_code_dense(mods[k]) if k >= 1 and isinstance(mods[k], (nn.LeakyReLU, nn.ReLU)) else None
+        if (code is not None and type(mods[k - 1]) is nn.Linear and FUSE_EPILOGUES and x.is_cuda):
+            h = _apply_fast_sequence(mods[:k - 1], x)
+            last = mods[k - 1]
+            if ops.linear_act_classifier_supported(h, last.weight, classifier.weight):
+                return ops.linear_act_classifier(h, last.weight, last.bias, code, classifier.weight, classifier.bias)
+            h = ops.linear(h, last.weight, last.bias, code)
+            return h, classifier(h)
+        h = _apply_fast_linear(module, x)
+        return h, classifier(h)
     if type(module) is nn.Linear:
         return ops.linear(x, module.weight, module.bias)
     if type(module) is nn.Sequential:
-        mods = list(module)
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if type(m) is nn.Linear and FUSE_EPILOGUES and x.is_cuda:
-                j = i + 1
-                drop = None
-                if j < len(mods) and type(mods[j]) is nn.Dropout:
-                    drop, j = mods[j], j + 1
-                code = _act_code_dense(mods[j]) if j < len(mods) and isinstance(mods[j], (nn.LeakyReLU, nn.ReLU)) else None
-                if code is not None:
-                    pd = float(drop.p) if (drop is not None and drop.training) else 0.0
-                    if 0.0 < pd < 1.0 and ops.linear_drop_supported(x, m.weight):
-                        # dropout rides with the product's autograd node: its backward and the activation's are one pass
-                        x = ops.linear(x, m.weight, m.bias, code, drop=(pd, _draw_seed()))
-                    else:
-                        x = ops.linear(x, m.weight, m.bias, code)
-                        if drop is not None:
-                            x = _hash_dropout(drop, x)
-                    i = j + 1
-                    continue
-            x = _apply_fast_linear(m, x)
-            i += 1
-        return x
+        return _apply_fast_sequence(list(module), x)
     return module(x)
 
 
@@ -464,7 +483,9 @@ class GINConv(nn.Module):
         else:
             self.register_buffer("eps", torch.FloatTensor([init_eps]))
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None, classifier: Optional[nn.Linear] = None):
+        """``classifier`` (extension): the *Net's ``gnn_out``; returns ``(rst, classifier(rst))``, joined to the MLP's last
+        product when the layer has no activation of its own."""
         if edge_weight is not None:
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
@@ -473,11 +494,13 @@ class GINConv(nn.Module):
         else:
             w_dst = csc.degree_scale("in", -1.0) if self._aggregator_type == "mean" else None
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, None, w_dst, self.eps))     # (1+eps)*x fused into the SpMM
+        if classifier is not None and self.apply_func is not None and self.activation is None:
+            return _apply_fast_linear(self.apply_func, rst, classifier)
         if self.apply_func is not None:
             rst = _apply_fast_linear(self.apply_func, rst)
         if self.activation is not None:
             rst = self.activation(rst)
-        return rst
+        return rst if classifier is None else (rst, classifier(rst))
 
 
 class SAGEConv(nn.Module):

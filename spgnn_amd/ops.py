@@ -669,9 +669,15 @@ class _LinearFn(torch.autograd.Function):
     by-product of the operand stream."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, addend=None, drop=None):
+    def forward(ctx, x, weight, bias, act, addend=None, drop=None, w_cls=None, b_cls=None):
         """``drop`` = (p, seed): the result is dropout(act(...), p) under spgnn_cat_dropout's hash mask; the backward pass
-        then undoes dropout and activation in ONE pass (spgnn_act_bwd_dropout)."""
+        then undoes dropout and activation in ONE pass (spgnn_act_bwd_dropout).  For ReLU / LeakyReLU / no activation the mask
+        is applied by the product's own epilogue (the derivative needs the sign of the stored value only, so the undropped
+        result is never written); ELU / tanh keep both.
+        ``w_cls`` (J, C) / ``b_cls``: a skinny classifier on the result joins the node, outputs (y, logits) - when only the
+        logits carry a gradient the (N, C) gradient of y is formed, multiplied by act' and consumed in one pass
+        (spgnn_act_bwd_proj) instead of written by spgnn_scores_bwd_x and re-read by spgnn_act_bwd."""
+        ctx.set_materialize_grads(False)
         x = _rowmajor(x)
         if not _rows_aligned(x):
             x = cat_padded((x,))                                           # 16-byte rows for the GEMM operand
@@ -697,31 +703,74 @@ class _LinearFn(torch.autograd.Function):
             addend = _rowmajor(addend)
             assert addend.shape == (N, C) and _rows_aligned(addend)
             q.c.addend, q.c.addend_stride = addend.data_ptr(), addend.stride(0)
+        dropping = drop is not None and drop[0] > 0.0
+        assert not dropping or C % 4 == 0, "linear(drop=...): the output width must be a multiple of 4"
+        in_epilogue = dropping and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and blk is not None and EPILOGUE_DROPOUT
+        if in_epilogue:
+            q.c.drop_p, q.c.drop_seed, q.c.drop_seed_offset = float(drop[0]), int(drop[1]), _seed_off_ptr(x.device)
         import ctypes
         with torch.cuda.device(x.device), _timed("gemm_nt", (N, C, K)):
             _capi.check(_capi.load().spgnn_gemm_nt_problem_run(ctypes.byref(q.c), int(bps), _stream(x)), "spgnn_gemm_nt_problem_run")
         ctx.act, ctx.has_bias, ctx.has_addend, ctx.scale_block, ctx.drop = act, bias is not None, addend is not None, blk, None
-        if drop is not None and drop[0] > 0.0 and C % 4 == 0:
+        ctx.has_cls = w_cls is not None
+        if dropping:
+            assert w_cls is None
+            ctx.drop = (float(drop[0]), int(drop[1]))
+            if in_epilogue:                                               # y IS the dropped result
+                ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
+                return y
             yd = torch.empty_like(y)
             blk = new_scale_block(x.device)
             with torch.cuda.device(x.device):
                 _capi.check(_capi.load().spgnn_cat_dropout(y.data_ptr(), y.stride(0), yd.data_ptr(), yd.stride(0), N, C, 0, C, float(drop[0]),
                                                            int(drop[1]), _seed_off_ptr(x.device), 0, blk.data_ptr(), _stream(x)),
                             "spgnn_cat_dropout")
-            ctx.drop, ctx.scale_block = (float(drop[0]), int(drop[1])), blk
+            ctx.scale_block = blk
             ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
             return yd
-        assert drop is None or drop[0] == 0.0, "linear(drop=...): the output width must be a multiple of 4"
+        if w_cls is not None:
+            logits = scores_fwd(y, w_cls.detach(), bias=b_cls.detach() if b_cls is not None else None)
+            ctx.has_bcls = b_cls is not None
+            ctx.save_for_backward(x, w, sx, sw, y, w_cls)
+            return y, logits
         ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
-    def backward(ctx, g):
-        x, w, sx, sw, y = ctx.saved_tensors
+    def backward(ctx, g, g_logits=None):
+        n_in = 8
+        if g is None and g_logits is None:
+            return (None,) * n_in
+        w_cls = None
+        if ctx.has_cls:
+            x, w, sx, sw, y, w_cls = ctx.saved_tensors
+        else:
+            x, w, sx, sw, y = ctx.saved_tensors
         N, K = x.shape
         C = w.shape[0]
-        g = _rowmajor(g)
-        if ctx.drop is not None:                        # dropout's and the activation's backward in one pass, mask regenerated
+        g_wcls = g_bcls = sg = None
+        if g_logits is not None:
+            cs = column_sums(g_logits)
+            g_logits = _rowmajor(g_logits)
+            wc = w_cls.detach()
+            if ctx.needs_input_grad[6]:
+                g_wcls = scores_bwd_w(g_logits, y)
+            g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[7] else None
+            if g is None and C % 4 == 0 and act_bwd_proj_supported(1, C, wc.shape[0], wc):
+                # g_logits Wc * act'(y) in one pass: the (N, C) gradient of y is never written
+                g, sg = act_bwd_proj(g_logits, wc, y if ctx.act != ACT_NONE else None, 1, C, ctx.act)
+            else:
+                if g is None:
+                    g = torch.empty((N, (C + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :C]
+                    scores_bwd_x_(g, g_logits, wc, accumulate=False)
+                else:
+                    g0 = _rowmajor(g)
+                    g = g0.clone() if _rows_aligned(g0) else cat_padded((g0,))
+                    scores_bwd_x_(g, g_logits, wc, accumulate=True)
+        if sg is not None:
+            pass                                          # activation already undone (spgnn_act_bwd_proj)
+        elif ctx.drop is not None:                        # dropout's and the activation's backward in one pass, mask regenerated
+            g = _rowmajor(g)
             if not _rows_aligned(g):
                 g = g.contiguous()
             g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
@@ -733,8 +782,9 @@ class _LinearFn(torch.autograd.Function):
                             "spgnn_act_bwd_dropout")
             g = g_pre
         elif ctx.act != ACT_NONE and C % 4 == 0:
-            g, sg = act_bwd(g, y, 1, C, ctx.act, False)
+            g, sg = act_bwd(_rowmajor(g), y, 1, C, ctx.act, False)
         else:
+            g = _rowmajor(g)
             if ctx.act != ACT_NONE:
                 g = g * {ACT_ELU: torch.where(y > 0, torch.ones_like(y), y + 1), ACT_TANH: 1 - y * y,
                          ACT_RELU: (y > 0).to(y.dtype), ACT_LRELU: torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))}[ctx.act]
@@ -754,7 +804,7 @@ class _LinearFn(torch.autograd.Function):
                 g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
             else:
                 g_w = gemm_tn(g, x, sg, sx)
-        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None), None
+        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None), None, g_wcls, g_bcls
 
 
 def linear_drop_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -791,6 +841,26 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     elif act == ACT_RELU:
         y = torch.relu(y)
     return y
+
+
+def linear_act_classifier_supported(x: torch.Tensor, weight: torch.Tensor, w_cls: torch.Tensor) -> bool:
+    N = x.shape[0] if x.dim() == 2 else 0
+    return (LINEAR_ACT_CLASSIFIER and x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32
+            and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
+            and w_cls.shape[0] <= 32 and w_cls.shape[1] == weight.shape[0] and w_cls.dtype == torch.float32)
+
+
+def linear_act_classifier(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int, w_cls: torch.Tensor,
+                          b_cls: Optional[torch.Tensor]):
+    """y = act(F.linear(x, weight, bias)) and logits = F.linear(y, w_cls, b_cls) as ONE autograd node -> (y, logits): the last
+    product of the reference's GIN MLP (models.py:236-246) followed by the *Net's ``gnn_out`` (models.py:988).  See
+    _LinearFn.forward; needs :func:`linear_act_classifier_supported`."""
+    assert linear_act_classifier_supported(x, weight, w_cls)
+    y, logits = _LinearFn.apply(x, weight, bias, act, None, None, w_cls, b_cls)
+    blk = getattr(y.grad_fn, "scale_block", None) if y.grad_fn is not None else None
+    if blk is not None:
+        y._spgnn_scale = (y._version, blk)
+    return y, logits
 
 
 class _LinearClassifierFn(torch.autograd.Function):
@@ -957,6 +1027,8 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+LINEAR_ACT_CLASSIFIER = True   # a skinny classifier behind Linear + activation joins that product's node (GIN's last MLP)
+EPILOGUE_DROPOUT = True   # linear(drop=): the hash mask applied by the product's epilogue (ReLU / LeakyReLU / none)
 EMIT_SCALES = True     # spmm_sum and ops.linear leave max |result| in a scale block (no absmax pass when the result feeds a product)
 PRESPLIT_B = True      # weight operands of the NT products pre-split once per step (spgnn_presplit); False: fp32 rows, split per tile
 

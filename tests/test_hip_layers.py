@@ -442,11 +442,15 @@ def test_sgd_mean_form_and_step_begin():
         pool.end()
 
 
-def test_linear_with_dropout_equals_linear_then_hash_dropout():
-    """ops.linear(..., drop=(p, seed)): the product's node applies the hash dropout itself and undoes dropout + activation in
-    one backward pass (spgnn_act_bwd_dropout) - values and gradients equal linear followed by ops.cat_dropout bit for bit."""
+@pytest.mark.parametrize("N,K,C,act", [(3000, 96, 128, "LRELU"), (2500, 64, 1024, "LRELU"), (1111, 100, 132, "RELU"),
+                                        (4100, 256, 512, "NONE"), (900, 64, 64, "ELU")])
+def test_linear_with_dropout_equals_linear_then_hash_dropout(N, K, C, act):
+    """ops.linear(..., drop=(p, seed)): the product's epilogue applies the hash dropout itself (ReLU / LeakyReLU / none; ELU
+    keeps the two-kernel form) and the node undoes dropout + activation in one backward pass (spgnn_act_bwd_dropout) from the
+    dropped result alone - values and gradients equal linear followed by ops.cat_dropout bit for bit, interior and ragged
+    tiles, every NT kernel."""
     torch.manual_seed(4)
-    N, K, C = 3000, 96, 128
+    act = getattr(ops, "ACT_" + act)
     x0 = torch.randn(N, K, device="cuda")
     w0, b0 = torch.randn(C, K, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
     gout = torch.randn(N, C, device="cuda")
@@ -454,17 +458,54 @@ def test_linear_with_dropout_equals_linear_then_hash_dropout():
     for fused in (True, False):
         x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
         if fused:
-            y = ops.linear(x, w, b, ops.ACT_LRELU, drop=(0.1, 777))
+            y = ops.linear(x, w, b, act, drop=(0.1, 777))
         else:
-            y = ops.cat_dropout((ops.linear(x, w, b, ops.ACT_LRELU),), 0.1, 777)
+            y = ops.cat_dropout((ops.linear(x, w, b, act),), 0.1, 777)
         assert getattr(y, "_spgnn_scale", None) is not None
         (y * gout).sum().backward()
         res.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone(), ops.scale_value(y._spgnn_scale[1])))
     for a, b_ in zip(res[0][:4], res[1][:4]):
         assert torch.equal(a, b_)
     assert res[0][4] == res[1][4]
-    kept = float((res[0][0] != 0).float().mean())
-    assert 0.85 < kept < 0.95
+XX, [(3000, 96, 128, 22, "LRELU"), (2049, 64, 1024, 22, "LRELU"), (777, 128, 64, 6, "RELU"),
+                                          (1500, 64, 256, 3, "NONE")])
+def test_linear_act_classifier_equals_the_three_nodes(N, K, C, J, act):
+    """ops.linear_act_classifier (Linear + activation + skinny classifier as one node; backward through spgnn_act_bwd_proj when
+    only the logits carry a gradient): same values as ops.linear -> ops.skinny_linear bit for bit, gradients to the last bits
+    (g_logits Wc is summed in another order), and against fp64; a gradient into y as well takes the general route."""
+    torch.manual_seed(11)
+    act_c = getattr(ops, "ACT_" + act)
+    x0 = torch.randn(N, K, device="cuda")
+    w0, b0 = torch.randn(C, K, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
+    wc0, bc0 = torch.randn(J, C, device="cuda") * 0.2, torch.randn(J, device="cuda") * 0.1
+    gl, gy = torch.randn(N, J, device="cuda"), torch.randn(N, C, device="cuda") * 0.05
+    ref_act = {"LRELU": lambda t: torch.nn.functional.leaky_relu(t, 0.01), "RELU": torch.relu, "NONE": lambda t: t}[act]
+    for with_y in (False, True):
+        res = []
+        for form in ("fused", "split", "fp64"):
+            dt = torch.float64 if form == "fp64" else torch.float32
+            ps = [t.clone().to(dt).requires_grad_(True) for t in (x0, w0, b0, wc0, bc0)]
+            x, w, b, wc, bc = ps
+            if form == "fused":
+                y, lg = ops.linear_act_classifier(x, w, b, act_c, wc, bc)
+                assert getattr(y, "_spgnn_scale", None) is not None
+            elif form == "split":
+                y = ops.linear(x, w, b, act_c)
+                lg = ops.skinny_linear(y, wc, bc)
+            else:
+                y = ref_act(torch.nn.functional.linear(x, w, b))
+                lg = torch.nn.functional.linear(y, wc, bc)
+            loss = (lg * gl.to(dt)).sum()
+            if with_y:
+                loss = loss + (y * gy.to(dt)).sum()
+            loss.backward()
+            res.append([y.detach(), lg.detach()] + [t.grad for t in ps])
+        fused, split, ref = res
+        assert torch.equal(fused[0], split[0]) and torch.equal(fused[1], split[1])
+        for i, (a, b_, r) in enumerate(zip(fused, split, ref)):
+            scale = float(r.abs().max()) + 1e-30
+            e_f, e_s = float((a.double() - r).abs().max()) / scale, float((b_.double() - r).abs().max()) / scale
+            assert e_f < 2e-5 and e_f <= 2.0 * e_s + 2e-6, (i, e_f, e_s)
 
 
 def test_emitted_scales_equal_an_absmax_pass():
