@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 42
+#define SPGNN_ABI_VERSION 43
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -323,6 +323,15 @@ int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices,
                    int64_t N, int64_t E, int32_t F,
                    float* absmax_out /* nullable scale block (see spgnn_gemm_nt): max |out| folded into its slots */,
                    spgnn_stream_t stream);
+/* The same with feature dropout of the stored rows, out = dropout(act(...), p_drop), under spgnn_cat_dropout's mask for an
+ * F-wide row (counter v * F + column; seed + *seed_offset when the pointer is set) - GINConv's MLP
+ * (reference models.py:236-246: Linear -> Dropout -> LeakyReLU) when the first Linear is applied BEFORE the aggregation
+ * (in_feats > out_feats: both are linear, so  ((1 + eps) x + A x) W^T = (1 + eps) (x W^T) + A (x W^T)  and the gather runs on
+ * the narrow rows).  absmax_out sees the dropped values; spgnn_act_bwd_dropout undoes dropout + activation from them. */
+int spgnn_spmm_sum_dropout(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
+                           const float* w_dst, const float* self_eps, const float* bias, int32_t activation, float* out,
+                           int64_t out_stride, int64_t N, int64_t E, int32_t F, float* absmax_out, float p_drop, uint64_t seed,
+                           const uint64_t* seed_offset, spgnn_stream_t stream);
 
 /*
  * Max SpMM (DGL gspmm(copy_u, max); SAGEConv 'pool', reference models.py:668-679):

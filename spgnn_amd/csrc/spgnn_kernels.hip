@@ -1594,6 +1594,8 @@ struct SpmmSum {
   int64_t N; int F; int T;
   const float* bias; int act;            // optional epilogue out = act(... + bias[col]) (GraphConv: reference models.py:172-182)
   float* absmax;                         // optional scale block: max |out| folded into its slots (the result as a GEMM operand)
+  // optional feature dropout of the stored rows (after bias / activation): spgnn_cat_dropout's mask for an F-wide row
+  float drop_p, drop_inv; uint64_t drop_seed; const uint64_t* drop_seed_off;
 };
 
 // TT = 64: one node per wave with wave-uniform index / weight values in SGPRs; TT = 0: run-time team width
@@ -1644,6 +1646,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
   }
   const float wd = a.w_dst ? a.w_dst[v] : 1.f;
   const float sc = a.self_eps ? 1.f + a.self_eps[0] : 0.f;
+  const uint64_t dseed = a.drop_p > 0.f ? a.drop_seed + (a.drop_seed_off ? a.drop_seed_off[0] : 0) : 0;
   float amx = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1652,6 +1655,10 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_vec(SpmmSum a) {
     if (a.self_eps) fma4(o, sc, ld4(a.x + v * a.x_ld + c));
     if (a.bias) { const float4 b = ld4(a.bias + c); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
     if (a.act != SPGNN_ACT_NONE) { o.x = act_fwd(o.x, a.act); o.y = act_fwd(o.y, a.act); o.z = act_fwd(o.z, a.act); o.w = act_fwd(o.w, a.act); }
+    if (a.drop_p > 0.f) {
+      const float4 k = feat_keep4(dseed, v * a.F + c, a.drop_p, a.drop_inv);
+      o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
+    }
     st4(a.out + v * a.out_ld + c, o);
     amx = absmax4(amx, o);
   }
@@ -3178,17 +3185,29 @@ int spgnn_scores_from_parts(const float* parts, float* s, int64_t s_stride, int6
 int spgnn_spmm_sum(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
                    const float* w_dst, const float* self_eps, const float* bias, int32_t activation, float* out,
                    int64_t out_stride, int64_t N, int64_t E, int32_t F, float* absmax_out, spgnn_stream_t stream) {
+  return spgnn_spmm_sum_dropout(indptr, indices, x, x_stride, w_src, w_dst, self_eps, bias, activation, out, out_stride, N, E, F,
+                                absmax_out, 0.f, 0, nullptr, stream);
+}
+
+int spgnn_spmm_sum_dropout(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, const float* w_src,
+                           const float* w_dst, const float* self_eps, const float* bias, int32_t activation, float* out,
+                           int64_t out_stride, int64_t N, int64_t E, int32_t F, float* absmax_out, float p_drop, uint64_t seed,
+                           const uint64_t* seed_offset, spgnn_stream_t stream) {
   if (N < 0 || E < 0 || F <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_sum: bad N/E/F");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_sum: p_drop outside [0, 1)");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_spmm_sum: activation");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !out || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_sum: null pointer");
   if (x_stride < F || out_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_sum: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation, absmax_out};
+  SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation, absmax_out,
+            p_drop, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed, seed_offset};
   int T, R;
   if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && (!bias || aligned16(bias))) {
     a.T = T;
     DISPATCH_R(T, R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
+  } else if (p_drop > 0.f) {
+    return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_sum_dropout: dropout needs 16-byte rows of a supported width");
   } else {
     hipLaunchKernelGGL(spmm_sum_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
   }

@@ -409,6 +409,7 @@ def _hash_dropout(drop: nn.Dropout, x: torch.Tensor) -> torch.Tensor:
     return ops.cat_dropout((x,), p, _draw_seed())
 
 
+GIN_PROJECT_FIRST = True  # GINConv applies its MLP's first Linear before the aggregation when that narrows the rows
 FUSE_EPILOGUES = True     # bias / activation of GraphConv, the GIN MLP and SAGEConv inside the producing kernel's epilogue
 
 
@@ -439,6 +440,22 @@ def _apply_fast_sequence(mods, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _apply_fast_sequence_classifier(mods, x: torch.Tensor, classifier: nn.Linear):
+    """(h, classifier(h)) for h = the modules applied in order; a trailing Linear + activation takes the classifier into its
+    autograd node (ops.linear_act_classifier)."""
+    k = len(mods) - 1
+    code = _act_code_dense(mods[k]) if k >= 1 and isinstance(mods[k], (nn.LeakyReLU, nn.ReLU)) else None
+    if code is not None and type(mods[k - 1]) is nn.Linear and FUSE_EPILOGUES and x.is_cuda:
+        h = _apply_fast_sequence(mods[:k - 1], x)
+        last = mods[k - 1]
+        if ops.linear_act_classifier_supported(h, last.weight, classifier.weight):
+            return ops.linear_act_classifier(h, last.weight, last.bias, code, classifier.weight, classifier.bias)
+        h = ops.linear(h, last.weight, last.bias, code)
+        return h, classifier(h)
+    h = _apply_fast_sequence(mods, x)
+    return h, classifier(h)
+
+
 def _apply_fast_linear(module: nn.Module, x: torch.Tensor, classifier: Optional[nn.Linear] = None):
     """``module(x)`` with every plain ``nn.Linear`` (also inside an ``nn.Sequential``, e.g. the reference's GIN MLP,
     models.py:236-246: Linear, Dropout, LeakyReLU, Linear, LeakyReLU) evaluated by ops.linear on the matrix-core GEMMs; any
@@ -448,18 +465,7 @@ def _apply_fast_linear(module: nn.Module, x: torch.Tensor, classifier: Optional[
     ``classifier`` (a Linear with <= 32 outputs, the *Net's ``gnn_out``): returns ``(module(x), classifier(module(x)))``; when
     the module ends in Linear + activation the classifier joins that product's autograd node (ops.linear_act_classifier)."""
     if classifier is not None:
-        mods = list(module) if type(module) is nn.Sequential else [module]
-        k = len(mods) - 1
-        code = _act_code_dense(mods[k]) if k >= 1 and isinstance(mods[k], (nn.LeakyReLU, nn.ReLU)) else None
-        if (code is not None and type(mods[k - 1]) is nn.Linear and FUSE_EPILOGUES and x.is_cuda):
-            h = _apply_fast_sequence(mods[:k - 1], x)
-            last = mods[k - 1]
-            if ops.linear_act_classifier_supported(h, last.weight, classifier.weight):
-                return ops.linear_act_classifier(h, last.weight, last.bias, code, classifier.weight, classifier.bias)
-            h = ops.linear(h, last.weight, last.bias, code)
-            return h, classifier(h)
-        h = _apply_fast_linear(module, x)
-        return h, classifier(h)
+        return _apply_fast_sequence_classifier(list(module) if type(module) is nn.Sequential else [module], x, classifier)
     if type(module) is nn.Linear:
         return ops.linear(x, module.weight, module.bias)
     if type(module) is nn.Sequential:
@@ -489,6 +495,37 @@ class GINConv(nn.Module):
         if edge_weight is not None:
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
+        mods = list(self.apply_func) if type(self.apply_func) is nn.Sequential else [self.apply_func]
+        first = mods[0]
+        if (GIN_PROJECT_FIRST and FUSE_EPILOGUES and self._aggregator_type != "max" and type(first) is nn.Linear
+                and first.in_features > first.out_features and first.out_features % 4 == 0 and feat.is_cuda
+                and feat.dtype == torch.float32 and getattr(csc, "num_dst", None) is None):
+            # The MLP's first Linear BEFORE the aggregation: both are linear, ((1 + eps) x + A x) W^T = (1 + eps) u + A u with
+            # u = x W^T, so the gather, its transpose in the backward pass and eps' gradient run on out_features-wide rows
+            # (1024 -> 256 on the first layer), and the input gradient of the first layer's product is never needed.  Bias,
+            # activation and dropout go into the aggregation's epilogue.
+            j, drop = 1, None
+            if j < len(mods) and type(mods[j]) is nn.Dropout:
+                drop, j = mods[j], j + 1
+            code = _act_code_dense(mods[j]) if j < len(mods) and isinstance(mods[j], (nn.LeakyReLU, nn.ReLU)) else None
+            if code is None:
+                j, drop, code = 1, None, ops.ACT_NONE            # Linear alone: the rest of the MLP runs as it is
+            else:
+                j += 1
+            u = ops.linear(feat, first.weight, None)
+            w_dst = csc.degree_scale("in", -1.0) if self._aggregator_type == "mean" else None
+            pd = float(drop.p) if (drop is not None and drop.training) else 0.0
+            rst = ops.spmm_sum(csc, u, None, w_dst, self.eps, bias=first.bias, act=code,
+                               drop=(pd, _draw_seed()) if 0.0 < pd < 1.0 else None)
+            if pd >= 1.0:
+                rst = drop(rst)
+            rest = mods[j:]
+            if classifier is not None and self.activation is None and rest:
+                return _apply_fast_sequence_classifier(rest, rst, classifier)
+            rst = _apply_fast_sequence(rest, rst)
+            if self.activation is not None:
+                rst = self.activation(rst)
+            return rst if classifier is None else (rst, classifier(rst))
         if self._aggregator_type == "max":
             rst = _dst_rows(csc, (1 + self.eps) * feat + ops.spmm_max(csc, feat))
         else:

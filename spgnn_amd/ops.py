@@ -2126,31 +2126,43 @@ def gat_layer_agg_first(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D: i
 # --------------------------------------------------------------------------------------------
 # SpMM sum / max
 # --------------------------------------------------------------------------------------------
-def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=None, act: int = ACT_NONE, absmax=None) -> torch.Tensor:
-    """``absmax``: a scale block the kernel folds max |out| into (the result as the next product's operand)."""
+def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=None, act: int = ACT_NONE, absmax=None,
+                 drop=None) -> torch.Tensor:
+    """``absmax``: a scale block the kernel folds max |out| into (the result as the next product's operand).  ``drop`` =
+    (p, seed): the stored rows are dropout(act(...), p) under the hash mask."""
     _require_cuda(x, w_src, w_dst, eps, bias)
     F_ = x.shape[1]
     out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device), _timed("spmm_sum", (N, E, F_)):
-        _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
-                                       _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_, _ptr(absmax),
-                                       _stream(x)), "spgnn_spmm_sum")
+        if drop is not None and drop[0] > 0.0:
+            _capi.check(lib.spgnn_spmm_sum_dropout(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
+                                                   _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_,
+                                                   _ptr(absmax), float(drop[0]), int(drop[1]), _seed_off_ptr(x.device), _stream(x)),
+                        "spgnn_spmm_sum_dropout")
+        else:
+            _capi.check(lib.spgnn_spmm_sum(indptr.data_ptr(), indices.data_ptr(), x.data_ptr(), x.stride(0), _ptr(w_src),
+                                           _ptr(w_dst), _ptr(eps), _ptr(bias), act, out.data_ptr(), out.stride(0), N, E, F_, _ptr(absmax),
+                                           _stream(x)), "spgnn_spmm_sum")
     return out
 
 
 class _SpmmSumFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst, bias=None, act: int = ACT_NONE):
+    def forward(ctx, x, eps, csc: DeviceCSC, w_src, w_dst, bias=None, act: int = ACT_NONE, drop=None):
         x = _rowmajor(x)
         fuse = (bias is not None or act != ACT_NONE) and x.shape[1] % 4 == 0
         blk = new_scale_block(x.device) if (EMIT_SCALES and x.shape[1] % 4 == 0) else None
+        dropping = drop is not None and drop[0] > 0.0
+        if dropping and not (x.shape[1] % 4 == 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU)):
+            raise RuntimeError("spmm_sum(drop=...): width % 4 == 0 and ReLU / LeakyReLU / no activation only")
         out = spmm_sum_raw(csc.indptr, csc.indices, x, w_src, w_dst, eps, csc.num_nodes, csc.num_edges, bias if fuse else None,
-                           act if fuse else ACT_NONE, absmax=blk)
+                           act if fuse else ACT_NONE, absmax=blk, drop=drop if dropping else None)
         ctx.scale_block = blk
         if not fuse and (bias is not None or act != ACT_NONE):
             raise RuntimeError("spmm_sum: the bias / activation epilogue needs a width that is a multiple of 4")
         ctx.csc, ctx.w, ctx.act, ctx.has_bias = csc, (w_src, w_dst), act, bias is not None
+        ctx.drop = (float(drop[0]), int(drop[1])) if dropping else None
         ctx.save_for_backward(x if eps is not None else None, eps, out if act != ACT_NONE else None)
         return out
 
@@ -2161,25 +2173,40 @@ class _SpmmSumFn(torch.autograd.Function):
         w_src, w_dst = ctx.w
         g_out = _rowmajor(g_out)
         g_bias = None
-        if ctx.act != ACT_NONE:                     # gradient of the pre-activation rows: one flat pass (spgnn_act_bwd)
+        if ctx.drop is not None:                    # dropout's and the activation's backward in one pass, mask regenerated; the
+            g = g_out if _rows_aligned(g_out) else g_out.contiguous()      # derivative needs the sign of the stored value only
+            N, C = g.shape
+            g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
+                _capi.check(_capi.load().spgnn_act_bwd_dropout(g.data_ptr(), g.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
+                                                               g_pre.data_ptr(), g_pre.stride(0), 0, N, C, ctx.act,
+                                                               ctx.drop[0], ctx.drop[1], _seed_off_ptr(g.device), _stream(g)),
+                            "spgnn_act_bwd_dropout")
+            g_out = g_pre
+        elif ctx.act != ACT_NONE:                   # gradient of the pre-activation rows: one flat pass (spgnn_act_bwd)
             g_out, _ = act_bwd(g_out if _rows_aligned(g_out) else g_out.contiguous(), out, 1, out.shape[1], ctx.act, False)
         if ctx.has_bias and ctx.needs_input_grad[5]:
             g_bias = g_out.sum(0)
         g_x = g_eps = None
+        blk = None
         if ctx.needs_input_grad[0]:   # transpose: swap the roles of the two scalings
-            g_x = spmm_sum_raw(csc.out_indptr, csc.out_indices, g_out, w_dst, w_src, eps, csc.num_nodes, csc.num_edges)
+            blk = new_scale_block(g_out.device) if (EMIT_SCALES and g_out.shape[1] % 4 == 0) else None
+            g_x = spmm_sum_raw(csc.out_indptr, csc.out_indices, g_out, w_dst, w_src, eps, csc.num_nodes, csc.num_edges, absmax=blk)
+            if blk is not None:
+                g_x._spgnn_scale = (g_x._version, blk)   # for the node behind (a product's backward): no absmax pass over g_x
         if eps is not None and ctx.needs_input_grad[1]:
             if g_out.is_contiguous() and x.is_contiguous():      # one pass over both tensors, no (N, F) temporary
                 g_eps = torch.dot(g_out.reshape(-1), x.reshape(-1)).reshape(eps.shape)
             else:
                 g_eps = (g_out * x).sum().reshape(eps.shape)
-        return g_x, g_eps, None, None, None, g_bias, None
+        return g_x, g_eps, None, None, None, g_bias, None, None
 
 
-def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None, bias=None, act: int = ACT_NONE) -> torch.Tensor:
-    """out[v] = act((1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u] + bias)."""
+def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None, bias=None, act: int = ACT_NONE, drop=None) -> torch.Tensor:
+    """out[v] = act((1+eps)*x[v] (if eps given) + w_dst[v] * sum_{u in in(v)} w_src[u] * x[u] + bias); ``drop`` = (p, seed):
+    followed by dropout under the hash mask, in the same kernel."""
     _require_cuda(x)
-    out = _SpmmSumFn.apply(x, eps, csc, w_src, w_dst, bias, act)
+    out = _SpmmSumFn.apply(x, eps, csc, w_src, w_dst, bias, act, drop)
     blk = getattr(out.grad_fn, "scale_block", None) if out.grad_fn is not None else None
     if blk is not None:
         out._spgnn_scale = (out._version, blk)          # its GEMM operand scale, emitted by the kernel itself
