@@ -2132,6 +2132,8 @@ def spmm_sum_raw(indptr, indices, x, w_src, w_dst, eps, N: int, E: int, bias=Non
     (p, seed): the stored rows are dropout(act(...), p) under the hash mask."""
     _require_cuda(x, w_src, w_dst, eps, bias)
     F_ = x.shape[1]
+    if bias is not None and bias.data_ptr() % 16:
+        bias = bias.clone()                                   # the vector kernels read it with 16-byte loads
     out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device), _timed("spmm_sum", (N, E, F_)):

@@ -79,18 +79,23 @@ class FlatBucket:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        total = (self.numel + 2 + 3) // 4 * 4
+        # every parameter starts on a 16-byte boundary of the bucket (a one-element parameter such as GINConv's eps would
+        # otherwise leave every later weight and bias misaligned for the kernels' 16-byte loads); the padding floats stay zero
+        # in all three buffers (zero gradient -> zero momentum -> no update)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off                     # extent of the parameter region (padding included)
+        total = self.numel + 4
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
-            off += n
         self.loss_slot = self.flat_grad[self.numel:self.numel + 1]          # [loss numerator, class-weight sum]: the order
         self.wsum_slot = self.flat_grad[self.numel + 1:self.numel + 2]      # ops.masked_ce_sums writes them in
         self.sums_slot = self.flat_grad[self.numel:self.numel + 2]
@@ -114,13 +119,18 @@ class FlatBucket:
     def gather_grads(self):
         """After backward: one batched copy of all gradients into the flat bucket; ``.grad`` becomes the bucket view again."""
         parts = []
+
+        def zeros(k):
+            z = self._zeros.get(k)
+            if z is None:
+                z = self._zeros[k] = torch.zeros(k, dtype=torch.float32, device=self.flat_grad.device)
+            return z
         for p in self.params:
             g = p.grad
-            if g is None:                # parameter not reached by this loss (e.g. unused auxiliary heads)
-                g = self._zeros.get(p.numel())
-                if g is None:
-                    g = self._zeros[p.numel()] = torch.zeros(p.numel(), dtype=torch.float32, device=self.flat_grad.device)
-            parts.append(g.reshape(-1))
+            n = p.numel()
+            parts.append(zeros(n) if g is None else g.reshape(-1))   # None: not reached by this loss (e.g. unused auxiliary heads)
+            if n % 4:
+                parts.append(zeros(4 - n % 4))                       # the padding up to the next parameter
         torch.cat(parts, out=self.flat_grad[:self.numel])
         for p, v in zip(self.params, self._views):
             p.grad = v
@@ -250,12 +260,11 @@ class TrainStep:
         load the other's file; plus ``"spgnn"``: the step count, the attention-dropout seed counter and the mask
         generator's state, which a resumed run needs to continue the same random streams."""
         b = self.bucket
-        state, off = {}, 0
-        for i, p in enumerate(b.params):
+        state = {}
+        for i, (p, off) in enumerate(zip(b.params, b.offsets)):
             n = p.numel()
             if b.steps > 0:                      # torch creates the buffer at the first step
                 state[i] = {"momentum_buffer": b.flat_mom[off:off + n].view_as(p).detach().clone()}
-            off += n
         group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
                  "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
                  "params": list(range(len(b.params)))}
@@ -278,8 +287,8 @@ class TrainStep:
             raise ValueError("only plain SGD with momentum is supported (nesterov / dampening / maximize are set)")
         state = sd.get("state", {})
         ids = g0["params"]
-        off, have = 0, 0
-        for i, p in enumerate(b.params):
+        have = 0
+        for i, (p, off) in enumerate(zip(b.params, b.offsets)):
             n = p.numel()
             st = state.get(ids[i], state.get(str(ids[i])))
             buf = None if st is None else st.get("momentum_buffer")
@@ -290,7 +299,6 @@ class TrainStep:
                 have += 1
             else:
                 b.flat_mom[off:off + n].zero_()
-            off += n
         self.momentum, self.weight_decay = float(g0.get("momentum", self.momentum)), float(g0.get("weight_decay", self.weight_decay))
         self.set_lr(float(g0.get("lr", self.lr)))
         extra = sd.get("spgnn")

@@ -250,10 +250,8 @@ def test_train_step_state_dict_round_trip_matches_torch_sgd_layout():
         c3 = train.TrainStep(fresh(), w, 0.15, 0.05, 0.9)
         c3.load_state_dict(opt3.state_dict())
         assert c3.bucket.steps == 1
-        off = 0
-        for i, p in enumerate(m3.parameters()):
+        for p, off in zip(m3.parameters(), c3.bucket.offsets):
             assert torch.equal(c3.bucket.flat_mom[off:off + p.numel()].view_as(p), opt3.state[p]["momentum_buffer"])
-            off += p.numel()
         opt4 = torch.optim.SGD(list(fresh().parameters()), lr=0.05, momentum=0.9)
         opt4.load_state_dict({k: v for k, v in sd.items() if k != "spgnn"})
         with pytest.raises(ValueError):

@@ -33,6 +33,6 @@ for train in (False, True):
             off = 0
             for n, p in model.named_parameters():
                 if p.requires_grad:
-                    k = p.numel(); c = int(torch.isnan(ts.bucket.flat_grad[off:off + k]).sum()); off += k
+                    k = p.numel(); c = int(torch.isnan(ts.bucket.flat_grad[off:off + k]).sum()); off += (k + 3) // 4 * 4
                     if c: print("   ", n, c, "/", k)
             sys.exit(1)
