@@ -1360,6 +1360,66 @@ __global__ __launch_bounds__(kBlock) void act_bwd_flat_kernel(const float* __res
   }
 }
 
+// The same pass that also leaves the COLUMN SUMS of g_pre (the bias gradient of a layer whose bias sits in the aggregation's
+// epilogue: GraphConv, reference models.py:172-182, and GINConv's first Linear applied before the aggregation) as per-block
+// partials colpart[block][W], summed afterwards in block order (spgnn_sum_partials) - deterministic, and no pass of a
+// reduction kernel over g_pre.  W / 4 must divide the block size: a thread then keeps ONE column group for all its rows
+// (grid stride = a multiple of W / 4), accumulates it in registers, and the block folds its 256 / (W / 4) row lanes through LDS
+// in a fixed order.  Two rows per trip (independent loads) since the grid is capped at spgnn_act_bwd_colsum_blocks().
+__global__ __launch_bounds__(kBlock) void act_bwd_colsum_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
+                                                                int64_t out_ld, float* __restrict__ g_pre, int64_t gp_ld,
+                                                                float* __restrict__ absmax, float* __restrict__ colpart, int64_t N,
+                                                                int W, int act, float drop_p, uint64_t seed,
+                                                                const uint64_t* __restrict__ seed_off) {
+  __shared__ float4 red[kBlock];
+  const int w4 = W >> 2;
+  const int rows_per_block = kBlock / w4;                       // w4 divides kBlock (host check)
+  const int c = (threadIdx.x % w4) * 4;
+  const int64_t rstep = (int64_t)gridDim.x * rows_per_block;
+  float mx = 0.f;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (seed_off) seed += seed_off[0];
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  auto one = [&](int64_t v, float4 q, float4 o) __attribute__((always_inline)) {
+    if (drop_p > 0.f) {
+      const float4 k = feat_keep4(seed, v * W + c, drop_p, inv_keep);
+      q.x *= k.x; q.y *= k.y; q.z *= k.z; q.w *= k.w;
+    }
+    if (act != SPGNN_ACT_NONE) {
+      q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
+      q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+    }
+    st4(g_pre + v * gp_ld + c, q);
+    mx = absmax4(mx, q);
+    cs.x += q.x; cs.y += q.y; cs.z += q.z; cs.w += q.w;
+  };
+  int64_t v = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / w4;
+  for (; v + rstep < N; v += 2 * rstep) {
+    const float4 q0 = ld4(g + v * g_ld + c), q1 = ld4(g + (v + rstep) * g_ld + c);
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+    if (act != SPGNN_ACT_NONE) { o0 = ld4(out + v * out_ld + c); o1 = ld4(out + (v + rstep) * out_ld + c); }
+    one(v, q0, o0);
+    one(v + rstep, q1, o1);
+  }
+  if (v < N) {
+    const float4 q0 = ld4(g + v * g_ld + c);
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act != SPGNN_ACT_NONE) o0 = ld4(out + v * out_ld + c);
+    one(v, q0, o0);
+  }
+  red[threadIdx.x] = cs;
+  __syncthreads();
+  if ((int)threadIdx.x < w4) {
+    float4 t = red[threadIdx.x];
+    for (int r = 1; r < rows_per_block; ++r) { const float4 u = red[r * w4 + threadIdx.x]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    st4(colpart + (int64_t)blockIdx.x * W + c, t);
+  }
+  if (absmax) {
+    mx = team_max(mx, 64);
+    if ((threadIdx.x & 63) == 0) spgnn_detail::slots_max(absmax, mx, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  }
+}
+
 // act_bwd with the classifier's input gradient formed on the fly (mean-over-heads output layer followed by a skinny
 // Linear, reference models.py:1125 `gnn_out`):
 //   g_pre[v, h*D + c] = (1/H) * (sum_j gS[v, j] * W[j, c]) * act'(out[v, h*D + c])
@@ -3066,6 +3126,32 @@ int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float*
   hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
                      out_stride, g_pre, g_pre_stride, absmax, N, (int)W, activation, p_drop, seed, seed_offset);
   return check_launch("spgnn_act_bwd_dropout");
+}
+
+int32_t spgnn_act_bwd_colsum_blocks(int64_t N, int32_t W) {
+  if (N <= 0 || W <= 0 || W % 4 || kBlock % (W / 4)) return 0;          // unsupported width: W / 4 must divide 256
+  const int64_t rows_per_block = kBlock / (W / 4);
+  int64_t b = (N + 2 * rows_per_block - 1) / (2 * rows_per_block);      // two rows per thread and trip
+  if (b > 2048) b = 2048;
+  return (int32_t)(b < 1 ? 1 : b);
+}
+
+int spgnn_act_bwd_colsum(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
+                         int64_t g_pre_stride, float* absmax, float* colsum_partials, int64_t N, int32_t W, int32_t activation,
+                         float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (N <= 0 || W <= 0 || W % 4 || kBlock % (W / 4)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_colsum: bad N/W (N > 0, W / 4 must divide 256)");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_colsum: activation");
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_colsum: p_drop outside [0, 1)");
+  if (!g_out || !g_pre || !colsum_partials || (activation != SPGNN_ACT_NONE && !out)) return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_colsum: null pointer");
+  if (g_out_stride < W || g_pre_stride < W || (activation != SPGNN_ACT_NONE && out_stride < W))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_colsum: row stride smaller than row");
+  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)) ||
+      !aligned16(colsum_partials))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_colsum: rows must be 16-byte aligned");
+  const int32_t blocks = spgnn_act_bwd_colsum_blocks(N, W);
+  hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
+                     out_stride, g_pre, g_pre_stride, absmax, colsum_partials, N, (int)W, activation, p_drop, seed, seed_offset);
+  return check_launch("spgnn_act_bwd_colsum");
 }
 
 int32_t spgnn_act_bwd_proj_blocks(int64_t N) {

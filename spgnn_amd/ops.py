@@ -1027,6 +1027,7 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+BIAS_COLSUM = True     # spmm_sum's backward takes the bias gradient from the activation-backward pass (spgnn_act_bwd_colsum)
 LINEAR_ACT_CLASSIFIER = True   # a skinny classifier behind Linear + activation joins that product's node (GIN's last MLP)
 EPILOGUE_DROPOUT = True   # linear(drop=): the hash mask applied by the product's epilogue (ReLU / LeakyReLU / none)
 EMIT_SCALES = True     # spmm_sum and ops.linear leave max |result| in a scale block (no absmax pass when the result feeds a product)
@@ -2175,19 +2176,35 @@ class _SpmmSumFn(torch.autograd.Function):
         w_src, w_dst = ctx.w
         g_out = _rowmajor(g_out)
         g_bias = None
-        if ctx.drop is not None:                    # dropout's and the activation's backward in one pass, mask regenerated; the
-            g = g_out if _rows_aligned(g_out) else g_out.contiguous()      # derivative needs the sign of the stored value only
+        want_bias = ctx.has_bias and ctx.needs_input_grad[5]
+        drop_p, drop_seed = ctx.drop if ctx.drop is not None else (0.0, 0)
+        if ctx.drop is not None or ctx.act != ACT_NONE:
+            # dropout's and the activation's backward in one pass (mask regenerated; with dropout the derivative is taken from the
+            # dropped rows: sign only), and - when the bias gradient is wanted - its column sums from the same pass
+            g = g_out if _rows_aligned(g_out) else g_out.contiguous()
             N, C = g.shape
-            g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
-            with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
-                _capi.check(_capi.load().spgnn_act_bwd_dropout(g.data_ptr(), g.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
-                                                               g_pre.data_ptr(), g_pre.stride(0), 0, N, C, ctx.act,
-                                                               ctx.drop[0], ctx.drop[1], _seed_off_ptr(g.device), _stream(g)),
-                            "spgnn_act_bwd_dropout")
-            g_out = g_pre
-        elif ctx.act != ACT_NONE:                   # gradient of the pre-activation rows: one flat pass (spgnn_act_bwd)
-            g_out, _ = act_bwd(g_out if _rows_aligned(g_out) else g_out.contiguous(), out, 1, out.shape[1], ctx.act, False)
-        if ctx.has_bias and ctx.needs_input_grad[5]:
+            lib = _capi.load()
+            nb = lib.spgnn_act_bwd_colsum_blocks(N, C) if (want_bias and BIAS_COLSUM) else 0
+            if nb > 0:
+                g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
+                part = torch.empty((nb, C), dtype=torch.float32, device=g.device)
+                with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
+                    _capi.check(lib.spgnn_act_bwd_colsum(g.data_ptr(), g.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
+                                                         g_pre.data_ptr(), g_pre.stride(0), 0, part.data_ptr(), N, C, ctx.act,
+                                                         drop_p, drop_seed, _seed_off_ptr(g.device), _stream(g)),
+                                "spgnn_act_bwd_colsum")
+                g_out, g_bias = g_pre, sum_partials(part)
+            elif ctx.drop is not None:
+                g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
+                with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
+                    _capi.check(lib.spgnn_act_bwd_dropout(g.data_ptr(), g.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
+                                                          g_pre.data_ptr(), g_pre.stride(0), 0, N, C, ctx.act,
+                                                          drop_p, drop_seed, _seed_off_ptr(g.device), _stream(g)),
+                                "spgnn_act_bwd_dropout")
+                g_out = g_pre
+            else:
+                g_out, _ = act_bwd(g, out, 1, out.shape[1], ctx.act, False)
+        if want_bias and g_bias is None:
             g_bias = g_out.sum(0)
         g_x = g_eps = None
         blk = None

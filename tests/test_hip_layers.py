@@ -533,9 +533,11 @@ def test_spmm_sum_with_dropout_equals_spmm_sum_then_hash_dropout(F_, act):
         else:
             y = ops.cat_dropout((ops.spmm_sum(csc, x, None, w_dst, eps, bias=b, act=act),), 0.1, 4242)
         (y * gout).sum().backward()
-        res.append((y.detach().clone(), x.grad.clone(), b.grad.clone(), eps.grad.clone(), ops.scale_value(y._spgnn_scale[1])))
-    for a, b_ in zip(res[0][:4], res[1][:4]):
+        res.append((y.detach().clone(), x.grad.clone(), eps.grad.clone(), b.grad.clone(), ops.scale_value(y._spgnn_scale[1])))
+    for a, b_ in zip(res[0][:3], res[1][:3]):
         assert torch.equal(a, b_)
+    # the bias gradient is a column sum taken in a different order by the two forms (spgnn_act_bwd_colsum / torch)
+    assert float((res[0][3] - res[1][3]).abs().max()) <= 2e-6 * float(gout.abs().sum(0).max())
     assert res[0][4] == res[1][4]
 
 
@@ -576,6 +578,35 @@ def test_ginconv_first_linear_before_the_aggregation(fi, fo, training, monkeypat
         assert set(gp1) == set(gp0) and "eps" in gp1
         for n_ in gp0:
             assert rel_err(gp1[n_], gp0[n_]) < 5e-6, n_
+
+
+@pytest.mark.parametrize("N,W,act,p", [(5000, 256, "ELU", 0.0), (777, 64, "LRELU", 0.1), (3001, 1024, "RELU", 0.0), (130, 128, "TANH", 0.0),
+                                        (9, 4, "LRELU", 0.3)])
+def test_act_bwd_colsum_is_act_bwd_plus_column_sums(N, W, act, p):
+    """spgnn_act_bwd_colsum: g_pre bit for bit as spgnn_act_bwd_dropout, plus per-block column sums whose ordered sum
+    (spgnn_sum_partials) is the bias gradient - against an fp64 sum, and identical from run to run."""
+    torch.manual_seed(N + W)
+    lib = ops._capi.load()
+    act_c = getattr(ops, "ACT_" + act)
+    g = torch.randn(N, W, device="cuda")
+    out = torch.randn(N, W, device="cuda").clamp_(-0.9, 0.9)
+    ref = torch.empty_like(g)
+    assert lib.spgnn_act_bwd_dropout(g.data_ptr(), W, out.data_ptr(), W, ref.data_ptr(), W, 0, N, W, act_c, p, 99, 0, 0) == 0
+    nb = lib.spgnn_act_bwd_colsum_blocks(N, W)
+    assert nb > 0 and lib.spgnn_act_bwd_colsum_blocks(N, 24) == 0          # 6 float4 per row do not divide 256
+    sums = []
+    for _ in range(2):
+        g_pre = torch.empty_like(g)
+        part = torch.full((nb, W), float("nan"), device="cuda")
+        blk = ops.new_scale_block(g.device)
+        assert lib.spgnn_act_bwd_colsum(g.data_ptr(), W, out.data_ptr(), W, g_pre.data_ptr(), W, blk.data_ptr(), part.data_ptr(), N, W,
+                                        act_c, p, 99, 0, 0) == 0
+        assert torch.equal(g_pre, ref)
+        assert ops.scale_value(blk) == float(ops.pow2_scale(ref))
+        sums.append(ops.sum_partials(part))
+    assert torch.equal(sums[0], sums[1])
+    want = ref.double().sum(0)
+    assert float((sums[0].double() - want).abs().max()) <= 1e-5 * float(ref.abs().double().sum(0).max())
 
 
 def test_emitted_scales_equal_an_absmax_pass():
