@@ -685,6 +685,7 @@ class _LinearFn(torch.autograd.Function):
         C = weight.shape[0]
         prep = _prepared_linear_operands(weight, C, K)
         ctx.wt = None
+        ctx.w_transposed = weight.dim() == 2 and weight.stride(1) != 1 and weight.stride(0) == 1 and K % 4 == 0 and C % 4 == 0
         if prep is not None:
             # padded rows, scale, pre-split form and the transposes: built by this pass's spgnn_weight_prep
             w, wb, sw, ctx.wt = prep
@@ -802,6 +803,10 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if ctx.has_bias:
                 g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
+            elif ctx.w_transposed:
+                # the weight is the transposed view of an (in, out) parameter (GraphConv): x^T g lands in the parameter's own
+                # layout, so autograd's accumulation takes the tensor as it is instead of copying a transposed view
+                g_w = gemm_tn(x, g, sx, sg).t()
             else:
                 g_w = gemm_tn(g, x, sg, sx)
         return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None), None, g_wcls, g_bcls

@@ -5,9 +5,9 @@ from torch.profiler import profile, ProfilerActivity
 from spgnn_amd import models, synthetic
 from spgnn_amd.configs import class_weight_list, get_config
 from spgnn_amd.train import TrainStep
-cfg = get_config("st_pgat_spgnn_3")
+cfg = get_config(os.environ.get("CONFIG", "st_pgat_spgnn_3"))
 model = models.build_model(cfg.MODEL).cuda()
-g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
 step = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, 1e-4, 0.9)
 for _ in range(3): step.step(g)
 torch.cuda.synchronize()
