@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 44
+#define SPGNN_ABI_VERSION 45
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -234,11 +234,15 @@ int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float*
  * epilogue (GraphConv, reference models.py:172-182; GINConv's first Linear applied before the aggregation) - as per-block
  * partials colsum_partials[spgnn_act_bwd_colsum_blocks(N, W)][W]; spgnn_sum_partials over the blocks gives the (W) sums in
  * a fixed order.  W / 4 must divide 256 (the _blocks helper returns 0 otherwise: use spgnn_act_bwd + a reduction).
- * p_drop = 0: no dropout (then `out` is the undropped activation output, any SPGNN_ACT_*). */
+ * p_drop = 0: no dropout (then `out` is the undropped activation output, any SPGNN_ACT_*).
+ * dot_x (nullable, (N, W) rows): the pass also forms sum_v <g_pre[v, :], dot_x[v, :]> - GINConv's eps gradient
+ * (reference models.py:358-383) with dot_x = the aggregation's input rows.  The partial rows then have W + 4 floats
+ * (float W = the block's share of the dot product, the rest 0): colsum_partials[blocks][W + 4]. */
 int32_t spgnn_act_bwd_colsum_blocks(int64_t N, int32_t W);
 int spgnn_act_bwd_colsum(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
                          int64_t g_pre_stride, float* absmax, float* colsum_partials, int64_t N, int32_t W, int32_t activation,
-                         float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
+                         float p_drop, uint64_t seed, const uint64_t* seed_offset, const float* dot_x, int64_t dot_x_stride,
+                         spgnn_stream_t stream);
 
 /* spgnn_act_bwd for a mean-over-heads output layer that feeds a skinny Linear (the reference's classifier
  * `gnn_out = nn.Linear(node_embed_dim, out_ch)`, models.py:1125, on the head mean of models.py:482), with that

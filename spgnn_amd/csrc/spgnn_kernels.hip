@@ -1370,8 +1370,14 @@ __global__ __launch_bounds__(kBlock) void act_bwd_colsum_kernel(const float* __r
                                                                 int64_t out_ld, float* __restrict__ g_pre, int64_t gp_ld,
                                                                 float* __restrict__ absmax, float* __restrict__ colpart, int64_t N,
                                                                 int W, int act, float drop_p, uint64_t seed,
-                                                                const uint64_t* __restrict__ seed_off) {
+                                                                const uint64_t* __restrict__ seed_off,
+                                                                const float* __restrict__ dot_x, int64_t dx_ld) {
+  // dot_x (nullable): also sum_v <g_pre[v, :], dot_x[v, :]> (GINConv's eps gradient, reference models.py:358-383, with dot_x
+  // = the aggregation's input rows) - the block's share goes into float W of its partial row, whose pitch is then W + 4
   __shared__ float4 red[kBlock];
+  __shared__ float dred[kBlock / 64];
+  const int pitch = dot_x ? W + 4 : W;
+  float dsum = 0.f;
   const int w4 = W >> 2;
   const int rows_per_block = kBlock / w4;                       // w4 divides kBlock (host check)
   const int c = (threadIdx.x % w4) * 4;
@@ -1392,6 +1398,7 @@ __global__ __launch_bounds__(kBlock) void act_bwd_colsum_kernel(const float* __r
     st4(g_pre + v * gp_ld + c, q);
     mx = absmax4(mx, q);
     cs.x += q.x; cs.y += q.y; cs.z += q.z; cs.w += q.w;
+    if (dot_x) { const float4 u = ld4(dot_x + v * dx_ld + c); dsum += (q.x * u.x + q.y * u.y) + (q.z * u.z + q.w * u.w); }
   };
   int64_t v = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / w4;
   for (; v + rstep < N; v += 2 * rstep) {
@@ -1412,7 +1419,17 @@ __global__ __launch_bounds__(kBlock) void act_bwd_colsum_kernel(const float* __r
   if ((int)threadIdx.x < w4) {
     float4 t = red[threadIdx.x];
     for (int r = 1; r < rows_per_block; ++r) { const float4 u = red[r * w4 + threadIdx.x]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    st4(colpart + (int64_t)blockIdx.x * W + c, t);
+    st4(colpart + (int64_t)blockIdx.x * pitch + c, t);
+  }
+  if (dot_x) {                                              // wave sums (fixed butterfly), then the four waves in order
+    dsum = team_sum(dsum, 64);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d = dred[0];
+      for (int w = 1; w < kBlock / 64; ++w) d += dred[w];
+      st4(colpart + (int64_t)blockIdx.x * pitch + W, make_float4(d, 0.f, 0.f, 0.f));
+    }
   }
   if (absmax) {
     mx = team_max(mx, 64);
@@ -3138,7 +3155,8 @@ int32_t spgnn_act_bwd_colsum_blocks(int64_t N, int32_t W) {
 
 int spgnn_act_bwd_colsum(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
                          int64_t g_pre_stride, float* absmax, float* colsum_partials, int64_t N, int32_t W, int32_t activation,
-                         float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                         float p_drop, uint64_t seed, const uint64_t* seed_offset, const float* dot_x, int64_t dot_x_stride,
+                         spgnn_stream_t stream) {
   if (N <= 0 || W <= 0 || W % 4 || kBlock % (W / 4)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_colsum: bad N/W (N > 0, W / 4 must divide 256)");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_colsum: activation");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_colsum: p_drop outside [0, 1)");
@@ -3146,11 +3164,12 @@ int spgnn_act_bwd_colsum(const float* g_out, int64_t g_out_stride, const float* 
   if (g_out_stride < W || g_pre_stride < W || (activation != SPGNN_ACT_NONE && out_stride < W))
     return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_colsum: row stride smaller than row");
   if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_pre, g_pre_stride) || (activation != SPGNN_ACT_NONE && !vec_ok(out, out_stride)) ||
-      !aligned16(colsum_partials))
+      !aligned16(colsum_partials) || (dot_x && (dot_x_stride < W || !vec_ok(dot_x, dot_x_stride))))
     return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_colsum: rows must be 16-byte aligned");
   const int32_t blocks = spgnn_act_bwd_colsum_blocks(N, W);
   hipLaunchKernelGGL(act_bwd_colsum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
-                     out_stride, g_pre, g_pre_stride, absmax, colsum_partials, N, (int)W, activation, p_drop, seed, seed_offset);
+                     out_stride, g_pre, g_pre_stride, absmax, colsum_partials, N, (int)W, activation, p_drop, seed, seed_offset, dot_x,
+                     dot_x_stride);
   return check_launch("spgnn_act_bwd_colsum");
 }
 

@@ -2182,6 +2182,8 @@ class _SpmmSumFn(torch.autograd.Function):
         g_out = _rowmajor(g_out)
         g_bias = None
         want_bias = ctx.has_bias and ctx.needs_input_grad[5]
+        want_eps = eps is not None and ctx.needs_input_grad[1]
+        g_eps = None
         drop_p, drop_seed = ctx.drop if ctx.drop is not None else (0.0, 0)
         if ctx.drop is not None or ctx.act != ACT_NONE:
             # dropout's and the activation's backward in one pass (mask regenerated; with dropout the derivative is taken from the
@@ -2191,14 +2193,20 @@ class _SpmmSumFn(torch.autograd.Function):
             lib = _capi.load()
             nb = lib.spgnn_act_bwd_colsum_blocks(N, C) if (want_bias and BIAS_COLSUM) else 0
             if nb > 0:
+                # eps' gradient sum_v <g_pre[v], x[v]> rides along (float C of every partial row)
+                with_dot = want_eps and x.stride(1) == 1 and _rows_aligned(x)
                 g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
-                part = torch.empty((nb, C), dtype=torch.float32, device=g.device)
+                part = torch.empty((nb, C + 4 if with_dot else C), dtype=torch.float32, device=g.device)
                 with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
                     _capi.check(lib.spgnn_act_bwd_colsum(g.data_ptr(), g.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
                                                          g_pre.data_ptr(), g_pre.stride(0), 0, part.data_ptr(), N, C, ctx.act,
-                                                         drop_p, drop_seed, _seed_off_ptr(g.device), _stream(g)),
+                                                         drop_p, drop_seed, _seed_off_ptr(g.device), x.data_ptr() if with_dot else 0,
+                                                         x.stride(0) if with_dot else 0, _stream(g)),
                                 "spgnn_act_bwd_colsum")
-                g_out, g_bias = g_pre, sum_partials(part)
+                sums = sum_partials(part)
+                g_out, g_bias = g_pre, sums[:C]
+                if with_dot:
+                    g_eps = sums[C:C + 1].reshape(eps.shape)
             elif ctx.drop is not None:
                 g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
                 with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
@@ -2211,14 +2219,14 @@ class _SpmmSumFn(torch.autograd.Function):
                 g_out, _ = act_bwd(g, out, 1, out.shape[1], ctx.act, False)
         if want_bias and g_bias is None:
             g_bias = g_out.sum(0)
-        g_x = g_eps = None
+        g_x = None
         blk = None
         if ctx.needs_input_grad[0]:   # transpose: swap the roles of the two scalings
             blk = new_scale_block(g_out.device) if (EMIT_SCALES and g_out.shape[1] % 4 == 0) else None
             g_x = spmm_sum_raw(csc.out_indptr, csc.out_indices, g_out, w_dst, w_src, eps, csc.num_nodes, csc.num_edges, absmax=blk)
             if blk is not None:
                 g_x._spgnn_scale = (g_x._version, blk)   # for the node behind (a product's backward): no absmax pass over g_x
-        if eps is not None and ctx.needs_input_grad[1]:
+        if want_eps and g_eps is None:
             if g_out.is_contiguous() and x.is_contiguous():      # one pass over both tensors, no (N, F) temporary
                 g_eps = torch.dot(g_out.reshape(-1), x.reshape(-1)).reshape(eps.shape)
             else:

@@ -534,10 +534,12 @@ def test_spmm_sum_with_dropout_equals_spmm_sum_then_hash_dropout(F_, act):
             y = ops.cat_dropout((ops.spmm_sum(csc, x, None, w_dst, eps, bias=b, act=act),), 0.1, 4242)
         (y * gout).sum().backward()
         res.append((y.detach().clone(), x.grad.clone(), eps.grad.clone(), b.grad.clone(), ops.scale_value(y._spgnn_scale[1])))
-    for a, b_ in zip(res[0][:3], res[1][:3]):
+    for a, b_ in zip(res[0][:2], res[1][:2]):
         assert torch.equal(a, b_)
-    # the bias gradient is a column sum taken in a different order by the two forms (spgnn_act_bwd_colsum / torch)
+    # the bias gradient (a column sum) and eps' gradient (a dot product) are summed in a different order by the two forms
+    # (inside spgnn_act_bwd_colsum / by torch)
     assert float((res[0][3] - res[1][3]).abs().max()) <= 2e-6 * float(gout.abs().sum(0).max())
+    assert abs(float(res[0][2]) - float(res[1][2])) <= 2e-6 * float((gout.abs() * x0.abs()).sum())
     assert res[0][4] == res[1][4]
 
 
@@ -594,19 +596,25 @@ def test_act_bwd_colsum_is_act_bwd_plus_column_sums(N, W, act, p):
     assert lib.spgnn_act_bwd_dropout(g.data_ptr(), W, out.data_ptr(), W, ref.data_ptr(), W, 0, N, W, act_c, p, 99, 0, 0) == 0
     nb = lib.spgnn_act_bwd_colsum_blocks(N, W)
     assert nb > 0 and lib.spgnn_act_bwd_colsum_blocks(N, 24) == 0          # 6 float4 per row do not divide 256
+    xd = torch.randn(N, W, device="cuda")
     sums = []
-    for _ in range(2):
+    for rep in range(3):
+        with_dot = rep < 2
         g_pre = torch.empty_like(g)
-        part = torch.full((nb, W), float("nan"), device="cuda")
+        P = W + 4 if with_dot else W
+        part = torch.full((nb, P), float("nan"), device="cuda")
         blk = ops.new_scale_block(g.device)
         assert lib.spgnn_act_bwd_colsum(g.data_ptr(), W, out.data_ptr(), W, g_pre.data_ptr(), W, blk.data_ptr(), part.data_ptr(), N, W,
-                                        act_c, p, 99, 0, 0) == 0
+                                        act_c, p, 99, 0, xd.data_ptr() if with_dot else 0, W if with_dot else 0, 0) == 0
         assert torch.equal(g_pre, ref)
         assert ops.scale_value(blk) == float(ops.pow2_scale(ref))
         sums.append(ops.sum_partials(part))
-    assert torch.equal(sums[0], sums[1])
+    assert torch.equal(sums[0], sums[1]) and torch.equal(sums[0][:W], sums[2])
     want = ref.double().sum(0)
-    assert float((sums[0].double() - want).abs().max()) <= 1e-5 * float(ref.abs().double().sum(0).max())
+    assert float((sums[0][:W].double() - want).abs().max()) <= 1e-5 * float(ref.abs().double().sum(0).max())
+    dot = float((ref.double() * xd.double()).sum())                      # the eps gradient riding along
+    assert abs(float(sums[0][W]) - dot) <= 1e-5 * float((ref.double() * xd.double()).abs().sum())
+    assert float(sums[0][W + 1:].abs().max()) == 0.0
 
 
 def test_emitted_scales_equal_an_absmax_pass():
