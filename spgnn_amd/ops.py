@@ -809,7 +809,12 @@ class _LinearFn(torch.autograd.Function):
                 g_w = gemm_tn(x, g, sx, sg).t()
             else:
                 g_w = gemm_tn(g, x, sg, sx)
-        return g_x, g_w, g_b, None, (g if ctx.has_addend and ctx.needs_input_grad[4] else None), None, g_wcls, g_bcls
+        g_add = None
+        if ctx.has_addend and ctx.needs_input_grad[4]:
+            g_add = g                                    # the addend's producer (the pair's first product) takes it with its scale
+            if sg is not None:
+                g._spgnn_scale = (g._version, sg)
+        return g_x, g_w, g_b, None, g_add, None, g_wcls, g_bcls
 
 
 def linear_drop_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
