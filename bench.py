@@ -115,12 +115,11 @@ def algorithmic_bytes(key) -> float:
     if base == "spmm_sum":
         _, N, E, F = key
         return 4 * 2 * N * F + 4 * (N + 1 + E)
-    if base == "spmm_max_fwd":
+    if base in ("spmm_max_fwd", "spmm_max_bwd"):      # rows in + rows out + the argmax (one byte per element in the compact form)
         _, N, E, F = key
-        return 4 * 3 * N * F + 4 * (N + 1 + E)
-    if base == "spmm_max_bwd":
-        _, N, E, F = key
-        return 4 * 3 * N * F + 4 * (N + 1 + 2 * E)
+        q = F // 4
+        compact = F % 4 == 0 and any(q % t == 0 and q // t in (1, 2, 4, 8) for t in (64, 32, 16))     # spgnn_spmm_max_u8_supported
+        return 4 * 2 * N * F + (1 if compact else 4) * N * F + 4 * (N + 1 + (E if base == "spmm_max_fwd" else 2 * E))
     raise KeyError(name)
 
 

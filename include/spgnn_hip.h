@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 45
+#define SPGNN_ABI_VERSION 46
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -367,6 +367,18 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
                        float* g_x, int64_t g_x_stride,
                        int64_t N, int64_t E, int32_t F,
                        spgnn_stream_t stream);
+
+/* The same pair with a COMPACT argmax: one byte per element = the winner's position inside v's in-edge list (255: none; every
+ * in-degree must be <= 254), rows 4-byte aligned.  The backward pass gathers the arg row of every out-neighbour, so this
+ * quarter-size form is what the training path uses whenever spgnn_spmm_max_u8_supported(F) (F / 4 a whole number of 16-,
+ * 32- or 64-lane teams with 1, 2, 4 or 8 float4 per lane); `indptr` = the CSC offsets the forward call walked. */
+int32_t spgnn_spmm_max_u8_supported(int32_t F);
+int spgnn_spmm_max_fwd_u8(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, float* out,
+                          int64_t out_stride, uint8_t* arg, int64_t arg_stride, int64_t N, int64_t E, int32_t F,
+                          spgnn_stream_t stream);
+int spgnn_spmm_max_bwd_u8(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                          const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                          int64_t g_x_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream);
 
 /*
  * fp32-accurate projection GEMM on the fp16 matrix cores (replaces the cuBLAS/rocBLAS SGEMMs behind

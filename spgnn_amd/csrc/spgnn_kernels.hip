@@ -1766,10 +1766,14 @@ struct SpmmMaxFwd {
   float* out; int64_t out_ld;
   int32_t* arg; int64_t arg_ld;
   int64_t N; int F; int T;
+  uint8_t* arg8;        // compact form (spgnn_spmm_max_fwd_u8): the winner's position INSIDE v's in-edge list, 255 = none
 };
 
-template <int TT, int R>
-__global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec(SpmmMaxFwd a) {
+// U8: the argmax goes out as one byte per element (position inside the destination's in-edge list, in-degree <= 254) instead
+// of the 32-bit CSC slot: the backward pass gathers the arg rows of every out-neighbour, so at 1024 columns the slot form
+// moves 4 KB per edge there (and 315 MB per pass at 76k nodes) where one KB does.
+template <int TT, int R, bool U8>
+__device__ __forceinline__ void spmm_max_fwd_body(const SpmmMaxFwd& a) {
   constexpr bool WAVE = TT == 64;
   const int T = WAVE ? 64 : a.T;
   const int64_t v = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
@@ -1828,9 +1832,17 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec(SpmmMaxFwd a) {
     if (arg[r].z < 0) o.z = 0.f;
     if (arg[r].w < 0) o.w = 0.f;
     st4(a.out + v * a.out_ld + c, o);
-    *reinterpret_cast<int4*>(a.arg + v * a.arg_ld + c) = arg[r];
+    if constexpr (U8) {
+      const unsigned b0 = arg[r].x < 0 ? 255u : (unsigned)(arg[r].x - beg), b1 = arg[r].y < 0 ? 255u : (unsigned)(arg[r].y - beg);
+      const unsigned b2 = arg[r].z < 0 ? 255u : (unsigned)(arg[r].z - beg), b3 = arg[r].w < 0 ? 255u : (unsigned)(arg[r].w - beg);
+      *reinterpret_cast<uint32_t*>(a.arg8 + v * a.arg_ld + c) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    } else {
+      *reinterpret_cast<int4*>(a.arg + v * a.arg_ld + c) = arg[r];
+    }
   }
 }
+template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec(SpmmMaxFwd a) { spmm_max_fwd_body<TT, R, false>(a); }
+template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_fwd_vec_u8(SpmmMaxFwd a) { spmm_max_fwd_body<TT, R, true>(a); }
 
 __global__ void spmm_max_fwd_scalar(SpmmMaxFwd a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1851,10 +1863,11 @@ struct SpmmMaxBwd {
   const int32_t* arg; int64_t arg_ld;
   float* g_x; int64_t g_x_ld;
   int64_t N; int F; int T;
+  const uint8_t* arg8; const int32_t* indptr;     // compact form: positions inside the in-edge lists + the CSC offsets
 };
 
-template <int TT, int R>
-__global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
+template <int TT, int R, bool U8>
+__device__ __forceinline__ void spmm_max_bwd_body(const SpmmMaxBwd& a) {
   constexpr bool WAVE = TT == 64;
   const int T = WAVE ? 64 : a.T;
   const int64_t u = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
@@ -1871,6 +1884,13 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
       vv[k] = uni<WAVE>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
       pp[k] = uni<WAVE>(k < deg ? a.out_pos[beg + (k < deg ? k : deg - 1)] : -2);      // -2 never equals an arg
     }
+    if constexpr (U8) {                              // CSC slot -> position inside the destination's list
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) {
+        const int b = uni<WAVE>(a.indptr[vv[k]]);
+        pp[k] = k < deg ? pp[k] - b : 256;           // 256 never equals a byte
+      }
+    }
     constexpr int kGather = R >= 4 ? 1 : 2;          // two row streams (arg, g_out) per edge
 #pragma unroll
     for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
@@ -1881,7 +1901,12 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int c = (r * T + lane) * 4;
-          ar[q][r] = *reinterpret_cast<const int4*>(a.arg + (int64_t)vv[k0 + q] * a.arg_ld + c);
+          if constexpr (U8) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(a.arg8 + (int64_t)vv[k0 + q] * a.arg_ld + c);
+            ar[q][r] = make_int4((int)(w & 255u), (int)((w >> 8) & 255u), (int)((w >> 16) & 255u), (int)(w >> 24));
+          } else {
+            ar[q][r] = *reinterpret_cast<const int4*>(a.arg + (int64_t)vv[k0 + q] * a.arg_ld + c);
+          }
           g[q][r] = ld4(a.g_out + (int64_t)vv[k0 + q] * a.g_out_ld + c);
         }
 #pragma unroll
@@ -1898,11 +1923,17 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
   } else {
     for (int k = beg; k < end; ++k) {
       const int64_t v = a.out_indices[k];
-      const int pos = a.out_pos[k];
+      const int pos = U8 ? a.out_pos[k] - a.indptr[v] : a.out_pos[k];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int c = (r * T + lane) * 4;
-        const int4 ar = *reinterpret_cast<const int4*>(a.arg + v * a.arg_ld + c);
+        int4 ar;
+        if constexpr (U8) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(a.arg8 + v * a.arg_ld + c);
+          ar = make_int4((int)(w & 255u), (int)((w >> 8) & 255u), (int)((w >> 16) & 255u), (int)(w >> 24));
+        } else {
+          ar = *reinterpret_cast<const int4*>(a.arg + v * a.arg_ld + c);
+        }
         const float4 g = ld4(a.g_out + v * a.g_out_ld + c);
         if (ar.x == pos) acc[r].x += g.x;
         if (ar.y == pos) acc[r].y += g.y;
@@ -1914,6 +1945,8 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) st4(a.g_x + u * a.g_x_ld + (r * T + lane) * 4, acc[r]);
 }
+template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) { spmm_max_bwd_body<TT, R, false>(a); }
+template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec_u8(SpmmMaxBwd a) { spmm_max_bwd_body<TT, R, true>(a); }
 
 __global__ void spmm_max_bwd_scalar(SpmmMaxBwd a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3327,7 +3360,7 @@ int spgnn_spmm_max_fwd(const int32_t* indptr, const int32_t* indices, const floa
   if (!indptr || !x || !out || !arg || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_fwd: null pointer");
   if (x_stride < F || out_stride < F || arg_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_fwd: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmMaxFwd a{indptr, indices, x, x_stride, out, out_stride, arg, arg_stride, N, F, 0};
+  SpmmMaxFwd a{indptr, indices, x, x_stride, out, out_stride, arg, arg_stride, N, F, 0, nullptr};
   int T, R;
   if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && vec_ok(arg, arg_stride)) {
     a.T = T;
@@ -3348,7 +3381,7 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   if (g_out_stride < F || arg_stride < F || g_x_stride < F)
     return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0};
+  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0, nullptr, nullptr};
   int T, R;
   if (pick_team(F, T, R) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
     a.T = T;
@@ -3357,6 +3390,39 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
     hipLaunchKernelGGL(spmm_max_bwd_scalar, dim3(scalar_grid(N * F)), dim3(kBlock), 0, st, a);
   }
   return check_launch("spgnn_spmm_max_bwd");
+}
+
+int32_t spgnn_spmm_max_u8_supported(int32_t F) { int T, R; return pick_team(F, T, R) ? 1 : 0; }
+
+int spgnn_spmm_max_fwd_u8(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, float* out,
+                          int64_t out_stride, uint8_t* arg, int64_t arg_stride, int64_t N, int64_t E, int32_t F,
+                          spgnn_stream_t stream) {
+  int T, R;
+  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_fwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !x || !out || !arg || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_fwd_u8: null pointer");
+  if (x_stride < F || out_stride < F || arg_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_fwd_u8: row stride smaller than row");
+  if (!vec_ok(x, x_stride) || !vec_ok(out, out_stride) || (reinterpret_cast<uintptr_t>(arg) & 3) || (arg_stride & 3))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_fwd_u8: rows must be 16-byte (arg: 4-byte) aligned");
+  SpmmMaxFwd a{indptr, indices, x, x_stride, out, out_stride, nullptr, arg_stride, N, F, T, arg};
+  DISPATCH_R(T, R, spmm_max_fwd_vec_u8, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return check_launch("spgnn_spmm_max_fwd_u8");
+}
+
+int spgnn_spmm_max_bwd_u8(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                          const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                          int64_t g_x_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
+  int T, R;
+  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_bwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
+  if (N == 0) return SPGNN_OK;
+  if (!indptr || !out_indptr || !g_out || !arg || !g_x || (E > 0 && (!out_indices || !out_pos)))
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_bwd_u8: null pointer");
+  if (g_out_stride < F || arg_stride < F || g_x_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd_u8: row stride smaller than row");
+  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_x, g_x_stride) || (reinterpret_cast<uintptr_t>(arg) & 3) || (arg_stride & 3))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd_u8: rows must be 16-byte (arg: 4-byte) aligned");
+  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, nullptr, arg_stride, g_x, g_x_stride, N, F, T, arg, indptr};
+  DISPATCH_R(T, R, spmm_max_bwd_vec_u8, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return check_launch("spgnn_spmm_max_bwd_u8");
 }
 
 }  // extern "C"

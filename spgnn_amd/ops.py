@@ -2250,18 +2250,27 @@ def spmm_sum(csc: DeviceCSC, x, w_src=None, w_dst=None, eps=None, bias=None, act
     return out
 
 
+COMPACT_MAX_ARG = True   # spmm_max keeps its argmax as one byte per element (position inside the in-edge list) when it can
+
+
 class _SpmmMaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, csc: DeviceCSC):
         x = _rowmajor(x)
         N, E, F_ = csc.num_nodes, csc.num_edges, x.shape[1]
         out = torch.empty((N, F_), dtype=torch.float32, device=x.device)
-        arg = torch.empty((N, F_), dtype=torch.int32, device=x.device)
         lib = _capi.load()
+        ctx.u8 = bool(COMPACT_MAX_ARG and csc.max_in_degree <= 254 and _rows_aligned(x) and lib.spgnn_spmm_max_u8_supported(F_))
+        arg = torch.empty((N, F_), dtype=torch.uint8 if ctx.u8 else torch.int32, device=x.device)
         with torch.cuda.device(x.device), _timed("spmm_max_fwd", (N, E, F_)):
-            _capi.check(lib.spgnn_spmm_max_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
-                                               out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
-                                               _stream(x)), "spgnn_spmm_max_fwd")
+            if ctx.u8:
+                _capi.check(lib.spgnn_spmm_max_fwd_u8(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                      out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
+                                                      _stream(x)), "spgnn_spmm_max_fwd_u8")
+            else:
+                _capi.check(lib.spgnn_spmm_max_fwd(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                   out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
+                                                   _stream(x)), "spgnn_spmm_max_fwd")
         ctx.csc = csc
         ctx.save_for_backward(arg)
         return out
@@ -2272,13 +2281,21 @@ class _SpmmMaxFn(torch.autograd.Function):
         csc = ctx.csc
         g_out = _rowmajor(g_out)
         N, E, F_ = csc.num_nodes, csc.num_edges, g_out.shape[1]
-        g_x = torch.empty((N, F_), dtype=torch.float32, device=g_out.device)
         lib = _capi.load()
+        if ctx.u8 and not _rows_aligned(g_out):
+            g_out = g_out.contiguous()
+        g_x = torch.empty((N, F_), dtype=torch.float32, device=g_out.device)
         with torch.cuda.device(g_out.device), _timed("spmm_max_bwd", (N, E, F_)):
-            _capi.check(lib.spgnn_spmm_max_bwd(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                               csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0),
-                                               arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,
-                                               _stream(g_out)), "spgnn_spmm_max_bwd")
+            if ctx.u8:
+                _capi.check(lib.spgnn_spmm_max_bwd_u8(csc.indptr.data_ptr(), csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                      csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0),
+                                                      arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,
+                                                      _stream(g_out)), "spgnn_spmm_max_bwd_u8")
+            else:
+                _capi.check(lib.spgnn_spmm_max_bwd(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                   csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0),
+                                                   arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,
+                                                   _stream(g_out)), "spgnn_spmm_max_bwd")
         return g_x, None
 
 

@@ -363,6 +363,34 @@ def test_spmm_sum_and_max_vs_oracle(F_):
     assert rel_err(x.grad, xo.grad) < GRAD_TOL
 
 
+@pytest.mark.parametrize("F_", [64, 128, 256, 1024, 32])        # 32: eight float4 per row, no team shape - slot form
+def test_spmm_max_compact_argmax_equals_the_slot_form(F_, monkeypatch):
+    """The one-byte argmax (position inside the in-edge list, spgnn_spmm_max_fwd_u8 / _bwd_u8) routes every gradient exactly as
+    the 32-bit CSC-slot form: values and gradients bit for bit - on trees, on a 70-child star (degree loop), with every edge
+    tied, and with a node of in-degree 300 (no compact form: the op falls back by itself)."""
+    torch.manual_seed(F_)
+    star = lambda k: (np.concatenate([np.zeros(k, np.int64), np.arange(1, k + 1), np.arange(k + 1)]),
+                      np.concatenate([np.arange(1, k + 1), np.zeros(k, np.int64), np.arange(k + 1)]), k + 1)
+    s70, d70, n70 = star(70)
+    s300, d300, n300 = star(300)
+    graphs = [_graph([150, 33, 1, 90], seed=F_)[0], TreeGraph((s70, d70), n70).to("cuda"), TreeGraph((s300, d300), n300).to("cuda")]
+    for gi, g in enumerate(graphs):
+        csc = g.csc()
+        n = csc.num_nodes
+        for tied in (False, True):
+            x0 = torch.ones(n, F_, device="cuda") if tied else torch.randn(n, F_, device="cuda").round(decimals=1)   # some ties too
+            cot = torch.randn(n, F_, device="cuda")
+            res = []
+            for compact in (True, False):
+                monkeypatch.setattr(ops, "COMPACT_MAX_ARG", compact)
+                x = x0.clone().requires_grad_(True)
+                y = ops.spmm_max(csc, x)
+                assert y.grad_fn.u8 == bool(compact and gi < 2 and ops._capi.load().spgnn_spmm_max_u8_supported(F_))
+                (y * cot).sum().backward()
+                res.append((y.detach().clone(), x.grad.clone()))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_spmm_max_ties_go_to_one_edge():
     g, src, dst, n = _graph([40], seed=2)
     x = torch.ones(n, 64, device="cuda", requires_grad=True)                     # every in-edge ties
