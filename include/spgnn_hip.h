@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 46
+#define SPGNN_ABI_VERSION 47
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -774,6 +774,16 @@ int spgnn_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
 int spgnn_weight_cat_bf16(const float* w_a, int64_t a_stride, int32_t rows_a, const float* w_b, int64_t b_stride,
                           int32_t rows_b, int32_t K, uint16_t* w, int64_t w_stride, uint16_t* w_t, int64_t w_t_stride,
                           spgnn_stream_t stream);
+
+/* The same for every projection layer of a forward pass in ONE launch.  `jobs`: a DEVICE table, one entry per layer (fields =
+ * the arguments above; tiles_x from spgnn_weight_cat_bf16_blocks, first_block = the running sum of that function's results,
+ * total_blocks = the final sum).  Results are bit-identical to n_jobs single calls. */
+typedef struct spgnn_weight_cat_bf16_job {
+  const float* a; int64_t a_stride; const float* b; int64_t b_stride; uint16_t* w; int64_t w_stride; uint16_t* w_t; int64_t w_t_stride;
+  int32_t rows_a; int32_t rows_b; int32_t K; int32_t first_block; int32_t tiles_x; int32_t reserved;
+} spgnn_weight_cat_bf16_job;
+int32_t spgnn_weight_cat_bf16_blocks(int32_t rows, int32_t K, int64_t w_stride, int64_t w_t_stride /* 0: no transpose */, int32_t* tiles_x);
+int spgnn_weight_cat_bf16_multi(const spgnn_weight_cat_bf16_job* jobs, int32_t n_jobs, int32_t total_blocks, spgnn_stream_t stream);
 
 /* x (N, K) fp32 -> y (N, y_stride) bf16 (round to nearest even), columns [K, y_stride) zero: node data (fvs, pos_enc)
  * converted once per loader batch. */

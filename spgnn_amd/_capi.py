@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -56,6 +56,12 @@ class SumJob(C.Structure):               # spgnn_sum_job
     _fields_ = [("kind", _i32), ("splits", _i32), ("partials", _vp), ("split_stride", _i64), ("out", _vp), ("out_stride", _i64),
                 ("n", _i64), ("H", _i32), ("D", _i32), ("ld", _i32), ("M", _i32), ("N", _i32), ("split_col", _i32), ("ld_in", _i64),
                 ("out2", _vp), ("out2_stride", _i64), ("extra", _vp), ("extra_col", _i32), ("reserved", _i32)]
+
+
+class WeightCatBf16Job(C.Structure):     # spgnn_weight_cat_bf16_job
+    _fields_ = [("a", _vp), ("a_stride", _i64), ("b", _vp), ("b_stride", _i64), ("w", _vp), ("w_stride", _i64), ("w_t", _vp),
+                ("w_t_stride", _i64), ("rows_a", _i32), ("rows_b", _i32), ("K", _i32), ("first_block", _i32), ("tiles_x", _i32),
+                ("reserved", _i32)]
 
 
 class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
@@ -171,6 +177,8 @@ SIGNATURES = {
     "spgnn_gemm_nt_bf16_tile": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _f32p, _i32, _f32p, _f32p, _f32p, _i32, _i32, _vp],
     "spgnn_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _i64, _i64, _vp],
     "spgnn_weight_cat_bf16": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp],
+    "spgnn_weight_cat_bf16_blocks": [_i32, _i32, _i64, _i64, _vp],
+    "spgnn_weight_cat_bf16_multi": [_vp, _i32, _i32, _vp],
     "spgnn_cast_rows_bf16": [_f32p, _i64, _i64, _i32, _vp, _i64, _vp],
 }
 

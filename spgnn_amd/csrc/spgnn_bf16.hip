@@ -472,13 +472,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16(ArgsTN a) {
 
 // [w_a ; w_b] (fp32 parameters, row blocks) -> bf16 operand W (R, ldw) and, optionally, its transpose (K, ldt); pad
 // columns are written as zeros.  One 32 x 32 tile per block through LDS.
-__global__ __launch_bounds__(256) void weight_cat_bf16_kernel(const float* __restrict__ A, int64_t lda, int ra,
-                                                              const float* __restrict__ B, int64_t ldb, int rb, int K,
-                                                              uint16_t* __restrict__ W, int64_t ldw,
-                                                              uint16_t* __restrict__ Wt, int64_t ldt) {
-  __shared__ float tile[32][33];
+__device__ __forceinline__ void weight_cat_bf16_tile(const float* __restrict__ A, int64_t lda, int ra,
+                                                     const float* __restrict__ B, int64_t ldb, int rb, int K,
+                                                     uint16_t* __restrict__ W, int64_t ldw,
+                                                     uint16_t* __restrict__ Wt, int64_t ldt, int r0, int k0, float (*tile)[33]) {
   const int R = ra + rb;
-  const int r0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -501,6 +499,26 @@ __global__ __launch_bounds__(256) void weight_cat_bf16_kernel(const float* __res
       Wt[(int64_t)k * ldt + r] = *reinterpret_cast<const uint16_t*>(&h);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void weight_cat_bf16_kernel(const float* __restrict__ A, int64_t lda, int ra,
+                                                              const float* __restrict__ B, int64_t ldb, int rb, int K,
+                                                              uint16_t* __restrict__ W, int64_t ldw,
+                                                              uint16_t* __restrict__ Wt, int64_t ldt) {
+  __shared__ float tile[32][33];
+  weight_cat_bf16_tile(A, lda, ra, B, ldb, rb, K, W, ldw, Wt, ldt, blockIdx.y * 32, blockIdx.x * 32, tile);
+}
+
+// every projection layer's operands in ONE launch: block b belongs to the job whose [first_block, next first_block) holds it
+// (a handful of jobs: linear scan), and is tile (b' % tiles_x, b' / tiles_x) of that job - the arithmetic of the single kernel
+__global__ __launch_bounds__(256) void weight_cat_bf16_multi_kernel(const spgnn_weight_cat_bf16_job* __restrict__ jobs, int n_jobs) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+  const spgnn_weight_cat_bf16_job q = jobs[j];
+  const int local = (int)blockIdx.x - q.first_block;
+  weight_cat_bf16_tile(q.a, q.a_stride, q.rows_a, q.b, q.b_stride, q.rows_b, q.K, q.w, q.w_stride, q.w_t, q.w_t_stride,
+                       (local / q.tiles_x) * 32, (local % q.tiles_x) * 32, tile);
 }
 
 // x (N, K) fp32 -> y (N, ldy) bf16, columns [K, ldy) zero
@@ -620,6 +638,21 @@ int spgnn_weight_cat_bf16(const float* a, int64_t a_stride, int32_t rows_a, cons
   hipLaunchKernelGGL(weight_cat_bf16_kernel, dim3((unsigned)((kmax + 31) / 32), (unsigned)((rmax + 31) / 32)), dim3(256), 0,
                      (hipStream_t)stream, a, a_stride, rows_a, b, b_stride, rows_b, K, w, w_stride, w_t, w_t_stride);
   return check_launch("spgnn_weight_cat_bf16");
+}
+
+int32_t spgnn_weight_cat_bf16_blocks(int32_t rows, int32_t K, int64_t w_stride, int64_t w_t_stride, int32_t* tiles_x) {
+  const int64_t kmax = w_stride > K ? w_stride : K, rmax = w_t_stride > rows ? w_t_stride : rows;
+  const int32_t tx = (int32_t)((kmax + 31) / 32), ty = (int32_t)((rmax + 31) / 32);
+  if (tiles_x) *tiles_x = tx;
+  return tx * ty;
+}
+
+int spgnn_weight_cat_bf16_multi(const spgnn_weight_cat_bf16_job* jobs, int32_t n_jobs, int32_t total_blocks, spgnn_stream_t stream) {
+  using namespace bfg;
+  if (n_jobs <= 0 || total_blocks <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_weight_cat_bf16_multi: bad n_jobs / total_blocks");
+  if (!jobs) return fail(SPGNN_ERR_NULLPTR, "spgnn_weight_cat_bf16_multi: null pointer");
+  hipLaunchKernelGGL(weight_cat_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, (int)n_jobs);
+  return check_launch("spgnn_weight_cat_bf16_multi");
 }
 
 int spgnn_cast_rows_bf16(const float* x, int64_t x_stride, int64_t N, int32_t K, uint16_t* y, int64_t y_stride,

@@ -212,7 +212,8 @@ class GAT(nn.Module):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))`` with the classifier
         joined to the output layer's autograd node (not with ``norm``: the normalisation sits in between)."""
         h = _data_in(g, g.ndata["fvs"], self.storage_dtype)
-        with ops.prepared_weights(_prep_specs(self.gat_layers[:-1], h.is_cuda and h.dtype == torch.float32, output=self.gat_layers[-1])):
+        with ops.prepared_weights(_prep_specs(self.gat_layers[:-1], h.is_cuda and h.dtype == torch.float32, output=self.gat_layers[-1])), \
+                ops_bf16.prepared_weights(_prep_specs(self.gat_layers[:-1], h.is_cuda and h.dtype == torch.bfloat16)):
             return self._forward(g, h, classifier)
 
     def _forward(self, g, h, classifier):

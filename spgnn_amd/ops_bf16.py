@@ -68,8 +68,86 @@ def cast_rows(x: torch.Tensor) -> torch.Tensor:
     return out[:, :K]
 
 
+class _WeightPrepBf16:
+    """Persistent bf16 operand buffers and the device job table of spgnn_weight_cat_bf16_multi for one list of layers."""
+
+    def __init__(self, specs, device):
+        import ctypes
+        lib = _capi.load()
+        self.n = len(specs)
+        tab = (_capi.WeightCatBf16Job * self.n)()
+        self.entries, first = [], 0
+        for i, (w_a, w_b, want_t) in enumerate(specs):
+            R1, K = w_a.shape
+            R2 = 0 if w_b is None else w_b.shape[0]
+            R = R1 + R2
+            w = torch.empty((R, _pad8(K)), dtype=BF16, device=device)
+            w_t = torch.empty((K, _pad8(R)), dtype=BF16, device=device) if want_t else None
+            t = tab[i]
+            t.a, t.a_stride = w_a.data_ptr(), w_a.stride(0)
+            t.b, t.b_stride = (w_b.data_ptr(), w_b.stride(0)) if w_b is not None else (0, 0)
+            t.w, t.w_stride = w.data_ptr(), w.stride(0)
+            t.w_t, t.w_t_stride = (w_t.data_ptr(), w_t.stride(0)) if want_t else (0, 0)
+            t.rows_a, t.rows_b, t.K, t.first_block = R1, R2, K, first
+            tx = ctypes.c_int32(0)
+            first += int(lib.spgnn_weight_cat_bf16_blocks(R, K, w.stride(0), w_t.stride(0) if want_t else 0, ctypes.addressof(tx)))
+            t.tiles_x = tx.value
+            self.entries.append((w[:, :K], w_t[:, :R] if want_t else None))
+        self.blocks = first
+        self.table = torch.frombuffer(bytearray(bytes(memoryview(tab))), dtype=torch.uint8).to(device)
+
+    def run(self):
+        with torch.cuda.device(self.table.device):
+            _capi.check(_capi.load().spgnn_weight_cat_bf16_multi(self.table.data_ptr(), self.n, self.blocks, _stream(self.table)),
+                        "spgnn_weight_cat_bf16_multi")
+
+
+_PREP_CACHE: dict = {}       # layout key -> _WeightPrepBf16 (buffers and table are reused by every forward pass)
+_PREP_ACTIVE: dict = {}      # (id(w_a), id(w_b)) -> ((w, w_t), want_t): installed for the duration of one model forward
+BATCH_WEIGHT_PREP = True     # every project-first layer's bf16 operands in one launch per forward; False: one launch per layer
+
+
+class prepared_weights:
+    """``with prepared_weights(specs):`` - ``specs`` = [(w_a, w_b or None, want_t), ...] of the project-first GATConv layers a
+    forward pass will run on bf16 rows: ONE spgnn_weight_cat_bf16_multi launch builds all their operands (bit-identical to one
+    spgnn_weight_cat_bf16 per layer); inside the block :func:`weight_operands` hands them out without launching anything.
+    Values are those of the parameters at entry (the block must not update them)."""
+
+    def __init__(self, specs):
+        self.specs = [tuple(sp[:3]) for sp in specs if len(sp) == 3 and sp[0].is_cuda and sp[0].dtype == torch.float32
+                      and sp[0].stride(1) == 1 and (sp[1] is None or sp[1].stride(1) == 1)] if BATCH_WEIGHT_PREP else []
+        self.prev = None
+
+    def __enter__(self):
+        global _PREP_ACTIVE
+        self.prev = _PREP_ACTIVE
+        if not self.specs:
+            return self
+        dev = self.specs[0][0].device
+        key = (str(dev),) + tuple((a.data_ptr(), a.stride(0), tuple(a.shape), 0 if b is None else b.data_ptr(),
+                                   0 if b is None else b.stride(0), None if b is None else tuple(b.shape), bool(t))
+                                  for a, b, t in self.specs)
+        prep = _PREP_CACHE.get(key)
+        if prep is None:
+            if len(_PREP_CACHE) > 8:
+                _PREP_CACHE.clear()
+            prep = _PREP_CACHE[key] = _WeightPrepBf16(self.specs, dev)
+        prep.run()
+        _PREP_ACTIVE = {(id(a), id(b) if b is not None else 0): (e, bool(t)) for (a, b, t), e in zip(self.specs, prep.entries)}
+        return self
+
+    def __exit__(self, *exc):
+        global _PREP_ACTIVE
+        _PREP_ACTIVE = self.prev
+        return False
+
+
 def weight_operands(w_a: torch.Tensor, w_b: Optional[torch.Tensor], want_t: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """[w_a ; w_b] (fp32 parameters) -> (W (R, K) bf16 rows, W^T (K, R) bf16 rows or None): one kernel per layer and step."""
+    """[w_a ; w_b] (fp32 parameters) -> (W (R, K) bf16 rows, W^T (K, R) bf16 rows or None): from the forward pass's
+    :class:`prepared_weights` launch when there is one, else one kernel per layer and step."""
+    hit = _PREP_ACTIVE.get((id(w_a), id(w_b) if w_b is not None else 0))
+    if hit is not None and (hit[1] or not want_t):
+        return hit[0][0], (hit[0][1] if want_t else None)
     R1, K = w_a.shape
     R2 = 0 if w_b is None else w_b.shape[0]
     R = R1 + R2

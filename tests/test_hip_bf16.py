@@ -140,6 +140,26 @@ def test_weight_operands_and_cast():
     assert torch.equal(xb.cpu(), x.to(BF)) and xb.stride(0) == 40 and float(xb._base[:, 39:].abs().max()) == 0.0
 
 
+def test_prepared_weights_bf16_one_launch_equals_one_per_layer():
+    """ops_bf16.prepared_weights: every project-first layer's bf16 operands from ONE spgnn_weight_cat_bf16_multi launch, bit for
+    bit those of a spgnn_weight_cat_bf16 call per layer (ragged widths, with and without a second block / a transpose); inside
+    the block weight_operands launches nothing and hands out the prepared buffers."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [((512, 1063), (512, 1063), False), ((256, 1024), (256, 1024), True), ((128, 128), None, True), ((96, 39), (40, 39), True),
+              ((64, 250), None, False)]
+    ws = [(torch.randn(a, generator=g).cuda(), None if b is None else torch.randn(b, generator=g).cuda(), t) for a, b, t in shapes]
+    single = [ops_bf16.weight_operands(a, b, t) for a, b, t in ws]
+    with ops_bf16.prepared_weights(ws):
+        for (a, b, t), (w1, t1) in zip(ws, single):
+            w, wt = ops_bf16.weight_operands(a, b, t)
+            assert (id(a), id(b) if b is not None else 0) in ops_bf16._PREP_ACTIVE
+            assert torch.equal(w, w1) and ops_bf16.rows_ok(w) and torch.equal(w._base, w1._base)      # pad columns too
+            assert (wt is None) == (not t) and (wt is None or (torch.equal(wt, t1) and torch.equal(wt._base, t1._base)))
+            if t:                                                   # a transpose prepared but not asked for
+                assert ops_bf16.weight_operands(a, b, False)[1] is None
+    assert not ops_bf16._PREP_ACTIVE
+
+
 def test_cat_dropout_bf16_matches_fp32_mask():
     """Same counter hash as the fp32 kernel: equal keep masks; backward multiplies by the same mask."""
     N, w1, w2, p, seed = 257, 64, 128, 0.3, 1234

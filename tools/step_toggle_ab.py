@@ -2,9 +2,9 @@
 usage: step_toggle_ab.py <trees> name=module.ATTR:value[,module.ATTR:value] ...   (e.g. base= lspe_off=models.FUSE_LSPE:0)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spgnn_amd import models, ops, nn as snn, synthetic, train
+from spgnn_amd import models, ops, ops_bf16, nn as snn, synthetic, train
 from spgnn_amd.configs import class_weight_list, get_config
-mods = {"models": models, "ops": ops, "nn": snn, "train": train}
+mods = {"models": models, "ops": ops, "ops_bf16": ops_bf16, "nn": snn, "train": train}
 trees = int(sys.argv[1])
 cfgname = os.environ.get("CONFIG", "st_pgat_spgnn_3")
 variants = []
