@@ -37,7 +37,12 @@ __device__ __attribute__((aligned(16))) uint16_t g_zero_chunk[8];
 
 constexpr int BN = 128;          // tile columns (2 waves x 64)
 constexpr int SUB = 32;          // elements per LDS sub-image row (64 bytes), two k16 MFMA steps
-constexpr int KSUB = 2;          // sub-images per stage: BK = 64 elements per barrier
+// One 32-element sub-image per stage and three stage buffers: two stages of DMA are in flight while one is consumed.  With
+// two sub-images per stage and two buffers (round 2) the 1024 -> 1024 product took 183 us, with this 174; 512 -> 512 61 / 58;
+// 384 -> 1024 97 / 92; four buffers 173 / 61 / 97 (tools/gemm_bf16_ab.py, one process; results bit-identical: the k order
+// does not change).
+constexpr int KSUB = 1;          // sub-images per stage: BK = 32 KSUB elements per barrier
+constexpr int NBUF = 3;          // LDS stage buffers: NBUF - 1 stages of DMA in flight while one is consumed
 
 struct ArgsNT {
   const uint16_t* A; int64_t lda;
@@ -115,7 +120,7 @@ __device__ __forceinline__ bf16x8 frag_swz(const uint16_t* img, int row, int chu
 }
 
 template <int WM, int WN, int MI> constexpr int nt_lds_bytes() {
-  const int stages = 2 * KSUB * (32 * MI * WM * SUB + 64 * WN * SUB) * 2, slabs = WM * WN * 32 * 68 * 4;
+  const int stages = NBUF * KSUB * (32 * MI * WM * SUB + 64 * WN * SUB) * 2, slabs = WM * WN * 32 * 68 * 4;
   return stages > slabs ? stages : slabs;
 }
 
@@ -152,22 +157,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_
   const int nk = (a.K + KSUB * SUB - 1) / (KSUB * SUB);
 #define SPGNN_STAGE_IN(T_)                                                                                   \
   {                                                                                                          \
-    uint16_t* sb_ = smem + ((T_) & 1) * STAGE;                                                               \
+    uint16_t* sb_ = smem + ((T_) % NBUF) * STAGE;                                                            \
     _Pragma("unroll") for (int u_ = 0; u_ < KSUB; ++u_) {                                                    \
       stage_image<TBM, NT>(a.A, a.lda, row0, a.M, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG)); \
       stage_image<TBN, NT>(a.B, a.ldb, col0, a.N, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG) + A_IMG); \
     }                                                                                                        \
   }
-  SPGNN_STAGE_IN(0)
+  constexpr int P = NBUF - 1;                               // stages in flight ahead of the one being consumed
+#pragma unroll
+  for (int p_ = 0; p_ < P; ++p_)
+    if (p_ < nk) SPGNN_STAGE_IN(p_)
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) {
-      SPGNN_STAGE_IN(t + 1)                                 // next stage in flight while this one is consumed
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    if (t + P < nk) {
+      SPGNN_STAGE_IN(t + P)                                 // into the buffer the previous iteration consumed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * P) : "memory");   // all but the newest P stages have landed: stage t is there
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                           // every wave's pieces of stage t have landed
-    const uint16_t* cb = smem + (t & 1) * STAGE;
+    const uint16_t* cb = smem + (t % NBUF) * STAGE;
 #pragma unroll
     for (int u = 0; u < KSUB; ++u) {
       const uint16_t* ai = cb + u * (A_IMG + B_IMG);

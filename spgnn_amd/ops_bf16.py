@@ -188,7 +188,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 def _tn_splits(R: int, M: int, N: int) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, min(64, 512 // tiles, R // 256))
+    splits = max(1, min(128, 512 // tiles, R // 256))       # one- to four-tile products: 128 row ranges (256 x 128: 27 -> 22 us; tools/tn_splits_bf16.py)
     if splits >= 8 or tiles >= 16:          # one split per XCD (see ops.gemm_tn)
         splits = 32 if tiles >= 16 and R >= 32 * 512 else (splits // 8 * 8 if splits >= 8 else splits)
         if tiles >= 64 and splits == 32:       # 1024 x 1024: 16 splits 232 us, 32: 244 (tools/tn_splits_bf16.py): the partial tiles weigh more

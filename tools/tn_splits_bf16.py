@@ -9,11 +9,11 @@ def t_once(fn, iters=10):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters
-for (M, N) in [(1024, 1024), (1024, 384), (512, 512), (256, 256), (256, 128)]:
+for (M, N) in [(1024, 1024), (512, 512), (256, 256), (256, 128), (128, 128)]:
     g = ops_bf16.cast_rows(torch.randn(R, M, device="cuda") * 1e-3)
     x = ops_bf16.cast_rows(torch.randn(R, N, device="cuda"))
     res = {}
-    for sp in (8, 16, 24, 32, 48, 64):
+    for sp in (16, 32, 64, 96, 128, 192, 256):
         fn = lambda: ops_bf16.gemm_tn(g, x, splits=sp)
         fn(); fn()
         ts = sorted(t_once(fn) for _ in range(5))
