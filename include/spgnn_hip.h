@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 47
+#define SPGNN_ABI_VERSION 48
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -758,6 +758,13 @@ int spgnn_gemm_nt_bf16_tile(const uint16_t* A, int64_t lda, const uint16_t* B, i
                             int32_t c_is_f32, int64_t M, int64_t N, int64_t K, const float* bias, int32_t activation,
                             const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                             int32_t tile, spgnn_stream_t stream);
+/* The product with score partials and the LAYOUT of score_out named: 0 = (M, score_cols / 64, 2) partial pairs as above;
+ * 1 = (M, 2 * score_cols / 64) rows [el_0 .. el_{H-1} | er_0 .. er_{H-1}] - for layers whose heads are exactly one 64-column
+ * block wide (D = 64: the five 2 x 64 layers of st_gat_6, reference exp_settings/st_gat_6.py:81-106) the dots ARE el / er and
+ * go straight where spgnn_gat_fwd_bf16 reads them: no spgnn_scores_from_parts launch. */
+int spgnn_gemm_nt_bf16_scores(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
+                              int32_t c_is_f32, int64_t M, int64_t N, int64_t K, const float* score_l, const float* score_r,
+                              float* score_out, int32_t score_cols, int32_t score_layout, spgnn_stream_t stream);
 
 /*
  * Weight gradients: partial[s] (M, N; row stride ldc; fp32) = A[rows of split s, :M]^T * B[rows of split s, :N] for

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -175,6 +175,7 @@ SIGNATURES = {
     "spgnn_cat_dropout_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _vp],
     "spgnn_gemm_nt_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
     "spgnn_gemm_nt_bf16_tile": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _f32p, _i32, _f32p, _f32p, _f32p, _i32, _i32, _vp],
+    "spgnn_gemm_nt_bf16_scores": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i32, _i32, _vp],
     "spgnn_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _f32p, _i64, _i64, _i32, _i64, _i64, _i64, _f32p, _i64, _i64, _vp],
     "spgnn_weight_cat_bf16": [_f32p, _i64, _i32, _f32p, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp],
     "spgnn_weight_cat_bf16_blocks": [_i32, _i32, _i64, _i64, _vp],

@@ -52,6 +52,7 @@ struct ArgsNT {
   int nbm, nbn;
   const float* bias; int act;
   const float* sc_l; const float* sc_r; float* sc_out; int sc_cols;
+  int sc_direct;                  // 1: one 64-column block per head - the dots go straight into the (M, 2H) [el | er] rows
 };
 
 __device__ __forceinline__ float elu_nb(float x) {          // same function as spgnn_gemm.hip's elu_fwd_nb
@@ -257,7 +258,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_
           float pr = s_.x * sr.x + s_.y * sr.y + s_.z * sr.z + s_.w * sr.w;
           pl = row16_sum(pl); pr = row16_sum(pr);
           if ((lane & 15) == 0)
-            *reinterpret_cast<float2*>(a.sc_out + (row * (a.sc_cols >> 6) + (col >> 6)) * 2) = make_float2(pl, pr);
+{
+            const int nb_ = a.sc_cols >> 6, b_ = col >> 6;
+            if (a.sc_direct) { float* p_ = a.sc_out + (int64_t)row * (2 * nb_); p_[b_] = pl; p_[nb_ + b_] = pr; }
+            else *reinterpret_cast<float2*>(a.sc_out + ((int64_t)row * nb_ + b_) * 2) = make_float2(pl, pr);
+          }
         }
         if (F32OUT) {
           typedef float f4v __attribute__((ext_vector_type(4)));
@@ -287,7 +292,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_
         float pr = s_.x * sr.x + s_.y * sr.y + s_.z * sr.z + s_.w * sr.w;
         pl = row16_sum(pl); pr = row16_sum(pr);
         if ((lane & 15) == 0 && row < a.M)
-          *reinterpret_cast<float2*>(a.sc_out + ((int64_t)row * (a.sc_cols >> 6) + (col >> 6)) * 2) = make_float2(pl, pr);
+{
+          const int nb_ = a.sc_cols >> 6, b_ = col >> 6;
+          if (a.sc_direct) { float* p_ = a.sc_out + (int64_t)row * (2 * nb_); p_[b_] = pl; p_[nb_ + b_] = pr; }
+          else *reinterpret_cast<float2*>(a.sc_out + ((int64_t)row * nb_ + b_) * 2) = make_float2(pl, pr);
+        }
       }
       if (row < a.M && col_ok) {
         if (F32OUT) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (int64_t)row * a.ldc + col) = v;
@@ -549,8 +558,10 @@ extern "C" {
 
 static int gemm_nt_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
                              int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
-                             const float* score_r, float* score_out, int32_t score_cols, int32_t tile, spgnn_stream_t stream) {
+                             const float* score_r, float* score_out, int32_t score_cols, int32_t tile, int32_t score_layout,
+                             spgnn_stream_t stream) {
   using namespace bfg;
+  if (score_layout != 0 && score_layout != 1) return fail(SPGNN_ERR_ENUM, "spgnn_gemm_nt_bf16: score_layout must be 0 or 1");
   if (tile != 0 && tile != 2 && tile != 4 && tile != 5) return fail(SPGNN_ERR_ENUM, "spgnn_gemm_nt_bf16: tile must be 0, 2, 4 or 5");
   if (M < 0 || N <= 0 || K <= 0 || N > (1 << 24) || K > (1 << 24)) return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_bf16: bad M/N/K");
   if (M == 0) return SPGNN_OK;
@@ -579,7 +590,7 @@ static int gemm_nt_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, 
   const int64_t nbm = (M + tbm - 1) / tbm;
   if (nbm * nbn > (1ll << 30)) return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_bf16: too many tiles");
   ArgsNT a{A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)K8, (int)nbm, (int)nbn, bias, act, score_l, score_r, score_out,
-           score_out ? score_cols : 0};
+           score_out ? score_cols : 0, score_layout};
   const unsigned grid = (unsigned)((nbm * nbn + 7) / 8 * 8);
   hipStream_t st = (hipStream_t)stream;
 #define SPGNN_NT_LAUNCH(WM_, WN_, MI_, F32_)                                                                  \
@@ -603,13 +614,20 @@ static int gemm_nt_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, 
 int spgnn_gemm_nt_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
                        int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
                        const float* score_r, float* score_out, int32_t score_cols, spgnn_stream_t stream) {
-  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, 0, stream);
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, 0, 0, stream);
 }
 
 int spgnn_gemm_nt_bf16_tile(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
                             int64_t M, int64_t N, int64_t K, const float* bias, int32_t act, const float* score_l,
                             const float* score_r, float* score_out, int32_t score_cols, int32_t tile, spgnn_stream_t stream) {
-  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, tile, stream);
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, bias, act, score_l, score_r, score_out, score_cols, tile, 0, stream);
+}
+
+int spgnn_gemm_nt_bf16_scores(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc, int32_t c_is_f32,
+                              int64_t M, int64_t N, int64_t K, const float* score_l, const float* score_r, float* score_out,
+                              int32_t score_cols, int32_t score_layout, spgnn_stream_t stream) {
+  return gemm_nt_bf16_impl(A, lda, B, ldb, C, ldc, c_is_f32, M, N, K, nullptr, SPGNN_ACT_NONE, score_l, score_r, score_out, score_cols, 0,
+                           score_layout, stream);
 }
 
 int spgnn_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

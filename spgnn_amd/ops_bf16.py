@@ -104,6 +104,7 @@ class _WeightPrepBf16:
 
 _PREP_CACHE: dict = {}       # layout key -> _WeightPrepBf16 (buffers and table are reused by every forward pass)
 _PREP_ACTIVE: dict = {}      # (id(w_a), id(w_b)) -> ((w, w_t), want_t): installed for the duration of one model forward
+SCORES_DIRECT = True         # D = 64 layers: el / er straight from the projection's epilogue (no spgnn_scores_from_parts launch)
 BATCH_WEIGHT_PREP = True     # every project-first layer's bf16 operands in one launch per forward; False: one launch per layer
 
 
@@ -164,7 +165,8 @@ def weight_operands(w_a: torch.Tensor, w_b: Optional[torch.Tensor], want_t: bool
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, out_f32: bool = False,
             bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, score_l: Optional[torch.Tensor] = None,
-            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+            score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0,
+            score_direct: bool = False) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T -> (M,N) bf16 rows (or fp32 with ``out_f32``); bf16 MFMA, fp32 accumulate.  ``bias`` (N,) fp32 /
     ``act``: epilogue act(C + bias).  ``score_out`` (M, C/64, 2) fp32 with ``score_l`` / ``score_r`` (C,) fp32: per
     64-column block dot products of the first C output columns, taken from the values as stored."""
@@ -179,7 +181,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     with torch.cuda.device(a.device), _timed("gemm_nt_bf16", (M, N, K)):
         args = (a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), int(out_f32), M, N, K, _ptr(bias),
                 act, _ptr(score_l), _ptr(score_r), _ptr(score_out), score_l.numel() if score_out is not None else 0)
-        if tile:                                   # block tile pinned by the caller (2 / 4 / 5): bit-identical results
+        if score_direct:                           # score_out is the (M, 2H) [el | er] tensor itself (heads of one 64-column block)
+            assert score_out is not None and bias is None and act == ACT_NONE and not tile
+            _capi.check(_capi.load().spgnn_gemm_nt_bf16_scores(*args[:10], *args[12:], 1, _stream(a)), "spgnn_gemm_nt_bf16_scores")
+        elif tile:                                 # block tile pinned by the caller (2 / 4 / 5): bit-identical results
             _capi.check(_capi.load().spgnn_gemm_nt_bf16_tile(*args, tile, _stream(a)), "spgnn_gemm_nt_bf16_tile")
         else:
             _capi.check(_capi.load().spgnn_gemm_nt_bf16(*args, _stream(a)), "spgnn_gemm_nt_bf16")
@@ -290,9 +295,13 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         w, w_t = weight_operands(w_fc, w_res, want_t=need_gx)
         ctx.attn_shape = attn_l.shape
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
-        parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
-        y = gemm_nt(x, w, score_l=al, score_r=ar, score_out=parts)
-        s = scores_from_parts(parts, H, D)
+        if D == 64 and SCORES_DIRECT:            # a head is one 64-column block: the epilogue's dots ARE el / er
+            s = torch.empty((N, 2 * H), dtype=torch.float32, device=x.device)
+            y = gemm_nt(x, w, score_l=al, score_r=ar, score_out=s, score_direct=True)
+        else:
+            parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
+            y = gemm_nt(x, w, score_l=al, score_r=ar, score_out=parts)
+            s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
         od = None if out_drop is None else (float(out_drop[0]), int(out_drop[1]), HD, 0)

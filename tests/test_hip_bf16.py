@@ -112,6 +112,14 @@ def test_gemm_nt_bf16_score_partials():
     ref_l = (ft * sl.double()).view(M, HD // 64, 64).sum(-1)
     ref_r = (ft * sr.double()).view(M, HD // 64, 64).sum(-1)
     assert rel_err(parts[..., 0], ref_l) < 2e-6 and rel_err(parts[..., 1], ref_r) < 2e-6
+    # heads of exactly one 64-column block: the direct [el | er] layout holds the same numbers, the product is unchanged
+    for Md in (M, 3000):
+        ad = torch.randn(Md, K, generator=g).to(BF).float()
+        p2 = torch.empty((Md, HD // 64, 2), device="cuda")
+        y2 = ops_bf16.gemm_nt(_rows(ad), _rows(b), score_l=sl.cuda(), score_r=sr.cuda(), score_out=p2)
+        s = torch.full((Md, 2 * (HD // 64)), float("nan"), device="cuda")
+        yd = ops_bf16.gemm_nt(_rows(ad), _rows(b), score_l=sl.cuda(), score_r=sr.cuda(), score_out=s, score_direct=True)
+        assert torch.equal(yd, y2) and torch.equal(s, ops.scores_from_parts(p2, HD // 64, 64))
 
 
 @pytest.mark.parametrize("R,M,N", [(1, 8, 8), (500, 128, 64), (4097, 256, 128), (9000, 512, 1063), (20000, 1024, 40),
