@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 48
+#define SPGNN_ABI_VERSION 49
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -230,6 +230,13 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads,
 int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
                           int64_t g_pre_stride, float* absmax /* nullable scale block */, int64_t N, int32_t W,
                           int32_t activation, float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
+/* The same when only the DROPPED activation output was kept (a product or aggregation that applied the dropout in its own
+ * epilogue: spgnn_gemm_nt_problem.drop_p, spgnn_spmm_sum_dropout): a kept element is out * (1 - p_drop) again - to one
+ * rounding - and a dropped element's derivative does not matter (its mask is 0), so ELU / tanh derivatives come from
+ * `out_dropped` as well; for ReLU / LeakyReLU (sign only) both entries give identical results. */
+int spgnn_act_bwd_dropped(const float* g_out, int64_t g_out_stride, const float* out_dropped, int64_t out_stride, float* g_pre,
+                          int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
+                          uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
 /* spgnn_act_bwd_dropout that ALSO leaves the column sums of g_pre - the bias gradient when the bias sits in the aggregation's
  * epilogue (GraphConv, reference models.py:172-182; GINConv's first Linear applied before the aggregation) - as per-block
  * partials colsum_partials[spgnn_act_bwd_colsum_blocks(N, W)][W]; spgnn_sum_partials over the blocks gives the (W) sums in

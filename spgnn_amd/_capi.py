@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 48
+ABI_VERSION = 49
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -142,6 +142,7 @@ SIGNATURES = {
     "spgnn_act_bwd_proj": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
     "spgnn_act_bwd_proj_blocks": [_i64],
     "spgnn_act_bwd_dropout": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
+    "spgnn_act_bwd_dropped": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_act_bwd_colsum": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _f32, _u64, _vp, _f32p, _i64, _vp],
     "spgnn_act_bwd_colsum_blocks": [_i64, _i32],
     "spgnn_act_bwd": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],

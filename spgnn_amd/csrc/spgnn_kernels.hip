@@ -1333,7 +1333,9 @@ __global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(kBlock) void act_bwd_flat_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
                                                               int64_t out_ld, float* __restrict__ g_pre, int64_t gp_ld,
                                                               float* __restrict__ absmax, int64_t N, int W, int act, float drop_p,
-                                                              uint64_t seed, const uint64_t* __restrict__ seed_off) {
+                                                              uint64_t seed, const uint64_t* __restrict__ seed_off, float o_scale) {
+  // o_scale: 1, or 1 - p when `out` holds the DROPPED activation output (kept elements were multiplied by 1 / (1 - p); the
+  // derivative of a dropped element is irrelevant: its mask is 0)
   const int w4 = W >> 2;
   const int64_t total = N * w4;
   float mx = 0.f;
@@ -1348,8 +1350,8 @@ __global__ __launch_bounds__(kBlock) void act_bwd_flat_kernel(const float* __res
     }
     if (act != SPGNN_ACT_NONE) {
       const float4 o = ld4(out + v * out_ld + c);
-      q.x *= act_bwd_from_out(o.x, act); q.y *= act_bwd_from_out(o.y, act);
-      q.z *= act_bwd_from_out(o.z, act); q.w *= act_bwd_from_out(o.w, act);
+      q.x *= act_bwd_from_out(o.x * o_scale, act); q.y *= act_bwd_from_out(o.y * o_scale, act);
+      q.z *= act_bwd_from_out(o.z * o_scale, act); q.w *= act_bwd_from_out(o.w * o_scale, act);
     }
     st4(g_pre + v * gp_ld + c, q);
     mx = absmax4(mx, q);
@@ -3150,7 +3152,7 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
     int64_t blocks = (N * (HD / 4) + kBlock - 1) / kBlock;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
-                       out_stride, g_pre, g_pre_stride, absmax, N, (int)HD, activation, 0.f, (uint64_t)0, (const uint64_t*)nullptr);
+                       out_stride, g_pre, g_pre_stride, absmax, N, (int)HD, activation, 0.f, (uint64_t)0, (const uint64_t*)nullptr, 1.f);
     return check_launch("spgnn_act_bwd");
   }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((N + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
@@ -3159,9 +3161,9 @@ int spgnn_act_bwd(const float* g_out, int64_t g_out_stride, int32_t mean_heads, 
   return check_launch("spgnn_act_bwd");
 }
 
-int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
-                          int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
-                          uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+static int act_bwd_dropout_impl(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
+                                int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
+                                uint64_t seed, const uint64_t* seed_offset, bool out_dropped, spgnn_stream_t stream) {
   if (N < 0 || W <= 0 || W % 4) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_dropout: bad N/W (W must be a multiple of 4)");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_dropout: activation");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_dropout: p_drop outside [0, 1)");
@@ -3174,8 +3176,23 @@ int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float*
   int64_t blocks = (N * (W / 4) + kBlock - 1) / kBlock;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(act_bwd_flat_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, g_out, g_out_stride, out,
-                     out_stride, g_pre, g_pre_stride, absmax, N, (int)W, activation, p_drop, seed, seed_offset);
+                     out_stride, g_pre, g_pre_stride, absmax, N, (int)W, activation, p_drop, seed, seed_offset,
+                     out_dropped ? 1.f - p_drop : 1.f);
   return check_launch("spgnn_act_bwd_dropout");
+}
+
+int spgnn_act_bwd_dropout(const float* g_out, int64_t g_out_stride, const float* out, int64_t out_stride, float* g_pre,
+                          int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
+                          uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return act_bwd_dropout_impl(g_out, g_out_stride, out, out_stride, g_pre, g_pre_stride, absmax, N, W, activation, p_drop, seed,
+                              seed_offset, false, stream);
+}
+
+int spgnn_act_bwd_dropped(const float* g_out, int64_t g_out_stride, const float* out_dropped, int64_t out_stride, float* g_pre,
+                          int64_t g_pre_stride, float* absmax, int64_t N, int32_t W, int32_t activation, float p_drop,
+                          uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  return act_bwd_dropout_impl(g_out, g_out_stride, out_dropped, out_stride, g_pre, g_pre_stride, absmax, N, W, activation, p_drop,
+                              seed, seed_offset, true, stream);
 }
 
 int32_t spgnn_act_bwd_colsum_blocks(int64_t N, int32_t W) {

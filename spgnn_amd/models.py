@@ -91,6 +91,7 @@ def _linear_specs(module: nn.Module, x: torch.Tensor):
     return [(m.weight, None, want_t) for m in module.modules() if type(m) is nn.Linear and m.weight.is_cuda]
 
 
+FUSE_SAGE_DROP = True          # SAGE: a layer's feature dropout applied by the previous layer's last product
 FUSE_LSPE = True               # GATPSPGNN: structure + position GATConv of a level in ONE traversal (ops.lspe_level); False: two layers
 
 
@@ -458,9 +459,15 @@ class SAGE(nn.Module):
         (linear) output layer's product."""
         h = g.ndata["fvs"]
         with ops.prepared_weights(_linear_specs(self, h)):
-            for layer in self.g_layers[:-1]:
-                h = layer(g, h)
-            return self.g_layers[-1](g, h, classifier=classifier)
+            dropped = False
+            for l, layer in enumerate(self.g_layers[:-1]):
+                # the next layer's feature dropout rides in this layer's last product (its epilogue applies the hash mask)
+                nxt = self.g_layers[l + 1]
+                p = float(nxt.feat_drop.p) if nxt.training else 0.0
+                fuse = FUSE_SAGE_DROP and 0.0 < p < 1.0 and h.is_cuda and h.dtype == torch.float32 and layer._out_feats % 4 == 0
+                h = layer(g, h, feat_dropped=dropped, out_drop=(p, _draw_seed()) if fuse else None)
+                dropped = fuse
+            return self.g_layers[-1](g, h, classifier=classifier, feat_dropped=dropped)
 
 
 # =================================================================================================

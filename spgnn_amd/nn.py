@@ -579,19 +579,31 @@ class SAGEConv(nn.Module):
                 state_dict[prefix + "fc_self.bias"] = torch.zeros_like(b)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None, classifier: Optional[nn.Linear] = None):
+    def forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight=None, classifier: Optional[nn.Linear] = None,
+                feat_dropped: bool = False, out_drop=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(rst, classifier(rst))`` - joined to this layer's
-        product when the layer is linear (no activation, no norm) and takes the K-concatenated form below."""
+        product when the layer is linear (no activation, no norm) and takes the K-concatenated form below.
+        ``feat_dropped`` / ``out_drop`` = (p, seed) (extensions, as GATConv's): ``feat`` already carries this layer's feature
+        dropout / the result is to carry the NEXT layer's (reference models.py:691-696 stacks the layers, each starting with
+        ``feat_drop``) - applied by the last product's epilogue where that exists, by the hash-dropout kernel otherwise."""
         if classifier is None:
-            return self._forward(graph, feat, edge_weight, None)
-        res = self._forward(graph, feat, edge_weight, classifier)
+            return self._out_dropped(self._forward(graph, feat, edge_weight, None, feat_dropped, out_drop), out_drop)
+        res = self._forward(graph, feat, edge_weight, classifier, feat_dropped, None)
         return res if isinstance(res, tuple) else (res, classifier(res))
 
-    def _forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight, classifier):
+    @staticmethod
+    def _out_dropped(res, out_drop):
+        rst, done = res if isinstance(res, tuple) else (res, False)
+        if out_drop is not None and not done:
+            rst = ops.cat_dropout((rst,), out_drop[0], out_drop[1])
+        return rst
+
+    def _forward(self, graph: TreeGraph, feat: torch.Tensor, edge_weight, classifier, feat_dropped=False, out_drop=None):
+        """-> rst, or (rst, True) when ``out_drop`` was applied by the last product's epilogue."""
         if edge_weight is not None:
             raise DGLError("edge_weight is not supported")
         csc = graph.csc(feat.device)
-        h = _hash_dropout(self.feat_drop, feat)
+        h = feat if feat_dropped else _hash_dropout(self.feat_drop, feat)
         act = _act_code_dense(self.activation)
         fuse = FUSE_EPILOGUES and h.is_cuda and act is not None and self._out_feats % 4 == 0
         if self._aggre_type in ("pool", "mean"):
@@ -624,12 +636,16 @@ class SAGEConv(nn.Module):
                 if (classifier is not None and act == ops.ACT_NONE and self.norm is None
                         and ops.linear_classifier_supported(xc, wc, classifier.weight)):
                     return ops._LinearClassifierFn.apply(xc, wc, bc, classifier.weight, classifier.bias)
-                rst = ops.linear(xc, wc, bc, act)
-                return rst if self.norm is None else self.norm(rst)
+                in_ep = out_drop is not None and self.norm is None and classifier is None
+                rst = ops.linear(xc, wc, bc, act, drop=out_drop if in_ep else None)
+                return (rst, True) if in_ep else (rst if self.norm is None else self.norm(rst))
             if fuse:        # fc_neigh's product adds fc_self's result and applies the activation in its epilogue
+                in_ep = (out_drop is not None and self.norm is None and classifier is None
+                         and ops.linear_drop_supported(neigh, self.fc_neigh.weight))
                 rst = ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias, act,
-                                 addend=ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias))
-                return rst if self.norm is None else self.norm(rst)
+                                 addend=ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias),
+                                 drop=out_drop if in_ep else None)
+                return (rst, True) if in_ep else (rst if self.norm is None else self.norm(rst))
             rst = (ops.linear(_dst_rows(csc, h), self.fc_self.weight, self.fc_self.bias)
                    + ops.linear(neigh, self.fc_neigh.weight, self.fc_neigh.bias))
         else:  # gcn: (sum_in x_u + x_v) / (deg + 1)

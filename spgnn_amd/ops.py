@@ -671,9 +671,9 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, addend=None, drop=None, w_cls=None, b_cls=None):
         """``drop`` = (p, seed): the result is dropout(act(...), p) under spgnn_cat_dropout's hash mask; the backward pass
-        then undoes dropout and activation in ONE pass (spgnn_act_bwd_dropout).  For ReLU / LeakyReLU / no activation the mask
-        is applied by the product's own epilogue (the derivative needs the sign of the stored value only, so the undropped
-        result is never written); ELU / tanh keep both.
+        then undoes dropout and activation in ONE pass.  The mask is applied by the product's own epilogue and only the dropped
+        result is kept: ReLU / LeakyReLU derivatives need its sign, ELU / tanh ones the value, which for a kept element is
+        the stored one times (1 - p) again (spgnn_act_bwd_dropped).
         ``w_cls`` (J, C) / ``b_cls``: a skinny classifier on the result joins the node, outputs (y, logits) - when only the
         logits carry a gradient the (N, C) gradient of y is formed, multiplied by act' and consumed in one pass
         (spgnn_act_bwd_proj) instead of written by spgnn_scores_bwd_x and re-read by spgnn_act_bwd."""
@@ -706,7 +706,7 @@ class _LinearFn(torch.autograd.Function):
             q.c.addend, q.c.addend_stride = addend.data_ptr(), addend.stride(0)
         dropping = drop is not None and drop[0] > 0.0
         assert not dropping or C % 4 == 0, "linear(drop=...): the output width must be a multiple of 4"
-        in_epilogue = dropping and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and blk is not None and EPILOGUE_DROPOUT
+        in_epilogue = dropping and blk is not None and EPILOGUE_DROPOUT
         if in_epilogue:
             q.c.drop_p, q.c.drop_seed, q.c.drop_seed_offset = float(drop[0]), int(drop[1]), _seed_off_ptr(x.device)
         import ctypes
@@ -717,6 +717,7 @@ class _LinearFn(torch.autograd.Function):
         if dropping:
             assert w_cls is None
             ctx.drop = (float(drop[0]), int(drop[1]))
+            ctx.drop_in_epilogue = bool(in_epilogue)
             if in_epilogue:                                               # y IS the dropped result
                 ctx.save_for_backward(x, w, sx, sw, y if act != ACT_NONE else None)
                 return y
@@ -777,10 +778,11 @@ class _LinearFn(torch.autograd.Function):
             g_pre = torch.empty((N, C), dtype=torch.float32, device=g.device)
             sg = new_scale_block(g.device)
             with torch.cuda.device(g.device), _timed("act_bwd", (N, 1, C, ctx.act, 0)):
-                _capi.check(_capi.load().spgnn_act_bwd_dropout(g.data_ptr(), g.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
-                                                               g_pre.data_ptr(), g_pre.stride(0), sg.data_ptr(), N, C, ctx.act,
-                                                               ctx.drop[0], ctx.drop[1], _seed_off_ptr(g.device), _stream(g)),
-                            "spgnn_act_bwd_dropout")
+                # from the dropped result when that is all the forward kept (the product's epilogue applied the mask)
+                fn = _capi.load().spgnn_act_bwd_dropped if ctx.drop_in_epilogue else _capi.load().spgnn_act_bwd_dropout
+                _capi.check(fn(g.data_ptr(), g.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+                               g_pre.data_ptr(), g_pre.stride(0), sg.data_ptr(), N, C, ctx.act,
+                               ctx.drop[0], ctx.drop[1], _seed_off_ptr(g.device), _stream(g)), "spgnn_act_bwd_dropout")
             g = g_pre
         elif ctx.act != ACT_NONE and C % 4 == 0:
             g, sg = act_bwd(_rowmajor(g), y, 1, C, ctx.act, False)

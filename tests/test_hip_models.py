@@ -482,3 +482,26 @@ def test_two_rank_graph_replay_equals_two_rank_eager():
         assert np.allclose(le[2:], lg, rtol=1e-5), (le, lg)
         assert torch.allclose(pe, pg, rtol=1e-5, atol=1e-7)
     assert torch.equal(ret[0]["graph"][1], ret[1]["graph"][1])      # replicas stay identical
+
+
+def test_sage_feature_dropout_in_the_previous_layers_epilogue(monkeypatch):
+    """SAGE in training mode: layer l + 1's feature dropout applied by layer l's last product (models.FUSE_SAGE_DROP) - same
+    seeds, same masks: logits equal the layer-by-layer form bit for bit, gradients to the rounding of ELU's recovered value."""
+    from spgnn_amd import synthetic
+    cfg = get_config("st_sage_3")
+    g = synthetic.make_batch(8, rank=3, device="cuda", pos_enc_dim=None)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(models, "FUSE_SAGE_DROP", fused)
+        torch.manual_seed(0)
+        model = models.build_model(cfg.MODEL).cuda(); model.init(None); model.set_gcn_only(); model.train(True)
+        torch.manual_seed(5)
+        logits, emb = model(g)
+        (logits * torch.linspace(-1, 1, logits.shape[1], device="cuda")).sum().backward()
+        res[fused] = (logits.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) >= 20
+    for n in res[True][1]:
+        assert rel_err(res[True][1][n], res[False][1][n]) < 2e-6, n
+    kept = float((res[True][0] != 0).float().mean())
+    assert kept > 0.99
