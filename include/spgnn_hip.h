@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 49
+#define SPGNN_ABI_VERSION 50
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -386,6 +386,13 @@ int spgnn_spmm_max_fwd_u8(const int32_t* indptr, const int32_t* indices, const f
 int spgnn_spmm_max_bwd_u8(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
                           const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
                           int64_t g_x_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream);
+/* spgnn_spmm_max_bwd_u8 for an x that was a ReLU output (SAGEConv 'pool': max over relu(fc_pool(h)), reference
+ * models.py:668-679): g_x comes out already multiplied by relu'(x) = [relu_out > 0] - the gradient of fc_pool's
+ * pre-activation - and max |g_x| is folded into the scale block `absmax` (nullable): no activation-backward pass over g_x. */
+int spgnn_spmm_max_bwd_u8_relu(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                               const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                               int64_t g_x_stride, const float* relu_out, int64_t relu_out_stride, float* absmax, int64_t N,
+                               int64_t E, int32_t F, spgnn_stream_t stream);
 
 /*
  * fp32-accurate projection GEMM on the fp16 matrix cores (replaces the cuBLAS/rocBLAS SGEMMs behind

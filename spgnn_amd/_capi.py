@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -104,6 +104,7 @@ SIGNATURES = {
     "spgnn_spmm_max_u8_supported": [_i32],
     "spgnn_spmm_max_fwd_u8": [_i32p, _i32p, _f32p, _i64, _f32p, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
     "spgnn_spmm_max_bwd_u8": [_i32p, _i32p, _i32p, _i32p, _f32p, _i64, _vp, _i64, _f32p, _i64, _i64, _i64, _i32, _vp],
+    "spgnn_spmm_max_bwd_u8_relu": [_i32p, _i32p, _i32p, _i32p, _f32p, _i64, _vp, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i32, _vp],
     "spgnn_gemm_nt": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,
                       _f32p, _i32, _f32p, _f32p, _f32p, _i32, _i32, _vp],
     "spgnn_gemm_nt_tile": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i64, _f32p, _i64, _i32,

@@ -1866,6 +1866,9 @@ struct SpmmMaxBwd {
   float* g_x; int64_t g_x_ld;
   int64_t N; int F; int T;
   const uint8_t* arg8; const int32_t* indptr;     // compact form: positions inside the in-edge lists + the CSC offsets
+  // optional: x was a ReLU output (SAGEConv's fc_pool, reference models.py:668-679) - g_x is masked by relu_of > 0 right here
+  // (the activation's backward pass over g_x is not needed) and max |g_x| goes to the scale block `absmax`
+  const float* relu_of; int64_t relu_ld; float* absmax;
 };
 
 template <int TT, int R, bool U8>
@@ -1944,8 +1947,22 @@ __device__ __forceinline__ void spmm_max_bwd_body(const SpmmMaxBwd& a) {
       }
     }
   }
+  float amx = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) st4(a.g_x + u * a.g_x_ld + (r * T + lane) * 4, acc[r]);
+  for (int r = 0; r < R; ++r) {
+    const int c = (r * T + lane) * 4;
+    float4 q = acc[r];
+    if (a.relu_of) {
+      const float4 o = ld4(a.relu_of + u * a.relu_ld + c);
+      q.x = o.x > 0.f ? q.x : 0.f; q.y = o.y > 0.f ? q.y : 0.f; q.z = o.z > 0.f ? q.z : 0.f; q.w = o.w > 0.f ? q.w : 0.f;
+    }
+    st4(a.g_x + u * a.g_x_ld + c, q);
+    amx = absmax4(amx, q);
+  }
+  if (a.absmax) {
+    amx = team_max(amx, T);
+    if (lane == 0) spgnn_detail::slots_max(a.absmax, amx, (unsigned)u);
+  }
 }
 template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec(SpmmMaxBwd a) { spmm_max_bwd_body<TT, R, false>(a); }
 template <int TT, int R> __global__ __launch_bounds__(kBlock) void spmm_max_bwd_vec_u8(SpmmMaxBwd a) { spmm_max_bwd_body<TT, R, true>(a); }
@@ -3398,7 +3415,8 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   if (g_out_stride < F || arg_stride < F || g_x_stride < F)
     return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd: row stride smaller than row");
   hipStream_t st = (hipStream_t)stream;
-  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0, nullptr, nullptr};
+  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0, nullptr, nullptr,
+               nullptr, 0, nullptr};
   int T, R;
   if (pick_team(F, T, R) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
     a.T = T;
@@ -3426,20 +3444,40 @@ int spgnn_spmm_max_fwd_u8(const int32_t* indptr, const int32_t* indices, const f
   return check_launch("spgnn_spmm_max_fwd_u8");
 }
 
-int spgnn_spmm_max_bwd_u8(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
-                          const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
-                          int64_t g_x_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
+static int spmm_max_bwd_u8_impl(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                                const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                                int64_t g_x_stride, const float* relu_of, int64_t relu_stride, float* absmax, int64_t N, int64_t E,
+                                int32_t F, spgnn_stream_t stream) {
   int T, R;
   if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_bwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !out_indptr || !g_out || !arg || !g_x || (E > 0 && (!out_indices || !out_pos)))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_bwd_u8: null pointer");
-  if (g_out_stride < F || arg_stride < F || g_x_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd_u8: row stride smaller than row");
-  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_x, g_x_stride) || (reinterpret_cast<uintptr_t>(arg) & 3) || (arg_stride & 3))
+  if (g_out_stride < F || arg_stride < F || g_x_stride < F || (relu_of && relu_stride < F))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd_u8: row stride smaller than row");
+  if (!vec_ok(g_out, g_out_stride) || !vec_ok(g_x, g_x_stride) || !vec_ok(relu_of, relu_stride) || (reinterpret_cast<uintptr_t>(arg) & 3) ||
+      (arg_stride & 3))
     return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_bwd_u8: rows must be 16-byte (arg: 4-byte) aligned");
-  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, nullptr, arg_stride, g_x, g_x_stride, N, F, T, arg, indptr};
+  SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, nullptr, arg_stride, g_x, g_x_stride, N, F, T, arg, indptr,
+               relu_of, relu_stride, absmax};
   DISPATCH_R(T, R, spmm_max_bwd_vec_u8, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, (hipStream_t)stream, a);
   return check_launch("spgnn_spmm_max_bwd_u8");
+}
+
+int spgnn_spmm_max_bwd_u8(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                          const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                          int64_t g_x_stride, int64_t N, int64_t E, int32_t F, spgnn_stream_t stream) {
+  return spmm_max_bwd_u8_impl(indptr, out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, nullptr, 0,
+                              nullptr, N, E, F, stream);
+}
+
+int spgnn_spmm_max_bwd_u8_relu(const int32_t* indptr, const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos,
+                               const float* g_out, int64_t g_out_stride, const uint8_t* arg, int64_t arg_stride, float* g_x,
+                               int64_t g_x_stride, const float* relu_out, int64_t relu_out_stride, float* absmax, int64_t N,
+                               int64_t E, int32_t F, spgnn_stream_t stream) {
+  if (!relu_out) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_bwd_u8_relu: null pointer");
+  return spmm_max_bwd_u8_impl(indptr, out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, relu_out,
+                              relu_out_stride, absmax, N, E, F, stream);
 }
 
 }  // extern "C"

@@ -607,7 +607,9 @@ class SAGEConv(nn.Module):
         act = _act_code_dense(self.activation)
         fuse = FUSE_EPILOGUES and h.is_cuda and act is not None and self._out_feats % 4 == 0
         if self._aggre_type in ("pool", "mean"):
-            if self._aggre_type == "pool":
+            if self._aggre_type == "pool" and ops.pool_max_supported(csc, h, self.fc_pool.weight):
+                neigh = ops.pool_max(csc, h, self.fc_pool.weight, self.fc_pool.bias)       # one node: relu' inside the routing kernel
+            elif self._aggre_type == "pool":
                 pool = ops.linear(h, self.fc_pool.weight, self.fc_pool.bias, ops.ACT_RELU)
                 neigh = _dst_rows(csc, ops.spmm_max(csc, pool))
                 tag = getattr(pool, "_spgnn_scale", None)

@@ -751,6 +751,8 @@ class _LinearFn(torch.autograd.Function):
         N, K = x.shape
         C = w.shape[0]
         g_wcls = g_bcls = sg = None
+        if getattr(ctx, "pre_activated", False):      # the caller hands over the PRE-activation gradient with its scale (ops.pool_max)
+            g, sg = _rowmajor(g), ctx.pre_scale
         if g_logits is not None:
             cs = column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
@@ -2299,6 +2301,82 @@ class _SpmmMaxFn(torch.autograd.Function):
                                                    arg.data_ptr(), arg.stride(0), g_x.data_ptr(), g_x.stride(0), N, E, F_,
                                                    _stream(g_out)), "spgnn_spmm_max_bwd")
         return g_x, None
+
+
+class _PlainCtx:
+    """Stand-in for an autograd ctx when one Function runs another's forward / backward as a part of its own."""
+
+    def __init__(self):
+        self.saved_tensors, self.needs_input_grad = (), ()
+
+    def set_materialize_grads(self, _value):
+        pass
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _PoolMaxFn(torch.autograd.Function):
+    """SAGEConv 'pool' up to the aggregation as ONE node: neigh[v] = max_{u in in(v)} relu(h[u] W^T + b) (reference
+    models.py:668-679 via dgl SAGEConv).  Forward = ops.linear (ReLU epilogue) + the max aggregation with the one-byte argmax;
+    backward: the routing kernel masks its result by relu' itself (spgnn_spmm_max_bwd_u8_relu) - the gradient of fc_pool's
+    pre-activation in one pass instead of routing + an activation-backward pass over (N, in_feats) - and the product's own
+    backward (_LinearFn) continues from there."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, csc: DeviceCSC):
+        inner = _PlainCtx()
+        pool = _LinearFn.forward(inner, h, weight, bias, ACT_RELU)
+        N, E, F_ = csc.num_nodes, csc.num_edges, pool.shape[1]
+        out = torch.empty((N, F_), dtype=torch.float32, device=pool.device)
+        arg = torch.empty((N, F_), dtype=torch.uint8, device=pool.device)
+        with torch.cuda.device(pool.device), _timed("spmm_max_fwd", (N, E, F_)):
+            _capi.check(_capi.load().spgnn_spmm_max_fwd_u8(csc.indptr.data_ptr(), csc.indices.data_ptr(), pool.data_ptr(), pool.stride(0),
+                                                           out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
+                                                           _stream(pool)), "spgnn_spmm_max_fwd_u8")
+        ctx.inner, ctx.csc, ctx.pool, ctx.arg = inner, csc, pool, arg
+        ctx.scale_block = inner.scale_block       # every element of a neighbourhood maximum is an element of pool (or 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        csc, pool, arg, inner = ctx.csc, ctx.pool, ctx.arg, ctx.inner
+        g_out = _rowmajor(g_out)
+        if not _rows_aligned(g_out):
+            g_out = g_out.contiguous()
+        N, E, F_ = csc.num_nodes, csc.num_edges, g_out.shape[1]
+        g_pre = torch.empty((N, F_), dtype=torch.float32, device=g_out.device)
+        sg = new_scale_block(g_out.device)
+        with torch.cuda.device(g_out.device), _timed("spmm_max_bwd", (N, E, F_)):
+            _capi.check(_capi.load().spgnn_spmm_max_bwd_u8_relu(csc.indptr.data_ptr(), csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                                csc.out_pos.data_ptr(), g_out.data_ptr(), g_out.stride(0), arg.data_ptr(),
+                                                                arg.stride(0), g_pre.data_ptr(), g_pre.stride(0), pool.data_ptr(),
+                                                                pool.stride(0), sg.data_ptr(), N, E, F_, _stream(g_out)),
+                        "spgnn_spmm_max_bwd_u8_relu")
+        inner.needs_input_grad = tuple(ctx.needs_input_grad[:3]) + (False,) * 5
+        inner.pre_activated, inner.pre_scale = True, sg
+        g_x, g_w, g_b = _LinearFn.backward(inner, g_pre)[:3]
+        return g_x, g_w, g_b, None
+
+
+POOL_MAX_FUSED = True    # SAGEConv 'pool': fc_pool + ReLU + max aggregation as one autograd node (relu' applied by the routing kernel)
+
+
+def pool_max_supported(csc: DeviceCSC, h: torch.Tensor, weight: torch.Tensor) -> bool:
+    N = h.shape[0] if h.dim() == 2 else 0
+    return bool(POOL_MAX_FUSED and COMPACT_MAX_ARG and h.is_cuda and GEMM_MODE == "f16x3" and N >= 512 and N == csc.num_nodes
+                and weight.shape[0] >= 32 and weight.shape[1] >= 32 and h.dtype == torch.float32 and weight.dtype == torch.float32
+                and csc.max_in_degree <= 254 and getattr(csc, "num_dst", None) is None
+                and _capi.load().spgnn_spmm_max_u8_supported(int(weight.shape[0])))
+
+
+def pool_max(csc: DeviceCSC, h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """max over in-neighbours of relu(F.linear(h, weight, bias)); needs :func:`pool_max_supported`."""
+    out = _PoolMaxFn.apply(h, weight, bias, csc)
+    blk = getattr(out.grad_fn, "scale_block", None) if out.grad_fn is not None else None
+    if blk is not None:
+        out._spgnn_scale = (out._version, blk)
+    return out
 
 
 def spmm_max(csc: DeviceCSC, x) -> torch.Tensor:

@@ -391,6 +391,32 @@ def test_spmm_max_compact_argmax_equals_the_slot_form(F_, monkeypatch):
             assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("fi,fo", [(1024, 256), (128, 64), (64, 1024)])
+def test_sage_pool_front_as_one_node_equals_three(fi, fo, monkeypatch):
+    """SAGEConv 'pool': fc_pool + ReLU + max aggregation as one autograd node whose routing kernel applies relu' itself
+    (ops.pool_max, spgnn_spmm_max_bwd_u8_relu) - output and every gradient bit for bit those of linear -> spmm_max with the
+    activation-backward pass in between."""
+    torch.manual_seed(fi + fo)
+    g, _, _, n = _graph([150, 170, 130, 160, 140], seed=4)
+    layer = snn.SAGEConv(fi, fo, "pool", activation=F.elu).cuda()
+    with torch.no_grad():
+        layer.fc_pool.bias.normal_(0, 0.2)
+    x0 = torch.randn(n, fi, device="cuda")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "POOL_MAX_FUSED", fused)
+        x = x0.clone().requires_grad_(True)
+        for p_ in layer.parameters():
+            p_.grad = None
+        y = layer(g, x)
+        (y * torch.linspace(-1, 1, fo, device="cuda")).sum().backward()
+        res[fused] = (y.detach().clone(), x.grad.clone(), {n_: p_.grad.clone() for n_, p_ in layer.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n_ in res[True][2]:
+        assert torch.equal(res[True][2][n_], res[False][2][n_]), n_
+    assert float(res[True][2]["fc_pool.weight"].abs().max()) > 0
+
+
 def test_spmm_max_ties_go_to_one_edge():
     g, src, dst, n = _graph([40], seed=2)
     x = torch.ones(n, 64, device="cuda", requires_grad=True)                     # every in-edge ties
