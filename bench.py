@@ -81,6 +81,9 @@ def algorithmic_bytes(key) -> float:
     if base == "scores_bwd_w":       # read x, gS; partials negligible
         _, N, K, J = key
         return s * N * K + 4 * N * J
+    if base == "scores_bwd_w_pair":  # two such passes in one launch
+        _, N, K0, J0, K1, J1 = key
+        return s * N * (K0 + K1) + 4 * N * (J0 + J1)
     if base == "scores_bwd_x":       # read + write gX; read gS
         _, N, K, J = key
         return 4 * 2 * N * K + 4 * N * J

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 50
+#define SPGNN_ABI_VERSION 51
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -319,6 +319,12 @@ int spgnn_scores_fwd(const float* x, int64_t x_stride, const float* w, int32_t K
 int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64_t x_stride,
                        float* part, int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J,
                        spgnn_stream_t stream);
+/* Two spgnn_scores_bwd_w passes over the same N nodes in ONE launch (J0, J1 <= 8): a level's structure and position layers'
+ * attention-vector gradients (reference models.py:472-484).  Partials exactly as from the two single calls. */
+int spgnn_scores_bwd_w_pair(const float* gs0, int64_t gs0_stride, const float* x0, int64_t x0_stride, float* part0, int32_t splits0,
+                            int32_t Kp0, int32_t K0, int32_t J0, const float* gs1, int64_t gs1_stride, const float* x1,
+                            int64_t x1_stride, float* part1, int32_t splits1, int32_t Kp1, int32_t K1, int32_t J1, int64_t N,
+                            spgnn_stream_t stream);
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp,
                        float* gx, int64_t gx_stride, int32_t accumulate, int64_t N, int32_t K, int32_t J,
                        spgnn_stream_t stream);

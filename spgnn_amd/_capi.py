@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 50
+ABI_VERSION = 51
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -95,6 +95,8 @@ SIGNATURES = {
     "spgnn_scores_fwd": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_scale_from_partials": [_f32p, _i64, _f32, _f32p, _vp, _vp],
     "spgnn_scores_bwd_w": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i64, _i32, _i32, _vp],
+    "spgnn_scores_bwd_w_pair": [_f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i32, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i32, _i32, _i32,
+                                _i32, _i64, _vp],
     "spgnn_scores_bwd_x": [_f32p, _i64, _f32p, _i32, _f32p, _i64, _i32, _i64, _i32, _i32, _vp],
     "spgnn_spmm_sum": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _i64, _i64, _i32, _f32p, _vp],
     "spgnn_spmm_sum_dropout": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _i64, _i64, _i32, _f32p, _f32, _u64,

@@ -2125,19 +2125,19 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
 // one wave per 256 columns x one row range (four waves of a block side by side: a row is then read as one 4 KB
 // run instead of 1 KB pieces at different times - DRAM-friendlier); partial sums per range, reduced by the caller
 template <typename ST, int J>
-__global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
-                                                          const ST* __restrict__ X, int64_t ldx,
-                                                          float* __restrict__ part, int Kp, int64_t N, int K,
-                                                          int64_t rows_per_split, int jn) {
+__device__ __forceinline__ void scores_bwd_w_body(const float* __restrict__ gS, int64_t ldg,
+                                                  const ST* __restrict__ X, int64_t ldx,
+                                                  float* __restrict__ part, int Kp, int64_t N, int K,
+                                                  int64_t rows_per_split, int jn, const unsigned bx, const unsigned by) {
   // a block's waves sit side by side on one row: 4 KB contiguous per row.  Every lane of a wave stays in the loop (the gS
   // rows travel through lanes, see below): lanes past the width read column 0 and store nothing; a float4 that hangs over
   // the width reads the row's padding (rows are 16-byte aligned with a stride that is a multiple of 4) and the columns
   // that do not exist are cleared before the store.
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int k = (bx * blockDim.x + threadIdx.x) * 4;
   if ((k & ~255) >= K) return;         // a wave with no column at all (wave-uniform)
   const bool live = k < K;
   const int kk = live ? k : 0;
-  const int64_t n0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t n0 = (int64_t)by * rows_per_split;
   const int64_t n1 = n0 + rows_per_split < N ? n0 + rows_per_split : N;
   float4 acc[J];
 #pragma unroll
@@ -2187,8 +2187,28 @@ __global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restri
     if (j < jn) {
       float4 q = acc[j];
       q.y = k + 1 < K ? q.y : 0.f; q.z = k + 2 < K ? q.z : 0.f; q.w = k + 3 < K ? q.w : 0.f;
-      st4(part + ((int64_t)blockIdx.y * jn + j) * Kp + k, q);
+      st4(part + ((int64_t)by * jn + j) * Kp + k, q);
     }
+}
+
+template <typename ST, int J>
+__global__ __launch_bounds__(256) void scores_bwd_w_kernel(const float* __restrict__ gS, int64_t ldg,
+                                                          const ST* __restrict__ X, int64_t ldx,
+                                                          float* __restrict__ part, int Kp, int64_t N, int K,
+                                                          int64_t rows_per_split, int jn) {
+  scores_bwd_w_body<ST, J>(gS, ldg, X, ldx, part, Kp, N, K, rows_per_split, jn, blockIdx.x, blockIdx.y);
+}
+
+// Two independent passes in one launch (a level's structure and position layers: the attention-vector gradients of both,
+// reference models.py:472-484): row ranges [0, nb0) of the grid's y run the first, the rest the second, each with the
+// arithmetic it has alone (a wave with no column of its problem leaves at once).
+struct ScoresBwdW { const float* gS; int64_t ldg; const float* X; int64_t ldx; float* part; int Kp; int64_t N; int K; int64_t rps; int jn; int gx; };
+template <int J>
+__global__ __launch_bounds__(256) void scores_bwd_w_pair_kernel(ScoresBwdW p0, ScoresBwdW p1, unsigned nb0) {
+  const bool second = blockIdx.y >= nb0;
+  const ScoresBwdW& p = second ? p1 : p0;
+  if ((int)blockIdx.x >= p.gx) return;
+  scores_bwd_w_body<float, J>(p.gS, p.ldg, p.X, p.ldx, p.part, p.Kp, p.N, p.K, p.rps, p.jn, blockIdx.x, second ? blockIdx.y - nb0 : blockIdx.y);
 }
 
 template <typename ST, int J>     // ST: storage type of the rows of gX (gS, W fp32)
@@ -3542,6 +3562,30 @@ int spgnn_scores_bwd_w(const float* gs, int64_t gs_stride, const float* x, int64
                          case 24: X(24); break; default: X(32); break; }
 #undef X
   return check_launch("spgnn_scores_bwd_w");
+}
+
+int spgnn_scores_bwd_w_pair(const float* gs0, int64_t gs0_stride, const float* x0, int64_t x0_stride, float* part0, int32_t splits0,
+                            int32_t Kp0, int32_t K0, int32_t J0, const float* gs1, int64_t gs1_stride, const float* x1,
+                            int64_t x1_stride, float* part1, int32_t splits1, int32_t Kp1, int32_t K1, int32_t J1, int64_t N,
+                            spgnn_stream_t stream) {
+  if (N < 0 || K0 <= 0 || K1 <= 0 || splits0 <= 0 || splits1 <= 0 || Kp0 < K0 || Kp1 < K1 || ((Kp0 | Kp1) & 15) || J0 <= 0 || J1 <= 0 ||
+      J0 > 8 || J1 > 8)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w_pair: bad N/K/Kp/splits/J (J <= 8)");
+  if (!gs0 || !x0 || !part0 || !gs1 || !x1 || !part1) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w_pair: null pointer");
+  if (x0_stride < K0 || gs0_stride < J0 || (x0_stride & 3) || !aligned16(x0) || !aligned16(part0) || x1_stride < K1 || gs1_stride < J1 ||
+      (x1_stride & 3) || !aligned16(x1) || !aligned16(part1))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w_pair: x rows must be 16-byte aligned (stride % 4 == 0)");
+  const int bw0 = K0 >= 1024 ? 4 : (K0 + 255) / 256, bw1 = K1 >= 1024 ? 4 : (K1 + 255) / 256;
+  const int bw = bw0 > bw1 ? bw0 : bw1;                    // one block shape for both: the wider problem's
+  ScoresBwdW p0{gs0, gs0_stride, x0, x0_stride, part0, Kp0, N, K0, (N + splits0 - 1) / splits0, J0, (K0 + 256 * bw - 1) / (256 * bw)};
+  ScoresBwdW p1{gs1, gs1_stride, x1, x1_stride, part1, Kp1, N, K1, (N + splits1 - 1) / splits1, J1, (K1 + 256 * bw - 1) / (256 * bw)};
+  const dim3 grid((unsigned)(p0.gx > p1.gx ? p0.gx : p1.gx), (unsigned)(splits0 + splits1)), block(64 * bw);
+  hipStream_t st = (hipStream_t)stream;
+  const int jp = padded_j(J0 > J1 ? J0 : J1);
+  if (jp <= 2) hipLaunchKernelGGL((scores_bwd_w_pair_kernel<2>), grid, block, 0, st, p0, p1, (unsigned)splits0);
+  else if (jp <= 4) hipLaunchKernelGGL((scores_bwd_w_pair_kernel<4>), grid, block, 0, st, p0, p1, (unsigned)splits0);
+  else hipLaunchKernelGGL((scores_bwd_w_pair_kernel<8>), grid, block, 0, st, p0, p1, (unsigned)splits0);
+  return check_launch("spgnn_scores_bwd_w_pair");
 }
 
 int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* x, int64_t x_stride, float* part,

@@ -490,6 +490,37 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0, d
     return sum_partials(part)[:, :K]
 
 
+PAIR_SCORE_GRADS = True   # a level's two attention-vector gradient passes (structure J = 2H, position J = 2) as one launch
+
+
+def scores_bwd_w_blockdiag_pair(g_s0: torch.Tensor, x0: torch.Tensor, H0: int, g_s1: torch.Tensor, x1: torch.Tensor, H1: int,
+                                defer: "SumJobs"):
+    """``scores_bwd_w(g_s0, x0, blockdiag_heads=H0, defer=...)`` and the same for (g_s1, x1, H1) with BOTH streaming passes
+    in one launch (spgnn_scores_bwd_w_pair) - bit-identical to the two calls, which is what runs when the shapes do not fit."""
+    N = x0.shape[0]
+    ok = (PAIR_SCORE_GRADS and defer is not None and N == x1.shape[0] and N > 0 and g_s0.shape[1] <= 8 and g_s1.shape[1] <= 8
+          and _rows_aligned(x0) and _rows_aligned(x1) and x0.device == x1.device)
+    if not ok:
+        return (scores_bwd_w(g_s0, x0, blockdiag_heads=H0, defer=defer), scores_bwd_w(g_s1, x1, blockdiag_heads=H1, defer=defer))
+    parts, outs, args = [], [], []
+    for g_s, x, H in ((g_s0, x0, H0), (g_s1, x1, H1)):
+        K, J = x.shape[1], g_s.shape[1]
+        Kp = _pad16(K)
+        splits = max(1, min(_SCORES_SPLIT_WAVES_SMALL // ((K + 255) // 256), N // 16))       # as scores_bwd_w
+        part = torch.empty((splits, J, Kp), dtype=torch.float32, device=x.device)
+        D = K // H
+        out = torch.empty((2, H, D), dtype=torch.float32, device=x.device)
+        parts.append(part); outs.append(out)
+        args += [g_s.data_ptr(), g_s.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), splits, Kp, K, J]
+        defer_job = _capi.SumJob(kind=1, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), H=H, D=D, ld=Kp)
+        outs.append(defer_job)
+    with torch.cuda.device(x0.device), _timed("scores_bwd_w_pair", (N, x0.shape[1], g_s0.shape[1], x1.shape[1], g_s1.shape[1])):
+        _capi.check(_capi.load().spgnn_scores_bwd_w_pair(*args, N, _stream(x0)), "spgnn_scores_bwd_w_pair")
+    defer.add(outs[1], parts[0], outs[0])
+    defer.add(outs[3], parts[1], outs[2])
+    return outs[0], outs[2]
+
+
 def scores_bwd_x_(g_x: torch.Tensor, g_s: torch.Tensor, w_lr: torch.Tensor, accumulate: bool = True) -> None:
     """g_x (+)= g_s @ w_lr, in place."""
     N, K = g_x.shape
@@ -1665,9 +1696,14 @@ class _LspeLevelFn(torch.autograd.Function):
             need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
             if need_bias and grads_b[i] is None:
                 grads_b[i] = g_pre[i].sum(0)
-            if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
-                m = scores_bwd_w(g_s[i], ys[i][:, :H * D], blockdiag_heads=H, defer=jobs)
-                grads_al[i], grads_ar[i] = m[0].view(ctx.attn_shapes[i]), m[1].view(ctx.attn_shapes[i])
+        want_a = [ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i] for i in range(2)]
+        if want_a[0] and want_a[1]:                      # both layers' attention-vector gradients: one streaming launch
+            ms = scores_bwd_w_blockdiag_pair(g_s[0], ys[0][:, :Hs[0] * D], Hs[0], g_s[1], ys[1][:, :Hs[1] * D], Hs[1], jobs)
+        else:
+            ms = [scores_bwd_w(g_s[i], ys[i][:, :Hs[i] * D], blockdiag_heads=Hs[i], defer=jobs) if want_a[i] else None for i in range(2)]
+        for i in range(2):
+            if ms[i] is not None:
+                grads_al[i], grads_ar[i] = ms[i][0].view(ctx.attn_shapes[i]), ms[i][1].view(ctx.attn_shapes[i])
         if nt[0] is not None and nt[1] is not None:
             gemm_nt_pair(nt[0], nt[1])
         else:

@@ -86,11 +86,13 @@ def test_pair_launches_leave_the_step_bitwise_unchanged(monkeypatch):
     res, names = [], []
     for pair in (True, False):
         monkeypatch.setattr(ops, "PAIR_GEMMS", pair)
+        monkeypatch.setattr(ops, "PAIR_SCORE_GRADS", pair)          # ... and the two attention-vector gradient passes
         ops.KernelTimer.start()
         res.append(_run(model, g, cfg, True, True, monkeypatch))
         names.append([k[0] for k in ops.KernelTimer.sequence])
         ops.KernelTimer.stop()
     assert "gemm_nt_pair" in names[0] and "gemm_tn_pair" in names[0] and "gemm_nt_pair" not in names[1]
+    assert "scores_bwd_w_pair" in names[0] and "scores_bwd_w_pair" not in names[1]
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
     assert set(res[0][1]) == set(res[1][1])

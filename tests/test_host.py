@@ -346,7 +346,7 @@ def test_bench_accounting_knows_every_kernel_key():
     keys = [("gat_fwd", N, E, 2, 64, 1, 0, 1), ("gat_bwd_dst", N, E, 2, 64, 1, 0), ("gat_bwd_src", N, E, 2, 64),
             ("lspe_fwd", N, E, 64), ("lspe_bwd_dst", N, E, 64, 1), ("lspe_bwd_src", N, E, 64),
             ("gat_agg_fwd", N, E, 2, 192, 1), ("gat_agg_bwd_dst", N, E, 2, 192), ("gat_agg_bwd_src", N, E, 2, 192),
-            ("scores_fwd", N, 1024, 22), ("scores_bwd_w", N, 1024, 22), ("scores_bwd_x", N, 1024, 22),
+            ("scores_fwd", N, 1024, 22), ("scores_bwd_w", N, 1024, 22), ("scores_bwd_w_pair", N, 512, 4, 256, 2), ("scores_bwd_x", N, 1024, 22),
             ("act_bwd", N, 1, 64, 4, 0), ("act_bwd_proj", N, 2, 1024, 1, 22), ("masked_ce", N, 22),
             ("spmm_sum", N, E, 64), ("spmm_max_fwd", N, E, 64), ("spmm_max_bwd", N, E, 64),
             ("gat_fwd_bf16", N, E, 2, 64, 1, 0, 1)]
