@@ -1993,15 +1993,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NG 16-column groups (J <= 16 * NG), RG 16-row groups per wave; ST: storage type of the rows of X (W, S fp32).
 // A wave keeps its W fragments in registers across its RG row groups: with one group per wave the 22 x 1024 classifier
 // weights were re-read from L1 for every 16 rows - twice the bytes of x (1024 -> 22: 2.7 TB/s of x).
-template <typename ST, int NG, int RG>
+// KS = 4 (deep products, K >= 512): the four waves of a block share ONE set of 16 RG rows and each takes a quarter of the
+// k range; the partial accumulators meet in LDS and wave 0 adds them in wave order (deterministic).  Four times the waves
+// for the same rows: the 1024 -> 22 classifier product ran with ~2 waves per SIMD, each alone with its load latency.
+template <typename ST, int NG, int RG, int KS>
 __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ W, int Kp,
                                                           float* __restrict__ S, int64_t lds_, int64_t N, int K, int J,
                                                           float* __restrict__ absmax, const float* __restrict__ bias) {
-  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  static_assert(KS == 1 || KS == kBlock / 64, "k split = the waves of a block");
+  const int ks = KS > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const int64_t wave = KS > 1 ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;   // index of the row set
   const int lane = threadIdx.x & 63;
   const int64_t row0 = wave * (16 * RG);
-  if (row0 >= N) return;
+  if (row0 >= N) return;                // (block-uniform with KS > 1)
   const int r = lane & 15, q = lane >> 4;
   bool rv[RG]; const ST* xp[RG]; float rvf[RG];
 #pragma unroll
@@ -2025,13 +2030,17 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
   float amx[RG];                      // every element of x passes through this kernel: its absmax is free
 #pragma unroll
   for (int t = 0; t < RG; ++t) amx[t] = 0.f;
-  const int kfull = K & ~15;
+  const int kfull_all = K & ~15;
+  // this wave's k range [kbeg, kfull): whole 16-element steps
+  const int kq = KS > 1 ? ((kfull_all / 16 + KS - 1) / KS) * 16 : kfull_all;
+  const int kbeg = ks * kq < kfull_all ? ks * kq : kfull_all;
+  const int kfull = kbeg + kq < kfull_all ? kbeg + kq : kfull_all;
   // main loop: straight-line body, unrolled so that all row loads of a trip are in flight before the first MFMA.
   // Loads are unconditional: rows past N and columns past J read row 0 / column 0 (valid memory) and only feed
   // outputs that are never stored.  A per-lane test around a load (or around the absmax update) is a branch to hipcc:
   // the loop was not unrolled and every trip waited vmcnt(0) for its own loads - one load in flight per wave.
   constexpr int UK = RG >= 4 ? 2 : 4;  // k16 steps per trip (4 RG UK / 4 ... row loads + NG UK weight loads in flight)
-  int k0 = 0;
+  int k0 = kbeg;
   for (; k0 + 16 * UK <= kfull; k0 += 16 * UK) {
     float4 xa[RG][UK], wb[NG][UK];
 #pragma unroll
@@ -2073,8 +2082,8 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
       }
     }
   }
-  if (kfull < K) {                      // ragged tail: element-wise guards on X (W is zero padded)
-    const int kt = kfull, k = kt + 4 * q;
+  if (kfull_all < K && ks == KS - 1) {  // ragged tail (the last wave's): element-wise guards on X (W is zero padded)
+    const int kt = kfull_all, k = kt + 4 * q;
     float4 wb[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) wb[g] = wv[g] ? ld4(wp[g] + kt) : z4;
@@ -2103,8 +2112,28 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
     for (int t = 0; t < RG; ++t) {
       float m = amx[t];
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-      if (lane == 0 && row0 + 16 * t < N) spgnn_detail::slots_max(absmax, m, (unsigned)(wave * RG + t));
+      if (lane == 0 && row0 + 16 * t < N) spgnn_detail::slots_max(absmax, m, (unsigned)(wave * RG + t));   // max: any order
     }
+  }
+  if constexpr (KS > 1) {               // partial accumulators of waves 1 .. KS-1 -> LDS; wave 0 adds them in wave order
+    __shared__ f32x4 red[(KS - 1) * RG * NG * 64];
+    if (ks > 0) {
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) red[(((ks - 1) * RG + t) * NG + g) * 64 + lane] = acc[t][g];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int w = 1; w < KS; ++w)
+#pragma unroll
+      for (int t = 0; t < RG; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const f32x4 p_ = red[(((w - 1) * RG + t) * NG + g) * 64 + lane];
+          acc[t][g][0] += p_[0]; acc[t][g][1] += p_[1]; acc[t][g][2] += p_[2]; acc[t][g][3] += p_[3];     // (no vector add: packed fp32 ops are fenced out of this file)
+        }
   }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -3511,12 +3540,16 @@ static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int
                               int32_t K, int32_t J, float* absmax, const float* bias, hipStream_t st) {
   const bool wide = kScoresRG > 1 && J > 16 && N >= 16 * kScoresRG * 1024;   // >= 1024 waves of the wide form
   const int rg = wide ? kScoresRG : 1;
-  const int64_t waves = (N + 16 * rg - 1) / (16 * rg);
-  const dim3 grid((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
-#define X(NG_, RG_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, bias)
-  if (J <= 16) X(1, 1);
-  else if (wide) X(2, kScoresRG);
-  else X(2, 1);
+  const int64_t waves = (N + 16 * rg - 1) / (16 * rg);                        // row sets
+  // the four waves of a block split k (see the kernel): 1024 -> 22 at N = 76 410 100 -> 81-83 us (tools/scores_ab.py, one
+  // process); with 64 rows per block instead of 32: 86
+  const bool ksplit = wide && K >= 512;
+  const dim3 grid((unsigned)(ksplit ? waves : (waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
+#define X(NG_, RG_, KS_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_, KS_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, bias)
+  if (J <= 16) X(1, 1, 1);
+  else if (ksplit) X(2, kScoresRG, kBlock / 64);
+  else if (wide) X(2, kScoresRG, 1);
+  else X(2, 1, 1);
 #undef X
 }
 
