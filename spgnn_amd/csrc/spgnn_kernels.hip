@@ -2636,9 +2636,12 @@ __global__ __launch_bounds__(kBlock) void step_begin_kernel(int64_t* __restrict_
   if (i < words) blocks[i] = (i % W == 0) ? -(float)spgnn_detail::kScaleSlots : 0.f;
 }
 
-// T < 64 only occurs with R = 1 (pick_team tries 64 lanes first)
+// T < 64 comes with R = 1 (pick_team tries 64 lanes first) or, for the SpMM kernels' narrow rows, as 16 lanes x R = 2 / 4
+constexpr bool kSpmmNarrow = true;   // SpMM kernels: rows of <= 256 floats on 16-lane teams (pick_team's `narrow`)
 #define DISPATCH_R(T_, R_, KERNEL, ...)                                                          \
-  if ((T_) != 64) { hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); }                           \
+  if ((T_) != 64 && (R_) == 2) { hipLaunchKernelGGL((KERNEL<0, 2>), __VA_ARGS__); }               \
+  else if ((T_) != 64 && (R_) == 4) { hipLaunchKernelGGL((KERNEL<0, 4>), __VA_ARGS__); }          \
+  else if ((T_) != 64) { hipLaunchKernelGGL((KERNEL<0, 1>), __VA_ARGS__); }                      \
   else switch (R_) {                                                                             \
     case 1: hipLaunchKernelGGL((KERNEL<64, 1>), __VA_ARGS__); break;                             \
     case 2: hipLaunchKernelGGL((KERNEL<64, 2>), __VA_ARGS__); break;                             \
@@ -3424,7 +3427,9 @@ int spgnn_spmm_sum_dropout(const int32_t* indptr, const int32_t* indices, const 
   SpmmSum a{indptr, indices, x, x_stride, w_src, w_dst, self_eps, out, out_stride, N, F, 0, bias, (int)activation, absmax_out,
             p_drop, p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed, seed_offset};
   int T, R;
-  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && (!bias || aligned16(bias))) {
+  // rows of 128 / 256 floats on 16-lane teams (four nodes per wave, 2 / 4 float4 per lane) like the GAT kernels' narrow
+  // layers: a wave walks four index -> row chains instead of one (st_gcn_3 1.285 -> 1.143 ms, st_gin_3 3.81 -> 3.70, one process)
+  if (pick_team(F, T, R, kSpmmNarrow) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && (!bias || aligned16(bias))) {
     a.T = T;
     DISPATCH_R(T, R, spmm_sum_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else if (p_drop > 0.f) {
@@ -3445,7 +3450,7 @@ int spgnn_spmm_max_fwd(const int32_t* indptr, const int32_t* indices, const floa
   hipStream_t st = (hipStream_t)stream;
   SpmmMaxFwd a{indptr, indices, x, x_stride, out, out_stride, arg, arg_stride, N, F, 0, nullptr};
   int T, R;
-  if (pick_team(F, T, R) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && vec_ok(arg, arg_stride)) {
+  if (pick_team(F, T, R, kSpmmNarrow) && vec_ok(x, x_stride) && vec_ok(out, out_stride) && vec_ok(arg, arg_stride)) {
     a.T = T;
     DISPATCH_R(T, R, spmm_max_fwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {
@@ -3467,7 +3472,7 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   SpmmMaxBwd a{out_indptr, out_indices, out_pos, g_out, g_out_stride, arg, arg_stride, g_x, g_x_stride, N, F, 0, nullptr, nullptr,
                nullptr, 0, nullptr};
   int T, R;
-  if (pick_team(F, T, R) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
+  if (pick_team(F, T, R, kSpmmNarrow) && vec_ok(g_out, g_out_stride) && vec_ok(arg, arg_stride) && vec_ok(g_x, g_x_stride)) {
     a.T = T;
     DISPATCH_R(T, R, spmm_max_bwd_vec, dim3(grid_for(N, kBlock / T)), dim3(kBlock), 0, st, a);
   } else {
@@ -3476,13 +3481,13 @@ int spgnn_spmm_max_bwd(const int32_t* out_indptr, const int32_t* out_indices, co
   return check_launch("spgnn_spmm_max_bwd");
 }
 
-int32_t spgnn_spmm_max_u8_supported(int32_t F) { int T, R; return pick_team(F, T, R) ? 1 : 0; }
+int32_t spgnn_spmm_max_u8_supported(int32_t F) { int T, R; return pick_team(F, T, R, kSpmmNarrow) ? 1 : 0; }
 
 int spgnn_spmm_max_fwd_u8(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride, float* out,
                           int64_t out_stride, uint8_t* arg, int64_t arg_stride, int64_t N, int64_t E, int32_t F,
                           spgnn_stream_t stream) {
   int T, R;
-  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_fwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
+  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R, kSpmmNarrow)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_fwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !out || !arg || (E > 0 && !indices)) return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_fwd_u8: null pointer");
   if (x_stride < F || out_stride < F || arg_stride < F) return fail(SPGNN_ERR_STRIDE, "spgnn_spmm_max_fwd_u8: row stride smaller than row");
@@ -3498,7 +3503,7 @@ static int spmm_max_bwd_u8_impl(const int32_t* indptr, const int32_t* out_indptr
                                 int64_t g_x_stride, const float* relu_of, int64_t relu_stride, float* absmax, int64_t N, int64_t E,
                                 int32_t F, spgnn_stream_t stream) {
   int T, R;
-  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_bwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
+  if (N < 0 || E < 0 || F <= 0 || !pick_team(F, T, R, kSpmmNarrow)) return fail(SPGNN_ERR_SHAPE, "spgnn_spmm_max_bwd_u8: bad N/E/F (see spgnn_spmm_max_u8_supported)");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !out_indptr || !g_out || !arg || !g_x || (E > 0 && (!out_indices || !out_pos)))
     return fail(SPGNN_ERR_NULLPTR, "spgnn_spmm_max_bwd_u8: null pointer");
