@@ -12,13 +12,14 @@ for p in paths:
     libs[os.path.basename(p)] = _capi.load()
 cfg = get_config(sys.argv[1] if len(sys.argv) > 1 else "st_pgat_spgnn_3")
 torch.manual_seed(0)
-g = synthetic.make_batch(512, rank=0, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+g = synthetic.make_batch(int(os.environ.get("TREES", "512")), rank=0, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
 steps = {}
 for k, lib in libs.items():
     _capi._lib = lib
     torch.manual_seed(0)
     model = models.build_model(cfg.MODEL).cuda()
     model.init(None); model.set_gcn_only(); model.train(True)
+    if os.environ.get("DTYPE") == "bf16": models.set_storage_dtype(model, torch.bfloat16)
     st = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, 1e-4, 0.9)
     for _ in range(5): st.step(g)
     st.capture(g)
