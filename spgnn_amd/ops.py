@@ -2370,13 +2370,15 @@ class _PoolMaxFn(torch.autograd.Function):
             _capi.check(_capi.load().spgnn_spmm_max_fwd_u8(csc.indptr.data_ptr(), csc.indices.data_ptr(), pool.data_ptr(), pool.stride(0),
                                                            out.data_ptr(), out.stride(0), arg.data_ptr(), arg.stride(0), N, E, F_,
                                                            _stream(pool)), "spgnn_spmm_max_fwd_u8")
-        ctx.inner, ctx.csc, ctx.pool, ctx.arg = inner, csc, pool, arg
+        ctx.inner, ctx.csc = inner, csc
+        ctx.save_for_backward(pool, arg)
         ctx.scale_block = inner.scale_block       # every element of a neighbourhood maximum is an element of pool (or 0)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        csc, pool, arg, inner = ctx.csc, ctx.pool, ctx.arg, ctx.inner
+        csc, inner = ctx.csc, ctx.inner
+        pool, arg = ctx.saved_tensors
         g_out = _rowmajor(g_out)
         if not _rows_aligned(g_out):
             g_out = g_out.contiguous()
