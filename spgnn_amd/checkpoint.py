@@ -53,10 +53,11 @@ def _load_file(cpk_path, map_location, trusted: bool):
     """``torch.load`` restricted to tensors and plain containers (``weights_only=True``).  A checkpoint that pickles other
     objects (the reference stores its metric object's ``state_dict``, plain data, but older files may hold more) is only
     unpickled in full when the caller says the file is ``trusted``: unpickling runs arbitrary code from the file."""
+    import pickle
     try:
         return torch.load(cpk_path, map_location=map_location, weights_only=True)
-    except Exception as e:                   # pickle.UnpicklingError and friends: something outside the allow-list
-        if not trusted:
+    except pickle.UnpicklingError as e:      # something outside the weights_only allow-list; a missing or truncated file, a
+        if not trusted:                      # bad map_location etc. (OSError / RuntimeError / EOFError) propagate as they are
             raise RuntimeError(f"{cpk_path}: the checkpoint holds objects beyond tensors and plain containers ({e}); pass "
                                "trusted=True to unpickle it in full (only for files you wrote yourself), or allow-list "
                                "its classes with torch.serialization.add_safe_globals") from e

@@ -76,11 +76,11 @@ def packed_fp32_report(obj: str) -> dict:
     return {f: (n, xl.get(f, 0)) for f, n in pk.items()}
 
 
-def _check_isa(src: str, verbose: bool) -> None:
+def _check_isa(src: str, verbose: bool, obj: str = None) -> None:
     """The fence behind DESIGN.md section 4.1's hazard: packed fp32 ops next to cross-lane reads gave transiently wrong
     values when a second process shared the GPU.  The row kernels' object must hold none at all (build error otherwise);
     for the GEMM objects, whose cross-lane sums are guarded by hand, the functions where both occur are listed."""
-    rep = packed_fp32_report(_obj(src))
+    rep = packed_fp32_report(obj or _obj(src))
     base = os.path.basename(src)
     if base in NO_PACKED_FP32:
         if rep:
@@ -99,16 +99,30 @@ def build(force: bool = False, verbose: bool = True) -> str:
     todo = [s for s in SOURCES if force or _stale(_obj(s), [s, os.path.abspath(__file__)] + HEADERS)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", _obj(src)]
+        # the object only takes its final name once the ISA check has passed: a failed check (or a missing llvm-objdump)
+        # must not leave an "up to date" object behind that the next build() would link unchecked
+        tmp = _obj(src) + ".unchecked.o"
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        return tmp
 
     if todo:
+        if not os.path.exists(os.path.join(LLVM_BIN, "llvm-objdump")):
+            raise RuntimeError(f"llvm-objdump not found under {LLVM_BIN} (set LLVM_BIN): the packed-fp32 ISA fence of the build "
+                               "cannot run, refusing to produce unchecked objects")
         with ThreadPoolExecutor(max_workers=len(todo)) as ex:
-            list(ex.map(compile_one, todo))
-        for src in todo:
-            _check_isa(src, verbose)
+            tmps = list(ex.map(compile_one, todo))
+        try:
+            for src, tmp in zip(todo, tmps):
+                _check_isa(src, verbose, obj=tmp)
+            for src, tmp in zip(todo, tmps):
+                os.replace(tmp, _obj(src))
+        finally:
+            for tmp in tmps:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     objs = [_obj(s) for s in SOURCES]
     if todo or _stale(OUT, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

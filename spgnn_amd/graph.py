@@ -171,7 +171,11 @@ def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True):
     if dev.type != "cuda":
         raise RuntimeError("build_csc_device needs a ROCm device (host graphs: edges_from_adj + build_csc_numpy)")
     lib = _capi.load()
-    mats = [np.ascontiguousarray(a, dtype=np.uint8) for a in adjs]
+    # any non-zero entry is an edge (nx.DiGraph(adj) in the reference, edges_from_adj here): a plain uint8 cast would turn
+    # 0.5 or 256 into "no edge" and the device path would disagree with the host path
+    # (the kernels test bytes against zero, so uint8 / bool matrices go up as they are)
+    mats = [np.ascontiguousarray(a).view(np.uint8) if (isinstance(a, np.ndarray) and a.dtype in (np.uint8, np.bool_))
+            else np.ascontiguousarray(np.asarray(a) != 0).view(np.uint8) for a in adjs]
     for a in mats:
         if a.ndim != 2 or a.shape[0] != a.shape[1]:
             raise ValueError(f"adj must be square, got {a.shape}")

@@ -1146,6 +1146,29 @@ class _WeightPrep:
 
 
 _PREP_CACHE: dict = {}       # layout key -> _WeightPrep (buffers and table are reused by every forward pass)
+_PREP_CACHE_MAX = 8          # unpinned entries kept (least recently used goes first)
+CAPTURE_REFS = None          # a list while train.TrainStep.capture records a step: everything whose device addresses the
+                             # HIP graph bakes in is appended, and the captured step keeps the list alive as long as its graphs
+
+
+def _prep_lookup(cache: dict, key, make):
+    """The cached operand set for one layout, created on a miss.  Eviction is LRU over entries that no HIP graph has
+    recorded: a prep that ran while the stream was capturing is pinned (its buffers' addresses are inside the graph; a
+    replay after a drop would read and write freed memory) and is also handed to the capturing step (CAPTURE_REFS), so
+    the buffers live exactly as long as something can replay them."""
+    prep = cache.pop(key, None)
+    if prep is None:
+        prep = make()
+        prep.pinned = False
+        loose = [k for k, v in cache.items() if not v.pinned]
+        for k in loose[:max(0, len(loose) + 1 - _PREP_CACHE_MAX)]:
+            del cache[k]
+    cache[key] = prep                                   # re-inserted last: dict order is the recency order
+    if torch.cuda.is_current_stream_capturing():
+        prep.pinned = True
+        if CAPTURE_REFS is not None:
+            CAPTURE_REFS.append(prep)
+    return prep
 _PREP_ACTIVE: dict = {}      # (id(w_a), id(w_b)) -> (entry, want_t): installed for the duration of one model forward
 BATCH_WEIGHT_PREP = True     # all projection layers' operands in one spgnn_weight_prep call per forward; False: per layer
 
@@ -1171,11 +1194,7 @@ class prepared_weights:
         key = (str(dev),) + tuple((sp[0].data_ptr(), sp[0].stride(0), tuple(sp[0].shape), 0 if sp[1] is None else sp[1].data_ptr(),
                                    0 if sp[1] is None else sp[1].stride(0), None if sp[1] is None else tuple(sp[1].shape), bool(sp[2]),
                                    sp[3] if len(sp) > 3 else "") for sp in self.specs)
-        prep = _PREP_CACHE.get(key)
-        if prep is None:
-            if len(_PREP_CACHE) > 8:
-                _PREP_CACHE.clear()
-            prep = _PREP_CACHE[key] = _WeightPrep(self.specs, dev)
+        prep = _prep_lookup(_PREP_CACHE, key, lambda: _WeightPrep(self.specs, dev))
         prep.run()
         _PREP_ACTIVE = {(id(sp[0]), id(sp[1]) if sp[1] is not None else 0) + ((sp[3],) if len(sp) > 3 else ()): (e, bool(sp[2]))
                         for sp, e in zip(self.specs, prep.entries)}

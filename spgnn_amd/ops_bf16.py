@@ -128,11 +128,7 @@ class prepared_weights:
         key = (str(dev),) + tuple((a.data_ptr(), a.stride(0), tuple(a.shape), 0 if b is None else b.data_ptr(),
                                    0 if b is None else b.stride(0), None if b is None else tuple(b.shape), bool(t))
                                   for a, b, t in self.specs)
-        prep = _PREP_CACHE.get(key)
-        if prep is None:
-            if len(_PREP_CACHE) > 8:
-                _PREP_CACHE.clear()
-            prep = _PREP_CACHE[key] = _WeightPrepBf16(self.specs, dev)
+        prep = _ops._prep_lookup(_PREP_CACHE, key, lambda: _WeightPrepBf16(self.specs, dev))     # LRU; pinned once a HIP graph holds it
         prep.run()
         _PREP_ACTIVE = {(id(a), id(b) if b is not None else 0): (e, bool(t)) for (a, b, t), e in zip(self.specs, prep.entries)}
         return self

@@ -338,12 +338,20 @@ class TrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # thread-local capture mode: other threads (the process group's watchdog) may touch the runtime meanwhile
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._front(g)
-        self._graph_back = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
-            self._static_loss = self._back(self.bucket.loss_slot)
+        # whatever persistent buffer the recorded launches address outside the graphs' own pool (the weight-prep operand sets
+        # of ops / ops_bf16) is collected here and lives as long as this step can replay
+        prev_refs, ops.CAPTURE_REFS = ops.CAPTURE_REFS, []
+        try:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self._front(g)
+            self._graph_back = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
+                self._static_loss = self._back(self.bucket.loss_slot)
+            self._capture_refs = ops.CAPTURE_REFS
+        finally:
+            ops.CAPTURE_REFS = prev_refs
+        self._captured_graph = g                    # the node data and index arrays the graphs read
         return self
 
     def replay(self) -> torch.Tensor:

@@ -30,6 +30,43 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.spgnn_gat_bwd_src(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 4, 0.0, 0, 0, 0) == 0    # N == 0: no-op
 
 
+def test_integration_stub_names_the_current_abi_version():
+    """INTEGRATION.md's binding stub is what a maintainer pastes first: its version assert must be the header's."""
+    header = open(os.path.join(ROOT, "include", "spgnn_hip.h")).read()
+    ver = int(re.search(r"#define SPGNN_ABI_VERSION (\d+)", header).group(1))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = [int(v) for v in re.findall(r"spgnn_abi_version\(\)\s*==\s*(\d+)", doc)]
+    assert stub and all(v == ver for v in stub), (stub, ver)
+    from spgnn_amd import _capi
+    assert _capi.ABI_VERSION == ver
+
+
+def test_prep_cache_never_evicts_what_a_graph_recorded(monkeypatch):
+    """ops._prep_lookup: LRU over loose entries; an entry that ran under stream capture is pinned and is handed
+    to the capturing step's reference list."""
+    from spgnn_amd import ops
+
+    class P:
+        pass
+    cache = {}
+    capturing = {"on": False}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing["on"])
+    monkeypatch.setattr(ops, "CAPTURE_REFS", [])
+    capturing["on"] = True
+    held = ops._prep_lookup(cache, "captured", P)
+    capturing["on"] = False
+    assert held.pinned and ops.CAPTURE_REFS == [held]
+    for i in range(3 * ops._PREP_CACHE_MAX):
+        ops._prep_lookup(cache, ("loose", i), P)
+    assert cache["captured"] is held
+    loose = [k for k in cache if k != "captured"]
+    assert len(loose) == ops._PREP_CACHE_MAX and loose[-1] == ("loose", 3 * ops._PREP_CACHE_MAX - 1)
+    first = loose[0]
+    assert ops._prep_lookup(cache, first, P) is not None and list(cache)[-1] == first      # a hit becomes the most recent
+    ops._prep_lookup(cache, "new", P)
+    assert first in cache and loose[1] not in cache
+
+
 def test_ops_refuse_cpu_tensors():
     from spgnn_amd import nn as snn
     from spgnn_amd.graph import TreeGraph
