@@ -302,10 +302,28 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         loss = run_step()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    comm_ev = None
+    if world > 1 and launch != "eager":
+        # HIP events on the compute stream around the step's one collective (TrainStep._reduce, issued eagerly between the two
+        # graphs): what the all-reduce costs inside the replayed step, per step
+        comm_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        plain_reduce = step._reduce
+        it = iter(comm_ev)
+
+        def timed_reduce(loss_num):
+            pair = next(it, None)
+            if pair is None:
+                return plain_reduce(loss_num)
+            pair[0].record()
+            r = plain_reduce(loss_num)
+            pair[1].record()
+            return r
     import gc
     gc.collect()                                    # a collection of the previous leg's objects inside a 20-step leg showed up
     gc.disable()                                    # as 1.54 ms wall against 1.11 ms by events (r03): keep the host out of it
     try:
+        if comm_ev is not None:
+            step._reduce = timed_reduce
         t0 = time.perf_counter()
         marks[0].record()
         for i in range(steps):
@@ -315,6 +333,26 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         elapsed = time.perf_counter() - t0
     finally:
         gc.enable()
+        if comm_ev is not None:
+            step._reduce = plain_reduce
+    comm = None
+    if world > 1:
+        ar_ms = sorted(a.elapsed_time(b) for a, b in comm_ev) if comm_ev is not None else []
+        backend = dist.get_backend()
+        try:
+            lib_ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            lib_ver = None
+        # the world size as the collective library itself sees it: a sum of ones over the group
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        comm = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "library_version": lib_ver,
+                "world_size": dist.get_world_size(), "ranks_counted_by_allreduce": int(ones.item()),
+                "collective": "one sum all-reduce of the flat fp32 gradient bucket per step (loss normaliser in its tail)",
+                "bucket_bytes": int(step.bucket.flat_grad.numel() * 4),
+                "allreduce_ms": ({"p50": pct(ar_ms, 0.5), "p90": pct(ar_ms, 0.9), "n": len(ar_ms),
+                                  "how": "HIP events on the compute stream around dist.all_reduce inside the timed replays (rank 0)"}
+                                 if ar_ms else None)}
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     kt_dom, eager_leg = {}, None
     if not no_eager_leg and not no_kernel_timers:
@@ -365,6 +403,12 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                         "n": len(step_ms), "how": "HIP events on the compute stream around every timed step (rank 0)"},
             "copy_bandwidth": copy_bw,
         }
+        if comm is not None:
+            out["comm"] = comm
+            out["config"]["comm"] = {k: comm[k] for k in ("backend", "library_version", "ranks_counted_by_allreduce", "bucket_bytes")}
+            if comm["allreduce_ms"]:
+                out["config"]["comm"]["allreduce_ms_p50"] = comm["allreduce_ms"]["p50"]
+                out["config"]["comm"]["allreduce_ms_p90"] = comm["allreduce_ms"]["p90"]
         if kt_all:
             try:                                    # never lose the bench line to the accounting of an unknown kernel key
                 nprobe = max(probe, 1)
@@ -494,6 +538,16 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                                                    "three fp16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi): "
                                                    "executed_mfma_frac = 3 x frac; against the native fp32 matrix pipe (157.3 TFLOP/s) "
                                                    "the same rate is frac_of_fp32_matrix_peak"}
+                        if k123 is not None:
+                            # the north-star figure (BASELINE.json: message passing vs the HBM roofline) inside the object the
+                            # driver keeps: SURVEY 8d's K1-K3 = every lspe_* / gat_* launch of a step
+                            out["roofline"]["hbm"] = {
+                                "bound": "hbm", "kernels": "K1-K3: " + " ".join(k123["kernels"]),
+                                "ms_per_step": k123["ms_per_step"], "survey_bytes_per_step": sv_bytes, "own_bytes_per_step": k_bytes,
+                                "achieved": sv_bytes / (k123["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": k123["frac_of_survey_roofline"], "own_frac": k123["own_frac_of_hbm_peak"],
+                                "layer_edges_per_s": k123["layer_edges_per_s"],
+                                "traffic": traffic_of(gat_keys), "launches_per_step": sum(per_step(k)[1] for k in gat_keys)}
 
                 # ---- composite roofline (SURVEY.md 8d / BASELINE.md 2): t_graph + max(t_gemm_bytes, t_gemm_flops) -----
                 t_graph = mp_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
@@ -523,6 +577,85 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             out["eager"] = eager_leg
         return out, (cfg, model, samples)
     return None, (cfg, model, samples)
+
+
+def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300, granule=512):
+    """The reference's loader-batch cycle as a measured quantity (job_runner.py:1870-1920, exp_settings/st_pgat_spgnn_3.py:29,34:
+    GCN_STEPS = 300 optimizer steps on every freshly built batch of TRAIN_BATCH_SIZE = 64 trees): per batch assemble
+    (data.assemble_batch: pinned packing, upload, device CSC, device anchors + distance encoding), load into the batch arena of
+    its size class (spgnn_amd/arena.py; the first batch of a class also pays warm-up + capture) and ``inner`` steps as HIP-graph
+    replays.  Reported beside it: the r3 flow (a fresh capture for every batch) and the steady-state replay of an unpadded
+    64-tree batch, which the amortised figure is a multiple of."""
+    from spgnn_amd import data, models, synthetic
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    cfg = get_config(config)
+    torch.manual_seed(0)
+
+    def fresh_step():
+        model = models.build_model(cfg.MODEL).to(dev)
+        model.init(None); model.set_gcn_only(); model.train()
+        return TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, cfg.OPTIMIZER["lr"], cfg.OPTIMIZER["momentum"], seed=99)
+
+    def wall(fn):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(dev)
+        return r, (time.perf_counter() - t0) * 1e3
+
+    batches = [synthetic.synthetic_trees(trees, rank=200 + b) for b in range(n_batches)]     # the dataset: host trees, not timed
+    # steady state: an unpadded batch, captured, replayed
+    ts0 = fresh_step()
+    g0, _ = wall(lambda: data.assemble_batch(batches[0], dev, cfg.POS_ENC_DIM))
+    ts0.capture(g0)
+    for _ in range(10):
+        ts0.replay()
+    _, t = wall(lambda: [ts0.replay() for _ in range(inner)])
+    steady = t / inner
+    del ts0, g0
+    # the arena flow
+    ts = fresh_step()
+    per_batch = []
+    for b, samples in enumerate(batches):
+        g, asm = wall(lambda: data.assemble_batch(samples, dev, cfg.POS_ENC_DIM))
+        known = len(ts._captures)
+        ag, load = wall(lambda: ts.arena_graph(g, granule))
+        cap = 0.0
+        done = 0
+        if not ts.select(ag):
+            _, cap = wall(lambda: ts.capture(ag))
+            done = ts.capture_steps
+        _, rep = wall(lambda: [ts.replay() for _ in range(inner - done)])
+        per_batch.append({"nodes": g.number_of_nodes(), "class_nodes": ag.number_of_nodes(), "new_class": len(ts._captures) > known,
+                          "assemble_ms": asm, "arena_load_ms": load, "capture_ms": cap, "replay_ms_per_step": rep / (inner - done),
+                          "amortised_ms_per_step": (load + cap + rep) / inner,
+                          "amortised_incl_assemble_ms_per_step": (asm + load + cap + rep) / inner})
+        del g
+    hits = [q for q in per_batch if not q["new_class"]]
+    miss = [q for q in per_batch if q["new_class"]]
+    mean = lambda xs: sum(xs) / len(xs) if xs else None
+    # the r3 flow on the same batches: warm-up + capture + instantiate for every batch
+    ts2 = fresh_step()
+    rec = []
+    for samples in batches[:3]:
+        g = data.assemble_batch(samples, dev, cfg.POS_ENC_DIM)
+        _, cap = wall(lambda: ts2.capture(g))
+        _, rep = wall(lambda: [ts2.replay() for _ in range(inner - ts2.capture_steps)])
+        rec.append({"capture_ms": cap, "amortised_ms_per_step": (cap + rep) / inner})
+        ts2._captures.clear()
+        del g
+    return {"workload": f"{config}, {n_batches} loader batches of {trees} synthetic trees, {inner} optimizer steps on each (reference GCN_STEPS), "
+                        f"fp32, dropout on, arena granule {granule} nodes",
+            "steady_state_ms_per_step": steady, "classes_captured": len(ts._captures), "batches": per_batch,
+            "amortised_ms_per_step_known_class": mean([q["amortised_ms_per_step"] for q in hits]),
+            "amortised_ms_per_step_new_class": mean([q["amortised_ms_per_step"] for q in miss]),
+            "amortised_over_steady_known_class": (mean([q["amortised_ms_per_step"] for q in hits]) / steady) if hits else None,
+            "assemble_ms": mean([q["assemble_ms"] for q in per_batch]), "arena_load_ms": mean([q["arena_load_ms"] for q in per_batch]),
+            "capture_ms": mean([q["capture_ms"] for q in miss]),
+            "recapture_every_batch": {"capture_ms": mean([q["capture_ms"] for q in rec]),
+                                      "amortised_ms_per_step": mean([q["amortised_ms_per_step"] for q in rec]),
+                                      "amortised_over_steady": mean([q["amortised_ms_per_step"] for q in rec]) / steady}}
 
 
 # BASELINE.json configs 2-4 beside the headline (config 5 at N = 1): run after it, short, inside the same JSON line
@@ -561,6 +694,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short legs for BASELINE configs 2-4 after the headline")
     ap.add_argument("--cpu-trees", type=int, default=64)
+    ap.add_argument("--batch-cycle-only", action="store_true", help="run only the loader-batch cycle leg (secondary.batch_cycle_64) and print it")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
@@ -588,6 +722,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
+    if args.batch_cycle_only:
+        print(json.dumps({"batch_cycle_64": batch_cycle(dev)}), flush=True)
+        return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
                                          no_kernel_timers=args.no_kernel_timers)
@@ -608,7 +745,17 @@ def main():
                     del o2, _ctx
                 except Exception as e:                  # never lose the headline to a secondary leg
                     sec[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+            try:
+                sec["batch_cycle_64"] = batch_cycle(dev)
+            except Exception as e:
+                sec["batch_cycle_64"] = {"error": repr(e)[:300]}
             out["secondary"] = sec
+            bc = sec["batch_cycle_64"]
+            if "error" not in bc:                       # the figures the driver's record keeps (config is kept whole)
+                out["config"]["batch_cycle_64"] = {k: (round(bc[k], 4) if isinstance(bc[k], float) else bc[k]) for k in
+                                                   ("steady_state_ms_per_step", "amortised_ms_per_step_known_class", "amortised_over_steady_known_class",
+                                                    "assemble_ms", "arena_load_ms", "capture_ms", "classes_captured")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

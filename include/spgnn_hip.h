@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 51
+#define SPGNN_ABI_VERSION 52
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -429,7 +429,14 @@ int spgnn_spmm_max_bwd_u8_relu(const int32_t* indptr, const int32_t* out_indptr,
  * b_presplit = 1: B is the PRE-SPLIT form of the operand written by spgnn_presplit with scale_b (same shape and strides;
  * every 16-byte group of four fp32 values replaced by the packed fp16 pairs [hi01, hi23, lo01, lo23] the kernel would
  * otherwise form itself for every row tile).  Bit-identical results; weights are split once per step this way.
+ * The argument is a MASK (every NT entry point): SPGNN_PRESPLIT_B (1) as above; SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B (3):
+ * A is pre-split as well (spgnn_presplit with scale_a).  A model's first layer multiplies node DATA - cat[fvs, pos_enc],
+ * reference models.py:425-428, 474-477 - which is constant over the GCN_STEPS = 300 inner steps on a loader batch
+ * (job_runner.py:1892): it is split once per batch, and its products neither convert nor stage it as fp32 any more.
+ * A-only (2) is not instantiated (SPGNN_ERR_ENUM).  Bit-identical to the in-kernel split under the same scale.
  */
+#define SPGNN_PRESPLIT_B 1
+#define SPGNN_PRESPLIT_A 2
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
@@ -549,12 +556,15 @@ typedef struct spgnn_gemm_nt_problem {
 typedef struct spgnn_gemm_tn_problem {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t split_stride; int64_t R; int64_t M; int64_t N;
   const float* scale_a; const float* scale_b; float* colsum_a; int64_t colsum_stride; int64_t colsum_split_stride;
-  int32_t splits; int32_t reserved;
+  int32_t splits;
+  int32_t b_presplit;      /* 1: B (R x N; X, the layer input) is the pre-split form written by spgnn_presplit with scale_b - the
+                              weight gradient of a model's first layer reads constant node data (see spgnn_gemm_nt); 0: fp32 rows */
 } spgnn_gemm_tn_problem;
 int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream);   /* one product, every option */
 int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
                        spgnn_stream_t stream);
-int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);
+int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);   /* same b_presplit in both */
+int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* problem, spgnn_stream_t stream);                               /* one product (= spgnn_gemm_tn + b_presplit) */
 
 /* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */

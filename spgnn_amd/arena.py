@@ -1,0 +1,186 @@
+"""Batch arenas: loader batches of one size class share ONE set of device buffers, so a training step captured on the
+first batch of the class (train.TrainStep.capture: two HIP graphs) serves every later one - a new batch is a handful of
+device copies into fixed addresses plus ``replay()``, not a warm-up, a capture and an instantiation.
+
+Reference loop being served (job_runner.py:1870-1920, exp_settings/st_pgat_spgnn_3.py:29,34): for every loader batch of
+TRAIN_BATCH_SIZE = 64 trees, build the batched graph, then take GCN_STEPS = 300 optimizer steps on it.  The batches
+differ in node and edge count (trees of 100-300 branches), and a HIP graph bakes in every kernel's grid size, every
+N / E argument and every pointer.  So a batch is PADDED to its size class: N up to the next multiple of ``granule``
+nodes, E up to the edge count of that many nodes, by appending pad nodes that
+
+  * form components of their own (one path + isolated nodes; every pad node has its self loop, as every real node does:
+    ``g.add_edges(g.nodes(), g.nodes())``, job_runner.py:1800) - no edge joins them to a tree, so no real node's output
+    changes (the adjacency stays block diagonal, the same fact tree-sharded data parallelism rests on);
+  * carry zero features and positional encodings and label 0;
+  * are never sampled into the loss: their sampling probability is -1 (train.TrainStep._sampling), so the node mask of
+    job_runner.py:1896 excludes them, their logit gradient is zero and they contribute nothing to any weight gradient.
+
+What padding does change: per-tensor GEMM scales see the pad rows' activations (bounded by the bias terms), and split-K
+row ranges move - i.e. fp32 summation order, within the parity tolerance, never an index (tests/test_arena.py compares
+replays on an arena with eager steps on the same padded graph bit for bit, and with the unpadded batch to 1e-5).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import graph as G
+from . import ops
+
+__all__ = ["BatchArena", "size_class"]
+
+
+def size_class(num_nodes: int, num_edges: int, num_trees: int, granule: int = 256) -> Tuple[int, int]:
+    """(n_cap, e_cap) of the arena a batch of ``num_nodes`` / ``num_edges`` (self loops included) goes to.  n_cap: the next
+    multiple of ``granule`` strictly above N (at least one pad node).  e_cap: for tree batches E = 3N - 2B, so the edge
+    count of n_cap nodes in B + 1 trees - the pad is then ONE path and every batch of B trees in this node class shares the
+    class; a batch that does not fit that (not trees, or another B) gets the class of its own edge count."""
+    n_cap = (num_nodes // granule + 1) * granule
+    n_pad = n_cap - num_nodes
+    e_cap = 3 * n_cap - 2 * (num_trees + 1)
+    twice_m = e_cap - num_edges - n_pad                   # pad edges beyond the self loops: 2 per undirected path edge
+    if twice_m < 0 or twice_m % 2 or twice_m // 2 > n_pad - 1:
+        e_cap = num_edges + n_pad + 2 * (n_pad - 1)       # the whole pad as one path
+    return n_cap, e_cap
+
+
+def _pad_graph(n_pad: int, m: int) -> Dict[str, np.ndarray]:
+    """Index arrays of the pad component(s): nodes 0..m a path (m undirected edges), nodes m+1.. isolated, a self loop on
+    every node; edge ids in the reference's order (off-diagonal entries by (u, v), then the self loops,
+    job_runner.py:1779-1801).  Local node / edge / slot numbers: the arena offsets them."""
+    j = np.arange(m + 1, dtype=np.int64)
+    u = np.concatenate([j[1:], j[:-1]])
+    v = np.concatenate([j[1:] - 1, j[:-1] + 1])
+    order = np.lexsort((v, u))
+    loops = np.arange(n_pad, dtype=np.int64)
+    src, dst = np.concatenate([u[order], loops]), np.concatenate([v[order], loops])
+    arrays = G.build_csc_numpy(src, dst, n_pad)
+    arrays["src"], arrays["dst"] = src.astype(np.int32), dst.astype(np.int32)
+    return arrays
+
+
+class BatchArena:
+    """Fixed-address storage for the batches of one size class on one device."""
+
+    INDEX_KEYS = ("indptr", "indices", "eid", "out_indptr", "out_indices", "out_pos")
+
+    def __init__(self, first: G.TreeGraph, granule: int = 256):
+        dev = first.device
+        if dev.type != "cuda":
+            raise RuntimeError("BatchArena serves captured HIP graphs: it needs a ROCm device")
+        N, E, B = first.number_of_nodes(), first.number_of_edges(), first.batch_size
+        self.granule, self.device = granule, dev
+        self.n_cap, self.e_cap = size_class(N, E, B, granule)
+        self.key = self.class_key(first, granule)
+        i32 = lambda n: torch.zeros((n,), dtype=torch.int32, device=dev)
+        t = dict(indptr=i32(self.n_cap + 1), indices=i32(self.e_cap), eid=i32(self.e_cap), out_indptr=i32(self.n_cap + 1),
+                 out_indices=i32(self.e_cap), out_pos=i32(self.e_cap))
+        self.src, self.dst = i32(self.e_cap), i32(self.e_cap)
+        csc = G.DeviceCSC.from_tensors(t, self.n_cap, self.e_cap)
+        g = self.graph = G.TreeGraph.from_device(self.src, self.dst, self.n_cap, csc, [self.n_cap], [self.e_cap])
+        g._stable_storage = True
+        g._refresh_hooks = []
+        g.arena = self
+        # node data: same names, widths and dtypes as the first batch; aliases (ndata['p'] is ndata['pos_enc']) stay aliases
+        made: Dict[int, torch.Tensor] = {}
+        for k, v in first.ndata.items():
+            buf = made.get(id(v))
+            if buf is None:
+                buf = made[id(v)] = torch.zeros((self.n_cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
+            dict.__setitem__(g.ndata, k, buf)            # (plain insert: _NData.__setitem__ would clear the derived cache)
+        self.loads = 0
+
+    @staticmethod
+    def class_key(g: G.TreeGraph, granule: int = 256):
+        csc = g.csc(g.device)
+        n_cap, e_cap = size_class(g.number_of_nodes(), g.number_of_edges(), g.batch_size, granule)
+        nd = tuple(sorted((k, tuple(v.shape[1:]), str(v.dtype)) for k, v in g.ndata.items()))
+        # the kernels choose their forms from the degree bounds (<= 8 in- / out-edges: the straight-line paths): a batch
+        # on the other side of that line must not replay a graph captured on this side
+        return (str(g.device), n_cap, e_cap, csc.max_in_degree <= 8, csc.max_out_degree <= 8, nd)
+
+    def load(self, g: G.TreeGraph) -> G.TreeGraph:
+        """Copy batch ``g`` (a device graph with its node data; e.g. data.assemble_batch) into the arena, pad it to the class
+        and refresh everything derived from it, in place.  -> the arena's graph (always the same object)."""
+        if self.class_key(g, self.granule) != self.key:
+            raise ValueError("batch does not belong to this arena's size class")
+        ag, dev = self.graph, self.device
+        csc, acsc = g.csc(dev), ag.csc(dev)
+        N, E = g.number_of_nodes(), g.number_of_edges()
+        n_pad = self.n_cap - N
+        m = (self.e_cap - E - n_pad) // 2
+        pad = _pad_graph(n_pad, m)
+        order = ("indptr", "out_indptr", "indices", "out_indices", "eid", "out_pos", "src", "dst")
+        host = np.concatenate([pad[k].astype(np.int32, copy=False) for k in order])
+        up = torch.from_numpy(host).to(dev)                                # ONE upload for the pad's index arrays
+        off, pieces = 0, {}
+        for k in order:
+            pieces[k] = up[off:off + pad[k].shape[0]]
+            off += pad[k].shape[0]
+        with torch.no_grad():
+            for k in ("indptr", "out_indptr"):                              # slot offsets: real edges fill slots [0, E)
+                dst = getattr(acsc, k)
+                dst[:N + 1].copy_(getattr(csc, k))
+                torch.add(pieces[k][1:], E, out=dst[N + 1:])
+            for k, shift in (("indices", N), ("out_indices", N), ("eid", E), ("out_pos", E)):
+                dst = getattr(acsc, k)
+                dst[:E].copy_(getattr(csc, k))
+                torch.add(pieces[k], shift, out=dst[E:])
+            s_, d_ = g.edges()
+            self.src[:E].copy_(s_); self.dst[:E].copy_(d_)
+            torch.add(pieces["src"], N, out=self.src[E:]); torch.add(pieces["dst"], N, out=self.dst[E:])
+            seen = set()
+            for k, v in g.ndata.items():
+                buf = ag.ndata[k]
+                if id(buf) in seen:
+                    continue
+                seen.add(id(buf))
+                buf[:N].copy_(v)
+                buf[N:].zero_()
+        acsc.min_in_degree = min(csc.min_in_degree, 1)
+        acsc.max_in_degree = max(csc.max_in_degree, 3 if m > 1 else (2 if m == 1 else 1))
+        acsc.max_out_degree = max(csc.max_out_degree, 3 if m > 1 else (2 if m == 1 else 1))
+        acsc.min_out_degree = min(getattr(csc, "min_out_degree", 1) or 1, 1)
+        ag.num_real_nodes, ag.num_real_edges = N, E
+        ag.batch_num_nodes_list = list(g.batch_num_nodes_list) + [n_pad]
+        ag.batch_num_edges_list = list(g.batch_num_edges_list) + [self.e_cap - E]
+        ag._src_np = ag._dst_np = None
+        self._refresh(acsc)
+        self.loads += 1
+        return ag
+
+    def _refresh(self, acsc: G.DeviceCSC) -> None:
+        """Everything computed FROM the batch, recomputed into the storage a captured step already addresses: the padded
+        neighbour rows and degree vectors of the graph, the cached concatenations / aligned copies of node data with their
+        GEMM scales and pre-split images, and whatever a training step registered (its sampling probabilities)."""
+        ag = self.graph
+        with torch.no_grad():
+            old = dict(acsc._cache)
+            acsc._cache = {}
+            for key, val in old.items():
+                if key == "ell":
+                    new = acsc.ell()
+                elif key == "in_deg":
+                    new = acsc.in_degrees_f()
+                elif key == "out_deg":
+                    new = acsc.out_degrees_f()
+                elif isinstance(key, tuple) and key[0] == "deg_scale":
+                    new = acsc.degree_scale(key[1], key[2])
+                else:
+                    continue
+                for o, n_ in zip(val if isinstance(val, tuple) else (val,), new if isinstance(new, tuple) else (new,)):
+                    o.copy_(n_)
+            acsc._cache = old
+            for key, builder in list(ag._derived_builders.items()):
+                held = ag._tensor_cache[key]
+                held.copy_(builder())
+                ops.refresh_batch_constant(held)
+            seen = set()
+            for v in ag.ndata.values():
+                if id(v) not in seen and getattr(v, "_spgnn_const", False):
+                    ops.refresh_batch_constant(v)
+                seen.add(id(v))
+            for fn in ag._refresh_hooks:
+                fn()

@@ -467,7 +467,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   }
 }
 
-template <int WM, bool BPS, bool DROP>
+template <int WM, bool APS, bool BPS, bool DROP>   // APS / BPS: the A / B operand arrives pre-split (see Args)
 __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, const unsigned nb) {   // workgroup b of the nb this product owns
   constexpr int TBM = 64 * WM, NT = 128 * WM;
   constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
@@ -504,10 +504,10 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
   BIO::load_any(a.B, a.ldb, col0, a.N, BK, a.K, rb1);
   {
     _Float16* st = smem;
-    AIO::mask(ra0, 0, a.K);
+    AIO::template mask_as<APS>(ra0, 0, a.K);
     BIO::template mask_as<BPS>(rb0, 0, a.K);
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) AIO::store_one(st, st + A_IMG, ra0[i], i, sA);
+    for (int i = 0; i < NLA; ++i) AIO::template put<APS>(st, st + A_IMG, ra0[i], i, sA);
 #pragma unroll
     for (int i = 0; i < NLB; ++i) BIO::template put<BPS>(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
   }
@@ -523,7 +523,7 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
     _Float16* nbuf = smem + (1 - (PAR_)) * STAGE;                                                            \
     const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
     if (!(STEADY_) && has_next) {                                                                            \
-      AIO::mask(RA, ((T_) + 1) * BK, a.K);                                                                   \
+      AIO::template mask_as<APS>(RA, ((T_) + 1) * BK, a.K);                                                  \
       BIO::template mask_as<BPS>(RB, ((T_) + 1) * BK, a.K);                                                                  \
     }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
@@ -547,7 +547,7 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
           const int slot = ks * 4 + c / 3;                                                                   \
           _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                    \
             if (q * 8 / NLA == slot || (NLA > 8 && q % 8 == slot))                                           \
-              AIO::store_one(nbuf, nbuf + A_IMG, RA[q], q, sA);                                              \
+              AIO::template put<APS>(nbuf, nbuf + A_IMG, RA[q], q, sA);                                      \
           _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                    \
             if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                           \
               BIO::template put<BPS>(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                    \
@@ -590,14 +590,14 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
 // leaves idle instead of in a launch of their own.
 struct PairArgs { Args p[2]; unsigned nb0; };
 
-template <int WM, bool BPS>
+template <int WM, bool APS, bool BPS>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
-  nt_v2_body<WM, BPS, true>(a, blockIdx.x, gridDim.x);
+  nt_v2_body<WM, APS, BPS, true>(a, blockIdx.x, gridDim.x);
 }
-template <int WM, bool BPS>
+template <int WM, bool APS, bool BPS>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(PairArgs pa) {
   const bool second = blockIdx.x >= pa.nb0;                 // block-uniform: the arguments are read from one half of the kernarg
-  nt_v2_body<WM, BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  nt_v2_body<WM, APS, BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(Pai
 // (B once, A for two of the four row tiles at a time) to stay inside 256 registers.  LDS: 2 stages x 4 images of
 // 256 rows x 80 bytes = 160 KB.
 // -------------------------------------------------------------------------------------------------
-template <bool BPS, bool DROP>
+template <bool APS, bool BPS, bool DROP>
 __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, const unsigned nb) {
   constexpr int TB = 256;
   constexpr int IMG = TB * PITCH;                               // halves per image
@@ -653,6 +653,8 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
   }
 #define SPGNN_PUTB(IMG0_, R_, I_)                                                                            \
   { if constexpr (BPS) SPGNN_RAW(IMG0_, R_, I_) else SPGNN_CVT(IMG0_, R_, I_, sB) }
+#define SPGNN_PUTA(IMG0_, R_, I_)                                                                            \
+  { if constexpr (APS) SPGNN_RAW(IMG0_, R_, I_) else SPGNN_CVT(IMG0_, R_, I_, sA) }
 #define SPGNN_MASKG(R_, K0_)                                                                                 \
   {                                                                                                          \
     if (!((K0_) + kq < a.K)) { _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) R_[q_] = u32x4{0u, 0u, 0u, 0u}; } \
@@ -680,10 +682,10 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
   for (int i = 0; i < 4; ++i) ra[i] = SPGNN_LDA(i, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) rb[i] = SPGNN_LDB(i, 0);
-  SPGNN_MASK(ra, 0)
+  if constexpr (APS) SPGNN_MASKG(ra, 0) else SPGNN_MASK(ra, 0)
   if constexpr (BPS) SPGNN_MASKG(rb, 0) else SPGNN_MASK(rb, 0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) SPGNN_CVT(smem, ra[i], i, sA)
+  for (int i = 0; i < 4; ++i) SPGNN_PUTA(smem, ra[i], i)
 #pragma unroll
   for (int i = 0; i < 4; ++i) SPGNN_PUTB(smem + 2 * IMG, rb[i], i)
 #pragma unroll
@@ -702,7 +704,7 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
     _Float16* nbuf = smem + (1 - (PAR_)) * STAGE;                                                            \
     const bool has_next = (STEADY_) || (T_) + 1 < nk;                                                        \
     if (!(STEADY_) && has_next) {                                                                            \
-      SPGNN_MASK(ra, ((T_) + 1) * BK)                                                                        \
+      if constexpr (APS) SPGNN_MASKG(ra, ((T_) + 1) * BK) else SPGNN_MASK(ra, ((T_) + 1) * BK)               \
       if constexpr (BPS) SPGNN_MASKG(rb, ((T_) + 1) * BK) else SPGNN_MASK(rb, ((T_) + 1) * BK)               \
     }                                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                                 \
@@ -730,7 +732,7 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
             const int slot = ks * 4 + h * 2 + c / 6;                       /* 8 slots = 4 A + 4 B registers */ \
             const int k2 = ((T_) + 2) * BK;                                                                  \
             if (slot < 4) {                                                                                  \
-              SPGNN_CVT(nbuf, ra[slot], slot, sA)                                                            \
+              SPGNN_PUTA(nbuf, ra[slot], slot)                                                               \
               ra[slot] = SPGNN_LDA(slot, k2);                                                                \
             } else {                                                                                         \
               SPGNN_PUTB(nbuf + 2 * IMG, rb[slot - 4], slot - 4)                                             \
@@ -761,18 +763,19 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
 #undef SPGNN_MASK
 #undef SPGNN_MASKG
 #undef SPGNN_PUTB
+#undef SPGNN_PUTA
 #undef SPGNN_RAW
 
   store_tile_through_lds<DROP>(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
-template <bool BPS>
+template <bool APS, bool BPS>
 __global__ __launch_bounds__(512) void gemm_nt_f16x3_v3(Args a) {
-  nt_v3_body<BPS, true>(a, blockIdx.x, gridDim.x);
+  nt_v3_body<APS, BPS, true>(a, blockIdx.x, gridDim.x);
 }
-template <bool BPS>
+template <bool APS, bool BPS>
 __global__ __launch_bounds__(512) void gemm_nt_pair_v3(PairArgs pa) {
   const bool second = blockIdx.x >= pa.nb0;
-  nt_v3_body<BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  nt_v3_body<APS, BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // A phase-skewed form of this kernel (the two waves of every SIMD one phase apart - R: fragment reads + wait, M: twelve
@@ -835,6 +838,15 @@ __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, 
   *reinterpret_cast<uint2*>(lo_img + off) = l;
 }
 
+// pre-split operand (see Args): the staged 16 bytes ARE the hi / lo halves of four consecutive columns of one k-row
+__device__ __forceinline__ void store_raw_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i) {
+  const int idx = threadIdx.x + kThreads * i;
+  const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
+  *reinterpret_cast<uint2*>(hi_img + off) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+  *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+}
+
+template <bool BPS>      // BPS: B (= X, the layer input; constant node data for a model's first layer) arrives pre-split
 __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, const unsigned nblocks) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];          // 2 stages x (Ah | Al | Bh | Bl)
   constexpr int STAGE = 4 * TTILE;
@@ -906,11 +918,19 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
     R_[q].z = rv && (C_) + 2 < (W_) ? R_[q].z : 0.f;                                                         \
     R_[q].w = rv && (C_) + 3 < (W_) ? R_[q].w : 0.f;                                                         \
   }
+  // pre-split rows: a group that straddles the width is zero padded in memory; one at or beyond it came from column 0
+#define SPGNN_TN_MASKG(R_, C_, W_, ROWS_TOO, T_)                                                             \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + trow + 8 * q < r_end;                       \
+    if (!(rv && (C_) < (W_))) R_[q] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+  }
 #define SPGNN_TN_MASK(T_, RA, RB, ROWS_TOO)                                                                  \
   {                                                                                                          \
     if ((ROWS_TOO) || edge_a) SPGNN_TN_MASK1(RA, ca, a.M, ROWS_TOO, T_)                                      \
-    if ((ROWS_TOO) || edge_b) SPGNN_TN_MASK1(RB, cbn, a.N, ROWS_TOO, T_)                                     \
+    if ((ROWS_TOO) || edge_b) { if constexpr (BPS) SPGNN_TN_MASKG(RB, cbn, a.N, ROWS_TOO, T_) else SPGNN_TN_MASK1(RB, cbn, a.N, ROWS_TOO, T_) } \
   }
+#define SPGNN_TN_PUTB(HI_, LO_, R_, I_)                                                                      \
+  { if constexpr (BPS) store_raw_t(HI_, LO_, R_, I_); else store_one_t(HI_, LO_, R_, I_, sB); }
 #define SPGNN_TN_CSUM(RA)                                                            \
   if (do_colsum) {                                                                   \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
@@ -924,7 +944,7 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) store_one_t(st, st + TTILE, ra0[q], q, sA);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) store_one_t(st + 2 * TTILE, st + 3 * TTILE, rb0[q], q, sB);
+    for (int q = 0; q < 4; ++q) SPGNN_TN_PUTB(st + 2 * TTILE, st + 3 * TTILE, rb0[q], q)
     __syncthreads();
     SPGNN_TN_LOAD_ANY(2, ra0, rb0)
 
@@ -957,7 +977,7 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
         if (has_next && c % 3 == 2) {                                                                        \
           const int slot = ks * 4 + c / 3;                              /* 8 slots, 8 float4 to convert */   \
           if (slot < 4) store_one_t(nbuf, nbuf + TTILE, RA[slot], slot, sA);                                 \
-          else store_one_t(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4, sB);                  \
+          else SPGNN_TN_PUTB(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4)                     \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -982,6 +1002,8 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
 #undef SPGNN_TN_LOAD_ANY
 #undef SPGNN_TN_MASK
 #undef SPGNN_TN_MASK1
+#undef SPGNN_TN_MASKG
+#undef SPGNN_TN_PUTB
 #undef SPGNN_TN_CSUM
 
   if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
@@ -1021,11 +1043,13 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
       }
     }
 }
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) { tn_v2_body(a, blockIdx.x, gridDim.x); }
+template <bool BPS>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) { tn_v2_body<BPS>(a, blockIdx.x, gridDim.x); }
 struct PairArgsTN { ArgsTN p[2]; unsigned nb0; };
+template <bool BPS>
 __global__ __launch_bounds__(kThreads, 2) void gemm_tn_pair_v2(PairArgsTN pa) {          // see gemm_nt_pair_v2
   const bool second = blockIdx.x >= pa.nb0;
-  tn_v2_body(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  tn_v2_body<BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
@@ -1711,24 +1735,33 @@ static size_t gemm_nt_lds(int variant) {
                       : 2 * (2 * TBM + 2 * gemm::BN) * gemm::PITCH * sizeof(_Float16);
 }
 
-static int gemm_nt_launch(const NtPlan& p0, const NtPlan* p1, int32_t b_presplit, hipStream_t st) {
+// `presplit`: SPGNN_PRESPLIT_B (1) = B pre-split, SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B (3) = both operands pre-split (a
+// constant A - node data of a model's first layer - is split once per loader batch, next to weights split once per step)
+static bool presplit_mask_ok(int32_t presplit) { return presplit == 0 || presplit == SPGNN_PRESPLIT_B || presplit == (SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B); }
+
+static int gemm_nt_launch(const NtPlan& p0, const NtPlan* p1, int32_t presplit, hipStream_t st) {
   const int variant = p0.variant;
   const size_t lds_bytes = gemm_nt_lds(variant);
   const int threads = variant == 2 ? 256 : 512;
 #define SPGNN_LAUNCH_NT(KERNEL_, BLOCKS_, ARG_)                                                                \
   { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; \
     hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(BLOCKS_)), dim3(threads), lds_bytes, st, ARG_); }
+#define SPGNN_LAUNCH_NT_PS(KERNEL_, BLOCKS_, ARG_, ...)                                                        \
+  { if (presplit == 3) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ true, true>), BLOCKS_, ARG_)                        \
+    else if (presplit == 1) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ false, true>), BLOCKS_, ARG_)                  \
+    else SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ false, false>), BLOCKS_, ARG_) }
   if (!p1) {
-    if (variant == 5) { if (b_presplit) SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<true>, p0.blocks, p0.a) else SPGNN_LAUNCH_NT(gemm::gemm_nt_f16x3_v3<false>, p0.blocks, p0.a) }
-    else if (variant == 4) { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, true>), p0.blocks, p0.a) else SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<4, false>), p0.blocks, p0.a) }
-    else { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, true>), p0.blocks, p0.a) else SPGNN_LAUNCH_NT((gemm::gemm_nt_f16x3_v2<2, false>), p0.blocks, p0.a) }
+    if (variant == 5) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v3, p0.blocks, p0.a, )
+    else if (variant == 4) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 4, )
+    else SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 2, )
   } else {
     gemm::PairArgs pa{{p0.a, p1->a}, (unsigned)p0.blocks};
     const int64_t blocks = p0.blocks + p1->blocks;
-    if (variant == 5) { if (b_presplit) SPGNN_LAUNCH_NT(gemm::gemm_nt_pair_v3<true>, blocks, pa) else SPGNN_LAUNCH_NT(gemm::gemm_nt_pair_v3<false>, blocks, pa) }
-    else if (variant == 4) { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<4, true>), blocks, pa) else SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<4, false>), blocks, pa) }
-    else { if (b_presplit) SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<2, true>), blocks, pa) else SPGNN_LAUNCH_NT((gemm::gemm_nt_pair_v2<2, false>), blocks, pa) }
+    if (variant == 5) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v3, blocks, pa, )
+    else if (variant == 4) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v2, blocks, pa, 4, )
+    else SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v2, blocks, pa, 2, )
   }
+#undef SPGNN_LAUNCH_NT_PS
 #undef SPGNN_LAUNCH_NT
   return spgnn_detail::check_launch("spgnn_gemm");
 }
@@ -1739,7 +1772,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                         int32_t activation, const float* score_l, const float* score_r, float* score_out, int32_t score_cols,
                         const float* mean_other, int64_t mean_other_stride, float* mean_out, int64_t mean_out_stride,
                         int32_t tile, int32_t b_presplit, spgnn_stream_t stream) {
-  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (!presplit_mask_ok(b_presplit)) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   NtPlan p;
   const int rc = gemm_nt_plan(A, lda, B, ldb, C, ldc, M, N, K, scale_a, scale_b, upd_u, upd_u_stride, upd_v, upd_v_stride, upd_j, bias,
                               activation, score_l, score_r, score_out, score_cols, mean_other, mean_other_stride, mean_out,
@@ -1763,7 +1796,7 @@ static int nt_plan_of(const spgnn_gemm_nt_problem* q, NtPlan* p) {
 
 int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream) {
   if (!problem) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (!presplit_mask_ok(b_presplit)) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   NtPlan p;
   const int rc = nt_plan_of(problem, &p);
   if (rc != SPGNN_OK || p.blocks == 0) return rc;
@@ -1773,7 +1806,7 @@ int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_pr
 int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
                        spgnn_stream_t stream) {
   if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  if (b_presplit != 0 && b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (!presplit_mask_ok(b_presplit)) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if (first->drop_p > 0.f || second->drop_p > 0.f)                 // the pair kernels carry no dropout epilogue
     return spgnn_detail::fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_pair: drop_p is a single-product option (spgnn_gemm_nt_problem_run)");
   NtPlan p0, p1;
@@ -1850,6 +1883,7 @@ int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale
 static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                         int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
                         float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, gemm::ArgsTN* a, int64_t* blocks) {
+  *blocks = 0;
   if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
   if (!A || !B || !C) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
@@ -1866,6 +1900,18 @@ static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb
   return SPGNN_OK;
 }
 
+static int gemm_tn_launch1(const gemm::ArgsTN& a, int64_t blocks, int32_t b_presplit, hipStream_t st) {
+  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
+  if (b_presplit) {
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2<true>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2<true>, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, st, a);
+  } else {
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2<false>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2<false>, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, st, a);
+  }
+  return spgnn_detail::check_launch("spgnn_gemm");
+}
+
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                   int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
                   float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
@@ -1873,10 +1919,17 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   const int rc = gemm_tn_plan(A, lda, B, ldb, C, ldc, split_stride, splits, R, M, N, scale_a, scale_b, colsum_a, colsum_stride,
                               colsum_split_stride, &a, &blocks);
   if (rc != SPGNN_OK) return rc;
-  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-  hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, a);
-  return spgnn_detail::check_launch("spgnn_gemm");
+  return gemm_tn_launch1(a, blocks, 0, (hipStream_t)stream);
+}
+
+int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* q, spgnn_stream_t stream) {
+  if (!q) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
+  if (q->b_presplit != 0 && q->b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  gemm::ArgsTN a; int64_t blocks;
+  const int rc = gemm_tn_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->split_stride, q->splits, q->R, q->M, q->N, q->scale_a,
+                              q->scale_b, q->colsum_a, q->colsum_stride, q->colsum_split_stride, &a, &blocks);
+  if (rc != SPGNN_OK) return rc;
+  return gemm_tn_launch1(a, blocks, q->b_presplit, (hipStream_t)stream);
 }
 
 int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream) {
@@ -1891,10 +1944,17 @@ int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_p
     if (rc != SPGNN_OK) return rc;
   }
   if (b0 + b1 > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  if ((first->b_presplit != 0 && first->b_presplit != 1) || first->b_presplit != second->b_presplit)
+    return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn_pair: b_presplit must be 0 or 1 and the same for both products (one kernel runs both)");
   pa.nb0 = (unsigned)b0;
   const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-  hipLaunchKernelGGL(gemm::gemm_tn_pair_v2, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
+  if (first->b_presplit) {
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2<true>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+    hipLaunchKernelGGL(gemm::gemm_tn_pair_v2<true>, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
+  } else {
+    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2<false>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
+    hipLaunchKernelGGL(gemm::gemm_tn_pair_v2<false>, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
+  }
   return spgnn_detail::check_launch("spgnn_gemm");
 }
 

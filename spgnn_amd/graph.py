@@ -262,6 +262,9 @@ class _NData(dict):
         cache = getattr(self._g, "_tensor_cache", None)
         if cache:
             cache.clear()
+        builders = getattr(self._g, "_derived_builders", None)
+        if builders:
+            builders.clear()
 
 
 class TreeGraph:
@@ -287,6 +290,8 @@ class TreeGraph:
         self.ndata = _NData(self)
         self._csc: Dict[str, DeviceCSC] = {}
         self._tensor_cache: Dict[tuple, torch.Tensor] = {}     # per-batch constants derived from node data
+        self._derived_builders: Dict[tuple, object] = {}       # ... and how each is rebuilt (models._derived)
+        self._stable_storage = False                           # True on a batch arena's graph (arena.BatchArena)
 
     is_block = False      # Block (below) is the bipartite message-flow graph of neighbour-sampled training
 

@@ -100,48 +100,75 @@ def _cat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return cat_padded((a, b)) if a.is_cuda else torch.cat([a, b], dim=1)
 
 
+def _ndata_key(g, t: torch.Tensor):
+    """What identifies node-data tensor ``t`` in the per-batch cache of ``g``: on a batch arena (spgnn_amd/arena.py: node data
+    rewritten IN PLACE by every loader batch, derived tensors refreshed in place by ``g.refresh_derived()``) its ndata name;
+    otherwise address, version and shape - a replaced or modified tensor makes a new entry."""
+    if getattr(g, "_stable_storage", False):
+        for name, v in g.ndata.items():
+            if v is t:
+                return ("ndata", name)
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _derived(g, key, builder):
+    """The per-batch constant ``key`` of ``g``, built once per loader batch by ``builder()`` (a graph without the cache:
+    built every time).  The builder is kept: an arena graph recomputes every derived tensor into the same storage."""
+    cache = getattr(g, "_tensor_cache", None)
+    if cache is None:
+        return builder()
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) > 16 and not getattr(g, "_stable_storage", False):
+            cache.clear()
+            getattr(g, "_derived_builders", {}).clear()
+        hit = cache[key] = ops.mark_batch_constant(builder().detach())
+        if hasattr(g, "_derived_builders"):
+            g._derived_builders[key] = builder
+    return hit
+
+
 def _data_cat(g, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """cat of two node-DATA tensors (fvs, pos_enc).  The batched graph and its node data are reused for all
     GCN_STEPS = 300 inner steps (reference job_runner.py:1892), so the concatenation is built once per batch
-    and kept on the graph (keyed by the tensors' identity and version)."""
+    and kept on the graph (keyed by the tensors' identity and version); the GEMMs keep its scale and its pre-split image
+    on it (ops.const_operand)."""
     if a.requires_grad or b.requires_grad or not a.is_cuda or not hasattr(g, "_tensor_cache"):
         return _cat(a, b)
-    key = ("cat", a.data_ptr(), b.data_ptr(), a._version, b._version, tuple(a.shape), tuple(b.shape))
-    hit = g._tensor_cache.get(key)
-    if hit is None:
-        if len(g._tensor_cache) > 8:
-            g._tensor_cache.clear()
-        hit = g._tensor_cache[key] = _cat(a, b).detach()
-    return hit
+    ka, kb = _ndata_key(g, a), _ndata_key(g, b)
+    return _derived(g, ("cat", ka, kb), lambda: _cat(*_ndata_pair(g, ka, kb, a, b)))
+
+
+def _ndata_pair(g, ka, kb, a, b):
+    """The CURRENT tensors behind two cache keys (an arena's builders run again after the node data was rewritten)."""
+    return (g.ndata[ka[1]] if ka[0] == "ndata" else a), (g.ndata[kb[1]] if kb[0] == "ndata" else b)
 
 
 def _data_aligned(g, t: torch.Tensor) -> torch.Tensor:
     """A node-data tensor with 16-byte-aligned rows (e.g. pos_enc, 39 floats wide -> row stride 40), made once
     per batch: the aligned copy is what the MFMA kernels read."""
     already = t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
-    if t.requires_grad or not t.is_cuda or already or not hasattr(g, "_tensor_cache"):
+    if t.requires_grad or not t.is_cuda or not hasattr(g, "_tensor_cache"):
         return t
-    key = ("aligned", t.data_ptr(), t._version, tuple(t.shape))
-    hit = g._tensor_cache.get(key)
-    if hit is None:
-        hit = g._tensor_cache[key] = cat_padded((t,)).detach()
-    return hit
+    if already:
+        return ops.mark_batch_constant(t) if any(v is t for v in g.ndata.values()) else t
+    k = _ndata_key(g, t)
+    return _derived(g, ("aligned", k), lambda: cat_padded((g.ndata[k[1]] if k[0] == "ndata" else t,)))
 
 
 def _data_in(g, t: torch.Tensor, dtype) -> torch.Tensor:
     """A node-DATA tensor in the head's storage dtype: fp32 data -> bf16 rows (16-byte rows, zero padded) once per batch
     (the batched graph and its node data are reused for all GCN_STEPS inner steps, reference job_runner.py:1892)."""
     if dtype is None or t.dtype == dtype:
+        if t.is_cuda and not t.requires_grad and t.dtype == torch.float32 and any(v is t for v in g.ndata.values()):
+            ops.mark_batch_constant(t)          # fp32 node data feeding the first layer's products as it is
         return t
     if dtype != torch.bfloat16 or t.dtype != torch.float32:
         raise ValueError(f"storage dtype {dtype} from node data of dtype {t.dtype} is not supported")
     if t.requires_grad or not hasattr(g, "_tensor_cache"):
         return ops_bf16.cast_rows(t)
-    key = ("bf16", t.data_ptr(), t._version, tuple(t.shape))
-    hit = g._tensor_cache.get(key)
-    if hit is None:
-        hit = g._tensor_cache[key] = ops_bf16.cast_rows(t).detach()
-    return hit
+    k = _ndata_key(g, t)
+    return _derived(g, ("bf16", k), lambda: ops_bf16.cast_rows(g.ndata[k[1]] if k[0] == "ndata" else t))
 
 
 def set_storage_dtype(model: nn.Module, dtype) -> nn.Module:
@@ -179,7 +206,7 @@ class GCN(nn.Module):
     def forward(self, g, classifier=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
         (linear) output layer's product."""
-        h = g.ndata["fvs"]
+        h = _data_in(g, g.ndata["fvs"], None)      # fp32 node data: a batch constant for the first layer's products
         specs = [(l.weight, None, True) for l in self.gcn_layers if l.weight is not None] if (h.is_cuda and h.dtype == torch.float32) else []
         with ops.prepared_weights(specs):       # GraphConv's (in, out) weights: the product reads the TRANSPOSED image
             for layer in self.gcn_layers[:-1]:
@@ -255,7 +282,7 @@ class GIN(nn.Module):
     def forward(self, g, classifier=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
         last MLP's second product."""
-        h = g.ndata["fvs"]
+        h = _data_in(g, g.ndata["fvs"], None)      # fp32 node data: a batch constant for the first layer's products
         with ops.prepared_weights(_linear_specs(self, h)):
             for layer in self.gin_layers[:-1]:
                 h = layer(g, h)
@@ -457,7 +484,7 @@ class SAGE(nn.Module):
     def forward(self, g, classifier=None):
         """``classifier`` (extension): the ``*Net``'s ``gnn_out``; returns ``(h, classifier(h))``, the classifier joined to the
         (linear) output layer's product."""
-        h = g.ndata["fvs"]
+        h = _data_in(g, g.ndata["fvs"], None)      # fp32 node data: a batch constant for the first layer's products
         with ops.prepared_weights(_linear_specs(self, h)):
             dropped = False
             for l, layer in enumerate(self.g_layers[:-1]):

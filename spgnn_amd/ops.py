@@ -729,7 +729,9 @@ class _LinearFn(torch.autograd.Function):
         sx = operand_scale(x)
         y = torch.empty((N, C), dtype=torch.float32, device=x.device)
         blk = new_scale_block(x.device) if EMIT_SCALES else None            # max |y| from the product's own epilogue
-        q = NtProblem(x, wb, sx, sw, out=y, b_presplit=bps)
+        xa, aps = const_operand(x, sx) if bps else (x, False)             # node data (the first layer's input): split once per batch
+        ctx.x_ps = xa if aps else None
+        q = NtProblem(xa, wb, sx, sw, out=y, b_presplit=bps, a_presplit=aps)
         q.c.bias, q.c.activation, q.c.absmax_out = _ptr(bias), int(act), _ptr(blk)
         if addend is not None:                                             # act(x W^T + b + addend) in one epilogue
             addend = _rowmajor(addend)
@@ -742,7 +744,7 @@ class _LinearFn(torch.autograd.Function):
             q.c.drop_p, q.c.drop_seed, q.c.drop_seed_offset = float(drop[0]), int(drop[1]), _seed_off_ptr(x.device)
         import ctypes
         with torch.cuda.device(x.device), _timed("gemm_nt", (N, C, K)):
-            _capi.check(_capi.load().spgnn_gemm_nt_problem_run(ctypes.byref(q.c), int(bps), _stream(x)), "spgnn_gemm_nt_problem_run")
+            _capi.check(_capi.load().spgnn_gemm_nt_problem_run(ctypes.byref(q.c), q.b_presplit, _stream(x)), "spgnn_gemm_nt_problem_run")
         ctx.act, ctx.has_bias, ctx.has_addend, ctx.scale_block, ctx.drop = act, bias is not None, addend is not None, blk, None
         ctx.has_cls = w_cls is not None
         if dropping:
@@ -836,14 +838,16 @@ class _LinearFn(torch.autograd.Function):
                 w_t = w.t().contiguous() if C % 4 == 0 else torch.nn.functional.pad(w.t(), (0, -C % 4)).contiguous()[:, :C]
                 gemm_nt(g, w_t, sg, sw, out=g_x)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            xps = getattr(ctx, "x_ps", None)
+            xb, bps = (xps, True) if xps is not None else (x, False)
             if ctx.has_bias:
-                g_w, g_b = gemm_tn(g, x, sg, sx, want_colsum=True)
+                g_w, g_b = gemm_tn(g, xb, sg, sx, want_colsum=True, b_presplit=bps)
             elif ctx.w_transposed:
                 # the weight is the transposed view of an (in, out) parameter (GraphConv): x^T g lands in the parameter's own
                 # layout, so autograd's accumulation takes the tensor as it is instead of copying a transposed view
                 g_w = gemm_tn(x, g, sx, sg).t()
             else:
-                g_w = gemm_tn(g, x, sg, sx)
+                g_w = gemm_tn(g, xb, sg, sx, b_presplit=bps)
         g_add = None
         if ctx.has_addend and ctx.needs_input_grad[4]:
             g_add = g                                    # the addend's producer (the pair's first product) takes it with its scale
@@ -1070,6 +1074,46 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     if not x.requires_grad:
         x._spgnn_scale = (x._version, sc)
     return sc
+
+
+A_PRESPLIT = True      # constant node data (a model's first-layer input) goes to its products pre-split, once per loader batch
+
+
+def mark_batch_constant(t: torch.Tensor) -> torch.Tensor:
+    """``t`` is node DATA of the current loader batch (fvs, cat[fvs, pos_enc], the aligned pos_enc): constant over the
+    reference's GCN_STEPS = 300 inner steps (job_runner.py:1892), so what the GEMMs derive from it - the power-of-two scale and
+    the pre-split image - is made once per batch and kept on the tensor (:func:`const_operand`)."""
+    t._spgnn_const = True
+    return t
+
+
+def const_operand(x: torch.Tensor, scale: torch.Tensor):
+    """(operand, pre-split?) for ``x`` as the fp32 side of a product whose other operand is pre-split: the image
+    :func:`presplit` makes of a batch constant under ``scale`` (built on first use, remembered with the tensor's version),
+    else ``x`` itself."""
+    if not (A_PRESPLIT and PRESPLIT_B and getattr(x, "_spgnn_const", False)) or x.requires_grad or not _rows_aligned(x):
+        return x, False
+    tag = getattr(x, "_spgnn_aps", None)
+    if tag is not None and tag[0] == x._version and tag[2] is scale:
+        return tag[1], True
+    if torch.cuda.is_current_stream_capturing():
+        return x, False                      # never allocate a persistent image inside a capture (the warm-up steps made it)
+    ps = presplit(x, scale=scale)[0]
+    x._spgnn_aps = (x._version, ps, scale)
+    return ps, True
+
+
+def refresh_batch_constant(t: torch.Tensor) -> None:
+    """After ``t`` was rewritten IN PLACE with the next loader batch (arena.BatchArena): its scale and its pre-split image are
+    recomputed into the tensors the captured step already addresses."""
+    tag = getattr(t, "_spgnn_scale", None)
+    if tag is not None:
+        tag[1].copy_(pow2_scale(t))
+        t._spgnn_scale = (t._version, tag[1])
+    aps = getattr(t, "_spgnn_aps", None)
+    if aps is not None:
+        presplit(t, scale=aps[2], out=aps[1])
+        t._spgnn_aps = (t._version, aps[1], aps[2])
 
 
 BIAS_COLSUM = True     # spmm_sum's backward takes the bias gradient from the activation-backward pass (spgnn_act_bwd_colsum)
@@ -1391,7 +1435,9 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
         wb, ps = _b_operand(w_cat)
         ctx.w_t, ctx.w_t_ps = _bt_operand(w_cat, ps)
-        y = gemm_nt(x, wb, sx, sw, score_l=al, score_r=ar, score_out=parts, b_presplit=ps)
+        xa, aps = const_operand(x, sx) if ps else (x, False)       # node data (a model's first layer): split once per loader batch
+        ctx.x_ps = xa if aps else None
+        y = gemm_nt(xa, wb, sx, sw, score_l=al, score_r=ar, score_out=parts, b_presplit=ps, a_presplit=aps)
         s = scores_from_parts(parts, H, D)
         ft = y[:, :HD]
         res = y[:, HD:] if has_res else None
@@ -1449,11 +1495,12 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             big = g_y.shape[1] * K >= _TN_MIN_ELEMS
             if big:
+                xb, bps = (ctx.x_ps, True) if ctx.x_ps is not None else (x, False)
                 if need_bias and has_res:
-                    g_wcat, cs = gemm_tn(g_y, x, sg, sx, want_colsum=True, defer=jobs)
+                    g_wcat, cs = gemm_tn(g_y, xb, sg, sx, want_colsum=True, defer=jobs, b_presplit=bps)
                     g_bias = cs[HD:]
                 else:
-                    g_wcat = gemm_tn(g_y, x, sg, sx, defer=jobs)
+                    g_wcat = gemm_tn(g_y, xb, sg, sx, defer=jobs, b_presplit=bps)
             else:
                 g_wcat = _dw_gemm(g_y, x)
         if need_bias and g_bias is None:
@@ -1589,16 +1636,17 @@ class _LspeLevelFn(torch.autograd.Function):
         E = csc.num_edges
         dev = x_s.device
         lib = _capi.load()
-        ys, ss, parts, scales, wts = [], [], [], [], []
+        ys, ss, parts, scales, wts, x_ps = [], [], [], [], [], []
         ctx.attn_shapes = (al_s.shape, al_p.shape)
         vecs = [(al_s.reshape(-1).contiguous(), ar_s.reshape(-1).contiguous()), (al_p.reshape(-1).contiguous(), ar_p.reshape(-1).contiguous())]
         prods = []
         for x, w, (al, ar), H in ((x_s, w_s, vecs[0], 2), (x_p, w_p, vecs[1], 1)):
             sx, sw = operand_scale(x), operand_scale(w)
             wb, ps = _b_operand(w)
+            xa, aps = const_operand(x, sx) if ps else (x, False)         # level 0: node data, split once per loader batch
             pt = torch.empty((N, H * D // 64, 2), dtype=torch.float32, device=dev)
-            prods.append(NtProblem(x, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps))
-            parts.append(pt); scales.append((sx, sw)); wts.append(_bt_operand(w, ps))
+            prods.append(NtProblem(xa, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps, a_presplit=aps))
+            parts.append(pt); scales.append((sx, sw)); wts.append(_bt_operand(w, ps)); x_ps.append(xa if aps else None)
         ys = list(gemm_nt_pair(prods[0], prods[1]))        # the two projections: one launch
         for pt, H in zip(parts, (2, 1)):
             ss.append(scores_from_parts(pt, H, D) if not LSPE_SCORES_IN_KERNEL else torch.empty((N, 2 * H), dtype=torch.float32, device=dev))
@@ -1623,6 +1671,7 @@ class _LspeLevelFn(torch.autograd.Function):
                                            xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], sc_buf.data_ptr(), sc_xp.data_ptr(),
                                            N, E, D, _seed_off_ptr(dev), _stream(x_s)), "spgnn_lspe_fwd")
         ctx.csc, ctx.D, ctx.cfg, ctx.wts, ctx.has_bias = csc, D, cfg, wts, (bias_s is not None, bias_p is not None)
+        ctx.x_ps = x_ps                          # the pre-split images of constant inputs (not autograd tensors: batch data)
         ctx.save_for_backward(x_s, x_p, w_s, w_p, vecs[0][0], vecs[0][1], vecs[1][0], vecs[1][1], ys[0], ys[1], ss[0], ss[1], attn[0], attn[1],
                               scales[0][0], scales[0][1], scales[1][0], scales[1][1], buf, xp)
         ctx.mark_non_differentiable(attn[0], attn[1], sc_buf, sc_xp)
@@ -1690,7 +1739,9 @@ class _LspeLevelFn(torch.autograd.Function):
             need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
             if ctx.needs_input_grad[2 + i]:
                 if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
-                    tn[i] = TnProblem(g_y[i], x, sg, sx, want_colsum=bool(need_bias and res[i]), defer=jobs)
+                    xb = ctx.x_ps[i]
+                    tn[i] = TnProblem(g_y[i], xb if xb is not None else x, sg, sx, want_colsum=bool(need_bias and res[i]), defer=jobs,
+                                      b_presplit=xb is not None)
                 else:
                     grads_w[i] = _dw_gemm(g_y[i], x)
             if ctx.needs_input_grad[i]:
@@ -2486,7 +2537,7 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 
 
 def presplit(w: torch.Tensor, scale: Optional[torch.Tensor] = None, partials: Optional[torch.Tensor] = None,
-             w2: Optional[torch.Tensor] = None):
+             w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """Pre-split form of a GEMM ``b`` operand (spgnn_presplit): ``w`` (R, K) fp32 with 16-byte rows -> a tensor of the same
     shape and strides holding, per group of four columns, the packed fp16 hi / lo pairs of scale * w.  The scale is given
     (``scale``) or derived from ``partials`` (block maxima) - then it is returned too.  ``w2``: a second matrix under the same
@@ -2496,7 +2547,9 @@ def presplit(w: torch.Tensor, scale: Optional[torch.Tensor] = None, partials: Op
     def like(t):
         buf = torch.empty((t.shape[0], t.stride(0)), dtype=torch.float32, device=t.device)
         return buf[:, :t.shape[1]]
-    w_ps, w2_ps = like(w), (like(w2) if w2 is not None else None)
+    if out is not None:                      # refill an existing pre-split image (a batch arena keeps its address)
+        assert out.shape == w.shape and out.stride() == w.stride() and out.dtype == torch.float32
+    w_ps, w2_ps = (out if out is not None else like(w)), (like(w2) if w2 is not None else None)
     sc_out = torch.empty(1, dtype=torch.float32, device=w.device) if scale is None else None
     with torch.cuda.device(w.device):
         _capi.check(_capi.load().spgnn_presplit(_ptr(partials), partials.numel() if partials is not None else 0, _ptr(scale), _ptr(sc_out),
@@ -2511,11 +2564,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
             upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, act: int = 0, score_l: Optional[torch.Tensor] = None,
             score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0,
-            b_presplit: bool = False) -> torch.Tensor:
+            b_presplit: bool = False, a_presplit: bool = False) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
     in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias).  ``score_out``
     (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns.
-    ``b_presplit``: ``b`` is the pre-split form of the operand (:func:`presplit`, made with ``scale_b``)."""
+    ``b_presplit``: ``b`` is the pre-split form of the operand (:func:`presplit`, made with ``scale_b``); ``a_presplit``
+    (only together with it): ``a`` likewise, made with ``scale_a`` (constant node data, split once per loader batch)."""
+    b_presplit = int(bool(b_presplit)) | (2 if a_presplit else 0)
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -2546,7 +2601,8 @@ PAIR_GEMMS = True       # a level's structure + position products as ONE launch 
 class NtProblem:
     """One gemm_nt call, described but not launched (see :func:`gemm_nt_pair`); ``out`` is allocated here."""
 
-    def __init__(self, a, b, scale_a=None, scale_b=None, out=None, score_l=None, score_r=None, score_out=None, b_presplit=False):
+    def __init__(self, a, b, scale_a=None, scale_b=None, out=None, score_l=None, score_r=None, score_out=None, b_presplit=False,
+                 a_presplit=False):
         _require_cuda(a, b)
         M, K = a.shape
         N = b.shape[0]
@@ -2554,8 +2610,9 @@ class NtProblem:
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         assert out.shape == (M, N) and out.stride(1) == 1
-        self.out, self.shape, self.b_presplit = out, (M, N, K), bool(b_presplit)
-        self.kw = dict(scale_a=scale_a, scale_b=scale_b, out=out, score_l=score_l, score_r=score_r, score_out=score_out, b_presplit=b_presplit)
+        self.out, self.shape, self.b_presplit = out, (M, N, K), int(bool(b_presplit)) | (2 if a_presplit else 0)   # the C ABI's mask
+        self.kw = dict(scale_a=scale_a, scale_b=scale_b, out=out, score_l=score_l, score_r=score_r, score_out=score_out,
+                       b_presplit=b_presplit, a_presplit=a_presplit)
         self.a, self.b = a, b
         q = self.c = _capi.GemmNtProblem()
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K
@@ -2633,7 +2690,8 @@ class TnProblem:
 
     def __init__(self, a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
                  scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
-                 out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
+                 out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None,
+                 b_presplit: bool = False):
         _require_cuda(a, b)
         R, M = a.shape
         N = b.shape[1]
@@ -2659,13 +2717,12 @@ class TnProblem:
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.split_stride = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc
         q.R, q.M, q.N, q.scale_a, q.scale_b = R, M, N, _ptr(scale_a), _ptr(scale_b)
         q.colsum_a, q.colsum_stride, q.colsum_split_stride, q.splits = cs_ptr, ldc, M * ldc, splits
+        q.b_presplit = self.b_presplit = int(bool(b_presplit))      # b = the pre-split image of X (presplit() under scale_b)
 
     def launch(self):
-        q = self.c
+        import ctypes
         with torch.cuda.device(self.a.device), _timed("gemm_tn", self.shape):
-            _capi.check(_capi.load().spgnn_gemm_tn(q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.split_stride, q.splits, q.R, q.M, q.N,
-                                                   q.scale_a, q.scale_b, q.colsum_a, q.colsum_stride, q.colsum_split_stride,
-                                                   _stream(self.a)), "spgnn_gemm_tn")
+            _capi.check(_capi.load().spgnn_gemm_tn_problem_run(ctypes.byref(self.c), _stream(self.a)), "spgnn_gemm_tn_problem_run")
         return self
 
     def finish(self):
@@ -2686,19 +2743,21 @@ class TnProblem:
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
-            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None):
+            out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None,
+            b_presplit: bool = False):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
     over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
     accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
     stride): write the result there - with ``out2`` columns [0, out.shape[1]) to ``out`` and the rest to ``out2``;
-    ``colsum_out`` (M,) contiguous likewise for the column sums."""
-    return TnProblem(a, b, scale_a, scale_b, want_colsum, out, out2, colsum_out, defer).launch().finish()
+    ``colsum_out`` (M,) contiguous likewise for the column sums.  ``b_presplit``: ``b`` is the pre-split image of the
+    operand (:func:`presplit` under ``scale_b``)."""
+    return TnProblem(a, b, scale_a, scale_b, want_colsum, out, out2, colsum_out, defer, b_presplit).launch().finish()
 
 
 def gemm_tn_pair(first: TnProblem, second: TnProblem):
     """Both weight-gradient products in one launch (spgnn_gemm_tn_pair), then each one's ``finish()`` - bit-identical to two
     gemm_tn calls, which is what runs when PAIR_GEMMS is off."""
-    if not PAIR_GEMMS or first.a.device != second.a.device:
+    if not PAIR_GEMMS or first.a.device != second.a.device or first.b_presplit != second.b_presplit:
         return first.launch().finish(), second.launch().finish()
     import ctypes
     with torch.cuda.device(first.a.device), _timed("gemm_tn_pair", first.shape + second.shape):

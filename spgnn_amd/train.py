@@ -151,7 +151,7 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
-        self._sampling_cache = None
+        self._captures, self._arenas = {}, {}       # id(graph) -> its two HIP graphs; size class -> arena.BatchArena
         self._graph = None
         self._lr_dev = None
         self._one = self._loss_out = None
@@ -159,10 +159,25 @@ class TrainStep:
         self._mask_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & ((1 << 62) - 1)
 
     def _sampling(self, g):
+        """Per-node sampling probabilities of ``g``'s labels, kept ON THE GRAPH (a captured step addresses the tensor; one
+        step object may hold captures on several graphs).  Pad nodes of a batch arena (spgnn_amd/arena.py) get -1: the mask
+        ``rn < p`` of job_runner.py:1896 never keeps them.  On an arena the values are recomputed into the same storage
+        whenever a batch is loaded (a refresh hook on the graph)."""
         y = g.ndata["y"]
-        if self._sampling_cache is None or self._sampling_cache[0] is not y:
-            self._sampling_cache = (y, sampling_probabilities(y, self.sampling_rate))
-        return self._sampling_cache[1]
+        store = g.__dict__.setdefault("_sampling_p", {})
+        hit = store.get(self.sampling_rate)
+        if hit is None or hit[0] is not y or hit[1] != y._version:
+            p = sampling_probabilities(y, self.sampling_rate)
+            n_real = getattr(g, "num_real_nodes", None)
+            if n_real is not None:
+                p[n_real:] = -1.0
+            if hit is not None and getattr(g, "_stable_storage", False) and hit[2].shape == p.shape:
+                hit[2].copy_(p)                      # same address: what the captured loss kernel reads
+                p = hit[2]
+            elif getattr(g, "_stable_storage", False):
+                g._refresh_hooks.append(lambda: self._sampling(g))
+            store[self.sampling_rate] = (y, y._version, p)
+        return store[self.sampling_rate][2]
 
     def step(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns the (global) loss as a device scalar; never synchronises with the host."""
@@ -327,8 +342,9 @@ class TrainStep:
         step advances in its first launch (spgnn_step_begin) - no generator state to restore before a replay; the
         learning rate is read from a device scalar (``set_lr`` keeps working)."""
         dev = self.bucket.flat_param.device
-        self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
-        self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)     # installed as ops.DROPOUT_SEED_OFFSET inside _front only
+        if self._lr_dev is None:                   # created once: earlier captures (other batch arenas) keep reading them
+            self._lr_dev = torch.full((1,), float(self.lr), dtype=torch.float32, device=dev)
+            self._seed_ctr = torch.zeros(1, dtype=torch.int64, device=dev)     # installed as ops.DROPOUT_SEED_OFFSET inside _front only
         self._use_default_rng = True
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -352,10 +368,47 @@ class TrainStep:
         finally:
             ops.CAPTURE_REFS = prev_refs
         self._captured_graph = g                    # the node data and index arrays the graphs read
+        self._captures[id(g)] = {"graph": g, "front": self._graph, "back": self._graph_back, "loss": self._static_loss,
+                                 "refs": self._capture_refs}
+        self.capture_steps = max(warmup, 1)        # optimizer steps the warm-up took on ``g`` (they count towards GCN_STEPS)
         return self
+
+    def select(self, g) -> bool:
+        """Make the capture recorded on graph ``g`` the one :meth:`replay` runs (a step object holds one capture per batch
+        arena).  -> whether there is one."""
+        rec = self._captures.get(id(g))
+        if rec is None:
+            return False
+        self._graph, self._graph_back, self._static_loss, self._capture_refs = rec["front"], rec["back"], rec["loss"], rec["refs"]
+        self._captured_graph = g
+        return True
 
     def replay(self) -> torch.Tensor:
         self._graph.replay()
         self._reduce(self.bucket.loss_slot)
         self._graph_back.replay()
         return self._static_loss
+
+    # ---- the reference's loader-batch cycle (job_runner.py:1870-1920): GCN_STEPS steps on every freshly built batch ----
+    def arena_graph(self, g, granule: int = 256):
+        """``g`` (a device batch, e.g. data.assemble_batch) copied into the batch arena of its size class - created on first
+        use - and padded to the class (spgnn_amd/arena.py).  -> the arena's graph, the object to capture / replay on."""
+        from .arena import BatchArena
+        key = BatchArena.class_key(g, granule)
+        arena = self._arenas.get(key)
+        if arena is None:
+            arena = self._arenas[key] = BatchArena(g, granule)
+        return arena.load(g)
+
+    def run_batch(self, g, steps: int, granule: int = 256) -> torch.Tensor:
+        """``steps`` optimizer steps on loader batch ``g`` as HIP-graph replays: the first batch of a size class pays the
+        warm-up steps and the capture, every later one only the copies into the arena.  -> the last step's loss (device)."""
+        ag = self.arena_graph(g, granule)
+        done = 0
+        if not self.select(ag):
+            self.capture(ag)
+            done = self.capture_steps
+            loss = self._static_loss
+        for _ in range(max(steps - done, 0)):
+            loss = self.replay()
+        return loss

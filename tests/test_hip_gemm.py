@@ -91,6 +91,68 @@ def test_gemm_nt_presplit_b_is_bit_identical(M, N, K):
     assert torch.equal(ops.gemm_nt(g, bt_ps, sg, sb, b_presplit=True), ops.gemm_nt(g, bt, sg, sb))
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 384, 1063), (300, 130, 39), (1030, 1024, 384), (513, 260, 100), (4200, 512, 1024)])
+def test_gemm_presplit_a_is_bit_identical(M, N, K):
+    """a_presplit (round 4): a CONSTANT fp32 operand - node data feeding a model's first layer, reference models.py:425-428 -
+    split once per loader batch by spgnn_presplit.  The forward product (A pre-split next to pre-split weights, every tile
+    variant) and the weight-gradient product (X pre-split as the TN kernel's B operand, single and pair launches, ragged
+    widths and row counts) give bit for bit what the in-kernel conversion gives."""
+    torch.manual_seed(M * 3 + N + K)
+    Kp = (K + 3) // 4 * 4
+    x = torch.randn(M, Kp + 4, device="cuda")[:, :K]                       # padded row stride, as cat_padded leaves it
+    w = (torch.randn(N, Kp, device="cuda") / 7)[:, :K]
+    sx, sw = ops.pow2_scale(x), ops.pow2_scale(w)
+    x_ps, w_ps = ops.presplit(x, scale=sx)[0], ops.presplit(w, scale=sw)[0]
+    assert x_ps.stride() == x.stride()
+    ref = ops.gemm_nt(x, w, sx, sw)
+    for tile in (0, 2, 4, 5):
+        assert torch.equal(ops.gemm_nt(x_ps, w_ps, sx, sw, tile=tile, b_presplit=True, a_presplit=True), ref), tile
+    with pytest.raises(RuntimeError):                                       # A-only is not instantiated: the ABI says so
+        ops.gemm_nt(x_ps, w, sx, sw, a_presplit=True)
+    # weight gradient g^T x with x pre-split (the TN kernel's B operand)
+    Np = (N + 3) // 4 * 4
+    g = torch.randn(M, Np + 4, device="cuda")[:, :N]
+    sg = ops.pow2_scale(g)
+    gw, cs = ops.gemm_tn(g, x, sg, sx, want_colsum=True)
+    gw2, cs2 = ops.gemm_tn(g, x_ps, sg, sx, want_colsum=True, b_presplit=True)
+    assert torch.equal(gw, gw2) and torch.equal(cs, cs2)
+    assert rel_err(gw, g.double().t() @ x.double()) < 2e-6
+    # pair launches: both products with pre-split constants (a level's structure + position layers on node data)
+    x1 = torch.randn(M, 40, device="cuda")[:, :39]
+    w1 = (torch.randn(96, 40, device="cuda") / 3)[:, :39]
+    s1, sw1 = ops.pow2_scale(x1), ops.pow2_scale(w1)
+    x1_ps, w1_ps = ops.presplit(x1, scale=s1)[0], ops.presplit(w1, scale=sw1)[0]
+    r0, r1 = ops.gemm_nt(x, w, sx, sw), ops.gemm_nt(x1, w1, s1, sw1)
+    p0 = ops.NtProblem(x_ps, w_ps, sx, sw, b_presplit=True, a_presplit=True)
+    p1 = ops.NtProblem(x1_ps, w1_ps, s1, sw1, b_presplit=True, a_presplit=True)
+    o0, o1 = ops.gemm_nt_pair(p0, p1)
+    assert torch.equal(o0, r0) and torch.equal(o1, r1)
+    g1 = torch.randn(M, 96, device="cuda")
+    sg1 = ops.pow2_scale(g1)
+    t_ref = (ops.gemm_tn(g, x, sg, sx), ops.gemm_tn(g1, x1, sg1, s1))
+    t0 = ops.TnProblem(g, x_ps, sg, sx, b_presplit=True)
+    t1 = ops.TnProblem(g1, x1_ps, sg1, s1, b_presplit=True)
+    q0, q1 = ops.gemm_tn_pair(t0, t1)
+    assert torch.equal(q0, t_ref[0]) and torch.equal(q1, t_ref[1])
+
+
+def test_const_operand_is_built_once_and_refreshed_in_place():
+    """ops.const_operand: the pre-split image of a marked batch constant is made on first use and reused while the tensor is
+    unchanged; refresh_batch_constant rewrites scale and image IN PLACE after the data was overwritten (batch arena)."""
+    x = torch.randn(600, 64, device="cuda")
+    sx = ops.operand_scale(x)
+    assert ops.const_operand(x, sx) == (x, False)                           # not marked: nothing happens
+    ops.mark_batch_constant(x)
+    ps, on = ops.const_operand(x, sx)
+    assert on and ops.const_operand(x, sx)[0] is ps
+    assert torch.equal(ps.view(torch.int32), ops.presplit(x, scale=sx)[0].view(torch.int32))
+    x.copy_(torch.randn(600, 64, device="cuda") * 37.0)
+    ops.refresh_batch_constant(x)
+    assert ops.operand_scale(x) is sx and torch.equal(sx, ops.pow2_scale(x))
+    ps2, on = ops.const_operand(x, sx)
+    assert on and ps2 is ps and torch.equal(ps.view(torch.int32), ops.presplit(x, scale=ops.pow2_scale(x))[0].view(torch.int32))
+
+
 def test_gemm_scaling_keeps_extreme_magnitudes():
     """Values far outside fp16's range (1e-9 .. 1e+7) survive through the power-of-two scales."""
     for mag_a, mag_b in [(1e-9, 1e-3), (1e7, 1e3), (1e-12, 1e6)]:
