@@ -90,15 +90,27 @@ __device__ __forceinline__ float elu_fwd_nb(float x) {
   return x > 0.f ? x : n;
 }
 
+// hi = fp16_rtz(s x), lo = fp16_rtz(s x - hi) in TEN vector instructions per four values: two packed multiplies, two packed
+// conversions, one v_fma_mix_f32 per value for the residual - it reads the fp16 hi half IN PLACE as its addend and folds the
+// scale in as the multiplier (s is a power of two: s x is exact, and so is s x - hi) - and two packed conversions.  The
+// 128 x 128-tile kernels convert eight float4 per thread and stage beside 24 MFMAs: at sixteen instructions per float4 (the
+// first form: hi recovered as `x & 0xFFFFE000`, four multiplies, four ANDs, four subtractions) the conversions alone held the
+// SIMD's issue port for an estimated ~21 of every MFMA's 32 cycles.  Measured in round 4 (two libraries in one process,
+// tools/step_ab.py): 5.187 vs 5.188 ms per step at 512 trees, 1.072 vs 1.070 at 64, st_gin_3 3.727 vs 3.733 - NEUTRAL: the
+// conversions' issue slots are not what holds these kernels.  Kept for the second property: the residual is taken from the
+// hi that was actually stored - the AND form assumed a normal fp16 hi and was off by up to one fp16 subnormal quantum
+// (2^-39 of the tensor maximum) for |s x| < 2^-14.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4_pk(float4 v, float s, uint2& hi, uint2& lo) {
-  const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+  const f32x2 ss = {s, s};
+  const f32x2 a = f32x2{v.x, v.y} * ss, b = f32x2{v.z, v.w} * ss;
   union { pk2 h; unsigned u; } h01, h23, l01, l23;
-  h01.h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  h23.h = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-  const float f0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u), f1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
-  const float f2 = __uint_as_float(__float_as_uint(x2) & 0xFFFFE000u), f3 = __uint_as_float(__float_as_uint(x3) & 0xFFFFE000u);
-  l01.h = __builtin_amdgcn_cvt_pkrtz(x0 - f0, x1 - f1);
-  l23.h = __builtin_amdgcn_cvt_pkrtz(x2 - f2, x3 - f3);
+  h01.h = __builtin_amdgcn_cvt_pkrtz(a.x, a.y);
+  h23.h = __builtin_amdgcn_cvt_pkrtz(b.x, b.y);
+  const float r0 = __builtin_fmaf(v.x, s, -(float)h01.h[0]), r1 = __builtin_fmaf(v.y, s, -(float)h01.h[1]);
+  const float r2 = __builtin_fmaf(v.z, s, -(float)h23.h[0]), r3 = __builtin_fmaf(v.w, s, -(float)h23.h[1]);
+  l01.h = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  l23.h = __builtin_amdgcn_cvt_pkrtz(r2, r3);
   hi = make_uint2(h01.u, h23.u);
   lo = make_uint2(l01.u, l23.u);
 }

@@ -67,6 +67,34 @@ def test_prep_cache_never_evicts_what_a_graph_recorded(monkeypatch):
     assert first in cache and loose[1] not in cache
 
 
+def test_isa_fence_finds_a_packed_write_feeding_a_cross_lane_read(monkeypatch):
+    """csrc/build.py packed_crosslane_hazards: the build fails when a DPP / bpermute / readlane operand was
+    last written by a packed fp32 op; a plain move in between (single_pass()) clears it; registers of a pair are tracked."""
+    from spgnn_amd.csrc import build as b
+    isa = """
+0000000000001000 <bad_kernel>:
+	v_pk_fma_f32 v[4:5], v[0:1], v[2:3], v[4:5] op_sel_hi:[0,1,1]  // 000000001000: 00000000
+	v_add_f32_dpp v6, v5, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf  // 000000001008: 00000000
+	s_endpgm
+0000000000002000 <fenced_kernel>:
+	v_pk_mul_f32 v[4:5], v[0:1], v[2:3]  // 000000002000: 00000000
+	v_mov_b32_e32 v5, v5  // 000000002008: 00000000
+	v_add_f32_dpp v6, v5, v5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf  // 000000002010: 00000000
+	ds_bpermute_b32 v7, v8, v4  // 000000002018: 00000000
+	s_endpgm
+0000000000003000 <far_kernel>:
+	v_pk_add_f32 v[10:11], v[0:1], v[2:3]  // 000000003000: 00000000
+""" + "\tv_add_f32_e32 v20, v21, v22  // 0: 0\n" * (b.HAZARD_WINDOW + 1) + """	v_readlane_b32 s4, v10, 3  // 000000003100: 00000000
+	s_endpgm
+"""
+    monkeypatch.setattr(b, "device_isa", lambda obj: isa)
+    hz = b.packed_crosslane_hazards("x.o")
+    fns = [h[0] for h in hz]
+    assert fns.count("bad_kernel") == 1 and "v5" in hz[0][1]
+    assert fns.count("fenced_kernel") == 1 and "ds_bpermute" in [h for h in hz if h[0] == "fenced_kernel"][0][1]     # v4 of the pair, unfenced
+    assert "far_kernel" not in fns                                     # beyond the window: the two passes are long done
+
+
 def test_ops_refuse_cpu_tensors():
     from spgnn_amd import nn as snn
     from spgnn_amd.graph import TreeGraph

@@ -43,7 +43,8 @@ def _run_pair(tmp_path, config, dtype, trees=64, reps=200):
 
 @pytest.mark.parametrize("config,dtype", [("st_pgat_spgnn_3", "f32"),     # the fused level kernels (spgnn_lspe.hip) + aggregate-first layer
                                           ("st_gat_6", "bf16"),           # bf16 rows: BASELINE config 4's model
-                                          ("st_gat_3", "f32")])           # the fp32 gat_fwd / gat_bwd_dst / gat_bwd_src instantiations
+                                          ("st_gat_3", "f32"),            # the fp32 gat_fwd / gat_bwd_dst / gat_bwd_src instantiations
+                                          ("gemm_kernels", "f32")])       # the matrix-core kernels alone: every cross-lane epilogue, all tiles
 def test_two_processes_share_the_gpu_bitwise_repeatable(tmp_path, config, dtype):
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")

@@ -10,6 +10,15 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return (a - b).abs().max().item() / (denom if denom > 0 else 1.0)
 
 
+def mixed_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """Elementwise mixed error max_i |a_i - b_i| / (|b_i| + rms(b)): a value of e means every element satisfies
+    |a - b| <= e * |b| + e * rms(b) - small elements are held to the tensor's typical magnitude, not to its maximum
+    (the normwise ``rel_err`` says nothing about them)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    rms = b.pow(2).mean().sqrt().item()
+    return ((a - b).abs() / (b.abs() + (rms if rms > 0 else 1.0))).max().item()
+
+
 def keep_scale_host(seed: int, idx: np.ndarray, p: float) -> np.ndarray:
     """Bit-exact host copy of the kernels' counter-based attention-dropout mask
     (spgnn_kernels.hip keep_scale): returns 1/(1-p) where kept, 0 where dropped."""
