@@ -84,6 +84,9 @@ def algorithmic_bytes(key) -> float:
     if base == "scores_bwd_w_pair":  # two such passes in one launch
         _, N, K0, J0, K1, J1 = key
         return s * N * (K0 + K1) + 4 * N * (J0 + J1)
+    if base == "scores_bwd_w_multi": # every layer's pass in one launch: key = (N, sum K, sum J, jobs, bytes per row element)
+        _, N, Ks, Js, _n, sb = key
+        return sb * N * Ks + 4 * N * Js
     if base == "scores_bwd_x":       # read + write gX; read gS
         _, N, K, J = key
         return 4 * 2 * N * K + 4 * N * J

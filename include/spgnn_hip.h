@@ -325,6 +325,16 @@ int spgnn_scores_bwd_w_pair(const float* gs0, int64_t gs0_stride, const float* x
                             int32_t Kp0, int32_t K0, int32_t J0, const float* gs1, int64_t gs1_stride, const float* x1,
                             int64_t x1_stride, float* part1, int32_t splits1, int32_t Kp1, int32_t K1, int32_t J1, int64_t N,
                             spgnn_stream_t stream);
+
+/* Up to eight spgnn_scores_bwd_w passes over the same N rows in ONE launch (fp32 rows, or bf16 rows with x_is_bf16): the
+ * attention-vector gradients of all GATConv layers of a model, g_attn = g_s^T ft (DGL: the autograd of (ft * attn).sum(-1),
+ * reference models.py:301-314 call sites), collected by the training step and run once the backward pass is through - each
+ * pass alone is latency-bound and fills a fraction of the chip.  Job k = the arguments of spgnn_scores_bwd_w (J <= 8); results
+ * bit-identical to the single launches.  Partials are summed by the caller (spgnn_sum_partials_multi). */
+typedef struct spgnn_scores_bwd_w_job {
+  const float* g_s; int64_t g_s_stride; const void* x; int64_t x_stride; float* partials; int32_t splits; int32_t Kp; int32_t K; int32_t J;
+} spgnn_scores_bwd_w_job;
+int spgnn_scores_bwd_w_multi(const spgnn_scores_bwd_w_job* jobs, int32_t n_jobs, int64_t N, int32_t x_is_bf16, spgnn_stream_t stream);
 int spgnn_scores_bwd_x(const float* gs, int64_t gs_stride, const float* w, int32_t Kp,
                        float* gx, int64_t gx_stride, int32_t accumulate, int64_t N, int32_t K, int32_t J,
                        spgnn_stream_t stream);
@@ -672,8 +682,12 @@ int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentu
  * What a training step arms before its first kernel, in one launch: `counter` (nullable, device int64: the dropout / mask
  * stream position the kernels read through their `seed_offset` arguments) += 1, and the `n_scale_blocks` scale blocks at
  * `scale_blocks` (260 floats each, see spgnn_gemm_nt) return to {-256, 0, 0, 0, 0 x 256}.
+ * RANGE MONITOR: a split GEMM whose slot-block operand has a non-zero slot more than 2^18 below its largest slot (whole rows
+ * or blocks of the tensor outside the range in which hi + lo carries 22 bits) sets header word 1 of that block; this call adds
+ * the number of flagged blocks to `range_violations` (nullable, device uint32, sticky) before re-arming them.  Detection
+ * only - the products' arithmetic is unchanged; a caller that sees the counter move re-runs in plain fp32.
  */
-int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, spgnn_stream_t stream);
+int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, uint32_t* range_violations, spgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16-storage path (BASELINE.json config 4: st_gat_6, 512 trees, bf16; reference precision hook

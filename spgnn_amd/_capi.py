@@ -34,6 +34,11 @@ class GemmTnProblem(C.Structure):         # spgnn_gemm_tn_problem
                 ("colsum_split_stride", _i64), ("splits", _i32), ("b_presplit", _i32)]
 
 
+class ScoresBwdWJob(C.Structure):         # spgnn_scores_bwd_w_job
+    _fields_ = [("g_s", _vp), ("g_s_stride", _i64), ("x", _vp), ("x_stride", _i64), ("partials", _vp), ("splits", _i32), ("Kp", _i32),
+                ("K", _i32), ("J", _i32)]
+
+
 class LspeFwdGroup(C.Structure):          # spgnn_lspe_fwd_group
     _fields_ = [("ft", _vp), ("ft_stride", _i64), ("res", _vp), ("res_stride", _i64), ("bias", _vp), ("el", _vp), ("er", _vp),
                 ("s_stride", _i64), ("attn", _vp), ("score_parts", _vp), ("H", _i32), ("act", _i32), ("slope", _f32), ("p_drop", _f32),
@@ -130,7 +135,7 @@ SIGNATURES = {
     "spgnn_masked_ce": [_f32p, _i64, _vp, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i32, _vp],
     "spgnn_masked_ce_step": [_f32p, _i64, _vp, _f32p, _u64, _vp, _f32p, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _f32p, _i64, _i32, _vp],
     "spgnn_sgd_momentum_step_mean": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
-    "spgnn_step_begin": [_vp, _f32p, _i32, _vp],
+    "spgnn_step_begin": [_vp, _f32p, _i32, _vp, _vp],
     "spgnn_linear_mean_fold_fwd": [_f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _i32, _i32, _i32, _i32, _f32p, _i64, _vp, _i64,
                                    _f32p, _f32p, _i64, _f32p, _f32p, _f32p, _vp, _i32, _vp],
     "spgnn_linear_mean_fold_workspace": [_i32, _i32],
@@ -140,6 +145,7 @@ SIGNATURES = {
     "spgnn_gemm_nt_problem_run": [_vp, _i32, _vp],
     "spgnn_gemm_tn_pair": [_vp, _vp, _vp],
     "spgnn_gemm_tn_problem_run": [_vp, _vp],
+    "spgnn_scores_bwd_w_multi": [_vp, _i32, _i64, _i32, _vp],
     "spgnn_sample_neighbors": [_i32p, _i32p, _i32p, _i64, _vp, _i64, _i32, _i32p, _u64, _i32p, _i32p, _i32p, _i32p, _vp],
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],
     "spgnn_head_mean": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _vp],

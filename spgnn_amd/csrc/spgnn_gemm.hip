@@ -496,7 +496,7 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
+  const float sA = spgnn_detail::load_scale_monitored(a.sA), sB = spgnn_detail::load_scale_monitored(a.sB);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -635,7 +635,7 @@ __device__ __forceinline__ void nt_v3_body(const Args& a, const unsigned b, cons
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
+  const float sA = spgnn_detail::load_scale_monitored(a.sA), sB = spgnn_detail::load_scale_monitored(a.sB);
 
   // Operand tiles come through buffer descriptors: one 32-bit per-thread offset per operand, everything else (tile
   // row, staging register, stage) in the scalar offset; rows past the end read as zero (no clamps, no 64-bit address
@@ -882,7 +882,7 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
-  const float sA = spgnn_detail::load_scale(a.sA), sB = spgnn_detail::load_scale(a.sB);
+  const float sA = spgnn_detail::load_scale_monitored(a.sA), sB = spgnn_detail::load_scale_monitored(a.sB);
 
   f32x16 acc[2][2];
 #pragma unroll

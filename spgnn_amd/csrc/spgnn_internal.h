@@ -42,6 +42,31 @@ __device__ __forceinline__ float load_scale(const float* __restrict__ p) {
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   return pow2_scale_of(m);
 }
+// load_scale for the operand of a split GEMM, with the RANGE MONITOR (round 4): hi + lo keeps 22 bits only for values within
+// 2^18 of the tensor's maximum (below that lo falls into fp16's subnormals: DESIGN.md section 4.2's envelope).  The 256 slots
+// are maxima over disjoint pieces of the operand (whole rows - slot = node index mod 256 - for the row kernels, a wave's
+// 32 x 64 piece of a tile for a product's epilogue), so a NON-ZERO slot more than 2^18 below the largest one means whole rows
+// or blocks of the operand sit outside the envelope - a row-structured heavy tail, e.g. a few exploding nodes - and their
+// results lose relative accuracy.  The consuming kernel then sets header word 1 of the block (every workgroup stores
+// the same value: no atomics); spgnn_step_begin adds the set flags of a step's pool to a device counter before it re-arms
+// the blocks.  Detection only: the arithmetic is unchanged (recovery: ops.GEMM_MODE = "fp32").  {s} blocks carry no slots.
+constexpr float kRangeEnvelope = 262144.f;             // 2^18
+__device__ __forceinline__ float load_scale_monitored(const float* __restrict__ p) {
+  if (!p) return 1.f;
+  const float h = p[0];
+  if (h > 0.f) return h;
+  const int lane = threadIdx.x & 63;
+  float m = 0.f, lo = INFINITY;
+#pragma unroll
+  for (int i = 0; i < kScaleSlots / 64; ++i) {
+    const float v = p[kScaleHeader + lane + 64 * i];
+    m = fmaxf(m, v);
+    lo = fminf(lo, v > 0.f ? v : INFINITY);
+  }
+  for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off, 64)); lo = fminf(lo, __shfl_xor(lo, off, 64)); }
+  if (lo * kRangeEnvelope < m && lane == 0) const_cast<float*>(p)[1] = 1.f;
+  return pow2_scale_of(m);
+}
 // one lane per team / block: fold m >= 0 into slot idx of a scale block
 __device__ __forceinline__ void slots_max(float* block, float m, unsigned idx) {
   unsigned* w = reinterpret_cast<unsigned*>(block + kScaleHeader) + (idx & (kScaleSlots - 1));

@@ -2240,6 +2240,23 @@ __global__ __launch_bounds__(256) void scores_bwd_w_pair_kernel(ScoresBwdW p0, S
   scores_bwd_w_body<float, J>(p.gS, p.ldg, p.X, p.ldx, p.part, p.Kp, p.N, p.K, p.rps, p.jn, blockIdx.x, second ? blockIdx.y - nb0 : blockIdx.y);
 }
 
+// Up to eight such passes in one launch (spgnn_scores_bwd_w_multi): every GATConv of a model leaves one of these latency-bound
+// passes in its backward (75-150 rows per wave in a dependent chain, a quarter of the chip busy), and none of them feeds
+// anything but its own attention vectors' gradient - so a training step collects them and runs them side by side once the
+// backward pass is through (ops.AttnGradQueue).  Row ranges [y0[k], y0[k+1]) of the grid's y run job k, with the arithmetic
+// it has in a launch of its own.
+constexpr int kMaxScoreJobs = 8;
+struct ScoresBwdWJobs { ScoresBwdW j[kMaxScoreJobs]; unsigned y0[kMaxScoreJobs + 1]; int n; };
+template <typename ST, int J>
+__global__ __launch_bounds__(256) void scores_bwd_w_multi_kernel(ScoresBwdWJobs a) {
+  int k = 0;
+  while (k + 1 < a.n && blockIdx.y >= a.y0[k + 1]) ++k;
+  const ScoresBwdW& p = a.j[k];
+  if ((int)blockIdx.x >= p.gx) return;
+  scores_bwd_w_body<ST, J>(p.gS, p.ldg, reinterpret_cast<const ST*>(p.X), p.ldx, p.part, p.Kp, p.N, p.K, p.rps, p.jn, blockIdx.x,
+                           blockIdx.y - a.y0[k]);
+}
+
 template <typename ST, int J>     // ST: storage type of the rows of gX (gS, W fp32)
 __global__ __launch_bounds__(64) void scores_bwd_x_kernel(const float* __restrict__ gS, int64_t ldg,
                                                           const float* __restrict__ W, int Kp,
@@ -2629,11 +2646,18 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
 
 // The device state a training step arms before its first kernel, in one launch: the dropout / mask counter advances and
 // every scale block of the step's pool returns to {-256, 0, 0, 0, 0 x 256} (spgnn_internal.h).
-__global__ __launch_bounds__(kBlock) void step_begin_kernel(int64_t* __restrict__ counter, float* __restrict__ blocks, int64_t words) {
+// Before a block is re-armed its range flag (header word 1, set by a GEMM that found rows of the operand outside the split's
+// 2^18 envelope: spgnn_internal.h load_scale_monitored) is added to `violations` - a sticky device counter the host polls
+// when it likes (integer adds: order-independent).
+__global__ __launch_bounds__(kBlock) void step_begin_kernel(int64_t* __restrict__ counter, float* __restrict__ blocks, int64_t words,
+                                                            unsigned* __restrict__ violations) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i == 0 && counter) counter[0] += 1;
   constexpr int W = spgnn_detail::kScaleHeader + spgnn_detail::kScaleSlots;
-  if (i < words) blocks[i] = (i % W == 0) ? -(float)spgnn_detail::kScaleSlots : 0.f;
+  if (i < words) {
+    if (violations && i % W == 1 && blocks[i] != 0.f) atomicAdd(violations, 1u);
+    blocks[i] = (i % W == 0) ? -(float)spgnn_detail::kScaleSlots : 0.f;
+  }
 }
 
 // T < 64 comes with R = 1 (pick_team tries 64 lanes first) or, for the SpMM kernels' narrow rows, as 16 lanes x R = 2 / 4
@@ -3626,6 +3650,43 @@ int spgnn_scores_bwd_w_pair(const float* gs0, int64_t gs0_stride, const float* x
   return check_launch("spgnn_scores_bwd_w_pair");
 }
 
+int spgnn_scores_bwd_w_multi(const spgnn_scores_bwd_w_job* jobs, int32_t n_jobs, int64_t N, int32_t x_is_bf16, spgnn_stream_t stream) {
+  if (n_jobs < 0 || n_jobs > kMaxScoreJobs || N < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w_multi: n_jobs outside [0, 8] or N < 0");
+  if (n_jobs == 0 || N == 0) return SPGNN_OK;
+  if (!jobs) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w_multi: null pointer");
+  ScoresBwdWJobs a{};
+  int bw = 1, jmax = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const spgnn_scores_bwd_w_job& q = jobs[i];
+    if (q.K <= 0 || q.splits <= 0 || q.Kp < q.K || (q.Kp & 15) || q.J <= 0 || q.J > 8)
+      return fail(SPGNN_ERR_SHAPE, "spgnn_scores_bwd_w_multi: bad K/Kp/splits/J (J <= 8)");
+    if (!q.g_s || !q.x || !q.partials) return fail(SPGNN_ERR_NULLPTR, "spgnn_scores_bwd_w_multi: null pointer");
+    const bool rows_ok = x_is_bf16 ? vec_ok_t(reinterpret_cast<const bf16s*>(q.x), q.x_stride) : (!(q.x_stride & 3) && aligned16(q.x));
+    if (q.x_stride < q.K || q.g_s_stride < q.J || !rows_ok || !aligned16(q.partials))
+      return fail(SPGNN_ERR_STRIDE, "spgnn_scores_bwd_w_multi: x rows must be vector aligned (stride % 4 == 0), partials 16-byte aligned");
+    const int b = q.K >= 1024 ? 4 : (q.K + 255) / 256;
+    bw = b > bw ? b : bw;
+    jmax = q.J > jmax ? q.J : jmax;
+  }
+  unsigned y = 0; int gx = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const spgnn_scores_bwd_w_job& q = jobs[i];
+    a.j[i] = ScoresBwdW{q.g_s, q.g_s_stride, reinterpret_cast<const float*>(q.x), q.x_stride, q.partials, q.Kp, N, q.K,
+                        (N + q.splits - 1) / q.splits, q.J, (q.K + 256 * bw - 1) / (256 * bw)};
+    a.y0[i] = y; y += (unsigned)q.splits;
+    gx = a.j[i].gx > gx ? a.j[i].gx : gx;
+  }
+  a.y0[n_jobs] = y; a.n = n_jobs;
+  const dim3 grid((unsigned)gx, y), block(64 * bw);
+  hipStream_t st = (hipStream_t)stream;
+  const int jp = padded_j(jmax);
+#define X(ST_, JP) hipLaunchKernelGGL((scores_bwd_w_multi_kernel<ST_, JP>), grid, block, 0, st, a)
+  if (x_is_bf16) { if (jp <= 2) X(bf16s, 2); else if (jp <= 4) X(bf16s, 4); else X(bf16s, 8); }
+  else { if (jp <= 2) X(float, 2); else if (jp <= 4) X(float, 4); else X(float, 8); }
+#undef X
+  return check_launch("spgnn_scores_bwd_w_multi");
+}
+
 int spgnn_scores_bwd_w_bf16(const float* gs, int64_t gs_stride, const uint16_t* x, int64_t x_stride, float* part,
                             int32_t splits, int32_t Kp, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
   if (N < 0 || K <= 0 || splits <= 0 || Kp < K || (Kp & 15) || J <= 0 || J > 32)
@@ -3817,13 +3878,13 @@ int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentu
                     first_step, stream);
 }
 
-int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, spgnn_stream_t stream) {
+int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, uint32_t* range_violations, spgnn_stream_t stream) {
   if (n_scale_blocks < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_step_begin: n_scale_blocks < 0");
   if (n_scale_blocks > 0 && !scale_blocks) return fail(SPGNN_ERR_NULLPTR, "spgnn_step_begin: null pointer");
   if (!counter && n_scale_blocks == 0) return SPGNN_OK;
   const int64_t words = (int64_t)n_scale_blocks * (spgnn_detail::kScaleHeader + spgnn_detail::kScaleSlots);
   const int64_t blocks = words > 0 ? (words + kBlock - 1) / kBlock : 1;
-  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, counter, scale_blocks, words);
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, counter, scale_blocks, words, range_violations);
   return check_launch("spgnn_step_begin");
 }
 

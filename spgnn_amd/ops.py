@@ -314,13 +314,16 @@ class ScalePool:
         self.capacity = capacity
         self.buf = _scale_template(self.device, capacity).clone()
         self.cursor, self.active = 0, False
+        # range monitor (include/spgnn_hip.h, spgnn_step_begin): operands of this pool's steps that had whole rows / blocks more
+        # than 2^18 below their maximum - outside the envelope in which the split GEMMs are fp32-accurate - counted on the device
+        self.violations = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def begin(self, counter: Optional[torch.Tensor] = None):
         """Re-arm every block; ``counter`` (device int64 scalar, optional) advances by one in the same launch
         (spgnn_step_begin): the step's dropout / mask stream position."""
         with torch.cuda.device(self.device):
-            _capi.check(_capi.load().spgnn_step_begin(_ptr(counter), self.buf.data_ptr(), self.capacity, _stream(self.buf)),
-                        "spgnn_step_begin")
+            _capi.check(_capi.load().spgnn_step_begin(_ptr(counter), self.buf.data_ptr(), self.capacity, self.violations.data_ptr(),
+                                                      _stream(self.buf)), "spgnn_step_begin")
         self.cursor, self.active = 0, True
 
     def end(self):
@@ -351,6 +354,18 @@ def new_scale_block(device) -> torch.Tensor:
     p = _SCALE_POOLS.get(str(torch.device(device)))
     b = p.take() if p is not None else None
     return b if b is not None else _scale_template(device, 1)[0].clone()
+
+
+def range_violations(device) -> int:
+    """Operands seen so far by the training steps on ``device`` that left the split GEMMs' accuracy envelope (synchronises:
+    poll it per epoch, not per step).  The flags of the step in flight are counted when the NEXT step begins."""
+    p = _SCALE_POOLS.get(str(torch.device(device)))
+    return int(p.violations.item()) if p is not None else 0
+
+
+def range_flag(scale: torch.Tensor) -> bool:
+    """Whether a product that consumed scale block ``scale`` flagged it (header word 1; tests, eager use)."""
+    return scale.numel() > 1 and float(scale[1]) != 0.0
 
 
 def scale_value(scale: torch.Tensor) -> float:
@@ -488,6 +503,79 @@ def scores_bwd_w(g_s: torch.Tensor, x: torch.Tensor, blockdiag_heads: int = 0, d
         defer.add(_capi.SumJob(kind=0, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), n=J * Kp), part, out)
         return out[:, :K]
     return sum_partials(part)[:, :K]
+
+
+DEFER_ATTN_GRADS = True   # a training step runs every layer's attention-vector gradient pass in ONE launch after the backward pass
+ATTN_GRAD_QUEUE = None    # the AttnGradQueue of the step whose backward pass is being issued (train.TrainStep._front), else None
+
+
+class AttnGradQueue:
+    """The attention-vector gradients of every GATConv of a model, g_attn_l / g_attn_r = block diagonal of g_s^T ft (DGL:
+    autograd of ``(ft * attn).sum(-1)``; reference call sites models.py:301-314, 425-456), as ONE streaming launch per
+    training step instead of one per layer or level (spgnn_scores_bwd_w_multi; each pass alone is latency-bound and fills a
+    quarter of the chip).  Nothing else depends on these gradients, so a layer's backward only RECORDS its pass here and
+    returns no gradient for attn_l / attn_r; ``flush()`` - called by the step after ``backward()`` - launches all of them,
+    sums the split partials in one more launch and hands each parameter its gradient (``.grad``, accumulated if one is
+    there).  Only a training step installs a queue: plain ``loss.backward()`` keeps the per-layer launches and autograd's
+    own bookkeeping.  Values are bit-identical either way."""
+
+    def __init__(self, device):
+        self.device, self.items = torch.device(device), []
+
+    def add(self, g_s: torch.Tensor, ft: torch.Tensor, H: int, p_l: torch.Tensor, p_r: torch.Tensor) -> bool:
+        """Record one layer's pass: g_s (N, 2H) fp32, ft (N, H*D) rows (fp32 or bf16), the two parameters.  -> False when the
+        shapes do not fit the kernel (the caller then runs its own launch)."""
+        N, K = ft.shape
+        J = g_s.shape[1]
+        if N == 0 or J > 8 or ft.stride(1) != 1 or ft.stride(0) % 4 or (self.items and self.items[0][1].shape[0] != N) \
+                or (self.items and self.items[0][1].dtype != ft.dtype):
+            return False
+        if ft.data_ptr() % (16 if ft.dtype == torch.float32 else 8):
+            return False
+        self.items.append((g_s, ft, H, p_l, p_r))
+        return True
+
+    def flush(self) -> None:
+        items, self.items = self.items, []
+        if not items:
+            return
+        import ctypes
+        lib = _capi.load()
+        sums = SumJobs(self.device)
+        outs = []
+        for i0 in range(0, len(items), 8):
+            chunk = items[i0:i0 + 8]
+            jobs = (_capi.ScoresBwdWJob * len(chunk))()
+            keep = []
+            N = chunk[0][1].shape[0]
+            bf16 = chunk[0][1].dtype == torch.bfloat16
+            for q, (g_s, ft, H, p_l, p_r) in zip(jobs, chunk):
+                K, J = ft.shape[1], g_s.shape[1]
+                Kp = _pad16(K)
+                splits = max(1, min(_SCORES_SPLIT_WAVES_SMALL // ((K + 255) // 256), N // 16))      # as scores_bwd_w / attn_vector_grads
+                part = torch.empty((splits, J, Kp), dtype=torch.float32, device=ft.device)
+                out = torch.empty((2, H, K // H), dtype=torch.float32, device=ft.device)
+                q.g_s, q.g_s_stride, q.x, q.x_stride, q.partials = g_s.data_ptr(), g_s.stride(0), ft.data_ptr(), ft.stride(0), part.data_ptr()
+                q.splits, q.Kp, q.K, q.J = splits, Kp, K, J
+                keep.append((part, out))
+                outs.append((out, p_l, p_r))
+                sums.add(_capi.SumJob(kind=1, splits=splits, partials=part.data_ptr(), split_stride=J * Kp, out=out.data_ptr(), H=H,
+                                      D=K // H, ld=Kp), part, out)
+            key = (N, sum(it[1].shape[1] for it in chunk), sum(it[0].shape[1] for it in chunk), len(chunk), 2 if bf16 else 4)
+            with torch.cuda.device(self.device), _timed("scores_bwd_w_multi", key):
+                _capi.check(lib.spgnn_scores_bwd_w_multi(jobs, len(chunk), N, int(bf16), _stream(chunk[0][1])), "spgnn_scores_bwd_w_multi")
+        sums.flush()
+        for out, p_l, p_r in outs:
+            for p, g in ((p_l, out[0]), (p_r, out[1])):
+                g = g.view(p.shape)
+                p.grad = g if p.grad is None else p.grad + g
+
+
+def queue_attn_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int, p_l, p_r) -> bool:
+    """Hand a layer's attention-vector gradient pass to the running step's queue (see AttnGradQueue).  -> whether it took it."""
+    q = ATTN_GRAD_QUEUE
+    return bool(q is not None and DEFER_ATTN_GRADS and p_l is not None and p_r is not None and p_l.requires_grad and p_r.requires_grad
+                and q.add(g_s, ft, H, p_l, p_r))
 
 
 PAIR_SCORE_GRADS = True   # a level's two attention-vector gradient passes (structure J = 2H, position J = 2) as one launch
@@ -1431,6 +1519,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             sx = pow2_scale(x)
         sw = operand_scale(w_cat)                  # attached by weight_cat, else one absmax pass
         ctx.attn_shape = attn_l.shape              # (H, D) or the parameter's own (1, H, D): no select / stack autograd nodes
+        ctx.attn_params = (attn_l, attn_r)
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
         wb, ps = _b_operand(w_cat)
@@ -1506,7 +1595,9 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         if need_bias and g_bias is None:
             g_bias = g_pre.sum(0)
         g_al = g_ar = None
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and queue_attn_grads(g_s, y[:, :HD], H, *ctx.attn_params):
+            pass                                       # the step's queue runs the pass with every other layer's (AttnGradQueue)
+        elif ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             m = scores_bwd_w(g_s, y[:, :HD], blockdiag_heads=H, defer=jobs)  # (2, H, D): [0] = g_attn_l, [1] = g_attn_r (contiguous views)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
         jobs.flush()                               # the two split-K reductions in one launch
@@ -1672,6 +1763,7 @@ class _LspeLevelFn(torch.autograd.Function):
                                            N, E, D, _seed_off_ptr(dev), _stream(x_s)), "spgnn_lspe_fwd")
         ctx.csc, ctx.D, ctx.cfg, ctx.wts, ctx.has_bias = csc, D, cfg, wts, (bias_s is not None, bias_p is not None)
         ctx.x_ps = x_ps                          # the pre-split images of constant inputs (not autograd tensors: batch data)
+        ctx.attn_params = ((al_s, ar_s), (al_p, ar_p))     # the parameters themselves: a step's AttnGradQueue hands them their gradients
         ctx.save_for_backward(x_s, x_p, w_s, w_p, vecs[0][0], vecs[0][1], vecs[1][0], vecs[1][1], ys[0], ys[1], ss[0], ss[1], attn[0], attn[1],
                               scales[0][0], scales[0][1], scales[1][0], scales[1][1], buf, xp)
         ctx.mark_non_differentiable(attn[0], attn[1], sc_buf, sc_xp)
@@ -1767,6 +1859,10 @@ class _LspeLevelFn(torch.autograd.Function):
             if need_bias and grads_b[i] is None:
                 grads_b[i] = g_pre[i].sum(0)
         want_a = [ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i] for i in range(2)]
+        for i in range(2):                               # a training step runs these passes for ALL levels in one launch afterwards
+            if want_a[i] and ctx.needs_input_grad[4 + 2 * i] and ctx.needs_input_grad[5 + 2 * i] and \
+                    queue_attn_grads(g_s[i], ys[i][:, :Hs[i] * D], Hs[i], *ctx.attn_params[i]):
+                want_a[i] = False
         if want_a[0] and want_a[1]:                      # both layers' attention-vector gradients: one streaming launch
             ms = scores_bwd_w_blockdiag_pair(g_s[0], ys[0][:, :Hs[0] * D], Hs[0], g_s[1], ys[1][:, :Hs[1] * D], Hs[1], jobs)
         else:

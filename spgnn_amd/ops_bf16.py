@@ -290,6 +290,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         w, w_t = weight_operands(w_fc, w_res, want_t=need_gx)
         ctx.attn_shape = attn_l.shape
+        ctx.attn_params = (attn_l, attn_r)
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         if D == 64 and SCORES_DIRECT:            # a head is one 64-column block: the epilogue's dots ARE el / er
             s = torch.empty((N, 2 * H), dtype=torch.float32, device=x.device)
@@ -363,7 +364,9 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         if need_bias and g_bias is None:
             g_bias = g_pre.float().sum(0)
         g_al = g_ar = None
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and _ops.queue_attn_grads(g_s, y[:, :HD], H, *ctx.attn_params):
+            pass                                        # one launch for every layer's pass after the backward (ops.AttnGradQueue)
+        elif ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             m = attn_vector_grads(g_s, y[:, :HD], H, defer=jobs)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
         jobs.flush()

@@ -208,9 +208,12 @@ class TrainStep:
                 draw_seed = self._mask_seed
             else:
                 draws = torch.rand(p.shape, device=p.device, generator=self.gen)
+        # every GATConv's attention-vector gradient pass is collected during backward and issued as ONE launch after it
+        queue = ops.AttnGradQueue(b.flat_param.device) if (on_gpu and ops.DEFER_ATTN_GRADS) else None
         try:
             if ctr is not None:
                 ops.DROPOUT_SEED_OFFSET = ctr
+            ops.ATTN_GRAD_QUEUE = queue
             logits = self.model(g)[0]
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
@@ -223,8 +226,11 @@ class TrainStep:
             else:
                 num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
                 num.backward()
+            if queue is not None:
+                queue.flush()                # (inside the step's scale-pool window: its partial sums take no block, but stay in order)
         finally:
             ops.DROPOUT_SEED_OFFSET = prev_off
+            ops.ATTN_GRAD_QUEUE = None
             if pool is not None:
                 pool.end()
         b.gather_grads()
@@ -262,6 +268,12 @@ class TrainStep:
         n = b.numel                          # the parameters only: the bucket's tail slots carry the weight sum and the loss
         ops.sgd_momentum_step_(b.flat_param[:n], b.flat_grad[:n], b.flat_mom[:n], self.lr, self.momentum, self.weight_decay,
                                first_step=(b.steps == 0), grad_scale=inv, lr_dev=self._lr_dev)
+
+    def range_violations(self) -> int:
+        """GEMM operands of the steps so far that had rows / blocks outside the split products' 2^18 accuracy envelope
+        (ops.range_violations: a device counter; this call synchronises).  0 is the normal state; when it moves, re-run the
+        affected span with ``ops.GEMM_MODE = "fp32"`` (plain fp32 products) and compare."""
+        return ops.range_violations(self.bucket.flat_param.device) if self.bucket.flat_param.is_cuda else 0
 
     def set_lr(self, lr: float):
         self.lr = lr

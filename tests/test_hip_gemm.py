@@ -175,7 +175,8 @@ def test_gemm_heavy_tailed_operand_error_on_body_rows(ratio, body_bound):
     THOSE rows' results.  Measured envelope: outliers 1e4 x the body - fp32-class (an fp32 GEMM over
     K = 512 terms sits at ~1e-6); 1e6 x - 9e-6, i.e. one decimal digit lost on the body rows, still inside the 1e-5 bar;
     the normwise error of the whole product is unaffected.  (Per-row-block scales would remove the effect for the NT
-    kernel only - the weight-gradient kernel reduces over the rows; not built.)"""
+    kernel only - the weight-gradient kernel reduces over the rows; not built.  Round 4 adds the GUARD instead: operands
+    whose rows / blocks leave the 2^18 envelope are flagged on the device and counted, test_range_monitor_* below.)"""
     M, N, K = 4096, 256, 512
     g = torch.Generator(device="cuda").manual_seed(11)
     a = torch.randn(M, K, device="cuda", generator=g) * 1e-3
@@ -196,6 +197,47 @@ def test_gemm_heavy_tailed_operand_error_on_body_rows(ratio, body_bound):
     assert rel_err(gw, refw) < 2e-6
     if bool(cols.any()):
         assert rel_err(gw[cols], refw[cols]) < body_bound
+
+
+def test_range_monitor_flags_rows_outside_the_envelope():
+    """Round 4 guard for the per-tensor scale: a product whose slot-block operand holds whole rows more
+    than 2^18 below the tensor maximum - where hi + lo no longer carries 22 bits - sets the block's range flag; the next
+    spgnn_step_begin adds the flagged blocks to the pool's device counter and re-arms them.  A well-conditioned operand leaves
+    the flag clear.  (Detection only: the result itself is the enveloped one the test above measures.)"""
+    dev = torch.device("cuda")
+    pool = ops.scale_pool(dev)
+    before = ops.range_violations(dev)
+    pool.begin()
+    try:
+        M, K, N = 4096, 256, 128
+        w = torch.randn(N, K, device=dev) / 9
+        sw = ops.pow2_scale(w)
+        # rows 0..15 are 1e7 times the body: every slot but sixteen sits outside the 2^18 = 2.6e5 envelope
+        a_bad = torch.randn(M, K, device=dev) * 1e-3
+        a_bad[:16] *= 1e7
+        a_ok = torch.randn(M, K, device=dev)
+        a_ok[:16] *= 1e3                                                 # inside the envelope: no flag
+        blocks = []
+        for a in (a_bad, a_ok):
+            # a producer that folds row maxima into the slots: the fused concat / dropout kernel with p = 0
+            y = ops.cat_dropout((a,), 0.0, 0)
+            blk = y._spgnn_scale[1]
+            assert not ops.range_flag(blk)
+            c = ops.gemm_nt(y, w, blk, sw)
+            assert torch.isfinite(c).all()
+            blocks.append(blk)
+        torch.cuda.synchronize()
+        assert ops.range_flag(blocks[0]) and not ops.range_flag(blocks[1])
+        # the weight-gradient kernel reads the same block as its A operand's scale
+        y_bad = ops.cat_dropout((a_bad,), 0.0, 0)
+        assert not ops.range_flag(y_bad._spgnn_scale[1])
+        g = ops.gemm_tn(y_bad, a_ok, y_bad._spgnn_scale[1], ops.pow2_scale(a_ok))
+        torch.cuda.synchronize()
+        assert torch.isfinite(g).all() and ops.range_flag(y_bad._spgnn_scale[1])
+    finally:
+        pool.end()
+    pool.begin(); pool.end()                                            # the next step's first launch harvests the flags
+    assert ops.range_violations(dev) == before + 2
 
 
 def test_gemm_mode_switch_gives_same_layer_output(monkeypatch):

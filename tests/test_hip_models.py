@@ -337,6 +337,37 @@ def test_graph_replay_matches_eager_and_refreshes_dropout():
     _ops.DROPOUT_SEED_OFFSET = None
 
 
+@pytest.mark.parametrize("name,bf16", [("st_pgat_spgnn_3", False), ("st_gat_3", False), ("st_gat_6", True)])
+def test_deferred_attention_vector_gradients_are_bit_identical(name, bf16, monkeypatch):
+    """ops.AttnGradQueue (round 4): a training step collects every GATConv's attention-vector gradient pass during backward
+    and runs them as ONE spgnn_scores_bwd_w_multi launch afterwards.  The flat gradient bucket - every parameter's gradient,
+    attn_l / attn_r included - is bit for bit what the per-layer launches give, and an eager ``loss.backward()`` outside a
+    step (no queue) still fills the attention vectors' gradients through autograd."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build(name, seed=8)
+    if bf16:
+        models.set_storage_dtype(model, torch.bfloat16)
+    model.eval()
+    g = synthetic.make_batch(5, rank=2, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    grads = []
+    for defer in (True, False):
+        monkeypatch.setattr(_ops, "DEFER_ATTN_GRADS", defer)
+        ts = TrainStep(copy.deepcopy(model), w, 1.0, 1e-3, 0.9)
+        ts._front(g)
+        grads.append(ts.bucket.flat_grad.clone())
+        names = [n for n, p in ts.model.named_parameters() if p.requires_grad]
+        assert any("attn_l" in n for n in names)
+    assert torch.equal(grads[0], grads[1])
+    assert _ops.ATTN_GRAD_QUEUE is None
+    m2 = copy.deepcopy(model)
+    m2(g)[0].square().mean().backward()                       # plain autograd: the layers run their own passes
+    for n, p in m2.named_parameters():
+        if "attn_" in n and p.requires_grad and "lobe" not in n and "lung" not in n:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    _ops.DROPOUT_SEED_OFFSET = None
+
+
 @pytest.mark.parametrize("N,C", [(1000, 22), (1, 22), (257, 3), (4096, 64)])
 def test_fused_masked_ce_matches_cross_entropy(N, C):
     """spgnn_masked_ce == F.cross_entropy(pre[mask], y[mask], weight=w) (reference job_runner.py:1896-1900): loss
