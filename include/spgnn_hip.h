@@ -567,14 +567,22 @@ typedef struct spgnn_gemm_tn_problem {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t split_stride; int64_t R; int64_t M; int64_t N;
   const float* scale_a; const float* scale_b; float* colsum_a; int64_t colsum_stride; int64_t colsum_split_stride;
   int32_t splits;
-  int32_t b_presplit;      /* 1: B (R x N; X, the layer input) is the pre-split form written by spgnn_presplit with scale_b - the
-                              weight gradient of a model's first layer reads constant node data (see spgnn_gemm_nt); 0: fp32 rows */
+  int32_t flags;           /* SPGNN_TN_B_PRESPLIT: B (R x N; X, the layer input) is the pre-split form written by spgnn_presplit with
+                              scale_b - the weight gradient of a model's first layer reads constant node data (see spgnn_gemm_nt);
+                              SPGNN_TN_TILE_128 / _256: pin the block tile's rows (default: spgnn_gemm_tn_tile_rows) */
 } spgnn_gemm_tn_problem;
+#define SPGNN_TN_B_PRESPLIT 1
+#define SPGNN_TN_TILE_128 0x10
+#define SPGNN_TN_TILE_256 0x20
+/* Rows of the (rows x 128) block tile spgnn_gemm_tn / _problem_run / _pair take for this shape: 256 (8 waves, one workgroup per
+ * CU) when M is a multiple of 256, M * N >= 384 * 1024 and R >= 4096, else 128.  Both tile shapes give bit-identical results; a caller
+ * choosing `splits` counts tiles with it: ceil(M / rows) * ceil(N / 128). */
+int32_t spgnn_gemm_tn_tile_rows(int64_t R, int64_t M, int64_t N, int32_t flags);
 int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_presplit, spgnn_stream_t stream);   /* one product, every option */
 int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_problem* second, int32_t b_presplit,
                        spgnn_stream_t stream);
-int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);   /* same b_presplit in both */
-int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* problem, spgnn_stream_t stream);                               /* one product (= spgnn_gemm_tn + b_presplit) */
+int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream);   /* same SPGNN_TN_B_PRESPLIT in both; the first one's tile */
+int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* problem, spgnn_stream_t stream);                               /* one product (= spgnn_gemm_tn + flags) */
 
 /* scale[0] = 2^(14 - e), max|x| <= 2^e (1 for an all-zero tensor).  workspace: up to 2048 floats of device
  * memory for per-block partial maxima (no atomics).  x rows must be 16-byte aligned. */

@@ -31,7 +31,7 @@ class GemmNtProblem(C.Structure):         # spgnn_gemm_nt_problem
 class GemmTnProblem(C.Structure):         # spgnn_gemm_tn_problem
     _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("split_stride", _i64), ("R", _i64),
                 ("M", _i64), ("N", _i64), ("scale_a", _vp), ("scale_b", _vp), ("colsum_a", _vp), ("colsum_stride", _i64),
-                ("colsum_split_stride", _i64), ("splits", _i32), ("b_presplit", _i32)]
+                ("colsum_split_stride", _i64), ("splits", _i32), ("flags", _i32)]
 
 
 class ScoresBwdWJob(C.Structure):         # spgnn_scores_bwd_w_job
@@ -145,6 +145,7 @@ SIGNATURES = {
     "spgnn_gemm_nt_problem_run": [_vp, _i32, _vp],
     "spgnn_gemm_tn_pair": [_vp, _vp, _vp],
     "spgnn_gemm_tn_problem_run": [_vp, _vp],
+    "spgnn_gemm_tn_tile_rows": [_i64, _i64, _i64, _i32],
     "spgnn_scores_bwd_w_multi": [_vp, _i32, _i64, _i32, _vp],
     "spgnn_sample_neighbors": [_i32p, _i32p, _i32p, _i64, _vp, _i64, _i32, _i32p, _u64, _i32p, _i32p, _i32p, _i32p, _vp],
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],

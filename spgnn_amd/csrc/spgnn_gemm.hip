@@ -809,8 +809,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pair_v3(PairArgs pa) {
 // -------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 constexpr int TBK = 32;                          // rows (reduction) per stage
-constexpr int TPITCH = 160;                      // halves per LDS row: 128 + 32
-constexpr int TTILE = TBK * TPITCH;              // one fp16 image
 
 struct ArgsTN {
   const float* A; int64_t lda;                   // (R, M)
@@ -825,56 +823,77 @@ struct ArgsTN {
   int splits;
 };
 
-// fragment of the 32 (m) x 16 (k) operand block whose first column is m0 and first k-row is k0
+// fragment of the 32 (m) x 16 (k) operand block whose first column is m0 and first k-row is k0 (PITCH_ halves per k-row)
+template <int PITCH_>
 __device__ __forceinline__ half8 tr_frag(const _Float16* img, int m0, int k0, int lane) {
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   const int col = m0 + (g & 1) * 16 + 4 * pp;
   const int krow = k0 + (g >> 1) * 8 + q;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + krow * TPITCH + col));
-  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (krow + 4) * TPITCH + col));
+  const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + krow * PITCH_ + col));
+  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (krow + 4) * PITCH_ + col));
   union { s16x4 v[2]; half8 h; } u;
   u.v[0] = lo4; u.v[1] = hi4;
   return u.h;
 }
 
+// Tile geometry of the TN kernels: (64 WM) x 128 block tile, 2 WM waves of 64 x 64, 32 reduction rows per stage.
+//   WM = 2: 128 x 128, 256 threads, two workgroups per CU (round 1)
+//   WM = 4: 256 x 128, 512 threads, one workgroup per CU (round 4): per MFMA 3/4 of the operand bytes come through the
+//           vector memory pipe and L2, 3/4 of the values are converted and half the barriers are met - the step the NT
+//           kernels took from 256 x 128 to 256 x 256.  Same arithmetic in the same order per output element: bit-identical.
 // fp32 tiles are prefetched two stages ahead into two register sets, the conversion + LDS store of stage t+1 is
 // interleaved between the MFMAs of stage t (double-buffered LDS, one barrier per stage) - the schedule of
-// gemm_nt_f16x3_v2.
+// gemm_nt_f16x3_v2.  An operand tile is 32 rows x COLS columns, k-major as it arrives; thread t's float4 #i sits in row
+// (t + NT i) / (COLS / 4), column group (t + NT i) % (COLS / 4).
+template <int WM>
+struct TnGeo {
+  static constexpr int BMt = 64 * WM, NT = 128 * WM;
+  static constexpr int PA = BMt + 32, PB = BN + 32;            // halves per LDS k-row (pitch = 64 mod 256 bytes: conflict-free tr reads)
+  static constexpr int A_IMG = TBK * PA, B_IMG = TBK * PB;
+  static constexpr int STAGE = 2 * A_IMG + 2 * B_IMG;          // Ah | Al | Bh | Bl
+  static constexpr int CA4 = BMt / 4, CB4 = BN / 4;            // float4 per tile row
+  static constexpr int NLA = TBK * CA4 / NT, NLB = TBK * CB4 / NT;      // float4 per thread and stage: 4 and 4 (WM = 2) / 4 and 2 (WM = 4)
+  static constexpr int RSA = NT / CA4, RSB = NT / CB4;         // rows between a thread's consecutive float4
+  static constexpr size_t lds_bytes = 2 * (size_t)STAGE * sizeof(_Float16);
+};
+template <int COLS4, int PITCH_, int NT_>
 __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
-  const int idx = threadIdx.x + kThreads * i;
-  const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
+  const int idx = threadIdx.x + NT_ * i;
+  const int off = (idx / COLS4) * PITCH_ + (idx % COLS4) * 4;
   uint2 h, l;
   split4_pk(v, s, h, l);
   *reinterpret_cast<uint2*>(hi_img + off) = h;
   *reinterpret_cast<uint2*>(lo_img + off) = l;
 }
-
 // pre-split operand (see Args): the staged 16 bytes ARE the hi / lo halves of four consecutive columns of one k-row
+template <int COLS4, int PITCH_, int NT_>
 __device__ __forceinline__ void store_raw_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i) {
-  const int idx = threadIdx.x + kThreads * i;
-  const int off = (idx >> 5) * TPITCH + (idx & 31) * 4;
+  const int idx = threadIdx.x + NT_ * i;
+  const int off = (idx / COLS4) * PITCH_ + (idx % COLS4) * 4;
   *reinterpret_cast<uint2*>(hi_img + off) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
   *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
 }
 
-template <bool BPS>      // BPS: B (= X, the layer input; constant node data for a model's first layer) arrives pre-split
-__device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, const unsigned nblocks) {
+template <int WM, bool BPS>      // BPS: B (= X, the layer input; constant node data for a model's first layer) arrives pre-split
+__device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, const unsigned nblocks) {
+  using G = TnGeo<WM>;
+  constexpr int BMt = G::BMt, NT = G::NT, PA = G::PA, PB = G::PB, A_IMG = G::A_IMG, B_IMG = G::B_IMG, STAGE = G::STAGE;
+  constexpr int NLA = G::NLA, NLB = G::NLB;
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];          // 2 stages x (Ah | Al | Bh | Bl)
-  constexpr int STAGE = 4 * TTILE;
 
   // Placement.  Every tile of one split streams the same row range of both operands, so the (split, tile) work items,
   // split-major, are dealt to the XCDs in eight CONTIGUOUS ranges (workgroups go to XCDs round-robin by linear id): an
   // XCD works on one or two splits at a time, their row ranges are fetched into that XCD's L2 once and the tiles'
   // re-reads (8-9x per operand at 128x128 tiles) are L2 hits instead of fabric traffic.  Any split count works, so the
-  // caller picks the one whose workgroup count fills whole rounds of the chip (2 per CU).  The grid is padded to a
+  // caller picks the one whose workgroup count fills whole rounds of the chip.  The grid is padded to a
   // multiple of 8; the pad workgroups leave at once.
   const unsigned tiles_ = (unsigned)(a.nbm * a.nbn);
   const unsigned w_ = (bid & 7u) * (nblocks >> 3) + (bid >> 3);
   if (w_ >= tiles_ * (unsigned)a.splits) return;
   const unsigned split = w_ / tiles_, tile = w_ % tiles_;
   const int bm = tile / a.nbn, bn = tile % a.nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
+  const int m0 = bm * BMt, n0 = bn * BN;
   const int64_t r_beg = (int64_t)split * a.rows_per_split;
   const int64_t r_end = r_beg + a.rows_per_split < a.R ? r_beg + a.rows_per_split : a.R;
   const int nk = r_beg < r_end ? (int)((r_end - r_beg + TBK - 1) / TBK) : 0;
@@ -892,60 +911,66 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  float4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool do_colsum = a.colsum != nullptr && bn == 0;
 
   // Loads are unconditional straight-line code (see TileIO in the NT kernel: a branch around a load makes hipcc drain
-  // the VM queue at every stage).  A thread's four float4 of a tile share one column (idx & 31 = tid & 31) and sit in
-  // rows (tid >> 5) + 8 i.  A float4 that starts at or beyond the width is fetched from column 0 instead, rows past the
-  // split's range from its last row; SPGNN_TN_MASK zeroes both before the set is summed / converted.  In the steady
-  // loop all rows exist, so only tiles that hang over the width (edge_a / edge_b, block-uniform) are masked there.
-  const int tcol = (threadIdx.x & 31) * 4, trow = threadIdx.x >> 5;
-  const int ca = m0 + tcol, cbn = n0 + tcol;
+  // the VM queue at every stage).  A thread's float4 of a tile share one column group and sit RSA / RSB rows apart.  A
+  // float4 that starts at or beyond the width is fetched from column 0 instead, rows past the split's range from its last
+  // row; SPGNN_TN_MASK zeroes both before the set is summed / converted.  In the steady loop all rows exist, so only tiles
+  // that hang over the width (edge_a / edge_b, block-uniform) are masked there.
+  const int tcolA = ((int)threadIdx.x % G::CA4) * 4, trowA = (int)threadIdx.x / G::CA4;
+  const int tcolB = ((int)threadIdx.x % G::CB4) * 4, trowB = (int)threadIdx.x / G::CB4;
+  const int ca = m0 + tcolA, cbn = n0 + tcolB;
   const float* pA = a.A + (ca < a.M ? ca : 0);
   const float* pB = a.B + (cbn < a.N ? cbn : 0);
-  const bool edge_a = m0 + BM > a.M, edge_b = n0 + BN > a.N;
+  const bool edge_a = m0 + BMt > a.M, edge_b = n0 + BN > a.N;
   const int64_t r_last = r_end - 1;
 #define SPGNN_TN_LOAD_FULL(T_, RA, RB)                                                                       \
   {                                                                                                          \
-    const int64_t rr = r_beg + (int64_t)(T_) * TBK + trow;                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) RA[q] = *reinterpret_cast<const float4*>(pA + (rr + 8 * q) * a.lda); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) RB[q] = *reinterpret_cast<const float4*>(pB + (rr + 8 * q) * a.ldb); \
+    const int64_t rr = r_beg + (int64_t)(T_) * TBK;                                                          \
+    _Pragma("unroll") for (int q = 0; q < NLA; ++q) RA[q] = *reinterpret_cast<const float4*>(pA + (rr + trowA + G::RSA * q) * a.lda); \
+    _Pragma("unroll") for (int q = 0; q < NLB; ++q) RB[q] = *reinterpret_cast<const float4*>(pB + (rr + trowB + G::RSB * q) * a.ldb); \
   }
 #define SPGNN_TN_LOAD_ANY(T_, RA, RB)                                                                        \
   {                                                                                                          \
-    const int64_t rr = r_beg + (int64_t)(T_) * TBK + trow;                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
-      const int64_t r_ = rr + 8 * q < r_end ? rr + 8 * q : r_last;                                           \
+    const int64_t rr = r_beg + (int64_t)(T_) * TBK;                                                          \
+    _Pragma("unroll") for (int q = 0; q < NLA; ++q) {                                                        \
+      const int64_t r_ = rr + trowA + G::RSA * q < r_end ? rr + trowA + G::RSA * q : r_last;                 \
       RA[q] = *reinterpret_cast<const float4*>(pA + r_ * a.lda);                                             \
+    }                                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NLB; ++q) {                                                        \
+      const int64_t r_ = rr + trowB + G::RSB * q < r_end ? rr + trowB + G::RSB * q : r_last;                 \
       RB[q] = *reinterpret_cast<const float4*>(pB + r_ * a.ldb);                                             \
     }                                                                                                        \
   }
-#define SPGNN_TN_MASK1(R_, C_, W_, ROWS_TOO, T_)                                                             \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + trow + 8 * q < r_end;                       \
+#define SPGNN_TN_MASK1(R_, NL_, TROW_, RS_, C_, W_, ROWS_TOO, T_)                                            \
+  _Pragma("unroll") for (int q = 0; q < NL_; ++q) {                                                          \
+    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + TROW_ + RS_ * q < r_end;                    \
     R_[q].x = rv && (C_) + 0 < (W_) ? R_[q].x : 0.f;                                                         \
     R_[q].y = rv && (C_) + 1 < (W_) ? R_[q].y : 0.f;                                                         \
     R_[q].z = rv && (C_) + 2 < (W_) ? R_[q].z : 0.f;                                                         \
     R_[q].w = rv && (C_) + 3 < (W_) ? R_[q].w : 0.f;                                                         \
   }
   // pre-split rows: a group that straddles the width is zero padded in memory; one at or beyond it came from column 0
-#define SPGNN_TN_MASKG(R_, C_, W_, ROWS_TOO, T_)                                                             \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + trow + 8 * q < r_end;                       \
+#define SPGNN_TN_MASKG(R_, NL_, TROW_, RS_, C_, W_, ROWS_TOO, T_)                                            \
+  _Pragma("unroll") for (int q = 0; q < NL_; ++q) {                                                          \
+    const bool rv = !(ROWS_TOO) || r_beg + (int64_t)(T_) * TBK + TROW_ + RS_ * q < r_end;                    \
     if (!(rv && (C_) < (W_))) R_[q] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
   }
 #define SPGNN_TN_MASK(T_, RA, RB, ROWS_TOO)                                                                  \
   {                                                                                                          \
-    if ((ROWS_TOO) || edge_a) SPGNN_TN_MASK1(RA, ca, a.M, ROWS_TOO, T_)                                      \
-    if ((ROWS_TOO) || edge_b) { if constexpr (BPS) SPGNN_TN_MASKG(RB, cbn, a.N, ROWS_TOO, T_) else SPGNN_TN_MASK1(RB, cbn, a.N, ROWS_TOO, T_) } \
+    if ((ROWS_TOO) || edge_a) SPGNN_TN_MASK1(RA, NLA, trowA, G::RSA, ca, a.M, ROWS_TOO, T_)                  \
+    if ((ROWS_TOO) || edge_b) { if constexpr (BPS) SPGNN_TN_MASKG(RB, NLB, trowB, G::RSB, cbn, a.N, ROWS_TOO, T_) \
+                                else SPGNN_TN_MASK1(RB, NLB, trowB, G::RSB, cbn, a.N, ROWS_TOO, T_) }         \
   }
+#define SPGNN_TN_PUTA(HI_, LO_, R_, I_) store_one_t<G::CA4, PA, NT>(HI_, LO_, R_, I_, sA);
 #define SPGNN_TN_PUTB(HI_, LO_, R_, I_)                                                                      \
-  { if constexpr (BPS) store_raw_t(HI_, LO_, R_, I_); else store_one_t(HI_, LO_, R_, I_, sB); }
+  { if constexpr (BPS) store_raw_t<G::CB4, PB, NT>(HI_, LO_, R_, I_); else store_one_t<G::CB4, PB, NT>(HI_, LO_, R_, I_, sB); }
 #define SPGNN_TN_CSUM(RA)                                                            \
   if (do_colsum) {                                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
+    _Pragma("unroll") for (int q = 0; q < NLA; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
   }
   if (nk > 0) {                                          // block-uniform; an empty split only writes zeros
     SPGNN_TN_LOAD_ANY(0, ra0, rb0)
@@ -954,14 +979,14 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
     SPGNN_TN_CSUM(ra0)
     _Float16* st = smem_t;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) store_one_t(st, st + TTILE, ra0[q], q, sA);
+    for (int q = 0; q < NLA; ++q) SPGNN_TN_PUTA(st, st + A_IMG, ra0[q], q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) SPGNN_TN_PUTB(st + 2 * TTILE, st + 3 * TTILE, rb0[q], q)
+    for (int q = 0; q < NLB; ++q) SPGNN_TN_PUTB(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[q], q)
     __syncthreads();
     SPGNN_TN_LOAD_ANY(2, ra0, rb0)
 
   // stage T_: MFMAs on buffer PAR_ (= T_ & 1); register set (RA, RB) = stage T_+1 is converted into the other buffer,
-  // one float4 pair per accumulator group; then the set is refilled with stage T_+3.  STEADY_ = 1: stages T_+1 and
+  // one float4 per three MFMAs; then the set is refilled with stage T_+3.  STEADY_ = 1: stages T_+1 and
   // T_+3 exist with all their rows (no tests); STEADY_ = 0: the last stages (set masked first, harmless refill).
 #define SPGNN_TN_STAGE(T_, PAR_, RA, RB, STEADY_)                                                            \
   {                                                                                                          \
@@ -975,21 +1000,21 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
     _Pragma("unroll") for (int ks = 0; ks < TBK / 16; ++ks) {                                                \
       half8 ah[2], al[2], bh[2], bl[2];                                                                      \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-        ah[i] = tr_frag(cb, wm * 64 + i * 32, ks * 16, lane);                                                \
-        al[i] = tr_frag(cb + TTILE, wm * 64 + i * 32, ks * 16, lane);                                        \
+        ah[i] = tr_frag<PA>(cb, wm * 64 + i * 32, ks * 16, lane);                                            \
+        al[i] = tr_frag<PA>(cb + A_IMG, wm * 64 + i * 32, ks * 16, lane);                                    \
       }                                                                                                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
-        bh[j] = tr_frag(cb + 2 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
-        bl[j] = tr_frag(cb + 3 * TTILE, wn * 64 + j * 32, ks * 16, lane);                                    \
+        bh[j] = tr_frag<PB>(cb + 2 * A_IMG, wn * 64 + j * 32, ks * 16, lane);                                \
+        bl[j] = tr_frag<PB>(cb + 2 * A_IMG + B_IMG, wn * 64 + j * 32, ks * 16, lane);                        \
       }                                                                                                      \
       _Pragma("unroll") for (int c = 0; c < 12; ++c) {                   /* product-major, as the NT kernel */ \
         const int pr = c >> 2, ij = c & 3;                                                                   \
         const int i = ij >> 1, j = ij & 1;                                                                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
         if (has_next && c % 3 == 2) {                                                                        \
-          const int slot = ks * 4 + c / 3;                              /* 8 slots, 8 float4 to convert */   \
-          if (slot < 4) store_one_t(nbuf, nbuf + TTILE, RA[slot], slot, sA);                                 \
-          else SPGNN_TN_PUTB(nbuf + 2 * TTILE, nbuf + 3 * TTILE, RB[slot - 4], slot - 4)                     \
+          const int slot = ks * 4 + c / 3;                              /* 8 slots, NLA + NLB float4 to convert */ \
+          if (slot < NLA) SPGNN_TN_PUTA(nbuf, nbuf + A_IMG, RA[slot], slot)                                  \
+          else if (slot - NLA < NLB) SPGNN_TN_PUTB(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[slot - NLA < NLB ? slot - NLA : 0], slot - NLA) \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -1015,23 +1040,24 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
 #undef SPGNN_TN_MASK
 #undef SPGNN_TN_MASK1
 #undef SPGNN_TN_MASKG
+#undef SPGNN_TN_PUTA
 #undef SPGNN_TN_PUTB
 #undef SPGNN_TN_CSUM
 
-  if (do_colsum) {                                 // fold the 8 row groups (tid >> 5) that share a column chunk
+  if (do_colsum) {                                 // fold the 8 row groups that share a column chunk
     float* red = reinterpret_cast<float*>(smem_t);
-    *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4) = csum;
+    *reinterpret_cast<float4*>(red + trowA * BMt + tcolA) = csum;
     __syncthreads();
-    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < a.M) {
+    if ((int)threadIdx.x < BMt && m0 + (int)threadIdx.x < a.M) {
       float t_ = 0.f;
 #pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) t_ += red[g_ * 128 + threadIdx.x];
+      for (int g_ = 0; g_ < G::RSA; ++g_) t_ += red[g_ * BMt + threadIdx.x];
       a.colsum[(int64_t)split * a.cs_split_stride + (int64_t)(m0 + threadIdx.x) * a.cs_stride] = t_;
     }
   }
   const float alpha = 1.f / (sA * sB);
   float* Cp = a.C + (int64_t)split * a.split_stride;
-  if (m0 + BM <= a.M && n0 + BN <= a.N) {              // interior tile (block-uniform): no per-element tests
+  if (m0 + BMt <= a.M && n0 + BN <= a.N) {             // interior tile (block-uniform): no per-element tests
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1055,13 +1081,13 @@ __device__ __forceinline__ void tn_v2_body(const ArgsTN& a, const unsigned bid, 
       }
     }
 }
-template <bool BPS>
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_f16x3_v2(ArgsTN a) { tn_v2_body<BPS>(a, blockIdx.x, gridDim.x); }
+template <int WM, bool BPS>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_tn_f16x3(ArgsTN a) { tn_body<WM, BPS>(a, blockIdx.x, gridDim.x); }
 struct PairArgsTN { ArgsTN p[2]; unsigned nb0; };
-template <bool BPS>
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_pair_v2(PairArgsTN pa) {          // see gemm_nt_pair_v2
+template <int WM, bool BPS>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_tn_pair(PairArgsTN pa) {          // see gemm_nt_pair_v2
   const bool second = blockIdx.x >= pa.nb0;
-  tn_v2_body<BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  tn_body<WM, BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
@@ -1892,9 +1918,19 @@ int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale
   return spgnn_detail::check_launch("spgnn_presplit");
 }
 
+// Tile rows of the weight-gradient kernel: 256 (gemm_tn<4>: 8 waves, one workgroup per CU) when the result has whole 256-row
+// tiles and the reduction is long enough to fill the chip with them, else 128 (gemm_tn<2>).  `flags` may pin it.
+static int gemm_tn_rows(int64_t R, int64_t M, int64_t N, int32_t flags) {
+  if (flags & SPGNN_TN_TILE_256) return 256;
+  if (flags & SPGNN_TN_TILE_128) return 128;
+  // tools/tn_tiles.py (MI355X, one process; best split count of each form): R = 76 410: 1024 x 1063 623 -> 579 us, 1024 x 384
+  // 223 -> 211, 512 x 768 224 -> 210, 256 x 384 71 -> 69, 256 x 256 53 = 53; R = 9 641: 99 -> 93, 47 -> 45, 46 -> 45, 28 = 28
+  return (M % 256 == 0 && R >= 4096 && M * N >= 384 * 1024) ? 256 : 128;
+}
+
 static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                         int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
-                        float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, gemm::ArgsTN* a, int64_t* blocks) {
+                        float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, int tile_rows, gemm::ArgsTN* a, int64_t* blocks) {
   *blocks = 0;
   if (R < 0 || M <= 0 || N <= 0 || splits <= 0 || M > INT32_MAX || N > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   if (colsum_a && (colsum_stride < 1 || (splits > 1 && colsum_split_stride < 1))) return spgnn_detail::fail_at(SPGNN_ERR_STRIDE, __func__, __LINE__);
@@ -1906,68 +1942,77 @@ static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb
   rps = (rps + gemm::TBK - 1) / gemm::TBK * gemm::TBK;
   if (rps == 0) rps = gemm::TBK;
   *a = gemm::ArgsTN{A, lda, B, ldb, C, ldc, split_stride, R, (int)M, (int)N, rps, scale_a, scale_b,
-                    (int)((M + gemm::BM - 1) / gemm::BM), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, (int)splits};
+                    (int)((M + tile_rows - 1) / tile_rows), (int)((N + gemm::BN - 1) / gemm::BN), colsum_a, colsum_stride, colsum_split_stride, (int)splits};
   *blocks = ((int64_t)a->nbm * a->nbn * splits + 7) & ~int64_t(7);
   if (*blocks > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
   return SPGNN_OK;
 }
 
-static int gemm_tn_launch1(const gemm::ArgsTN& a, int64_t blocks, int32_t b_presplit, hipStream_t st) {
-  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-  if (b_presplit) {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2<true>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2<true>, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, st, a);
-  } else {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_f16x3_v2<false>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_tn_f16x3_v2<false>, dim3((unsigned)blocks), dim3(gemm::kThreads), lds_bytes, st, a);
+static bool tn_flags_ok(int32_t f) {
+  return !(f & ~(SPGNN_TN_B_PRESPLIT | SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256)) && (f & (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256)) != (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256);
+}
+
+// one product (p1 null) or a pair, in the kernel of `tile_rows` x 128 tiles
+static int gemm_tn_launch(const gemm::ArgsTN& a0, int64_t b0, const gemm::ArgsTN* a1, int64_t b1, int tile_rows, bool bps, hipStream_t st) {
+  const size_t lds_bytes = tile_rows == 256 ? gemm::TnGeo<4>::lds_bytes : gemm::TnGeo<2>::lds_bytes;
+  const int threads = tile_rows == 256 ? 512 : 256;
+#define SPGNN_LAUNCH_TN(KERNEL_, BLOCKS_, ARG_)                                                                \
+  { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; \
+    hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(BLOCKS_)), dim3(threads), lds_bytes, st, ARG_); }
+#define SPGNN_LAUNCH_TN_V(KERNEL_, BLOCKS_, ARG_)                                                              \
+  { if (tile_rows == 256) { if (bps) SPGNN_LAUNCH_TN((KERNEL_<4, true>), BLOCKS_, ARG_) else SPGNN_LAUNCH_TN((KERNEL_<4, false>), BLOCKS_, ARG_) } \
+    else { if (bps) SPGNN_LAUNCH_TN((KERNEL_<2, true>), BLOCKS_, ARG_) else SPGNN_LAUNCH_TN((KERNEL_<2, false>), BLOCKS_, ARG_) } }
+  if (!a1) SPGNN_LAUNCH_TN_V(gemm::gemm_tn_f16x3, b0, a0)
+  else {
+    gemm::PairArgsTN pa{{a0, *a1}, (unsigned)b0};
+    SPGNN_LAUNCH_TN_V(gemm::gemm_tn_pair, b0 + b1, pa)
   }
+#undef SPGNN_LAUNCH_TN_V
+#undef SPGNN_LAUNCH_TN
   return spgnn_detail::check_launch("spgnn_gemm");
 }
+
+int32_t spgnn_gemm_tn_tile_rows(int64_t R, int64_t M, int64_t N, int32_t flags) { return gemm_tn_rows(R, M, N, flags); }
 
 int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_stride,
                   int32_t splits, int64_t R, int64_t M, int64_t N, const float* scale_a, const float* scale_b,
                   float* colsum_a, int64_t colsum_stride, int64_t colsum_split_stride, spgnn_stream_t stream) {
   gemm::ArgsTN a; int64_t blocks;
+  const int rows = gemm_tn_rows(R, M, N, 0);
   const int rc = gemm_tn_plan(A, lda, B, ldb, C, ldc, split_stride, splits, R, M, N, scale_a, scale_b, colsum_a, colsum_stride,
-                              colsum_split_stride, &a, &blocks);
+                              colsum_split_stride, rows, &a, &blocks);
   if (rc != SPGNN_OK) return rc;
-  return gemm_tn_launch1(a, blocks, 0, (hipStream_t)stream);
+  return gemm_tn_launch(a, blocks, nullptr, 0, rows, false, (hipStream_t)stream);
 }
 
 int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* q, spgnn_stream_t stream) {
   if (!q) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  if (q->b_presplit != 0 && q->b_presplit != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
+  if (!tn_flags_ok(q->flags)) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   gemm::ArgsTN a; int64_t blocks;
+  const int rows = gemm_tn_rows(q->R, q->M, q->N, q->flags);
   const int rc = gemm_tn_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->split_stride, q->splits, q->R, q->M, q->N, q->scale_a,
-                              q->scale_b, q->colsum_a, q->colsum_stride, q->colsum_split_stride, &a, &blocks);
+                              q->scale_b, q->colsum_a, q->colsum_stride, q->colsum_split_stride, rows, &a, &blocks);
   if (rc != SPGNN_OK) return rc;
-  return gemm_tn_launch1(a, blocks, q->b_presplit, (hipStream_t)stream);
+  return gemm_tn_launch(a, blocks, nullptr, 0, rows, (q->flags & SPGNN_TN_B_PRESPLIT) != 0, (hipStream_t)stream);
 }
 
 int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream) {
   if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
-  gemm::PairArgsTN pa; int64_t b0, b1;
+  if (!tn_flags_ok(first->flags) || !tn_flags_ok(second->flags) ||
+      (first->flags & SPGNN_TN_B_PRESPLIT) != (second->flags & SPGNN_TN_B_PRESPLIT))
+    return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn_pair: bad flags, or SPGNN_TN_B_PRESPLIT differs between the products (one kernel runs both)");
+  // both products run in the FIRST one's tile shape (pass the larger one first), as the NT pair does
+  const int rows = gemm_tn_rows(first->R, first->M, first->N, first->flags);
+  gemm::ArgsTN a[2]; int64_t bl[2];
   const spgnn_gemm_tn_problem* q[2] = {first, second};
-  int64_t* bl[2] = {&b0, &b1};
   for (int i = 0; i < 2; ++i) {
     const int rc = gemm_tn_plan(q[i]->A, q[i]->lda, q[i]->B, q[i]->ldb, q[i]->C, q[i]->ldc, q[i]->split_stride, q[i]->splits, q[i]->R,
                                 q[i]->M, q[i]->N, q[i]->scale_a, q[i]->scale_b, q[i]->colsum_a, q[i]->colsum_stride,
-                                q[i]->colsum_split_stride, &pa.p[i], bl[i]);
+                                q[i]->colsum_split_stride, rows, &a[i], &bl[i]);
     if (rc != SPGNN_OK) return rc;
   }
-  if (b0 + b1 > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
-  if ((first->b_presplit != 0 && first->b_presplit != 1) || first->b_presplit != second->b_presplit)
-    return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn_pair: b_presplit must be 0 or 1 and the same for both products (one kernel runs both)");
-  pa.nb0 = (unsigned)b0;
-  const size_t lds_bytes = 2 * 4 * gemm::TTILE * sizeof(_Float16);
-  if (first->b_presplit) {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2<true>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_tn_pair_v2<true>, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
-  } else {
-    { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm::gemm_tn_pair_v2<false>, (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; }
-    hipLaunchKernelGGL(gemm::gemm_tn_pair_v2<false>, dim3((unsigned)(b0 + b1)), dim3(gemm::kThreads), lds_bytes, (hipStream_t)stream, pa);
-  }
-  return spgnn_detail::check_launch("spgnn_gemm");
+  if (bl[0] + bl[1] > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
+  return gemm_tn_launch(a[0], bl[0], &a[1], bl[1], rows, (first->flags & SPGNN_TN_B_PRESPLIT) != 0, (hipStream_t)stream);
 }
 
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream) {

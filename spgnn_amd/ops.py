@@ -340,8 +340,16 @@ class ScalePool:
 _SCALE_POOLS: dict = {}
 
 
+def _dev_key(device) -> str:
+    """'cuda' and 'cuda:<current>' are one device: one pool."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 def scale_pool(device) -> ScalePool:
-    key = str(torch.device(device))
+    key = _dev_key(device)
     p = _SCALE_POOLS.get(key)
     if p is None:
         p = _SCALE_POOLS[key] = ScalePool(device)
@@ -351,7 +359,7 @@ def scale_pool(device) -> ScalePool:
 def new_scale_block(device) -> torch.Tensor:
     """A zeroed scale block for the producers of one GEMM operand to fold their maxima into; the tensor itself is then
     passed wherever a scale is taken (gemm_nt / gemm_tn ``scale_*``, ``_spgnn_scale``)."""
-    p = _SCALE_POOLS.get(str(torch.device(device)))
+    p = _SCALE_POOLS.get(_dev_key(device))
     b = p.take() if p is not None else None
     return b if b is not None else _scale_template(device, 1)[0].clone()
 
@@ -359,7 +367,7 @@ def new_scale_block(device) -> torch.Tensor:
 def range_violations(device) -> int:
     """Operands seen so far by the training steps on ``device`` that left the split GEMMs' accuracy envelope (synchronises:
     poll it per epoch, not per step).  The flags of the step in flight are counted when the NEXT step begins."""
-    p = _SCALE_POOLS.get(str(torch.device(device)))
+    p = _SCALE_POOLS.get(_dev_key(device))
     return int(p.violations.item()) if p is not None else 0
 
 
@@ -946,7 +954,7 @@ class _LinearFn(torch.autograd.Function):
 
 def linear_drop_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """Whether linear(x, weight, ..., drop=...) can run: the matrix-core path and an output width that is a multiple of 4."""
-    return bool(x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= 512 and weight.shape[0] >= 32
+    return bool(x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= MIN_GEMM_ROWS and weight.shape[0] >= 32
                 and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0)
 
 
@@ -957,7 +965,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     dropout of the result under the hash mask (matrix-core path with a width that is a multiple of 4 only; see
     :func:`linear_drop_supported`)."""
     N = x.shape[0] if x.dim() == 2 else 0
-    if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32 and weight.shape[1] >= 32
+    if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= MIN_GEMM_ROWS and weight.shape[0] >= 32 and weight.shape[1] >= 32
             and x.dtype == torch.float32 and weight.dtype == torch.float32
             and (addend is None or (weight.shape[0] % 4 == 0 and addend.shape == (N, weight.shape[0])))):
         y = _LinearFn.apply(x, weight, bias, act, addend, drop)
@@ -982,7 +990,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 def linear_act_classifier_supported(x: torch.Tensor, weight: torch.Tensor, w_cls: torch.Tensor) -> bool:
     N = x.shape[0] if x.dim() == 2 else 0
-    return (LINEAR_ACT_CLASSIFIER and x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= 512 and weight.shape[0] >= 32
+    return (LINEAR_ACT_CLASSIFIER and x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= MIN_GEMM_ROWS and weight.shape[0] >= 32
             and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
             and w_cls.shape[0] <= 32 and w_cls.shape[1] == weight.shape[0] and w_cls.dtype == torch.float32)
 
@@ -1085,7 +1093,7 @@ class _LinearClassifierFn(torch.autograd.Function):
 
 
 def linear_classifier_supported(x: torch.Tensor, weight: torch.Tensor, w_cls: torch.Tensor) -> bool:
-    return (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= 512 and weight.shape[0] >= 32
+    return (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and x.shape[0] >= MIN_GEMM_ROWS and weight.shape[0] >= 32
             and weight.shape[1] >= 32 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and w_cls.shape[0] <= 32 and w_cls.shape[1] == weight.shape[0] and weight.shape[0] % 4 == 0)
 
@@ -1164,6 +1172,9 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+MIN_GEMM_ROWS = 512    # dense layers (nn.Linear inside GraphConv / GINConv / SAGEConv, the linear-mean output layer) with fewer rows go
+                       # to torch.mm: a product of a few hundred rows is launch-bound either way.  Tests set it to 1 so that the
+                       # 2-3-tree parity cases of rows D / E / F run the library's own matrix-core kernels too.
 A_PRESPLIT = True      # constant node data (a model's first-layer input) goes to its products pre-split, once per loader batch
 
 
@@ -2312,7 +2323,7 @@ def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D:
     if blk is not None:
         zx._spgnn_scale = (zx._version, blk)
     if (FUSE_LINEAR_MEAN_FOLD and w_cls is not None and w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 4 == 0
-            and zx.shape[0] >= 512 and GEMM_MODE == "f16x3" and zx.dtype == torch.float32):
+            and zx.shape[0] >= MIN_GEMM_ROWS and GEMM_MODE == "f16x3" and zx.dtype == torch.float32):
         out, logits = _LinearMeanClassifierFn.apply(zx, w_fc, w_res, bias, w_cls, b_cls, H, D)
         return out, attn, logits
     parts = [w_fc.view(H, D, F_).permute(1, 0, 2).reshape(D, H * F_)]
@@ -2568,7 +2579,7 @@ POOL_MAX_FUSED = True    # SAGEConv 'pool': fc_pool + ReLU + max aggregation as 
 
 def pool_max_supported(csc: DeviceCSC, h: torch.Tensor, weight: torch.Tensor) -> bool:
     N = h.shape[0] if h.dim() == 2 else 0
-    return bool(POOL_MAX_FUSED and COMPACT_MAX_ARG and h.is_cuda and GEMM_MODE == "f16x3" and N >= 512 and N == csc.num_nodes
+    return bool(POOL_MAX_FUSED and COMPACT_MAX_ARG and h.is_cuda and GEMM_MODE == "f16x3" and N >= MIN_GEMM_ROWS and N == csc.num_nodes
                 and weight.shape[0] >= 32 and weight.shape[1] >= 32 and h.dtype == torch.float32 and weight.dtype == torch.float32
                 and csc.max_in_degree <= 254 and getattr(csc, "num_dst", None) is None
                 and _capi.load().spgnn_spmm_max_u8_supported(int(weight.shape[0])))
@@ -2766,7 +2777,10 @@ def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
     return H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and GEMM_MODE == "f16x3"
 
 
-def _tn_splits(tiles: int, R: int) -> int:
+TN_TILE = 0             # block-tile rows of the weight-gradient kernel: 0 = chosen by the library from the shape, 128 / 256 = pinned (A/B, tests)
+
+
+def _tn_splits(tiles: int, R: int, rows: int = 128) -> int:
     # Split count.  The kernel deals the (split, tile) work items to the XCDs in contiguous ranges, so any count keeps a
     # split's row range in one or two L2s.  Small products: enough splits for ~512 workgroups (two per CU), at least 256
     # rows each.  Large ones (tools/tn_splits.py, R = 76 410, incl. the partial-sum reduction): 1024 x 1063 (72 tiles)
@@ -2774,6 +2788,13 @@ def _tn_splits(tiles: int, R: int) -> int:
     # kernel is bound chip-wide, not per CU), fewer splits lose to the shorter pipeline per byte of L2 refill;
     # 1024 x 384 / 512 x 768 (24 tiles) 21: 209 / 209, 32: 215 / 213, 42: 216 / 215, 64: 229 / 226;
     # 256 x 384 (6) 64: 72, 85: 65, 128: 70; 256 x 256 (4) 64: 52, 128: 48, 256: 60; 128 x 128 (1) 64: 41, 256: 26, 512: 29.
+    if rows == 256:             # 256 x 128 tiles, one workgroup per CU: half the tiles of the 128-row form, the same row ranges
+        # tools/tn_tiles.py, R = 76 410: 1024 x 1063 (36 tiles) 16 splits 664 us, 21: 579, 32: 614, 43: 663; 1024 x 384 / 512 x 768
+        # (12 tiles) 16: 232 / 228, 21: 211 / 210, 32: 242 / 243; R = 9 641: 36 tiles 7: 93, 16: 115; 12 tiles 16: 44, 21: 45
+        splits = max(1, min(256, 256 // tiles, R // 256))
+        if tiles >= 8 and R >= 32 * 512:
+            splits = 21
+        return splits
     splits = max(1, min(256, 512 // tiles, R // 256))
     if tiles >= 16 and R >= 32 * 512:
         splits = 32 if tiles >= 48 else 21
@@ -2787,13 +2808,16 @@ class TnProblem:
     def __init__(self, a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
                  scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
                  out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None,
-                 b_presplit: bool = False):
+                 b_presplit: bool = False, tile: Optional[int] = None, splits: Optional[int] = None):
         _require_cuda(a, b)
         R, M = a.shape
         N = b.shape[1]
         assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        splits = _tn_splits(tiles, R)
+        tile = TN_TILE if tile is None else tile
+        flags = int(bool(b_presplit)) | (0x10 if tile == 128 else 0x20 if tile == 256 else 0)       # SPGNN_TN_B_PRESPLIT | SPGNN_TN_TILE_*
+        rows = int(_capi.load().spgnn_gemm_tn_tile_rows(R, M, N, flags))
+        tiles = ((M + rows - 1) // rows) * ((N + 127) // 128)
+        splits = _tn_splits(tiles, R, rows) if splits is None else int(splits)
         ldn = (N + 3) // 4 * 4
         ldc = ldn + 4 if want_colsum else ldn          # the column sums ride in a spare column: one reduction over splits
         part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
@@ -2813,7 +2837,7 @@ class TnProblem:
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.split_stride = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc
         q.R, q.M, q.N, q.scale_a, q.scale_b = R, M, N, _ptr(scale_a), _ptr(scale_b)
         q.colsum_a, q.colsum_stride, q.colsum_split_stride, q.splits = cs_ptr, ldc, M * ldc, splits
-        q.b_presplit = self.b_presplit = int(bool(b_presplit))      # b = the pre-split image of X (presplit() under scale_b)
+        q.flags, self.b_presplit, self.rows = flags, int(bool(b_presplit)), rows      # b_presplit: b = the pre-split image of X (presplit() under scale_b)
 
     def launch(self):
         import ctypes
@@ -2840,14 +2864,14 @@ class TnProblem:
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
             scale_b: Optional[torch.Tensor] = None, want_colsum: bool = False, out: Optional[torch.Tensor] = None,
             out2: Optional[torch.Tensor] = None, colsum_out: Optional[torch.Tensor] = None, defer: Optional["SumJobs"] = None,
-            b_presplit: bool = False):
+            b_presplit: bool = False, tile: Optional[int] = None, splits: Optional[int] = None):
     """a (R,M)^T @ b (R,N) -> (M,N): reduction over the rows of both operands (weight gradients), split-K
     over row chunks with a deterministic partial-sum reduction.  ``want_colsum``: also return a.sum(0) (M,),
     accumulated from the operand stream the kernel reads anyway.  ``out`` [, ``out2``] (row-major views, unit column
     stride): write the result there - with ``out2`` columns [0, out.shape[1]) to ``out`` and the rest to ``out2``;
     ``colsum_out`` (M,) contiguous likewise for the column sums.  ``b_presplit``: ``b`` is the pre-split image of the
     operand (:func:`presplit` under ``scale_b``)."""
-    return TnProblem(a, b, scale_a, scale_b, want_colsum, out, out2, colsum_out, defer, b_presplit).launch().finish()
+    return TnProblem(a, b, scale_a, scale_b, want_colsum, out, out2, colsum_out, defer, b_presplit, tile, splits).launch().finish()
 
 
 def gemm_tn_pair(first: TnProblem, second: TnProblem):

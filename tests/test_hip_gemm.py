@@ -136,6 +136,35 @@ def test_gemm_presplit_a_is_bit_identical(M, N, K):
     assert torch.equal(q0, t_ref[0]) and torch.equal(q1, t_ref[1])
 
 
+@pytest.mark.parametrize("R,M,N", [(5000, 512, 300), (3001, 256, 39), (20000, 1024, 1063), (4100, 384, 200), (2500, 128, 128), (70, 256, 64)])
+def test_gemm_tn_256_row_tiles_are_bit_identical(R, M, N):
+    """Round 4: the weight-gradient kernel in 256 x 128 block tiles (8 waves, one workgroup per CU) - same split ranges, same
+    accumulation order per output element as the 128 x 128 form: bit-identical results and column sums, ragged M / N / R, X
+    pre-split or not, single and pair launches (the second product of a pair runs in the first one's tile)."""
+    torch.manual_seed(R + M + N)
+    Np = (N + 3) // 4 * 4
+    g = torch.randn(R, M, device="cuda")
+    x = torch.randn(R, Np + 4, device="cuda")[:, :N]
+    sg, sx = ops.pow2_scale(g), ops.pow2_scale(x)
+    x_ps = ops.presplit(x, scale=sx)[0]
+    for splits in (1, 5):
+        ref, cs = ops.gemm_tn(g, x, sg, sx, want_colsum=True, tile=128, splits=splits)
+        got, cs2 = ops.gemm_tn(g, x, sg, sx, want_colsum=True, tile=256, splits=splits)
+        assert torch.equal(ref, got) and torch.equal(cs, cs2), splits
+        assert torch.equal(ops.gemm_tn(g, x_ps, sg, sx, tile=256, splits=splits, b_presplit=True), ref)
+    assert rel_err(ref, g.double().t() @ x.double()) < 2e-6
+    auto = ops.TnProblem(g, x, sg, sx)
+    assert auto.rows == (256 if (M % 256 == 0 and R >= 4096 and M * N >= 384 * 1024) else 128)
+    # pair: a second, small product rides in the first one's tile shape
+    g1 = torch.randn(R, 96, device="cuda")
+    x1 = torch.randn(R, 40, device="cuda")[:, :39]
+    s1, t1 = ops.pow2_scale(g1), ops.pow2_scale(x1)
+    want = (ops.gemm_tn(g, x, sg, sx, tile=128, splits=3), ops.gemm_tn(g1, x1, s1, t1, tile=128, splits=2))
+    for tile in (128, 256):
+        a, b = ops.gemm_tn_pair(ops.TnProblem(g, x, sg, sx, tile=tile, splits=3), ops.TnProblem(g1, x1, s1, t1, tile=tile, splits=2))
+        assert torch.equal(a, want[0]) and torch.equal(b, want[1]), tile
+
+
 def test_const_operand_is_built_once_and_refreshed_in_place():
     """ops.const_operand: the pre-split image of a marked batch constant is made on first use and reused while the tensor is
     unchanged; refresh_batch_constant rewrites scale and image IN PLACE after the data was overwritten (batch arena)."""

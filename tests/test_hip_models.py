@@ -52,6 +52,40 @@ def test_config_forward_matches_oracle(name):
     assert outs[0].shape == (g.number_of_nodes(), 22)
 
 
+@pytest.mark.parametrize("name", ["st_gcn_3", "st_gin_3", "st_sage_3", "st_gat_3"])
+def test_small_batches_on_the_librarys_own_products(name, monkeypatch):
+    """below ops.MIN_GEMM_ROWS = 512 rows the dense layers of rows D / E / F (and the linear-mean output
+    layer) go to torch.mm, so the 2-3-tree parity cases never touched spgnn_gemm_*.  With the threshold at 1 the same small
+    batch runs the library's matrix-core kernels - ragged row tiles, one-tile weight gradients - forward and loss gradients
+    against the oracle."""
+    from spgnn_amd import ops as _ops
+    monkeypatch.setattr(_ops, "MIN_GEMM_ROWS", 1)
+    cfg, model = _build(name, seed=9)
+    g = synthetic.make_batch(2, rank=5, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    assert g.number_of_nodes() < 512
+    model.eval()
+    _ops.KernelTimer.start()
+    outs = model(g)
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(3)) < 0.5
+    loss = masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda())
+    loss.backward()
+    ran = {k[0] for k in _ops.KernelTimer.stop()}
+    assert "gemm_nt" in ran and ("gemm_tn" in ran or name == "st_gat_3"), ran
+    refs, sd = _oracle(cfg, model, g, grad=True)
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < TOL
+    O.masked_weighted_ce(refs[0], y.cpu(), mask, w).backward()
+    bad = []
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None and sd[n].grad is not None:
+            e = rel_err(p.grad, sd[n].grad)
+            if e >= 1e-4 and not (cfg.KIND == "sage" and (p.grad.cpu().double() - sd[n].grad.double()).norm() / sd[n].grad.double().norm() < 5e-3):
+                bad.append((n, e))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("name,trees", [("st_pgat_spgnn_3", 2), ("st_pgat_spgnnnl_3", 2), ("st_gat_3", 2), ("st_gcn_3", 2), ("st_gin_3", 2),
                                         ("st_sage_3", 2), ("st_gat_6_nr", 2),
                                         # >= 512 nodes: the dense layers of rows D / E / F take the matrix-core products with their
