@@ -447,6 +447,14 @@ int spgnn_spmm_max_bwd_u8_relu(const int32_t* indptr, const int32_t* out_indptr,
  */
 #define SPGNN_PRESPLIT_B 1
 #define SPGNN_PRESPLIT_A 2
+/* SPGNN_GEMM_WIDE (may be or-ed into the mask of every NT entry point; SPGNN_TN_WIDE for the TN ones): WIDE-RANGE arithmetic.
+ * hi + lo carries 22 bits only for values within 2^18 of the tensor's maximum - below that lo is an fp16 subnormal - so an
+ * operand whose rows differ by more than that (gradients late in training, un-normalised features) loses relative accuracy
+ * on its small rows.  In the wide form lo is kept as 2^11 lo (a normal fp16 wherever hi is one), the two cross products go to
+ * a second accumulator set that the epilogue adds times 2^-11: the same three MFMAs per product, 22 bits within ~2^28 of the
+ * maximum.  The wide kernels run in 128 x 128 (NT) / 128-row (TN) tiles, one workgroup per CU (two accumulator sets); an operand pre-split for one form
+ * (spgnn_presplit `wide`, spgnn_weight_prep mode bit 1) must be consumed in that form. */
+#define SPGNN_GEMM_WIDE 4
 int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, const float* scale_a, const float* scale_b,
                   const float* upd_u, int64_t upd_u_stride, const float* upd_v, int64_t upd_v_stride, int32_t upd_j,
@@ -460,7 +468,8 @@ int spgnn_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
  * spgnn_scale_from_partials would (then scale_in = null); scale_out (nullable) receives it.  src1 / dst1 nullable. */
 int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale_in, float* scale_out,
                    const float* src0, int64_t ld0, int64_t R0, int64_t K0, float* dst0,
-                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, spgnn_stream_t stream);
+                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, int32_t wide /* 1: the SPGNN_GEMM_WIDE form */,
+                   spgnn_stream_t stream);
 
 /* spgnn_gemm_nt for the SECOND head of a two-head layer whose heads are averaged (the reference's output GATConv,
  * `.mean(1)` at models.py:327 / 482): besides C = act(A B^T + bias) it writes
@@ -574,6 +583,7 @@ typedef struct spgnn_gemm_tn_problem {
 #define SPGNN_TN_B_PRESPLIT 1
 #define SPGNN_TN_TILE_128 0x10
 #define SPGNN_TN_TILE_256 0x20
+#define SPGNN_TN_WIDE 0x100          /* the wide-range arithmetic of SPGNN_GEMM_WIDE (B pre-split in that form, if pre-split) */
 /* Rows of the (rows x 128) block tile spgnn_gemm_tn / _problem_run / _pair take for this shape: 256 (8 waves, one workgroup per
  * CU) when M is a multiple of 256, M * N >= 384 * 1024 and R >= 4096, else 128.  Both tile shapes give bit-identical results; a caller
  * choosing `splits` counts tiles with it: ceil(M / rows) * ceil(N / 128). */
@@ -951,7 +961,8 @@ int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* t
  * ps / ps_t = the same two matrices in the pre-split form spgnn_gemm_nt takes with b_presplit, scale = the operand's
  * power-of-two scale (one float).  first_block = running sum of spgnn_weight_prep_blocks over the earlier entries;
  * total_blocks = the sum over all; workspace: total_blocks floats of scratch (no initialisation needed).  Results are bit-identical
- * to the per-layer calls.  mode 0: [a; b] as above.  mode 1: the COLUMN concatenation [a | b] (rows_a rows, K = all columns,
+ * to the per-layer calls.  mode bit 1 (value 2): ps / ps_t in the wide-range form (SPGNN_GEMM_WIDE).  mode bit 0 clear: [a; b] as above;
+ * set: the COLUMN concatenation [a | b] (rows_a rows, K = all columns,
  * rows_b = the columns `a` contributes; b nullable with rows_b = K) - the aggregate-first output layer's per-head operand
  * [W_fc,h | W_res,h] (spgnn_gat_agg_fwd); head h of the transpose is the column block [h D, (h+1) D) of dst_t / ps_t.
  * ================================================================================================= */

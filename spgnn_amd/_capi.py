@@ -119,7 +119,7 @@ SIGNATURES = {
     "spgnn_gemm_nt_headmean": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64,
                                _f32p, _i64, _i32, _vp],
     "spgnn_gemm_nt_add": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _i32, _vp],
-    "spgnn_presplit": [_f32p, _i64, _f32p, _f32p, _f32p, _i64, _i64, _i64, _f32p, _f32p, _i64, _i64, _i64, _f32p, _vp],
+    "spgnn_presplit": [_f32p, _i64, _f32p, _f32p, _f32p, _i64, _i64, _i64, _f32p, _f32p, _i64, _i64, _i64, _f32p, _i32, _vp],
     "spgnn_gat_agg_supported": [_i32, _i32],
     "spgnn_gat_agg_fwd": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _f32p, _i64, _i64,
                           _i32, _i32, _f32, _f32, _u64, _vp, _vp],

@@ -100,15 +100,24 @@ __device__ __forceinline__ float elu_fwd_nb(float x) {
 // conversions' issue slots are not what holds these kernels.  Kept for the second property: the residual is taken from the
 // hi that was actually stored - the AND form assumed a normal fp16 hi and was off by up to one fp16 subnormal quantum
 // (2^-39 of the tensor maximum) for |s x| < 2^-14.
+//
+// WIDE (round 4, the wide-range arithmetic of SPGNN_GEMM_WIDE): the residual is stored as lo' = 2^11 lo.  lo <= 2^-11 |s x|, so lo'
+// sits in the binade range of hi and is a NORMAL fp16 wherever hi is - the plain form loses lo to fp16's subnormals once |s x|
+// < 2^-3, i.e. 2^18 below the tensor maximum (the envelope of DESIGN.md section 4.2).  The kernels then keep the two cross
+// products hi lo' + lo' hi in a second accumulator set and add it, times 2^-11, in the epilogue: the same three MFMAs per
+// product, 22 bits for every value within ~2^28 of the maximum.  Operands pre-split in one form must be consumed in that form.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kWideLo = 2048.f, kWideLoInv = 1.f / 2048.f;
+template <bool WIDE = false>
 __device__ __forceinline__ void split4_pk(float4 v, float s, uint2& hi, uint2& lo) {
   const f32x2 ss = {s, s};
   const f32x2 a = f32x2{v.x, v.y} * ss, b = f32x2{v.z, v.w} * ss;
   union { pk2 h; unsigned u; } h01, h23, l01, l23;
   h01.h = __builtin_amdgcn_cvt_pkrtz(a.x, a.y);
   h23.h = __builtin_amdgcn_cvt_pkrtz(b.x, b.y);
-  const float r0 = __builtin_fmaf(v.x, s, -(float)h01.h[0]), r1 = __builtin_fmaf(v.y, s, -(float)h01.h[1]);
-  const float r2 = __builtin_fmaf(v.z, s, -(float)h23.h[0]), r3 = __builtin_fmaf(v.w, s, -(float)h23.h[1]);
+  float r0 = __builtin_fmaf(v.x, s, -(float)h01.h[0]), r1 = __builtin_fmaf(v.y, s, -(float)h01.h[1]);
+  float r2 = __builtin_fmaf(v.z, s, -(float)h23.h[0]), r3 = __builtin_fmaf(v.w, s, -(float)h23.h[1]);
+  if constexpr (WIDE) { r0 *= kWideLo; r1 *= kWideLo; r2 *= kWideLo; r3 *= kWideLo; }
   l01.h = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   l23.h = __builtin_amdgcn_cvt_pkrtz(r2, r3);
   hi = make_uint2(h01.u, h23.u);
@@ -190,17 +199,18 @@ struct TileIO {
     *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
   }
   // convert + store float4 #i (called between MFMAs)
+  template <bool WIDE = false>
   static __device__ __forceinline__ void store_one(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
     const int idx = threadIdx.x + NT * i;
     const int off = pair_row(idx >> 3) * PITCH + (idx & 7) * 4;
     uint2 h, l;
-    split4_pk(v, s, h, l);
+    split4_pk<WIDE>(v, s, h, l);
     *reinterpret_cast<uint2*>(hi_img + off) = h;
     *reinterpret_cast<uint2*>(lo_img + off) = l;
   }
-  template <bool RAW>
+  template <bool RAW, bool WIDE = false>
   static __device__ __forceinline__ void put(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
-    if constexpr (RAW) store_raw(hi_img, lo_img, v, i); else store_one(hi_img, lo_img, v, i, s);
+    if constexpr (RAW) store_raw(hi_img, lo_img, v, i); else store_one<WIDE>(hi_img, lo_img, v, i, s);
   }
   template <bool RAW>
   static __device__ __forceinline__ void mask_as(float4 (&r)[NL], int k0, int K) {
@@ -479,7 +489,7 @@ __device__ __forceinline__ void store_tile_through_lds(const ARGS& a, f32x16 (&a
   }
 }
 
-template <int WM, bool APS, bool BPS, bool DROP>   // APS / BPS: the A / B operand arrives pre-split (see Args)
+template <int WM, bool APS, bool BPS, bool DROP, bool WIDE>   // APS / BPS: the A / B operand arrives pre-split (see Args); WIDE: split4_pk
 __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, const unsigned nb) {   // workgroup b of the nb this product owns
   constexpr int TBM = 64 * WM, NT = 128 * WM;
   constexpr int A_IMG = TBM * PITCH, B_IMG = BN * PITCH;
@@ -498,13 +508,13 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
   const int fr = lane & 31, fh = lane >> 5;
   const float sA = spgnn_detail::load_scale_monitored(a.sA), sB = spgnn_detail::load_scale_monitored(a.sB);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], acc2[2][2];                                // acc2 (WIDE only): the cross products, carrying 2^11
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
   const int nk = (a.K + BK - 1) / BK;
   float4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];             // two prefetch sets (stage parity)
@@ -519,9 +529,9 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
     AIO::template mask_as<APS>(ra0, 0, a.K);
     BIO::template mask_as<BPS>(rb0, 0, a.K);
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) AIO::template put<APS>(st, st + A_IMG, ra0[i], i, sA);
+    for (int i = 0; i < NLA; ++i) AIO::template put<APS, WIDE>(st, st + A_IMG, ra0[i], i, sA);
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) BIO::template put<BPS>(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
+    for (int i = 0; i < NLB; ++i) BIO::template put<BPS, WIDE>(st + 2 * A_IMG, st + 2 * A_IMG + B_IMG, rb0[i], i, sB);
   }
   __syncthreads();
 
@@ -554,15 +564,18 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
       _Pragma("unroll") for (int c = 0; c < 12; ++c) {                                                       \
         const int pr = c >> 2, ij = c & 3;                                                                   \
         const int i = ij >> 1, j = ij & 1;                                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
+        if (WIDE && pr != 2)                                                                                 \
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc2[i][j], 0, 0, 0); \
+        else                                                                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
         if (has_next && c % 3 == 2) { /* a slice of next stage's conversion after every third MFMA */        \
           const int slot = ks * 4 + c / 3;                                                                   \
           _Pragma("unroll") for (int q = 0; q < NLA; ++q)                                                    \
             if (q * 8 / NLA == slot || (NLA > 8 && q % 8 == slot))                                           \
-              AIO::template put<APS>(nbuf, nbuf + A_IMG, RA[q], q, sA);                                      \
+              AIO::template put<APS, WIDE>(nbuf, nbuf + A_IMG, RA[q], q, sA);                                \
           _Pragma("unroll") for (int q = 0; q < NLB; ++q)                                                    \
             if (q * 8 / NLB == slot || (NLB > 8 && q % 8 == slot))                                           \
-              BIO::template put<BPS>(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);                    \
+              BIO::template put<BPS, WIDE>(nbuf + 2 * A_IMG, nbuf + 2 * A_IMG + B_IMG, RB[q], q, sB);              \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -593,6 +606,14 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
   if (t < nk) SPGNN_STAGE(t, 0, ra1, rb1, 0)
 #undef SPGNN_STAGE
 
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc2[i][j][e], kWideLoInv, acc[i][j][e]);
+  }
   store_tile_through_lds<DROP>(a, acc, smem, row0, col0, wave, lane, wm, wn, 1.f / (sA * sB));
 }
 
@@ -602,14 +623,15 @@ __device__ __forceinline__ void nt_v2_body(const Args& a, const unsigned b, cons
 // leaves idle instead of in a launch of their own.
 struct PairArgs { Args p[2]; unsigned nb0; };
 
-template <int WM, bool APS, bool BPS>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
-  nt_v2_body<WM, APS, BPS, true>(a, blockIdx.x, gridDim.x);
+// (WIDE: two accumulator sets - 128 registers - beside the staging sets: one workgroup per CU, so that the accumulators can live in AGPRs)
+template <int WM, bool APS, bool BPS, bool WIDE>
+__global__ __launch_bounds__(128 * WM, (WM == 2 && !WIDE) ? 2 : 1) void gemm_nt_f16x3_v2(Args a) {
+  nt_v2_body<WM, APS, BPS, true, WIDE>(a, blockIdx.x, gridDim.x);
 }
-template <int WM, bool APS, bool BPS>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_pair_v2(PairArgs pa) {
+template <int WM, bool APS, bool BPS, bool WIDE>
+__global__ __launch_bounds__(128 * WM, (WM == 2 && !WIDE) ? 2 : 1) void gemm_nt_pair_v2(PairArgs pa) {
   const bool second = blockIdx.x >= pa.nb0;                 // block-uniform: the arguments are read from one half of the kernarg
-  nt_v2_body<WM, APS, BPS, false>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  nt_v2_body<WM, APS, BPS, false, WIDE>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -857,12 +879,12 @@ struct TnGeo {
   static constexpr int RSA = NT / CA4, RSB = NT / CB4;         // rows between a thread's consecutive float4
   static constexpr size_t lds_bytes = 2 * (size_t)STAGE * sizeof(_Float16);
 };
-template <int COLS4, int PITCH_, int NT_>
+template <int COLS4, int PITCH_, int NT_, bool WIDE>
 __device__ __forceinline__ void store_one_t(_Float16* hi_img, _Float16* lo_img, const float4& v, int i, float s) {
   const int idx = threadIdx.x + NT_ * i;
   const int off = (idx / COLS4) * PITCH_ + (idx % COLS4) * 4;
   uint2 h, l;
-  split4_pk(v, s, h, l);
+  split4_pk<WIDE>(v, s, h, l);
   *reinterpret_cast<uint2*>(hi_img + off) = h;
   *reinterpret_cast<uint2*>(lo_img + off) = l;
 }
@@ -875,7 +897,7 @@ __device__ __forceinline__ void store_raw_t(_Float16* hi_img, _Float16* lo_img, 
   *reinterpret_cast<uint2*>(lo_img + off) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
 }
 
-template <int WM, bool BPS>      // BPS: B (= X, the layer input; constant node data for a model's first layer) arrives pre-split
+template <int WM, bool BPS, bool WIDE>      // BPS: B (= X, the layer input; constant node data for a model's first layer) arrives pre-split
 __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, const unsigned nblocks) {
   using G = TnGeo<WM>;
   constexpr int BMt = G::BMt, NT = G::NT, PA = G::PA, PB = G::PB, A_IMG = G::A_IMG, B_IMG = G::B_IMG, STAGE = G::STAGE;
@@ -903,13 +925,13 @@ __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, con
   const int fr = lane & 31, fh = lane >> 5;
   const float sA = spgnn_detail::load_scale_monitored(a.sA), sB = spgnn_detail::load_scale_monitored(a.sB);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], acc2[2][2];                                // acc2 (WIDE only): the cross products, carrying 2^11
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
   float4 ra0[NLA], rb0[NLB], ra1[NLA], rb1[NLB];
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -965,9 +987,9 @@ __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, con
     if ((ROWS_TOO) || edge_b) { if constexpr (BPS) SPGNN_TN_MASKG(RB, NLB, trowB, G::RSB, cbn, a.N, ROWS_TOO, T_) \
                                 else SPGNN_TN_MASK1(RB, NLB, trowB, G::RSB, cbn, a.N, ROWS_TOO, T_) }         \
   }
-#define SPGNN_TN_PUTA(HI_, LO_, R_, I_) store_one_t<G::CA4, PA, NT>(HI_, LO_, R_, I_, sA);
+#define SPGNN_TN_PUTA(HI_, LO_, R_, I_) store_one_t<G::CA4, PA, NT, WIDE>(HI_, LO_, R_, I_, sA);
 #define SPGNN_TN_PUTB(HI_, LO_, R_, I_)                                                                      \
-  { if constexpr (BPS) store_raw_t<G::CB4, PB, NT>(HI_, LO_, R_, I_); else store_one_t<G::CB4, PB, NT>(HI_, LO_, R_, I_, sB); }
+  { if constexpr (BPS) store_raw_t<G::CB4, PB, NT>(HI_, LO_, R_, I_); else store_one_t<G::CB4, PB, NT, WIDE>(HI_, LO_, R_, I_, sB); }
 #define SPGNN_TN_CSUM(RA)                                                            \
   if (do_colsum) {                                                                   \
     _Pragma("unroll") for (int q = 0; q < NLA; ++q) { csum.x += RA[q].x; csum.y += RA[q].y; csum.z += RA[q].z; csum.w += RA[q].w; } \
@@ -1010,7 +1032,10 @@ __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, con
       _Pragma("unroll") for (int c = 0; c < 12; ++c) {                   /* product-major, as the NT kernel */ \
         const int pr = c >> 2, ij = c & 3;                                                                   \
         const int i = ij >> 1, j = ij & 1;                                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
+        if (WIDE && pr != 2)                                                                                 \
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc2[i][j], 0, 0, 0); \
+        else                                                                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? al[i] : ah[i], pr == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0); \
         if (has_next && c % 3 == 2) {                                                                        \
           const int slot = ks * 4 + c / 3;                              /* 8 slots, NLA + NLB float4 to convert */ \
           if (slot < NLA) SPGNN_TN_PUTA(nbuf, nbuf + A_IMG, RA[slot], slot)                                  \
@@ -1055,6 +1080,14 @@ __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, con
       a.colsum[(int64_t)split * a.cs_split_stride + (int64_t)(m0 + threadIdx.x) * a.cs_stride] = t_;
     }
   }
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc2[i][j][e], kWideLoInv, acc[i][j][e]);
+  }
   const float alpha = 1.f / (sA * sB);
   float* Cp = a.C + (int64_t)split * a.split_stride;
   if (m0 + BMt <= a.M && n0 + BN <= a.N) {             // interior tile (block-uniform): no per-element tests
@@ -1081,13 +1114,13 @@ __device__ __forceinline__ void tn_body(const ArgsTN& a, const unsigned bid, con
       }
     }
 }
-template <int WM, bool BPS>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_tn_f16x3(ArgsTN a) { tn_body<WM, BPS>(a, blockIdx.x, gridDim.x); }
+template <int WM, bool BPS, bool WIDE>
+__global__ __launch_bounds__(128 * WM, (WM == 2 && !WIDE) ? 2 : 1) void gemm_tn_f16x3(ArgsTN a) { tn_body<WM, BPS, WIDE>(a, blockIdx.x, gridDim.x); }
 struct PairArgsTN { ArgsTN p[2]; unsigned nb0; };
-template <int WM, bool BPS>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_tn_pair(PairArgsTN pa) {          // see gemm_nt_pair_v2
+template <int WM, bool BPS, bool WIDE>
+__global__ __launch_bounds__(128 * WM, (WM == 2 && !WIDE) ? 2 : 1) void gemm_tn_pair(PairArgsTN pa) {          // see gemm_nt_pair_v2
   const bool second = blockIdx.x >= pa.nb0;
-  tn_body<WM, BPS>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
+  tn_body<WM, BPS, WIDE>(pa.p[second ? 1 : 0], second ? blockIdx.x - pa.nb0 : blockIdx.x, second ? gridDim.x - pa.nb0 : pa.nb0);
 }
 
 // out[i] = sum_s part[s * stride + i]: the deterministic reduction of split-K partial tiles (weight gradients, skinny
@@ -1351,7 +1384,8 @@ __global__ __launch_bounds__(256) void scale_from_partials_mb(const float* __res
 __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ partial, int n, const float* __restrict__ scale_in,
                                                        float* __restrict__ scale_out,
                                                        const float* __restrict__ s0, int64_t ld0, int R0, int K0, float* __restrict__ d0,
-                                                       const float* __restrict__ s1, int64_t ld1, int R1, int K1, float* __restrict__ d1) {
+                                                       const float* __restrict__ s1, int64_t ld1, int R1, int K1, float* __restrict__ d1,
+                                                       int wide) {
   __shared__ float red[4];
   float sc;
   if (scale_in) {
@@ -1377,7 +1411,7 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
     float4 v = *reinterpret_cast<const float4*>(src);
     v.y = c + 1 < K ? v.y : 0.f; v.z = c + 2 < K ? v.z : 0.f; v.w = c + 3 < K ? v.w : 0.f;
     uint2 h, l;
-    split4_pk(v, sc, h, l);
+    if (wide) split4_pk<true>(v, sc, h, l); else split4_pk<false>(v, sc, h, l);
     *reinterpret_cast<uint4*>((first ? d0 : d1) + (int64_t)r * ld + c) = make_uint4(h.x, h.y, l.x, l.y);
   }
 }
@@ -1397,7 +1431,8 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
   int l = 0;
   while (l + 1 < n_layers && (int64_t)blockIdx.x >= tab[l + 1].first_block) ++l;
   const spgnn_weight_prep_layer L = tab[l];
-  const bool cols = L.mode == 1;                         // [a | b]: rows_b = the columns a contributes
+  const bool cols = (L.mode & 1) != 0;                   // [a | b]: rows_b = the columns a contributes
+  const bool wide = (L.mode & 2) != 0;                   // pre-split images in the wide-range form (split4_pk<true>)
   const int R = cols ? L.rows_a : L.rows_a + L.rows_b, K = L.K;
   const int tiles_x = (int)((L.dst_stride + 31) / 32);
   const int b = (int)(blockIdx.x - L.first_block);
@@ -1438,7 +1473,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
       const float4 v = make_float4(tile[gr][gc], tile[gr][gc + 1], tile[gr][gc + 2], tile[gr][gc + 3]);     // beyond K: zeros
       *reinterpret_cast<float4*>(L.dst + (int64_t)r * L.dst_stride + c) = v;
       uint2 h, lo;
-      split4_pk(v, sc, h, lo);
+      if (wide) split4_pk<true>(v, sc, h, lo); else split4_pk<false>(v, sc, h, lo);
       *reinterpret_cast<uint4*>(L.ps + (int64_t)r * L.dst_stride + c) = make_uint4(h.x, h.y, lo.x, lo.y);
     }
   }
@@ -1448,7 +1483,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const spgnn_weight_pre
       const float4 v = make_float4(tile[gc][gr], tile[gc + 1][gr], tile[gc + 2][gr], tile[gc + 3][gr]);     // beyond R: zeros
       *reinterpret_cast<float4*>(L.dst_t + (int64_t)c * L.dst_t_stride + r) = v;
       uint2 h, lo;
-      split4_pk(v, sc, h, lo);
+      if (wide) split4_pk<true>(v, sc, h, lo); else split4_pk<false>(v, sc, h, lo);
       *reinterpret_cast<uint4*>(L.ps_t + (int64_t)c * L.dst_t_stride + r) = make_uint4(h.x, h.y, lo.x, lo.y);
     }
   }
@@ -1775,7 +1810,10 @@ static size_t gemm_nt_lds(int variant) {
 
 // `presplit`: SPGNN_PRESPLIT_B (1) = B pre-split, SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B (3) = both operands pre-split (a
 // constant A - node data of a model's first layer - is split once per loader batch, next to weights split once per step)
-static bool presplit_mask_ok(int32_t presplit) { return presplit == 0 || presplit == SPGNN_PRESPLIT_B || presplit == (SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B); }
+static bool presplit_mask_ok(int32_t presplit) {
+  const int32_t ps = presplit & ~SPGNN_GEMM_WIDE;
+  return !(presplit & ~(SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B | SPGNN_GEMM_WIDE)) && (ps == 0 || ps == SPGNN_PRESPLIT_B || ps == (SPGNN_PRESPLIT_A | SPGNN_PRESPLIT_B));
+}
 
 static int gemm_nt_launch(const NtPlan& p0, const NtPlan* p1, int32_t presplit, hipStream_t st) {
   const int variant = p0.variant;
@@ -1785,20 +1823,32 @@ static int gemm_nt_launch(const NtPlan& p0, const NtPlan* p1, int32_t presplit, 
   { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; \
     hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(BLOCKS_)), dim3(threads), lds_bytes, st, ARG_); }
 #define SPGNN_LAUNCH_NT_PS(KERNEL_, BLOCKS_, ARG_, ...)                                                        \
-  { if (presplit == 3) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ true, true>), BLOCKS_, ARG_)                        \
-    else if (presplit == 1) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ false, true>), BLOCKS_, ARG_)                  \
+  { if (ps == 3) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ true, true>), BLOCKS_, ARG_)                              \
+    else if (ps == 1) SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ false, true>), BLOCKS_, ARG_)                        \
     else SPGNN_LAUNCH_NT((KERNEL_<__VA_ARGS__ false, false>), BLOCKS_, ARG_) }
+#define SPGNN_LAUNCH_NT_V2(KERNEL_, BLOCKS_, ARG_, WM_, WIDE_)                                                 \
+  { if (ps == 3) SPGNN_LAUNCH_NT((KERNEL_<WM_, true, true, WIDE_>), BLOCKS_, ARG_)                              \
+    else if (ps == 1) SPGNN_LAUNCH_NT((KERNEL_<WM_, false, true, WIDE_>), BLOCKS_, ARG_)                        \
+    else SPGNN_LAUNCH_NT((KERNEL_<WM_, false, false, WIDE_>), BLOCKS_, ARG_) }
+  const int32_t ps = presplit & ~SPGNN_GEMM_WIDE;
+  const bool wide = (presplit & SPGNN_GEMM_WIDE) != 0;
+  // the wide-range form exists in 128 x 128 tiles only: its two accumulator sets (128 registers) fit beside the staging sets
+  // when a wave may use the AGPRs, i.e. with one 4-wave workgroup per CU; the 8-wave tiles would spill
+  if (wide && variant != 2) return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_nt: the wide-range form runs in 128 x 128 tiles only (tile 0 or 2)");
   if (!p1) {
     if (variant == 5) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v3, p0.blocks, p0.a, )
-    else if (variant == 4) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 4, )
-    else SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 2, )
+    else if (variant == 4) SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 4, false)
+    else if (wide) SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 2, true)
+    else SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_f16x3_v2, p0.blocks, p0.a, 2, false)
   } else {
     gemm::PairArgs pa{{p0.a, p1->a}, (unsigned)p0.blocks};
     const int64_t blocks = p0.blocks + p1->blocks;
     if (variant == 5) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v3, blocks, pa, )
-    else if (variant == 4) SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v2, blocks, pa, 4, )
-    else SPGNN_LAUNCH_NT_PS(gemm::gemm_nt_pair_v2, blocks, pa, 2, )
+    else if (variant == 4) SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_pair_v2, blocks, pa, 4, false)
+    else if (wide) SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_pair_v2, blocks, pa, 2, true)
+    else SPGNN_LAUNCH_NT_V2(gemm::gemm_nt_pair_v2, blocks, pa, 2, false)
   }
+#undef SPGNN_LAUNCH_NT_V2
 #undef SPGNN_LAUNCH_NT_PS
 #undef SPGNN_LAUNCH_NT
   return spgnn_detail::check_launch("spgnn_gemm");
@@ -1816,6 +1866,7 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* B, int64_t ldb
                               activation, score_l, score_r, score_out, score_cols, mean_other, mean_other_stride, mean_out,
                               mean_out_stride, nullptr, tile, &p);
   if (rc != SPGNN_OK || p.blocks == 0) return rc;
+  if ((b_presplit & SPGNN_GEMM_WIDE) && tile == 0 && p.variant != 2) gemm_nt_retile(&p, 2);       // the wide-range form: 128 x 128 tiles
   return gemm_nt_launch(p, nullptr, b_presplit, (hipStream_t)stream);
 }
 
@@ -1838,6 +1889,7 @@ int spgnn_gemm_nt_problem_run(const spgnn_gemm_nt_problem* problem, int32_t b_pr
   NtPlan p;
   const int rc = nt_plan_of(problem, &p);
   if (rc != SPGNN_OK || p.blocks == 0) return rc;
+  if ((b_presplit & SPGNN_GEMM_WIDE) && p.variant != 2) gemm_nt_retile(&p, 2);
   return gemm_nt_launch(p, nullptr, b_presplit, (hipStream_t)stream);
 }
 
@@ -1852,6 +1904,10 @@ int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_p
   if (rc != SPGNN_OK) return rc;
   rc = nt_plan_of(second, &p1);
   if (rc != SPGNN_OK) return rc;
+  if (b_presplit & SPGNN_GEMM_WIDE) {
+    if (p0.variant != 2) gemm_nt_retile(&p0, 2);
+    if (p1.variant != 2) gemm_nt_retile(&p1, 2);
+  }
   if (p0.blocks == 0 && p1.blocks == 0) return SPGNN_OK;
   if (p0.blocks == 0) return gemm_nt_launch(p1, nullptr, b_presplit, (hipStream_t)stream);
   if (p1.blocks == 0) return gemm_nt_launch(p0, nullptr, b_presplit, (hipStream_t)stream);
@@ -1900,7 +1956,8 @@ int spgnn_gemm_nt_add(const float* A, int64_t lda, const float* B, int64_t ldb, 
 
 int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale_in, float* scale_out,
                    const float* src0, int64_t ld0, int64_t R0, int64_t K0, float* dst0,
-                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, spgnn_stream_t stream) {
+                   const float* src1, int64_t ld1, int64_t R1, int64_t K1, float* dst1, int32_t wide, spgnn_stream_t stream) {
+  if (wide != 0 && wide != 1) return spgnn_detail::fail_at(SPGNN_ERR_ENUM, __func__, __LINE__);
   if ((!partials || n_partials <= 0) == (scale_in == nullptr)) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);   // exactly one source of the scale
   if (n_partials > INT32_MAX || R0 < 0 || K0 <= 0 || R0 > INT32_MAX || K0 > INT32_MAX || (src1 && (R1 < 0 || K1 <= 0 || R1 > INT32_MAX || K1 > INT32_MAX)))
     return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
@@ -1914,7 +1971,7 @@ int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gemm::presplit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, (int)n_partials, scale_in,
-                     scale_out, src0, ld0, (int)R0, (int)K0, dst0, src1, ld1, (int)R1, (int)(src1 ? K1 : 0), dst1);
+                     scale_out, src0, ld0, (int)R0, (int)K0, dst0, src1, ld1, (int)R1, (int)(src1 ? K1 : 0), dst1, (int)wide);
   return spgnn_detail::check_launch("spgnn_presplit");
 }
 
@@ -1922,7 +1979,7 @@ int spgnn_presplit(const float* partials, int64_t n_partials, const float* scale
 // tiles and the reduction is long enough to fill the chip with them, else 128 (gemm_tn<2>).  `flags` may pin it.
 static int gemm_tn_rows(int64_t R, int64_t M, int64_t N, int32_t flags) {
   if (flags & SPGNN_TN_TILE_256) return 256;
-  if (flags & SPGNN_TN_TILE_128) return 128;
+  if ((flags & SPGNN_TN_TILE_128) || (flags & SPGNN_TN_WIDE)) return 128;        // (the wide-range form: 128-row tiles, see gemm_nt_launch)
   // tools/tn_tiles.py (MI355X, one process; best split count of each form): R = 76 410: 1024 x 1063 623 -> 579 us, 1024 x 384
   // 223 -> 211, 512 x 768 224 -> 210, 256 x 384 71 -> 69, 256 x 256 53 = 53; R = 9 641: 99 -> 93, 47 -> 45, 46 -> 45, 28 = 28
   return (M % 256 == 0 && R >= 4096 && M * N >= 384 * 1024) ? 256 : 128;
@@ -1949,25 +2006,30 @@ static int gemm_tn_plan(const float* A, int64_t lda, const float* B, int64_t ldb
 }
 
 static bool tn_flags_ok(int32_t f) {
-  return !(f & ~(SPGNN_TN_B_PRESPLIT | SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256)) && (f & (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256)) != (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256);
+  return !(f & ~(SPGNN_TN_B_PRESPLIT | SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256 | SPGNN_TN_WIDE)) && (f & (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256)) != (SPGNN_TN_TILE_128 | SPGNN_TN_TILE_256);
 }
 
 // one product (p1 null) or a pair, in the kernel of `tile_rows` x 128 tiles
-static int gemm_tn_launch(const gemm::ArgsTN& a0, int64_t b0, const gemm::ArgsTN* a1, int64_t b1, int tile_rows, bool bps, hipStream_t st) {
+static int gemm_tn_launch(const gemm::ArgsTN& a0, int64_t b0, const gemm::ArgsTN* a1, int64_t b1, int tile_rows, bool bps, bool wide, hipStream_t st) {
   const size_t lds_bytes = tile_rows == 256 ? gemm::TnGeo<4>::lds_bytes : gemm::TnGeo<2>::lds_bytes;
   const int threads = tile_rows == 256 ? 512 : 256;
 #define SPGNN_LAUNCH_TN(KERNEL_, BLOCKS_, ARG_)                                                                \
   { const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)(KERNEL_), (int)lds_bytes); if (rc_ != SPGNN_OK) return rc_; \
     hipLaunchKernelGGL((KERNEL_), dim3((unsigned)(BLOCKS_)), dim3(threads), lds_bytes, st, ARG_); }
+#define SPGNN_LAUNCH_TN_W(KERNEL_, BLOCKS_, ARG_, WM_, WIDE_)                                                  \
+  { if (bps) SPGNN_LAUNCH_TN((KERNEL_<WM_, true, WIDE_>), BLOCKS_, ARG_) else SPGNN_LAUNCH_TN((KERNEL_<WM_, false, WIDE_>), BLOCKS_, ARG_) }
 #define SPGNN_LAUNCH_TN_V(KERNEL_, BLOCKS_, ARG_)                                                              \
-  { if (tile_rows == 256) { if (bps) SPGNN_LAUNCH_TN((KERNEL_<4, true>), BLOCKS_, ARG_) else SPGNN_LAUNCH_TN((KERNEL_<4, false>), BLOCKS_, ARG_) } \
-    else { if (bps) SPGNN_LAUNCH_TN((KERNEL_<2, true>), BLOCKS_, ARG_) else SPGNN_LAUNCH_TN((KERNEL_<2, false>), BLOCKS_, ARG_) } }
+  { if (tile_rows == 256) SPGNN_LAUNCH_TN_W(KERNEL_, BLOCKS_, ARG_, 4, false)                                  \
+    else if (wide) SPGNN_LAUNCH_TN_W(KERNEL_, BLOCKS_, ARG_, 2, true)                                          \
+    else SPGNN_LAUNCH_TN_W(KERNEL_, BLOCKS_, ARG_, 2, false) }
+  if (wide && tile_rows != 128) return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn: the wide-range form runs in 128-row tiles only");
   if (!a1) SPGNN_LAUNCH_TN_V(gemm::gemm_tn_f16x3, b0, a0)
   else {
     gemm::PairArgsTN pa{{a0, *a1}, (unsigned)b0};
     SPGNN_LAUNCH_TN_V(gemm::gemm_tn_pair, b0 + b1, pa)
   }
 #undef SPGNN_LAUNCH_TN_V
+#undef SPGNN_LAUNCH_TN_W
 #undef SPGNN_LAUNCH_TN
   return spgnn_detail::check_launch("spgnn_gemm");
 }
@@ -1982,7 +2044,7 @@ int spgnn_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
   const int rc = gemm_tn_plan(A, lda, B, ldb, C, ldc, split_stride, splits, R, M, N, scale_a, scale_b, colsum_a, colsum_stride,
                               colsum_split_stride, rows, &a, &blocks);
   if (rc != SPGNN_OK) return rc;
-  return gemm_tn_launch(a, blocks, nullptr, 0, rows, false, (hipStream_t)stream);
+  return gemm_tn_launch(a, blocks, nullptr, 0, rows, false, false, (hipStream_t)stream);
 }
 
 int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* q, spgnn_stream_t stream) {
@@ -1993,14 +2055,14 @@ int spgnn_gemm_tn_problem_run(const spgnn_gemm_tn_problem* q, spgnn_stream_t str
   const int rc = gemm_tn_plan(q->A, q->lda, q->B, q->ldb, q->C, q->ldc, q->split_stride, q->splits, q->R, q->M, q->N, q->scale_a,
                               q->scale_b, q->colsum_a, q->colsum_stride, q->colsum_split_stride, rows, &a, &blocks);
   if (rc != SPGNN_OK) return rc;
-  return gemm_tn_launch(a, blocks, nullptr, 0, rows, (q->flags & SPGNN_TN_B_PRESPLIT) != 0, (hipStream_t)stream);
+  return gemm_tn_launch(a, blocks, nullptr, 0, rows, (q->flags & SPGNN_TN_B_PRESPLIT) != 0, (q->flags & SPGNN_TN_WIDE) != 0, (hipStream_t)stream);
 }
 
 int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_problem* second, spgnn_stream_t stream) {
   if (!first || !second) return spgnn_detail::fail_at(SPGNN_ERR_NULLPTR, __func__, __LINE__);
   if (!tn_flags_ok(first->flags) || !tn_flags_ok(second->flags) ||
-      (first->flags & SPGNN_TN_B_PRESPLIT) != (second->flags & SPGNN_TN_B_PRESPLIT))
-    return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn_pair: bad flags, or SPGNN_TN_B_PRESPLIT differs between the products (one kernel runs both)");
+      (first->flags & (SPGNN_TN_B_PRESPLIT | SPGNN_TN_WIDE)) != (second->flags & (SPGNN_TN_B_PRESPLIT | SPGNN_TN_WIDE)))
+    return spgnn_detail::fail(SPGNN_ERR_ENUM, "spgnn_gemm_tn_pair: bad flags, or SPGNN_TN_B_PRESPLIT / SPGNN_TN_WIDE differ between the products (one kernel runs both)");
   // both products run in the FIRST one's tile shape (pass the larger one first), as the NT pair does
   const int rows = gemm_tn_rows(first->R, first->M, first->N, first->flags);
   gemm::ArgsTN a[2]; int64_t bl[2];
@@ -2012,7 +2074,7 @@ int spgnn_gemm_tn_pair(const spgnn_gemm_tn_problem* first, const spgnn_gemm_tn_p
     if (rc != SPGNN_OK) return rc;
   }
   if (bl[0] + bl[1] > INT32_MAX) return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
-  return gemm_tn_launch(a[0], bl[0], &a[1], bl[1], rows, (first->flags & SPGNN_TN_B_PRESPLIT) != 0, (hipStream_t)stream);
+  return gemm_tn_launch(a[0], bl[0], &a[1], bl[1], rows, (first->flags & SPGNN_TN_B_PRESPLIT) != 0, (first->flags & SPGNN_TN_WIDE) != 0, (hipStream_t)stream);
 }
 
 int spgnn_sum_partials(const float* partials, int64_t split_stride, int32_t splits, int64_t n, float* out, spgnn_stream_t stream) {

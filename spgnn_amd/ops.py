@@ -1172,6 +1172,10 @@ def operand_scale(x: torch.Tensor) -> torch.Tensor:
     return sc
 
 
+GEMM_WIDE = False       # split GEMMs in their WIDE-RANGE form (include/spgnn_hip.h, SPGNN_GEMM_WIDE): lo kept as 2^11 lo, the cross products in a
+                        # second accumulator set - 22 bits within ~2^28 of an operand's maximum instead of 2^18, in 128 x 128 tiles (slower).  Set
+                        # between steps only (a step's forward and backward must agree); train.TrainStep(range_policy="auto") sets it when the
+                        # range monitor reports operands outside the narrow envelope.
 MIN_GEMM_ROWS = 512    # dense layers (nn.Linear inside GraphConv / GINConv / SAGEConv, the linear-mean output layer) with fewer rows go
                        # to torch.mm: a product of a few hundred rows is launch-bound either way.  Tests set it to 1 so that the
                        # 2-3-tree parity cases of rows D / E / F run the library's own matrix-core kernels too.
@@ -1192,13 +1196,19 @@ def const_operand(x: torch.Tensor, scale: torch.Tensor):
     else ``x`` itself."""
     if not (A_PRESPLIT and PRESPLIT_B and getattr(x, "_spgnn_const", False)) or x.requires_grad or not _rows_aligned(x):
         return x, False
-    tag = getattr(x, "_spgnn_aps", None)
+    wide = bool(GEMM_WIDE)
+    images = getattr(x, "_spgnn_aps", None)                  # {wide: (version, image, scale)}: one image per arithmetic form
+    tag = images.get(wide) if images else None
     if tag is not None and tag[0] == x._version and tag[2] is scale:
+        if CAPTURE_REFS is not None and torch.cuda.is_current_stream_capturing():
+            CAPTURE_REFS.append((tag[1], scale))             # the recorded launches address the image: the step keeps it alive
         return tag[1], True
     if torch.cuda.is_current_stream_capturing():
         return x, False                      # never allocate a persistent image inside a capture (the warm-up steps made it)
     ps = presplit(x, scale=scale)[0]
-    x._spgnn_aps = (x._version, ps, scale)
+    if images is None:
+        images = x._spgnn_aps = {}
+    images[wide] = (x._version, ps, scale)
     return ps, True
 
 
@@ -1209,10 +1219,9 @@ def refresh_batch_constant(t: torch.Tensor) -> None:
     if tag is not None:
         tag[1].copy_(pow2_scale(t))
         t._spgnn_scale = (t._version, tag[1])
-    aps = getattr(t, "_spgnn_aps", None)
-    if aps is not None:
-        presplit(t, scale=aps[2], out=aps[1])
-        t._spgnn_aps = (t._version, aps[1], aps[2])
+    for wide, aps in (getattr(t, "_spgnn_aps", None) or {}).items():
+        presplit(t, scale=aps[2], out=aps[1], wide=wide)
+        t._spgnn_aps[wide] = (t._version, aps[1], aps[2])
 
 
 BIAS_COLSUM = True     # spmm_sum's backward takes the bias gradient from the activation-backward pass (spgnn_act_bwd_colsum)
@@ -1274,7 +1283,7 @@ class _WeightPrep:
             t.dst, t.ps, t.dst_stride = dst.data_ptr(), ps.data_ptr(), Kp
             t.dst_t, t.ps_t, t.dst_t_stride = (dst_t.data_ptr(), ps_t.data_ptr(), Rp) if want_t else (0, 0, 0)
             t.scale, t.first_block, t.rows_a, t.rows_b, t.K = scale.data_ptr(), first, R1, (Ka if cols else R2), K
-            t.mode = 1 if cols else 0
+            t.mode = (1 if cols else 0) | (2 if GEMM_WIDE else 0)          # bit 1: pre-split images in the wide-range form
             first += int(lib.spgnn_weight_prep_blocks(R, Kp, Rp if want_t else 0))
             self.entries.append((dst, ps, dst_t, ps_t, scale, (R1, R2, K, R)))
         self.blocks = first
@@ -1334,7 +1343,7 @@ class prepared_weights:
         if not self.specs:
             return self
         dev = self.specs[0][0].device
-        key = (str(dev),) + tuple((sp[0].data_ptr(), sp[0].stride(0), tuple(sp[0].shape), 0 if sp[1] is None else sp[1].data_ptr(),
+        key = (str(dev), bool(GEMM_WIDE)) + tuple((sp[0].data_ptr(), sp[0].stride(0), tuple(sp[0].shape), 0 if sp[1] is None else sp[1].data_ptr(),
                                    0 if sp[1] is None else sp[1].stride(0), None if sp[1] is None else tuple(sp[1].shape), bool(sp[2]),
                                    sp[3] if len(sp) > 3 else "") for sp in self.specs)
         prep = _prep_lookup(_PREP_CACHE, key, lambda: _WeightPrep(self.specs, dev))
@@ -2644,7 +2653,7 @@ def pow2_scale(x: torch.Tensor) -> torch.Tensor:
 
 
 def presplit(w: torch.Tensor, scale: Optional[torch.Tensor] = None, partials: Optional[torch.Tensor] = None,
-             w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+             w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, wide: Optional[bool] = None):
     """Pre-split form of a GEMM ``b`` operand (spgnn_presplit): ``w`` (R, K) fp32 with 16-byte rows -> a tensor of the same
     shape and strides holding, per group of four columns, the packed fp16 hi / lo pairs of scale * w.  The scale is given
     (``scale``) or derived from ``partials`` (block maxima) - then it is returned too.  ``w2``: a second matrix under the same
@@ -2662,7 +2671,8 @@ def presplit(w: torch.Tensor, scale: Optional[torch.Tensor] = None, partials: Op
         _capi.check(_capi.load().spgnn_presplit(_ptr(partials), partials.numel() if partials is not None else 0, _ptr(scale), _ptr(sc_out),
                                                 w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], w_ps.data_ptr(),
                                                 _ptr(w2), w2.stride(0) if w2 is not None else 0, w2.shape[0] if w2 is not None else 0,
-                                                w2.shape[1] if w2 is not None else 0, _ptr(w2_ps), _stream(w)), "spgnn_presplit")
+                                                w2.shape[1] if w2 is not None else 0, _ptr(w2_ps), int(GEMM_WIDE if wide is None else wide),
+                                                _stream(w)), "spgnn_presplit")
     return w_ps, w2_ps, (scale if scale is not None else sc_out)
 
 
@@ -2671,13 +2681,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
             upd_u: Optional[torch.Tensor] = None, upd_v: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, act: int = 0, score_l: Optional[torch.Tensor] = None,
             score_r: Optional[torch.Tensor] = None, score_out: Optional[torch.Tensor] = None, tile: int = 0,
-            b_presplit: bool = False, a_presplit: bool = False) -> torch.Tensor:
+            b_presplit: bool = False, a_presplit: bool = False, wide: Optional[bool] = None) -> torch.Tensor:
     """a (M,K) @ b (N,K)^T [+ upd_u (M,J) @ upd_v (J,N), exact fp32, fused into the epilogue] -> (M,N); fp32
     in/out, fp16x3 split on the matrix cores.  ``bias`` (N,) / ``act``: epilogue act(C + bias).  ``score_out``
     (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns.
     ``b_presplit``: ``b`` is the pre-split form of the operand (:func:`presplit`, made with ``scale_b``); ``a_presplit``
     (only together with it): ``a`` likewise, made with ``scale_a`` (constant node data, split once per loader batch)."""
-    b_presplit = int(bool(b_presplit)) | (2 if a_presplit else 0)
+    b_presplit = int(bool(b_presplit)) | (2 if a_presplit else 0) | (4 if (GEMM_WIDE if wide is None else wide) else 0)
     _require_cuda(a, b)
     M, K = a.shape
     N = b.shape[0]
@@ -2717,7 +2727,8 @@ class NtProblem:
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         assert out.shape == (M, N) and out.stride(1) == 1
-        self.out, self.shape, self.b_presplit = out, (M, N, K), int(bool(b_presplit)) | (2 if a_presplit else 0)   # the C ABI's mask
+        self.out, self.shape = out, (M, N, K)
+        self.b_presplit = int(bool(b_presplit)) | (2 if a_presplit else 0) | (4 if GEMM_WIDE else 0)   # the C ABI's mask
         self.kw = dict(scale_a=scale_a, scale_b=scale_b, out=out, score_l=score_l, score_r=score_r, score_out=score_out,
                        b_presplit=b_presplit, a_presplit=a_presplit)
         self.a, self.b = a, b
@@ -2755,7 +2766,7 @@ def gemm_nt_headmean(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, out: to
         _capi.check(_capi.load().spgnn_gemm_nt_headmean(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                                                         out.stride(0), M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act,
                                                         other.data_ptr(), other.stride(0), mean_out.data_ptr(),
-                                                        mean_out.stride(0), int(b_presplit), _stream(out)), "spgnn_gemm_nt_headmean")
+                                                        mean_out.stride(0), int(b_presplit) | (4 if GEMM_WIDE else 0), _stream(out)), "spgnn_gemm_nt_headmean")
 
 
 def gemm_nt_add(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, addend: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -2769,7 +2780,7 @@ def gemm_nt_add(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, addend: torc
     with torch.cuda.device(a.device), _timed("gemm_nt", (M, N, K)):
         _capi.check(_capi.load().spgnn_gemm_nt_add(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
                                                    M, N, K, _ptr(scale_a), _ptr(scale_b), _ptr(bias), act, addend.data_ptr(),
-                                                   addend.stride(0), int(b_presplit), _stream(a)), "spgnn_gemm_nt_add")
+                                                   addend.stride(0), int(b_presplit) | (4 if GEMM_WIDE else 0), _stream(a)), "spgnn_gemm_nt_add")
     return out
 
 
@@ -2814,7 +2825,7 @@ class TnProblem:
         N = b.shape[1]
         assert b.shape[0] == R and _rows_aligned(a) and _rows_aligned(b)
         tile = TN_TILE if tile is None else tile
-        flags = int(bool(b_presplit)) | (0x10 if tile == 128 else 0x20 if tile == 256 else 0)       # SPGNN_TN_B_PRESPLIT | SPGNN_TN_TILE_*
+        flags = int(bool(b_presplit)) | (0x10 if tile == 128 else 0x20 if tile == 256 else 0) | (0x100 if GEMM_WIDE else 0)   # SPGNN_TN_B_PRESPLIT | _TILE_* | _WIDE
         rows = int(_capi.load().spgnn_gemm_tn_tile_rows(R, M, N, flags))
         tiles = ((M + rows - 1) // rows) * ((N + 127) // 128)
         splits = _tn_splits(tiles, R, rows) if splits is None else int(splits)

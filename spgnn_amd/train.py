@@ -141,7 +141,14 @@ class TrainStep:
     [all-reduce] -> SGD(momentum)."""
 
     def __init__(self, model: torch.nn.Module, class_weights: Sequence[float], sampling_rate: float, lr: float,
-                 momentum: float = 0.9, weight_decay: float = 0.0, process_group=None, seed: int = 0):
+                 momentum: float = 0.9, weight_decay: float = 0.0, process_group=None, seed: int = 0,
+                 range_policy: str = "monitor"):
+        """``range_policy``: what :meth:`run_batch` does with the GEMM range monitor: "monitor" only
+        counts (``range_violations()``); "auto" switches the split GEMMs to their wide-range form (``ops.GEMM_WIDE``) for all
+        later batches once an operand left the narrow envelope, dropping the captures recorded in the narrow form."""
+        if range_policy not in ("monitor", "auto"):
+            raise ValueError("range_policy must be 'monitor' or 'auto'")
+        self.range_policy, self._violations_seen = range_policy, None      # None: the counter's value at the first run_batch (it is per device, not per step)
         self.model = model
         self.bucket = FlatBucket(list(model.parameters()))
         dev = self.bucket.flat_param.device
@@ -415,6 +422,13 @@ class TrainStep:
     def run_batch(self, g, steps: int, granule: int = 256) -> torch.Tensor:
         """``steps`` optimizer steps on loader batch ``g`` as HIP-graph replays: the first batch of a size class pays the
         warm-up steps and the capture, every later one only the copies into the arena.  -> the last step's loss (device)."""
+        if self.range_policy == "auto" and not ops.GEMM_WIDE and self.bucket.flat_param.is_cuda:
+            v = self.range_violations()              # one 4-byte read per loader batch (the flags of the previous batch's steps)
+            if self._violations_seen is not None and v > self._violations_seen:
+                ops.GEMM_WIDE = True                 # wide-range products from here on; the narrow captures and images are stale
+                self._captures.clear()
+                self._graph = self._graph_back = None
+            self._violations_seen = v
         ag = self.arena_graph(g, granule)
         done = 0
         if not self.select(ag):

@@ -228,6 +228,51 @@ def test_gemm_heavy_tailed_operand_error_on_body_rows(ratio, body_bound):
         assert rel_err(gw[cols], refw[cols]) < body_bound
 
 
+@pytest.mark.parametrize("ratio", [1e6, 1e8])
+def test_wide_range_form_keeps_body_rows_at_fp32_accuracy(ratio, monkeypatch):
+    """SPGNN_GEMM_WIDE / SPGNN_TN_WIDE (round 4): lo kept as 2^11 lo and the cross products in a second
+    accumulator set.  The heavy-tailed operand of the test above - 0.01 % of the entries `ratio` times the body - now gives
+    rows (NT) and columns (TN) that never touch an outlier at 1e-5 of THEIR OWN magnitude, at 1e6 x and 1e8 x; on ordinary
+    data the wide form agrees with the narrow one to fp32 rounding, is exact on integers, and its pre-split images
+    (spgnn_presplit wide = 1) are consumed bit-identically to the in-kernel conversion."""
+    M, N, K = 4096, 256, 512
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(M, K, device="cuda", generator=g) * 1e-3
+    hot = torch.rand(M, K, device="cuda", generator=g) < 1e-4
+    a = torch.where(hot, a * ratio, a)
+    b = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    body = ~hot.any(dim=1)
+    sa, sb = ops.pow2_scale(a), ops.pow2_scale(b)
+    ref = a.double() @ b.double().t()
+    narrow = ops.gemm_nt(a, b, sa, sb, wide=False)
+    wide = ops.gemm_nt(a, b, sa, sb, wide=True)
+    e_n, e_w = rel_err(narrow[body], ref[body]), rel_err(wide[body], ref[body])
+    print(f"ratio {ratio:g}: body rows narrow {e_n:.2e}, wide {e_w:.2e}")
+    assert e_w < 1e-5 and rel_err(wide, ref) < 2e-6
+    monkeypatch.setattr(ops, "GEMM_WIDE", True)              # presplit / TnProblem read the module switch
+    x = torch.randn(M, 192, device="cuda", generator=g)
+    sx = ops.pow2_scale(x)
+    gw = ops.gemm_tn(a, x, sa, sx)
+    refw = a.double().t() @ x.double()
+    cols = ~hot.any(dim=0)
+    assert rel_err(gw, refw) < 2e-6
+    if bool(cols.any()):
+        assert rel_err(gw[cols], refw[cols]) < 1e-5
+    # pre-split images in the wide form: bit-identical to the in-kernel wide conversion, NT (both operands) and TN
+    a_ps, b_ps, x_ps = ops.presplit(a, scale=sa)[0], ops.presplit(b, scale=sb)[0], ops.presplit(x, scale=sx)[0]
+    assert torch.equal(ops.gemm_nt(a_ps, b_ps, sa, sb, b_presplit=True, a_presplit=True), wide)
+    assert torch.equal(ops.gemm_tn(a, x_ps, sa, sx, b_presplit=True), gw)
+    assert not torch.equal(b_ps.view(torch.int32), ops.presplit(b, scale=sb, wide=False)[0].view(torch.int32))
+    # ordinary operands: wide == narrow to fp32 rounding; exact on integers
+    p_, q_ = torch.randn(700, 300, device="cuda"), torch.randn(130, 300, device="cuda")
+    sp, sq = ops.pow2_scale(p_), ops.pow2_scale(q_)
+    assert rel_err(ops.gemm_nt(p_, q_, sp, sq), ops.gemm_nt(p_, q_, sp, sq, wide=False)) < 1e-6
+    pi, qi = _mat(300, 96, ints=True), _mat(64, 96, ints=True)
+    assert torch.equal(ops.gemm_nt(pi, qi), pi @ qi.t())
+    with pytest.raises(RuntimeError):                        # the wide form has 128 x 128 tiles only
+        ops.gemm_nt(p_, q_, sp, sq, tile=5)
+
+
 def test_range_monitor_flags_rows_outside_the_envelope():
     """Round 4 guard for the per-tensor scale: a product whose slot-block operand holds whole rows more
     than 2^18 below the tensor maximum - where hi + lo no longer carries 22 bits - sets the block's range flag; the next

@@ -371,6 +371,42 @@ def test_graph_replay_matches_eager_and_refreshes_dropout():
     _ops.DROPOUT_SEED_OFFSET = None
 
 
+def test_wide_range_products_model_parity_and_the_auto_policy(monkeypatch):
+    """ops.GEMM_WIDE (SPGNN_GEMM_WIDE, round 4): the flagship model with every split product in its wide-range form - logits
+    and loss gradients against the oracle at the usual bars - and TrainStep(range_policy="auto"): once the range monitor's
+    counter moves, the next loader batch switches the process to the wide form and drops the narrow captures."""
+    from spgnn_amd import ops as _ops
+    monkeypatch.setattr(_ops, "GEMM_WIDE", True)
+    cfg, model = _build("st_pgat_spgnn_3", seed=10)
+    g = synthetic.make_batch(5, rank=6, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model.eval()
+    outs = model(g)
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(4)) < 0.5
+    masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda()).backward()
+    refs, sd = _oracle(cfg, model, g, grad=True)
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < TOL
+    O.masked_weighted_ce(refs[0], y.cpu(), mask, w).backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None and sd[n].grad is not None and float(sd[n].grad.abs().max()) > 1e-6:
+            assert rel_err(p.grad, sd[n].grad) < 1e-4, n
+    # the policy: narrow until the monitor reports, wide afterwards
+    monkeypatch.setattr(_ops, "GEMM_WIDE", False)
+    cfg, model = _build("st_gat_3", seed=11)
+    model.eval()
+    ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), 1.0, 1e-3, 0.9, range_policy="auto")
+    g1 = synthetic.make_batch(4, rank=1, device="cuda", pos_enc_dim=None)
+    l1 = float(ts.run_batch(g1, 4, granule=1024))
+    assert not _ops.GEMM_WIDE and len(ts._captures) == 1
+    _ops.scale_pool(g1.device).violations.add_(1)            # what spgnn_step_begin does when a product flagged its operand
+    l2 = float(ts.run_batch(g1, 4, granule=1024))
+    assert _ops.GEMM_WIDE and len(ts._captures) == 1 and np.isfinite([l1, l2]).all()
+    assert abs(l2 - l1) < 0.5 * abs(l1)                       # training continued from the same parameters
+    _ops.DROPOUT_SEED_OFFSET = None
+
+
 @pytest.mark.parametrize("name,bf16", [("st_pgat_spgnn_3", False), ("st_gat_3", False), ("st_gat_6", True)])
 def test_deferred_attention_vector_gradients_are_bit_identical(name, bf16, monkeypatch):
     """ops.AttnGradQueue (round 4): a training step collects every GATConv's attention-vector gradient pass during backward
