@@ -159,20 +159,22 @@ class BatchArena:
         with torch.no_grad():
             old = dict(acsc._cache)
             acsc._cache = {}
-            for key, val in old.items():
-                if key == "ell":
-                    new = acsc.ell()
-                elif key == "in_deg":
-                    new = acsc.in_degrees_f()
-                elif key == "out_deg":
-                    new = acsc.out_degrees_f()
-                elif isinstance(key, tuple) and key[0] == "deg_scale":
-                    new = acsc.degree_scale(key[1], key[2])
-                else:
-                    continue
-                for o, n_ in zip(val if isinstance(val, tuple) else (val,), new if isinstance(new, tuple) else (new,)):
-                    o.copy_(n_)
-            acsc._cache = old
+            try:
+                for key, val in old.items():
+                    if key == "ell":
+                        new = acsc.ell()
+                    elif key == "in_deg":
+                        new = acsc.in_degrees_f()
+                    elif key == "out_deg":
+                        new = acsc.out_degrees_f()
+                    elif isinstance(key, tuple) and key[0] == "deg_scale":
+                        new = acsc.degree_scale(key[1], key[2])
+                    else:
+                        continue
+                    for o, n_ in zip(val if isinstance(val, tuple) else (val,), new if isinstance(new, tuple) else (new,)):
+                        o.copy_(n_)
+            finally:
+                acsc._cache = old                    # the tensors a captured step addresses stay the cached ones, whatever happened
             for key, builder in list(ag._derived_builders.items()):
                 held = ag._tensor_cache[key]
                 held.copy_(builder())

@@ -434,7 +434,7 @@ class TrainStep:
         if not self.select(ag):
             self.capture(ag)
             done = self.capture_steps
-            loss = self._static_loss
+        loss = self._static_loss                     # the device scalar every replay of this capture writes
         for _ in range(max(steps - done, 0)):
             loss = self.replay()
         return loss
