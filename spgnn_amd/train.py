@@ -278,8 +278,9 @@ class TrainStep:
 
     def range_violations(self) -> int:
         """GEMM operands of the steps so far that had rows / blocks outside the split products' 2^18 accuracy envelope
-        (ops.range_violations: a device counter; this call synchronises).  0 is the normal state; when it moves, re-run the
-        affected span with ``ops.GEMM_MODE = "fp32"`` (plain fp32 products) and compare."""
+        (ops.range_violations: a device counter; this call synchronises).  0 is the normal state; when it moves, the products'
+        wide-range form (``ops.GEMM_WIDE``; ``range_policy="auto"`` switches to it by itself) restores fp32 accuracy for
+        operands within ~2^28 of their maximum; ``ops.GEMM_MODE = "fp32"`` (rocBLAS) is the unconditional fallback."""
         return ops.range_violations(self.bucket.flat_param.device) if self.bucket.flat_param.is_cuda else 0
 
     def set_lr(self, lr: float):

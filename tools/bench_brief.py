@@ -10,6 +10,10 @@ brief(d, "headline")
 for k, v in d.get("secondary", {}).items():
     if "error" in v:
         print(k, "ERROR", v["error"])
+    elif "ms_per_step" not in v:                  # the loader-batch cycle leg
+        print(f"{k}: steady {v['steady_state_ms_per_step']:.3f} ms/step, known class {v['amortised_ms_per_step_known_class']:.3f} "
+              f"({v['amortised_over_steady_known_class']:.3f} x), arena load {v['arena_load_ms']:.2f} ms, capture {v['capture_ms']:.1f} ms, "
+              f"capture per batch {v['recapture_every_batch']['amortised_over_steady']:.3f} x")
     else:
         brief(v, k)
 if len(sys.argv) > 2:
