@@ -422,7 +422,12 @@ struct LspeBwdSrc {
   int64_t N; int D; const uint64_t* seed_off;
 };
 
-template <int T>
+// T lanes per node, RR float4 chunks per lane and head: D = 4 T RR.  RR = 1 is the geometry of the other two kernels (T = D / 4);
+// RR > 1 puts MORE NODES IN A WAVE (D = 256 on 32- or 16-lane teams, D = 128 on 16-lane teams): this kernel is the one bound by
+// its per-node chain - out-list row -> 24 scattered attention / g_e words by CSC slot -> neighbour rows - not by bytes (3.4-3.8
+// TB/s against 4.9-5.1 for the dst-major kernels), and a wave hides more of that chain with two or four of them in flight
+// (the step the SpMM kernels took in round 3).  Same arithmetic in the same order per element: results do not depend on RR.
+template <int T, int RR>
 __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
   constexpr bool WAVE = T == 64;
   constexpr int NREG = T >= 32 ? 1 : 2;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
   const int64_t u = xcd_block() * (kBlock / T) + uni<WAVE>((int)(threadIdx.x / T));
   if (u >= a.N) return;
   const int beg = uni<WAVE>(a.out_indptr[u]), end = uni<WAVE>(a.out_indptr[u + 1]), deg = end - beg;
-  const int D = a.D, c0 = lane * 4;
+  const int D = a.D;
   int vv[kMaxFast];
 #pragma unroll
   for (int k = 0; k < kMaxFast; ++k) vv[k] = uni<WAVE>(a.out_nbr8[u * 8 + k]);
@@ -466,52 +471,76 @@ __global__ __launch_bounds__(kBlock) void lspe_bwd_src_kernel(LspeBwdSrc a) {
 #pragma unroll
     for (int k = 0; k < kMaxFast; ++k) w[k][s] = table_get<T, NREG>(wv, s * 8 + k, tbase);
   }
-  float4 acc[kNS];
+  float4 acc[kNS][RR];
 #pragma unroll
-  for (int r = 0; r < kNS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int kGather = 2;
+  for (int r = 0; r < kNS; ++r)
+#pragma unroll
+    for (int c = 0; c < RR; ++c) acc[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int kGather = RR >= 4 ? 1 : 2;             // neighbour rows requested together: 6-12 float4 in flight per lane
 #pragma unroll
   for (int k0 = 0; k0 < kMaxFast; k0 += kGather) {
     if (WAVE ? !(k0 < deg) : !__any(k0 < deg)) break;
-    float4 x[kGather][kNS];
+    float4 x[kGather][kNS][RR];
 #pragma unroll
     for (int q = 0; q < kGather; ++q)
 #pragma unroll
       for (int r = 0; r < kNS; ++r) {
         const GrpS& gr = a.g[r < kHeads0 ? 0 : 1];
-        x[q][r] = ld4(gr.g_pre + (int64_t)vv[k0 + q] * gr.g_pre_ld + (r < kHeads0 ? r * D : 0) + c0);
+        const float* row = gr.g_pre + (int64_t)vv[k0 + q] * gr.g_pre_ld + (r < kHeads0 ? r * D : 0);
+#pragma unroll
+        for (int c = 0; c < RR; ++c) x[q][r][c] = ld4(row + (c * T + lane) * 4);
       }
 #pragma unroll
     for (int q = 0; q < kGather; ++q)
 #pragma unroll
-      for (int r = 0; r < kNS; ++r) fma4(acc[r], w[k0 + q][r], x[q][r]);
+      for (int r = 0; r < kNS; ++r)
+#pragma unroll
+        for (int c = 0; c < RR; ++c) fma4(acc[r][c], w[k0 + q][r], x[q][r][c]);
   }
   // score term (el / er are taken FROM ft, DGL's own form): g_ft[u, h, :] += g_el[u, h] attn_l[h, :] + g_er[u, h] attn_r[h, :]
 #pragma unroll
   for (int r = 0; r < kNS; ++r) {
     const GrpS& gr = a.g[r < kHeads0 ? 0 : 1];
     const int hl = r < kHeads0 ? r : r - kHeads0;
-    const int cg = hl * D + c0;
     const float ger = gr.g_er[u * gr.gs_ld + hl];
-    fma4(acc[r], gel[r], ld4(gr.sc_l + cg));
-    fma4(acc[r], ger, ld4(gr.sc_r + cg));
-    st4(gr.g_ft + u * gr.g_ft_ld + cg, acc[r]);
+#pragma unroll
+    for (int c = 0; c < RR; ++c) {
+      const int cg = hl * D + (c * T + lane) * 4;
+      fma4(acc[r][c], gel[r], ld4(gr.sc_l + cg));
+      fma4(acc[r][c], ger, ld4(gr.sc_r + cg));
+      st4(gr.g_ft + u * gr.g_ft_ld + cg, acc[r][c]);
+    }
     if (lane == 0) gr.g_el[u * gr.gs_ld + hl] = gel[r];
   }
   if (a.g[0].absmax) {
     float mx = 0.f;
 #pragma unroll
-    for (int r = 0; r < kHeads0; ++r) mx = absmax4(mx, acc[r]);
+    for (int r = 0; r < kHeads0; ++r)
+#pragma unroll
+      for (int c = 0; c < RR; ++c) mx = absmax4(mx, acc[r][c]);
     mx = team_max(mx, T);
     if (lane == 0) spgnn_detail::slots_max(a.g[0].absmax, mx, (unsigned)u);
   }
   if (a.g[1].absmax) {
     float mx = 0.f;
 #pragma unroll
-    for (int r = kHeads0; r < kNS; ++r) mx = absmax4(mx, acc[r]);
+    for (int r = kHeads0; r < kNS; ++r)
+#pragma unroll
+      for (int c = 0; c < RR; ++c) mx = absmax4(mx, acc[r][c]);
     mx = team_max(mx, T);
     if (lane == 0) spgnn_detail::slots_max(a.g[1].absmax, mx, (unsigned)u);
   }
+}
+
+// src-major geometry: 16-lane teams for every level width (four nodes per wave), RR = D / 64 chunks per lane and head.  Measured as
+// three libraries in one process (tools/step_ab.py; T = D / 4 as the other two kernels | D = 256 on 32 lanes, 128 on 16 | both on 16):
+// 5.164 | 5.173 | 5.144 ms per step at 512 trees, 1.078 | 1.077 | 1.071 at 64.
+int launch_lspe_bwd_src(const LspeBwdSrc& a, int D, hipStream_t st) {
+  const dim3 grid(grid_for(a.N, kBlock / 16)), block(kBlock);
+  if (D == 256) hipLaunchKernelGGL((lspe_bwd_src_kernel<16, 4>), grid, block, 0, st, a);
+  else if (D == 128) hipLaunchKernelGGL((lspe_bwd_src_kernel<16, 2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((lspe_bwd_src_kernel<16, 1>), grid, block, 0, st, a);
+  return check_launch("spgnn_lspe_bwd_src");
 }
 
 bool lspe_geometry(int32_t D, int& T) {
@@ -644,8 +673,7 @@ int spgnn_lspe_bwd_src(const int32_t* out_indptr, const int32_t* out_nbr8, const
                   s.absmax, s.H, s.p_drop, 1.f / (1.f - s.p_drop), s.seed};
   }
   a.N = N; a.D = D; a.seed_off = seed_offset;
-  return launch_lspe(a, T, (hipStream_t)stream, lspe_bwd_src_kernel<16>, lspe_bwd_src_kernel<32>, lspe_bwd_src_kernel<64>,
-                     "spgnn_lspe_bwd_src");
+  return launch_lspe_bwd_src(a, D, (hipStream_t)stream);
 }
 
 }  // extern "C"
