@@ -646,7 +646,6 @@ def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300,
         _, cap = wall(lambda: ts2.capture(g))
         _, rep = wall(lambda: [ts2.replay() for _ in range(inner - ts2.capture_steps)])
         rec.append({"capture_ms": cap, "amortised_ms_per_step": (cap + rep) / inner})
-        ts2._captures.clear()
         del g
     return {"workload": f"{config}, {n_batches} loader batches of {trees} synthetic trees, {inner} optimizer steps on each (reference GCN_STEPS), "
                         f"fp32, dropout on, arena granule {granule} nodes",

@@ -388,16 +388,20 @@ class TrainStep:
         finally:
             ops.CAPTURE_REFS = prev_refs
         self._captured_graph = g                    # the node data and index arrays the graphs read
-        self._captures[id(g)] = {"graph": g, "front": self._graph, "back": self._graph_back, "loss": self._static_loss,
-                                 "refs": self._capture_refs}
+        # kept per ARENA graph (a handful of size classes, each reused by every later batch of its class); a capture on an ordinary
+        # graph replaces the previous such capture - the r3 pattern "capture every loader batch" must not pile up graphs and their
+        # private memory pools
+        key = id(g) if getattr(g, "_stable_storage", False) else "adhoc"
+        self._captures[key] = {"graph": g, "front": self._graph, "back": self._graph_back, "loss": self._static_loss,
+                               "refs": self._capture_refs}
         self.capture_steps = max(warmup, 1)        # optimizer steps the warm-up took on ``g`` (they count towards GCN_STEPS)
         return self
 
     def select(self, g) -> bool:
         """Make the capture recorded on graph ``g`` the one :meth:`replay` runs (a step object holds one capture per batch
         arena).  -> whether there is one."""
-        rec = self._captures.get(id(g))
-        if rec is None:
+        rec = self._captures.get(id(g) if getattr(g, "_stable_storage", False) else "adhoc")
+        if rec is None or rec["graph"] is not g:
             return False
         self._graph, self._graph_back, self._static_loss, self._capture_refs = rec["front"], rec["back"], rec["loss"], rec["refs"]
         self._captured_graph = g
