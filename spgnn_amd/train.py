@@ -159,6 +159,7 @@ class TrainStep:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._captures, self._arenas = {}, {}       # id(graph) -> its two HIP graphs; size class -> arena.BatchArena
+        self.max_arenas = 8                         # size classes kept (buffers + captured graphs each); beyond: least recently used out
         self._graph = None
         self._lr_dev = None
         self._one = self._loss_out = None
@@ -419,9 +420,14 @@ class TrainStep:
         use - and padded to the class (spgnn_amd/arena.py).  -> the arena's graph, the object to capture / replay on."""
         from .arena import BatchArena
         key = BatchArena.class_key(g, granule)
-        arena = self._arenas.get(key)
+        arena = self._arenas.pop(key, None)
         if arena is None:
-            arena = self._arenas[key] = BatchArena(g, granule)
+            while len(self._arenas) >= self.max_arenas:          # least recently used class goes, with its capture
+                _, old = next(iter(self._arenas.items()))
+                self._captures.pop(id(old.graph), None)
+                del self._arenas[next(iter(self._arenas))]
+            arena = BatchArena(g, granule)
+        self._arenas[key] = arena                                # re-inserted last: dict order is the recency order
         return arena.load(g)
 
     def run_batch(self, g, steps: int, granule: int = 256) -> torch.Tensor:
