@@ -146,4 +146,9 @@ def test_batch_cycle_with_dropout_and_two_size_classes():
     ts.run_batch(g3, 3, granule=1024)
     assert torch.equal(before[:ts.bucket.numel] + 0, ts.bucket.flat_param[:ts.bucket.numel]) or \
         rel_err(ts.bucket.flat_param[:ts.bucket.numel], before[:ts.bucket.numel]) < 1e-7   # momentum tail with lr 0 moves nothing
+    ts.max_arenas = 1                                                                       # LRU over size classes: a NEW class evicts the others
+    g4 = synthetic.make_batch(5, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ts.run_batch(g4, 4, granule=1024)
+    assert len(ts._arenas) == 1 and len(ts._captures) == 1
+    assert np.isfinite(float(ts.run_batch(g1, 4, granule=1024)))                           # its class is simply built again
     ops.DROPOUT_SEED_OFFSET = None
