@@ -69,8 +69,9 @@ def _build(name, seed=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_gat_3"])
-def test_two_batches_through_one_captured_step_equal_eager_runs(name):
+@pytest.mark.parametrize("name,bf16", [("st_pgat_spgnn_3", False), ("st_gat_3", False), ("st_gcn_3", False), ("st_gin_3", False),
+                                       ("st_sage_3", False), ("st_gat_6", True)])
+def test_two_batches_through_one_captured_step_equal_eager_runs(name, bf16):
     """batch A is captured (3 warm-up steps + capture), batch B - other trees, other N and E, same size
     class - is a copy into the arena plus replays of the SAME two HIP graphs.  Parameters after 4 + 4 steps equal (i) eager
     steps on the same padded graphs (separate arena objects, separate storage; same arithmetic: 1e-6) and (ii) eager steps
@@ -79,22 +80,25 @@ def test_two_batches_through_one_captured_step_equal_eager_runs(name):
     from spgnn_amd.arena import BatchArena
     from spgnn_amd.configs import class_weight_list
     from spgnn_amd.train import TrainStep
+    from spgnn_amd import models as _models
     cfg, model = _build(name, seed=5)
+    if bf16:
+        _models.set_storage_dtype(model, torch.bfloat16)
     model.eval()                                                       # deterministic arithmetic (no dropout masks)
     w = class_weight_list(cfg.CLASS_WEIGHTS)
-    ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
-    gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
     assert ga.number_of_nodes() != gb.number_of_nodes()
     GRAN = 2048                                                        # both batches (~900 nodes) in one class
     assert BatchArena.class_key(ga, GRAN) == BatchArena.class_key(gb, GRAN)
     m_pad, m_raw = copy.deepcopy(model), copy.deepcopy(model)
-    ts = TrainStep(model, w, 1.0, 1e-2, 0.9)                           # sampling rate 1: the mask does not depend on the RNG
+    ts = TrainStep(model, w, 1.0, 1e-3, 0.9)                           # sampling rate 1: the mask does not depend on the RNG
     la = ts.run_batch(ga, 4, granule=GRAN)
     lb = ts.run_batch(gb, 4, granule=GRAN)
     assert len(ts._captures) == 1 and len(ts._arenas) == 1 and next(iter(ts._arenas.values())).loads == 2
     n = ts.bucket.numel
     # (i) eager on the same padded graphs
-    ts_p = TrainStep(m_pad, w, 1.0, 1e-2, 0.9)
+    ts_p = TrainStep(m_pad, w, 1.0, 1e-3, 0.9)
     pa, pb = BatchArena(ga, GRAN).load(ga), BatchArena(gb, GRAN).load(gb)
     for _ in range(4):
         lpa = ts_p.step(pa)
@@ -103,18 +107,21 @@ def test_two_batches_through_one_captured_step_equal_eager_runs(name):
     assert rel_err(la, lpa) < 1e-6 and rel_err(lb, lpb) < 1e-6
     assert rel_err(ts.bucket.flat_param[:n], ts_p.bucket.flat_param[:n]) < 1e-6
     # (ii) eager on the unpadded batches
-    ts_r = TrainStep(m_raw, w, 1.0, 1e-2, 0.9)
+    ts_r = TrainStep(m_raw, w, 1.0, 1e-3, 0.9)
     for _ in range(4):
         lra = ts_r.step(ga)
     for _ in range(4):
         lrb = ts_r.step(gb)
-    assert rel_err(la, lra) < 1e-5 and rel_err(lb, lrb) < 1e-5
-    assert rel_err(ts.bucket.flat_param[:n], ts_r.bucket.flat_param[:n]) < 1e-5
+    # (bf16 rows: an fp32 summation-order change can move a stored value across a rounding boundary - 2^-8 relative; SAGE's
+    # max-pool routing can flip on near-ties: both looser, as in tests/test_hip_bf16.py / test_hip_models.py)
+    tol = 2e-2 if bf16 else 5e-3 if cfg.KIND == "sage" else 1e-5
+    assert rel_err(la, lra) < tol and rel_err(lb, lrb) < tol
+    assert rel_err(ts.bucket.flat_param[:n], ts_r.bucket.flat_param[:n]) < tol
     # the arena's real rows give the unpadded forward; pad rows never reach the loss
     ag = ts.arena_graph(gb, GRAN)
     with torch.no_grad():
         lo_pad, lo_raw = model(ag)[0], model(gb)[0]
-    assert rel_err(lo_pad[:gb.number_of_nodes()], lo_raw) < 1e-6
+    assert rel_err(lo_pad[:gb.number_of_nodes()], lo_raw) < (2e-2 if bf16 else 1e-6 if cfg.KIND != "sage" else 1e-5)
     p = ts._sampling(ag)
     assert bool((p[gb.number_of_nodes():] == -1).all()) and bool((p[:gb.number_of_nodes()] == 1).all())
     ops.DROPOUT_SEED_OFFSET = None
