@@ -159,3 +159,34 @@ def test_batch_cycle_with_dropout_and_two_size_classes():
     assert len(ts._arenas) == 1 and len(ts._captures) == 1
     assert np.isfinite(float(ts.run_batch(g1, 4, granule=1024)))                           # its class is simply built again
     ops.DROPOUT_SEED_OFFSET = None
+
+
+@pytest.mark.gpu
+def test_random_batch_sequence_through_arenas_tracks_unpadded_training():
+    """Twenty loader batches of random tree counts and sizes through run_batch (size classes come and go under a small LRU,
+    captures are reused and rebuilt) against plain eager steps on the unpadded batches: the same training trajectory."""
+    from spgnn_amd import ops, synthetic
+    from spgnn_amd.configs import class_weight_list
+    from spgnn_amd.train import TrainStep
+    cfg, model = _build("st_pgat_spgnn_3", seed=21)
+    model.eval()
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ref = copy.deepcopy(model)
+    ts, ts_ref = TrainStep(model, w, 1.0, 1e-3, 0.9), TrainStep(ref, w, 1.0, 1e-3, 0.9)
+    ts.max_arenas = 3
+    rng = np.random.default_rng(5)
+    classes = set()
+    for b in range(20):
+        trees = int(rng.integers(2, 6))
+        samples = synthetic.synthetic_trees(trees, rank=50 + b, n_lo=40, n_hi=90)
+        g = synthetic.batch_from_samples(samples, "cuda", cfg.POS_ENC_DIM)
+        steps = int(rng.integers(4, 7))
+        la = ts.run_batch(g, steps, granule=128)
+        for _ in range(steps):
+            lr_ = ts_ref.step(g)
+        classes.add((g.batch_size, (g.number_of_nodes() // 128 + 1) * 128))
+        assert rel_err(la, lr_) < 1e-4, (b, float(la), float(lr_))
+    n = ts.bucket.numel
+    assert len(classes) > 3 and len(ts._arenas) <= 3
+    assert rel_err(ts.bucket.flat_param[:n], ts_ref.bucket.flat_param[:n]) < 1e-5
+    ops.DROPOUT_SEED_OFFSET = None
