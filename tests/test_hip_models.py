@@ -585,6 +585,52 @@ def test_two_rank_graph_replay_equals_two_rank_eager():
     assert torch.equal(ret[0]["graph"][1], ret[1]["graph"][1])      # replicas stay identical
 
 
+def _dp_cycle_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from spgnn_amd import models, synthetic
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_config("st_gat_3")
+    out = {}
+    for mode in ("eager", "cycle"):
+        torch.manual_seed(0)
+        model = models.build_model(cfg.MODEL).cuda()
+        model.init(None); model.set_gcn_only(); model.eval()
+        ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), 1.0, 0.02, 0.9, seed=5)
+        losses = []
+        for b in range(3):                                            # three loader batches; rank 1's are larger (other size classes)
+            g = synthetic.make_batch(3 + rank + (b % 2), rank=10 * b + rank, device="cuda", pos_enc_dim=None)
+            if mode == "eager":
+                for _ in range(4):
+                    l = ts.step(g)
+            else:
+                l = ts.run_batch(g, 4, granule=512)                   # the first batch of a class: 3 warm-up steps + 1 replay
+            losses.append(float(l))
+        out[mode] = (losses, ts.bucket.flat_param[:ts.bucket.numel].detach().cpu().clone(), len(ts._captures))
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_two_rank_loader_batch_cycle_equals_two_rank_eager():
+    """The loader-batch cycle with world_size 2 (gloo on the one GPU): every rank pads its own batches into its own size classes
+    and captures when IT meets a new class - a rank replaying while its peer is warming up still issues exactly one all-reduce
+    per step, so the collectives line up; losses and parameters follow the eager 2-rank run and the replicas stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_cycle_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        le, pe, _ = ret[r]["eager"]
+        lc, pc, ncap = ret[r]["cycle"]
+        assert ncap >= 1 and all(np.isfinite(le)) and all(np.isfinite(lc))
+        assert np.allclose(le, lc, rtol=1e-4), (le, lc)
+        assert rel_err(pc, pe) < 1e-4                                 # normwise: padding moves fp32 summation order (tests/test_arena.py)
+    assert torch.equal(ret[0]["cycle"][1], ret[1]["cycle"][1])
+
+
 def test_sage_feature_dropout_in_the_previous_layers_epilogue(monkeypatch):
     """SAGE in training mode: layer l + 1's feature dropout applied by layer l's last product (models.FUSE_SAGE_DROP) - same
     seeds, same masks: logits equal the layer-by-layer form bit for bit, gradients to the rounding of ELU's recovered value."""
