@@ -423,7 +423,9 @@ int spgnn_spmm_max_bwd_u8_relu(const int32_t* indptr, const int32_t* out_indptr,
  * {-256, 0, 0, 0, m_1 ... m_256}: 256 "slots" of maxima which the kernels that PRODUCE the operand fold their rows'
  * largest magnitudes into (their `absmax` arguments; one result-free atomicMax per node team - max is order-independent,
  * so the scale is deterministic); the GEMM derives s = 2^(14 - e), max_i m_i <= 2^e, itself.  The slots must be zero
- * before the first producer runs.  This replaces one reduction launch per operand and step.
+ * before the first producer runs.  This replaces one reduction launch per operand and step.  Header word 1 of a slot block is an
+ * OUTPUT of the consuming product: it is set to 1 when a non-zero slot lies more than 2^18 below the largest one (the range monitor,
+ * see spgnn_step_begin) - the pointers are `const` because the scale itself is read-only, the flag word is not.
  * A and B rows must be 16-byte aligned (lda, ldb multiples of 4); K may be ragged.
  * Optional exact fp32 rank-J update fused into the epilogue: C += U[M,J] * V[J,N] (upd_j <= 32; V rows
  * 16-byte aligned and zero padded to a multiple of 4 columns; upd_j = 0 disables it).  The layer uses it for
