@@ -635,6 +635,10 @@ def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300,
                           "amortised_ms_per_step": (load + cap + rep) / inner,
                           "amortised_incl_assemble_ms_per_step": (asm + load + cap + rep) / inner})
         del g
+    # the whole loop as a training job runs it (TrainStep.run_batches): the assembly of batch i + 1 on a side stream under
+    # the replays of batch i.  Same batches again - their classes are known now - one wall clock around everything.
+    _, pipe = wall(lambda: ts.run_batches(batches, inner, lambda s_: data.assemble_batch(s_, dev, cfg.POS_ENC_DIM), granule))
+    pipelined = pipe / (inner * len(batches))
     hits = [q for q in per_batch if not q["new_class"]]
     miss = [q for q in per_batch if q["new_class"]]
     mean = lambda xs: sum(xs) / len(xs) if xs else None
@@ -653,6 +657,10 @@ def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300,
             "amortised_ms_per_step_known_class": mean([q["amortised_ms_per_step"] for q in hits]),
             "amortised_ms_per_step_new_class": mean([q["amortised_ms_per_step"] for q in miss]),
             "amortised_over_steady_known_class": (mean([q["amortised_ms_per_step"] for q in hits]) / steady) if hits else None,
+            "amortised_incl_assemble_ms_per_step_known_class": mean([q["amortised_incl_assemble_ms_per_step"] for q in hits]),
+            "pipelined_loop": {"what": "TrainStep.run_batches over the same batches (classes known): assembly of batch i+1 under the "
+                                       "replays of batch i; wall time of the whole loop / steps, assembly INCLUDED",
+                               "ms_per_step": pipelined, "over_steady": pipelined / steady},
             "assemble_ms": mean([q["assemble_ms"] for q in per_batch]), "arena_load_ms": mean([q["arena_load_ms"] for q in per_batch]),
             "capture_ms": mean([q["capture_ms"] for q in miss]),
             "recapture_every_batch": {"capture_ms": mean([q["capture_ms"] for q in rec]),

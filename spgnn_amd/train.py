@@ -430,9 +430,45 @@ class TrainStep:
         self._arenas[key] = arena                                # re-inserted last: dict order is the recency order
         return arena.load(g)
 
-    def run_batch(self, g, steps: int, granule: int = 256) -> torch.Tensor:
-        """``steps`` optimizer steps on loader batch ``g`` as HIP-graph replays: the first batch of a size class pays the
-        warm-up steps and the capture, every later one only the copies into the arena.  -> the last step's loss (device)."""
+    def run_batches(self, batches, steps: int, assemble, granule: int = 256):
+        """The whole loader loop of job_runner.py:1870-1920: for every host batch ``b`` of ``batches`` - ``g = assemble(b)`` (e.g.
+        ``lambda b: data.assemble_batch(b, "cuda", POS_ENC_DIM)``), then ``steps`` optimizer steps on it - with the assembly of
+        batch i + 1 (pinned packing, uploads, device CSC, anchors, distance encoding: ~8 ms at 64 trees) issued on a side stream
+        right after batch i's replays were queued, so it runs UNDER them; between two batches only the arena load (~1 ms) is
+        left.  Same arithmetic as ``run_batch`` per batch.  -> the last-step losses (device scalars cloned per batch)."""
+        dev = self.bucket.flat_param.device
+        if dev.type != "cuda":
+            raise RuntimeError("run_batches replays captured HIP graphs: it needs a ROCm device")
+        main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+        it = iter(batches)
+
+        def stage(b, after):
+            if after is not None:
+                side.wait_event(after)           # the previous staged batch was copied into its arena: its blocks may be reused
+            with torch.cuda.stream(side):
+                g = assemble(b)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return g, ev
+
+        losses, loaded = [], None
+        first = next(it, None)
+        nxt = stage(first, None) if first is not None else None
+        while nxt is not None:
+            g, ready = nxt
+            main.wait_event(ready)
+            self._range_policy_check()
+            ag = self.arena_graph(g, granule)    # copies on the main stream, ordered after the assembly
+            loaded = torch.cuda.Event()
+            loaded.record(main)
+            del g
+            loss = self._replays_on(ag, steps)   # queued, not waited for
+            b = next(it, None)
+            nxt = stage(b, loaded) if b is not None else None      # ... and the next assembly runs under them
+            losses.append(loss.clone())
+        return losses
+
+    def _range_policy_check(self) -> None:
         if self.range_policy == "auto" and not ops.GEMM_WIDE and self.bucket.flat_param.is_cuda:
             v = self.range_violations()              # one 4-byte read per loader batch (the flags of the previous batch's steps)
             if self._violations_seen is not None and v > self._violations_seen:
@@ -440,7 +476,8 @@ class TrainStep:
                 self._captures.clear()
                 self._graph = self._graph_back = None
             self._violations_seen = v
-        ag = self.arena_graph(g, granule)
+
+    def _replays_on(self, ag, steps: int) -> torch.Tensor:
         done = 0
         if not self.select(ag):
             self.capture(ag)
@@ -449,3 +486,9 @@ class TrainStep:
         for _ in range(max(steps - done, 0)):
             loss = self.replay()
         return loss
+
+    def run_batch(self, g, steps: int, granule: int = 256) -> torch.Tensor:
+        """``steps`` optimizer steps on loader batch ``g`` as HIP-graph replays: the first batch of a size class pays the
+        warm-up steps and the capture, every later one only the copies into the arena.  -> the last step's loss (device)."""
+        self._range_policy_check()
+        return self._replays_on(self.arena_graph(g, granule), steps)

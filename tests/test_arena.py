@@ -190,3 +190,32 @@ def test_random_batch_sequence_through_arenas_tracks_unpadded_training():
     assert len(classes) > 3 and len(ts._arenas) <= 3
     assert rel_err(ts.bucket.flat_param[:n], ts_ref.bucket.flat_param[:n]) < 1e-5
     ops.DROPOUT_SEED_OFFSET = None
+
+
+@pytest.mark.gpu
+def test_run_batches_prefetches_the_next_assembly_and_equals_run_batch():
+    """The whole loader loop (TrainStep.run_batches: batch i + 1 assembled on a side stream under batch i's replays) gives
+    the parameters of the same batches through run_batch one after the other - the side stream moves WHEN the assembly runs, never
+    what it computes - also when the staged blocks are reused by the next assembly."""
+    from spgnn_amd import data, ops, synthetic
+    from spgnn_amd.configs import class_weight_list
+    from spgnn_amd.train import TrainStep
+    cfg, model = _build("st_pgat_spgnn_3", seed=8)
+    model.train()
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ref = copy.deepcopy(model)
+    batches = [synthetic.synthetic_trees(5, rank=70 + b, n_lo=60, n_hi=120) for b in range(7)]
+    asm = lambda s_: data.assemble_batch(s_, "cuda", cfg.POS_ENC_DIM)
+    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=4)
+    torch.manual_seed(77)                                              # the dropout seeds a capture bakes in are host draws
+    losses = ts.run_batches(batches, 6, asm, granule=1024)
+    ts_ref = TrainStep(ref, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=4)
+    torch.manual_seed(77)
+    losses_ref = [ts_ref.run_batch(asm(b), 6, granule=1024).clone() for b in batches]
+    torch.cuda.synchronize()
+    errs = [rel_err(a, b) for a, b in zip(losses, losses_ref)]
+    n = ts.bucket.numel
+    assert len(losses) == 7 and max(errs) < 1e-6, errs                 # (atomic float adds in the backward: not bit for bit)
+    assert rel_err(ts.bucket.flat_param[:n], ts_ref.bucket.flat_param[:n]) < 1e-6
+    assert ts.run_batches([], 3, asm) == []
+    ops.DROPOUT_SEED_OFFSET = None
