@@ -766,6 +766,7 @@ def main():
                 out["config"]["batch_cycle_64"] = {k: (round(bc[k], 4) if isinstance(bc[k], float) else bc[k]) for k in
                                                    ("steady_state_ms_per_step", "amortised_ms_per_step_known_class", "amortised_over_steady_known_class",
                                                     "assemble_ms", "arena_load_ms", "capture_ms", "classes_captured")}
+                out["config"]["batch_cycle_64"]["whole_loop_incl_assembly_over_steady"] = round(bc["pipelined_loop"]["over_steady"], 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
