@@ -78,6 +78,24 @@ def test_logits_loss_and_gradients_match_the_oracle_at_64_trees(name):
     print(f"{name} 64 trees: worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
 
 
+@pytest.mark.parametrize("name", ["st_gcn_3", "st_gin_3", "st_sage_3", "st_pgat_spgnnnl_3", "st_gat_6", "st_gat_1"])
+def test_every_other_head_matches_the_oracle_at_64_trees(name):
+    """The remaining model families of north_star (GCN / GIN / SAGE, the PENL ablation, the deep and the one-layer GAT) at the
+    reference's TRAIN_BATCH_SIZE: every output of the head against the fp32 oracle, normwise and elementwise."""
+    cfg, model = _build(name, seed=13)
+    g = synthetic.make_batch(64, rank=1, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    assert g.number_of_nodes() > 9000
+    with torch.no_grad():
+        outs = model(g)
+        refs, _ = _oracle(cfg, model, g)
+    outs = outs if isinstance(outs, (tuple, list)) else (outs,)
+    refs = refs if isinstance(refs, (tuple, list)) else (refs,)
+    for o, r in zip(outs, refs):
+        e_n, e_m = rel_err(o, r), mixed_err(o, r)
+        print(f"{name} 64 trees {tuple(o.shape)}: normwise {e_n:.2e}, elementwise mixed {e_m:.2e}")
+        assert o.shape == r.shape and e_n < TOL and e_m < 2 * TOL
+
+
 @pytest.mark.parametrize("name", ["st_pgat_spgnn_3", "st_gat_6"])
 def test_logits_match_the_oracle_at_512_trees(name):
     cfg, model = _build(name, seed=12)
