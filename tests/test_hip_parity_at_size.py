@@ -39,10 +39,10 @@ def _oracle(cfg, model, g, dtype=torch.float32, grad=False):
     return O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu().to(dtype), pe), sd
 
 
-@pytest.mark.parametrize("name", ["st_gat_3", "st_pgat_spgnn_3"])
+@pytest.mark.parametrize("name", ["st_gat_3", "st_pgat_spgnn_3", "st_gcn_3", "st_gin_3"])
 def test_logits_loss_and_gradients_match_the_oracle_at_64_trees(name):
     cfg, model = _build(name, seed=11)
-    g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
     assert g.number_of_nodes() > 9000
     w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
     y = g.ndata["y"]
@@ -63,7 +63,14 @@ def test_logits_loss_and_gradients_match_the_oracle_at_64_trees(name):
         assert e_n < TOL and e_m < TOL
         assert rel_err(o, r64) < TOL
     assert rel_err(loss, ref_loss) < TOL
-    # every parameter gradient (rule of test_hip_models.test_config_loss_gradients_match_oracle)
+    # every parameter gradient (rule of test_hip_models.test_config_loss_gradients_match_oracle).  GIN's LeakyReLU has a
+    # derivative JUMP at zero: among the 2.5 M hidden units of a 64-tree batch one or two lie within 1e-8 of it (measured,
+    # MI355X, this seed: |pre| = 7.9e-10 and 1.6e-8), any fp32 evaluation in another summation order puts them on the other
+    # branch, and each such unit moves the gradients behind it by up to a few 1e-3 of their maximum (tools/gin_flip_check.py
+    # shows the unit; with the products' wide-range form, which happens to keep both units' signs, every gradient is within
+    # 8e-6).  That is conditioning of the comparison, not of the kernels - the forward outputs above hold 1e-5 - so GIN's
+    # gradients are bounded at 1e-2 here; the smooth (ELU) heads and GCN hold 1e-4.
+    gtol = 1e-2 if name == "st_gin_3" else 1e-4
     gmax = max(float(v.grad.abs().max()) for v in sd64.values() if v.grad is not None)
     worst = 0.0
     for n, p in model.named_parameters():
@@ -72,7 +79,7 @@ def test_logits_loss_and_gradients_match_the_oracle_at_64_trees(name):
         assert p.grad is not None and sd[n].grad is not None, n
         e32 = rel_err(p.grad, sd[n].grad)
         tiny = (p.grad.cpu().double() - sd64[n].grad).abs().max() < 1e-7 * gmax
-        ok = e32 < 1e-4 or tiny or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6
+        ok = e32 < gtol or tiny or rel_err(p.grad, sd64[n].grad) < 5 * rel_err(sd[n].grad, sd64[n].grad) + 1e-6
         worst = max(worst, 0.0 if tiny else e32)
         assert ok, (n, e32, rel_err(p.grad, sd64[n].grad), rel_err(sd[n].grad, sd64[n].grad))
     print(f"{name} 64 trees: worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
