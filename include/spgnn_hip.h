@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 52
+#define SPGNN_ABI_VERSION 53
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -1011,8 +1011,9 @@ int spgnn_linear_mean_fold_bwd(const float* M1, int64_t M1_stride, const float* 
                                int32_t J, float* g_w_fc, int64_t g_w_fc_stride, float* g_w_res, int64_t g_w_res_stride, float* g_bias,
                                float* g_w_cls, int64_t g_w_cls_stride, int32_t x_block, spgnn_stream_t stream);
 
-/* Up to 8 of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two attention-vector
- * gradients come out of four spgnn_gemm_tn / spgnn_scores_bwd_w calls whose partial sums were four more launches).  `jobs`
+/* Up to 24 (8 before ABI 53) of the deterministic split-K reductions above in ONE launch (a level's two weight gradients and two
+ * attention-vector gradients come out of four spgnn_gemm_tn / spgnn_scores_bwd_w calls whose partial sums were four more launches;
+ * a training step queues the reductions of its whole backward pass - nothing in it reads a weight gradient - and issues one).  `jobs`
  * is a HOST array; kind 0 = spgnn_sum_partials (n, out), 1 = spgnn_sum_partials_blockdiag (H, D, ld, out), 2 =
  * spgnn_sum_partials_compact (M, N, ld_in, out / out_stride, out2 / out2_stride / split_col, extra / extra_col); the fields
  * have the meaning of the same-named arguments there and results are bit-identical to the single calls. */

@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256) void sum_partials_compact_kernel(const float* 
 }
 
 // several reductions of the three kinds above in ONE launch (spgnn_sum_partials_multi): the job is found from the block index
-constexpr int kMaxSumJobs = 8;
+constexpr int kMaxSumJobs = 24;          // 24 x 112 bytes of jobs + offsets: 2.8 KB of kernel arguments
 struct SumJobs { spgnn_sum_job j[kMaxSumJobs]; unsigned first[kMaxSumJobs + 1]; int n; };
 __global__ __launch_bounds__(256) void sum_jobs_kernel(SumJobs a) {
   __shared__ float4 red[256];

@@ -251,18 +251,34 @@ _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-bloc
 _TN_MIN_ELEMS = 16384   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
 
 
+DEFER_STEP_SUMS = True   # inside a training step, every split-K reduction of the backward pass waits for ONE launch after it
+STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep while it issues a step's forward and backward
+
+
 class SumJobs:
     """Deferred split-K reductions: gemm_tn / scores_bwd_w append their partial-sum step here instead of launching it, and
-    ``flush()`` runs up to eight of them in ONE launch (spgnn_sum_partials_multi; bit-identical to the single launches).
-    The outputs the producers returned are filled by the flush."""
+    ``flush()`` runs up to ``MAX`` of them in ONE launch (spgnn_sum_partials_multi; bit-identical to the single launches).
+    The outputs the producers returned are filled by the flush.  While a training step has installed its own queue
+    (``STEP_SUMS``) the jobs go there instead and ``flush()`` does nothing: nothing inside a backward pass reads a weight
+    gradient, so the whole step's reductions run as one launch after it (five launches of 11-18 us before)."""
 
-    def __init__(self, device):
+    MAX = 24                                     # spgnn_sum_partials_multi's limit (kMaxSumJobs)
+
+    def __init__(self, device, local: bool = False):
+        """``local``: these outputs are read again inside the backward pass - they feed another autograd node that computes
+        with them (the folded score weights' gradient, which fold_scores' backward consumes), or they are one of TWO gradients of
+        a parameter, which autograd adds on arrival: never handed to the step."""
         self.device, self.jobs, self.keep = device, [], []
+        q = STEP_SUMS
+        self.step = q if (q is not None and not local and DEFER_STEP_SUMS and q.device == torch.device(device)) else None
 
     def add(self, job, *tensors):
+        if self.step is not None:
+            self.step.add(job, *tensors)
+            return
         self.jobs.append(job)
         self.keep.extend(tensors)
-        if len(self.jobs) == 8:
+        if len(self.jobs) == self.MAX:
             self.flush()
 
     def flush(self):
@@ -273,6 +289,31 @@ class SumJobs:
             _capi.check(_capi.load().spgnn_sum_partials_multi(arr, len(self.jobs), torch.cuda.current_stream(self.device).cuda_stream),
                         "spgnn_sum_partials_multi")
         self.jobs, self.keep = [], []
+
+
+class StepSums:
+    """The reductions of one training step's backward pass (see SumJobs).  The partials and outputs are held through
+    ``detach()`` aliases: they keep the storage alive without adding a reference to the tensors themselves - autograd takes a
+    gradient over as it is only while it holds the last reference to it, and clones it otherwise, which here would copy an
+    output the flush has not filled yet."""
+
+    def __init__(self, device):
+        self.device, self.jobs, self.keep = torch.device(device), [], []
+
+    def add(self, job, *tensors):
+        self.jobs.append(job)
+        self.keep.extend(t.detach() for t in tensors if t is not None)
+
+    def flush(self):
+        jobs, keep = self.jobs, self.keep
+        self.jobs, self.keep = [], []
+        for i0 in range(0, len(jobs), SumJobs.MAX):
+            chunk = jobs[i0:i0 + SumJobs.MAX]
+            arr = (_capi.SumJob * len(chunk))(*chunk)
+            with torch.cuda.device(self.device):
+                _capi.check(_capi.load().spgnn_sum_partials_multi(arr, len(chunk), torch.cuda.current_stream(self.device).cuda_stream),
+                            "spgnn_sum_partials_multi")
+        del keep
 
 
 def sum_partials(part: torch.Tensor) -> torch.Tensor:
@@ -2052,7 +2093,9 @@ class _GATAggFirstFn(torch.autograd.Function):
         E = csc.num_edges
         zs = z.shape[1] // H
         g_wcls = g_bcls = None
-        jobs = SumJobs(x.device)                   # every split-K reduction of this node in one launch at the end
+        # every split-K reduction of this node in one launch at the end - its own, not the step's: fc.weight receives a second
+        # gradient through the folded score projection (fold_scores' backward), which autograd ADDS to this one on arrival
+        jobs = SumJobs(x.device, local=True)
         if ctx.has_cls and g_logits is not None:
             cs_ = column_sums(g_logits) if (ctx.has_cls_bias and ctx.needs_input_grad[6]) else None
             g_logits = g_logits.contiguous()

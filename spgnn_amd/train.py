@@ -218,10 +218,13 @@ class TrainStep:
                 draws = torch.rand(p.shape, device=p.device, generator=self.gen)
         # every GATConv's attention-vector gradient pass is collected during backward and issued as ONE launch after it
         queue = ops.AttnGradQueue(b.flat_param.device) if (on_gpu and ops.DEFER_ATTN_GRADS) else None
+        # ... and so are the split-K reductions behind every weight gradient (nothing inside the backward pass reads one)
+        sums = ops.StepSums(b.flat_param.device) if (on_gpu and ops.DEFER_STEP_SUMS) else None
         try:
             if ctr is not None:
                 ops.DROPOUT_SEED_OFFSET = ctr
             ops.ATTN_GRAD_QUEUE = queue
+            ops.STEP_SUMS = sums
             logits = self.model(g)[0]
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
@@ -236,9 +239,12 @@ class TrainStep:
                 num.backward()
             if queue is not None:
                 queue.flush()                # (inside the step's scale-pool window: its partial sums take no block, but stay in order)
+            if sums is not None:
+                sums.flush()                 # the attention queue's reductions included: it found this queue installed
         finally:
             ops.DROPOUT_SEED_OFFSET = prev_off
             ops.ATTN_GRAD_QUEUE = None
+            ops.STEP_SUMS = None
             if pool is not None:
                 pool.end()
         b.gather_grads()

@@ -603,3 +603,36 @@ def test_deferred_partial_sums_equal_single_launches():
     assert not jobs.jobs
     assert torch.equal(w, ref_w) and torch.equal(cs, ref_cs) and torch.equal(p1, o1) and torch.equal(p2, o2)
     assert torch.equal(bd, ref_bd) and torch.equal(pl, ref_pl)
+
+
+@pytest.mark.gpu
+def test_twenty_deferred_partial_sums_in_one_launch():
+    """spgnn_sum_partials_multi takes up to 24 jobs since ABI 53 (a training step queues the reductions of its whole backward
+    pass, ops.StepSums): twenty reductions of all three kinds in one launch equal the single launches bit for bit, and a
+    twenty-fifth is refused by the library."""
+    from spgnn_amd import _capi
+    torch.manual_seed(6)
+    R = 6000
+    refs, outs = [], []
+    jobs = ops.SumJobs(torch.device("cuda", 0), local=True)
+    assert jobs.MAX == 24
+    for i in range(20):
+        if i % 3 == 0:
+            g, x = _mat(R, 128 + 64 * (i % 2), 1e-3), _mat(R, 100 + 4 * i)
+            refs.append(ops.gemm_tn(g, x, want_colsum=True))
+            outs.append(ops.gemm_tn(g, x, want_colsum=True, defer=jobs))
+        elif i % 3 == 1:
+            gs, ft = torch.randn(R, 4, device="cuda"), _mat(R, 128)
+            refs.append(ops.scores_bwd_w(gs, ft, blockdiag_heads=2))
+            outs.append(ops.scores_bwd_w(gs, ft, blockdiag_heads=2, defer=jobs))
+        else:
+            g22, x1 = torch.randn(R, 22, device="cuda"), _mat(R, 256)
+            refs.append(ops.scores_bwd_w(g22, x1))
+            outs.append(ops.scores_bwd_w(g22, x1, defer=jobs))
+    assert len(jobs.jobs) == 20
+    jobs.flush()
+    for r, o in zip(refs, outs):
+        for a, b in zip(r if isinstance(r, tuple) else (r,), o if isinstance(o, tuple) else (o,)):
+            assert torch.equal(a, b)
+    arr = (_capi.SumJob * 25)()
+    assert _capi.load().spgnn_sum_partials_multi(arr, 25, ops._stream(refs[-1])) != 0

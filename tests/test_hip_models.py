@@ -438,6 +438,34 @@ def test_deferred_attention_vector_gradients_are_bit_identical(name, bf16, monke
     _ops.DROPOUT_SEED_OFFSET = None
 
 
+@pytest.mark.parametrize("name,bf16", [("st_pgat_spgnn_3", False), ("st_pgat_spgnnnl_3", False), ("st_gat_3", False), ("st_gat_1", False),
+                                       ("st_gat_6", True), ("st_gcn_3", False), ("st_gin_3", False), ("st_sage_3", False)])
+def test_step_wide_deferred_sums_are_bit_identical(name, bf16, monkeypatch):
+    """ops.StepSums (round 4): inside a training step the split-K reductions behind the weight gradients wait for ONE launch
+    after the backward pass.  That is only sound for outputs nothing reads before then - a gradient that feeds another
+    autograd node, or one of two gradients of the same parameter (the aggregate-first output layer's fc.weight), must stay
+    in its node's own launch (SumJobs(local=True)).  Every model family: the flat gradient bucket with the step-wide queue
+    equals the one without it bit for bit, over two steps (the second starts from parameters the first one moved)."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build(name, seed=9)
+    if bf16:
+        models.set_storage_dtype(model, torch.bfloat16)
+    model.eval()
+    g = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    out = []
+    for defer in (True, False):
+        monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", defer)
+        ts = TrainStep(copy.deepcopy(model), w, 1.0, 1e-3, 0.9)
+        ts.step(g)
+        ts._front(g)
+        out.append((ts.bucket.flat_grad.clone(), ts.bucket.flat_param.clone()))
+        assert _ops.STEP_SUMS is None
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.isfinite(out[0][0]).all() and float(out[0][0].abs().max()) > 0
+    _ops.DROPOUT_SEED_OFFSET = None
+
+
 @pytest.mark.parametrize("N,C", [(1000, 22), (1, 22), (257, 3), (4096, 64)])
 def test_fused_masked_ce_matches_cross_entropy(N, C):
     """spgnn_masked_ce == F.cross_entropy(pre[mask], y[mask], weight=w) (reference job_runner.py:1896-1900): loss
