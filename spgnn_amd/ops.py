@@ -251,6 +251,7 @@ _SCALE_WS: dict = {}     # per (device, stream): two zeroed words the multi-bloc
 _TN_MIN_ELEMS = 16384   # weight gradients smaller than this go to rocBLAS (measured: 65536 -> 16384 moves the position stream's 512 x 39 and 128 x 128 gradients to the split-K kernel with the bias column sums riding along: 6.73 -> 6.67 ms/step)
 
 
+TN_PAIR_SPLITS = True    # a level's two weight-gradient products choose their split count together (tn_pair_splits)
 DEFER_STEP_SUMS = True   # inside a training step, every split-K reduction of the backward pass waits for ONE launch after it
 STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep while it issues a step's forward and backward
 
@@ -1886,6 +1887,10 @@ class _LspeLevelFn(torch.autograd.Function):
         grads_x, grads_w, grads_al, grads_ar, grads_b = [None, None], [None, None], [None, None], [None, None], [None, None]
         jobs = SumJobs(dev)                        # the level's four split-K reductions run as one launch at the end
         tn, nt = [None, None], [None, None]        # the weight-gradient and input-gradient products of both layers: one launch each
+        pair_splits = (None, None)
+        if PAIR_GEMMS and TN_PAIR_SPLITS and all(ctx.needs_input_grad[2 + i] and g_y[i].shape[1] * xs[i].shape[1] >= _TN_MIN_ELEMS for i in range(2)) \
+                and (ctx.x_ps[0] is not None) == (ctx.x_ps[1] is not None):
+            pair_splits = tn_pair_splits(N, (g_y[0].shape[1], xs[0].shape[1]), (g_y[1].shape[1], xs[1].shape[1]), ctx.x_ps[0] is not None)
         for i, H in enumerate(Hs):
             HD = H * D
             x, K = xs[i], xs[i].shape[1]
@@ -1896,7 +1901,7 @@ class _LspeLevelFn(torch.autograd.Function):
                 if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
                     xb = ctx.x_ps[i]
                     tn[i] = TnProblem(g_y[i], xb if xb is not None else x, sg, sx, want_colsum=bool(need_bias and res[i]), defer=jobs,
-                                      b_presplit=xb is not None)
+                                      b_presplit=xb is not None, splits=pair_splits[i])
                 else:
                     grads_w[i] = _dw_gemm(g_y[i], x)
             if ctx.needs_input_grad[i]:
@@ -2855,6 +2860,31 @@ def _tn_splits(tiles: int, R: int, rows: int = 128) -> int:
     if tiles >= 16 and R >= 32 * 512:
         splits = 32 if tiles >= 48 else 21
     return splits
+
+
+def tn_pair_splits(R: int, shape0, shape1, b_presplit: bool = False):
+    """Split counts for two weight-gradient products that will share ONE launch (gemm_tn_pair), or (None, None) to keep each
+    product's own count.  Both run in the first product's tile rows; with each product's own count the pair can spill a few
+    short workgroups into a second round (R = 9 641: 12 x 21 + 2 x 37 = 326 workgroups on 256 slots).  One common count that
+    fits the pair into a single round gives every workgroup the same row range; taken when its range is shorter than the own
+    counts' first-round range plus the spilled one."""
+    if R >= 32 * 512:          # the large-R counts of _tn_splits are measured optima of the pair as it runs (a common count for the
+        return None, None      # 256 x 384 + 128 x 128 pair at R = 76 410 cost the step 1 %)
+    (M0, N0), (M1, N1) = shape0, shape1
+    flags = int(bool(b_presplit)) | (0x10 if TN_TILE == 128 else 0x20 if TN_TILE == 256 else 0) | (0x100 if GEMM_WIDE else 0)
+    lib = _capi.load()
+    rows = int(lib.spgnn_gemm_tn_tile_rows(R, M0, N0, flags))
+    rows1 = int(lib.spgnn_gemm_tn_tile_rows(R, M1, N1, flags))
+    tiles = lambda M, N, r: ((M + r - 1) // r) * ((N + 127) // 128)
+    t0, t1 = tiles(M0, N0, rows), tiles(M1, N1, rows)
+    s0, s1 = _tn_splits(t0, R, rows), _tn_splits(tiles(M1, N1, rows1), R, rows1)
+    slots = 256 if rows == 256 else 512
+    if t0 * s0 + t1 * s1 <= slots:
+        return None, None
+    sj = max(1, min(slots // (t0 + t1), R // 256))
+    if R / sj < R / s0 + R / s1:
+        return sj, sj
+    return None, None
 
 
 class TnProblem:
