@@ -285,7 +285,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     gat_names = tuple(k for k in {k[0] for k in kt_all} if k.startswith(GAT_PREFIXES))
     bracket = [k for k in kt_all if k[0] in roof_names or k[0] in gat_names or k[0] in GEMM_NAMES]
     sync()
-    # Timed region.  Default: every step is a replay of the captured step (two HIP graphs around the gradient
+    # Timed region.  Default: every step is a replay of the captured step (one HIP graph; two around the gradient
     # all-reduce, TrainStep.capture) - eagerly the launches and autograd's host work per step take the host as long as
     # the GPU needs for the kernels, so a slow host core would be what is measured.  --eager times eagerly issued steps.
     launch, capture_error = "eager", None

@@ -1,5 +1,5 @@
 """Batch arenas: loader batches of one size class share ONE set of device buffers, so a training step captured on the
-first batch of the class (train.TrainStep.capture: two HIP graphs) serves every later one - a new batch is a handful of
+first batch of the class (train.TrainStep.capture: one HIP graph, two when ranks exchange) serves every later one - a new batch is a handful of
 device copies into fixed addresses plus ``replay()``, not a warm-up, a capture and an instantiation.
 
 Reference loop being served (job_runner.py:1870-1920, exp_settings/st_pgat_spgnn_3.py:29,34): for every loader batch of

@@ -136,6 +136,9 @@ class FlatBucket:
             p.grad = v
 
 
+ONE_GRAPH_PER_STEP = True    # one process: the captured step is ONE HIP graph (two, split at the all-reduce, when ranks exchange)
+
+
 class TrainStep:
     """One optimizer step on a static batched graph: mask -> forward -> loss -> backward ->
     [all-reduce] -> SGD(momentum)."""
@@ -158,7 +161,7 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
-        self._captures, self._arenas = {}, {}       # id(graph) -> its two HIP graphs; size class -> arena.BatchArena
+        self._captures, self._arenas = {}, {}       # id(graph) -> its HIP graph(s); size class -> arena.BatchArena
         self.max_arenas = 8                         # size classes kept (buffers + captured graphs each); beyond: least recently used out
         self._graph = None
         self._lr_dev = None
@@ -363,7 +366,7 @@ class TrainStep:
         each plus autograd's host work, and the host, not the GPU, sets the pace once the kernels are fast enough; a
         replay is two graph launches.  Two graphs, split where the ranks exchange: ``front`` = mask draw, forward, loss,
         backward, gradient gather; [eager: the RCCL all-reduces of ``_reduce``]; ``back`` = SGD update and the loss
-        scalar.  One process runs the same two graphs with nothing in between.
+        scalar.  One process has nothing to do between the halves and captures both into ONE graph.
         Randomness stays fresh per replay: every mask of the step (node sampling, feature and attention dropout) is a
         counter hash of a host seed frozen at capture plus a device counter (ops.DROPOUT_SEED_OFFSET) that the captured
         step advances in its first launch (spgnn_step_begin) - no generator state to restore before a replay; the
@@ -388,9 +391,13 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._front(g)
-            self._graph_back = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
-                self._static_loss = self._back(self.bucket.loss_slot)
+                if self.world == 1 and ONE_GRAPH_PER_STEP:       # nothing happens between the halves: one graph launch per step
+                    self._static_loss = self._back(self.bucket.loss_slot)
+            self._graph_back = None
+            if not (self.world == 1 and ONE_GRAPH_PER_STEP):
+                self._graph_back = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
+                    self._static_loss = self._back(self.bucket.loss_slot)
             self._capture_refs = ops.CAPTURE_REFS
         finally:
             ops.CAPTURE_REFS = prev_refs
@@ -416,8 +423,9 @@ class TrainStep:
 
     def replay(self) -> torch.Tensor:
         self._graph.replay()
-        self._reduce(self.bucket.loss_slot)
-        self._graph_back.replay()
+        if self._graph_back is not None:
+            self._reduce(self.bucket.loss_slot)
+            self._graph_back.replay()
         return self._static_loss
 
     # ---- the reference's loader-batch cycle (job_runner.py:1870-1920): GCN_STEPS steps on every freshly built batch ----
