@@ -3572,10 +3572,19 @@ static void scores_fwd_launch(const ST* x, int64_t x_stride, const float* w, int
   const int64_t waves = (N + 16 * rg - 1) / (16 * rg);                        // row sets
   // the four waves of a block split k (see the kernel): 1024 -> 22 at N = 76 410 100 -> 81-83 us (tools/scores_ab.py, one
   // process); with 64 rows per block instead of 32: 86
-  const bool ksplit = wide && K >= 512;
+  // Small batches (the reference's 64-tree batch: N = 9 641) have too few 16-row sets to fill the chip with one wave each - 604
+  // waves on 1024 SIMDs, 26 us for 39 MB - so the deep classifier product splits k over the block's four waves there too, with
+  // one row group per wave (SPGNN_SCORES_NO_SMALL_KSPLIT: the A/B switch).
+#ifndef SPGNN_SCORES_NO_SMALL_KSPLIT
+  const bool ksplit_small = !wide && J > 16 && K >= 512;
+#else
+  const bool ksplit_small = false;
+#endif
+  const bool ksplit = (wide && K >= 512) || ksplit_small;
   const dim3 grid((unsigned)(ksplit ? waves : (waves + kBlock / 64 - 1) / (kBlock / 64))), block(kBlock);
 #define X(NG_, RG_, KS_) hipLaunchKernelGGL((scores_fwd_mfma<ST, NG_, RG_, KS_>), grid, block, 0, st, x, x_stride, w, Kp, s, s_stride, N, K, J, absmax, bias)
   if (J <= 16) X(1, 1, 1);
+  else if (ksplit_small) X(2, 1, kBlock / 64);
   else if (ksplit) X(2, kScoresRG, kBlock / 64);
   else if (wide) X(2, kScoresRG, 1);
   else X(2, 1, 1);
