@@ -1911,6 +1911,24 @@ int spgnn_gemm_nt_pair(const spgnn_gemm_nt_problem* first, const spgnn_gemm_nt_p
   if (p0.blocks == 0 && p1.blocks == 0) return SPGNN_OK;
   if (p0.blocks == 0) return gemm_nt_launch(p1, nullptr, b_presplit, (hipStream_t)stream);
   if (p1.blocks == 0) return gemm_nt_launch(p0, nullptr, b_presplit, (hipStream_t)stream);
+#ifndef SPGNN_NT_PAIR_NO_ROUND_RULE
+  // The first product chose 256 x 128 tiles from its own shape; count the PAIR's tiles before taking that over.  One workgroup
+  // per CU means a started round costs a whole tile time however few tiles it holds (M = 76 410: 1 196 + 598 = 1 794 = 7.008
+  // rounds; M = 9 641: 228 + 76 = 304 = 1.19).  128 x 128 tiles run two per CU - a round of 512 takes about the same time, 4 % more
+  // per flop - and a last round of at most 256 has every CU to itself (~0.55 of a round).  Results are bit-identical in every
+  // tile shape, so this only moves time.
+  if (p0.variant == 4 && !(b_presplit & SPGNN_GEMM_WIDE)) {
+    NtPlan q0 = p0, q1 = p1;
+    gemm_nt_retile(&q1, 4);
+    const int64_t t4 = (int64_t)q0.a.nbm * q0.a.nbn + (int64_t)q1.a.nbm * q1.a.nbn;
+    gemm_nt_retile(&q0, 2); gemm_nt_retile(&q1, 2);
+    const int64_t t2 = (int64_t)q0.a.nbm * q0.a.nbn + (int64_t)q1.a.nbm * q1.a.nbn;
+    const double est4 = (double)((t4 + 255) / 256);
+    const int64_t rem2 = t2 % 512;
+    const double est2 = 1.04 * ((double)(t2 / 512) + (rem2 == 0 ? 0.0 : rem2 <= 256 ? 0.55 : 1.0));
+    if (est2 < est4 - 0.01) { p0 = q0; p1 = q1; }
+  }
+#endif
   if (p1.variant != p0.variant) {                              // both in the first product's kernel
     if (p0.variant == 5 && !((int64_t)second->M * second->lda * 4 < (int64_t(1) << 31) && (int64_t)second->N * second->ldb * 4 < (int64_t(1) << 31)))
       return spgnn_detail::fail_at(SPGNN_ERR_SHAPE, __func__, __LINE__);
