@@ -680,3 +680,30 @@ def test_sage_feature_dropout_in_the_previous_layers_epilogue(monkeypatch):
         assert rel_err(res[True][1][n], res[False][1][n]) < 2e-6, n
     kept = float((res[True][0] != 0).float().mean())
     assert kept > 0.99
+
+
+def test_bench_two_rank_rehearsal_through_self_launch():
+    """`python3 bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts both ranks itself (before any GPU call),
+    they run the whole N > 1 flow of the training step on the one GPU of this box (SPGNN_BENCH_REHEARSAL=1: gloo moves the
+    bucket, RCCL refuses two ranks per device), rank 0 prints ONE line with n_gpus 2, and the flat keys the driver's record
+    keeps are there.  The numbers of a rehearsal mean nothing; the protocol is what is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPGNN_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--trees", "8",
+                        "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 3 and out["scaling"] == "weak"
+    c = out["config"]
+    assert c["comm_world_size"] == 2 and c["comm_backend"].startswith("gloo") and c["global_trees"] == 16
+    assert c["launch"] == "hip-graph replay", c.get("capture_error")
+    assert c["allreduce_ms_p50"] > 0.0 and c["comm_bucket_bytes"] == 4 * 2501080
+    assert out["value"] > 0 and np.isfinite(out["loss"])
+    assert out["roofline"]["hbm_frac"] > 0 and out["roofline"]["hbm_ms_per_step"] > 0

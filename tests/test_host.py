@@ -423,3 +423,76 @@ def test_bench_accounting_knows_every_kernel_key():
         bench.gemm_bytes(("gemm_tn", N, 512, 768)) + bench.gemm_bytes(("gemm_tn", N, 256, 256))
     assert set(bench.GEMM_NAMES) >= {"gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair"}
     assert len(bench.SECONDARY_LEGS) == 3
+
+
+def _run_bench(argv, env_extra, timeout=180):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command) must start
+    the two ranks itself, rendezvous on 127.0.0.1, print ONE JSON line from rank 0 and exit 0.  Dry mode:
+    the same launch / rendezvous / one-line protocol over gloo on CPU tensors - the GPU rehearsal of the whole step is
+    tests/test_hip_models.py::test_bench_two_rank_rehearsal_through_self_launch."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SPGNN_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["config"]["comm_world_size"] == 2                    # counted by the all-reduce itself
+    assert out["config"]["launched_by"] == "bench.py self_launch"
+
+
+def test_bench_under_torch_distributed_run_keeps_working():
+    """The driver's documented N > 1 form: python -m torch.distributed.run ... bench.py --gpus N (dry mode on the CPU)."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SPGNN_BENCH_DRY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["comm_world_size"] == 2 and out["config"]["launched_by"] == "torch.distributed.run"
+
+
+def test_bench_self_launch_returns_a_failed_ranks_exit_code():
+    """Without a GPU the real ranks stop at "needs a ROCm GPU": the launcher must come back with a non-zero code instead of
+    hanging on the surviving ranks (here every rank fails; the one-rank-dies case is the same poll loop)."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"SPGNN_BENCH_REHEARSAL": "1"}, timeout=120)
+    assert r.returncode != 0
+    assert "needs a ROCm GPU" in r.stderr
+
+
+def test_bench_flat_scalars_for_the_drivers_record():
+    """The driver keeps scalar members of `roofline` / `config` only: flatten_for_driver must repeat the nested K1-K3 figure."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {"config": {}, "roofline": {"bound": "mfma", "frac": 0.1, "hbm": {"frac": 0.6, "own_frac": 0.55, "ms_per_step": 1.1, "survey_bytes_per_step": 5.2e9,
+                                                                            "own_bytes_per_step": 4.9e9, "achieved": 4700.0, "traffic": 5.0e9,
+                                                                            "layer_edges_per_s": 1.4e9, "launches_per_step": 12}},
+           "gemm": {"ms_per_step": 3.3}, "message_passing": {"ms_per_step": 1.7}, "step_ms": {"median": 5.2}, "copy_bandwidth": {"GBps": 4900.0}}
+    bench.flatten_for_driver(out)
+    r, c = out["roofline"], out["config"]
+    assert r["hbm_frac"] == 0.6 and r["hbm_ms_per_step"] == 1.1 and r["hbm_survey_bytes"] == 5.2e9 and r["hbm_traffic"] == 5.0e9
+    assert c["gemm_ms_per_step"] == 3.3 and c["message_passing_ms_per_step"] == 1.7 and c["step_ms_median"] == 5.2
+    assert all(not isinstance(v, (dict, list)) for k, v in r.items() if k.startswith("hbm_"))
