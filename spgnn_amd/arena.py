@@ -99,7 +99,10 @@ class BatchArena:
         nd = tuple(sorted((k, tuple(v.shape[1:]), str(v.dtype)) for k, v in g.ndata.items()))
         # the kernels choose their forms from the degree bounds (<= 8 in- / out-edges: the straight-line paths): a batch
         # on the other side of that line must not replay a graph captured on this side
-        return (str(g.device), n_cap, e_cap, csc.max_in_degree <= 8, csc.max_out_degree <= 8, nd)
+        #  ... and so must a batch with a sink or a source-less node (no self loop somewhere): the fused LSPE level
+        # (ops.lspe_supported) and GATConv's zero-in-degree error both look at the minimum degrees
+        return (str(g.device), n_cap, e_cap, csc.max_in_degree <= 8, csc.max_out_degree <= 8,
+                csc.min_in_degree >= 1, int(getattr(csc, "min_out_degree", 0) or 0) >= 1, nd)
 
     def load(self, g: G.TreeGraph) -> G.TreeGraph:
         """Copy batch ``g`` (a device graph with its node data; e.g. data.assemble_batch) into the arena, pad it to the class
@@ -142,7 +145,7 @@ class BatchArena:
         acsc.min_in_degree = min(csc.min_in_degree, 1)
         acsc.max_in_degree = max(csc.max_in_degree, 3 if m > 1 else (2 if m == 1 else 1))
         acsc.max_out_degree = max(csc.max_out_degree, 3 if m > 1 else (2 if m == 1 else 1))
-        acsc.min_out_degree = min(getattr(csc, "min_out_degree", 1) or 1, 1)
+        acsc.min_out_degree = min(int(getattr(csc, "min_out_degree", 0) or 0), 1)    # unknown counts as 0: never claims an edge that may not be there
         ag.num_real_nodes, ag.num_real_edges = N, E
         ag.batch_num_nodes_list = list(g.batch_num_nodes_list) + [n_pad]
         ag.batch_num_edges_list = list(g.batch_num_edges_list) + [self.e_cap - E]
@@ -181,7 +184,9 @@ class BatchArena:
                 ops.refresh_batch_constant(held)
             seen = set()
             for v in ag.ndata.values():
-                if id(v) not in seen and getattr(v, "_spgnn_const", False):
+                # every node-data tensor that carries a GEMM scale or a pre-split image, marked constant or not: a captured
+                # step would otherwise keep the previous batch's scale
+                if id(v) not in seen and (getattr(v, "_spgnn_const", False) or hasattr(v, "_spgnn_scale") or hasattr(v, "_spgnn_aps")):
                     ops.refresh_batch_constant(v)
                 seen.add(id(v))
             for fn in ag._refresh_hooks:

@@ -253,6 +253,7 @@ _TN_MIN_ELEMS = 16384   # weight gradients smaller than this go to rocBLAS (meas
 
 TN_PAIR_SPLITS = True    # a level's two weight-gradient products choose their split count together (tn_pair_splits)
 DEFER_STEP_SUMS = True   # inside a training step, every split-K reduction of the backward pass waits for ONE launch after it
+DEBUG_POISON_DEFERRED = False   # tests: deferred outputs start as NaN, so a read before the flush cannot pass unnoticed
 STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep while it issues a step's forward and backward
 
 
@@ -299,15 +300,40 @@ class StepSums:
     output the flush has not filled yet."""
 
     def __init__(self, device):
-        self.device, self.jobs, self.keep = torch.device(device), [], []
+        self.device, self.jobs, self.keep, self.outs = torch.device(device), [], [], []
 
-    def add(self, job, *tensors):
+    def add(self, job, part, *outs):
+        """``part``: the split partials; ``outs``: what the reduction will fill (weight gradient [, its second column range,
+        its bias column sums])."""
         self.jobs.append(job)
-        self.keep.extend(t.detach() for t in tensors if t is not None)
+        self.keep.append(part.detach())
+        for t in outs:
+            if t is None:
+                continue
+            d = t.detach()
+            if DEBUG_POISON_DEFERRED:        # tests: an early read of an unfilled output must not pass unnoticed
+                d.fill_(float("nan"))
+            self.keep.append(d)
+            self.outs.append(d)
+
+    def check_taken_over(self, params) -> None:
+        """Call after ``backward()`` and BEFORE ``flush()``: every deferred output must by now BE (the storage of) some
+        parameter's ``.grad`` - autograd took the tensor over as it was.  Where it cloned or added on arrival instead (a
+        parameter used by two layers or twice by one, a tensor hook, ``retain_grad``, a non-leaf parameter) it copied memory
+        this queue has not filled yet, and the step's gradients would be silently wrong: raise."""
+        if not self.outs:
+            return
+        owned = {p.grad.untyped_storage().data_ptr() for p in params if p.grad is not None}
+        lost = [o for o in self.outs if o.untyped_storage().data_ptr() not in owned]
+        if lost:
+            raise RuntimeError(
+                f"{len(lost)} of {len(self.outs)} deferred split-K gradient sums were copied by autograd before they were filled "
+                "(a parameter shared by two layers or used twice, a gradient hook, retain_grad or a non-leaf parameter): their "
+                "values are not valid.  Set spgnn_amd.ops.DEFER_STEP_SUMS = False (and DEFER_ATTN_GRADS = False) for this model.")
 
     def flush(self):
         jobs, keep = self.jobs, self.keep
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.outs = [], [], []
         for i0 in range(0, len(jobs), SumJobs.MAX):
             chunk = jobs[i0:i0 + SumJobs.MAX]
             arr = (_capi.SumJob * len(chunk))(*chunk)
@@ -591,7 +617,15 @@ class AttnGradQueue:
             return
         import ctypes
         lib = _capi.load()
-        sums = SumJobs(self.device)
+        # The step-wide queue fills these outputs only AFTER this method returns, which is fine as long as every gradient is
+        # just ASSIGNED below.  A parameter that already holds a gradient (autograd delivered another layer's first) or that two
+        # recorded passes share is ADDED to here and now: those sums must be complete when this method reads them.
+        seen, shared = set(), False
+        for (_g, _f, _h, p_l, p_r) in items:
+            for p in (p_l, p_r):
+                shared = shared or p.grad is not None or id(p) in seen
+                seen.add(id(p))
+        sums = SumJobs(self.device, local=shared)
         outs = []
         for i0 in range(0, len(items), 8):
             chunk = items[i0:i0 + 8]
@@ -625,6 +659,7 @@ def queue_attn_grads(g_s: torch.Tensor, ft: torch.Tensor, H: int, p_l, p_r) -> b
     """Hand a layer's attention-vector gradient pass to the running step's queue (see AttnGradQueue).  -> whether it took it."""
     q = ATTN_GRAD_QUEUE
     return bool(q is not None and DEFER_ATTN_GRADS and p_l is not None and p_r is not None and p_l.requires_grad and p_r.requires_grad
+                and p_l.is_leaf and p_r.is_leaf               # the queue ASSIGNS .grad: a non-leaf attention vector would lose its gradient
                 and q.add(g_s, ft, H, p_l, p_r))
 
 

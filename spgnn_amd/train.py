@@ -163,7 +163,7 @@ class TrainStep:
         self.gen.manual_seed(seed)
         self._captures, self._arenas = {}, {}       # id(graph) -> its HIP graph(s); size class -> arena.BatchArena
         self.max_arenas = 8                         # size classes kept (buffers + captured graphs each); beyond: least recently used out
-        self._graph = None
+        self._graph = self._graph_back = self._captured_graph = None
         self._lr_dev = None
         self._one = self._loss_out = None
         # seed of the mask stream a captured step draws inside its loss kernel (spgnn_masked_ce_step); eager steps use self.gen
@@ -243,6 +243,7 @@ class TrainStep:
             if queue is not None:
                 queue.flush()                # (inside the step's scale-pool window: its partial sums take no block, but stay in order)
             if sums is not None:
+                sums.check_taken_over(b.params)      # every deferred output must BE a parameter's .grad by now
                 sums.flush()                 # the attention queue's reductions included: it found this queue installed
         finally:
             ops.DROPOUT_SEED_OFFSET = prev_off
@@ -422,6 +423,8 @@ class TrainStep:
         return True
 
     def replay(self) -> torch.Tensor:
+        if self._graph is None:
+            raise RuntimeError("no captured step is selected (capture() first; the selected capture's arena may have been evicted)")
         self._graph.replay()
         if self._graph_back is not None:
             self._reduce(self.bucket.loss_slot)
@@ -439,6 +442,8 @@ class TrainStep:
             while len(self._arenas) >= self.max_arenas:          # least recently used class goes, with its capture
                 _, old = next(iter(self._arenas.items()))
                 self._captures.pop(id(old.graph), None)
+                if self._captured_graph is old.graph:            # never leave replay() pointing at graphs whose buffers are freed
+                    self._graph = self._graph_back = self._captured_graph = None
                 del self._arenas[next(iter(self._arenas))]
             arena = BatchArena(g, granule)
         self._arenas[key] = arena                                # re-inserted last: dict order is the recency order
@@ -494,7 +499,12 @@ class TrainStep:
     def _replays_on(self, ag, steps: int) -> torch.Tensor:
         done = 0
         if not self.select(ag):
-            self.capture(ag)
+            # the warm-up steps of a capture are real optimizer steps: never more of them than the caller asked for
+            # (GCN_STEPS < 3 would otherwise over-train the first batch of a class), and with several ranks every rank must
+            # issue exactly ``steps`` all-reduces for this batch whether it captures or replays
+            if steps < 1:
+                raise ValueError("run_batch / run_batches need steps >= 1 (a capture takes at least one optimizer step)")
+            self.capture(ag, warmup=min(3, steps))
             done = self.capture_steps
         loss = self._static_loss                     # the device scalar every replay of this capture writes
         for _ in range(max(steps - done, 0)):

@@ -296,10 +296,12 @@ def _oracle_logits(cfg, model, g, dtype, storage, grad=False):
     return O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu().to(dtype), None, storage=storage), sd
 
 
-@pytest.mark.parametrize("name", ["st_gat_6", "st_gat_3"])
-def test_bf16_model_forward_and_gradients(name):
+@pytest.mark.parametrize("name,trees", [("st_gat_6", 3), ("st_gat_3", 3), ("st_gat_6", 64)])
+def test_bf16_model_forward_and_gradients(name, trees):
+    """(st_gat_6, 64): BASELINE config 4's model against its storage-model oracle at the reference's TRAIN_BATCH_SIZE, not only
+    on a 3-tree batch."""
     cfg, model = _build(name)
-    g = synthetic.make_batch(3, rank=5, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    g = synthetic.make_batch(trees, rank=5, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
     model.eval()
     w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
     y = g.ndata["y"]

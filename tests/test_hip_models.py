@@ -170,10 +170,12 @@ def test_linear_mean_fold_kernels_equal_the_torch_assembly(embedding_in_loss, mo
         assert rel_err(a, b) < 2e-5 or float((a - b).abs().max()) < 1e-7 * gmax, (n, rel_err(a, b))
 
 
-def test_st_gat_3_with_eight_heads_matches_oracle():
+@pytest.mark.parametrize("trees", [2, 64])
+def test_st_gat_3_with_eight_heads_matches_oracle(trees):
     """BASELINE.json words config 2 as "st_gat_3 (3-layer 8-head GAT)"; the reference's st_gat_3 has 2 heads
     (exp_settings/st_gat_3.py:101-102).  H is a run-time parameter here: the same model with num_heads = 8 (hidden layers
-    8 x 256 / 8 x 128 / 8 x 64, output 2 x 1024), forward and loss gradients against the oracle at model level."""
+    8 x 256 / 8 x 128 / 8 x 64, output 2 x 1024), forward and loss gradients against the oracle at model level - on a 2-tree
+    batch and at BASELINE config 2's own batch of 64 trees."""
     cfg = get_config("st_gat_3")
     torch.manual_seed(0)
     model = models.build_model({**cfg.MODEL, "num_heads": 8}).cuda()
@@ -184,7 +186,7 @@ def test_st_gat_3_with_eight_heads_matches_oracle():
                 p.normal_(0, 0.05)
     model.set_gcn_only(); model.eval()
     assert model.state_dict()["gat.gat_layers.0.fc.weight"].shape == (2048, 1024)
-    g = synthetic.make_batch(2, rank=6, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    g = synthetic.make_batch(trees, rank=6, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
     w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
     y = g.ndata["y"]
     mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(5)) < 0.5
@@ -454,6 +456,7 @@ def test_step_wide_deferred_sums_are_bit_identical(name, bf16, monkeypatch):
     g = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     out = []
+    monkeypatch.setattr(_ops, "DEBUG_POISON_DEFERRED", True)      # deferred outputs start as NaN: an early read cannot pass unnoticed
     for defer in (True, False):
         monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", defer)
         ts = TrainStep(copy.deepcopy(model), w, 1.0, 1e-3, 0.9)
@@ -463,6 +466,61 @@ def test_step_wide_deferred_sums_are_bit_identical(name, bf16, monkeypatch):
         assert _ops.STEP_SUMS is None
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert torch.isfinite(out[0][0]).all() and float(out[0][0].abs().max()) > 0
+    _ops.DROPOUT_SEED_OFFSET = None
+
+
+def test_two_gatconvs_sharing_their_attention_vectors_get_the_summed_gradient(monkeypatch):
+    """ADVICE r4: AttnGradQueue.flush ADDS to a parameter that already holds a gradient or that two recorded passes share;
+    under the step-wide queue those sums were still unfilled memory at that point.  Two GATConv layers of st_gat_3 share
+    attn_l / attn_r (same shape): the step's gradient for the shared vectors must equal plain autograd's (which adds the two
+    layers' contributions), with the deferred outputs poisoned with NaN so that an early read cannot pass."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build("st_gat_6", seed=12)
+    model.eval()
+    layers = model.gat.gat_layers
+    a, b = layers[3], layers[4]                                   # two 128 -> 2 x 64 hidden layers
+    assert a.attn_l.shape == b.attn_l.shape
+    b.attn_l, b.attn_r = a.attn_l, a.attn_r                       # shared parameters
+    g = synthetic.make_batch(5, rank=4, device="cuda", pos_enc_dim=None)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    monkeypatch.setattr(_ops, "DEBUG_POISON_DEFERRED", True)
+    got = {}
+    for defer in (True, False):
+        monkeypatch.setattr(_ops, "DEFER_ATTN_GRADS", defer)
+        monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", defer)
+        m = copy.deepcopy(model)
+        assert m.gat.gat_layers[4].attn_l is m.gat.gat_layers[3].attn_l
+        ts = TrainStep(m, w, 1.0, 1e-3, 0.9)
+        ts._front(g)
+        got[defer] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    for n, v in got[False].items():
+        assert torch.isfinite(got[True][n]).all(), n
+        scale = float(v.abs().max()) + 1e-30
+        assert float((got[True][n] - v).abs().max()) <= 2e-6 * scale, n      # (a + b) vs (b + a): fp32 rounding only
+    shared = got[True]["gat.gat_layers.3.attn_l"]
+    assert float(shared.abs().max()) > 0
+    _ops.DROPOUT_SEED_OFFSET = None
+
+
+def test_step_wide_sums_raise_when_autograd_copied_an_unfilled_gradient(monkeypatch):
+    """the step-wide queue is sound only while autograd takes every deferred output over as the parameter's .grad.
+    A gradient hook on a weight makes autograd hand the hook's result on instead: the guard must raise, not train on garbage."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build("st_gat_3", seed=13)
+    model.eval()
+    g = synthetic.make_batch(4, rank=5, device="cuda", pos_enc_dim=None)
+    ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), 1.0, 1e-3, 0.9)
+    ts._front(g)                                                   # sound as built
+    h = model.gat.gat_layers[1].fc.weight.register_hook(lambda gr: gr * 1.0)
+    with pytest.raises(RuntimeError, match="deferred split-K gradient sums"):
+        ts._front(g)
+    h.remove()
+    assert _ops.STEP_SUMS is None and _ops.ATTN_GRAD_QUEUE is None
+    monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", False)           # the documented way out
+    h = model.gat.gat_layers[1].fc.weight.register_hook(lambda gr: gr * 1.0)
+    ts._front(g)
+    h.remove()
+    assert torch.isfinite(ts.bucket.flat_grad).all()
     _ops.DROPOUT_SEED_OFFSET = None
 
 
