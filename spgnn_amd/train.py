@@ -164,6 +164,7 @@ class TrainStep:
         self._captures, self._arenas = {}, {}       # id(graph) -> its HIP graph(s); size class -> arena.BatchArena
         self.max_arenas = 8                         # size classes kept (buffers + captured graphs each); beyond: least recently used out
         self._graph = self._graph_back = self._captured_graph = None
+        self._verify_deferred = True                # the first step checks that no deferred gradient was read before it was filled
         self._lr_dev = None
         self._one = self._loss_out = None
         # seed of the mask stream a captured step draws inside its loss kernel (spgnn_masked_ce_step); eager steps use self.gen
@@ -223,7 +224,15 @@ class TrainStep:
         queue = ops.AttnGradQueue(b.flat_param.device) if (on_gpu and ops.DEFER_ATTN_GRADS) else None
         # ... and so are the split-K reductions behind every weight gradient (nothing inside the backward pass reads one)
         sums = ops.StepSums(b.flat_param.device) if (on_gpu and ops.DEFER_STEP_SUMS) else None
+        # That is sound only while autograd takes every deferred output over untouched.  The FIRST step of this object proves it
+        # for this model (its structure - shared parameters, hooks, retain_grad - is what decides, and is the same on every later
+        # step): the deferred outputs start as NaN, so whatever autograd copied, added or handed to a hook before the flush shows
+        # up as a NaN in the gathered bucket (one host read, once).  Never under stream capture.
+        verify = bool(sums is not None and self._verify_deferred and not torch.cuda.is_current_stream_capturing())
+        prev_poison = ops.DEBUG_POISON_DEFERRED
         try:
+            if verify:
+                ops.DEBUG_POISON_DEFERRED = True
             if ctr is not None:
                 ops.DROPOUT_SEED_OFFSET = ctr
             ops.ATTN_GRAD_QUEUE = queue
@@ -249,9 +258,18 @@ class TrainStep:
             ops.DROPOUT_SEED_OFFSET = prev_off
             ops.ATTN_GRAD_QUEUE = None
             ops.STEP_SUMS = None
+            ops.DEBUG_POISON_DEFERRED = prev_poison
             if pool is not None:
                 pool.end()
         b.gather_grads()
+        if verify:
+            if not bool(torch.isfinite(b.flat_grad[:b.numel]).all()):
+                raise RuntimeError(
+                    "a deferred split-K gradient sum was read before it was filled (a parameter shared by two layers or used twice, "
+                    "a gradient hook, retain_grad, a custom backward that reads a weight gradient) - or the first step's gradients "
+                    "are not finite for another reason.  Set spgnn_amd.ops.DEFER_STEP_SUMS = False and DEFER_ATTN_GRADS = False for "
+                    "this model.")
+            self._verify_deferred = False
         if not direct:
             b.wsum_slot.copy_(den.detach().reshape(1))
             b.loss_slot.copy_(num.detach().reshape(1))

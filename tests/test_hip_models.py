@@ -503,24 +503,43 @@ def test_two_gatconvs_sharing_their_attention_vectors_get_the_summed_gradient(mo
 
 
 def test_step_wide_sums_raise_when_autograd_copied_an_unfilled_gradient(monkeypatch):
-    """the step-wide queue is sound only while autograd takes every deferred output over as the parameter's .grad.
-    A gradient hook on a weight makes autograd hand the hook's result on instead: the guard must raise, not train on garbage."""
+    """the step-wide queue is sound only while autograd takes every deferred output over untouched.  The first step
+    of a TrainStep proves that for its model (deferred outputs start as NaN; a NaN in the gathered bucket = an early read).
+    A gradient hook on a weight makes autograd hand the hook's result - computed from the unfilled tensor - on instead: the
+    step must raise, not train on garbage.  (fc.weight's gradient is one of two views of a deferred output, the other being
+    res_fc.weight's: a storage-level check alone would not see this.)"""
     from spgnn_amd import ops as _ops
     cfg, model = _build("st_gat_3", seed=13)
     model.eval()
     g = synthetic.make_batch(4, rank=5, device="cuda", pos_enc_dim=None)
-    ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), 1.0, 1e-3, 0.9)
-    ts._front(g)                                                   # sound as built
-    h = model.gat.gat_layers[1].fc.weight.register_hook(lambda gr: gr * 1.0)
-    with pytest.raises(RuntimeError, match="deferred split-K gradient sums"):
-        ts._front(g)
-    h.remove()
-    assert _ops.STEP_SUMS is None and _ops.ATTN_GRAD_QUEUE is None
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ts = TrainStep(copy.deepcopy(model), w, 1.0, 1e-3, 0.9)
+    ts._front(g)                                                   # sound as built: the proof passes and is not repeated
+    assert not ts._verify_deferred and torch.isfinite(ts.bucket.flat_grad).all()
+    m2 = copy.deepcopy(model)
+    h = m2.gat.gat_layers[1].fc.weight.register_hook(lambda gr: gr * 1.0)
+    ts2 = TrainStep(m2, w, 1.0, 1e-3, 0.9)
+    with pytest.raises(RuntimeError, match="deferred split-K gradient sum"):
+        ts2._front(g)
+    assert _ops.STEP_SUMS is None and _ops.ATTN_GRAD_QUEUE is None and not _ops.DEBUG_POISON_DEFERRED
     monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", False)           # the documented way out
-    h = model.gat.gat_layers[1].fc.weight.register_hook(lambda gr: gr * 1.0)
-    ts._front(g)
+    ts3 = TrainStep(m2, w, 1.0, 1e-3, 0.9)
+    ts3._front(g)
     h.remove()
-    assert torch.isfinite(ts.bucket.flat_grad).all()
+    assert torch.isfinite(ts3.bucket.flat_grad).all()
+    # a sole-alias gradient that autograd replaced is also caught by the per-step storage check (no host read)
+    monkeypatch.setattr(_ops, "DEFER_STEP_SUMS", True)
+    m4 = copy.deepcopy(model)
+    ts4 = TrainStep(m4, w, 1.0, 1e-3, 0.9)
+    ts4._front(g)
+    h = m4.gnn_out.weight.register_hook(lambda gr: gr * 1.0)
+    try:
+        ts4._front(g)
+        caught = False
+    except RuntimeError:
+        caught = True
+    h.remove()
+    print("storage-level check caught a hook on the classifier weight:", caught)
     _ops.DROPOUT_SEED_OFFSET = None
 
 
