@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 53
+#define SPGNN_ABI_VERSION 54
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -158,6 +158,110 @@ int spgnn_gat_bwd_src(const int32_t* out_indptr, const int32_t* out_indices, con
                       int64_t N, int64_t E, int32_t H, int32_t D,
                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       spgnn_stream_t stream);
+
+/*
+ * Tree-resident LDS tiles for the three GATConv traversals above (ABI 54; csrc/spgnn_tile.hip) - BASELINE.json north_star's
+ * "LDS staging of neighbour tiles".  Replaces the same DGL primitives as spgnn_gat_fwd / _bwd_dst / _bwd_src (reference
+ * models.py:301-314, 425-456); arguments have the meaning they have there.  The batched graph is block-diagonal
+ * (dgl.batch, job_runner.py:1882): a workgroup owns a TILE of consecutive nodes - tile t = [tile_ptr[t], tile_ptr[t + 1]),
+ * at most max_tile_nodes of them, normally whole trees - and a 64 R-column slice of the rows; it streams the tile's slice of
+ * ft (g_pre for the source-major half), its scores, attention words, padded neighbour rows and CSC offsets into LDS once
+ * (coalesced 16-byte loads) and serves every gather from there; only a node's own rows are read from / written to global
+ * memory.  Tiles need not be closed under neighbours (an id outside the tile takes a global load), so any partition of
+ * [0, N) into runs of <= max_tile_nodes is correct; empty tiles are allowed (a fixed-length tile_ptr for batch arenas).
+ * Requirements (the caller keeps everything else on the row kernels): 1 <= degree <= 8 in the direction walked, the
+ * padded (N, 8) rows nbr8 / out_nbr8 / out_pos8, D in {64, 128, 256} with spgnn_gat_tile_supported(H, D, bytes per row
+ * element, max_tile_nodes), no head-mean output.  Forward and source-major half: bit-identical to the row kernels; the
+ * destination-major half sums its per-edge dots over another lane geometry (fp32 rounding).
+ */
+int spgnn_gat_tile_supported(int32_t H, int32_t D, int32_t elem_bytes, int32_t max_tile_nodes);
+int spgnn_gat_fwd_tile(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                       const int32_t* indptr, const int32_t* nbr8,
+                       const float* ft, int64_t ft_stride,
+                       const float* el, const float* er, int64_t s_stride,
+                       const float* res /* nullable */, int64_t res_stride,
+                       const float* bias /* nullable */,
+                       float* out, int64_t out_stride,
+                       float* attn,
+                       float* absmax /* nullable */,
+                       int64_t N, int32_t H, int32_t D,
+                       float negative_slope, int32_t activation,
+                       float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                       float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
+                       spgnn_stream_t stream);
+int spgnn_gat_bwd_dst_tile(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                           const int32_t* indptr, const int32_t* nbr8,
+                           const float* ft, int64_t ft_stride,
+                           const float* el, const float* er, int64_t s_stride,
+                           const float* attn,
+                           const float* g_out, int64_t g_out_stride,
+                           const float* out /* nullable iff activation == NONE */, int64_t out_stride,
+                           float* g_pre, int64_t g_pre_stride,
+                           float* g_e,
+                           float* g_er, int64_t g_s_stride,
+                           float* absmax /* nullable */,
+                           int64_t N, int32_t H, int32_t D,
+                           float negative_slope, int32_t activation,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
+                           spgnn_stream_t stream);
+int spgnn_gat_bwd_src_tile(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                           const int32_t* indptr,
+                           const int32_t* out_indptr, const int32_t* out_nbr8, const int32_t* out_pos8,
+                           const float* attn, const float* g_e,
+                           const float* g_pre, int64_t g_pre_stride,
+                           float* g_ft, int64_t g_ft_stride,
+                           float* g_el, int64_t g_s_stride,
+                           float* absmax /* nullable */,
+                           const float* score_l, const float* score_r /* nullable: attn_l, attn_r flat (H*D) */,
+                           const float* g_er /* with score_l */,
+                           int64_t N, int32_t H, int32_t D,
+                           float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                           spgnn_stream_t stream);
+/* the same on bf16 rows (bf16 storage, fp32 accumulate; see spgnn_gat_fwd_bf16) */
+int spgnn_gat_fwd_tile_bf16(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                            const int32_t* indptr, const int32_t* nbr8,
+                            const uint16_t* ft, int64_t ft_stride,
+                            const float* el, const float* er, int64_t s_stride,
+                            const uint16_t* res, int64_t res_stride,
+                            const float* bias,
+                            uint16_t* out, int64_t out_stride,
+                            float* attn,
+                            float* absmax,
+                            int64_t N, int32_t H, int32_t D,
+                            float negative_slope, int32_t activation,
+                            float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                            float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
+                            spgnn_stream_t stream);
+int spgnn_gat_bwd_dst_tile_bf16(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                                const int32_t* indptr, const int32_t* nbr8,
+                                const uint16_t* ft, int64_t ft_stride,
+                                const float* el, const float* er, int64_t s_stride,
+                                const float* attn,
+                                const uint16_t* g_out, int64_t g_out_stride,
+                                const uint16_t* out, int64_t out_stride,
+                                uint16_t* g_pre, int64_t g_pre_stride,
+                                float* g_e,
+                                float* g_er, int64_t g_s_stride,
+                                float* absmax,
+                                int64_t N, int32_t H, int32_t D,
+                                float negative_slope, int32_t activation,
+                                float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                                float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset,
+                                spgnn_stream_t stream);
+int spgnn_gat_bwd_src_tile_bf16(const int32_t* tile_ptr, int64_t n_tiles, int32_t max_tile_nodes,
+                                const int32_t* indptr,
+                                const int32_t* out_indptr, const int32_t* out_nbr8, const int32_t* out_pos8,
+                                const float* attn, const float* g_e,
+                                const uint16_t* g_pre, int64_t g_pre_stride,
+                                uint16_t* g_ft, int64_t g_ft_stride,
+                                float* g_el, int64_t g_s_stride,
+                                float* absmax,
+                                const float* score_l, const float* score_r,
+                                const float* g_er,
+                                int64_t N, int32_t H, int32_t D,
+                                float p_drop, uint64_t seed, const uint64_t* seed_offset,
+                                spgnn_stream_t stream);
 
 /*
  * Aggregate-first form of the same GATConv (reference call site models.py:456-482, the 192 -> 2 x 1024 output layer

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 53
+ABI_VERSION = 54
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -76,7 +76,18 @@ class WeightPrepLayer(C.Structure):      # spgnn_weight_prep_layer
 
 
 # name -> argtypes; must list every function include/spgnn_hip.h declares (tests check this)
+_TILE_FWD = [_i32p, _i64, _i32, _i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _vp, _i64, _f32p, _vp, _i64, _f32p, _f32p, _i64, _i32, _i32,
+             _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp]
+_TILE_DST = [_i32p, _i64, _i32, _i32p, _i32p, _vp, _i64, _f32p, _f32p, _i64, _f32p, _vp, _i64, _vp, _i64, _vp, _i64, _f32p, _f32p, _i64,
+             _f32p, _i64, _i32, _i32, _f32, _i32, _f32, _u64, _vp, _f32, _u64, _i32, _i32, _vp]
+_TILE_SRC = [_i32p, _i64, _i32, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _vp, _i64, _vp, _i64, _f32p, _i64, _f32p, _f32p, _f32p, _f32p,
+             _i64, _i32, _i32, _f32, _u64, _vp, _vp]
+
 SIGNATURES = {
+    "spgnn_gat_tile_supported": [_i32, _i32, _i32, _i32],
+    "spgnn_gat_fwd_tile": _TILE_FWD, "spgnn_gat_fwd_tile_bf16": _TILE_FWD,
+    "spgnn_gat_bwd_dst_tile": _TILE_DST, "spgnn_gat_bwd_dst_tile_bf16": _TILE_DST,
+    "spgnn_gat_bwd_src_tile": _TILE_SRC, "spgnn_gat_bwd_src_tile_bf16": _TILE_SRC,
     "spgnn_sum_partials_multi": [C.POINTER(SumJob), _i32, _vp],
     "spgnn_weight_prep_blocks": [_i32, _i64, _i64],
     "spgnn_weight_prep": [_vp, _i32, _i64, _vp, _vp],

@@ -79,6 +79,7 @@ class BatchArena:
                  out_indices=i32(self.e_cap), out_pos=i32(self.e_cap))
         self.src, self.dst = i32(self.e_cap), i32(self.e_cap)
         csc = G.DeviceCSC.from_tensors(t, self.n_cap, self.e_cap)
+        csc._fixed_tile_count = True             # DeviceCSC.tiles: the launch grids cover the fixed-length tile table (see _refresh)
         g = self.graph = G.TreeGraph.from_device(self.src, self.dst, self.n_cap, csc, [self.n_cap], [self.e_cap])
         g._stable_storage = True
         g._refresh_hooks = []
@@ -150,6 +151,7 @@ class BatchArena:
         ag.batch_num_nodes_list = list(g.batch_num_nodes_list) + [n_pad]
         ag.batch_num_edges_list = list(g.batch_num_edges_list) + [self.e_cap - E]
         ag._src_np = ag._dst_np = None
+        acsc.segments = ag.batch_num_nodes_list          # this batch's tree boundaries (+ the pad): the LDS tiles are cut there
         self._refresh(acsc)
         self.loads += 1
         return ag
@@ -172,6 +174,11 @@ class BatchArena:
                         new = acsc.out_degrees_f()
                     elif isinstance(key, tuple) and key[0] == "deg_scale":
                         new = acsc.degree_scale(key[1], key[2])
+                    elif isinstance(key, tuple) and key[0] == "tiles":
+                        acsc._cache = {key: val}             # rewritten IN PLACE (same length for every batch of the class)
+                        acsc.tiles(key[1], rebuild=True)
+                        acsc._cache = {}
+                        continue
                     else:
                         continue
                     for o, n_ in zip(val if isinstance(val, tuple) else (val,), new if isinstance(new, tuple) else (new,)):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libspgnn_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
-SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_graph.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
+SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_tile.hip", "spgnn_graph.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
 HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h"), os.path.join(HERE, "spgnn_rows.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE]
 # Per-source flags.  The row kernels are built WITHOUT the SLP vectorizer: the packed fp32 ops it forms (v_pk_fma_f32 fed by
@@ -22,8 +22,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.jo
 # gat_fwd_vec / gat_agg_fwd); with both vectorizers off the object holds NO packed fp32 arithmetic, and _check_isa() below
 # keeps it that way (the mechanism of the hazard is unconfirmed, so the fence is "no such instruction in this file").
 _ROW_FLAGS = ["-fno-slp-vectorize", "-fno-vectorize", "-DSPGNN_NO_SLP_VECTORIZE"]
-EXTRA_FLAGS = {"spgnn_kernels.hip": _ROW_FLAGS, "spgnn_lspe.hip": _ROW_FLAGS}
-NO_PACKED_FP32 = ("spgnn_kernels.hip", "spgnn_lspe.hip")     # objects that must not contain v_pk_{fma,mul,add}_f32 at all
+EXTRA_FLAGS = {"spgnn_kernels.hip": _ROW_FLAGS, "spgnn_lspe.hip": _ROW_FLAGS, "spgnn_tile.hip": _ROW_FLAGS}
+NO_PACKED_FP32 = ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_tile.hip")     # objects that must not contain v_pk_{fma,mul,add}_f32 at all
 LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 

@@ -141,6 +141,47 @@ class DeviceCSC:
             self._cache["ell"] = (nbr8, out_nbr8, out_pos8)
         return self._cache["ell"]
 
+    def tiles(self, cap: int, rebuild: bool = False):
+        """Node tiles for the tree-resident LDS kernels (csrc/spgnn_tile.hip): -> (tile_ptr int32 device tensor, n_tiles).
+        Runs of consecutive nodes of at most ``cap`` nodes each, cut at the batch's tree boundaries (``self.segments``: nodes
+        per tree, attached by TreeGraph.csc; a tree is closed under neighbours - dgl.batch, reference job_runner.py:1882) so
+        that in the normal case every gather of a tile is served from LDS; a tree larger than ``cap`` is split (the kernels
+        load out-of-tile neighbours from global memory), a graph without boundaries is cut uniformly.  The tensor has the
+        FIXED length 2 ceil(N / cap) + 3 - greedy packing never needs more tiles, since two consecutive tiles together
+        exceed ``cap`` - with empty tiles at the end, so a batch arena can rewrite it in place under a captured step."""
+        key = ("tiles", int(cap))
+        if key in self._cache and not rebuild:
+            return self._cache[key]
+        N = self.num_nodes
+        n_max = 2 * ((N + cap - 1) // cap) + 2
+        bounds, cur, pos = [0], 0, 0
+        segs = getattr(self, "segments", None)
+        if not segs or sum(segs) != N:
+            segs = [N]
+        for n in segs:
+            n = int(n)
+            while n > 0:
+                take = min(n, cap)
+                if cur + take > cap:
+                    bounds.append(pos)
+                    cur = 0
+                cur += take
+                pos += take
+                n -= take
+        if pos > bounds[-1]:
+            bounds.append(pos)
+        n_tiles = len(bounds) - 1
+        assert n_tiles <= n_max and all(b1 - b0 <= cap for b0, b1 in zip(bounds, bounds[1:]))
+        bounds += [N] * (n_max + 1 - len(bounds))
+        t = torch.tensor(bounds, dtype=torch.int32).to(self.device)
+        old = self._cache.get(key)
+        if old is not None and old[0].shape == t.shape and rebuild:
+            old[0].copy_(t)                      # same address: what a captured step reads
+            t = old[0]
+        # the launch grid always covers n_max tiles when the storage may be rewritten under a capture; else the used ones
+        self._cache[key] = (t, n_max if getattr(self, "_fixed_tile_count", False) else n_tiles)
+        return self._cache[key]
+
     def in_degrees_f(self) -> torch.Tensor:
         if "in_deg" not in self._cache:
             self._cache["in_deg"] = (self.indptr[1:] - self.indptr[:-1]).to(torch.float32)
@@ -414,6 +455,7 @@ class TreeGraph:
         if key not in self._csc:
             arrays = build_csc_numpy(self._src, self._dst, self._n)
             self._csc[key] = DeviceCSC(arrays, self._n, self.number_of_edges(), device)
+        self._csc[key].segments = self.batch_num_nodes_list          # tree boundaries: DeviceCSC.tiles cuts there
         return self._csc[key]
 
     # ---- conversions -----------------------------------------------------------------
