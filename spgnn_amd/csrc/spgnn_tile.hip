@@ -36,7 +36,6 @@ using spgnn_detail::check_launch;
 using spgnn_detail::fail;
 
 constexpr int kTeam = 16;                   // lanes per node: one 64-column chunk group per R
-constexpr int kTileMaxThreads = 1024;
 
 #define SPGNN_CHECK_ARG(cond, code) do { if (!(cond)) return spgnn_detail::fail_at((code), __func__, __LINE__); } while (0)
 
@@ -49,32 +48,57 @@ __device__ __forceinline__ float4 lds_ldv(const bf16s* p) {
 }
 
 // ---- phase A helpers -------------------------------------------------------------------------------------------------
-// rows [n0, n0 + nt) x columns [col0, col0 + CW) of a (N, ld) tensor -> LDS rows of CW elements, 16-byte pieces
-template <typename ST, int CW>
-__device__ __forceinline__ void stage_rows(ST* __restrict__ dst, const ST* __restrict__ src, int64_t ld, int64_t n0, int nt, int col0) {
-  constexpr int EPV = 16 / (int)sizeof(ST);             // elements per 16-byte piece
-  constexpr int PPR = CW / EPV;                         // pieces per row
-  const int total = nt * PPR;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int row = idx / PPR, pc = idx % PPR;
-    const uint4 q = *reinterpret_cast<const uint4*>(src + (n0 + row) * ld + col0 + pc * EPV);
-    *reinterpret_cast<uint4*>(dst + row * CW + pc * EPV) = q;
+// Compile-time tile geometry: at most kCap nodes per tile, kThreads threads per workgroup (64 teams: at most kIter nodes
+// per team).  With both fixed every thread knows at compile time how many 16-byte pieces it can be asked to stage, so
+// phase A is written as "issue every load, then store": ONE memory latency for the whole tile instead of one per loop
+// trip (a loop of load -> ds_write pairs waits for each load before the next is issued).
+constexpr int kCap = 192;
+constexpr int kThreads = 1024;
+constexpr int kTeams = kThreads / kTeam;
+constexpr int kIter = (kCap + kTeams - 1) / kTeams;            // 3
+
+// rows [n0, n0 + nt) x columns [col0, col0 + CW) of a (N, ld) tensor: this thread's pieces -> registers / -> LDS
+template <typename ST, int CW> struct RowStage {
+  static constexpr int EPV = 16 / (int)sizeof(ST);              // elements per 16-byte piece
+  static constexpr int PPR = CW / EPV;                          // pieces per row
+  static constexpr int NP = (kCap * PPR + kThreads - 1) / kThreads;
+  uint4 q[NP];
+  __device__ __forceinline__ void load(const ST* __restrict__ src, int64_t ld, int64_t n0, int nt, int col0) {
+    const int total = nt * PPR;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int idx = min((int)threadIdx.x + j * kThreads, total - 1);      // clamped: unconditional loads
+      const int row = idx / PPR, pc = idx % PPR;
+      q[j] = *reinterpret_cast<const uint4*>(src + (n0 + row) * ld + col0 + pc * EPV);
+    }
   }
-}
-// one float per node: column h of a (N, ld) score tensor
-__device__ __forceinline__ void stage_col(float* __restrict__ dst, const float* __restrict__ src, int64_t ld, int64_t n0, int nt) {
-  for (int i = threadIdx.x; i < nt; i += blockDim.x) dst[i] = src[(n0 + i) * ld];
-}
-// (nt, 8) int32 rows as 16-byte pieces
-__device__ __forceinline__ void stage_ell(int* __restrict__ dst, const int32_t* __restrict__ src, int64_t n0, int nt) {
-  for (int idx = threadIdx.x; idx < nt * 2; idx += blockDim.x)
-    reinterpret_cast<uint4*>(dst)[idx] = reinterpret_cast<const uint4*>(src + n0 * 8)[idx];
-}
-__device__ __forceinline__ void stage_ptr(int* __restrict__ dst, const int32_t* __restrict__ src, int64_t n0, int nt) {
-  for (int i = threadIdx.x; i <= nt; i += blockDim.x) dst[i] = src[n0 + i];
-}
+  __device__ __forceinline__ void store(ST* __restrict__ dst, int nt) const {
+    const int total = nt * PPR;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int idx = (int)threadIdx.x + j * kThreads;
+      if (idx < total) *reinterpret_cast<uint4*>(dst + (idx / PPR) * CW + (idx % PPR) * EPV) = q[j];
+    }
+  }
+};
+// per-node scalars and the padded (nt, 8) rows: one element / one 16-byte piece per thread (kThreads >= 2 kCap + 1)
+static_assert(kThreads >= 2 * kCap + 1, "one piece per thread in phase A");
 
 __device__ __forceinline__ int align4(int x) { return (x + 3) & ~3; }
+
+// a lane's chunk of a row as it is stored (fp32: 16 bytes, bf16: 8 bytes): what a prefetched own row is kept as
+template <typename ST> struct Raw;
+template <> struct Raw<float> { typedef uint4 T; };
+template <> struct Raw<bf16s> { typedef uint2 T; };
+__device__ __forceinline__ uint4 ld_raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint2 ld_raw(const bf16s* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvt_raw(uint4 u) {
+  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ float4 cvt_raw(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
 
 // =====================================================================================================================
 // forward
@@ -90,48 +114,61 @@ template <typename ST> struct TileFwd {
 
 // grid.x = tiles, grid.y = H * D / (64 R) slices; R float4 chunks per lane, all inside one head
 template <typename ST, int R>
-__global__ __launch_bounds__(kTileMaxThreads) void gat_fwd_tile(TileFwd<ST> a) {
+__global__ __launch_bounds__(kThreads) void gat_fwd_tile(TileFwd<ST> a) {
   constexpr int CW = 64 * R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.seed_off) { a.seed += a.seed_off[0]; a.fseed += a.seed_off[0]; }
   const int64_t n0 = a.tile_ptr[blockIdx.x];
-  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), a.cap);
+  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), kCap);
   if (nt <= 0) return;
   const int sph = a.D / CW;                             // slices per head
   const int h = blockIdx.y / sph, cg = blockIdx.y % sph;
   const int col0 = h * a.D + cg * CW;
   ST* rows_s = reinterpret_cast<ST*>(smem);
-  float* el_s = reinterpret_cast<float*>(smem + (size_t)a.cap * CW * sizeof(ST));
-  float* er_s = el_s + align4(a.cap);
-  int* ip_s = reinterpret_cast<int*>(er_s + align4(a.cap));
-  int* nbr_s = ip_s + align4(a.cap + 1);
+  float* el_s = reinterpret_cast<float*>(smem + (size_t)kCap * CW * sizeof(ST));
+  float* er_s = el_s + kCap;
+  int* ip_s = reinterpret_cast<int*>(er_s + kCap);
+  int* nbr_s = ip_s + align4(kCap + 1);
+  const int tid = threadIdx.x, lane = tid & (kTeam - 1), team = tid / kTeam;
+  const int ccol = col0 + lane * 4;                     // this lane's column in chunk 0 (chunk r: + 64 r)
 
-  stage_rows<ST, CW>(rows_s, a.ft, a.ft_ld, n0, nt, col0);
-  stage_col(el_s, a.el + h, a.s_ld, n0, nt);
-  stage_col(er_s, a.er + h, a.s_ld, n0, nt);
-  stage_ptr(ip_s, a.indptr, n0, nt);
-  stage_ell(nbr_s, a.nbr8, n0, nt);
-  __syncthreads();
-
-  const int lane = threadIdx.x & (kTeam - 1), team = threadIdx.x / kTeam, nteams = blockDim.x / kTeam;
-  const int k = lane & 7;
-  const int tbase = (threadIdx.x & 63) & ~(kTeam - 1);
-  const bool write_attn = cg == 0 && lane < 8;
+  // ---- every load of the tile at once: the slice of ft, scores, offsets, padded neighbour rows, the teams' own rows ----
+  RowStage<ST, CW> rs;
+  rs.load(a.ft, a.ft_ld, n0, nt, col0);
+  const int ic = min(tid, nt - 1);
+  const float el_v = a.el[(n0 + ic) * a.s_ld + h], er_v = a.er[(n0 + ic) * a.s_ld + h];
+  const int ip_v = a.indptr[n0 + min(tid, nt)];
+  const uint4 nb_v = reinterpret_cast<const uint4*>(a.nbr8 + n0 * 8)[min(tid, 2 * nt - 1)];
+  typename Raw<ST>::T resv[kIter][R];
+  if (a.res) {
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int64_t v = n0 + min(team + it * kTeams, nt - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) resv[it][r] = ld_raw(a.res + v * a.res_ld + ccol + 64 * r);
+    }
+  }
   float4 bq[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) bq[r] = a.bias ? ld4(a.bias + col0 + (r * kTeam + lane) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < R; ++r) bq[r] = a.bias ? ld4(a.bias + ccol + 64 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+  rs.store(rows_s, nt);
+  if (tid < nt) { el_s[tid] = el_v; er_s[tid] = er_v; }
+  if (tid <= nt) ip_s[tid] = ip_v;
+  if (tid < 2 * nt) reinterpret_cast<uint4*>(nbr_s)[tid] = nb_v;
+  __syncthreads();
 
-  for (int i = team; i < nt; i += nteams) {
+  const int k = lane & 7;
+  const int tbase = (tid & 63) & ~(kTeam - 1);
+  const bool write_attn = cg == 0 && lane < 8;
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int i = team + it * kTeams;
+    if (i >= nt) break;
     const int64_t v = n0 + i;
     const int beg = ip_s[i], deg = ip_s[i + 1] - beg;
-    // the node's own row first: the only global read of the iteration is in flight during the softmax
     float4 acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.res) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = ldv(a.res + v * a.res_ld + col0 + (r * kTeam + lane) * 4);
-    }
+    for (int r = 0; r < R; ++r) acc[r] = a.res ? cvt_raw(resv[it][r]) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { acc[r].x += bq[r].x; acc[r].y += bq[r].y; acc[r].z += bq[r].z; acc[r].w += bq[r].w; }
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(kTileMaxThreads) void gat_fwd_tile(TileFwd<ST> a) {
         for (int r = 0; r < R; ++r) {
           float4 xr;
           if (ink) xr = lds_ldv(rows_s + ulk * CW + (r * kTeam + lane) * 4);
-          else xr = ldv(a.ft + (int64_t)ug * a.ft_ld + col0 + (r * kTeam + lane) * 4);
+          else xr = ldv(a.ft + (int64_t)ug * a.ft_ld + ccol + 64 * r);
           fma4(acc[r], wk, xr);
         }
       }
@@ -192,7 +229,7 @@ __global__ __launch_bounds__(kTileMaxThreads) void gat_fwd_tile(TileFwd<ST> a) {
     float amx = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int c = col0 + (r * kTeam + lane) * 4;
+      const int c = ccol + 64 * r;
       float4 d = acc[r];
       if (a.fp > 0.f) {
         const float4 kf = feat_keep4(a.fseed, v * a.ftotal + a.foff + c, a.fp, a.finv);
@@ -221,53 +258,80 @@ template <typename ST> struct TileBwdDst {
   float fp; float finv; uint64_t fseed; int ftotal; int foff;
 };
 
+constexpr int kSlotPieces = (8 * kCap + kThreads - 1) / kThreads;     // attention words of a tile's slots per thread (2)
+
 template <typename ST, int R>
-__global__ __launch_bounds__(kTileMaxThreads) void gat_bwd_dst_tile(TileBwdDst<ST> a) {
+__global__ __launch_bounds__(kThreads) void gat_bwd_dst_tile(TileBwdDst<ST> a) {
   constexpr int CW = 64 * R;                            // == D
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.seed_off) { a.seed += a.seed_off[0]; a.fseed += a.seed_off[0]; }
   const int64_t n0 = a.tile_ptr[blockIdx.x];
-  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), a.cap);
+  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), kCap);
   if (nt <= 0) return;
   const int h = blockIdx.y;
   const int col0 = h * a.D;
   ST* rows_s = reinterpret_cast<ST*>(smem);
-  float* el_s = reinterpret_cast<float*>(smem + (size_t)a.cap * CW * sizeof(ST));
-  float* er_s = el_s + align4(a.cap);
-  int* ip_s = reinterpret_cast<int*>(er_s + align4(a.cap));
-  int* nbr_s = ip_s + align4(a.cap + 1);
-  float* at_s = reinterpret_cast<float*>(nbr_s + (size_t)a.cap * 8);      // attention words of the tile's slots (this head)
+  float* el_s = reinterpret_cast<float*>(smem + (size_t)kCap * CW * sizeof(ST));
+  float* er_s = el_s + kCap;
+  int* ip_s = reinterpret_cast<int*>(er_s + kCap);
+  int* nbr_s = ip_s + align4(kCap + 1);
+  float* at_s = reinterpret_cast<float*>(nbr_s + kCap * 8);      // attention words of the tile's slots (this head)
+  const int tid = threadIdx.x, lane = tid & (kTeam - 1), team = tid / kTeam;
+  const int ccol = col0 + lane * 4;
 
-  stage_rows<ST, CW>(rows_s, a.ft, a.ft_ld, n0, nt, col0);
-  stage_col(el_s, a.el + h, a.s_ld, n0, nt);
-  stage_col(er_s, a.er + h, a.s_ld, n0, nt);
-  stage_ptr(ip_s, a.indptr, n0, nt);
-  stage_ell(nbr_s, a.nbr8, n0, nt);
+  RowStage<ST, CW> rs;
+  rs.load(a.ft, a.ft_ld, n0, nt, col0);
+  const int ic = min(tid, nt - 1);
+  const float el_v = a.el[(n0 + ic) * a.s_ld + h], er_v = a.er[(n0 + ic) * a.s_ld + h];
+  const int ip_v = a.indptr[n0 + min(tid, nt)];
+  const uint4 nb_v = reinterpret_cast<const uint4*>(a.nbr8 + n0 * 8)[min(tid, 2 * nt - 1)];
   const int s0 = a.indptr[n0];
-  const int ns = min(a.indptr[n0 + nt] - s0, a.cap * 8);
-  for (int j = threadIdx.x; j < ns; j += blockDim.x) at_s[j] = a.attn[(int64_t)(s0 + j) * a.H + h];
+  const int ns = min(a.indptr[n0 + nt] - s0, 8 * kCap);
+  float at_v[kSlotPieces];
+#pragma unroll
+  for (int j = 0; j < kSlotPieces; ++j) at_v[j] = a.attn[(int64_t)(s0 + min(tid + j * kThreads, ns - 1)) * a.H + h];
+  typename Raw<ST>::T gv[kIter][R], ov[kIter][R];
+  const ST* op = a.act != SPGNN_ACT_NONE ? a.out : a.g_out;      // no activation: `out` is not read (a second copy of g_out, unused)
+  const int64_t old_ = a.act != SPGNN_ACT_NONE ? a.out_ld : a.g_out_ld;
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int64_t v = n0 + min(team + it * kTeams, nt - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      gv[it][r] = ld_raw(a.g_out + v * a.g_out_ld + ccol + 64 * r);
+      ov[it][r] = ld_raw(op + v * old_ + ccol + 64 * r);
+    }
+  }
+  rs.store(rows_s, nt);
+  if (tid < nt) { el_s[tid] = el_v; er_s[tid] = er_v; }
+  if (tid <= nt) ip_s[tid] = ip_v;
+  if (tid < 2 * nt) reinterpret_cast<uint4*>(nbr_s)[tid] = nb_v;
+#pragma unroll
+  for (int j = 0; j < kSlotPieces; ++j)
+    if (tid + j * kThreads < ns) at_s[tid + j * kThreads] = at_v[j];
   __syncthreads();
 
-  const int lane = threadIdx.x & (kTeam - 1), team = threadIdx.x / kTeam, nteams = blockDim.x / kTeam;
   const int k = lane & 7;
-
-  for (int i = team; i < nt; i += nteams) {
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int i = team + it * kTeams;
+    if (i >= nt) break;
     const int64_t v = n0 + i;
     const int beg = ip_s[i], deg = ip_s[i + 1] - beg;
     float4 g[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) g[r] = ldv(a.g_out + v * a.g_out_ld + col0 + (r * kTeam + lane) * 4);
+    for (int r = 0; r < R; ++r) g[r] = cvt_raw(gv[it][r]);
     if (a.fp > 0.f) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float4 kf = feat_keep4(a.fseed, v * a.ftotal + a.foff + col0 + (r * kTeam + lane) * 4, a.fp, a.finv);
+        const float4 kf = feat_keep4(a.fseed, v * a.ftotal + a.foff + ccol + 64 * r, a.fp, a.finv);
         g[r].x *= kf.x; g[r].y *= kf.y; g[r].z *= kf.z; g[r].w *= kf.w;
       }
     }
     if (a.act != SPGNN_ACT_NONE) {
       float4 o[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) o[r] = ldv(a.out + v * a.out_ld + col0 + (r * kTeam + lane) * 4);
+      for (int r = 0; r < R; ++r) o[r] = cvt_raw(ov[it][r]);
       if (a.fp > 0.f) {
         const float un = 1.f - a.fp;
 #pragma unroll
@@ -276,7 +340,7 @@ __global__ __launch_bounds__(kTileMaxThreads) void gat_bwd_dst_tile(TileBwdDst<S
       act_bwd_rows<R>(g, o, a.act);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) stv(a.g_pre + v * a.g_pre_ld + col0 + (r * kTeam + lane) * 4, g[r]);
+    for (int r = 0; r < R; ++r) stv(a.g_pre + v * a.g_pre_ld + ccol + 64 * r, g[r]);
     if (!is_f32<ST>::value) {            // the dots must see what the source-major half and the GEMMs read: the ROUNDED g_pre
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -329,7 +393,7 @@ __global__ __launch_bounds__(kTileMaxThreads) void gat_bwd_dst_tile(TileBwdDst<S
         for (int r = 0; r < R; ++r) {
           float4 xr;
           if (ink) xr = lds_ldv(rows_s + ulk * CW + (r * kTeam + lane) * 4);
-          else xr = ldv(a.ft + (int64_t)ug * a.ft_ld + col0 + (r * kTeam + lane) * 4);
+          else xr = ldv(a.ft + (int64_t)ug * a.ft_ld + ccol + 64 * r);
           d += dot4(xr, g[r]);
         }
 #pragma unroll
@@ -382,59 +446,70 @@ template <typename ST> struct TileBwdSrc {
 };
 
 template <typename ST, int R>
-__global__ __launch_bounds__(kTileMaxThreads) void gat_bwd_src_tile(TileBwdSrc<ST> a) {
+__global__ __launch_bounds__(kThreads) void gat_bwd_src_tile(TileBwdSrc<ST> a) {
   constexpr int CW = 64 * R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.seed_off) a.seed += a.seed_off[0];
   const int64_t n0 = a.tile_ptr[blockIdx.x];
-  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), a.cap);
+  const int nt = min((int)(a.tile_ptr[blockIdx.x + 1] - n0), kCap);
   if (nt <= 0) return;
   const int sph = a.D / CW;
   const int h = blockIdx.y / sph, cg = blockIdx.y % sph;
   const int col0 = h * a.D + cg * CW;
   ST* rows_s = reinterpret_cast<ST*>(smem);
-  int* oip_s = reinterpret_cast<int*>(smem + (size_t)a.cap * CW * sizeof(ST));
-  int* onb_s = oip_s + align4(a.cap + 1);
-  int* ops_s = onb_s + (size_t)a.cap * 8;
-  float* at_s = reinterpret_cast<float*>(ops_s + (size_t)a.cap * 8);
-  float* ge_s = at_s + (size_t)a.cap * 8;
+  int* oip_s = reinterpret_cast<int*>(smem + (size_t)kCap * CW * sizeof(ST));
+  int* onb_s = oip_s + align4(kCap + 1);
+  int* ops_s = onb_s + kCap * 8;
+  float* at_s = reinterpret_cast<float*>(ops_s + kCap * 8);
+  float* ge_s = at_s + kCap * 8;
+  const int tid = threadIdx.x, lane = tid & (kTeam - 1), team = tid / kTeam;
+  const int ccol = col0 + lane * 4;
 
-  stage_rows<ST, CW>(rows_s, a.g_pre, a.g_pre_ld, n0, nt, col0);
-  stage_ptr(oip_s, a.out_indptr, n0, nt);
-  stage_ell(onb_s, a.out_nbr8, n0, nt);
-  stage_ell(ops_s, a.out_pos8, n0, nt);
+  RowStage<ST, CW> rs;
+  rs.load(a.g_pre, a.g_pre_ld, n0, nt, col0);
+  const int oip_v = a.out_indptr[n0 + min(tid, nt)];
+  const uint4 onb_v = reinterpret_cast<const uint4*>(a.out_nbr8 + n0 * 8)[min(tid, 2 * nt - 1)];
+  const uint4 ops_v = reinterpret_cast<const uint4*>(a.out_pos8 + n0 * 8)[min(tid, 2 * nt - 1)];
   const int s0 = a.indptr[n0];
-  const int ns = min(a.indptr[n0 + nt] - s0, a.cap * 8);
-  for (int j = threadIdx.x; j < ns; j += blockDim.x) {
-    at_s[j] = a.attn[(int64_t)(s0 + j) * a.H + h];
-    ge_s[j] = a.g_e[(int64_t)(s0 + j) * a.H + h];
+  const int ns = min(a.indptr[n0 + nt] - s0, 8 * kCap);
+  float at_v[kSlotPieces], ge_v[kSlotPieces];
+#pragma unroll
+  for (int j = 0; j < kSlotPieces; ++j) {
+    const int64_t w = (int64_t)(s0 + min(tid + j * kThreads, ns - 1)) * a.H + h;
+    at_v[j] = a.attn[w];
+    ge_v[j] = a.g_e[w];
   }
+  float gerv[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) gerv[it] = a.sc_l ? a.g_er[(n0 + min(team + it * kTeams, nt - 1)) * a.gs_ld + h] : 0.f;
+  float4 scl[R], scr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    scl[r] = a.sc_l ? ld4(a.sc_l + ccol + 64 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    scr[r] = a.sc_l ? ld4(a.sc_r + ccol + 64 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  rs.store(rows_s, nt);
+  if (tid <= nt) oip_s[tid] = oip_v;
+  if (tid < 2 * nt) { reinterpret_cast<uint4*>(onb_s)[tid] = onb_v; reinterpret_cast<uint4*>(ops_s)[tid] = ops_v; }
+#pragma unroll
+  for (int j = 0; j < kSlotPieces; ++j)
+    if (tid + j * kThreads < ns) { at_s[tid + j * kThreads] = at_v[j]; ge_s[tid + j * kThreads] = ge_v[j]; }
   __syncthreads();
 
-  const int lane = threadIdx.x & (kTeam - 1), team = threadIdx.x / kTeam, nteams = blockDim.x / kTeam;
   const int k = lane & 7;
-  const int tbase = (threadIdx.x & 63) & ~(kTeam - 1);
-  float4 scl[R], scr[R];
-  if (a.sc_l) {
+  const int tbase = (tid & 63) & ~(kTeam - 1);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      scl[r] = ld4(a.sc_l + col0 + (r * kTeam + lane) * 4);
-      scr[r] = ld4(a.sc_r + col0 + (r * kTeam + lane) * 4);
-    }
-  }
-
-  for (int i = team; i < nt; i += nteams) {
+  for (int it = 0; it < kIter; ++it) {
+    const int i = team + it * kTeams;
+    if (i >= nt) break;
     const int64_t u = n0 + i;
     const int deg = oip_s[i + 1] - oip_s[i];
-    float ger = 0.f;
-    if (a.sc_l) ger = a.g_er[u * a.gs_ld + h];
     const bool valid = k < deg;
     const int pe = ops_s[i * 8 + k];
     const int pl = pe - s0;
     const int64_t slot = (int64_t)pe * a.H + h;
     float x, gq;
-    const bool ins = (unsigned)pl < (unsigned)ns;
-    if (ins) { x = at_s[pl]; gq = ge_s[pl]; } else { x = a.attn[slot]; gq = a.g_e[slot]; }
+    if ((unsigned)pl < (unsigned)ns) { x = at_s[pl]; gq = ge_s[pl]; } else { x = a.attn[slot]; gq = a.g_e[slot]; }
     if (a.p > 0.f) x *= keep_scale(a.seed, slot, a.p, a.inv_keep);
     const float wv = valid ? x : 0.f;
     const float gel = group8_sum(valid ? gq : 0.f);
@@ -473,19 +548,19 @@ __global__ __launch_bounds__(kTileMaxThreads) void gat_bwd_src_tile(TileBwdSrc<S
         for (int r = 0; r < R; ++r) {
           float4 xr;
           if (ink) xr = lds_ldv(rows_s + vlk * CW + (r * kTeam + lane) * 4);
-          else xr = ldv(a.g_pre + (int64_t)vgk * a.g_pre_ld + col0 + (r * kTeam + lane) * 4);
+          else xr = ldv(a.g_pre + (int64_t)vgk * a.g_pre_ld + ccol + 64 * r);
           fma4(acc[r], wk, xr);
         }
       }
     }
     if (a.sc_l) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) { fma4(acc[r], gel, scl[r]); fma4(acc[r], ger, scr[r]); }
+      for (int r = 0; r < R; ++r) { fma4(acc[r], gel, scl[r]); fma4(acc[r], gerv[it], scr[r]); }
     }
     float amx = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      stv(a.g_ft + u * a.g_ft_ld + col0 + (r * kTeam + lane) * 4, acc[r]);
+      stv(a.g_ft + u * a.g_ft_ld + ccol + 64 * r, acc[r]);
       amx = absmax4(amx, acc[r]);
     }
     if (cg == 0 && lane == 0) a.g_el[u * a.gs_ld + h] = gel;
@@ -506,10 +581,10 @@ template <typename ST> int pick_r(int D, int cap, int budget) {
     if (D % (64 * r) == 0 && (int64_t)cap * 64 * r * (int)sizeof(ST) <= budget) return r;
   return 0;
 }
-int fwd_extra(int cap) { return 4 * (2 * ((cap + 3) & ~3) + ((cap + 4) & ~3) + 8 * cap); }
+int fwd_extra(int cap) { return 4 * (2 * cap + ((cap + 4) & ~3) + 8 * cap); }
 int dst_extra(int cap) { return fwd_extra(cap) + 4 * 8 * cap; }
 int src_extra(int cap) { return 4 * (((cap + 4) & ~3) + 4 * 8 * cap); }
-int pick_threads(int lds_bytes) { return lds_bytes > 48 * 1024 ? 1024 : 512; }
+int pick_threads(int) { return kThreads; }
 
 template <typename K, typename A>
 int launch_tile(K kernel, const A& a, int64_t n_tiles, int slices, int lds, hipStream_t st, const char* name) {
@@ -525,7 +600,7 @@ int gat_fwd_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_tiles
                       int64_t res_stride, const float* bias, ST* out, int64_t out_stride, float* attn, float* absmax, int64_t N,
                       int32_t H, int32_t D, float slope, int32_t act, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                       float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset, hipStream_t st) {
-  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && D >= 64 && D % 64 == 0 && cap >= 1, SPGNN_ERR_SHAPE);
+  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && D >= 64 && D % 64 == 0 && cap >= 1 && cap <= kCap, SPGNN_ERR_SHAPE);
   if (N == 0 || n_tiles == 0) return SPGNN_OK;
   SPGNN_CHECK_ARG(tile_ptr && indptr && nbr8 && ft && el && er && out && attn, SPGNN_ERR_NULLPTR);
   SPGNN_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && out_drop_p >= 0.f && out_drop_p < 1.f, SPGNN_ERR_ENUM);
@@ -534,12 +609,12 @@ int gat_fwd_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_tiles
   SPGNN_CHECK_ARG(ft_stride % al == 0 && out_stride % 4 == 0 && (!res || res_stride % 4 == 0), SPGNN_ERR_STRIDE);
   SPGNN_CHECK_ARG(aligned16(ft) && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (!res || (reinterpret_cast<uintptr_t>(res) & 7) == 0),
                   SPGNN_ERR_STRIDE);
-  const int R = pick_r<ST>(D, cap, 64 * 1024);
+  const int R = pick_r<ST>(D, kCap, 64 * 1024);
   SPGNN_CHECK_ARG(R > 0, SPGNN_ERR_SHAPE);
   TileFwd<ST> a{tile_ptr, indptr, nbr8, ft, ft_stride, el, er, s_stride, res, res_stride, bias, out, out_stride, attn, H, D, cap,
                 slope, act, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, out_drop_p, 1.f / (1.f - out_drop_p), out_drop_seed,
                 out_drop_total, out_drop_offset, absmax};
-  const int lds = cap * 64 * R * (int)sizeof(ST) + fwd_extra(cap);
+  const int lds = kCap * 64 * R * (int)sizeof(ST) + fwd_extra(kCap);
   SPGNN_CHECK_ARG(lds <= kLdsBudget, SPGNN_ERR_SHAPE);
   const int slices = H * D / (64 * R);
   if (R == 4) return launch_tile(gat_fwd_tile<ST, 4>, a, n_tiles, slices, lds, st, name);
@@ -554,7 +629,7 @@ int gat_bwd_dst_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_t
                           int64_t g_pre_stride, float* g_e, float* g_er, int64_t g_s_stride, float* absmax, int64_t N, int32_t H,
                           int32_t D, float slope, int32_t act, float p_drop, uint64_t seed, const uint64_t* seed_offset,
                           float out_drop_p, uint64_t out_drop_seed, int32_t out_drop_total, int32_t out_drop_offset, hipStream_t st) {
-  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && (D == 64 || D == 128 || D == 256) && cap >= 1, SPGNN_ERR_SHAPE);
+  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && (D == 64 || D == 128 || D == 256) && cap >= 1 && cap <= kCap, SPGNN_ERR_SHAPE);
   if (N == 0 || n_tiles == 0) return SPGNN_OK;
   SPGNN_CHECK_ARG(tile_ptr && indptr && nbr8 && ft && el && er && attn && g_out && g_pre && g_e && g_er, SPGNN_ERR_NULLPTR);
   SPGNN_CHECK_ARG(act == SPGNN_ACT_NONE || out, SPGNN_ERR_NULLPTR);
@@ -568,7 +643,7 @@ int gat_bwd_dst_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_t
   TileBwdDst<ST> a{tile_ptr, indptr, nbr8, ft, ft_stride, el, er, s_stride, attn, g_out, g_out_stride, out, out_stride, g_pre,
                    g_pre_stride, g_e, g_er, g_s_stride, absmax, H, D, cap, slope, act, p_drop, 1.f / (1.f - p_drop), seed,
                    seed_offset, out_drop_p, 1.f / (1.f - out_drop_p), out_drop_seed, out_drop_total, out_drop_offset};
-  const int lds = cap * D * (int)sizeof(ST) + dst_extra(cap);
+  const int lds = kCap * D * (int)sizeof(ST) + dst_extra(kCap);
   SPGNN_CHECK_ARG(lds <= kLdsBudget, SPGNN_ERR_SHAPE);
   if (R == 4) return launch_tile(gat_bwd_dst_tile<ST, 4>, a, n_tiles, H, lds, st, name);
   if (R == 2) return launch_tile(gat_bwd_dst_tile<ST, 2>, a, n_tiles, H, lds, st, name);
@@ -581,7 +656,7 @@ int gat_bwd_src_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_t
                           const float* g_e, const ST* g_pre, int64_t g_pre_stride, ST* g_ft, int64_t g_ft_stride, float* g_el,
                           int64_t g_s_stride, float* absmax, const float* score_l, const float* score_r, const float* g_er,
                           int64_t N, int32_t H, int32_t D, float p_drop, uint64_t seed, const uint64_t* seed_offset, hipStream_t st) {
-  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && D >= 64 && D % 64 == 0 && cap >= 1, SPGNN_ERR_SHAPE);
+  SPGNN_CHECK_ARG(N >= 0 && n_tiles >= 0 && H >= 1 && D >= 64 && D % 64 == 0 && cap >= 1 && cap <= kCap, SPGNN_ERR_SHAPE);
   if (N == 0 || n_tiles == 0) return SPGNN_OK;
   SPGNN_CHECK_ARG(tile_ptr && indptr && out_indptr && out_nbr8 && out_pos8 && attn && g_e && g_pre && g_ft && g_el, SPGNN_ERR_NULLPTR);
   SPGNN_CHECK_ARG((score_l == nullptr) == (score_r == nullptr) && (!score_l || g_er), SPGNN_ERR_NULLPTR);
@@ -590,11 +665,11 @@ int gat_bwd_src_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_t
   SPGNN_CHECK_ARG(g_pre_stride % al == 0 && g_ft_stride % 4 == 0, SPGNN_ERR_STRIDE);
   SPGNN_CHECK_ARG(aligned16(g_pre) && (reinterpret_cast<uintptr_t>(g_ft) & 7) == 0 && (!score_l || (aligned16(score_l) && aligned16(score_r))),
                   SPGNN_ERR_STRIDE);
-  const int R = pick_r<ST>(D, cap, 64 * 1024);
+  const int R = pick_r<ST>(D, kCap, 64 * 1024);
   SPGNN_CHECK_ARG(R > 0, SPGNN_ERR_SHAPE);
   TileBwdSrc<ST> a{tile_ptr, indptr, out_indptr, out_nbr8, out_pos8, attn, g_e, g_pre, g_pre_stride, g_ft, g_ft_stride, g_el,
                    g_s_stride, absmax, score_l, score_r, g_er, H, D, cap, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
-  const int lds = cap * 64 * R * (int)sizeof(ST) + src_extra(cap);
+  const int lds = kCap * 64 * R * (int)sizeof(ST) + src_extra(kCap);
   SPGNN_CHECK_ARG(lds <= kLdsBudget, SPGNN_ERR_SHAPE);
   const int slices = H * D / (64 * R);
   if (R == 4) return launch_tile(gat_bwd_src_tile<ST, 4>, a, n_tiles, slices, lds, st, name);
@@ -607,9 +682,9 @@ int gat_bwd_src_tile_impl(const char* name, const int32_t* tile_ptr, int64_t n_t
 extern "C" {
 
 int spgnn_gat_tile_supported(int32_t H, int32_t D, int32_t elem_bytes, int32_t max_tile_nodes) {
-  if (H < 1 || D < 64 || D % 64 || max_tile_nodes < 1 || (elem_bytes != 2 && elem_bytes != 4)) return 0;
+  if (H < 1 || max_tile_nodes < 1 || max_tile_nodes > kCap || (elem_bytes != 2 && elem_bytes != 4)) return 0;
   if (D != 64 && D != 128 && D != 256) return 0;                       // the destination-major half holds a whole head
-  return (int64_t)max_tile_nodes * D * elem_bytes + dst_extra(max_tile_nodes) <= kLdsBudget ? 1 : 0;
+  return (int64_t)kCap * D * elem_bytes + dst_extra(kCap) <= kLdsBudget ? 1 : 0;
 }
 
 #define SPGNN_TILE_FWD_ARGS(ST)                                                                                          \

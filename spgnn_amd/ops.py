@@ -139,21 +139,30 @@ def _ell(csc):
 # --------------------------------------------------------------------------------------------
 # tree-resident LDS tiles (csrc/spgnn_tile.hip)
 # --------------------------------------------------------------------------------------------
-TILE_KERNELS = True      # GATConv traversals of narrow rows as tree-resident LDS tiles (False: the row kernels everywhere; A/B, tests)
-TILE_NODES = 192         # most nodes of a tile: whole trees of up to this many nodes stay closed (airway trees: 100-300 branches)
-TILE_MAX_ROW_BYTES = {4: 1024, 2: 1024}    # bytes per stored element -> widest H*D row (bytes) the tile kernels take over
+TILE_KERNELS = True      # tree-resident LDS tiles where they are measured faster (tile_plan); False: the row kernels everywhere
+TILE_FORCE = False       # tests / tools: every traversal the tile kernels support runs on them, whatever the table says
+TILE_NODES = 192         # most nodes of a tile (the kernels' compile-time capacity): whole trees of up to 192 nodes stay closed
+TILE_MIN_NODES = 32768   # below this a launch is one short round of workgroups either way and the row kernels' 64-node blocks win
+# Where the tiles win (tools/tile_ab.py, MI355X, 512 trees, one process; profiles/r05_tile_ab_*.json).  Only the SOURCE-MAJOR
+# half - the traversal whose every gather is a 4-byte word by CSC slot besides the rows - and mostly on bf16 rows: 2 x 256
+# 43.6 -> 38.5 us, 2 x 128 25.3 -> 23.0, 2 x 64 17.2 -> 16.3; fp32 1 x 64 13.2 -> 11.1.  The forward and the destination-major
+# half LOSE 10-35 % at every shape (their time is the node's own rows streaming in and out plus per-node VALU work - softmax,
+# hashes, activation - which staging the neighbours in LDS does not touch), and at 64 trees everything loses (64 tiles).
+TILE_TABLE = {("src", 2): lambda H, D: True, ("src", 4): lambda H, D: H * D == 64}
 
 
-def tile_plan(csc: DeviceCSC, H: int, D: int, elem_bytes: int):
-    """(tile_ptr, n_tiles, cap) when the three traversals of an (H, D) GATConv layer on ``csc`` run as LDS tiles, else None:
-    every node needs 1..8 edges in both directions and the padded neighbour rows (the tile kernels have no general-degree
-    path), the head must fit the destination-major kernel's LDS (spgnn_gat_tile_supported) and the row must be narrow enough
-    for the tiles to beat the row kernels (TILE_MAX_ROW_BYTES: measured)."""
-    if not TILE_KERNELS or not USE_ELL or csc.num_nodes == 0 or getattr(csc, "num_dst", None) is not None:
+def tile_plan(csc: DeviceCSC, H: int, D: int, elem_bytes: int, kind: str = "src"):
+    """(tile_ptr, n_tiles, cap) when traversal ``kind`` ("fwd" / "dst" / "src") of an (H, D) GATConv layer on ``csc`` runs as
+    LDS tiles (csrc/spgnn_tile.hip), else None: every node needs 1..8 edges in both directions and the padded neighbour rows
+    (the tile kernels have no general-degree path), a head must fit the kernels' LDS (spgnn_gat_tile_supported), and the
+    shape must be one where the tiles are measured faster than the row kernels (TILE_TABLE) unless TILE_FORCE."""
+    if not (TILE_KERNELS or TILE_FORCE) or not USE_ELL or csc.num_nodes == 0 or getattr(csc, "num_dst", None) is not None:
         return None
+    if not TILE_FORCE:
+        use = TILE_TABLE.get((kind, elem_bytes))
+        if use is None or csc.num_nodes < TILE_MIN_NODES or not use(H, D):
+            return None
     if not (1 <= csc.min_in_degree and csc.max_in_degree <= 8 and 1 <= int(getattr(csc, "min_out_degree", 0) or 0) and csc.max_out_degree <= 8):
-        return None
-    if H * D * elem_bytes > TILE_MAX_ROW_BYTES.get(elem_bytes, 0):
         return None
     if not _capi.load().spgnn_gat_tile_supported(H, D, elem_bytes, TILE_NODES):
         return None
@@ -191,7 +200,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
     out_mean = torch.empty((N, D), dtype=torch.float32, device=ft.device) if mean else None
     attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
     lib = _capi.load()
-    plan = None if mean else tile_plan(csc, H, D, 4)
+    plan = None if mean else tile_plan(csc, H, D, 4, "fwd")
     if plan is not None:
         with torch.cuda.device(ft.device), _timed("gat_fwd", (N, E, H, D, int(res is not None), 0, 1)):
             _capi.check(lib.spgnn_gat_fwd_tile(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(), _ell(csc)[0], ft.data_ptr(),
@@ -226,44 +235,41 @@ def gat_bwd_raw(csc: DeviceCSC, ft, el, er, attn, g_out, out, H: int, D: int, sl
     g_e = torch.empty((E, H), dtype=torch.float32, device=ft.device)
     assert g_el.stride(0) == g_er.stride(0)
     lib = _capi.load()
-    plan = None if mean else tile_plan(csc, H, D, 4)
-    if plan is not None:
-        with torch.cuda.device(ft.device):
-            st = _stream(ft)
-            ell = _ell(csc)
-            with _timed("gat_bwd_dst", (N, E, H, D, act, 0)):
-                _capi.check(lib.spgnn_gat_bwd_dst_tile(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(), ell[0], ft.data_ptr(),
+    plan_d = None if mean else tile_plan(csc, H, D, 4, "dst")
+    plan_s = tile_plan(csc, H, D, 4, "src")
+    with torch.cuda.device(ft.device):
+        st = _stream(ft)
+        ell = _ell(csc)
+        with _timed("gat_bwd_dst", (N, E, H, D, act, int(mean))):
+            if plan_d is not None:
+                _capi.check(lib.spgnn_gat_bwd_dst_tile(plan_d[0].data_ptr(), plan_d[1], plan_d[2], csc.indptr.data_ptr(), ell[0], ft.data_ptr(),
                                                        ft.stride(0), el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
                                                        g_out.data_ptr(), g_out.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
                                                        g_pre.data_ptr(), g_pre.stride(0), g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0),
                                                        _ptr(absmax) if absmax_dst else 0, N, H, D, slope, act, p_drop, seed,
                                                        _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), st), "spgnn_gat_bwd_dst_tile")
-            with _timed("gat_bwd_src", (N, E, H, D)):
-                _capi.check(lib.spgnn_gat_bwd_src_tile(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(), csc.out_indptr.data_ptr(),
+            else:
+                _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), ell[0], ft.data_ptr(), ft.stride(0),
+                                                  el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
+                                                  g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
+                                                  out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
+                                                  g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax) if absmax_dst else 0, N, E, H, D, slope,
+                                                  act, p_drop, seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), st),
+                            "spgnn_gat_bwd_dst")
+        with _timed("gat_bwd_src", (N, E, H, D)):
+            if plan_s is not None:
+                _capi.check(lib.spgnn_gat_bwd_src_tile(plan_s[0].data_ptr(), plan_s[1], plan_s[2], csc.indptr.data_ptr(), csc.out_indptr.data_ptr(),
                                                        ell[1], ell[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(), g_pre.stride(0),
                                                        g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(), g_el.stride(0), _ptr(absmax),
                                                        _ptr(score_l), _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, H, D,
                                                        p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src_tile")
-        return g_e
-    with torch.cuda.device(ft.device):
-        st = _stream(ft)
-        t_dst = _timed("gat_bwd_dst", (N, E, H, D, act, int(mean))).__enter__()
-        _capi.check(lib.spgnn_gat_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], ft.data_ptr(), ft.stride(0),
-                                          el.data_ptr(), er.data_ptr(), el.stride(0), attn.data_ptr(),
-                                          g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
-                                          out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
-                                          g_e.data_ptr(), g_er.data_ptr(), g_er.stride(0), _ptr(absmax) if absmax_dst else 0, N, E, H, D, slope,
-                                          act, p_drop, seed, _seed_off_ptr(ft.device), *(out_drop or (0.0, 0, 0, 0)), st),
-                    "spgnn_gat_bwd_dst")
-        t_dst.__exit__()
-        t_src = _timed("gat_bwd_src", (N, E, H, D)).__enter__()
-        _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                          csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
-                                          g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
-                                          g_el.stride(0), _ptr(absmax), _ptr(score_l),
-                                          _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, E, H, D,
-                                          p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src")
-        t_src.__exit__()
+            else:
+                _capi.check(lib.spgnn_gat_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                  csc.out_pos.data_ptr(), ell[1], ell[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                                  g_pre.stride(0), g_ft.data_ptr(), g_ft.stride(0), g_el.data_ptr(),
+                                                  g_el.stride(0), _ptr(absmax), _ptr(score_l),
+                                                  _ptr(score_r), g_er.data_ptr() if score_l is not None else 0, N, E, H, D,
+                                                  p_drop, seed, _seed_off_ptr(ft.device), st), "spgnn_gat_bwd_src")
     return g_e
 
 

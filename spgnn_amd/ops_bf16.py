@@ -260,7 +260,7 @@ def gat_fwd_raw(csc: DeviceCSC, ft, el, er, res, bias, H: int, D: int, slope: fl
     out = None if skip_out else torch.empty((N, H * D), dtype=BF16, device=ft.device)
     out_mean = torch.empty((N, D), dtype=torch.float32, device=ft.device) if fuse else None
     attn = torch.empty((E, H), dtype=torch.float32, device=ft.device)
-    plan = None if (mean or out is None) else _ops.tile_plan(csc, H, D, 2)
+    plan = None if (mean or out is None) else _ops.tile_plan(csc, H, D, 2, "fwd")
     if plan is not None:                        # tree-resident LDS tiles (csrc/spgnn_tile.hip): narrow rows
         with torch.cuda.device(ft.device), _timed("gat_fwd_bf16", (N, E, H, D, int(res is not None), 0, 1)):
             _capi.check(lib.spgnn_gat_fwd_tile_bf16(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(), _ell(csc)[0], ft.data_ptr(),
@@ -342,40 +342,39 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         g_pre = g_y[:, HD:] if has_res else torch.empty((N, HD), dtype=BF16, device=x.device)
         g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
         lib = _capi.load()
-        plan = None if mean else _ops.tile_plan(csc, H, D, 2)
-        if plan is not None:
-            with torch.cuda.device(x.device):
-                st = _stream(x)
-                ell = _ell(csc)
-                with _timed("gat_bwd_dst_bf16", (N, E, H, D, act, 0)):
-                    _capi.check(lib.spgnn_gat_bwd_dst_tile_bf16(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(), ell[0], y.data_ptr(),
-                                                                y.stride(0), s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
-                                                                g_out.data_ptr(), g_out.stride(0), _ptr(out),
+        plan_d = None if mean else _ops.tile_plan(csc, H, D, 2, "dst")
+        plan_s = _ops.tile_plan(csc, H, D, 2, "src")        # tree-resident LDS tiles where they are faster (ops.TILE_TABLE)
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            ell = _ell(csc)
+            with _timed("gat_bwd_dst_bf16", (N, E, H, D, act, int(mean))):
+                if plan_d is not None:
+                    _capi.check(lib.spgnn_gat_bwd_dst_tile_bf16(plan_d[0].data_ptr(), plan_d[1], plan_d[2], csc.indptr.data_ptr(), ell[0],
+                                                                y.data_ptr(), y.stride(0), s.data_ptr(), s[:, H:].data_ptr(), s.stride(0),
+                                                                attn.data_ptr(), g_out.data_ptr(), g_out.stride(0), _ptr(out),
                                                                 out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                                                 g_e.data_ptr(), g_s[:, H:].data_ptr(), g_s.stride(0), 0, N, H, D, slope, act,
                                                                 p_drop, seed, _seed_off_ptr(x.device), *(ctx.out_drop or (0.0, 0, 0, 0)), st),
                                 "spgnn_gat_bwd_dst_tile_bf16")
-                with _timed("gat_bwd_src_bf16", (N, E, H, D)):
-                    _capi.check(lib.spgnn_gat_bwd_src_tile_bf16(plan[0].data_ptr(), plan[1], plan[2], csc.indptr.data_ptr(),
-                                                                csc.out_indptr.data_ptr(), ell[1], ell[2], attn.data_ptr(), g_e.data_ptr(),
-                                                                g_pre.data_ptr(), g_pre.stride(0), g_y.data_ptr(), g_y.stride(0),
-                                                                g_s.data_ptr(), g_s.stride(0), 0, al.data_ptr(), ar.data_ptr(),
-                                                                g_s[:, H:].data_ptr(), N, H, D, p_drop, seed, _seed_off_ptr(x.device), st),
-                                "spgnn_gat_bwd_src_tile_bf16")
-        if plan is None:
-            with torch.cuda.device(x.device):
-                st = _stream(x)
-                with _timed("gat_bwd_dst_bf16", (N, E, H, D, act, int(mean))):
-                    _capi.check(lib.spgnn_gat_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), _ell(csc)[0], y.data_ptr(), y.stride(0),
+                else:
+                    _capi.check(lib.spgnn_gat_bwd_dst_bf16(csc.indptr.data_ptr(), csc.indices.data_ptr(), ell[0], y.data_ptr(), y.stride(0),
                                                            s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
                                                            g_out.data_ptr(), g_out.stride(0), int(mean), _ptr(out),
                                                            out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
                                                            g_e.data_ptr(), g_s[:, H:].data_ptr(), g_s.stride(0), N, E, H, D, slope, act,
                                                            p_drop, seed, _seed_off_ptr(x.device), *(ctx.out_drop or (0.0, 0, 0, 0)), st),
                                 "spgnn_gat_bwd_dst_bf16")
-                with _timed("gat_bwd_src_bf16", (N, E, H, D)):
+            with _timed("gat_bwd_src_bf16", (N, E, H, D)):
+                if plan_s is not None:
+                    _capi.check(lib.spgnn_gat_bwd_src_tile_bf16(plan_s[0].data_ptr(), plan_s[1], plan_s[2], csc.indptr.data_ptr(),
+                                                                csc.out_indptr.data_ptr(), ell[1], ell[2], attn.data_ptr(), g_e.data_ptr(),
+                                                                g_pre.data_ptr(), g_pre.stride(0), g_y.data_ptr(), g_y.stride(0),
+                                                                g_s.data_ptr(), g_s.stride(0), 0, al.data_ptr(), ar.data_ptr(),
+                                                                g_s[:, H:].data_ptr(), N, H, D, p_drop, seed, _seed_off_ptr(x.device), st),
+                                "spgnn_gat_bwd_src_tile_bf16")
+                else:
                     _capi.check(lib.spgnn_gat_bwd_src_bf16(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                                           csc.out_pos.data_ptr(), _ell(csc)[1], _ell(csc)[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
+                                                           csc.out_pos.data_ptr(), ell[1], ell[2], attn.data_ptr(), g_e.data_ptr(), g_pre.data_ptr(),
                                                            g_pre.stride(0), g_y.data_ptr(), g_y.stride(0), g_s.data_ptr(),
                                                            g_s.stride(0), al.data_ptr(), ar.data_ptr(), g_s[:, H:].data_ptr(), N, E, H, D,
                                                            p_drop, seed, _seed_off_ptr(x.device), st), "spgnn_gat_bwd_src_bf16")

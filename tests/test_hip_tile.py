@@ -57,13 +57,20 @@ def _run_fp32(csc, y, s, bias, g_out, H, D, act, p, od, score):
 def test_fp32_tile_kernels_equal_the_row_kernels(H, D, act, p, od, score, monkeypatch):
     g, n = _graph([150, 23, 1, 180, 64, 121, 7], seed=H * 100 + D)
     csc = g.csc("cuda")
-    assert ops.tile_plan(csc, H, D, 4) is not None
+    monkeypatch.setattr(ops, "TILE_FORCE", True)
+    assert all(ops.tile_plan(csc, H, D, 4, kind) is not None for kind in ("fwd", "dst", "src"))
     y, s, bias, g_out = _inputs(n, H, D, torch.float32, seed=5)
-    monkeypatch.setattr(ops, "TILE_KERNELS", False)
+    monkeypatch.setattr(ops, "TILE_FORCE", False); monkeypatch.setattr(ops, "TILE_KERNELS", False)
     ref = _run_fp32(csc, y, s, bias, g_out, H, D, act, p, od, score)
-    monkeypatch.setattr(ops, "TILE_KERNELS", True)
+    monkeypatch.setattr(ops, "TILE_FORCE", True)
     got = _run_fp32(csc, y, s, bias, g_out, H, D, act, p, od, score)
     HD = H * D
+    if H == 4:
+        # four heads of 64 columns: the row kernel takes its whole-table softmax (a head narrower than its 64-lane team), whose
+        # exp sum runs over the slots in order instead of pairwise: attention equal to fp32 rounding, not to the bit
+        assert rel_err(got["out"], ref["out"]) < 1e-6 and rel_err(got["attn"], ref["attn"]) < 1e-6
+        assert rel_err(got["g_y"], ref["g_y"]) < 2e-6 and rel_err(got["g_e"], ref["g_e"]) < 2e-6 and rel_err(got["g_s"], ref["g_s"]) < 2e-6
+        return
     assert torch.equal(got["out"], ref["out"]) and torch.equal(got["attn"], ref["attn"])          # forward: bit-identical
     assert torch.equal(got["blk"], ref["blk"])                                                     # ... and the same scale maxima
     assert torch.equal(got["g_y"][:, HD:], ref["g_y"][:, HD:])                                     # g_pre: elementwise, bit-identical
@@ -81,9 +88,9 @@ def test_tiles_that_split_trees_give_the_same_results(cap, monkeypatch):
     g, n = _graph([150, 90, 33, 170], seed=9)
     csc = g.csc("cuda")
     y, s, bias, g_out = _inputs(n, H, D, torch.float32, seed=6)
-    monkeypatch.setattr(ops, "TILE_KERNELS", False)
+    monkeypatch.setattr(ops, "TILE_FORCE", False); monkeypatch.setattr(ops, "TILE_KERNELS", False)
     ref = _run_fp32(csc, y, s, bias, g_out, H, D, ops.ACT_ELU, 0.1, 0.1, True)
-    monkeypatch.setattr(ops, "TILE_KERNELS", True)
+    monkeypatch.setattr(ops, "TILE_FORCE", True)
     monkeypatch.setattr(ops, "TILE_NODES", cap)
     t, n_tiles = csc.tiles(cap)
     tp = t.cpu().numpy()
@@ -117,7 +124,8 @@ def test_bf16_layer_on_tiles_equals_the_row_kernels(H, D, act, drop, monkeypatch
     BF = torch.bfloat16
     g, n = _graph([150, 23, 180, 64, 121, 7, 1], seed=H + D)
     csc = g.csc("cuda")
-    assert ops.tile_plan(csc, H, D, 2) is not None
+    monkeypatch.setattr(ops, "TILE_FORCE", True)
+    assert all(ops.tile_plan(csc, H, D, 2, kind) is not None for kind in ("fwd", "dst", "src"))
     K = 128
     torch.manual_seed(D)
     x0 = torch.randn(n, K, device="cuda").to(BF)
@@ -130,6 +138,7 @@ def test_bf16_layer_on_tiles_equals_the_row_kernels(H, D, act, drop, monkeypatch
     res = {}
     for tiles in (False, True):
         monkeypatch.setattr(ops, "TILE_KERNELS", tiles)
+        monkeypatch.setattr(ops, "TILE_FORCE", tiles)
         ps = [t.clone().requires_grad_(True) for t in (w_fc, w_res, al, ar, bias)]
         x = x0.clone().requires_grad_(True)
         out, attn = ops_bf16._GATLayerBf16Fn.apply(x, ps[0], ps[1], ps[2], ps[3], ps[4], csc, H, D, 0.2, act, drop, 99, False,
@@ -166,3 +175,16 @@ def test_arena_rewrites_the_tile_table_in_place():
     real = [x for x in second if x <= b.number_of_nodes()]
     assert all(x in cuts_b for x in real)                                      # this batch's boundaries, not the first one's
     assert not np.array_equal(first, second)
+
+
+def test_the_default_table_puts_only_the_measured_winners_on_tiles():
+    """ops.TILE_TABLE (tools/tile_ab.py, profiles/r05_tile_ab_*.json): the source-major half on bf16 rows and on 64-column fp32
+    rows, for batches of at least TILE_MIN_NODES nodes; everything else stays on the row kernels."""
+    g = synthetic.make_batch(256, rank=0, device="cuda", pos_enc_dim=None, fv_dim=8)
+    csc = g.csc("cuda")
+    assert csc.num_nodes >= ops.TILE_MIN_NODES
+    assert ops.tile_plan(csc, 2, 64, 2, "src") is not None and ops.tile_plan(csc, 2, 256, 2, "src") is not None
+    assert ops.tile_plan(csc, 1, 64, 4, "src") is not None and ops.tile_plan(csc, 2, 64, 4, "src") is None
+    assert ops.tile_plan(csc, 2, 64, 2, "fwd") is None and ops.tile_plan(csc, 2, 64, 2, "dst") is None
+    small = synthetic.make_batch(8, rank=0, device="cuda", pos_enc_dim=None, fv_dim=8).csc("cuda")
+    assert ops.tile_plan(small, 2, 64, 2, "src") is None
