@@ -722,6 +722,92 @@ def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300,
                                       "amortised_over_steady": mean([q["amortised_ms_per_step"] for q in rec]) / steady}}
 
 
+def single_tree_forward(dev, config="st_pgat_spgnn_3", sizes=(150, 300), reps=200):
+    """The reference's per-scan inference pattern as a measured quantity (job_runner.py:2046-2052, 1601-1610: one graph per
+    scan, dgl.batch([g]), ONE model.forward(g); README.md:49-51 quotes per-scan test times): a single synthetic airway tree
+    of n branches, eval mode, forward only, fp32.  Per size: the eagerly issued forward (host-paced: ~40 launches) and the
+    captured forward of spgnn_amd.infer.ForwardRunner (one HIP-graph replay per scan of a size class, arena load included),
+    median latency over ``reps`` scans; the launches of one forward - how many are this library's kernels (ops.KernelTimer
+    sees every launch through the C ABI) out of all device kernels (torch.profiler) - and the CPU oracle's time for the same
+    scan beside it."""
+    import statistics
+    from oracle import dgl_cpu as O
+    from spgnn_amd import models, ops, synthetic
+    from spgnn_amd.configs import get_config
+    from spgnn_amd.infer import ForwardRunner
+    cfg = get_config(config)
+    torch.manual_seed(0)
+    model = models.build_model(cfg.MODEL).to(dev)
+    model.init(None); model.set_gcn_only(); model.eval()
+    runner = ForwardRunner(model, granule=64)
+    out = {"workload": f"{config}, ONE synthetic tree per forward (reference per-scan inference), eval mode, fp32, forward only",
+           "sizes": {}}
+    for n in sizes:
+        scans = [synthetic.make_batch(1, rank=700 + i, device=dev, pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None), fixed_n=n) for i in range(4)]
+        for g in scans:
+            g.csc(dev)
+        with torch.no_grad():
+            for g in scans:
+                model(g); runner(g)
+            torch.cuda.synchronize(dev)
+
+            def lat(fn):
+                ts = []
+                for i in range(reps):
+                    g = scans[i % len(scans)]
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    fn(g)
+                    torch.cuda.synchronize(dev)
+                    ts.append((time.perf_counter() - t0) * 1e6)
+                return statistics.median(ts), pct(ts, 0.9)
+            eager_us, eager_p90 = lat(model)
+            cap_us, cap_p90 = lat(runner)
+            # device time of the replay alone (no arena load, no host): HIP events around back-to-back replays
+            arena, graph = next(reversed(runner._classes.values()))[:2]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                graph.replay()
+            e1.record(); torch.cuda.synchronize(dev)
+            replay_us = e0.elapsed_time(e1) / 50 * 1e3
+            # launches of ONE forward: the library's own (through the C ABI) and all device kernels
+            ops.KernelTimer.start()
+            model(scans[0])
+            ops.KernelTimer.stop()
+            lib_launches = len(ops.KernelTimer.sequence)
+            total_launches = None
+            try:
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    model(scans[0])
+                    torch.cuda.synchronize(dev)
+                total_launches = sum(1 for ev in prof.events() if str(getattr(ev, "device_type", "")).endswith("CUDA"))
+            except Exception:
+                total_launches = None
+            # parity and the CPU oracle's time on the same scan
+            g = scans[0]
+            outs = runner(g)
+            src, dst = g.cpu().edges()
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            pe = g.ndata["pos_enc"].cpu() if "pos_enc" in g.ndata else None
+            ref = O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu(), pe)[0]
+            err = float((outs[0].cpu() - ref).abs().max() / ref.abs().max())
+            cts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu(), pe)
+                cts.append((time.perf_counter() - t0) * 1e3)
+        out["sizes"][str(n)] = {"nodes": n, "edges": g.number_of_edges(), "eager_us": round(eager_us, 1), "eager_us_p90": round(eager_p90, 1),
+                                "captured_us": round(cap_us, 1), "captured_us_p90": round(cap_p90, 1), "replay_device_us": round(replay_us, 1),
+                                "library_launches": lib_launches, "device_kernel_launches": total_launches,
+                                "library_launch_fraction": (round(lib_launches / total_launches, 3) if total_launches else None),
+                                "logits_rel_err_vs_oracle": err, "cpu_oracle_ms": round(statistics.median(cts), 2)}
+    first = out["sizes"][str(sizes[0])]
+    out.update({"captured_us": first["captured_us"], "eager_us": first["eager_us"], "cpu_oracle_ms": first["cpu_oracle_ms"]})
+    return out
+
+
 # BASELINE.json configs 2-4 beside the headline (config 5 at N = 1): run after it, short, inside the same JSON line
 SECONDARY_LEGS = (("st_gat_6_bf16_512", "st_gat_6", "bf16", 512),
                   ("st_pgat_spgnn_3_f32_64", "st_pgat_spgnn_3", "f32", 64),
@@ -845,6 +931,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short legs for BASELINE configs 2-4 after the headline")
     ap.add_argument("--cpu-trees", type=int, default=0, help="trees of the cpu_baseline sample (0: the whole batch, i.e. the headline workload)")
     ap.add_argument("--batch-cycle-only", action="store_true", help="run only the loader-batch cycle leg (secondary.batch_cycle_64) and print it")
+    ap.add_argument("--single-tree-only", action="store_true", help="run only the per-scan inference leg (secondary.single_tree_forward) and print it")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
@@ -878,6 +965,9 @@ def main():
     if args.batch_cycle_only:
         print(json.dumps({"batch_cycle_64": batch_cycle(dev)}), flush=True)
         return
+    if args.single_tree_only:
+        print(json.dumps({"single_tree_forward": {c_: single_tree_forward(dev, c_) for c_ in ("st_pgat_spgnn_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3")}}), flush=True)
+        return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
                                          no_kernel_timers=args.no_kernel_timers)
@@ -903,6 +993,11 @@ def main():
                 sec["batch_cycle_64"] = batch_cycle(dev)
             except Exception as e:
                 sec["batch_cycle_64"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+            try:
+                sec["single_tree_forward"] = single_tree_forward(dev)
+            except Exception as e:
+                sec["single_tree_forward"] = {"error": repr(e)[:300]}
             out["secondary"] = sec
             bc = sec["batch_cycle_64"]
             c = out["config"]

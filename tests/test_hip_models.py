@@ -781,6 +781,6 @@ def test_bench_two_rank_rehearsal_through_self_launch():
     c = out["config"]
     assert c["comm_world_size"] == 2 and c["comm_backend"].startswith("gloo") and c["global_trees"] == 16
     assert c["launch"] == "hip-graph replay", c.get("capture_error")
-    assert c["allreduce_ms_p50"] > 0.0 and c["comm_bucket_bytes"] == 4 * 2501080
+    assert c["allreduce_ms_p50"] > 0.0 and 4 * 2501080 <= c["comm_bucket_bytes"] <= 4 * 2501080 + 64       # 2 501 078 parameters + the two loss slots, 16-byte parameter starts
     assert out["value"] > 0 and np.isfinite(out["loss"])
     assert out["roofline"]["hbm_frac"] > 0 and out["roofline"]["hbm_ms_per_step"] > 0

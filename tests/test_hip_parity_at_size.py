@@ -87,47 +87,67 @@ def _assert_gradients(model, sd, sd64, gtol, only=None):
     return worst
 
 
-def _gin_flipped_units(model, g):
-    """st_gin_3: per GINConv layer, the output units whose LeakyReLU branch in the HIP forward differs from an fp64 evaluation
-    of the same layer stack (plain torch on the GPU; reference models.py:358-383: mean aggregation incl. the self loop,
-    (1 + eps) x + agg, Linear -> LeakyReLU -> Linear -> LeakyReLU in eval mode) -> [(layer, count, max |pre64| / rms)]."""
-    layers = list(model.gin.gin_layers)
-    outs = []
-    hooks = [l.register_forward_hook(lambda m, i, o: outs.append((o[0] if isinstance(o, tuple) else o).detach())) for l in layers]
-    with torch.no_grad():
-        model(g)
-    for h in hooks:
-        h.remove()
-    src, dst = g.edges()
-    src, dst = src.long(), dst.long()
-    x = g.ndata["fvs"].double()
-    deg = torch.zeros(x.shape[0], dtype=torch.float64, device=x.device).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float64))
-    found = []
-    for li, (l, o) in enumerate(zip(layers, outs)):
-        f = l.apply_func
-        agg = torch.zeros_like(x).index_add_(0, dst, x[src]) / deg.clamp(min=1)[:, None]
-        h = (1 + l.eps.double()) * x + agg
-        h = torch.nn.functional.leaky_relu(h @ f[0].weight.double().t() + f[0].bias.double(), 0.01)
-        pre = h @ f[3].weight.double().t() + f[3].bias.double()
-        flips = (o > 0) != (pre > 0)
-        n = int(flips.sum())
-        found.append((li, n, float(pre[flips].abs().max() / pre.pow(2).mean().sqrt()) if n else 0.0))
-        x = torch.nn.functional.leaky_relu(pre, 0.01)
-    return found
+class _Gin64:
+    """st_gin_3's head + classifier + loss in fp64 on the GPU in plain torch, with the branch of chosen LeakyReLU units
+    TOGGLED (reference models.py:343-400, 358-383: GINConv 'mean' incl. the self loop, (1 + eps) x + agg, Linear -> [Dropout,
+    eval: identity] -> LeakyReLU -> Linear -> LeakyReLU; gnn_out models.py:988; loss job_runner.py:1400).  Test infrastructure:
+    pinned to oracle/dgl_cpu.py by comparing its untoggled gradients with the CPU oracle's in the test."""
+
+    def __init__(self, model, g, y, mask, w):
+        self.names = [n for n, p in model.named_parameters() if p.requires_grad and (n.startswith("gin.") or n.startswith("gnn_out."))]
+        self.p = {n: q.detach().double() for n, q in model.named_parameters() if n in self.names}
+        src, dst = g.edges()
+        self.src, self.dst = src.long(), dst.long()
+        self.x0 = g.ndata["fvs"].double()
+        self.deg = torch.zeros(self.x0.shape[0], dtype=torch.float64, device=self.x0.device).index_add_(
+            0, self.dst, torch.ones_like(self.dst, dtype=torch.float64)).clamp(min=1)[:, None]
+        self.y, self.mask, self.w = y.cuda(), mask.cuda(), w.double().cuda()
+        self.layers = len(model.gin.gin_layers)
+
+    def run(self, toggles=()):
+        """-> ({name: grad}, [(layer, stage, pre-activation)]); ``toggles``: (layer, stage, flat unit index) whose branch is
+        the OTHER one than the sign of its fp64 pre-activation."""
+        P = {n: q.clone().requires_grad_(True) for n, q in self.p.items()}
+        tog = {}
+        for (l, st, idx) in toggles:
+            tog.setdefault((l, st), []).append(idx)
+        pres = []
+
+        def lrelu(v, key):
+            pos = v > 0
+            if key in tog:
+                flat = pos.clone().view(-1)
+                ii = torch.tensor(tog[key], device=v.device)
+                flat[ii] = ~flat[ii]
+                pos = flat.view_as(pos)
+            pres.append((key[0], key[1], v.detach()))
+            return torch.where(pos, v, 0.01 * v)
+        x = self.x0
+        for l in range(self.layers):
+            pre = f"gin.gin_layers.{l}."
+            agg = torch.zeros_like(x).index_add_(0, self.dst, x[self.src]) / self.deg
+            h = (1 + P[pre + "eps"]) * x + agg
+            h = lrelu(h @ P[pre + "apply_func.0.weight"].t() + P[pre + "apply_func.0.bias"], (l, 0))
+            x = lrelu(h @ P[pre + "apply_func.3.weight"].t() + P[pre + "apply_func.3.bias"], (l, 1))
+        logits = x @ P["gnn_out.weight"].t() + P["gnn_out.bias"]
+        lp = torch.log_softmax(logits, 1)
+        wy = self.w[self.y] * self.mask.double()
+        loss = -(wy * lp.gather(1, self.y[:, None])[:, 0]).sum() / wy.sum()
+        grads = torch.autograd.grad(loss, [P[n] for n in self.names])
+        return {n: q.detach() for n, q in zip(self.names, grads)}, pres
 
 
-def test_gin_gradients_at_64_trees_hold_the_bar_outside_the_leaky_relu_kink(monkeypatch):
-    """VERDICT r4 item 6 / ADVICE r4: GIN's gradients were bounded at 1e-2 at this size because LeakyReLU's derivative jumps at
-    zero and one or two of the 2.5 M hidden units of a 64-tree batch sit within 1e-8 of it - a bound that would also hide a
-    real indexing error.  Now: (1) the flipped units are FOUND (HIP output sign vs an fp64 evaluation), there are at most a
-    handful and each has |pre| < 1e-6 rms - so a flip is conditioning, not a kernel error; (2) every parameter the flipped
-    units cannot reach - the layers AFTER the last flipped one and the classifier: their gradients depend on the forward
-    values and on the signal from the loss only - holds 1e-4 in the default form; (3) in the products' wide-range form
-    (ops.GEMM_WIDE; same traversal, activation and reduction kernels, another rounding of the products), which keeps these
-    units' branches, EVERY gradient holds 1e-4 (measured <= 8e-6)."""
+def test_gin_gradients_at_64_trees_equal_the_oracle_up_to_identified_leaky_relu_branches(monkeypatch):
+    """VERDICT r4 item 6 / ADVICE r4.  GIN's gradients were bounded at 1e-2 at this size: LeakyReLU's derivative jumps at zero,
+    a 64-tree batch has 22 M LeakyReLU units, a handful of them sit within 1e-6 rms of zero, and an fp32 evaluation in another
+    summation order takes the other branch there - each such unit moves the gradients behind it by up to a few 1e-3.  A 1e-2
+    bound would also hide a real indexing error, so the comparison is now EXACT about the branches: the ambiguous units are
+    enumerated from the fp64 pre-activations (|pre| < 3e-6 rms: a few dozen), the gradient change of toggling each ONE is
+    computed in fp64 (a unit's effect is additive to second order), the subset the HIP evaluation took is fitted greedily, and
+    every parameter's gradient must then agree at 1e-4 - in the default form of the split products and in the wide-range one.
+    Nothing but the branch of those specific units can be explained away: an indexing error is not in their span."""
     from spgnn_amd import ops
-    name = "st_gin_3"
-    cfg, model = _build(name, seed=11)
+    cfg, model = _build("st_gin_3", seed=11)
     g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=None)
     w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
     y = g.ndata["y"]
@@ -136,38 +156,60 @@ def test_gin_gradients_at_64_trees_hold_the_bar_outside_the_leaky_relu_kink(monk
     O.masked_weighted_ce(refs[0], y.cpu(), mask, w).backward()
     refs64, sd64 = _oracle(cfg, model, g, dtype=torch.float64, grad=True)
     O.masked_weighted_ce(refs64[0], y.cpu(), mask, w.double()).backward()
+    # the fp64 restatement used for the toggles IS the oracle: untoggled, its gradients equal the CPU fp64 oracle's
+    net = _Gin64(model, g, y, mask, w)
+    g0, pres = net.run()
+    for n in net.names:
+        assert rel_err(g0[n], sd64[n].grad) < 1e-9, n
+    # ambiguous units: within 3e-6 rms of the kink (HIP's fp32 pre-activations are ~1e-7 relative off the fp64 ones)
+    amb = []
+    for (l, st, pre) in pres:
+        rms = pre.pow(2).mean().sqrt()
+        idx = torch.nonzero((pre.abs() < 3e-6 * rms).view(-1))[:, 0].tolist()
+        amb += [(l, st, i) for i in idx]
+    print(f"st_gin_3 64 trees: {sum(p_[2].numel() for p_ in pres) / 1e6:.1f} M LeakyReLU units, {len(amb)} within 3e-6 rms of zero "
+          f"(per layer/stage: {sorted({(l, st): sum(1 for a in amb if a[:2] == (l, st)) for (l, st, _) in amb}.items())})")
+    assert len(amb) <= 400
+    deltas = []
+    for a in amb:
+        gi, _ = net.run([a])
+        deltas.append({n: gi[n] - g0[n] for n in net.names})
+    scale = {n: float(g0[n].abs().max()) + 1e-300 for n in net.names}
 
-    def run():
+    def fit_and_check(tag):
         model.zero_grad(set_to_none=True)
         outs = model(g)
-        loss = masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda())
-        loss.backward()
-        return outs, loss
+        masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda()).backward()
+        assert rel_err(outs[0], refs[0]) < TOL
+        got = {n: dict(model.named_parameters())[n].grad.double() for n in net.names}
+        res = {n: got[n] - g0[n] for n in net.names}
+        norm = lambda r: sum(float((r[n] / scale[n]).pow(2).sum()) for n in net.names)
+        raw = max(float(res[n].abs().max()) / scale[n] for n in net.names)
+        taken = []
+        for _ in range(3):                               # greedy, a few sweeps: toggle a unit whenever that shrinks the residual
+            changed = False
+            for i, d in enumerate(deltas):
+                sign = -1.0 if i in taken else 1.0
+                trial = {n: res[n] - sign * d[n] for n in net.names}
+                if norm(trial) < norm(res) * (1 - 1e-9):
+                    res = trial
+                    taken.remove(i) if i in taken else taken.append(i)
+                    changed = True
+            if not changed:
+                break
+        worst = max(float(res[n].abs().max()) / scale[n] for n in net.names)
+        print(f"   {tag}: worst gradient error vs fp64 {raw:.2e} before, {worst:.2e} after fitting the branches of {len(taken)} unit(s) "
+              f"{[amb[i][:2] for i in taken]}")
+        for n in net.names:
+            e = float(res[n].abs().max()) / scale[n]
+            assert e < 1e-4, (tag, n, e)
+        # every other trainable parameter (none for this model) keeps the plain rule
+        _assert_gradients(model, sd, sd64, 1e-4, only=lambda pn: pn not in net.names)
+        return raw
 
-    # default (narrow) form
-    flips = _gin_flipped_units(model, g)
-    outs, loss = run()
-    assert rel_err(outs[0], refs[0]) < TOL and rel_err(loss, O.masked_weighted_ce(refs[0], y.cpu(), mask, w)) < TOL
-    total = sum(n for _, n, _ in flips)
-    print(f"st_gin_3 64 trees, default form: LeakyReLU branch flips per layer {[(li, n, f'{r:.1e}') for li, n, r in flips]}")
-    assert total <= 8 and all(r < 1e-6 for _, _, r in flips), flips
-    last = max([li for li, n, _ in flips if n], default=-1)
-    clean = lambda pn: not pn.startswith("gin.gin_layers.") or int(pn.split(".")[2]) > last
-    worst_clean = _assert_gradients(model, sd, sd64, 1e-4, only=clean)
-    worst_all = _assert_gradients(model, sd, sd64, 1e-2)              # behind a flipped unit: the old bound, now with its reason on record
-    print(f"   parameters no flipped unit reaches (layers > {last} + classifier): worst {worst_clean:.2e}; all: {worst_all:.2e}")
-    # wide-range form
+    fit_and_check("default form")
     monkeypatch.setattr(ops, "GEMM_WIDE", True)
-    flips_w = _gin_flipped_units(model, g)
-    outs, loss = run()
-    assert rel_err(outs[0], refs[0]) < TOL
-    print(f"st_gin_3 64 trees, wide-range form: flips {[(li, n) for li, n, _ in flips_w]}")
-    if sum(n for _, n, _ in flips_w) == 0:
-        worst_w = _assert_gradients(model, sd, sd64, 1e-4)
-        print(f"   every gradient, wide-range form: worst {worst_w:.2e}")
-    else:                                                             # another box / library build may round these units the other way:
-        last_w = max(li for li, n, _ in flips_w if n)                 # then the same reach argument applies to this form
-        _assert_gradients(model, sd, sd64, 1e-4, only=lambda pn: not pn.startswith("gin.gin_layers.") or int(pn.split(".")[2]) > last_w)
+    fit_and_check("wide-range form")
 
 
 @pytest.mark.parametrize("name", ["st_gcn_3", "st_gin_3", "st_sage_3", "st_pgat_spgnnnl_3", "st_gat_6", "st_gat_1"])
