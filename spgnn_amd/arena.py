@@ -61,6 +61,29 @@ def _pad_graph(n_pad: int, m: int) -> Dict[str, np.ndarray]:
     return arrays
 
 
+_PAD_CACHE: Dict[tuple, Dict[str, torch.Tensor]] = {}     # (device, n_pad, m) -> the pad's index arrays on the device
+
+
+def _pad_pieces(n_pad: int, m: int, dev) -> Dict[str, torch.Tensor]:
+    """:func:`_pad_graph` on the device, ONE upload per (n_pad, m): the pad depends on nothing else, and a stream of scans or
+    loader batches revisits the same few shapes (per-scan inference paid ~0.2 ms of numpy + upload per scan for it)."""
+    key = (str(dev), int(n_pad), int(m))
+    hit = _PAD_CACHE.pop(key, None)
+    if hit is None:
+        pad = _pad_graph(n_pad, m)
+        order = ("indptr", "out_indptr", "indices", "out_indices", "eid", "out_pos", "src", "dst")
+        host = np.concatenate([pad[k].astype(np.int32, copy=False) for k in order])
+        up = torch.from_numpy(host).to(dev)
+        off, hit = 0, {}
+        for k in order:
+            hit[k] = up[off:off + pad[k].shape[0]]
+            off += pad[k].shape[0]
+        while len(_PAD_CACHE) >= 256:
+            _PAD_CACHE.pop(next(iter(_PAD_CACHE)))
+    _PAD_CACHE[key] = hit
+    return hit
+
+
 class BatchArena:
     """Fixed-address storage for the batches of one size class on one device."""
 
@@ -115,14 +138,7 @@ class BatchArena:
         N, E = g.number_of_nodes(), g.number_of_edges()
         n_pad = self.n_cap - N
         m = (self.e_cap - E - n_pad) // 2
-        pad = _pad_graph(n_pad, m)
-        order = ("indptr", "out_indptr", "indices", "out_indices", "eid", "out_pos", "src", "dst")
-        host = np.concatenate([pad[k].astype(np.int32, copy=False) for k in order])
-        up = torch.from_numpy(host).to(dev)                                # ONE upload for the pad's index arrays
-        off, pieces = 0, {}
-        for k in order:
-            pieces[k] = up[off:off + pad[k].shape[0]]
-            off += pad[k].shape[0]
+        pieces = _pad_pieces(n_pad, m, dev)                                 # the pad's index arrays on the device (cached per shape)
         with torch.no_grad():
             for k in ("indptr", "out_indptr"):                              # slot offsets: real edges fill slots [0, E)
                 dst = getattr(acsc, k)
