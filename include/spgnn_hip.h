@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 54
+#define SPGNN_ABI_VERSION 55
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -365,6 +365,16 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
                        int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
                        int32_t D, int32_t activation, spgnn_stream_t stream);
 int32_t spgnn_act_bwd_proj_blocks(int64_t N);
+/* spgnn_act_bwd_proj that ALSO forms the skinny Linear's weight gradient (ABI 55) from the rows it reads anyway:
+ *   g_w[j, c] = sum_v g_s[v, j] * (1/H) sum_h out[v, h*D + c]         (the classifier's g_logits^T @ head mean; DGL: autograd of
+ *                                                                      nn.Linear on `.mean(1)`, reference models.py:482, 1125)
+ * as per-workgroup partials w_grad_partials[spgnn_act_bwd_proj_wgrad_blocks(N)][J][D]; the caller adds the blocks in order
+ * (spgnn_sum_partials / spgnn_sum_partials_multi).  The head mean then need not be read a second time
+ * (spgnn_scores_bwd_w).  H in {1, 2}, J <= 24, an activation (so that `out` is read), D % 4 == 0, D <= 1024. */
+int32_t spgnn_act_bwd_proj_wgrad_blocks(int64_t N);
+int spgnn_act_bwd_proj_wgrad(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                             int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, float* w_grad_partials,
+                             int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
 
 /*
  * Layer-input assembly of the hidden SPGNN layers, dropout(cat[h_s, h_p]) (reference models.py:477-481 + GATConv's

@@ -1445,12 +1445,18 @@ __global__ __launch_bounds__(kBlock) void act_bwd_colsum_kernel(const float* __r
 // i.e. spgnn_scores_bwd_x (g_mean = g_logits W, written) + spgnn_act_bwd (g_mean re-read) in one pass: g_mean never
 // exists in memory.  A thread owns four columns and keeps their W entries in registers (J float4); a block walks a row
 // range, two rows per trip with all loads issued first; gS rows are wave-uniform (scalar loads); one |max| per block.
-template <int JP, int HT, int RB>       // HT: heads at compile time (0: run-time H <= 4); RB rows per trip
+// WG (ABI 55): the pass ALSO forms the skinny Linear's WEIGHT gradient g_W[j, c] = sum_v gS[v, j] * mean_h out[v, h*D + c] -
+// the classifier's (reference gnn_out, models.py:1125) - from the rows it holds anyway: a thread owns its four columns for
+// every row of the block's range, so the J x 4 accumulators need no cross-lane step; per-block partials
+// wgrad[block][j][D], summed by the caller in block order.  Replaces a second pass over the (N, D) head mean
+// (spgnn_scores_bwd_w: 313 MB read at 512 trees).
+template <int JP, int HT, int RB, bool WG>       // HT: heads at compile time (0: run-time H <= 4); RB rows per trip
 __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restrict__ gS, int64_t ldg, int J,
                                                            const float* __restrict__ W, int64_t ldw,
                                                            const float* __restrict__ out, int64_t out_ld,
                                                            float* __restrict__ g_pre, int64_t gp_ld, float* __restrict__ absmax,
-                                                           int64_t N, int64_t rows_per_block, int Hrt, int D, int act) {
+                                                           int64_t N, int64_t rows_per_block, int Hrt, int D, int act,
+                                                           float* __restrict__ wgrad) {
   __shared__ float red[4];
   constexpr int HMAX = HT ? HT : 4;
   const int H = HT ? HT : Hrt;
@@ -1458,10 +1464,12 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
   const bool cv = c < D;
   const int cc = cv ? c : 0;
   float4 w[JP];
+  float4 gw[WG ? JP : 1];
 #pragma unroll
   for (int j = 0; j < JP; ++j) {
     const float4 q = ld4(W + (int64_t)(j < J ? j : 0) * ldw + cc);
     w[j] = j < J ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WG) gw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_h = 1.f / (float)H;
   const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
@@ -1470,11 +1478,15 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
   // the row of gS is fetched by ONE vector load (lane j holds gS[row, j]) issued with the row's other loads and
   // broadcast by v_readlane: scalar loads would each expose their latency (and spilled 88 SGPRs with two rows in flight)
   const int jl = (threadIdx.x & 63) < J ? (threadIdx.x & 63) : 0;
-#define SPGNN_ABP_GM(GM, GV)                                                                                 \
+#define SPGNN_ABP_GM(GM, GV, EM)                                                                             \
   {                                                                                                          \
     GM = make_float4(0.f, 0.f, 0.f, 0.f);                                                                    \
     _Pragma("unroll") for (int j = 0; j < JP; ++j)                                                           \
-      if (j < J) fma4(GM, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GV), j)), w[j]);           \
+      if (j < J) {                                                                                           \
+        const float gj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GV), j));                   \
+        fma4(GM, gj, w[j]);                                                                                  \
+        if (WG) fma4(gw[j], gj, EM);                                                                         \
+      }                                                                                                      \
     GM.x *= inv_h; GM.y *= inv_h; GM.z *= inv_h; GM.w *= inv_h;                                              \
   }
 #define SPGNN_ABP_OUT(GM, O, ROW, HH)                                                                        \
@@ -1501,8 +1513,14 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
     for (int r = 0; r < RB; ++r) gv[r] = gS[(n + r) * ldg + jl];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      float4 gm;
-      SPGNN_ABP_GM(gm, gv[r])
+      float4 gm, em = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (WG) {                                          // the head mean of this row's four columns (WG needs `out`: host-checked)
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+          if (HT || h < H) { em.x += o[r][h].x; em.y += o[r][h].y; em.z += o[r][h].z; em.w += o[r][h].w; }
+        em.x *= inv_h; em.y *= inv_h; em.z *= inv_h; em.w *= inv_h;
+      }
+      SPGNN_ABP_GM(gm, gv[r], em)
 #pragma unroll
       for (int h = 0; h < HMAX; ++h)
         if (HT || h < H) SPGNN_ABP_OUT(gm, o[r][h], n + r, h)
@@ -1510,16 +1528,28 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
   }
   for (; n < n1; ++n) {
     const float gv = gS[n * ldg + jl];
-    float4 gm;
-    SPGNN_ABP_GM(gm, gv)
-    for (int h = 0; h < H; ++h) {
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (act != SPGNN_ACT_NONE) o = ld4(out + n * out_ld + (int64_t)h * D + cc);
-      SPGNN_ABP_OUT(gm, o, n, h)
+    float4 ot[HMAX];
+    float4 em = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+      ot[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((HT || h < H) && act != SPGNN_ACT_NONE) ot[h] = ld4(out + n * out_ld + (int64_t)h * D + cc);
+      if (WG && (HT || h < H)) { em.x += ot[h].x; em.y += ot[h].y; em.z += ot[h].z; em.w += ot[h].w; }
     }
+    em.x *= inv_h; em.y *= inv_h; em.z *= inv_h; em.w *= inv_h;
+    float4 gm;
+    SPGNN_ABP_GM(gm, gv, em)
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (HT || h < H) SPGNN_ABP_OUT(gm, ot[h], n, h)
   }
 #undef SPGNN_ABP_GM
 #undef SPGNN_ABP_OUT
+  if (WG && cv) {
+#pragma unroll
+    for (int j = 0; j < JP; ++j)
+      if (j < J) st4(wgrad + ((int64_t)blockIdx.x * J + j) * D + c, gw[j]);
+  }
   mx = team_max(mx, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
@@ -3339,13 +3369,47 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
   const int32_t blocks = spgnn_act_bwd_proj_blocks(N);
   const int64_t rpb = (N + blocks - 1) / blocks;
   hipStream_t st = (hipStream_t)stream;
-#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
-                                      (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation)
+#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows, false>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
+                                      (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation, \
+                                      (float*)nullptr)
 #define X(JP) { if (H == 2) XH(JP, 2); else if (H == 1) XH(JP, 1); else XH(JP, 0); }
   if (J <= 8) X(8) else if (J <= 16) X(16) else if (J <= 24) X(24) else X(32)
 #undef X
 #undef XH
   return check_launch("spgnn_act_bwd_proj");
+}
+
+int32_t spgnn_act_bwd_proj_wgrad_blocks(int64_t N) {
+  int64_t b = (N + 31) / 32;                         // every block leaves a J x D partial: two blocks per CU at large N keep the
+  if (b > 512) b = 512;                              // partials at 46 MB for the 22 x 1024 classifier (four rows per trip in flight)
+  return (int32_t)(b < 1 ? 1 : b);
+}
+
+int spgnn_act_bwd_proj_wgrad(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                             int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, float* w_grad_partials,
+                             int64_t N, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream) {
+  if (N < 0 || (H != 1 && H != 2) || D <= 0 || D % 4 || D > 1024 || J <= 0 || J > 24)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_proj_wgrad: bad N/H/D/J (H in {1, 2}, D % 4 == 0, D <= 1024, J <= 24)");
+  if (activation <= SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_proj_wgrad: activation");
+  if (N == 0) return SPGNN_OK;
+  if (!g_s || !w || !g_pre || !absmax_partials || !out || !w_grad_partials)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_proj_wgrad: null pointer");
+  const int64_t HD = (int64_t)H * D;
+  if (g_s_stride < J || w_stride < D || g_pre_stride < HD || out_stride < HD)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_proj_wgrad: row stride smaller than row");
+  if (!vec_ok(w, w_stride) || !vec_ok(g_pre, g_pre_stride) || !vec_ok(out, out_stride) || !aligned16(w_grad_partials))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_act_bwd_proj_wgrad: rows must be 16-byte aligned");
+  const int32_t blocks = spgnn_act_bwd_proj_wgrad_blocks(N);
+  const int64_t rpb = (N + blocks - 1) / blocks;
+  hipStream_t st = (hipStream_t)stream;
+#define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows, true>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
+                                      (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation, \
+                                      w_grad_partials)
+#define X(JP) { if (H == 2) XH(JP, 2); else XH(JP, 1); }
+  if (J <= 8) X(8) else if (J <= 16) X(16) else X(24)
+#undef X
+#undef XH
+  return check_launch("spgnn_act_bwd_proj_wgrad");
 }
 
 int spgnn_fold_scores_fwd(const float* W, int64_t w_stride, const float* attn_l, const float* attn_r, float* w_lr,

@@ -1022,10 +1022,16 @@ class _LinearFn(torch.autograd.Function):
             cs = column_sums(g_logits)
             g_logits = _rowmajor(g_logits)
             wc = w_cls.detach()
-            if ctx.needs_input_grad[6]:
+            fused = g is None and C % 4 == 0 and act_bwd_proj_supported(1, C, wc.shape[0], wc)
+            ride = fused and ctx.needs_input_grad[6] and act_bwd_proj_wgrad_supported(1, C, wc.shape[0], ctx.act, y)
+            if ctx.needs_input_grad[6] and not ride:
                 g_wcls = scores_bwd_w(g_logits, y)
             g_bcls = cs if ctx.has_bcls and ctx.needs_input_grad[7] else None
-            if g is None and C % 4 == 0 and act_bwd_proj_supported(1, C, wc.shape[0], wc):
+            if ride:                                      # ... with the classifier's weight gradient g_logits^T y from the same rows
+                wj = SumJobs(x.device)                    # (the step's queue when one is installed: only the parameter reads g_wcls)
+                g, sg, g_wcls = act_bwd_proj(g_logits, wc, y, 1, C, ctx.act, wgrad_jobs=wj)
+                wj.flush()
+            elif fused:
                 # g_logits Wc * act'(y) in one pass: the (N, C) gradient of y is never written
                 g, sg = act_bwd_proj(g_logits, wc, y if ctx.act != ACT_NONE else None, 1, C, ctx.act)
             else:
@@ -2104,13 +2110,30 @@ def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, ac
     return g_pre, amax
 
 
-def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int):
+ACT_BWD_PROJ_WGRAD = True    # the classifier's weight gradient rides in spgnn_act_bwd_proj (no second pass over the head mean)
+
+
+def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int,
+                 wgrad_jobs: Optional["SumJobs"] = None):
     """act_bwd of a mean-over-heads layer whose mean feeds a skinny Linear (weight ``w`` (J, D)), with that Linear's
-    input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), its scale block)."""
+    input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), its scale block).  With ``wgrad_jobs`` (a SumJobs queue) and
+    a supported shape the pass also forms that Linear's WEIGHT gradient g_s^T @ mean_h(out) from the rows it reads anyway
+    (spgnn_act_bwd_proj_wgrad; the per-block partials are summed by the queue): -> (g_pre, block, g_w (J, D))."""
     N, J = g_s.shape
     lib = _capi.load()
     g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_s.device)
     part = new_scale_block(g_s.device)
+    if wgrad_jobs is not None:
+        blocks = int(lib.spgnn_act_bwd_proj_wgrad_blocks(N))
+        wpart = torch.empty((blocks, J, D), dtype=torch.float32, device=g_s.device)
+        g_w = torch.empty((J, D), dtype=torch.float32, device=g_s.device)
+        with torch.cuda.device(g_s.device), _timed("act_bwd_proj", (N, H, D, act, J)):
+            _capi.check(lib.spgnn_act_bwd_proj_wgrad(g_s.data_ptr(), g_s.stride(0), J, w.data_ptr(), w.stride(0), out.data_ptr(),
+                                                     out.stride(0), g_pre.data_ptr(), g_pre.stride(0), part.data_ptr(), wpart.data_ptr(),
+                                                     N, H, D, act, _stream(g_s)), "spgnn_act_bwd_proj_wgrad")
+        wgrad_jobs.add(_capi.SumJob(kind=0, splits=blocks, partials=wpart.data_ptr(), split_stride=J * D, out=g_w.data_ptr(), n=J * D),
+                       wpart, g_w)
+        return g_pre, part, g_w
     with torch.cuda.device(g_s.device), _timed("act_bwd_proj", (N, H, D, act, J)):
         _capi.check(lib.spgnn_act_bwd_proj(g_s.data_ptr(), g_s.stride(0), J, w.data_ptr(), w.stride(0), _ptr(out),
                                            out.stride(0) if out is not None else 0, g_pre.data_ptr(), g_pre.stride(0),
@@ -2120,6 +2143,10 @@ def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]
 
 def act_bwd_proj_supported(H: int, D: int, J: int, w: torch.Tensor) -> bool:
     return H <= 4 and D % 4 == 0 and D <= 1024 and J <= 32 and w.stride(1) == 1 and _rows_aligned(w)
+
+
+def act_bwd_proj_wgrad_supported(H: int, D: int, J: int, act: int, out: Optional[torch.Tensor]) -> bool:
+    return bool(ACT_BWD_PROJ_WGRAD and H in (1, 2) and J <= 24 and act != ACT_NONE and out is not None and (J * D) % 4 == 0)
 
 
 class _GATAggFirstFn(torch.autograd.Function):
@@ -2198,11 +2225,16 @@ class _GATAggFirstFn(torch.autograd.Function):
         if ctx.has_cls and g_logits is not None:
             cs_ = column_sums(g_logits) if (ctx.has_cls_bias and ctx.needs_input_grad[6]) else None
             g_logits = g_logits.contiguous()
-            if ctx.needs_input_grad[5]:
+            fused = g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls)
+            ride = fused and ctx.needs_input_grad[5] and act_bwd_proj_wgrad_supported(H, D, g_logits.shape[1], act, out)
+            if ctx.needs_input_grad[5] and not ride:
                 g_wcls = scores_bwd_w(g_logits, rst, defer=jobs)
             if cs_ is not None:
                 g_bcls = cs_
-            if g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls):
+            if ride:
+                # ... and the classifier's weight gradient g_logits^T mean_h(out) from the same rows: no second pass over the head mean
+                g_pre, amax, g_wcls = act_bwd_proj(g_logits, w_cls, out, H, D, act, wgrad_jobs=jobs)
+            elif fused:
                 # the usual training case (only the logits reach the loss): g_mean = g_logits W is formed inside act_bwd
                 g_pre, amax = act_bwd_proj(g_logits, w_cls, out, H, D, act)
             else:

@@ -784,3 +784,29 @@ def test_bench_two_rank_rehearsal_through_self_launch():
     assert c["allreduce_ms_p50"] > 0.0 and 4 * 2501080 <= c["comm_bucket_bytes"] <= 4 * 2501080 + 64       # 2 501 078 parameters + the two loss slots, 16-byte parameter starts
     assert out["value"] > 0 and np.isfinite(out["loss"])
     assert out["roofline"]["hbm_frac"] > 0 and out["roofline"]["hbm_ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("name,trees", [("st_pgat_spgnn_3", 5), ("st_gin_3", 5), ("st_pgat_spgnn_3", 40)])
+def test_classifier_weight_gradient_rides_in_act_bwd_proj(name, trees, monkeypatch):
+    """ops.ACT_BWD_PROJ_WGRAD (round 5): the classifier's weight gradient g_logits^T mean_h(out) (reference gnn_out on the head
+    mean, models.py:482, 1125) is formed by spgnn_act_bwd_proj_wgrad from the rows that pass reads anyway, instead of a second
+    pass over the (N, 1024) head mean.  Every other gradient is bit-identical; gnn_out.weight differs by summation order only."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build(name, seed=21)
+    model.eval()
+    g = synthetic.make_batch(trees, rank=7, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    got = {}
+    for ride in (True, False):
+        monkeypatch.setattr(_ops, "ACT_BWD_PROJ_WGRAD", ride)
+        m = copy.deepcopy(model)
+        ts = TrainStep(m, w, 1.0, 1e-3, 0.9)
+        ts._front(g)
+        got[ride] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert "gnn_out.weight" in got[True]
+    for n, v in got[False].items():
+        if n == "gnn_out.weight":
+            assert rel_err(got[True][n], v) < 2e-6 and float(v.abs().max()) > 0, (n, rel_err(got[True][n], v))
+        else:
+            assert torch.equal(got[True][n], v), n
+    _ops.DROPOUT_SEED_OFFSET = None
