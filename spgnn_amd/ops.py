@@ -2110,7 +2110,12 @@ def act_bwd(g_out: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, ac
     return g_pre, amax
 
 
-ACT_BWD_PROJ_WGRAD = True    # the classifier's weight gradient rides in spgnn_act_bwd_proj (no second pass over the head mean)
+# The classifier's weight gradient riding in spgnn_act_bwd_proj (spgnn_act_bwd_proj_wgrad: no second pass over the head mean).
+# Built, bit-comparable (tests/test_hip_models.py), measured NEUTRAL in one process (tools/step_toggle_ab.py, MI355X, round 5;
+# profiles/r05_act_bwd_proj_wgrad_ab.txt): st_pgat_spgnn_3 4.965 / 5.010 vs 4.980 ms at 512 trees, 1.000 vs 0.995 at 64, st_gin_3
+# 3.609 vs 3.608 - the 88 extra accumulator registers (250 VGPRs: two waves per SIMD) and the doubled FMA count cost the pass what
+# the removed launch (0.09 ms) saved.  Off by default: the two-pass form has the smaller kernel.
+ACT_BWD_PROJ_WGRAD = False
 
 
 def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int,
