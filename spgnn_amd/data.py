@@ -78,9 +78,12 @@ def _pinned(shape, dtype, pin: bool) -> torch.Tensor:
     return t.pin_memory() if pin else t
 
 
-def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: Optional[bool] = None) -> G.TreeGraph:
+def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: Optional[bool] = None,
+                   graph_mode: str = "all_connected") -> G.TreeGraph:
     """``batch``: a collated dict of lists (``collate_native``) or a list of sample dicts.  Returns the batched
-    graph on ``device`` with ndata fvs / fvs_out / y [/ pos_enc / p] and its CSC/CSR already built."""
+    graph on ``device`` with ndata fvs / fvs_out / y [/ pos_enc / p] and its CSC/CSR already built.  ``graph_mode``: the
+    reference's GRAPH_MODE (graph.edges_from_adj; "tree_downstream" = parent -> child edges only, job_runner.py:1334-1336;
+    anchors and distances of the positional encoding always follow the undirected tree, as job_runner.py:1759-1777 does)."""
     if isinstance(batch, dict):
         samples = [{k: batch[k][i] for k in SCHEMA_KEYS} for i in range(len(batch["adj"]))]
     else:
@@ -99,13 +102,13 @@ def assemble_batch(batch, device="cuda", pos_enc_dim: Optional[int] = 39, pin: O
     pes = []
     if on_gpu:
         # edge list, CSC and CSR of the whole batch on the device, from the packed adjacency matrices (spgnn_build_csc)
-        src, dst, csc, nn_, ne_ = G.build_csc_device([s["adj"] for s in samples], dev, pin=pin)
+        src, dst, csc, nn_, ne_ = G.build_csc_device([s["adj"] for s in samples], dev, pin=pin, graph_mode=graph_mode)
         g = G.TreeGraph.from_device(src, dst, N, csc, nn_, ne_)
     else:
         srcs, dsts, off = [], [], 0
         for s, n in zip(samples, ns):
             adj = np.asarray(s["adj"])
-            u, v = G.edges_from_adj(adj, add_self_loops=True)
+            u, v = G.edges_from_adj(adj, add_self_loops=True, graph_mode=graph_mode)
             srcs.append(u + off); dsts.append(v + off)
             if pos_enc_dim:                                  # host path (CPU graphs): per-tree anchors + BFS in Python
                 anc = anchors_from_cnn_prediction(np.asarray(s["fvs_out"], dtype=np.float32), adj, pos_enc_dim)

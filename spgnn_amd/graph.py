@@ -36,16 +36,28 @@ __all__ = [
 ]
 
 
-def edges_from_adj(adj: np.ndarray, add_self_loops: bool = True):
+GRAPH_MODES = ("all_connected", "tree_downstream")
+
+
+def edges_from_adj(adj: np.ndarray, add_self_loops: bool = True, graph_mode: str = "all_connected"):
     """Directed edge list of one tree by the reference rule (job_runner.py:1779-1801).
 
     ``nx.DiGraph(adj)`` enumerates non-zero entries row by row, i.e. sorted by (u, v);
     ``dgl.remove_self_loop`` drops the diagonal keeping order; ``g.add_edges(nodes, nodes)``
     appends (i, i) for i = 0..n-1.
+
+    ``graph_mode`` = the reference's ``GRAPH_MODE`` setting (job_runner.py:1329-1339, GCNTrain.from_adj_to_graph):
+    "all_connected" (every config of the reference) keeps both directions of every tree edge; "tree_downstream" keeps the
+    upper triangle only - ``nx.DiGraph(np.triu(adj))``: parent -> child edges, the parent having the smaller index.  An
+    ``adj`` that is already upper triangular gives the same directed graph in either mode (job_runner.py:1329-1332).
     """
+    if graph_mode not in GRAPH_MODES:
+        raise ValueError(f"graph_mode must be one of {GRAPH_MODES}, got {graph_mode!r}")
     a = np.asarray(adj)
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError(f"adj must be square, got {a.shape}")
+    if graph_mode == "tree_downstream":
+        a = np.triu(a)
     n = a.shape[0]
     u, v = np.nonzero(a)                 # row-major == sorted by (u, v)
     keep = u != v
@@ -202,7 +214,7 @@ class DeviceCSC:
         return self._cache[key]
 
 
-def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True):
+def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True, graph_mode: str = "all_connected"):
     """Edge list + CSC + CSR of a loader batch built ON THE DEVICE from the trees' adjacency matrices (reference rule:
     job_runner.py:1779-1801 + dgl.batch, restated in csrc/spgnn_graph.hip): the n x n uint8 matrices are packed into one
     (pinned) buffer, uploaded once, and two kernels + two prefix sums produce every index array; the host reads back five
@@ -215,6 +227,10 @@ def build_csc_device(adjs: Sequence[np.ndarray], device, pin: bool = True):
     # any non-zero entry is an edge (nx.DiGraph(adj) in the reference, edges_from_adj here): a plain uint8 cast would turn
     # 0.5 or 256 into "no edge" and the device path would disagree with the host path
     # (the kernels test bytes against zero, so uint8 / bool matrices go up as they are)
+    if graph_mode not in GRAPH_MODES:
+        raise ValueError(f"graph_mode must be one of {GRAPH_MODES}, got {graph_mode!r}")
+    if graph_mode == "tree_downstream":      # the reference's nx.DiGraph(np.triu(adj)) (job_runner.py:1334-1336): the kernels see the triangle
+        adjs = [np.triu(np.asarray(a)) for a in adjs]
     mats = [np.ascontiguousarray(a).view(np.uint8) if (isinstance(a, np.ndarray) and a.dtype in (np.uint8, np.bool_))
             else np.ascontiguousarray(np.asarray(a) != 0).view(np.uint8) for a in adjs]
     for a in mats:
@@ -757,10 +773,11 @@ def to_networkx(g: TreeGraph):
     return G
 
 
-def graph_from_adj(adj, device="cpu", add_self_loops: bool = True) -> TreeGraph:
+def graph_from_adj(adj, device="cpu", add_self_loops: bool = True, graph_mode: str = "all_connected") -> TreeGraph:
     """One tree's graph straight from the dense ``adj`` of the cached-embedding schema
     (reference job_runner.py:796-803), equivalent to the nx.DiGraph -> DGLGraph ->
-    remove_self_loop -> add_edges(nodes, nodes) sequence of job_runner.py:1779-1800."""
+    remove_self_loop -> add_edges(nodes, nodes) sequence of job_runner.py:1779-1800; ``graph_mode``: see
+    :func:`edges_from_adj` (the reference's GRAPH_MODE)."""
     a = adj.detach().cpu().numpy() if torch.is_tensor(adj) else np.asarray(adj)
-    u, v = edges_from_adj(a, add_self_loops)
+    u, v = edges_from_adj(a, add_self_loops, graph_mode)
     return TreeGraph((u, v), a.shape[0], device)

@@ -191,3 +191,34 @@ def test_build_csc_device_bit_exact_at_512_trees():
     g = G.TreeGraph.from_device(src, dst, off, csc, nn_, ne_)
     assert g.csc("cuda") is csc and g.number_of_edges() == e_src.shape[0] and np.array_equal(g._src, e_src)
     assert torch.equal(g.edges()[0].cpu(), torch.from_numpy(e_src))
+
+
+@pytest.mark.gpu
+def test_tree_downstream_batches_on_the_device_and_through_a_model():
+    """GRAPH_MODE == "tree_downstream" (reference job_runner.py:1334-1336) end to end: the device builder gives the networkx
+    rule's edge list, and a GAT head run on the directed batch (every node: its parent's message and its own) equals the CPU
+    oracle on the same edge list."""
+    from oracle import dgl_cpu as O
+    from oracle import graph_rule_nx as R
+    from spgnn_amd import graph as G, models
+    from spgnn_amd.configs import get_config
+    from spgnn_amd.data import assemble_batch
+    samples = synthetic.synthetic_trees(6, rank=3)
+    adjs = [s["adj"] for s in samples]
+    ns = [a.shape[0] for a in adjs]
+    src, dst, csc, nn_, ne_ = G.build_csc_device(adjs, "cuda", graph_mode="tree_downstream")
+    e_src, e_dst = R.batch_edges([R.edges_gcn(a, "tree_downstream") for a in adjs], ns)
+    assert np.array_equal(src.cpu().numpy(), e_src) and np.array_equal(dst.cpu().numpy(), e_dst)
+    assert ne_ == [2 * n - 1 for n in ns] and csc.min_in_degree == 1 and csc.min_out_degree == 1
+    g = assemble_batch(samples, "cuda", pos_enc_dim=None, graph_mode="tree_downstream")
+    assert g.number_of_edges() == e_src.shape[0]
+    cfg = get_config("st_gat_3")
+    torch.manual_seed(0)
+    model = models.build_model(cfg.MODEL).cuda()
+    model.init(None); model.set_gcn_only(); model.eval()
+    with torch.no_grad():
+        logits = model(g)[0]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = O.net_forward(cfg.KIND, sd, torch.from_numpy(e_src), torch.from_numpy(e_dst), sum(ns), g.ndata["fvs"].cpu(), None)[0]
+    err = float((logits.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err

@@ -130,3 +130,27 @@ def test_synthetic_workload_shape():
     bg = synthetic.batch_from_samples(samples)
     assert bg.ndata["pos_enc"].shape == (bg.number_of_nodes(), 39)
     assert bg.number_of_edges() == 3 * bg.number_of_nodes() - 2 * 4
+
+
+def test_tree_downstream_graph_mode_follows_the_reference_rule():
+    """GRAPH_MODE == "tree_downstream" (reference job_runner.py:1334-1336: nx.DiGraph(np.triu(adj)), self loops removed, then
+    g.add_edges(nodes, nodes)): parent -> child edges only.  Bit-exact against the networkx restatement, for symmetric trees
+    and for an adjacency matrix that is already upper triangular (job_runner.py:1329-1332: the same directed graph in either
+    mode); no config of the reference selects it, the boundary still has it."""
+    from oracle import graph_rule_nx as R
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 33, 150):
+        adj = synthetic.random_tree_adj(n, rng)
+        u, v = G.edges_from_adj(adj, graph_mode="tree_downstream")
+        ru, rv = R.edges_gcn(adj, "tree_downstream")
+        assert np.array_equal(u, ru) and np.array_equal(v, rv)
+        assert u.shape[0] == 2 * n - 1 and (u <= v).all()                  # n - 1 parent -> child edges + n self loops
+        tri = np.triu(adj)
+        for mode in G.GRAPH_MODES:
+            u2, v2 = G.edges_from_adj(tri, graph_mode=mode)
+            ru2, rv2 = R.edges_gcn(tri, mode)
+            assert np.array_equal(u2, ru2) and np.array_equal(v2, rv2) and np.array_equal(u2, u)
+    with pytest.raises(ValueError):
+        G.edges_from_adj(np.eye(3), graph_mode="upstream")
+    g = G.graph_from_adj(synthetic.random_tree_adj(20, rng), graph_mode="tree_downstream")
+    assert g.number_of_edges() == 39
