@@ -42,7 +42,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 MFMA_F16_PEAK = 2500.0      # dense fp16 / bf16 TFLOP/s
 FP32_MATRIX_PEAK = 157.3    # native fp32 MFMA TFLOP/s (the pipe an fp32 GEMM would otherwise use)
-GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair", "gemm_nt_bf16", "gemm_tn_bf16")
+GEMM_NAMES = ("gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair", "gemm_nt_bf16", "gemm_tn_bf16", "gemm_nt_skinny")
 HELPER_NAMES = ("absmax", "split_rows")
 GAT_PREFIXES = ("gat_fwd", "gat_bwd", "gat_agg", "lspe_")
 # roofline.traffic is NOT measured by this run: PMC counters need rocprofv3 passes of their own

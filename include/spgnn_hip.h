@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 55
+#define SPGNN_ABI_VERSION 56
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -371,6 +371,17 @@ int32_t spgnn_act_bwd_proj_blocks(int64_t N);
  * as per-workgroup partials w_grad_partials[spgnn_act_bwd_proj_wgrad_blocks(N)][J][D]; the caller adds the blocks in order
  * (spgnn_sum_partials / spgnn_sum_partials_multi).  The head mean then need not be read a second time
  * (spgnn_scores_bwd_w).  H in {1, 2}, J <= 24, an activation (so that `out` is read), D % 4 == 0, D <= 1024. */
+/* Projection of a SMALL batch (ABI 56): C = act(A B^T + bias), A (M, K), B (N, K), fp32, for M up to a few hundred rows - the
+ * reference's per-scan inference (ONE tree per model.forward, job_runner.py:2046-2052) and few-tree batches.  Same contract as
+ * spgnn_gemm_nt for the options it has (bias, activation, GATConv's score partials score_out (M, score_cols / 64, 2) of the
+ * first score_cols columns with score_l / score_r; those exclude bias / activation), on the fp32 matrix pipe
+ * (v_mfma_f32_16x16x4_f32: exact fp32 products, no operand scales, no pre-split forms), 16 x 64 output tiles with the
+ * reduction split over the four waves of a workgroup: M / 16 x N / 64 short workgroups instead of a handful of long ones.
+ * Replaces rocBLAS (nn.Linear -> cuBLAS in the reference) below ops.SKINNY_ROWS rows. */
+int spgnn_gemm_nt_skinny(const float* a, int64_t a_stride, const float* b, int64_t b_stride, float* c, int64_t c_stride, int64_t M,
+                         int64_t N, int64_t K, const float* bias /* nullable */, int32_t activation,
+                         const float* score_l, const float* score_r, float* score_out /* nullable */, int32_t score_cols,
+                         spgnn_stream_t stream);
 int32_t spgnn_act_bwd_proj_wgrad_blocks(int64_t N);
 int spgnn_act_bwd_proj_wgrad(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
                              int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, float* w_grad_partials,

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 55
+ABI_VERSION = 56
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -84,6 +84,7 @@ _TILE_SRC = [_i32p, _i64, _i32, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _vp, _
              _i64, _i32, _i32, _f32, _u64, _vp, _vp]
 
 SIGNATURES = {
+    "spgnn_gemm_nt_skinny": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _i64, _i64, _i64, _f32p, _i32, _f32p, _f32p, _f32p, _i32, _vp],
     "spgnn_act_bwd_proj_wgrad_blocks": [_i64],
     "spgnn_act_bwd_proj_wgrad": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _f32p, _i64, _i32, _i32, _i32, _vp],
     "spgnn_gat_tile_supported": [_i32, _i32, _i32, _i32],

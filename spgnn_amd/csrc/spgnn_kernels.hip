@@ -2181,6 +2181,139 @@ __global__ __launch_bounds__(kBlock) void scores_fwd_mfma(const ST* __restrict__
     }
 }
 
+// =================================================================================================
+// Skinny product for SMALL batches (ABI 56): C = act(A B^T + bias), A (M, K), B (N, K), M up to a few hundred rows - the
+// per-scan inference forward of the reference (ONE tree per model.forward, job_runner.py:2046-2052: M = 100-300) and the
+// 2-5-tree batches of tests.  The split-fp16 kernels of spgnn_gemm.hip tile for M in the tens of thousands: at M = 150 a
+// 1063 -> 1024 projection is 16 workgroups walking 34 K stages one after the other (35 us, 4 x rocBLAS).  Here a
+// workgroup owns 16 rows x 64 columns, its four waves split K, the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact
+// fp32 products, fp32 accumulation) does the arithmetic and the partial accumulators meet in LDS in wave order
+// (deterministic): M / 16 x N / 64 workgroups, every one of them short.  Optional epilogue as the large kernels':
+// bias, activation, and GATConv's per-64-column score partials <C[row, 64 b : 64 b + 64], attn[...]> (spgnn_gemm_nt).
+// =================================================================================================
+template <int KS>
+__global__ __launch_bounds__(kBlock) void gemm_nt_skinny(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                                                         const float* __restrict__ bias, int act,
+                                                         const float* __restrict__ score_l, const float* __restrict__ score_r,
+                                                         float* __restrict__ score_out, int score_cols) {
+  static_assert(KS == kBlock / 64, "k split = the waves of a block");
+  constexpr int NG = 4;                                  // 16-column groups per workgroup: one 64-column block
+  const int ks = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const int col0 = (int)blockIdx.y * 64;
+  const bool rv = row0 + r < M;
+  const float* ap = A + (rv ? row0 + r : 0) * lda + 4 * q;
+  const float* bp[NG]; bool cvv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    cvv[g] = col0 + 16 * g + r < N;
+    bp[g] = B + (int64_t)(cvv[g] ? col0 + 16 * g + r : 0) * ldb + 4 * q;
+  }
+  f32x4 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kfull_all = K & ~15;
+  const int kq = ((kfull_all / 16 + KS - 1) / KS) * 16;
+  const int kbeg = ks * kq < kfull_all ? ks * kq : kfull_all;
+  const int kfull = kbeg + kq < kfull_all ? kbeg + kq : kfull_all;
+  constexpr int UK = 4;                                  // k16 steps per trip: 4 + 16 row loads in flight before the first MFMA
+  int k0 = kbeg;
+  for (; k0 + 16 * UK <= kfull; k0 += 16 * UK) {
+    float4 xa[UK], wb[NG][UK];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) xa[u] = ld4(ap + k0 + 16 * u);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int u = 0; u < UK; ++u) wb[g][u] = ld4(bp[g] + k0 + 16 * u);
+#pragma unroll
+    for (int u = 0; u < UK; ++u)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].x, wb[g][u].x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].y, wb[g][u].y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].z, wb[g][u].z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u].w, wb[g][u].w, acc[g], 0, 0, 0);
+      }
+  }
+  for (; k0 < kfull; k0 += 16) {
+    const float4 xa = ld4(ap + k0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 wb = ld4(bp[g] + k0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
+    }
+  }
+  if (kfull_all < K && ks == KS - 1) {   // ragged tail (the last wave's): element-wise guards on both operands (row strides are
+    const int kt = kfull_all, k = kt + 4 * q;           // multiples of 4 >= K: a chunk that starts below K lies inside the row)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xa = z4;
+    if (k < K) {
+      const float4 t_ = ld4(ap + kt);
+      xa.x = t_.x; if (k + 1 < K) xa.y = t_.y; if (k + 2 < K) xa.z = t_.z; if (k + 3 < K) xa.w = t_.w;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 wb = z4;
+      if (k < K) {
+        const float4 t_ = ld4(bp[g] + kt);
+        wb.x = t_.x; if (k + 1 < K) wb.y = t_.y; if (k + 2 < K) wb.z = t_.z; if (k + 3 < K) wb.w = t_.w;
+      }
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, wb.x, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, wb.y, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, wb.z, acc[g], 0, 0, 0);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, wb.w, acc[g], 0, 0, 0);
+    }
+  }
+  __shared__ f32x4 red[(KS - 1) * NG * 64];
+  if (ks > 0) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) red[((ks - 1) * NG + g) * 64 + lane] = acc[g];
+  }
+  __syncthreads();
+  if (ks > 0) return;
+#pragma unroll
+  for (int w = 1; w < KS; ++w)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 p_ = red[((w - 1) * NG + g) * 64 + lane];
+      acc[g][0] += p_[0]; acc[g][1] += p_[1]; acc[g][2] += p_[2]; acc[g][3] += p_[3];
+    }
+  // C / D layout of 16x16x4: col = lane & 15 (+ 16 g), row = (lane >> 4) * 4 + reg
+  float sl[4] = {0.f, 0.f, 0.f, 0.f}, sr[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_s = score_out != nullptr && col0 < score_cols;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int col = col0 + 16 * g + r;
+    const float bcol = (bias && cvv[g]) ? bias[col] : 0.f;
+    const float al = (want_s && cvv[g]) ? score_l[col] : 0.f, ar = (want_s && cvv[g]) ? score_r[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[g][j] + bcol;
+      if (want_s) { sl[j] = fmaf(v, al, sl[j]); sr[j] = fmaf(v, ar, sr[j]); }      // (score layers carry no bias / activation here)
+      v = act_fwd(v, act);
+      const int64_t orow = row0 + q * 4 + j;
+      if (cvv[g] && orow < M) C[orow * ldc + col] = v;
+    }
+  }
+  if (want_s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a_ = team_sum(sl[j], 16), b_ = team_sum(sr[j], 16);
+      const int64_t orow = row0 + q * 4 + j;
+      if (r == 0 && orow < M) {
+        float* o = score_out + (orow * (score_cols / 64) + blockIdx.y) * 2;
+        o[0] = a_; o[1] = b_;
+      }
+    }
+  }
+}
+
 // one wave per 256 columns x one row range (four waves of a block side by side: a row is then read as one 4 KB
 // run instead of 1 KB pieces at different times - DRAM-friendlier); partial sums per range, reduced by the caller
 template <typename ST, int J>
@@ -3377,6 +3510,23 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
 #undef X
 #undef XH
   return check_launch("spgnn_act_bwd_proj");
+}
+
+int spgnn_gemm_nt_skinny(const float* a, int64_t a_stride, const float* b, int64_t b_stride, float* c, int64_t c_stride, int64_t M,
+                         int64_t N, int64_t K, const float* bias, int32_t activation, const float* score_l, const float* score_r,
+                         float* score_out, int32_t score_cols, spgnn_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0 || N > (1 << 24) || K > (1 << 24)) return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_skinny: bad M/N/K");
+  if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_gemm_nt_skinny: activation");
+  if (M == 0) return SPGNN_OK;
+  if (!a || !b || !c) return fail(SPGNN_ERR_NULLPTR, "spgnn_gemm_nt_skinny: null pointer");
+  if (a_stride < K || b_stride < K || c_stride < N) return fail(SPGNN_ERR_STRIDE, "spgnn_gemm_nt_skinny: row stride smaller than row");
+  if (!vec_ok(a, a_stride) || !vec_ok(b, b_stride)) return fail(SPGNN_ERR_STRIDE, "spgnn_gemm_nt_skinny: operand rows must be 16-byte aligned");
+  if (score_out && (!score_l || !score_r || score_cols <= 0 || score_cols % 64 || score_cols > N || bias || activation != SPGNN_ACT_NONE))
+    return fail(SPGNN_ERR_SHAPE, "spgnn_gemm_nt_skinny: score partials need score_l / score_r, score_cols % 64 == 0 <= N, no bias / activation");
+  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + 63) / 64));
+  hipLaunchKernelGGL((gemm_nt_skinny<kBlock / 64>), grid, dim3(kBlock), 0, (hipStream_t)stream, a, a_stride, b, b_stride, c, c_stride, M,
+                     (int)N, (int)K, bias, (int)activation, score_l, score_r, score_out, (int)score_cols);
+  return check_launch("spgnn_gemm_nt_skinny");
 }
 
 int32_t spgnn_act_bwd_proj_wgrad_blocks(int64_t N) {

@@ -1116,6 +1116,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             y._spgnn_scale = (y._version, blk)          # the result's GEMM operand scale, from the product's epilogue
         return y
     assert drop is None, "linear(drop=...) needs the matrix-core path (linear_drop_supported)"
+    if (x.is_cuda and x.dim() == 2 and skinny_rows(N) and addend is None and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and act in (ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU, ACT_LRELU)):
+        # a small inference batch (one scan): the library's skinny product instead of rocBLAS, bias and activation in its epilogue
+        xa = x if _rows_aligned(x) else cat_padded((_rowmajor(x),))
+        wa = weight if (_rows_aligned(weight) and weight.stride(1) == 1) else cat_padded((weight.detach(),))
+        if xa.shape[1] == wa.shape[1]:
+            return gemm_nt_skinny(xa, wa, bias=bias.contiguous() if bias is not None else None, act=act)
     y = torch.nn.functional.linear(x, weight, bias)
     if addend is not None:
         y = y + addend
@@ -1382,9 +1389,39 @@ def _tagged(w: torch.Tensor, name: str):
     return tag[1] if tag is not None and tag[0] == w._version else None
 
 
-def _b_operand(w: torch.Tensor):
+SKINNY_GEMM = True       # small inference batches: projections on spgnn_gemm_nt_skinny (16 x 64 tiles, k split over the waves, fp32 MFMA)
+SKINNY_ROWS = 640        # ... up to this many rows (about four airway trees); the split-fp16 kernels tile for tens of thousands
+
+
+def skinny_rows(rows: int) -> bool:
+    """Whether a product with ``rows`` output rows belongs on the skinny kernel: inference only (no autograd: the per-scan
+    forward of reference job_runner.py:2046-2052 - training keeps one arithmetic for forward and backward), few rows."""
+    return bool(SKINNY_GEMM and GEMM_MODE == "f16x3" and 0 < rows <= SKINNY_ROWS and not torch.is_grad_enabled())
+
+
+def gemm_nt_skinny(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                   act: int = 0, score_l=None, score_r=None, score_out=None) -> torch.Tensor:
+    """a (M, K) @ b (N, K)^T -> (M, N), fp32 operands with 16-byte rows, on spgnn_gemm_nt_skinny."""
+    _require_cuda(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and _rows_aligned(a) and _rows_aligned(b)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    with torch.cuda.device(a.device), _timed("gemm_nt_skinny", (M, N, K)):
+        _capi.check(_capi.load().spgnn_gemm_nt_skinny(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                                      M, N, K, _ptr(bias), act, _ptr(score_l), _ptr(score_r), _ptr(score_out),
+                                                      score_l.numel() if score_out is not None else 0, _stream(a)), "spgnn_gemm_nt_skinny")
+    return out
+
+
+def _b_operand(w: torch.Tensor, rows: Optional[int] = None):
     """(tensor, b_presplit) to pass as the ``b`` operand of gemm_nt for a weight operand: its pre-split form when
-    weight_cat attached one (and ``w`` is unchanged since), else the fp32 rows themselves."""
+    weight_cat attached one (and ``w`` is unchanged since), else the fp32 rows themselves.  ``rows``: the product's row
+    count - a small inference batch (:func:`skinny_rows`) takes the fp32 rows: its kernel computes in fp32."""
+    if rows is not None and skinny_rows(rows):
+        return w, False
     ps = _tagged(w, "_spgnn_ps") if PRESPLIT_B else None
     return (ps, True) if ps is not None else (w, False)
 
@@ -1578,7 +1615,7 @@ class _GATLayerFn(torch.autograd.Function):
         if split:                                      # (N, HD [+HD]) = [ft | res] on the fp16 matrix cores
             s, sx = scores_fwd(x, w_lr, want_scale=True)   # (N, 2H) = [el | er]; the scale of x comes for free
             sw = operand_scale(w_cat)                      # attached by weight_cat, else one absmax pass
-            wb, ps = _b_operand(w_cat)
+            wb, ps = _b_operand(w_cat, x.shape[0])
             y = gemm_nt(x, wb, sx, sw, b_presplit=ps)
         else:
             sx = sw = None
@@ -1686,7 +1723,7 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
         ctx.attn_params = (attn_l, attn_r)
         al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
         parts = torch.empty((N, HD // 64, 2), dtype=torch.float32, device=x.device)
-        wb, ps = _b_operand(w_cat)
+        wb, ps = _b_operand(w_cat, N)
         ctx.w_t, ctx.w_t_ps = _bt_operand(w_cat, ps)
         xa, aps = const_operand(x, sx) if ps else (x, False)       # node data (a model's first layer): split once per loader batch
         ctx.x_ps = xa if aps else None
@@ -1897,7 +1934,7 @@ class _LspeLevelFn(torch.autograd.Function):
         prods = []
         for x, w, (al, ar), H in ((x_s, w_s, vecs[0], 2), (x_p, w_p, vecs[1], 1)):
             sx, sw = operand_scale(x), operand_scale(w)
-            wb, ps = _b_operand(w)
+            wb, ps = _b_operand(w, N)
             xa, aps = const_operand(x, sx) if ps else (x, False)         # level 0: node data, split once per loader batch
             pt = torch.empty((N, H * D // 64, 2), dtype=torch.float32, device=dev)
             prods.append(NtProblem(xa, wb, sx, sw, score_l=al, score_r=ar, score_out=pt, b_presplit=ps, a_presplit=aps))
@@ -2187,7 +2224,7 @@ class _GATAggFirstFn(torch.autograd.Function):
         out = torch.empty((N, H * D), dtype=torch.float32, device=x.device)
         fuse_mean = mean and headmean_fusable(out, H, D)
         rst = None
-        wb, ps = (wc_ps, True) if wc_ps is not None else (wc, False)
+        wb, ps = (wc_ps, True) if (wc_ps is not None and not skinny_rows(N)) else (wc, False)
         for h in range(H):
             bh_ = bias[h * D:(h + 1) * D] if bias is not None else None
             if fuse_mean and h == 1:                   # the second head's tiles also write 0.5 * (head 0 + head 1)
@@ -2196,7 +2233,7 @@ class _GATAggFirstFn(torch.autograd.Function):
             else:
                 gemm_nt(z[:, h * zs:(h + 1) * zs], wb[h], sz, sw, out=out[:, h * D:(h + 1) * D], bias=bh_, act=act, b_presplit=ps)
         ctx.csc, ctx.cfg = csc, (H, D, has_res, slope, act, p_drop, seed, mean)
-        ctx.has_bias, ctx.presplit = bias is not None, wc_ps is not None
+        ctx.has_bias, ctx.presplit = bias is not None, ps
         if rst is None:
             rst = head_mean(out, H, D) if mean else out
         has_cls = w_cls is not None and mean
@@ -2868,6 +2905,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, scale_a: Optional[torch.Tensor] = 
     (M, C/64, 2) with ``score_l`` / ``score_r`` (C,): per 64-column block dot products of the first C output columns.
     ``b_presplit``: ``b`` is the pre-split form of the operand (:func:`presplit`, made with ``scale_b``); ``a_presplit``
     (only together with it): ``a`` likewise, made with ``scale_a`` (constant node data, split once per loader batch)."""
+    if (not b_presplit and not a_presplit and upd_u is None and not tile and skinny_rows(a.shape[0]) and _rows_aligned(a) and _rows_aligned(b)
+            and (score_out is None or (bias is None and act == 0 and score_l.numel() % 64 == 0))):
+        return gemm_nt_skinny(a, b, out=out, bias=bias, act=act, score_l=score_l, score_r=score_r, score_out=score_out)
     b_presplit = int(bool(b_presplit)) | (2 if a_presplit else 0) | (4 if (GEMM_WIDE if wide is None else wide) else 0)
     _require_cuda(a, b)
     M, K = a.shape
@@ -2926,8 +2966,8 @@ class NtProblem:
 def gemm_nt_pair(first: NtProblem, second: NtProblem):
     """Both products in one launch (spgnn_gemm_nt_pair; pass the larger one first: its block tile is used for both) -
     bit-identical to ``first.run(); second.run()``, which is what happens when PAIR_GEMMS is off or the operand forms differ."""
-    if not PAIR_GEMMS or first.b_presplit != second.b_presplit or first.a.device != second.a.device:
-        return first.run(), second.run()
+    if not PAIR_GEMMS or first.b_presplit != second.b_presplit or first.a.device != second.a.device or skinny_rows(first.shape[0]):
+        return first.run(), second.run()                   # (a small inference batch: each product on the skinny kernel)
     import ctypes
     with torch.cuda.device(first.a.device), _timed("gemm_nt_pair", first.shape + second.shape):
         _capi.check(_capi.load().spgnn_gemm_nt_pair(ctypes.byref(first.c), ctypes.byref(second.c), int(first.b_presplit),
@@ -2966,6 +3006,8 @@ def gemm_nt_add(a: torch.Tensor, b: torch.Tensor, scale_a, scale_b, addend: torc
 
 
 def headmean_fusable(out: torch.Tensor, H: int, D: int) -> bool:
+    if skinny_rows(out.shape[0]):
+        return False                                       # small inference batch: skinny products + spgnn_head_mean
     return H == 2 and D % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and GEMM_MODE == "f16x3"
 
 

@@ -636,3 +636,63 @@ def test_twenty_deferred_partial_sums_in_one_launch():
             assert torch.equal(a, b)
     arr = (_capi.SumJob * 25)()
     assert _capi.load().spgnn_sum_partials_multi(arr, 25, ops._stream(refs[-1])) != 0
+
+
+@pytest.mark.parametrize("M,K,N", [(150, 1063, 1024), (300, 384, 1024), (7, 39, 512), (1, 64, 64), (128, 768, 512), (33, 20, 70), (640, 192, 2048)])
+def test_skinny_product_is_an_fp32_gemm(M, K, N):
+    """spgnn_gemm_nt_skinny (per-scan inference, reference job_runner.py:2046-2052: M = 100-300 rows): exact fp32 products on the
+    fp32 matrix pipe - as close to fp64 as rocBLAS' SGEMM, exact on small-integer data, every ragged edge (rows, columns, K)."""
+    from spgnn_amd import ops
+    torch.manual_seed(M + K + N)
+    Kp = (K + 3) // 4 * 4
+    a = torch.zeros(M, Kp, device="cuda")[:, :K]
+    b = torch.zeros(N, Kp, device="cuda")[:, :K]
+    a.copy_(torch.randn(M, K)); b.copy_(torch.randn(N, K) * 0.1)
+    ref = a.double() @ b.double().t()
+    got = ops.gemm_nt_skinny(a, b)
+    e_lib = float((got.double() - ref).abs().max() / ref.abs().max())
+    e_blas = float(((a @ b.t()).double() - ref).abs().max() / ref.abs().max())
+    assert e_lib < max(2 * e_blas, 2e-6), (e_lib, e_blas)
+    ai, bi = torch.randint(-8, 9, (M, K), device="cuda").float(), torch.randint(-8, 9, (N, K), device="cuda").float()
+    a.copy_(ai); b.copy_(bi)
+    assert torch.equal(ops.gemm_nt_skinny(a, b), ai @ bi.t())                  # small integers: exact
+
+
+def test_skinny_product_epilogues():
+    """bias + activation, and GATConv's score partials per 64-column block, against torch."""
+    from spgnn_amd import ops
+    torch.manual_seed(5)
+    M, K, N, C = 150, 384, 1024, 512
+    a, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.1
+    bias = torch.randn(N, device="cuda")
+    got = ops.gemm_nt_skinny(a, b, bias=bias, act=ops.ACT_ELU)
+    ref = torch.nn.functional.elu(a.double() @ b.double().t() + bias.double())
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    al, ar = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    parts = torch.zeros(M, C // 64, 2, device="cuda")
+    y = ops.gemm_nt_skinny(a, b, score_l=al, score_r=ar, score_out=parts)
+    yd = (a.double() @ b.double().t())[:, :C].view(M, C // 64, 64)
+    rl = (yd * al.double().view(C // 64, 64)).sum(-1)
+    rr = (yd * ar.double().view(C // 64, 64)).sum(-1)
+    assert float((parts[..., 0].double() - rl).abs().max() / rl.abs().max()) < 2e-6
+    assert float((parts[..., 1].double() - rr).abs().max() / rr.abs().max()) < 2e-6
+    assert float((y.double() - a.double() @ b.double().t()).abs().max()) < 1e-4
+
+
+def test_small_inference_batches_take_the_skinny_kernel_and_training_does_not(monkeypatch):
+    """ops.skinny_rows: no-grad products of up to SKINNY_ROWS rows; anything with autograd on keeps the split-fp16 kernels (one
+    arithmetic for a step's forward and backward)."""
+    from spgnn_amd import ops
+    a, b = torch.randn(100, 64, device="cuda"), torch.randn(128, 64, device="cuda")
+    seen = []
+    real = ops.gemm_nt_skinny
+    monkeypatch.setattr(ops, "gemm_nt_skinny", lambda *x, **k: (seen.append(1), real(*x, **k))[1])
+    with torch.no_grad():
+        y0 = ops.gemm_nt(a, b)
+    assert seen == [1]
+    y1 = ops.gemm_nt(a, b)
+    assert seen == [1] and float((y0 - y1).abs().max() / y1.abs().max()) < 3e-6
+    big = torch.randn(ops.SKINNY_ROWS + 1, 64, device="cuda")
+    with torch.no_grad():
+        ops.gemm_nt(big, b)
+    assert seen == [1]
