@@ -7,6 +7,10 @@ the host paces it; :class:`ForwardRunner` captures the eval-mode forward once pe
 spgnn_amd/arena.py: the tree is copied into fixed buffers and padded with pad nodes that form components of their own, so no
 real node's value changes) and replays it for every later scan of the class: a scan = a dozen small device copies + one HIP
 graph launch.  No gradients, no dropout (``model.eval()``), outputs sliced back to the scan's real nodes.
+
+The parameters are FROZEN for a runner: what the forward derives from them alone (the projection operands of
+spgnn_weight_prep, the folded score vectors) is computed once and kept out of the captured graph, so a replay starts at the
+first kernel that touches node data.  After loading other weights into the model call ``runner.reset()``.
 """
 from __future__ import annotations
 
@@ -27,6 +31,20 @@ class ForwardRunner:
     def __init__(self, model: torch.nn.Module, granule: int = 64, max_classes: int = 16):
         self.model, self.granule, self.max_classes = model, granule, max_classes
         self._classes: Dict[tuple, Tuple[BatchArena, torch.cuda.CUDAGraph, tuple]] = {}
+        self._frozen: dict = {}                    # ops.FROZEN_WEIGHTS of this runner: what the forward derives from the parameters alone
+
+    def _forward(self, ag):
+        """The model's forward with this runner's frozen-weight cache installed and the step's scale blocks pooled (one re-arm
+        launch instead of a clone per block; inference never reads them back)."""
+        from . import ops
+        pool = ops.scale_pool(ag.device)
+        prev, ops.FROZEN_WEIGHTS = ops.FROZEN_WEIGHTS, self._frozen
+        pool.begin()
+        try:
+            return self.model(ag)
+        finally:
+            pool.end()
+            ops.FROZEN_WEIGHTS = prev
 
     def _capture(self, arena: BatchArena):
         ag = arena.graph
@@ -34,8 +52,8 @@ class ForwardRunner:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):                     # lazy initialisations, allocator pools, operand caches
-                self.model(ag)
+            for _ in range(2):                     # lazy initialisations, allocator pools; fills the frozen-weight cache:
+                self._forward(ag)                  # projection operands and folded score vectors of the CURRENT parameters
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         from . import ops
@@ -43,12 +61,17 @@ class ForwardRunner:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
-                outs = self.model(ag)
+                outs = self._forward(ag)           # recorded WITHOUT the weight-only launches: a replay starts at the node data
             refs = ops.CAPTURE_REFS
         finally:
             ops.CAPTURE_REFS = prev_refs
         outs = outs if isinstance(outs, (tuple, list)) else (outs,)
         return graph, tuple(outs), refs
+
+    def reset(self) -> None:
+        """Drop every capture and the frozen-weight cache: call after the model's parameters changed (another checkpoint)."""
+        self._classes.clear()
+        self._frozen = {}
 
     def __call__(self, g):
         if self.model.training:

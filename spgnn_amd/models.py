@@ -190,7 +190,16 @@ def set_trainable(model: nn.Module, trainable: bool) -> None:
 # =================================================================================================
 # heads
 # =================================================================================================
-class GCN(nn.Module):
+class _InferenceScoped:
+    """Module calls made under torch.no_grad() announce it to the ops (ops.inference_scope): small inference batches - the
+    reference's one-scan-per-forward test path, job_runner.py:2046-2052 - then take the skinny projection kernel."""
+
+    def __call__(self, *args, **kwargs):
+        with ops.inference_scope():
+            return super().__call__(*args, **kwargs)
+
+
+class GCN(_InferenceScoped, nn.Module):
     def __init__(self, num_layers, in_dim, num_hiddens, num_classes, activation):
         super().__init__()
         self.num_layers = num_layers
@@ -214,7 +223,7 @@ class GCN(nn.Module):
             return self.gcn_layers[-1](g, h, classifier=classifier)
 
 
-class GAT(nn.Module):
+class GAT(_InferenceScoped, nn.Module):
     def __init__(self, num_layers, in_dim, num_hiddens, out_ch, heads, activation, feat_drop, attn_drop,
                  negative_slope, residual, norm=False):
         super().__init__()
@@ -271,7 +280,7 @@ def _gin_mlp(n_in, n_out):
                          nn.LeakyReLU())
 
 
-class GIN(nn.Module):
+class GIN(_InferenceScoped, nn.Module):
     def __init__(self, num_layers, in_dim, num_hiddens, out_ch, norm=False):
         super().__init__()
         self.num_layers, self.in_dim, self.out_ch, self.norm = num_layers, in_dim, out_ch, norm
@@ -299,7 +308,7 @@ class GIN(nn.Module):
         return F.normalize(h, p=2, dim=1) if self.norm else h
 
 
-class GATPSPGNN(nn.Module):
+class GATPSPGNN(_InferenceScoped, nn.Module):
     """SPGNN "PEL": a structure stream on cat[h_s, h_p] and a learnable position stream
     (1-head residual GATConv, tanh) on h_p.  Reference models.py:403-484."""
 
@@ -421,7 +430,7 @@ class GATPSPGNN(nn.Module):
         return h_s, h_p
 
 
-class GATPSPGNNNL(nn.Module):
+class GATPSPGNNNL(_InferenceScoped, nn.Module):
     """"PENL" ablation: the static pos_enc is concatenated before every layer.
     Reference models.py:487-540."""
 
@@ -459,7 +468,7 @@ class GATPSPGNNNL(nn.Module):
         return h_s, h_p
 
 
-class SAGE(nn.Module):
+class SAGE(_InferenceScoped, nn.Module):
     def __init__(self, num_layers, in_dim, num_hiddens, out_ch, node_ks, node_sample_rate=0.3, activation=F.elu,
                  feat_drop=0.1, aggregator_type="pool", norm=None):
         super().__init__()
@@ -500,7 +509,7 @@ class SAGE(nn.Module):
 # =================================================================================================
 # *Net wrappers: [frozen CNN trunk] + GNN head + Linear classifier
 # =================================================================================================
-class _GraphNetBase(nn.Module):
+class _GraphNetBase(_InferenceScoped, nn.Module):
     """Shared plumbing of the reference's ``*Net`` classes: constructor bookkeeping, optional CNN
     trunk, ``gnn_out``, trainability switches and ``init``."""
 

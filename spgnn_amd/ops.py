@@ -559,9 +559,25 @@ class _FoldScoresFn(torch.autograd.Function):
         return g_w, g_al.view(ctx.attn_shape), g_ar.view(ctx.attn_shape)
 
 
+# Inference with FROZEN weights (spgnn_amd.infer.ForwardRunner): everything a forward pass derives from the parameters alone -
+# the projection operands of spgnn_weight_prep, the folded score vectors - is computed once when the forward is captured and
+# is NOT part of the captured graph: a replay starts at the first kernel that touches node data.  A dict while a ForwardRunner
+# issues the model's forward (its entries live as long as the runner's capture), else None.  The caller owns the contract:
+# parameters must not change between capture and replay (ForwardRunner.reset() after loading other weights).
+FROZEN_WEIGHTS: Optional[dict] = None
+
+
 def fold_scores(w_fc: torch.Tensor, attn_l: torch.Tensor, attn_r: torch.Tensor) -> torch.Tensor:
     _require_cuda(w_fc, attn_l, attn_r)
     assert w_fc.stride(1) == 1
+    fz = FROZEN_WEIGHTS
+    if fz is not None and INFERENCE:
+        key = ("fold", id(w_fc), id(attn_l), id(attn_r))
+        hit = fz.get(key)
+        if hit is None and not torch.cuda.is_current_stream_capturing():
+            hit = fz[key] = _FoldScoresFn.apply(w_fc, attn_l, attn_r)
+        if hit is not None:
+            return hit
     return _FoldScoresFn.apply(w_fc, attn_l, attn_r)
 
 
@@ -1393,10 +1409,31 @@ SKINNY_GEMM = True       # small inference batches: projections on spgnn_gemm_nt
 SKINNY_ROWS = 640        # ... up to this many rows (about four airway trees); the split-fp16 kernels tile for tens of thousands
 
 
+INFERENCE = False        # set for the duration of a model call made under torch.no_grad() (inference_scope)
+
+
+class inference_scope:
+    """``with inference_scope():`` around a model / head call: ``ops.INFERENCE`` is True inside iff the CALLER has autograd off
+    (``torch.no_grad()`` / ``torch.inference_mode()``).  torch.is_grad_enabled() cannot be asked further down: it is False
+    inside every autograd.Function.forward, training or not."""
+
+    def __enter__(self):
+        global INFERENCE
+        self.prev = INFERENCE
+        INFERENCE = INFERENCE or not torch.is_grad_enabled()
+        return self
+
+    def __exit__(self, *exc):
+        global INFERENCE
+        INFERENCE = self.prev
+        return False
+
+
 def skinny_rows(rows: int) -> bool:
-    """Whether a product with ``rows`` output rows belongs on the skinny kernel: inference only (no autograd: the per-scan
-    forward of reference job_runner.py:2046-2052 - training keeps one arithmetic for forward and backward), few rows."""
-    return bool(SKINNY_GEMM and GEMM_MODE == "f16x3" and 0 < rows <= SKINNY_ROWS and not torch.is_grad_enabled())
+    """Whether a product with ``rows`` output rows belongs on the skinny kernel: inference only (a model called under
+    torch.no_grad(): the per-scan forward of reference job_runner.py:2046-2052 - a training step keeps one arithmetic for its
+    forward and backward products), few rows."""
+    return bool(SKINNY_GEMM and INFERENCE and GEMM_MODE == "f16x3" and 0 < rows <= SKINNY_ROWS)
 
 
 def gemm_nt_skinny(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -1528,7 +1565,13 @@ class prepared_weights:
                                    0 if sp[1] is None else sp[1].stride(0), None if sp[1] is None else tuple(sp[1].shape), bool(sp[2]),
                                    sp[3] if len(sp) > 3 else "") for sp in self.specs)
         prep = _prep_lookup(_PREP_CACHE, key, lambda: _WeightPrep(self.specs, dev))
-        prep.run()
+        fz = FROZEN_WEIGHTS
+        if fz is not None and INFERENCE and fz.get(("prep", key)) is prep:
+            pass                                         # frozen weights: the operand set built for this runner is current
+        else:
+            prep.run()
+            if fz is not None and INFERENCE and not torch.cuda.is_current_stream_capturing():
+                fz[("prep", key)] = prep                 # (keeps the buffers alive with the runner's capture)
         _PREP_ACTIVE = {(id(sp[0]), id(sp[1]) if sp[1] is not None else 0) + ((sp[3],) if len(sp) > 3 else ()): (e, bool(sp[2]))
                         for sp, e in zip(self.specs, prep.entries)}
         return self

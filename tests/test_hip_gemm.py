@@ -687,12 +687,13 @@ def test_small_inference_batches_take_the_skinny_kernel_and_training_does_not(mo
     seen = []
     real = ops.gemm_nt_skinny
     monkeypatch.setattr(ops, "gemm_nt_skinny", lambda *x, **k: (seen.append(1), real(*x, **k))[1])
-    with torch.no_grad():
+    with torch.no_grad(), ops.inference_scope():             # what a model call under no_grad sets up (models._InferenceScoped)
         y0 = ops.gemm_nt(a, b)
     assert seen == [1]
-    y1 = ops.gemm_nt(a, b)
+    with ops.inference_scope():                               # autograd on at the call: not inference
+        y1 = ops.gemm_nt(a, b)
     assert seen == [1] and float((y0 - y1).abs().max() / y1.abs().max()) < 3e-6
     big = torch.randn(ops.SKINNY_ROWS + 1, 64, device="cuda")
-    with torch.no_grad():
+    with torch.no_grad(), ops.inference_scope():
         ops.gemm_nt(big, b)
-    assert seen == [1]
+    assert seen == [1] and not ops.INFERENCE
