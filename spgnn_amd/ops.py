@@ -316,6 +316,39 @@ DEBUG_POISON_DEFERRED = False   # tests: deferred outputs start as NaN, so a rea
 STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep while it issues a step's forward and backward
 
 
+OVERLAP_TN = True        # a training step issues its weight-gradient products on a side stream (SideLaunch): they overlap the
+TN_SIDE: Optional["SideLaunch"] = None      # traversals that follow; installed by train.TrainStep around forward + backward
+
+
+class SideLaunch:
+    """Weight-gradient products (spgnn_gemm_tn / _pair) of a training step on a SIDE stream.  Nothing inside a backward pass
+    reads a weight gradient, while the input-gradient product and the next level's traversals are on the critical path: an
+    MFMA-bound product and the HBM-bound traversals use different parts of the chip, and issued on two streams they overlap
+    (tools/overlap_probe.py, MI355X: a 558 us weight-gradient product next to 864 us of GAT traversals: 1 283 us against 1 389
+    one after the other).  Under capture the side stream becomes a parallel branch of the step's HIP graph.  Tensors the side
+    launches read are kept alive here until ``join()``: the caching allocator may otherwise hand their memory to a later
+    allocation of the main stream while the product still reads it."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.keep, self.pending = [], False
+
+    def run(self, fn, *keep):
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)                  # everything issued so far (the operands' producers) comes first
+        with torch.cuda.stream(self.side):
+            fn()
+        self.keep.extend(keep)
+        self.pending = True
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.pending = False
+        self.keep.clear()
+
+
 class SumJobs:
     """Deferred split-K reductions: gemm_tn / scores_bwd_w append their partial-sum step here instead of launching it, and
     ``flush()`` runs up to ``MAX`` of them in ONE launch (spgnn_sum_partials_multi; bit-identical to the single launches).
@@ -345,6 +378,8 @@ class SumJobs:
     def flush(self):
         if not self.jobs:
             return
+        if TN_SIDE is not None:
+            TN_SIDE.join()                           # these sums read partials a side-stream product may still be writing
         arr = (_capi.SumJob * len(self.jobs))(*self.jobs)
         with torch.cuda.device(self.device):
             _capi.check(_capi.load().spgnn_sum_partials_multi(arr, len(self.jobs), torch.cuda.current_stream(self.device).cuda_stream),
@@ -3141,10 +3176,22 @@ class TnProblem:
         q.colsum_a, q.colsum_stride, q.colsum_split_stride, q.splits = cs_ptr, ldc, M * ldc, splits
         q.flags, self.b_presplit, self.rows = flags, int(bool(b_presplit)), rows      # b_presplit: b = the pre-split image of X (presplit() under scale_b)
 
+    def _side(self):
+        """The step's side stream when this product's sums are deferred (nothing reads its partials before a join)."""
+        q = TN_SIDE
+        return q if (q is not None and OVERLAP_TN and self.defer is not None and q.device == self.a.device) else None
+
     def launch(self):
         import ctypes
-        with torch.cuda.device(self.a.device), _timed("gemm_tn", self.shape):
-            _capi.check(_capi.load().spgnn_gemm_tn_problem_run(ctypes.byref(self.c), _stream(self.a)), "spgnn_gemm_tn_problem_run")
+
+        def go():
+            with torch.cuda.device(self.a.device), _timed("gemm_tn", self.shape):
+                _capi.check(_capi.load().spgnn_gemm_tn_problem_run(ctypes.byref(self.c), _stream(self.a)), "spgnn_gemm_tn_problem_run")
+        q = self._side()
+        if q is not None:
+            q.run(go, self.a, self.b, self.part)
+        else:
+            go()
         return self
 
     def finish(self):
@@ -3182,6 +3229,13 @@ def gemm_tn_pair(first: TnProblem, second: TnProblem):
     if not PAIR_GEMMS or first.a.device != second.a.device or first.b_presplit != second.b_presplit:
         return first.launch().finish(), second.launch().finish()
     import ctypes
-    with torch.cuda.device(first.a.device), _timed("gemm_tn_pair", first.shape + second.shape):
-        _capi.check(_capi.load().spgnn_gemm_tn_pair(ctypes.byref(first.c), ctypes.byref(second.c), _stream(first.a)), "spgnn_gemm_tn_pair")
+
+    def go():
+        with torch.cuda.device(first.a.device), _timed("gemm_tn_pair", first.shape + second.shape):
+            _capi.check(_capi.load().spgnn_gemm_tn_pair(ctypes.byref(first.c), ctypes.byref(second.c), _stream(first.a)), "spgnn_gemm_tn_pair")
+    q = first._side() if second._side() is not None else None
+    if q is not None:
+        q.run(go, first.a, first.b, first.part, second.a, second.b, second.part)
+    else:
+        go()
     return first.finish(), second.finish()

@@ -229,6 +229,12 @@ class TrainStep:
         # step): the deferred outputs start as NaN, so whatever autograd copied, added or handed to a hook before the flush shows
         # up as a NaN in the gathered bucket (one host read, once).  Never under stream capture.
         verify = bool(sums is not None and self._verify_deferred and not torch.cuda.is_current_stream_capturing())
+        # the weight-gradient products go to a side stream and overlap the traversals that follow them (ops.SideLaunch)
+        side = None
+        if on_gpu and ops.OVERLAP_TN:
+            if getattr(self, "_tn_side", None) is None:
+                self._tn_side = ops.SideLaunch(b.flat_param.device)
+            side = self._tn_side
         prev_poison = ops.DEBUG_POISON_DEFERRED
         try:
             if verify:
@@ -237,6 +243,7 @@ class TrainStep:
                 ops.DROPOUT_SEED_OFFSET = ctr
             ops.ATTN_GRAD_QUEUE = queue
             ops.STEP_SUMS = sums
+            ops.TN_SIDE = side
             logits = self.model(g)[0]
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
@@ -249,6 +256,8 @@ class TrainStep:
             else:
                 num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
                 num.backward()
+            if side is not None:
+                side.join()                  # every weight-gradient product is complete before anything sums its partials
             if queue is not None:
                 queue.flush()                # (inside the step's scale-pool window: its partial sums take no block, but stay in order)
             if sums is not None:
@@ -258,6 +267,9 @@ class TrainStep:
             ops.DROPOUT_SEED_OFFSET = prev_off
             ops.ATTN_GRAD_QUEUE = None
             ops.STEP_SUMS = None
+            ops.TN_SIDE = None
+            if side is not None:
+                side.join()                  # (also on the error path: never leave the side stream dangling in a capture)
             ops.DEBUG_POISON_DEFERRED = prev_poison
             if pool is not None:
                 pool.end()
