@@ -2127,6 +2127,19 @@ class _LspeLevelFn(torch.autograd.Function):
                 else:
                     nt[i] = NtProblem(g_y[i], w_t if w_t is not None else ws[i].t().contiguous(), sg, sw, out=gx)
                 grads_x[i] = gx
+        def input_gradients():
+            if nt[0] is not None and nt[1] is not None:
+                gemm_nt_pair(nt[0], nt[1])
+            else:
+                for q in nt:
+                    if q is not None:
+                        q.run()
+        # With a side stream for the weight gradients (SideLaunch) the input-gradient products go FIRST: they are on the critical
+        # path, and the weight-gradient pair then starts behind them - next to the NEXT level's HBM-bound traversals, which is
+        # where an MFMA-bound product overlaps (two products side by side only time-slice the CUs).
+        nt_first = TN_SIDE is not None and OVERLAP_TN
+        if nt_first:
+            input_gradients()
         if tn[0] is not None and tn[1] is not None:
             r = gemm_tn_pair(tn[0], tn[1])
         else:
@@ -2153,12 +2166,8 @@ class _LspeLevelFn(torch.autograd.Function):
         for i in range(2):
             if ms[i] is not None:
                 grads_al[i], grads_ar[i] = ms[i][0].view(ctx.attn_shapes[i]), ms[i][1].view(ctx.attn_shapes[i])
-        if nt[0] is not None and nt[1] is not None:
-            gemm_nt_pair(nt[0], nt[1])
-        else:
-            for q in nt:
-                if q is not None:
-                    q.run()
+        if not nt_first:
+            input_gradients()
         jobs.flush()
         return (grads_x[0], grads_x[1], grads_w[0], grads_w[1], grads_al[0], grads_ar[0], grads_al[1], grads_ar[1], grads_b[0], grads_b[1],
                 None, None, None)

@@ -256,10 +256,10 @@ class TrainStep:
             else:
                 num, den = weighted_nll_sums(logits, y, mask_from_draws(draws, p), self.class_weight)
                 num.backward()
-            if side is not None:
-                side.join()                  # every weight-gradient product is complete before anything sums its partials
             if queue is not None:
                 queue.flush()                # (inside the step's scale-pool window: its partial sums take no block, but stay in order)
+            if side is not None:
+                side.join()                  # every weight-gradient product is complete before anything sums its partials
             if sums is not None:
                 sums.check_taken_over(b.params)      # every deferred output must BE a parameter's .grad by now
                 sums.flush()                 # the attention queue's reductions included: it found this queue installed
