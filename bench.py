@@ -289,12 +289,15 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     for _ in range(warmup - probe):
         loss = step.step(g)
     kt_all = {}
+    overlap_tn = ops.OVERLAP_TN          # the per-kernel legs time every launch ALONE (no weight-gradient product on the side stream)
     if probe:
         sync()
+        ops.OVERLAP_TN = False
         ops.KernelTimer.start()
         for _ in range(probe):
             loss = step.step(g)
         kt_all = ops.KernelTimer.stop()
+        ops.OVERLAP_TN = overlap_tn
     # The roofline kernel is FIXED per dtype (not "whichever shape won this run"): all launches of it in a step.
     spmm_model = cfg.KIND in ("gcn", "gin", "sage")           # rows D / E / F: the SpMM kernels are the roofline kernel (HBM-bound)
     roof_names = (("gat_fwd_bf16", "gat_bwd_dst_bf16", "gat_bwd_src_bf16", "gat_agg_fwd_bf16", "gat_agg_bwd_dst_bf16",
@@ -379,6 +382,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         # a replay cannot carry HIP events per launch: the roofline kernels' launches are bracketed in eagerly issued
         # steps right after the timed region (same kernels, same operands, same stream; only these kernels carry events)
         n_leg = min(steps, 20)
+        ops.OVERLAP_TN = False
         ops.KernelTimer.start(only=bracket or None)
         t1 = time.perf_counter()
         for _ in range(n_leg):
@@ -386,6 +390,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         sync()
         eager_leg = {"ms_per_step": (time.perf_counter() - t1) / n_leg * 1e3, "steps": n_leg}
         kt_dom = ops.KernelTimer.stop()
+        ops.OVERLAP_TN = overlap_tn
         if not kt_all:
             kt_all, probe = dict(kt_dom), n_leg
     loss_val = float(loss)
@@ -417,7 +422,8 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                                    f"dropout {'off' if no_dropout else 'on'}",
                        "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
-                       "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc},
+                       "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc,
+                       "weight_gradients_on_side_stream": bool(ops.OVERLAP_TN and N >= ops.OVERLAP_TN_MIN_ROWS)},
             "graph_edges_per_s": E_all * steps / elapsed, "loss": loss_val,
             "step_ms": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
                         "n": len(step_ms), "how": "HIP events on the compute stream around every timed step (rank 0)"},

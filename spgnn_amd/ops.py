@@ -318,6 +318,15 @@ STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep w
 
 OVERLAP_TN = True        # a training step issues its weight-gradient products on a side stream (SideLaunch): they overlap the
 TN_SIDE: Optional["SideLaunch"] = None      # traversals that follow; installed by train.TrainStep around forward + backward
+OVERLAP_TN_MIN_ROWS = 32768    # ... for batches of at least this many nodes.  One process, alternating (tools/step_toggle_ab.py, MI355X,
+                               # round 5): st_pgat_spgnn_3 4.990 / 4.980 vs 5.058 / 5.037 ms at 512 trees (-1.2 %), st_gat_3 2.880 vs 2.903;
+                               # at 64 trees 1.027 vs 1.003 (the fork and join cost more than the short products hide): off there
+
+
+def side_for(rows: int, device) -> Optional["SideLaunch"]:
+    """The running step's side stream for a weight-gradient product over ``rows`` node rows, or None."""
+    q = TN_SIDE
+    return q if (q is not None and OVERLAP_TN and rows >= OVERLAP_TN_MIN_ROWS and q.device == torch.device(device)) else None
 
 
 class SideLaunch:
@@ -1860,6 +1869,19 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
                     absmax_dst=has_res)
         need_bias = ctx.has_bias and ctx.needs_input_grad[4]
         g_bias = g_wcat = None
+
+        def input_gradient():
+            Kp = (K + 3) // 4 * 4
+            gx = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
+            if ctx.w_t_ps is not None:
+                gemm_nt(g_y, ctx.w_t_ps, sg, sw, out=gx, b_presplit=True)
+            else:
+                gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=gx)
+            return gx
+        g_x = None
+        nt_first = ctx.needs_input_grad[0] and side_for(N, x.device) is not None
+        if nt_first:                                   # the critical-path product first: the weight gradient then runs on the step's
+            g_x = input_gradient()                     # side stream next to the following layer's traversals (SideLaunch)
         if ctx.needs_input_grad[1]:
             big = g_y.shape[1] * K >= _TN_MIN_ELEMS
             if big:
@@ -1880,14 +1902,8 @@ class _GATLayerScoresFromFtFn(torch.autograd.Function):
             m = scores_bwd_w(g_s, y[:, :HD], blockdiag_heads=H, defer=jobs)  # (2, H, D): [0] = g_attn_l, [1] = g_attn_r (contiguous views)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
         jobs.flush()                               # the two split-K reductions in one launch
-        g_x = None
-        if ctx.needs_input_grad[0]:
-            Kp = (K + 3) // 4 * 4
-            g_x = torch.empty((N, Kp), dtype=torch.float32, device=x.device)[:, :K]
-            if ctx.w_t_ps is not None:
-                gemm_nt(g_y, ctx.w_t_ps, sg, sw, out=g_x, b_presplit=True)
-            else:
-                gemm_nt(g_y, ctx.w_t if ctx.w_t is not None else w_cat.t().contiguous(), sg, sw, out=g_x)
+        if ctx.needs_input_grad[0] and not nt_first:
+            g_x = input_gradient()
         return g_x, g_wcat, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -2137,7 +2153,7 @@ class _LspeLevelFn(torch.autograd.Function):
         # With a side stream for the weight gradients (SideLaunch) the input-gradient products go FIRST: they are on the critical
         # path, and the weight-gradient pair then starts behind them - next to the NEXT level's HBM-bound traversals, which is
         # where an MFMA-bound product overlaps (two products side by side only time-slice the CUs).
-        nt_first = TN_SIDE is not None and OVERLAP_TN
+        nt_first = side_for(N, dev) is not None
         if nt_first:
             input_gradients()
         if tn[0] is not None and tn[1] is not None:
@@ -3187,8 +3203,7 @@ class TnProblem:
 
     def _side(self):
         """The step's side stream when this product's sums are deferred (nothing reads its partials before a join)."""
-        q = TN_SIDE
-        return q if (q is not None and OVERLAP_TN and self.defer is not None and q.device == self.a.device) else None
+        return side_for(self.shape[0], self.a.device) if self.defer is not None else None
 
     def launch(self):
         import ctypes

@@ -210,9 +210,16 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits:
     ldc = ldn + 4 if want_colsum else ldn
     part = torch.empty((splits, M, ldc), dtype=torch.float32, device=a.device)
     cs_ptr = part[0, 0, ldn:].data_ptr() if want_colsum else 0
-    with torch.cuda.device(a.device), _timed("gemm_tn_bf16", (R, M, N)):
-        _capi.check(lib.spgnn_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc,
-                                           splits, R, M, N, cs_ptr, ldc, M * ldc, _stream(a)), "spgnn_gemm_tn_bf16")
+
+    def go():
+        with torch.cuda.device(a.device), _timed("gemm_tn_bf16", (R, M, N)):
+            _capi.check(lib.spgnn_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc,
+                                               splits, R, M, N, cs_ptr, ldc, M * ldc, _stream(a)), "spgnn_gemm_tn_bf16")
+    side = _ops.side_for(R, a.device) if defer is not None else None      # a training step's side stream (ops.SideLaunch)
+    if side is not None:
+        side.run(go, a, b, part)
+    else:
+        go()
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     cs = torch.empty((M,), dtype=torch.float32, device=a.device) if want_colsum else None
     if defer is not None:                     # ops.SumJobs: the reduction joins the caller's other ones in one launch
@@ -381,6 +388,10 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         need_bias = ctx.has_bias and ctx.needs_input_grad[5]
         g_wfc = g_wres = g_bias = None
         from .ops import SumJobs
+        g_x = None
+        nt_first = ctx.needs_input_grad[0] and _ops.side_for(N, x.device) is not None
+        if nt_first:                                    # the critical-path product first; the weight gradient then runs on the side
+            g_x = gemm_nt(g_y, w_t)                     # stream next to the following layer's traversals (ops.SideLaunch)
         jobs = SumJobs(x.device)                        # the layer's two split-K reductions in one launch
         if ctx.needs_input_grad[1] or (has_res and ctx.needs_input_grad[2]):
             if need_bias and has_res:                   # column sums of g_pre ride along with the operand stream
@@ -399,8 +410,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
             m = attn_vector_grads(g_s, y[:, :HD], H, defer=jobs)
             g_al, g_ar = m[0].view(ctx.attn_shape), m[1].view(ctx.attn_shape)
         jobs.flush()
-        g_x = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not nt_first:
             g_x = gemm_nt(g_y, w_t)
         return g_x, g_wfc, g_wres, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None
 
