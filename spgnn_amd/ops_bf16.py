@@ -23,6 +23,8 @@ from .ops import (ACT_NONE, _ell, _pad16, _padded_rows, _ptr, _require_cuda, _ro
                   scores_from_parts, sum_partials)
 from . import ops as _ops
 
+SIDE_TN_BF16 = False      # weight-gradient products of the bf16 layers on the step's side stream (see gemm_tn): measured slower
+
 BF16 = torch.bfloat16
 
 
@@ -215,7 +217,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, want_colsum: bool = False, splits:
         with torch.cuda.device(a.device), _timed("gemm_tn_bf16", (R, M, N)):
             _capi.check(lib.spgnn_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), part.data_ptr(), ldc, M * ldc,
                                                splits, R, M, N, cs_ptr, ldc, M * ldc, _stream(a)), "spgnn_gemm_tn_bf16")
-    side = _ops.side_for(R, a.device) if defer is not None else None      # a training step's side stream (ops.SideLaunch)
+    # a training step's side stream (ops.SideLaunch) - measured SLOWER on bf16 rows (st_gat_6, 512 trees: 2.117 vs 2.074 ms per
+    # step: the single-product weight gradients are too short for the fork / join to pay), so off unless SIDE_TN_BF16 is set
+    side = _ops.side_for(R, a.device) if (defer is not None and SIDE_TN_BF16) else None
     if side is not None:
         side.run(go, a, b, part)
     else:
@@ -389,7 +393,7 @@ class _GATLayerBf16Fn(torch.autograd.Function):
         g_wfc = g_wres = g_bias = None
         from .ops import SumJobs
         g_x = None
-        nt_first = ctx.needs_input_grad[0] and _ops.side_for(N, x.device) is not None
+        nt_first = SIDE_TN_BF16 and ctx.needs_input_grad[0] and _ops.side_for(N, x.device) is not None
         if nt_first:                                    # the critical-path product first; the weight gradient then runs on the side
             g_x = gemm_nt(g_y, w_t)                     # stream next to the following layer's traversals (ops.SideLaunch)
         jobs = SumJobs(x.device)                        # the layer's two split-K reductions in one launch
