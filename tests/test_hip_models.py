@@ -810,3 +810,37 @@ def test_classifier_weight_gradient_rides_in_act_bwd_proj(name, trees, monkeypat
         else:
             assert torch.equal(got[True][n], v), n
     _ops.DROPOUT_SEED_OFFSET = None
+
+
+@pytest.mark.parametrize("name,trees,min_rows", [("st_pgat_spgnn_3", 6, 1), ("st_gat_3", 6, 1), ("st_pgat_spgnnnl_3", 5, 1), ("st_gin_3", 5, 1),
+                                                   ("st_pgat_spgnn_3", 230, 32768)])
+def test_side_stream_weight_gradients_are_bit_identical(name, trees, min_rows, monkeypatch):
+    """ops.SideLaunch (round 5): a training step issues its weight-gradient products on a side stream, behind the input-gradient
+    products, so that they run next to the following level's traversals.  Only the ORDER of launches and the stream change:
+    the flat gradient bucket and the parameters after two steps are bit for bit those of the single-stream step - eagerly issued
+    and as HIP-graph replays (the side stream is a parallel branch of the captured step) - with the deferred outputs poisoned
+    with NaN so that a sum reading a partial before the join could not pass."""
+    from spgnn_amd import ops as _ops
+    cfg, model = _build(name, seed=17)
+    model.train()
+    g = synthetic.make_batch(trees, rank=8, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    assert g.number_of_nodes() >= min_rows
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    monkeypatch.setattr(_ops, "OVERLAP_TN_MIN_ROWS", min_rows)
+    monkeypatch.setattr(_ops, "DEBUG_POISON_DEFERRED", True)
+    got = {}
+    for side in (True, False):
+        monkeypatch.setattr(_ops, "OVERLAP_TN", side)
+        ts = TrainStep(copy.deepcopy(model), w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=3)
+        ts.step(g); ts._front(g)
+        eager = (ts.bucket.flat_grad.clone(), ts.bucket.flat_param.clone())
+        ts2 = TrainStep(copy.deepcopy(model), w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=3)
+        ts2.capture(g, warmup=1)
+        ts2.replay(); ts2.replay()
+        torch.cuda.synchronize()
+        got[side] = (eager, ts2.bucket.flat_param.clone(), float(ts2._static_loss))
+        assert _ops.TN_SIDE is None
+    assert torch.equal(got[True][0][0], got[False][0][0]) and torch.equal(got[True][0][1], got[False][0][1])
+    assert torch.isfinite(got[True][0][0]).all() and float(got[True][0][0].abs().max()) > 0
+    assert torch.equal(got[True][1], got[False][1]) and got[True][2] == got[False][2]
+    _ops.DROPOUT_SEED_OFFSET = None
