@@ -822,8 +822,8 @@ def test_side_stream_weight_gradients_are_bit_identical(name, trees, min_rows, m
     with NaN so that a sum reading a partial before the join could not pass."""
     from spgnn_amd import ops as _ops
     cfg, model = _build(name, seed=17)
-    model.train()
-    g = synthetic.make_batch(trees, rank=8, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    model.eval()                                     # (the layers' dropout seeds come from torch's global generator: two step objects
+    g = synthetic.make_batch(trees, rank=8, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))   # would draw different masks)
     assert g.number_of_nodes() >= min_rows
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     monkeypatch.setattr(_ops, "OVERLAP_TN_MIN_ROWS", min_rows)
