@@ -318,7 +318,6 @@ STEP_SUMS: Optional["StepSums"] = None          # installed by train.TrainStep w
 
 OVERLAP_TN = True        # a training step issues its weight-gradient products on a side stream (SideLaunch): they overlap the
 TN_SIDE: Optional["SideLaunch"] = None      # traversals that follow; installed by train.TrainStep around forward + backward
-SPLIT_LEVEL0_TN = True         # level 0's structure weight gradient as two products, the g_pre half beside the source-major kernel
 OVERLAP_TN_MIN_ROWS = 32768    # ... for batches of at least this many nodes.  One process, alternating (tools/step_toggle_ab.py, MI355X,
                                # round 5): st_pgat_spgnn_3 4.990 / 4.980 vs 5.058 / 5.037 ms at 512 trees (-1.2 %), st_gat_3 2.880 vs 2.903;
                                # at 64 trees 1.027 vs 1.003 (the fork and join cost more than the short products hide): off there
@@ -2091,13 +2090,6 @@ class _LspeLevelFn(torch.autograd.Function):
         g_e = [torch.empty((E, H), dtype=torch.float32, device=dev) for H in Hs]
         amax = [new_scale_block(dev) for _ in Hs]           # one block per layer: [g_ft | g_pre] is one operand
         g_pre = [g_y[i][:, Hs[i] * D:] if res[i] else torch.empty((N, Hs[i] * D), dtype=torch.float32, device=dev) for i in range(2)]
-        # Level 0 (data inputs: no input gradient follows) with the step's side stream: the structure layer's weight gradient is
-        # issued as TWO products - its g_pre half (res_fc) right after the destination-major kernel, NEXT TO the source-major
-        # kernel, its g_ft half (fc) afterwards - instead of one product alone at the very end of the backward pass.  Each half
-        # then has its own scale block (the halves' producers would otherwise race on one block while the first product reads it).
-        split0 = bool(SPLIT_LEVEL0_TN and side_for(N, dev) is not None and not ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]
-                      and res[0] and ctx.needs_input_grad[2] and (2 * D) * xs[0].shape[1] >= _TN_MIN_ELEMS)
-        amax_pre0 = new_scale_block(dev) if split0 else amax[0]
         nbr8, out_nbr8, out_pos8 = csc.ell()
         GD = (_capi.LspeBwdDstGroup * 2)()
         GS = (_capi.LspeBwdSrcGroup * 2)()
@@ -2106,7 +2098,7 @@ class _LspeLevelFn(torch.autograd.Function):
             d.ft, d.ft_stride = ys[i].data_ptr(), ys[i].stride(0)
             d.el, d.er, d.s_stride, d.attn = ss[i].data_ptr(), ss[i][:, H:].data_ptr(), ss[i].stride(0), attns[i].data_ptr()
             d.g_pre, d.g_pre_stride = g_pre[i].data_ptr(), g_pre[i].stride(0)
-            d.g_e, d.g_er, d.gs_stride, d.absmax = g_e[i].data_ptr(), g_s[i][:, H:].data_ptr(), g_s[i].stride(0), (amax_pre0 if i == 0 else amax[i]).data_ptr()
+            d.g_e, d.g_er, d.gs_stride, d.absmax = g_e[i].data_ptr(), g_s[i][:, H:].data_ptr(), g_s[i].stride(0), amax[i].data_ptr()
             d.H, d.act, d.slope, d.p_drop, d.seed = H, cfg["act"][i], cfg["slope"][i], cfg["p_attn"][i], cfg["seed_attn"][i]
             q.attn, q.g_e, q.g_pre, q.g_pre_stride = attns[i].data_ptr(), g_e[i].data_ptr(), g_pre[i].data_ptr(), g_pre[i].stride(0)
             q.g_ft, q.g_ft_stride = g_y[i].data_ptr(), g_y[i].stride(0)
@@ -2120,22 +2112,14 @@ class _LspeLevelFn(torch.autograd.Function):
                                                    g_xp.stride(0) if g_xp is not None else 0, buf.data_ptr(), buf.stride(0), cfg["fp"],
                                                    cfg["fseed"], xp.data_ptr(), xp.stride(0), cfg["fp2"], cfg["fseed2"], N, E, D,
                                                    _seed_off_ptr(dev), st), "spgnn_lspe_bwd_dst")
-            jobs = SumJobs(dev)                    # the level's four split-K reductions run as one launch at the end
-            half0 = None
-            if split0:
-                HD0 = Hs[0] * D
-                gw0 = torch.empty((2 * HD0, xs[0].shape[1]), dtype=torch.float32, device=dev)
-                xb0 = ctx.x_ps[0]
-                nb0 = ctx.has_bias[0] and ctx.needs_input_grad[8]
-                half0 = TnProblem(g_pre[0], xb0 if xb0 is not None else xs[0], amax_pre0, scl[0][0], want_colsum=bool(nb0), out=gw0[HD0:],
-                                  defer=jobs, b_presplit=xb0 is not None).launch().finish()
             with _timed("lspe_bwd_src", (N, E, D)):
                 _capi.check(lib.spgnn_lspe_bwd_src(csc.out_indptr.data_ptr(), out_nbr8.data_ptr(), out_pos8.data_ptr(), GS, N, E, D,
                                                    _seed_off_ptr(dev), st), "spgnn_lspe_bwd_src")
         grads_x, grads_w, grads_al, grads_ar, grads_b = [None, None], [None, None], [None, None], [None, None], [None, None]
+        jobs = SumJobs(dev)                        # the level's four split-K reductions run as one launch at the end
         tn, nt = [None, None], [None, None]        # the weight-gradient and input-gradient products of both layers: one launch each
         pair_splits = (None, None)
-        if not split0 and PAIR_GEMMS and TN_PAIR_SPLITS and all(ctx.needs_input_grad[2 + i] and g_y[i].shape[1] * xs[i].shape[1] >= _TN_MIN_ELEMS for i in range(2)) \
+        if PAIR_GEMMS and TN_PAIR_SPLITS and all(ctx.needs_input_grad[2 + i] and g_y[i].shape[1] * xs[i].shape[1] >= _TN_MIN_ELEMS for i in range(2)) \
                 and (ctx.x_ps[0] is not None) == (ctx.x_ps[1] is not None):
             pair_splits = tn_pair_splits(N, (g_y[0].shape[1], xs[0].shape[1]), (g_y[1].shape[1], xs[1].shape[1]), ctx.x_ps[0] is not None)
         for i, H in enumerate(Hs):
@@ -2145,10 +2129,7 @@ class _LspeLevelFn(torch.autograd.Function):
             sg = amax[i]
             need_bias = ctx.has_bias[i] and ctx.needs_input_grad[8 + i]
             if ctx.needs_input_grad[2 + i]:
-                if split0 and i == 0:
-                    xb = ctx.x_ps[0]                 # the g_ft half (fc.weight's rows); the g_pre half is already running
-                    tn[0] = TnProblem(g_y[0][:, :HD], xb if xb is not None else x, sg, sx, out=gw0[:HD], defer=jobs, b_presplit=xb is not None)
-                elif g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
+                if g_y[i].shape[1] * K >= _TN_MIN_ELEMS:
                     xb = ctx.x_ps[i]
                     tn[i] = TnProblem(g_y[i], xb if xb is not None else x, sg, sx, want_colsum=bool(need_bias and res[i]), defer=jobs,
                                       b_presplit=xb is not None, splits=pair_splits[i])
@@ -2180,11 +2161,7 @@ class _LspeLevelFn(torch.autograd.Function):
         else:
             r = [t.launch().finish() if t is not None else None for t in tn]
         for i, H in enumerate(Hs):
-            if split0 and i == 0:
-                grads_w[0] = gw0                     # rows [0, HD): the g_ft half's product; [HD, 2 HD): the g_pre half's
-                if isinstance(half0, tuple):
-                    grads_b[0] = half0[1]            # column sums of g_pre = the bias gradient
-            elif tn[i] is not None:
+            if tn[i] is not None:
                 if tn[i].want_colsum:
                     grads_w[i], cs = r[i]
                     grads_b[i] = cs[H * D:]

@@ -828,7 +828,6 @@ def test_side_stream_weight_gradients_are_bit_identical(name, trees, min_rows, m
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     monkeypatch.setattr(_ops, "OVERLAP_TN_MIN_ROWS", min_rows)
     monkeypatch.setattr(_ops, "DEBUG_POISON_DEFERRED", True)
-    monkeypatch.setattr(_ops, "SPLIT_LEVEL0_TN", False)         # (the split level-0 product has its own test below: other scales)
     got = {}
     for side in (True, False):
         monkeypatch.setattr(_ops, "OVERLAP_TN", side)
@@ -844,37 +843,4 @@ def test_side_stream_weight_gradients_are_bit_identical(name, trees, min_rows, m
     assert torch.equal(got[True][0][0], got[False][0][0]) and torch.equal(got[True][0][1], got[False][0][1])
     assert torch.isfinite(got[True][0][0]).all() and float(got[True][0][0].abs().max()) > 0
     assert torch.equal(got[True][1], got[False][1]) and got[True][2] == got[False][2]
-    _ops.DROPOUT_SEED_OFFSET = None
-
-
-@pytest.mark.parametrize("trees,min_rows", [(6, 1), (230, 32768)])
-def test_level0_weight_gradient_as_two_side_stream_products(trees, min_rows, monkeypatch):
-    """ops.SPLIT_LEVEL0_TN (round 5): at level 0 (data inputs, no input gradient) the structure layer's weight gradient is two
-    products - the g_pre half (res_fc.weight, bias) beside the source-major kernel, the g_ft half (fc.weight) afterwards - each
-    with the scale block of its own half.  Same sums, other power-of-two scales: every gradient equals the one-product form to
-    fp32 rounding, every other parameter's gradient bit for bit; eager and captured."""
-    from spgnn_amd import ops as _ops
-    cfg, model = _build("st_pgat_spgnn_3", seed=19)
-    model.eval()
-    g = synthetic.make_batch(trees, rank=9, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
-    w = class_weight_list(cfg.CLASS_WEIGHTS)
-    monkeypatch.setattr(_ops, "OVERLAP_TN_MIN_ROWS", min_rows)
-    monkeypatch.setattr(_ops, "DEBUG_POISON_DEFERRED", True)
-    got = {}
-    for split in (True, False):
-        monkeypatch.setattr(_ops, "SPLIT_LEVEL0_TN", split)
-        m = copy.deepcopy(model)
-        ts = TrainStep(m, w, 1.0, 1e-3, 0.9, seed=3)
-        ts._front(g)
-        grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
-        ts2 = TrainStep(copy.deepcopy(model), w, 1.0, 1e-3, 0.9, seed=3)
-        ts2.capture(g, warmup=1); ts2.replay(); torch.cuda.synchronize()
-        got[split] = (grads, ts2.bucket.flat_param.clone())
-    level0 = ("gat.gat_layers.0.fc.weight", "gat.gat_layers.0.res_fc.weight", "gat.gat_layers.0.bias")
-    for n, v in got[False][0].items():
-        if n in level0:
-            assert rel_err(got[True][0][n], v) < 2e-6 and float(v.abs().max()) > 0, (n, rel_err(got[True][0][n], v))
-        else:
-            assert torch.equal(got[True][0][n], v), n
-    assert rel_err(got[True][1], got[False][1]) < 1e-6
     _ops.DROPOUT_SEED_OFFSET = None
