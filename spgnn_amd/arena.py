@@ -115,6 +115,9 @@ class BatchArena:
                 buf = made[id(v)] = torch.zeros((self.n_cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
             dict.__setitem__(g.ndata, k, buf)            # (plain insert: _NData.__setitem__ would clear the derived cache)
         self.loads = 0
+        self._rows_dirty = 0                      # node-data rows [0, _rows_dirty) may be non-zero (buffers start zeroed)
+        self.refresh_constants = True             # False: the GEMM scales / pre-split images of node data are not refreshed per load
+                                                  # (per-scan inference on the skinny products, which take neither: infer.ForwardRunner)
 
     @staticmethod
     def class_key(g: G.TreeGraph, granule: int = 256):
@@ -128,10 +131,11 @@ class BatchArena:
         return (str(g.device), n_cap, e_cap, csc.max_in_degree <= 8, csc.max_out_degree <= 8,
                 csc.min_in_degree >= 1, int(getattr(csc, "min_out_degree", 0) or 0) >= 1, nd)
 
-    def load(self, g: G.TreeGraph) -> G.TreeGraph:
+    def load(self, g: G.TreeGraph, key=None) -> G.TreeGraph:
         """Copy batch ``g`` (a device graph with its node data; e.g. data.assemble_batch) into the arena, pad it to the class
-        and refresh everything derived from it, in place.  -> the arena's graph (always the same object)."""
-        if self.class_key(g, self.granule) != self.key:
+        and refresh everything derived from it, in place.  -> the arena's graph (always the same object).  ``key``: the
+        batch's class key when the caller has just computed it (per-scan inference: no second pass over the node data dict)."""
+        if (key if key is not None else self.class_key(g, self.granule)) != self.key:
             raise ValueError("batch does not belong to this arena's size class")
         ag, dev = self.graph, self.device
         csc, acsc = g.csc(dev), ag.csc(dev)
@@ -158,7 +162,9 @@ class BatchArena:
                     continue
                 seen.add(id(buf))
                 buf[:N].copy_(v)
-                buf[N:].zero_()
+                if self._rows_dirty > N:                 # pad rows a LARGER earlier batch filled: back to zero (else they still are)
+                    buf[N:self._rows_dirty].zero_()
+        self._rows_dirty = N
         acsc.min_in_degree = min(csc.min_in_degree, 1)
         acsc.max_in_degree = max(csc.max_in_degree, 3 if m > 1 else (2 if m == 1 else 1))
         acsc.max_out_degree = max(csc.max_out_degree, 3 if m > 1 else (2 if m == 1 else 1))
@@ -204,12 +210,14 @@ class BatchArena:
             for key, builder in list(ag._derived_builders.items()):
                 held = ag._tensor_cache[key]
                 held.copy_(builder())
-                ops.refresh_batch_constant(held)
+                if self.refresh_constants:
+                    ops.refresh_batch_constant(held)
             seen = set()
             for v in ag.ndata.values():
                 # every node-data tensor that carries a GEMM scale or a pre-split image, marked constant or not: a captured
                 # step would otherwise keep the previous batch's scale
-                if id(v) not in seen and (getattr(v, "_spgnn_const", False) or hasattr(v, "_spgnn_scale") or hasattr(v, "_spgnn_aps")):
+                if self.refresh_constants and id(v) not in seen and (getattr(v, "_spgnn_const", False) or hasattr(v, "_spgnn_scale")
+                                                                      or hasattr(v, "_spgnn_aps")):
                     ops.refresh_batch_constant(v)
                 seen.add(id(v))
             for fn in ag._refresh_hooks:

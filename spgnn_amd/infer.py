@@ -82,11 +82,15 @@ class ForwardRunner:
             while len(self._classes) >= self.max_classes:
                 self._classes.pop(next(iter(self._classes)))
             arena = BatchArena(g, self.granule)
-            arena.load(g)
+            from . import ops
+            # scans of this class run their projections on the skinny kernel (fp32, no operand scales, no pre-split images):
+            # nothing to refresh per scan beyond the data itself
+            arena.refresh_constants = not (ops.SKINNY_GEMM and arena.n_cap <= ops.SKINNY_ROWS)
+            arena.load(g, key)
             graph, outs, refs = self._capture(arena)
             hit = (arena, graph, outs, refs)
         else:
-            hit[0].load(g)
+            hit[0].load(g, key)
         self._classes[key] = hit                   # re-inserted last: dict order = recency
         hit[1].replay()
         n = g.number_of_nodes()
