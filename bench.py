@@ -250,7 +250,7 @@ def pct(xs, q):
 
 
 def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=False, no_eager_leg=False, no_dropout=False,
-            no_kernel_timers=False, copy_bw=None):
+            no_kernel_timers=False, copy_bw=None, heads=0):
     """One measured workload: build the model and the batch, warm up, capture, time ``steps`` steps between barrier +
     synchronize, then the instrumented eager leg.  -> (the JSON object on rank 0 else None, (cfg, model, samples))."""
     from spgnn_amd import _capi, models, ops, synthetic
@@ -259,6 +259,8 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     _capi.load()                                              # fail loudly if the HIP library is missing
 
     cfg = get_config(config)
+    if heads:                                                 # BASELINE.json words config 2 as "8-head"; the reference file has 2
+        cfg.MODEL["num_heads"] = heads
     torch.manual_seed(0)                                      # identical replicas on every rank
     model = models.build_model(cfg.MODEL).to(dev)
     model.init(None)
@@ -417,7 +419,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             "metric": "message-passing edges/sec (fwd+bwd), batched trees", "value": value, "unit": "layer-edges/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"{config} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
+            "config": {"workload": f"{config}{f' with {heads} heads' if heads else ''} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
                                    f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
                                    f"dropout {'off' if no_dropout else 'on'}",
                        "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
@@ -931,6 +933,7 @@ def main():
     ap.add_argument("--config", default="st_pgat_spgnn_3")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage dtype of node-feature rows inside the GNN head")
     ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
+    ap.add_argument("--heads", type=int, default=0, help="override the hidden GAT layers' head count (0: the config's own)")
     ap.add_argument("--eager", action="store_true",
                     help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
     ap.add_argument("--no-eager-leg", action="store_true", help="graph mode: skip the eager steps after the timed region "
@@ -979,7 +982,7 @@ def main():
         return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
-                                         no_kernel_timers=args.no_kernel_timers)
+                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees) if args.cpu_trees else args.trees)

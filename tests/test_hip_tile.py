@@ -188,3 +188,52 @@ def test_the_default_table_puts_only_the_measured_winners_on_tiles():
     assert ops.tile_plan(csc, 2, 64, 2, "fwd") is None and ops.tile_plan(csc, 2, 64, 2, "dst") is None
     small = synthetic.make_batch(8, rank=0, device="cuda", pos_enc_dim=None, fv_dim=8).csc("cuda")
     assert ops.tile_plan(small, 2, 64, 2, "src") is None
+
+
+@pytest.mark.parametrize("name,bf16", [("st_gat_3", False), ("st_gat_6", True)])
+def test_captured_arena_step_on_tiles_follows_each_loaded_batch(name, bf16, monkeypatch):
+    """End to end what test_arena_rewrites_the_tile_table_in_place checks at table level: a TrainStep captured on batch A with
+    all three traversals on LDS tiles, then REPLAYED on batch B (other trees, other boundaries; the arena rewrites the tile
+    table in place, the captured grid stays), against eager steps on the row kernels over the same batches.  A stale table
+    would put B's nodes into A's tiles (neighbours outside the staged range, rows of other trees): losses and parameters
+    would part at once."""
+    import copy
+    from spgnn_amd import models
+    from spgnn_amd.arena import BatchArena
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    cfg = get_config(name)
+    torch.manual_seed(11)
+    model = models.build_model(cfg.MODEL).cuda()
+    model.init(None)
+    model.set_gcn_only()
+    if bf16:
+        models.set_storage_dtype(model, torch.bfloat16)
+    model.eval()                                                                   # no dropout masks: same arithmetic both ways
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=None)
+    gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=None)
+    GRAN = 2048
+    assert BatchArena.class_key(ga, GRAN) == BatchArena.class_key(gb, GRAN)
+    assert list(ga.batch_num_nodes_list) != list(gb.batch_num_nodes_list)
+    m_rows = copy.deepcopy(model)
+    monkeypatch.setattr(ops, "TILE_KERNELS", True)
+    monkeypatch.setattr(ops, "TILE_FORCE", True)
+    ts = TrainStep(model, w, 1.0, 1e-3, 0.9)
+    la = ts.run_batch(ga, 4, granule=GRAN)
+    arena = next(iter(ts._arenas.values()))
+    acsc = arena.graph.csc("cuda")
+    assert ops.tile_plan(acsc, 2, 64, 2 if bf16 else 4, "src") is not None         # the captured step did run on tiles
+    lb = ts.run_batch(gb, 4, granule=GRAN)
+    assert len(ts._captures) == 1 and arena.loads == 2
+    monkeypatch.setattr(ops, "TILE_KERNELS", False)
+    monkeypatch.setattr(ops, "TILE_FORCE", False)
+    ts_r = TrainStep(m_rows, w, 1.0, 1e-3, 0.9)
+    for _ in range(4):
+        lra = ts_r.step(ga)
+    for _ in range(4):
+        lrb = ts_r.step(gb)
+    tol = 2e-2 if bf16 else 1e-5
+    n = ts.bucket.numel
+    assert rel_err(la, lra) < tol and rel_err(lb, lrb) < tol, (rel_err(la, lra), rel_err(lb, lrb))
+    assert rel_err(ts.bucket.flat_param[:n], ts_r.bucket.flat_param[:n]) < tol
