@@ -37,12 +37,10 @@ __device__ __attribute__((aligned(16))) uint16_t g_zero_chunk[8];
 
 constexpr int BN = 128;          // tile columns (2 waves x 64)
 constexpr int SUB = 32;          // elements per LDS sub-image row (64 bytes), two k16 MFMA steps
-// One 32-element sub-image per stage and three stage buffers: two stages of DMA are in flight while one is consumed.  With
-// two sub-images per stage and two buffers (round 2) the 1024 -> 1024 product took 183 us, with this 174; 512 -> 512 61 / 58;
-// 384 -> 1024 97 / 92; four buffers 173 / 61 / 97 (tools/gemm_bf16_ab.py, one process; results bit-identical: the k order
-// does not change).
+// One 32-element sub-image per stage (with two per stage and two buffers, round 2, the 1024 -> 1024 product took 183 us
+// against 174 with three buffers of one) and NBUF stage buffers, a template parameter of the NT kernel: every buffer but the
+// one being consumed holds a stage of DMA in flight.  Results do not depend on either: the k order does not change.
 constexpr int KSUB = 1;          // sub-images per stage: BK = 32 KSUB elements per barrier
-constexpr int NBUF = 3;          // LDS stage buffers: NBUF - 1 stages of DMA in flight while one is consumed
 
 struct ArgsNT {
   const uint16_t* A; int64_t lda;
@@ -120,8 +118,8 @@ __device__ __forceinline__ bf16x8 frag_swz(const uint16_t* img, int row, int chu
   return *reinterpret_cast<const bf16x8*>(img + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3));
 }
 
-template <int WM, int WN, int MI> constexpr int nt_lds_bytes() {
-  const int stages = NBUF * KSUB * (32 * MI * WM * SUB + 64 * WN * SUB) * 2, slabs = WM * WN * 32 * 68 * 4;
+template <int WM, int WN, int MI, int NB> constexpr int nt_lds_bytes() {
+  const int stages = NB * KSUB * (32 * MI * WM * SUB + 64 * WN * SUB) * 2, slabs = WM * WN * 32 * 68 * 4;
   return stages > slabs ? stages : slabs;
 }
 
@@ -129,7 +127,7 @@ template <int WM, int WN, int MI> constexpr int nt_lds_bytes() {
 //   <2, 2, 2> 128 x 128 (4 waves, two blocks per CU), <4, 2, 2> 256 x 128 (8 waves), <2, 4, 4> 256 x 256 (8 waves of
 //   128 x 64: per MFMA 3/4 of the LDS fragment bytes of the 64 x 64 wave tile - with 64 x 64 wave tiles the fragment reads
 //   of a stage take as many LDS cycles as its MFMAs take matrix-pipe cycles - and half the DMA bytes of the 256 x 128 tile).
-template <int WM, int WN, int MI, bool F32OUT>
+template <int WM, int WN, int MI, bool F32OUT, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_bf16(ArgsNT a) {
   constexpr int TBM = 32 * MI * WM, TBN = 64 * WN, NT = 64 * WM * WN;
   constexpr int A_IMG = TBM * SUB, B_IMG = TBN * SUB;             // elements per sub-image
@@ -164,40 +162,69 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_nt_
       stage_image<TBN, NT>(a.B, a.ldb, col0, a.N, ((T_) * KSUB + u_) * SUB, a.K8, sb_ + u_ * (A_IMG + B_IMG) + A_IMG); \
     }                                                                                                        \
   }
-  constexpr int P = NBUF - 1;                               // stages in flight ahead of the one being consumed
+  // ONE barrier per stage, fragments read one k16 step ahead of the MFMAs that consume them: the reads of a stage's second
+  // step are issued before the first step's MFMAs, the reads of the NEXT stage's first step (behind the barrier that makes
+  // it visible) before the second step's - no MFMA waits on an LDS read issued right before it, and the barrier that
+  // publishes stage t + 1 is also the one after which stage t's buffer may be refilled (every wave's reads of it have
+  // returned: lgkmcnt(0) before the barrier).
+  static_assert(KSUB == 1 && SUB == 32 && NBUF >= 3, "the pipelined loop walks two k16 steps per stage");
+  auto read_frags = [&](const uint16_t* cb, const int ks, bf16x8 (&af)[MI], bf16x8 (&bf)[2]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = frag_swz(cb, wm * (32 * MI) + i * 32 + fr, ks * 2 + fh);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[j] = frag_swz(cb + A_IMG, wn * 64 + j * 32 + fr, ks * 2 + fh);
+  };
+  // the MFMAs of one k16 step in two parts: the first one alone (it waits for the step's fragments, read a whole step
+  // ago), then - behind the reads of the NEXT step, pinned there by scheduling barriers: left to itself the compiler hoists
+  // those reads above the first MFMA and then waits for all of them with one lgkmcnt(0) - the other 2 MI - 1
+  auto mma_first = [&](const bf16x8 (&af)[MI], const bf16x8 (&bf)[2]) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][0], 0, 0, 0);
+  };
+  auto mma_rest = [&](const bf16x8 (&af)[MI], const bf16x8 (&bf)[2]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  constexpr int P = NBUF;                                   // stages issued before the first one is consumed: every buffer
 #pragma unroll
   for (int p_ = 0; p_ < P; ++p_)
     if (p_ < nk) SPGNN_STAGE_IN(p_)
-  for (int t = 0; t < nk; ++t) {
-    if (t + P < nk) {
-      SPGNN_STAGE_IN(t + P)                                 // into the buffer the previous iteration consumed
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * P) : "memory");   // all but the newest P stages have landed: stage t is there
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                           // every wave's pieces of stage t have landed
-    const uint16_t* cb = smem + (t % NBUF) * STAGE;
-#pragma unroll
-    for (int u = 0; u < KSUB; ++u) {
-      const uint16_t* ai = cb + u * (A_IMG + B_IMG);
-      const uint16_t* bi = ai + A_IMG;
-#pragma unroll
-      for (int ks = 0; ks < SUB / 16; ++ks) {
-        bf16x8 af[MI], bf[2];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = frag_swz(ai, wm * (32 * MI) + i * 32 + fr, ks * 2 + fh);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = frag_swz(bi, wn * 64 + j * 32 + fr, ks * 2 + fh);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                           // buffer t & 1 is free for stage t + 2
+  // stage 0 has landed when at most the P - 1 stages behind it are outstanding
+  if (nk >= P) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (P - 1)) : "memory"); }
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a0[MI], b0[2], a1[MI], b1[2];
+  read_frags(smem, 0, a0, b0);
+  for (int t = 0; t + 1 < nk; ++t) {                        // (the last stage is peeled: no branch around an MFMA)
+    mma_first(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(smem + (t % NBUF) * STAGE, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rest(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    // issued so far: stages 0 .. t + P - 1; stage t + 1 has landed when at most the P - 2 behind it are outstanding
+    if (t + P - 1 < nk) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS * (P - 2)) : "memory"); }
+    else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();                           // stage t + 1 visible; nobody reads stage t's buffer any more
+    mma_first(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + P < nk) SPGNN_STAGE_IN(t + P)                   // into the buffer of stage t (P == NBUF)
+    read_frags(smem + ((t + 1) % NBUF) * STAGE, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rest(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  mma_first(a0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(smem + ((nk - 1) % NBUF) * STAGE, 1, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_rest(a0, b0);
+  mma_first(a1, b1);
+  mma_rest(a1, b1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                             // the epilogue slabs overlay the stage buffers
 #undef SPGNN_STAGE_IN
 
   // Epilogue through LDS: an accumulator register holds one element of 32 different columns of one row, which would
@@ -593,19 +620,21 @@ static int gemm_nt_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, 
            score_out ? score_cols : 0, score_layout};
   const unsigned grid = (unsigned)((nbm * nbn + 7) / 8 * 8);
   hipStream_t st = (hipStream_t)stream;
-#define SPGNN_NT_LAUNCH(WM_, WN_, MI_, F32_)                                                                  \
-  {                                                                                                          \
-    constexpr int lds_ = nt_lds_bytes<WM_, WN_, MI_>();                                                      \
-    const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm_nt_bf16<WM_, WN_, MI_, F32_>, lds_);  \
-    if (rc_ != SPGNN_OK) return rc_;                                                                         \
-    hipLaunchKernelGGL((gemm_nt_bf16<WM_, WN_, MI_, F32_>), dim3(grid), dim3(64 * WM_ * WN_), lds_, st, a);  \
+#define SPGNN_NT_LAUNCH(WM_, WN_, MI_, F32_, NB_)                                                                  \
+  {                                                                                                               \
+    constexpr int lds_ = nt_lds_bytes<WM_, WN_, MI_, NB_>();                                                      \
+    const int rc_ = spgnn_detail::ensure_dynamic_lds((const void*)gemm_nt_bf16<WM_, WN_, MI_, F32_, NB_>, lds_);  \
+    if (rc_ != SPGNN_OK) return rc_;                                                                              \
+    hipLaunchKernelGGL((gemm_nt_bf16<WM_, WN_, MI_, F32_, NB_>), dim3(grid), dim3(64 * WM_ * WN_), lds_, st, a);  \
   }
+  // stage buffers (tools/gemm_bf16_ab.py, M = 76 410, us with 3 / 4 buffers): 256 x 256 tiles 1024 -> 1024 178 / 174; 256 x 128
+  // tiles 1024 -> 512 114 / 102, 512 -> 512 65 / 59; 128 x 128 tiles (two blocks per CU) 512 -> 256 34 / 36, 256 -> 128 16 / 18
   if (sq) {
-    if (c_is_f32) SPGNN_NT_LAUNCH(2, 4, 4, true) else SPGNN_NT_LAUNCH(2, 4, 4, false)
+    if (c_is_f32) SPGNN_NT_LAUNCH(2, 4, 4, true, 4) else SPGNN_NT_LAUNCH(2, 4, 4, false, 4)
   } else if (big) {
-    if (c_is_f32) SPGNN_NT_LAUNCH(4, 2, 2, true) else SPGNN_NT_LAUNCH(4, 2, 2, false)
+    if (c_is_f32) SPGNN_NT_LAUNCH(4, 2, 2, true, 4) else SPGNN_NT_LAUNCH(4, 2, 2, false, 4)
   } else {
-    if (c_is_f32) SPGNN_NT_LAUNCH(2, 2, 2, true) else SPGNN_NT_LAUNCH(2, 2, 2, false)
+    if (c_is_f32) SPGNN_NT_LAUNCH(2, 2, 2, true, 3) else SPGNN_NT_LAUNCH(2, 2, 2, false, 3)
   }
 #undef SPGNN_NT_LAUNCH
   return check_launch("spgnn_gemm_nt_bf16");

@@ -49,10 +49,12 @@ def test_gemm_nt_bf16_exact_on_integers(M, N, K):
     assert out16.dtype == BF and torch.equal(out16.float().cpu(), (a @ b.t()).to(BF).float())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 512, 1063), (2049, 132, 40), (777, 1024, 200), (260, 260, 264)])
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 512, 1063), (2049, 132, 40), (777, 1024, 200), (260, 260, 264),
+                                   (260, 260, 8), (300, 132, 96), (515, 256, 104), (300, 128, 160), (258, 64, 192)])
 def test_gemm_nt_bf16_every_tile_variant(M, N, K):
     """128 x 128, 256 x 128 and 256 x 256 (waves of 128 x 64) block tiles: exact on integers, bit-identical to each other on
-    random data with bias + ELU and with the score partials, fp32 and bf16 results, ragged rows / columns / K."""
+    random data with bias + ELU and with the score partials, fp32 and bf16 results, ragged rows / columns / K; 1 to 34 k
+    stages of 32 (the kernels keep 3 or 4 stages in flight and peel the last: fewer stages than buffers, as many, one more)."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randint(-3, 4, (M, K), generator=g).float()
     b = torch.randint(-3, 4, (N, K), generator=g).float()

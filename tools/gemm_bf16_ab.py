@@ -41,4 +41,12 @@ for (C, K) in shapes:
             _capi._lib = lib
             res[n].append(t_once(fn))
     fl = 2.0 * R * C * K
+    if kind == "nt":                                   # yardstick only (the library's product of the same operands; never shipped)
+        xt, wt = x[:, :K], w[:, :K]
+        lib = sorted(t_once(lambda: torch.mm(xt, wt.t())) for _ in range(7))[3]
+        print(f"   torch.mm (hipBLASLt/rocBLAS) {lib*1e3:.0f} us ({fl/lib/1e9:.0f} TF)", flush=True)
+    else:
+        gt, xt = g[:, :C], x[:, :K]
+        lib = sorted(t_once(lambda: torch.mm(gt.t(), xt)) for _ in range(7))[3]
+        print(f"   torch.mm (hipBLASLt/rocBLAS, bf16 out) {lib*1e3:.0f} us ({fl/lib/1e9:.0f} TF)", flush=True)
     print(f"{kind} C={C} K={K} identical={same}: " + "  ".join(f"{n} {sorted(v)[len(v)//2]*1e3:.0f} us ({fl/sorted(v)[len(v)//2]/1e9:.0f} TF)" for n, v in res.items()), flush=True)
