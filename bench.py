@@ -117,6 +117,15 @@ def algorithmic_bytes(key) -> float:
     if base == "masked_ce":
         _, N, C = key
         return 4 * 2 * N * C + 4 * 4 * N
+    if base == "loss_rows":          # the step's mask as a row list (TrainStep(loss_rows_only=True)): read p twice, write idx and inv
+        _, N, cap = key
+        return 4 * 3 * N + 4 * cap
+    if base == "gather_rows":        # listed rows in, list-order rows out
+        _, cap, C = key
+        return 4 * 2 * cap * C
+    if base == "expand_rows":        # list-order rows in (at most), node-order rows out
+        _, N, C = key
+        return 4 * N * C
     if base in ("gemm_nt", "gemm_tn", "gemm_nt_pair", "gemm_tn_pair") or base in HELPER_NAMES:
         return 0.0                    # compute-side kernels: accounted in "gemm" / "composite", not in the message-passing bytes
     if base == "spmm_sum":
@@ -250,7 +259,7 @@ def pct(xs, q):
 
 
 def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=False, no_eager_leg=False, no_dropout=False,
-            no_kernel_timers=False, copy_bw=None, heads=0):
+            no_kernel_timers=False, copy_bw=None, heads=0, loss_rows=False):
     """One measured workload: build the model and the batch, warm up, capture, time ``steps`` steps between barrier +
     synchronize, then the instrumented eager leg.  -> (the JSON object on rank 0 else None, (cfg, model, samples))."""
     from spgnn_amd import _capi, models, ops, synthetic
@@ -276,7 +285,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     g.csc(dev)                                                # CSC/CSR built once per loader batch (static for all steps)
     N, E = g.number_of_nodes(), g.number_of_edges()
     step = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, cfg.OPTIMIZER["lr"],
-                     cfg.OPTIMIZER["momentum"], seed=1234 + rank)
+                     cfg.OPTIMIZER["momentum"], seed=1234 + rank, loss_rows_only=loss_rows)
 
     def sync():
         torch.cuda.synchronize()
@@ -421,7 +430,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{config}{f' with {heads} heads' if heads else ''} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
                                    f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
-                                   f"dropout {'off' if no_dropout else 'on'}",
+                                   f"dropout {'off' if no_dropout else 'on'}" + (", loss rows only behind the last aggregation" if loss_rows else ""),
                        "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
                        "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc,
@@ -933,6 +942,9 @@ def main():
     ap.add_argument("--config", default="st_pgat_spgnn_3")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage dtype of node-feature rows inside the GNN head")
     ap.add_argument("--trees", type=int, default=512, help="trees per GPU")
+    ap.add_argument("--loss-rows-only", action="store_true",
+                    help="TrainStep(loss_rows_only=True): output-layer projection, classifier and their backward products on the rows the "
+                         "step's mask keeps only (same loss and gradients; NOT the headline: the headline runs every row)")
     ap.add_argument("--heads", type=int, default=0, help="override the hidden GAT layers' head count (0: the config's own)")
     ap.add_argument("--eager", action="store_true",
                     help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
@@ -982,7 +994,7 @@ def main():
         return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
-                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads)
+                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads, loss_rows=args.loss_rows_only)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees) if args.cpu_trees else args.trees)
@@ -1000,6 +1012,23 @@ def main():
                     del o2, _ctx
                 except Exception as e:                  # never lose the headline to a secondary leg
                     sec[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+            # the headline workload with TrainStep(loss_rows_only=True) - NOT the headline number: the headline runs every row of
+            # every layer, as the reference's forward does; this leg runs what follows the last aggregation on the rows the
+            # step's mask keeps (no other row reaches the loss or a gradient: same loss, same gradients)
+            try:
+                o2, _ctx = run_leg("st_pgat_spgnn_3", "f32", 512, min(args.steps, 20), min(args.warmup, 5), rank=0, world=1, dev=dev,
+                                   no_dropout=args.no_dropout, no_kernel_timers=args.no_kernel_timers,
+                                   copy_bw=out.get("copy_bandwidth"), loss_rows=True)
+                s2 = secondary_summary(o2)
+                s2["what"] = ("the headline workload with TrainStep(loss_rows_only=True): output-layer projection, head mean, classifier and "
+                              "their backward products only on the rows the step's mask keeps (reference job_runner.py:1896-1900 takes the "
+                              "loss over pre[mask]); identical loss and gradients up to fp32 summation order "
+                              "(tests/test_hip_loss_rows.py); every traversal still visits every edge")
+                sec["st_pgat_spgnn_3_f32_512_loss_rows_only"] = s2
+                del o2, _ctx
+            except Exception as e:
+                sec["st_pgat_spgnn_3_f32_512_loss_rows_only"] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
             try:
                 sec["batch_cycle_64"] = batch_cycle(dev)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 56
+#define SPGNN_ABI_VERSION 57
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -778,6 +778,34 @@ int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64
                          float* g_colsum /* nullable, C <= 32, needs sums + g_logits: sum_i g_logits[i, :] - the gradient of a classifier
                                             bias - added by the last workgroup in block order */,
                          int64_t N, int32_t C, spgnn_stream_t stream);
+
+/*
+ * The rows of a step that reach the loss.  The reference evaluates ``F.cross_entropy(pre[mask], y[mask], weight=w)``
+ * (job_runner.py:1896-1900): a node outside the mask contributes neither to the loss nor to any gradient, and the output
+ * layer's projection, the classifier (models.py:1127-1174) and their backward products are row-wise - a training step may
+ * run them on the kept rows only (spgnn_amd.train.TrainStep(loss_rows_only=True); identical loss and gradients).
+ * spgnn_loss_rows lists the kept nodes in ascending order with the loss kernel's own draw (`draws`, or - null - the counter
+ * hash of (draw_seed, seed_offset[0], node)): idx[0 .. cnt) = the nodes, idx[cnt .. cap) = 0, inv[n] = position of node n
+ * or -1, cnt_flag[0] = cnt = min(kept, cap), cnt_flag[1] set (never cleared) when kept > cap - spgnn_masked_ce_rows then
+ * returns NaN sums.  block_counts: workspace of ceil(N / 256) int32.  Two launches, no host synchronisation.
+ */
+int spgnn_loss_rows(const float* draws /* nullable */, uint64_t draw_seed, const int64_t* seed_offset /* nullable */,
+                    const float* sampling_p, int64_t N, int32_t* block_counts, int32_t cap, int32_t* idx, int32_t* inv,
+                    int32_t* cnt_flag, spgnn_stream_t stream);
+/* dst[c, :] = c < cnt_flag[0] ? src[idx[c], :] : 0 for c in [0, cap); cols % 4 == 0, 16-byte aligned rows. */
+int spgnn_gather_rows(const float* src, int64_t src_stride, const int32_t* idx, const int32_t* cnt_flag, int64_t cap, int32_t cols,
+                      float* dst, int64_t dst_stride, spgnn_stream_t stream);
+/* dst[n, :] = inv[n] >= 0 ? src[inv[n], :] : 0 for n in [0, N): the listed rows back in node order, zeros elsewhere. */
+int spgnn_expand_rows(const float* src, int64_t src_stride, const int32_t* inv, int64_t N, int32_t cols, float* dst,
+                      int64_t dst_stride, spgnn_stream_t stream);
+/*
+ * spgnn_masked_ce_step on LISTED rows: logits / g_logits have `cap` rows, row i belongs to node rows[i] (its label:
+ * labels[rows[i]]) and counts when i < rows_cnt[0]; no draw (the list is the draw).  Same sums, gradient and column sums.
+ */
+int spgnn_masked_ce_rows(const float* logits, int64_t logits_stride, const int64_t* labels, const int32_t* rows,
+                         const int32_t* rows_cnt, const float* class_weight, float* partials, float* sums, uint32_t* ticket,
+                         float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum, int64_t cap, int32_t C,
+                         spgnn_stream_t stream);
 
 /*
  * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's

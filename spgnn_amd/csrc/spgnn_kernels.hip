@@ -2649,6 +2649,118 @@ __global__ __launch_bounds__(64) void distal_leafs_kernel(const int32_t* __restr
 }
 
 // =================================================================================================
+// The rows of a step that reach the loss (reference job_runner.py:1896-1900: ``pre[mask]`` - labelled nodes always, the others
+// with probability SAMPLING_RATE).  The output layer's projection, the classifier and their backward products are row-wise:
+// a row outside the mask influences neither the loss nor any gradient, so a training step may evaluate them on the kept
+// rows only.  spgnn_loss_rows lists those rows in ascending node order (the same draw as the loss kernel: `draws`, or the
+// counter hash of (draw_seed, step counter, node)), spgnn_gather_rows / spgnn_expand_rows move rows between the node order
+// and the list.  Two launches: per-block counts, then every block sums the counts before it and writes its nodes - the
+// list's order does not depend on scheduling.
+// =================================================================================================
+__device__ __forceinline__ bool loss_row_kept(const float* __restrict__ draws, uint64_t sd, const float* __restrict__ p, int64_t i) {
+  const float rn = draws ? draws[i] : (float)(uint32_t)(mix64(sd, i) >> 40) * (1.0f / 16777216.0f);
+  return rn < p[i];
+}
+
+__global__ __launch_bounds__(kBlock) void loss_rows_count_kernel(const float* __restrict__ draws, uint64_t draw_seed,
+                                                                 const int64_t* __restrict__ seed_off, const float* __restrict__ p,
+                                                                 int64_t N, int32_t* __restrict__ counts) {
+  __shared__ int wsum[kBlock / 64];
+  const uint64_t sd = draw_seed + (seed_off ? 0xD1B54A32D192ED03ull * (uint64_t)seed_off[0] : 0ull);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool keep = i < N && loss_row_kept(draws, sd, p, i);
+  const unsigned long long b = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < kBlock / 64; ++q) t += wsum[q];
+    counts[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void loss_rows_write_kernel(const float* __restrict__ draws, uint64_t draw_seed,
+                                                                 const int64_t* __restrict__ seed_off, const float* __restrict__ p,
+                                                                 int64_t N, const int32_t* __restrict__ counts, int32_t cap,
+                                                                 int32_t* __restrict__ idx, int32_t* __restrict__ inv,
+                                                                 int32_t* __restrict__ cnt_flag) {
+  __shared__ int red[kBlock / 64];
+  __shared__ int wsum[kBlock / 64];
+  __shared__ int base_s, total_s;
+  // counts of the blocks before this one (and of all of them): each thread a strided share, then the block's sum
+  int before = 0, all = 0;
+  for (unsigned q = threadIdx.x; q < gridDim.x; q += kBlock) {
+    const int c = counts[q];
+    all += c;
+    if (q < blockIdx.x) before += c;
+  }
+  for (int pass = 0; pass < 2; ++pass) {                        // integer sums: wave shuffles, then the block's waves through LDS
+    int v = pass == 0 ? before : all;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+#pragma unroll
+      for (int q = 0; q < kBlock / 64; ++q) t += red[q];
+      if (pass == 0) base_s = t; else total_s = t;
+    }
+    __syncthreads();
+  }
+  const uint64_t sd = draw_seed + (seed_off ? 0xD1B54A32D192ED03ull * (uint64_t)seed_off[0] : 0ull);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool keep = i < N && loss_row_kept(draws, sd, p, i);
+  const unsigned long long b = __ballot(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wsum[wave] = __popcll(b);
+  __syncthreads();
+  int pos = base_s + __popcll(b & ((1ull << lane) - 1ull));
+  for (int q = 0; q < wave; ++q) pos += wsum[q];
+  if (i < N) {
+    const bool in = keep && pos < cap;
+    if (in) idx[pos] = (int32_t)i;
+    inv[i] = in ? pos : -1;
+  }
+  if (blockIdx.x == 0) {
+    const int total = total_s;
+    const int cnt = total < cap ? total : cap;
+    if (threadIdx.x == 0) {
+      cnt_flag[0] = cnt;
+      if (total > cap) cnt_flag[1] = 1;                       // sticky: the host reads it once per loader batch
+    }
+    for (int c = cnt + (int)threadIdx.x; c < cap; c += kBlock) idx[c] = 0;    // unused slots name a valid node
+  }
+}
+
+// dst[c, :] = c < cnt ? src[idx[c], :] : 0, c in [0, cap)   (cols4 = columns / 4; rows 16-byte aligned)
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ cnt_flag, int64_t cap, int cols4,
+                                                             float* __restrict__ dst, int64_t ldd) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= cap * cols4) return;
+  const int64_t c = e / cols4;
+  const int k = (int)(e - c * cols4) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < (int64_t)cnt_flag[0]) v = ld4(src + (int64_t)idx[c] * lds_ + k);
+  st4(dst + c * ldd + k, v);
+}
+
+// dst[n, :] = inv[n] >= 0 ? src[inv[n], :] : 0, n in [0, N)
+__global__ __launch_bounds__(kBlock) void expand_rows_kernel(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ inv,
+                                                             int64_t N, int cols4, float* __restrict__ dst, int64_t ldd) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= N * cols4) return;
+  const int64_t n = e / cols4;
+  const int k = (int)(e - n * cols4) * 4;
+  const int32_t c = inv[n];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c >= 0) v = ld4(src + (int64_t)c * lds_ + k);
+  st4(dst + n * ldd + k, v);
+}
+
+// =================================================================================================
 // Masked, class-weighted cross entropy in one pass (reference job_runner.py:1896-1900:
 // mask = rn < sampling_t; loss = F.cross_entropy(pre[mask], y[mask], weight=w)).  One thread per node:
 //   m_i = rn_i < sampling_p[i];  nll_i = logsumexp(logits[i,:]) - logits[i, y_i]
@@ -2667,7 +2779,11 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
                                                            const float* __restrict__ class_w, float* __restrict__ partial,
                                                            float* __restrict__ sums, unsigned* __restrict__ ticket,
                                                            float* __restrict__ g_logits, int64_t g_ld, float* __restrict__ colpart,
-                                                           float* __restrict__ colsum, int64_t N, int C) {
+                                                           float* __restrict__ colsum, int64_t N, int C,
+                                                           const int32_t* __restrict__ row_list, const int32_t* __restrict__ rows_cnt) {
+  // `row_list` (spgnn_masked_ce_rows): logits / g_logits hold one row per LISTED node (spgnn_loss_rows: the nodes the mask keeps,
+  // rows_cnt[0] of them, rows_cnt[1] != 0 when the list overflowed its capacity): row i belongs to node row_list[i], its mask
+  // is i < rows_cnt[0] - no draw here, the list IS the draw - and an overflow turns every weight into NaN
   __shared__ float red[2][kBlock / 64];
   __shared__ bool last;
   // C <= 32 (the 22 airway labels): the block's 256 rows go through LDS, so that the global loads and the gradient stores are
@@ -2688,16 +2804,21 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
   float num = 0.f, den = 0.f;
   if (i < N) {
     const float* row = staged ? tile + threadIdx.x * P : logits + i * ld;
-    const int64_t yl = labels[i];
-    const bool y_ok = yl >= 0 && yl < C;                     // F.cross_entropy raises for such a label; here the node gets a
-    const int y = y_ok ? (int)yl : 0;                        // NaN weight, so the loss is NaN instead of an out-of-bounds read
-    float rn;
-    if (draws) rn = draws[i];
+    const bool listed = row_list != nullptr && i < (int64_t)rows_cnt[0];
+    const int64_t yl = row_list ? (listed ? labels[row_list[i]] : 0) : labels[i];
+    const bool y_ok = yl >= 0 && yl < C && !(row_list && rows_cnt[1] != 0);   // F.cross_entropy raises for such a label; here the node
+    const int y = y_ok ? (int)yl : 0;                        // gets a NaN weight, so the loss is NaN instead of an out-of-bounds read
+    float m;
+    if (row_list) m = listed ? 1.f : 0.f;
     else {
-      const uint64_t sd = draw_seed + (seed_off ? 0xD1B54A32D192ED03ull * (uint64_t)seed_off[0] : 0ull);
-      rn = (float)(uint32_t)(mix64(sd, i) >> 40) * (1.0f / 16777216.0f);
+      float rn;
+      if (draws) rn = draws[i];
+      else {
+        const uint64_t sd = draw_seed + (seed_off ? 0xD1B54A32D192ED03ull * (uint64_t)seed_off[0] : 0ull);
+        rn = (float)(uint32_t)(mix64(sd, i) >> 40) * (1.0f / 16777216.0f);
+      }
+      m = rn < sampling_p[i] ? 1.f : 0.f;
     }
-    const float m = rn < sampling_p[i] ? 1.f : 0.f;
     const float w = y_ok ? m * class_w[y] : NAN;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
@@ -4029,21 +4150,74 @@ int spgnn_masked_ce(const float* logits, int64_t logits_stride, const int64_t* l
                               g_logits, g_stride, nullptr, nullptr, N, C, stream);
 }
 
-int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
-                         const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
-                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum,
-                         int64_t N, int32_t C, spgnn_stream_t stream) {
+static int masked_ce_launch(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                            const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
+                            float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum,
+                            int64_t N, int32_t C, const int32_t* rows, const int32_t* rows_cnt, spgnn_stream_t stream) {
   if (N < 0 || C <= 0) return fail(SPGNN_ERR_SHAPE, "spgnn_masked_ce: bad N/C");
   if (N == 0) {
     if (sums) { const hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream); if (e != hipSuccess) return fail(-(1000 + (int)e), "spgnn_masked_ce_step: hipMemsetAsync"); }
     return SPGNN_OK;
   }
-  if (!logits || !labels || !sampling_p || !class_weight || !partials || (sums && !ticket)) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
+  if (!logits || !labels || !class_weight || !partials || (sums && !ticket)) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
   if (logits_stride < C || (g_logits && g_stride < C)) return fail(SPGNN_ERR_STRIDE, "spgnn_masked_ce: row stride smaller than row");
   hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, logits,
                      logits_stride, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, partials, sums, ticket, g_logits,
-                     g_stride, (sums && g_colsum && C <= 32) ? colsum_partials : nullptr, g_colsum, N, C);
+                     g_stride, (sums && g_colsum && C <= 32) ? colsum_partials : nullptr, g_colsum, N, C, rows, rows_cnt);
   return check_launch("spgnn_masked_ce");
+}
+
+int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                         const int64_t* seed_offset, const float* sampling_p, const float* class_weight, float* partials,
+                         float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum,
+                         int64_t N, int32_t C, spgnn_stream_t stream) {
+  if (!sampling_p) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce: null pointer");
+  return masked_ce_launch(logits, logits_stride, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, partials, sums, ticket,
+                          g_logits, g_stride, colsum_partials, g_colsum, N, C, nullptr, nullptr, stream);
+}
+
+int spgnn_masked_ce_rows(const float* logits, int64_t logits_stride, const int64_t* labels, const int32_t* rows, const int32_t* rows_cnt,
+                         const float* class_weight, float* partials, float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride,
+                         float* colsum_partials, float* g_colsum, int64_t cap, int32_t C, spgnn_stream_t stream) {
+  if (!rows || !rows_cnt) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce_rows: null pointer");
+  return masked_ce_launch(logits, logits_stride, labels, nullptr, 0, nullptr, nullptr, class_weight, partials, sums, ticket, g_logits,
+                          g_stride, colsum_partials, g_colsum, cap, C, rows, rows_cnt, stream);
+}
+
+int spgnn_loss_rows(const float* draws, uint64_t draw_seed, const int64_t* seed_offset, const float* sampling_p, int64_t N,
+                    int32_t* block_counts, int32_t cap, int32_t* idx, int32_t* inv, int32_t* cnt_flag, spgnn_stream_t stream) {
+  if (N < 0 || cap <= 0 || N > (1ll << 30)) return fail(SPGNN_ERR_SHAPE, "spgnn_loss_rows: bad N / cap");
+  if (!sampling_p || !block_counts || !idx || !inv || !cnt_flag) return fail(SPGNN_ERR_NULLPTR, "spgnn_loss_rows: null pointer");
+  const unsigned nb = N > 0 ? scalar_grid(N) : 1u;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_rows_count_kernel, dim3(nb), dim3(kBlock), 0, st, draws, draw_seed, seed_offset, sampling_p, N, block_counts);
+  hipLaunchKernelGGL(loss_rows_write_kernel, dim3(nb), dim3(kBlock), 0, st, draws, draw_seed, seed_offset, sampling_p, N, block_counts,
+                     cap, idx, inv, cnt_flag);
+  return check_launch("spgnn_loss_rows");
+}
+
+int spgnn_gather_rows(const float* src, int64_t src_stride, const int32_t* idx, const int32_t* cnt_flag, int64_t cap, int32_t cols,
+                      float* dst, int64_t dst_stride, spgnn_stream_t stream) {
+  if (cap < 0 || cols <= 0 || (cols & 3)) return fail(SPGNN_ERR_SHAPE, "spgnn_gather_rows: cols must be a positive multiple of 4");
+  if (cap == 0) return SPGNN_OK;
+  if (!src || !idx || !cnt_flag || !dst) return fail(SPGNN_ERR_NULLPTR, "spgnn_gather_rows: null pointer");
+  if (src_stride < cols || dst_stride < cols || (src_stride & 3) || (dst_stride & 3) || !aligned16(src) || !aligned16(dst))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_gather_rows: rows must be 16-byte aligned (stride % 4 == 0)");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(scalar_grid(cap * (cols / 4))), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, idx,
+                     cnt_flag, cap, cols / 4, dst, dst_stride);
+  return check_launch("spgnn_gather_rows");
+}
+
+int spgnn_expand_rows(const float* src, int64_t src_stride, const int32_t* inv, int64_t N, int32_t cols, float* dst, int64_t dst_stride,
+                      spgnn_stream_t stream) {
+  if (N < 0 || cols <= 0 || (cols & 3)) return fail(SPGNN_ERR_SHAPE, "spgnn_expand_rows: cols must be a positive multiple of 4");
+  if (N == 0) return SPGNN_OK;
+  if (!src || !inv || !dst) return fail(SPGNN_ERR_NULLPTR, "spgnn_expand_rows: null pointer");
+  if (src_stride < cols || dst_stride < cols || (src_stride & 3) || (dst_stride & 3) || !aligned16(src) || !aligned16(dst))
+    return fail(SPGNN_ERR_STRIDE, "spgnn_expand_rows: rows must be 16-byte aligned (stride % 4 == 0)");
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(scalar_grid(N * (cols / 4))), dim3(kBlock), 0, (hipStream_t)stream, src, src_stride, inv, N,
+                     cols / 4, dst, dst_stride);
+  return check_launch("spgnn_expand_rows");
 }
 
 int spgnn_sample_neighbors(const int32_t* indptr, const int32_t* indices, const int32_t* eid, int64_t num_nodes,

@@ -904,6 +904,7 @@ class _MaskedCE(torch.autograd.Function):
     def forward(ctx, logits, labels, draws, sampling_p, class_weight):
         opts, _MaskedCE._opts = (_MaskedCE._opts or {}), None
         out, seed, unit = opts.get("out"), opts.get("draw_seed", 0), bool(opts.get("unit_grad"))
+        rows = opts.get("rows")                 # LossRows: ``logits`` holds one row per LISTED node
         N, C = logits.shape
         if logits.stride(1) != 1:
             logits = logits.contiguous()
@@ -920,7 +921,14 @@ class _MaskedCE(torch.autograd.Function):
         colpart = torch.empty((max(nb, 1), 32), dtype=torch.float32, device=dev) if colsum is not None else None
         with torch.cuda.device(dev), _timed("masked_ce", (N, C)):
             # the last workgroup adds the per-block pairs (block order): no reduction launch
-            _capi.check(_capi.load().spgnn_masked_ce_step(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            if rows is not None:
+                assert N == rows.cap, "the logits of a loss-rows step have one row per listed node"
+                _capi.check(_capi.load().spgnn_masked_ce_rows(logits.data_ptr(), logits.stride(0), labels.data_ptr(), rows.idx.data_ptr(),
+                                                              rows.cnt.data_ptr(), class_weight.data_ptr(), part.data_ptr(), s.data_ptr(),
+                                                              ticket.data_ptr(), _ptr(g), C, _ptr(colpart), _ptr(colsum), N, C,
+                                                              _stream(logits)), "spgnn_masked_ce_rows")
+            else:
+              _capi.check(_capi.load().spgnn_masked_ce_step(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                           _seed_off_ptr(dev) if draws is None else 0, sampling_p.data_ptr(),
                                                           class_weight.data_ptr(), part.data_ptr(), s.data_ptr(), ticket.data_ptr(),
                                                           _ptr(g), C, _ptr(colpart), _ptr(colsum), N, C, _stream(logits)),
@@ -951,16 +959,78 @@ def column_sums(g: torch.Tensor) -> torch.Tensor:
     return cs if cs is not None and cs.shape[0] == g.shape[1] else g.sum(0)
 
 
+# --------------------------------------------------------------------------------------------
+# The rows of a step that reach the loss (reference job_runner.py:1896-1900: F.cross_entropy(pre[mask], y[mask], weight=w)).
+# A node outside the mask contributes neither to the loss nor to any gradient, and what follows the last aggregation - the
+# output layer's projection, the head mean, the classifier, their backward products - is row-wise: a training step may run
+# that part on the kept rows only (about 0.27 N at SAMPLING_RATE 0.15 with ~21 labelled nodes per tree) with the same loss
+# and gradients.  train.TrainStep(loss_rows_only=True) lists the rows before the forward pass and installs the list here; the
+# node that fuses output layer and classifier (_GATAggFirstFn) picks it up and hands back ONE ROW PER LISTED NODE.
+# --------------------------------------------------------------------------------------------
+LOSS_ROWS: Optional["LossRows"] = None
+
+
+class LossRows:
+    """``idx`` (cap,) int32: the kept nodes in ascending order (slots past the count name node 0); ``inv`` (N,) int32: a node's
+    slot or -1; ``cnt`` (2,) int32 on the device: [count, overflow flag].  ``cap`` is fixed on the host (a captured step's launch
+    grids are), the count is not: slots past it hold zero rows, and a draw that keeps more than ``cap`` nodes sets the flag
+    (never cleared by the kernels) and turns the loss into NaN."""
+
+    def __init__(self, N: int, cap: int, device, cnt: Optional[torch.Tensor] = None):
+        self.N, self.cap, self.used = int(N), int(cap), False
+        self.idx = torch.empty((self.cap,), dtype=torch.int32, device=device)
+        self.inv = torch.empty((max(self.N, 1),), dtype=torch.int32, device=device)
+        self.cnt = cnt if cnt is not None else torch.zeros((2,), dtype=torch.int32, device=device)
+        self._counts = torch.empty(((self.N + 255) // 256 or 1,), dtype=torch.int32, device=device)
+
+
+def loss_rows(sampling_p: torch.Tensor, draws: Optional[torch.Tensor], draw_seed: int, cap: int,
+              cnt: Optional[torch.Tensor] = None) -> LossRows:
+    """The nodes with ``rn < sampling_p`` - rn from ``draws`` or, None, from the counter hash of (``draw_seed``, the step counter
+    installed as DROPOUT_SEED_OFFSET, node): exactly the mask spgnn_masked_ce_step would draw from the same arguments."""
+    _require_cuda(sampling_p, draws)
+    N = sampling_p.shape[0]
+    r = LossRows(N, cap, sampling_p.device, cnt)
+    with torch.cuda.device(sampling_p.device), _timed("loss_rows", (N, cap)):
+        _capi.check(_capi.load().spgnn_loss_rows(_ptr(draws), int(draw_seed) & 0xFFFFFFFFFFFFFFFF,
+                                                 _seed_off_ptr(sampling_p.device) if draws is None else 0, sampling_p.data_ptr(), N,
+                                                 r._counts.data_ptr(), r.cap, r.idx.data_ptr(), r.inv.data_ptr(), r.cnt.data_ptr(),
+                                                 _stream(sampling_p)), "spgnn_loss_rows")
+    return r
+
+
+def gather_rows(x: torch.Tensor, rows: LossRows) -> torch.Tensor:
+    """x (N, C) -> (cap, C): the listed rows in list order, zero rows behind them."""
+    assert x.shape[0] == rows.N and x.shape[1] % 4 == 0 and x.stride(1) == 1 and _rows_aligned(x)
+    out = torch.empty((rows.cap, x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("gather_rows", (rows.cap, x.shape[1])):
+        _capi.check(_capi.load().spgnn_gather_rows(x.data_ptr(), x.stride(0), rows.idx.data_ptr(), rows.cnt.data_ptr(), rows.cap, x.shape[1],
+                                                   out.data_ptr(), out.stride(0), _stream(x)), "spgnn_gather_rows")
+    return out
+
+
+def expand_rows(xc: torch.Tensor, rows: LossRows) -> torch.Tensor:
+    """xc (cap, C) -> (N, C): the listed rows back at their nodes, zero rows everywhere else."""
+    assert xc.shape[0] == rows.cap and xc.shape[1] % 4 == 0 and xc.stride(1) == 1 and _rows_aligned(xc)
+    out = torch.empty((rows.N, xc.shape[1]), dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device), _timed("expand_rows", (rows.N, xc.shape[1])):
+        _capi.check(_capi.load().spgnn_expand_rows(xc.data_ptr(), xc.stride(0), rows.inv.data_ptr(), rows.N, xc.shape[1], out.data_ptr(),
+                                                   out.stride(0), _stream(xc)), "spgnn_expand_rows")
+    return out
+
+
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[torch.Tensor], sampling_p: torch.Tensor,
-                   class_weight: torch.Tensor, out: Optional[torch.Tensor] = None, draw_seed: int = 0, unit_grad: bool = False):
+                   class_weight: torch.Tensor, out: Optional[torch.Tensor] = None, draw_seed: int = 0, unit_grad: bool = False,
+                   rows: Optional["LossRows"] = None):
     """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900).
     ``out`` (2,) fp32, optional: where the two sums are to be written (train.FlatBucket's tail slots).  ``draws`` None: the
     kernel draws rn_i itself from its counter hash of (``draw_seed``, the step counter installed as DROPOUT_SEED_OFFSET, i).
     ``unit_grad``: the caller promises to back-propagate the numerator with gradient exactly 1 (``num.backward()``), so the
-    stored gradient is handed on without the multiplication."""
+    stored gradient is handed on without the multiplication.  ``rows`` (:class:`LossRows`, made from the same draws):
+    ``logits`` has one row per listed node instead of one per node - the same two sums up to summation order."""
     _require_cuda(logits, labels, draws, sampling_p, class_weight)
     assert labels.dtype == torch.int64 and logits.dtype == torch.float32
-    _MaskedCE._opts = {"out": out, "draw_seed": int(draw_seed), "unit_grad": unit_grad}
+    _MaskedCE._opts = {"out": out, "draw_seed": int(draw_seed), "unit_grad": unit_grad, "rows": rows}
     return _MaskedCE.apply(logits, labels.contiguous(), None if draws is None else draws.contiguous(), sampling_p.contiguous(),
                            class_weight.contiguous())
 
@@ -2312,6 +2382,15 @@ class _GATAggFirstFn(torch.autograd.Function):
         s = scores_fwd(x, w_lr)
         z, attn, sz = gat_agg_fwd_raw(csc, x, s[:, :H], s[:, H:], H, slope, p_drop, seed, has_res)
         zs = z.shape[1] // H
+        # a loss-rows step (LOSS_ROWS): everything behind the aggregation runs on the listed rows only - M rows from here on,
+        # outputs and saved tensors included; z's scale block stays the one of all rows (a maximum over a superset)
+        rows = LOSS_ROWS if (LOSS_ROWS is not None and w_cls is not None and mean and LOSS_ROWS.N == N and z.shape[1] % 4 == 0
+                             and _rows_aligned(z)) else None
+        ctx.rows = rows
+        if rows is not None:
+            rows.used = True
+            z = gather_rows(z, rows)
+            N = rows.cap
         hit = _PREP_ACTIVE.get((id(w_fc), id(w_res) if has_res else 0, "cols")) if PRESPLIT_B else None
         ctx.wt = None
         if hit is not None and hit[0][5][2] == zs and hit[0][5][3] == H * D and zs % 4 == 0 and D % 4 == 0:
@@ -2363,6 +2442,7 @@ class _GATAggFirstFn(torch.autograd.Function):
         N, F_ = x.shape
         E = csc.num_edges
         zs = z.shape[1] // H
+        rows = ctx.rows                        # a loss-rows step: z, out, rst, g_logits and g_pre have one row per listed node
         g_wcls = g_bcls = None
         # every split-K reduction of this node in one launch at the end - its own, not the step's: fc.weight receives a second
         # gradient through the folded score projection (fold_scores' backward), which autograd ADDS to this one on arrival
@@ -2422,6 +2502,8 @@ class _GATAggFirstFn(torch.autograd.Function):
                 tns[-1].launch().finish()
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
+        if rows is not None:
+            g_z = expand_rows(g_z, rows)       # back in node order (zero rows for the nodes outside the mask) for the traversals
         g_s = torch.empty_like(s)
         g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
         lib = _capi.load()

@@ -145,8 +145,14 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, class_weights: Sequence[float], sampling_rate: float, lr: float,
                  momentum: float = 0.9, weight_decay: float = 0.0, process_group=None, seed: int = 0,
-                 range_policy: str = "monitor"):
-        """``range_policy``: what :meth:`run_batch` does with the GEMM range monitor: "monitor" only
+                 range_policy: str = "monitor", loss_rows_only: bool = False):
+        """``loss_rows_only``: run what follows the last aggregation - output-layer projection, head mean, classifier and their
+        backward products - only on the rows the step's mask keeps (``F.cross_entropy(pre[mask], ...)``, reference
+        job_runner.py:1896-1900: no other row reaches the loss or a gradient).  Same loss and gradients up to fp32 summation
+        order; the model's forward then returns one row per kept node instead of one per node, so it is a switch of the training
+        step, not of the model.  Used by the heads that fuse output layer and classifier (ops._GATAggFirstFn: the SPGNN nets); the
+        others run as before.  See :meth:`_loss_rows`.
+        ``range_policy``: what :meth:`run_batch` does with the GEMM range monitor: "monitor" only
         counts (``range_violations()``); "auto" switches the split GEMMs to their wide-range form (``ops.GEMM_WIDE``) for all
         later batches once an operand left the narrow envelope, dropping the captures recorded in the narrow form."""
         if range_policy not in ("monitor", "auto"):
@@ -169,6 +175,37 @@ class TrainStep:
         self._one = self._loss_out = None
         # seed of the mask stream a captured step draws inside its loss kernel (spgnn_masked_ce_step); eager steps use self.gen
         self._mask_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & ((1 << 62) - 1)
+        self.loss_rows_only = bool(loss_rows_only)
+        self._rows_cnt = None                       # (2,) int32 on the device: [rows kept by the last step, capacity-overflow flag]
+
+    def _loss_rows_cap(self, g, p: torch.Tensor) -> int:
+        """Capacity of the step's row list on ``g``: the kept count is (labelled nodes) + Binomial(others, rate) - mean plus
+        eight standard deviations (about 1e-15 per step), 15 % on top when other batches will be loaded into the same buffers
+        (a batch arena), rounded up to 256-row tiles.  0: the list would not be shorter than 0.8 N - the step runs dense.
+        One host read per graph, cached on it.  A draw beyond the capacity cannot be repaired inside a captured step: the
+        list kernel raises a flag and the loss is NaN; :meth:`check_loss_rows` (called by run_batch / run_batches once per
+        loader batch) turns the flag into an error."""
+        store = g.__dict__.setdefault("_loss_rows_cap", {})
+        cap = store.get(self.sampling_rate)
+        if cap is None:
+            pc = p.clamp(min=0.0).double()
+            mu, var = float(pc.sum()), float((pc * (1.0 - pc)).sum())
+            if getattr(g, "_stable_storage", False):
+                mu *= 1.15
+            want = mu + 8.0 * var ** 0.5 + 32.0
+            cap = int(-(-want // 256) * 256)
+            n = p.shape[0]
+            cap = 0 if cap > 0.8 * n else cap
+            store[self.sampling_rate] = cap
+        return cap
+
+    def check_loss_rows(self) -> None:
+        """Raise if a step's mask kept more rows than its list could hold (one host read)."""
+        if self._rows_cnt is not None and int(self._rows_cnt[1].item()) != 0:
+            self._rows_cnt[1].zero_()
+            raise RuntimeError("loss_rows_only: a step's mask kept more rows than the row list's capacity (the loss of that step is "
+                               "NaN and its update is lost); the labelled share of this batch is far above the one the capacity was "
+                               "sized on - run this loader batch with loss_rows_only=False")
 
     def _sampling(self, g):
         """Per-node sampling probabilities of ``g``'s labels, kept ON THE GRAPH (a captured step addresses the tensor; one
@@ -244,11 +281,23 @@ class TrainStep:
             ops.ATTN_GRAD_QUEUE = queue
             ops.STEP_SUMS = sums
             ops.TN_SIDE = side
+            rows = None
+            if self.loss_rows_only and on_gpu and not getattr(self, "_rows_not_taken", False):
+                cap = self._loss_rows_cap(g, p)
+                if cap:
+                    if self._rows_cnt is None:
+                        self._rows_cnt = torch.zeros((2,), dtype=torch.int32, device=p.device)
+                    rows = ops.loss_rows(p, draws, draw_seed, cap, cnt=self._rows_cnt)     # the same draw the loss kernel would make
+            ops.LOSS_ROWS = rows
             logits = self.model(g)[0]
+            ops.LOSS_ROWS = None
+            if rows is not None and not rows.used:
+                rows = None                  # this model's head does not take the list: its logits have one row per node
+                self._rows_not_taken = True  # (a property of the model: later steps do not make the list)
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
                 nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot, draw_seed=draw_seed,
-                                        unit_grad=True)                               # land in the bucket's tail
+                                        unit_grad=True, rows=rows)                    # land in the bucket's tail
                 num, den = nd[0], nd[1]
                 if self._one is None or self._one.device != num.device:
                     self._one = torch.ones((), dtype=torch.float32, device=num.device)
@@ -268,6 +317,7 @@ class TrainStep:
             ops.ATTN_GRAD_QUEUE = None
             ops.STEP_SUMS = None
             ops.TN_SIDE = None
+            ops.LOSS_ROWS = None
             if side is not None:
                 side.join()                  # (also on the error path: never leave the side stream dangling in a capture)
             ops.DEBUG_POISON_DEFERRED = prev_poison
@@ -518,6 +568,8 @@ class TrainStep:
         return losses
 
     def _range_policy_check(self) -> None:
+        if self.loss_rows_only:
+            self.check_loss_rows()                   # (one 4-byte read per loader batch: the flag of the previous batch's steps)
         if self.range_policy == "auto" and not ops.GEMM_WIDE and self.bucket.flat_param.is_cuda:
             v = self.range_violations()              # one 4-byte read per loader batch (the flags of the previous batch's steps)
             if self._violations_seen is not None and v > self._violations_seen:

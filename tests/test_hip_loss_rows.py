@@ -1,0 +1,146 @@
+"""train.TrainStep(loss_rows_only=True): the part of a training step behind the last aggregation - output-layer projection, head
+mean, classifier, their backward products - on the rows the mask keeps only (reference job_runner.py:1896-1900:
+``F.cross_entropy(pre[mask], y[mask], weight=w)``; no other row reaches the loss or a gradient).  The list kernels against torch,
+the step against the dense step (same draws: same loss and parameters up to fp32 summation order) and against the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from spgnn_amd import _capi, models, ops, synthetic
+from spgnn_amd.configs import class_weight_list, get_config
+from spgnn_amd.train import TrainStep
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,rate,cap", [(1, 1.0, 256), (255, 0.3, 256), (256, 0.0, 256), (5000, 0.15, 1024), (76410, 0.27, 22016),
+                                        (3000, 0.9, 512)])
+def test_row_list_is_the_mask_in_node_order(N, rate, cap):
+    g = torch.Generator(device="cuda").manual_seed(N)
+    p = torch.full((N,), rate, device="cuda")
+    p[::7] = 1.0                                                   # "labelled" nodes: always kept
+    p[3::11] = -1.0                                                # pad nodes of an arena: never
+    draws = torch.rand(N, device="cuda", generator=g)
+    want = torch.nonzero(draws < p).flatten().to(torch.int32)
+    r = ops.loss_rows(p, draws, 0, cap)
+    cnt, over = (int(v) for v in r.cnt.tolist())
+    assert over == (1 if want.numel() > cap else 0)
+    k = min(want.numel(), cap)
+    assert cnt == k and torch.equal(r.idx[:k], want[:k]) and bool((r.idx[k:] == 0).all())
+    inv = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    inv[want[:k].long()] = torch.arange(k, dtype=torch.int32, device="cuda")
+    assert torch.equal(r.inv[:N], inv)
+    x = torch.randn(N, 8, device="cuda")
+    xc = ops.gather_rows(x, r)
+    assert xc.shape == (cap, 8) and torch.equal(xc[:k], x[want[:k].long()]) and bool((xc[k:] == 0).all())
+    back = ops.expand_rows(xc, r)
+    ref = torch.zeros_like(x)
+    ref[want[:k].long()] = x[want[:k].long()]
+    assert torch.equal(back, ref)
+
+
+def test_row_list_from_the_counter_hash_is_the_loss_kernels_mask():
+    """``draws`` None: the list kernel and spgnn_masked_ce_step draw from the same hash - the loss over the listed rows equals the
+    dense loss with the kernel's own mask, and so do the logit gradients."""
+    N, C = 4000, 22
+    torch.manual_seed(3)
+    logits = torch.randn(N, C, device="cuda")
+    y = torch.randint(0, C, (N,), device="cuda")
+    y[torch.rand(N, device="cuda") < 0.85] = 0                    # most nodes unlabelled, as in the airway trees
+    p = torch.full((N,), 0.15, device="cuda")
+    p[y > 0] = 1.0
+    w = torch.rand(C, device="cuda") + 0.5
+    dense_in = logits.clone().requires_grad_(True)
+    num, den = ops.masked_ce_sums(dense_in, y, None, p, w, draw_seed=12345)
+    num.backward()
+    r = ops.loss_rows(p, None, 12345, 2048)
+    k = int(r.cnt[0])
+    assert 0 < k < 2048 and int(r.cnt[1]) == 0
+    lc = ops.gather_rows(torch.cat([logits, logits.new_zeros(N, 2)], 1), r)[:, :C].contiguous().requires_grad_(True)
+    num_r, den_r = ops.masked_ce_sums(lc, y, None, p, w, draw_seed=12345, rows=r)
+    num_r.backward()
+    assert rel_err(num_r, num) < 1e-6 and rel_err(den_r, den) < 1e-6
+    kept = r.idx[:k].long()
+    assert torch.equal(lc.grad[:k], dense_in.grad[kept]) and bool((lc.grad[k:] == 0).all())
+    others = torch.ones(N, dtype=torch.bool, device="cuda")
+    others[kept] = False
+    assert bool((dense_in.grad[others] == 0).all())               # the rows outside the list carry no gradient at all
+
+
+def test_overflow_raises_the_flag_and_poisons_the_loss():
+    N, C = 1000, 22
+    p = torch.ones(N, device="cuda")
+    r = ops.loss_rows(p, torch.zeros(N, device="cuda"), 0, 256)
+    assert r.cnt.tolist() == [256, 1]
+    logits = torch.randn(256, C, device="cuda")
+    num, den = ops.masked_ce_sums(logits, torch.zeros(N, dtype=torch.int64, device="cuda"), None, p, torch.ones(C, device="cuda"), rows=r)
+    assert bool(torch.isnan(num)) and bool(torch.isnan(den))
+
+
+def _model(name, seed):
+    cfg = get_config(name)
+    torch.manual_seed(seed)
+    m = models.build_model(cfg.MODEL).cuda()
+    m.init(None)
+    m.set_gcn_only()
+    return cfg, m
+
+
+@pytest.mark.parametrize("name,trees,train_mode", [("st_pgat_spgnn_3", 6, False), ("st_pgat_spgnn_3", 64, True), ("st_pgat_spgnnnl_3", 6, False),
+                                                   ("st_gat_3", 6, False)])
+def test_loss_rows_step_equals_the_dense_step(name, trees, train_mode):
+    """Four optimizer steps with and without the switch from the same parameters, the same mask stream and (train mode) the same
+    hash dropout masks: losses and parameters agree to fp32 summation order.  st_gat_3's head (no activation on the output layer:
+    the linear-mean form) does not take the list and must run unchanged."""
+    cfg, model = _model(name, 21)
+    model.train(train_mode)
+    dense = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(trees, rank=2, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=True)
+    ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5)
+    if train_mode:                                 # the counter-hash streams (mask and dropout): what a captured step uses
+        for ts in (ts_r, ts_d):
+            ts._seed_ctr = torch.zeros((1,), dtype=torch.int64, device="cuda")
+            ts._use_default_rng = True
+    for i in range(4):
+        torch.manual_seed(100 + i)                 # the layers draw their dropout seeds from torch's CPU generator: same for both
+        lr_ = ts_r.step(g)
+        torch.manual_seed(100 + i)
+        ld_ = ts_d.step(g)
+        assert rel_err(lr_, ld_) < 2e-6, (float(lr_), float(ld_))
+    takes = name != "st_gat_3"
+    assert (ts_r._rows_cnt is not None and int(ts_r._rows_cnt[0]) > 0) if takes else True
+    n = ts_r.bucket.numel
+    assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 2e-6
+    ts_r.check_loss_rows()
+    if takes:
+        N = g.number_of_nodes()
+        assert int(ts_r._rows_cnt[0]) < 0.5 * N                   # the list is what makes the step cheaper: well under half the nodes
+
+
+def test_captured_loss_rows_step_replays_with_fresh_masks():
+    """run_batch (arena + HIP-graph replays) with the switch: the replays draw a new mask each (the list kernel reads the step
+    counter from device memory like the loss kernel), the losses follow the dense captured step's."""
+    cfg, model = _model("st_pgat_spgnn_3", 4)
+    model.train(True)
+    dense = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(8, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=True)
+    ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9)
+    counts = []
+    for i, k in enumerate((4, 1, 1, 1)):
+        torch.manual_seed(200 + i)                 # (the dropout seeds a capture freezes come from torch's CPU generator)
+        lr_ = ts_r.run_batch(g, k, granule=512)
+        torch.manual_seed(200 + i)
+        ld_ = ts_d.run_batch(g, k, granule=512)
+        assert rel_err(lr_, ld_) < 1e-5, (float(lr_), float(ld_))
+        counts.append(int(ts_r._rows_cnt[0]))
+    assert len(set(counts)) > 1                                    # a fresh mask per replay
+    n = ts_r.bucket.numel
+    assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 1e-5
+    ts_r.check_loss_rows()
