@@ -144,3 +144,33 @@ def test_captured_loss_rows_step_replays_with_fresh_masks():
     n = ts_r.bucket.numel
     assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 1e-5
     ts_r.check_loss_rows()
+
+
+def test_loss_rows_step_matches_the_oracle_at_64_trees():
+    """Not only the dense HIP step: the loss and every parameter gradient of a loss-rows step at TRAIN_BATCH_SIZE against the
+    CPU oracle's ``F.cross_entropy(pre[mask], y[mask], weight=w)`` over the full forward (reference job_runner.py:1896-1900),
+    fp32 and fp64, with the gradient rule of tests/test_hip_parity_at_size.py."""
+    from oracle import dgl_cpu as O
+    from tests.test_hip_parity_at_size import _assert_gradients, _build, _oracle
+    cfg, model = _build("st_pgat_spgnn_3", seed=11)
+    g = synthetic.make_batch(64, rank=0, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    N = g.number_of_nodes()
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    draws = torch.rand(N, generator=torch.Generator().manual_seed(5))
+    mask = draws < torch.where(y.cpu() != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
+    ts = TrainStep(model, w.tolist(), cfg.SAMPLING_RATE, 1e-3, 0.9, loss_rows_only=True)
+    num = ts._front(g, draws.cuda()).clone()              # gradient SUMS of the numerator in p.grad, the weight sum in the bucket
+    den = ts.bucket.wsum_slot.clone()
+    assert int(ts._rows_cnt[0]) == int(mask.sum()) and int(ts._rows_cnt[1]) == 0
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad = p.grad / den
+    refs, sd = _oracle(cfg, model, g, grad=True)
+    ref_loss = O.masked_weighted_ce(refs[0], y.cpu(), mask, w)
+    ref_loss.backward()
+    refs64, sd64 = _oracle(cfg, model, g, dtype=torch.float64, grad=True)
+    O.masked_weighted_ce(refs64[0], y.cpu(), mask, w.double()).backward()
+    assert rel_err(num / den, ref_loss) < 1e-5
+    worst = _assert_gradients(model, sd, sd64, 1e-4)
+    print(f"loss-rows step, 64 trees: loss {rel_err(num / den, ref_loss):.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
