@@ -430,7 +430,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{config}{f' with {heads} heads' if heads else ''} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
                                    f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
-                                   f"dropout {'off' if no_dropout else 'on'}" + (", loss rows only behind the last aggregation" if loss_rows else ""),
+                                   f"dropout {'off' if no_dropout else 'on'}" + (", loss rows only behind the last aggregation" + (" (backward pass only)" if loss_rows == "backward" else "") if loss_rows else ""),
                        "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
                        "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc,
@@ -945,6 +945,9 @@ def main():
     ap.add_argument("--loss-rows-only", action="store_true",
                     help="TrainStep(loss_rows_only=True): output-layer projection, classifier and their backward products on the rows the "
                          "step's mask keeps only (same loss and gradients; NOT the headline: the headline runs every row)")
+    ap.add_argument("--loss-rows-backward", action="store_true",
+                    help='TrainStep(loss_rows_only="backward"): dense forward, only the BACKWARD products of that part on the kept rows '
+                         "(the rows skipped are exactly zero in the dense step)")
     ap.add_argument("--heads", type=int, default=0, help="override the hidden GAT layers' head count (0: the config's own)")
     ap.add_argument("--eager", action="store_true",
                     help="time eagerly issued steps instead of HIP-graph replays of the step (TrainStep.capture)")
@@ -994,7 +997,7 @@ def main():
         return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
-                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads, loss_rows=args.loss_rows_only)
+                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads, loss_rows=("backward" if args.loss_rows_backward else args.loss_rows_only))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees) if args.cpu_trees else args.trees)
@@ -1013,22 +1016,26 @@ def main():
                 except Exception as e:                  # never lose the headline to a secondary leg
                     sec[name] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
-            # the headline workload with TrainStep(loss_rows_only=True) - NOT the headline number: the headline runs every row of
-            # every layer, as the reference's forward does; this leg runs what follows the last aggregation on the rows the
-            # step's mask keeps (no other row reaches the loss or a gradient: same loss, same gradients)
-            try:
-                o2, _ctx = run_leg("st_pgat_spgnn_3", "f32", 512, min(args.steps, 20), min(args.warmup, 5), rank=0, world=1, dev=dev,
-                                   no_dropout=args.no_dropout, no_kernel_timers=args.no_kernel_timers,
-                                   copy_bw=out.get("copy_bandwidth"), loss_rows=True)
-                s2 = secondary_summary(o2)
-                s2["what"] = ("the headline workload with TrainStep(loss_rows_only=True): output-layer projection, head mean, classifier and "
-                              "their backward products only on the rows the step's mask keeps (reference job_runner.py:1896-1900 takes the "
-                              "loss over pre[mask]); identical loss and gradients up to fp32 summation order "
-                              "(tests/test_hip_loss_rows.py); every traversal still visits every edge")
-                sec["st_pgat_spgnn_3_f32_512_loss_rows_only"] = s2
-                del o2, _ctx
-            except Exception as e:
-                sec["st_pgat_spgnn_3_f32_512_loss_rows_only"] = {"error": repr(e)[:300]}
+            # the headline workload with TrainStep(loss_rows_only=...) - NOT the headline number: the headline runs every row of
+            # every layer, forward and backward.  "backward": dense forward, the output layer's backward products on the rows the
+            # step's mask keeps (the rows skipped are exactly zero in the dense step); True: the forward behind the last
+            # aggregation on those rows too (no other row reaches the loss or a gradient).  Same loss, same gradients.
+            for leg_name, mode in (("st_pgat_spgnn_3_f32_512_loss_rows_backward", "backward"), ("st_pgat_spgnn_3_f32_512_loss_rows_only", True)):
+                try:
+                    o2, _ctx = run_leg("st_pgat_spgnn_3", "f32", 512, min(args.steps, 20), min(args.warmup, 5), rank=0, world=1, dev=dev,
+                                       no_dropout=args.no_dropout, no_kernel_timers=args.no_kernel_timers,
+                                       copy_bw=out.get("copy_bandwidth"), loss_rows=mode)
+                    s2 = secondary_summary(o2)
+                    s2["what"] = ("the headline workload with TrainStep(loss_rows_only=%r): %s only on the rows the step's mask keeps "
+                                  "(reference job_runner.py:1896-1900 takes the loss over pre[mask]); identical loss and gradients up to fp32 "
+                                  "summation order (tests/test_hip_loss_rows.py); every traversal still visits every edge"
+                                  % (mode, "the output layer's BACKWARD products (dense forward)" if mode == "backward" else
+                                     "output-layer projection, head mean, classifier and their backward products"))
+                    sec[leg_name] = s2
+                    del o2, _ctx
+                except Exception as e:
+                    sec[leg_name] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
             torch.cuda.empty_cache()
             try:
                 sec["batch_cycle_64"] = batch_cycle(dev)

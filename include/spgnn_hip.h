@@ -792,6 +792,14 @@ int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64
 int spgnn_loss_rows(const float* draws /* nullable */, uint64_t draw_seed, const int64_t* seed_offset /* nullable */,
                     const float* sampling_p, int64_t N, int32_t* block_counts, int32_t cap, int32_t* idx, int32_t* inv,
                     int32_t* cnt_flag, spgnn_stream_t stream);
+/*
+ * spgnn_act_bwd_proj for a row list: g_pre (cap rows) row q = the pass's result for node rows[q] (rows of g_s and out are
+ * addressed through the list) when q < rows_cnt[0], zero otherwise.  In a dense step the rows of g_pre outside the mask are
+ * exactly zero (their g_s rows are): the layer's two backward products may run on the listed rows alone.
+ */
+int spgnn_act_bwd_proj_rows(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                            int64_t out_stride, const int32_t* rows, const int32_t* rows_cnt, float* g_pre, int64_t g_pre_stride,
+                            float* absmax_partials, int64_t cap, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
 /* dst[c, :] = c < cnt_flag[0] ? src[idx[c], :] : 0 for c in [0, cap); cols % 4 == 0, 16-byte aligned rows. */
 int spgnn_gather_rows(const float* src, int64_t src_stride, const int32_t* idx, const int32_t* cnt_flag, int64_t cap, int32_t cols,
                       float* dst, int64_t dst_stride, spgnn_stream_t stream);

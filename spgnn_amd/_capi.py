@@ -169,6 +169,7 @@ SIGNATURES = {
     "spgnn_block_relabel": [_i32p, _i32p, _i32p, _i64, _i64, _i32p, _i64, _vp, _i32p, _vp],
     "spgnn_head_mean": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _vp],
     "spgnn_act_bwd_proj": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
+    "spgnn_act_bwd_proj_rows": [_f32p, _i64, _i32, _f32p, _i64, _f32p, _i64, _vp, _vp, _f32p, _i64, _f32p, _i64, _i32, _i32, _i32, _vp],
     "spgnn_act_bwd_proj_blocks": [_i64],
     "spgnn_act_bwd_dropout": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_act_bwd_dropped": [_f32p, _i64, _f32p, _i64, _f32p, _i64, _f32p, _i64, _i32, _i32, _f32, _u64, _vp, _vp],

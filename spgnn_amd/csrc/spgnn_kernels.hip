@@ -1456,7 +1456,10 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
                                                            const float* __restrict__ out, int64_t out_ld,
                                                            float* __restrict__ g_pre, int64_t gp_ld, float* __restrict__ absmax,
                                                            int64_t N, int64_t rows_per_block, int Hrt, int D, int act,
-                                                           float* __restrict__ wgrad) {
+                                                           float* __restrict__ wgrad, const int32_t* __restrict__ row_list,
+                                                           const int32_t* __restrict__ rows_cnt) {
+  // `row_list` (spgnn_act_bwd_proj_rows): g_pre has one row per LISTED node (N = the list's capacity) - row q is formed from
+  // rows row_list[q] of gS and out when q < rows_cnt[0], and is zero otherwise
   __shared__ float red[4];
   constexpr int HMAX = HT ? HT : 4;
   const int H = HT ? HT : Hrt;
@@ -1498,19 +1501,28 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
     }                                                                                                        \
     if (cv) { st4(g_pre + (ROW) * gp_ld + (int64_t)(HH) * D + c, q); mx = absmax4(mx, q); }                  \
   }
+  const int64_t listed = row_list ? (int64_t)rows_cnt[0] : 0;
+  const bool overflowed = row_list && rows_cnt[1] != 0;      // the list lost rows: poison the gradient instead of dropping them
   int64_t n = n0;
   for (; n + RB <= n1; n += RB) {      // RB rows per trip, every load of the trip issued before the first use
     float4 o[RB][HMAX];
     float gv[RB];
+    int64_t sr[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) sr[r] = row_list ? (n + r < listed ? (int64_t)row_list[n + r] : 0) : n + r;
     if (act != SPGNN_ACT_NONE) {
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int h = 0; h < HMAX; ++h)
-          if (HT || h < H) o[r][h] = ld4(out + (n + r) * out_ld + (int64_t)h * D + cc);
+          if (HT || h < H) o[r][h] = ld4(out + sr[r] * out_ld + (int64_t)h * D + cc);
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) gv[r] = gS[(n + r) * ldg + jl];
+    for (int r = 0; r < RB; ++r) {
+      gv[r] = gS[sr[r] * ldg + jl];
+      if (row_list && n + r >= listed) gv[r] = 0.f;
+      if (overflowed) gv[r] = NAN;
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       float4 gm, em = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1527,13 +1539,16 @@ __global__ __launch_bounds__(256) void act_bwd_proj_kernel(const float* __restri
     }
   }
   for (; n < n1; ++n) {
-    const float gv = gS[n * ldg + jl];
+    const int64_t sr = row_list ? (n < listed ? (int64_t)row_list[n] : 0) : n;
+    float gv = gS[sr * ldg + jl];
+    if (row_list && n >= listed) gv = 0.f;
+    if (overflowed) gv = NAN;
     float4 ot[HMAX];
     float4 em = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
       ot[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((HT || h < H) && act != SPGNN_ACT_NONE) ot[h] = ld4(out + n * out_ld + (int64_t)h * D + cc);
+      if ((HT || h < H) && act != SPGNN_ACT_NONE) ot[h] = ld4(out + sr * out_ld + (int64_t)h * D + cc);
       if (WG && (HT || h < H)) { em.x += ot[h].x; em.y += ot[h].y; em.z += ot[h].z; em.w += ot[h].w; }
     }
     em.x *= inv_h; em.y *= inv_h; em.z *= inv_h; em.w *= inv_h;
@@ -3605,9 +3620,9 @@ int32_t spgnn_act_bwd_proj_blocks(int64_t N) {
   return (int32_t)(b < 1 ? 1 : b);
 }
 
-int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
-                       int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
-                       int32_t D, int32_t activation, spgnn_stream_t stream) {
+static int act_bwd_proj_launch(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                               int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
+                               int32_t D, int32_t activation, const int32_t* row_list, const int32_t* rows_cnt, spgnn_stream_t stream) {
   if (N < 0 || H <= 0 || H > 4 || D <= 0 || D % 4 || D > 1024 || J <= 0 || J > 32)
     return fail(SPGNN_ERR_SHAPE, "spgnn_act_bwd_proj: bad N/H/D/J (H <= 4, D % 4 == 0, D <= 1024, J <= 32)");
   if (activation < SPGNN_ACT_NONE || activation > SPGNN_ACT_LRELU) return fail(SPGNN_ERR_ENUM, "spgnn_act_bwd_proj: activation");
@@ -3624,12 +3639,27 @@ int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const fl
   hipStream_t st = (hipStream_t)stream;
 #define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows, false>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
                                       (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation, \
-                                      (float*)nullptr)
+                                      (float*)nullptr, row_list, rows_cnt)
 #define X(JP) { if (H == 2) XH(JP, 2); else if (H == 1) XH(JP, 1); else XH(JP, 0); }
   if (J <= 8) X(8) else if (J <= 16) X(16) else if (J <= 24) X(24) else X(32)
 #undef X
 #undef XH
   return check_launch("spgnn_act_bwd_proj");
+}
+
+int spgnn_act_bwd_proj(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                       int64_t out_stride, float* g_pre, int64_t g_pre_stride, float* absmax_partials, int64_t N, int32_t H,
+                       int32_t D, int32_t activation, spgnn_stream_t stream) {
+  return act_bwd_proj_launch(g_s, g_s_stride, J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, H, D, activation,
+                             nullptr, nullptr, stream);
+}
+
+int spgnn_act_bwd_proj_rows(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
+                            int64_t out_stride, const int32_t* rows, const int32_t* rows_cnt, float* g_pre, int64_t g_pre_stride,
+                            float* absmax_partials, int64_t cap, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream) {
+  if (!rows || !rows_cnt) return fail(SPGNN_ERR_NULLPTR, "spgnn_act_bwd_proj_rows: null pointer");
+  return act_bwd_proj_launch(g_s, g_s_stride, J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, cap, H, D, activation,
+                             rows, rows_cnt, stream);
 }
 
 int spgnn_gemm_nt_skinny(const float* a, int64_t a_stride, const float* b, int64_t b_stride, float* c, int64_t c_stride, int64_t M,
@@ -3679,7 +3709,7 @@ int spgnn_act_bwd_proj_wgrad(const float* g_s, int64_t g_s_stride, int32_t J, co
   hipStream_t st = (hipStream_t)stream;
 #define XH(JP, HT) hipLaunchKernelGGL((act_bwd_proj_kernel<JP, HT, kAbpRows, true>), dim3((unsigned)blocks), dim3(256), 0, st, g_s, g_s_stride, \
                                       (int)J, w, w_stride, out, out_stride, g_pre, g_pre_stride, absmax_partials, N, rpb, (int)H, (int)D, (int)activation, \
-                                      w_grad_partials)
+                                      w_grad_partials, (const int32_t*)nullptr, (const int32_t*)nullptr)
 #define X(JP) { if (H == 2) XH(JP, 2); else XH(JP, 1); }
   if (J <= 8) X(8) else if (J <= 16) X(16) else X(24)
 #undef X

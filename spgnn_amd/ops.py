@@ -976,8 +976,10 @@ class LossRows:
     grids are), the count is not: slots past it hold zero rows, and a draw that keeps more than ``cap`` nodes sets the flag
     (never cleared by the kernels) and turns the loss into NaN."""
 
-    def __init__(self, N: int, cap: int, device, cnt: Optional[torch.Tensor] = None):
-        self.N, self.cap, self.used = int(N), int(cap), False
+    def __init__(self, N: int, cap: int, device, cnt: Optional[torch.Tensor] = None, forward: bool = True):
+        # ``forward`` False: the forward pass runs every row (the model's outputs are the reference's, row for row) and only the
+        # BACKWARD products use the list - the rows they skip are exactly zero in the dense step
+        self.N, self.cap, self.used, self.forward = int(N), int(cap), False, bool(forward)
         self.idx = torch.empty((self.cap,), dtype=torch.int32, device=device)
         self.inv = torch.empty((max(self.N, 1),), dtype=torch.int32, device=device)
         self.cnt = cnt if cnt is not None else torch.zeros((2,), dtype=torch.int32, device=device)
@@ -985,12 +987,12 @@ class LossRows:
 
 
 def loss_rows(sampling_p: torch.Tensor, draws: Optional[torch.Tensor], draw_seed: int, cap: int,
-              cnt: Optional[torch.Tensor] = None) -> LossRows:
+              cnt: Optional[torch.Tensor] = None, forward: bool = True) -> LossRows:
     """The nodes with ``rn < sampling_p`` - rn from ``draws`` or, None, from the counter hash of (``draw_seed``, the step counter
     installed as DROPOUT_SEED_OFFSET, node): exactly the mask spgnn_masked_ce_step would draw from the same arguments."""
     _require_cuda(sampling_p, draws)
     N = sampling_p.shape[0]
-    r = LossRows(N, cap, sampling_p.device, cnt)
+    r = LossRows(N, cap, sampling_p.device, cnt, forward)
     with torch.cuda.device(sampling_p.device), _timed("loss_rows", (N, cap)):
         _capi.check(_capi.load().spgnn_loss_rows(_ptr(draws), int(draw_seed) & 0xFFFFFFFFFFFFFFFF,
                                                  _seed_off_ptr(sampling_p.device) if draws is None else 0, sampling_p.data_ptr(), N,
@@ -2329,13 +2331,24 @@ ACT_BWD_PROJ_WGRAD = False
 
 
 def act_bwd_proj(g_s: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], H: int, D: int, act: int,
-                 wgrad_jobs: Optional["SumJobs"] = None):
+                 wgrad_jobs: Optional["SumJobs"] = None, rows: Optional["LossRows"] = None):
     """act_bwd of a mean-over-heads layer whose mean feeds a skinny Linear (weight ``w`` (J, D)), with that Linear's
     input gradient g_s @ w formed on the fly -> (g_pre (N, H*D), its scale block).  With ``wgrad_jobs`` (a SumJobs queue) and
     a supported shape the pass also forms that Linear's WEIGHT gradient g_s^T @ mean_h(out) from the rows it reads anyway
     (spgnn_act_bwd_proj_wgrad; the per-block partials are summed by the queue): -> (g_pre, block, g_w (J, D))."""
     N, J = g_s.shape
     lib = _capi.load()
+    if rows is not None:
+        # ``g_s`` / ``out`` in node order, the result one row per LISTED node (zero rows behind the count)
+        assert wgrad_jobs is None and N == rows.N
+        g_pre = torch.empty((rows.cap, H * D), dtype=torch.float32, device=g_s.device)
+        part = new_scale_block(g_s.device)
+        with torch.cuda.device(g_s.device), _timed("act_bwd_proj", (rows.cap, H, D, act, J)):
+            _capi.check(lib.spgnn_act_bwd_proj_rows(g_s.data_ptr(), g_s.stride(0), J, w.data_ptr(), w.stride(0), _ptr(out),
+                                                    out.stride(0) if out is not None else 0, rows.idx.data_ptr(), rows.cnt.data_ptr(),
+                                                    g_pre.data_ptr(), g_pre.stride(0), part.data_ptr(), rows.cap, H, D, act,
+                                                    _stream(g_s)), "spgnn_act_bwd_proj_rows")
+        return g_pre, part
     g_pre = torch.empty((N, H * D), dtype=torch.float32, device=g_s.device)
     part = new_scale_block(g_s.device)
     if wgrad_jobs is not None:
@@ -2389,8 +2402,9 @@ class _GATAggFirstFn(torch.autograd.Function):
         ctx.rows = rows
         if rows is not None:
             rows.used = True
-            z = gather_rows(z, rows)
-            N = rows.cap
+            if rows.forward:
+                z = gather_rows(z, rows)
+                N = rows.cap
         hit = _PREP_ACTIVE.get((id(w_fc), id(w_res) if has_res else 0, "cols")) if PRESPLIT_B else None
         ctx.wt = None
         if hit is not None and hit[0][5][2] == zs and hit[0][5][3] == H * D and zs % 4 == 0 and D % 4 == 0:
@@ -2443,6 +2457,7 @@ class _GATAggFirstFn(torch.autograd.Function):
         E = csc.num_edges
         zs = z.shape[1] // H
         rows = ctx.rows                        # a loss-rows step: z, out, rst, g_logits and g_pre have one row per listed node
+        compact = rows is not None and rows.forward        # (or, list used by the backward pass only: g_pre and z from here on)
         g_wcls = g_bcls = None
         # every split-K reduction of this node in one launch at the end - its own, not the step's: fc.weight receives a second
         # gradient through the folded score projection (fold_scores' backward), which autograd ADDS to this one on arrival
@@ -2459,6 +2474,12 @@ class _GATAggFirstFn(torch.autograd.Function):
             if ride:
                 # ... and the classifier's weight gradient g_logits^T mean_h(out) from the same rows: no second pass over the head mean
                 g_pre, amax, g_wcls = act_bwd_proj(g_logits, w_cls, out, H, D, act, wgrad_jobs=jobs)
+            elif fused and rows is not None and not rows.forward:
+                # dense forward, list in the backward pass: the rows of g_pre outside the mask are exactly zero (their g_logits
+                # rows are) - form the listed ones only, and run the layer's two products on them
+                g_pre, amax = act_bwd_proj(g_logits, w_cls, out, H, D, act, rows=rows)
+                z = gather_rows(z, rows)
+                compact = True
             elif fused:
                 # the usual training case (only the logits reach the loss): g_mean = g_logits W is formed inside act_bwd
                 g_pre, amax = act_bwd_proj(g_logits, w_cls, out, H, D, act)
@@ -2502,7 +2523,7 @@ class _GATAggFirstFn(torch.autograd.Function):
                 tns[-1].launch().finish()
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
-        if rows is not None:
+        if compact:
             g_z = expand_rows(g_z, rows)       # back in node order (zero rows for the nodes outside the mask) for the traversals
         g_s = torch.empty_like(s)
         g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)

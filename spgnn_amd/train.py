@@ -151,7 +151,9 @@ class TrainStep:
         job_runner.py:1896-1900: no other row reaches the loss or a gradient).  Same loss and gradients up to fp32 summation
         order; the model's forward then returns one row per kept node instead of one per node, so it is a switch of the training
         step, not of the model.  Used by the heads that fuse output layer and classifier (ops._GATAggFirstFn: the SPGNN nets); the
-        others run as before.  See :meth:`_loss_rows`.
+        others run as before.  ``"backward"``: the forward pass stays dense (``model(g)`` inside the step returns every row, as
+        the reference's does) and only the BACKWARD products of that part run on the kept rows - the rows they skip are exactly
+        zero in the dense step (their logit gradients are).  See :meth:`_loss_rows_cap`.
         ``range_policy``: what :meth:`run_batch` does with the GEMM range monitor: "monitor" only
         counts (``range_violations()``); "auto" switches the split GEMMs to their wide-range form (``ops.GEMM_WIDE``) for all
         later batches once an operand left the narrow envelope, dropping the captures recorded in the narrow form."""
@@ -175,7 +177,9 @@ class TrainStep:
         self._one = self._loss_out = None
         # seed of the mask stream a captured step draws inside its loss kernel (spgnn_masked_ce_step); eager steps use self.gen
         self._mask_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & ((1 << 62) - 1)
-        self.loss_rows_only = bool(loss_rows_only)
+        if loss_rows_only not in (False, True, "backward"):
+            raise ValueError('loss_rows_only must be False, True or "backward"')
+        self.loss_rows_only = loss_rows_only
         self._rows_cnt = None                       # (2,) int32 on the device: [rows kept by the last step, capacity-overflow flag]
 
     def _loss_rows_cap(self, g, p: torch.Tensor) -> int:
@@ -287,7 +291,8 @@ class TrainStep:
                 if cap:
                     if self._rows_cnt is None:
                         self._rows_cnt = torch.zeros((2,), dtype=torch.int32, device=p.device)
-                    rows = ops.loss_rows(p, draws, draw_seed, cap, cnt=self._rows_cnt)     # the same draw the loss kernel would make
+                    rows = ops.loss_rows(p, draws, draw_seed, cap, cnt=self._rows_cnt,      # the same draw the loss kernel makes
+                                         forward=self.loss_rows_only is True)
             ops.LOSS_ROWS = rows
             logits = self.model(g)[0]
             ops.LOSS_ROWS = None
@@ -297,7 +302,7 @@ class TrainStep:
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
                 nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot, draw_seed=draw_seed,
-                                        unit_grad=True, rows=rows)                    # land in the bucket's tail
+                                        unit_grad=True, rows=rows if (rows is not None and rows.forward) else None)   # land in the bucket's tail
                 num, den = nd[0], nd[1]
                 if self._one is None or self._one.device != num.device:
                     self._one = torch.ones((), dtype=torch.float32, device=num.device)

@@ -89,18 +89,20 @@ def _model(name, seed):
     return cfg, m
 
 
+@pytest.mark.parametrize("mode", [True, "backward"])
 @pytest.mark.parametrize("name,trees,train_mode", [("st_pgat_spgnn_3", 6, False), ("st_pgat_spgnn_3", 64, True), ("st_pgat_spgnnnl_3", 6, False),
                                                    ("st_gat_3", 6, False)])
-def test_loss_rows_step_equals_the_dense_step(name, trees, train_mode):
+def test_loss_rows_step_equals_the_dense_step(name, trees, train_mode, mode):
     """Four optimizer steps with and without the switch from the same parameters, the same mask stream and (train mode) the same
     hash dropout masks: losses and parameters agree to fp32 summation order.  st_gat_3's head (no activation on the output layer:
-    the linear-mean form) does not take the list and must run unchanged."""
+    the linear-mean form) does not take the list and must run unchanged.  ``mode`` "backward": dense forward (the step's model
+    call returns every row), the list only in the backward products."""
     cfg, model = _model(name, 21)
     model.train(train_mode)
     dense = copy.deepcopy(model)
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     g = synthetic.make_batch(trees, rank=2, device="cuda", pos_enc_dim=getattr(cfg, "POS_ENC_DIM", None))
-    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=True)
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=mode)
     ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5)
     if train_mode:                                 # the counter-hash streams (mask and dropout): what a captured step uses
         for ts in (ts_r, ts_d):
@@ -122,7 +124,8 @@ def test_loss_rows_step_equals_the_dense_step(name, trees, train_mode):
         assert int(ts_r._rows_cnt[0]) < 0.5 * N                   # the list is what makes the step cheaper: well under half the nodes
 
 
-def test_captured_loss_rows_step_replays_with_fresh_masks():
+@pytest.mark.parametrize("mode", [True, "backward"])
+def test_captured_loss_rows_step_replays_with_fresh_masks(mode):
     """run_batch (arena + HIP-graph replays) with the switch: the replays draw a new mask each (the list kernel reads the step
     counter from device memory like the loss kernel), the losses follow the dense captured step's."""
     cfg, model = _model("st_pgat_spgnn_3", 4)
@@ -130,7 +133,7 @@ def test_captured_loss_rows_step_replays_with_fresh_masks():
     dense = copy.deepcopy(model)
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     g = synthetic.make_batch(8, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
-    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=True)
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=mode)
     ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9)
     counts = []
     for i, k in enumerate((4, 1, 1, 1)):
@@ -146,7 +149,8 @@ def test_captured_loss_rows_step_replays_with_fresh_masks():
     ts_r.check_loss_rows()
 
 
-def test_loss_rows_step_matches_the_oracle_at_64_trees():
+@pytest.mark.parametrize("mode", [True, "backward"])
+def test_loss_rows_step_matches_the_oracle_at_64_trees(mode):
     """Not only the dense HIP step: the loss and every parameter gradient of a loss-rows step at TRAIN_BATCH_SIZE against the
     CPU oracle's ``F.cross_entropy(pre[mask], y[mask], weight=w)`` over the full forward (reference job_runner.py:1896-1900),
     fp32 and fp64, with the gradient rule of tests/test_hip_parity_at_size.py."""
@@ -159,7 +163,7 @@ def test_loss_rows_step_matches_the_oracle_at_64_trees():
     y = g.ndata["y"]
     draws = torch.rand(N, generator=torch.Generator().manual_seed(5))
     mask = draws < torch.where(y.cpu() != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
-    ts = TrainStep(model, w.tolist(), cfg.SAMPLING_RATE, 1e-3, 0.9, loss_rows_only=True)
+    ts = TrainStep(model, w.tolist(), cfg.SAMPLING_RATE, 1e-3, 0.9, loss_rows_only=mode)
     num = ts._front(g, draws.cuda()).clone()              # gradient SUMS of the numerator in p.grad, the weight sum in the bucket
     den = ts.bucket.wsum_slot.clone()
     assert int(ts._rows_cnt[0]) == int(mask.sum()) and int(ts._rows_cnt[1]) == 0
@@ -173,4 +177,22 @@ def test_loss_rows_step_matches_the_oracle_at_64_trees():
     O.masked_weighted_ce(refs64[0], y.cpu(), mask, w.double()).backward()
     assert rel_err(num / den, ref_loss) < 1e-5
     worst = _assert_gradients(model, sd, sd64, 1e-4)
-    print(f"loss-rows step, 64 trees: loss {rel_err(num / den, ref_loss):.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
+    print(f"loss-rows step ({mode}), 64 trees: loss {rel_err(num / den, ref_loss):.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
+
+
+def test_backward_only_list_overflow_poisons_the_gradients():
+    """The dense loss of a "backward" step cannot show a truncated list: the gradient pass does (NaN), and check_loss_rows
+    raises."""
+    cfg, model = _model("st_pgat_spgnn_3", 2)
+    model.eval()
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(6, rank=2, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only="backward")
+    g.__dict__["_loss_rows_cap"] = {cfg.SAMPLING_RATE: 512}               # (forced: the ~27 % of ~900 nodes fit)
+    ts.step(g)                                                             # a good step first (it also passes the first-step check)
+    assert bool(torch.isfinite(ts.bucket.flat_grad[:ts.bucket.numel]).all())
+    ts._sampling(g).fill_(1.0)                                             # every node kept: 900 rows into 512 slots
+    ts.step(g)
+    assert not bool(torch.isfinite(ts.bucket.flat_grad[:ts.bucket.numel]).all())
+    with pytest.raises(RuntimeError, match="capacity"):
+        ts.check_loss_rows()
