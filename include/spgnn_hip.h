@@ -800,6 +800,21 @@ int spgnn_loss_rows(const float* draws /* nullable */, uint64_t draw_seed, const
 int spgnn_act_bwd_proj_rows(const float* g_s, int64_t g_s_stride, int32_t J, const float* w, int64_t w_stride, const float* out,
                             int64_t out_stride, const int32_t* rows, const int32_t* rows_cnt, float* g_pre, int64_t g_pre_stride,
                             float* absmax_partials, int64_t cap, int32_t H, int32_t D, int32_t activation, spgnn_stream_t stream);
+/*
+ * spgnn_gat_agg_bwd_dst / _src reading the gradient of the z blocks through a row list: g_z_listed holds one row per listed
+ * node, node v's row is g_z_listed[inv[v]] and is all zeros when inv[v] < 0 (such a node's g_e and g_er are written as zeros
+ * without reading its neighbours' rows; its contribution to every g_x is nothing).  Every CSC / CSR slot is still visited.
+ */
+int spgnn_gat_agg_bwd_dst_rows(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride,
+                               const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_z_listed,
+                               int64_t g_z_stride, int32_t head_stride, const int32_t* inv, float* g_e, float* g_er,
+                               int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop,
+                               uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
+int spgnn_gat_agg_bwd_src_rows(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                               const float* g_e, const float* g_z_listed, int64_t g_z_stride, int32_t head_stride,
+                               int32_t x_copy_offset, const int32_t* inv, const float* g_er, const float* w_lr, int64_t w_lr_stride,
+                               float* g_x, int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H,
+                               int32_t F, float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream);
 /* dst[c, :] = c < cnt_flag[0] ? src[idx[c], :] : 0 for c in [0, cap); cols % 4 == 0, 16-byte aligned rows. */
 int spgnn_gather_rows(const float* src, int64_t src_stride, const int32_t* idx, const int32_t* cnt_flag, int64_t cap, int32_t cols,
                       float* dst, int64_t dst_stride, spgnn_stream_t stream);

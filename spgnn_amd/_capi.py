@@ -141,6 +141,10 @@ SIGNATURES = {
                               _i64, _i64, _i32, _i32, _f32, _f32, _u64, _vp, _vp],
     "spgnn_gat_agg_bwd_src": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _i32, _i32, _f32p, _f32p, _i64, _f32p, _i64,
                               _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
+    "spgnn_gat_agg_bwd_dst_rows": [_i32p, _i32p, _f32p, _i64, _f32p, _f32p, _i64, _f32p, _f32p, _i64, _i32, _vp, _f32p, _f32p, _i64,
+                                   _i64, _i64, _i32, _i32, _f32, _f32, _u64, _vp, _vp],
+    "spgnn_gat_agg_bwd_src_rows": [_i32p, _i32p, _i32p, _f32p, _f32p, _f32p, _i64, _i32, _i32, _vp, _f32p, _f32p, _i64, _f32p, _i64,
+                                   _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _u64, _vp, _vp],
     "spgnn_fold_scores_fwd": [_f32p, _i64, _f32p, _f32p, _f32p, _i32, _i32, _i32, _i32, _vp],
     "spgnn_fold_scores_bwd": [_f32p, _i64, _f32p, _f32p, _f32p, _i32, _f32p, _i64, _f32p, _f32p, _i32, _i32, _i32, _vp],
     "spgnn_cat_dropout": [_f32p, _i64, _f32p, _i64, _i64, _i32, _i32, _i32, _f32, _u64, _vp, _i32, _f32p, _vp],

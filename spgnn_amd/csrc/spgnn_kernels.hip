@@ -1057,7 +1057,8 @@ template <typename ST> struct GatAggBwdDstT {
   float* g_e; float* g_er; int64_t gs_ld;
   int64_t N; int F;
   float slope; float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
-};
+  const int32_t* inv;                              // nullable (spgnn_gat_agg_bwd_dst_rows): gz holds one row per LISTED node; node v's
+};                                                 // row is gz[inv[v]], or all zeros when inv[v] < 0 (its g_e, g_er are then zero)
 
 template <typename ST, int H, int R, int T>
 __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDstT<ST> a) {
@@ -1066,6 +1067,20 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDstT<ST> a) {
   const int64_t v = xcd_block() * (kBlock / T) + uni<T == 64>((int)(threadIdx.x / T));
   if (v >= a.N) return;
   const int beg = uni<T == 64>(a.indptr[v]), end = uni<T == 64>(a.indptr[v + 1]), deg = end - beg;
+  int64_t gv_row = v;
+  if (a.inv) {
+    gv_row = uni<T == 64>(a.inv[v]);
+    if (gv_row < 0) {                               // a zero gradient row: every dot product, g_e and g_er of this node is zero
+      if (lane == 0) {
+        for (int j = beg; j < end; ++j)
+#pragma unroll
+          for (int h = 0; h < H; ++h) a.g_e[(int64_t)j * H + h] = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) a.g_er[v * a.gs_ld + h] = 0.f;
+      }
+      return;
+    }
+  }
   int col[R]; bool ok[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { const int c = (r * T + lane) * 4; ok[r] = c < a.F; col[r] = ok[r] ? c : 0; }
@@ -1074,7 +1089,7 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_dst(GatAggBwdDstT<ST> a) {
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float4 q = ldv(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]);
+      const float4 q = ldv(a.gz + gv_row * a.gz_ld + (int64_t)h * a.zs + col[r]);
       g[h][r] = ok[r] ? q : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   float erv[H];
@@ -1181,6 +1196,7 @@ template <typename ST> struct GatAggBwdSrcT {
   float* g_el; int64_t gs_ld;
   int64_t N; int F;
   float p; float inv_keep; uint64_t seed; const uint64_t* seed_off;
+  const int32_t* inv;                              // nullable (spgnn_gat_agg_bwd_src_rows): as in GatAggBwdDstT
 };
 
 template <typename ST, int H, int R, int T>
@@ -1196,12 +1212,13 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrcT<ST> a) {
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.xoff >= 0) {                                // gradient of the residual operand copies
+  const int64_t gu_row = a.inv ? (int64_t)uni<T == 64>(a.inv[u]) : u;
+  if (a.xoff >= 0 && gu_row >= 0) {                 // gradient of the residual operand copies
 #pragma unroll
     for (int h = 0; h < H; ++h)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float4 q = ldv(a.gz + u * a.gz_ld + (int64_t)h * a.zs + a.xoff + col[r]);
+        const float4 q = ldv(a.gz + gu_row * a.gz_ld + (int64_t)h * a.zs + a.xoff + col[r]);
         acc[r].x += q.x; acc[r].y += q.y; acc[r].z += q.z; acc[r].w += q.w;
       }
   }
@@ -1214,6 +1231,10 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrcT<ST> a) {
     for (int k = 0; k < kMaxFast; ++k) {
       vv[k] = uni<T == 64>(a.out_indices[beg + (k < deg ? k : deg - 1)]);
       pp[k] = uni<T == 64>(a.out_pos[beg + (k < deg ? k : deg - 1)]);
+    }
+    if (a.inv) {                                    // the destinations' rows in the list (-1: a zero row, skipped below)
+#pragma unroll
+      for (int k = 0; k < kMaxFast; ++k) vv[k] = uni<T == 64>(a.inv[vv[k]]);
     }
     float w[kMaxFast][H];
 #pragma unroll
@@ -1236,7 +1257,9 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrcT<ST> a) {
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int r = 0; r < R; ++r) gr[q][h][r] = ldv(a.gz + (int64_t)vv[k0 + q] * a.gz_ld + (int64_t)h * a.zs + col[r]);
+          for (int r = 0; r < R; ++r)
+            gr[q][h][r] = vv[k0 + q] >= 0 ? ldv(a.gz + (int64_t)vv[k0 + q] * a.gz_ld + (int64_t)h * a.zs + col[r])
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < G; ++q)
 #pragma unroll
@@ -1246,15 +1269,18 @@ __global__ __launch_bounds__(kBlock) void gat_agg_bwd_src(GatAggBwdSrcT<ST> a) {
     }
   } else {
     for (int k = beg; k < end; ++k) {
-      const int64_t v = a.out_indices[k], pos = a.out_pos[k];
+      const int64_t pos = a.out_pos[k];
+      const int64_t v = a.inv ? (int64_t)a.inv[a.out_indices[k]] : (int64_t)a.out_indices[k];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const int64_t eidx = pos * H + h;
         float w = a.attn[eidx];
         if (a.p > 0.f) w *= keep_scale(a.seed, eidx, a.p, a.inv_keep);
         gel[h] += a.g_e[eidx];
+        if (v >= 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) fma4(acc[r], w, ldv(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]));
+          for (int r = 0; r < R; ++r) fma4(acc[r], w, ldv(a.gz + v * a.gz_ld + (int64_t)h * a.zs + col[r]));
+        }
       }
     }
   }
@@ -3384,7 +3410,7 @@ static int gat_agg_bwd_dst_impl(const char* name, const int32_t* indptr, const i
                           const float* el, const float* er, int64_t s_stride, const float* attn, const ST* g_z,
                           int64_t g_z_stride, int32_t head_stride, float* g_e, float* g_er, int64_t g_s_stride, int64_t N,
                           int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop, uint64_t seed,
-                          const uint64_t* seed_offset, spgnn_stream_t stream) {
+                          const uint64_t* seed_offset, spgnn_stream_t stream, const int32_t* inv = nullptr) {
   if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_bwd_dst: bad N/E/H/F");
   if (N == 0) return SPGNN_OK;
   if (!indptr || !x || !el || !er || !attn || !g_z || !g_e || !g_er || (E > 0 && !indices))
@@ -3395,7 +3421,7 @@ static int gat_agg_bwd_dst_impl(const char* name, const int32_t* indptr, const i
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_dst: rows must be 16-byte aligned");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_dst: p_drop not in [0,1)");
   GatAggBwdDstT<ST> a{indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride, head_stride, g_e, g_er, g_s_stride,
-                 N, F, negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+                 N, F, negative_slope, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, inv};
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(kBlock);
   if (agg_team16(F)) {
@@ -3417,7 +3443,7 @@ static int gat_agg_bwd_src_impl(const char* name, const int32_t* out_indptr, con
                           const float* g_e, const ST* g_z, int64_t g_z_stride, int32_t head_stride,
                           int32_t x_copy_offset, const float* g_er, const float* w_lr, int64_t w_lr_stride, ST* g_x,
                           int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F,
-                          float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+                          float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream, const int32_t* inv = nullptr) {
   if (N < 0 || E < 0 || !spgnn_gat_agg_supported(H, F)) return fail(SPGNN_ERR_SHAPE, "spgnn_gat_agg_bwd_src: bad N/E/H/F");
   if (N == 0) return SPGNN_OK;
   if (!out_indptr || !attn || !g_e || !g_z || !g_x || !g_el || (w_lr && !g_er) || (E > 0 && (!out_indices || !out_pos)))
@@ -3431,7 +3457,7 @@ static int gat_agg_bwd_src_impl(const char* name, const int32_t* out_indptr, con
     return fail(SPGNN_ERR_STRIDE, "spgnn_gat_agg_bwd_src: rows must be 16-byte aligned");
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(SPGNN_ERR_ENUM, "spgnn_gat_agg_bwd_src: p_drop not in [0,1)");
   GatAggBwdSrcT<ST> a{out_indptr, out_indices, out_pos, attn, g_e, g_z, g_z_stride, head_stride, x_copy_offset, g_er, w_lr,
-                 w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, F, p_drop, 1.f / (1.f - p_drop), seed, seed_offset};
+                 w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, F, p_drop, 1.f / (1.f - p_drop), seed, seed_offset, inv};
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(kBlock);
   if (agg_team16(F)) {
@@ -3476,6 +3502,28 @@ int spgnn_gat_agg_bwd_dst(const int32_t* indptr, const int32_t* indices, const f
   return gat_agg_bwd_dst_impl<float>("spgnn_gat_agg_bwd_dst", indptr, indices, x, x_stride, el, er, s_stride, attn, g_z, g_z_stride,
                                      head_stride, g_e, g_er, g_s_stride, N, E, H, F, negative_slope, p_drop, seed, seed_offset,
                                      stream);
+}
+
+int spgnn_gat_agg_bwd_dst_rows(const int32_t* indptr, const int32_t* indices, const float* x, int64_t x_stride,
+                               const float* el, const float* er, int64_t s_stride, const float* attn, const float* g_z_listed,
+                               int64_t g_z_stride, int32_t head_stride, const int32_t* inv, float* g_e, float* g_er,
+                               int64_t g_s_stride, int64_t N, int64_t E, int32_t H, int32_t F, float negative_slope, float p_drop,
+                               uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (!inv) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_bwd_dst_rows: null pointer");
+  return gat_agg_bwd_dst_impl<float>("spgnn_gat_agg_bwd_dst_rows", indptr, indices, x, x_stride, el, er, s_stride, attn, g_z_listed,
+                                     g_z_stride, head_stride, g_e, g_er, g_s_stride, N, E, H, F, negative_slope, p_drop, seed,
+                                     seed_offset, stream, inv);
+}
+
+int spgnn_gat_agg_bwd_src_rows(const int32_t* out_indptr, const int32_t* out_indices, const int32_t* out_pos, const float* attn,
+                               const float* g_e, const float* g_z_listed, int64_t g_z_stride, int32_t head_stride,
+                               int32_t x_copy_offset, const int32_t* inv, const float* g_er, const float* w_lr, int64_t w_lr_stride,
+                               float* g_x, int64_t g_x_stride, float* g_el, int64_t g_s_stride, int64_t N, int64_t E, int32_t H,
+                               int32_t F, float p_drop, uint64_t seed, const uint64_t* seed_offset, spgnn_stream_t stream) {
+  if (!inv) return fail(SPGNN_ERR_NULLPTR, "spgnn_gat_agg_bwd_src_rows: null pointer");
+  return gat_agg_bwd_src_impl<float>("spgnn_gat_agg_bwd_src_rows", out_indptr, out_indices, out_pos, attn, g_e, g_z_listed, g_z_stride,
+                                     head_stride, x_copy_offset, g_er, w_lr, w_lr_stride, g_x, g_x_stride, g_el, g_s_stride, N, E, H,
+                                     F, p_drop, seed, seed_offset, stream, inv);
 }
 
 int spgnn_gat_agg_bwd_dst_bf16(const int32_t* indptr, const int32_t* indices, const uint16_t* x, int64_t x_stride,

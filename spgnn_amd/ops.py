@@ -968,6 +968,7 @@ def column_sums(g: torch.Tensor) -> torch.Tensor:
 # node that fuses output layer and classifier (_GATAggFirstFn) picks it up and hands back ONE ROW PER LISTED NODE.
 # --------------------------------------------------------------------------------------------
 LOSS_ROWS: Optional["LossRows"] = None
+LIST_AWARE_TRAVERSALS = True     # the output layer's backward traversals read the listed g_z rows through LossRows.inv (off: expand first)
 
 
 class LossRows:
@@ -2523,30 +2524,48 @@ class _GATAggFirstFn(torch.autograd.Function):
                 tns[-1].launch().finish()
         if need_bias and not need_w:
             g_bias = g_pre.sum(0)
-        if compact:
-            g_z = expand_rows(g_z, rows)       # back in node order (zero rows for the nodes outside the mask) for the traversals
+        # (a loss-rows step: g_z stays one row per LISTED node - the two traversals read it through rows.inv, a node outside the
+        # list has a zero row; LIST_AWARE_TRAVERSALS off: the expanded copy in node order, as the dense step has it)
+        listed_gz = compact and LIST_AWARE_TRAVERSALS
+        if compact and not listed_gz:
+            g_z = expand_rows(g_z, rows)
         g_s = torch.empty_like(s)
         g_e = torch.empty((E, H), dtype=torch.float32, device=x.device)
         lib = _capi.load()
         with torch.cuda.device(x.device):
             st = _stream(x)
             with _timed("gat_agg_bwd_dst", (N, E, H, F_)):
-                _capi.check(lib.spgnn_gat_agg_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
-                                                      s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
-                                                      g_z.data_ptr(), g_z.stride(0), zs, g_e.data_ptr(), g_s[:, H:].data_ptr(),
-                                                      g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
-                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst")
+                if listed_gz:
+                    _capi.check(lib.spgnn_gat_agg_bwd_dst_rows(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                               s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                               g_z.data_ptr(), g_z.stride(0), zs, rows.inv.data_ptr(), g_e.data_ptr(),
+                                                               g_s[:, H:].data_ptr(), g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
+                                                               _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst_rows")
+                else:
+                    _capi.check(lib.spgnn_gat_agg_bwd_dst(csc.indptr.data_ptr(), csc.indices.data_ptr(), x.data_ptr(), x.stride(0),
+                                                          s.data_ptr(), s[:, H:].data_ptr(), s.stride(0), attn.data_ptr(),
+                                                          g_z.data_ptr(), g_z.stride(0), zs, g_e.data_ptr(), g_s[:, H:].data_ptr(),
+                                                          g_s.stride(0), N, E, H, F_, slope, p_drop, seed,
+                                                          _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_dst")
             need_x = ctx.needs_input_grad[0]
             Fp = (F_ + 3) // 4 * 4
             g_x = torch.empty((N, Fp), dtype=torch.float32, device=x.device)[:, :F_]
             w_lr_c = w_lr.contiguous()
             with _timed("gat_agg_bwd_src", (N, E, H, F_)):
-                _capi.check(lib.spgnn_gat_agg_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
-                                                      csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_z.data_ptr(),
-                                                      g_z.stride(0), zs, F_ if has_res else -1, g_s[:, H:].data_ptr(),
-                                                      w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
-                                                      g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
-                                                      _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
+                if listed_gz:
+                    _capi.check(lib.spgnn_gat_agg_bwd_src_rows(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                               csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_z.data_ptr(),
+                                                               g_z.stride(0), zs, F_ if has_res else -1, rows.inv.data_ptr(),
+                                                               g_s[:, H:].data_ptr(), w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(),
+                                                               g_x.stride(0), g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
+                                                               _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src_rows")
+                else:
+                    _capi.check(lib.spgnn_gat_agg_bwd_src(csc.out_indptr.data_ptr(), csc.out_indices.data_ptr(),
+                                                          csc.out_pos.data_ptr(), attn.data_ptr(), g_e.data_ptr(), g_z.data_ptr(),
+                                                          g_z.stride(0), zs, F_ if has_res else -1, g_s[:, H:].data_ptr(),
+                                                          w_lr_c.data_ptr(), w_lr_c.stride(0), g_x.data_ptr(), g_x.stride(0),
+                                                          g_s.data_ptr(), g_s.stride(0), N, E, H, F_, p_drop, seed,
+                                                          _seed_off_ptr(x.device), st), "spgnn_gat_agg_bwd_src")
         g_wlr = scores_bwd_w(g_s, x, defer=jobs) if ctx.needs_input_grad[3] else None
         jobs.flush()
         return ((g_x if need_x else None), g_wfc, g_wres, g_wlr, g_bias, g_wcls, g_bcls, None, None, None, None, None, None,

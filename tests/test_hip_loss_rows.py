@@ -196,3 +196,21 @@ def test_backward_only_list_overflow_poisons_the_gradients():
     assert not bool(torch.isfinite(ts.bucket.flat_grad[:ts.bucket.numel]).all())
     with pytest.raises(RuntimeError, match="capacity"):
         ts.check_loss_rows()
+
+
+def test_list_aware_traversals_equal_the_expanded_copy(monkeypatch):
+    """The output layer's two backward traversals reading the listed g_z rows through ``inv`` (zero rows skipped) against the same
+    traversals on the expanded node-order copy: the same sums in the same order - bit-identical parameters after two steps."""
+    cfg, model = _model("st_pgat_spgnn_3", 8)
+    model.eval()
+    other = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(12, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    res = []
+    for aware, m in ((True, model), (False, other)):
+        monkeypatch.setattr(ops, "LIST_AWARE_TRAVERSALS", aware)
+        ts = TrainStep(m, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=True)
+        for _ in range(2):
+            ts.step(g)
+        res.append(ts.bucket.flat_param[:ts.bucket.numel].clone())
+    assert torch.equal(res[0], res[1])
