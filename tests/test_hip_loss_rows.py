@@ -214,3 +214,30 @@ def test_list_aware_traversals_equal_the_expanded_copy(monkeypatch):
             ts.step(g)
         res.append(ts.bucket.flat_param[:ts.bucket.numel].clone())
     assert torch.equal(res[0], res[1])
+
+
+def test_loss_rows_through_an_arena_follow_each_loaded_batch():
+    """Two loader batches of one size class through run_batch: the second is a copy into the arena plus replays of the graph
+    captured on the first - the list kernel reads the sampling probabilities the arena load rewrote (other labelled nodes, other
+    pad rows), with the capacity fixed at capture (15 % headroom for exactly this)."""
+    cfg, model = _model("st_pgat_spgnn_3", 6)
+    model.train(True)
+    dense = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    assert ga.number_of_nodes() != gb.number_of_nodes()
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=True)
+    ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9)
+    for i, g in enumerate((ga, gb, ga)):
+        torch.manual_seed(300 + i)
+        lr_ = ts_r.run_batch(g, 4, granule=2048)
+        torch.manual_seed(300 + i)
+        ld_ = ts_d.run_batch(g, 4, granule=2048)
+        assert rel_err(lr_, ld_) < 1e-5, (i, float(lr_), float(ld_))
+        y = g.ndata["y"]
+        assert int((y != 0).sum()) <= int(ts_r._rows_cnt[0]) < 0.5 * g.number_of_nodes()      # this batch's labelled nodes are all listed
+    assert len(ts_r._captures) == 1 and len(ts_r._arenas) == 1
+    n = ts_r.bucket.numel
+    assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 1e-5
+    ts_r.check_loss_rows()
