@@ -1022,6 +1022,43 @@ def expand_rows(xc: torch.Tensor, rows: LossRows) -> torch.Tensor:
     return out
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """x (N, C) -> the listed rows (cap, C), differentiable: the gradient goes back to the listed nodes' rows, zero rows to all
+    others.  Put behind a model's LAST aggregation in a loss-rows step, it makes every row-wise operation after it - Linear
+    stacks, activations, the classifier - run on the kept rows without knowing.  fp32 rows, or bf16 rows moved as pairs."""
+
+    @staticmethod
+    def forward(ctx, x, rows: LossRows):
+        ctx.rows, ctx.dtype = rows, x.dtype
+        xv = x if x.dtype == torch.float32 else x.view(torch.float32)
+        out = gather_rows(xv, rows)
+        return out if x.dtype == torch.float32 else out.view(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rowmajor(g)
+        if g.dtype != torch.float32:
+            return expand_rows(g.contiguous().view(torch.float32), ctx.rows).view(ctx.dtype), None
+        if not _rows_aligned(g):
+            g = g.contiguous()
+        return expand_rows(g, ctx.rows), None
+
+
+def take_loss_rows(x: torch.Tensor, has_classifier: bool) -> torch.Tensor:
+    """``x`` = what a model's last aggregation produced.  In a loss-rows step whose forward pass uses the list
+    (TrainStep(loss_rows_only=True)) and whose head ends in the fused classifier: the listed rows of ``x`` (and the list is marked
+    as taken: the logits will have one row per listed node).  Otherwise ``x`` itself."""
+    rows = LOSS_ROWS
+    if rows is None or not rows.forward or not has_classifier or rows.N != x.shape[0] or x.stride(1) != 1:
+        return x
+    ok = (x.dtype == torch.float32 and x.shape[1] % 4 == 0 and _rows_aligned(x)) or \
+         (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+    if not ok:
+        return x
+    rows.used = True
+    return _GatherRowsFn.apply(x, rows)
+
+
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[torch.Tensor], sampling_p: torch.Tensor,
                    class_weight: torch.Tensor, out: Optional[torch.Tensor] = None, draw_seed: int = 0, unit_grad: bool = False,
                    rows: Optional["LossRows"] = None):
@@ -2772,8 +2809,9 @@ def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D:
     F_ = x.shape[1]
     zx, attn = _GATAggregateFn.apply(x, w_lr, csc, H, slope, p_drop, seed)
     blk = getattr(zx.grad_fn, "scale_block", None) if zx.grad_fn is not None else None
+    zx = take_loss_rows(zx, w_cls is not None)         # a loss-rows step: the product, the mean and the classifier on the kept rows
     if blk is not None:
-        zx._spgnn_scale = (zx._version, blk)
+        zx._spgnn_scale = (zx._version, blk)           # (the maximum over all rows bounds the listed ones)
     if (FUSE_LINEAR_MEAN_FOLD and w_cls is not None and w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 4 == 0
             and zx.shape[0] >= MIN_GEMM_ROWS and GEMM_MODE == "f16x3" and zx.dtype == torch.float32):
         out, logits = _LinearMeanClassifierFn.apply(zx, w_fc, w_res, bias, w_cls, b_cls, H, D)

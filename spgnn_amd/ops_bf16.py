@@ -702,6 +702,7 @@ def gat_layer_linear_mean(csc: DeviceCSC, x, w_fc, w_res, w_lr, bias, H: int, D:
     F_ = x.shape[1]
     zx, attn = _GATAggregateBf16Fn.apply(as_rows(x), w_lr, csc, H, slope, p_drop, seed)
     from . import ops as _ops
+    zx = _ops.take_loss_rows(zx, w_cls is not None)    # a loss-rows step: the product, the mean and the classifier on the kept rows
     if (_ops.FUSE_LINEAR_MEAN_FOLD and w_cls is not None and w_cls.shape[0] <= 32 and w_cls.shape[1] == D and D % 8 == 0
             and ((H + 1) * F_) % 8 == 0):
         out, logits = _LinearMeanClassifierBf16Fn.apply(zx, w_fc, w_res, bias, w_cls, b_cls, H, D)
