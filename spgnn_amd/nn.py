@@ -371,6 +371,8 @@ class GraphConv(nn.Module):
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
         else:
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, w_src, w_dst))
+            if classifier is not None and rst.is_cuda and getattr(csc, "num_dst", None) is None:
+                rst = ops.take_loss_rows(rst, True)      # a loss-rows step: the product and the classifier on the kept rows
             if weight is not None:
                 if (fuse and classifier is not None and act == ops.ACT_NONE
                         and ops.linear_classifier_supported(rst, weight.t(), classifier.weight)):
@@ -519,6 +521,8 @@ class GINConv(nn.Module):
                                drop=(pd, _draw_seed()) if 0.0 < pd < 1.0 else None)
             if pd >= 1.0:
                 rst = drop(rst)
+            if classifier is not None:
+                rst = ops.take_loss_rows(rst, True)      # a loss-rows step: the rest of the MLP and the classifier on the kept rows
             rest = mods[j:]
             if classifier is not None and self.activation is None and rest:
                 return _apply_fast_sequence_classifier(rest, rst, classifier)
@@ -531,6 +535,8 @@ class GINConv(nn.Module):
         else:
             w_dst = csc.degree_scale("in", -1.0) if self._aggregator_type == "mean" else None
             rst = _dst_rows(csc, ops.spmm_sum(csc, feat, None, w_dst, self.eps))     # (1+eps)*x fused into the SpMM
+        if classifier is not None and rst.is_cuda and getattr(csc, "num_dst", None) is None:
+            rst = ops.take_loss_rows(rst, True)          # a loss-rows step: the MLP and the classifier on the kept rows
         if classifier is not None and self.apply_func is not None and self.activation is None:
             return _apply_fast_linear(self.apply_func, rst, classifier)
         if self.apply_func is not None:
@@ -625,6 +631,8 @@ class SAGEConv(nn.Module):
                 # Output wider than both inputs together (64 -> 1024): ONE product on [neigh | h] with [W_neigh | W_self]
                 # (the addend form writes, re-reads and re-writes the (N, out) result: 0.94 GB against 0.35 GB here)
                 xc = ops.cat_dropout((neigh, h), 0.0, 0)
+                if classifier is not None:
+                    xc = ops.take_loss_rows(xc, True)    # a loss-rows step: the product and the classifier on the kept rows
                 bs = [b for b in (self.fc_neigh.bias, self.fc_self.bias) if b is not None]
                 bc = (bs[0] + bs[1] if len(bs) == 2 else bs[0]) if bs else None
                 if (classifier is not None and act == ops.ACT_NONE and self.norm is None and classifier.weight.shape[0] <= 32

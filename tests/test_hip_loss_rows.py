@@ -266,3 +266,24 @@ def test_bf16_storage_loss_rows_step_equals_the_dense_step(name, trees):
             assert rel_err(ts_r.bucket.flat_grad[:n], ts_d.bucket.flat_grad[:n]) < 1e-6
     assert ts_r._rows_cnt is not None and 0 < int(ts_r._rows_cnt[0]) < 0.5 * g.number_of_nodes()
     assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["st_gcn_3", "st_gin_3", "st_sage_3"])
+def test_loss_rows_for_the_spmm_heads(name):
+    """GraphConv / GINConv / SAGEConv nets: the differentiable gather sits behind the LAST aggregation (ops.take_loss_rows in
+    nn.GraphConv / GINConv / SAGEConv with ``classifier=``), everything after it - st_gin_3's two 1024-wide products included -
+    runs on the kept rows.  Same losses and parameters as the dense step."""
+    cfg, model = _model(name, 17)
+    model.eval()
+    dense = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(16, rank=2, device="cuda", pos_enc_dim=None)
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=True)
+    ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5)
+    for i in range(3):
+        lr_, ld_ = ts_r.step(g), ts_d.step(g)
+        assert rel_err(lr_, ld_) < 2e-6, (i, float(lr_), float(ld_))
+    assert ts_r._rows_cnt is not None and 0 < int(ts_r._rows_cnt[0]) < 0.5 * g.number_of_nodes()
+    n = ts_r.bucket.numel
+    # (SAGE's max-pool routing and GIN's LeakyReLU branches are decided on rows that both steps compute with the same arithmetic)
+    assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 5e-6
