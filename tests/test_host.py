@@ -496,3 +496,30 @@ def test_bench_flat_scalars_for_the_drivers_record():
     assert r["hbm_frac"] == 0.6 and r["hbm_ms_per_step"] == 1.1 and r["hbm_survey_bytes"] == 5.2e9 and r["hbm_traffic"] == 5.0e9
     assert c["gemm_ms_per_step"] == 3.3 and c["message_passing_ms_per_step"] == 1.7 and c["step_ms_median"] == 5.2
     assert all(not isinstance(v, (dict, list)) for k, v in r.items() if k.startswith("hbm_"))
+
+
+def test_loss_rows_capacity_rule():
+    """train.TrainStep._loss_rows_cap (host arithmetic): mean + 8 sigma of the kept count, 256-row tiles, 15 % headroom on a batch
+    arena, and 0 (= run dense) when the list would not be clearly shorter than the node count."""
+    import types
+
+    import torch
+
+    from spgnn_amd.train import TrainStep
+    ts = TrainStep.__new__(TrainStep)
+    ts.sampling_rate = 0.15
+    big = types.SimpleNamespace()
+    p = torch.full((76410,), 0.15)
+    p[::7] = 1.0                                                   # ~14 % labelled
+    p[-300:] = -1.0                                                # pad rows never count
+    mu = float(p.clamp(min=0).sum())
+    var = float((p.clamp(min=0) * (1 - p.clamp(min=0))).sum())
+    cap = ts._loss_rows_cap(big, p)
+    assert cap % 256 == 0 and mu + 8 * var ** 0.5 <= cap < mu + 8 * var ** 0.5 + 32 + 256 and cap < 0.35 * 76410
+    assert ts._loss_rows_cap(big, p * 0 + 1.0) == cap              # cached on the graph: one host read per graph
+    arena = types.SimpleNamespace(_stable_storage=True)
+    assert ts._loss_rows_cap(arena, p) > cap                       # headroom for the other batches of the size class
+    small = types.SimpleNamespace()
+    assert ts._loss_rows_cap(small, torch.full((150,), 0.15)) == 0   # 256 slots for 150 nodes: no gain, run dense
+    dense = types.SimpleNamespace()
+    assert ts._loss_rows_cap(dense, torch.ones(50000)) == 0        # every node labelled: the list would be the node set
