@@ -287,3 +287,24 @@ def test_loss_rows_for_the_spmm_heads(name):
     n = ts_r.bucket.numel
     # (SAGE's max-pool routing and GIN's LeakyReLU branches are decided on rows that both steps compute with the same arithmetic)
     assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 5e-6
+
+
+@pytest.mark.parametrize("mode", [True, "backward"])
+def test_loss_rows_steps_repeat_bit_for_bit(mode):
+    """The list is made by counts and ordered writes (no atomics, no arrival order), the products on it are the dense step's
+    kernels: two runs from the same state and seeds end in bit-identical parameters."""
+    cfg, model = _model("st_pgat_spgnn_3", 31)
+    model.train(True)
+    twin = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(24, rank=5, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ends = []
+    for m in (model, twin):
+        ts = TrainStep(m, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=77, loss_rows_only=mode)
+        ts._seed_ctr = torch.zeros((1,), dtype=torch.int64, device="cuda")
+        ts._use_default_rng = True
+        for i in range(3):
+            torch.manual_seed(400 + i)
+            ts.step(g)
+        ends.append(ts.bucket.flat_param[:ts.bucket.numel].clone())
+    assert torch.equal(ends[0], ends[1])
