@@ -1028,7 +1028,8 @@ def main():
                     s2 = secondary_summary(o2)
                     s2["what"] = ("the headline workload with TrainStep(loss_rows_only=%r): %s only on the rows the step's mask keeps "
                                   "(reference job_runner.py:1896-1900 takes the loss over pre[mask]); identical loss and gradients up to fp32 "
-                                  "summation order (tests/test_hip_loss_rows.py); every traversal still visits every edge"
+                                  "summation order (tests/test_hip_loss_rows.py); every traversal still visits every edge (the output layer's two backward "
+                                  "traversals read the listed gradient rows only: their share of roofline_k123 is priced on the dense byte count)"
                                   % (mode, "the output layer's BACKWARD products (dense forward)" if mode == "backward" else
                                      "output-layer projection, head mean, classifier and their backward products"))
                     sec[leg_name] = s2
