@@ -1524,8 +1524,9 @@ def const_operand(x: torch.Tensor, scale: torch.Tensor):
         return tag[1], True
     if torch.cuda.is_current_stream_capturing():
         return x, False                      # never allocate a persistent image inside a capture (the warm-up steps made it)
-    if not torch.is_grad_enabled():
-        return x, False                      # a single inference pass (reference test.py): one product does not repay a split pass
+    if INFERENCE:                            # (not torch.is_grad_enabled(): that is False inside EVERY autograd.Function.forward,
+        return x, False                      # which is where the products are issued from - the training step never got its image)
+                                             # a single inference pass (reference test.py): one product does not repay a split pass
     ps = presplit(x, scale=scale)[0]
     if images is None:
         images = x._spgnn_aps = {}
