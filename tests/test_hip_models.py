@@ -844,3 +844,30 @@ def test_side_stream_weight_gradients_are_bit_identical(name, trees, min_rows, m
     assert torch.isfinite(got[True][0][0]).all() and float(got[True][0][0].abs().max()) > 0
     assert torch.equal(got[True][1], got[False][1]) and got[True][2] == got[False][2]
     _ops.DROPOUT_SEED_OFFSET = None
+
+
+@pytest.mark.gpu
+def test_training_step_splits_its_node_data_once_per_batch():
+    """Guard for a silent regression (docs/HISTORY.md, round 5): the products of a TRAINING step must find the pre-split image of
+    the batch's constant node data (ops.const_operand) - the test that skips it for single inference passes may not look at
+    torch.is_grad_enabled(), which is False inside every autograd.Function.forward."""
+    from spgnn_amd import models, ops, synthetic
+    from spgnn_amd.configs import class_weight_list, get_config
+    from spgnn_amd.train import TrainStep
+    cfg = get_config("st_pgat_spgnn_3")
+    torch.manual_seed(0)
+    model = models.build_model(cfg.MODEL).cuda()
+    model.init(None)
+    model.set_gcn_only()
+    g = synthetic.make_batch(4, rank=0, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, 1e-4, 0.9)
+    ts.step(g)
+    consts = [t for t in list(g._tensor_cache.values()) + list(g.ndata.values()) if getattr(t, "_spgnn_const", False)]
+    assert consts and ops.A_PRESPLIT and ops.PRESPLIT_B
+    split = [t for t in consts if getattr(t, "_spgnn_aps", None)]
+    assert split, "no constant node-data tensor carries a pre-split image after a training step"
+    model.eval()
+    g2 = synthetic.make_batch(4, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    with torch.no_grad():
+        model(g2)                                   # a single inference pass: no split pass, no image
+    assert not [t for t in list(g2._tensor_cache.values()) + list(g2.ndata.values()) if getattr(t, "_spgnn_aps", None)]
