@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 57
+#define SPGNN_ABI_VERSION 58
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -821,6 +821,12 @@ int spgnn_gather_rows(const float* src, int64_t src_stride, const int32_t* idx, 
 /* dst[n, :] = inv[n] >= 0 ? src[inv[n], :] : 0 for n in [0, N): the listed rows back in node order, zeros elsewhere. */
 int spgnn_expand_rows(const float* src, int64_t src_stride, const int32_t* inv, int64_t N, int32_t cols, float* dst,
                       int64_t dst_stride, spgnn_stream_t stream);
+/* spgnn_masked_ce_step whose class weights turn NaN when rows_cnt[1] != 0 (the step's row list overflowed; a step that uses the
+ * list in its backward pass only has a dense loss, which would otherwise not show it). */
+int spgnn_masked_ce_step_flagged(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                                 const int64_t* seed_offset, const float* sampling_p, const int32_t* rows_cnt, const float* class_weight,
+                                 float* partials, float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride,
+                                 float* colsum_partials, float* g_colsum, int64_t N, int32_t C, spgnn_stream_t stream);
 /*
  * spgnn_masked_ce_step on LISTED rows: logits / g_logits have `cap` rows, row i belongs to node rows[i] (its label:
  * labels[rows[i]]) and counts when i < rows_cnt[0]; no draw (the list is the draw).  Same sums, gradient and column sums.
@@ -874,6 +880,16 @@ int spgnn_sgd_momentum_step(float* param, const float* grad, float* momentum_buf
 int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentum_buf, const float* weight_sum,
                                  const float* loss_num, float* loss_out, const float* lr_dev, int64_t n, float lr,
                                  float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream);
+/*
+ * spgnn_sgd_momentum_step_mean with a guard: a step whose loss (loss_num[0] / weight_sum[0]) is not finite is not applied -
+ * parameters and momentum buffer untouched, skipped_steps[0] += 1, loss_out still carries the NaN.  Used by the loss-rows
+ * training steps, whose row list can (with probability ~1e-15 per step on the batch it was sized on, more on a later batch of
+ * the arena with more labelled nodes) overflow its fixed capacity: the loss is then NaN by construction, the step is lost
+ * instead of the parameters, and the host enlarges the list at the next loader batch (TrainStep.check_loss_rows).
+ */
+int spgnn_sgd_momentum_step_guarded(float* param, const float* grad, float* momentum_buf, const float* weight_sum,
+                                    const float* loss_num, float* loss_out, const float* lr_dev, uint32_t* skipped_steps, int64_t n,
+                                    float lr, float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream);
 /*
  * What a training step arms before its first kernel, in one launch: `counter` (nullable, device int64: the dropout / mask
  * stream position the kernels read through their `seed_offset` arguments) += 1, and the `n_scale_blocks` scale blocks at

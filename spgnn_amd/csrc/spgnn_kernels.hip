@@ -2822,6 +2822,8 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
                                                            float* __restrict__ g_logits, int64_t g_ld, float* __restrict__ colpart,
                                                            float* __restrict__ colsum, int64_t N, int C,
                                                            const int32_t* __restrict__ row_list, const int32_t* __restrict__ rows_cnt) {
+  // `rows_cnt` alone (spgnn_masked_ce_step_flagged): a dense pass whose weights turn NaN when rows_cnt[1] != 0 - the step's row
+  // list overflowed and only its backward pass uses it.
   // `row_list` (spgnn_masked_ce_rows): logits / g_logits hold one row per LISTED node (spgnn_loss_rows: the nodes the mask keeps,
   // rows_cnt[0] of them, rows_cnt[1] != 0 when the list overflowed its capacity): row i belongs to node row_list[i], its mask
   // is i < rows_cnt[0] - no draw here, the list IS the draw - and an overflow turns every weight into NaN
@@ -2847,7 +2849,7 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
     const float* row = staged ? tile + threadIdx.x * P : logits + i * ld;
     const bool listed = row_list != nullptr && i < (int64_t)rows_cnt[0];
     const int64_t yl = row_list ? (listed ? labels[row_list[i]] : 0) : labels[i];
-    const bool y_ok = yl >= 0 && yl < C && !(row_list && rows_cnt[1] != 0);   // F.cross_entropy raises for such a label; here the node
+    const bool y_ok = yl >= 0 && yl < C && !(rows_cnt && rows_cnt[1] != 0);   // F.cross_entropy raises for such a label; here the node
     const int y = y_ok ? (int)yl : 0;                        // gets a NaN weight, so the loss is NaN instead of an out-of-bounds read
     float m;
     if (row_list) m = listed ? 1.f : 0.f;
@@ -2955,9 +2957,17 @@ __global__ __launch_bounds__(kBlock) void masked_ce_kernel(const float* __restri
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                     const float* __restrict__ gscale, const float* __restrict__ gdenom,
                                     const float* __restrict__ loss_num, float* __restrict__ loss_out,
-                                    const float* __restrict__ lr_dev, int64_t n, float lr, float mom, float wd, int first) {
+                                    const float* __restrict__ lr_dev, int64_t n, float lr, float mom, float wd, int first,
+                                    unsigned* __restrict__ skipped) {
   const float sc = gdenom ? 1.f / gdenom[0] : (gscale ? gscale[0] : 1.f);
   if (loss_out && blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = loss_num[0] * sc;
+  // guarded form (spgnn_sgd_momentum_step_guarded): a step whose loss is not finite is NOT applied - parameters and momentum
+  // stay as they are, the counter goes up by one; the loss scalar above still reports the NaN.  Every rank sees the same
+  // all-reduced loss numerator, so every rank skips the same steps.
+  if (skipped && loss_num && !isfinite(loss_num[0] * sc)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1u;
+    return;
+  }
   if (lr_dev) lr = lr_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float w = p[i];
@@ -4254,6 +4264,15 @@ int spgnn_masked_ce_step(const float* logits, int64_t logits_stride, const int64
                           g_logits, g_stride, colsum_partials, g_colsum, N, C, nullptr, nullptr, stream);
 }
 
+int spgnn_masked_ce_step_flagged(const float* logits, int64_t logits_stride, const int64_t* labels, const float* draws, uint64_t draw_seed,
+                                 const int64_t* seed_offset, const float* sampling_p, const int32_t* rows_cnt, const float* class_weight,
+                                 float* partials, float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride,
+                                 float* colsum_partials, float* g_colsum, int64_t N, int32_t C, spgnn_stream_t stream) {
+  if (!sampling_p || !rows_cnt) return fail(SPGNN_ERR_NULLPTR, "spgnn_masked_ce_step_flagged: null pointer");
+  return masked_ce_launch(logits, logits_stride, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, partials, sums, ticket,
+                          g_logits, g_stride, colsum_partials, g_colsum, N, C, nullptr, rows_cnt, stream);
+}
+
 int spgnn_masked_ce_rows(const float* logits, int64_t logits_stride, const int64_t* labels, const int32_t* rows, const int32_t* rows_cnt,
                          const float* class_weight, float* partials, float* sums, uint32_t* ticket, float* g_logits, int64_t g_stride,
                          float* colsum_partials, float* g_colsum, int64_t cap, int32_t C, spgnn_stream_t stream) {
@@ -4330,7 +4349,7 @@ int spgnn_block_relabel(const int32_t* flag, const int32_t* rank, int32_t* local
 
 static int sgd_launch(float* param, const float* grad, float* momentum_buf, const float* grad_scale, const float* grad_denom,
                       const float* loss_num, float* loss_out, const float* lr_dev, int64_t n, float lr, float momentum,
-                      float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+                      float weight_decay, int32_t first_step, spgnn_stream_t stream, uint32_t* skipped = nullptr) {
   if (n < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_sgd_momentum_step: n < 0");
   if (n == 0 && !loss_out) return SPGNN_OK;
   if (!param || !grad || !momentum_buf || (loss_out && !loss_num)) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step: null pointer");
@@ -4338,7 +4357,7 @@ static int sgd_launch(float* param, const float* grad, float* momentum_buf, cons
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, param, grad,
-                     momentum_buf, grad_scale, grad_denom, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay, first_step);
+                     momentum_buf, grad_scale, grad_denom, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay, first_step, skipped);
   return check_launch("spgnn_sgd_momentum_step");
 }
 
@@ -4355,6 +4374,14 @@ int spgnn_sgd_momentum_step_mean(float* param, const float* grad, float* momentu
   if (!weight_sum) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step_mean: null pointer");
   return sgd_launch(param, grad, momentum_buf, nullptr, weight_sum, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay,
                     first_step, stream);
+}
+
+int spgnn_sgd_momentum_step_guarded(float* param, const float* grad, float* momentum_buf, const float* weight_sum,
+                                    const float* loss_num, float* loss_out, const float* lr_dev, uint32_t* skipped_steps, int64_t n,
+                                    float lr, float momentum, float weight_decay, int32_t first_step, spgnn_stream_t stream) {
+  if (!weight_sum || !loss_num || !skipped_steps) return fail(SPGNN_ERR_NULLPTR, "spgnn_sgd_momentum_step_guarded: null pointer");
+  return sgd_launch(param, grad, momentum_buf, nullptr, weight_sum, loss_num, loss_out, lr_dev, n, lr, momentum, weight_decay,
+                    first_step, stream, skipped_steps);
 }
 
 int spgnn_step_begin(int64_t* counter, float* scale_blocks, int32_t n_scale_blocks, uint32_t* range_violations, spgnn_stream_t stream) {

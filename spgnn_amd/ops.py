@@ -905,6 +905,7 @@ class _MaskedCE(torch.autograd.Function):
         opts, _MaskedCE._opts = (_MaskedCE._opts or {}), None
         out, seed, unit = opts.get("out"), opts.get("draw_seed", 0), bool(opts.get("unit_grad"))
         rows = opts.get("rows")                 # LossRows: ``logits`` holds one row per LISTED node
+        flag = opts.get("flag")                 # (2,) int32 [count, overflow]: a dense pass that turns NaN when the step's list overflowed
         N, C = logits.shape
         if logits.stride(1) != 1:
             logits = logits.contiguous()
@@ -927,6 +928,13 @@ class _MaskedCE(torch.autograd.Function):
                                                               rows.cnt.data_ptr(), class_weight.data_ptr(), part.data_ptr(), s.data_ptr(),
                                                               ticket.data_ptr(), _ptr(g), C, _ptr(colpart), _ptr(colsum), N, C,
                                                               _stream(logits)), "spgnn_masked_ce_rows")
+            elif flag is not None:
+                _capi.check(_capi.load().spgnn_masked_ce_step_flagged(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws),
+                                                                      int(seed) & 0xFFFFFFFFFFFFFFFF, _seed_off_ptr(dev) if draws is None else 0,
+                                                                      sampling_p.data_ptr(), flag.data_ptr(), class_weight.data_ptr(),
+                                                                      part.data_ptr(), s.data_ptr(), ticket.data_ptr(), _ptr(g), C,
+                                                                      _ptr(colpart), _ptr(colsum), N, C, _stream(logits)),
+                            "spgnn_masked_ce_step_flagged")
             else:
               _capi.check(_capi.load().spgnn_masked_ce_step(logits.data_ptr(), logits.stride(0), labels.data_ptr(), _ptr(draws), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                           _seed_off_ptr(dev) if draws is None else 0, sampling_p.data_ptr(),
@@ -1061,16 +1069,17 @@ def take_loss_rows(x: torch.Tensor, has_classifier: bool) -> torch.Tensor:
 
 def masked_ce_sums(logits: torch.Tensor, labels: torch.Tensor, draws: Optional[torch.Tensor], sampling_p: torch.Tensor,
                    class_weight: torch.Tensor, out: Optional[torch.Tensor] = None, draw_seed: int = 0, unit_grad: bool = False,
-                   rows: Optional["LossRows"] = None):
+                   rows: Optional["LossRows"] = None, flag: Optional[torch.Tensor] = None):
     """-> (sum_i m_i w[y_i] nll_i, sum_i m_i w[y_i]), m = draws < sampling_p (reference job_runner.py:1896-1900).
     ``out`` (2,) fp32, optional: where the two sums are to be written (train.FlatBucket's tail slots).  ``draws`` None: the
     kernel draws rn_i itself from its counter hash of (``draw_seed``, the step counter installed as DROPOUT_SEED_OFFSET, i).
     ``unit_grad``: the caller promises to back-propagate the numerator with gradient exactly 1 (``num.backward()``), so the
     stored gradient is handed on without the multiplication.  ``rows`` (:class:`LossRows`, made from the same draws):
-    ``logits`` has one row per listed node instead of one per node - the same two sums up to summation order."""
+    ``logits`` has one row per listed node instead of one per node - the same two sums up to summation order.  ``flag`` (a
+    LossRows.cnt tensor, without ``rows``): the dense pass, NaN when the list of this step overflowed."""
     _require_cuda(logits, labels, draws, sampling_p, class_weight)
     assert labels.dtype == torch.int64 and logits.dtype == torch.float32
-    _MaskedCE._opts = {"out": out, "draw_seed": int(draw_seed), "unit_grad": unit_grad, "rows": rows}
+    _MaskedCE._opts = {"out": out, "draw_seed": int(draw_seed), "unit_grad": unit_grad, "rows": rows, "flag": flag}
     return _MaskedCE.apply(logits, labels.contiguous(), None if draws is None else draws.contiguous(), sampling_p.contiguous(),
                            class_weight.contiguous())
 
@@ -3097,7 +3106,7 @@ def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tenso
                        weight_decay: float = 0.0, first_step: bool = False,
                        grad_scale: Optional[torch.Tensor] = None, lr_dev: Optional[torch.Tensor] = None,
                        weight_sum: Optional[torch.Tensor] = None, loss_num: Optional[torch.Tensor] = None,
-                       loss_out: Optional[torch.Tensor] = None) -> None:
+                       loss_out: Optional[torch.Tensor] = None, skipped: Optional[torch.Tensor] = None) -> None:
     """``lr_dev`` (device scalar) overrides ``lr`` at run time (learning-rate schedules under graph replay).  ``weight_sum``
     (device scalar) instead of ``grad_scale``: the gradient is divided by it in the kernel, and with ``loss_num`` /
     ``loss_out`` the same launch writes loss_out[0] = loss_num[0] / weight_sum[0] (spgnn_sgd_momentum_step_mean)."""
@@ -3107,6 +3116,13 @@ def sgd_momentum_step_(param: torch.Tensor, grad: torch.Tensor, buf: torch.Tenso
     lib = _capi.load()
     if weight_sum is not None:
         assert grad_scale is None and (loss_out is None or loss_num is not None)
+        if skipped is not None:         # (1,) int32 counter: a step with a non-finite loss is not applied (spgnn_sgd_momentum_step_guarded)
+            with torch.cuda.device(param.device):
+                _capi.check(lib.spgnn_sgd_momentum_step_guarded(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), weight_sum.data_ptr(),
+                                                                loss_num.data_ptr(), _ptr(loss_out), _ptr(lr_dev), skipped.data_ptr(),
+                                                                param.numel(), lr, momentum, weight_decay, int(first_step),
+                                                                _stream(param)), "spgnn_sgd_momentum_step_guarded")
+            return
         with torch.cuda.device(param.device):
             _capi.check(lib.spgnn_sgd_momentum_step_mean(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), weight_sum.data_ptr(),
                                                          _ptr(loss_num), _ptr(loss_out), _ptr(lr_dev), param.numel(), lr, momentum,

@@ -181,35 +181,51 @@ class TrainStep:
             raise ValueError('loss_rows_only must be False, True or "backward"')
         self.loss_rows_only = loss_rows_only
         self._rows_cnt = None                       # (2,) int32 on the device: [rows kept by the last step, capacity-overflow flag]
+        self._skipped = None                        # (1,) int32 on the device: steps the guarded SGD kernel did not apply (non-finite loss)
+        self._rows_headroom, self._rows_gen = 1.0, 0    # capacity factor / generation of the per-graph capacity caches
 
     def _loss_rows_cap(self, g, p: torch.Tensor) -> int:
         """Capacity of the step's row list on ``g``: the kept count is (labelled nodes) + Binomial(others, rate) - mean plus
         eight standard deviations (about 1e-15 per step), 15 % on top when other batches will be loaded into the same buffers
         (a batch arena), rounded up to 256-row tiles.  0: the list would not be shorter than 0.8 N - the step runs dense.
         One host read per graph, cached on it.  A draw beyond the capacity cannot be repaired inside a captured step: the
-        list kernel raises a flag and the loss is NaN; :meth:`check_loss_rows` (called by run_batch / run_batches once per
-        loader batch) turns the flag into an error."""
+        list kernel raises a flag, the loss of that step is NaN and the guarded optimizer kernel does not apply it
+        (spgnn_sgd_momentum_step_guarded: parameters and momentum stay); :meth:`check_loss_rows` (called by run_batch /
+        run_batches once per loader batch) then enlarges the capacities and drops the captures made with the old ones."""
         store = g.__dict__.setdefault("_loss_rows_cap", {})
-        cap = store.get(self.sampling_rate)
+        key = (self.sampling_rate, self._rows_gen)
+        cap = store.get(key)
         if cap is None:
             pc = p.clamp(min=0.0).double()
             mu, var = float(pc.sum()), float((pc * (1.0 - pc)).sum())
-            if getattr(g, "_stable_storage", False):
-                mu *= 1.15
+            mu *= self._rows_headroom * (1.15 if getattr(g, "_stable_storage", False) else 1.0)
             want = mu + 8.0 * var ** 0.5 + 32.0
             cap = int(-(-want // 256) * 256)
             n = p.shape[0]
             cap = 0 if cap > 0.8 * n else cap
-            store[self.sampling_rate] = cap
+            store[key] = cap
         return cap
 
-    def check_loss_rows(self) -> None:
-        """Raise if a step's mask kept more rows than its list could hold (one host read)."""
-        if self._rows_cnt is not None and int(self._rows_cnt[1].item()) != 0:
-            self._rows_cnt[1].zero_()
-            raise RuntimeError("loss_rows_only: a step's mask kept more rows than the row list's capacity (the loss of that step is "
-                               "NaN and its update is lost); the labelled share of this batch is far above the one the capacity was "
-                               "sized on - run this loader batch with loss_rows_only=False")
+    def check_loss_rows(self) -> int:
+        """One host read: did a step's mask keep more rows than its list could hold since the last check?  Such a step had a
+        NaN loss and was not applied (the guarded optimizer kernel).  Then: every capacity grows by half (recomputed per graph on
+        its next step), the captures recorded with the old capacities are dropped, a warning names the lost steps.
+        -> the number of steps skipped so far."""
+        if self._rows_cnt is None:
+            return 0
+        skipped = int(self._skipped.item()) if self._skipped is not None else 0
+        if int(self._rows_cnt[1].item()) == 0:
+            return skipped
+        import warnings
+        self._rows_cnt[1].zero_()
+        self._rows_headroom *= 1.5
+        self._rows_gen += 1
+        self._captures.clear()
+        self._graph = self._graph_back = self._captured_graph = None
+        warnings.warn(f"loss_rows_only: a step's mask kept more rows than its row list could hold; {skipped} step(s) so far had a NaN "
+                      f"loss and were not applied.  The lists now get {self._rows_headroom:.2f} x the headroom; captured steps are "
+                      "recorded again.", RuntimeWarning)
+        return skipped
 
     def _sampling(self, g):
         """Per-node sampling probabilities of ``g``'s labels, kept ON THE GRAPH (a captured step addresses the tensor; one
@@ -302,7 +318,8 @@ class TrainStep:
             direct = logits.is_cuda
             if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
                 nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot, draw_seed=draw_seed,
-                                        unit_grad=True, rows=rows if (rows is not None and rows.forward) else None)   # land in the bucket's tail
+                                        unit_grad=True, rows=rows if (rows is not None and rows.forward) else None,
+                                        flag=self._rows_cnt if (rows is not None and not rows.forward) else None)   # land in the bucket's tail
                 num, den = nd[0], nd[1]
                 if self._one is None or self._one.device != num.device:
                     self._one = torch.ones((), dtype=torch.float32, device=num.device)
@@ -355,9 +372,11 @@ class TrainStep:
             n = b.numel
             if self._loss_out is None:
                 self._loss_out = torch.zeros((1,), dtype=torch.float32, device=b.flat_param.device)
+            if self.loss_rows_only and self._skipped is None:
+                self._skipped = torch.zeros((1,), dtype=torch.int32, device=b.flat_param.device)
             ops.sgd_momentum_step_(b.flat_param[:n], b.flat_grad[:n], b.flat_mom[:n], self.lr, self.momentum, self.weight_decay,
                                    first_step=(b.steps == 0), lr_dev=self._lr_dev, weight_sum=b.wsum_slot, loss_num=b.loss_slot,
-                                   loss_out=self._loss_out)
+                                   loss_out=self._loss_out, skipped=self._skipped if self.loss_rows_only else None)
             b.steps += 1
             return self._loss_out.reshape(())
         inv = torch.reciprocal(b.wsum_slot)

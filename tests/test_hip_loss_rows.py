@@ -181,22 +181,33 @@ def test_loss_rows_step_matches_the_oracle_at_64_trees(mode):
     print(f"loss-rows step ({mode}), 64 trees: loss {rel_err(num / den, ref_loss):.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")
 
 
-def test_backward_only_list_overflow_poisons_the_gradients():
-    """The dense loss of a "backward" step cannot show a truncated list: the gradient pass does (NaN), and check_loss_rows
-    raises."""
+@pytest.mark.parametrize("mode", [True, "backward"])
+def test_list_overflow_loses_the_step_not_the_parameters(mode):
+    """A draw beyond the list's capacity: the step's loss is NaN (the dense loss of a "backward" step included), the guarded
+    optimizer kernel does not apply it - parameters and momentum as before - and check_loss_rows() warns, enlarges the
+    capacities and lets training go on."""
     cfg, model = _model("st_pgat_spgnn_3", 2)
     model.eval()
     w = class_weight_list(cfg.CLASS_WEIGHTS)
     g = synthetic.make_batch(6, rank=2, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
-    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only="backward")
-    g.__dict__["_loss_rows_cap"] = {cfg.SAMPLING_RATE: 512}               # (forced: the ~27 % of ~900 nodes fit)
-    ts.step(g)                                                             # a good step first (it also passes the first-step check)
-    assert bool(torch.isfinite(ts.bucket.flat_grad[:ts.bucket.numel]).all())
-    ts._sampling(g).fill_(1.0)                                             # every node kept: 900 rows into 512 slots
-    ts.step(g)
-    assert not bool(torch.isfinite(ts.bucket.flat_grad[:ts.bucket.numel]).all())
-    with pytest.raises(RuntimeError, match="capacity"):
-        ts.check_loss_rows()
+    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=mode)
+    g.__dict__["_loss_rows_cap"] = {(cfg.SAMPLING_RATE, 0): 512}          # (forced: the ~27 % of ~900 nodes fit)
+    l0 = ts.step(g)                                                        # a good step first (it also passes the first-step check)
+    assert bool(torch.isfinite(l0)) and ts.check_loss_rows() == 0
+    n = ts.bucket.numel
+    before, mom = ts.bucket.flat_param[:n].clone(), ts.bucket.flat_mom[:n].clone()
+    p = ts._sampling(g)
+    keep = p.clone()
+    p.fill_(1.0)                                                           # every node kept: 900 rows into 512 slots
+    l1 = ts.step(g)
+    assert bool(torch.isnan(l1))
+    assert torch.equal(ts.bucket.flat_param[:n], before) and torch.equal(ts.bucket.flat_mom[:n], mom)
+    with pytest.warns(RuntimeWarning, match="row list"):
+        assert ts.check_loss_rows() == 1
+    assert ts.check_loss_rows() == 1 and int(ts._rows_cnt[1]) == 0         # flag cleared, the counter stays
+    p.copy_(keep)
+    l2 = ts.step(g)                                                        # capacities recomputed (1.5 x the headroom): training goes on
+    assert bool(torch.isfinite(l2)) and not torch.equal(ts.bucket.flat_param[:n], before)
 
 
 def test_list_aware_traversals_equal_the_expanded_copy(monkeypatch):

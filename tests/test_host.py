@@ -507,7 +507,7 @@ def test_loss_rows_capacity_rule():
 
     from spgnn_amd.train import TrainStep
     ts = TrainStep.__new__(TrainStep)
-    ts.sampling_rate = 0.15
+    ts.sampling_rate, ts._rows_headroom, ts._rows_gen = 0.15, 1.0, 0
     big = types.SimpleNamespace()
     p = torch.full((76410,), 0.15)
     p[::7] = 1.0                                                   # ~14 % labelled
@@ -523,3 +523,5 @@ def test_loss_rows_capacity_rule():
     assert ts._loss_rows_cap(small, torch.full((150,), 0.15)) == 0   # 256 slots for 150 nodes: no gain, run dense
     dense = types.SimpleNamespace()
     assert ts._loss_rows_cap(dense, torch.ones(50000)) == 0        # every node labelled: the list would be the node set
+    ts._rows_headroom, ts._rows_gen = 1.5, 1                       # after an overflow (check_loss_rows): recomputed, with more room
+    assert ts._loss_rows_cap(big, p) > 1.3 * cap
