@@ -319,3 +319,60 @@ def test_loss_rows_steps_repeat_bit_for_bit(mode):
             ts.step(g)
         ends.append(ts.bucket.flat_param[:ts.bucket.numel].clone())
     assert torch.equal(ends[0], ends[1])
+
+
+def _dp_rows_worker(rank, world, port, ret):
+    import os
+    import warnings
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_config("st_pgat_spgnn_3")
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    out = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        model = models.build_model(cfg.MODEL).cuda()
+        model.init(None); model.set_gcn_only(); model.eval()
+        g = synthetic.make_batch(6 + rank, rank=rank, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)       # other trees, other counts per rank
+        ts = TrainStep(model, w, cfg.SAMPLING_RATE, 0.02, 0.9, seed=5, loss_rows_only=mode)
+        losses = [float(ts.step(g)) for _ in range(3)]
+        n = ts.bucket.numel
+        params = ts.bucket.flat_param[:n].detach().cpu().clone()
+        extra = None
+        if mode:
+            if rank == 1:                                            # the list overflows on ONE rank only
+                ts._sampling(g).fill_(1.0)
+                g.__dict__["_loss_rows_cap"][(cfg.SAMPLING_RATE, 0)] = 256
+            lost = float(ts.step(g))
+            same = torch.equal(ts.bucket.flat_param[:n].detach().cpu(), params)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                skipped = ts.check_loss_rows()
+            extra = (lost, same, skipped, len(caught))
+        out[mode] = (losses, params, extra)
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_two_ranks_loss_rows_equal_dense_and_skip_an_overflowed_step_together():
+    """world_size 2 (two processes on the one GPU, gloo carrying the tensors): each rank lists its own rows, the bucket's
+    all-reduce is the dense step's; losses and parameters equal the dense 2-rank run.  Then the list overflows on rank 1 only:
+    the all-reduced loss is NaN on BOTH ranks, the guarded optimizer kernel skips the step on both - the replicas stay identical -
+    and only rank 1 has a flag to clear."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_rows_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ld, pd, _ = ret[r][False]
+        lr_, pr, extra = ret[r][True]
+        assert np.allclose(ld, lr_, rtol=2e-6), (ld, lr_)
+        assert rel_err(pr, pd) < 5e-6
+        lost, same, skipped, warned = extra
+        assert np.isnan(lost) and same and skipped == 1
+        assert warned == (1 if r == 1 else 0)
+    assert torch.equal(ret[0][True][1], ret[1][True][1])              # replicas identical
