@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 58
+#define SPGNN_ABI_VERSION 60
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -1140,6 +1140,24 @@ int spgnn_lspe_bwd_src(const int32_t* out_indptr, const int32_t* out_nbr8, const
  *   2. the caller forms the exclusive prefix sums row_start / col_start (N + 1 entries, int64) and E = row_start[N] + N;
  *   3. spgnn_build_csc fills src / dst (E), indptr / out_indptr (N + 1), indices / eid / out_indices / out_pos (E).
  * ================================================================================================= */
+/*
+ * A batch arena's index arrays in one launch (spgnn_amd/arena.py: a loader batch or an inference scan copied into fixed
+ * buffers and padded to its size class): per job dst[i] = src[i], i < n; dst[n + i] = pad[i] + pad_add, i < n_pad.
+ */
+#define SPGNN_COPY_PAD_MAX_JOBS 8
+typedef struct spgnn_copy_pad_job {
+  int32_t* dst; const int32_t* src; const int32_t* pad;
+  int32_t n, n_pad, pad_add, reserved;
+} spgnn_copy_pad_job;
+typedef struct spgnn_copy_pad_jobs { spgnn_copy_pad_job job[SPGNN_COPY_PAD_MAX_JOBS]; int32_t n_jobs; } spgnn_copy_pad_jobs;
+int spgnn_copy_pad_i32(const spgnn_copy_pad_jobs* jobs, spgnn_stream_t stream);
+/*
+ * The padded neighbour rows the row kernels read next to indptr (`nbr8` / `out_nbr8` / `out_pos8`, N x 8 int32):
+ * out[v, k] = arr[min(ptr[v] + min(k, max(deg(v) - 1, 0)), E - 1)] for one or two arrays in the slot order of `ptr`.
+ * One launch per call (the torch formulation was a dozen small launches per loader batch / per inference scan).
+ */
+int spgnn_ell_rows(const int32_t* ptr, const int32_t* a0, const int32_t* a1 /* nullable */, int64_t N, int64_t E, int32_t* out0,
+                   int32_t* out1 /* nullable with a1 */, spgnn_stream_t stream);
 int spgnn_build_csc_count(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,
                           int32_t* row_count, int32_t* col_count, spgnn_stream_t stream);
 int spgnn_build_csc(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 58
+ABI_VERSION = 60
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -57,6 +57,14 @@ class LspeBwdSrcGroup(C.Structure):       # spgnn_lspe_bwd_src_group
                 ("p_drop", _f32), ("seed", _u64)]
 
 
+class CopyPadJob(C.Structure):           # spgnn_copy_pad_job
+    _fields_ = [("dst", _vp), ("src", _vp), ("pad", _vp), ("n", _i32), ("n_pad", _i32), ("pad_add", _i32), ("reserved", _i32)]
+
+
+class CopyPadJobs(C.Structure):          # spgnn_copy_pad_jobs
+    _fields_ = [("job", CopyPadJob * 8), ("n_jobs", _i32)]
+
+
 class SumJob(C.Structure):               # spgnn_sum_job
     _fields_ = [("kind", _i32), ("splits", _i32), ("partials", _vp), ("split_stride", _i64), ("out", _vp), ("out_stride", _i64),
                 ("n", _i64), ("H", _i32), ("D", _i32), ("ld", _i32), ("M", _i32), ("N", _i32), ("split_col", _i32), ("ld_in", _i64),
@@ -95,6 +103,8 @@ SIGNATURES = {
     "spgnn_weight_prep_blocks": [_i32, _i64, _i64],
     "spgnn_weight_prep": [_vp, _i32, _i64, _vp, _vp],
     "spgnn_build_csc_count": [_vp, _vp, _vp, _i64, _i32p, _i32p, _vp],
+    "spgnn_ell_rows": [_i32p, _i32p, _vp, _i64, _i64, _i32p, _vp, _vp],
+    "spgnn_copy_pad_i32": [_vp, _vp],
     "spgnn_build_csc": [_vp, _vp, _vp, _i64, _vp, _vp, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i64, _i64, _vp],
     "spgnn_lspe_supported": [_i32],
     "spgnn_lspe_fwd": [_i32p, _i32p, C.POINTER(LspeFwdGroup), _f32p, _i64, _f32, _u64, _f32p, _i64, _f32, _u64, _f32p, _f32p, _i64, _i64,

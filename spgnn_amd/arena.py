@@ -101,6 +101,7 @@ class BatchArena:
         t = dict(indptr=i32(self.n_cap + 1), indices=i32(self.e_cap), eid=i32(self.e_cap), out_indptr=i32(self.n_cap + 1),
                  out_indices=i32(self.e_cap), out_pos=i32(self.e_cap))
         self.src, self.dst = i32(self.e_cap), i32(self.e_cap)
+        self.keep_edges = True          # False (infer.ForwardRunner): load() skips the edge-id-order copy of the edge list
         csc = G.DeviceCSC.from_tensors(t, self.n_cap, self.e_cap)
         csc._fixed_tile_count = True             # DeviceCSC.tiles: the launch grids cover the fixed-length tile table (see _refresh)
         g = self.graph = G.TreeGraph.from_device(self.src, self.dst, self.n_cap, csc, [self.n_cap], [self.e_cap])
@@ -144,17 +145,33 @@ class BatchArena:
         m = (self.e_cap - E - n_pad) // 2
         pieces = _pad_pieces(n_pad, m, dev)                                 # the pad's index arrays on the device (cached per shape)
         with torch.no_grad():
-            for k in ("indptr", "out_indptr"):                              # slot offsets: real edges fill slots [0, E)
-                dst = getattr(acsc, k)
-                dst[:N + 1].copy_(getattr(csc, k))
-                torch.add(pieces[k][1:], E, out=dst[N + 1:])
-            for k, shift in (("indices", N), ("out_indices", N), ("eid", E), ("out_pos", E)):
-                dst = getattr(acsc, k)
-                dst[:E].copy_(getattr(csc, k))
-                torch.add(pieces[k], shift, out=dst[E:])
-            s_, d_ = g.edges()
-            self.src[:E].copy_(s_); self.dst[:E].copy_(d_)
-            torch.add(pieces["src"], N, out=self.src[E:]); torch.add(pieces["dst"], N, out=self.dst[E:])
+            # the six index arrays in ONE launch (spgnn_copy_pad_i32): the batch's array, then the pad component's shifted by the
+            # batch's edge / node count (slot offsets: real edges fill slots [0, E), pad nodes follow the real ones)
+            import ctypes
+            from . import _capi
+            jobs = _capi.CopyPadJobs()
+            q = 0
+            for k, n_real, shift, skip in (("indptr", N + 1, E, 1), ("out_indptr", N + 1, E, 1), ("indices", E, N, 0),
+                                           ("out_indices", E, N, 0), ("eid", E, E, 0), ("out_pos", E, E, 0)):
+                dst, src_, pad = getattr(acsc, k), getattr(csc, k), pieces[k]
+                if src_.dtype != torch.int32 or not src_.is_contiguous():
+                    src_ = src_.to(torch.int32).contiguous()
+                n_tail = dst.shape[0] - n_real                             # the pad component's share of this array
+                assert pad.dtype == torch.int32 and pad.shape[0] - skip == n_tail and src_.shape[0] == n_real and dst.dtype == torch.int32
+                jobs.job[q] = _capi.CopyPadJob(dst.data_ptr(), src_.data_ptr(), pad.data_ptr() + 4 * skip, n_real, n_tail, shift, 0)
+                q += 1
+            jobs.n_jobs = q
+            with torch.cuda.device(dev):
+                _capi.check(_capi.load().spgnn_copy_pad_i32(ctypes.addressof(jobs), torch.cuda.current_stream(dev).cuda_stream),
+                            "spgnn_copy_pad_i32")
+            if self.keep_edges:                                             # src / dst in edge-id order (graph.edges(); no kernel reads them)
+                ed = getattr(g, "_edges_dev", None)
+                s_, d_ = ed if (ed is not None and ed[0].device == self.src.device) else g.edges()
+                self.src[:E].copy_(s_); self.dst[:E].copy_(d_)
+                torch.add(pieces["src"], N, out=self.src[E:]); torch.add(pieces["dst"], N, out=self.dst[E:])
+                ag._edges_dev = (self.src, self.dst)
+            else:
+                ag._edges_dev = None                                        # asking for them raises (graph._host_edges)
             seen = set()
             for k, v in g.ndata.items():
                 buf = ag.ndata[k]

@@ -109,9 +109,62 @@ __global__ __launch_bounds__(kThreads) void build_csc_fill_kernel(const uint8_t*
   }
 }
 
+// The padded neighbour rows of DeviceCSC.ell (spgnn_amd/graph.py): out[v, k] = arr[min(ptr[v] + min(k, max(deg(v) - 1, 0)), E - 1)],
+// k < 8, for up to two arrays over the same slot order (indices; or out_indices and out_pos).  One thread per (node, k).
+__global__ __launch_bounds__(256) void ell_rows_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ a0,
+                                                       const int32_t* __restrict__ a1, int64_t N, int64_t E,
+                                                       int32_t* __restrict__ o0, int32_t* __restrict__ o1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * 8) return;
+  const int64_t v = i >> 3;
+  const int k = (int)(i & 7);
+  const int beg = ptr[v], deg = ptr[v + 1] - beg;
+  int64_t pos = (int64_t)beg + (k < deg - 1 ? k : (deg > 0 ? deg - 1 : 0));
+  pos = pos < E - 1 ? pos : E - 1;
+  o0[i] = a0[pos];
+  if (a1) o1[i] = a1[pos];
+}
+
+// Several int32 arrays filled in one launch: dst[i] = src[i] for i < n, then dst[n + i] = pad[i] + pad_add for i < n_pad (a batch
+// arena's index arrays: the loaded batch's array, then the pad component's shifted by the batch's node / edge count).
+__global__ __launch_bounds__(256) void copy_pad_i32_kernel(spgnn_copy_pad_jobs jobs) {
+  const spgnn_copy_pad_job& j = jobs.job[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)j.n + j.n_pad; i += (int64_t)gridDim.x * 256)
+    j.dst[i] = i < j.n ? j.src[i] : j.pad[i - j.n] + j.pad_add;
+}
+
 }  // namespace
 
 extern "C" {
+
+int spgnn_copy_pad_i32(const spgnn_copy_pad_jobs* jobs, spgnn_stream_t stream) {
+  if (!jobs) return fail(SPGNN_ERR_NULLPTR, "spgnn_copy_pad_i32: null pointer");
+  if (jobs->n_jobs < 0 || jobs->n_jobs > SPGNN_COPY_PAD_MAX_JOBS) return fail(SPGNN_ERR_SHAPE, "spgnn_copy_pad_i32: bad job count");
+  if (jobs->n_jobs == 0) return SPGNN_OK;
+  int64_t longest = 0;
+  for (int q = 0; q < jobs->n_jobs; ++q) {
+    const spgnn_copy_pad_job& j = jobs->job[q];
+    if (j.n < 0 || j.n_pad < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_copy_pad_i32: negative length");
+    if (!j.dst || (j.n > 0 && !j.src) || (j.n_pad > 0 && !j.pad)) return fail(SPGNN_ERR_NULLPTR, "spgnn_copy_pad_i32: null pointer");
+    longest = longest > (int64_t)j.n + j.n_pad ? longest : (int64_t)j.n + j.n_pad;
+  }
+  if (longest == 0) return SPGNN_OK;
+  int64_t bx = (longest + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(copy_pad_i32_kernel, dim3((unsigned)bx, (unsigned)jobs->n_jobs), dim3(256), 0, (hipStream_t)stream, *jobs);
+  return check_launch("spgnn_copy_pad_i32");
+}
+
+int spgnn_ell_rows(const int32_t* ptr, const int32_t* a0, const int32_t* a1, int64_t N, int64_t E, int32_t* out0, int32_t* out1,
+                   spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || N > (1ll << 27)) return fail(SPGNN_ERR_SHAPE, "spgnn_ell_rows: bad N / E");
+  if (N == 0) return SPGNN_OK;
+  if (E == 0) return fail(SPGNN_ERR_SHAPE, "spgnn_ell_rows: a graph without edges has no neighbour rows (the caller writes zeros)");
+  if (!ptr || !a0 || !out0 || (a1 && !out1)) return fail(SPGNN_ERR_NULLPTR, "spgnn_ell_rows: null pointer");
+  hipLaunchKernelGGL(ell_rows_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ptr, a0, a1, N, E, out0,
+                     out1);
+  return check_launch("spgnn_ell_rows");
+}
 
 int spgnn_build_csc_count(const uint8_t* adj, const int64_t* adj_ptr, const int64_t* tree_ptr, int64_t num_trees,
                           int32_t* row_count, int32_t* col_count, spgnn_stream_t stream) {

@@ -143,7 +143,17 @@ class DeviceCSC:
             def rows(ptr, *arrays):
                 if self.num_nodes == 0 or self.num_edges == 0:
                     return tuple(torch.zeros((self.num_nodes, 8), dtype=torch.int32, device=ptr.device) for _ in arrays)
-                deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
+                if ptr.is_cuda and all(a.dtype == torch.int32 and a.is_contiguous() for a in (ptr,) + arrays):
+                    from . import _capi                                  # one launch (spgnn_ell_rows)
+                    outs = tuple(torch.empty((self.num_nodes, 8), dtype=torch.int32, device=ptr.device) for _ in arrays)
+                    with torch.cuda.device(ptr.device):
+                        _capi.check(_capi.load().spgnn_ell_rows(ptr.data_ptr(), arrays[0].data_ptr(),
+                                                                arrays[1].data_ptr() if len(arrays) > 1 else 0, self.num_nodes,
+                                                                self.num_edges, outs[0].data_ptr(),
+                                                                outs[1].data_ptr() if len(arrays) > 1 else 0,
+                                                                torch.cuda.current_stream(ptr.device).cuda_stream), "spgnn_ell_rows")
+                    return outs
+                deg = (ptr[1:] - ptr[:-1]).to(torch.int64)         # (host graphs: the same rows by torch indexing)
                 k = torch.arange(8, device=ptr.device, dtype=torch.int64)
                 pos = ptr[:-1].to(torch.int64)[:, None] + torch.minimum(k[None, :], (deg - 1).clamp(min=0)[:, None])
                 pos.clamp_(max=self.num_edges - 1)
@@ -355,6 +365,9 @@ class TreeGraph:
     # host copies of the edge list: a graph assembled on the device (build_csc_device) downloads them on first use only
     def _host_edges(self):
         if self._src_np is None:
+            if self._edges_dev is None:
+                raise RuntimeError("this graph's edge list was not kept (a per-scan inference arena, BatchArena.keep_edges = False): "
+                                   "its CSC / CSR index arrays are current, src / dst in edge-id order are not")
             s_, d_ = self._edges_dev
             self._src_np, self._dst_np = s_.cpu().numpy().astype(np.int64), d_.cpu().numpy().astype(np.int64)
         return self._src_np, self._dst_np

@@ -86,6 +86,7 @@ class ForwardRunner:
             # scans of this class run their projections on the skinny kernel (fp32, no operand scales, no pre-split images):
             # nothing to refresh per scan beyond the data itself
             arena.refresh_constants = not (ops.SKINNY_GEMM and arena.n_cap <= ops.SKINNY_ROWS)
+            arena.keep_edges = False               # the forward pass reads CSC / CSR only: no src / dst copy per scan
             arena.load(g, key)
             graph, outs, refs = self._capture(arena)
             hit = (arena, graph, outs, refs)

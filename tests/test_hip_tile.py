@@ -168,6 +168,7 @@ def test_arena_rewrites_the_tile_table_in_place():
     ptr, first = t.data_ptr(), t.cpu().numpy().copy()
     assert n_grid == len(first) - 1                                            # the grid covers the whole fixed-length table
     ag = ar.load(b)
+    assert ag.batch_num_nodes_list == list(b.batch_num_nodes_list) + [ar.n_cap - b.number_of_nodes()]     # the pad component last
     t2, n_grid2 = ag.csc("cuda").tiles(192)
     second = t2.cpu().numpy()
     assert t2.data_ptr() == ptr and n_grid2 == n_grid and len(second) == len(first)
