@@ -199,7 +199,7 @@ def _cpu_sample(cfg, model, samples, n_trees, iters, warm, budget_s):
     times = []
     t_start = time.perf_counter()
     for i in range(warm + iters):
-        if len(times) >= min(3, iters) and time.perf_counter() - t_start > budget_s:
+        if len(times) >= min(2, iters) and time.perf_counter() - t_start > budget_s:
             break
         t0 = time.perf_counter()
         out = O.net_forward(cfg.KIND, sd, src, dst, n, g.ndata["fvs"], g.ndata.get("pos_enc"))[0]
@@ -208,21 +208,21 @@ def _cpu_sample(cfg, model, samples, n_trees, iters, warm, budget_s):
         del grads, out, loss
         if i >= warm:
             times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+    import statistics
+    med = statistics.median(times)
     return {"value": E * cfg.CONV_LAYERS / med, "unit": "layer-edges/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_trees} trees of rank 0's batch (N={n}, E={E}), fp32 fwd+bwd, median of {len(times)} "
-                      f"after {warm} warm-up(s) on {cores} threads, {med * 1e3:.1f} ms/iter, DGL-CPU-equivalent (restated) on torch CPU ops",
-            "ms_per_iter": med * 1e3, "nodes": n, "edges": E}
+            "sample": f"{n_trees} trees (N={n}, E={E}) fp32 fwd+bwd, median of {len(times)} after {warm} warm-up, {cores} threads, "
+                      f"{med * 1e3:.0f} ms/iter, restated DGL-CPU",
+            "ms_per_iter": med * 1e3, "nodes": n, "edges": E, "iters": len(times), "warmups": warm}
 
 
-def cpu_baseline(cfg, model, samples, n_trees, small_trees=64):
+def cpu_baseline(cfg, model, samples, n_trees, small_trees=64, small_sample=False):
     """DGL-CPU-equivalent (restated) fwd+bwd on the host cores: oracle/dgl_cpu.py, same weights, eval-mode arithmetic (no
     dropout), fp32, all usable host threads.  The reported sample is the HEADLINE workload itself (all ``n_trees`` trees of
-    rank 0's batch: 3 iterations after 1 warm-up, ~5 s each); the 64-tree sample of earlier rounds (median of 10 after 3
-    warm-ups) rides beside it as ``sample64`` / ``value64``.  Bounded: ~25 + ~10 s of CPU work."""
-    full = _cpu_sample(cfg, model, samples, n_trees, iters=3, warm=1, budget_s=60.0)
-    if n_trees > small_trees:
+    rank 0's batch: 2 iterations after 1 warm-up, ~7 s each: ~20 s of CPU work); ``small_sample`` adds the 64-tree sample
+    of earlier rounds (median of 10 after 3 warm-ups) as ``sample64`` / ``value64``."""
+    full = _cpu_sample(cfg, model, samples, n_trees, iters=2, warm=1, budget_s=40.0)
+    if small_sample and n_trees > small_trees:
         try:
             small = _cpu_sample(cfg, model, samples, small_trees, iters=10, warm=3, budget_s=25.0)
             full["value64"] = small["value"]
@@ -259,13 +259,14 @@ def pct(xs, q):
 
 
 def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=False, no_eager_leg=False, no_dropout=False,
-            no_kernel_timers=False, copy_bw=None, heads=0, loss_rows=False):
+            no_kernel_timers=False, copy_bw=None, heads=0, loss_rows=False, exchange=None):
     """One measured workload: build the model and the batch, warm up, capture, time ``steps`` steps between barrier +
     synchronize, then the instrumented eager leg.  -> (the JSON object on rank 0 else None, (cfg, model, samples))."""
     from spgnn_amd import _capi, models, ops, synthetic
     from spgnn_amd.configs import class_weight_list, get_config
     from spgnn_amd.train import TrainStep
     _capi.load()                                              # fail loudly if the HIP library is missing
+    exchange = world > 1 if exchange is None else bool(exchange)   # ranks exchange gradients (also forced on with ONE rank)
 
     cfg = get_config(config)
     if heads:                                                 # BASELINE.json words config 2 as "8-head"; the reference file has 2
@@ -285,11 +286,11 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     g.csc(dev)                                                # CSC/CSR built once per loader batch (static for all steps)
     N, E = g.number_of_nodes(), g.number_of_edges()
     step = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, cfg.OPTIMIZER["lr"],
-                     cfg.OPTIMIZER["momentum"], seed=1234 + rank, loss_rows_only=loss_rows)
+                     cfg.OPTIMIZER["momentum"], seed=1234 + rank, loss_rows_only=loss_rows, always_exchange=exchange)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -337,7 +338,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     comm_ev = None
-    if world > 1 and launch != "eager":
+    if exchange and launch != "eager":
         # HIP events on the compute stream around the step's one collective (TrainStep._reduce, issued eagerly between the two
         # graphs): what the all-reduce costs inside the replayed step, per step
         comm_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -370,7 +371,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         if comm_ev is not None:
             step._reduce = plain_reduce
     comm = None
-    if world > 1:
+    if exchange:
         ar_ms = sorted(a.elapsed_time(b) for a, b in comm_ev) if comm_ev is not None else []
         backend = dist.get_backend()
         try:
@@ -388,7 +389,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                                   "how": "HIP events on the compute stream around dist.all_reduce inside the timed replays (rank 0)"}
                                  if ar_ms else None)}
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-    kt_dom, eager_leg = {}, None
+    kt_dom, eager_leg, in_step = {}, None, None
     if not no_eager_leg and not no_kernel_timers:
         # a replay cannot carry HIP events per launch: the roofline kernels' launches are bracketed in eagerly issued
         # steps right after the timed region (same kernels, same operands, same stream; only these kernels carry events)
@@ -404,6 +405,18 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         ops.OVERLAP_TN = overlap_tn
         if not kt_all:
             kt_all, probe = dict(kt_dom), n_leg
+        # the same K1-K3 launches as the SHIPPED step runs them: weight-gradient products on the side stream beside them
+        side_on = bool(overlap_tn and N >= ops.OVERLAP_TN_MIN_ROWS)
+        gat_bracket = [k for k in bracket if k[0] in gat_names]
+        if side_on and gat_bracket:
+            ops.KernelTimer.start(only=gat_bracket)
+            for _ in range(n_leg):
+                step.step(g)
+            sync()
+            kt_in_step = ops.KernelTimer.stop()
+            in_step = {"ms_per_step": sum(sum(v) for v in kt_in_step.values()) / n_leg, "steps": n_leg, "side_stream": True}
+        elif gat_bracket:       # no side stream in this configuration: the step runs these launches as the isolated leg does
+            in_step = {"ms_per_step": sum(sum(kt_dom[k]) for k in gat_bracket if k in kt_dom) / n_leg, "steps": n_leg, "side_stream": False}
     loss_val = float(loss)
     if copy_bw is None and rank == 0:
         copy_bw = copy_bandwidth(dev)
@@ -428,9 +441,10 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             "metric": "message-passing edges/sec (fwd+bwd), batched trees", "value": value, "unit": "layer-edges/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"{config}{f' with {heads} heads' if heads else ''} training step (fwd+loss+bwd+allreduce+SGD), {trees} trees/GPU, "
-                                   f"random fan-out trees n~U[120,180], {'bf16 storage / fp32 accumulate' if bf16 else 'fp32'}, "
-                                   f"dropout {'off' if no_dropout else 'on'}" + (", loss rows only behind the last aggregation" + (" (backward pass only)" if loss_rows == "backward" else "") if loss_rows else ""),
+            # <= 118 characters (the driver's record cuts strings at 120)
+            "config": {"workload": f"{config}{f' {heads} heads' if heads else ''} train step fwd+loss+bwd+allreduce+SGD, {trees} trees/GPU n~U[120,180], "
+                                   f"{'bf16 rows' if bf16 else 'fp32'}, dropout {'off' if no_dropout else 'on'}"
+                                   + ((", loss rows (bwd)" if loss_rows == "backward" else ", loss rows") if loss_rows else ""),
                        "trees_per_gpu": trees, "global_trees": trees * world, "nodes": int(N_all),
                        "edges": int(E_all), "conv_layers": L, "trainable_params": n_params,
                        "parallelism": f"dp{world}", "launch": launch, "gemm": gemm_desc,
@@ -542,6 +556,10 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                             "frac_of_survey_roofline": (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (k_ms * 1e-3) if sv_bytes else None,
                             "traffic_GB_per_step": (lambda t: t / 1e9 if t is not None else None)(traffic_of(gat_keys)),
                             "measured_in": where}
+                    if in_step and sv_bytes:
+                        k123["in_step_ms_per_step"] = in_step["ms_per_step"]
+                        k123["in_step_frac_of_survey_roofline"] = (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (in_step["ms_per_step"] * 1e-3)
+                        k123["in_step_side_stream"] = in_step["side_stream"]
                     out["roofline_k123"] = k123
                 out["message_passing"] = {"ms_per_step": mp_ms, "share_of_step": mp_ms / ms,
                                           "algorithmic_GB_per_step": mp_bytes / 1e9,
@@ -561,9 +579,8 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                         r_bytes = sum(algorithmic_bytes(k) * per_step(k)[1] for k in rkeys)
                         ach = r_bytes / (r_ms * 1e-3) / 1e9
                         tr = traffic_of(rkeys)
-                        what = ("spgnn_gat_fwd_bf16 + spgnn_gat_bwd_dst_bf16 + spgnn_gat_bwd_src_bf16 + the output layer's "
-                                "spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16 (all launches of a step)") if bf16 else \
-                               "the SpMM kernels " + " + ".join(sorted({"spgnn_" + k[0] for k in rkeys})) + " (all launches of a step, forward and backward)"
+                        what = "spgnn_gat_{fwd,bwd_dst,bwd_src}_bf16 + spgnn_gat_agg_{fwd,bwd_dst,bwd_src}_bf16: all launches of a step" if bf16 else \
+                               " + ".join(sorted({"spgnn_" + k[0] for k in rkeys})) + ": all launches of a step (fwd + bwd)"
                         out["roofline"] = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                            "frac": ach / HBM_PEAK_GBPS, "traffic": tr, "traffic_source": TRAFFIC_SOURCE if tr is not None else None,
                                            "frac_of_copy_bandwidth": ach / copy_bw["GBps"] if copy_bw else None,
@@ -572,8 +589,7 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                     else:
                         r_fl = sum(gemm_flops(k) * per_step(k)[1] for k in rkeys)
                         ach = r_fl / (r_ms * 1e-3) / 1e12
-                        out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt / spgnn_gemm_nt_pair (all launches of a step: forward projections and "
-                                           "input gradients; a pair = a level's structure + position products in one launch)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
+                        out["roofline"] = {"bound": "mfma", "kernel": "spgnn_gemm_nt(_pair): all launches of a step (forward projections + input gradients)", "achieved": ach, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s",
                                            "frac": ach / MFMA_F16_PEAK, "executed_mfma_frac": 3.0 * ach / MFMA_F16_PEAK,
                                            "frac_of_fp32_matrix_peak": ach / FP32_MATRIX_PEAK, "traffic": traffic_of(rkeys), "traffic_source": TRAFFIC_SOURCE,
                                            "algorithmic_flops_per_step": r_fl, "ms_per_step": r_ms, "launches_per_step": r_n,
@@ -592,6 +608,10 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
                                 "frac": k123["frac_of_survey_roofline"], "own_frac": k123["own_frac_of_hbm_peak"],
                                 "layer_edges_per_s": k123["layer_edges_per_s"],
                                 "traffic": traffic_of(gat_keys), "launches_per_step": sum(per_step(k)[1] for k in gat_keys)}
+                            if in_step:
+                                out["roofline"]["hbm"]["in_step_ms_per_step"] = in_step["ms_per_step"]
+                                out["roofline"]["hbm"]["in_step_frac"] = (sv_bytes / (HBM_PEAK_GBPS * 1e9)) / (in_step["ms_per_step"] * 1e-3)
+                                out["roofline"]["hbm"]["in_step_side_stream"] = in_step["side_stream"]
 
                 # ---- composite roofline (SURVEY.md 8d / BASELINE.md 2): t_graph + max(t_gemm_bytes, t_gemm_flops) -----
                 t_graph = mp_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
@@ -639,10 +659,16 @@ def flatten_for_driver(out):
             r["hbm_traffic"] = h["traffic"]
             r["hbm_layer_edges_per_s"] = h["layer_edges_per_s"]
             r["hbm_launches_per_step"] = h["launches_per_step"]
+            if "in_step_frac" in h:
+                r["hbm_in_step_frac"] = h["in_step_frac"]
+                r["hbm_in_step_ms_per_step"] = h["in_step_ms_per_step"]
     k = out.get("roofline_k123")
     if isinstance(k, dict) and isinstance(r, dict) and "hbm_frac" not in r:
         r["k123_frac_of_survey_roofline"] = k["frac_of_survey_roofline"]
         r["k123_ms_per_step"] = k["ms_per_step"]
+        if "in_step_frac_of_survey_roofline" in k:
+            r["k123_in_step_frac_of_survey_roofline"] = k["in_step_frac_of_survey_roofline"]
+            r["k123_in_step_ms_per_step"] = k["in_step_ms_per_step"]
     c = out["config"]
     for name, key in (("gemm", "ms_per_step"), ("message_passing", "ms_per_step")):
         if isinstance(out.get(name), dict):
@@ -651,6 +677,90 @@ def flatten_for_driver(out):
         c["step_ms_median"] = out["step_ms"]["median"]
     if isinstance(out.get("copy_bandwidth"), dict):
         c["copy_bandwidth_GBps"] = out["copy_bandwidth"]["GBps"]
+
+
+LINE_LIMIT = 12288      # bytes: r04's 19.6 KB line was parsed by the driver, r05's 31.3 KB line was not; stay far below both
+
+
+def _num(x, digits=6):
+    """A scalar for the line: floats to ``digits`` significant digits, NaN / inf -> None (strict JSON), the rest as it is."""
+    if isinstance(x, str):
+        return x[:118]
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return str(x)[:100]
+
+
+def driver_line(out):
+    """The ONE stdout line: the contract's top-level keys + `config`, `roofline`, `cpu_baseline` as FLAT SCALARS only (the
+    driver's record keeps scalar members and cuts strings at 120 characters).  No prose members, no nested legs: the full
+    object (every leg, per-shape tables, notes) goes to bench_detail.json.  Bounded by LINE_LIMIT (tests/test_host.py)."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+           "dtype", "data", "graph_edges_per_s", "loss", "dry_run", "accounting_error")
+    line = {k: _num(out[k], 9) for k in top if k in out}
+    c_in = out.get("config") or {}
+    c = {k: _num(v) for k, v in c_in.items() if not isinstance(v, (dict, list, tuple))}
+    if isinstance(c.get("workload"), str):
+        c["workload"] = c["workload"][:118]
+    if isinstance(c.get("gemm"), str):
+        c["gemm"] = c["gemm"][:80]
+    sm = out.get("step_ms")
+    if isinstance(sm, dict):
+        c["step_ms_median"], c["step_ms_p10"], c["step_ms_p90"] = _num(sm.get("median")), _num(sm.get("p10")), _num(sm.get("p90"))
+    comp = out.get("composite")
+    if isinstance(comp, dict):
+        for k in ("hbm_only_ms", "as_executed_ms", "fp32_matrix_ms", "step_vs_hbm_only", "step_vs_as_executed"):
+            c["composite_" + k] = _num(comp.get(k))
+    mp = out.get("message_passing")
+    if isinstance(mp, dict):
+        c["message_passing_frac_of_hbm_peak"] = _num(mp.get("frac_of_hbm_peak"))
+    if isinstance(out.get("eager"), dict):
+        c["eager_ms_per_step"] = _num(out["eager"].get("ms_per_step"))
+    line["config"] = c
+    r_in = out.get("roofline")
+    if isinstance(r_in, dict):
+        skip = ("traffic_source", "measured_in", "note")
+        r = {k: _num(v) for k, v in r_in.items() if not isinstance(v, (dict, list, tuple)) and k not in skip}
+        if isinstance(r.get("kernel"), str):
+            r["kernel"] = r["kernel"][:118]
+        r["traffic_measured_in_this_run"] = False          # profiles/traffic_latest.json: the builder's rocprofv3 --pmc passes
+        line["roofline"] = r
+    b_in = out.get("cpu_baseline")
+    if isinstance(b_in, dict):
+        b = {k: _num(v) for k, v in b_in.items() if not isinstance(v, (dict, list, tuple)) and k != "sample64"}
+        if isinstance(b.get("sample"), str):
+            b["sample"] = b["sample"][:118]
+        line["cpu_baseline"] = b
+    line["detail"] = out.get("detail_file", "bench_detail.json")
+    txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    if len(txt) > LINE_LIMIT:                               # never outgrow the driver again: shed the optional scalars, longest first
+        for part in ("config", "roofline"):
+            for k in sorted(line.get(part, {}), key=lambda q: -len(q)):
+                if len(txt) <= LINE_LIMIT:
+                    break
+                if k.startswith(("sec_", "composite_", "batch_cycle_", "hbm_own", "comm_library")):
+                    del line[part][k]
+                    txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+    return txt
+
+
+def write_detail(out, path):
+    """The full object of the run (every leg, nested) as a file beside the line; -> the path written, or None."""
+    for cand in (path, os.path.join(ROOT, "bench_detail.json"), os.path.join(os.environ.get("TMPDIR", "/tmp"), "bench_detail.json")):
+        if not cand:
+            continue
+        try:
+            with open(cand, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            return cand
+        except OSError:
+            continue
+    return None
 
 
 def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300, granule=512):
@@ -739,7 +849,7 @@ def batch_cycle(dev, config="st_pgat_spgnn_3", trees=64, n_batches=6, inner=300,
                                       "amortised_over_steady": mean([q["amortised_ms_per_step"] for q in rec]) / steady}}
 
 
-def single_tree_forward(dev, config="st_pgat_spgnn_3", sizes=(150, 300), reps=200):
+def single_tree_forward(dev, config="st_pgat_spgnn_3", sizes=(150, 300), reps=200, count_launches=False):
     """The reference's per-scan inference pattern as a measured quantity (job_runner.py:2046-2052, 1601-1610: one graph per
     scan, dgl.batch([g]), ONE model.forward(g); README.md:49-51 quotes per-scan test times): a single synthetic airway tree
     of n branches, eval mode, forward only, fp32.  Per size: the eagerly issued forward (host-paced: ~40 launches) and the
@@ -795,6 +905,8 @@ def single_tree_forward(dev, config="st_pgat_spgnn_3", sizes=(150, 300), reps=20
             lib_launches = len(ops.KernelTimer.sequence)
             total_launches = None
             try:
+                if not count_launches:          # the default run does not pay for a torch.profiler pass (tools/infer_trace.py counts)
+                    raise RuntimeError("not counted")
                 from torch.profiler import ProfilerActivity, profile
                 with profile(activities=[ProfilerActivity.CUDA]) as prof:
                     model(scans[0])
@@ -848,6 +960,30 @@ def secondary_summary(out):
     return s
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT any torch.cuda / HIP call (the launcher must never bring up the runtime:
+    torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi does not answer): the KFD topology lists every
+    agent, GPUs are the nodes with SIMDs; a *_VISIBLE_DEVICES list narrows it.  None: cannot tell (the ranks will)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            for ln in open(path):
+                t = ln.split()
+                if len(t) == 2 and t[0] == "simd_count" and int(t[1]) > 0:
+                    n += 1
+        except OSError:
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n: int) -> int:
     """`python3 bench.py --gpus N` without torch.distributed.run: start the N ranks ourselves - fresh child processes of this
     same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly the environment torch.distributed.run
@@ -860,8 +996,8 @@ def self_launch(n: int) -> int:
     import threading
     rehearsal = os.environ.get("SPGNN_BENCH_REHEARSAL", "0") == "1" or os.environ.get("SPGNN_BENCH_DRY", "0") == "1"
     if not rehearsal:
-        have = torch.cuda.device_count()        # counting devices does not initialise the GPU
-        if have < n:
+        have = visible_gpus()                   # /sys only: the launcher never brings up the GPU runtime
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but {have} GPU(s) visible", file=sys.stderr)
             return 2
     with socket.socket() as sk:                 # a free rendezvous port on the loopback interface
@@ -960,13 +1096,21 @@ def main():
     ap.add_argument("--batch-cycle-only", action="store_true", help="run only the loader-batch cycle leg (secondary.batch_cycle_64) and print it")
     ap.add_argument("--single-tree-only", action="store_true", help="run only the per-scan inference leg (secondary.single_tree_forward) and print it")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL nested object on stdout (tools/; tens of KB) instead of the "
+                    "driver's flat line; the default writes it to --detail-out only")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full nested object of the run goes")
+    ap.add_argument("--cpu-small-sample", action="store_true", help="cpu_baseline: also time the 64-tree sample of rounds 1-4 (value64)")
+    ap.add_argument("--count-launches", action="store_true", help="single-tree leg: count all device launches of a forward with torch.profiler")
     ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # SPGNN_BENCH_FORCE_LAUNCH=1: take the launcher path at ANY N, and keep the rank-exchange code on with one rank (RCCL at
+    # world size 1, the two-graph step, the real TrainStep._reduce) - how a one-GPU box exercises the N > 1 code path
+    forced = os.environ.get("SPGNN_BENCH_FORCE_LAUNCH", "0") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or forced):
         # plain `python3 bench.py --gpus N`: this process becomes the launcher of N ranks and never touches the GPU itself
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
@@ -982,8 +1126,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    exchange = world > 1 or (forced and "WORLD_SIZE" in os.environ)
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -993,14 +1139,16 @@ def main():
         print(json.dumps({"batch_cycle_64": batch_cycle(dev)}), flush=True)
         return
     if args.single_tree_only:
-        print(json.dumps({"single_tree_forward": {c_: single_tree_forward(dev, c_) for c_ in ("st_pgat_spgnn_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3")}}), flush=True)
+        print(json.dumps({"single_tree_forward": {c_: single_tree_forward(dev, c_, count_launches=args.count_launches) for c_ in ("st_pgat_spgnn_3", "st_gat_3", "st_gcn_3", "st_gin_3", "st_sage_3")}}), flush=True)
         return
     out, (cfg, model, samples) = run_leg(args.config, args.dtype, args.trees, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                                          eager=args.eager, no_eager_leg=args.no_eager_leg, no_dropout=args.no_dropout,
-                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads, loss_rows=("backward" if args.loss_rows_backward else args.loss_rows_only))
+                                         no_kernel_timers=args.no_kernel_timers, heads=args.heads, loss_rows=("backward" if args.loss_rows_backward else args.loss_rows_only),
+                                         exchange=exchange)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees) if args.cpu_trees else args.trees)
+            out["cpu_baseline"] = cpu_baseline(cfg, model, samples, min(args.cpu_trees, args.trees) if args.cpu_trees else args.trees,
+                                               small_sample=args.cpu_small_sample)
         headline = args.config == "st_pgat_spgnn_3" and args.dtype == "f32" and args.trees == 512
         if world == 1 and headline and not args.no_secondary:
             del model, samples
@@ -1044,7 +1192,7 @@ def main():
                 sec["batch_cycle_64"] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
             try:
-                sec["single_tree_forward"] = single_tree_forward(dev)
+                sec["single_tree_forward"] = single_tree_forward(dev, count_launches=args.count_launches)
             except Exception as e:
                 sec["single_tree_forward"] = {"error": repr(e)[:300]}
             out["secondary"] = sec
@@ -1066,11 +1214,21 @@ def main():
                     c[f"sec_{name}_roofline_{rr.get('bound', '')}_frac"] = round(rr["frac"], 4)
                 if "hbm_frac" in rr:
                     c[f"sec_{name}_k123_hbm_frac"] = round(rr["hbm_frac"], 4)
+                if "k123_frac_of_survey_roofline" in rr:
+                    c[f"sec_{name}_k123_hbm_frac"] = round(rr["k123_frac_of_survey_roofline"], 4)
+                if "executed_mfma_frac" in rr:
+                    c[f"sec_{name}_executed_mfma_frac"] = round(rr["executed_mfma_frac"], 4)
                 for q in ("replay_device_us", "captured_us", "eager_us", "cpu_oracle_ms"):
                     if q in leg:
                         c[f"sec_{name}_{q}"] = leg[q]
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        detail = write_detail(out, args.detail_out)
+        out["detail_file"] = os.path.basename(detail) if detail else "not written"
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            print(driver_line(out), flush=True)
+        print(f"bench.py: full object of this run -> {detail}", file=sys.stderr, flush=True)
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -145,7 +145,7 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, class_weights: Sequence[float], sampling_rate: float, lr: float,
                  momentum: float = 0.9, weight_decay: float = 0.0, process_group=None, seed: int = 0,
-                 range_policy: str = "monitor", loss_rows_only: bool = False):
+                 range_policy: str = "monitor", loss_rows_only: bool = False, always_exchange: bool = False):
         """``loss_rows_only``: run what follows the last aggregation - output-layer projection, head mean, classifier and their
         backward products - only on the rows the step's mask keeps (``F.cross_entropy(pre[mask], ...)``, reference
         job_runner.py:1896-1900: no other row reaches the loss or a gradient).  Same loss and gradients up to fp32 summation
@@ -154,6 +154,9 @@ class TrainStep:
         others run as before.  ``"backward"``: the forward pass stays dense (``model(g)`` inside the step returns every row, as
         the reference's does) and only the BACKWARD products of that part run on the kept rows - the rows they skip are exactly
         zero in the dense step (their logit gradients are).  See :meth:`_loss_rows_cap`.
+        ``always_exchange``: issue the step's all-reduce (and split the captured step in two graphs around it) even when the
+        process group has ONE rank - the multi-rank step with nothing to add, which lets a one-GPU box exercise the RCCL path
+        (bench.py, SPGNN_BENCH_FORCE_LAUNCH).
         ``range_policy``: what :meth:`run_batch` does with the GEMM range monitor: "monitor" only
         counts (``range_violations()``); "auto" switches the split GEMMs to their wide-range form (``ops.GEMM_WIDE``) for all
         later batches once an operand left the narrow envelope, dropping the captures recorded in the narrow form."""
@@ -167,6 +170,7 @@ class TrainStep:
         self.sampling_rate, self.lr, self.momentum, self.weight_decay = sampling_rate, lr, momentum, weight_decay
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.exchange = self.world > 1 or bool(always_exchange and dist.is_available() and dist.is_initialized())
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self._captures, self._arenas = {}, {}       # id(graph) -> its HIP graph(s); size class -> arena.BatchArena
@@ -362,7 +366,7 @@ class TrainStep:
     def _reduce(self, loss_num: torch.Tensor) -> torch.Tensor:
         """The step's only exchange: ONE sum all-reduce of the flat gradient bucket (RCCL); the class-weight sum and the loss
         numerator ride in its last two slots."""
-        if self.world > 1:
+        if self.exchange:
             dist.all_reduce(self.bucket.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
         return loss_num
 
@@ -496,10 +500,10 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._front(g)
-                if self.world == 1 and ONE_GRAPH_PER_STEP:       # nothing happens between the halves: one graph launch per step
+                if not self.exchange and ONE_GRAPH_PER_STEP:     # nothing happens between the halves: one graph launch per step
                     self._static_loss = self._back(self.bucket.loss_slot)
             self._graph_back = None
-            if not (self.world == 1 and ONE_GRAPH_PER_STEP):
+            if self.exchange or not ONE_GRAPH_PER_STEP:
                 self._graph_back = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_back, capture_error_mode="thread_local"):
                     self._static_loss = self._back(self.bucket.loss_slot)

@@ -786,6 +786,38 @@ def test_bench_two_rank_rehearsal_through_self_launch():
     assert out["roofline"]["hbm_frac"] > 0 and out["roofline"]["hbm_ms_per_step"] > 0
 
 
+def test_bench_real_launcher_and_rccl_with_one_rank():
+    """The REAL (non-rehearsal) N > 1 launcher path as far as one GPU allows: SPGNN_BENCH_FORCE_LAUNCH=1
+    makes `bench.py --gpus 1` take self_launch - whose parent counts GPUs from /sys and never calls torch.cuda - and its one
+    child initialise the "nccl" (= RCCL) process group at world size 1, run the multi-rank step (two HIP graphs around the
+    real TrainStep._reduce -> dist.all_reduce on the flat bucket) and report the collective on the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPGNN_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SPGNN_BENCH_REHEARSAL", "SPGNN_BENCH_DRY", "SPGNN_BENCH_CHILD"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3", "--trees", "8",
+                        "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 1 and c["comm_world_size"] == 1 and c["comm_backend"].startswith("nccl"), c
+    assert c["launch"] == "hip-graph replay", c.get("capture_error")
+    assert c["allreduce_ms_p50"] > 0.0 and 4 * 2501080 <= c["comm_bucket_bytes"] <= 4 * 2501080 + 64
+    assert out["value"] > 0 and np.isfinite(out["loss"])
+    # ... and the all-reduce with one rank changes nothing: the same run without the forced exchange gives the same loss
+    env2 = {k: v for k, v in env.items() if k != "SPGNN_BENCH_FORCE_LAUNCH"}
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3", "--trees", "8",
+                         "--no-secondary", "--no-cpu-baseline"], env=env2, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    out2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.strip()][0])
+    assert out2["config"]["comm_backend"].startswith("none") and out2["loss"] == pytest.approx(out["loss"], rel=1e-6)
+
+
 @pytest.mark.parametrize("name,trees", [("st_pgat_spgnn_3", 5), ("st_gin_3", 5), ("st_pgat_spgnn_3", 40)])
 def test_classifier_weight_gradient_rides_in_act_bwd_proj(name, trees, monkeypatch):
     """ops.ACT_BWD_PROJ_WGRAD (round 5): the classifier's weight gradient g_logits^T mean_h(out) (reference gnn_out on the head

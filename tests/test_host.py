@@ -1,6 +1,7 @@
 """CPU-only checks: the C-ABI library loads and exports every symbol include/spgnn_hip.h declares,
 the embedded configs equal the reference's exp_settings, the loss/mask host logic equals the
 reference formulation, and the N>1 data-parallel step (gloo, world_size 2) equals the 1-rank step."""
+import json
 import os
 import re
 import socket
@@ -496,6 +497,143 @@ def test_bench_flat_scalars_for_the_drivers_record():
     assert r["hbm_frac"] == 0.6 and r["hbm_ms_per_step"] == 1.1 and r["hbm_survey_bytes"] == 5.2e9 and r["hbm_traffic"] == 5.0e9
     assert c["gemm_ms_per_step"] == 3.3 and c["message_passing_ms_per_step"] == 1.7 and c["step_ms_median"] == 5.2
     assert all(not isinstance(v, (dict, list)) for k, v in r.items() if k.startswith("hbm_"))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _strict_loads(txt):
+    def refuse(tok):
+        raise ValueError("non-finite constant in the line: " + tok)
+    return json.loads(txt, parse_constant=refuse)
+
+
+def test_bench_driver_line_is_short_flat_and_strict():
+    """The ONE stdout line the driver parses (a 31 KB line left BENCH_r05.parsed null).  Built here from the
+    recorded full object of a real default run (tests/golden/bench_full_object_r05e.json: headline + five secondary legs +
+    batch cycle + single-tree leg): one line, far below 12 KB, strict JSON, the contract's keys, and `config` / `roofline` /
+    `cpu_baseline` hold scalars only - no prose members, no nested legs."""
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_object_r05e.json")))
+    assert len(json.dumps(full)) > 25000                       # the object that broke the driver's parser
+    # what the new legs add to a run's object
+    full["roofline"]["hbm"]["in_step_frac"] = 0.40
+    full["roofline"]["hbm"]["in_step_ms_per_step"] = 1.63
+    bench.flatten_for_driver(full)
+    full["loss"] = float("nan")                                # a diverged run must still give a strict line
+    full["config"]["capture_error"] = "x" * 300
+    txt = bench.driver_line(full)
+    assert "\n" not in txt and len(txt) < bench.LINE_LIMIT == 12288 and len(txt) < 6000, len(txt)
+    line = _strict_loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["loss"] is None and line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert line["value"] == pytest.approx(full["value"], rel=1e-8) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-8)
+    for part in ("config", "roofline", "cpu_baseline"):
+        for k, v in line[part].items():
+            assert not isinstance(v, (dict, list)), (part, k)
+            assert not isinstance(v, str) or len(v) <= 118, (part, k, len(v))
+            assert k not in ("what", "note", "how", "measured_in", "traffic_source"), (part, k)
+    assert "secondary" not in line and "composite" not in line and "gemm" not in line
+    r, c, b = line["roofline"], line["config"], line["cpu_baseline"]
+    assert r["bound"] == "mfma" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["hbm_frac"] == pytest.approx(0.5859, abs=1e-3) and r["hbm_in_step_frac"] == 0.40 and r["traffic"] > 0
+    assert c["sec_st_pgat_spgnn_3_f32_64_ms"] > 0 and c["sec_single_tree_forward_captured_us"] > 0 and c["batch_cycle_over_steady"] > 0
+    assert c["workload"].startswith("st_pgat_spgnn_3") and c["step_ms_median"] > 0
+    assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and isinstance(b["sample"], str)
+
+
+def test_bench_driver_line_sheds_optional_scalars_before_it_outgrows_the_limit():
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_object_r05e.json")))
+    for i in range(600):                                       # a future builder adds legs without thinking of the driver
+        full["config"][f"sec_future_leg_{i:04d}_ms"] = 1.0 + i
+    txt = bench.driver_line(full)
+    assert len(txt) <= bench.LINE_LIMIT
+    line = _strict_loads(txt)
+    assert "value" in line and "frac" in line["roofline"] and "workload" in line["config"] and "value" in line["cpu_baseline"]
+
+
+def test_bench_prints_exactly_one_stdout_line_and_writes_the_detail_file(tmp_path):
+    """End to end through main() in dry mode (no GPU): stdout is ONE line of strict JSON and nothing after it."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SPGNN_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 12288
+    _strict_loads(lines[0])
+    # write_detail falls back instead of failing the run
+    bench = _load_bench()
+    got = bench.write_detail({"a": 1}, str(tmp_path / "no_such_dir" / "x.json"))
+    assert got is not None and os.path.exists(got)
+    os.remove(got)
+    got = bench.write_detail({"a": 1}, str(tmp_path / "d.json"))
+    assert got == str(tmp_path / "d.json") and json.load(open(got)) == {"a": 1}
+
+
+def test_bench_launcher_never_touches_torch_cuda_and_runs_forced_with_one_rank():
+    """the launcher parent counts GPUs from the KFD topology in /sys, not through torch.cuda (whose
+    device_count() can fall back to hipGetDeviceCount and bring up the runtime in a process that then starts its ranks).
+    And SPGNN_BENCH_FORCE_LAUNCH=1 takes the launcher path with ONE rank (dry mode here; RCCL on the GPU box:
+    tests/test_hip_models.py::test_bench_real_launcher_and_rccl_with_one_rank)."""
+    import inspect
+    bench = _load_bench()
+    for fn in (bench.self_launch, bench.visible_gpus):
+        src = inspect.getsource(fn)
+        assert "torch.cuda" not in src.split('"""')[2] and "hipGetDeviceCount" not in src.split('"""')[2], fn.__name__
+    n = bench.visible_gpus()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    if not torch.cuda.is_available():
+        assert n in (None, 0)
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1"], {"SPGNN_BENCH_DRY": "1", "SPGNN_BENCH_FORCE_LAUNCH": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = _strict_loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["comm_world_size"] == 1 and out["config"]["launched_by"] == "bench.py self_launch"
+
+
+def test_train_step_always_exchange_issues_the_collective_with_one_rank():
+    """TrainStep(always_exchange=True) in a ONE-rank process group: _reduce calls dist.all_reduce on the flat bucket (a sum over
+    one rank: the identity), so the multi-rank step runs - and gives what the plain step gives."""
+    from spgnn_amd.train import FlatBucket, TrainStep
+    port = _free_port()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        calls = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+        lin = torch.nn.Linear(6, 3)
+        ts = TrainStep.__new__(TrainStep)
+        ts.bucket, ts.pg, ts.world = FlatBucket(list(lin.parameters())), None, 1
+        ts.bucket.flat_grad.normal_()
+        before = ts.bucket.flat_grad.clone()
+        dist.all_reduce = spy
+        try:
+            ts.exchange = False
+            ts._reduce(ts.bucket.loss_slot)
+            assert calls == []
+            ts.exchange = True
+            ts._reduce(ts.bucket.loss_slot)
+        finally:
+            dist.all_reduce = real
+        assert calls == [ts.bucket.flat_grad.numel()] and torch.equal(ts.bucket.flat_grad, before)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_loss_rows_capacity_rule():

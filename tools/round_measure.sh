@@ -18,8 +18,8 @@ pmc() {  # <config> <dtype> <trees>
 }
 prof() {  # <config> <dtype>
   local c=$1 dt=$2 D=$O/prof_${1}_${2}
-  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt} -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline --no-secondary"
-  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --config $c --dtype $dt --no-cpu-baseline --no-secondary > $D.log 2> $D.err) || return 1
+  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt} -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary"
+  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary > $D.log 2> $D.err) || return 1
   grep '^{' $D.log | tail -1 > $D.json
   (cd $R && python3 tools/save_profile.py $D $TAG $D.json "$CMD" > $D.summary.txt)
   (cd $R && python3 tools/trace_steps.py $D > profiles/${TAG}_step_sequence_${c}_${dt}.txt 2> /dev/null) || true
@@ -27,16 +27,16 @@ prof() {  # <config> <dtype>
 pmc st_pgat_spgnn_3 f32 512 && pmc st_gat_6 bf16 512 && pmc st_pgat_spgnn_3 f32 64 && pmc st_gat_3 f32 64 && prof st_pgat_spgnn_3 f32 && prof st_gat_6 bf16 || echo "MEASURE STEP FAILED"
 echo "profiling done" > $O/progress.txt
 cd $R
-python bench.py --no-secondary > $O/bench_f32.log 2> $O/bench_f32.err; grep '^{' $O/bench_f32.log | tail -1 > profiles/${TAG}_bench_st_pgat_spgnn_3_f32.json
-python bench.py --config st_gat_6 --dtype bf16 --no-secondary > $O/bench_bf16.log 2> $O/bench_bf16.err; grep '^{' $O/bench_bf16.log | tail -1 > profiles/${TAG}_bench_st_gat_6_bf16.json
+python bench.py --full-line --no-secondary > $O/bench_f32.log 2> $O/bench_f32.err; grep '^{' $O/bench_f32.log | tail -1 > profiles/${TAG}_bench_st_pgat_spgnn_3_f32.json
+python bench.py --full-line --config st_gat_6 --dtype bf16 --no-secondary > $O/bench_bf16.log 2> $O/bench_bf16.err; grep '^{' $O/bench_bf16.log | tail -1 > profiles/${TAG}_bench_st_gat_6_bf16.json
 echo "bench lines done" >> $O/progress.txt
 for c in st_gat_3 st_gat_6 st_gcn_3 st_gin_3 st_sage_3; do
-  python bench.py --config $c --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | grep '^{' | tail -1 > $O/cfg_${c}_f32.json
+  python bench.py --full-line --config $c --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | grep '^{' | tail -1 > $O/cfg_${c}_f32.json
 done
-python bench.py --trees 64 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > $O/cfg_headline_64trees.json
+python bench.py --full-line --trees 64 --no-cpu-baseline --no-secondary 2>/dev/null | grep '^{' | tail -1 > $O/cfg_headline_64trees.json
 echo "configs done" >> $O/progress.txt
-python bench.py > $O/bench_default.log 2> $O/bench_default.err; grep '^{' $O/bench_default.log | tail -1 > profiles/${TAG}_bench_default_with_secondary_legs.json
-python bench.py --batch-cycle-only 2> /dev/null | grep '^{' | tail -1 > profiles/${TAG}_batch_cycle_64trees.json
+python bench.py --full-line > $O/bench_default.log 2> $O/bench_default.err; grep '^{' $O/bench_default.log | tail -1 > profiles/${TAG}_bench_default_with_secondary_legs.json
+python bench.py --full-line --batch-cycle-only 2> /dev/null | grep '^{' | tail -1 > profiles/${TAG}_batch_cycle_64trees.json
 cp profiles/${TAG}_* profiles/traffic_latest.json $O/profiles/
 python - <<P
 import json, glob, os
