@@ -85,7 +85,9 @@ class ForwardRunner:
             from . import ops
             # scans of this class run their projections on the skinny kernel (fp32, no operand scales, no pre-split images):
             # nothing to refresh per scan beyond the data itself
-            arena.refresh_constants = not (ops.SKINNY_GEMM and arena.n_cap <= ops.SKINNY_ROWS)
+            # (only below MIN_GEMM_ROWS: from there on some layer forms - fused output layers, pooled SAGE products - may still
+            # take a matrix-core product whose operand scale is cached on the node data and must follow every scan)
+            arena.refresh_constants = not (ops.SKINNY_GEMM and arena.n_cap <= ops.SKINNY_ROWS and arena.n_cap < ops.MIN_GEMM_ROWS)
             arena.keep_edges = False               # the forward pass reads CSC / CSR only: no src / dst copy per scan
             arena.load(g, key)
             graph, outs, refs = self._capture(arena)

@@ -1286,7 +1286,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     dropout of the result under the hash mask (matrix-core path with a width that is a multiple of 4 only; see
     :func:`linear_drop_supported`)."""
     N = x.shape[0] if x.dim() == 2 else 0
-    if (x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= MIN_GEMM_ROWS and weight.shape[0] >= 32 and weight.shape[1] >= 32
+    # a small inference batch goes to the skinny product (exact fp32, no operand scale) even where the row count would also
+    # admit the matrix-core path (512 <= N <= SKINNY_ROWS): a replayed per-scan forward must not depend on a scale that was
+    # computed from the FIRST scan's data (ADVICE r5)
+    skinny = bool(skinny_rows(N) and addend is None and drop is None and act in (ACT_NONE, ACT_ELU, ACT_TANH, ACT_RELU, ACT_LRELU))
+    if (not skinny and x.is_cuda and GEMM_MODE == "f16x3" and x.dim() == 2 and N >= MIN_GEMM_ROWS and weight.shape[0] >= 32 and weight.shape[1] >= 32
             and x.dtype == torch.float32 and weight.dtype == torch.float32
             and (addend is None or (weight.shape[0] % 4 == 0 and addend.shape == (N, weight.shape[0])))):
         y = _LinearFn.apply(x, weight, bias, act, addend, drop)

@@ -210,6 +210,30 @@ class TrainStep:
             store[key] = cap
         return cap
 
+    def _arena_rows_check(self, g, p: torch.Tensor) -> None:
+        """Called when a new batch was loaded into arena graph ``g`` (its refresh hook): the row-list capacity of the step
+        captured on ``g`` came from an EARLIER batch of the size class, and a batch with more labelled nodes (they are always
+        kept) may not fit it - every inner step of that loader batch would overflow and be skipped.  One host read
+        per loader batch: mean + 8 sigma of THIS batch's kept count; beyond the capacity the capacity grows (15 % on top) and
+        the capture made with the old one is dropped, so the batch's first step records a new one."""
+        if not self.loss_rows_only:
+            return
+        store = g.__dict__.get("_loss_rows_cap")
+        key = (self.sampling_rate, self._rows_gen)
+        cap = store.get(key) if store else None
+        if not cap:                                  # not computed yet, or 0: the step on this graph runs dense
+            return
+        pc = p.clamp(min=0.0).double()
+        mu, var = torch.stack([pc.sum(), (pc * (1.0 - pc)).sum()]).tolist()
+        want = mu + 8.0 * var ** 0.5 + 32.0
+        if want <= cap:
+            return
+        new = int(-(-(want * 1.15) // 256) * 256)
+        store[key] = 0 if new > 0.8 * p.shape[0] else new
+        self._captures.pop(id(g), None)
+        if self._captured_graph is g:
+            self._graph = self._graph_back = self._captured_graph = None
+
     def check_loss_rows(self) -> int:
         """One host read: did a step's mask keep more rows than its list could hold since the last check?  Such a step had a
         NaN loss and was not applied (the guarded optimizer kernel).  Then: every capacity grows by half (recomputed per graph on
@@ -217,15 +241,29 @@ class TrainStep:
         -> the number of steps skipped so far."""
         if self._rows_cnt is None:
             return 0
-        skipped = int(self._skipped.item()) if self._skipped is not None else 0
-        if int(self._rows_cnt[1].item()) == 0:
-            return skipped
         import warnings
+        if self._skipped is not None:                # ONE blocking read: [steps skipped, overflow flag]
+            skipped, flag = torch.cat([self._skipped, self._rows_cnt[1:2]]).tolist()
+        else:
+            skipped, flag = 0, int(self._rows_cnt[1].item())
+        if flag == 0:
+            if skipped > getattr(self, "_skipped_seen", 0):
+                # the guarded optimizer kernel skips EVERY step with a non-finite loss; without an overflow that is divergence,
+                # a zero weight sum or a bad label - the reference would propagate the NaN, so say it (ADVICE r5)
+                warnings.warn(f"loss_rows_only: {skipped - getattr(self, '_skipped_seen', 0)} step(s) had a non-finite loss WITHOUT a "
+                              "row-list overflow and were not applied: the training has diverged (or a batch has no kept node).",
+                              RuntimeWarning)
+            self._skipped_seen = skipped
+            return skipped
+        self._skipped_seen = skipped
         self._rows_cnt[1].zero_()
         self._rows_headroom *= 1.5
         self._rows_gen += 1
-        self._captures.clear()
-        self._graph = self._graph_back = self._captured_graph = None
+        # only captures whose graph carries a row list were recorded with a capacity; the others stay
+        for k in [k for k, rec in self._captures.items() if any(rec["graph"].__dict__.get("_loss_rows_cap", {}).values())]:
+            if self._captured_graph is self._captures[k]["graph"]:
+                self._graph = self._graph_back = self._captured_graph = None
+            del self._captures[k]
         warnings.warn(f"loss_rows_only: a step's mask kept more rows than its row list could hold; {skipped} step(s) so far had a NaN "
                       f"loss and were not applied.  The lists now get {self._rows_headroom:.2f} x the headroom; captured steps are "
                       "recorded again.", RuntimeWarning)
@@ -248,7 +286,7 @@ class TrainStep:
                 hit[2].copy_(p)                      # same address: what the captured loss kernel reads
                 p = hit[2]
             elif getattr(g, "_stable_storage", False):
-                g._refresh_hooks.append(lambda: self._sampling(g))
+                g._refresh_hooks.append(lambda: self._arena_rows_check(g, self._sampling(g)))
             store[self.sampling_rate] = (y, y._version, p)
         return store[self.sampling_rate][2]
 

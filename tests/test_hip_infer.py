@@ -80,3 +80,29 @@ def test_forward_runner_refuses_a_training_mode_model():
     g = synthetic.make_batch(1, rank=60, device="cuda", pos_enc_dim=None, fixed_n=64)
     with pytest.raises(RuntimeError, match="eval"):
         ForwardRunner(model)(g)
+
+
+@pytest.mark.parametrize("name", ["st_gcn_3", "st_sage_3", "st_gin_3", "st_gat_3", "st_pgat_spgnn_3"])
+@pytest.mark.parametrize("n_first,n_second", [(520, 560), (600, 590)])
+def test_forward_runner_follows_the_feature_range_of_every_scan(name, n_first, n_second):
+    """size classes of 512-640 nodes are large enough for the matrix-core products (ops.MIN_GEMM_ROWS), whose fp16
+    split works under a per-tensor power-of-two scale of the node data.  A captured forward must not keep the FIRST scan's
+    scale: the second scan of the class has features 2^12 times larger (fp16 would overflow under the stale scale) - replay,
+    eager forward and the oracle still agree."""
+    cfg, model = _model(name, seed=6)
+    runner = ForwardRunner(model, granule=64)
+    pe = getattr(cfg, "POS_ENC_DIM", None)
+    a = synthetic.make_batch(1, rank=70, device="cuda", pos_enc_dim=pe, fixed_n=n_first)
+    b = synthetic.make_batch(1, rank=71, device="cuda", pos_enc_dim=pe, fixed_n=n_second)
+    with torch.no_grad():
+        a.ndata["fvs"].mul_(2.0 ** -6)
+        b.ndata["fvs"].mul_(2.0 ** 6)
+    for g in (a, b, a):
+        got = runner(g)
+        assert len(runner._classes) == 1                       # one size class (576 or 640 nodes): one capture serves all three
+        with torch.no_grad():
+            eager = model(g)
+        ref = _oracle(cfg, model, g)
+        assert torch.isfinite(got[0]).all()
+        assert rel_err(got[0], eager[0]) < 2e-6, (name, rel_err(got[0], eager[0]))
+        assert rel_err(got[0], ref[0]) < 1e-5, (name, rel_err(got[0], ref[0]))

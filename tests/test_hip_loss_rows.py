@@ -255,6 +255,64 @@ def test_loss_rows_through_an_arena_follow_each_loaded_batch():
     ts_r.check_loss_rows()
 
 
+def test_arena_batch_with_more_labelled_nodes_than_the_captured_capacity_is_recaptured_not_lost():
+    """the row-list capacity of a captured step came from the FIRST batch of its size class.  A later batch of the
+    class with many more labelled nodes (always kept) exceeds it on every inner step - before the fix all of that loader
+    batch's steps were NaN and skipped.  Now the arena load recomputes mean + 8 sigma from the batch's own probabilities, grows
+    the capacity and drops the old capture: no step is lost, and the losses equal the dense step's."""
+    cfg, model = _model("st_pgat_spgnn_3", 6)
+    model.train(True)
+    dense = copy.deepcopy(model)
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    y = gb.ndata["y"]
+    torch.manual_seed(1)
+    more = torch.rand(y.shape, device=y.device) < 0.6
+    y[more & (y == 0)] = 3                                                  # 60 % of the second batch labelled
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=True)
+    ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9)
+    caps = []
+    for i, g in enumerate((ga, gb, ga)):
+        torch.manual_seed(300 + i)
+        lr_ = ts_r.run_batch(g, 4, granule=2048)
+        torch.manual_seed(300 + i)
+        ld_ = ts_d.run_batch(g, 4, granule=2048)
+        assert bool(torch.isfinite(lr_)) and rel_err(lr_, ld_) < 1e-5, (i, float(lr_), float(ld_))
+        ag = next(iter(ts_r._arenas.values())).graph
+        caps.append(ag.__dict__["_loss_rows_cap"][(cfg.SAMPLING_RATE, 0)])
+        assert int((g.ndata["y"] != 0).sum()) <= int(ts_r._rows_cnt[0]) <= caps[-1]
+        assert int(ts_r._rows_cnt[1]) == 0
+    assert caps[1] > caps[0] and caps[2] == caps[1]                          # grown once, kept (capacities never shrink)
+    assert int((gb.ndata["y"] != 0).sum()) > caps[0]                        # ... and it had to: the labelled nodes alone overflow the old list
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert ts_r.check_loss_rows() == 0                                  # no step skipped, nothing to warn about
+    n = ts_r.bucket.numel
+    assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 1e-5
+
+
+def test_steps_skipped_without_an_overflow_are_reported():
+    """the guarded optimizer kernel skips every step whose loss is not finite.  Without a row-list overflow that is
+    divergence (the reference would carry the NaN on): check_loss_rows() says so instead of counting silently."""
+    cfg, model = _model("st_pgat_spgnn_3", 2)
+    model.eval()
+    w = class_weight_list(cfg.CLASS_WEIGHTS)
+    g = synthetic.make_batch(6, rank=2, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    ts = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=5, loss_rows_only=True)
+    assert bool(torch.isfinite(ts.step(g))) and ts.check_loss_rows() == 0
+    p = ts._sampling(g)
+    keep = p.clone()
+    p.fill_(-1.0)                                                           # no node kept: weight sum 0, loss 0 / 0 - and no overflow
+    assert not bool(torch.isfinite(ts.step(g)))
+    with pytest.warns(RuntimeWarning, match="WITHOUT a row-list overflow"):
+        assert ts.check_loss_rows() == 1
+    p.copy_(keep)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert ts.check_loss_rows() == 1                                    # reported once
+
+
 @pytest.mark.parametrize("name,trees", [("st_gat_6", 6), ("st_gat_6", 64)])
 def test_bf16_storage_loss_rows_step_equals_the_dense_step(name, trees):
     """BASELINE config 4's model (bf16 rows, linear-mean head) with the list: rows of the output product, the head mean and the
