@@ -308,13 +308,18 @@ def sage_conv_pool(src: Tensor, dst: Tensor, num_nodes: int, feat: Tensor, fc_po
 # model stacks (reference models.py:160-540, 650-696) driven by a state_dict
 # --------------------------------------------------------------------------------------
 def _gat_layer(sd: Dict[str, Tensor], prefix: str, src, dst, n, h, slope, act, storage=None, store_out=True,
-               residual_identity=False):
+               residual_identity=False, feat_keep=None, attn_keep=None):
     """``residual_identity``: the layer is residual with in_feats == out_feats (DGL then uses an Identity ``res_fc``, which
-    has no state_dict entry, so it cannot be inferred from ``sd``)."""
+    has no state_dict entry, so it cannot be inferred from ``sd``).
+    ``feat_keep`` (N, F_in) / ``attn_keep`` (E, H): already scaled dropout multipliers (mask / (1 - p)) standing in for the
+    layer's ``feat_drop`` / ``attn_drop`` in training mode: DGL's GATConv applies ``feat_drop`` to the layer INPUT - ``fc`` and
+    ``res_fc`` both read the dropped rows - and ``attn_drop`` to the softmax weights (Appendix A.1)."""
     w_res = sd.get(prefix + "res_fc.weight")
+    if feat_keep is not None:
+        h = h * feat_keep
     return gat_conv(src, dst, n, h, sd[prefix + "fc.weight"], sd[prefix + "attn_l"], sd[prefix + "attn_r"],
                     w_res, sd.get(prefix + "bias"), slope, act, storage=storage, store_out=store_out,
-                    residual_identity=residual_identity and w_res is None)[0]
+                    residual_identity=residual_identity and w_res is None, attn_keep=attn_keep)[0]
 
 
 def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
@@ -352,16 +357,24 @@ def gat_stack(sd, src, dst, n, fvs, prefix="gat_layers.", negative_slope=0.2, ac
     return F.normalize(out, p=2, dim=1) if norm else out
 
 
-def spgnn_pel_stack(sd, src, dst, n, fvs, pos_enc, negative_slope=0.2, activation=F.elu, p_activation=torch.tanh):
-    """reference models.py:472-484 (GATPSPGNN.forward)."""
+def spgnn_pel_stack(sd, src, dst, n, fvs, pos_enc, negative_slope=0.2, activation=F.elu, p_activation=torch.tanh, drop=None):
+    """reference models.py:472-484 (GATPSPGNN.forward).
+    ``drop``: training mode with GIVEN masks - {("feat" | "attn", "s" | "p", layer): scaled multiplier} for the structure
+    ("s": gat_layers) and position ("p": pgnn_layers) GATConv's ``feat_drop`` (N, F_in) and ``attn_drop`` (E, H); a missing
+    key = that dropout is off (the reference builds layer 0 of both streams, the last position layer and the output layer
+    with rate 0: models.py:431-434, 449-456).  None: eval mode."""
     L = _count_layers(sd, "pgnn_layers.")
+    d = drop or {}
     h_s, h_p = fvs, pos_enc
     for l in range(L):
         h_s = torch.cat([h_s, h_p], dim=1)
-        h_s = _gat_layer(sd, f"gat_layers.{l}.", src, dst, n, h_s, negative_slope, activation).flatten(1)
-        h_p = _gat_layer(sd, f"pgnn_layers.{l}.", src, dst, n, h_p, negative_slope, p_activation).flatten(1)
+        h_s = _gat_layer(sd, f"gat_layers.{l}.", src, dst, n, h_s, negative_slope, activation,
+                         feat_keep=d.get(("feat", "s", l)), attn_keep=d.get(("attn", "s", l))).flatten(1)
+        h_p = _gat_layer(sd, f"pgnn_layers.{l}.", src, dst, n, h_p, negative_slope, p_activation,
+                         feat_keep=d.get(("feat", "p", l)), attn_keep=d.get(("attn", "p", l))).flatten(1)
     h_s = torch.cat([h_s, h_p], dim=1)
-    h_s = _gat_layer(sd, f"gat_layers.{L}.", src, dst, n, h_s, negative_slope, activation).mean(1)
+    h_s = _gat_layer(sd, f"gat_layers.{L}.", src, dst, n, h_s, negative_slope, activation,
+                     feat_keep=d.get(("feat", "s", L)), attn_keep=d.get(("attn", "s", L))).mean(1)
     return h_s, h_p
 
 

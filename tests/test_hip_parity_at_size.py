@@ -279,3 +279,93 @@ def test_loss_and_gradients_match_the_oracle_at_512_trees():
         assert e < 1e-4 or tiny, (n, e)
     print(f"{name} 512 trees: loss {e_loss:.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e} ({worst_name})")
     assert e_loss < TOL
+
+
+def _spgnn_host_masks(plan, model, g):
+    """The dropout multipliers of ONE training-mode forward of GATPSPGNN, rebuilt on the host from the forward's own seed plan
+    (spgnn_amd.models.GATPSPGNN._seed_plan: per level the next structure layer's feature dropout over cat[h_s, h_p], the
+    structure / position layer's attention dropout, the next position layer's feature dropout) with the bit-exact host
+    copies of the kernels' counter hashes (tests/util.py) - in the oracle's layout: {(kind, stream, layer): multiplier}."""
+    import numpy as np
+
+    from tests.util import keep4_scale_host, keep_scale_host
+    csc = g.csc()
+    N, E = g.number_of_nodes(), csc.num_edges
+    eid = csc.eid.cpu().numpy()
+    head = model.gat
+    drop = {}
+
+    def attn(seed, H, p):
+        slot = keep_scale_host(seed, np.arange(E * H), p).reshape(E, H)          # CSC slot order -> edge-id order
+        edge = np.empty_like(slot)
+        edge[eid] = slot
+        return torch.from_numpy(edge)
+    for l, d in enumerate(plan):
+        s_layer, p_layer = head.gat_layers[l], head.pgnn_layers[l]
+        w_s, w_p = s_layer._num_heads * s_layer._out_feats, p_layer._num_heads * p_layer._out_feats
+        if d["fp"] > 0:
+            drop[("feat", "s", l + 1)] = torch.from_numpy(keep4_scale_host(d["fseed"], N, (w_s, w_p), d["fp"]))
+        if d["ps"] > 0:
+            drop[("attn", "s", l)] = attn(d["seed_s"], s_layer._num_heads, d["ps"])
+        if d["pp"] > 0:
+            drop[("attn", "p", l)] = attn(d["seed_p"], p_layer._num_heads, d["pp"])
+        if d["fp2"] > 0:
+            drop[("feat", "p", l + 1)] = torch.from_numpy(keep4_scale_host(d["fseed2"], N, (w_p,), d["fp2"]))
+    return drop
+
+
+@pytest.mark.parametrize("trees", [3, 64])
+def test_training_mode_step_with_dropout_on_matches_the_oracle(trees):
+    """the TIMED workload's arithmetic - st_pgat_spgnn_3 in TRAINING mode, feature and attention dropout
+    on (reference models.py:431-434, 449-456: rate 0.1 on structure layers 1, 2 and position layer 1) - end to end against the
+    oracle at TRAIN_BATCH_SIZE = 64 trees.  The HIP forward draws its masks from counter hashes of per-forward seeds; the test
+    records the forward's seed plan, rebuilds every mask on the host bit for bit and hands them to the oracle as multipliers
+    (oracle.dgl_cpu.spgnn_pel_stack drop=).  Logits and loss 1e-5, every gradient 1e-4 (rule of _assert_gradients)."""
+    cfg, model = _build("st_pgat_spgnn_3", seed=12)
+    model.train(True)
+    g = synthetic.make_batch(trees, rank=1, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    w = torch.tensor(class_weight_list(cfg.CLASS_WEIGHTS))
+    y = g.ndata["y"]
+    mask = torch.rand(y.shape[0], generator=torch.Generator().manual_seed(6)) < torch.where(y.cpu() != 0, torch.tensor(1.0), torch.tensor(cfg.SAMPLING_RATE))
+    plans = []
+    orig = model.gat._seed_plan
+
+    def recording_plan():
+        plans.append(orig())
+        return plans[-1]
+    model.gat._seed_plan = recording_plan
+    torch.manual_seed(77)
+    outs = model(g)
+    loss = masked_weighted_ce(outs[0], y, mask.cuda(), w.cuda())
+    loss.backward()
+    assert len(plans) == 1
+    plan = plans[0]
+    rates = [(d["fp"], d["ps"], d["pp"], d["fp2"]) for d in plan]
+    assert rates == [(0.1, 0.0, 0.0, 0.1), (0.1, 0.1, 0.1, 0.0), (0.0, 0.1, 0.0, 0.0)], rates     # the reference's placement
+    drop = _spgnn_host_masks(plan, model, g)
+    assert sorted(drop) == [("attn", "p", 1), ("attn", "s", 1), ("attn", "s", 2), ("feat", "p", 1), ("feat", "s", 1), ("feat", "s", 2)]
+    for k, m in drop.items():
+        kept = float((m > 0).float().mean())
+        assert abs(kept - 0.9) < (0.05 if trees < 10 else 0.01), (k, kept)
+    src, dst = g.cpu().edges()
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        sd = {k: v.detach().cpu().to(dtype if v.dtype.is_floating_point else v.dtype).requires_grad_(v.dtype.is_floating_point)
+              for k, v in model.state_dict().items()}
+        refs = O.net_forward(cfg.KIND, sd, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu().to(dtype), g.ndata["pos_enc"].cpu().to(dtype),
+                             drop={k: m.to(dtype) for k, m in drop.items()})
+        ref_loss = O.masked_weighted_ce(refs[0], y.cpu(), mask, w.to(dtype))
+        ref_loss.backward()
+        res[dtype] = (refs, sd, ref_loss)
+    refs, sd, ref_loss = res[torch.float32]
+    refs64, sd64, _ = res[torch.float64]
+    # dropout really is on: the eval-mode oracle is far away
+    ev = O.net_forward(cfg.KIND, {k: v.detach() for k, v in sd.items()}, src, dst, g.number_of_nodes(), g.ndata["fvs"].cpu(), g.ndata["pos_enc"].cpu())
+    assert rel_err(outs[0], ev[0]) > 1e-2
+    for o, r, r64 in zip(outs, refs, refs64):
+        e_n, e_m = rel_err(o, r), mixed_err(o, r)
+        print(f"st_pgat_spgnn_3 TRAIN mode {trees} trees {tuple(o.shape)}: normwise {e_n:.2e}, elementwise mixed {e_m:.2e}; vs fp64 {rel_err(o, r64):.2e}")
+        assert e_n < TOL and e_m < TOL and rel_err(o, r64) < TOL
+    assert rel_err(loss, ref_loss) < TOL
+    worst = _assert_gradients(model, sd, sd64, 1e-4)
+    print(f"st_pgat_spgnn_3 TRAIN mode {trees} trees: loss {rel_err(loss, ref_loss):.2e}, worst non-tiny gradient normwise error vs the fp32 oracle {worst:.2e}")

@@ -169,3 +169,42 @@ def test_batching_equals_concatenation():
         srcs.append(u + off); dsts.append(v + off); xs.append(x); off += n
     big = O.gat_conv(torch.cat(srcs), torch.cat(dsts), off, torch.cat(xs), w, al, ar)[0]
     assert torch.allclose(big, torch.cat(outs), atol=1e-13)
+
+
+def test_spgnn_stack_dropout_multipliers_stand_in_for_training_mode():
+    """oracle.dgl_cpu.spgnn_pel_stack(drop=...): all-ones multipliers reproduce eval mode bit for bit; a feature mask on a
+    structure layer's input acts on BOTH of that layer's products (DGL's GATConv drops the layer input: fc and res_fc read
+    the dropped rows) and an attention mask on the softmax weights - checked against the layer called by hand."""
+    import torch.nn.functional as F
+
+    from spgnn_amd import models, synthetic
+    from spgnn_amd.configs import get_config
+    cfg = get_config("st_pgat_spgnn_3")
+    torch.manual_seed(0)
+    m = models.build_model(cfg.MODEL)
+    m.init(None)
+    g = synthetic.make_batch(2, rank=0, device="cpu", pos_enc_dim=39)
+    src, dst = g.edges()
+    n, E = g.number_of_nodes(), src.shape[0]
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    args = (cfg.KIND, sd, src, dst, n, g.ndata["fvs"], g.ndata["pos_enc"])
+    base = O.net_forward(*args)
+    ones = {("feat", "s", 1): torch.ones(n, 768), ("attn", "s", 1): torch.ones(E, 2), ("attn", "p", 1): torch.ones(E, 1),
+            ("feat", "p", 1): torch.ones(n, 256), ("feat", "s", 2): torch.ones(n, 384), ("attn", "s", 2): torch.ones(E, 2)}
+    same = O.net_forward(*args, drop=ones)
+    assert all(torch.equal(a, b) for a, b in zip(base, same))
+    gen = torch.Generator().manual_seed(3)
+    fk = (torch.rand(n, 768, generator=gen) >= 0.1).float() / 0.9
+    ak = (torch.rand(E, 2, generator=gen) >= 0.1).float() / 0.9
+    got = O.net_forward(*args, drop={("feat", "s", 1): fk, ("attn", "s", 1): ak})
+    assert (got[0] - base[0]).abs().max() > 1e-3
+    # by hand: level 0 as is, then structure layer 1 on the dropped concatenation with the masked attention
+    sub = {k[4:]: v for k, v in sd.items() if k.startswith("gat.")}
+    x0 = torch.cat([g.ndata["fvs"], g.ndata["pos_enc"]], 1)
+    h_s = O._gat_layer(sub, "gat_layers.0.", src, dst, n, x0, 0.2, F.elu).flatten(1)
+    h_p = O._gat_layer(sub, "pgnn_layers.0.", src, dst, n, g.ndata["pos_enc"], 0.2, torch.tanh).flatten(1)
+    x1 = torch.cat([h_s, h_p], 1) * fk
+    want, a = O.gat_conv(src, dst, n, x1, sub["gat_layers.1.fc.weight"], sub["gat_layers.1.attn_l"], sub["gat_layers.1.attn_r"],
+                         sub["gat_layers.1.res_fc.weight"], sub.get("gat_layers.1.bias"), 0.2, F.elu, attn_keep=ak)
+    h_s1 = O._gat_layer(sub, "gat_layers.1.", src, dst, n, torch.cat([h_s, h_p], 1), 0.2, F.elu, feat_keep=fk, attn_keep=ak)
+    assert torch.equal(want, h_s1)
