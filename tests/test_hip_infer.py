@@ -87,16 +87,18 @@ def test_forward_runner_refuses_a_training_mode_model():
 def test_forward_runner_follows_the_feature_range_of_every_scan(name, n_first, n_second):
     """size classes of 512-640 nodes are large enough for the matrix-core products (ops.MIN_GEMM_ROWS), whose fp16
     split works under a per-tensor power-of-two scale of the node data.  A captured forward must not keep the FIRST scan's
-    scale: the second scan of the class has features 2^12 times larger (fp16 would overflow under the stale scale) - replay,
-    eager forward and the oracle still agree."""
+    scale: the second scan of the class has features 16 times larger (the split leaves two bits of headroom: fp16 overflows
+    under the stale scale) - replay, eager forward and the oracle still agree.  (Not 2^12 as a first version had it: 64 x
+    larger features make the attention logits 64 x larger and the softmax that much worse conditioned - the eager forward
+    itself is then 5e-5 from the oracle.)"""
     cfg, model = _model(name, seed=6)
     runner = ForwardRunner(model, granule=64)
     pe = getattr(cfg, "POS_ENC_DIM", None)
     a = synthetic.make_batch(1, rank=70, device="cuda", pos_enc_dim=pe, fixed_n=n_first)
     b = synthetic.make_batch(1, rank=71, device="cuda", pos_enc_dim=pe, fixed_n=n_second)
     with torch.no_grad():
-        a.ndata["fvs"].mul_(2.0 ** -6)
-        b.ndata["fvs"].mul_(2.0 ** 6)
+        a.ndata["fvs"].mul_(2.0 ** -2)
+        b.ndata["fvs"].mul_(2.0 ** 2)
     for g in (a, b, a):
         got = runner(g)
         assert len(runner._classes) == 1                       # one size class (576 or 640 nodes): one capture serves all three
