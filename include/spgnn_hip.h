@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 60
+#define SPGNN_ABI_VERSION 61
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -835,6 +835,29 @@ int spgnn_masked_ce_rows(const float* logits, int64_t logits_stride, const int64
                          const int32_t* rows_cnt, const float* class_weight, float* partials, float* sums, uint32_t* ticket,
                          float* g_logits, int64_t g_stride, float* colsum_partials, float* g_colsum, int64_t cap, int32_t C,
                          spgnn_stream_t stream);
+
+/*
+ * ABI 61.  The tail of a training step behind the output layer in ONE pass over its rows: the skinny classifier
+ * (reference models.py:1125, 1167-1170: n_out = gnn_out(n_embed)), the masked class-weighted cross entropy of
+ * spgnn_masked_ce_step (job_runner.py:1896-1900; same mask rule, same draws, same NaN weight for a label outside [0, J))
+ * and the classifier's weight / bias gradient.  Replaces spgnn_scores_fwd + spgnn_masked_ce_step + spgnn_scores_bwd_w on
+ * (x, w): x (N, K) is read from HBM once instead of twice.
+ *   logits[n, :]   = x[n, :] w^T + bias                      w (J, Kp) zero padded to Kp = 16 ceil(K / 16), J <= 32
+ *   g_logits[n, :] = m_n class_weight[y_n] (softmax(logits[n, :]) - e_{y_n})        (gradient of the loss NUMERATOR)
+ *   sums           = [sum_n m_n cw[y_n] nll_n, sum_n m_n cw[y_n]]   (last workgroup, block order; `ticket` as spgnn_masked_ce_step)
+ *   w_partials     (B, J, Kp): per-workgroup partials of g_logits^T x, B = ceil(N / spgnn_classifier_ce_rows_per_block(N));
+ *                  add them in block order (spgnn_sum_partials / _multi) for the classifier's weight gradient
+ *   g_colsum       (J) nullable with colsum_partials (B, 32): sum_n g_logits[n, :], the classifier bias' gradient
+ * `flag` nullable: int32[2], flag[1] != 0 turns every weight into NaN (a step whose row list overflowed).
+ * K % 128 == 0, K <= 1024; x rows 16-byte aligned.  partials: (B, 2) workspace.  No host synchronisation.
+ */
+int spgnn_classifier_ce_rows_per_block(int64_t N);
+int spgnn_classifier_ce(const float* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias /* nullable */,
+                        const int64_t* labels, const float* draws /* nullable */, uint64_t draw_seed,
+                        const int64_t* seed_offset /* nullable */, const float* sampling_p, const float* class_weight,
+                        const int32_t* flag /* nullable */, float* logits, int64_t logits_stride, float* g_logits, int64_t g_stride,
+                        float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials /* nullable */,
+                        float* g_colsum /* nullable */, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 
 /*
  * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's

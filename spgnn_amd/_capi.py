@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 60
+ABI_VERSION = 61
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -166,6 +166,9 @@ SIGNATURES = {
     "spgnn_gather_rows": [_f32p, _i64, _vp, _vp, _i64, _i32, _f32p, _i64, _vp],
     "spgnn_expand_rows": [_f32p, _i64, _vp, _i64, _i32, _f32p, _i64, _vp],
     "spgnn_masked_ce_rows": [_f32p, _i64, _vp, _vp, _vp, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _f32p, _i64, _i32, _vp],
+    "spgnn_classifier_ce_rows_per_block": [_i64],
+    "spgnn_classifier_ce": [_f32p, _i64, _f32p, _i32, _f32p, _vp, _f32p, _u64, _vp, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _i64, _f32p, _f32p,
+                            _f32p, _vp, _f32p, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_sgd_momentum_step_mean": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
     "spgnn_sgd_momentum_step_guarded": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "spgnn_masked_ce_step_flagged": [_f32p, _i64, _vp, _f32p, _u64, _vp, _f32p, _vp, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _f32p,

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(os.path.dirname(HERE), "libspgnn_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
-SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_tile.hip", "spgnn_graph.hip", "spgnn_gemm.hip", "spgnn_bf16.hip")]
+SOURCES = [os.path.join(HERE, n) for n in ("spgnn_kernels.hip", "spgnn_lspe.hip", "spgnn_tile.hip", "spgnn_graph.hip", "spgnn_gemm.hip", "spgnn_bf16.hip", "spgnn_head.hip")]
 HEADERS = [os.path.join(ROOT, "include", "spgnn_hip.h"), os.path.join(HERE, "spgnn_internal.h"), os.path.join(HERE, "spgnn_rows.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE]
 # Per-source flags.  The row kernels are built WITHOUT the SLP vectorizer: the packed fp32 ops it forms (v_pk_fma_f32 fed by

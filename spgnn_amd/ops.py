@@ -960,6 +960,69 @@ class _MaskedCE(torch.autograd.Function):
         return g * g_num, None, None, None, None
 
 
+# --------------------------------------------------------------------------------------------
+# The step's loss joined to the node that ends in the classifier (train.TrainStep installs LOSS_HEAD around model(g)):
+# logits, masked cross entropy, logit gradient and the classifier's weight / bias gradient from ONE pass over the classifier's
+# input rows (spgnn_classifier_ce) instead of spgnn_scores_fwd + spgnn_masked_ce_step + spgnn_scores_bwd_w.
+# --------------------------------------------------------------------------------------------
+LOSS_HEAD: Optional["LossHead"] = None
+FUSED_LOSS_HEAD = True           # False: the three separate launches (A/B, tests)
+
+
+class LossHead:
+    """What the loss of the step being issued needs (labels, sampling probabilities, the draws or the seed of the kernel's own
+    draw, class weights, where the two sums go).  The node that takes it sets ``used`` and leaves ``g_logits`` - the gradient of
+    the loss NUMERATOR with respect to the logits it returned: the step starts backward from it
+    (``torch.autograd.backward(logits, g_logits)``) and the node's backward finds the classifier's gradients already formed."""
+
+    def __init__(self, labels, sampling_p, draws, draw_seed: int, class_weight, sums_out, flag=None):
+        self.labels, self.sampling_p, self.draws, self.draw_seed = labels, sampling_p, draws, int(draw_seed)
+        self.class_weight, self.sums_out, self.flag = class_weight, sums_out, flag
+        self.used, self.g_logits = False, None
+
+
+_CE_TICKETS: dict = {}
+
+
+def classifier_ce_supported(x: torch.Tensor, w_cls: torch.Tensor) -> bool:
+    return bool(FUSED_LOSS_HEAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.stride(1) == 1
+                and _rows_aligned(x) and x.shape[1] % 128 == 0 and x.shape[1] <= 1024 and w_cls.shape[0] <= 32
+                and w_cls.shape[1] == x.shape[1] and w_cls.dtype == torch.float32)
+
+
+def classifier_ce(x: torch.Tensor, w_cls: torch.Tensor, b_cls: Optional[torch.Tensor], head: LossHead):
+    """-> (logits (N, J), g_logits (N, J), w_partials (B, J, Kp), g_bias (J,) or None); the two loss sums land in
+    ``head.sums_out``.  The classifier's weight gradient is ``w_partials.sum(0)[:, :K]`` (a deferred SumJob of the caller)."""
+    _require_cuda(x, w_cls, head.labels, head.sampling_p, head.class_weight)
+    N, K = x.shape
+    J = w_cls.shape[0]
+    dev = x.device
+    Kp = _pad16(K)
+    w_p = _padded_rows(w_cls.detach(), Kp)
+    lib = _capi.load()
+    rps = int(lib.spgnn_classifier_ce_rows_per_block(N))
+    B = (N + rps - 1) // rps
+    logits = torch.empty((N, J), dtype=torch.float32, device=dev)
+    g_logits = torch.empty((N, J), dtype=torch.float32, device=dev)
+    wpart = torch.empty((B, J, Kp), dtype=torch.float32, device=dev)
+    part = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    colpart = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    colsum = torch.empty((J,), dtype=torch.float32, device=dev)
+    ticket = _CE_TICKETS.get(str(dev))
+    if ticket is None:
+        ticket = _CE_TICKETS[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    bias_c = None if b_cls is None else b_cls.detach().contiguous()
+    draws = None if head.draws is None else head.draws.contiguous()
+    with torch.cuda.device(dev), _timed("classifier_ce", (N, K, J)):
+        _capi.check(lib.spgnn_classifier_ce(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, _ptr(bias_c), head.labels.data_ptr(), _ptr(draws),
+                                            head.draw_seed & 0xFFFFFFFFFFFFFFFF, _seed_off_ptr(dev) if draws is None else 0,
+                                            head.sampling_p.data_ptr(), head.class_weight.data_ptr(), _ptr(head.flag), logits.data_ptr(),
+                                            logits.stride(0), g_logits.data_ptr(), g_logits.stride(0), wpart.data_ptr(), part.data_ptr(),
+                                            head.sums_out.data_ptr(), ticket.data_ptr(), colpart.data_ptr(), colsum.data_ptr(), N, K, J,
+                                            _stream(x)), "spgnn_classifier_ce")
+    return logits, g_logits, wpart, colsum
+
+
 def column_sums(g: torch.Tensor) -> torch.Tensor:
     """g.sum(0) - or, when ``g`` is the logit gradient the loss kernel just handed over, the column sums that kernel's last
     workgroup already formed (the attribute exists only on that very tensor: any op in between makes a new one)."""
@@ -2486,8 +2549,17 @@ class _GATAggFirstFn(torch.autograd.Function):
             rst = head_mean(out, H, D) if mean else out
         has_cls = w_cls is not None and mean
         logits = None
+        ctx.head = None
         if has_cls:
-            logits = scores_fwd(rst, w_cls, bias=b_cls)
+            head = LOSS_HEAD
+            if head is not None and not head.used and rows is None and rst.shape[0] == head.labels.shape[0] and classifier_ce_supported(rst, w_cls):
+                # the step's loss joins this node: logits, loss sums, logit gradient and the classifier's own gradients from one
+                # pass over the head mean (spgnn_classifier_ce); backward starts from head.g_logits
+                logits, head.g_logits, wpart, colsum = classifier_ce(rst, w_cls, b_cls, head)
+                head.used = True
+                ctx.head = (wpart, colsum)
+            else:
+                logits = scores_fwd(rst, w_cls, bias=b_cls)
         ctx.has_cls, ctx.has_cls_bias = has_cls, has_cls and b_cls is not None
         ctx.save_for_backward(x, wc, w_lr, s, attn, z, out if act != ACT_NONE else None, sz, sw,
                               rst if has_cls else None, w_cls if has_cls else None)
@@ -2515,11 +2587,29 @@ class _GATAggFirstFn(torch.autograd.Function):
         # gradient through the folded score projection (fold_scores' backward), which autograd ADDS to this one on arrival
         jobs = SumJobs(x.device, local=True)
         if ctx.has_cls and g_logits is not None:
-            cs_ = column_sums(g_logits) if (ctx.has_cls_bias and ctx.needs_input_grad[6]) else None
+            head, ctx.head = ctx.head, None
+            cs_ = None
+            if head is None:
+                cs_ = column_sums(g_logits) if (ctx.has_cls_bias and ctx.needs_input_grad[6]) else None
+            elif ctx.has_cls_bias and ctx.needs_input_grad[6]:
+                cs_ = head[1]                                       # the loss kernel's own column sums
             g_logits = g_logits.contiguous()
             fused = g_out is None and act_bwd_proj_supported(H, D, g_logits.shape[1], w_cls)
-            ride = fused and ctx.needs_input_grad[5] and act_bwd_proj_wgrad_supported(H, D, g_logits.shape[1], act, out)
-            if ctx.needs_input_grad[5] and not ride:
+            ride = head is None and fused and ctx.needs_input_grad[5] and act_bwd_proj_wgrad_supported(H, D, g_logits.shape[1], act, out)
+            if ctx.needs_input_grad[5] and head is not None:
+                # g_logits^T rst: the per-workgroup partials are there since the forward pass, only their sum is left
+                wpart = head[0]
+                Bp, Jc, Kpc = wpart.shape
+                if Bp == 1:
+                    g_wcls = wpart[0][:, :rst.shape[1]]
+                else:
+                    g_full = torch.empty((Jc, Kpc), dtype=torch.float32, device=x.device)
+                    jobs.add(_capi.SumJob(kind=0, splits=Bp, partials=wpart.data_ptr(), split_stride=Jc * Kpc, out=g_full.data_ptr(), n=Jc * Kpc),
+                             wpart, g_full)
+                    g_wcls = g_full[:, :rst.shape[1]]
+                    del g_full
+                del wpart, head
+            elif ctx.needs_input_grad[5] and not ride:
                 g_wcls = scores_bwd_w(g_logits, rst, defer=jobs)
             if cs_ is not None:
                 g_bcls = cs_
@@ -2772,7 +2862,15 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
         w_comb, blk, _, b_mean, P, c0 = linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D, x_block=x_block)
         sx = operand_scale(zx)
         y = gemm_nt(zx, w_comb[:, :Kc], sx, blk, bias=b_mean)
-        logits = scores_fwd(zx, P[:, :Kc], bias=c0)
+        head, ctx.head = LOSS_HEAD, None
+        if head is not None and not head.used and zx.shape[0] == head.labels.shape[0] and classifier_ce_supported(zx, P[:, :Kc]):
+            # the step's loss joins this node (spgnn_classifier_ce on the folded classifier): logits, loss sums, logit gradient
+            # and the partials of g_logits^T Zx from one pass over Zx
+            logits, head.g_logits, wpart, colsum = classifier_ce(zx, P[:, :Kc], c0, head)
+            head.used = True
+            ctx.head = (wpart, colsum)
+        else:
+            logits = scores_fwd(zx, P[:, :Kc], bias=c0)
         ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
         ctx.save_for_backward(zx, w_comb, sx, blk, P, w_cls, b_mean)
         return y, logits
@@ -2787,9 +2885,14 @@ class _LinearMeanClassifierFn(torch.autograd.Function):
         g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
         cs = M1 = None
         if g_logits is not None:
-            cs = column_sums(g_logits)
+            head, ctx.head = ctx.head, None
             g_logits = _rowmajor(g_logits)
-            M1 = scores_bwd_w(g_logits, zx)                              # g_logits^T Zx (J, Kc)
+            if head is not None:                          # the loss kernel left the column sums and the partials of g_logits^T Zx
+                cs = head[1]
+                M1 = sum_partials(head[0])[:, :Kc]
+            else:
+                cs = column_sums(g_logits)
+                M1 = scores_bwd_w(g_logits, zx)                          # g_logits^T Zx (J, Kc)
             g_bcls = cs if has_bcls else None
         if g_y is None:                                   # the folded route (the training step): no (N, D) gradient exists
             if ctx.needs_input_grad[0]:

@@ -352,13 +352,24 @@ class TrainStep:
                     rows = ops.loss_rows(p, draws, draw_seed, cap, cnt=self._rows_cnt,      # the same draw the loss kernel makes
                                          forward=self.loss_rows_only is True)
             ops.LOSS_ROWS = rows
+            # the loss itself joins the node that ends in the classifier where that node can take it (ops.LossHead: one pass
+            # for logits, loss sums, logit gradient and the classifier's own gradients); dense steps only
+            head = None
+            if on_gpu and rows is None and not self.loss_rows_only and ops.FUSED_LOSS_HEAD:
+                head = ops.LossHead(y, p, draws, draw_seed, self.class_weight, b.sums_slot)
+            ops.LOSS_HEAD = head
             logits = self.model(g)[0]
             ops.LOSS_ROWS = None
+            ops.LOSS_HEAD = None
             if rows is not None and not rows.used:
                 rows = None                  # this model's head does not take the list: its logits have one row per node
                 self._rows_not_taken = True  # (a property of the model: later steps do not make the list)
             direct = logits.is_cuda
-            if direct:                       # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
+            if head is not None and head.used:
+                # sums already in the bucket's tail; the stored gradient of the numerator starts the backward pass
+                num, den = b.loss_slot, b.wsum_slot
+                torch.autograd.backward(logits, head.g_logits)
+            elif direct:                     # one kernel: mask, log-softmax, weighted NLL sums and the gradient; the two sums
                 nd = ops.masked_ce_sums(logits, y, draws, p, self.class_weight, out=b.sums_slot, draw_seed=draw_seed,
                                         unit_grad=True, rows=rows if (rows is not None and rows.forward) else None,
                                         flag=self._rows_cnt if (rows is not None and not rows.forward) else None)   # land in the bucket's tail
@@ -382,6 +393,7 @@ class TrainStep:
             ops.STEP_SUMS = None
             ops.TN_SIDE = None
             ops.LOSS_ROWS = None
+            ops.LOSS_HEAD = None
             if side is not None:
                 side.join()                  # (also on the error path: never leave the side stream dangling in a capture)
             ops.DEBUG_POISON_DEFERRED = prev_poison
