@@ -2552,7 +2552,8 @@ class _GATAggFirstFn(torch.autograd.Function):
         ctx.head = None
         if has_cls:
             head = LOSS_HEAD
-            if head is not None and not head.used and rows is None and rst.shape[0] == head.labels.shape[0] and classifier_ce_supported(rst, w_cls):
+            if (head is not None and not head.used and (rows is None or not rows.forward) and rst.shape[0] == head.labels.shape[0]
+                    and classifier_ce_supported(rst, w_cls)):
                 # the step's loss joins this node: logits, loss sums, logit gradient and the classifier's own gradients from one
                 # pass over the head mean (spgnn_classifier_ce); backward starts from head.g_logits
                 logits, head.g_logits, wpart, colsum = classifier_ce(rst, w_cls, b_cls, head)

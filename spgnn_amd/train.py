@@ -247,7 +247,7 @@ class TrainStep:
         else:
             skipped, flag = 0, int(self._rows_cnt[1].item())
         if flag == 0:
-            if skipped > getattr(self, "_skipped_seen", 0):
+            if skipped > getattr(self, "_skipped_seen", 0) and self.world == 1:      # (several ranks: another rank's list may have overflowed)
                 # the guarded optimizer kernel skips EVERY step with a non-finite loss; without an overflow that is divergence,
                 # a zero weight sum or a bad label - the reference would propagate the NaN, so say it
                 warnings.warn(f"loss_rows_only: {skipped - getattr(self, '_skipped_seen', 0)} step(s) had a non-finite loss WITHOUT a "
@@ -355,8 +355,10 @@ class TrainStep:
             # the loss itself joins the node that ends in the classifier where that node can take it (ops.LossHead: one pass
             # for logits, loss sums, logit gradient and the classifier's own gradients); dense steps only
             head = None
-            if on_gpu and rows is None and not self.loss_rows_only and ops.FUSED_LOSS_HEAD:
-                head = ops.LossHead(y, p, draws, draw_seed, self.class_weight, b.sums_slot)
+            if on_gpu and ops.FUSED_LOSS_HEAD and (rows is None or not rows.forward) and (rows is not None or not self.loss_rows_only):
+                # (a "backward" loss-rows step has a dense forward: the same kernel, NaN when the step's list overflowed)
+                head = ops.LossHead(y, p, draws, draw_seed, self.class_weight, b.sums_slot,
+                                    flag=self._rows_cnt if rows is not None else None)
             ops.LOSS_HEAD = head
             logits = self.model(g)[0]
             ops.LOSS_ROWS = None
