@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 61
+#define SPGNN_ABI_VERSION 62
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -1174,6 +1174,28 @@ typedef struct spgnn_copy_pad_job {
 } spgnn_copy_pad_job;
 typedef struct spgnn_copy_pad_jobs { spgnn_copy_pad_job job[SPGNN_COPY_PAD_MAX_JOBS]; int32_t n_jobs; } spgnn_copy_pad_jobs;
 int spgnn_copy_pad_i32(const spgnn_copy_pad_jobs* jobs, spgnn_stream_t stream);
+/*
+ * ABI 62.  A whole arena load in one launch: the index arrays of spgnn_copy_pad_i32 (`i32_jobs`, nullable) plus 2-D copies of
+ * rows of 4-byte WORDS (`row_jobs`, nullable; all lengths and strides in words, so fp32 and int64 node data alike):
+ *   dst[r, dst_col : dst_col + width] = src[r, 0 : width]  for r < rows_copy,   = 0  for rows_copy <= r < rows_total
+ * - the loaded batch's node data into the arena's buffers (pad rows a larger earlier batch filled go back to zero) and the
+ * tensors derived from it (cat[fvs, pos_enc] with 16-byte rows, aligned copies; reference models.py:474-477 reads them per
+ * forward) straight from the incoming batch.  Per-scan inference (job_runner.py:2046-2052) paid ~17 small launches here.
+ */
+#define SPGNN_ROW_COPY_MAX_JOBS 16
+typedef struct spgnn_row_copy_job {
+  uint32_t* dst; const uint32_t* src;
+  int64_t dst_stride, src_stride, rows_copy, rows_total;
+  int32_t dst_col, width;
+} spgnn_row_copy_job;
+typedef struct spgnn_row_copy_jobs { spgnn_row_copy_job job[SPGNN_ROW_COPY_MAX_JOBS]; int32_t n_jobs; } spgnn_row_copy_jobs;
+int spgnn_arena_load(const spgnn_copy_pad_jobs* i32_jobs /* nullable */, const spgnn_row_copy_jobs* row_jobs /* nullable */,
+                     spgnn_stream_t stream);
+/* spgnn_ell_rows for both directions of a graph in one launch: nbr8 from (indptr, indices), out_nbr8 / out_pos8 from
+ * (out_indptr, out_indices, out_pos). */
+int spgnn_ell_rows_both(const int32_t* indptr, const int32_t* indices, const int32_t* out_indptr, const int32_t* out_indices,
+                        const int32_t* out_pos, int64_t N, int64_t E, int32_t* nbr8, int32_t* out_nbr8, int32_t* out_pos8,
+                        spgnn_stream_t stream);
 /*
  * The padded neighbour rows the row kernels read next to indptr (`nbr8` / `out_nbr8` / `out_pos8`, N x 8 int32):
  * out[v, k] = arr[min(ptr[v] + min(k, max(deg(v) - 1, 0)), E - 1)] for one or two arrays in the slot order of `ptr`.

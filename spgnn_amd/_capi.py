@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 61
+ABI_VERSION = 62
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -63,6 +63,15 @@ class CopyPadJob(C.Structure):           # spgnn_copy_pad_job
 
 class CopyPadJobs(C.Structure):          # spgnn_copy_pad_jobs
     _fields_ = [("job", CopyPadJob * 8), ("n_jobs", _i32)]
+
+
+class RowCopyJob(C.Structure):           # spgnn_row_copy_job
+    _fields_ = [("dst", _vp), ("src", _vp), ("dst_stride", _i64), ("src_stride", _i64), ("rows_copy", _i64), ("rows_total", _i64),
+                ("dst_col", _i32), ("width", _i32)]
+
+
+class RowCopyJobs(C.Structure):          # spgnn_row_copy_jobs
+    _fields_ = [("job", RowCopyJob * 16), ("n_jobs", _i32)]
 
 
 class SumJob(C.Structure):               # spgnn_sum_job
@@ -166,6 +175,8 @@ SIGNATURES = {
     "spgnn_gather_rows": [_f32p, _i64, _vp, _vp, _i64, _i32, _f32p, _i64, _vp],
     "spgnn_expand_rows": [_f32p, _i64, _vp, _i64, _i32, _f32p, _i64, _vp],
     "spgnn_masked_ce_rows": [_f32p, _i64, _vp, _vp, _vp, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _f32p, _i64, _i32, _vp],
+    "spgnn_arena_load": [_vp, _vp, _vp],
+    "spgnn_ell_rows_both": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "spgnn_classifier_ce_rows_per_block": [_i64],
     "spgnn_classifier_ce": [_f32p, _i64, _f32p, _i32, _f32p, _vp, _f32p, _u64, _vp, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _i64, _f32p, _f32p,
                             _f32p, _vp, _f32p, _f32p, _i64, _i32, _i32, _vp],

@@ -145,8 +145,10 @@ class BatchArena:
         m = (self.e_cap - E - n_pad) // 2
         pieces = _pad_pieces(n_pad, m, dev)                                 # the pad's index arrays on the device (cached per shape)
         with torch.no_grad():
-            # the six index arrays in ONE launch (spgnn_copy_pad_i32): the batch's array, then the pad component's shifted by the
-            # batch's edge / node count (slot offsets: real edges fill slots [0, E), pad nodes follow the real ones)
+            # the six index arrays, every node-data tensor and the tensors derived from node data in ONE launch (spgnn_arena_load,
+            # ABI 62; before: spgnn_copy_pad_i32 + a copy and a zero fill per tensor + a builder call and a copy per derived tensor,
+            # ~17 launches per inference scan).  Index arrays: the batch's array, then the pad component's shifted by the batch's
+            # edge / node count (slot offsets: real edges fill slots [0, E), pad nodes follow the real ones)
             import ctypes
             from . import _capi
             jobs = _capi.CopyPadJobs()
@@ -161,9 +163,10 @@ class BatchArena:
                 jobs.job[q] = _capi.CopyPadJob(dst.data_ptr(), src_.data_ptr(), pad.data_ptr() + 4 * skip, n_real, n_tail, shift, 0)
                 q += 1
             jobs.n_jobs = q
+            rows, slow, derived_done = self._row_jobs(g, N)
             with torch.cuda.device(dev):
-                _capi.check(_capi.load().spgnn_copy_pad_i32(ctypes.addressof(jobs), torch.cuda.current_stream(dev).cuda_stream),
-                            "spgnn_copy_pad_i32")
+                _capi.check(_capi.load().spgnn_arena_load(ctypes.addressof(jobs), ctypes.addressof(rows) if rows.n_jobs else None,
+                                                         torch.cuda.current_stream(dev).cuda_stream), "spgnn_arena_load")
             if self.keep_edges:                                             # src / dst in edge-id order (graph.edges(); no kernel reads them)
                 ed = getattr(g, "_edges_dev", None)
                 s_, d_ = ed if (ed is not None and ed[0].device == self.src.device) else g.edges()
@@ -172,15 +175,11 @@ class BatchArena:
                 ag._edges_dev = (self.src, self.dst)
             else:
                 ag._edges_dev = None                                        # asking for them raises (graph._host_edges)
-            seen = set()
-            for k, v in g.ndata.items():
-                buf = ag.ndata[k]
-                if id(buf) in seen:
-                    continue
-                seen.add(id(buf))
+            for buf, v in slow:                          # (tensors the row-copy jobs cannot express: odd byte widths, strided rows)
                 buf[:N].copy_(v)
                 if self._rows_dirty > N:                 # pad rows a LARGER earlier batch filled: back to zero (else they still are)
                     buf[N:self._rows_dirty].zero_()
+        self._derived_done = derived_done
         self._rows_dirty = N
         acsc.min_in_degree = min(csc.min_in_degree, 1)
         acsc.max_in_degree = max(csc.max_in_degree, 3 if m > 1 else (2 if m == 1 else 1))
@@ -195,6 +194,88 @@ class BatchArena:
         self.loads += 1
         return ag
 
+    @staticmethod
+    def _words(t: torch.Tensor):
+        """(words per row, row stride in words) of a tensor whose rows can be copied as 4-byte words, else None."""
+        es = t.element_size()
+        if t.dim() == 0 or es % 4 or t.data_ptr() % 4:
+            return None
+        if t.dim() == 1:
+            return (es // 4, es // 4) if t.stride(0) == 1 else None
+        inner = 1
+        for d in range(t.dim() - 1, 0, -1):              # dims 1.. must be dense; dim 0 may carry a padded stride
+            if t.stride(d) != inner:
+                return None
+            inner *= t.shape[d]
+        if t.stride(0) < inner or inner == 0:
+            return None
+        return inner * es // 4, t.stride(0) * es // 4
+
+    def _row_jobs(self, g: G.TreeGraph, N: int):
+        """The row-copy jobs of one load: every node-data tensor of ``g`` into its arena buffer, and the derived tensors whose
+        recipe is a plain concatenation / aligned copy of node data (models._data_cat / _data_aligned) straight from ``g``'s
+        tensors.  -> (jobs, [(buffer, tensor)] left to torch copies, the derived keys the jobs cover).
+        The job table is PLANNED once per layout of the incoming node data (names, widths, dtypes, strides) and set of derived
+        tensors; a load then only fills in the source pointers and the two row counts (per-scan inference: the planning was
+        a third of the host time of a scan)."""
+        from . import _capi
+        ag = self.graph
+        sig = (tuple((k, tuple(v.shape[1:]), v.dtype, v.stride()) for k, v in g.ndata.items()), tuple(ag._derived_builders))
+        plan = self._plan if getattr(self, "_plan_sig", None) == sig else None
+        if plan is None:
+            entries, slow_names, done = [], [], set()       # entries: (dst tensor, dst stride, dst col, width, source name, src stride)
+
+            def add(dst, dst_col_w, src, name):
+                ws, wd = self._words(src), self._words(dst)
+                if ws is None or wd is None or len(entries) >= 16 or src.dtype != dst.dtype or dst_col_w + ws[0] > wd[1]:
+                    return False
+                entries.append((dst, wd[1], dst_col_w, ws[0], name, ws[1]))
+                return True
+            seen = set()
+            for k, v in g.ndata.items():
+                buf = ag.ndata[k]
+                if id(buf) in seen:
+                    continue
+                seen.add(id(buf))
+                if not (tuple(buf.shape[1:]) == tuple(v.shape[1:]) and add(buf, 0, v, k)):
+                    slow_names.append(k)
+            for key in list(ag._derived_builders):
+                held = ag._tensor_cache[key]
+                names = None
+                if key[0] == "cat" and all(isinstance(k_, tuple) and k_[0] == "ndata" for k_ in key[1:]):
+                    names = [k_[1] for k_ in key[1:]]
+                elif key[0] == "aligned" and isinstance(key[1], tuple) and key[1][0] == "ndata":
+                    names = [key[1][1]]
+                parts = [g.ndata.get(n_) for n_ in names] if names else None
+                if not parts or any(p_ is None or p_.dim() != 2 or p_.dtype != held.dtype for p_ in parts) or held.dim() != 2 \
+                        or sum(p_.shape[1] for p_ in parts) != held.shape[1] or len(entries) + len(parts) > 16:
+                    continue
+                n0, col, ok = len(entries), 0, True
+                for n_, p_ in zip(names, parts):
+                    ok = ok and add(held, col * held.element_size() // 4, p_, n_)
+                    col += p_.shape[1]
+                if ok:
+                    done.add(key)
+                else:
+                    del entries[n0:]
+            jobs = _capi.RowCopyJobs()
+            for q, (dst, dstr, dcol, w, _name, sstr) in enumerate(entries):
+                jobs.job[q] = _capi.RowCopyJob(dst.data_ptr(), 0, dstr, sstr, 0, 0, dcol, w)
+            jobs.n_jobs = len(entries)
+            plan = self._plan = (jobs, entries, slow_names, done)
+            self._plan_sig = sig
+        jobs, entries, slow_names, done = plan
+        total = max(N, self._rows_dirty)
+        nd = g.ndata
+        bump = torch.autograd.graph.increment_version
+        for q, e in enumerate(entries):
+            j = jobs.job[q]
+            j.src, j.rows_copy, j.rows_total = nd[e[4]].data_ptr(), N, total
+            # the kernel writes behind torch's back: what torch's own copy_ did for the caches keyed on a tensor's version
+            # (TrainStep._sampling recomputes the sampling probabilities when ndata['y'] changed; ops.operand_scale)
+            bump(e[0])
+        return jobs, [(ag.ndata[k], nd[k]) for k in slow_names], done
+
     def _refresh(self, acsc: G.DeviceCSC) -> None:
         """Everything computed FROM the batch, recomputed into the storage a captured step already addresses: the padded
         neighbour rows and degree vectors of the graph, the cached concatenations / aligned copies of node data with their
@@ -206,6 +287,14 @@ class BatchArena:
             try:
                 for key, val in old.items():
                     if key == "ell":
+                        if acsc.indptr.is_cuda and acsc.num_edges > 0:       # both directions in one launch, into the cached rows
+                            from . import _capi
+                            with torch.cuda.device(self.device):
+                                _capi.check(_capi.load().spgnn_ell_rows_both(
+                                    acsc.indptr.data_ptr(), acsc.indices.data_ptr(), acsc.out_indptr.data_ptr(), acsc.out_indices.data_ptr(),
+                                    acsc.out_pos.data_ptr(), acsc.num_nodes, acsc.num_edges, val[0].data_ptr(), val[1].data_ptr(),
+                                    val[2].data_ptr(), torch.cuda.current_stream(self.device).cuda_stream), "spgnn_ell_rows_both")
+                            continue
                         new = acsc.ell()
                     elif key == "in_deg":
                         new = acsc.in_degrees_f()
@@ -224,9 +313,11 @@ class BatchArena:
                         o.copy_(n_)
             finally:
                 acsc._cache = old                    # the tensors a captured step addresses stay the cached ones, whatever happened
+            done = getattr(self, "_derived_done", ())
             for key, builder in list(ag._derived_builders.items()):
                 held = ag._tensor_cache[key]
-                held.copy_(builder())
+                if key not in done:                      # (the load's row-copy jobs wrote the plain concatenations already)
+                    held.copy_(builder())
                 if self.refresh_constants:
                     ops.refresh_batch_constant(held)
             seen = set()

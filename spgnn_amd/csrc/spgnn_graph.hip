@@ -133,9 +133,89 @@ __global__ __launch_bounds__(256) void copy_pad_i32_kernel(spgnn_copy_pad_jobs j
     j.dst[i] = i < j.n ? j.src[i] : j.pad[i - j.n] + j.pad_add;
 }
 
+// An arena load in ONE launch (ABI 62): the index arrays of spgnn_copy_pad_i32 (blockIdx.y < n_i32) and 2-D row copies of
+// 4-byte words (the rest): dst[r, col : col + width] = src[r, 0 : width] for r < rows_copy, zeros for rows_copy <= r < rows_total
+// - node data into the arena's buffers (pad rows a larger earlier batch left behind back to zero) and the derived tensors
+// (cat[fvs, pos_enc], 16-byte-row copies) straight from the incoming batch.
+__global__ __launch_bounds__(256) void arena_load_kernel(spgnn_copy_pad_jobs ij, spgnn_row_copy_jobs rj) {
+  if ((int)blockIdx.y < ij.n_jobs) {
+    const spgnn_copy_pad_job& j = ij.job[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)j.n + j.n_pad; i += (int64_t)gridDim.x * 256)
+      j.dst[i] = i < j.n ? j.src[i] : j.pad[i - j.n] + j.pad_add;
+    return;
+  }
+  const spgnn_row_copy_job& j = rj.job[blockIdx.y - ij.n_jobs];
+  const int64_t w = j.width, total = j.rows_total * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / w, c = i - r * w;
+    j.dst[r * j.dst_stride + j.dst_col + c] = r < j.rows_copy ? j.src[r * j.src_stride + c] : 0u;
+  }
+}
+
+// Both directions' padded neighbour rows in one launch: blockIdx.y = 0: nbr8 from (indptr, indices); 1: out_nbr8 / out_pos8.
+__global__ __launch_bounds__(256) void ell_rows_both_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                            const int32_t* __restrict__ out_indptr, const int32_t* __restrict__ out_indices,
+                                                            const int32_t* __restrict__ out_pos, int64_t N, int64_t E,
+                                                            int32_t* __restrict__ nbr8, int32_t* __restrict__ out_nbr8,
+                                                            int32_t* __restrict__ out_pos8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * 8) return;
+  const bool outd = blockIdx.y == 1;
+  const int32_t* ptr = outd ? out_indptr : indptr;
+  const int64_t v = i >> 3;
+  const int k = (int)(i & 7);
+  const int beg = ptr[v], deg = ptr[v + 1] - beg;
+  int64_t pos = (int64_t)beg + (k < deg - 1 ? k : (deg > 0 ? deg - 1 : 0));
+  pos = pos < E - 1 ? pos : E - 1;
+  if (outd) { out_nbr8[i] = out_indices[pos]; out_pos8[i] = out_pos[pos]; }
+  else nbr8[i] = indices[pos];
+}
+
 }  // namespace
 
 extern "C" {
+
+int spgnn_arena_load(const spgnn_copy_pad_jobs* i32_jobs, const spgnn_row_copy_jobs* row_jobs, spgnn_stream_t stream) {
+  spgnn_copy_pad_jobs ij; ij.n_jobs = 0;
+  spgnn_row_copy_jobs rj; rj.n_jobs = 0;
+  if (i32_jobs) ij = *i32_jobs;
+  if (row_jobs) rj = *row_jobs;
+  if (ij.n_jobs < 0 || ij.n_jobs > SPGNN_COPY_PAD_MAX_JOBS || rj.n_jobs < 0 || rj.n_jobs > SPGNN_ROW_COPY_MAX_JOBS)
+    return fail(SPGNN_ERR_SHAPE, "spgnn_arena_load: bad job count");
+  int64_t longest = 0;
+  for (int q = 0; q < ij.n_jobs; ++q) {
+    const spgnn_copy_pad_job& j = ij.job[q];
+    if (j.n < 0 || j.n_pad < 0) return fail(SPGNN_ERR_SHAPE, "spgnn_arena_load: negative length");
+    if (!j.dst || (j.n > 0 && !j.src) || (j.n_pad > 0 && !j.pad)) return fail(SPGNN_ERR_NULLPTR, "spgnn_arena_load: null pointer");
+    longest = longest > (int64_t)j.n + j.n_pad ? longest : (int64_t)j.n + j.n_pad;
+  }
+  for (int q = 0; q < rj.n_jobs; ++q) {
+    const spgnn_row_copy_job& j = rj.job[q];
+    if (j.width <= 0 || j.rows_copy < 0 || j.rows_total < j.rows_copy || j.dst_col < 0 || j.dst_stride < j.dst_col + j.width || j.src_stride < j.width)
+      return fail(SPGNN_ERR_SHAPE, "spgnn_arena_load: bad row-copy job");
+    if (!j.dst || (j.rows_copy > 0 && !j.src)) return fail(SPGNN_ERR_NULLPTR, "spgnn_arena_load: null pointer");
+    const int64_t n = j.rows_total * j.width;
+    longest = longest > n ? longest : n;
+  }
+  if (longest == 0 || ij.n_jobs + rj.n_jobs == 0) return SPGNN_OK;
+  int64_t bx = (longest + 1023) / 1024;                    // about four words per thread
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(arena_load_kernel, dim3((unsigned)bx, (unsigned)(ij.n_jobs + rj.n_jobs)), dim3(256), 0, (hipStream_t)stream, ij, rj);
+  return check_launch("spgnn_arena_load");
+}
+
+int spgnn_ell_rows_both(const int32_t* indptr, const int32_t* indices, const int32_t* out_indptr, const int32_t* out_indices,
+                        const int32_t* out_pos, int64_t N, int64_t E, int32_t* nbr8, int32_t* out_nbr8, int32_t* out_pos8,
+                        spgnn_stream_t stream) {
+  if (N < 0 || E < 0 || N > (1ll << 27)) return fail(SPGNN_ERR_SHAPE, "spgnn_ell_rows_both: bad N / E");
+  if (N == 0) return SPGNN_OK;
+  if (E == 0) return fail(SPGNN_ERR_SHAPE, "spgnn_ell_rows_both: a graph without edges has no neighbour rows");
+  if (!indptr || !indices || !out_indptr || !out_indices || !out_pos || !nbr8 || !out_nbr8 || !out_pos8)
+    return fail(SPGNN_ERR_NULLPTR, "spgnn_ell_rows_both: null pointer");
+  hipLaunchKernelGGL(ell_rows_both_kernel, dim3((unsigned)((N * 8 + 255) / 256), 2u), dim3(256), 0, (hipStream_t)stream, indptr, indices,
+                     out_indptr, out_indices, out_pos, N, E, nbr8, out_nbr8, out_pos8);
+  return check_launch("spgnn_ell_rows_both");
+}
 
 int spgnn_copy_pad_i32(const spgnn_copy_pad_jobs* jobs, spgnn_stream_t stream) {
   if (!jobs) return fail(SPGNN_ERR_NULLPTR, "spgnn_copy_pad_i32: null pointer");
