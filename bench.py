@@ -1099,6 +1099,8 @@ def main():
     ap.add_argument("--batch-cycle-only", action="store_true", help="run only the loader-batch cycle leg (secondary.batch_cycle_64) and print it")
     ap.add_argument("--single-tree-only", action="store_true", help="run only the per-scan inference leg (secondary.single_tree_forward) and print it")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-side-stream", action="store_true", help="ops.OVERLAP_TN off: every launch of the timed step alone on its stream "
+                    "(how roofline.hbm_frac is measured; the profile of such a run makes that figure reproducible from rocprofv3 --stats)")
     ap.add_argument("--full-line", action="store_true", help="print the FULL nested object on stdout (tools/; tens of KB) instead of the "
                     "driver's flat line; the default writes it to --detail-out only")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full nested object of the run goes")
@@ -1138,6 +1140,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
+    if args.no_side_stream:
+        from spgnn_amd import ops as _ops
+        _ops.OVERLAP_TN = False
     if args.batch_cycle_only:
         print(json.dumps({"batch_cycle_64": batch_cycle(dev)}), flush=True)
         return

@@ -16,15 +16,15 @@ pmc() {  # <config> <dtype> <trees>
   (cd $R && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/write -- python3 tools/pmc_step.py $c $dt $t $D/manifest_w.json > $D.write.log 2>&1) || return 1
   (cd $R && python3 tools/pmc_merge.py $D/fetch $D/write $D/manifest.json profiles/${TAG}_pmc_traffic_${c}_${dt}${sfx}.md profiles/traffic_latest.json)
 }
-prof() {  # <config> <dtype>
-  local c=$1 dt=$2 D=$O/prof_${1}_${2}
-  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt} -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary"
-  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary > $D.log 2> $D.err) || return 1
+prof() {  # <config> <dtype> [extra bench flag] [file suffix]
+  local c=$1 dt=$2 X=$3 S=$4 D=$O/prof_${1}_${2}$4
+  local CMD="rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/prof_${c}_${dt}${S} -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary $X"
+  (cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --full-line --config $c --dtype $dt --no-cpu-baseline --no-secondary $X > $D.log 2> $D.err) || return 1
   grep '^{' $D.log | tail -1 > $D.json
-  (cd $R && python3 tools/save_profile.py $D $TAG $D.json "$CMD" > $D.summary.txt)
-  (cd $R && python3 tools/trace_steps.py $D > profiles/${TAG}_step_sequence_${c}_${dt}.txt 2> /dev/null) || true
+  (cd $R && python3 tools/save_profile.py $D $TAG $D.json "$CMD" $S > $D.summary.txt)
+  (cd $R && python3 tools/trace_steps.py $D > profiles/${TAG}_step_sequence_${c}_${dt}${S}.txt 2> /dev/null) || true
 }
-pmc st_pgat_spgnn_3 f32 512 && pmc st_gat_6 bf16 512 && pmc st_pgat_spgnn_3 f32 64 && pmc st_gat_3 f32 64 && prof st_pgat_spgnn_3 f32 && prof st_gat_6 bf16 || echo "MEASURE STEP FAILED"
+pmc st_pgat_spgnn_3 f32 512 && pmc st_gat_6 bf16 512 && pmc st_pgat_spgnn_3 f32 64 && pmc st_gat_3 f32 64 && prof st_pgat_spgnn_3 f32 && prof st_pgat_spgnn_3 f32 --no-side-stream _no_side_stream && prof st_gat_6 bf16 || echo "MEASURE STEP FAILED"
 echo "profiling done" > $O/progress.txt
 cd $R
 python bench.py --full-line --no-secondary > $O/bench_f32.log 2> $O/bench_f32.err; grep '^{' $O/bench_f32.log | tail -1 > profiles/${TAG}_bench_st_pgat_spgnn_3_f32.json

@@ -1,15 +1,16 @@
 """Copy a rocprofv3 kernel_stats.csv into profiles/ with a markdown summary.
-usage: save_profile.py <rocprof dir> <tag> <bench_json> <command>"""
+usage: save_profile.py <rocprof dir> <tag> <bench_json> <command> [suffix]"""
 import glob, json, os, re, shutil, sys
 import pandas as pd
 
 d, tag, bj, cmd = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+sfx = sys.argv[5] if len(sys.argv) > 5 else ""
 f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 b = json.load(open(bj))
 cfgname, dtype = b["config"]["workload"].split(",")[0].split()[0], b["dtype"]
-stem = f"profiles/{tag}_kernel_stats_{cfgname}_{dtype}"
+stem = f"profiles/{tag}_kernel_stats_{cfgname}_{dtype}{sfx}"
 shutil.copy(f, stem + ".csv")
-shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof_{cfgname}_{dtype}.json")
+shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof_{cfgname}_{dtype}{sfx}.json")
 df = pd.read_csv(f).sort_values("TotalDurationNs", ascending=False)
 tot = df.TotalDurationNs.sum()
 rf = b["roofline"]
