@@ -10,7 +10,8 @@ graph launch.  No gradients, no dropout (``model.eval()``), outputs sliced back 
 
 The parameters are FROZEN for a runner: what the forward derives from them alone (the projection operands of
 spgnn_weight_prep, the folded score vectors) is computed once and kept out of the captured graph, so a replay starts at the
-first kernel that touches node data.  After loading other weights into the model call ``runner.reset()``.
+first kernel that touches node data.  A change of the parameters is noticed at the next call (their version counters and
+the update epoch ``train.TrainStep`` keeps on the model) and drops the captures; ``runner.reset()`` does the same by hand.
 """
 from __future__ import annotations
 
@@ -32,6 +33,7 @@ class ForwardRunner:
         self.model, self.granule, self.max_classes = model, granule, max_classes
         self._classes: Dict[tuple, Tuple[BatchArena, torch.cuda.CUDAGraph, tuple]] = {}
         self._frozen: dict = {}                    # ops.FROZEN_WEIGHTS of this runner: what the forward derives from the parameters alone
+        self._stamp = self._fingerprint()
 
     def _forward(self, ag):
         """The model's forward with this runner's frozen-weight cache installed and the step's scale blocks pooled (one re-arm
@@ -72,10 +74,23 @@ class ForwardRunner:
         """Drop every capture and the frozen-weight cache: call after the model's parameters changed (another checkpoint)."""
         self._classes.clear()
         self._frozen = {}
+        self._stamp = self._fingerprint()
+
+    def _fingerprint(self):
+        """What tells that the parameters changed since the captures were made: every parameter's version counter
+        (load_state_dict, optimizer.step, any in-place update through torch bump it) and the model's update epoch, which
+        train.TrainStep advances on every step and replay - its fused optimizer kernel writes the flat bucket through raw
+        pointers, which no version counter sees.  A few microseconds per call; a change drops the captures (reset())."""
+        ps = self.__dict__.get("_params")
+        if ps is None:                             # (the module tree is walked once: ~40 us for 60 parameters, per scan otherwise)
+            ps = self._params = list(self.model.parameters())
+        return ([p._version for p in ps], getattr(self.model, "_spgnn_param_epoch", 0))
 
     def __call__(self, g):
         if self.model.training:
             raise RuntimeError("ForwardRunner replays an eval-mode forward: call model.eval() first")
+        if self._classes and self._fingerprint() != self._stamp:
+            self.reset()                           # the parameters moved under the frozen operands: capture again with the new ones
         key = BatchArena.class_key(g, self.granule)
         hit = self._classes.pop(key, None)
         if hit is None:

@@ -290,8 +290,15 @@ class TrainStep:
             store[self.sampling_rate] = (y, y._version, p)
         return store[self.sampling_rate][2]
 
+    def _touched(self) -> None:
+        """The parameters are about to change behind torch's back (the fused optimizer kernel writes the flat bucket through raw
+        pointers: no version counter moves): advance the model's update epoch, which infer.ForwardRunner reads."""
+        m = self.model
+        m._spgnn_param_epoch = getattr(m, "_spgnn_param_epoch", 0) + 1
+
     def step(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns the (global) loss as a device scalar; never synchronises with the host."""
+        self._touched()
         return self._back(self._reduce(self._front(g, draws)))
 
     def _front(self, g, draws: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -585,6 +592,7 @@ class TrainStep:
     def replay(self) -> torch.Tensor:
         if self._graph is None:
             raise RuntimeError("no captured step is selected (capture() first; the selected capture's arena may have been evicted)")
+        self._touched()
         self._graph.replay()
         if self._graph_back is not None:
             self._reduce(self.bucket.loss_slot)

@@ -108,3 +108,38 @@ def test_forward_runner_follows_the_feature_range_of_every_scan(name, n_first, n
         assert torch.isfinite(got[0]).all()
         assert rel_err(got[0], eager[0]) < 2e-6, (name, rel_err(got[0], eager[0]))
         assert rel_err(got[0], ref[0]) < 1e-5, (name, rel_err(got[0], ref[0]))
+
+
+def test_forward_runner_notices_updated_parameters():
+    """a ForwardRunner keeps operands derived from the parameters OUT of its captured graph (frozen weights).  A
+    training step between two scans (the fused optimizer kernel writes the flat bucket through raw pointers) or a
+    load_state_dict must not leave it replaying stale operands: the runner notices (update epoch / version counters), drops
+    its captures and records new ones - no reset() by hand."""
+    from spgnn_amd.configs import class_weight_list
+    from spgnn_amd.train import TrainStep
+    cfg, model = _model("st_pgat_spgnn_3", seed=8)
+    runner = ForwardRunner(model, granule=64)
+    g = synthetic.make_batch(1, rank=80, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM, fixed_n=150)
+    a = runner(g)[0].clone()
+    with torch.no_grad():
+        assert rel_err(a, model(g)[0]) < 2e-6
+    batch = synthetic.make_batch(4, rank=81, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
+    model.train()
+    ts = TrainStep(model, class_weight_list(cfg.CLASS_WEIGHTS), cfg.SAMPLING_RATE, 0.05, 0.9)
+    for _ in range(3):
+        ts.step(batch)
+    model.eval()
+    b = runner(g)[0].clone()
+    with torch.no_grad():
+        want = model(g)[0]
+    assert rel_err(b, want) < 2e-6 and rel_err(b, a) > 1e-4          # the new weights, not the frozen ones
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+    c = runner(g)[0].clone()
+    with torch.no_grad():
+        assert rel_err(c, model(g)[0]) < 2e-6 and rel_err(c, b) > 1e-4
+    model.load_state_dict(sd)
+    d = runner(g)[0]
+    assert rel_err(d, b) < 2e-6
