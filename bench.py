@@ -336,6 +336,11 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
         if float(ok) == 0.0:
             launch = "eager"
     run_step = step.replay if launch != "eager" else (lambda: step.step(g))
+    import gc
+    gc.collect()                                    # a collection of the previous leg's objects inside a 20-step leg showed up
+    gc.disable()                                    # as 1.54 ms wall against 1.11 ms by events (r03): keep the host out of it.
+    # (collected HERE, before the last warm replays: a collection right in front of the timed region left the GPU idle for
+    # ~0.1 s and the first timed steps ran at a lower clock - 5.12 ms per step over 20 steps against 4.9-5.0 steady)
     for _ in range(3):                              # replays of the fresh graphs before the clock starts
         loss = run_step()
     sync()
@@ -356,9 +361,6 @@ def run_leg(config, dtype, trees, steps, warmup, *, rank, world, dev, eager=Fals
             r = plain_reduce(loss_num)
             pair[1].record()
             return r
-    import gc
-    gc.collect()                                    # a collection of the previous leg's objects inside a 20-step leg showed up
-    gc.disable()                                    # as 1.54 ms wall against 1.11 ms by events (r03): keep the host out of it
     try:
         if comm_ev is not None:
             step._reduce = timed_reduce
