@@ -119,7 +119,7 @@ def algorithmic_bytes(key) -> float:
         return 4 * 2 * N * C + 4 * 4 * N
     if base == "classifier_ce":      # classifier + loss + its weight gradient from one read of the rows: x in, logits and g_logits out
         _, N, K, J = key
-        return 4 * N * K + 4 * 2 * N * J
+        return s * N * K + 4 * 2 * N * J
     if base == "loss_rows":          # the step's mask as a row list (TrainStep(loss_rows_only=True)): read p twice, write idx and inv
         _, N, cap = key
         return 4 * 3 * N + 4 * cap

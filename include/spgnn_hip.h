@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPGNN_ABI_VERSION 62
+#define SPGNN_ABI_VERSION 63
 
 #define SPGNN_OK            0
 #define SPGNN_ERR_NULLPTR  -1
@@ -845,19 +845,30 @@ int spgnn_masked_ce_rows(const float* logits, int64_t logits_stride, const int64
  *   logits[n, :]   = x[n, :] w^T + bias                      w (J, Kp) zero padded to Kp = 16 ceil(K / 16), J <= 32
  *   g_logits[n, :] = m_n class_weight[y_n] (softmax(logits[n, :]) - e_{y_n})        (gradient of the loss NUMERATOR)
  *   sums           = [sum_n m_n cw[y_n] nll_n, sum_n m_n cw[y_n]]   (last workgroup, block order; `ticket` as spgnn_masked_ce_step)
- *   w_partials     (B, J, Kp): per-workgroup partials of g_logits^T x, B = ceil(N / spgnn_classifier_ce_rows_per_block(N));
+ *   w_partials     (B, J, Kp): partials of g_logits^T x, B = spgnn_classifier_ce_partial_slices(N, K, J);
  *                  add them in block order (spgnn_sum_partials / _multi) for the classifier's weight gradient
  *   g_colsum       (J) nullable with colsum_partials (B, 32): sum_n g_logits[n, :], the classifier bias' gradient
  * `flag` nullable: int32[2], flag[1] != 0 turns every weight into NaN (a step whose row list overflowed).
  * K % 128 == 0, K <= 1024; x rows 16-byte aligned.  partials: (B, 2) workspace.  No host synchronisation.
  */
 int spgnn_classifier_ce_rows_per_block(int64_t N);
+/* slices of `w_partials` (the B above) for a problem: workgroups x row groups (rows of at most 512 columns with 17 .. 24
+ * classes are shared by 2 or 4 groups of the workgroup's column threads, each with a partial slice of its own) */
+int64_t spgnn_classifier_ce_partial_slices(int64_t N, int32_t K, int32_t J);
 int spgnn_classifier_ce(const float* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias /* nullable */,
                         const int64_t* labels, const float* draws /* nullable */, uint64_t draw_seed,
                         const int64_t* seed_offset /* nullable */, const float* sampling_p, const float* class_weight,
                         const int32_t* flag /* nullable */, float* logits, int64_t logits_stride, float* g_logits, int64_t g_stride,
                         float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials /* nullable */,
                         float* g_colsum /* nullable */, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
+/* ABI 63: the same pass over bf16 rows (BASELINE config 4: the folded classifier of the linear-mean output layer reads the bf16
+ * rows [z_0 .. z_{H-1} | x]); the rows are widened to fp32 exactly, every product and sum is fp32 as above.  x rows 8-byte aligned. */
+int spgnn_classifier_ce_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias /* nullable */,
+                             const int64_t* labels, const float* draws /* nullable */, uint64_t draw_seed,
+                             const int64_t* seed_offset /* nullable */, const float* sampling_p, const float* class_weight,
+                             const int32_t* flag /* nullable */, float* logits, int64_t logits_stride, float* g_logits, int64_t g_stride,
+                             float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials /* nullable */,
+                             float* g_colsum /* nullable */, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream);
 
 /*
  * Neighbour sampling on the device-resident CSC: dgl.sampling.sample_neighbors + dgl.to_block of the reference's

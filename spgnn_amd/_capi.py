@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspgnn_hip.so")
-ABI_VERSION = 62
+ABI_VERSION = 63
 
 _i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _f32p = C.c_void_p
@@ -178,8 +178,11 @@ SIGNATURES = {
     "spgnn_arena_load": [_vp, _vp, _vp],
     "spgnn_ell_rows_both": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp],
     "spgnn_classifier_ce_rows_per_block": [_i64],
+    "spgnn_classifier_ce_partial_slices": [_i64, _i32, _i32],
     "spgnn_classifier_ce": [_f32p, _i64, _f32p, _i32, _f32p, _vp, _f32p, _u64, _vp, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _i64, _f32p, _f32p,
                             _f32p, _vp, _f32p, _f32p, _i64, _i32, _i32, _vp],
+    "spgnn_classifier_ce_bf16": [_vp, _i64, _f32p, _i32, _f32p, _vp, _f32p, _u64, _vp, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _i64, _f32p, _f32p,
+                                 _f32p, _vp, _f32p, _f32p, _i64, _i32, _i32, _vp],
     "spgnn_sgd_momentum_step_mean": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _f32, _f32, _f32, _i32, _vp],
     "spgnn_sgd_momentum_step_guarded": [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "spgnn_masked_ce_step_flagged": [_f32p, _i64, _vp, _f32p, _u64, _vp, _f32p, _vp, _f32p, _f32p, _f32p, _vp, _f32p, _i64, _f32p, _f32p,
@@ -269,7 +272,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise SpgnnLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials", "spgnn_tree_anchors_workspace", "spgnn_weight_prep_blocks", "spgnn_linear_mean_fold_workspace") else C.c_int
+        fn.restype = C.c_char_p if name == "spgnn_last_error" else C.c_int64 if name in ("spgnn_cat_dropout_blocks", "spgnn_weight_cat_partials", "spgnn_tree_anchors_workspace", "spgnn_weight_prep_blocks", "spgnn_linear_mean_fold_workspace", "spgnn_classifier_ce_partial_slices") else C.c_int
     ver = lib.spgnn_abi_version()
     if ver != ABI_VERSION:
         raise SpgnnLibraryError(f"{LIB_PATH} has ABI version {ver}, python side expects {ABI_VERSION}; rebuild")

@@ -64,8 +64,16 @@ __device__ __forceinline__ void pk_fma4(Acc4& acc, float g, f32x2 xlo, f32x2 xhi
 // the kernel.  The block's J x K partial goes out once, at the end (spgnn_sum_partials_multi adds the blocks in order); loss
 // sums and bias gradient as in masked_ce_kernel (last workgroup, block order).  Deterministic: no atomics on data.
 // =================================================================================================
+struct bf16s { uint16_t bits; };             // bfloat16 storage of the rows (BASELINE config 4); every product is formed in fp32
+__device__ __forceinline__ float4 ldrow(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldrow(const bf16s* p) {       // four bf16 -> fp32, exact
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+
 struct ClsCe {
-  const float* x; int64_t ldx; const float* w; int Kp; const float* bias; const int64_t* labels; const float* draws;
+  const void* x; int64_t ldx; const float* w; int Kp; const float* bias; const int64_t* labels; const float* draws;
   uint64_t draw_seed; const int64_t* seed_off; const float* sampling_p; const float* class_w; const int32_t* flag;
   float* logits; int64_t ldl; float* g_logits; int64_t ldg; float* wpart; float* partial; float* sums; unsigned* ticket;
   float* colpart; float* colsum; int64_t N; int K; int J; int64_t rps;
@@ -80,15 +88,20 @@ constexpr int kCeThreads = 512;             // waves 0-3: logits on the matrix p
 // first read; global STORES of one role are never read by the other inside the kernel.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NG, int JA>
+// ST: storage type of the rows of x (float, or bf16s: two-byte rows, fp32 arithmetic).  RH (1, 2, 4): row groups of the C role -
+// with K <= 512 only K / 4 of the 256 C-threads have columns, so RH groups of them share a chunk's 16 rows (16 / RH rows each,
+// own accumulators, own partial slice): the folded classifier of the GAT heads reads 384-wide rows.
+template <typename ST, int NG, int JA, int RH>
 __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
+  constexpr int RPT = 16 / RH;               // rows of a chunk per C-thread
   // One workgroup per CU, two ROLES that work on neighbouring 16-row chunks at the same time (each SIMD hosts one wave of
   // either role, so the matrix pipe and the vector ALUs run side by side):
   //   A-waves (0-3): keep their W fragments in registers for the whole kernel (wave w: k range [w K/4, (w+1) K/4), 16 x J logits of
   //            chunk c on v_mfma_f32_16x16x4_f32 with the rows read from LDS), then 16 lanes per row: softmax, loss terms,
   //            logit gradient -> gl (LDS) and global;
   //   C-waves (4-7): thread t owns columns 4t .. 4t+3: loads the rows of chunk c + 2 (in flight under a whole step), writes chunk
-  //            c + 1 to the staging buffer, and adds g_logits[c - 1]^T x[c - 1] into its persistent J x 4 accumulators.
+  //            c + 1 to the staging buffer, and adds g_logits[c - 1]^T x[c - 1] into its persistent J x 4 accumulators
+  //            (RH > 1: thread (column group, row group h) does that for rows [h RPT, (h + 1) RPT) of every chunk).
   // Step c:   H1  A: logits(c) from S[c % 2]            | C: weight gradient of chunk c - 1 (S[(c-1) % 2], gl[(c-1) % 2])
   //           barrier
   //           H2  A: softmax / loss (c) -> gl[c % 2]    | C: staged rows of chunk c + 1 -> S[(c+1) % 2]; issue the loads of c + 2
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
   // ONE register array for both roles (a wave has one role for good; declared separately the compiler keeps both sets live
   // and spills): A: st[16 g + s] = this lane's B fragment W[r + 16 g][kbeg + 16 s + 4 q ..], zero past the range / past J;
   // C: st[j] = the J x 4 accumulators, st[JA + rr] = the 16 rows in flight
-  constexpr int kSt = (JA + 16 > 16 * NG) ? JA + 16 : 16 * NG;
+  constexpr int kSt = (JA + RPT > 16 * NG) ? JA + RPT : 16 * NG;
   union Regs { float4 st[kSt]; Acc4 acc[JA]; __device__ Regs() {} } u_;
   float4 (&st)[kSt] = u_.st;                 // A: fragments; C: st[JA + rr] = rows in flight
   Acc4 (&acc)[JA] = u_.acc;                  // C: the accumulators, as packed pairs (same registers as st[0 .. JA))
@@ -137,20 +150,23 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
   };
   // ---- C role state -------------------------------------------------------------------------------------------------
   const int ct = tid - 256;
-  const int kc = 4 * ct;
-  const bool cols = !is_a && kc < K;
+  const int cthreads = K >> 2;               // C-threads per row group
+  const int half = RH > 1 ? (is_a ? 0 : ct / cthreads) : 0;
+  const int kc = 4 * (RH > 1 ? ct - half * cthreads : ct);
+  const int r0 = half * RPT;                 // this thread's rows of a chunk: r0 .. r0 + RPT - 1
+  const bool cols = !is_a && (RH > 1 ? half < RH : kc < K);
   auto issue = [&](int c) {                  // C: rows of chunk c, columns 4 ct ..: 16 loads in flight, straight-line, unconditional
     const int64_t c0 = n0 + 16 * (int64_t)c;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int64_t row = c0 + rr < n1 ? c0 + rr : n1 - 1;        // rows past the range re-read the last one (their gradient rows are zero)
-      st[JA + rr] = ld4(a.x + row * a.ldx + kc);
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int64_t row = c0 + r0 + rr < n1 ? c0 + r0 + rr : n1 - 1;   // rows past the range re-read the last one (their gradient rows are zero)
+      st[JA + rr] = ldrow(reinterpret_cast<const ST*>(a.x) + row * a.ldx + kc);
     }
   };
   auto put = [&](int c) {                    // C: the loaded rows -> S[c % 2]
-    float* sp = stage[c & 1] + kc;
+    float* sp = stage[c & 1] + r0 * kPitch + kc;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) *reinterpret_cast<float4*>(sp + rr * kPitch) = st[JA + rr];
+    for (int rr = 0; rr < RPT; ++rr) *reinterpret_cast<float4*>(sp + rr * kPitch) = st[JA + rr];
   };
   // ---- prologue -----------------------------------------------------------------------------------------------------
   if (is_a) {
@@ -208,19 +224,16 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[wv][4 * q + i][r + 16 * g] = la[g][i];
     } else if (cols && c > 0) {
-      // gW[:, 4t .. 4t+3] += g_logits[c - 1]^T x[c - 1], rows and gradients from LDS
-      const int64_t p0 = c0 - 16;
-      const int rows = (int)(n1 - p0 < 16 ? n1 - p0 : 16);
-      const float* sc = stage[(c - 1) & 1] + kc;
-      const float (*gp)[32] = gl[(c - 1) & 1];
+      // gW[:, 4t .. 4t+3] += g_logits[c - 1]^T x[c - 1], rows and gradients from LDS (rows past the range carry zero gradients)
+      const float* sc = stage[(c - 1) & 1] + r0 * kPitch + kc;
+      const float (*gp)[32] = gl[(c - 1) & 1] + r0;
 #pragma unroll 4
-      for (int rr = 0; rr < 16; ++rr) {
-        if (rr >= rows) break;               // block-uniform
+      for (int rr = 0; rr < RPT; ++rr) {
         const float4 x4 = *reinterpret_cast<const float4*>(sc + rr * kPitch);
         const f32x2 xlo = {x4.x, x4.y}, xhi = {x4.z, x4.w};
 #pragma unroll
         for (int j4 = 0; j4 < JA; j4 += 4) {
-          const float4 g = *reinterpret_cast<const float4*>(&gp[rr][j4]);   // same address in every lane: a broadcast read
+          const float4 g = *reinterpret_cast<const float4*>(&gp[rr][j4]);   // same address in every lane of a row group: a broadcast read
           pk_fma4(acc[j4], g.x, xlo, xhi); pk_fma4(acc[j4 + 1], g.y, xlo, xhi); pk_fma4(acc[j4 + 2], g.z, xlo, xhi); pk_fma4(acc[j4 + 3], g.w, xlo, xhi);
         }
       }
@@ -262,14 +275,10 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
     lds_barrier();
   }
   if (cols && nc > 0) {                      // the last chunk's weight-gradient contribution
-    const int c = nc;
-    const int64_t p0 = n0 + 16 * (int64_t)(c - 1);
-    const int rows = (int)(n1 - p0 < 16 ? n1 - p0 : 16);
-    const float* sc = stage[(c - 1) & 1] + kc;
-    const float (*gp)[32] = gl[(c - 1) & 1];
+    const float* sc = stage[(nc - 1) & 1] + r0 * kPitch + kc;
+    const float (*gp)[32] = gl[(nc - 1) & 1] + r0;
 #pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-      if (rr >= rows) break;
+    for (int rr = 0; rr < RPT; ++rr) {
       const float4 x4 = *reinterpret_cast<const float4*>(sc + rr * kPitch);
       const f32x2 xlo = {x4.x, x4.y}, xhi = {x4.z, x4.w};
 #pragma unroll
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
   if (cols) {
 #pragma unroll
     for (int j = 0; j < JA; ++j)
-      if (j < J) st4(a.wpart + ((int64_t)blockIdx.x * J + j) * a.Kp + kc, make_float4(acc[j].lo.x, acc[j].lo.y, acc[j].hi.x, acc[j].hi.y));
+      if (j < J) st4(a.wpart + (((int64_t)blockIdx.x * RH + half) * J + j) * a.Kp + kc, make_float4(acc[j].lo.x, acc[j].lo.y, acc[j].hi.x, acc[j].hi.y));
   }
   // bias gradient: this block's column sums of g_logits (lanes (r, q) of A-wave wv hold rows 4 wv + q of every chunk)
   if (is_a) { csred[4 * wv + q][j0] = cs0; csred[4 * wv + q][j1] = cs1; }
@@ -342,6 +351,18 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
 
 extern "C" {
 
+static int classifier_ce_row_groups(int32_t K, int32_t J) {
+  // the 22-class airway heads (J in 17 .. 24) on rows of at most 512 columns: 2 (K > 256) or 4 row groups of C-threads
+  if (J < 17 || J > 24 || K > 512) return 1;
+  return K > 256 ? 2 : 4;
+}
+
+int64_t spgnn_classifier_ce_partial_slices(int64_t N, int32_t K, int32_t J) {
+  if (N <= 0) return 0;
+  const int64_t rps = spgnn_classifier_ce_rows_per_block(N);
+  return (N + rps - 1) / rps * classifier_ce_row_groups(K, J);
+}
+
 int spgnn_classifier_ce_rows_per_block(int64_t N) {
   // one workgroup per CU (256 of them) at the 512-tree batch, never fewer than 64 rows each: the J x K partial a workgroup
   // writes at its end (90 KB at 22 x 1024) must stay small against the rows it read (4 KB each)
@@ -350,27 +371,51 @@ int spgnn_classifier_ce_rows_per_block(int64_t N) {
   return (int)(rps < 64 ? 64 : rps);
 }
 
-int spgnn_classifier_ce(const float* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias, const int64_t* labels,
-                        const float* draws, uint64_t draw_seed, const int64_t* seed_offset, const float* sampling_p,
-                        const float* class_weight, const int32_t* flag, float* logits, int64_t logits_stride, float* g_logits,
-                        int64_t g_stride, float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials,
-                        float* g_colsum, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+static int classifier_ce_launch(const void* x, bool bf16, int64_t x_stride, const float* w, int32_t Kp, const float* bias,
+                                const int64_t* labels, const float* draws, uint64_t draw_seed, const int64_t* seed_offset,
+                                const float* sampling_p, const float* class_weight, const int32_t* flag, float* logits,
+                                int64_t logits_stride, float* g_logits, int64_t g_stride, float* w_partials, float* partials, float* sums,
+                                uint32_t* ticket, float* colsum_partials, float* g_colsum, int64_t N, int32_t K, int32_t J,
+                                spgnn_stream_t stream) {
   if (N <= 0 || K <= 0 || (K & 127) || K > 1024 || J <= 0 || J > 32 || Kp < K || (Kp & 15))
     return fail(SPGNN_ERR_SHAPE, "spgnn_classifier_ce: need N > 0, K % 128 == 0, K <= 1024, J <= 32, Kp >= K, Kp % 16 == 0");
   if (!x || !w || !labels || !sampling_p || !class_weight || !logits || !g_logits || !w_partials || !partials || !sums || !ticket)
     return fail(SPGNN_ERR_NULLPTR, "spgnn_classifier_ce: null pointer");
   if ((g_colsum != nullptr) != (colsum_partials != nullptr)) return fail(SPGNN_ERR_NULLPTR, "spgnn_classifier_ce: colsum needs its partials");
-  if (x_stride < K || (x_stride & 3) || !aligned16(x) || !aligned16(w) || !aligned16(w_partials) || logits_stride < J || g_stride < J)
-    return fail(SPGNN_ERR_STRIDE, "spgnn_classifier_ce: x / w / partial rows must be 16-byte aligned, logit rows at least J wide");
+  if (x_stride < K || (x_stride & 3) || (reinterpret_cast<uintptr_t>(x) & (bf16 ? 7 : 15)) || !aligned16(w) || !aligned16(w_partials) ||
+      logits_stride < J || g_stride < J)
+    return fail(SPGNN_ERR_STRIDE, "spgnn_classifier_ce: x rows must be 16-byte (bf16: 8-byte) aligned with stride % 4 == 0, w / partial rows 16-byte aligned, logit rows at least J wide");
   const int64_t rps = spgnn_classifier_ce_rows_per_block(N);
   const unsigned nb = (unsigned)((N + rps - 1) / rps);
   ClsCe a{x, x_stride, w, Kp, bias, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, flag, logits, logits_stride,
           g_logits, g_stride, w_partials, partials, sums, ticket, colsum_partials, g_colsum, N, K, J, rps};
   hipStream_t st = (hipStream_t)stream;
-#define X(NG_, JA_) hipLaunchKernelGGL((classifier_ce_kernel<NG_, JA_>), dim3(nb), dim3(kCeThreads), 0, st, a)
-  if (J <= 4) X(1, 4); else if (J <= 8) X(1, 8); else if (J <= 16) X(1, 16); else if (J <= 24) X(2, 24); else X(2, 32);
+#define X(ST_, NG_, JA_, RH_) hipLaunchKernelGGL((classifier_ce_kernel<ST_, NG_, JA_, RH_>), dim3(nb), dim3(kCeThreads), 0, st, a)
+  const int rh = classifier_ce_row_groups(K, J);
+#define Y(ST_) { if (J <= 4) X(ST_, 1, 4, 1); else if (J <= 8) X(ST_, 1, 8, 1); else if (J <= 16) X(ST_, 1, 16, 1); \
+                 else if (J <= 24) { if (rh == 4) X(ST_, 2, 24, 4); else if (rh == 2) X(ST_, 2, 24, 2); else X(ST_, 2, 24, 1); } else X(ST_, 2, 32, 1); }
+  if (bf16) Y(bf16s) else Y(float)
+#undef Y
 #undef X
   return check_launch("spgnn_classifier_ce");
+}
+
+int spgnn_classifier_ce(const float* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias, const int64_t* labels,
+                        const float* draws, uint64_t draw_seed, const int64_t* seed_offset, const float* sampling_p,
+                        const float* class_weight, const int32_t* flag, float* logits, int64_t logits_stride, float* g_logits,
+                        int64_t g_stride, float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials,
+                        float* g_colsum, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  return classifier_ce_launch(x, false, x_stride, w, Kp, bias, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, flag, logits,
+                              logits_stride, g_logits, g_stride, w_partials, partials, sums, ticket, colsum_partials, g_colsum, N, K, J, stream);
+}
+
+int spgnn_classifier_ce_bf16(const uint16_t* x, int64_t x_stride, const float* w, int32_t Kp, const float* bias, const int64_t* labels,
+                             const float* draws, uint64_t draw_seed, const int64_t* seed_offset, const float* sampling_p,
+                             const float* class_weight, const int32_t* flag, float* logits, int64_t logits_stride, float* g_logits,
+                             int64_t g_stride, float* w_partials, float* partials, float* sums, uint32_t* ticket, float* colsum_partials,
+                             float* g_colsum, int64_t N, int32_t K, int32_t J, spgnn_stream_t stream) {
+  return classifier_ce_launch(x, true, x_stride, w, Kp, bias, labels, draws, draw_seed, seed_offset, sampling_p, class_weight, flag, logits,
+                              logits_stride, g_logits, g_stride, w_partials, partials, sums, ticket, colsum_partials, g_colsum, N, K, J, stream);
 }
 
 }  // extern "C"

@@ -985,9 +985,13 @@ _CE_TICKETS: dict = {}
 
 
 def classifier_ce_supported(x: torch.Tensor, w_cls: torch.Tensor) -> bool:
-    return bool(FUSED_LOSS_HEAD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.stride(1) == 1
-                and _rows_aligned(x) and x.shape[1] % 128 == 0 and x.shape[1] <= 1024 and w_cls.shape[0] <= 32
-                and w_cls.shape[1] == x.shape[1] and w_cls.dtype == torch.float32)
+    """fp32 rows (16-byte aligned) or bf16 rows (8-byte aligned, row stride a multiple of 4 elements); K % 128 == 0, K <= 1024."""
+    if not (FUSED_LOSS_HEAD and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.stride(1) == 1 and x.shape[1] % 128 == 0
+            and x.shape[1] <= 1024 and w_cls.shape[0] <= 32 and w_cls.shape[1] == x.shape[1] and w_cls.dtype == torch.float32):
+        return False
+    if x.dtype == torch.float32:
+        return bool(_rows_aligned(x))
+    return bool(x.dtype == torch.bfloat16 and x.stride(0) % 4 == 0 and x.data_ptr() % 8 == 0)
 
 
 def classifier_ce(x: torch.Tensor, w_cls: torch.Tensor, b_cls: Optional[torch.Tensor], head: LossHead):
@@ -1001,20 +1005,23 @@ def classifier_ce(x: torch.Tensor, w_cls: torch.Tensor, b_cls: Optional[torch.Te
     w_p = _padded_rows(w_cls.detach(), Kp)
     lib = _capi.load()
     rps = int(lib.spgnn_classifier_ce_rows_per_block(N))
-    B = (N + rps - 1) // rps
+    nblk = (N + rps - 1) // rps                                  # workgroups: the loss / column-sum partials
+    B = int(lib.spgnn_classifier_ce_partial_slices(N, K, J))     # weight-gradient partial slices: workgroups x row groups
     logits = torch.empty((N, J), dtype=torch.float32, device=dev)
     g_logits = torch.empty((N, J), dtype=torch.float32, device=dev)
     wpart = torch.empty((B, J, Kp), dtype=torch.float32, device=dev)
-    part = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    colpart = torch.empty((B, 32), dtype=torch.float32, device=dev)
+    part = torch.empty((nblk, 2), dtype=torch.float32, device=dev)
+    colpart = torch.empty((nblk, 32), dtype=torch.float32, device=dev)
     colsum = torch.empty((J,), dtype=torch.float32, device=dev)
     ticket = _CE_TICKETS.get(str(dev))
     if ticket is None:
         ticket = _CE_TICKETS[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
     bias_c = None if b_cls is None else b_cls.detach().contiguous()
     draws = None if head.draws is None else head.draws.contiguous()
-    with torch.cuda.device(dev), _timed("classifier_ce", (N, K, J)):
-        _capi.check(lib.spgnn_classifier_ce(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, _ptr(bias_c), head.labels.data_ptr(), _ptr(draws),
+    bf16 = x.dtype == torch.bfloat16
+    fn = lib.spgnn_classifier_ce_bf16 if bf16 else lib.spgnn_classifier_ce
+    with torch.cuda.device(dev), _timed("classifier_ce_bf16" if bf16 else "classifier_ce", (N, K, J)):
+        _capi.check(fn(x.data_ptr(), x.stride(0), w_p.data_ptr(), Kp, _ptr(bias_c), head.labels.data_ptr(), _ptr(draws),
                                             head.draw_seed & 0xFFFFFFFFFFFFFFFF, _seed_off_ptr(dev) if draws is None else 0,
                                             head.sampling_p.data_ptr(), head.class_weight.data_ptr(), _ptr(head.flag), logits.data_ptr(),
                                             logits.stride(0), g_logits.data_ptr(), g_logits.stride(0), wpart.data_ptr(), part.data_ptr(),

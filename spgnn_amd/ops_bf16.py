@@ -647,7 +647,14 @@ class _LinearMeanClassifierBf16Fn(torch.autograd.Function):
         Kc = zx.shape[1]
         w_comb, _, w_bf, b_mean, P, c0 = ops.linear_mean_fold_buffers(w_fc, w_res, bias, w_cls, b_cls, H, D, bf16=True)
         y = gemm_nt(zx, w_bf[:, :Kc], out_f32=True, bias=b_mean)
-        logits = scores_fwd(zx, P[:, :Kc], bias=c0)
+        head, ctx.head = ops.LOSS_HEAD, None
+        if head is not None and not head.used and zx.shape[0] == head.labels.shape[0] and ops.classifier_ce_supported(zx, P[:, :Kc]):
+            # the step's loss joins this node (spgnn_classifier_ce_bf16 on the folded classifier): one pass over the bf16 rows
+            logits, head.g_logits, wpart, colsum = ops.classifier_ce(zx, P[:, :Kc], c0, head)
+            head.used = True
+            ctx.head = (wpart, colsum)
+        else:
+            logits = scores_fwd(zx, P[:, :Kc], bias=c0)
         ctx.cfg = (H, D, w_fc.shape[1], Kc, w_res is not None, bias is not None, b_cls is not None)
         ctx.save_for_backward(zx, w_comb, w_bf, P, w_cls, b_mean)
         return y, logits
@@ -662,9 +669,14 @@ class _LinearMeanClassifierBf16Fn(torch.autograd.Function):
         g_zx = g_fc = g_res = g_bias = g_wcls = g_bcls = None
         cs = M1 = None
         if g_logits is not None:
-            cs = _ops.column_sums(g_logits)
+            head, ctx.head = ctx.head, None
             g_logits = _rowmajor(g_logits)
-            M1 = scores_bwd_w(g_logits, zx)
+            if head is not None:                          # the loss kernel left the column sums and the partials of g_logits^T Zx
+                cs = head[1]
+                M1 = ops.sum_partials(head[0])[:, :Kc]
+            else:
+                cs = _ops.column_sums(g_logits)
+                M1 = scores_bwd_w(g_logits, zx)
             g_bcls = cs if has_bcls else None
         if g_y is None:                                   # folded route: g_Zx as bf16 rows straight from the fp32 logit gradient
             if ctx.needs_input_grad[0]:
