@@ -235,7 +235,8 @@ def test_list_aware_traversals_equal_the_expanded_copy(monkeypatch):
     assert torch.equal(res[0], res[1])
 
 
-def test_loss_rows_through_an_arena_follow_each_loaded_batch():
+@pytest.mark.parametrize("mode", [True, "backward"])
+def test_loss_rows_through_an_arena_follow_each_loaded_batch(mode):
     """Two loader batches of one size class through run_batch: the second is a copy into the arena plus replays of the graph
     captured on the first - the list kernel reads the sampling probabilities the arena load rewrote (other labelled nodes, other
     pad rows), with the capacity fixed at capture (15 % headroom for exactly this)."""
@@ -246,7 +247,7 @@ def test_loss_rows_through_an_arena_follow_each_loaded_batch():
     ga = synthetic.make_batch(6, rank=3, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
     gb = synthetic.make_batch(6, rank=4, device="cuda", pos_enc_dim=cfg.POS_ENC_DIM)
     assert ga.number_of_nodes() != gb.number_of_nodes()
-    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=True)
+    ts_r = TrainStep(model, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9, loss_rows_only=mode)      # "backward": what INTEGRATION.md recommends
     ts_d = TrainStep(dense, w, cfg.SAMPLING_RATE, 1e-3, 0.9, seed=9)
     for i, g in enumerate((ga, gb, ga)):
         torch.manual_seed(300 + i)
