@@ -941,7 +941,7 @@ def single_tree_forward(dev, config="st_pgat_spgnn_3", sizes=(150, 300), reps=20
     out.update({"replay_device_us": first["replay_device_us"], "captured_us": first["captured_us"], "eager_us": first["eager_us"],
                 "cpu_oracle_ms": first["cpu_oracle_ms"],
                 "what": "replay_device_us: the captured forward itself (HIP events around back-to-back graph replays); captured_us: one scan "
-                        "through ForwardRunner on the host clock, arena load (a dozen device copies) included; eager_us: model(g) issued eagerly"})
+                        "through ForwardRunner on the host clock, arena load (two launches: spgnn_arena_load + spgnn_ell_rows_both) included; eager_us: model(g) issued eagerly"})
     return out
 
 
