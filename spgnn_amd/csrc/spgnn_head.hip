@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
       // gW[:, 4t .. 4t+3] += g_logits[c - 1]^T x[c - 1], rows and gradients from LDS (rows past the range carry zero gradients)
       const float* sc = stage[(c - 1) & 1] + r0 * kPitch + kc;
       const float (*gp)[32] = gl[(c - 1) & 1] + r0;
-#pragma unroll 4
+#pragma unroll
       for (int rr = 0; rr < RPT; ++rr) {
         const float4 x4 = *reinterpret_cast<const float4*>(sc + rr * kPitch);
         const f32x2 xlo = {x4.x, x4.y}, xhi = {x4.z, x4.w};
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kCeThreads, 1) void classifier_ce_kernel(ClsCe a) {
   if (cols && nc > 0) {                      // the last chunk's weight-gradient contribution
     const float* sc = stage[(nc - 1) & 1] + r0 * kPitch + kc;
     const float (*gp)[32] = gl[(nc - 1) & 1] + r0;
-#pragma unroll 4
+#pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
       const float4 x4 = *reinterpret_cast<const float4*>(sc + rr * kPitch);
       const f32x2 xlo = {x4.x, x4.y}, xhi = {x4.z, x4.w};
