@@ -326,8 +326,8 @@ def test_steps_skipped_without_an_overflow_are_reported():
 def test_bf16_storage_loss_rows_step_equals_the_dense_step(name, trees):
     """BASELINE config 4's model (bf16 rows, linear-mean head) with the list: rows of the output product, the head mean and the
     classifier for the kept nodes only.  Row-wise arithmetic is the dense step's per row and weight-gradient sums differ by fp32
-    summation order only, so the FIRST step agrees to 1e-6; from the second on, parameters that differ in the 7th digit move
-    stored bf16 activations across rounding boundaries (2^-8 each) - the envelope of tests/test_arena.py's bf16 case."""
+    summation order only, so the FIRST step's loss agrees to 1e-6; from the second on, parameters that differ in the 7th digit
+    move stored bf16 activations across rounding boundaries (2^-8 each) - the envelope of tests/test_arena.py's bf16 case."""
     cfg, model = _model(name, 13)
     models.set_storage_dtype(model, torch.bfloat16)
     model.eval()
@@ -341,7 +341,10 @@ def test_bf16_storage_loss_rows_step_equals_the_dense_step(name, trees):
         assert rel_err(lr_, ld_) < (1e-6 if i == 0 else 2e-2), (i, float(lr_), float(ld_))
         if i == 0:
             n = ts_r.bucket.numel
-            assert rel_err(ts_r.bucket.flat_grad[:n], ts_d.bucket.flat_grad[:n]) < 1e-6
+            # (round 6: the dense step's logits now come from spgnn_classifier_ce_bf16, the listed step's from the separate
+            # launches - the same fp32 arithmetic in another summation order; a logit gradient that differs in its last bit rounds
+            # a few bf16 elements of g_Zx the other way (2^-8 each): the first step's gradients agree to 1e-3 normwise, measured 1e-4)
+            assert rel_err(ts_r.bucket.flat_grad[:n], ts_d.bucket.flat_grad[:n]) < 1e-3
     assert ts_r._rows_cnt is not None and 0 < int(ts_r._rows_cnt[0]) < 0.5 * g.number_of_nodes()
     assert rel_err(ts_r.bucket.flat_param[:n], ts_d.bucket.flat_param[:n]) < 2e-2
 
